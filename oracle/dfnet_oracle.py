@@ -1,0 +1,81 @@
+"""CPU oracle for the DFNet feature-extractor forward.  TEST INFRASTRUCTURE ONLY.
+
+A from-scratch CPU (torch fp32, functional) restatement of DFNet.forward
+(/root/reference/script/feature/dfnet.py:109-172) and AdaptLayers (:42-72).  Only
+`tests/`, `__graft_entry__.smoke()` and bench.py's cpu_baseline may import it.
+
+The VGG16 `features` stack the reference takes from torchvision==0.10.0
+(requirements.txt:96; call site dfnet.py:90-92) is third-party code absent from
+/root/reference; its published architecture (cfg "D") is restated here: 13 x
+[Conv3x3 stride 1 pad 1 + ReLU] with MaxPool(2,2) after convs 2, 4, 7, 10, 13.  No
+reference test pins results at that boundary ("parity unpinned" for the third-party
+stack); the code above it is pinned by tests/golden/g8_* captured from the reference's
+DFNet.forward running on that restated stack.
+
+Parameters: dict {state_dict key: tensor} with the reference's names
+(`encoder.{k}.weight`, `adaptation_layers.adapt_layer_{i}.{0,2,3}.*`, `fc_pose.*`).
+"""
+import torch
+import torch.nn.functional as F
+
+VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+TAP_CONV_INDEX = {"conv1_2": 2, "conv3_3": 14, "conv5_3": 28}  # positions in the 31-module encoder
+
+
+def encoder_taps(p, x, taps=(2, 14, 28), stop_after_last_tap=True):
+    """Run the VGG stack; return (pre-ReLU conv outputs at `taps`, final tensor or None).
+
+    Taps are cloned BEFORE the in-place ReLU (dfnet.py:126-131); with return_pose=False the
+    loop breaks right after the last tap (dfnet.py:133-136)."""
+    feats, idx = [], 0
+    for v in VGG16_CFG:
+        if v == "M":
+            x = F.max_pool2d(x, 2, 2)
+            idx += 1
+            continue
+        x = F.conv2d(x, p[f"encoder.{idx}.weight"], p[f"encoder.{idx}.bias"], padding=1)
+        if idx in taps:
+            feats.append(x.clone())
+            if idx == taps[-1] and stop_after_last_tap:
+                return feats, None
+        x = torch.relu(x)
+        idx += 2
+    return feats, x
+
+
+def adapt(p, i, f, eps=1e-5):
+    """Conv1x1 -> ReLU -> Conv5x5(pad 2) -> BatchNorm2d in eval mode (dfnet.py:57-62)."""
+    pre = f"adaptation_layers.adapt_layer_{i}"
+    f = torch.relu(F.conv2d(f, p[pre + ".0.weight"], p[pre + ".0.bias"]))
+    f = F.conv2d(f, p[pre + ".2.weight"], p[pre + ".2.bias"], padding=2)
+    return F.batch_norm(f, p[pre + ".3.running_mean"], p[pre + ".3.running_var"],
+                        p[pre + ".3.weight"], p[pre + ".3.bias"], training=False, eps=eps)
+
+
+def upsample(f, H, W):
+    """nn.UpsamplingBilinear2d(size) == bilinear, align_corners=True (dfnet.py:145)."""
+    return F.interpolate(f, size=(H, W), mode="bilinear", align_corners=True)
+
+
+def dfnet_forward(p, x, return_feature=False, isSingleStream=False, return_pose=True,
+                  upsampleH=240, upsampleW=427, taps=(2, 14, 28)):
+    """(feature_maps | None, predict | None) exactly as DFNet.forward (dfnet.py:109-172)."""
+    mean = x.new_tensor(MEAN)[:, None, None]
+    std = x.new_tensor(STD)[:, None, None]
+    x = (x - mean) / std
+    feats, last = encoder_taps(p, x, taps, stop_after_last_tap=not return_pose)
+    maps = None
+    if return_feature:
+        ad = [adapt(p, i, f) for i, f in enumerate(feats)]
+        if isSingleStream:
+            maps = [torch.stack([upsample(f, upsampleH, upsampleW) for f in ad])]
+        else:
+            half = ad[0].shape[0] // 2
+            maps = [torch.stack([upsample(f[:half], upsampleH, upsampleW) for f in ad]),
+                    torch.stack([upsample(f[half:], upsampleH, upsampleW) for f in ad])]
+    if not return_pose:
+        return maps, None
+    pooled = last.mean((2, 3))  # AdaptiveAvgPool2d(1) after relu5_3 + pool5
+    return maps, F.linear(pooled, p["fc_pose.weight"], p["fc_pose.bias"])

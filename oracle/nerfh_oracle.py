@@ -1,0 +1,281 @@
+"""CPU oracle for the NeRF-H render hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a from-scratch CPU (torch fp32) restatement of the reference's
+NeRF-H volumetric rendering path.  It exists to CHECK the HIP kernels and to
+provide the `cpu_baseline` leg of bench.py.  Only `tests/`,
+`__graft_entry__.smoke()` and bench.py's cpu_baseline may import it; nothing
+under `dfnet_amd/` does (the product path fails loudly without its HIP
+library instead of falling back to this file).
+
+Parity pinning: every function here is checked against outputs captured from
+the reference's own modules (imported from /root/reference in the build
+container by tests/golden/make_golden.py) — see tests/test_oracle_golden.py.
+
+All `file:line` citations are relative to /root/reference/script/.
+
+Conventions: parameters are plain dicts {state_dict key: tensor}, with the
+reference's key names (`xyz_encoding_1.0.weight`, `static_sigma.0.bias`, ...,
+models/nerfw.py:259-295).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+N_RAW = 9  # fine net channels: rgb_s(3) sigma_s rgb_t(3) sigma_t beta_t (models/nerfw.py:340-354)
+
+
+# --------------------------------------------------------------------------- rays
+def get_rays(H, W, focal, c2w):
+    """Pinhole rays of an H x W image (models/ray_utils.py:5-15).
+
+    Pixel centres sit at integer coordinates (no +0.5); rays_d is NOT
+    normalised; rays_o is the camera centre for every pixel.  Returns
+    (rays_o, rays_d), both [H, W, 3].
+    """
+    c2w = torch.as_tensor(c2w, dtype=torch.float32)
+    col = torch.linspace(0, W - 1, W)  # pixel x
+    row = torch.linspace(0, H - 1, H)  # pixel y
+    cx = ((col - W * .5) / focal)[None, :].expand(H, W)
+    cy = (-(row - H * .5) / focal)[:, None].expand(H, W)
+    cam = torch.stack([cx, cy, -torch.ones(H, W)], -1)  # camera-frame direction
+    # rays_d[h,w,a] = sum_b cam[h,w,b] * c2w[a,b]   (row-vector * R^T, ray_utils.py:12)
+    rays_d = torch.sum(cam[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, 3].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def pack_ray_rows(rays_o, rays_d, near, far, img_idx):
+    """The 21-float ray row [o d near far viewdir hist(10)] (models/rendering.py:364-389)."""
+    d = rays_d.reshape(-1, 3).float()
+    o = rays_o.reshape(-1, 3).float()
+    view = d / torch.norm(d, dim=-1, keepdim=True)
+    nf = torch.ones_like(d[:, :1])
+    idx = torch.as_tensor(img_idx, dtype=torch.float32)
+    if idx.dim() == 1:
+        idx = idx[None]
+    if idx.shape[0] != d.shape[0]:
+        idx = idx.repeat(d.shape[0], 1)
+    return torch.cat([o, d, near * nf, far * nf, view, idx], 1)
+
+
+# --------------------------------------------------------------------------- encoding
+def posenc(x, L):
+    """[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] (models/nerfw.py:105-133).
+
+    Each block is as wide as x; the bands are exact powers of two
+    (2**linspace(0, L-1, L), nerfw.py:117).
+    """
+    parts = [x]
+    for k in range(L):
+        f = float(2 ** k)
+        parts.append(torch.sin(x * f))
+        parts.append(torch.cos(x * f))
+    return torch.cat(parts, -1)
+
+
+def hist_embed(table, hist_idx):
+    """nn.Embedding lookup of the 10 histogram bins, flattened bin-major (models/nerfw.py:69-78)."""
+    rows = table[hist_idx.long()]  # [N, bins, dim]
+    return rows.reshape(rows.shape[0], -1)
+
+
+# --------------------------------------------------------------------------- network
+def _lin(p, name, x):
+    return F.linear(x, p[name + ".weight"], p[name + ".bias"])
+
+
+def nerfh_trunk(p, pe_xyz, D=8, skip=4):
+    """The D-layer ReLU trunk with [input, h] concat before layer index `skip` (models/nerfw.py:326-330)."""
+    h = pe_xyz
+    for i in range(D):
+        if i == skip:
+            h = torch.cat([pe_xyz, h], -1)
+        h = torch.relu(_lin(p, f"xyz_encoding_{i + 1}.0", h))
+    return h
+
+
+def nerfh_sigma(p, pe_xyz, D=8):
+    """Coarse test-time query: sigma only (models/nerfw.py:315-334); Softplus is inside the net."""
+    return F.softplus(_lin(p, "static_sigma.0", nerfh_trunk(p, pe_xyz, D)))
+
+
+def nerfh_static(p, pe_xyz, pe_dir_a, D=8):
+    """[rgb_s(3), sigma_s]: the `output_transient=False` branch (models/nerfw.py:336-343)."""
+    h = nerfh_trunk(p, pe_xyz, D)
+    sigma = F.softplus(_lin(p, "static_sigma.0", h))
+    fin = _lin(p, "xyz_encoding_final", h)
+    dire = torch.relu(_lin(p, "dir_encoding.0", torch.cat([fin, pe_dir_a], -1)))
+    rgb = torch.sigmoid(_lin(p, "static_rgb.0", dire))
+    return torch.cat([rgb, sigma], -1)
+
+
+def nerfh_fine(p, pe_xyz, pe_dir, a, t, D=8):
+    """Fine NeRF-H query -> [.., 9] (models/nerfw.py:297-354)."""
+    h = nerfh_trunk(p, pe_xyz, D)
+    sigma = F.softplus(_lin(p, "static_sigma.0", h))
+    fin = _lin(p, "xyz_encoding_final", h)
+    dire = torch.relu(_lin(p, "dir_encoding.0", torch.cat([fin, pe_dir, a], -1)))
+    rgb = torch.sigmoid(_lin(p, "static_rgb.0", dire))
+    tr = torch.cat([fin, t], -1)
+    for j in (0, 2, 4, 6):
+        tr = torch.relu(_lin(p, f"transient_encoding.{j}", tr))
+    t_sigma = F.softplus(_lin(p, "transient_sigma.0", tr))
+    t_rgb = torch.sigmoid(_lin(p, "transient_rgb.0", tr))
+    t_beta = F.softplus(_lin(p, "transient_beta.0", tr))
+    return torch.cat([rgb, sigma, t_rgb, t_sigma, t_beta], -1)
+
+
+def query_coarse_sigma(p, pts, L_xyz=10, netchunk=65536):
+    """run_network_NeRFW, typ='coarse', test_time (models/nerfw.py:37-46): [R,N,3] -> [R,N,1]."""
+    flat = pts.reshape(-1, 3)
+    out = [nerfh_sigma(p, posenc(flat[i:i + netchunk], L_xyz)) for i in range(0, flat.shape[0], netchunk)]
+    return torch.cat(out, 0).reshape(*pts.shape[:-1], 1)
+
+
+def query_fine(p, emb_a, emb_t, pts, viewdirs, hist_idx, L_xyz=10, L_dir=4, netchunk=65536):
+    """run_network_NeRFW, typ='fine' (models/nerfw.py:62-95): [R,N,3] -> [R,N,9]."""
+    R, N = pts.shape[:2]
+    flat = pts.reshape(-1, 3)
+    dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)
+    a = hist_embed(emb_a, hist_idx).repeat_interleave(N, 0)  # 'n1 c -> (n1 n2) c'
+    t = hist_embed(emb_t, hist_idx).repeat_interleave(N, 0)
+    out = []
+    for i in range(0, flat.shape[0], netchunk):
+        s = slice(i, i + netchunk)
+        out.append(nerfh_fine(p, posenc(flat[s], L_xyz), posenc(dirs[s], L_dir), a[s], t[s]))
+    return torch.cat(out, 0).reshape(R, N, N_RAW)
+
+
+# --------------------------------------------------------------------------- sampling / compositing
+def _deltas(z):
+    """z[i+1]-z[i] with a last interval of 1e2 and no |d| factor (models/rendering.py:161-166)."""
+    return torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e2)], -1)
+
+
+def _excl_cumprod(one_minus_alpha):
+    """T_i = prod_{j<i} (1-alpha_j), no epsilon inside (models/rendering.py:176-178)."""
+    shifted = torch.cat([torch.ones_like(one_minus_alpha[:, :1]), one_minus_alpha], -1)
+    return torch.cumprod(shifted[:, :-1], -1)
+
+
+def coarse_weights(sigma, z, noise=None):
+    """Coarse test-time compositing: alpha = 1-exp(-delta*relu(sigma+noise)) (models/rendering.py:173-193).
+
+    Returns (acc, weights).  `noise` stands for randn*raw_noise_std (zero at test time).
+    """
+    s = sigma if noise is None else sigma + noise
+    alpha = 1 - torch.exp(-_deltas(z) * torch.relu(s))
+    w = alpha * _excl_cumprod(1 - alpha)
+    return w.sum(-1), w
+
+
+def sample_pdf(bins, weights, n, det=True, u=None):
+    """Inverse-CDF importance sampling (models/rendering.py:24-65).
+
+    `u` overrides the uniform draws (shape [R, n]) for the non-deterministic mode.
+    """
+    w = weights + 1e-5
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    if u is None:
+        if det:
+            u = torch.linspace(0., 1., n).expand(cdf.shape[0], n)
+        else:
+            u = torch.rand(cdf.shape[0], n)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = cdf.gather(1, lo), cdf.gather(1, hi)
+    b_lo, b_hi = bins.gather(1, lo), bins.gather(1, hi)
+    den = c_hi - c_lo
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    return b_lo + (u - c_lo) / den * (b_hi - b_lo)
+
+
+def composite_fine(raw, z, beta_min=0.1, white_bkgd=False, test_time=True, static_only=True):
+    """Static + transient compositing of the 9-channel fine output (models/rendering.py:144-243).
+
+    Returns dict(rgb, disp, acc, weights, depth, transient_sigmas, beta).  At
+    test_time & static_only the reference returns the JOINT rgb (static+transient
+    under the joint transmittance), a depth from the STATIC-ONLY transmittance and
+    disp = 1/max(1e-10, depth/sum(joint w)) (rendering.py:211-230, quirk Q2).
+    """
+    rgb_s, sig_s = raw[..., 0:3], raw[..., 3]
+    rgb_t, sig_t, beta_t = raw[..., 4:7], raw[..., 7], raw[..., 8]
+    d = _deltas(z)
+    a_s = 1 - torch.exp(-d * sig_s)
+    a_t = 1 - torch.exp(-d * sig_t)
+    a = 1 - torch.exp(-d * (sig_s + sig_t))
+    T = _excl_cumprod(1 - a)
+    w_s, w_t, w = a_s * T, a_t * T, a * T
+    acc = w.sum(-1)
+    map_s = (w_s[..., None] * rgb_s).sum(-2)
+    if white_bkgd:
+        map_s = map_s + (1 - acc[:, None])
+    map_t = (w_t[..., None] * rgb_t).sum(-2)
+    beta = (w_t * beta_t).sum(-1) + beta_min
+    rgb = map_s + map_t
+    if test_time and static_only:
+        w_so = a_s * _excl_cumprod(1 - a_s)
+        depth = (w_so * z).sum(-1)
+    else:
+        depth = (w * z).sum(-1)
+    disp = 1. / torch.max(1e-10 * torch.ones_like(depth), depth / w.sum(-1))
+    return dict(rgb=rgb, disp=disp, acc=acc, weights=w, depth=depth, transient_sigmas=sig_t, beta=beta)
+
+
+# --------------------------------------------------------------------------- render
+def coarse_z(near, far, n, R):
+    """z = near(1-t) + far t, t = linspace(0,1,n) (models/rendering.py:269-275)."""
+    t = torch.linspace(0., 1., n)
+    return (near * (1. - t) + far * t).expand(R, n)
+
+
+def render_rays(rows, coarse, fine, emb_a, emb_t, Nc, Ni, netchunk=65536, retraw=False, stages=None):
+    """Test-time render of packed 21-float ray rows (models/rendering.py:245-337 with
+    perturb=0, raw_noise_std=0, lindisp=False, white_bkgd=False, test_time=True).
+
+    `stages`, if a dict, receives the intermediate tensors for stage-level parity tests.
+    """
+    o, d = rows[:, 0:3], rows[:, 3:6]
+    near, far = rows[:, 6:7], rows[:, 7:8]
+    view, hist = rows[:, 8:11], rows[:, 11:]
+    R = rows.shape[0]
+    z = coarse_z(near, far, Nc, R)
+    pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    sig = query_coarse_sigma(coarse, pts, netchunk=netchunk)[..., 0]
+    _, w = coarse_weights(sig, z)
+    mid = .5 * (z[:, 1:] + z[:, :-1])
+    zs = sample_pdf(mid, w[:, 1:-1], Ni, det=True)
+    zf, _ = torch.sort(torch.cat([z, zs], -1), -1)
+    pts_f = o[:, None, :] + d[:, None, :] * zf[..., None]
+    raw = query_fine(fine, emb_a, emb_t, pts_f, view, hist, netchunk=netchunk)
+    out = composite_fine(raw, zf)
+    if stages is not None:
+        stages.update(z_coarse=z, sigma_coarse=sig, weights_coarse=w, z_samples=zs, z_fine=zf, raw=raw)
+    ret = dict(rgb_map=out["rgb"], disp_map=out["disp"], acc_map=out["acc"])
+    if retraw:
+        ret["raw"] = raw
+    return ret
+
+
+def render(H, W, focal, chunk, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx,
+           c2w=None, rays=None, netchunk=65536):
+    """render() at test time (models/rendering.py:353-400): returns [rgb, disp, acc] shaped like the rays."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w, dtype=torch.float32)[:3, :4])
+    else:
+        rays_o, rays_d = rays
+    sh = rays_d.shape
+    rows = pack_ray_rows(rays_o, rays_d, near, far, img_idx)
+    outs = [render_rays(rows[i:i + chunk], coarse, fine, emb_a, emb_t, Nc, Ni, netchunk)
+            for i in range(0, rows.shape[0], chunk)]
+    cat = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+    return [cat[k].reshape(*sh[:-1], *cat[k].shape[1:]) for k in ("rgb_map", "disp_map", "acc_map")]
+
+
+def psnr(rgb, gt):
+    """-10 log10(mean((rgb-gt)^2)) (models/rendering.py:431-433)."""
+    return -10. * math.log10(float(((rgb - gt) ** 2).mean()))

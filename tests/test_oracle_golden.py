@@ -1,0 +1,126 @@
+"""Pin the CPU oracle (oracle/*.py) to the reference: every comparison here is against
+numbers captured from the reference's own modules by tests/golden/make_golden.py."""
+import numpy as np
+import torch
+
+from dfnet_amd import synthetic as syn
+from oracle import dfnet_oracle as dor
+from oracle import nerfh_oracle as orc
+
+T = torch.from_numpy
+
+
+def tt(d):
+    return {k: T(np.ascontiguousarray(v)) for k, v in d.items()}
+
+
+def close(a, b, rtol=1e-6, atol=1e-6):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def nets(W):
+    c, f, ea, et = syn.nerfh_weights(seed=0, W=W)
+    return tt(c), tt(f), T(ea), T(et)
+
+
+def test_g1_get_rays(gold):
+    g = gold("g1_get_rays")
+    o, d = orc.get_rays(int(g["H"]), int(g["W"]), float(g["focal"]), g["c2w"])
+    close(o, g["rays_o"], 0, 0)
+    close(d, g["rays_d"], 1e-7, 1e-7)
+
+
+def test_g2_posenc(gold):
+    g = gold("g2_posenc")
+    close(orc.posenc(T(g["x"]), 10), g["pe_xyz"], 0, 0)
+    close(orc.posenc(T(g["d"]), 4), g["pe_dir"], 0, 0)
+
+
+def test_g3_network_modes(gold):
+    for W in (128, 32):
+        g = gold(f"g3_nerfw_w{W}")
+        c, f, _, _ = nets(W)
+        x = T(g["x"])
+        close(orc.nerfh_sigma(c, x[:, :63]), g["coarse_sigma"])
+        close(orc.nerfh_static(c, x[:, :63], x[:, 63:90]), g["coarse_static"])
+        close(orc.nerfh_fine(f, x[:, :63], x[:, 63:90], x[:, 90:140], x[:, 140:160]), g["fine_raw"])
+
+
+def test_g4_composite(gold):
+    g = gold("g4_composite")
+    z = T(g["z"])
+    acc, w = orc.coarse_weights(T(g["sigma_coarse"])[..., 0], z)
+    close(acc, g["acc_coarse"])
+    close(w, g["w_coarse"])
+    out = orc.composite_fine(T(g["raw"]), z, test_time=True, static_only=True)
+    for k in ("rgb", "disp", "acc", "weights", "depth", "beta"):
+        close(out[k], g[k], 1e-6, 1e-6)
+    tr = orc.composite_fine(T(g["raw"]), z, test_time=False)
+    for k in ("rgb", "disp", "acc", "depth", "beta"):
+        close(tr[k], g["train_" + k], 1e-6, 1e-6)
+
+
+def test_g5_sample_pdf(gold):
+    g = gold("g5_sample_pdf")
+    ka = orc.sample_pdf(torch.linspace(0, 1, 8)[None], T(np.array([[0, 1, 2, 3, 2, 1, 0]], np.float32)), 5)
+    close(ka, g["known_answer"], 0, 1e-7)
+    close(ka, np.array([[0, .375, .5, .625, 1]], np.float32), 0, 1e-6)
+    b, w = T(g["bins"]), T(g["weights"])
+    close(orc.sample_pdf(b, w, 128), g["det128"], 0, 0)
+    close(orc.sample_pdf(b, w, 17), g["det17"], 0, 0)
+    close(orc.sample_pdf(b, w, 40, det=False, u=T(g["u"])), g["rand40"], 0, 0)
+
+
+def test_g6_render_rays(gold):
+    for tag in "abc":
+        g = gold("g6_render_rays_" + tag)
+        c, f, ea, et = nets(int(g["W"]))
+        rows = orc.pack_ray_rows(T(g["rays_o"]), T(g["rays_d"]), float(g["near"]), float(g["far"]), g["hist"])
+        assert rows.shape[1] == 21
+        out = orc.render_rays(rows, c, f, ea, et, int(g["Nc"]), int(g["Ni"]), retraw=True)
+        close(out["raw"], g["raw"], 2e-5, 2e-6)
+        close(out["rgb_map"], g["rgb"], 1e-5, 1e-6)
+        close(out["disp_map"], g["disp"], 1e-5, 1e-6)
+        close(out["acc_map"], g["acc"], 1e-5, 1e-6)
+
+
+def test_g7_render_image(gold):
+    g = gold("g7_render_image")
+    c, f, ea, et = nets(128)
+    rgb, disp, acc = orc.render(int(g["H"]), int(g["W"]), float(g["focal"]), 100, c, f, ea, et,
+                                int(g["Nc"]), int(g["Ni"]), float(g["near"]), float(g["far"]), g["hist"],
+                                c2w=g["c2w"])
+    close(rgb, g["rgb"], 1e-5, 1e-6)
+    close(disp, g["disp"], 1e-5, 1e-6)
+    close(acc, g["acc"], 1e-5, 1e-6)
+
+
+def test_g8_dfnet(gold):
+    p = tt(syn.dfnet_weights(seed=3))
+    g = gold("g8_dfnet_small")
+    cs = int(g["cstride"])
+    x = T(g["x"])
+    with torch.no_grad():
+        maps, pose = dor.dfnet_forward(p, x, True, False, True, 32, 48)
+        close(maps[0][:, :, ::cs], g["siam_t"], 1e-4, 1e-5)
+        close(maps[1][:, :, ::cs], g["siam_r"], 1e-4, 1e-5)
+        close(torch.sqrt((maps[0] ** 2).sum((1, 2, 3, 4))), g["siam_t_l2"], 1e-5, 0)
+        close(pose, g["pose"], 1e-4, 1e-5)
+        maps, pose = dor.dfnet_forward(p, x, True, True, False, 40, 56)
+        assert pose is None and len(maps) == 1
+        close(maps[0][:, :, ::cs], g["single"], 1e-4, 1e-5)
+        close(torch.sqrt((maps[0] ** 2).sum((1, 2, 3, 4))), g["single_l2"], 1e-5, 0)
+        maps, pose = dor.dfnet_forward(p, x)
+        assert maps is None
+        close(pose, g["pose_only"], 1e-4, 1e-5)
+        g2 = gold("g8_dfnet_120x160")
+        maps, _ = dor.dfnet_forward(p, T(g2["x"]), True, True, False, 120, 160)
+        full = maps[0][:, 0]
+        close(full[:, ::8, ::6, ::8], g2["sub"], 1e-4, 1e-5)
+        close(torch.sqrt((full ** 2).sum((1, 2, 3))), g2["l2"], 1e-5, 0)
+        ps = tt(syn.dfnet_weights(seed=3, taps=(64,)))
+        gs = gold("g8_dfnet_s_small")
+        maps, pose = dor.dfnet_forward(ps, x, True, True, True, 32, 48, taps=(2,))
+        close(maps[0][:, :, ::cs], gs["single"], 1e-4, 1e-5)
+        close(pose, gs["pose"], 1e-4, 1e-5)
