@@ -1,0 +1,93 @@
+"""ctypes binding of libdfnet_hip.so (include/dfnet_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or fails to load,
+importing callers get a RuntimeError telling them how to build it.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdfnet_hip.so")
+
+DFN_PREC_F16 = 0
+DFN_PREC_F32 = 1
+PRECISIONS = {"f16": DFN_PREC_F16, "fp16": DFN_PREC_F16, "f32": DFN_PREC_F32, "fp32": DFN_PREC_F32}
+
+COMP_TEST_TIME, COMP_STATIC_ONLY, COMP_WHITE_BKGD = 1, 2, 4
+
+
+class DfnError(RuntimeError):
+    pass
+
+
+class NerfhDesc(Structure):
+    _fields_ = [("depth", c_int), ("width", c_int), ("multires", c_int), ("multires_views", c_int),
+                ("hist_bin", c_int), ("dim_a", c_int), ("dim_t", c_int), ("n_vocab", c_int)]
+
+
+# name -> (restype, argtypes); mirrors include/dfnet_hip.h one to one
+_P = c_void_p
+SIGNATURES = {
+    "dfn_last_error": (c_char_p, []),
+    "dfn_abi_version": (c_int, []),
+    "dfn_nerfh_create": (c_int, [POINTER(NerfhDesc), POINTER(c_void_p)]),
+    "dfn_nerfh_destroy": (c_int, [_P]),
+    "dfn_nerfh_set_param": (c_int, [_P, c_char_p, _P, c_size_t]),
+    "dfn_nerfh_commit": (c_int, [_P]),
+    "dfn_raygen": (c_int, [c_int, c_int, c_float, _P, _P, _P, _P, _P]),
+    "dfn_posenc": (c_int, [_P, c_size_t, c_int, c_int, _P, _P]),
+    "dfn_mlp_coarse": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_float, c_float, _P, _P]),
+    "dfn_coarse_weights": (c_int, [_P, _P, c_size_t, c_int, _P, _P]),
+    "dfn_sample_pdf": (c_int, [_P, _P, c_size_t, c_int, c_int, _P, _P, _P]),
+    "dfn_sample_fine": (c_int, [_P, c_size_t, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
+    "dfn_fine_bias_bytes": (c_size_t, [c_size_t]),
+    "dfn_mlp_fine": (c_int, [_P, c_int, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_int, _P, _P, _P]),
+    "dfn_composite_fine": (c_int, [_P, _P, c_size_t, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "dfn_render_workspace_bytes": (c_size_t, [c_size_t, c_int, c_int]),
+    "dfn_render_rays": (c_int, [_P, c_int, _P, _P, _P, _P, c_size_t, c_size_t, c_int, c_int, c_float, c_float,
+                                _P, _P, _P, _P, _P, c_size_t, _P]),
+    "dfn_render_image": (c_int, [_P, c_int, _P, c_int, c_int, c_float, c_float, c_float, c_int, c_int, _P,
+                                 _P, _P, _P, _P, c_size_t, _P]),
+    "dfn_profile_enable": (c_int, [c_int]),
+    "dfn_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdfnet_hip.so once and declare every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP library is the product and has no fallback. "
+                "Build it with `make -C dfnet_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`).")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dfn_last_error()
+        raise DfnError(f"{what or 'libdfnet_hip'} failed (status {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 CUDA tensor (or None)."""
+    if t is None:
+        return None
+    import torch
+    if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32:
+        raise ValueError(f"expected a contiguous fp32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

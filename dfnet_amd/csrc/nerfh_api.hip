@@ -1,0 +1,556 @@
+// nerfh_api.hip — the C ABI (include/dfnet_hip.h) of the NeRF-H render path: handle, host-side
+// packing of the reference's state_dict tensors into MFMA A-fragments, stage entry points and
+// the whole-path dfn_render_rays / dfn_render_image drivers.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/dfnet_hip.h"
+#include "dfn_common.h"
+#include "nerfh_kernels.h"
+#include "nerfh_layout.h"
+
+using namespace dfn;
+
+// ------------------------------------------------------------------------------------------ errors
+namespace dfn {
+static thread_local char g_err[512] = "";
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+int device_cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+}  // namespace dfn
+
+extern "C" const char* dfn_last_error(void) { return g_err; }
+extern "C" int dfn_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------ handle
+struct PackedNet {
+  char* blob = nullptr;
+  uint32_t* tab = nullptr;
+  int n_units = 0;
+};
+
+struct dfn_nerfh_s {
+  dfn_nerfh_desc desc;
+  std::map<std::string, std::vector<float>> params;
+  bool committed = false;
+  PackedNet net[2][2];  // [coarse/fine][prec]
+  float* extra = nullptr;  // w_dir^T | b_dir | w_tr^T | b_tr | emb_a | emb_t
+  RayBiasWeights rb{};
+};
+
+static std::map<std::string, std::vector<size_t>> expected_shapes(const dfn_nerfh_desc& d) {
+  std::map<std::string, std::vector<size_t>> m;
+  const size_t W = d.width, na = size_t(d.hist_bin) * d.dim_a, nt = size_t(d.hist_bin) * d.dim_t;
+  for (int f = 0; f < 2; ++f) {
+    const std::string pre = f ? "fine." : "coarse.";
+    for (int i = 0; i < d.depth; ++i) {
+      const size_t k = i == 0 ? kChXyz : (i == 4 ? W + kChXyz : W);
+      m[pre + "xyz_encoding_" + std::to_string(i + 1) + ".0.weight"] = {W, k};
+      m[pre + "xyz_encoding_" + std::to_string(i + 1) + ".0.bias"] = {W};
+    }
+    m[pre + "xyz_encoding_final.weight"] = {W, W};
+    m[pre + "xyz_encoding_final.bias"] = {W};
+    m[pre + "dir_encoding.0.weight"] = {W / 2, W + kChDir + (f ? na : 0)};
+    m[pre + "dir_encoding.0.bias"] = {W / 2};
+    m[pre + "static_sigma.0.weight"] = {1, W};
+    m[pre + "static_sigma.0.bias"] = {1};
+    m[pre + "static_rgb.0.weight"] = {3, W / 2};
+    m[pre + "static_rgb.0.bias"] = {3};
+    if (f) {
+      const size_t ks[4] = {W + nt, W / 2, W / 2, W / 2};
+      for (int j = 0; j < 4; ++j) {
+        m[pre + "transient_encoding." + std::to_string(2 * j) + ".weight"] = {W / 2, ks[j]};
+        m[pre + "transient_encoding." + std::to_string(2 * j) + ".bias"] = {W / 2};
+      }
+      m[pre + "transient_sigma.0.weight"] = {1, W / 2};
+      m[pre + "transient_sigma.0.bias"] = {1};
+      m[pre + "transient_rgb.0.weight"] = {3, W / 2};
+      m[pre + "transient_rgb.0.bias"] = {3};
+      m[pre + "transient_beta.0.weight"] = {1, W / 2};
+      m[pre + "transient_beta.0.bias"] = {1};
+    }
+  }
+  m["embedding_a.weight"] = {size_t(d.n_vocab), size_t(d.dim_a)};
+  m["embedding_t.weight"] = {size_t(d.n_vocab), size_t(d.dim_t)};
+  return m;
+}
+
+extern "C" int dfn_nerfh_create(const dfn_nerfh_desc* desc, dfn_nerfh_t* out) {
+  if (!desc || !out) return set_error(DFN_ERR_ARG, "dfn_nerfh_create: null argument");
+  if (desc->depth != 8 || desc->width != kWidth || desc->multires != kLxyz || desc->multires_views != kLdir)
+    return set_error(DFN_ERR_UNSUPPORTED,
+                     "dfn_nerfh_create: kernels are specialised for netdepth=8 netwidth=%d multires=%d "
+                     "multires_views=%d (got %d/%d/%d/%d)",
+                     kWidth, kLxyz, kLdir, desc->depth, desc->width, desc->multires, desc->multires_views);
+  if (desc->hist_bin <= 0 || desc->dim_a <= 0 || desc->dim_t <= 0 || desc->n_vocab <= 0 ||
+      desc->hist_bin * (desc->dim_a + desc->dim_t) > 1024)
+    return set_error(DFN_ERR_ARG, "dfn_nerfh_create: bad embedding geometry");
+  auto* h = new dfn_nerfh_s();
+  h->desc = *desc;
+  *out = h;
+  return DFN_OK;
+}
+
+static void free_packed(dfn_nerfh_s* h) {
+  for (auto& a : h->net)
+    for (auto& n : a) {
+      if (n.blob) (void)hipFree(n.blob);
+      if (n.tab) (void)hipFree(n.tab);
+      n = PackedNet();
+    }
+  if (h->extra) (void)hipFree(h->extra);
+  h->extra = nullptr;
+}
+
+extern "C" int dfn_nerfh_destroy(dfn_nerfh_t h) {
+  if (!h) return DFN_OK;
+  free_packed(h);
+  delete h;
+  return DFN_OK;
+}
+
+extern "C" int dfn_nerfh_set_param(dfn_nerfh_t h, const char* name, const float* host, size_t numel) {
+  if (!h || !name || !host) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_param: null argument");
+  const auto shapes = expected_shapes(h->desc);
+  const auto it = shapes.find(name);
+  if (it == shapes.end()) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_param: unknown parameter '%s'", name);
+  size_t want = 1;
+  for (size_t s : it->second) want *= s;
+  if (want != numel)
+    return set_error(DFN_ERR_ARG, "dfn_nerfh_set_param: '%s' has %zu elements, expected %zu", name, numel, want);
+  h->params[name].assign(host, host + numel);
+  h->committed = false;
+  return DFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ packing
+namespace {
+
+struct Mat {  // a state_dict Linear
+  const float* w = nullptr;
+  const float* b = nullptr;
+  int rows = 0, cols = 0;
+};
+
+struct Packer {
+  const dfn_nerfh_s* h;
+  std::string pre;
+  Mat mat(const std::string& key) const {
+    Mat m;
+    const auto& w = h->params.at(pre + key + ".weight");
+    const auto& b = h->params.at(pre + key + ".bias");
+    m.w = w.data();
+    m.b = b.data();
+    m.rows = int(b.size());
+    m.cols = int(w.size() / b.size());
+    return m;
+  }
+  // Source (matrix, row) of row i of M-block mb of a layer; row < 0 = zero row.
+  void row_source(int layer, int mb, int i, Mat& m, int& row) const {
+    row = 32 * mb + i;
+    switch (layer) {
+      case LY_L1: case LY_L2: case LY_L3: case LY_L4: case LY_L5: case LY_L6: case LY_L7: case LY_L8:
+        m = mat("xyz_encoding_" + std::to_string(layer - LY_L1 + 1) + ".0");
+        break;
+      case LY_FIN:
+        if (mb < 4) m = mat("xyz_encoding_final");
+        else { m = mat("static_sigma.0"); row = i == 0 ? 0 : -1; }
+        break;
+      case LY_DIR: m = mat("dir_encoding.0"); break;
+      case LY_RGB: m = mat("static_rgb.0"); row = i < 3 ? i : -1; break;
+      case LY_TE0: m = mat("transient_encoding.0"); break;
+      case LY_TE1: m = mat("transient_encoding.2"); break;
+      case LY_TE2: m = mat("transient_encoding.4"); break;
+      case LY_TE3: m = mat("transient_encoding.6"); break;
+      case LY_THEAD:
+        if (i < 3) { m = mat("transient_rgb.0"); row = i; }
+        else if (i == 3) { m = mat("transient_sigma.0"); row = 0; }
+        else if (i == 8) { m = mat("transient_beta.0"); row = 0; }
+        else { m = mat("transient_beta.0"); row = -1; }
+        break;
+      case LY_SIG: m = mat("static_sigma.0"); row = i == 0 ? 0 : -1; break;
+    }
+  }
+  // Source column of slot s of half h; < 0 = zero.
+  static int col_source(int layer, int hh, int s) {
+    if (layer == LY_L1) return pe_xyz_feature(hh, s);
+    if (layer == LY_L5) return s < 32 ? pe_xyz_feature(hh, s) : kChXyz + hidden_feature(hh, s - 32);
+    return hidden_feature(hh, s);
+  }
+  // The bias folded per ray (DIR, TE0) is NOT packed into the unit.
+  static bool unit_has_bias(int layer) { return layer != LY_DIR && layer != LY_TE0; }
+
+  template <class P>
+  void pack(bool fine, std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
+    using Elem = typename std::conditional<P::kSlotsPerChunk == 8, _Float16, float>::type;
+    const int* seq = fine ? kFineSeq : kCoarseSeq;
+    const int nl = fine ? kFineLayers : kCoarseLayers;
+    for (int li = 0; li < nl; ++li) {
+      const int layer = seq[li];
+      const LayerShape sh = layer_shape(layer);
+      const int KC = sh.slots / P::kSlotsPerChunk;
+      const int group = P::kUnitPerMb ? 1 : sh.mb;
+      for (int mb0 = 0; mb0 < sh.mb; mb0 += group) {
+        const uint32_t bytes = unit_bytes<P>(sh.slots, group);
+        const uint32_t off = uint32_t(blob.size());
+        blob.resize(off + bytes, 0);
+        tab.push_back(off);
+        tab.push_back(bytes);
+        Elem* frag = reinterpret_cast<Elem*>(blob.data() + off);
+        float* bias = reinterpret_cast<float*>(blob.data() + off + size_t(group) * KC * 64 * P::kLaneBytes);
+        for (int g = 0; g < group; ++g) {
+          const int mb = mb0 + g;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, hh = lane >> 5;
+            Mat m;
+            int row;
+            row_source(layer, mb, i, m, row);
+            if (row >= m.rows) row = -1;
+            for (int kc = 0; kc < KC; ++kc)
+              for (int j = 0; j < P::kSlotsPerChunk; ++j) {
+                const int col = col_source(layer, hh, kc * P::kSlotsPerChunk + j);
+                const float v = (row >= 0 && col >= 0 && col < m.cols) ? m.w[size_t(row) * m.cols + col] : 0.f;
+                frag[((size_t(g) * KC + kc) * 64 + lane) * P::kSlotsPerChunk + j] = Elem(v);
+              }
+          }
+          for (int hh = 0; hh < 2; ++hh)
+            for (int r = 0; r < 16; ++r) {
+              Mat m;
+              int row;
+              row_source(layer, mb, mblock_row(hh, r), m, row);
+              if (row >= m.rows) row = -1;
+              bias[(g * 2 + hh) * 16 + r] = (row >= 0 && unit_has_bias(layer)) ? m.b[row] : 0.f;
+            }
+        }
+      }
+    }
+  }
+};
+
+int upload(const void* src, size_t bytes, void** dst) {
+  if (hipMalloc(dst, bytes ? bytes : 16) != hipSuccess) return set_error(DFN_ERR_HIP, "hipMalloc(%zu) failed", bytes);
+  if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    return set_error(DFN_ERR_HIP, "hipMemcpy H2D (%zu bytes) failed", bytes);
+  return DFN_OK;
+}
+
+}  // namespace
+
+extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_commit: null handle");
+  for (const auto& kv : expected_shapes(h->desc))
+    if (!h->params.count(kv.first)) return set_error(DFN_ERR_STATE, "dfn_nerfh_commit: parameter '%s' not set", kv.first.c_str());
+  free_packed(h);
+  for (int f = 0; f < 2; ++f)
+    for (int prec = 0; prec < 2; ++prec) {
+      Packer pk{h, f ? "fine." : "coarse."};
+      std::vector<uint8_t> blob;
+      std::vector<uint32_t> tab;
+      if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, blob, tab);
+      else pk.pack<PrecF32>(f, blob, tab);
+      PackedNet& n = h->net[f][prec];
+      int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
+      if (rc) return rc;
+      rc = upload(tab.data(), tab.size() * 4, reinterpret_cast<void**>(&n.tab));
+      if (rc) return rc;
+      n.n_units = int(tab.size() / 2);
+    }
+  // per-ray-bias weights: transposed tails of dir_encoding.0 / transient_encoding.0 + embeddings
+  const dfn_nerfh_desc& d = h->desc;
+  const int na = d.hist_bin * d.dim_a, nt = d.hist_bin * d.dim_t, kd = kChDir + na;
+  const auto& wd = h->params.at("fine.dir_encoding.0.weight");
+  const auto& bd = h->params.at("fine.dir_encoding.0.bias");
+  const auto& wt = h->params.at("fine.transient_encoding.0.weight");
+  const auto& bt = h->params.at("fine.transient_encoding.0.bias");
+  const auto& ea = h->params.at("embedding_a.weight");
+  const auto& et = h->params.at("embedding_t.weight");
+  std::vector<float> ex;
+  const size_t o_wd = 0, o_bd = o_wd + size_t(kd) * 64, o_wt = o_bd + 64, o_bt = o_wt + size_t(nt) * 64,
+               o_ea = o_bt + 64, o_et = o_ea + ea.size();
+  ex.resize(o_et + et.size());
+  const int ld_d = kWidth + kd, ld_t = kWidth + nt;
+  for (int j = 0; j < kd; ++j)
+    for (int f = 0; f < 64; ++f) ex[o_wd + size_t(j) * 64 + f] = wd[size_t(f) * ld_d + kWidth + j];
+  for (int j = 0; j < nt; ++j)
+    for (int f = 0; f < 64; ++f) ex[o_wt + size_t(j) * 64 + f] = wt[size_t(f) * ld_t + kWidth + j];
+  std::memcpy(&ex[o_bd], bd.data(), 64 * 4);
+  std::memcpy(&ex[o_bt], bt.data(), 64 * 4);
+  std::memcpy(&ex[o_ea], ea.data(), ea.size() * 4);
+  std::memcpy(&ex[o_et], et.data(), et.size() * 4);
+  int rc = upload(ex.data(), ex.size() * 4, reinterpret_cast<void**>(&h->extra));
+  if (rc) return rc;
+  h->rb.w_dir = h->extra + o_wd;
+  h->rb.b_dir = h->extra + o_bd;
+  h->rb.w_tr = h->extra + o_wt;
+  h->rb.b_tr = h->extra + o_bt;
+  h->rb.emb_a = h->extra + o_ea;
+  h->rb.emb_t = h->extra + o_et;
+  h->rb.hist_bin = d.hist_bin;
+  h->rb.dim_a = d.dim_a;
+  h->rb.dim_t = d.dim_t;
+  h->rb.n_vocab = d.n_vocab;
+  h->committed = true;
+  return DFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ profiling aid
+namespace {
+struct KernelTimer {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+} g_prof;
+struct ScopedTimer {
+  int which;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(int w, hipStream_t st) : which(w), s(st) {
+    if (!g_prof.on) return;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+  }
+  ~ScopedTimer() {
+    if (!a) return;
+    (void)hipEventRecord(b, s);
+    g_prof.ev[which].emplace_back(a, b);
+  }
+};
+}  // namespace
+
+extern "C" int dfn_profile_enable(int on) {
+  for (auto& v : g_prof.ev) {
+    for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    v.clear();
+  }
+  g_prof.on = on != 0;
+  return DFN_OK;
+}
+extern "C" int dfn_profile_read(int which, double* avg_ms, int* launches) {
+  if (which < 0 || which > 1 || !avg_ms || !launches) return set_error(DFN_ERR_ARG, "dfn_profile_read: bad argument");
+  double tot = 0;
+  for (auto& p : g_prof.ev[which]) {
+    float ms = 0;
+    if (hipEventSynchronize(p.second) != hipSuccess || hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess)
+      return set_error(DFN_ERR_HIP, "dfn_profile_read: event query failed");
+    tot += ms;
+  }
+  *launches = int(g_prof.ev[which].size());
+  *avg_ms = *launches ? tot / *launches : 0.0;
+  return DFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ stage entry points
+#define HS(s) reinterpret_cast<hipStream_t>(s)
+#define CHECK_HIP(expr, what)                                                                   \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return set_error(DFN_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+static int check_net(dfn_nerfh_t h, int prec, const char* fn) {
+  if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
+  if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_nerfh_commit() has not been called", fn);
+  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32) return set_error(DFN_ERR_ARG, "%s: unknown precision %d", fn, prec);
+  return DFN_OK;
+}
+
+extern "C" int dfn_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
+                          float* viewdirs, void* stream) {
+  if (H < 0 || W < 0 || !c2w || !rays_o || !rays_d || !(focal > 0)) return set_error(DFN_ERR_ARG, "dfn_raygen: bad argument");
+  CHECK_HIP(launch_raygen(H, W, focal, c2w, rays_o, rays_d, viewdirs, HS(stream)), "dfn_raygen");
+  return DFN_OK;
+}
+
+extern "C" int dfn_posenc(const float* x, size_t n, int L, int mode, float* out, void* stream) {
+  if (!x || !out || L < 0 || L > 16 || (mode != 0 && mode != 1)) return set_error(DFN_ERR_ARG, "dfn_posenc: bad argument");
+  CHECK_HIP(launch_posenc(x, n, L, mode, out, HS(stream)), "dfn_posenc");
+  return DFN_OK;
+}
+
+extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, size_t n_rays,
+                              int Nc, float near, float far, float* sigma, void* stream) {
+  if (int rc = check_net(h, prec, "dfn_mlp_coarse")) return rc;
+  if (!rays_o || !rays_d || !sigma || Nc < 1) return set_error(DFN_ERR_ARG, "dfn_mlp_coarse: bad argument");
+  const PackedNet& n = h->net[0][prec];
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, (long long)n_rays, Nc, near, far};
+  ScopedTimer t(0, HS(stream));
+  CHECK_HIP(launch_mlp(false, prec, a, device_cu_count(), HS(stream)), "dfn_mlp_coarse");
+  return DFN_OK;
+}
+
+extern "C" int dfn_coarse_weights(const float* sigma, const float* z, size_t n, int N, float* weights, void* stream) {
+  if (!sigma || !z || !weights || N < 1 || N > 2048) return set_error(DFN_ERR_ARG, "dfn_coarse_weights: bad argument");
+  CHECK_HIP(launch_coarse_weights(sigma, z, n, N, weights, HS(stream)), "dfn_coarse_weights");
+  return DFN_OK;
+}
+
+extern "C" int dfn_sample_pdf(const float* bins, const float* weights, size_t n, int nb, int Ni, const float* u,
+                              float* out, void* stream) {
+  if (!bins || !weights || !out || nb < 2 || Ni < 1 || 3 * nb + 2 * Ni > 8192)
+    return set_error(DFN_ERR_ARG, "dfn_sample_pdf: bad argument");
+  CHECK_HIP(launch_sample_pdf(bins, weights, n, nb, Ni, u, out, HS(stream)), "dfn_sample_pdf");
+  return DFN_OK;
+}
+
+extern "C" int dfn_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
+                               float* z_fine, float* weights_coarse, float* z_samples, void* stream) {
+  if (!sigma || !z_fine || Nc < 3 || Ni < 1 || 6 * Nc + 2 * Ni > 8192)
+    return set_error(DFN_ERR_ARG, "dfn_sample_fine: bad argument (need N_samples >= 3, N_importance >= 1)");
+  CHECK_HIP(launch_sample_fine(sigma, n_rays, Nc, Ni, near, far, z_fine, weights_coarse, z_samples, HS(stream)),
+            "dfn_sample_fine");
+  return DFN_OK;
+}
+
+extern "C" size_t dfn_fine_bias_bytes(size_t n_rays) { return (n_rays ? n_rays : 1) * kRayBiasFloats * sizeof(float); }
+
+extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
+                            const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf,
+                            float* raw, void* bias_ws, void* stream) {
+  if (int rc = check_net(h, prec, "dfn_mlp_fine")) return rc;
+  if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !raw || !bias_ws || Nf < 1 ||
+      (hist_rows != 1 && hist_rows != n_rays))
+    return set_error(DFN_ERR_ARG, "dfn_mlp_fine: bad argument (hist_rows must be 1 or n_rays)");
+  float* table = static_cast<float*>(bias_ws);
+  CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine(ray_bias)");
+  const PackedNet& n = h->net[1][prec];
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, (long long)n_rays, Nf, 0.f, 0.f};
+  ScopedTimer t(1, HS(stream));
+  CHECK_HIP(launch_mlp(true, prec, a, device_cu_count(), HS(stream)), "dfn_mlp_fine");
+  return DFN_OK;
+}
+
+extern "C" int dfn_composite_fine(const float* raw, const float* z, size_t n_rays, int Nf, float beta_min, int flags,
+                                  float* rgb, float* disp, float* acc, float* depth, float* weights, float* beta,
+                                  void* stream) {
+  if (!raw || !z || !rgb || !disp || !acc || Nf < 1 || Nf > 512)
+    return set_error(DFN_ERR_ARG, "dfn_composite_fine: bad argument (1 <= Nf <= 512)");
+  CHECK_HIP(launch_composite_fine(raw, z, n_rays, Nf, beta_min, flags, rgb, disp, acc, depth, weights, beta, HS(stream)),
+            "dfn_composite_fine");
+  return DFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ whole path
+namespace {
+constexpr size_t kChunkRays = 65536;  // rays per internal pass (bounds the raw buffer)
+inline size_t al(size_t b) { return (b + 255) & ~size_t(255); }
+struct Workspace {
+  float *o, *d, *v, *sigma, *z, *raw, *bias;
+  size_t total;
+};
+Workspace carve(char* base, size_t n_rays, int Nc, int Ni, bool own_rays) {
+  const size_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+  const size_t Nf = size_t(Nc) + Ni;
+  Workspace w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return reinterpret_cast<float*>(p); };
+  w.o = take(own_rays ? n_rays * 12 : 0);
+  w.d = take(own_rays ? n_rays * 12 : 0);
+  w.v = take(n_rays * 12);
+  w.sigma = take(chunk * Nc * 4);
+  w.z = take(chunk * Nf * 4);
+  w.raw = take(chunk * Nf * 9 * 4);
+  w.bias = take(chunk * kRayBiasFloats * 4);
+  w.total = off;
+  return w;
+}
+
+int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const float* v, const float* hist,
+                size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far, float* rgb, float* disp,
+                float* acc, float* raw_out, const Workspace& w, hipStream_t s) {
+  const int Nf = Nc + Ni;
+  const PackedNet& nc = h->net[0][prec];
+  const PackedNet& nf = h->net[1][prec];
+  const int cus = device_cu_count();
+  for (size_t r0 = 0; r0 < n_rays; r0 += kChunkRays) {
+    const size_t n = n_rays - r0 < kChunkRays ? n_rays - r0 : kChunkRays;
+    const float* co = o + r0 * 3;
+    const float* cd = d + r0 * 3;
+    const float* cv = v + r0 * 3;
+    const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
+    float* raw = raw_out ? raw_out + r0 * size_t(Nf) * 9 : w.raw;
+    {
+      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, (long long)n, Nc, near, far};
+      ScopedTimer t(0, s);
+      CHECK_HIP(launch_mlp(false, prec, a, cus, s), "render: coarse MLP");
+    }
+    CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s), "render: sample_fine");
+    CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.bias, s), "render: ray_bias");
+    {
+      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, (long long)n, Nf, 0.f, 0.f};
+      ScopedTimer t(1, s);
+      CHECK_HIP(launch_mlp(true, prec, a, cus, s), "render: fine MLP");
+    }
+    CHECK_HIP(launch_composite_fine(raw, w.z, n, Nf, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
+                                    disp + r0, acc + r0, nullptr, nullptr, nullptr, s),
+              "render: composite");
+  }
+  return DFN_OK;
+}
+
+int check_render_args(int Nc, int Ni, const char* fn) {
+  if (Nc < 3 || Ni < 1 || Nc + Ni > 512 || 6 * Nc + 2 * Ni > 8192)
+    return set_error(DFN_ERR_UNSUPPORTED, "%s: need 3 <= N_samples, 1 <= N_importance, N_samples+N_importance <= 512", fn);
+  return DFN_OK;
+}
+}  // namespace
+
+extern "C" size_t dfn_render_workspace_bytes(size_t n_rays, int Nc, int Ni) {
+  return carve(nullptr, n_rays ? n_rays : 1, Nc, Ni, true).total;
+}
+
+extern "C" int dfn_render_rays(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
+                               const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far,
+                               float* rgb, float* disp, float* acc, float* raw, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (int rc = check_net(h, prec, "dfn_render_rays")) return rc;
+  if (int rc = check_render_args(Nc, Ni, "dfn_render_rays")) return rc;
+  if (!rays_o || !rays_d || !hist || !rgb || !disp || !acc || !workspace || (hist_rows != 1 && hist_rows != n_rays))
+    return set_error(DFN_ERR_ARG, "dfn_render_rays: bad argument (hist_rows must be 1 or n_rays)");
+  if (!n_rays) return DFN_OK;
+  const Workspace w = carve(static_cast<char*>(workspace), n_rays, Nc, Ni, true);
+  if (w.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_render_rays: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  const float* v = viewdirs;
+  if (!v) {
+    CHECK_HIP(launch_viewdirs(rays_d, n_rays, w.v, HS(stream)), "dfn_render_rays: viewdirs");
+    v = w.v;
+  }
+  return render_core(h, prec, rays_o, rays_d, v, hist, hist_rows, n_rays, Nc, Ni, near, far, rgb, disp, acc, raw, w,
+                     HS(stream));
+}
+
+extern "C" int dfn_render_image(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, float focal, float near,
+                                float far, int Nc, int Ni, const float* hist, float* rgb, float* disp, float* acc,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_net(h, prec, "dfn_render_image")) return rc;
+  if (int rc = check_render_args(Nc, Ni, "dfn_render_image")) return rc;
+  if (!c2w || !hist || !rgb || !disp || !acc || !workspace || H < 1 || W < 1 || !(focal > 0))
+    return set_error(DFN_ERR_ARG, "dfn_render_image: bad argument");
+  const size_t n_rays = size_t(H) * W;
+  const Workspace w = carve(static_cast<char*>(workspace), n_rays, Nc, Ni, true);
+  if (w.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_render_image: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  CHECK_HIP(launch_raygen(H, W, focal, c2w, w.o, w.d, w.v, HS(stream)), "dfn_render_image: raygen");
+  return render_core(h, prec, w.o, w.d, w.v, hist, 1, n_rays, Nc, Ni, near, far, rgb, disp, acc, nullptr, w, HS(stream));
+}

@@ -1,0 +1,74 @@
+// nerfh_device.h — small device helpers shared by the MLP and the sampling/compositing kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dfn {
+
+#define DFN_DEV __device__ __forceinline__
+
+// ---- linspace / coarse depths ---------------------------------------------------------------
+// torch.linspace(0, 1, n)[i]: CPU/GPU kernels fill symmetrically from both ends.
+DFN_DEV float unit_linspace(int i, int n) {
+  const float step = n > 1 ? 1.f / float(n - 1) : 0.f;
+  return i < n / 2 ? __fmul_rn(step, float(i)) : __fsub_rn(1.f, __fmul_rn(step, float(n - 1 - i)));
+}
+// z = near*(1-t) + far*t without FMA contraction (reference: models/rendering.py:269-271).
+DFN_DEV float coarse_z_at(int i, int n, float near, float far) {
+  const float t = unit_linspace(i, n);
+  return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
+}
+
+// ---- positional-encoding trig -----------------------------------------------------------------
+// FAST path: u = x/(2 pi) as an unevaluated sum uh + ul (two-term product), so that
+// frac(2^k u) keeps full fp32 accuracy up to 2^9 |x|; then the hardware sin/cos, which take
+// their argument in revolutions.
+constexpr float kInv2PiHi = 0.15915494f;     // fl32(1/(2 pi)) = 0x1.45f306p-3
+constexpr float kInv2PiLo = 6.4206382e-09f;  // 1/(2 pi) - fl32(1/(2 pi))
+
+DFN_DEV void rev_split(float x, float& uh, float& ul) {
+  uh = x * kInv2PiHi;
+  ul = fmaf(x, kInv2PiHi, -uh) + x * kInv2PiLo;
+}
+// sin/cos of 2*pi*f*(uh+ul) for f a power of two.
+DFN_DEV void rev_sincos(float uh, float ul, float f, float& s, float& c) {
+  const float t = __builtin_amdgcn_fractf(uh * f) + ul * f;
+  s = __builtin_amdgcn_sinf(t);
+  c = __builtin_amdgcn_cosf(t);
+}
+
+// Wave-level ordering of LDS traffic: DS operations of one wavefront execute in issue order, so
+// all that is needed between a lane's LDS store and another lane's load is to stop the
+// compiler from reordering them.
+DFN_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- activations -----------------------------------------------------------------------------
+DFN_DEV float softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }  // nn.Softplus(beta=1, threshold=20)
+DFN_DEV float sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ---- wavefront (64-lane) scans and reductions ---------------------------------------------------
+DFN_DEV float wave_incl_prod(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d, 64);
+    if (lane >= d) v *= t;
+  }
+  return v;
+}
+DFN_DEV float wave_incl_sum(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+DFN_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+}  // namespace dfn

@@ -1,0 +1,53 @@
+// nerfh_kernels.h — internal launch interface between the C ABI (dfn_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dfn {
+
+struct MlpArgs {
+  const char* blob;        // packed MFMA fragments of the net (device)
+  const uint32_t* tab;     // [n_units][2] = (byte offset, byte size) of each staging unit (device)
+  int n_units;
+  const float* rays_o;     // [n_rays,3]
+  const float* rays_d;     // [n_rays,3]
+  const float* z;          // fine: [n_rays, n_samples]; coarse: unused (linspace in-kernel)
+  const float* ray_bias;   // fine: [n_rays, kRayBiasFloats]
+  float* out;              // coarse: sigma [n_rays, n_samples]; fine: raw [n_rays, n_samples, 9]
+  long long n_rays;
+  int n_samples;
+  float near, far;
+};
+
+hipError_t launch_mlp(bool fine, int prec, const MlpArgs& a, int n_cu, hipStream_t stream);
+
+// --- stages (nerfh_stages.hip)
+hipError_t launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
+                         float* viewdirs, hipStream_t stream);
+hipError_t launch_viewdirs(const float* rays_d, size_t n, float* viewdirs, hipStream_t stream);
+hipError_t launch_posenc(const float* x, size_t n, int L, int mode, float* out, hipStream_t stream);
+
+struct RayBiasWeights {       // device pointers, fp32
+  const float* w_dir;         // [77][64]  transposed dir_encoding.0.weight[:, 128:205]
+  const float* b_dir;         // [64]
+  const float* w_tr;          // [20][64]  transposed transient_encoding.0.weight[:, 128:148]
+  const float* b_tr;          // [64]
+  const float* emb_a;         // [n_vocab, dim_a]
+  const float* emb_t;         // [n_vocab, dim_t]
+  int hist_bin, dim_a, dim_t, n_vocab;
+};
+hipError_t launch_ray_bias(const RayBiasWeights& w, const float* viewdirs, const float* hist,
+                           size_t hist_rows, size_t n_rays, float* table, hipStream_t stream);
+
+hipError_t launch_coarse_weights(const float* sigma, const float* z, size_t n, int N, float* weights,
+                                 hipStream_t stream);
+hipError_t launch_sample_pdf(const float* bins, const float* weights, size_t n, int nb, int Ni,
+                             const float* u, float* out, hipStream_t stream);
+hipError_t launch_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
+                              float* z_fine, float* weights_coarse, float* z_samples, hipStream_t stream);
+hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays, int Nf, float beta_min,
+                                 int flags, float* rgb, float* disp, float* acc, float* depth,
+                                 float* weights, float* beta, hipStream_t stream);
+
+}  // namespace dfn

@@ -1,0 +1,106 @@
+// nerfh_layout.h — the NeRF-H MLP as a sequence of MFMA "layers", shared by the host-side
+// weight packer (nerfh_pack.cpp) and the device kernels (nerfh_mlp.hip).
+//
+// Formulation: every Linear is computed TRANSPOSED on the matrix cores,
+//     H_out^T[feature, point] = W[feature, k] * H_in^T[k, point]
+// with the weights as the MFMA A operand (M = 32 output features per M-block) and the
+// activations of 32 points as the B operand (N = 32 points).  The 32x32 C/D fragment of lane
+// (p = lane&31, h = lane>>5) holds, for point p, output features
+//     row(h, r) = (r&3) + 8*(r>>2) + 4*h,  r = 0..15
+// of the M-block.  Because the order of the contraction index is free, the C registers of
+// one layer ARE the B operand of the next once the next layer's weight columns are
+// permuted to match — activations never leave registers between layers.
+//
+// "Slot" s of half h: the s-th contraction element held by the lanes of half h.  A layer with
+// K (padded) inputs has K/2 slots per half.  f16 path: 8 slots per MFMA K-chunk
+// (v_mfma_f32_32x32x16_f16), f32 path: 1 slot per chunk (v_mfma_f32_32x32x2_f32).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define DFN_HD __host__ __device__
+#else
+#define DFN_HD
+#endif
+
+namespace dfn {
+
+constexpr int kWidth = 128;      // netwidth the kernels are specialised for
+constexpr int kLxyz = 10;        // multires
+constexpr int kLdir = 4;         // multires_views
+constexpr int kChXyz = 63, kChDir = 27;
+
+enum LayerId {
+  LY_L1 = 0, LY_L2, LY_L3, LY_L4, LY_L5, LY_L6, LY_L7, LY_L8,
+  LY_FIN,    // xyz_encoding_final (4 M-blocks, no activation) + static_sigma (5th M-block, row 0)
+  LY_DIR,    // dir_encoding.0 on the `final` columns; pe_dir/appearance columns fold into a per-ray bias
+  LY_RGB,    // static_rgb.0 (rows 0..2)
+  LY_TE0,    // transient_encoding.0 on the `final` columns; transient-embedding columns -> per-ray bias
+  LY_TE1, LY_TE2, LY_TE3,  // transient_encoding.{2,4,6}
+  LY_THEAD,  // rows 0..2 transient_rgb, row 3 transient_sigma, row 8 transient_beta (all on half 0)
+  LY_SIG,    // coarse net: static_sigma alone (row 0)
+  LY_COUNT
+};
+
+struct LayerShape { int slots; int mb; };  // slots per half (= K/2), number of 32-row M-blocks
+
+DFN_HD constexpr LayerShape layer_shape(int id) {
+  return id == LY_L1 ? LayerShape{32, 4}
+       : id == LY_L5 ? LayerShape{96, 4}
+       : id <= LY_L8 ? LayerShape{64, 4}
+       : id == LY_FIN ? LayerShape{64, 5}
+       : id == LY_DIR ? LayerShape{64, 2}
+       : id == LY_RGB ? LayerShape{32, 1}
+       : id == LY_TE0 ? LayerShape{64, 2}
+       : id <= LY_TE3 ? LayerShape{32, 2}
+       : id == LY_THEAD ? LayerShape{32, 1}
+       : LayerShape{64, 1};  // LY_SIG
+}
+
+// The layer sequences the kernels execute, in order.
+constexpr int kCoarseSeq[] = {LY_L1, LY_L2, LY_L3, LY_L4, LY_L5, LY_L6, LY_L7, LY_L8, LY_SIG};
+constexpr int kFineSeq[] = {LY_L1, LY_L2, LY_L3, LY_L4, LY_L5, LY_L6, LY_L7, LY_L8, LY_FIN,
+                            LY_DIR, LY_RGB, LY_TE0, LY_TE1, LY_TE2, LY_TE3, LY_THEAD};
+constexpr int kCoarseLayers = sizeof(kCoarseSeq) / sizeof(int);
+constexpr int kFineLayers = sizeof(kFineSeq) / sizeof(int);
+
+// Feature index (within a 128- or 64-wide hidden vector) held in slot s of half h when the
+// vector was produced by M-blocks of a previous layer.
+DFN_HD constexpr int hidden_feature(int h, int s) {
+  return 32 * (s >> 4) + 4 * h + (s & 3) + 8 * ((s & 15) >> 2);
+}
+// Row of an M-block held in C register r of half h.
+DFN_HD constexpr int mblock_row(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Slot -> column of the 63-wide xyz positional encoding (-1 = zero padding).  Half h computes
+// frequencies 5h..5h+4: slots 6k'+c (c<3: sin of coord c, c>=3: cos of coord c-3), then the
+// raw coordinates in slots 30, 31 (half 0: x, y; half 1: z, pad).
+DFN_HD constexpr int pe_xyz_feature(int h, int s) {
+  return s < 30 ? 3 + 6 * (5 * h + s / 6) + (s % 6) : (s == 30 ? (h ? 2 : 0) : (h ? -1 : 1));
+}
+
+// Per-precision fragment geometry.
+struct PrecF16 { static constexpr int kSlotsPerChunk = 8, kLaneBytes = 16; static constexpr bool kUnitPerMb = false; };
+struct PrecF32 { static constexpr int kSlotsPerChunk = 1, kLaneBytes = 4;  static constexpr bool kUnitPerMb = true; };
+
+constexpr uint32_t kPiece = 1024;  // staging granule: one wave-wide 16-byte LDS-DMA
+
+DFN_HD constexpr uint32_t align_piece(uint32_t b) { return (b + kPiece - 1) / kPiece * kPiece; }
+
+// Bytes of one staging unit holding `nmb` M-blocks of a layer with `slots` slots per half.
+template <class P>
+DFN_HD constexpr uint32_t unit_bytes(int slots, int nmb) {
+  return align_piece(uint32_t(nmb) * (slots / P::kSlotsPerChunk) * 64 * P::kLaneBytes + uint32_t(nmb) * 2 * 16 * 4);
+}
+// Largest unit of either network (sizes the two LDS staging buffers).
+template <class P>
+DFN_HD constexpr uint32_t max_unit_bytes() {
+  return P::kUnitPerMb ? unit_bytes<P>(96, 1) : unit_bytes<P>(96, 4) > unit_bytes<P>(64, 5) ? unit_bytes<P>(96, 4)
+                                                                                               : unit_bytes<P>(64, 5);
+}
+
+// Per-ray bias table written by the ray-bias kernel and read by the fine kernel:
+// [ray][table(0 = dir_encoding, 1 = transient_encoding.0)][mb(2)][h(2)][r(16)] fp32.
+constexpr int kRayBiasFloats = 2 * 2 * 2 * 16;
+
+}  // namespace dfn

@@ -1,0 +1,401 @@
+// nerfh_mlp.hip — the NeRF-H MLP on the CDNA4 matrix cores (gfx950 only).
+//
+// One persistent workgroup of 8 wavefronts per CU.  Each wavefront owns NB blocks of 32 sample
+// points and carries their activations through the WHOLE network in registers: a Linear layer
+// is computed transposed (weights = MFMA A operand, activations = B operand, see
+// nerfh_layout.h), so the fp32 C fragments of layer l, after bias/ReLU and conversion, are the
+// B operand of layer l+1 — no LDS or HBM round trip for activations.  Positional encoding,
+// the point o + d*z, Softplus/Sigmoid heads are fused in.  Only the weights move: every
+// layer's pre-permuted MFMA A-fragments stream L2 -> LDS with direct-to-LDS DMA
+// (global_load_lds_dwordx4) into a double buffer shared by the 8 waves, one barrier per unit.
+//
+// Replaces (reference, /root/reference/script/): models/rendering.py:269-292,305-313 (points),
+// models/nerfw.py:15-95 (run_network_NeRFW), :105-133 (Embedder.embed), :297-354 (NeRFW.forward).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nerfh_device.h"
+#include "nerfh_kernels.h"
+#include "nerfh_layout.h"
+
+namespace dfn {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <class P> struct FragOf;
+template <> struct FragOf<PrecF16> { using type = half8; };
+template <> struct FragOf<PrecF32> { using type = float; };
+
+template <class P> DFN_DEV f32x16 mfma(typename FragOf<P>::type a, typename FragOf<P>::type b, f32x16 c);
+template <> DFN_DEV f32x16 mfma<PrecF16>(half8 a, half8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <> DFN_DEV f32x16 mfma<PrecF32>(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// chunks (B-operand registers groups) per 32 produced features / per n slots
+template <class P> constexpr int chunks_of(int slots) { return slots / P::kSlotsPerChunk; }
+
+template <class P, int KC>
+DFN_DEV void set_slot(typename FragOf<P>::type (&arr)[KC], int s, float v) {
+  if constexpr (P::kSlotsPerChunk == 8) arr[s >> 3][s & 7] = (_Float16)v;
+  else arr[s] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight staging: the packed blob is a sequence of units (offset, bytes) in execution order.
+struct Stager {
+  const char* blob;
+  const uint32_t* tab;
+  int n_units;
+  int u;               // unit that the NEXT begin_unit() makes readable
+  uint32_t lds_cur;    // LDS byte offset holding (or receiving) unit u
+  uint32_t lds_nxt;
+  int lane, wave;
+  bool more;           // another tile follows this one (wave-uniform)
+};
+
+DFN_DEV void stage_issue(const Stager& st, char* smem, int unit, uint32_t lds_off) {
+  const uint32_t off = st.tab[2 * unit], size = st.tab[2 * unit + 1];
+  const char* src = st.blob + off + st.lane * 16;
+  for (uint32_t p = st.wave * kPiece; p < size; p += 8 * kPiece)
+    __builtin_amdgcn_global_load_lds((const void*)(src + p), LDS_PTR(smem + lds_off + p), 16, 0, 0);
+}
+
+// Make unit st.u readable and start streaming the following one into the other buffer.
+// Returns the LDS byte offset of the readable unit.
+DFN_DEV uint32_t begin_unit(Stager& st, char* smem) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of unit u has landed
+  __syncthreads();                                  // everyone's share landed; everyone left unit u-1
+  int nxt = st.u + 1;
+  const bool wrap = nxt == st.n_units;
+  if (wrap) nxt = 0;
+  if (!wrap || st.more) stage_issue(st, smem, nxt, st.lds_nxt);
+  const uint32_t cur = st.lds_cur;
+  st.lds_cur = st.lds_nxt;
+  st.lds_nxt = cur;
+  st.u = nxt;
+  return cur;
+}
+
+// ------------------------------------------------------------------------------------------
+// One 32-row M-block: acc[nb] += W_mb * Bin[nb] over KC chunks.  `wb` = LDS byte offset of the
+// block's first A fragment, already including lane * kLaneBytes.
+template <class P, int NB, int KC>
+DFN_DEV void mblock_mma(const char* smem, uint32_t wb, const typename FragOf<P>::type (&Bin)[NB][KC],
+                        f32x16 (&acc)[NB]) {
+  using F = typename FragOf<P>::type;
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const F a = *reinterpret_cast<const F*>(smem + wb + kc * 64 * P::kLaneBytes);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma<P>(a, Bin[nb][kc], acc[nb]);
+  }
+}
+
+DFN_DEV f32x16 load16(const float* p) {
+  const f32x4* q = reinterpret_cast<const f32x4*>(p);
+  f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+  f32x16 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = a[i]; r[4 + i] = b[i]; r[8 + i] = c[i]; r[12 + i] = d[i]; }
+  return r;
+}
+
+// C fragment -> B-operand registers of the next layer (ReLU optional).
+template <class P, bool RELU, int OC>
+DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb) {
+  if constexpr (P::kSlotsPerChunk == 8) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (_Float16)acc[8 * c + j];
+      if (RELU) {
+        const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        v = __builtin_elementwise_max(v, zero);
+      }
+      out[2 * mb + c] = v;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[16 * mb + r] = RELU ? fmaxf(acc[r], 0.f) : acc[r];
+  }
+}
+
+// A layer whose MB output M-blocks feed the next layer, plus (EXTRA) one trailing head M-block
+// whose raw accumulators go back to the caller.  RAYBIAS: accumulators start from a per-lane
+// global table (the per-ray folded bias) instead of the unit's LDS bias.
+template <class P, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS>
+DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)[NB][KC],
+                   typename FragOf<P>::type (&Bout)[NB][(MB ? MB : 1) * chunks_of<P>(16)],
+                   f32x16 (&head)[NB], const float* const (&raybias)[NB]) {
+  constexpr int TOT = MB + (EXTRA ? 1 : 0);
+  constexpr uint32_t MBW = KC * 64 * P::kLaneBytes;  // bytes of one M-block's fragments
+  const int h = st.lane >> 5;
+  uint32_t ub = 0;
+  if (!P::kUnitPerMb) ub = begin_unit(st, smem);
+#pragma unroll
+  for (int mb = 0; mb < TOT; ++mb) {
+    uint32_t wb, bb;
+    if (P::kUnitPerMb) {
+      ub = begin_unit(st, smem);
+      wb = ub;
+      bb = ub + MBW;
+    } else {
+      wb = ub + mb * MBW;
+      bb = ub + TOT * MBW + mb * 128;
+    }
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (RAYBIAS) acc[nb] = load16(raybias[nb] + (mb * 2 + h) * 16);
+      else acc[nb] = load16(reinterpret_cast<const float*>(smem + bb + h * 64));
+    }
+    mblock_mma<P, NB, KC>(smem, wb + st.lane * P::kLaneBytes, Bin, acc);
+    if (mb < MB) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb);
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) head[nb] = acc[nb];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Positional encoding of a point into the layer-1 B operand (slot map: pe_xyz_feature()).
+// FAST: x/(2pi) in two-term extended precision, exact fract, then v_sin_f32 / v_cos_f32 (which
+// take revolutions).  Otherwise full-range sinf/cosf of the exact product x * 2^k, bit-for-bit
+// the reference's sin(x * freq) up to libm rounding.
+template <class P, bool FAST, int NB, int PC>
+DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type (&pe)[NB][PC]) {
+  const float base = h ? 32.f : 1.f;  // half h owns frequencies 2^(5h) .. 2^(5h+4)
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xc = x[nb][c];
+      if (FAST) {
+        float uh, ul;
+        rev_split(xc, uh, ul);
+        uh *= base;
+        ul *= base;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          float sn, cs;
+          rev_sincos(uh, ul, float(1 << k), sn, cs);
+          set_slot<P>(pe[nb], 6 * k + c, sn);
+          set_slot<P>(pe[nb], 6 * k + 3 + c, cs);
+        }
+      } else {
+        const float xb = xc * base;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const float a = xb * float(1 << k);
+          set_slot<P>(pe[nb], 6 * k + c, sinf(a));
+          set_slot<P>(pe[nb], 6 * k + 3 + c, cosf(a));
+        }
+      }
+    }
+    set_slot<P>(pe[nb], 30, h ? x[nb][2] : x[nb][0]);
+    set_slot<P>(pe[nb], 31, h ? 0.f : x[nb][1]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The 8-layer trunk (xyz_encoding_1..8, skip concat [pe, h] before layer 5).
+template <class P, bool FAST, int NB>
+DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
+                   typename FragOf<P>::type (&out)[NB][chunks_of<P>(64)]) {
+  using F = typename FragOf<P>::type;
+  constexpr int PC = chunks_of<P>(32), HC = chunks_of<P>(64);
+  const int h = st.lane >> 5;
+  f32x16 nohead[NB];
+  const float* const norb[NB] = {};
+  F pe[NB][PC];
+  posenc_xyz<P, FAST, NB, PC>(x, h, pe);
+  F a[NB][HC], b[NB][HC];
+  layer<P, NB, PC, 4, true, false, false>(st, smem, pe, a, nohead, norb);
+  layer<P, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
+  layer<P, NB, HC, 4, true, false, false>(st, smem, b, a, nohead, norb);
+  layer<P, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
+  {
+    F cat[NB][PC + HC];
+    if constexpr (P::kSlotsPerChunk == 8) posenc_xyz<P, FAST, NB, PC>(x, h, pe);  // recompute: cheaper than 32 live VGPRs
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int i = 0; i < PC; ++i) cat[nb][i] = pe[nb][i];
+#pragma unroll
+      for (int i = 0; i < HC; ++i) cat[nb][PC + i] = b[nb][i];
+    }
+    layer<P, NB, PC + HC, 4, true, false, false>(st, smem, cat, a, nohead, norb);
+  }
+  layer<P, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
+  layer<P, NB, HC, 4, true, false, false>(st, smem, b, a, nohead, norb);
+  layer<P, NB, HC, 4, true, false, false>(st, smem, a, out, nohead, norb);
+}
+
+template <class P> constexpr int nb_of() { return P::kSlotsPerChunk == 8 ? 2 : 1; }
+template <class P> constexpr uint32_t lds_bytes() { return 2 * max_unit_bytes<P>(); }
+
+// ------------------------------------------------------------------------------------------
+template <class P, bool FAST>
+__global__ __launch_bounds__(512, 2) void nerfh_coarse_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NB = nb_of<P>();
+  constexpr int PPT = 8 * NB * 32;
+  using F = typename FragOf<P>::type;
+  Stager st;
+  st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
+  st.lds_cur = 0; st.lds_nxt = max_unit_bytes<P>();
+  st.lane = threadIdx.x & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = st.lane & 31, h = st.lane >> 5;
+  const long long n_pts = (long long)a.n_rays * a.n_samples;
+  const long long n_tiles = (n_pts + PPT - 1) / PPT;
+  long long tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  stage_issue(st, smem, 0, st.lds_cur);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    st.more = tile + gridDim.x < n_tiles;
+    float x[NB][3];
+    long long pt[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      pt[nb] = tile * PPT + st.wave * (NB * 32) + nb * 32 + p;
+      const long long q = pt[nb] < n_pts ? pt[nb] : n_pts - 1;
+      const long long ray = q / a.n_samples;
+      const int i = int(q - ray * a.n_samples);
+      const float z = coarse_z_at(i, a.n_samples, a.near, a.far);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        x[nb][c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], z));
+    }
+    F hid[NB][chunks_of<P>(64)];
+    trunk<P, FAST, NB>(st, smem, x, hid);
+    f32x16 head[NB];
+    F dummy[NB][chunks_of<P>(16)];
+    const float* const norb[NB] = {};
+    layer<P, NB, chunks_of<P>(64), 0, false, true, false>(st, smem, hid, dummy, head, norb);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (h == 0 && pt[nb] < n_pts) a.out[pt[nb]] = softplus(head[nb][0]);
+  }
+}
+
+template <class P, bool FAST>
+__global__ __launch_bounds__(512, 2) void nerfh_fine_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NB = nb_of<P>();
+  constexpr int PPT = 8 * NB * 32;
+  constexpr int HC = chunks_of<P>(64), QC = chunks_of<P>(32);
+  using F = typename FragOf<P>::type;
+  Stager st;
+  st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
+  st.lds_cur = 0; st.lds_nxt = max_unit_bytes<P>();
+  st.lane = threadIdx.x & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = st.lane & 31, h = st.lane >> 5;
+  const long long n_pts = (long long)a.n_rays * a.n_samples;
+  const long long n_tiles = (n_pts + PPT - 1) / PPT;
+  long long tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  stage_issue(st, smem, 0, st.lds_cur);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    st.more = tile + gridDim.x < n_tiles;
+    float x[NB][3];
+    long long pt[NB];
+    const float* rb_dir[NB];
+    const float* rb_tr[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      pt[nb] = tile * PPT + st.wave * (NB * 32) + nb * 32 + p;
+      const long long q = pt[nb] < n_pts ? pt[nb] : n_pts - 1;
+      const long long ray = q / a.n_samples;
+      const float z = a.z[q];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        x[nb][c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], z));
+      rb_dir[nb] = a.ray_bias + ray * kRayBiasFloats;
+      rb_tr[nb] = rb_dir[nb] + kRayBiasFloats / 2;
+    }
+    const float* const norb[NB] = {};
+    F hid[NB][HC];
+    trunk<P, FAST, NB>(st, smem, x, hid);
+    // xyz_encoding_final (no activation) + static_sigma
+    F fin[NB][HC];
+    f32x16 head[NB];
+    layer<P, NB, HC, 4, false, true, false>(st, smem, hid, fin, head, norb);
+    float o[NB][9];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) o[nb][3] = softplus(head[nb][0]);
+    // dir_encoding (per-ray bias = b + W[:,128:] [pe_dir, a]) -> static_rgb
+    {
+      F de[NB][QC], dummy[NB][chunks_of<P>(16)];
+      layer<P, NB, HC, 2, true, false, true>(st, smem, fin, de, head, rb_dir);
+      layer<P, NB, QC, 0, false, true, false>(st, smem, de, dummy, head, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[nb][c] = sigmoid(head[nb][c]);
+    }
+    // transient branch
+    {
+      F t0[NB][QC], t1[NB][QC], dummy[NB][chunks_of<P>(16)];
+      layer<P, NB, HC, 2, true, false, true>(st, smem, fin, t0, head, rb_tr);
+      layer<P, NB, QC, 2, true, false, false>(st, smem, t0, t1, head, norb);
+      layer<P, NB, QC, 2, true, false, false>(st, smem, t1, t0, head, norb);
+      layer<P, NB, QC, 2, true, false, false>(st, smem, t0, t1, head, norb);
+      layer<P, NB, QC, 0, false, true, false>(st, smem, t1, dummy, head, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[nb][4 + c] = sigmoid(head[nb][c]);
+        o[nb][7] = softplus(head[nb][3]);
+        o[nb][8] = softplus(head[nb][4]);  // C register 4 of half 0 = row 8 = transient_beta
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (h == 0 && pt[nb] < n_pts) {
+        float* dst = a.out + pt[nb] * 9;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) dst[c] = o[nb][c];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <class P, bool FAST>
+static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t stream) {
+  constexpr int PPT = 8 * nb_of<P>() * 32;
+  const long long n_pts = (long long)a.n_rays * a.n_samples;
+  if (n_pts <= 0) return hipSuccess;
+  const long long n_tiles = (n_pts + PPT - 1) / PPT;
+  const int grid = int(n_tiles < n_cu ? n_tiles : n_cu);
+  const uint32_t lds = lds_bytes<P>();
+  auto kern = fine ? nerfh_fine_kernel<P, FAST> : nerfh_coarse_kernel<P, FAST>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[fine]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    attr_done[fine] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_mlp(bool fine, int prec, const MlpArgs& a, int n_cu, hipStream_t stream) {
+  if (prec == 0) return launch_one<PrecF16, true>(fine, a, n_cu, stream);
+  return launch_one<PrecF32, false>(fine, a, n_cu, stream);
+}
+
+}  // namespace dfn

@@ -1,0 +1,439 @@
+// nerfh_stages.hip — the HBM-bound stages around the NeRF-H MLP (gfx950 only): ray generation,
+// the per-ray folded bias of the two layers that take per-ray/per-image constants,
+// coarse alpha/weights + inverse-CDF importance sampling + sort, and the static+transient
+// alpha compositing.  One wavefront (64 lanes) owns one ray in the sampling / compositing
+// kernels: scans along the ray are wave-level shuffles, per-ray arrays live in LDS.
+//
+// Replaces (reference, /root/reference/script/): models/ray_utils.py:5-15,
+// models/rendering.py:24-65 (sample_pdf), :132-243 (raw2outputs_NeRFW), :295-304, :364-389;
+// models/nerfw.py:69-81 (embedding lookup) and the dir/appearance/transient columns of
+// dir_encoding / transient_encoding (nerfw.py:336-346).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nerfh_device.h"
+#include "nerfh_kernels.h"
+#include "nerfh_layout.h"
+
+namespace dfn {
+
+static inline int grid_for(size_t n, int block, int cap = 256 * 8) {
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  return int(g < size_t(cap) ? g : size_t(cap));
+}
+
+// ------------------------------------------------------------------------------------------ raygen
+__global__ __launch_bounds__(256) void raygen_kernel(int H, int W, float focal, const float* __restrict__ c2w,
+                                                     float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                     float* __restrict__ viewdirs) {
+  const size_t n = size_t(H) * W;
+  float R[3][3], t[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) R[a][b] = c2w[a * 4 + b];
+    t[a] = c2w[a * 4 + 3];
+  }
+  const float hw = float(W) * .5f, hh = float(H) * .5f;
+  for (size_t px = blockIdx.x * size_t(blockDim.x) + threadIdx.x; px < n; px += size_t(gridDim.x) * blockDim.x) {
+    const int j = int(px / W), i = int(px - size_t(j) * W);
+    const float dx = (float(i) - hw) / focal;
+    const float dy = -(float(j) - hh) / focal;
+    float d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)  // sum over the camera axis, left to right, no FMA (ray_utils.py:12)
+      d[a] = __fadd_rn(__fadd_rn(__fmul_rn(dx, R[a][0]), __fmul_rn(dy, R[a][1])), __fmul_rn(-1.f, R[a][2]));
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      rays_o[px * 3 + a] = t[a];
+      rays_d[px * 3 + a] = d[a];
+      if (viewdirs) viewdirs[px * 3 + a] = d[a] / nrm;
+    }
+  }
+}
+
+hipError_t launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
+                         float* viewdirs, hipStream_t stream) {
+  const size_t n = size_t(H) * W;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(raygen_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, H, W, focal, c2w, rays_o, rays_d, viewdirs);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void viewdirs_kernel(const float* __restrict__ d, size_t n, float* __restrict__ v) {
+  for (size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x; r < n; r += size_t(gridDim.x) * blockDim.x) {
+    const float x = d[r * 3], y = d[r * 3 + 1], z = d[r * 3 + 2];
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    v[r * 3] = x / nrm; v[r * 3 + 1] = y / nrm; v[r * 3 + 2] = z / nrm;
+  }
+}
+hipError_t launch_viewdirs(const float* rays_d, size_t n, float* viewdirs, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(viewdirs_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, rays_d, n, viewdirs);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ posenc (test entry)
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x, size_t n, int L, int mode,
+                                                     float* __restrict__ out) {
+  const int C = 3 + 6 * L;
+  for (size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x; r < n; r += size_t(gridDim.x) * blockDim.x) {
+    float* o = out + r * C;
+    for (int c = 0; c < 3; ++c) {
+      const float xc = x[r * 3 + c];
+      o[c] = xc;
+      float uh, ul;
+      rev_split(xc, uh, ul);
+      for (int k = 0; k < L; ++k) {
+        const float f = float(1u << k);
+        float s, cs;
+        if (mode == 1) rev_sincos(uh, ul, f, s, cs);
+        else { s = sinf(xc * f); cs = cosf(xc * f); }
+        o[3 + 6 * k + c] = s;
+        o[3 + 6 * k + 3 + c] = cs;
+      }
+    }
+  }
+}
+hipError_t launch_posenc(const float* x, size_t n, int L, int mode, float* out, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, x, n, L, mode, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ per-ray bias
+// table[ray][0] = b_dir + W_dir[:, 128:] . [pe_dir(viewdir) (27), a (hist_bin*dim_a)]
+// table[ray][1] = b_tr  + W_tr [:, 128:] . t (hist_bin*dim_t)
+// stored in C-fragment order [mb][h][r] so the fine kernel's accumulators load it directly.
+__global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const float* __restrict__ viewdirs,
+                                                       const float* __restrict__ hist, size_t hist_rows,
+                                                       size_t n_rays, float* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int na = w.hist_bin * w.dim_a, nt = w.hist_bin * w.dim_t;
+  const int kd = kChDir + na;  // rows of w_dir
+  float* s_wd = sm;                  // [kd][64]
+  float* s_wt = s_wd + kd * 64;      // [nt][64]
+  float* s_in = s_wt + nt * 64;      // [2 rays][kd + nt]
+  for (int i = threadIdx.x; i < kd * 64; i += blockDim.x) s_wd[i] = w.w_dir[i];
+  for (int i = threadIdx.x; i < nt * 64; i += blockDim.x) s_wt[i] = w.w_tr[i];
+  const int sub = threadIdx.x >> 7;        // which of the block's 2 rays
+  const int o = threadIdx.x & 127;         // output index: table o>>6, feature o&63
+  const int stride_in = kd + nt;
+  float* my_in = s_in + sub * stride_in;
+  for (size_t base = size_t(blockIdx.x) * 2; base < n_rays; base += size_t(gridDim.x) * 2) {
+    __syncthreads();
+    const size_t ray = base + sub;
+    const bool ok = ray < n_rays;
+    if (ok) {
+      const float* hrow = hist + (hist_rows == 1 ? 0 : ray) * w.hist_bin;
+      // inputs: pe_dir (27) | a | t
+      if (o < 3) {
+        const float v = viewdirs[ray * 3 + o];
+        my_in[o] = v;
+        for (int k = 0; k < kLdir; ++k) {
+          const float f = float(1 << k);
+          my_in[3 + 6 * k + o] = sinf(v * f);
+          my_in[3 + 6 * k + 3 + o] = cosf(v * f);
+        }
+      }
+      for (int i = o; i < na + nt; i += 128) {
+        const bool is_a = i < na;
+        const int j = is_a ? i : i - na;
+        const int dim = is_a ? w.dim_a : w.dim_t;
+        long long idx = (long long)hrow[j / dim];  // .long() truncation (nerfw.py:69)
+        idx = idx < 0 ? 0 : (idx >= w.n_vocab ? w.n_vocab - 1 : idx);
+        my_in[kChDir + i] = (is_a ? w.emb_a : w.emb_t)[idx * dim + (j % dim)];
+      }
+    }
+    __syncthreads();
+    if (ok) {
+      const int tbl = o >> 6, f = o & 63;
+      float acc;
+      if (tbl == 0) {
+        acc = w.b_dir[f];
+        for (int j = 0; j < kd; ++j) acc = fmaf(s_wd[j * 64 + f], my_in[j], acc);
+      } else {
+        acc = w.b_tr[f];
+        for (int j = 0; j < nt; ++j) acc = fmaf(s_wt[j * 64 + f], my_in[kd + j], acc);
+      }
+      const int mb = f >> 5, row = f & 31;
+      const int h = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+      table[ray * kRayBiasFloats + ((tbl * 2 + mb) * 2 + h) * 16 + r] = acc;
+    }
+  }
+}
+
+hipError_t launch_ray_bias(const RayBiasWeights& w, const float* viewdirs, const float* hist,
+                           size_t hist_rows, size_t n_rays, float* table, hipStream_t stream) {
+  if (!n_rays) return hipSuccess;
+  const int na = w.hist_bin * w.dim_a, nt = w.hist_bin * w.dim_t;
+  const size_t lds = size_t((kChDir + na) * 64 + nt * 64 + 2 * (kChDir + na + nt)) * 4;
+  hipLaunchKernelGGL(ray_bias_kernel, dim3(grid_for((n_rays + 1) / 2, 1)), dim3(256), lds, stream, w, viewdirs,
+                     hist, hist_rows, n_rays, table);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ per-ray wave helpers
+// alpha_i = 1 - exp(-delta_i * relu(sigma_i)), w_i = alpha_i * prod_{j<i} (1 - alpha_j), for one ray
+// held as sig[0..N) / z[0..N) in LDS (rendering.py:161-193).  Writes w[0..N).
+DFN_DEV void ray_coarse_weights(const float* sig, const float* z, int N, float* w, int lane) {
+  float carry = 1.f;
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int i = c0 + lane;
+    float alpha = 0.f;
+    if (i < N) {
+      const float delta = i + 1 < N ? __fsub_rn(z[i + 1], z[i]) : 1e2f;
+      alpha = __fsub_rn(1.f, expf(-__fmul_rn(delta, fmaxf(sig[i], 0.f))));
+    }
+    const float incl = wave_incl_prod(__fsub_rn(1.f, alpha), lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.f;
+    if (i < N) w[i] = __fmul_rn(alpha, __fmul_rn(carry, excl));
+    carry = __fmul_rn(carry, __shfl(incl, 63, 64));
+  }
+}
+
+// Inverse-CDF sampling of one ray (rendering.py:24-65).  bins[0..nb), wts[0..nb-1) in LDS;
+// cdf[0..nb) scratch in LDS; writes out[0..Ni).  u == nullptr -> linspace(0,1,Ni).
+DFN_DEV void ray_sample_pdf(const float* bins, const float* wts, int nb, float* cdf, const float* u, int Ni,
+                            float* out, int lane) {
+  const int nw = nb - 1;
+  float part = 0.f;
+  for (int i = lane; i < nw; i += 64) part += __fadd_rn(wts[i], 1e-5f);
+  const float total = wave_sum(part);
+  float carry = 0.f;
+  if (lane == 0) cdf[0] = 0.f;
+  for (int c0 = 0; c0 < nw; c0 += 64) {
+    const int i = c0 + lane;
+    const float pdf = i < nw ? __fadd_rn(wts[i], 1e-5f) / total : 0.f;
+    const float incl = wave_incl_sum(pdf, lane);
+    if (i < nw) cdf[i + 1] = __fadd_rn(carry, incl);
+    carry = __fadd_rn(carry, __shfl(incl, 63, 64));
+  }
+  wave_sync();  // cdf visible to the whole wave
+  for (int j = lane; j < Ni; j += 64) {
+    const float uj = u ? u[j] : unit_linspace(j, Ni);
+    int lo = 0, hi = nb;  // first index with cdf > u  (searchsorted right=True)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= uj) lo = mid + 1; else hi = mid;
+    }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < nb - 1 ? lo : nb - 1;
+    const float c0 = cdf[below], c1 = cdf[above];
+    float den = __fsub_rn(c1, c0);
+    if (den < 1e-5f) den = 1.f;
+    const float t = __fsub_rn(uj, c0) / den;
+    out[j] = __fadd_rn(bins[below], __fmul_rn(t, __fsub_rn(bins[above], bins[below])));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ standalone stage kernels
+__global__ __launch_bounds__(256) void coarse_weights_kernel(const float* __restrict__ sigma, const float* __restrict__ z,
+                                                             size_t n, int N, float* __restrict__ weights) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* s_sig = sm + size_t(wave) * 3 * N;
+  float* s_z = s_sig + N;
+  float* s_w = s_z + N;
+  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < n; ray += size_t(gridDim.x) * 4) {
+    for (int i = lane; i < N; i += 64) { s_sig[i] = sigma[ray * N + i]; s_z[i] = z[ray * N + i]; }
+    wave_sync();
+    ray_coarse_weights(s_sig, s_z, N, s_w, lane);
+    wave_sync();
+    for (int i = lane; i < N; i += 64) weights[ray * N + i] = s_w[i];
+    wave_sync();
+  }
+}
+hipError_t launch_coarse_weights(const float* sigma, const float* z, size_t n, int N, float* weights,
+                                 hipStream_t stream) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(coarse_weights_kernel, dim3(grid_for((n + 3) / 4, 1)), dim3(256), size_t(4) * 3 * N * 4, stream,
+                     sigma, z, n, N, weights);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ wts,
+                                                         size_t n, int nb, int Ni, const float* __restrict__ u,
+                                                         float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = 3 * nb + 2 * Ni;
+  float* s_bins = sm + size_t(wave) * per;
+  float* s_w = s_bins + nb;
+  float* s_cdf = s_w + nb;
+  float* s_u = s_cdf + nb;
+  float* s_out = s_u + Ni;
+  for (size_t row = size_t(blockIdx.x) * 4 + wave; row < n; row += size_t(gridDim.x) * 4) {
+    for (int i = lane; i < nb; i += 64) s_bins[i] = bins[row * nb + i];
+    for (int i = lane; i < nb - 1; i += 64) s_w[i] = wts[row * (nb - 1) + i];
+    if (u) for (int i = lane; i < Ni; i += 64) s_u[i] = u[row * Ni + i];
+    wave_sync();
+    ray_sample_pdf(s_bins, s_w, nb, s_cdf, u ? s_u : nullptr, Ni, s_out, lane);
+    wave_sync();
+    for (int i = lane; i < Ni; i += 64) out[row * Ni + i] = s_out[i];
+    wave_sync();
+  }
+}
+hipError_t launch_sample_pdf(const float* bins, const float* weights, size_t n, int nb, int Ni, const float* u,
+                             float* out, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(sample_pdf_kernel, dim3(grid_for((n + 3) / 4, 1)), dim3(256), size_t(4) * (3 * nb + 2 * Ni) * 4,
+                     stream, bins, weights, n, nb, Ni, u, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ fused sampler
+// sigma [R,Nc] -> z_fine [R,Nc+Ni]: coarse weights over the linspace depths, z_mid bins,
+// sample_pdf(det) on the interior weights, then an exact sort of cat([z, z_samples]) by counting
+// ranks (ties broken by position, so the result is a permutation whatever the inputs).
+__global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ sigma, size_t n_rays, int Nc, int Ni,
+                                                          float near, float far, float* __restrict__ z_fine,
+                                                          float* __restrict__ weights_out, float* __restrict__ zs_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Nf = Nc + Ni;
+  const int NfP = (Nf + 3) & ~3;
+  const int per = (4 * Nc + NfP + Nf + 3) & ~3;
+  float* s_sig = sm + size_t(wave) * per;   // [Nc]
+  float* s_w = s_sig + Nc;                  // [Nc]
+  float* s_mid = s_w + Nc;                  // [Nc]  (Nc-1 used)
+  float* s_cdf = s_mid + Nc;                // [Nc]
+  float* s_all = s_cdf + Nc;                // [NfP]  cat([z, z_samples]), 16-byte aligned
+  float* s_out = s_all + NfP;               // [Nf]
+  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < n_rays; ray += size_t(gridDim.x) * 4) {
+    for (int i = lane; i < Nc; i += 64) {
+      s_sig[i] = sigma[ray * Nc + i];
+      s_all[i] = coarse_z_at(i, Nc, near, far);
+    }
+    for (int i = Nf + lane; i < NfP; i += 64) s_all[i] = __builtin_inff();
+    wave_sync();
+    ray_coarse_weights(s_sig, s_all, Nc, s_w, lane);
+    for (int i = lane; i < Nc - 1; i += 64) s_mid[i] = __fmul_rn(.5f, __fadd_rn(s_all[i + 1], s_all[i]));
+    wave_sync();
+    ray_sample_pdf(s_mid, s_w + 1, Nc - 1, s_cdf, nullptr, Ni, s_all + Nc, lane);
+    wave_sync();
+    if (weights_out) for (int i = lane; i < Nc; i += 64) weights_out[ray * Nc + i] = s_w[i];
+    if (zs_out) for (int i = lane; i < Ni; i += 64) zs_out[ray * Ni + i] = s_all[Nc + i];
+    // rank sort
+    for (int i = lane; i < Nf; i += 64) {
+      const float v = s_all[i];
+      int rank = 0;
+      for (int j = 0; j < NfP; j += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(s_all + j);
+        rank += (q.x < v || (q.x == v && j < i)) ? 1 : 0;
+        rank += (q.y < v || (q.y == v && j + 1 < i)) ? 1 : 0;
+        rank += (q.z < v || (q.z == v && j + 2 < i)) ? 1 : 0;
+        rank += (q.w < v || (q.w == v && j + 3 < i)) ? 1 : 0;
+      }
+      s_out[rank] = v;
+    }
+    wave_sync();
+    for (int i = lane; i < Nf; i += 64) z_fine[ray * Nf + i] = s_out[i];
+    wave_sync();
+  }
+}
+hipError_t launch_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
+                              float* z_fine, float* weights_coarse, float* z_samples, hipStream_t stream) {
+  if (!n_rays) return hipSuccess;
+  const int Nf = Nc + Ni, NfP = (Nf + 3) & ~3;
+  int per = 4 * Nc + NfP + Nf;
+  per = (per + 3) & ~3;
+  hipLaunchKernelGGL(sample_fine_kernel, dim3(grid_for((n_rays + 3) / 4, 1)), dim3(256), size_t(4) * per * 4, stream,
+                     sigma, n_rays, Nc, Ni, near, far, z_fine, weights_coarse, z_samples);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ compositing
+// One wave per ray, SPL consecutive samples per lane (rendering.py:144-243, fine branch).
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_fine_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                             size_t n_rays, int Nf, float beta_min, int flags,
+                                                             float* __restrict__ rgb, float* __restrict__ disp,
+                                                             float* __restrict__ acc, float* __restrict__ depth,
+                                                             float* __restrict__ weights, float* __restrict__ beta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool static_depth = (flags & 1) && (flags & 2);  // test_time && static_only
+  const bool white = flags & 4;
+  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < n_rays; ray += size_t(gridDim.x) * 4) {
+    const float* rr = raw + ray * size_t(Nf) * 9;
+    const float* zr = z + ray * size_t(Nf);
+    float v[SPL][9], zz[SPL + 1];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int i = lane * SPL + k;
+      zz[k] = i < Nf ? zr[i] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) v[k][c] = i < Nf ? rr[size_t(i) * 9 + c] : 0.f;
+    }
+    zz[SPL] = __shfl_down(zz[0], 1, 64);
+    float a_s[SPL], a_t[SPL], a_j[SPL];
+    float pj = 1.f, ps = 1.f;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int i = lane * SPL + k;
+      const float delta = i + 1 < Nf ? __fsub_rn(zz[k + 1], zz[k]) : 1e2f;
+      const bool ok = i < Nf;
+      a_s[k] = ok ? __fsub_rn(1.f, expf(-__fmul_rn(delta, v[k][3]))) : 0.f;
+      a_t[k] = ok ? __fsub_rn(1.f, expf(-__fmul_rn(delta, v[k][7]))) : 0.f;
+      a_j[k] = ok ? __fsub_rn(1.f, expf(-__fmul_rn(delta, __fadd_rn(v[k][3], v[k][7])))) : 0.f;
+      pj = __fmul_rn(pj, __fsub_rn(1.f, a_j[k]));
+      ps = __fmul_rn(ps, __fsub_rn(1.f, a_s[k]));
+    }
+    float Tj = __shfl_up(wave_incl_prod(pj, lane), 1, 64);
+    float Ts = __shfl_up(wave_incl_prod(ps, lane), 1, 64);
+    if (lane == 0) { Tj = 1.f; Ts = 1.f; }
+    float s_rgb[3] = {0.f, 0.f, 0.f}, s_acc = 0.f, s_depth = 0.f, s_beta = 0.f;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int i = lane * SPL + k;
+      const float ws = __fmul_rn(a_s[k], Tj), wt = __fmul_rn(a_t[k], Tj), wj = __fmul_rn(a_j[k], Tj);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s_rgb[c] += __fmul_rn(ws, v[k][c]) + __fmul_rn(wt, v[k][4 + c]);
+      s_acc += wj;
+      s_beta += __fmul_rn(wt, v[k][8]);
+      s_depth += static_depth ? __fmul_rn(__fmul_rn(a_s[k], Ts), zz[k]) : __fmul_rn(wj, zz[k]);
+      if (weights && i < Nf) weights[ray * size_t(Nf) + i] = wj;
+      Tj = __fmul_rn(Tj, __fsub_rn(1.f, a_j[k]));
+      Ts = __fmul_rn(Ts, __fsub_rn(1.f, a_s[k]));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s_rgb[c] = wave_sum(s_rgb[c]);
+    s_acc = wave_sum(s_acc);
+    s_depth = wave_sum(s_depth);
+    s_beta = wave_sum(s_beta);
+    if (lane == 0) {
+      const float bg = white ? 1.f - s_acc : 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb[ray * 3 + c] = s_rgb[c] + bg;
+      disp[ray] = 1.f / fmaxf(1e-10f, s_depth / s_acc);
+      acc[ray] = s_acc;
+      if (depth) depth[ray] = s_depth;
+      if (beta) beta[ray] = s_beta + beta_min;
+    }
+  }
+}
+
+hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays, int Nf, float beta_min, int flags,
+                                 float* rgb, float* disp, float* acc, float* depth, float* weights, float* beta,
+                                 hipStream_t stream) {
+  if (!n_rays) return hipSuccess;
+  const int spl = (Nf + 63) / 64;
+  const dim3 grid(grid_for((n_rays + 3) / 4, 1, 256 * 16)), block(256);
+#define DFN_COMP(S)                                                                                              \
+  hipLaunchKernelGGL(composite_fine_kernel<S>, grid, block, 0, stream, raw, z, n_rays, Nf, beta_min, flags, rgb, \
+                     disp, acc, depth, weights, beta)
+  if (spl <= 1) DFN_COMP(1);
+  else if (spl == 2) DFN_COMP(2);
+  else if (spl == 3) DFN_COMP(3);
+  else if (spl == 4) DFN_COMP(4);
+  else if (spl <= 6) DFN_COMP(6);
+  else if (spl <= 8) DFN_COMP(8);
+  else return hipErrorInvalidValue;
+#undef DFN_COMP
+  return hipGetLastError();
+}
+
+}  // namespace dfn

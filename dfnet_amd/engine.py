@@ -1,0 +1,193 @@
+"""NerfHEngine — host-side owner of a `dfn_nerfh_t` handle and thin tensor-level wrappers of the
+stage and whole-path entry points of libdfnet_hip.so.
+
+All tensors are fp32 CUDA tensors owned by torch (device memory + streams are torch's job; the
+arithmetic is the HIP library's).  Work is enqueued on torch's current stream.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+
+def _f32c(t):
+    return t.contiguous().float()
+
+
+class NerfHEngine:
+    """NeRF-H coarse+fine networks resident on one GPU in MFMA-fragment layout."""
+
+    def __init__(self, depth=8, width=128, multires=10, multires_views=4, hist_bin=10, dim_a=5, dim_t=2,
+                 n_vocab=1000, precision="f16"):
+        self.lib = _lib.load()
+        self.desc = _lib.NerfhDesc(depth, width, multires, multires_views, hist_bin, dim_a, dim_t, n_vocab)
+        self.handle = ctypes.c_void_p()
+        check(self.lib.dfn_nerfh_create(ctypes.byref(self.desc), ctypes.byref(self.handle)), "dfn_nerfh_create")
+        self.precision = precision
+        self.hist_bin = hist_bin
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.dfn_nerfh_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_numpy(self, coarse, fine, emb_a, emb_t):
+        """coarse/fine: {state_dict key: ndarray}; emb_a/emb_t: ndarrays."""
+        items = [("coarse." + k, v) for k, v in coarse.items()] + [("fine." + k, v) for k, v in fine.items()]
+        items += [("embedding_a.weight", emb_a), ("embedding_t.weight", emb_t)]
+        for name, arr in items:
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            check(self.lib.dfn_nerfh_set_param(self.handle, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
+                  f"dfn_nerfh_set_param({name})")
+        check(self.lib.dfn_nerfh_commit(self.handle), "dfn_nerfh_commit")
+        return self
+
+    def load_modules(self, network_fn, network_fine, embedding_a, embedding_t):
+        """Take the weights of torch modules with the reference's state_dict layout."""
+        sd = lambda m: {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        return self.load_numpy(sd(network_fn), sd(network_fine), embedding_a.weight.detach().cpu().numpy(),
+                               embedding_t.weight.detach().cpu().numpy())
+
+    def _prec(self, precision):
+        return _lib.PRECISIONS[precision or self.precision]
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ------------------------------------------------------------------ stages
+    def mlp_coarse(self, rays_o, rays_d, Nc, near, far, precision=None):
+        rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+        n = rays_o.shape[0]
+        sigma = torch.empty(n, Nc, device=rays_o.device)
+        check(self.lib.dfn_mlp_coarse(self.handle, self._prec(precision), ptr(rays_o), ptr(rays_d), n, Nc,
+                                      float(near), float(far), ptr(sigma), current_stream()), "dfn_mlp_coarse")
+        return sigma
+
+    def mlp_fine(self, rays_o, rays_d, viewdirs, hist, z_fine, precision=None):
+        rays_o, rays_d, viewdirs, z_fine = _f32c(rays_o), _f32c(rays_d), _f32c(viewdirs), _f32c(z_fine)
+        hist = _f32c(hist).reshape(-1, self.hist_bin)
+        n, Nf = z_fine.shape
+        raw = torch.empty(n, Nf, 9, device=rays_o.device)
+        bias = torch.empty(self.lib.dfn_fine_bias_bytes(n), dtype=torch.uint8, device=rays_o.device)
+        check(self.lib.dfn_mlp_fine(self.handle, self._prec(precision), ptr(rays_o), ptr(rays_d), ptr(viewdirs),
+                                    ptr(hist), hist.shape[0], n, ptr(z_fine), Nf, ptr(raw),
+                                    ctypes.c_void_p(bias.data_ptr()), current_stream()), "dfn_mlp_fine")
+        return raw
+
+    # ------------------------------------------------------------------ whole path
+    def render_rays(self, rays_o, rays_d, hist, Nc, Ni, near, far, viewdirs=None, retraw=False, precision=None):
+        """Test-time render of a ray batch -> (rgb [n,3], disp [n], acc [n], raw|None)."""
+        rays_o, rays_d = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3)
+        n = rays_o.shape[0]
+        dev = rays_o.device
+        hist = _f32c(hist).reshape(-1, self.hist_bin)
+        if viewdirs is not None:
+            viewdirs = _f32c(viewdirs).reshape(-1, 3)
+        rgb = torch.empty(n, 3, device=dev)
+        disp = torch.empty(n, device=dev)
+        acc = torch.empty(n, device=dev)
+        raw = torch.empty(n, Nc + Ni, 9, device=dev) if retraw else None
+        nbytes = self.lib.dfn_render_workspace_bytes(n, Nc, Ni)
+        ws = self._workspace(nbytes, dev)
+        check(self.lib.dfn_render_rays(self.handle, self._prec(precision), ptr(rays_o), ptr(rays_d), ptr(viewdirs),
+                                       ptr(hist), hist.shape[0], n, Nc, Ni, float(near), float(far), ptr(rgb),
+                                       ptr(disp), ptr(acc), ptr(raw), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                       current_stream()), "dfn_render_rays")
+        return rgb, disp, acc, raw
+
+    def render_image(self, c2w, H, W, focal, hist, Nc, Ni, near, far, precision=None, out=None):
+        """Test-time render of a full image from a [3,4] (or [4,4]) c2w -> (rgb [H,W,3], disp, acc [H,W])."""
+        c2w = _f32c(c2w)[:3, :4].contiguous()
+        dev = c2w.device
+        hist = _f32c(hist).reshape(-1)[: self.hist_bin].contiguous()
+        if out is None:
+            out = (torch.empty(H, W, 3, device=dev), torch.empty(H, W, device=dev), torch.empty(H, W, device=dev))
+        rgb, disp, acc = out
+        nbytes = self.lib.dfn_render_workspace_bytes(H * W, Nc, Ni)
+        ws = self._workspace(nbytes, dev)
+        check(self.lib.dfn_render_image(self.handle, self._prec(precision), ptr(c2w), H, W, float(focal), float(near),
+                                        float(far), Nc, Ni, ptr(hist), ptr(rgb), ptr(disp), ptr(acc),
+                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
+              "dfn_render_image")
+        return rgb, disp, acc
+
+
+# ---------------------------------------------------------------------- weight-free stage wrappers
+def raygen(H, W, focal, c2w, want_viewdirs=True):
+    lib = _lib.load()
+    c2w = _f32c(c2w)[:3, :4].contiguous()
+    dev = c2w.device
+    o = torch.empty(H, W, 3, device=dev)
+    d = torch.empty(H, W, 3, device=dev)
+    v = torch.empty(H, W, 3, device=dev) if want_viewdirs else None
+    check(lib.dfn_raygen(H, W, float(focal), ptr(c2w), ptr(o), ptr(d), ptr(v), current_stream()), "dfn_raygen")
+    return o, d, v
+
+
+def posenc(x, L, fast=False):
+    lib = _lib.load()
+    x = _f32c(x).reshape(-1, 3)
+    out = torch.empty(x.shape[0], 3 + 6 * L, device=x.device)
+    check(lib.dfn_posenc(ptr(x), x.shape[0], L, 1 if fast else 0, ptr(out), current_stream()), "dfn_posenc")
+    return out
+
+
+def coarse_weights(sigma, z):
+    lib = _lib.load()
+    sigma, z = _f32c(sigma), _f32c(z)
+    w = torch.empty_like(sigma)
+    check(lib.dfn_coarse_weights(ptr(sigma), ptr(z), sigma.shape[0], sigma.shape[1], ptr(w), current_stream()),
+          "dfn_coarse_weights")
+    return w
+
+
+def sample_pdf(bins, weights, Ni, u=None):
+    lib = _lib.load()
+    bins, weights = _f32c(bins), _f32c(weights)
+    if u is not None:
+        u = _f32c(u)
+    out = torch.empty(bins.shape[0], Ni, device=bins.device)
+    check(lib.dfn_sample_pdf(ptr(bins), ptr(weights), bins.shape[0], bins.shape[1], Ni, ptr(u), ptr(out),
+                             current_stream()), "dfn_sample_pdf")
+    return out
+
+
+def sample_fine(sigma, Ni, near, far, want_aux=False):
+    lib = _lib.load()
+    sigma = _f32c(sigma)
+    n, Nc = sigma.shape
+    z = torch.empty(n, Nc + Ni, device=sigma.device)
+    w = torch.empty(n, Nc, device=sigma.device) if want_aux else None
+    zs = torch.empty(n, Ni, device=sigma.device) if want_aux else None
+    check(lib.dfn_sample_fine(ptr(sigma), n, Nc, Ni, float(near), float(far), ptr(z), ptr(w), ptr(zs),
+                              current_stream()), "dfn_sample_fine")
+    return (z, w, zs) if want_aux else z
+
+
+def composite_fine(raw, z, beta_min=0.1, test_time=True, static_only=True, white_bkgd=False, want_aux=False):
+    lib = _lib.load()
+    raw, z = _f32c(raw), _f32c(z)
+    n, Nf = z.shape
+    dev = raw.device
+    rgb, disp, acc = torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+    depth = torch.empty(n, device=dev) if want_aux else None
+    w = torch.empty(n, Nf, device=dev) if want_aux else None
+    beta = torch.empty(n, device=dev) if want_aux else None
+    flags = (_lib.COMP_TEST_TIME if test_time else 0) | (_lib.COMP_STATIC_ONLY if static_only else 0) | \
+            (_lib.COMP_WHITE_BKGD if white_bkgd else 0)
+    check(lib.dfn_composite_fine(ptr(raw), ptr(z), n, Nf, float(beta_min), flags, ptr(rgb), ptr(disp), ptr(acc),
+                                 ptr(depth), ptr(w), ptr(beta), current_stream()), "dfn_composite_fine")
+    out = dict(rgb=rgb, disp=disp, acc=acc)
+    if want_aux:
+        out.update(depth=depth, weights=w, beta=beta)
+    return out

@@ -1,0 +1,152 @@
+/*
+ * dfnet_hip.h — C ABI of libdfnet_hip.so: the MI355X (gfx950) implementation of DFNet's
+ * NeRF-H volumetric-rendering hot path and DFNet feature-extractor forward.
+ *
+ * The reference (ActiveVisionLab/DFNet) has no FFI for this path — it sits behind plain
+ * Python functions — so every entry point below names the reference function (file:line,
+ * relative to /root/reference/script/) whose arithmetic it replaces.  INTEGRATION.md
+ * shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - flat extern "C", opaque handles, int status (0 = DFN_OK, negative = error; text via
+ *     dfn_last_error(), thread-local);
+ *   - NO ownership transfer: every data buffer is a caller-allocated DEVICE pointer
+ *     (fp32, contiguous, row-major) unless the parameter says "host";
+ *   - the caller passes its hipStream_t as `void* stream`; functions enqueue and return
+ *     (no implicit synchronisation) unless documented otherwise;
+ *   - one handle per device; a handle's methods are not re-entrant, different handles are
+ *     thread-safe.
+ */
+#ifndef DFNET_HIP_H
+#define DFNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  DFN_OK = 0,
+  DFN_ERR_ARG = -1,         /* bad argument (null pointer, size mismatch, unknown name) */
+  DFN_ERR_HIP = -2,         /* a HIP runtime call failed */
+  DFN_ERR_STATE = -3,       /* handle not committed / parameter missing */
+  DFN_ERR_UNSUPPORTED = -4  /* configuration outside what the kernels implement */
+};
+
+/* Arithmetic of the MLP / conv contractions. */
+enum {
+  DFN_PREC_F16 = 0, /* f16 MFMA inputs, fp32 accumulate (v_mfma_f32_32x32x16_f16); PE via v_sin/v_cos */
+  DFN_PREC_F32 = 1  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32); PE via full-range sinf/cosf */
+};
+
+const char* dfn_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int dfn_abi_version(void);
+
+/* ------------------------------------------------------------------ NeRF-H network handle
+ * Replaces models/nerfw.py:220-354 (class NeRFW, coarse + fine), the two histogram
+ * nn.Embedding tables (nerfw.py:385-391) and the Embedder (nerfw.py:98-133). */
+typedef struct dfn_nerfh_s* dfn_nerfh_t;
+
+typedef struct {
+  int depth;          /* args.netdepth        (8)    */
+  int width;          /* args.netwidth        (128)  */
+  int multires;       /* args.multires        (10)   */
+  int multires_views; /* args.multires_views  (4)    */
+  int hist_bin;       /* args.hist_bin        (10)   */
+  int dim_a;          /* per-bin appearance dim (5): in_channels_a = hist_bin*dim_a */
+  int dim_t;          /* per-bin transient dim  (2): in_channels_t = hist_bin*dim_t */
+  int n_vocab;        /* args.N_vocab         (1000) */
+} dfn_nerfh_desc;
+
+int dfn_nerfh_create(const dfn_nerfh_desc* desc, dfn_nerfh_t* out);
+int dfn_nerfh_destroy(dfn_nerfh_t h);
+/* Set one parameter from a HOST fp32 buffer.  `name` is "<net>.<state_dict key>" with
+ * <net> in {coarse, fine} (keys of nerfw.py:259-295, e.g. "fine.xyz_encoding_5.0.weight"),
+ * or "embedding_a.weight" / "embedding_t.weight". */
+int dfn_nerfh_set_param(dfn_nerfh_t h, const char* name, const float* host, size_t numel);
+/* Pack all parameters into the MFMA fragment layouts and upload them (synchronous). */
+int dfn_nerfh_commit(dfn_nerfh_t h);
+
+/* ------------------------------------------------------------------ stage-level entry points
+ * (each is the production kernel of that stage; exposed so parity tests can check a stage
+ *  against the oracle in isolation) */
+
+/* models/ray_utils.py:5-15 get_rays + rendering.py:366-371 viewdirs.  c2w: device [3,4]
+ * row-major (12 floats).  Outputs [H*W,3] each; viewdirs may be NULL. */
+int dfn_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
+               float* viewdirs, void* stream);
+
+/* models/nerfw.py:105-133 Embedder.embed.  x [n,3] -> out [n, 3+6L].  mode 0 = full-range
+ * sinf/cosf, 1 = the fast v_sin/v_cos path the f16 MLP kernels use. */
+int dfn_posenc(const float* x, size_t n, int L, int mode, float* out, void* stream);
+
+/* Coarse test-time query: rendering.py:269-292 (z, pts) + nerfw.py:37-46,315-334 (PE + trunk
+ * + static_sigma/Softplus).  sigma [n_rays, Nc]. */
+int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d,
+                   size_t n_rays, int Nc, float near, float far, float* sigma, void* stream);
+
+/* rendering.py:161-193 coarse alpha/weights.  sigma, z [n, N] -> weights [n, N]. */
+int dfn_coarse_weights(const float* sigma, const float* z, size_t n, int N, float* weights,
+                       void* stream);
+
+/* rendering.py:24-65 sample_pdf.  bins [n, nb], weights [n, nb-1] -> out [n, Ni].  u NULL =
+ * deterministic linspace(0,1,Ni); else u [n, Ni] are the uniform draws. */
+int dfn_sample_pdf(const float* bins, const float* weights, size_t n, int nb, int Ni,
+                   const float* u, float* out, void* stream);
+
+/* Fused production sampler: rendering.py:295-304 — coarse weights of sigma over the
+ * linspace z, z_mid, sample_pdf(det) on the interior weights, merge/sort with the coarse z.
+ * z_fine [n_rays, Nc+Ni]; weights_coarse / z_samples optional (may be NULL). */
+int dfn_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
+                    float* z_fine, float* weights_coarse, float* z_samples, void* stream);
+
+/* Fine query: rendering.py:305-313 + nerfw.py:62-95,297-354.  hist [hist_rows, hist_bin]
+ * (float-valued indices; hist_rows is 1 = one image for all rays, or n_rays); raw
+ * [n_rays, Nf, 9]; `bias_ws` is scratch of dfn_fine_bias_bytes(n_rays) bytes. */
+size_t dfn_fine_bias_bytes(size_t n_rays);
+int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d,
+                 const float* viewdirs, const float* hist, size_t hist_rows, size_t n_rays,
+                 const float* z_fine, int Nf, float* raw, void* bias_ws, void* stream);
+
+/* rendering.py:144-243 raw2outputs_NeRFW, typ="fine", output_transient=True.
+ * flags: bit0 test_time, bit1 static_only, bit2 white_bkgd.  rgb [n,3], disp/acc [n];
+ * depth, weights [n,Nf], beta optional (NULL to skip). */
+enum { DFN_COMP_TEST_TIME = 1, DFN_COMP_STATIC_ONLY = 2, DFN_COMP_WHITE_BKGD = 4 };
+int dfn_composite_fine(const float* raw, const float* z, size_t n_rays, int Nf, float beta_min,
+                       int flags, float* rgb, float* disp, float* acc, float* depth,
+                       float* weights, float* beta, void* stream);
+
+/* ------------------------------------------------------------------ whole-path entry points */
+
+/* Scratch needed by dfn_render_rays / dfn_render_image for up to n_rays rays. */
+size_t dfn_render_workspace_bytes(size_t n_rays, int Nc, int Ni);
+
+/* rendering.py:245-337 render_rays at test time (perturb=0, raw_noise_std=0, lindisp=False,
+ * white_bkgd=False, test_time=True) over caller-provided rays (rendering.py:361-362).
+ * viewdirs may be NULL (computed as d/|d|, rendering.py:366-371).  raw (optional)
+ * [n_rays, Nc+Ni, 9] is the `retraw` output. */
+int dfn_render_rays(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d,
+                    const float* viewdirs, const float* hist, size_t hist_rows, size_t n_rays,
+                    int Nc, int Ni, float near, float far, float* rgb, float* disp, float* acc,
+                    float* raw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* rendering.py:353-400 render(c2w=...) at test time: get_rays + the above for a full H x W
+ * image.  c2w device [3,4]; hist device [hist_bin]; rgb [H,W,3], disp/acc [H,W]. */
+int dfn_render_image(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, float focal,
+                     float near, float far, int Nc, int Ni, const float* hist, float* rgb,
+                     float* disp, float* acc, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Timing aid for bench.py: average device time in ms of the `which` kernel
+ * (0 = coarse MLP, 1 = fine MLP) over the launches since the last reset, measured with HIP
+ * events on `stream`.  Enabled by dfn_profile_enable(1); costs a sync when read. */
+int dfn_profile_enable(int on);
+int dfn_profile_read(int which, double* avg_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFNET_HIP_H */
