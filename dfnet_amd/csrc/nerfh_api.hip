@@ -452,14 +452,20 @@ extern "C" int dfn_composite_fine(const float* raw, const float* z, size_t n_ray
 
 // ------------------------------------------------------------------------------------------ whole path
 namespace {
-constexpr size_t kChunkRays = 65536;  // rays per internal pass (bounds the raw buffer)
+constexpr size_t kMaxChunkRays = 65536;  // rays per internal pass (bounds the raw buffer)
 inline size_t al(size_t b) { return (b + 255) & ~size_t(255); }
+// Equal passes of at most kMaxChunkRays rays (multiple of 64 rays so MLP tiles stay aligned).
+inline size_t chunk_rays(size_t n_rays) {
+  const size_t passes = (n_rays + kMaxChunkRays - 1) / kMaxChunkRays;
+  const size_t c = passes ? (n_rays + passes - 1) / passes : 1;
+  return (c + 63) & ~size_t(63);
+}
 struct Workspace {
   float *o, *d, *v, *sigma, *z, *raw, *bias;
   size_t total;
 };
 Workspace carve(char* base, size_t n_rays, int Nc, int Ni, bool own_rays) {
-  const size_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+  const size_t chunk = chunk_rays(n_rays);
   const size_t Nf = size_t(Nc) + Ni;
   Workspace w{};
   size_t off = 0;
@@ -482,8 +488,9 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
   const PackedNet& nc = h->net[0][prec];
   const PackedNet& nf = h->net[1][prec];
   const int cus = device_cu_count();
-  for (size_t r0 = 0; r0 < n_rays; r0 += kChunkRays) {
-    const size_t n = n_rays - r0 < kChunkRays ? n_rays - r0 : kChunkRays;
+  const size_t chunk = chunk_rays(n_rays);
+  for (size_t r0 = 0; r0 < n_rays; r0 += chunk) {
+    const size_t n = n_rays - r0 < chunk ? n_rays - r0 : chunk;
     const float* co = o + r0 * 3;
     const float* cd = d + r0 * 3;
     const float* cv = v + r0 * 3;

@@ -6,16 +6,45 @@ namespace dfn {
 
 #define DFN_DEV __device__ __forceinline__
 
+// ---- uncontracted fp32 arithmetic ---------------------------------------------------------------
+// hipcc contracts a*b+c into an FMA by default and HIP's __fmul_rn/__fadd_rn do not stop it; these do
+// (the pragma removes the `contract` flag from the instruction itself, which survives inlining).
+// Used wherever the reference's op-by-op rounding is reproduced (depths, rays, sampling, compositing).
+DFN_DEV float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+DFN_DEV float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+DFN_DEV float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 // ---- linspace / coarse depths ---------------------------------------------------------------
-// torch.linspace(0, 1, n)[i]: CPU/GPU kernels fill symmetrically from both ends.
+// torch.linspace(0, 1, n)[i]: torch fills symmetrically from both ends, and its upper half
+// `end - step*(n-1-i)` is compiled to ONE fused multiply-add (verified against torch CPU for
+// n = 5..192: the fused form matches bit for bit, the unfused one does not).
 DFN_DEV float unit_linspace(int i, int n) {
   const float step = n > 1 ? 1.f / float(n - 1) : 0.f;
-  return i < n / 2 ? __fmul_rn(step, float(i)) : __fsub_rn(1.f, __fmul_rn(step, float(n - 1 - i)));
+  return i < n / 2 ? mul_rn(step, float(i)) : fmaf(-step, float(n - 1 - i), 1.f);
 }
 // z = near*(1-t) + far*t without FMA contraction (reference: models/rendering.py:269-271).
 DFN_DEV float coarse_z_at(int i, int n, float near, float far) {
   const float t = unit_linspace(i, n);
-  return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
+  return add_rn(mul_rn(near, sub_rn(1.f, t)), mul_rn(far, t));
+}
+
+// ---- view direction -----------------------------------------------------------------------------
+// v = d / |d| with every operation correctly rounded and uncontracted, so that every kernel that
+// derives a view direction from the same d produces the same bits (rendering.py:366-371).
+DFN_DEV void normalize3(float x, float y, float z, float& vx, float& vy, float& vz) {
+  const float n = __fsqrt_rn(add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z)));
+  vx = __fdiv_rn(x, n);
+  vy = __fdiv_rn(y, n);
+  vz = __fdiv_rn(z, n);
 }
 
 // ---- positional-encoding trig -----------------------------------------------------------------

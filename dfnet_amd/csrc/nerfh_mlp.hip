@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void nerfh_coarse_kernel(MlpArgs a) {
       const float z = coarse_z_at(i, a.n_samples, a.near, a.far);
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        x[nb][c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], z));
+        x[nb][c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], z));
     }
     F hid[NB][chunks_of<P>(64)];
     trunk<P, FAST, NB>(st, smem, x, hid);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void nerfh_fine_kernel(MlpArgs a) {
       const float z = a.z[q];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        x[nb][c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], z));
+        x[nb][c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], z));
       rb_dir[nb] = a.ray_bias + ray * kRayBiasFloats;
       rb_tr[nb] = rb_dir[nb] + kRayBiasFloats / 2;
     }

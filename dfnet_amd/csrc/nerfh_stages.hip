@@ -43,13 +43,14 @@ __global__ __launch_bounds__(256) void raygen_kernel(int H, int W, float focal, 
     float d[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)  // sum over the camera axis, left to right, no FMA (ray_utils.py:12)
-      d[a] = __fadd_rn(__fadd_rn(__fmul_rn(dx, R[a][0]), __fmul_rn(dy, R[a][1])), __fmul_rn(-1.f, R[a][2]));
-    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+      d[a] = add_rn(add_rn(mul_rn(dx, R[a][0]), mul_rn(dy, R[a][1])), mul_rn(-1.f, R[a][2]));
+    float vd[3];
+    normalize3(d[0], d[1], d[2], vd[0], vd[1], vd[2]);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       rays_o[px * 3 + a] = t[a];
       rays_d[px * 3 + a] = d[a];
-      if (viewdirs) viewdirs[px * 3 + a] = d[a] / nrm;
+      if (viewdirs) viewdirs[px * 3 + a] = vd[a];
     }
   }
 }
@@ -64,9 +65,7 @@ hipError_t launch_raygen(int H, int W, float focal, const float* c2w, float* ray
 
 __global__ __launch_bounds__(256) void viewdirs_kernel(const float* __restrict__ d, size_t n, float* __restrict__ v) {
   for (size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x; r < n; r += size_t(gridDim.x) * blockDim.x) {
-    const float x = d[r * 3], y = d[r * 3 + 1], z = d[r * 3 + 2];
-    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
-    v[r * 3] = x / nrm; v[r * 3 + 1] = y / nrm; v[r * 3 + 2] = z / nrm;
+    normalize3(d[r * 3], d[r * 3 + 1], d[r * 3 + 2], v[r * 3], v[r * 3 + 1], v[r * 3 + 2]);
   }
 }
 hipError_t launch_viewdirs(const float* rays_d, size_t n, float* viewdirs, hipStream_t stream) {
@@ -184,14 +183,14 @@ DFN_DEV void ray_coarse_weights(const float* sig, const float* z, int N, float* 
     const int i = c0 + lane;
     float alpha = 0.f;
     if (i < N) {
-      const float delta = i + 1 < N ? __fsub_rn(z[i + 1], z[i]) : 1e2f;
-      alpha = __fsub_rn(1.f, expf(-__fmul_rn(delta, fmaxf(sig[i], 0.f))));
+      const float delta = i + 1 < N ? sub_rn(z[i + 1], z[i]) : 1e2f;
+      alpha = sub_rn(1.f, expf(-mul_rn(delta, fmaxf(sig[i], 0.f))));
     }
-    const float incl = wave_incl_prod(__fsub_rn(1.f, alpha), lane);
+    const float incl = wave_incl_prod(sub_rn(1.f, alpha), lane);
     float excl = __shfl_up(incl, 1, 64);
     if (lane == 0) excl = 1.f;
-    if (i < N) w[i] = __fmul_rn(alpha, __fmul_rn(carry, excl));
-    carry = __fmul_rn(carry, __shfl(incl, 63, 64));
+    if (i < N) w[i] = mul_rn(alpha, mul_rn(carry, excl));
+    carry = mul_rn(carry, __shfl(incl, 63, 64));
   }
 }
 
@@ -201,16 +200,16 @@ DFN_DEV void ray_sample_pdf(const float* bins, const float* wts, int nb, float* 
                             float* out, int lane) {
   const int nw = nb - 1;
   float part = 0.f;
-  for (int i = lane; i < nw; i += 64) part += __fadd_rn(wts[i], 1e-5f);
+  for (int i = lane; i < nw; i += 64) part += add_rn(wts[i], 1e-5f);
   const float total = wave_sum(part);
   float carry = 0.f;
   if (lane == 0) cdf[0] = 0.f;
   for (int c0 = 0; c0 < nw; c0 += 64) {
     const int i = c0 + lane;
-    const float pdf = i < nw ? __fadd_rn(wts[i], 1e-5f) / total : 0.f;
+    const float pdf = i < nw ? add_rn(wts[i], 1e-5f) / total : 0.f;
     const float incl = wave_incl_sum(pdf, lane);
-    if (i < nw) cdf[i + 1] = __fadd_rn(carry, incl);
-    carry = __fadd_rn(carry, __shfl(incl, 63, 64));
+    if (i < nw) cdf[i + 1] = add_rn(carry, incl);
+    carry = add_rn(carry, __shfl(incl, 63, 64));
   }
   wave_sync();  // cdf visible to the whole wave
   for (int j = lane; j < Ni; j += 64) {
@@ -223,10 +222,10 @@ DFN_DEV void ray_sample_pdf(const float* bins, const float* wts, int nb, float* 
     const int below = lo - 1 > 0 ? lo - 1 : 0;
     const int above = lo < nb - 1 ? lo : nb - 1;
     const float c0 = cdf[below], c1 = cdf[above];
-    float den = __fsub_rn(c1, c0);
+    float den = sub_rn(c1, c0);
     if (den < 1e-5f) den = 1.f;
-    const float t = __fsub_rn(uj, c0) / den;
-    out[j] = __fadd_rn(bins[below], __fmul_rn(t, __fsub_rn(bins[above], bins[below])));
+    const float t = sub_rn(uj, c0) / den;
+    out[j] = add_rn(bins[below], mul_rn(t, sub_rn(bins[above], bins[below])));
   }
 }
 
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     for (int i = Nf + lane; i < NfP; i += 64) s_all[i] = __builtin_inff();
     wave_sync();
     ray_coarse_weights(s_sig, s_all, Nc, s_w, lane);
-    for (int i = lane; i < Nc - 1; i += 64) s_mid[i] = __fmul_rn(.5f, __fadd_rn(s_all[i + 1], s_all[i]));
+    for (int i = lane; i < Nc - 1; i += 64) s_mid[i] = mul_rn(.5f, add_rn(s_all[i + 1], s_all[i]));
     wave_sync();
     ray_sample_pdf(s_mid, s_w + 1, Nc - 1, s_cdf, nullptr, Ni, s_all + Nc, lane);
     wave_sync();
@@ -374,13 +373,13 @@ __global__ __launch_bounds__(256) void composite_fine_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
       const int i = lane * SPL + k;
-      const float delta = i + 1 < Nf ? __fsub_rn(zz[k + 1], zz[k]) : 1e2f;
+      const float delta = i + 1 < Nf ? sub_rn(zz[k + 1], zz[k]) : 1e2f;
       const bool ok = i < Nf;
-      a_s[k] = ok ? __fsub_rn(1.f, expf(-__fmul_rn(delta, v[k][3]))) : 0.f;
-      a_t[k] = ok ? __fsub_rn(1.f, expf(-__fmul_rn(delta, v[k][7]))) : 0.f;
-      a_j[k] = ok ? __fsub_rn(1.f, expf(-__fmul_rn(delta, __fadd_rn(v[k][3], v[k][7])))) : 0.f;
-      pj = __fmul_rn(pj, __fsub_rn(1.f, a_j[k]));
-      ps = __fmul_rn(ps, __fsub_rn(1.f, a_s[k]));
+      a_s[k] = ok ? sub_rn(1.f, expf(-mul_rn(delta, v[k][3]))) : 0.f;
+      a_t[k] = ok ? sub_rn(1.f, expf(-mul_rn(delta, v[k][7]))) : 0.f;
+      a_j[k] = ok ? sub_rn(1.f, expf(-mul_rn(delta, add_rn(v[k][3], v[k][7])))) : 0.f;
+      pj = mul_rn(pj, sub_rn(1.f, a_j[k]));
+      ps = mul_rn(ps, sub_rn(1.f, a_s[k]));
     }
     float Tj = __shfl_up(wave_incl_prod(pj, lane), 1, 64);
     float Ts = __shfl_up(wave_incl_prod(ps, lane), 1, 64);
@@ -389,15 +388,15 @@ __global__ __launch_bounds__(256) void composite_fine_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
       const int i = lane * SPL + k;
-      const float ws = __fmul_rn(a_s[k], Tj), wt = __fmul_rn(a_t[k], Tj), wj = __fmul_rn(a_j[k], Tj);
+      const float ws = mul_rn(a_s[k], Tj), wt = mul_rn(a_t[k], Tj), wj = mul_rn(a_j[k], Tj);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) s_rgb[c] += __fmul_rn(ws, v[k][c]) + __fmul_rn(wt, v[k][4 + c]);
+      for (int c = 0; c < 3; ++c) s_rgb[c] += mul_rn(ws, v[k][c]) + mul_rn(wt, v[k][4 + c]);
       s_acc += wj;
-      s_beta += __fmul_rn(wt, v[k][8]);
-      s_depth += static_depth ? __fmul_rn(__fmul_rn(a_s[k], Ts), zz[k]) : __fmul_rn(wj, zz[k]);
+      s_beta += mul_rn(wt, v[k][8]);
+      s_depth += static_depth ? mul_rn(mul_rn(a_s[k], Ts), zz[k]) : mul_rn(wj, zz[k]);
       if (weights && i < Nf) weights[ray * size_t(Nf) + i] = wj;
-      Tj = __fmul_rn(Tj, __fsub_rn(1.f, a_j[k]));
-      Ts = __fmul_rn(Ts, __fsub_rn(1.f, a_s[k]));
+      Tj = mul_rn(Tj, sub_rn(1.f, a_j[k]));
+      Ts = mul_rn(Ts, sub_rn(1.f, a_s[k]));
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) s_rgb[c] = wave_sum(s_rgb[c]);

@@ -1,0 +1,67 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol the header
+declares, the ctypes table matches the header, and argument errors are reported without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dfnet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "dfnet_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dfnet_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.dfn_abi_version() == 1
+
+
+def test_create_rejects_unsupported_width():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    d = _lib.NerfhDesc(8, 256, 10, 4, 10, 5, 2, 1000)
+    rc = lib.dfn_nerfh_create(ctypes.byref(d), ctypes.byref(h))
+    assert rc == -4 and b"netwidth" in lib.dfn_last_error()
+
+
+def test_set_param_validation_and_commit_needs_all_params():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    d = _lib.NerfhDesc(8, 128, 10, 4, 10, 5, 2, 1000)
+    assert lib.dfn_nerfh_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    a = np.zeros(128 * 63, np.float32)
+    p = a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.dfn_nerfh_set_param(h, b"coarse.xyz_encoding_1.0.weight", p, a.size) == 0
+    assert lib.dfn_nerfh_set_param(h, b"coarse.xyz_encoding_1.0.weight", p, 7) == -1
+    assert b"expected 8064" in lib.dfn_last_error()
+    assert lib.dfn_nerfh_set_param(h, b"coarse.nope", p, 1) == -1
+    assert lib.dfn_nerfh_commit(h) == -3 and b"not set" in lib.dfn_last_error()
+    # an uncommitted handle must refuse to run, loudly
+    assert lib.dfn_mlp_coarse(h, 0, p, p, 1, 8, 0.0, 1.0, p, None) == -3
+    assert lib.dfn_nerfh_destroy(h) == 0
+
+
+def test_workspace_size_monotone():
+    lib = _lib.load()
+    a = lib.dfn_render_workspace_bytes(1000, 64, 128)
+    b = lib.dfn_render_workspace_bytes(307200, 64, 128)
+    assert 0 < a < b < (8 << 30)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdfnet_hip.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.load()

@@ -1,0 +1,251 @@
+"""GPU parity tests of the NeRF-H render path: every call goes through the C ABI of
+libdfnet_hip.so; the checker is the CPU oracle and the golden vectors captured from the reference.
+
+Tolerances: north_star asks for 1e-3 relative fp32.  The exact-fp32 MFMA path is held to 2e-5
+(fp32 round-off), the f16-input MFMA path to 1e-3 of the output range, stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from dfnet_amd import engine as eng
+from dfnet_amd import synthetic as syn
+from oracle import nerfh_oracle as orc
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+
+
+def relmax(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert not torch.isnan(a).any()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def tt(d):
+    return {k: T(v) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module")
+def scene():
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
+    return E, tt(cw), tt(fw), T(ea), T(et)
+
+
+def dev(x):
+    return torch.as_tensor(x).float().to(DEV).contiguous()
+
+
+# ------------------------------------------------------------------ stages vs golden vectors
+def test_raygen_golden(gold):
+    g = gold("g1_get_rays")
+    o, d, v = eng.raygen(int(g["H"]), int(g["W"]), float(g["focal"]), dev(g["c2w"]))
+    assert relmax(o, g["rays_o"]) == 0 and relmax(d, g["rays_d"]) < 2e-7
+    assert relmax(v, g["rays_d"] / np.linalg.norm(g["rays_d"], axis=-1, keepdims=True)) < 3e-7
+
+
+def test_posenc_golden(gold):
+    g = gold("g2_posenc")
+    assert relmax(eng.posenc(dev(g["x"]), 10), g["pe_xyz"]) < 3e-7      # full-range sinf/cosf
+    assert relmax(eng.posenc(dev(g["d"]), 4), g["pe_dir"]) < 3e-7
+    assert relmax(eng.posenc(dev(g["x"]), 10, fast=True), g["pe_xyz"]) < 2e-6  # v_sin/v_cos path of the f16 kernel
+
+
+def test_posenc_fast_range():
+    # |x| up to 4 -> arguments up to 2^9*4 = 2048 rad, beyond the 7-Scenes scene bounds
+    x = (torch.rand(50000, 3) * 8 - 4)
+    ref = torch.cat([x.double()] + [f(x.double() * 2.0 ** k) for k in range(10) for f in (torch.sin, torch.cos)], -1)
+    assert float((eng.posenc(x.to(DEV), 10, fast=True).cpu().double() - ref).abs().max()) < 2e-6
+    assert float((eng.posenc(x.to(DEV), 10).cpu().double() - ref).abs().max()) < 2e-7
+
+
+def test_coarse_weights_golden(gold):
+    g = gold("g4_composite")
+    w = eng.coarse_weights(dev(g["sigma_coarse"][..., 0]), dev(g["z"]))
+    assert relmax(w, g["w_coarse"]) < 2e-6
+
+
+def test_sample_pdf_golden(gold):
+    g = gold("g5_sample_pdf")
+    ka = eng.sample_pdf(dev(np.linspace(0, 1, 8, dtype=np.float32)[None]), dev([[0, 1, 2, 3, 2, 1, 0]]), 5)
+    np.testing.assert_allclose(ka.cpu().numpy(), [[0, .375, .5, .625, 1]], atol=1e-6)
+    b, w = dev(g["bins"]), dev(g["weights"])
+    # a cdf that differs in the last ulp moves a sample by O(1e-6) of the depth range
+    assert relmax(eng.sample_pdf(b, w, 128), g["det128"]) < 5e-6
+    assert relmax(eng.sample_pdf(b, w, 17), g["det17"]) < 5e-6
+    assert relmax(eng.sample_pdf(b, w, 40, u=dev(g["u"])), g["rand40"]) < 5e-6
+
+
+def test_composite_golden_all_modes(gold):
+    g = gold("g4_composite")
+    out = eng.composite_fine(dev(g["raw"]), dev(g["z"]), want_aux=True)
+    for k in ("rgb", "disp", "acc", "weights", "depth", "beta"):
+        assert relmax(out[k], g[k]) < 3e-6, k
+    tr = eng.composite_fine(dev(g["raw"]), dev(g["z"]), test_time=False, want_aux=True)
+    for k in ("rgb", "disp", "acc", "depth", "beta"):
+        assert relmax(tr[k], g["train_" + k]) < 3e-6, k
+
+
+# ------------------------------------------------------------------ MLP stages vs oracle
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("f16", 2e-4)])
+@pytest.mark.parametrize("n_rays,Nc", [(1, 3), (37, 64), (513, 8), (300, 33)])
+def test_mlp_coarse(scene, prec, tol, n_rays, Nc):
+    E, c, f, ea, et = scene
+    g = torch.Generator().manual_seed(n_rays * 100 + Nc)
+    o = torch.rand(n_rays, 3, generator=g) - .5
+    d = torch.randn(n_rays, 3, generator=g)
+    z = orc.coarse_z(0.1, 2.5, Nc, n_rays)
+    pts = o[:, None] + d[:, None] * z[..., None]
+    with torch.no_grad():
+        ref = orc.query_coarse_sigma(c, pts)[..., 0]
+    got = E.mlp_coarse(o.to(DEV), d.to(DEV), Nc, 0.1, 2.5, precision=prec)
+    assert relmax(got, ref) < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-6), ("f16", 3e-4)])
+@pytest.mark.parametrize("n_rays,Nf,per_ray_hist", [(1, 5, False), (40, 192, False), (129, 24, True), (77, 50, True)])
+def test_mlp_fine(scene, prec, tol, n_rays, Nf, per_ray_hist):
+    E, c, f, ea, et = scene
+    g = torch.Generator().manual_seed(n_rays * 1000 + Nf)
+    o = torch.rand(n_rays, 3, generator=g) - .5
+    d = torch.randn(n_rays, 3, generator=g) * .7
+    v = d / d.norm(dim=-1, keepdim=True)
+    z = torch.sort(torch.rand(n_rays, Nf, generator=g) * 2.5, -1)[0]
+    if per_ray_hist:
+        hist = torch.randint(0, 60, (n_rays, 10), generator=g).float()
+    else:
+        hist = T(syn.HIST_IDX)[None]
+    pts = o[:, None] + d[:, None] * z[..., None]
+    with torch.no_grad():
+        ref = orc.query_fine(f, ea, et, pts, v, hist.expand(n_rays, 10))
+    got = E.mlp_fine(o.to(DEV), d.to(DEV), v.to(DEV), hist.to(DEV), z.to(DEV), precision=prec)
+    for ch in (slice(0, 3), slice(3, 4), slice(4, 7), slice(7, 8), slice(8, 9)):
+        assert relmax(got[..., ch], ref[..., ch]) < tol, ch
+
+
+def test_sample_fine_vs_oracle(scene):
+    """Fused sampler vs oracle.  Inverse-CDF sampling is ill-conditioned where the pdf is ~1e-5 (a last-ulp
+    difference in the cdf moves a sample by ~1% of a bin), so rows with (near-)empty bins are checked by bin
+    occupancy instead of by value; well-conditioned rows are compared directly."""
+    g = torch.Generator().manual_seed(5)
+    for n, Nc, Ni in ((50, 64, 128), (9, 32, 64), (130, 8, 16), (17, 33, 70)):
+        sig = torch.rand(n, Nc, generator=g) * 8 + 0.5
+        sig[0] = 0          # empty ray: uniform pdf
+        sig[1, 5:] = -1     # relu -> all mass in the first bins, flat cdf tail
+        sig[2, :Nc // 2] = 0
+        z = orc.coarse_z(0., 2.5, Nc, n)
+        _, w = orc.coarse_weights(sig, z)
+        mid = .5 * (z[:, 1:] + z[:, :-1])
+        zs = orc.sample_pdf(mid, w[:, 1:-1], Ni)
+        zf = torch.sort(torch.cat([z, zs], -1), -1)[0]
+        got, gw, gzs = eng.sample_fine(sig.to(DEV), Ni, 0., 2.5, want_aux=True)
+        assert relmax(gw, w) < 3e-6
+        pdf = (w[:, 1:-1] + 1e-5) / (w[:, 1:-1] + 1e-5).sum(-1, keepdim=True)
+        good = pdf.min(-1)[0] > 2e-3
+        good[0] = True  # the uniform row is well conditioned
+        assert int(good.sum()) >= 1
+        assert relmax(gzs[good.to(DEV)], zs[good]) < 5e-6 and relmax(got[good.to(DEV)], zf[good]) < 5e-6
+        gz, gs = got.cpu(), gzs.cpu()
+        assert bool((gz[:, 1:] >= gz[:, :-1]).all()), "z_fine must be sorted"
+        assert bool((gs >= mid[:, :1]).all()) and bool((gs <= mid[:, -1:]).all())
+        for r in range(n):  # per-bin sample counts agree with the oracle to +-1
+            ha = torch.histc(gs[r], bins=Nc - 2, min=float(mid[r, 0]), max=float(mid[r, -1]))
+            hb = torch.histc(zs[r], bins=Nc - 2, min=float(mid[r, 0]), max=float(mid[r, -1]))
+            assert float((ha.cumsum(0) - hb.cumsum(0)).abs().max()) <= 1
+        # the output is an exact permutation of cat([z, z_samples]) as the kernel computed them
+        assert torch.equal(torch.sort(torch.cat([z.to(DEV), gzs], -1), -1)[0].cpu(), gz)
+
+
+# ------------------------------------------------------------------ whole path vs golden render
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16", 1e-3)])
+def test_render_rays_golden(scene, gold, prec, tol):
+    E = scene[0]
+    for tag in "ab":
+        g = gold("g6_render_rays_" + tag)
+        rgb, disp, acc, raw = E.render_rays(dev(g["rays_o"]), dev(g["rays_d"]), dev(g["hist"]), int(g["Nc"]),
+                                            int(g["Ni"]), float(g["near"]), float(g["far"]), retraw=True,
+                                            precision=prec)
+        assert relmax(raw, g["raw"]) < tol
+        assert relmax(rgb, g["rgb"]) < tol and relmax(disp, g["disp"]) < tol and relmax(acc, g["acc"]) < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16", 1e-3)])
+def test_render_image_golden(scene, gold, prec, tol):
+    E = scene[0]
+    g = gold("g7_render_image")
+    rgb, disp, acc = E.render_image(dev(g["c2w"]), int(g["H"]), int(g["W"]), float(g["focal"]), dev(g["hist"]),
+                                    int(g["Nc"]), int(g["Ni"]), float(g["near"]), float(g["far"]), precision=prec)
+    assert relmax(rgb, g["rgb"]) < tol and relmax(disp, g["disp"]) < tol and relmax(acc, g["acc"]) < tol
+
+
+def test_render_config1_shape_vs_oracle(scene):
+    """BASELINE configs[0] shape: 160x120 frame, 32+64 samples, against the oracle on every ray."""
+    E, c, f, ea, et = scene
+    H, W, focal = 120, 160, 585.0 / 4
+    c2w = T(syn.orbit_pose(2, 8))
+    with torch.no_grad():
+        ref = orc.render(H, W, focal, 32768, c, f, ea, et, 32, 64, 0., 2.5, syn.HIST_IDX, c2w=c2w)
+    for prec, tol in (("f32", 2e-5), ("f16", 1e-3)):
+        got = E.render_image(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 32, 64, 0., 2.5, precision=prec)
+        for a, b in zip(got, ref):
+            assert relmax(a, b) < tol
+        mse = float(((got[0].cpu() - ref[0]) ** 2).mean())
+        assert -10 * np.log10(max(mse, 1e-30)) > 60  # PSNR vs the reference render, dB
+
+
+# ------------------------------------------------------------------ full size: properties
+def test_full_frame_properties(scene):
+    """640x480, 64+128 (BASELINE configs[1]): determinism, chunk invariance, f16~f32, oracle on a subset."""
+    E, c, f, ea, et = scene
+    H, W, focal = 480, 640, 585.0
+    c2w = T(syn.orbit_pose(1, 8))
+    hist = dev(syn.HIST_IDX)
+    rgb, disp, acc = [t.clone() for t in E.render_image(c2w.to(DEV), H, W, focal, hist, 64, 128, 0., 2.5)]
+    rgb2, disp2, acc2 = E.render_image(c2w.to(DEV), H, W, focal, hist, 64, 128, 0., 2.5)
+    assert torch.equal(rgb, rgb2) and torch.equal(disp, disp2) and torch.equal(acc, acc2)  # idempotent, bit-exact
+    assert bool(torch.isfinite(rgb).all()) and float(acc.min()) >= 0 and float(acc.max()) <= 1 + 1e-5
+    assert float(rgb.min()) >= 0 and float(rgb.max()) <= 1 + 1e-5
+    # rays are independent: rendering any subset of the frame's rays alone gives the same bits
+    o, d, v = eng.raygen(H, W, focal, c2w.to(DEV))
+    sel = torch.randperm(H * W, generator=torch.Generator().manual_seed(0))[:5000].to(DEV)
+    srgb, sdisp, sacc, _ = E.render_rays(o.reshape(-1, 3)[sel], d.reshape(-1, 3)[sel], hist, 64, 128, 0., 2.5)
+    assert torch.equal(srgb, rgb.reshape(-1, 3)[sel]) and torch.equal(sacc, acc.reshape(-1)[sel])
+    # the two arithmetic paths agree to the f16 tolerance everywhere
+    r32, d32, a32 = E.render_image(c2w.to(DEV), H, W, focal, hist, 64, 128, 0., 2.5, precision="f32")
+    assert relmax(rgb, r32.cpu()) < 1e-3 and relmax(disp, d32.cpu()) < 1e-3 and relmax(acc, a32.cpu()) < 1e-3
+    # and the oracle on 256 of the rays
+    sub = sel[:256].cpu()
+    ro, rd = orc.get_rays(H, W, focal, c2w[:3, :4])
+    rows = orc.pack_ray_rows(ro.reshape(-1, 3)[sub], rd.reshape(-1, 3)[sub], 0., 2.5, syn.HIST_IDX)
+    with torch.no_grad():
+        ref = orc.render_rays(rows, c, f, ea, et, 64, 128)
+    assert relmax(rgb.reshape(-1, 3)[sub.to(DEV)], ref["rgb_map"]) < 1e-3
+    assert relmax(r32.reshape(-1, 3)[sub.to(DEV)], ref["rgb_map"]) < 2e-5
+    assert relmax(d32.reshape(-1)[sub.to(DEV)], ref["disp_map"]) < 2e-5
+
+
+def test_sharper_scene_f16_margin():
+    """Trained checkpoints are less contractive than default init: scale every weight matrix x1.6
+    and check the f16 path still holds 1e-3 (and report-by-assert the exact path stays at fp32 round-off)."""
+    cw, fw, ea, et = syn.nerfh_weights(0, gain=1.6)
+    E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
+    c, f = tt(cw), tt(fw)
+    H, W, focal = 24, 32, 29.0
+    c2w = T(syn.orbit_pose(5, 8))
+    with torch.no_grad():
+        ref = orc.render(H, W, focal, 32768, c, f, T(ea), T(et), 64, 128, 0., 2.5, syn.HIST_IDX, c2w=c2w)
+    got32 = E.render_image(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, precision="f32")
+    got16 = E.render_image(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, precision="f16")
+    assert relmax(got32[0], ref[0]) < 5e-5
+    assert relmax(got16[0], ref[0]) < 1e-3 and relmax(got16[1], ref[1]) < 1e-3
+
+
+def test_bad_arguments_raise(scene):
+    E = scene[0]
+    o = torch.zeros(4, 3, device=DEV)
+    with pytest.raises(Exception, match="N_samples"):
+        E.render_rays(o, o, dev(syn.HIST_IDX), 2, 8, 0., 1.)
+    with pytest.raises(Exception, match="hist_rows"):
+        E.render_rays(o, o, torch.zeros(3, 10, device=DEV), 8, 8, 0., 1.)
