@@ -1,0 +1,126 @@
+"""Dataset front-end producing the hot path's inputs: per frame `(img [1,3,H,W] in [0,1],
+pose [1,12], hist [1,hist_bin])`, plus `hwf` and `[near, far]`.
+
+Host-side I/O only (out of scope for kernels), restated compactly so the
+drop-in CLIs run: the 7-Scenes on-disk layout (`TrainSplit.txt`, `seq-XX/frame-XXXXXX.color.png`,
+`.pose.txt`; /root/reference/dataset_loaders/seven_scenes.py:185-354), the pose re-centring /
+axis flip / scene rescale of load_7Scenes.py:279-344 (`fix_coord`, including its `M·([R|T]·M)`
+product as written) and the 10-bin luma histogram index of seven_scenes.py:346-352.
+
+Path convention: `--datadir ../data/7Scenes/<scene>` holds world_setup.json and
+pose_avg_stats.txt; frames live under `<datadir>/../../deepslam_data/7Scenes/<scene>` (the
+reference hard-codes `../data/deepslam_data/7Scenes`, which is the same place for the standard tree).
+"""
+import json
+import os
+import os.path as osp
+
+import numpy as np
+import torch
+
+
+def _load_png(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.
+
+
+def _area_downscale(img, H, W):
+    """cv2.INTER_AREA: exact box mean for integer factors, PIL BOX otherwise."""
+    h, w = img.shape[:2]
+    if h % H == 0 and w % W == 0:
+        return img.reshape(H, h // H, W, w // W, 3).mean((1, 3), dtype=np.float32)
+    from PIL import Image
+    chans = [np.asarray(Image.fromarray(img[..., c]).resize((W, H), Image.BOX)) for c in range(3)]
+    return np.stack(chans, -1).astype(np.float32)
+
+
+def luma_histogram(img_chw, bins=10):
+    """Histogram index vector fed to the NeRF-H embeddings: Y = .299R+.587G+.114B, torch.histc over
+    [0,1], converted to integer percentages (seven_scenes.py:346-352)."""
+    y = 0.299 * img_chw[0] + 0.587 * img_chw[1] + 0.114 * img_chw[2]
+    h = torch.histc(y, bins=bins, min=0., max=1.)
+    return torch.round(h / h.sum() * 100)
+
+
+def recentre_poses(poses, pose_avg=None):
+    """[N,3,4] camera-to-world -> centred by the inverse average pose (load_7Scenes.py:143-197)."""
+    if pose_avg is None:
+        centre = poses[..., 3].mean(0)
+        z = poses[..., 2].mean(0)
+        z = z / np.linalg.norm(z)
+        x = np.cross(poses[..., 1].mean(0), z)
+        x = x / np.linalg.norm(x)
+        pose_avg = np.stack([x, np.cross(z, x), z, centre], 1)
+    avg = np.eye(4)
+    avg[:3] = pose_avg
+    homo = np.concatenate([poses, np.tile(np.array([[[0, 0, 0, 1.]]]), (len(poses), 1, 1))], 1)
+    return (np.linalg.inv(avg) @ homo)[:, :3], pose_avg
+
+
+def to_nerf_frame(poses, setup):
+    """Axis flip to 'up right backward' and scene rescale (load_7Scenes.py:311-338)."""
+    flip = np.diag([1., -1., -1., 1.])
+    homo = np.concatenate([poses, np.tile(np.array([[[0, 0, 0, 1.]]]), (len(poses), 1, 1))], 1)
+    out = (flip @ (homo @ flip))[:, :3, :4]
+    out[:, :3, 3] *= setup["pose_scale"]
+    if list(setup["move_all_cam_vec"]) != [0., 0., 0.]:
+        out[:, :3, 3] += np.asarray(setup["move_all_cam_vec"])
+    if setup["pose_scale2"] != 1.0:
+        out[:, :3, 3] *= setup["pose_scale2"]
+    return out
+
+
+class SevenScenesFrames(torch.utils.data.Dataset):
+    """One split of a 7-Scenes scene; items are (img [3,H,W], pose [12], hist [bins])."""
+
+    def __init__(self, frames_root, train, skip=1, df=1., focal=585., hist_bin=10):
+        split = osp.join(frames_root, 'TrainSplit.txt' if train else 'TestSplit.txt')
+        with open(split) as fh:
+            seqs = [int(l.split('sequence')[-1]) for l in fh if l.strip() and not l.startswith('#')]
+        self.files, poses = [], []
+        for seq in seqs:
+            d = osp.join(frames_root, 'seq-{:02d}'.format(seq))
+            ids = sorted(int(n[6:12]) for n in os.listdir(d) if 'pose' in n)[::max(int(skip), 1)]
+            for i in ids:
+                self.files.append(osp.join(d, 'frame-{:06d}.color.png'.format(i)))
+                poses.append(np.loadtxt(osp.join(d, 'frame-{:06d}.pose.txt'.format(i))).flatten()[:12])
+        self.poses = np.asarray(poses, dtype=np.float64).reshape(-1, 12)
+        h, w = _load_png(self.files[0]).shape[:2]
+        self.df = df
+        self.H, self.W, self.focal = int(h // df), int(w // df), focal / df
+        self.hist_bin = hist_bin
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        img = _load_png(self.files[i])
+        if self.df != 1.:
+            img = _area_downscale(img, self.H, self.W)
+        img = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
+        return img, torch.tensor(self.poses[i], dtype=torch.float32), luma_histogram(img, self.hist_bin)
+
+
+def load_7Scenes_dataloader_NeRF(args):
+    """(train_dl, val_dl, hwf, i_split, bounds, render_poses, render_img) as load_7Scenes.py:497-555."""
+    datadir = osp.normpath(args.datadir)
+    scene = osp.basename(datadir)
+    dataset = osp.basename(osp.dirname(datadir))
+    frames_root = osp.join(osp.dirname(osp.dirname(datadir)), 'deepslam_data', dataset, scene)
+    with open(osp.join(datadir, 'world_setup.json')) as fh:
+        setup = json.load(fh)
+    kw = dict(df=args.df, hist_bin=args.hist_bin)
+    train_set = SevenScenesFrames(frames_root, True, args.trainskip, **kw)
+    val_set = SevenScenesFrames(frames_root, False, args.testskip, **kw)
+    n_train = len(train_set)
+    allp = np.concatenate([train_set.poses, val_set.poses]).reshape(-1, 3, 4)
+    avg = np.loadtxt(osp.join(datadir, 'pose_avg_stats.txt')) if args.load_pose_avg_stats else None
+    allp, _ = recentre_poses(allp, avg)
+    allp = to_nerf_frame(allp, setup).reshape(-1, 12)
+    train_set.poses, val_set.poses = allp[:n_train], allp[n_train:]
+    shuffle = not (args.render_video_train or args.render_test)
+    train_dl = torch.utils.data.DataLoader(train_set, batch_size=1, shuffle=shuffle)
+    val_dl = torch.utils.data.DataLoader(val_set, batch_size=1, shuffle=False)
+    hwf = [train_set.H, train_set.W, train_set.focal]
+    idx = np.arange(n_train), np.arange(len(val_set)), np.arange(len(val_set))
+    return train_dl, val_dl, hwf, list(idx), np.array([setup["near"], setup["far"]]), None, None

@@ -1,0 +1,152 @@
+"""The three CLI flag surfaces of the reference — run_nerf.py, run_feature.py, train.py — as one
+table, plus a `key=value` config-file reader.
+
+The reference builds three overlapping configargparse parsers
+(/root/reference/script/models/options.py:2-99, feature/options.py, dm/options.py); the drop-in
+must accept every flag of each with the same name, type and default, and the same config_*.txt
+files (`key = value`, `#` comments, `flag=True` switches a store_true flag on).  configargparse is
+not a dependency here: config files are folded into argv ahead of the command line (so the command
+line wins, as in configargparse).
+
+Table row: (flag, kind, default, parsers[, per-parser default overrides]) with parsers a subset of
+"n" (run_nerf), "f" (run_feature), "d" (train.py / direct matching); kind is "flag" (store_true),
+"int", "float", "str" or "int+" / "float+" (nargs='+').
+"""
+import argparse
+
+_T = [
+    ("fff", "str", "1", "nfd"), ("device", "int", -1, "n"), ("multi_gpu", "flag", False, "nfd"),
+    ("expname", "str", None, "nfd"), ("basedir", "str", "../logs", "nfd", {"d": "../logs/"}),
+    ("datadir", "str", "./data/llff/fern", "nfd"),
+    # dataset / pose statistics
+    ("trainskip", "int", 1, "nfd"), ("df", "float", 1.0, "nfd"), ("reduce_embedding", "int", -1, "nfd"),
+    ("epochToMaxFreq", "int", -1, "nfd"), ("render_pose_only", "flag", False, "nfd"),
+    ("save_pose_avg_stats", "flag", False, "nfd"), ("load_pose_avg_stats", "flag", False, "nfd"),
+    ("train_local_nerf", "int", -1, "nfd"), ("render_video_train", "flag", False, "nfd"),
+    ("render_video_test", "flag", False, "nfd"), ("frustum_overlap_th", "float", None, "nf"),
+    ("no_DNeRF_viewdir", "flag", False, "nfd"), ("load_unique_view_stats", "flag", False, "nf"),
+    # NeRF network / optimiser
+    ("netdepth", "int", 8, "nfd"), ("netwidth", "int", 128, "nfd"), ("netdepth_fine", "int", 8, "nfd"),
+    ("netwidth_fine", "int", 128, "nfd"), ("N_rand", "int", 1536, "nfd"), ("lrate", "float", 5e-4, "nfd"),
+    ("lrate_decay", "float", 250, "nfd"), ("chunk", "int", 32768, "nfd"), ("netchunk", "int", 65536, "nfd"),
+    ("no_batching", "flag", False, "nfd", {"f": True}), ("no_reload", "flag", False, "nfd"),
+    ("ft_path", "str", None, "nfd"), ("no_grad_update", "flag", False, "nfd", {"d": True}),
+    # NeRF-H
+    ("NeRFH", "flag", False, "nfd", {"f": True}), ("N_vocab", "int", 1000, "nfd"), ("fix_index", "flag", False, "nfd"),
+    ("encode_hist", "flag", False, "nfd"), ("hist_bin", "int", 10, "nfd"), ("in_channels_a", "int", 50, "nfd"),
+    ("in_channels_t", "int", 20, "nfd"), ("svd_reg", "flag", False, "fd"),
+    # rendering
+    ("N_samples", "int", 64, "nfd"), ("N_importance", "int", 64, "nfd"), ("perturb", "float", 1.0, "nfd"),
+    ("use_viewdirs", "flag", True, "nfd"), ("i_embed", "int", 0, "nfd"), ("multires", "int", 10, "nfd"),
+    ("multires_views", "int", 4, "nfd"), ("raw_noise_std", "float", 0.0, "nfd"), ("render_only", "flag", False, "nfd"),
+    ("render_test", "flag", False, "nfd"), ("render_factor", "int", 0, "nfd"),
+    ("mesh_only", "flag", False, "nfd"), ("mesh_grid_size", "int", 80, "nfd"), ("precrop_iters", "int", 0, "nfd"),
+    ("precrop_frac", "float", 0.5, "nfd"), ("epochs", "int", 600, "nf", {"f": 2000}),
+    ("dataset_type", "str", "llff", "nfd"), ("testskip", "int", 1, "nfd"), ("white_bkgd", "flag", False, "nfd"),
+    ("half_res", "flag", False, "fd"), ("factor", "int", 8, "nfd"), ("no_ndc", "flag", False, "nfd"),
+    ("lindisp", "flag", False, "nfd"), ("spherify", "flag", False, "nfd"), ("llffhold", "int", 8, "nfd"),
+    ("no_bd_factor", "flag", False, "nfd"),
+    ("i_print", "int", 1, "nfd"), ("i_img", "int", 500, "nfd"), ("i_weights", "int", 200, "nfd"),
+    ("i_testset", "int", 200, "nfd"), ("i_video", "int", 50000, "nfd"),
+    # DFNet / direct feature matching
+    ("places365_model_path", "str", "", "f"), ("finetune_unlabel", "flag", False, "fd"),
+    ("i_eval", "int", 20, "fd", {"d": 50}), ("save_all_ckpt", "flag", False, "fd"), ("val_on_psnr", "flag", False, "fd"),
+    ("tinyimg", "flag", False, "f"), ("tinyscale", "float", 4.0, "f"), ("pose_only", "int", 1, "fd", {"d": 0}),
+    ("learning_rate", "float", 1e-4, "fd", {"d": 1e-5}), ("batch_size", "int", 1, "fd"),
+    ("featurenet_batch_size", "int", 8, "f"), ("pretrain_model_path", "str", "", "fd"),
+    ("pretrain_featurenet_path", "str", "", "d"), ("model_name", "str", None, "fd"),
+    ("combine_loss", "flag", False, "d"), ("combine_loss_w", "float+", [1, 1, 1], "fd", {"d": [0.5, 0.5]}),
+    ("patience", "int+", [200, 50], "fd"), ("resize_factor", "int", 2, "fd"), ("freezeBN", "flag", False, "fd"),
+    ("preprocess_ImgNet", "flag", False, "fd"), ("eval", "flag", False, "fd"), ("no_save_multiple", "flag", False, "fd"),
+    ("resnet34", "flag", False, "fd"), ("efficientnet", "flag", False, "fd"), ("efficientnet_block", "int", 6, "d"),
+    ("dropout", "float", 0.5, "fd"), ("DFNet", "flag", False, "fd"), ("DFNet_s", "flag", False, "fd"),
+    ("featurelossonly", "flag", False, "f"), ("random_view_synthesis", "flag", False, "f"),
+    ("rvs_refresh_rate", "int", 2, "f"), ("rvs_trans", "float", 5, "f"), ("rvs_rotation", "float", 1.2, "f"),
+    ("d_max", "float", 1, "f"), ("val_batch_size", "int", 1, "fd"), ("poselossonly", "flag", False, "f"),
+    ("tripletloss", "flag", False, "f"), ("triplet_margin", "float", 1.0, "f"),
+    ("render_feature_only", "flag", False, "f"), ("feature_matching_lvl", "int+", [0, 1, 2], "d"),
+    ("per_channel", "flag", False, "d"), ("featuremetric", "flag", False, "d"),
+    # --- additions of this implementation (not in the reference) ---
+    ("precision", "str", "f16", "nfd"),        # MFMA arithmetic of the HIP path: f16 | f32
+]
+_TYPES = {"int": int, "float": float, "str": str}
+
+
+def _read_config(path):
+    """`key = value` lines -> argv tokens.  `flag=True` emits the bare flag, `flag=False` nothing;
+    list values may be `[1, 2]` or space separated."""
+    argv = []
+    with open(path) as fh:
+        for line in fh:
+            line = line.split("#", 1)[0].strip()
+            if not line or line.startswith(";"):
+                continue
+            if "=" in line:
+                key, val = (s.strip() for s in line.split("=", 1))
+            else:
+                parts = line.split(None, 1)
+                key, val = parts[0], (parts[1].strip() if len(parts) > 1 else "true")
+            low = val.lower()
+            if low in ("true", "yes"):
+                argv.append("--" + key)
+            elif low in ("false", "no"):
+                continue
+            else:
+                val = val.strip("[]")
+                vals = [v.strip().strip("'\"") for v in val.replace(",", " ").split()] if (" " in val or "," in val) else [val.strip("'\"")]
+                argv += ["--" + key] + vals
+    return argv
+
+
+class ConfigParser(argparse.ArgumentParser):
+    """argparse with a `--config FILE` option folded in ahead of the command line."""
+
+    def parse_known_args(self, args=None, namespace=None):
+        import sys
+        args = list(sys.argv[1:] if args is None else args)
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--config", default=None)
+        known, rest = pre.parse_known_args(args)
+        self._config_path = known.config
+        if known.config:
+            rest = _read_config(known.config) + rest
+        ns, extra = super().parse_known_args(rest, namespace)
+        ns.config = known.config
+        return ns, extra
+
+
+def _build(which):
+    p = ConfigParser()
+    for row in _T:
+        name, kind, default, where = row[:4]
+        if which not in where:
+            continue
+        if len(row) > 4 and which in row[4]:
+            default = row[4][which]
+        if name == "fff":
+            p.add_argument("-f", "--fff", default=default)
+        elif kind == "flag":
+            p.add_argument("--" + name, action="store_true", default=default)
+        elif kind.endswith("+"):
+            p.add_argument("--" + name, nargs="+", type=_TYPES[kind[:-1]], default=default)
+        else:
+            p.add_argument("--" + name, type=_TYPES[kind], default=default)
+    return p
+
+
+def nerf_parser():
+    """Flags of run_nerf.py (/root/reference/script/models/options.py)."""
+    return _build("n")
+
+
+def feature_parser():
+    """Flags of run_feature.py (/root/reference/script/feature/options.py)."""
+    return _build("f")
+
+
+def dm_parser():
+    """Flags of train.py (/root/reference/script/dm/options.py)."""
+    return _build("d")
+
+
+config_parser = nerf_parser  # the name every reference options module exports

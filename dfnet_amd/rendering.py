@@ -1,0 +1,191 @@
+"""Host-side mirror of /root/reference/script/models/rendering.py: same function names, arguments
+and return shapes (`render`, `render_path`, `render_test`), evaluated by the HIP library.
+
+What the reference does per ray chunk in Python (`batchify_rays` -> `render_rays` -> `netchunk`
+loops, rendering.py:245-351) is one call into libdfnet_hip.so here; `chunk`/`netchunk` are accepted
+and ignored (tiling is internal).  `render_path`'s serial frame loop (rendering.py:420) becomes a
+frame-sharded loop with one gather when torch.distributed is initialised (dfnet_amd/dist.py).
+
+Only the test-time path is native so far (perturb=0, raw_noise_std=0, test_time=True — what
+`render_kwargs_test` carries); anything else raises NotImplementedError rather than falling back.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dist as ddist
+from .nerfw import to8b
+from .ray_utils import get_rays  # noqa: F401  (re-exported like the reference's `from models.ray_utils import *`)
+
+DEBUG = False
+
+
+def _engine_of(kwargs):
+    q = kwargs.get('network_query_fn')
+    eng = getattr(q, 'engine', None)
+    if eng is None:
+        raise TypeError("render(): render kwargs must come from dfnet_amd.nerfw.create_nerf "
+                        "(network_query_fn carries the HIP engine)")
+    return eng
+
+
+def _check_test_time(kw, ndc, c2w_staticcam, use_viewdirs):
+    bad = []
+    if ndc:
+        bad.append("ndc=True (LLFF forward-facing rays)")
+    if not kw.get('test_time', False):
+        bad.append("test_time=False (training-mode extras rgb0/beta/transient_sigmas)")
+    if float(kw.get('perturb', 0.) or 0.) > 0.:
+        bad.append("perturb>0 (stratified jitter)")
+    if float(kw.get('raw_noise_std', 0.) or 0.) != 0.:
+        bad.append("raw_noise_std!=0")
+    if kw.get('white_bkgd', False):
+        bad.append("white_bkgd")
+    if kw.get('lindisp', False):
+        bad.append("lindisp")
+    if not use_viewdirs:
+        bad.append("use_viewdirs=False")
+    if c2w_staticcam is not None:
+        bad.append("c2w_staticcam")
+    if int(kw.get('N_importance', 0)) <= 0:
+        bad.append("N_importance=0")
+    if bad:
+        raise NotImplementedError("dfnet_amd render(): not implemented natively yet: " + "; ".join(bad) +
+                                  " — there is deliberately no CPU fallback")
+
+
+def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, img_idx=torch.Tensor(0), **kwargs):
+    """Drop-in for rendering.py:353-400.  Returns [rgb_map, disp_map, acc_map, extras].
+
+    c2w given: full image, outputs [H,W,3], [H,W], [H,W].  Otherwise `rays` = (rays_o, rays_d) (a tuple
+    or a stacked [2,N,3] tensor), outputs shaped like rays_d[..., :1].  `img_idx`: the 10-bin histogram
+    index vector, shape [10], [1,10] or [N,10]."""
+    eng = _engine_of(kwargs)
+    _check_test_time(kwargs, ndc, c2w_staticcam, use_viewdirs)
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (c2w, rays) if t is not None):
+        raise NotImplementedError("differentiable render (DFNet_dm inner step) needs the backward kernels: not built yet")
+    Nc, Ni = int(kwargs['N_samples']), int(kwargs['N_importance'])
+    retraw = bool(kwargs.get('retraw', False))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hist = torch.as_tensor(img_idx, dtype=torch.float32, device=dev)
+    if c2w is not None:
+        c2w = torch.as_tensor(c2w, dtype=torch.float32, device=dev)
+        if retraw or hist.numel() != eng.hist_bin:
+            o, d = get_rays(H, W, focal, c2w)
+            return render(H, W, focal, chunk, rays=(o, d), ndc=ndc, near=near, far=far, use_viewdirs=use_viewdirs,
+                          img_idx=img_idx, **kwargs)
+        rgb, disp, acc = eng.render_image(c2w, int(H), int(W), float(focal), hist, Nc, Ni, near, far)
+        return [rgb, disp, acc, {}]
+    rays_o, rays_d = rays
+    rays_o = torch.as_tensor(rays_o, dtype=torch.float32, device=dev)
+    rays_d = torch.as_tensor(rays_d, dtype=torch.float32, device=dev)
+    sh = rays_d.shape
+    n = rays_d.numel() // 3
+    hist = hist.reshape(-1, eng.hist_bin)
+    if hist.shape[0] not in (1, n):
+        raise ValueError(f"img_idx must have 1 or {n} rows of {eng.hist_bin} bins, got {tuple(hist.shape)}")
+    rgb, disp, acc, raw = eng.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), hist, Nc, Ni, near, far,
+                                          retraw=retraw)
+    lead = list(sh[:-1])
+    extras = {'raw': raw.reshape(lead + list(raw.shape[1:]))} if retraw else {}
+    return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), extras]
+
+
+def _write_png(path, arr8):
+    try:
+        from PIL import Image
+        Image.fromarray(arr8).save(path)
+    except ImportError:  # minimal zlib PNG writer (8-bit gray or RGB)
+        import struct
+        import zlib
+        a = np.ascontiguousarray(arr8)
+        h, w = a.shape[:2]
+        ctype = 2 if a.ndim == 3 else 0
+        raw = b"".join(b"\x00" + a[r].tobytes() for r in range(h))
+        chunk = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+        with open(path, "wb") as fh:
+            fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+                     chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0,
+                single_gt_img=False, img_ids=torch.Tensor(0)):
+    """Drop-in for rendering.py:403-458: returns (rgbs [N,H,W,3], disps [N,H,W]) as float32 numpy.
+
+    Frames stay in HBM until the end (one D2H copy instead of a sync per frame).  With
+    torch.distributed initialised (world > 1) each rank renders its contiguous block of frames and
+    rank 0 gathers them; ranks != 0 return (None, None).  PSNR / PNG conventions follow the
+    reference: per-frame -10*log10(mean((rgb-gt)^2)) then the mean, `{:03d}.png`, `{:03d}_GT.png`,
+    `{:03d}_disp.png` (disp / max), to8b truncation."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = int(H // render_factor), int(W // render_factor), focal / render_factor
+    H, W = int(H), int(W)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    render_poses = torch.as_tensor(render_poses, dtype=torch.float32, device=dev)
+    img_ids = torch.as_tensor(img_ids, dtype=torch.float32, device=dev)
+    N = render_poses.shape[0]
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    lo, hi = ddist.frame_block(N, rank, world)
+    rgbs = torch.empty(hi - lo, H, W, 3, device=dev)
+    disps = torch.empty(hi - lo, H, W, device=dev)
+    t0 = time.time()
+    for j, i in enumerate(range(lo, hi)):
+        rgb, disp, _, _ = render(H, W, focal, chunk=chunk, c2w=render_poses[i][:3, :4], img_idx=img_ids[i],
+                                 **render_kwargs)
+        rgbs[j].copy_(rgb)
+        disps[j].copy_(disp)
+        if i == 0:
+            print(rgb.shape, disp.shape)
+    all_rgb = ddist.gather_frames(rgbs, N)
+    all_disp = ddist.gather_frames(disps, N)
+    if rank != 0:
+        return None, None
+    rgbs = all_rgb.cpu().numpy()
+    disps = all_disp.cpu().numpy()
+    print(f"rendered {N} frames of {W}x{H} on {world} GPU(s) in {time.time() - t0:.2f} s")
+    psnr = []
+    for i in range(N):
+        if gt_imgs is not None:
+            gt = gt_imgs if single_gt_img else gt_imgs[i]
+            psnr.append(-10. * np.log10(np.mean(np.square(rgbs[i] - gt))))
+        if savedir is not None:
+            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[i]))
+            if gt_imgs is not None:
+                _write_png(os.path.join(savedir, '{:03d}_GT.png'.format(i)), to8b(gt_imgs if single_gt_img else gt_imgs[i]))
+            _write_png(os.path.join(savedir, '{:03d}_disp.png'.format(i)), to8b(disps[i] / np.max(disps[i])))
+    if psnr:
+        print("Mean PSNR of this run is:", np.mean(psnr, 0))
+    return rgbs, disps
+
+
+def _drain(dl):
+    imgs, poses, idxs = [], [], []
+    for img, pose, img_idx in dl:
+        imgs.append(img.permute(0, 2, 3, 1))
+        p = torch.zeros(1, 4, 4)
+        p[0, :3, :4] = pose.reshape(3, 4)[:3, :4]
+        p[0, 3, 3] = 1.
+        poses.append(p)
+        idxs.append(img_idx)
+    return torch.cat(imgs, 0).numpy(), torch.cat(poses, 0), torch.cat(idxs, 0)
+
+
+def render_test(args, train_dl, val_dl, hwf, start, render_kwargs_test, decoder_coarse=None, decoder_fine=None):
+    """Drop-in for rendering.py:460-530: render the train split then the val split, write PNGs under
+    basedir/expname/evaluate_{train,val}_{test|path}_{start:06d}."""
+    tag = 'test' if args.render_test else 'path'
+    for name, dl in (("train", train_dl), ("val", val_dl)):
+        savedir = os.path.join(args.basedir, args.expname, 'evaluate_{}_{}_{:06d}'.format(name, tag, start))
+        os.makedirs(savedir, exist_ok=True)
+        images, poses, index = _drain(dl)
+        print(f'{name} poses shape', poses.shape)
+        with torch.no_grad():
+            render_path(args, poses, hwf, args.chunk, render_kwargs_test, gt_imgs=images, savedir=savedir,
+                        img_ids=index)
+        print(f'Saved {name} set')
+    return

@@ -1,0 +1,61 @@
+"""BASELINE configs[0] plumbing on the GPU: `run_nerf.py --config config_nerfh.txt --render_test`
+on a synthetic 7-Scenes-layout tree (160x120 after df=4, 32+64 samples, random-init weights, no
+checkpoint), checked frame by frame against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerfh_oracle as orc
+from tests.test_host_logic import make_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_run_nerf_render_test_cli(tmp_path):
+    from PIL import Image
+    from dfnet_amd import datasets, options
+    from dfnet_amd.nerfw import NeRFW
+    datadir = make_scene(str(tmp_path), n_train=2, n_val=2, H=480, W=640)
+    basedir = str(tmp_path / "logs")
+    cli = ["--config", os.path.join(ROOT, "script", "config_nerfh.txt"), "--render_test", "--datadir", datadir,
+           "--basedir", basedir, "--N_samples", "32", "--N_importance", "64", "--testskip", "1", "--trainskip", "1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "run_nerf.py")] + cli, cwd=os.path.join(ROOT, "script"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Mean PSNR of this run is:" in r.stdout and "Not ndc!" in r.stdout
+    out = os.path.join(basedir, "nerfh")
+    assert os.path.exists(os.path.join(out, "args.txt")) and os.path.exists(os.path.join(out, "config.txt"))
+    # the same weights the CLI drew (global seed 0, embeddings first, each NeRFW reseeds to 0)
+    torch.manual_seed(0)
+    ea, et = torch.nn.Embedding(1000, 5), torch.nn.Embedding(1000, 2)
+    coarse = NeRFW('coarse', D=8, W=128, skips=[4], in_channels_xyz=63, in_channels_dir=27)
+    fine = NeRFW('fine', D=8, W=128, skips=[4], in_channels_xyz=63, in_channels_dir=27, encode_appearance=True,
+                 encode_transient=True, in_channels_a=50, in_channels_t=20)
+    c = {k: v.detach() for k, v in coarse.state_dict().items()}
+    f = {k: v.detach() for k, v in fine.state_dict().items()}
+    args = options.nerf_parser().parse_args(cli)
+    train_dl, val_dl, hwf, _, bds, _, _ = datasets.load_7Scenes_dataloader_NeRF(args)
+    assert hwf == [120, 160, 585. / 4]
+    for split, dl in (("train", train_dl), ("val", val_dl)):
+        d = os.path.join(out, f"evaluate_{split}_test_000000")
+        for i, (img, pose, hist) in enumerate(dl):
+            for suffix in ("", "_GT", "_disp"):
+                assert os.path.exists(os.path.join(d, f"{i:03d}{suffix}.png"))
+            if i > 0:
+                continue
+            c2w = torch.eye(4)
+            c2w[:3, :4] = pose.reshape(3, 4)
+            with torch.no_grad():
+                rgb, disp, acc = orc.render(120, 160, 585. / 4, 32768, c, f, ea.weight.detach(), et.weight.detach(),
+                                            32, 64, float(bds[0]), float(bds[1]), hist[0].numpy(), c2w=c2w)
+            want = (255 * np.clip(rgb.numpy(), 0, 1)).astype(np.uint8)
+            got = np.asarray(Image.open(os.path.join(d, "000.png")))
+            assert got.shape == want.shape == (120, 160, 3)
+            assert int(np.abs(got.astype(int) - want.astype(int)).max()) <= 1  # to8b truncation of a 1e-3 match
+            gt = np.asarray(Image.open(os.path.join(d, "000_GT.png")))
+            assert int(np.abs(gt.astype(int) - (255 * img[0].permute(1, 2, 0).numpy()).astype(np.uint8).astype(int)).max()) == 0

@@ -1,0 +1,134 @@
+"""CPU tests of the host-side mirror: option tables / config files, dataset front-end on a synthetic
+7-Scenes-layout tree, frame sharding and the world_size-2 gloo gather."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from dfnet_amd import datasets, dist as ddist, options, synthetic as syn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parsers_defaults_match_reference_tables():
+    n = options.nerf_parser().parse_args([])
+    assert (n.netdepth, n.netwidth, n.N_samples, n.N_importance, n.chunk, n.netchunk) == (8, 128, 64, 64, 32768, 65536)
+    assert (n.multires, n.multires_views, n.N_vocab, n.hist_bin, n.in_channels_a, n.in_channels_t) == (10, 4, 1000, 10, 50, 20)
+    assert n.use_viewdirs is True and n.perturb == 1.0 and n.NeRFH is False and n.epochs == 600
+    f = options.feature_parser().parse_args([])
+    assert f.NeRFH is True and f.no_batching is True and f.epochs == 2000 and f.learning_rate == 1e-4
+    assert f.combine_loss_w == [1, 1, 1] and f.patience == [200, 50] and f.tinyscale == 4.0
+    d = options.dm_parser().parse_args([])
+    assert d.no_grad_update is True and d.learning_rate == 1e-5 and d.feature_matching_lvl == [0, 1, 2]
+    assert d.combine_loss_w == [0.5, 0.5] and d.basedir == "../logs/" and d.i_eval == 50
+    assert not hasattr(d, "tinyimg") and not hasattr(n, "DFNet")
+
+
+def test_config_file_then_cli_override(tmp_path):
+    cfg = tmp_path / "c.txt"
+    cfg.write_text("# comment\nexpname=nerfh\nbasedir = ../logs/heads\ndf=4\nNeRFH=True\nencode_hist=True\n"
+                   "render_test=False\nlrate_decay=0.754  # trailing\n")
+    a = options.nerf_parser().parse_args(["--config", str(cfg), "--df", "2", "--N_importance", "128"])
+    assert a.expname == "nerfh" and a.basedir == "../logs/heads" and a.NeRFH and a.encode_hist
+    assert a.df == 2.0 and a.render_test is False and a.lrate_decay == 0.754 and a.N_importance == 128
+    assert a.config == str(cfg)
+    cfg2 = tmp_path / "d.txt"
+    cfg2.write_text("combine_loss_w = [0., 0., 1.]\nfeature_matching_lvl = [0]\nDFNet=True\n")
+    d = options.dm_parser().parse_args(["--config", str(cfg2)])
+    assert d.combine_loss_w == [0., 0., 1.] and d.feature_matching_lvl == [0] and d.DFNet
+
+
+def make_scene(root, n_train=3, n_val=2, H=48, W=64, seed=0):
+    """A synthetic tree with the 7-Scenes layout under root/data/..."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    datadir = os.path.join(root, "data", "7Scenes", "heads")
+    frames = os.path.join(root, "data", "deepslam_data", "7Scenes", "heads")
+    os.makedirs(datadir)
+    json.dump({"near": 0, "far": 2.5, "pose_scale": 1, "pose_scale2": 1, "move_all_cam_vec": [0.0, 0.0, 1.0]},
+              open(os.path.join(datadir, "world_setup.json"), "w"))
+    np.savetxt(os.path.join(datadir, "pose_avg_stats.txt"), np.eye(4)[:3])
+    for name, seq, n in (("TrainSplit.txt", 2, n_train), ("TestSplit.txt", 1, n_val)):
+        os.makedirs(os.path.join(frames, f"seq-{seq:02d}"))
+        open(os.path.join(frames, name), "w").write(f"sequence{seq}\n")
+        for i in range(n):
+            img = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(frames, f"seq-{seq:02d}", f"frame-{i:06d}.color.png"))
+            np.savetxt(os.path.join(frames, f"seq-{seq:02d}", f"frame-{i:06d}.pose.txt"), syn.orbit_pose(i, 8))
+    return datadir
+
+
+def test_seven_scenes_front_end(tmp_path):
+    datadir = make_scene(str(tmp_path))
+    args = options.nerf_parser().parse_args(["--datadir", datadir, "--dataset_type", "7Scenes", "--df", "2",
+                                             "--load_pose_avg_stats", "--render_test"])
+    train_dl, val_dl, hwf, i_split, bds, _, _ = datasets.load_7Scenes_dataloader_NeRF(args)
+    assert hwf == [24, 32, 585. / 2] and list(bds) == [0, 2.5] and len(train_dl) == 3 and len(val_dl) == 2
+    img, pose, hist = next(iter(train_dl))
+    assert img.shape == (1, 3, 24, 32) and pose.shape == (1, 12) and hist.shape == (1, 10)
+    assert 0 <= float(img.min()) and float(img.max()) <= 1 and abs(float(hist.sum()) - 100) <= 5
+    assert bool((hist == hist.round()).all())
+    # pose convention: identity average pose -> flip y,z columns/rows as written, then z += 1
+    p = pose.reshape(3, 4).numpy()
+    src = syn.orbit_pose(0, 8)
+    flip = np.diag([1., -1., -1., 1.])
+    want = (flip @ (src @ flip))[:3]
+    want[:, 3] += [0, 0, 1]
+    np.testing.assert_allclose(p, want, atol=1e-6)
+
+
+def test_recentre_roundtrip():
+    rng = np.random.default_rng(0)
+    poses = np.stack([syn.orbit_pose(k, 8)[:3] for k in range(6)]).astype(np.float64)
+    cen, avg = datasets.recentre_poses(poses)
+    a4 = np.eye(4); a4[:3] = avg
+    back = (a4 @ np.concatenate([cen, np.tile([[[0, 0, 0, 1.]]], (6, 1, 1))], 1))[:, :3]
+    np.testing.assert_allclose(back, poses, atol=1e-12)
+    np.testing.assert_allclose(avg[:, :3].T @ avg[:, :3], np.eye(3), atol=1e-12)
+
+
+def test_frame_block_partition():
+    for n, w in ((8, 8), (1000, 8), (7, 8), (10, 3), (5, 2), (0, 4)):
+        blocks = [ddist.frame_block(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        sizes = [hi - lo for lo, hi in blocks]
+        assert max(sizes) - min(sizes) <= 1
+
+
+_GLOO_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from dfnet_amd import dist as ddist
+rank, world, _ = ddist.init_from_env(backend="gloo")
+n_frames = int(sys.argv[2])
+lo, hi = ddist.frame_block(n_frames, rank, world)
+local = torch.stack([torch.full((3, 4, 3), float(i)) for i in range(lo, hi)]) if hi > lo else torch.zeros(0, 3, 4, 3)
+out = ddist.gather_frames(local, n_frames)
+t = ddist.max_over_ranks(float(rank + 1), torch.device("cpu"))
+assert t == float(world)
+if rank == 0:
+    assert out.shape == (n_frames, 3, 4, 3), out.shape
+    assert all(float(out[i, 0, 0, 0]) == i and float(out[i].min()) == i for i in range(n_frames))
+    print("GATHER_OK", n_frames)
+else:
+    assert out is None
+ddist.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n_frames", [5, 8])
+def test_gather_frames_gloo_world2(tmp_path, n_frames):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER)
+    port = 29611 + n_frames
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(n_frames)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"GATHER_OK {n_frames}" in r.stdout
