@@ -1,0 +1,337 @@
+// dfnet_api.hip — C ABI of the DFNet feature extractor (include/dfnet_hip.h, dfn_dfnet_*):
+// parameter intake with the reference's state_dict names, BatchNorm folding, packing of every
+// convolution into MFMA A-fragments (both precisions), and the forward driver.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/dfnet_hip.h"
+#include "dfn_common.h"
+#include "dfnet_kernels.h"
+#include "nerfh_layout.h"
+
+using namespace dfn;
+
+namespace {
+
+struct ConvSpec {
+  std::string key;  // state_dict prefix, e.g. "encoder.5"
+  int cin, cout, ks;
+  bool relu;        // activation written to out_act
+  bool pool_after;  // VGG max-pool follows
+  int tap;          // hypercolumn level tapped BEFORE the ReLU, or -1
+  int enc_index;    // index in the 31-module encoder (for error messages)
+};
+
+struct PackedConv {
+  char* w[2] = {nullptr, nullptr};  // per precision
+  float* bias = nullptr;            // [cout/32][2][16]
+};
+
+const int kVgg[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, -1, 512, 512, 512, -1, 512, 512, 512, -1};
+
+}  // namespace
+
+struct dfn_dfnet_s {
+  int n_taps = 3, feat_dim = 12;
+  std::vector<ConvSpec> enc;        // 13 encoder convs
+  std::vector<int> tap_channels;    // 64, 256, 512
+  std::map<std::string, std::vector<float>> params;
+  std::map<std::string, std::vector<size_t>> shapes;
+  bool committed = false;
+  std::vector<PackedConv> enc_packed;
+  std::vector<PackedConv> ad1, ad5;  // per tap: 1x1 and BN-folded 5x5
+  float* fc = nullptr;               // fc_w [feat_dim,512] | fc_b
+};
+
+static void build_specs(dfn_dfnet_s* h) {
+  int cin = 3, idx = 0;
+  const int tap_at[3] = {2, 14, 28};
+  for (int v : kVgg) {
+    if (v < 0) { h->enc.back().pool_after = true; ++idx; continue; }
+    ConvSpec s{"encoder." + std::to_string(idx), cin, v, 3, true, false, -1, idx};
+    for (int t = 0; t < h->n_taps; ++t) if (tap_at[t] == idx) s.tap = t;
+    h->enc.push_back(s);
+    h->shapes[s.key + ".weight"] = {size_t(v), size_t(cin), 3, 3};
+    h->shapes[s.key + ".bias"] = {size_t(v)};
+    cin = v;
+    idx += 2;
+  }
+  const int chans[3] = {64, 256, 512};
+  for (int t = 0; t < h->n_taps; ++t) {
+    h->tap_channels.push_back(chans[t]);
+    const std::string p = "adaptation_layers.adapt_layer_" + std::to_string(t);
+    h->shapes[p + ".0.weight"] = {64, size_t(chans[t]), 1, 1};
+    h->shapes[p + ".0.bias"] = {64};
+    h->shapes[p + ".2.weight"] = {128, 64, 5, 5};
+    h->shapes[p + ".2.bias"] = {128};
+    for (const char* k : {".3.weight", ".3.bias", ".3.running_mean", ".3.running_var"}) h->shapes[p + k] = {128};
+  }
+  h->shapes["fc_pose.weight"] = {size_t(h->feat_dim), 512};
+  h->shapes["fc_pose.bias"] = {size_t(h->feat_dim)};
+}
+
+extern "C" int dfn_dfnet_create(int n_taps, int feat_dim, dfn_dfnet_t* out) {
+  if (!out || (n_taps != 1 && n_taps != 3) || feat_dim < 1 || feat_dim > 512)
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_create: n_taps must be 3 (DFNet) or 1 (DFNet_s), 1 <= feat_dim <= 512");
+  auto* h = new dfn_dfnet_s();
+  h->n_taps = n_taps;
+  h->feat_dim = feat_dim;
+  build_specs(h);
+  *out = h;
+  return DFN_OK;
+}
+
+static void free_dev(dfn_dfnet_s* h) {
+  auto drop = [](std::vector<PackedConv>& v) {
+    for (auto& p : v) {
+      for (auto& w : p.w) if (w) (void)hipFree(w);
+      if (p.bias) (void)hipFree(p.bias);
+    }
+    v.clear();
+  };
+  drop(h->enc_packed);
+  drop(h->ad1);
+  drop(h->ad5);
+  if (h->fc) (void)hipFree(h->fc);
+  h->fc = nullptr;
+}
+
+extern "C" int dfn_dfnet_destroy(dfn_dfnet_t h) {
+  if (!h) return DFN_OK;
+  free_dev(h);
+  delete h;
+  return DFN_OK;
+}
+
+extern "C" int dfn_dfnet_set_param(dfn_dfnet_t h, const char* name, const float* host, size_t numel) {
+  if (!h || !name || !host) return set_error(DFN_ERR_ARG, "dfn_dfnet_set_param: null argument");
+  const auto it = h->shapes.find(name);
+  if (it == h->shapes.end()) return set_error(DFN_ERR_ARG, "dfn_dfnet_set_param: unknown parameter '%s'", name);
+  size_t want = 1;
+  for (size_t s : it->second) want *= s;
+  if (want != numel)
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_set_param: '%s' has %zu elements, expected %zu", name, numel, want);
+  h->params[name].assign(host, host + numel);
+  h->committed = false;
+  return DFN_OK;
+}
+
+namespace {
+
+// Channel held in slot s of half hh of input block blk (first layer: only RGB in half 0, slots 0..2).
+inline int in_channel(bool first, int blk, int hh, int s) {
+  if (first) return (hh == 0 && s < 3) ? s : -1;
+  return 32 * blk + 4 * hh + (s & 3) + 8 * (s >> 2);
+}
+
+template <class P>
+void pack_conv(const float* w, int cout, int cin, int ks, bool first, int sb, int mb, std::vector<uint8_t>& blob) {
+  using Elem = typename std::conditional<P::kSlotsPerChunk == 8, _Float16, float>::type;
+  constexpr int SPC = P::kSlotsPerChunk;
+  const int nblk = first ? 1 : cin / 32, kcb = sb / SPC, groups = cout / 32 / mb;
+  blob.assign(size_t(groups) * nblk * ks * mb * ks * kcb * 64 * P::kLaneBytes, 0);
+  Elem* out = reinterpret_cast<Elem*>(blob.data());
+  size_t o = 0;
+  for (int cg = 0; cg < groups; ++cg)
+    for (int blk = 0; blk < nblk; ++blk)
+      for (int ky = 0; ky < ks; ++ky)
+        for (int m = 0; m < mb; ++m)
+          for (int kx = 0; kx < ks; ++kx)
+            for (int kc = 0; kc < kcb; ++kc)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < SPC; ++j, ++o) {
+                  const int co = 32 * (cg * mb + m) + (lane & 31);
+                  const int ci = in_channel(first, blk, lane >> 5, kc * SPC + j);
+                  out[o] = Elem(ci >= 0 && ci < cin ? w[((size_t(co) * cin + ci) * ks + ky) * ks + kx] : 0.f);
+                }
+}
+
+int upload_bytes(const void* src, size_t bytes, void** dst) {
+  if (hipMalloc(dst, bytes ? bytes : 16) != hipSuccess) return set_error(DFN_ERR_HIP, "hipMalloc(%zu) failed", bytes);
+  if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    return set_error(DFN_ERR_HIP, "hipMemcpy H2D (%zu bytes) failed", bytes);
+  return DFN_OK;
+}
+
+int pack_and_upload(const float* w, const float* b, int cout, int cin, int ks, bool first, PackedConv& pc) {
+  for (int prec = 0; prec < 2; ++prec) {
+    const int sb = first ? prep_sb(prec) : 16;
+    const int mb = conv_mb(prec, cout / 32);
+    std::vector<uint8_t> blob;
+    if (prec == 0) pack_conv<PrecF16>(w, cout, cin, ks, first, sb, mb, blob);
+    else pack_conv<PrecF32>(w, cout, cin, ks, first, sb, mb, blob);
+    if (int rc = upload_bytes(blob.data(), blob.size(), reinterpret_cast<void**>(&pc.w[prec]))) return rc;
+  }
+  std::vector<float> bias(size_t(cout / 32) * 32);
+  for (int m = 0; m < cout / 32; ++m)
+    for (int hh = 0; hh < 2; ++hh)
+      for (int r = 0; r < 16; ++r) bias[(m * 2 + hh) * 16 + r] = b[32 * m + mblock_row(hh, r)];
+  return upload_bytes(bias.data(), bias.size() * 4, reinterpret_cast<void**>(&pc.bias));
+}
+
+}  // namespace
+
+extern "C" int dfn_dfnet_commit(dfn_dfnet_t h) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_commit: null handle");
+  for (const auto& kv : h->shapes)
+    if (!h->params.count(kv.first)) return set_error(DFN_ERR_STATE, "dfn_dfnet_commit: parameter '%s' not set", kv.first.c_str());
+  free_dev(h);
+  h->enc_packed.resize(h->enc.size());
+  for (size_t i = 0; i < h->enc.size(); ++i) {
+    const ConvSpec& s = h->enc[i];
+    if (int rc = pack_and_upload(h->params[s.key + ".weight"].data(), h->params[s.key + ".bias"].data(), s.cout, s.cin, 3,
+                                 i == 0, h->enc_packed[i]))
+      return rc;
+  }
+  h->ad1.resize(h->n_taps);
+  h->ad5.resize(h->n_taps);
+  for (int t = 0; t < h->n_taps; ++t) {
+    const std::string p = "adaptation_layers.adapt_layer_" + std::to_string(t);
+    if (int rc = pack_and_upload(h->params[p + ".0.weight"].data(), h->params[p + ".0.bias"].data(), 64, h->tap_channels[t], 1,
+                                 false, h->ad1[t]))
+      return rc;
+    // fold eval-mode BatchNorm2d (eps = 1e-5) into the 5x5 conv: y = (conv + b - mean) * g/sqrt(var+eps) + beta
+    std::vector<float> w5 = h->params[p + ".2.weight"], b5 = h->params[p + ".2.bias"];
+    const auto& g = h->params[p + ".3.weight"];
+    const auto& beta = h->params[p + ".3.bias"];
+    const auto& mu = h->params[p + ".3.running_mean"];
+    const auto& var = h->params[p + ".3.running_var"];
+    for (int co = 0; co < 128; ++co) {
+      const float sc = g[co] / std::sqrt(var[co] + 1e-5f);
+      for (int k = 0; k < 64 * 25; ++k) w5[size_t(co) * 64 * 25 + k] *= sc;
+      b5[co] = (b5[co] - mu[co]) * sc + beta[co];
+    }
+    if (int rc = pack_and_upload(w5.data(), b5.data(), 128, 64, 5, false, h->ad5[t])) return rc;
+  }
+  std::vector<float> fc = h->params["fc_pose.weight"];
+  const auto& fb = h->params["fc_pose.bias"];
+  fc.insert(fc.end(), fb.begin(), fb.end());
+  if (int rc = upload_bytes(fc.data(), fc.size() * 4, reinterpret_cast<void**>(&h->fc))) return rc;
+  h->committed = true;
+  return DFN_OK;
+}
+
+namespace {
+inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+struct DfWs {
+  char *prep, *actA, *actB, *tap[3], *tmp64, *ad128;
+  size_t total;
+};
+DfWs carve_df(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
+  const size_t es = prec == 0 ? 2 : 4;
+  const size_t px = size_t(B) * H * W;
+  DfWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  w.prep = take(px * 2 * prep_sb(prec) * es);
+  w.actA = take(px * 64 * es);
+  w.actB = take(px * 64 * es);
+  const int div[3] = {1, 4, 16};
+  for (int t = 0; t < h->n_taps; ++t) w.tap[t] = take(size_t(B) * (H / div[t]) * (W / div[t]) * h->tap_channels[t] * es);
+  w.tmp64 = take(px * 64 * es);
+  w.ad128 = take(px * 128 * es);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W) {
+  if (!h || B < 1 || H < 1 || W < 1) return 0;
+  return carve_df(h, nullptr, prec, B, H, W).total;
+}
+
+#define HS(s) reinterpret_cast<hipStream_t>(s)
+#define CHECK_HIP(expr, what)                                                                   \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return set_error(DFN_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature,
+                                 int siamese, int return_pose, int upH, int upW, float* features, float* pose,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: null handle");
+  if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_forward: dfn_dfnet_commit() has not been called");
+  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: unknown precision %d", prec);
+  if (!x || !workspace || B < 1 || H < 32 || W < 32 || (return_feature && (!features || upH < 1 || upW < 1)) ||
+      (return_pose && !pose) || (return_feature && siamese && (B & 1)))
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: bad argument (need H,W >= 32; even batch for siamese)");
+  const DfWs w = carve_df(h, static_cast<char*>(workspace), prec, B, H, W);
+  if (w.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  hipStream_t s = HS(stream);
+  CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet: prep");
+  const void* cur = w.prep;
+  char* ping[2] = {w.actA, w.actB};
+  int pp = 0, ch = H, cw = W, nblk = 1;
+  int tap_h[3] = {0, 0, 0}, tap_w[3] = {0, 0, 0};
+  const void* last_act = nullptr;
+  int last_h = 0, last_w = 0;
+  for (size_t i = 0; i < h->enc.size(); ++i) {
+    const ConvSpec& sp = h->enc[i];
+    const bool is_last_tap = sp.tap == h->n_taps - 1;
+    const bool stop_here = is_last_tap && !return_pose;
+    ConvArgs a{};
+    a.in = cur;
+    a.w = h->enc_packed[i].w[prec];
+    a.bias = h->enc_packed[i].bias;
+    a.out_act = stop_here ? nullptr : ping[pp];
+    a.out_pre = (sp.tap >= 0 && return_feature) ? w.tap[sp.tap] : nullptr;
+    a.B = B; a.H = ch; a.W = cw;
+    a.nblk_in = nblk;
+    a.cout_blocks = sp.cout / 32;
+    a.relu = 1;
+    if (a.out_act || a.out_pre)
+      CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet: encoder conv");
+    if (sp.tap >= 0) { tap_h[sp.tap] = ch; tap_w[sp.tap] = cw; }
+    if (stop_here) break;
+    cur = ping[pp];
+    last_act = cur; last_h = ch; last_w = cw;
+    pp ^= 1;
+    nblk = sp.cout / 32;
+    if (sp.pool_after && i + 1 < h->enc.size()) {
+      CHECK_HIP(launch_maxpool(prec, cur, B, ch, cw, nblk, ping[pp], s), "dfnet: maxpool");
+      cur = ping[pp];
+      pp ^= 1;
+      ch /= 2; cw /= 2;
+    }
+  }
+  if (return_feature) {
+    const size_t es = prec == 0 ? 2 : 4;
+    const size_t plane = size_t(128) * upH * upW;
+    for (int t = 0; t < h->n_taps; ++t) {
+      ConvArgs a{};
+      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = h->ad1[t].bias; a.out_act = w.tmp64; a.out_pre = nullptr;
+      a.B = B; a.H = tap_h[t]; a.W = tap_w[t]; a.nblk_in = h->tap_channels[t] / 32; a.cout_blocks = 2; a.relu = 1;
+      CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet: adapt 1x1");
+      ConvArgs c{};
+      c.in = w.tmp64; c.w = h->ad5[t].w[prec]; c.bias = h->ad5[t].bias; c.out_act = w.ad128; c.out_pre = nullptr;
+      c.B = B; c.H = tap_h[t]; c.W = tap_w[t]; c.nblk_in = 2; c.cout_blocks = 4; c.relu = 0;
+      CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet: adapt 5x5");
+      if (!siamese) {
+        CHECK_HIP(launch_upsample(prec, w.ad128, B, tap_h[t], tap_w[t], upH, upW, features + size_t(t) * B * plane, plane, s),
+                  "dfnet: upsample");
+      } else {
+        const int hb = B / 2;
+        for (int half = 0; half < 2; ++half) {
+          const char* src = w.ad128 + size_t(half) * hb * tap_h[t] * tap_w[t] * 128 * es;
+          float* dst = features + (size_t(half) * h->n_taps + t) * hb * plane;
+          CHECK_HIP(launch_upsample(prec, src, hb, tap_h[t], tap_w[t], upH, upW, dst, plane, s), "dfnet: upsample");
+        }
+      }
+    }
+  }
+  if (return_pose) {
+    if (!last_act || last_h < 2 || last_w < 2) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: image too small for pool5");
+    CHECK_HIP(launch_pose_head(prec, last_act, B, last_h, last_w, h->fc, h->fc + size_t(h->feat_dim) * 512, h->feat_dim,
+                               pose, s),
+              "dfnet: pose head");
+  }
+  return DFN_OK;
+}

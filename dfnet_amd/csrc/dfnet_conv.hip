@@ -1,0 +1,329 @@
+// dfnet_conv.hip — DFNet's VGG-style feature pyramid on the CDNA4 matrix cores (gfx950 only).
+//
+// Implicit-GEMM convolution, stride 1, "same" zero padding, KS in {1,3,5}: the weights are the MFMA
+// A operand (M = 32 output channels per M-block), 32 consecutive output pixels of an image row are
+// the B operand (N = 32), the contraction runs over (input-channel block, ky, kx, channel chunk).
+// A workgroup of 4 wavefronts computes an 8x32-pixel output tile for MB M-blocks; each wavefront
+// owns two image rows (NB = 2) so an A fragment feeds 2 MFMAs and a B fragment feeds MB.
+// The input patch (tile + halo) of one 32-channel block sits in LDS with a padded pixel stride
+// (conflict-free ds_read_b128); the weights of one (block, ky) slice stream L2 -> LDS by
+// direct-to-LDS DMA.  Bias is preloaded into the accumulators; the epilogue writes the pre-ReLU
+// hypercolumn tap and/or the ReLU'd activation in the blocked-permuted NHWC layout
+// (dfnet_kernels.h) as one contiguous 32/64-byte run per lane.
+//
+// Replaces (reference): torchvision VGG16 `features` convs driven by
+// /root/reference/script/feature/dfnet.py:121-136 and the AdaptLayers convs (:57-62, BatchNorm
+// folded into the 5x5 weights on the host), the maxpools, UpsamplingBilinear2d (:145) and the
+// GAP+FC pose head (:168-170).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dfnet_kernels.h"
+#include "mfma_frag.h"
+
+namespace dfn {
+
+template <class P> struct ConvGeom;
+template <> struct ConvGeom<PrecF16> { static constexpr int kPad = 16, kVec = 16; };
+template <> struct ConvGeom<PrecF32> { static constexpr int kPad = 4, kVec = 4; };
+
+template <class P, int KS, int SB>
+constexpr int conv_patch_bytes() {
+  constexpr int ps = 2 * SB * int(sizeof(typename FragOf<P>::elem)) + ConvGeom<P>::kPad;
+  return ((kConvTileH + KS - 1) * (kConvTileW + KS - 1) * ps + 15) & ~15;
+}
+template <class P, int KS, int SB, int MB>
+constexpr int conv_wstage_bytes() { return MB * KS * (SB / P::kSlotsPerChunk) * 64 * P::kLaneBytes; }
+
+template <class P, int KS, int SB, int MB>
+__global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
+  using T = typename FragOf<P>::elem;
+  using F = typename FragOf<P>::type;
+  constexpr int SPC = P::kSlotsPerChunk, LB = P::kLaneBytes;
+  constexpr int KCB = SB / SPC;
+  constexpr int TH = kConvTileH, TW = kConvTileW, R = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int PIXB = 2 * SB * int(sizeof(T));
+  constexpr int PS = PIXB + ConvGeom<P>::kPad;
+  constexpr int VEC = ConvGeom<P>::kVec, SEG = PIXB / VEC;
+  constexpr int WST = conv_wstage_bytes<P, KS, SB, MB>();
+  static_assert(WST % 1024 == 0, "weight stage must be whole 1 KiB DMA pieces");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  char* wst = smem + conv_patch_bytes<P, KS, SB>();
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int cg = blockIdx.y, b = blockIdx.z;
+
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const f32x4* bq = reinterpret_cast<const f32x4*>(a.bias + ((cg * MB + mb) * 2 + h) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = bq[q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[mb][0][4 * q + i] = v[i]; acc[mb][1][4 * q + i] = v[i]; }
+    }
+  }
+
+  const char* in = static_cast<const char*>(a.in);
+  for (int blk = 0; blk < a.nblk_in; ++blk) {
+    __syncthreads();  // everyone is done with the previous patch and weight slice
+    for (int e = tid; e < PH * PW * SEG; e += 256) {
+      const int pix = e / SEG, seg = e - pix * SEG;
+      const int py = pix / PW, px = pix - py * PW;
+      const int gy = y0 + py - R, gx = x0 + px - R;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const size_t src = ((((size_t)b * a.H + (ok ? gy : 0)) * a.W + (ok ? gx : 0)) * a.nblk_in + blk) * PIXB + seg * VEC;
+      if constexpr (VEC == 16) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(in + src);
+        *reinterpret_cast<f32x4*>(patch + pix * PS + seg * VEC) = v;
+      } else {
+        float v = 0.f;
+        if (ok) v = *reinterpret_cast<const float*>(in + src);
+        *reinterpret_cast<float*>(patch + pix * PS + seg * VEC) = v;
+      }
+    }
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky) {
+      if (ky) __syncthreads();  // previous slice fully consumed
+      const char* wsrc = a.w + (((size_t)cg * a.nblk_in + blk) * KS + ky) * WST + lane * 16;
+      for (int q = wave * 1024; q < WST; q += 4096)
+        __builtin_amdgcn_global_load_lds((const void*)(wsrc + q), DFN_LDS_PTR(wst + q), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+        for (int kc = 0; kc < KCB; ++kc) {
+          F bf[2];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            bf[nb] = *reinterpret_cast<const F*>(patch + ((2 * wave + nb + ky) * PW + p + kx) * PS +
+                                                 (h * SB + kc * SPC) * int(sizeof(T)));
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const F af = *reinterpret_cast<const F*>(wst + (((mb * KS + kx) * KCB + kc) * 64 + lane) * LB);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma<P>(af, bf[nb], acc[mb][nb]);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: lane (p, h) owns pixel (y0 + 2*wave + nb, x0 + p), 16 results per M-block, contiguous in memory
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int y = y0 + 2 * wave + nb, x = x0 + p;
+    if (y >= a.H || x >= a.W) continue;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const size_t off = ((((size_t)b * a.H + y) * a.W + x) * a.cout_blocks + (cg * MB + mb)) * 32 + 16 * h;
+      alignas(16) T pre[16];
+      alignas(16) T act[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pre[r] = (T)acc[mb][nb][r];
+        act[r] = (T)(a.relu ? fmaxf(acc[mb][nb][r], 0.f) : acc[mb][nb][r]);
+      }
+      constexpr int NV = 16 * int(sizeof(T)) / 16;
+      if (a.out_pre) {
+        f32x4* d = reinterpret_cast<f32x4*>(static_cast<T*>(a.out_pre) + off);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) d[q] = reinterpret_cast<const f32x4*>(pre)[q];
+      }
+      if (a.out_act) {
+        f32x4* d = reinterpret_cast<f32x4*>(static_cast<T*>(a.out_act) + off);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) d[q] = reinterpret_cast<const f32x4*>(act)[q];
+      }
+    }
+  }
+}
+
+template <class P, int KS, int SB, int MB>
+static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t stream) {
+  if (a.cout_blocks % MB) return hipErrorInvalidValue;
+  constexpr int lds = conv_patch_bytes<P, KS, SB>() + conv_wstage_bytes<P, KS, SB, MB>();
+  auto kern = conv_kernel<P, KS, SB, MB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int tiles = ((a.H + kConvTileH - 1) / kConvTileH) * ((a.W + kConvTileW - 1) / kConvTileW);
+  hipLaunchKernelGGL(kern, dim3(tiles, a.cout_blocks / MB, a.B), dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+
+int conv_mb(int prec, int cout_blocks) { return (prec == 0 && cout_blocks % 4 == 0) ? 4 : 2; }
+int prep_sb(int prec) { return prec == 0 ? 8 : 4; }
+
+hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t stream) {
+  const bool wide = a.cout_blocks % 4 == 0;
+  if (prec == 0) {
+    if (sb == 8 && ks == 3) return launch_conv_t<PrecF16, 3, 8, 2>(a, stream);
+    if (sb != 16) return hipErrorInvalidValue;
+    if (ks == 1) return wide ? launch_conv_t<PrecF16, 1, 16, 4>(a, stream) : launch_conv_t<PrecF16, 1, 16, 2>(a, stream);
+    if (ks == 3) return wide ? launch_conv_t<PrecF16, 3, 16, 4>(a, stream) : launch_conv_t<PrecF16, 3, 16, 2>(a, stream);
+    if (ks == 5) return wide ? launch_conv_t<PrecF16, 5, 16, 4>(a, stream) : launch_conv_t<PrecF16, 5, 16, 2>(a, stream);
+  } else {
+    if (sb == 4 && ks == 3) return launch_conv_t<PrecF32, 3, 4, 2>(a, stream);
+    if (sb != 16) return hipErrorInvalidValue;
+    if (ks == 1) return launch_conv_t<PrecF32, 1, 16, 2>(a, stream);
+    if (ks == 3) return launch_conv_t<PrecF32, 3, 16, 2>(a, stream);
+    if (ks == 5) return launch_conv_t<PrecF32, 5, 16, 2>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------ input prep
+template <class T, int SB>
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, int B, int H, int W, T* __restrict__ out) {
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};  // dfnet.py:79-80
+  const size_t n = (size_t)B * H * W, plane = (size_t)H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / plane, r = i - b * plane;
+    T* o = out + i * (2 * SB);
+#pragma unroll
+    for (int s = 0; s < 2 * SB; ++s) o[s] = (T)0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (T)((x[(b * 3 + c) * plane + r] - mean[c]) / stdv[c]);  // half 0, slots 0..2
+  }
+}
+hipError_t launch_dfnet_prep(int prec, const float* x, int B, int H, int W, void* out, hipStream_t stream) {
+  const size_t n = (size_t)B * H * W;
+  const int grid = int((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (prec == 0) hipLaunchKernelGGL((prep_kernel<_Float16, 8>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<_Float16*>(out));
+  else hipLaunchKernelGGL((prep_kernel<float, 4>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<float*>(out));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ 2x2 max pool
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, int B, int H, int W, int C, T* __restrict__ out) {
+  const int Ho = H / 2, Wo = W / 2;
+  constexpr int V = 16 / int(sizeof(T));  // elements per 16-byte vector
+  const int cv = C / V;
+  const size_t n = (size_t)B * Ho * Wo * cv;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = int(i % cv);
+    size_t r = i / cv;
+    const int x = int(r % Wo); r /= Wo;
+    const int y = int(r % Ho);
+    const size_t b = r / Ho;
+    const T* s = in + (((b * H + 2 * y) * W + 2 * x) * (size_t)C) + c * V;
+    alignas(16) T v[4][V];
+    *reinterpret_cast<f32x4*>(v[0]) = *reinterpret_cast<const f32x4*>(s);
+    *reinterpret_cast<f32x4*>(v[1]) = *reinterpret_cast<const f32x4*>(s + C);
+    *reinterpret_cast<f32x4*>(v[2]) = *reinterpret_cast<const f32x4*>(s + (size_t)W * C);
+    *reinterpret_cast<f32x4*>(v[3]) = *reinterpret_cast<const f32x4*>(s + (size_t)W * C + C);
+    alignas(16) T o[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float m = fmaxf(fmaxf((float)v[0][k], (float)v[1][k]), fmaxf((float)v[2][k], (float)v[3][k]));
+      o[k] = (T)m;
+    }
+    *reinterpret_cast<f32x4*>(out + i * V) = *reinterpret_cast<const f32x4*>(o);
+  }
+}
+hipError_t launch_maxpool(int prec, const void* in, int B, int H, int W, int nblk, void* out, hipStream_t stream) {
+  const int C = nblk * 32;
+  const size_t n = (size_t)B * (H / 2) * (W / 2) * C / (prec == 0 ? 8 : 4);
+  if (!n) return hipSuccess;
+  const int grid = int((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  if (prec == 0) hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, static_cast<const _Float16*>(in), B, H, W, C, static_cast<_Float16*>(out));
+  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<const float*>(in), B, H, W, C, static_cast<float*>(out));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ bilinear upsample
+// nn.UpsamplingBilinear2d(size) = align_corners=True: src = dst * (in-1)/(out-1).  One thread per
+// output pixel and 32-channel block; lanes run along X so every fp32 NCHW plane row is written coalesced.
+template <class T>
+__global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ in, int B, int h, int w, int UH, int UW,
+                                                       float* __restrict__ out, size_t out_bstride) {
+  const float sy = UH > 1 ? float(h - 1) / float(UH - 1) : 0.f;
+  const float sx = UW > 1 ? float(w - 1) / float(UW - 1) : 0.f;
+  const size_t n = (size_t)B * 4 * UH * UW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int X = int(i % UW);
+    size_t r = i / UW;
+    const int Y = int(r % UH); r /= UH;
+    const int blk = int(r % 4);
+    const size_t b = r / 4;
+    const float fy = sy * float(Y), fx = sx * float(X);
+    const int yA = int(fy), xA = int(fx);
+    const int yB = yA + (yA < h - 1 ? 1 : 0), xB = xA + (xA < w - 1 ? 1 : 0);
+    const float ly = fy - float(yA), lx = fx - float(xA);
+    const float wy0 = 1.f - ly, wx0 = 1.f - lx;
+    const T* base = in + (b * h * (size_t)w) * 128 + blk * 32;
+    const T* p00 = base + ((size_t)yA * w + xA) * 128;
+    const T* p01 = base + ((size_t)yA * w + xB) * 128;
+    const T* p10 = base + ((size_t)yB * w + xA) * 128;
+    const T* p11 = base + ((size_t)yB * w + xB) * 128;
+    float* o = out + b * out_bstride + (size_t)blk * 32 * UH * UW + (size_t)Y * UW + X;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int e = hh * 16 + s;
+        const int ch = 4 * hh + (s & 3) + 8 * (s >> 2);
+        const float v = wy0 * (wx0 * (float)p00[e] + lx * (float)p01[e]) + ly * (wx0 * (float)p10[e] + lx * (float)p11[e]);
+        o[(size_t)ch * UH * UW] = v;
+      }
+  }
+}
+hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH, int UW, float* out,
+                           size_t out_bstride, hipStream_t stream) {
+  const size_t n = (size_t)B * 4 * UH * UW;
+  if (!n) return hipSuccess;
+  const int grid = int((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  if (prec == 0) hipLaunchKernelGGL(upsample_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, static_cast<const _Float16*>(in), B, h, w, UH, UW, out, out_bstride);
+  else hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<const float*>(in), B, h, w, UH, UW, out, out_bstride);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ pose head
+// relu5_3 -> pool5 (2x2 max) -> AdaptiveAvgPool2d(1) -> Linear(512, feat_dim).  One workgroup per image,
+// thread c owns stored channel position c (512 of them); fc weights are indexed through the permutation.
+template <class T>
+__global__ __launch_bounds__(512) void pose_head_kernel(const T* __restrict__ act, int h, int w, const float* __restrict__ fc_w,
+                                                        const float* __restrict__ fc_b, int feat_dim, float* __restrict__ pose) {
+  __shared__ float pooled[512];
+  const int c = threadIdx.x;  // stored position
+  const size_t b = blockIdx.x;
+  const int ho = h / 2, wo = w / 2;
+  float sum = 0.f;
+  for (int y = 0; y < ho; ++y)
+    for (int x = 0; x < wo; ++x) {
+      const T* s = act + ((b * h + 2 * y) * (size_t)w + 2 * x) * 512 + c;
+      sum += fmaxf(fmaxf((float)s[0], (float)s[512]), fmaxf((float)s[(size_t)w * 512], (float)s[(size_t)w * 512 + 512]));
+    }
+  const int blk = c >> 5, e = c & 31, hh = e >> 4, s = e & 15;
+  const int ch = blk * 32 + 4 * hh + (s & 3) + 8 * (s >> 2);
+  pooled[ch] = sum / float(ho * wo);
+  __syncthreads();
+  if (c < feat_dim) {
+    float accv = fc_b[c];
+    for (int k = 0; k < 512; ++k) accv = fmaf(fc_w[c * 512 + k], pooled[k], accv);
+    pose[b * feat_dim + c] = accv;
+  }
+}
+hipError_t launch_pose_head(int prec, const void* act, int B, int h, int w, const float* fc_w, const float* fc_b,
+                            int feat_dim, float* pose, hipStream_t stream) {
+  if (!B) return hipSuccess;
+  if (prec == 0) hipLaunchKernelGGL(pose_head_kernel<_Float16>, dim3(B), dim3(512), 0, stream, static_cast<const _Float16*>(act), h, w, fc_w, fc_b, feat_dim, pose);
+  else hipLaunchKernelGGL(pose_head_kernel<float>, dim3(B), dim3(512), 0, stream, static_cast<const float*>(act), h, w, fc_w, fc_b, feat_dim, pose);
+  return hipGetLastError();
+}
+
+}  // namespace dfn

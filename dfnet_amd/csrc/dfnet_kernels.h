@@ -1,0 +1,47 @@
+// dfnet_kernels.h — internal launch interface of the DFNet feature-extractor kernels.
+//
+// Activation layout in HBM ("blocked-permuted NHWC"): [B][H][W][C/32][2][16] elements of T (f16 or
+// f32).  Within a 32-channel block, element (h, s) holds true channel 4h + (s&3) + 8(s>>2): exactly
+// the order in which a 32x32 MFMA C fragment leaves lane half h, so a lane stores its 16 results
+// as ONE contiguous 32/64-byte run and the next layer reads its B operand as contiguous 16-byte
+// (f16: 8 slots) or 4-byte (f32: 1 slot) pieces.  The permutation is absorbed into the packed
+// weights on the host (same trick as the NeRF-H MLP, nerfh_layout.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dfn {
+
+constexpr int kConvTileH = 8, kConvTileW = 32;  // output pixels per workgroup: 4 waves x 2 rows x 32 columns
+
+struct ConvArgs {
+  const void* in;      // [B,H,W,nblk_in,2,SB]
+  const char* w;       // packed A fragments: [cout_group][blk][ky][mb][kx][kc][64 lanes][slots/chunk]
+  const float* bias;   // [Cout/32][2][16] in C-fragment order
+  void* out_act;       // [B,H,W,Cout/32,2,16] after the optional ReLU (may be null)
+  void* out_pre;       // same shape, BEFORE the ReLU (hypercolumn tap; may be null)
+  int B, H, W;
+  int nblk_in;         // input channel blocks
+  int cout_blocks;     // Cout/32
+  int relu;
+};
+
+// prec: 0 = f16 MFMA inputs / fp32 accumulate, 1 = exact fp32 MFMA.  ks in {1,3,5}; sb = slots per
+// half per input block (16, or 8/4 for the zero-padded RGB input of conv1_1).
+hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t stream);
+int conv_mb(int prec, int cout_blocks);  // M-blocks (of 32 output channels) one workgroup computes; fixes the packed layout
+
+// x [B,3,H,W] fp32 in [0,1] -> (x-mean)/std in the conv1_1 input layout [B,H,W,1,2,SB0].
+hipError_t launch_dfnet_prep(int prec, const float* x, int B, int H, int W, void* out, hipStream_t stream);
+int prep_sb(int prec);
+// 2x2/2 max pooling on the blocked layout: [B,H,W,nblk,32] -> [B,H/2,W/2,nblk,32].
+hipError_t launch_maxpool(int prec, const void* in, int B, int H, int W, int nblk, void* out, hipStream_t stream);
+// bilinear, align_corners=True, blocked [B,h,w,4,32] T -> fp32 NCHW planes out[b*out_bstride + c*UH*UW + Y*UW + X].
+hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH, int UW, float* out,
+                           size_t out_bstride, hipStream_t stream);
+// pose head: relu'd conv5_3 activations [B,h,w,16,32] -> maxpool2 -> global mean -> fc [feat_dim,512].
+hipError_t launch_pose_head(int prec, const void* act, int B, int h, int w, const float* fc_w, const float* fc_b,
+                            int feat_dim, float* pose, hipStream_t stream);
+
+}  // namespace dfn

@@ -1,0 +1,31 @@
+// mfma_frag.h — precision traits -> MFMA operand types and the matching 32x32 instruction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "nerfh_layout.h"
+
+namespace dfn {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class P> struct FragOf;
+template <> struct FragOf<PrecF16> { using type = half8; using elem = _Float16; };
+template <> struct FragOf<PrecF32> { using type = float; using elem = float; };
+
+// D = A(32 x k) * B(k x 32) + C; A/B lanes: row/col = lane&31, k-half = lane>>5.
+template <class P>
+__device__ __forceinline__ f32x16 mfma(typename FragOf<P>::type a, typename FragOf<P>::type b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 mfma<PrecF16>(half8 a, half8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 mfma<PrecF32>(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+#define DFN_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+}  // namespace dfn

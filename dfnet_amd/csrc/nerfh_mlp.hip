@@ -17,26 +17,9 @@
 #include "nerfh_device.h"
 #include "nerfh_kernels.h"
 #include "nerfh_layout.h"
+#include "mfma_frag.h"
 
 namespace dfn {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-template <class P> struct FragOf;
-template <> struct FragOf<PrecF16> { using type = half8; };
-template <> struct FragOf<PrecF32> { using type = float; };
-
-template <class P> DFN_DEV f32x16 mfma(typename FragOf<P>::type a, typename FragOf<P>::type b, f32x16 c);
-template <> DFN_DEV f32x16 mfma<PrecF16>(half8 a, half8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-template <> DFN_DEV f32x16 mfma<PrecF32>(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
 
 // chunks (B-operand registers groups) per 32 produced features / per n slots
 template <class P> constexpr int chunks_of(int slots) { return slots / P::kSlotsPerChunk; }
@@ -64,7 +47,7 @@ DFN_DEV void stage_issue(const Stager& st, char* smem, int unit, uint32_t lds_of
   const uint32_t off = st.tab[2 * unit], size = st.tab[2 * unit + 1];
   const char* src = st.blob + off + st.lane * 16;
   for (uint32_t p = st.wave * kPiece; p < size; p += 8 * kPiece)
-    __builtin_amdgcn_global_load_lds((const void*)(src + p), LDS_PTR(smem + lds_off + p), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const void*)(src + p), DFN_LDS_PTR(smem + lds_off + p), 16, 0, 0);
 }
 
 // Make unit st.u readable and start streaming the following one into the other buffer.

@@ -1,0 +1,91 @@
+"""Host-side mirror of /root/reference/script/feature/dfnet.py (classes DFNet, DFNet_s).
+
+The modules below are *parameter containers* with the reference's state_dict layout
+(`encoder.<k>.*`, `adaptation_layers.adapt_layer_<i>.{0,2,3}.*`, `fc_pose.*`), so the reference's
+`checkpoint-*.pt` files load unchanged; `forward` has the reference's signature and return
+convention and is evaluated by the HIP feature-extractor (dfn_dfnet_forward).  BatchNorm runs in
+eval mode on this path (reference: train.py:123, utils.py:30-39).
+
+torchvision's pretrained VGG16 weights (dfnet.py:90) are a download and unavailable offline: the
+encoder is created with default Conv2d init; load a checkpoint for real use.
+"""
+import torch
+import torch.nn as nn
+
+from .engine import DfnetEngine
+from .synthetic import VGG16_CFG
+
+
+def _vgg16_features():
+    layers, cin = [], 3
+    for v in VGG16_CFG:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return nn.Sequential(*layers)
+
+
+class AdaptLayers(nn.Module):
+    """adapt_layer_i = Conv1x1(C_i -> 64), ReLU, Conv5x5(64 -> output_dim, pad 2), BatchNorm2d (dfnet.py:42-72)."""
+
+    def __init__(self, channel_sizes, output_dim=128):
+        super().__init__()
+        for i, c in enumerate(channel_sizes):
+            self.add_module("adapt_layer_{}".format(i), nn.Sequential(
+                nn.Conv2d(c, 64, kernel_size=1, stride=1, padding=0), nn.ReLU(),
+                nn.Conv2d(64, output_dim, kernel_size=5, stride=1, padding=2), nn.BatchNorm2d(output_dim)))
+
+
+class _DFNetBase(nn.Module):
+    tap_channels = (64, 256, 512)
+    mean = [0.485, 0.456, 0.406]
+    std = [0.229, 0.224, 0.225]
+
+    def __init__(self, feat_dim=12, places365_model_path='', precision="f32"):
+        super().__init__()
+        self.encoder = _vgg16_features()
+        self.hypercolumn_indices = [2, 14, 28][:len(self.tap_channels)]
+        self.scales = [1, 4, 16][:len(self.tap_channels)]
+        self.adaptation_layers = AdaptLayers(self.tap_channels, 128)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc_pose = nn.Linear(512, feat_dim)
+        self.feat_dim = feat_dim
+        self.precision = precision
+        self._engine = None
+        self._engine_version = None
+
+    def _version(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def engine(self):
+        """The HIP engine holding the current weights (re-packed whenever a parameter tensor changed)."""
+        ver = self._version()
+        if self._engine is None or ver != self._engine_version:
+            if self._engine is None:
+                self._engine = DfnetEngine(len(self.tap_channels), self.feat_dim, self.precision)
+            self._engine.load_numpy({k: v.detach().cpu().numpy() for k, v in self.state_dict().items()})
+            self._engine_version = ver
+        return self._engine
+
+    def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427):
+        """Same contract as dfnet.py:109-172: returns (feature_maps, predict) with feature_maps None,
+        [stack] (single stream: 1 x [L,B,128,H,W]) or [stack_t, stack_r] (siamese: 2 x [L,B/2,128,H,W])."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
+            raise NotImplementedError("DFNet training (autograd through the HIP convs) is not built: call under "
+                                      "torch.no_grad() / .eval(); only the forward is on the hot path")
+        feats, pose = self.engine().forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW)
+        if feats is not None:
+            feats = [feats] if isSingleStream else [feats[0], feats[1]]
+        return feats, pose
+
+
+class DFNet(_DFNetBase):
+    ''' hypercolumns conv1_2, conv3_3, conv5_3 (dfnet.py:74-107) '''
+    tap_channels = (64, 256, 512)
+
+
+class DFNet_s(_DFNetBase):
+    ''' conv1_2 only (dfnet.py:174-207) '''
+    tap_channels = (64,)

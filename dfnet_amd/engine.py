@@ -122,6 +122,63 @@ class NerfHEngine:
         return rgb, disp, acc
 
 
+class DfnetEngine:
+    """DFNet / DFNet_s feature extractor resident on one GPU (convs packed as MFMA fragments)."""
+
+    def __init__(self, n_taps=3, feat_dim=12, precision="f32"):
+        self.lib = _lib.load()
+        self.n_taps, self.feat_dim, self.precision = n_taps, feat_dim, precision
+        self.handle = ctypes.c_void_p()
+        check(self.lib.dfn_dfnet_create(n_taps, feat_dim, ctypes.byref(self.handle)), "dfn_dfnet_create")
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.dfn_dfnet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def load_numpy(self, state):
+        """state: {state_dict key: ndarray} with the reference's DFNet names (num_batches_tracked ignored)."""
+        for name, arr in state.items():
+            if name.endswith("num_batches_tracked"):
+                continue
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            check(self.lib.dfn_dfnet_set_param(self.handle, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
+                  f"dfn_dfnet_set_param({name})")
+        check(self.lib.dfn_dfnet_commit(self.handle), "dfn_dfnet_commit")
+        return self
+
+    def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427,
+                precision=None):
+        """(features, pose): features is None, [n_taps,B,128,uH,uW] (single stream) or a (target, render) pair of
+        [n_taps,B/2,128,uH,uW]; pose is None or [B, feat_dim]."""
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        assert C == 3
+        prec = _lib.PRECISIONS[precision or self.precision]
+        dev = x.device
+        feats = pose = None
+        if return_feature:
+            shape = (self.n_taps, B, 128, upsampleH, upsampleW) if isSingleStream else \
+                (2, self.n_taps, B // 2, 128, upsampleH, upsampleW)
+            feats = torch.empty(shape, device=dev)
+        if return_pose:
+            pose = torch.empty(B, self.feat_dim, device=dev)
+        nbytes = self.lib.dfn_dfnet_workspace_bytes(self.handle, prec, B, H, W)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(self.lib.dfn_dfnet_forward(self.handle, prec, ptr(x), B, H, W, int(return_feature),
+                                         int(not isSingleStream), int(return_pose), int(upsampleH), int(upsampleW),
+                                         ptr(feats), ptr(pose), ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),
+                                         current_stream()), "dfn_dfnet_forward")
+        if return_feature and not isSingleStream:
+            feats = (feats[0], feats[1])
+        return feats, pose
+
+
 # ---------------------------------------------------------------------- weight-free stage wrappers
 def raygen(H, W, focal, c2w, want_viewdirs=True):
     lib = _lib.load()

@@ -140,6 +140,27 @@ int dfn_render_image(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, fl
                      float* disp, float* acc, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ------------------------------------------------------------------ DFNet feature extractor
+ * Replaces feature/dfnet.py:74-172 (class DFNet / DFNet_s: VGG16 `features` stack, AdaptLayers,
+ * UpsamplingBilinear2d, GAP + fc_pose).  n_taps = 3 (DFNet: conv1_2, conv3_3, conv5_3) or 1 (DFNet_s). */
+typedef struct dfn_dfnet_s* dfn_dfnet_t;
+int dfn_dfnet_create(int n_taps, int feat_dim, dfn_dfnet_t* out);
+int dfn_dfnet_destroy(dfn_dfnet_t h);
+/* HOST fp32 buffer; `name` is a state_dict key of the reference module: "encoder.<k>.weight|bias",
+ * "adaptation_layers.adapt_layer_<i>.<0|2>.weight|bias", "...adapt_layer_<i>.3.<weight|bias|running_mean|
+ * running_var>", "fc_pose.weight|bias". */
+int dfn_dfnet_set_param(dfn_dfnet_t h, const char* name, const float* host, size_t numel);
+/* Fold BatchNorm (eval mode, eps 1e-5) into the 5x5 convs, pack all convs into MFMA fragments, upload. */
+int dfn_dfnet_commit(dfn_dfnet_t h);
+size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W);
+/* DFNet.forward (dfnet.py:109-172).  x device [B,3,H,W] in [0,1].  features (if return_feature):
+ * siamese == 0 (isSingleStream): [n_taps, B, 128, upH, upW]; siamese != 0: two stacks
+ * [2][n_taps, B/2, 128, upH, upW] (target half first).  pose (if return_pose): [B, feat_dim].
+ * With return_pose == 0 the encoder stops after the last tap (dfnet.py:133-136). */
+int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature,
+                      int siamese, int return_pose, int upH, int upW, float* features, float* pose,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* Timing aid for bench.py: average device time in ms of the `which` kernel
  * (0 = coarse MLP, 1 = fine MLP) over the launches since the last reset, measured with HIP
  * events on `stream`.  Enabled by dfn_profile_enable(1); costs a sync when read. */

@@ -1,0 +1,112 @@
+"""GPU parity of the DFNet feature extractor (through dfn_dfnet_forward) against the golden vectors
+captured from the reference's DFNet.forward and against the CPU oracle.
+
+Tolerance (north_star: 1e-3 relative fp32): the exact-fp32 MFMA path is held to 2e-5 of the output
+range; the f16-input path to 3e-3 max / 1.2e-3 relative-L2 (13 conv layers of f16 rounding sit at
+~6-7e-4 relative L2 — measured, see DESIGN.md §6 — which is why f32 is this path's default)."""
+import numpy as np
+import pytest
+import torch
+
+from dfnet_amd import engine as eng
+from dfnet_amd import synthetic as syn
+from oracle import dfnet_oracle as dor
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+
+
+def relmax(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert not torch.isnan(a).any()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope="module")
+def net():
+    w = syn.dfnet_weights(3)
+    return eng.DfnetEngine(3, 12).load_numpy(w), {k: T(v) for k, v in w.items()}
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16", 3e-3)])
+def test_dfnet_golden_small(net, gold, prec, tol):
+    E, _ = net
+    g = gold("g8_dfnet_small")
+    cs = int(g["cstride"])
+    x = T(g["x"]).to(DEV)
+    (ft, fr), pose = E.forward(x, True, False, True, 32, 48, precision=prec)
+    assert ft.shape == (3, 1, 128, 32, 48) and fr.shape == (3, 1, 128, 32, 48)
+    for lvl in range(3):
+        assert relmax(ft[lvl, :, ::cs], g["siam_t"][lvl]) < tol, lvl
+        assert relmax(fr[lvl, :, ::cs], g["siam_r"][lvl]) < tol, lvl
+    l2 = torch.sqrt((ft ** 2).sum((1, 2, 3, 4))).cpu().numpy()
+    np.testing.assert_allclose(l2, g["siam_t_l2"], rtol=max(tol, 1e-4))
+    assert relmax(pose, g["pose"]) < tol
+    fs, none = E.forward(x, True, True, False, 40, 56, precision=prec)
+    assert none is None and fs.shape == (3, 2, 128, 40, 56)
+    for lvl in range(3):
+        assert relmax(fs[lvl, :, ::cs], g["single"][lvl]) < tol, lvl
+    none, p_only = E.forward(x, precision=prec)
+    assert none is None and relmax(p_only, g["pose_only"]) < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16", 3e-3)])
+def test_dfnet_golden_120x160(net, gold, prec, tol):
+    E, _ = net
+    g = gold("g8_dfnet_120x160")
+    fs, _ = E.forward(T(g["x"]).to(DEV), True, True, False, 120, 160, precision=prec)
+    full = fs[:, 0]
+    for lvl in range(3):
+        assert relmax(full[lvl, ::8, ::6, ::8], g["sub"][lvl]) < tol, lvl
+    l2 = torch.sqrt((full ** 2).sum((1, 2, 3))).cpu().numpy()
+    np.testing.assert_allclose(l2, g["l2"], rtol=max(tol, 1e-4))
+
+
+def test_dfnet_s_golden(gold):
+    w = syn.dfnet_weights(3, taps=(64,))
+    E = eng.DfnetEngine(1, 12).load_numpy(w)
+    g = gold("g8_dfnet_s_small")
+    fs, pose = E.forward(T(g["x"]).to(DEV), True, True, True, 32, 48)
+    assert fs.shape == (1, 2, 128, 32, 48)
+    assert relmax(fs[0, :, ::int(g["cstride"])], g["single"][0]) < 2e-5 and relmax(pose, g["pose"]) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,uH,uW", [(1, 33, 47, 33, 47), (3, 64, 96, 50, 70), (2, 240, 320, 240, 320)])
+def test_dfnet_vs_oracle_shapes(net, B, H, W, uH, uW):
+    """Ragged sizes (tile remainders, odd pooling) and an upsample that is not the input size."""
+    E, p = net
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H * W))
+    with torch.no_grad():
+        ref, rpose = dor.dfnet_forward(p, x, True, True, True, uH, uW)
+    got, pose = E.forward(x.to(DEV), True, True, True, uH, uW, precision="f32")
+    for lvl in range(3):
+        assert relmax(got[lvl], ref[0][lvl]) < 2e-5, lvl
+    assert relmax(pose, rpose) < 2e-5
+    g16, p16 = E.forward(x.to(DEV), True, True, True, uH, uW, precision="f16")
+    for lvl in range(3):
+        assert rel_l2(g16[lvl], ref[0][lvl]) < 1.2e-3 and relmax(g16[lvl], ref[0][lvl]) < 3e-3, lvl
+
+
+def test_dfnet_module_drop_in(gold):
+    """The nn.Module mirror: reference state_dict in, reference return convention out."""
+    from dfnet_amd.dfnet import DFNet
+    g = gold("g8_dfnet_small")
+    m = DFNet().eval()
+    sd = {k: T(v) for k, v in syn.dfnet_weights(3).items()}
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all("num_batches_tracked" in k for k in missing.missing_keys)
+    with torch.no_grad():
+        feats, pose = m(T(g["x"]).to(DEV), return_feature=True, isSingleStream=False, return_pose=True,
+                        upsampleH=32, upsampleW=48)
+    assert isinstance(feats, list) and len(feats) == 2 and feats[0].shape == (3, 1, 128, 32, 48)
+    assert relmax(feats[1][:, :, ::8], g["siam_r"]) < 2e-5 and relmax(pose, g["pose"]) < 2e-5
+    feats, pose = m(T(g["x"]).to(DEV), return_feature=True, isSingleStream=True, return_pose=False,
+                    upsampleH=40, upsampleW=56)
+    assert pose is None and len(feats) == 1 and relmax(feats[0][:, :, ::8], g["single"]) < 2e-5
