@@ -7,7 +7,7 @@ import ctypes
 import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdfnet_hip.so")
+LIB_PATH = os.environ.get("DFN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdfnet_hip.so")
 
 DFN_PREC_F16 = 0
 DFN_PREC_F32 = 1

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -54,7 +55,7 @@ struct dfn_nerfh_s {
   dfn_nerfh_desc desc;
   std::map<std::string, std::vector<float>> params;
   bool committed = false;
-  PackedNet net[2][2];  // [coarse/fine][prec]
+  PackedNet net[2][2][kVariants];  // [coarse/fine][prec][kernel variant]
   float* extra = nullptr;  // w_dir^T | b_dir | w_tr^T | b_tr | emb_a | emb_t
   RayBiasWeights rb{};
 };
@@ -114,11 +115,12 @@ extern "C" int dfn_nerfh_create(const dfn_nerfh_desc* desc, dfn_nerfh_t* out) {
 
 static void free_packed(dfn_nerfh_s* h) {
   for (auto& a : h->net)
-    for (auto& n : a) {
-      if (n.blob) (void)hipFree(n.blob);
-      if (n.tab) (void)hipFree(n.tab);
-      n = PackedNet();
-    }
+    for (auto& b : a)
+      for (auto& n : b) {
+        if (n.blob) (void)hipFree(n.blob);
+        if (n.tab) (void)hipFree(n.tab);
+        n = PackedNet();
+      }
   if (h->extra) (void)hipFree(h->extra);
   h->extra = nullptr;
 }
@@ -202,7 +204,7 @@ struct Packer {
   static bool unit_has_bias(int layer) { return layer != LY_DIR && layer != LY_TE0; }
 
   template <class P>
-  void pack(bool fine, std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
+  void pack(bool fine, int umb, std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
     using Elem = typename std::conditional<P::kSlotsPerChunk == 8, _Float16, float>::type;
     const int* seq = fine ? kFineSeq : kCoarseSeq;
     const int nl = fine ? kFineLayers : kCoarseLayers;
@@ -210,8 +212,8 @@ struct Packer {
       const int layer = seq[li];
       const LayerShape sh = layer_shape(layer);
       const int KC = sh.slots / P::kSlotsPerChunk;
-      const int group = P::kUnitPerMb ? 1 : sh.mb;
-      for (int mb0 = 0; mb0 < sh.mb; mb0 += group) {
+      for (int mb0 = 0; mb0 < sh.mb; mb0 += umb) {
+        const int group = sh.mb - mb0 < umb ? sh.mb - mb0 : umb;
         const uint32_t bytes = unit_bytes<P>(sh.slots, group);
         const uint32_t off = uint32_t(blob.size());
         blob.resize(off + bytes, 0);
@@ -263,19 +265,20 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
     if (!h->params.count(kv.first)) return set_error(DFN_ERR_STATE, "dfn_nerfh_commit: parameter '%s' not set", kv.first.c_str());
   free_packed(h);
   for (int f = 0; f < 2; ++f)
-    for (int prec = 0; prec < 2; ++prec) {
-      Packer pk{h, f ? "fine." : "coarse."};
-      std::vector<uint8_t> blob;
-      std::vector<uint32_t> tab;
-      if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, blob, tab);
-      else pk.pack<PrecF32>(f, blob, tab);
-      PackedNet& n = h->net[f][prec];
-      int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
-      if (rc) return rc;
-      rc = upload(tab.data(), tab.size() * 4, reinterpret_cast<void**>(&n.tab));
-      if (rc) return rc;
-      n.n_units = int(tab.size() / 2);
-    }
+    for (int prec = 0; prec < 2; ++prec)
+      for (int var = 0; var < kVariants; ++var) {
+        Packer pk{h, f ? "fine." : "coarse."};
+        std::vector<uint8_t> blob;
+        std::vector<uint32_t> tab;
+        if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, unit_mb<PrecF16>(var), blob, tab);
+        else pk.pack<PrecF32>(f, unit_mb<PrecF32>(var), blob, tab);
+        PackedNet& n = h->net[f][prec][var];
+        int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
+        if (rc) return rc;
+        rc = upload(tab.data(), tab.size() * 4, reinterpret_cast<void**>(&n.tab));
+        if (rc) return rc;
+        n.n_units = int(tab.size() / 2);
+      }
   // per-ray-bias weights: transposed tails of dir_encoding.0 / transient_encoding.0 + embeddings
   const dfn_nerfh_desc& d = h->desc;
   const int na = d.hist_bin * d.dim_a, nt = d.hist_bin * d.dim_t, kd = kChDir + na;
@@ -375,6 +378,29 @@ static int check_net(dfn_nerfh_t h, int prec, const char* fn) {
   return DFN_OK;
 }
 
+// Kernel variant: DFN_MLP_VARIANT=0|1|2 (A/B aid, see nerfh_layout.h).
+static int mlp_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DFN_MLP_VARIANT");
+    v = (e && e[0] >= '0' && e[0] < '0' + kVariants) ? e[0] - '0' : 0;
+  }
+  return v;
+}
+
+static unsigned long long* g_timing_buf = nullptr;  // DFN_TIMING builds only (tools/gpu_timing.py)
+extern "C" void dfn_debug_set_timing_buffer(void* p) { g_timing_buf = static_cast<unsigned long long*>(p); }
+
+static int mlp_skew() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DFN_MLP_SKEW");
+    v = e ? atoi(e) : 0;
+    if (v < 0 || v > 64) v = 0;
+  }
+  return v;
+}
+
 extern "C" int dfn_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
                           float* viewdirs, void* stream) {
   if (H < 0 || W < 0 || !c2w || !rays_o || !rays_d || !(focal > 0)) return set_error(DFN_ERR_ARG, "dfn_raygen: bad argument");
@@ -392,10 +418,10 @@ extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, cons
                               int Nc, float near, float far, float* sigma, void* stream) {
   if (int rc = check_net(h, prec, "dfn_mlp_coarse")) return rc;
   if (!rays_o || !rays_d || !sigma || Nc < 1) return set_error(DFN_ERR_ARG, "dfn_mlp_coarse: bad argument");
-  const PackedNet& n = h->net[0][prec];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, (long long)n_rays, Nc, near, far};
+  const PackedNet& n = h->net[0][prec][mlp_variant()];
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, (long long)n_rays, Nc, near, far, nullptr, mlp_skew()};
   ScopedTimer t(0, HS(stream));
-  CHECK_HIP(launch_mlp(false, prec, a, device_cu_count(), HS(stream)), "dfn_mlp_coarse");
+  CHECK_HIP(launch_mlp(false, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_coarse");
   return DFN_OK;
 }
 
@@ -433,10 +459,10 @@ extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const 
     return set_error(DFN_ERR_ARG, "dfn_mlp_fine: bad argument (hist_rows must be 1 or n_rays)");
   float* table = static_cast<float*>(bias_ws);
   CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine(ray_bias)");
-  const PackedNet& n = h->net[1][prec];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, (long long)n_rays, Nf, 0.f, 0.f};
+  const PackedNet& n = h->net[1][prec][mlp_variant()];
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf, mlp_skew()};
   ScopedTimer t(1, HS(stream));
-  CHECK_HIP(launch_mlp(true, prec, a, device_cu_count(), HS(stream)), "dfn_mlp_fine");
+  CHECK_HIP(launch_mlp(true, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_fine");
   return DFN_OK;
 }
 
@@ -485,8 +511,9 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
                 size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far, float* rgb, float* disp,
                 float* acc, float* raw_out, const Workspace& w, hipStream_t s) {
   const int Nf = Nc + Ni;
-  const PackedNet& nc = h->net[0][prec];
-  const PackedNet& nf = h->net[1][prec];
+  const int var = mlp_variant();
+  const PackedNet& nc = h->net[0][prec][var];
+  const PackedNet& nf = h->net[1][prec][var];
   const int cus = device_cu_count();
   const size_t chunk = chunk_rays(n_rays);
   for (size_t r0 = 0; r0 < n_rays; r0 += chunk) {
@@ -497,16 +524,16 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
     float* raw = raw_out ? raw_out + r0 * size_t(Nf) * 9 : w.raw;
     {
-      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, (long long)n, Nc, near, far};
+      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, (long long)n, Nc, near, far, nullptr, mlp_skew()};
       ScopedTimer t(0, s);
-      CHECK_HIP(launch_mlp(false, prec, a, cus, s), "render: coarse MLP");
+      CHECK_HIP(launch_mlp(false, prec, var, a, cus, s), "render: coarse MLP");
     }
     CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s), "render: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.bias, s), "render: ray_bias");
     {
-      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, (long long)n, Nf, 0.f, 0.f};
+      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, (long long)n, Nf, 0.f, 0.f, g_timing_buf, mlp_skew()};
       ScopedTimer t(1, s);
-      CHECK_HIP(launch_mlp(true, prec, a, cus, s), "render: fine MLP");
+      CHECK_HIP(launch_mlp(true, prec, var, a, cus, s), "render: fine MLP");
     }
     CHECK_HIP(launch_composite_fine(raw, w.z, n, Nf, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
                                     disp + r0, acc + r0, nullptr, nullptr, nullptr, s),

@@ -18,9 +18,11 @@ struct MlpArgs {
   long long n_rays;
   int n_samples;
   float near, far;
+  unsigned long long* timing;  // DFN_TIMING builds: per-wave cycle counters [total, dma wait, barrier, tile inputs]
+  int skew;                // de-phasing delay of the second wave per SIMD, in 64-clock units (tuning)
 };
 
-hipError_t launch_mlp(bool fine, int prec, const MlpArgs& a, int n_cu, hipStream_t stream);
+hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream);
 
 // --- stages (nerfh_stages.hip)
 hipError_t launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,

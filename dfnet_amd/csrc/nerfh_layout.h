@@ -80,8 +80,18 @@ DFN_HD constexpr int pe_xyz_feature(int h, int s) {
 }
 
 // Per-precision fragment geometry.
-struct PrecF16 { static constexpr int kSlotsPerChunk = 8, kLaneBytes = 16; static constexpr bool kUnitPerMb = false; };
-struct PrecF32 { static constexpr int kSlotsPerChunk = 1, kLaneBytes = 4;  static constexpr bool kUnitPerMb = true; };
+struct PrecF16 { static constexpr int kSlotsPerChunk = 8, kLaneBytes = 16; };
+struct PrecF32 { static constexpr int kSlotsPerChunk = 1, kLaneBytes = 4; };
+
+// Kernel variants (nerfh_mlp.hip): workgroup width and staging granularity (M-blocks per unit).
+//   variant 0: 8 waves per workgroup, 1 workgroup per CU, a unit = a whole layer (f16) / one M-block (f32)
+//   variant 1: 4 waves per workgroup, 2 workgroups per CU, a unit = 2 M-blocks (f16) / one M-block (f32)
+//   variant 2: 4 waves per workgroup x 4 point blocks, 1 workgroup per CU (1 wave per SIMD, 512 VGPRs), unit as variant 0
+constexpr int kVariants = 3;
+template <class P> DFN_HD constexpr int unit_mb(int variant) {
+  return P::kSlotsPerChunk == 1 ? 1 : (variant == 1 ? 2 : 8);
+}
+DFN_HD constexpr int variant_waves(int variant) { return variant == 0 ? 8 : 4; }
 
 constexpr uint32_t kPiece = 1024;  // staging granule: one wave-wide 16-byte LDS-DMA
 
@@ -92,11 +102,12 @@ template <class P>
 DFN_HD constexpr uint32_t unit_bytes(int slots, int nmb) {
   return align_piece(uint32_t(nmb) * (slots / P::kSlotsPerChunk) * 64 * P::kLaneBytes + uint32_t(nmb) * 2 * 16 * 4);
 }
-// Largest unit of either network (sizes the two LDS staging buffers).
+// Largest unit of either network when at most `umb` M-blocks go into one unit (sizes the two LDS
+// staging buffers): the widest layers are L5 (96 slots, 4 M-blocks) and FIN (64 slots, 5 M-blocks).
 template <class P>
-DFN_HD constexpr uint32_t max_unit_bytes() {
-  return P::kUnitPerMb ? unit_bytes<P>(96, 1) : unit_bytes<P>(96, 4) > unit_bytes<P>(64, 5) ? unit_bytes<P>(96, 4)
-                                                                                               : unit_bytes<P>(64, 5);
+DFN_HD constexpr uint32_t max_unit_bytes(int umb) {
+  const uint32_t a = unit_bytes<P>(96, umb < 4 ? umb : 4), b = unit_bytes<P>(64, umb < 5 ? umb : 5);
+  return a > b ? a : b;
 }
 
 // Per-ray bias table written by the ray-bias kernel and read by the fine kernel:

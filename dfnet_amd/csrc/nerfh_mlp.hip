@@ -1,18 +1,20 @@
 // nerfh_mlp.hip — the NeRF-H MLP on the CDNA4 matrix cores (gfx950 only).
 //
-// One persistent workgroup of 8 wavefronts per CU.  Each wavefront owns NB blocks of 32 sample
+// Persistent workgroups (variant 1: two 4-wave workgroups per CU, running unsynchronised so one's
+// epilogue VALU overlaps the other's MFMAs; variant 0: one 8-wave workgroup).  Each wavefront owns NB blocks of 32 sample
 // points and carries their activations through the WHOLE network in registers: a Linear layer
 // is computed transposed (weights = MFMA A operand, activations = B operand, see
 // nerfh_layout.h), so the fp32 C fragments of layer l, after bias/ReLU and conversion, are the
 // B operand of layer l+1 — no LDS or HBM round trip for activations.  Positional encoding,
 // the point o + d*z, Softplus/Sigmoid heads are fused in.  Only the weights move: every
 // layer's pre-permuted MFMA A-fragments stream L2 -> LDS with direct-to-LDS DMA
-// (global_load_lds_dwordx4) into a double buffer shared by the 8 waves, one barrier per unit.
+// (global_load_lds_dwordx4) into a double buffer shared by the workgroup's waves, one barrier per staging unit.
 //
 // Replaces (reference, /root/reference/script/): models/rendering.py:269-292,305-313 (points),
 // models/nerfw.py:15-95 (run_network_NeRFW), :105-133 (Embedder.embed), :297-354 (NeRFW.forward).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "nerfh_device.h"
 #include "nerfh_kernels.h"
@@ -39,26 +41,45 @@ struct Stager {
   int u;               // unit that the NEXT begin_unit() makes readable
   uint32_t lds_cur;    // LDS byte offset holding (or receiving) unit u
   uint32_t lds_nxt;
-  int lane, wave;
+  int lane, wave, waves;
+  unsigned long long t_sync, t_wait, t_last;  // DFN_TIMING: cycles in unit waits / barrier
+  int skew;            // s_sleep units (64 clk) the second wave of each SIMD waits after every unit barrier
   bool more;           // another tile follows this one (wave-uniform)
 };
 
 DFN_DEV void stage_issue(const Stager& st, char* smem, int unit, uint32_t lds_off) {
   const uint32_t off = st.tab[2 * unit], size = st.tab[2 * unit + 1];
   const char* src = st.blob + off + st.lane * 16;
-  for (uint32_t p = st.wave * kPiece; p < size; p += 8 * kPiece)
+  for (uint32_t p = st.wave * kPiece; p < size; p += st.waves * kPiece)
     __builtin_amdgcn_global_load_lds((const void*)(src + p), DFN_LDS_PTR(smem + lds_off + p), 16, 0, 0);
 }
 
 // Make unit st.u readable and start streaming the following one into the other buffer.
 // Returns the LDS byte offset of the readable unit.
 DFN_DEV uint32_t begin_unit(Stager& st, char* smem) {
+#ifdef DFN_TIMING
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of unit u has landed
+#ifdef DFN_TIMING
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();                                  // everyone's share landed; everyone left unit u-1
+#ifdef DFN_TIMING
+  const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+  st.t_wait += c1 - c0;
+  st.t_sync += c2 - c1;
+#endif
   int nxt = st.u + 1;
   const bool wrap = nxt == st.n_units;
   if (wrap) nxt = 0;
   if (!wrap || st.more) stage_issue(st, smem, nxt, st.lds_nxt);
+  // De-phase the two waves that share a SIMD (waves w and w+4 of an 8-wave workgroup): after the
+  // barrier they would otherwise run MFMA phases and epilogue (VALU) phases in lockstep and never
+  // overlap one's VALU with the other's MFMAs.
+  if (st.skew > 0 && st.wave >= 4) {
+    for (int i = 0; i < st.skew; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   const uint32_t cur = st.lds_cur;
   st.lds_cur = st.lds_nxt;
   st.lds_nxt = cur;
@@ -111,43 +132,123 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
   }
 }
 
+// One eighth of store_hidden: output register pair i (0..7) of an M-block's C fragment.
+template <class P, bool RELU, int OC>
+DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, int i) {
+  if constexpr (P::kSlotsPerChunk == 8) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const int c = i >> 2, j = i & 3;
+    half2v v = {(_Float16)acc[8 * c + 2 * j], (_Float16)acc[8 * c + 2 * j + 1]};
+    if (RELU) {
+      const half2v zero = {0, 0};
+      v = __builtin_elementwise_max(v, zero);
+    }
+    out[2 * mb + c][2 * j] = v[0];
+    out[2 * mb + c][2 * j + 1] = v[1];
+  } else {
+    out[16 * mb + 2 * i] = RELU ? fmaxf(acc[2 * i], 0.f) : acc[2 * i];
+    out[16 * mb + 2 * i + 1] = RELU ? fmaxf(acc[2 * i + 1], 0.f) : acc[2 * i + 1];
+  }
+}
+
 // A layer whose MB output M-blocks feed the next layer, plus (EXTRA) one trailing head M-block
-// whose raw accumulators go back to the caller.  RAYBIAS: accumulators start from a per-lane
-// global table (the per-ray folded bias) instead of the unit's LDS bias.
-template <class P, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS>
+// whose raw accumulators go back to the caller.  Weights arrive in staging units of UMB M-blocks.
+//
+// Software pipeline: inside a staging unit the A fragments form one flat stream t = (m-block, chunk);
+// fragment t+PF is fetched from LDS before the MFMAs of fragment t issue, so the ~100+-cycle LDS
+// latency hides under PF*NB MFMAs instead of stalling every chunk.  The bias is the C operand of
+// each accumulator's FIRST MFMA (no register copies) and is fetched one M-block ahead; RAYBIAS
+// layers preload every accumulator of the layer from the per-ray table at entry (global latency).
+template <class P, int UMB, bool PIPE, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS>
 DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)[NB][KC],
                    typename FragOf<P>::type (&Bout)[NB][(MB ? MB : 1) * chunks_of<P>(16)],
                    f32x16 (&head)[NB], const float* const (&raybias)[NB]) {
+  using F = typename FragOf<P>::type;
   constexpr int TOT = MB + (EXTRA ? 1 : 0);
-  constexpr uint32_t MBW = KC * 64 * P::kLaneBytes;  // bytes of one M-block's fragments
+  constexpr int PF = P::kSlotsPerChunk == 8 ? 3 : 4;  // fragments in flight
+  constexpr uint32_t FB = 64 * P::kLaneBytes;         // bytes of one A fragment
+  constexpr int PPK = (8 + KC - 1) / KC;              // epilogue pieces interleaved per chunk (PIPE)
   const int h = st.lane >> 5;
-  uint32_t ub = 0;
-  if (!P::kUnitPerMb) ub = begin_unit(st, smem);
+  // RAYBIAS: per-ray accumulator seeds come from a global table; with few point blocks all of the
+  // layer's seeds are fetched at entry (latency hidden behind the unit barrier), with NB = 4 they are
+  // fetched per M-block (register budget).
+  constexpr bool RB_ALL = RAYBIAS && NB <= 2;
+  f32x16 rb[RB_ALL ? TOT : 1][NB];
+  if (RB_ALL) {
 #pragma unroll
-  for (int mb = 0; mb < TOT; ++mb) {
-    uint32_t wb, bb;
-    if (P::kUnitPerMb) {
-      ub = begin_unit(st, smem);
-      wb = ub;
-      bb = ub + MBW;
-    } else {
-      wb = ub + mb * MBW;
-      bb = ub + TOT * MBW + mb * 128;
+    for (int mb = 0; mb < TOT; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) rb[mb][nb] = load16(raybias[nb] + (mb * 2 + h) * 16);
+  }
+  // PIPE: the finished accumulators of the previous M-block, converted piecewise between the MFMAs
+  // of the current one (one wave per SIMD has nobody else to overlap its epilogue with).
+  f32x16 pend[PIPE ? NB : 1];  // accumulators of M-block mb-1 while M-block mb runs
+#pragma unroll
+  for (int u0 = 0; u0 < TOT; u0 += UMB) {
+    const int nmb = (TOT - u0) < UMB ? (TOT - u0) : UMB;  // M-blocks in this unit (compile-time after unrolling)
+    const int nt = nmb * KC;
+    const uint32_t ub = begin_unit(st, smem);
+    const char* wl = smem + ub + st.lane * P::kLaneBytes;
+    const char* bl = smem + ub + nmb * KC * FB + h * 64;
+    F a[PF];
+#pragma unroll
+    for (int t = 0; t < PF; ++t)
+      if (t < nt) a[t] = *reinterpret_cast<const F*>(wl + t * FB);
+    f32x16 bias = {};
+    if (!RAYBIAS) bias = load16(reinterpret_cast<const float*>(bl));
+#pragma unroll
+    for (int lm = 0; lm < UMB; ++lm) {
+      if (lm < nmb) {
+        const int mb = u0 + lm;
+        f32x16 acc[NB];
+        f32x16 bias_next = bias;
+        if (RAYBIAS) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = RB_ALL ? rb[RB_ALL ? mb : 0][nb] : load16(raybias[nb] + (mb * 2 + h) * 16);
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int t = lm * KC + kc;
+          const F cur = a[t % PF];
+          if (t + PF < nt) a[t % PF] = *reinterpret_cast<const F*>(wl + (t + PF) * FB);
+          if (kc == 0 && !RAYBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
+          __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this chunk's MFMAs (hipcc otherwise sinks it to its use)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            if (kc == 0) acc[nb] = mfma<P>(cur, Bin[nb][0], RAYBIAS ? acc[nb] : bias);
+            else acc[nb] = mfma<P>(cur, Bin[nb][kc], acc[nb]);
+          }
+          if (PIPE && mb >= 1) {
+#pragma unroll
+            for (int q = 0; q < PPK; ++q) {
+              const int piece = kc * PPK + q;
+              if (piece < 8) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) store_hidden_piece<P, RELU>(pend[nb], Bout[nb], mb - 1, piece);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        bias = bias_next;
+        if (mb < MB) {
+          if (PIPE) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
+          } else {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb);
+          }
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) head[nb] = acc[nb];  // (the M-block before a head is converted during the head's MFMAs)
+        }
+      }
     }
-    f32x16 acc[NB];
+  }
+  if (PIPE && MB >= 1 && !EXTRA) {  // the last M-block has no successor to hide behind
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      if (RAYBIAS) acc[nb] = load16(raybias[nb] + (mb * 2 + h) * 16);
-      else acc[nb] = load16(reinterpret_cast<const float*>(smem + bb + h * 64));
-    }
-    mblock_mma<P, NB, KC>(smem, wb + st.lane * P::kLaneBytes, Bin, acc);
-    if (mb < MB) {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb);
-    } else {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) head[nb] = acc[nb];
-    }
+    for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1);
   }
 }
 
@@ -193,7 +294,7 @@ DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type
 
 // ------------------------------------------------------------------------------------------
 // The 8-layer trunk (xyz_encoding_1..8, skip concat [pe, h] before layer 5).
-template <class P, bool FAST, int NB>
+template <class P, int UMB, bool PIPE, bool FAST, int NB>
 DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
                    typename FragOf<P>::type (&out)[NB][chunks_of<P>(64)]) {
   using F = typename FragOf<P>::type;
@@ -204,13 +305,23 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
   F pe[NB][PC];
   posenc_xyz<P, FAST, NB, PC>(x, h, pe);
   F a[NB][HC], b[NB][HC];
-  layer<P, NB, PC, 4, true, false, false>(st, smem, pe, a, nohead, norb);
-  layer<P, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
-  layer<P, NB, HC, 4, true, false, false>(st, smem, b, a, nohead, norb);
-  layer<P, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
+  layer<P, UMB, PIPE, NB, PC, 4, true, false, false>(st, smem, pe, a, nohead, norb);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, b, a, nohead, norb);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
   {
     F cat[NB][PC + HC];
-    if constexpr (P::kSlotsPerChunk == 8) posenc_xyz<P, FAST, NB, PC>(x, h, pe);  // recompute: cheaper than 32 live VGPRs
+    if constexpr (P::kSlotsPerChunk == 8 && !PIPE) {  // recompute: cheaper than 32 VGPRs live across 4 layers
+      float x2[NB][3];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          x2[nb][c] = x[nb][c];
+          asm volatile("" : "+v"(x2[nb][c]));  // opaque copy: stops the compiler from CSE-ing the two encodings
+        }
+      posenc_xyz<P, FAST, NB, PC>(x2, h, pe);
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -218,26 +329,32 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
 #pragma unroll
       for (int i = 0; i < HC; ++i) cat[nb][PC + i] = b[nb][i];
     }
-    layer<P, NB, PC + HC, 4, true, false, false>(st, smem, cat, a, nohead, norb);
+    layer<P, UMB, PIPE, NB, PC + HC, 4, true, false, false>(st, smem, cat, a, nohead, norb);
   }
-  layer<P, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
-  layer<P, NB, HC, 4, true, false, false>(st, smem, b, a, nohead, norb);
-  layer<P, NB, HC, 4, true, false, false>(st, smem, a, out, nohead, norb);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, b, a, nohead, norb);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, out, nohead, norb);
 }
 
-template <class P> constexpr int nb_of() { return P::kSlotsPerChunk == 8 ? 2 : 1; }
-template <class P> constexpr uint32_t lds_bytes() { return 2 * max_unit_bytes<P>(); }
+template <class P, int UMB> constexpr uint32_t lds_bytes() { return 2 * max_unit_bytes<P>(UMB); }
 
 // ------------------------------------------------------------------------------------------
-template <class P, bool FAST>
-__global__ __launch_bounds__(512, 2) void nerfh_coarse_kernel(MlpArgs a) {
+template <class P, bool FAST, int WAVES, int UMB, int NB>
+__global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1) : 2)) void nerfh_coarse_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NB = nb_of<P>();
-  constexpr int PPT = 8 * NB * 32;
+  constexpr bool PIPE = WAVES == 4 && NB >= 3;  // one wave per SIMD: interleave epilogues into the MFMA stream
+  constexpr int PPT = WAVES * NB * 32;
   using F = typename FragOf<P>::type;
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
-  st.lds_cur = 0; st.lds_nxt = max_unit_bytes<P>();
+  st.lds_cur = 0; st.lds_nxt = max_unit_bytes<P>(UMB);
+  st.waves = WAVES;
+  st.skew = WAVES == 8 ? a.skew : 0;
+  st.t_sync = st.t_wait = 0;
+#ifdef DFN_TIMING
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long t_pro = 0;
+#endif
   st.lane = threadIdx.x & 63;
   st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = st.lane & 31, h = st.lane >> 5;
@@ -262,27 +379,34 @@ __global__ __launch_bounds__(512, 2) void nerfh_coarse_kernel(MlpArgs a) {
         x[nb][c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], z));
     }
     F hid[NB][chunks_of<P>(64)];
-    trunk<P, FAST, NB>(st, smem, x, hid);
+    trunk<P, UMB, PIPE, FAST, NB>(st, smem, x, hid);
     f32x16 head[NB];
     F dummy[NB][chunks_of<P>(16)];
     const float* const norb[NB] = {};
-    layer<P, NB, chunks_of<P>(64), 0, false, true, false>(st, smem, hid, dummy, head, norb);
+    layer<P, UMB, PIPE, NB, chunks_of<P>(64), 0, false, true, false>(st, smem, hid, dummy, head, norb);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       if (h == 0 && pt[nb] < n_pts) a.out[pt[nb]] = softplus(head[nb][0]);
   }
 }
 
-template <class P, bool FAST>
-__global__ __launch_bounds__(512, 2) void nerfh_fine_kernel(MlpArgs a) {
+template <class P, bool FAST, int WAVES, int UMB, int NB>
+__global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1) : 2)) void nerfh_fine_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NB = nb_of<P>();
-  constexpr int PPT = 8 * NB * 32;
+  constexpr bool PIPE = WAVES == 4 && NB >= 3;  // one wave per SIMD: interleave epilogues into the MFMA stream
+  constexpr int PPT = WAVES * NB * 32;
   constexpr int HC = chunks_of<P>(64), QC = chunks_of<P>(32);
   using F = typename FragOf<P>::type;
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
-  st.lds_cur = 0; st.lds_nxt = max_unit_bytes<P>();
+  st.lds_cur = 0; st.lds_nxt = max_unit_bytes<P>(UMB);
+  st.waves = WAVES;
+  st.skew = WAVES == 8 ? a.skew : 0;
+  st.t_sync = st.t_wait = 0;
+#ifdef DFN_TIMING
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long t_pro = 0;
+#endif
   st.lane = threadIdx.x & 63;
   st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = st.lane & 31, h = st.lane >> 5;
@@ -311,19 +435,28 @@ __global__ __launch_bounds__(512, 2) void nerfh_fine_kernel(MlpArgs a) {
     }
     const float* const norb[NB] = {};
     F hid[NB][HC];
-    trunk<P, FAST, NB>(st, smem, x, hid);
+#ifdef DFN_TIMING
+    {
+      const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+      float keep = 0.f;
+      for (int nb = 0; nb < NB; ++nb) keep += x[nb][0] + x[nb][1] + x[nb][2];
+      asm volatile("" ::"v"(keep));   // inputs have arrived
+      t_pro += __builtin_amdgcn_s_memtime() - c0;
+    }
+#endif
+    trunk<P, UMB, PIPE, FAST, NB>(st, smem, x, hid);
     // xyz_encoding_final (no activation) + static_sigma
     F fin[NB][HC];
     f32x16 head[NB];
-    layer<P, NB, HC, 4, false, true, false>(st, smem, hid, fin, head, norb);
+    layer<P, UMB, PIPE, NB, HC, 4, false, true, false>(st, smem, hid, fin, head, norb);
     float o[NB][9];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o[nb][3] = softplus(head[nb][0]);
     // dir_encoding (per-ray bias = b + W[:,128:] [pe_dir, a]) -> static_rgb
     {
       F de[NB][QC], dummy[NB][chunks_of<P>(16)];
-      layer<P, NB, HC, 2, true, false, true>(st, smem, fin, de, head, rb_dir);
-      layer<P, NB, QC, 0, false, true, false>(st, smem, de, dummy, head, norb);
+      layer<P, UMB, PIPE, NB, HC, 2, true, false, true>(st, smem, fin, de, head, rb_dir);
+      layer<P, UMB, PIPE, NB, QC, 0, false, true, false>(st, smem, de, dummy, head, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -332,11 +465,11 @@ __global__ __launch_bounds__(512, 2) void nerfh_fine_kernel(MlpArgs a) {
     // transient branch
     {
       F t0[NB][QC], t1[NB][QC], dummy[NB][chunks_of<P>(16)];
-      layer<P, NB, HC, 2, true, false, true>(st, smem, fin, t0, head, rb_tr);
-      layer<P, NB, QC, 2, true, false, false>(st, smem, t0, t1, head, norb);
-      layer<P, NB, QC, 2, true, false, false>(st, smem, t1, t0, head, norb);
-      layer<P, NB, QC, 2, true, false, false>(st, smem, t0, t1, head, norb);
-      layer<P, NB, QC, 0, false, true, false>(st, smem, t1, dummy, head, norb);
+      layer<P, UMB, PIPE, NB, HC, 2, true, false, true>(st, smem, fin, t0, head, rb_tr);
+      layer<P, UMB, PIPE, NB, QC, 2, true, false, false>(st, smem, t0, t1, head, norb);
+      layer<P, UMB, PIPE, NB, QC, 2, true, false, false>(st, smem, t1, t0, head, norb);
+      layer<P, UMB, PIPE, NB, QC, 2, true, false, false>(st, smem, t0, t1, head, norb);
+      layer<P, UMB, PIPE, NB, QC, 0, false, true, false>(st, smem, t1, dummy, head, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -353,18 +486,33 @@ __global__ __launch_bounds__(512, 2) void nerfh_fine_kernel(MlpArgs a) {
         for (int c = 0; c < 9; ++c) dst[c] = o[nb][c];
       }
   }
+#ifdef DFN_TIMING
+  if (a.timing && st.lane == 0) {
+    unsigned long long* t = a.timing + (blockIdx.x * WAVES + st.wave) * 4;
+    t[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    t[1] = st.t_wait;
+    t[2] = st.t_sync;
+    t[3] = t_pro;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
-template <class P, bool FAST>
+template <class P, bool FAST, int WAVES, int UMB, int NB, int WG_PER_CU>
 static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t stream) {
-  constexpr int PPT = 8 * nb_of<P>() * 32;
+  constexpr int PPT = WAVES * NB * 32;
   const long long n_pts = (long long)a.n_rays * a.n_samples;
   if (n_pts <= 0) return hipSuccess;
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
-  const int grid = int(n_tiles < n_cu ? n_tiles : n_cu);
-  const uint32_t lds = lds_bytes<P>();
-  auto kern = fine ? nerfh_fine_kernel<P, FAST> : nerfh_coarse_kernel<P, FAST>;
+  static int wg_per_cu = 0;
+  if (!wg_per_cu) {
+    const char* e = getenv("DFN_WG_PER_CU");  // tuning aid
+    wg_per_cu = (e && e[0] >= '1' && e[0] <= '8') ? e[0] - '0' : WG_PER_CU;
+  }
+  const long long slots = (long long)n_cu * wg_per_cu;  // resident workgroups
+  const int grid = int(n_tiles < slots ? n_tiles : slots);
+  const uint32_t lds = lds_bytes<P, UMB>();
+  auto kern = fine ? nerfh_fine_kernel<P, FAST, WAVES, UMB, NB> : nerfh_coarse_kernel<P, FAST, WAVES, UMB, NB>;
   static bool attr_done[2] = {false, false};
   if (!attr_done[fine]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -372,13 +520,21 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
     if (e != hipSuccess) return e;
     attr_done[fine] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_mlp(bool fine, int prec, const MlpArgs& a, int n_cu, hipStream_t stream) {
-  if (prec == 0) return launch_one<PrecF16, true>(fine, a, n_cu, stream);
-  return launch_one<PrecF32, false>(fine, a, n_cu, stream);
+// variant 0: 8 waves x NB 2, 1 WG/CU, unit = layer      (2 waves/SIMD, 256 VGPR)
+// variant 1: 4 waves x NB 2, 2 WG/CU, unit = 2 M-blocks  (2 waves/SIMD from different workgroups)
+// variant 2: 4 waves x NB 3, 1 WG/CU, unit = layer      (1 wave/SIMD, 512 registers: epilogues pipelined into the MFMA stream)
+hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
+  if (prec == 0) {
+    if (variant == 0) return launch_one<PrecF16, true, 8, 8, 2, 1>(fine, a, n_cu, stream);
+    if (variant == 1) return launch_one<PrecF16, true, 4, 2, 2, 2>(fine, a, n_cu, stream);
+    return launch_one<PrecF16, true, 4, 8, 3, 1>(fine, a, n_cu, stream);
+  }
+  if (variant == 1) return launch_one<PrecF32, false, 4, 1, 1, 2>(fine, a, n_cu, stream);
+  return launch_one<PrecF32, false, 8, 1, 1, 1>(fine, a, n_cu, stream);
 }
 
 }  // namespace dfn

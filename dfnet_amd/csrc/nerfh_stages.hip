@@ -114,21 +114,41 @@ __global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const f
   const int kd = kChDir + na;  // rows of w_dir
   float* s_wd = sm;                  // [kd][64]
   float* s_wt = s_wd + kd * 64;      // [nt][64]
-  float* s_in = s_wt + nt * 64;      // [2 rays][kd + nt]
+  float* s_in = s_wt + nt * 64;      // [4 rays][kd + nt]
+  float* s_base = s_in + 4 * (kd + nt);  // [2][64] image-constant part (shared histogram)
   for (int i = threadIdx.x; i < kd * 64; i += blockDim.x) s_wd[i] = w.w_dir[i];
   for (int i = threadIdx.x; i < nt * 64; i += blockDim.x) s_wt[i] = w.w_tr[i];
-  const int sub = threadIdx.x >> 7;        // which of the block's 2 rays
-  const int o = threadIdx.x & 127;         // output index: table o>>6, feature o&63
   const int stride_in = kd + nt;
+  const bool shared = hist_rows == 1;
+  auto gather = [&](const float* hrow, float* dst, int i) {  // embedding lookups: a (na) then t (nt)
+    const bool is_a = i < na;
+    const int j = is_a ? i : i - na;
+    const int dim = is_a ? w.dim_a : w.dim_t;
+    long long idx = (long long)hrow[j / dim];  // .long() truncation (nerfw.py:69)
+    idx = idx < 0 ? 0 : (idx >= w.n_vocab ? w.n_vocab - 1 : idx);
+    dst[kChDir + i] = (is_a ? w.emb_a : w.emb_t)[idx * dim + (j % dim)];
+  };
+  if (shared) {  // one histogram for every ray: fold bias + appearance / transient columns once per block
+    for (int i = threadIdx.x; i < na + nt; i += blockDim.x) gather(hist, s_in, i);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int tbl = threadIdx.x >> 6, f = threadIdx.x & 63;
+      float acc = tbl ? w.b_tr[f] : w.b_dir[f];
+      if (tbl == 0) for (int j = kChDir; j < kd; ++j) acc = fmaf(s_wd[j * 64 + f], s_in[j], acc);
+      else for (int j = 0; j < nt; ++j) acc = fmaf(s_wt[j * 64 + f], s_in[kd + j], acc);
+      s_base[threadIdx.x] = acc;
+    }
+  }
+  const int rpb = shared ? 4 : 2;                         // rays per block iteration
+  const int sub = shared ? threadIdx.x >> 6 : threadIdx.x >> 7;
+  const int o = shared ? threadIdx.x & 63 : threadIdx.x & 127;
   float* my_in = s_in + sub * stride_in;
-  for (size_t base = size_t(blockIdx.x) * 2; base < n_rays; base += size_t(gridDim.x) * 2) {
+  for (size_t base = size_t(blockIdx.x) * rpb; base < n_rays; base += size_t(gridDim.x) * rpb) {
     __syncthreads();
     const size_t ray = base + sub;
     const bool ok = ray < n_rays;
     if (ok) {
-      const float* hrow = hist + (hist_rows == 1 ? 0 : ray) * w.hist_bin;
-      // inputs: pe_dir (27) | a | t
-      if (o < 3) {
+      if (o < 3) {  // pe_dir (27): [v, sin(2^k v), cos(2^k v)]
         const float v = viewdirs[ray * 3 + o];
         my_in[o] = v;
         for (int k = 0; k < kLdir; ++k) {
@@ -137,29 +157,35 @@ __global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const f
           my_in[3 + 6 * k + 3 + o] = cosf(v * f);
         }
       }
-      for (int i = o; i < na + nt; i += 128) {
-        const bool is_a = i < na;
-        const int j = is_a ? i : i - na;
-        const int dim = is_a ? w.dim_a : w.dim_t;
-        long long idx = (long long)hrow[j / dim];  // .long() truncation (nerfw.py:69)
-        idx = idx < 0 ? 0 : (idx >= w.n_vocab ? w.n_vocab - 1 : idx);
-        my_in[kChDir + i] = (is_a ? w.emb_a : w.emb_t)[idx * dim + (j % dim)];
+      if (!shared) {
+        const float* hrow = hist + ray * w.hist_bin;
+        for (int i = o; i < na + nt; i += 128) gather(hrow, my_in, i);
       }
     }
     __syncthreads();
     if (ok) {
-      const int tbl = o >> 6, f = o & 63;
-      float acc;
-      if (tbl == 0) {
-        acc = w.b_dir[f];
-        for (int j = 0; j < kd; ++j) acc = fmaf(s_wd[j * 64 + f], my_in[j], acc);
+      auto put = [&](int tbl, int f, float v) {
+        const int mb = f >> 5, row = f & 31;
+        const int h = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+        table[ray * kRayBiasFloats + ((tbl * 2 + mb) * 2 + h) * 16 + r] = v;
+      };
+      if (shared) {
+        float acc = s_base[o];
+        for (int j = 0; j < kChDir; ++j) acc = fmaf(s_wd[j * 64 + o], my_in[j], acc);
+        put(0, o, acc);
+        put(1, o, s_base[64 + o]);
       } else {
-        acc = w.b_tr[f];
-        for (int j = 0; j < nt; ++j) acc = fmaf(s_wt[j * 64 + f], my_in[kd + j], acc);
+        const int tbl = o >> 6, f = o & 63;
+        float acc;
+        if (tbl == 0) {
+          acc = w.b_dir[f];
+          for (int j = 0; j < kd; ++j) acc = fmaf(s_wd[j * 64 + f], my_in[j], acc);
+        } else {
+          acc = w.b_tr[f];
+          for (int j = 0; j < nt; ++j) acc = fmaf(s_wt[j * 64 + f], my_in[kd + j], acc);
+        }
+        put(tbl, f, acc);
       }
-      const int mb = f >> 5, row = f & 31;
-      const int h = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
-      table[ray * kRayBiasFloats + ((tbl * 2 + mb) * 2 + h) * 16 + r] = acc;
     }
   }
 }
@@ -168,8 +194,9 @@ hipError_t launch_ray_bias(const RayBiasWeights& w, const float* viewdirs, const
                            size_t hist_rows, size_t n_rays, float* table, hipStream_t stream) {
   if (!n_rays) return hipSuccess;
   const int na = w.hist_bin * w.dim_a, nt = w.hist_bin * w.dim_t;
-  const size_t lds = size_t((kChDir + na) * 64 + nt * 64 + 2 * (kChDir + na + nt)) * 4;
-  hipLaunchKernelGGL(ray_bias_kernel, dim3(grid_for((n_rays + 1) / 2, 1)), dim3(256), lds, stream, w, viewdirs,
+  const size_t lds = size_t((kChDir + na) * 64 + nt * 64 + 4 * (kChDir + na + nt) + 128) * 4;
+  const size_t rpb = hist_rows == 1 ? 4 : 2;
+  hipLaunchKernelGGL(ray_bias_kernel, dim3(grid_for((n_rays + rpb - 1) / rpb, 1)), dim3(256), lds, stream, w, viewdirs,
                      hist, hist_rows, n_rays, table);
   return hipGetLastError();
 }
@@ -286,8 +313,8 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, size_t n, 
 
 // ------------------------------------------------------------------------------------------ fused sampler
 // sigma [R,Nc] -> z_fine [R,Nc+Ni]: coarse weights over the linspace depths, z_mid bins,
-// sample_pdf(det) on the interior weights, then an exact sort of cat([z, z_samples]) by counting
-// ranks (ties broken by position, so the result is a permutation whatever the inputs).
+// sample_pdf(det) on the interior weights, then an exact sort of cat([z, z_samples]) (fix-up passes +
+// rank merge of two sorted lists; ties: coarse depth first, so the result is always a permutation).
 __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ sigma, size_t n_rays, int Nc, int Ni,
                                                           float near, float far, float* __restrict__ z_fine,
                                                           float* __restrict__ weights_out, float* __restrict__ zs_out) {
@@ -316,16 +343,33 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     wave_sync();
     if (weights_out) for (int i = lane; i < Nc; i += 64) weights_out[ray * Nc + i] = s_w[i];
     if (zs_out) for (int i = lane; i < Ni; i += 64) zs_out[ray * Ni + i] = s_all[Nc + i];
-    // rank sort
+    // Exact sort of cat([z, z_samples]): z is sorted by construction; the inverse-CDF samples are
+    // sorted up to last-ulp inversions at bin boundaries, so a couple of odd-even transposition
+    // passes (repeated until a full pass swaps nothing = sorted) fix them, then the two sorted lists
+    // are merged by rank: rank(z_i) = i + #{samples < z_i}, rank(s_j) = j + #{z <= s_j}.
+    float* zs = s_all + Nc;
+    for (int guard = 0; guard < Ni; ++guard) {
+      bool swapped = false;
+      for (int phase = 0; phase < 2; ++phase) {
+        for (int k = 2 * lane + phase; k + 1 < Ni; k += 128) {
+          const float lo = zs[k], hi = zs[k + 1];
+          if (lo > hi) { zs[k] = hi; zs[k + 1] = lo; swapped = true; }
+        }
+        wave_sync();
+      }
+      if (!__any(swapped)) break;
+    }
     for (int i = lane; i < Nf; i += 64) {
       const float v = s_all[i];
-      int rank = 0;
-      for (int j = 0; j < NfP; j += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(s_all + j);
-        rank += (q.x < v || (q.x == v && j < i)) ? 1 : 0;
-        rank += (q.y < v || (q.y == v && j + 1 < i)) ? 1 : 0;
-        rank += (q.z < v || (q.z == v && j + 2 < i)) ? 1 : 0;
-        rank += (q.w < v || (q.w == v && j + 3 < i)) ? 1 : 0;
+      int lo = 0, hi, rank;
+      if (i < Nc) {  // lower bound in the samples
+        hi = Ni;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zs[mid] < v) lo = mid + 1; else hi = mid; }
+        rank = i + lo;
+      } else {       // upper bound in the coarse depths
+        hi = Nc;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_all[mid] <= v) lo = mid + 1; else hi = mid; }
+        rank = (i - Nc) + lo;
       }
       s_out[rank] = v;
     }

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-wave cycle accounting of the fine MLP kernel (DFN_TIMING build: libdfnet_hip_timing.so)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["DFN_LIB_PATH"] = os.path.join(ROOT, "dfnet_amd", "libdfnet_hip_timing.so")
+sys.path.insert(0, ROOT)
+from dfnet_amd import _lib, engine as eng, synthetic as syn
+lib = _lib.load()
+dev = "cuda:0"
+cw, fw, ea, et = syn.nerfh_weights(0)
+E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
+buf = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
+c2w = torch.from_numpy(syn.orbit_pose(0, 8)).to(dev)
+hist = torch.from_numpy(syn.HIST_IDX).to(dev)
+E.render_image(c2w, 480, 640, 585.0, hist, 64, 128, 0., 2.5)
+lib.dfn_debug_set_timing_buffer.argtypes = [ctypes.c_void_p]
+lib.dfn_debug_set_timing_buffer(ctypes.c_void_p(buf.data_ptr()))
+E.render_image(c2w, 480, 640, 585.0, hist, 64, 128, 0., 2.5)
+torch.cuda.synchronize()
+t = buf.cpu().numpy().reshape(-1, 4).astype(np.float64)
+t = t[t[:, 0] > 0]
+tot = t[:, 0]
+print("waves", len(t), "total cycles/wave mean %.3g" % tot.mean(), "(last launch of the frame)")
+for i, n in ((1, "dma wait (vmcnt0)"), (2, "barrier"), (3, "tile input wait")):
+    print("%-20s %.1f%% (min %.1f%% max %.1f%%)" % (n, 100 * (t[:, i] / tot).mean(), 100 * (t[:, i] / tot).min(), 100 * (t[:, i] / tot).max()))
+w = t.reshape(-1, 8, 4)
+print("per wave-slot mean barrier%:", np.round(100 * (w[:, :, 2] / w[:, :, 0]).mean(0), 1))
+print("per wave-slot mean dma-wait%:", np.round(100 * (w[:, :, 1] / w[:, :, 0]).mean(0), 1))
