@@ -42,21 +42,27 @@ struct Stager {
   uint32_t lds_cur;    // LDS byte offset holding (or receiving) unit u
   uint32_t lds_nxt;
   int lane, wave, waves;
+  uint32_t pf_off, pf_size;  // table entry of the unit the NEXT begin_unit() will start streaming (prefetched)
   unsigned long long t_sync, t_wait, t_last;  // DFN_TIMING: cycles in unit waits / barrier
   int skew;            // s_sleep units (64 clk) the second wave of each SIMD waits after every unit barrier
   bool more;           // another tile follows this one (wave-uniform)
 };
 
-DFN_DEV void stage_issue(const Stager& st, char* smem, int unit, uint32_t lds_off) {
-  const uint32_t off = st.tab[2 * unit], size = st.tab[2 * unit + 1];
+DFN_DEV void stage_issue_at(const Stager& st, char* smem, uint32_t off, uint32_t size, uint32_t lds_off) {
   const char* src = st.blob + off + st.lane * 16;
   for (uint32_t p = st.wave * kPiece; p < size; p += st.waves * kPiece)
     __builtin_amdgcn_global_load_lds((const void*)(src + p), DFN_LDS_PTR(smem + lds_off + p), 16, 0, 0);
+}
+DFN_DEV void stage_issue(const Stager& st, char* smem, int unit, uint32_t lds_off) {
+  stage_issue_at(st, smem, st.tab[2 * unit], st.tab[2 * unit + 1], lds_off);
 }
 
 // Make unit st.u readable and start streaming the following one into the other buffer.
 // Returns the LDS byte offset of the readable unit.
 DFN_DEV uint32_t begin_unit(Stager& st, char* smem) {
+#ifdef DFN_ABL_NOSYNC  // ablation: no DMA, no barrier
+  return st.lds_cur;
+#endif
 #ifdef DFN_TIMING
   const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -73,7 +79,13 @@ DFN_DEV uint32_t begin_unit(Stager& st, char* smem) {
   int nxt = st.u + 1;
   const bool wrap = nxt == st.n_units;
   if (wrap) nxt = 0;
-  if (!wrap || st.more) stage_issue(st, smem, nxt, st.lds_nxt);
+  if (!wrap || st.more) stage_issue_at(st, smem, st.pf_off, st.pf_size, st.lds_nxt);
+  {  // fetch the table entry needed by the next call now, so its scalar-load latency is off the critical path
+    int nn = nxt + 1;
+    if (nn == st.n_units) nn = 0;
+    st.pf_off = st.tab[2 * nn];
+    st.pf_size = st.tab[2 * nn + 1];
+  }
   // De-phase the two waves that share a SIMD (waves w and w+4 of an 8-wave workgroup): after the
   // barrier they would otherwise run MFMA phases and epilogue (VALU) phases in lockstep and never
   // overlap one's VALU with the other's MFMAs.
@@ -114,6 +126,10 @@ DFN_DEV f32x16 load16(const float* p) {
 // C fragment -> B-operand registers of the next layer (ReLU optional).
 template <class P, bool RELU, int OC>
 DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb) {
+#ifdef DFN_ABL_NOEPI  // ablation: no conversion/ReLU work (results are garbage, timing only)
+  asm volatile("" ::"v"(acc));
+  return;
+#endif
   if constexpr (P::kSlotsPerChunk == 8) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -191,9 +207,15 @@ DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)
     const char* wl = smem + ub + st.lane * P::kLaneBytes;
     const char* bl = smem + ub + nmb * KC * FB + h * 64;
     F a[PF];
+#ifdef DFN_ABL_NOLDS
+#define DFN_AFRAG(t) a0_abl
+    const F a0_abl = *reinterpret_cast<const F*>(wl);
+#else
+#define DFN_AFRAG(t) (*reinterpret_cast<const F*>(wl + (t) * FB))
+#endif
 #pragma unroll
     for (int t = 0; t < PF; ++t)
-      if (t < nt) a[t] = *reinterpret_cast<const F*>(wl + t * FB);
+      if (t < nt) a[t] = DFN_AFRAG(t);
     f32x16 bias = {};
     if (!RAYBIAS) bias = load16(reinterpret_cast<const float*>(bl));
 #pragma unroll
@@ -210,7 +232,7 @@ DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)
         for (int kc = 0; kc < KC; ++kc) {
           const int t = lm * KC + kc;
           const F cur = a[t % PF];
-          if (t + PF < nt) a[t % PF] = *reinterpret_cast<const F*>(wl + (t + PF) * FB);
+          if (t + PF < nt) a[t % PF] = DFN_AFRAG(t + PF);
           if (kc == 0 && !RAYBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
           __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this chunk's MFMAs (hipcc otherwise sinks it to its use)
 #pragma unroll
@@ -259,6 +281,11 @@ DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)
 // the reference's sin(x * freq) up to libm rounding.
 template <class P, bool FAST, int NB, int PC>
 DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type (&pe)[NB][PC]) {
+#ifdef DFN_ABL_NOPE  // ablation: no trig (timing only)
+  for (int nb = 0; nb < NB; ++nb)
+    for (int s = 0; s < 32; ++s) set_slot<P>(pe[nb], s, x[nb][s % 3]);
+  return;
+#endif
   const float base = h ? 32.f : 1.f;  // half h owns frequencies 2^(5h) .. 2^(5h+4)
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -363,6 +390,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
   stage_issue(st, smem, 0, st.lds_cur);
+  st.pf_off = st.tab[st.n_units > 1 ? 2 : 0];
+  st.pf_size = st.tab[st.n_units > 1 ? 3 : 1];
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3];
@@ -415,6 +444,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
   stage_issue(st, smem, 0, st.lds_cur);
+  st.pf_off = st.tab[st.n_units > 1 ? 2 : 0];
+  st.pf_size = st.tab[st.n_units > 1 ? 3 : 1];
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3];
