@@ -48,6 +48,7 @@ SIGNATURES = {
                                 _P, _P, _P, _P, _P, c_size_t, _P]),
     "dfn_render_image": (c_int, [_P, c_int, _P, c_int, c_int, c_float, c_float, c_float, c_int, c_int, _P,
                                  _P, _P, _P, _P, c_size_t, _P]),
+    "dfn_upsample_bicubic": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dfn_dfnet_create": (c_int, [c_int, c_int, POINTER(c_void_p)]),
     "dfn_dfnet_destroy": (c_int, [_P]),
     "dfn_dfnet_set_param": (c_int, [_P, c_char_p, _P, c_size_t]),

@@ -448,6 +448,12 @@ extern "C" int dfn_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni
   return DFN_OK;
 }
 
+extern "C" int dfn_upsample_bicubic(const float* in, int H, int W, int C, int outH, int outW, float* out, void* stream) {
+  if (!in || !out || H < 1 || W < 1 || C < 1 || outH < 1 || outW < 1) return set_error(DFN_ERR_ARG, "dfn_upsample_bicubic: bad argument");
+  CHECK_HIP(launch_bicubic(in, H, W, C, outH, outW, out, HS(stream)), "dfn_upsample_bicubic");
+  return DFN_OK;
+}
+
 extern "C" size_t dfn_fine_bias_bytes(size_t n_rays) { return (n_rays ? n_rays : 1) * kRayBiasFloats * sizeof(float); }
 
 extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,

@@ -52,4 +52,6 @@ hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays
                                  int flags, float* rgb, float* disp, float* acc, float* depth,
                                  float* weights, float* beta, hipStream_t stream);
 
+hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream);
+
 }  // namespace dfn

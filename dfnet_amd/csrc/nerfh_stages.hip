@@ -479,4 +479,45 @@ hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ bicubic resize
+// nn.Upsample(size, mode='bicubic') (align_corners=False, A = -0.75, border-replicated taps) on an
+// [H, W, C] image -> [UH, UW, C]: the x4 enlargement of a quarter-resolution render
+// (/root/reference/script/feature/misc.py:230-237, direct_feature_matching.py:344-346).
+DFN_DEV float cubic_w1(float x) { const float A = -0.75f; return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }       // |x| <= 1
+DFN_DEV float cubic_w2(float x) { const float A = -0.75f; return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }  // 1 < |x| < 2
+
+__global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ in, int H, int W, int C, int UH, int UW,
+                                                      float* __restrict__ out) {
+  const float sy = float(H) / float(UH), sx = float(W) / float(UW);
+  const size_t n = size_t(UH) * UW * C;
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    const int c = int(i % C);
+    const int X = int((i / C) % UW), Y = int(i / (size_t(C) * UW));
+    const float fy = sy * (float(Y) + .5f) - .5f, fx = sx * (float(X) + .5f) - .5f;
+    const int iy = int(floorf(fy)), ix = int(floorf(fx));
+    const float ty = fy - float(iy), tx = fx - float(ix);
+    const float wy[4] = {cubic_w2(ty + 1.f), cubic_w1(ty), cubic_w1(1.f - ty), cubic_w2(2.f - ty)};
+    const float wx[4] = {cubic_w2(tx + 1.f), cubic_w1(tx), cubic_w1(1.f - tx), cubic_w2(2.f - tx)};
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = min(max(iy - 1 + a, 0), H - 1);
+      float row = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int xx = min(max(ix - 1 + b, 0), W - 1);
+        row += wx[b] * in[(size_t(yy) * W + xx) * C + c];
+      }
+      acc += wy[a] * row;
+    }
+    out[i] = acc;
+  }
+}
+hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream) {
+  const size_t n = size_t(UH) * UW * C;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(bicubic_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, in, H, W, C, UH, UW, out);
+  return hipGetLastError();
+}
+
 }  // namespace dfn

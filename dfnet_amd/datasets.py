@@ -124,3 +124,35 @@ def load_7Scenes_dataloader_NeRF(args):
     hwf = [train_set.H, train_set.W, train_set.focal]
     idx = np.arange(n_train), np.arange(len(val_set)), np.arange(len(val_set))
     return train_dl, val_dl, hwf, list(idx), np.array([setup["near"], setup["far"]]), None, None
+
+
+def load_7Scenes_dataloader(args):
+    """(train_dl, val_dl, test_dl, hwf, i_split, near, far) for the pose-regression / feature CLIs
+    (load_7Scenes.py:422-495): poses re-centred and axis-flipped but NOT rescaled (the scene rescale is applied
+    later by fix_coord_supp); the datasets carry pose_scale / pose_scale2 / move_all_cam_vec."""
+    if not args.pose_only:
+        raise Exception('load_7Scenes_dataloader() currently only support PoseNet Training, not NeRF training')
+    datadir = osp.normpath(args.datadir)
+    scene, dataset = osp.basename(datadir), osp.basename(osp.dirname(datadir))
+    frames_root = osp.join(osp.dirname(osp.dirname(datadir)), 'deepslam_data', dataset, scene)
+    with open(osp.join(datadir, 'world_setup.json')) as fh:
+        setup = json.load(fh)
+    kw = dict(df=args.df, hist_bin=args.hist_bin)
+    train_set = SevenScenesFrames(frames_root, not args.finetune_unlabel, args.trainskip, **kw)
+    val_set = SevenScenesFrames(frames_root, False, args.testskip, **kw)
+    n_train = len(train_set)
+    allp = np.concatenate([train_set.poses, val_set.poses]).reshape(-1, 3, 4)
+    avg = np.loadtxt(osp.join(datadir, 'pose_avg_stats.txt')) if args.load_pose_avg_stats else None
+    allp, _ = recentre_poses(allp, avg)
+    unit = dict(pose_scale=1, pose_scale2=1.0, move_all_cam_vec=[0., 0., 0.])
+    allp = to_nerf_frame(allp, unit).reshape(-1, 12)
+    train_set.poses, val_set.poses = allp[:n_train], allp[n_train:]
+    for ds in (train_set, val_set):
+        ds.pose_scale, ds.pose_scale2, ds.move_all_cam_vec = setup["pose_scale"], setup["pose_scale2"], setup["move_all_cam_vec"]
+        ds.near, ds.far = setup["near"], setup["far"]
+    train_dl = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=True)
+    val_dl = torch.utils.data.DataLoader(val_set, batch_size=args.val_batch_size, shuffle=False)
+    test_dl = torch.utils.data.DataLoader(val_set, batch_size=1, shuffle=False)
+    hwf = [train_set.H, train_set.W, train_set.focal]
+    idx = [np.arange(n_train), np.arange(len(val_set)), np.arange(len(val_set))]
+    return train_dl, val_dl, test_dl, hwf, idx, float(min(setup["near"], setup["far"])), float(max(setup["near"], setup["far"]))

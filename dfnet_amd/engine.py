@@ -248,3 +248,14 @@ def composite_fine(raw, z, beta_min=0.1, test_time=True, static_only=True, white
     if want_aux:
         out.update(depth=depth, weights=w, beta=beta)
     return out
+
+
+def upsample_bicubic(img, outH, outW):
+    """[H,W,C] -> [outH,outW,C], torch's nn.Upsample(mode='bicubic') semantics (align_corners=False)."""
+    lib = _lib.load()
+    img = _f32c(img)
+    H, W, C = img.shape
+    out = torch.empty(outH, outW, C, device=img.device)
+    check(lib.dfn_upsample_bicubic(ptr(img), H, W, C, int(outH), int(outW), ptr(out), current_stream()),
+          "dfn_upsample_bicubic")
+    return out

@@ -140,6 +140,11 @@ int dfn_render_image(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, fl
                      float* disp, float* acc, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* nn.Upsample(size=(outH,outW), mode='bicubic') (align_corners=False) of an [H,W,C] device image: the
+ * x`tinyscale` enlargement of a low-resolution render (feature/misc.py:230-237,
+ * feature/direct_feature_matching.py:344-346).  out [outH,outW,C]. */
+int dfn_upsample_bicubic(const float* in, int H, int W, int C, int outH, int outW, float* out, void* stream);
+
 /* ------------------------------------------------------------------ DFNet feature extractor
  * Replaces feature/dfnet.py:74-172 (class DFNet / DFNet_s: VGG16 `features` stack, AdaptLayers,
  * UpsamplingBilinear2d, GAP + fc_pose).  n_taps = 3 (DFNet: conv1_2, conv3_3, conv5_3) or 1 (DFNet_s). */

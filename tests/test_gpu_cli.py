@@ -59,3 +59,23 @@ def test_run_nerf_render_test_cli(tmp_path):
             assert int(np.abs(got.astype(int) - want.astype(int)).max()) <= 1  # to8b truncation of a 1e-3 match
             gt = np.asarray(Image.open(os.path.join(d, "000_GT.png")))
             assert int(np.abs(gt.astype(int) - (255 * img[0].permute(1, 2, 0).numpy()).astype(np.uint8).astype(int)).max()) == 0
+
+
+def test_run_feature_render_feature_only_cli(tmp_path):
+    """run_feature.py --render_feature_only on the synthetic tree: NeRF-H quarter-res renders + bicubic x4,
+    siamese DFNet forward, feature PNGs written."""
+    datadir = make_scene(str(tmp_path), n_train=2, n_val=2, H=128, W=160)
+    basedir = str(tmp_path / "logs")
+    cli = ["--config", os.path.join(ROOT, "script", "config_dfnet.txt"), "--render_feature_only", "--datadir", datadir,
+           "--basedir", basedir, "--N_samples", "16", "--N_importance", "32", "--df", "2", "--testskip", "1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "run_feature.py")] + cli, cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "render features done" in r.stdout
+    from PIL import Image
+    for sub in ("target", "rgb"):
+        for i in range(2):
+            p = tmp_path / "tmp" / "nerfh" / sub / f"{i:04d}.png"
+            assert p.exists()
+            a = np.asarray(Image.open(p))
+            assert a.shape == (64, 80) and a.max() == 255 and a.min() == 0

@@ -249,3 +249,42 @@ def test_bad_arguments_raise(scene):
         E.render_rays(o, o, dev(syn.HIST_IDX), 2, 8, 0., 1.)
     with pytest.raises(Exception, match="hist_rows"):
         E.render_rays(o, o, torch.zeros(3, 10, device=DEV), 8, 8, 0., 1.)
+
+
+def test_bicubic_upsample_vs_torch():
+    """dfn_upsample_bicubic == nn.Upsample(size, mode='bicubic') (the tinyimg x4 path, misc.py:230-237)."""
+    g = torch.Generator().manual_seed(3)
+    for (h, w, H, W) in ((30, 40, 120, 160), (60, 80, 240, 320), (7, 5, 20, 33)):
+        img = torch.rand(h, w, 3, generator=g)
+        ref = torch.nn.Upsample(size=(H, W), mode='bicubic')(img.permute(2, 0, 1)[None])[0].permute(1, 2, 0)
+        got = eng.upsample_bicubic(img.to(DEV), H, W)
+        assert relmax(got, ref) < 2e-6
+
+
+def test_render_nerfw_imgs_helper(scene):
+    """feature/misc.py:203-247 mirror: fix_coord_supp + render (+ bicubic when --tinyimg) per frame."""
+    from types import SimpleNamespace
+    from dfnet_amd import feature_misc as fm
+    from dfnet_amd.nerfw import HipQuery
+    E, c, f, ea, et = scene
+    kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=16, N_samples=8, use_viewdirs=True,
+              white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    setup = dict(pose_scale=1.0, pose_scale2=1.0, move_all_cam_vec=[0., 0., 1.0])
+    H, W, focal = 24, 32, 30.0
+    frames = [(torch.rand(1, 3, H, W), T(syn.orbit_pose(k, 8))[:3, :4].reshape(1, 12).clone(), T(syn.HIST_IDX)[None]) for k in range(2)]
+    class DL(list):
+        dataset = frames
+    for tiny in (False, True):
+        args = SimpleNamespace(tinyimg=tiny, tinyscale=4., chunk=32768)
+        targets, rgbs, poses, idxs = fm.render_nerfw_imgs(args, DL(frames), [H, W, focal], DEV, kw, setup)
+        assert targets.shape == (2, H, W, 3) and rgbs.shape == (2, H, W, 3) and poses.shape == (2, 3, 4) and idxs.shape == (2, 1, 10)
+        c2w = torch.eye(4); c2w[:3, :4] = poses[1]; c2w[2, 3] += 1.0   # fix_coord_supp of the reference: t += move
+        h, w, fo = (H // 4, W // 4, focal / 4) if tiny else (H, W, focal)
+        with torch.no_grad():
+            ref = orc.render(h, w, fo, 32768, c, f, ea, et, 8, 16, 0., 2.5, syn.HIST_IDX, c2w=c2w)[0]
+            if tiny:
+                ref = torch.nn.Upsample(size=(H, W), mode='bicubic')(ref.permute(2, 0, 1)[None])[0].permute(1, 2, 0)
+        assert relmax(rgbs[1], ref) < 1e-3
+    a, b = torch.rand(8, 5, 6), torch.rand(8, 5, 6)
+    want = 1 - torch.nn.functional.cosine_similarity(a.reshape(8, -1), b.reshape(8, -1), dim=1, eps=1e-6).mean()
+    assert abs(float(fm.feature_loss(a, b)) - float(want)) < 1e-7
