@@ -86,8 +86,9 @@ struct PrecF32 { static constexpr int kSlotsPerChunk = 1, kLaneBytes = 4; };
 // Kernel variants (nerfh_mlp.hip): workgroup width and staging granularity (M-blocks per unit).
 //   variant 0: 8 waves per workgroup, 1 workgroup per CU, a unit = a whole layer (f16) / one M-block (f32)
 //   variant 1: 4 waves per workgroup, 2 workgroups per CU, a unit = 2 M-blocks (f16) / one M-block (f32)
-//   variant 2: 4 waves per workgroup x 4 point blocks, 1 workgroup per CU (1 wave per SIMD, 512 VGPRs), unit as variant 0
-constexpr int kVariants = 3;
+//   variant 3: variant 0's geometry without the pipelined epilogue (A/B reference)
+//   variant 2: 4 waves per workgroup x 3 point blocks, 1 workgroup per CU (1 wave per SIMD, 512 VGPRs), unit as variant 0
+constexpr int kVariants = 4;
 template <class P> DFN_HD constexpr int unit_mb(int variant) {
   return P::kSlotsPerChunk == 1 ? 1 : (variant == 1 ? 2 : 8);
 }

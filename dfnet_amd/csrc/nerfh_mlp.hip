@@ -44,6 +44,8 @@ struct Stager {
   int lane, wave, waves;
   uint32_t pf_off, pf_size;  // table entry of the unit the NEXT begin_unit() will start streaming (prefetched)
   unsigned long long t_sync, t_wait, t_last;  // DFN_TIMING: cycles in unit waits / barrier
+  unsigned long long* trace;
+  int n_trace;
   int skew;            // s_sleep units (64 clk) the second wave of each SIMD waits after every unit barrier
   bool more;           // another tile follows this one (wave-uniform)
 };
@@ -75,6 +77,11 @@ DFN_DEV uint32_t begin_unit(Stager& st, char* smem) {
   const unsigned long long c2 = __builtin_amdgcn_s_memtime();
   st.t_wait += c1 - c0;
   st.t_sync += c2 - c1;
+  if (st.trace && st.n_trace < 96 && st.lane == 0) {  // timeline of the first units: (enter, after barrier)
+    st.trace[2 * st.n_trace] = c0;
+    st.trace[2 * st.n_trace + 1] = c2;
+  }
+  ++st.n_trace;
 #endif
   int nxt = st.u + 1;
   const bool wrap = nxt == st.n_units;
@@ -148,22 +155,33 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
   }
 }
 
-// One eighth of store_hidden: output register pair i (0..7) of an M-block's C fragment.
+// One eighth of store_hidden: output register pair i (0..7) of an M-block's C fragment.  The two empty
+// asm statements anchor the conversion at this point of the instruction stream: without them LLVM treats the
+// pure arithmetic as freely movable and sinks it out from between the MFMAs it is meant to hide behind.
 template <class P, bool RELU, int OC>
 DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, int i) {
   if constexpr (P::kSlotsPerChunk == 8) {
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const int c = i >> 2, j = i & 3;
-    half2v v = {(_Float16)acc[8 * c + 2 * j], (_Float16)acc[8 * c + 2 * j + 1]};
-    if (RELU) {
-      const half2v zero = {0, 0};
-      v = __builtin_elementwise_max(v, zero);
-    }
+    // volatile asm = fixed position in the instruction stream (between the MFMAs it hides behind), plain
+    // register reads of the finished accumulators, no copies.  The accumulators read here were written by
+    // MFMAs at least three MFMA issues earlier, which covers the XDL-write -> VALU-read wait states.
+    uint32_t bits;
+    if (RELU)
+      asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(bits) : "v"(acc[8 * c + 2 * j]), "v"(acc[8 * c + 2 * j + 1]));
+    else
+      asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bits) : "v"(acc[8 * c + 2 * j]), "v"(acc[8 * c + 2 * j + 1]));
+    const half2v v = __builtin_bit_cast(half2v, bits);
     out[2 * mb + c][2 * j] = v[0];
     out[2 * mb + c][2 * j + 1] = v[1];
   } else {
-    out[16 * mb + 2 * i] = RELU ? fmaxf(acc[2 * i], 0.f) : acc[2 * i];
-    out[16 * mb + 2 * i + 1] = RELU ? fmaxf(acc[2 * i + 1], 0.f) : acc[2 * i + 1];
+    float x0 = acc[2 * i], x1 = acc[2 * i + 1];
+    asm volatile("" : "+v"(x0), "+v"(x1));
+    x0 = RELU ? fmaxf(x0, 0.f) : x0;
+    x1 = RELU ? fmaxf(x1, 0.f) : x1;
+    asm volatile("" : "+v"(x0), "+v"(x1));
+    out[16 * mb + 2 * i] = x0;
+    out[16 * mb + 2 * i + 1] = x1;
   }
 }
 
@@ -183,7 +201,7 @@ DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)
   constexpr int TOT = MB + (EXTRA ? 1 : 0);
   constexpr int PF = P::kSlotsPerChunk == 8 ? 3 : 4;  // fragments in flight
   constexpr uint32_t FB = 64 * P::kLaneBytes;         // bytes of one A fragment
-  constexpr int PPK = (8 + KC - 1) / KC;              // epilogue pieces interleaved per chunk (PIPE)
+  constexpr int PPK = (8 * NB + KC - 1) / KC;         // epilogue pieces (of 8 per point block) interleaved per chunk (PIPE)
   const int h = st.lane >> 5;
   // RAYBIAS: per-ray accumulator seeds come from a global table; with few point blocks all of the
   // layer's seeds are fetched at entry (latency hidden behind the unit barrier), with NB = 4 they are
@@ -233,21 +251,18 @@ DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)
           const int t = lm * KC + kc;
           const F cur = a[t % PF];
           if (t + PF < nt) a[t % PF] = DFN_AFRAG(t + PF);
-          if (kc == 0 && !RAYBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
+          if (kc == (PIPE ? KC / 2 : 0) && !RAYBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
           __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this chunk's MFMAs (hipcc otherwise sinks it to its use)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             if (kc == 0) acc[nb] = mfma<P>(cur, Bin[nb][0], RAYBIAS ? acc[nb] : bias);
             else acc[nb] = mfma<P>(cur, Bin[nb][kc], acc[nb]);
           }
-          if (PIPE && mb >= 1) {
+          if (PIPE && mb >= 1) {  // previous M-block's conversion, block by block (frees pend[0] first)
 #pragma unroll
             for (int q = 0; q < PPK; ++q) {
               const int piece = kc * PPK + q;
-              if (piece < 8) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) store_hidden_piece<P, RELU>(pend[nb], Bout[nb], mb - 1, piece);
-              }
+              if (piece < 8 * NB) store_hidden_piece<P, RELU>(pend[piece >> 3], Bout[piece >> 3], mb - 1, piece & 7);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -293,16 +308,13 @@ DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type
     for (int c = 0; c < 3; ++c) {
       const float xc = x[nb][c];
       if (FAST) {
-        float uh, ul;
+        float uh, ul, sn[5], cs[5];
         rev_split(xc, uh, ul);
-        uh *= base;
-        ul *= base;
+        rev_sincos_octaves5(uh, ul, base, sn, cs);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-          float sn, cs;
-          rev_sincos(uh, ul, float(1 << k), sn, cs);
-          set_slot<P>(pe[nb], 6 * k + c, sn);
-          set_slot<P>(pe[nb], 6 * k + 3 + c, cs);
+          set_slot<P>(pe[nb], 6 * k + c, sn[k]);
+          set_slot<P>(pe[nb], 6 * k + 3 + c, cs[k]);
         }
       } else {
         const float xb = xc * base;
@@ -366,10 +378,9 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
 template <class P, int UMB> constexpr uint32_t lds_bytes() { return 2 * max_unit_bytes<P>(UMB); }
 
 // ------------------------------------------------------------------------------------------
-template <class P, bool FAST, int WAVES, int UMB, int NB>
+template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE>
 __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1) : 2)) void nerfh_coarse_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool PIPE = WAVES == 4 && NB >= 3;  // one wave per SIMD: interleave epilogues into the MFMA stream
   constexpr int PPT = WAVES * NB * 32;
   using F = typename FragOf<P>::type;
   Stager st;
@@ -378,9 +389,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   st.waves = WAVES;
   st.skew = WAVES == 8 ? a.skew : 0;
   st.t_sync = st.t_wait = 0;
+  st.trace = nullptr;
+  st.n_trace = 0;
 #ifdef DFN_TIMING
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_pro = 0;
+  if (a.timing && blockIdx.x == 7) st.trace = a.timing + 8192 * 4 + st.wave * 192;  // after the per-wave totals
 #endif
   st.lane = threadIdx.x & 63;
   st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -415,14 +429,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
     layer<P, UMB, PIPE, NB, chunks_of<P>(64), 0, false, true, false>(st, smem, hid, dummy, head, norb);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-      if (h == 0 && pt[nb] < n_pts) a.out[pt[nb]] = softplus(head[nb][0]);
+      if (h == 0 && pt[nb] < n_pts) a.out[pt[nb]] = act_softplus<FAST>(head[nb][0]);
   }
 }
 
-template <class P, bool FAST, int WAVES, int UMB, int NB>
+template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE>
 __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1) : 2)) void nerfh_fine_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool PIPE = WAVES == 4 && NB >= 3;  // one wave per SIMD: interleave epilogues into the MFMA stream
   constexpr int PPT = WAVES * NB * 32;
   constexpr int HC = chunks_of<P>(64), QC = chunks_of<P>(32);
   using F = typename FragOf<P>::type;
@@ -432,9 +445,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   st.waves = WAVES;
   st.skew = WAVES == 8 ? a.skew : 0;
   st.t_sync = st.t_wait = 0;
+  st.trace = nullptr;
+  st.n_trace = 0;
 #ifdef DFN_TIMING
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_pro = 0;
+  if (a.timing && blockIdx.x == 7) st.trace = a.timing + 8192 * 4 + st.wave * 192;  // after the per-wave totals
 #endif
   st.lane = threadIdx.x & 63;
   st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
     layer<P, UMB, PIPE, NB, HC, 4, false, true, false>(st, smem, hid, fin, head, norb);
     float o[NB][9];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) o[nb][3] = softplus(head[nb][0]);
+    for (int nb = 0; nb < NB; ++nb) o[nb][3] = act_softplus<FAST>(head[nb][0]);
     // dir_encoding (per-ray bias = b + W[:,128:] [pe_dir, a]) -> static_rgb
     {
       F de[NB][QC], dummy[NB][chunks_of<P>(16)];
@@ -491,7 +507,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[nb][c] = sigmoid(head[nb][c]);
+        for (int c = 0; c < 3; ++c) o[nb][c] = act_sigmoid<FAST>(head[nb][c]);
     }
     // transient branch
     {
@@ -504,9 +520,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[nb][4 + c] = sigmoid(head[nb][c]);
-        o[nb][7] = softplus(head[nb][3]);
-        o[nb][8] = softplus(head[nb][4]);  // C register 4 of half 0 = row 8 = transient_beta
+        for (int c = 0; c < 3; ++c) o[nb][4 + c] = act_sigmoid<FAST>(head[nb][c]);
+        o[nb][7] = act_softplus<FAST>(head[nb][3]);
+        o[nb][8] = act_softplus<FAST>(head[nb][4]);  // C register 4 of half 0 = row 8 = transient_beta
       }
     }
 #pragma unroll
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
 }
 
 // ------------------------------------------------------------------------------------------
-template <class P, bool FAST, int WAVES, int UMB, int NB, int WG_PER_CU>
+template <class P, bool FAST, int WAVES, int UMB, int NB, int WG_PER_CU, bool PIPE>
 static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t stream) {
   constexpr int PPT = WAVES * NB * 32;
   const long long n_pts = (long long)a.n_rays * a.n_samples;
@@ -543,7 +559,7 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
   const long long slots = (long long)n_cu * wg_per_cu;  // resident workgroups
   const int grid = int(n_tiles < slots ? n_tiles : slots);
   const uint32_t lds = lds_bytes<P, UMB>();
-  auto kern = fine ? nerfh_fine_kernel<P, FAST, WAVES, UMB, NB> : nerfh_coarse_kernel<P, FAST, WAVES, UMB, NB>;
+  auto kern = fine ? nerfh_fine_kernel<P, FAST, WAVES, UMB, NB, PIPE> : nerfh_coarse_kernel<P, FAST, WAVES, UMB, NB, PIPE>;
   static bool attr_done[2] = {false, false};
   if (!attr_done[fine]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -555,17 +571,19 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
   return hipGetLastError();
 }
 
-// variant 0: 8 waves x NB 2, 1 WG/CU, unit = layer      (2 waves/SIMD, 256 VGPR)
+// variant 0: 8 waves x NB 2, 1 WG/CU, unit = layer, epilogue pipelined into the next M-block's MFMAs
 // variant 1: 4 waves x NB 2, 2 WG/CU, unit = 2 M-blocks  (2 waves/SIMD from different workgroups)
-// variant 2: 4 waves x NB 3, 1 WG/CU, unit = layer      (1 wave/SIMD, 512 registers: epilogues pipelined into the MFMA stream)
+// variant 2: 4 waves x NB 3, 1 WG/CU, unit = layer      (1 wave/SIMD, 512 registers, pipelined epilogue)
+// variant 3: variant 0 without the pipelined epilogue (A/B reference)
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
   if (prec == 0) {
-    if (variant == 0) return launch_one<PrecF16, true, 8, 8, 2, 1>(fine, a, n_cu, stream);
-    if (variant == 1) return launch_one<PrecF16, true, 4, 2, 2, 2>(fine, a, n_cu, stream);
-    return launch_one<PrecF16, true, 4, 8, 3, 1>(fine, a, n_cu, stream);
+    if (variant == 0) return launch_one<PrecF16, true, 8, 8, 2, 1, true>(fine, a, n_cu, stream);
+    if (variant == 1) return launch_one<PrecF16, true, 4, 2, 2, 2, false>(fine, a, n_cu, stream);
+    if (variant == 2) return launch_one<PrecF16, true, 4, 8, 3, 1, true>(fine, a, n_cu, stream);
+    return launch_one<PrecF16, true, 8, 8, 2, 1, false>(fine, a, n_cu, stream);
   }
-  if (variant == 1) return launch_one<PrecF32, false, 4, 1, 1, 2>(fine, a, n_cu, stream);
-  return launch_one<PrecF32, false, 8, 1, 1, 1>(fine, a, n_cu, stream);
+  if (variant == 1) return launch_one<PrecF32, false, 4, 1, 1, 2, false>(fine, a, n_cu, stream);
+  return launch_one<PrecF32, false, 8, 1, 1, 1, false>(fine, a, n_cu, stream);
 }
 
 }  // namespace dfn

@@ -85,11 +85,18 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x
       o[c] = xc;
       float uh, ul;
       rev_split(xc, uh, ul);
+      float s5[5], c5[5];
       for (int k = 0; k < L; ++k) {
         const float f = float(1u << k);
         float s, cs;
-        if (mode == 1) rev_sincos(uh, ul, f, s, cs);
-        else { s = sinf(xc * f); cs = cosf(xc * f); }
+        if (mode == 1) {  // exactly what the f16 MLP kernels do: groups of five octaves from one sin/cos
+          if (k % 5 == 0) rev_sincos_octaves5(uh, ul, f, s5, c5);
+          s = s5[k % 5];
+          cs = c5[k % 5];
+        } else {
+          s = sinf(xc * f);
+          cs = cosf(xc * f);
+        }
         o[3 + 6 * k + c] = s;
         o[3 + 6 * k + 3 + c] = cs;
       }

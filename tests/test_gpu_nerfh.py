@@ -50,14 +50,14 @@ def test_posenc_golden(gold):
     g = gold("g2_posenc")
     assert relmax(eng.posenc(dev(g["x"]), 10), g["pe_xyz"]) < 3e-7      # full-range sinf/cosf
     assert relmax(eng.posenc(dev(g["d"]), 4), g["pe_dir"]) < 3e-7
-    assert relmax(eng.posenc(dev(g["x"]), 10, fast=True), g["pe_xyz"]) < 2e-6  # v_sin/v_cos path of the f16 kernel
+    assert relmax(eng.posenc(dev(g["x"]), 10, fast=True), g["pe_xyz"]) < 2e-5  # v_sin/v_cos + double-angle path of the f16 kernel
 
 
 def test_posenc_fast_range():
     # |x| up to 4 -> arguments up to 2^9*4 = 2048 rad, beyond the 7-Scenes scene bounds
     x = (torch.rand(50000, 3) * 8 - 4)
     ref = torch.cat([x.double()] + [f(x.double() * 2.0 ** k) for k in range(10) for f in (torch.sin, torch.cos)], -1)
-    assert float((eng.posenc(x.to(DEV), 10, fast=True).cpu().double() - ref).abs().max()) < 2e-6
+    assert float((eng.posenc(x.to(DEV), 10, fast=True).cpu().double() - ref).abs().max()) < 2e-5  # 30x below f16 rounding
     assert float((eng.posenc(x.to(DEV), 10).cpu().double() - ref).abs().max()) < 2e-7
 
 

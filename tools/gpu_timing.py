@@ -10,7 +10,8 @@ lib = _lib.load()
 dev = "cuda:0"
 cw, fw, ea, et = syn.nerfh_weights(0)
 E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
-buf = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
+NW = 8192
+buf = torch.zeros(NW * 4 + 8 * 192 + 64, dtype=torch.int64, device=dev)
 c2w = torch.from_numpy(syn.orbit_pose(0, 8)).to(dev)
 hist = torch.from_numpy(syn.HIST_IDX).to(dev)
 E.render_image(c2w, 480, 640, 585.0, hist, 64, 128, 0., 2.5)
@@ -18,7 +19,8 @@ lib.dfn_debug_set_timing_buffer.argtypes = [ctypes.c_void_p]
 lib.dfn_debug_set_timing_buffer(ctypes.c_void_p(buf.data_ptr()))
 E.render_image(c2w, 480, 640, 585.0, hist, 64, 128, 0., 2.5)
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(-1, 4).astype(np.float64)
+raw = buf.cpu().numpy()
+t = raw[:NW * 4].reshape(-1, 4).astype(np.float64)
 t = t[t[:, 0] > 0]
 tot = t[:, 0]
 print("waves", len(t), "total cycles/wave mean %.3g" % tot.mean(), "(last launch of the frame)")
@@ -27,3 +29,10 @@ for i, n in ((1, "dma wait (vmcnt0)"), (2, "barrier"), (3, "tile input wait")):
 w = t.reshape(-1, 8, 4)
 print("per wave-slot mean barrier%:", np.round(100 * (w[:, :, 2] / w[:, :, 0]).mean(0), 1))
 print("per wave-slot mean dma-wait%:", np.round(100 * (w[:, :, 1] / w[:, :, 0]).mean(0), 1))
+
+tr = raw[NW * 4: NW * 4 + 8 * 192].reshape(8, 96, 2).astype(np.int64)
+base = tr[:, 0, 0].min()
+print("timeline of workgroup 7: per unit u, waves 0 and 4: enter barrier, released, busy until next enter")
+for u in range(0, 34):
+    e0, r0 = tr[0, u] - base; e4, r4 = tr[4, u] - base
+    print(f"u{u:2d}  w0 enter {e0:7d} rel {r0:7d} busy {tr[0, u + 1, 0] - base - r0:6d} | w4 enter {e4:7d} rel {r4:7d} busy {tr[4, u + 1, 0] - base - r4:6d}")
