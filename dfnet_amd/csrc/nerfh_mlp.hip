@@ -46,6 +46,7 @@ struct Stager {
   unsigned long long t_sync, t_wait, t_last;  // DFN_TIMING: cycles in unit waits / barrier
   unsigned long long* trace;
   int n_trace;
+  int younger_loads;   // global loads issued AFTER this unit's DMA that may stay in flight across the next begin_unit()
   int skew;            // s_sleep units (64 clk) the second wave of each SIMD waits after every unit barrier
   bool more;           // another tile follows this one (wave-uniform)
 };
@@ -68,7 +69,12 @@ DFN_DEV uint32_t begin_unit(Stager& st, char* smem) {
 #ifdef DFN_TIMING
   const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of unit u has landed
+  // this wave's share of unit u has landed (vector memory returns in order: loads issued after the DMA,
+  // i.e. the next tile's input prefetch, may remain outstanding)
+  if (st.younger_loads == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if (st.younger_loads == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st.younger_loads = 0;
 #ifdef DFN_TIMING
   const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -375,7 +381,10 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
   layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, out, nohead, norb);
 }
 
-template <class P, int UMB> constexpr uint32_t lds_bytes() { return 2 * max_unit_bytes<P>(UMB); }
+// two staging buffers + per-wave next-tile input slots (7 dwords x 64 lanes per 64 points)
+template <class P, int UMB, int WAVES, int NB> constexpr uint32_t lds_bytes() {
+  return 2 * max_unit_bytes<P>(UMB) + WAVES * ((NB * 32 + 63) / 64) * 7 * 256;
+}
 
 // ------------------------------------------------------------------------------------------
 template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE>
@@ -389,6 +398,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   st.waves = WAVES;
   st.skew = WAVES == 8 ? a.skew : 0;
   st.t_sync = st.t_wait = 0;
+  st.younger_loads = 0;
   st.trace = nullptr;
   st.n_trace = 0;
 #ifdef DFN_TIMING
@@ -413,9 +423,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       pt[nb] = tile * PPT + st.wave * (NB * 32) + nb * 32 + p;
-      const long long q = pt[nb] < n_pts ? pt[nb] : n_pts - 1;
-      const long long ray = q / a.n_samples;
-      const int i = int(q - ray * a.n_samples);
+      const uint32_t q = uint32_t(pt[nb] < n_pts ? pt[nb] : n_pts - 1);
+      const uint32_t ray = q / uint32_t(a.n_samples);
+      const int i = int(q - ray * uint32_t(a.n_samples));
       const float z = coarse_z_at(i, a.n_samples, a.near, a.far);
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -438,6 +448,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PPT = WAVES * NB * 32;
   constexpr int HC = chunks_of<P>(64), QC = chunks_of<P>(32);
+  constexpr int PF_ROUNDS = (NB * 32 + 63) / 64;  // 64-point rounds of the next-tile input prefetch
   using F = typename FragOf<P>::type;
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
@@ -445,6 +456,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   st.waves = WAVES;
   st.skew = WAVES == 8 ? a.skew : 0;
   st.t_sync = st.t_wait = 0;
+  st.younger_loads = 0;
   st.trace = nullptr;
   st.n_trace = 0;
 #ifdef DFN_TIMING
@@ -462,22 +474,39 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   stage_issue(st, smem, 0, st.lds_cur);
   st.pf_off = st.tab[st.n_units > 1 ? 2 : 0];
   st.pf_size = st.tab[st.n_units > 1 ? 3 : 1];
+  // Tile inputs.  The first tile's are loaded normally; every later tile's are PREFETCHED during the
+  // previous tile's small layers with explicit loads (exact count, see Stager::younger_loads) and only
+  // waited for at the end of that tile, so the HBM latency of z / o / d is off the critical path.
+  float zin[NB], oin[NB][3], din[NB][3];
+  long long pt[NB], ray_of[NB];
+  auto tile_coords = [&](long long t) {  // launch_one() guarantees n_pts < 2^31: 32-bit division
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      pt[nb] = t * PPT + st.wave * (NB * 32) + nb * 32 + p;
+      const uint32_t q = uint32_t(pt[nb] < n_pts ? pt[nb] : n_pts - 1);
+      ray_of[nb] = q / uint32_t(a.n_samples);
+    }
+  };
+  tile_coords(tile);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const long long q = pt[nb] < n_pts ? pt[nb] : n_pts - 1;
+    zin[nb] = a.z[q];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { oin[nb][c] = a.rays_o[ray_of[nb] * 3 + c]; din[nb][c] = a.rays_d[ray_of[nb] * 3 + c]; }
+  }
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3];
-    long long pt[NB];
+    long long pt_cur[NB];
     const float* rb_dir[NB];
     const float* rb_tr[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      pt[nb] = tile * PPT + st.wave * (NB * 32) + nb * 32 + p;
-      const long long q = pt[nb] < n_pts ? pt[nb] : n_pts - 1;
-      const long long ray = q / a.n_samples;
-      const float z = a.z[q];
+      pt_cur[nb] = pt[nb];
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        x[nb][c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], z));
-      rb_dir[nb] = a.ray_bias + ray * kRayBiasFloats;
+      for (int c = 0; c < 3; ++c) x[nb][c] = add_rn(oin[nb][c], mul_rn(din[nb][c], zin[nb]));
+      rb_dir[nb] = a.ray_bias + ray_of[nb] * kRayBiasFloats;
       rb_tr[nb] = rb_dir[nb] + kRayBiasFloats / 2;
     }
     const float* const norb[NB] = {};
@@ -503,6 +532,25 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
     {
       F de[NB][QC], dummy[NB][chunks_of<P>(16)];
       layer<P, UMB, PIPE, NB, HC, 2, true, false, true>(st, smem, fin, de, head, rb_dir);
+      if (st.more) {
+        // Prefetch the next tile's inputs by LDS-DMA (no destination registers, exact instruction count):
+        // lane l of round r fetches z, o, d of the wave's point 64 r + l into this wave's LDS slot.
+        const long long base = (tile + gridDim.x) * PPT + st.wave * (NB * 32);
+        char* slot = smem + 2 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 7 * 256);
+#pragma unroll
+        for (int r = 0; r < PF_ROUNDS; ++r) {
+          const long long ptn = base + r * 64 + st.lane;
+          const uint32_t q = uint32_t(ptn < n_pts ? ptn : n_pts - 1);
+          const uint32_t ray = q / uint32_t(a.n_samples);
+          __builtin_amdgcn_global_load_lds((const void*)(a.z + q), DFN_LDS_PTR(slot + (r * 7) * 256), 4, 0, 0);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            __builtin_amdgcn_global_load_lds((const void*)(a.rays_o + ray * 3 + c), DFN_LDS_PTR(slot + (r * 7 + 1 + c) * 256), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(a.rays_d + ray * 3 + c), DFN_LDS_PTR(slot + (r * 7 + 4 + c) * 256), 4, 0, 0);
+          }
+        }
+        st.younger_loads = 7 * PF_ROUNDS;
+      }
       layer<P, UMB, PIPE, NB, QC, 0, false, true, false>(st, smem, de, dummy, head, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -527,11 +575,24 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-      if (h == 0 && pt[nb] < n_pts) {
-        float* dst = a.out + pt[nb] * 9;
+      if (h == 0 && pt_cur[nb] < n_pts) {
+        float* dst = a.out + pt_cur[nb] * 9;
 #pragma unroll
         for (int c = 0; c < 9; ++c) dst[c] = o[nb][c];
       }
+    if (st.more) {  // pick up the prefetched inputs of the next tile (this wave's own LDS slot: no barrier needed)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tile_coords(tile + gridDim.x);
+      const char* slot = smem + 2 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 7 * 256);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int loc = nb * 32 + p, r = loc >> 6, l = loc & 63;
+        const float* f = reinterpret_cast<const float*>(slot + r * 7 * 256) + l;
+        zin[nb] = f[0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { oin[nb][c] = f[(1 + c) * 64]; din[nb][c] = f[(4 + c) * 64]; }
+      }
+    }
   }
 #ifdef DFN_TIMING
   if (a.timing && st.lane == 0) {
@@ -550,6 +611,7 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
   constexpr int PPT = WAVES * NB * 32;
   const long long n_pts = (long long)a.n_rays * a.n_samples;
   if (n_pts <= 0) return hipSuccess;
+  if (n_pts >= (1LL << 31)) return hipErrorInvalidValue;  // kernels index points with 32 bits; callers chunk
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   static int wg_per_cu = 0;
   if (!wg_per_cu) {
@@ -558,7 +620,7 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
   }
   const long long slots = (long long)n_cu * wg_per_cu;  // resident workgroups
   const int grid = int(n_tiles < slots ? n_tiles : slots);
-  const uint32_t lds = lds_bytes<P, UMB>();
+  const uint32_t lds = lds_bytes<P, UMB, WAVES, NB>();
   auto kern = fine ? nerfh_fine_kernel<P, FAST, WAVES, UMB, NB, PIPE> : nerfh_coarse_kernel<P, FAST, WAVES, UMB, NB, PIPE>;
   static bool attr_done[2] = {false, false};
   if (!attr_done[fine]) {
