@@ -33,6 +33,22 @@ MAC_COARSE, MAC_FINE = 130944, 182720  # algorithmic MAC per sample, SURVEY.md A
 PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 
 
+def pmc_traffic(kernel="nerfh_fine_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/*_pmc_summary.json: separate --pmc passes of this same command, tools/gpu_round.sh).
+    FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
+    (MI355X_MICROARCH.md §HBM), so it is doubled.  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    for name, c in d.items():
+        if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c and c.get("dispatches"):
+            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / c["dispatches"]
+    return None
+
+
 def cpu_baseline(sample_rays):
     """The oracle (torch CPU port of the reference path) on `sample_rays` rays of frame 0."""
     from oracle import nerfh_oracle as orc
@@ -127,7 +143,10 @@ def main():
                        if args.precision == "f16" else "exact fp32 MFMA",
                        "parallelism": f"frames sharded over {world} GPU(s), gather at end"},
             "roofline": {"bound": "mfma", "kernel": "nerfh_fine_kernel", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": pmc_traffic() if args.precision == "f16" else None,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) from profiles/; "
+                                         "algorithmic bytes per launch = rays * (768 z + 24 o,d + 512 ray-bias + 6912 raw)",
                          "launches_per_step": launches.value / K, "avg_launch_ms": avg_ms.value,
                          "algorithmic_flops_per_launch": fine_flops_per_launch,
                          "coarse_kernel_avg_launch_ms": c_ms.value,

@@ -1,15 +1,38 @@
 #!/bin/bash
-# One GPU-box pass: parity tests, smoke, bench, rocprof kernel stats.  Outputs under gpurun_out/.
+# One GPU-box pass: parity tests, smoke, bench, rocprof kernel stats, PMC passes.  Outputs under gpurun_out/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r01}
 cd $R
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-tail -15 gpurun_out/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+tail -4 gpurun_out/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err; echo "rocprof rc=$?"
-cat $R/gpurun_out/prof_bench.json
-find $R/gpurun_out/prof -type f | head;
-f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f"
+rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o $TAG -- python $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err; echo "rocprof rc=$?"
+head -9 $R/gpurun_out/prof/${TAG}_kernel_stats.csv | cut -c1-160
+mkdir -p $R/gpurun_out/pmc
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0"
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc -o pass$i -- $CMD > $R/gpurun_out/pmc/pass$i.log 2>&1
+  echo "pmc pass $i rc=$?"
+done
+python3 - <<PY
+import csv, glob, collections, json
+out = {}
+for f in sorted(glob.glob("$R/gpurun_out/pmc/pass*_counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k].add(row["Dispatch_Id"])
+    for k, d in agg.items():
+        out.setdefault(k, {"dispatches": len(n[k])}).update({c: v for c, v in d.items()})
+json.dump(out, open("$R/gpurun_out/pmc/summary.json", "w"), indent=1)
+for k, d in out.items():
+    if "nerfh" in k or "composite" in k or "sample" in k: print(k, {c: (f"{v:.4g}" if isinstance(v, float) else v) for c, v in d.items()})
+PY
