@@ -203,15 +203,72 @@ struct Packer {
   // The bias folded per ray (DIR, TE0) is NOT packed into the unit.
   static bool unit_has_bias(int layer) { return layer != LY_DIR && layer != LY_TE0; }
 
+  // One layer's M-blocks [mb0, mb0+group) as [A fragments][bias fragments], appended at `base`.
+  template <class P>
+  void pack_blocks(int layer, int mb0, int group, uint8_t* base) const {
+    using Elem = typename std::conditional<P::kSlotsPerChunk == 8, _Float16, float>::type;
+    const LayerShape sh = layer_shape(layer);
+    const int KC = sh.slots / P::kSlotsPerChunk;
+    Elem* frag = reinterpret_cast<Elem*>(base);
+    float* bias = reinterpret_cast<float*>(base + size_t(group) * KC * 64 * P::kLaneBytes);
+    for (int g = 0; g < group; ++g) {
+      const int mb = mb0 + g;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 31, hh = lane >> 5;
+        Mat m;
+        int row;
+        row_source(layer, mb, i, m, row);
+        if (row >= m.rows) row = -1;
+        for (int kc = 0; kc < KC; ++kc)
+          for (int j = 0; j < P::kSlotsPerChunk; ++j) {
+            const int col = col_source(layer, hh, kc * P::kSlotsPerChunk + j);
+            const float v = (row >= 0 && col >= 0 && col < m.cols) ? m.w[size_t(row) * m.cols + col] : 0.f;
+            frag[((size_t(g) * KC + kc) * 64 + lane) * P::kSlotsPerChunk + j] = Elem(v);
+          }
+      }
+      for (int hh = 0; hh < 2; ++hh)
+        for (int r = 0; r < 16; ++r) {
+          Mat m;
+          int row;
+          row_source(layer, mb, mblock_row(hh, r), m, row);
+          if (row >= m.rows) row = -1;
+          bias[(g * 2 + hh) * 16 + r] = (row >= 0 && unit_has_bias(layer)) ? m.b[row] : 0.f;
+        }
+    }
+  }
+  template <class P>
+  static uint32_t blocks_bytes(int layer, int group) {
+    const LayerShape sh = layer_shape(layer);
+    return uint32_t(group) * (sh.slots / P::kSlotsPerChunk) * 64 * P::kLaneBytes + uint32_t(group) * 128;
+  }
+
+  // The packed blob: staging units in execution order.  umb >= 8: a unit holds whole layers and the small
+  // layers of one group (kFineGroup / kCoarseGroup) share a unit; otherwise a unit is <= umb M-blocks of a layer.
   template <class P>
   void pack(bool fine, int umb, std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
-    using Elem = typename std::conditional<P::kSlotsPerChunk == 8, _Float16, float>::type;
     const int* seq = fine ? kFineSeq : kCoarseSeq;
+    const int* grp = fine ? kFineGroup : kCoarseGroup;
     const int nl = fine ? kFineLayers : kCoarseLayers;
+    if (umb >= 8) {
+      for (int li = 0; li < nl;) {
+        int lj = li;
+        uint32_t bytes = 0;
+        while (lj < nl && grp[lj] == grp[li]) bytes += blocks_bytes<P>(seq[lj], layer_shape(seq[lj]).mb), ++lj;
+        const uint32_t off = uint32_t(blob.size());
+        blob.resize(off + align_piece(bytes), 0);
+        tab.push_back(off);
+        tab.push_back(align_piece(bytes));
+        uint32_t at = off;
+        for (int l = li; l < lj; ++l) {
+          pack_blocks<P>(seq[l], 0, layer_shape(seq[l]).mb, blob.data() + at);
+          at += blocks_bytes<P>(seq[l], layer_shape(seq[l]).mb);
+        }
+        li = lj;
+      }
+      return;
+    }
     for (int li = 0; li < nl; ++li) {
-      const int layer = seq[li];
-      const LayerShape sh = layer_shape(layer);
-      const int KC = sh.slots / P::kSlotsPerChunk;
+      const LayerShape sh = layer_shape(seq[li]);
       for (int mb0 = 0; mb0 < sh.mb; mb0 += umb) {
         const int group = sh.mb - mb0 < umb ? sh.mb - mb0 : umb;
         const uint32_t bytes = unit_bytes<P>(sh.slots, group);
@@ -219,32 +276,7 @@ struct Packer {
         blob.resize(off + bytes, 0);
         tab.push_back(off);
         tab.push_back(bytes);
-        Elem* frag = reinterpret_cast<Elem*>(blob.data() + off);
-        float* bias = reinterpret_cast<float*>(blob.data() + off + size_t(group) * KC * 64 * P::kLaneBytes);
-        for (int g = 0; g < group; ++g) {
-          const int mb = mb0 + g;
-          for (int lane = 0; lane < 64; ++lane) {
-            const int i = lane & 31, hh = lane >> 5;
-            Mat m;
-            int row;
-            row_source(layer, mb, i, m, row);
-            if (row >= m.rows) row = -1;
-            for (int kc = 0; kc < KC; ++kc)
-              for (int j = 0; j < P::kSlotsPerChunk; ++j) {
-                const int col = col_source(layer, hh, kc * P::kSlotsPerChunk + j);
-                const float v = (row >= 0 && col >= 0 && col < m.cols) ? m.w[size_t(row) * m.cols + col] : 0.f;
-                frag[((size_t(g) * KC + kc) * 64 + lane) * P::kSlotsPerChunk + j] = Elem(v);
-              }
-          }
-          for (int hh = 0; hh < 2; ++hh)
-            for (int r = 0; r < 16; ++r) {
-              Mat m;
-              int row;
-              row_source(layer, mb, mblock_row(hh, r), m, row);
-              if (row >= m.rows) row = -1;
-              bias[(g * 2 + hh) * 16 + r] = (row >= 0 && unit_has_bias(layer)) ? m.b[row] : 0.f;
-            }
-        }
+        pack_blocks<P>(seq[li], mb0, group, blob.data() + off);
       }
     }
   }

@@ -61,6 +61,9 @@ DFN_HD constexpr LayerShape layer_shape(int id) {
 constexpr int kCoarseSeq[] = {LY_L1, LY_L2, LY_L3, LY_L4, LY_L5, LY_L6, LY_L7, LY_L8, LY_SIG};
 constexpr int kFineSeq[] = {LY_L1, LY_L2, LY_L3, LY_L4, LY_L5, LY_L6, LY_L7, LY_L8, LY_FIN,
                             LY_DIR, LY_RGB, LY_TE0, LY_TE1, LY_TE2, LY_TE3, LY_THEAD};
+// Staging-unit group of each layer when a unit may hold whole layers (unit_mb >= 8): small layers share a unit.
+constexpr int kCoarseGroup[] = {0, 1, 2, 3, 4, 5, 6, 7, 7};
+constexpr int kFineGroup[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 10, 10, 10, 10, 10};
 constexpr int kCoarseLayers = sizeof(kCoarseSeq) / sizeof(int);
 constexpr int kFineLayers = sizeof(kFineSeq) / sizeof(int);
 
@@ -108,7 +111,7 @@ DFN_HD constexpr uint32_t unit_bytes(int slots, int nmb) {
 template <class P>
 DFN_HD constexpr uint32_t max_unit_bytes(int umb) {
   const uint32_t a = unit_bytes<P>(96, umb < 4 ? umb : 4), b = unit_bytes<P>(64, umb < 5 ? umb : 5);
-  return a > b ? a : b;
+  return a > b ? a : b;  // (the merged small-layer units, 46 208 / 41 600 / 20 864 bytes, are smaller than L5's)
 }
 
 // Per-ray bias table written by the ray-bias kernel and read by the fine kernel:

@@ -42,6 +42,7 @@ struct Stager {
   uint32_t lds_cur;    // LDS byte offset holding (or receiving) unit u
   uint32_t lds_nxt;
   int lane, wave, waves;
+  uint32_t ubase, uoff;      // LDS offset of the open unit / bytes of it consumed by the layers so far
   uint32_t pf_off, pf_size;  // table entry of the unit the NEXT begin_unit() will start streaming (prefetched)
   unsigned long long t_sync, t_wait, t_last;  // DFN_TIMING: cycles in unit waits / barrier
   unsigned long long* trace;
@@ -192,27 +193,36 @@ DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&ou
 }
 
 // A layer whose MB output M-blocks feed the next layer, plus (EXTRA) one trailing head M-block
-// whose raw accumulators go back to the caller.  Weights arrive in staging units of UMB M-blocks.
+// whose raw accumulators go back to the caller.  Weights arrive in staging units of UMB M-blocks;
+// NEWUNIT = false continues inside the unit opened by the previous layer (small layers are packed
+// several to a unit: no barrier, no DMA wait between them).
 //
 // Software pipeline: inside a staging unit the A fragments form one flat stream t = (m-block, chunk);
 // fragment t+PF is fetched from LDS before the MFMAs of fragment t issue, so the ~100+-cycle LDS
 // latency hides under PF*NB MFMAs instead of stalling every chunk.  The bias is the C operand of
 // each accumulator's FIRST MFMA (no register copies) and is fetched one M-block ahead; RAYBIAS
-// layers preload every accumulator of the layer from the per-ray table at entry (global latency).
-template <class P, int UMB, bool PIPE, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS>
-DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)[NB][KC],
+// layers seed their accumulators from the per-ray table.
+//
+// PIPE: the f32 -> f16 (+ReLU) conversion of M-block m-1 is issued piecewise between the MFMAs of
+// M-block m.  CIN >= 0: the previous layer left its LAST M-block unconverted in `carry`; it lands in
+// chunks CIN, CIN+1 of Bin and is converted during this layer's chunks 0..CIN-1 (before they are read).
+// COUT: leave this layer's last M-block in `carry` for the next layer instead of converting it here.
+template <class P, int UMB, bool PIPE, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS, bool NEWUNIT,
+          int CIN, bool CIN_RELU, bool COUT>
+DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][KC],
                    typename FragOf<P>::type (&Bout)[NB][(MB ? MB : 1) * chunks_of<P>(16)],
-                   f32x16 (&head)[NB], const float* const (&raybias)[NB]) {
+                   f32x16 (&head)[NB], const float* const (&raybias)[NB], f32x16 (&carry)[NB]) {
   using F = typename FragOf<P>::type;
   constexpr int TOT = MB + (EXTRA ? 1 : 0);
   constexpr int PF = P::kSlotsPerChunk == 8 ? 3 : 4;  // fragments in flight
   constexpr uint32_t FB = 64 * P::kLaneBytes;         // bytes of one A fragment
-  constexpr int PPK = (8 * NB + KC - 1) / KC;         // epilogue pieces (of 8 per point block) interleaved per chunk (PIPE)
+  constexpr int PPK = (8 * NB + KC - 1) / KC;         // conversion pieces (8 per point block) interleaved per chunk
+  constexpr int PPKI = CIN > 0 ? (8 * NB + CIN - 1) / CIN : 0;  // same for the carried-in M-block
+  static_assert(CIN < 0 || (PIPE && P::kSlotsPerChunk == 8 && CIN > 0 && CIN + 1 < KC + 1), "carry-in needs the pipelined f16 path");
+  static_assert(!COUT || (PIPE && MB >= 1 && !EXTRA), "carry-out needs a regular last M-block");
+  static_assert(NEWUNIT || UMB >= TOT, "a layer that continues a unit must fit in it");
   const int h = st.lane >> 5;
-  // RAYBIAS: per-ray accumulator seeds come from a global table; with few point blocks all of the
-  // layer's seeds are fetched at entry (latency hidden behind the unit barrier), with NB = 4 they are
-  // fetched per M-block (register budget).
-  constexpr bool RB_ALL = RAYBIAS && NB <= 2;
+  constexpr bool RB_ALL = RAYBIAS && NB <= 2;  // fetch all per-ray seeds at entry (latency behind the barrier)
   f32x16 rb[RB_ALL ? TOT : 1][NB];
   if (RB_ALL) {
 #pragma unroll
@@ -220,14 +230,15 @@ DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) rb[mb][nb] = load16(raybias[nb] + (mb * 2 + h) * 16);
   }
-  // PIPE: the finished accumulators of the previous M-block, converted piecewise between the MFMAs
-  // of the current one (one wave per SIMD has nobody else to overlap its epilogue with).
   f32x16 pend[PIPE ? NB : 1];  // accumulators of M-block mb-1 while M-block mb runs
 #pragma unroll
   for (int u0 = 0; u0 < TOT; u0 += UMB) {
     const int nmb = (TOT - u0) < UMB ? (TOT - u0) : UMB;  // M-blocks in this unit (compile-time after unrolling)
     const int nt = nmb * KC;
-    const uint32_t ub = begin_unit(st, smem);
+    uint32_t ub;
+    if (NEWUNIT) { ub = begin_unit(st, smem); st.ubase = ub; st.uoff = 0; }
+    else ub = st.ubase + st.uoff;
+    st.uoff += nmb * KC * FB + nmb * 128;
     const char* wl = smem + ub + st.lane * P::kLaneBytes;
     const char* bl = smem + ub + nmb * KC * FB + h * 64;
     F a[PF];
@@ -264,6 +275,14 @@ DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)
             if (kc == 0) acc[nb] = mfma<P>(cur, Bin[nb][0], RAYBIAS ? acc[nb] : bias);
             else acc[nb] = mfma<P>(cur, Bin[nb][kc], acc[nb]);
           }
+          if (CIN > 0 && mb == 0 && kc < CIN) {  // the previous layer's last M-block -> chunks CIN, CIN+1 of Bin
+#pragma unroll
+            for (int q = 0; q < PPKI; ++q) {
+              const int piece = kc * PPKI + q;
+              if (piece < 8 * NB) store_hidden_piece<P, CIN_RELU>(carry[piece >> 3], Bin[piece >> 3], CIN / 2, piece & 7);
+            }
+            if (kc == CIN - 1) asm volatile("s_nop 3");  // VALU-written B operand is read by the very next MFMA
+          }
           if (PIPE && mb >= 1) {  // previous M-block's conversion, block by block (frees pend[0] first)
 #pragma unroll
             for (int q = 0; q < PPK; ++q) {
@@ -289,9 +308,14 @@ DFN_DEV void layer(Stager& st, char* smem, const typename FragOf<P>::type (&Bin)
       }
     }
   }
-  if (PIPE && MB >= 1 && !EXTRA) {  // the last M-block has no successor to hide behind
+  if (PIPE && MB >= 1 && !EXTRA) {  // the last M-block has no successor inside this layer
+    if (COUT) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1);
+      for (int nb = 0; nb < NB; ++nb) carry[nb] = pend[nb];
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1);
+    }
   }
 }
 
@@ -341,19 +365,21 @@ DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type
 // The 8-layer trunk (xyz_encoding_1..8, skip concat [pe, h] before layer 5).
 template <class P, int UMB, bool PIPE, bool FAST, int NB>
 DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
-                   typename FragOf<P>::type (&out)[NB][chunks_of<P>(64)]) {
+                   typename FragOf<P>::type (&out)[NB][chunks_of<P>(64)], f32x16 (&carry)[NB]) {
   using F = typename FragOf<P>::type;
   constexpr int PC = chunks_of<P>(32), HC = chunks_of<P>(64);
+  constexpr bool CY = PIPE && P::kSlotsPerChunk == 8;  // hand a layer's last M-block to the next layer unconverted
+  constexpr int CI = CY ? 6 : -1;                      // ... where it lands in chunks 6, 7 of the 128-wide input
   const int h = st.lane >> 5;
   f32x16 nohead[NB];
   const float* const norb[NB] = {};
   F pe[NB][PC];
   posenc_xyz<P, FAST, NB, PC>(x, h, pe);
   F a[NB][HC], b[NB][HC];
-  layer<P, UMB, PIPE, NB, PC, 4, true, false, false>(st, smem, pe, a, nohead, norb);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, b, a, nohead, norb);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
+  layer<P, UMB, PIPE, NB, PC, 4, true, false, false, true, -1, true, CY>(st, smem, pe, a, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
   {
     F cat[NB][PC + HC];
     if constexpr (P::kSlotsPerChunk == 8 && !PIPE) {  // recompute: cheaper than 32 VGPRs live across 4 layers
@@ -374,11 +400,11 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
 #pragma unroll
       for (int i = 0; i < HC; ++i) cat[nb][PC + i] = b[nb][i];
     }
-    layer<P, UMB, PIPE, NB, PC + HC, 4, true, false, false>(st, smem, cat, a, nohead, norb);
+    layer<P, UMB, PIPE, NB, PC + HC, 4, true, false, false, true, (CY ? PC + 6 : -1), true, CY>(st, smem, cat, a, nohead, norb, carry);
   }
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, b, nohead, norb);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, b, a, nohead, norb);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false>(st, smem, a, out, nohead, norb);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, out, nohead, norb, carry);  // out's chunks 6, 7 stay in `carry`
 }
 
 // two staging buffers + per-wave next-tile input slots (7 dwords x 64 lanes per 64 points)
@@ -431,12 +457,14 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
       for (int c = 0; c < 3; ++c)
         x[nb][c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], z));
     }
+    constexpr bool CY = PIPE && P::kSlotsPerChunk == 8, MERGE = UMB >= 8;
     F hid[NB][chunks_of<P>(64)];
-    trunk<P, UMB, PIPE, FAST, NB>(st, smem, x, hid);
+    f32x16 carry[NB];
+    trunk<P, UMB, PIPE, FAST, NB>(st, smem, x, hid, carry);
     f32x16 head[NB];
     F dummy[NB][chunks_of<P>(16)];
     const float* const norb[NB] = {};
-    layer<P, UMB, PIPE, NB, chunks_of<P>(64), 0, false, true, false>(st, smem, hid, dummy, head, norb);
+    layer<P, UMB, PIPE, NB, chunks_of<P>(64), 0, false, true, false, !MERGE, (CY ? 6 : -1), true, false>(st, smem, hid, dummy, head, norb, carry);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       if (h == 0 && pt[nb] < n_pts) a.out[pt[nb]] = act_softplus<FAST>(head[nb][0]);
@@ -520,18 +548,20 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
       t_pro += __builtin_amdgcn_s_memtime() - c0;
     }
 #endif
-    trunk<P, UMB, PIPE, FAST, NB>(st, smem, x, hid);
+    constexpr bool CY = PIPE && P::kSlotsPerChunk == 8, MERGE = UMB >= 8;
+    f32x16 carry[NB];
+    trunk<P, UMB, PIPE, FAST, NB>(st, smem, x, hid, carry);
     // xyz_encoding_final (no activation) + static_sigma
     F fin[NB][HC];
     f32x16 head[NB];
-    layer<P, UMB, PIPE, NB, HC, 4, false, true, false>(st, smem, hid, fin, head, norb);
+    layer<P, UMB, PIPE, NB, HC, 4, false, true, false, true, (CY ? 6 : -1), true, false>(st, smem, hid, fin, head, norb, carry);
     float o[NB][9];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o[nb][3] = act_softplus<FAST>(head[nb][0]);
     // dir_encoding (per-ray bias = b + W[:,128:] [pe_dir, a]) -> static_rgb
     {
       F de[NB][QC], dummy[NB][chunks_of<P>(16)];
-      layer<P, UMB, PIPE, NB, HC, 2, true, false, true>(st, smem, fin, de, head, rb_dir);
+      layer<P, UMB, PIPE, NB, HC, 2, true, false, true, true, -1, true, CY>(st, smem, fin, de, head, rb_dir, carry);
       if (st.more) {
         // Prefetch the next tile's inputs by LDS-DMA (no destination registers, exact instruction count):
         // lane l of round r fetches z, o, d of the wave's point 64 r + l into this wave's LDS slot.
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
         }
         st.younger_loads = 7 * PF_ROUNDS;
       }
-      layer<P, UMB, PIPE, NB, QC, 0, false, true, false>(st, smem, de, dummy, head, norb);
+      layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, de, dummy, head, norb, carry);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -560,11 +590,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
     // transient branch
     {
       F t0[NB][QC], t1[NB][QC], dummy[NB][chunks_of<P>(16)];
-      layer<P, UMB, PIPE, NB, HC, 2, true, false, true>(st, smem, fin, t0, head, rb_tr);
-      layer<P, UMB, PIPE, NB, QC, 2, true, false, false>(st, smem, t0, t1, head, norb);
-      layer<P, UMB, PIPE, NB, QC, 2, true, false, false>(st, smem, t1, t0, head, norb);
-      layer<P, UMB, PIPE, NB, QC, 2, true, false, false>(st, smem, t0, t1, head, norb);
-      layer<P, UMB, PIPE, NB, QC, 0, false, true, false>(st, smem, t1, dummy, head, norb);
+      layer<P, UMB, PIPE, NB, HC, 2, true, false, true, true, -1, true, CY>(st, smem, fin, t0, head, rb_tr, carry);
+      layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
+      layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t1, t0, head, norb, carry);
+      layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
+      layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, t1, dummy, head, norb, carry);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -640,7 +670,7 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
   if (prec == 0) {
     if (variant == 0) return launch_one<PrecF16, true, 8, 8, 2, 1, true>(fine, a, n_cu, stream);
-    if (variant == 1) return launch_one<PrecF16, true, 4, 2, 2, 2, false>(fine, a, n_cu, stream);
+    if (variant == 1) return launch_one<PrecF16, true, 4, 2, 2, 2, true>(fine, a, n_cu, stream);
     if (variant == 2) return launch_one<PrecF16, true, 4, 8, 3, 1, true>(fine, a, n_cu, stream);
     return launch_one<PrecF16, true, 8, 8, 2, 1, false>(fine, a, n_cu, stream);
   }
