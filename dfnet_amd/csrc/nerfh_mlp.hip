@@ -21,6 +21,10 @@
 #include "nerfh_layout.h"
 #include "mfma_frag.h"
 
+#ifndef DFN_PF
+#define DFN_PF 3  // f16 A fragments in flight per wave
+#endif
+
 namespace dfn {
 
 // chunks (B-operand registers groups) per 32 produced features / per n slots
@@ -214,7 +218,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
                    f32x16 (&head)[NB], const float* const (&raybias)[NB], f32x16 (&carry)[NB]) {
   using F = typename FragOf<P>::type;
   constexpr int TOT = MB + (EXTRA ? 1 : 0);
-  constexpr int PF = P::kSlotsPerChunk == 8 ? 3 : 4;  // fragments in flight
+  constexpr int PF = P::kSlotsPerChunk == 8 ? DFN_PF : 4;  // fragments in flight
   constexpr uint32_t FB = 64 * P::kLaneBytes;         // bytes of one A fragment
   constexpr int PPK = (8 * NB + KC - 1) / KC;         // conversion pieces (8 per point block) interleaved per chunk
   constexpr int PPKI = CIN > 0 ? (8 * NB + CIN - 1) / CIN : 0;  // same for the carried-in M-block
