@@ -1,0 +1,77 @@
+"""Forward pass of the DFNet_dm step, mirroring /root/reference/script/feature/direct_feature_matching.py:
+`preprocess_features_for_loss` (:41-50), `inference_pose_regression` (:63-93) and the forward half of
+`train_on_batch` (:322-376): pose regression -> (SVD orthogonalisation) -> scene rescale -> NeRF-H render at
+quarter resolution -> bicubic x4 -> siamese DFNet features -> cosine feature loss (+ photometric / pose terms).
+
+Every arithmetic-heavy stage runs in the HIP library (DFNet forward, render, bicubic); what remains here are
+the few-element reductions of the loss.  The BACKWARD half (loss.backward(), Adam on the pose net) needs
+gradient kernels for render / DFNet and is not built: `matching_step_forward` returns the losses only.
+The reference renders only pose 0 of the batch (:342, i.e. batch size 1 in effect); this implementation renders
+every pose of the batch."""
+import torch
+
+from .engine import upsample_bicubic
+from .feature_misc import feature_loss, fix_coord_supp
+from .rendering import render
+
+
+def preprocess_features_for_loss(feature):
+    """[L,B,C,H,W] -> [B, L*C, H, W] (:41-50)."""
+    feature = feature.permute(1, 0, 2, 3, 4)
+    B, L, C, H, W = feature.size()
+    return feature.reshape((B, L * C, H, W))
+
+
+def inference_pose_regression(args, data, device, model, retFeature=False, isSingleStream=True, return_pose=True):
+    """DFNet forward wrapper (:63-93): returns (features, pose [B,3,4]) or (features, None)."""
+    inputs = data.to(device)
+    _, _, H, W = data.size()
+    features, predict_pose = model(inputs, return_feature=retFeature, isSingleStream=isSingleStream,
+                                   return_pose=return_pose, upsampleH=H, upsampleW=W)
+    if not return_pose:
+        return features, predict_pose
+    pose = predict_pose.reshape(inputs.shape[0], 3, 4)
+    if getattr(args, "svd_reg", False):
+        u, s, v = torch.svd(pose[:, :3, :3].clone())
+        pose[:, :3, :3] = torch.matmul(u, v.transpose(-2, -1))
+    return features, pose
+
+
+def matching_step_forward(args, data, model, feat_model, pose, img_idx, hwf, half_res, device, world_setup_dict,
+                          **render_kwargs_test):
+    """Losses of one DFNet_dm step without the update.  data [B,3,H,W] in [0,1], pose [B,12|3x4] ground truth,
+    img_idx [B,bins].  Returns dict(loss, pose_loss, photo_loss, feat_loss, psnr, rgb [B,3,H,W], pose_pred)."""
+    H, W, focal = hwf
+    H, W = int(H), int(W)
+    data = data.to(device)
+    B = data.shape[0]
+    with torch.no_grad():
+        _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
+        pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
+        img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
+        rgbs = []
+        for b in range(B):
+            if half_res:
+                rgb, _, _, _ = render(H // 4, W // 4, focal / 4, chunk=args.chunk, c2w=pose_nerf[b, :3, :4],
+                                      img_idx=img_idx[b], **render_kwargs_test)
+                rgb = upsample_bicubic(rgb, H, W)
+            else:
+                rgb, _, _, _ = render(H, W, focal, chunk=args.chunk, c2w=pose_nerf[b, :3, :4], img_idx=img_idx[b],
+                                      **render_kwargs_test)
+            rgbs.append(rgb.permute(2, 0, 1))
+        rgb = torch.stack(rgbs)
+        feats, _ = inference_pose_regression(args, torch.cat([data, rgb]), device, feat_model, retFeature=True,
+                                             isSingleStream=False, return_pose=False)
+        idx = torch.tensor(args.feature_matching_lvl, device=device)
+        f_t = preprocess_features_for_loss(torch.index_select(feats[0], 0, idx))
+        f_r = preprocess_features_for_loss(torch.index_select(feats[1], 0, idx))
+        feat_l = torch.stack([feature_loss(f_r[b], f_t[b], per_channel=args.per_channel) for b in range(B)]).mean()
+        photo_l = torch.mean((rgb - data) ** 2)
+        pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
+        if getattr(args, "combine_loss", False):
+            w = args.combine_loss_w
+            loss = w[0] * pose_l + w[1] * photo_l + w[2] * feat_l
+        else:
+            loss = feat_l
+        psnr = -10. * torch.log10(photo_l)
+    return dict(loss=loss, pose_loss=pose_l, photo_loss=photo_l, feat_loss=feat_l, psnr=psnr, rgb=rgb, pose_pred=pose_)

@@ -110,3 +110,55 @@ def test_dfnet_module_drop_in(gold):
     feats, pose = m(T(g["x"]).to(DEV), return_feature=True, isSingleStream=True, return_pose=False,
                     upsampleH=40, upsampleW=56)
     assert pose is None and len(feats) == 1 and relmax(feats[0][:, :, ::8], g["single"]) < 2e-5
+
+
+def test_dm_step_forward_vs_oracle():
+    """DFNet_dm forward (direct_feature_matching.py:322-376) against the same composition of the two oracles."""
+    from types import SimpleNamespace
+    from dfnet_amd.dfnet import DFNet
+    from dfnet_amd.direct_feature_matching import matching_step_forward
+    from dfnet_amd.nerfw import HipQuery
+    from oracle import nerfh_oracle as orc
+    H, W, focal = 64, 96, 80.0
+    w = syn.dfnet_weights(3)
+    sd = {k: T(v) for k, v in w.items()}
+    model, feat_model = DFNet().eval(), DFNet().eval()
+    model.load_state_dict(sd, strict=False)
+    feat_model.load_state_dict(sd, strict=False)
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine(precision="f32").load_numpy(cw, fw, ea, et)
+    kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=16, N_samples=8, use_viewdirs=True,
+              white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    setup = dict(pose_scale=1.0, pose_scale2=1.0, move_all_cam_vec=[0., 0., 1.0])
+    args = SimpleNamespace(svd_reg=True, chunk=32768, feature_matching_lvl=[0, 2], per_channel=False, combine_loss=True,
+                           combine_loss_w=[0.3, 0.2, 1.0])
+    g = torch.Generator().manual_seed(1)
+    data = torch.rand(2, 3, H, W, generator=g)
+    gt = torch.stack([T(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(2)])
+    hist = T(syn.HIST_IDX).repeat(2, 1)
+    out = matching_step_forward(args, data, model, feat_model, gt, hist, [H, W, focal], True, DEV, setup, **kw)
+    # oracle composition
+    with torch.no_grad():
+        _, pp = dor.dfnet_forward(sd, data)
+        pose = pp.reshape(2, 3, 4).clone()
+        u, s, v = torch.svd(pose[:, :3, :3].clone())
+        pose[:, :3, :3] = u @ v.transpose(-2, -1)
+        assert relmax(out["pose_pred"], pose) < 1e-4
+        pose[:, :3, 3] += torch.tensor([0., 0., 1.0])
+        c, f = {k: T(x) for k, x in cw.items()}, {k: T(x) for k, x in fw.items()}
+        rgbs = []
+        for b in range(2):
+            c2w = torch.eye(4); c2w[:3, :4] = pose[b]
+            r = orc.render(H // 4, W // 4, focal / 4, 32768, c, f, T(ea), T(et), 8, 16, 0., 2.5, syn.HIST_IDX, c2w=c2w)[0]
+            rgbs.append(torch.nn.Upsample(size=(H, W), mode='bicubic')(r.permute(2, 0, 1)[None])[0])
+        rgb = torch.stack(rgbs)
+        assert relmax(out["rgb"], rgb) < 1e-3
+        feats, _ = dor.dfnet_forward(sd, torch.cat([data, rgb]), True, False, False, H, W)
+        ft, fr = feats[0][[0, 2]].permute(1, 0, 2, 3, 4).reshape(2, 256, H, W), feats[1][[0, 2]].permute(1, 0, 2, 3, 4).reshape(2, 256, H, W)
+        fl = torch.stack([1 - torch.nn.functional.cosine_similarity(fr[b].reshape(256, -1), ft[b].reshape(256, -1), dim=1, eps=1e-6).mean() for b in range(2)]).mean()
+        photo = ((rgb - data) ** 2).mean()
+        pl = torch.nn.functional.mse_loss(pp.reshape(2, 12) * 0 + pose.reshape(2, 12) * 0 + out["pose_pred"].cpu().reshape(2, 12), gt)
+        want = 0.3 * pl + 0.2 * photo + 1.0 * fl
+    assert abs(float(out["feat_loss"]) - float(fl)) < 2e-4 * max(1.0, abs(float(fl)))
+    assert abs(float(out["photo_loss"]) - float(photo)) < 1e-4
+    assert abs(float(out["loss"]) - float(want)) < 5e-4 * max(1.0, abs(float(want)))
