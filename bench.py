@@ -49,8 +49,9 @@ def pmc_traffic(kernel="nerfh_fine_kernel"):
     return None
 
 
-def cpu_baseline(sample_rays):
-    """The oracle (torch CPU port of the reference path) on `sample_rays` rays of frame 0."""
+def cpu_baseline(sample_rays, engine=None, device=None):
+    """The oracle (torch CPU port of the reference path) on `sample_rays` rays of frame 0; with `engine`, the
+    same rays are also rendered by the HIP path and compared (PSNR / max relative error vs the oracle)."""
     from oracle import nerfh_oracle as orc
     T = torch.from_numpy
     cw, fw, ea, et = syn.nerfh_weights(0)
@@ -62,11 +63,19 @@ def cpu_baseline(sample_rays):
     with torch.no_grad():
         orc.render_rays(rows[:512], c, f, T(ea), T(et), NC, NI)  # warm-up
         t0 = time.perf_counter()
-        orc.render_rays(rows, c, f, T(ea), T(et), NC, NI)
+        ref = orc.render_rays(rows, c, f, T(ea), T(et), NC, NI)
         dt = time.perf_counter() - t0
-    return {"value": sample_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{sample_rays} random rays of frame 0 at 64+128 samples, one chunk, {dt:.1f} s "
-                      f"(oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32)"}
+    out = {"value": sample_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{sample_rays} random rays of frame 0 at 64+128 samples, one chunk, {dt:.1f} s "
+                     f"(oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32)"}
+    if engine is not None:
+        rgb, disp, acc, _ = engine.render_rays(rows[:, 0:3].to(device), rows[:, 3:6].to(device),
+                                               torch.from_numpy(syn.HIST_IDX).to(device), NC, NI, NEAR, FAR)
+        d = (rgb.cpu() - ref["rgb_map"]).double()
+        out["parity_vs_oracle"] = {"psnr_db": float(-10 * torch.log10((d ** 2).mean().clamp_min(1e-30))),
+                                   "rgb_max_rel": float(d.abs().max() / ref["rgb_map"].abs().max()),
+                                   "disp_max_rel": float((disp.cpu() - ref["disp_map"]).abs().max() / ref["disp_map"].abs().max())}
+    return out
 
 
 def main():
@@ -153,7 +162,7 @@ def main():
                          "whole_path_mfma_frac": value / world * 2.0 * (MAC_COARSE * NC + MAC_FINE * (NC + NI)) / 1e12 / peak},
         }
         if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, E, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

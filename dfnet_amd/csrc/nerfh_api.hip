@@ -451,7 +451,7 @@ extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, cons
   if (int rc = check_net(h, prec, "dfn_mlp_coarse")) return rc;
   if (!rays_o || !rays_d || !sigma || Nc < 1) return set_error(DFN_ERR_ARG, "dfn_mlp_coarse: bad argument");
   const PackedNet& n = h->net[0][prec][mlp_variant()];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, (long long)n_rays, Nc, near, far, nullptr, mlp_skew()};
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr, mlp_skew()};
   ScopedTimer t(0, HS(stream));
   CHECK_HIP(launch_mlp(false, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_coarse");
   return DFN_OK;
@@ -498,7 +498,7 @@ extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const 
   float* table = static_cast<float*>(bias_ws);
   CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine(ray_bias)");
   const PackedNet& n = h->net[1][prec][mlp_variant()];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf, mlp_skew()};
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, nullptr, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf, mlp_skew()};
   ScopedTimer t(1, HS(stream));
   CHECK_HIP(launch_mlp(true, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_fine");
   return DFN_OK;
@@ -525,7 +525,7 @@ inline size_t chunk_rays(size_t n_rays) {
   return (c + 63) & ~size_t(63);
 }
 struct Workspace {
-  float *o, *d, *v, *sigma, *z, *raw, *bias;
+  float *o, *d, *v, *sigma, *z, *raw, *bias, *partial;
   size_t total;
 };
 Workspace carve(char* base, size_t n_rays, int Nc, int Ni, bool own_rays) {
@@ -541,6 +541,7 @@ Workspace carve(char* base, size_t n_rays, int Nc, int Ni, bool own_rays) {
   w.z = take(chunk * Nf * 4);
   w.raw = take(chunk * Nf * 9 * 4);
   w.bias = take(chunk * kRayBiasFloats * 4);
+  w.partial = take(chunk * ((Nf + 63) / 64) * 12 * 4);
   w.total = off;
   return w;
 }
@@ -549,7 +550,10 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
                 size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far, float* rgb, float* disp,
                 float* acc, float* raw_out, const Workspace& w, hipStream_t s) {
   const int Nf = Nc + Ni;
+  // Compositing is fused into the fine kernel when a wave's 64 points are one ray segment and raw is not wanted
+  // (f16 variants 0/1/3 hold 64 points per wave; the f32 and 3-block variants keep the separate compositor).
   const int var = mlp_variant();
+  const bool fused = !raw_out && Nf % 64 == 0 && prec == DFN_PREC_F16 && var != 2 && !getenv("DFN_NO_FUSED_COMPOSITE");
   const PackedNet& nc = h->net[0][prec][var];
   const PackedNet& nf = h->net[1][prec][var];
   const int cus = device_cu_count();
@@ -562,20 +566,25 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
     float* raw = raw_out ? raw_out + r0 * size_t(Nf) * 9 : w.raw;
     {
-      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, (long long)n, Nc, near, far, nullptr, mlp_skew()};
+      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr, mlp_skew()};
       ScopedTimer t(0, s);
       CHECK_HIP(launch_mlp(false, prec, var, a, cus, s), "render: coarse MLP");
     }
     CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s), "render: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.bias, s), "render: ray_bias");
     {
-      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, (long long)n, Nf, 0.f, 0.f, g_timing_buf, mlp_skew()};
+      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, fused ? w.partial : nullptr, (long long)n, Nf, 0.f, 0.f, g_timing_buf, mlp_skew()};
       ScopedTimer t(1, s);
       CHECK_HIP(launch_mlp(true, prec, var, a, cus, s), "render: fine MLP");
     }
-    CHECK_HIP(launch_composite_fine(raw, w.z, n, Nf, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
-                                    disp + r0, acc + r0, nullptr, nullptr, nullptr, s),
-              "render: composite");
+    if (fused)
+      CHECK_HIP(launch_composite_combine(w.partial, n, Nf / 64, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
+                                         disp + r0, acc + r0, s),
+                "render: composite combine");
+    else
+      CHECK_HIP(launch_composite_fine(raw, w.z, n, Nf, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
+                                      disp + r0, acc + r0, nullptr, nullptr, nullptr, s),
+                "render: composite");
   }
   return DFN_OK;
 }

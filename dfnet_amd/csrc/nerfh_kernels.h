@@ -15,6 +15,7 @@ struct MlpArgs {
   const float* z;          // fine: [n_rays, n_samples]; coarse: unused (linspace in-kernel)
   const float* ray_bias;   // fine: [n_rays, kRayBiasFloats]
   float* out;              // coarse: sigma [n_rays, n_samples]; fine: raw [n_rays, n_samples, 9]
+  float* partial;          // fine, fused compositing: [n_rays * n_samples / 64][12] per-segment composites (raw unused)
   long long n_rays;
   int n_samples;
   float near, far;
@@ -52,6 +53,9 @@ hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays
                                  int flags, float* rgb, float* disp, float* acc, float* depth,
                                  float* weights, float* beta, hipStream_t stream);
 
+// Chains the per-64-sample segment composites written by the fused fine kernel: partial [n_rays, segs, 12].
+hipError_t launch_composite_combine(const float* partial, size_t n_rays, int segs, float beta_min, int flags, float* rgb,
+                                    float* disp, float* acc, hipStream_t stream);
 hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream);
 
 }  // namespace dfn

@@ -76,8 +76,8 @@ DFN_DEV uint32_t begin_unit(Stager& st, char* smem) {
 #endif
   // this wave's share of unit u has landed (vector memory returns in order: loads issued after the DMA,
   // i.e. the next tile's input prefetch, may remain outstanding)
-  if (st.younger_loads == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if (st.younger_loads == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  if (st.younger_loads == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (st.younger_loads == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   st.younger_loads = 0;
 #ifdef DFN_TIMING
@@ -411,9 +411,9 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
   layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, out, nohead, norb, carry);  // out's chunks 6, 7 stay in `carry`
 }
 
-// two staging buffers + per-wave next-tile input slots (7 dwords x 64 lanes per 64 points)
+// two staging buffers + per-wave next-tile input slots (8 dwords x 64 lanes per 64 points: z, o, d, next z)
 template <class P, int UMB, int WAVES, int NB> constexpr uint32_t lds_bytes() {
-  return 2 * max_unit_bytes<P>(UMB) + WAVES * ((NB * 32 + 63) / 64) * 7 * 256;
+  return 2 * max_unit_bytes<P>(UMB) + WAVES * ((NB * 32 + 63) / 64) * 8 * 256;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   // Tile inputs.  The first tile's are loaded normally; every later tile's are PREFETCHED during the
   // previous tile's small layers with explicit loads (exact count, see Stager::younger_loads) and only
   // waited for at the end of that tile, so the HBM latency of z / o / d is off the critical path.
-  float zin[NB], oin[NB][3], din[NB][3];
+  float zin[NB], znext[NB], oin[NB][3], din[NB][3];
   long long pt[NB], ray_of[NB];
   auto tile_coords = [&](long long t) {  // launch_one() guarantees n_pts < 2^31: 32-bit division
 #pragma unroll
@@ -524,6 +524,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   for (int nb = 0; nb < NB; ++nb) {
     const long long q = pt[nb] < n_pts ? pt[nb] : n_pts - 1;
     zin[nb] = a.z[q];
+    znext[nb] = a.z[q + 1 < n_pts ? q + 1 : q];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { oin[nb][c] = a.rays_o[ray_of[nb] * 3 + c]; din[nb][c] = a.rays_d[ray_of[nb] * 3 + c]; }
   }
@@ -568,22 +569,23 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
       layer<P, UMB, PIPE, NB, HC, 2, true, false, true, true, -1, true, CY>(st, smem, fin, de, head, rb_dir, carry);
       if (st.more) {
         // Prefetch the next tile's inputs by LDS-DMA (no destination registers, exact instruction count):
-        // lane l of round r fetches z, o, d of the wave's point 64 r + l into this wave's LDS slot.
+        // lane l of round r fetches z, o, d and the next sample's z of the wave's point 64 r + l into this wave's LDS slot.
         const long long base = (tile + gridDim.x) * PPT + st.wave * (NB * 32);
-        char* slot = smem + 2 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 7 * 256);
+        char* slot = smem + 2 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
         for (int r = 0; r < PF_ROUNDS; ++r) {
           const long long ptn = base + r * 64 + st.lane;
           const uint32_t q = uint32_t(ptn < n_pts ? ptn : n_pts - 1);
           const uint32_t ray = q / uint32_t(a.n_samples);
-          __builtin_amdgcn_global_load_lds((const void*)(a.z + q), DFN_LDS_PTR(slot + (r * 7) * 256), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds((const void*)(a.z + q), DFN_LDS_PTR(slot + (r * 8) * 256), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds((const void*)(a.z + (q + 1 < uint32_t(n_pts) ? q + 1 : q)), DFN_LDS_PTR(slot + (r * 8 + 7) * 256), 4, 0, 0);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            __builtin_amdgcn_global_load_lds((const void*)(a.rays_o + ray * 3 + c), DFN_LDS_PTR(slot + (r * 7 + 1 + c) * 256), 4, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void*)(a.rays_d + ray * 3 + c), DFN_LDS_PTR(slot + (r * 7 + 4 + c) * 256), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(a.rays_o + ray * 3 + c), DFN_LDS_PTR(slot + (r * 8 + 1 + c) * 256), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(a.rays_d + ray * 3 + c), DFN_LDS_PTR(slot + (r * 8 + 4 + c) * 256), 4, 0, 0);
           }
         }
-        st.younger_loads = 7 * PF_ROUNDS;
+        st.younger_loads = 8 * PF_ROUNDS;
       }
       layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, de, dummy, head, norb, carry);
 #pragma unroll
@@ -607,22 +609,64 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
         o[nb][8] = act_softplus<FAST>(head[nb][4]);  // C register 4 of half 0 = row 8 = transient_beta
       }
     }
+    if (a.partial) {
+      // Fused compositing (n_samples % 64 == 0): this wave holds 64 consecutive samples of ONE ray, sample
+      // 32 nb + p on lane p of half 0.  Transmittance factorises over segments, so the wave composites its
+      // segment locally (products P and sums relative to the segment start) and a tiny combine pass chains
+      // the segments of a ray (nerfh_stages.hip: composite_combine_kernel).  `raw` never reaches HBM.
+      const bool live = h == 0;
+      float Pj = 1.f, Ps = 1.f;                    // running products through the previous blocks of the segment
+      float s_rgb[3] = {0.f, 0.f, 0.f}, s_acc = 0.f, s_dso = 0.f, s_dj = 0.f, s_beta = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-      if (h == 0 && pt_cur[nb] < n_pts) {
-        float* dst = a.out + pt_cur[nb] * 9;
+      for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t smp = uint32_t(pt_cur[nb]) % uint32_t(a.n_samples);
+        const float delta = smp + 1 == uint32_t(a.n_samples) ? 1e2f : sub_rn(znext[nb], zin[nb]);
+        const float sg_s = o[nb][3], sg_t = o[nb][7];
+        const float as = live ? sub_rn(1.f, FAST ? __expf(-mul_rn(delta, sg_s)) : expf(-mul_rn(delta, sg_s))) : 0.f;
+        const float at = live ? sub_rn(1.f, FAST ? __expf(-mul_rn(delta, sg_t)) : expf(-mul_rn(delta, sg_t))) : 0.f;
+        const float aj = live ? sub_rn(1.f, FAST ? __expf(-mul_rn(delta, add_rn(sg_s, sg_t))) : expf(-mul_rn(delta, add_rn(sg_s, sg_t)))) : 0.f;
+        const float ij = wave_incl_prod(1.f - aj, st.lane), is = wave_incl_prod(1.f - as, st.lane);
+        float ej = __shfl_up(ij, 1, 64), es = __shfl_up(is, 1, 64);
+        if (st.lane == 0) { ej = 1.f; es = 1.f; }
+        const float Tj = Pj * ej, Ts = Ps * es;
+        const float ws = as * Tj, wt = at * Tj, wj = aj * Tj;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) dst[c] = o[nb][c];
+        for (int c = 0; c < 3; ++c) s_rgb[c] += live ? ws * o[nb][c] + wt * o[nb][4 + c] : 0.f;
+        s_acc += wj;
+        s_dso += as * Ts * zin[nb];
+        s_dj += wj * zin[nb];
+        s_beta += live ? wt * o[nb][8] : 0.f;
+        Pj *= __shfl(ij, 31, 64);   // lanes 32..63 carry alpha = 0: lane 31 holds the block's full product
+        Ps *= __shfl(is, 31, 64);
       }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s_rgb[c] = wave_sum(s_rgb[c]);
+      s_acc = wave_sum(s_acc); s_dso = wave_sum(s_dso); s_dj = wave_sum(s_dj); s_beta = wave_sum(s_beta);
+      if (st.lane == 0 && pt_cur[0] < n_pts) {
+        f32x4* dst = reinterpret_cast<f32x4*>(a.partial + (size_t)(uint32_t(pt_cur[0]) >> 6) * 12);
+        dst[0] = f32x4{s_rgb[0], s_rgb[1], s_rgb[2], s_acc};
+        dst[1] = f32x4{s_dso, s_dj, s_beta, Pj};
+        dst[2] = f32x4{Ps, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        if (h == 0 && pt_cur[nb] < n_pts) {
+          float* dst = a.out + pt_cur[nb] * 9;
+#pragma unroll
+          for (int c = 0; c < 9; ++c) dst[c] = o[nb][c];
+        }
+    }
     if (st.more) {  // pick up the prefetched inputs of the next tile (this wave's own LDS slot: no barrier needed)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       tile_coords(tile + gridDim.x);
-      const char* slot = smem + 2 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 7 * 256);
+      const char* slot = smem + 2 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int loc = nb * 32 + p, r = loc >> 6, l = loc & 63;
-        const float* f = reinterpret_cast<const float*>(slot + r * 7 * 256) + l;
+        const float* f = reinterpret_cast<const float*>(slot + r * 8 * 256) + l;
         zin[nb] = f[0];
+        znext[nb] = f[7 * 64];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { oin[nb][c] = f[(1 + c) * 64]; din[nb][c] = f[(4 + c) * 64]; }
       }

@@ -486,6 +486,37 @@ hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ segment combine
+// Fused path: the fine MLP kernel composites each 64-sample segment locally; a ray's S segments chain as
+// total += T_prefix * local_sum, T_prefix *= P_segment (rendering.py:176-230 factorised over segments).
+__global__ __launch_bounds__(256) void composite_combine_kernel(const float* __restrict__ partial, size_t n_rays, int segs,
+                                                                float beta_min, int flags, float* __restrict__ rgb,
+                                                                float* __restrict__ disp, float* __restrict__ acc) {
+  const bool static_depth = (flags & 1) && (flags & 2);
+  for (size_t ray = blockIdx.x * size_t(blockDim.x) + threadIdx.x; ray < n_rays; ray += size_t(gridDim.x) * blockDim.x) {
+    float Tj = 1.f, Ts = 1.f, r = 0.f, g = 0.f, b = 0.f, a = 0.f, d = 0.f;
+    for (int s = 0; s < segs; ++s) {
+      const float4* q = reinterpret_cast<const float4*>(partial + (ray * segs + s) * 12);
+      const float4 u = q[0], v = q[1], w = q[2];
+      r += Tj * u.x; g += Tj * u.y; b += Tj * u.z; a += Tj * u.w;
+      d += static_depth ? Ts * v.x : Tj * v.y;
+      Tj *= v.w;
+      Ts *= w.x;
+    }
+    const float bg = (flags & 4) ? 1.f - a : 0.f;
+    rgb[ray * 3] = r + bg; rgb[ray * 3 + 1] = g + bg; rgb[ray * 3 + 2] = b + bg;
+    disp[ray] = 1.f / fmaxf(1e-10f, d / a);
+    acc[ray] = a;
+  }
+}
+hipError_t launch_composite_combine(const float* partial, size_t n_rays, int segs, float beta_min, int flags, float* rgb,
+                                    float* disp, float* acc, hipStream_t stream) {
+  if (!n_rays) return hipSuccess;
+  hipLaunchKernelGGL(composite_combine_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, stream, partial, n_rays, segs,
+                     beta_min, flags, rgb, disp, acc);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ bicubic resize
 // nn.Upsample(size, mode='bicubic') (align_corners=False, A = -0.75, border-replicated taps) on an
 // [H, W, C] image -> [UH, UW, C]: the x4 enlargement of a quarter-resolution render

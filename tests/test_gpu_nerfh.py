@@ -226,6 +226,46 @@ def test_full_frame_properties(scene):
     assert relmax(d32.reshape(-1)[sub.to(DEV)], ref["disp_map"]) < 2e-5
 
 
+def test_fused_compositing_matches_separate_compositor(scene):
+    """64+128 samples: the fine kernel composites 64-sample segments in-kernel and a combine pass chains them
+    (no raw in HBM); asking for raw takes the raw + composite_fine path.  Same maps to fp32 round-off."""
+    E = scene[0]
+    o, d, _ = eng.raygen(96, 128, 146.0, T(syn.orbit_pose(3, 8)).to(DEV))
+    hist = dev(syn.HIST_IDX)
+    a = E.render_rays(o.reshape(-1, 3), d.reshape(-1, 3), hist, 64, 128, 0., 2.5)
+    b = E.render_rays(o.reshape(-1, 3), d.reshape(-1, 3), hist, 64, 128, 0., 2.5, retraw=True)
+    assert a[3] is None and b[3] is not None
+    for x, y in zip(a[:3], b[:3]):
+        assert relmax(x, y.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_alternate_kernel_geometries(variant, gold):
+    """DFN_MLP_VARIANT selects other workgroup geometries of the same kernels (A/B aids, nerfh_layout.h); the
+    variant is latched per process, so each runs in a child.  Held to the same golden render."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, torch\n"
+        "from dfnet_amd import engine as eng, synthetic as syn\n"
+        "g = np.load('tests/golden/g7_render_image.npz')\n"
+        "E = eng.NerfHEngine().load_numpy(*syn.nerfh_weights(0))\n"
+        "d = lambda x: torch.as_tensor(x).float().cuda().contiguous()\n"
+        "r = E.render_image(d(g['c2w']), int(g['H']), int(g['W']), float(g['focal']), d(g['hist']), int(g['Nc']),"
+        " int(g['Ni']), float(g['near']), float(g['far']))\n"
+        "o, dd, _ = eng.raygen(48, 64, 73.0, d(g['c2w']))\n"
+        "f = E.render_rays(o.reshape(-1, 3), dd.reshape(-1, 3), d(g['hist']), 64, 128, 0., 2.5)\n"
+        "u = E.render_rays(o.reshape(-1, 3), dd.reshape(-1, 3), d(g['hist']), 64, 128, 0., 2.5, retraw=True)\n"
+        "e = max(float(np.abs(r[i].cpu().numpy() - g[k]).max() / np.abs(g[k]).max()) for i, k in enumerate(('rgb', 'disp', 'acc')))\n"
+        "e2 = max(float((f[i] - u[i]).abs().max() / u[i].abs().max()) for i in range(3))\n"
+        "print('ERR', e, e2)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DFN_MLP_VARIANT=str(variant), PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    e, e2 = [float(v) for v in out.stdout.strip().split("ERR")[-1].split()]
+    assert e < 1e-3 and e2 < 2e-6
+
+
 def test_sharper_scene_f16_margin():
     """Trained checkpoints are less contractive than default init: scale every weight matrix x1.6
     and check the f16 path still holds 1e-3 (and report-by-assert the exact path stays at fp32 round-off)."""
