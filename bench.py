@@ -155,7 +155,8 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic() if args.precision == "f16" else None,
                          "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) from profiles/; "
-                                         "algorithmic bytes per launch = rays * (768 z + 24 o,d + 512 ray-bias + 6912 raw)",
+                                         "algorithmic bytes per launch = rays * (768 z + 24 o,d + 512 ray-bias + 144 segment composites); "
+                                         "raw (6912 B/ray) stays in registers since compositing is fused",
                          "launches_per_step": launches.value / K, "avg_launch_ms": avg_ms.value,
                          "algorithmic_flops_per_launch": fine_flops_per_launch,
                          "coarse_kernel_avg_launch_ms": c_ms.value,

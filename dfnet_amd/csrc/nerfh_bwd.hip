@@ -1,0 +1,392 @@
+// nerfh_bwd.hip — gradient of the fine NeRF-H network w.r.t. its INPUTS (sample position and view direction)
+// on the CDNA4 matrix cores (gfx950 only).
+//
+// The DFNet_dm step back-propagates a feature/photometric loss through render(c2w = predicted pose) into the
+// pose (/root/reference/script/feature/direct_feature_matching.py:340-376, loss.backward()).  The NeRF weights
+// are frozen there and the coarse net receives no gradient (z_samples.detach(), models/rendering.py:302), so what
+// autograd computes is d L / d (point, viewdir) of the FINE net per sample.  This kernel does that in one pass
+// per tile of sample points, activations and their gradients in registers throughout:
+//   1. forward, exactly as nerfh_fine_kernel (same packed weights, same per-ray bias table), recording the ReLU
+//      sign of every hidden unit as one bit per lane-resident feature (21 registers per 32-point block);
+//   2. head derivatives (Sigmoid / Softplus, models/nerfw.py:281-295) applied to the incoming d L / d raw;
+//   3. backward: every Linear again as a transposed MFMA product, now with W^T as the A operand
+//      (nerfh_layout.h: BwdLayerId) — the C fragment of one backward layer, masked, is the B operand of the next;
+//   4. the positional-encoding Jacobians (models/nerfw.py:105-133) fold d pe_xyz / d pe_dir to 3 + 3 floats.
+// Output per sample: [d L/d point (3), d L/d viewdir through this sample (3)]; the per-ray reduction
+// (d o = sum, d d = sum z * ..., viewdir normalisation) is ray_grad_reduce_kernel in nerfh_stages.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nerfh_mlp_core.h"
+
+namespace dfn {
+
+template <class P, int N>
+DFN_DEV float get_slot(const typename FragOf<P>::type (&arr)[N], int s) {
+  if constexpr (P::kSlotsPerChunk == 8) return (float)arr[s >> 3][s & 7];
+  else return arr[s];
+}
+
+// ReLU on the first C chunks of v, recording (v > 0) per element: bit e of m, e = chunk * slots_per_chunk + slot.
+template <class P, int C, int N>
+DFN_DEV void relu_mask(typename FragOf<P>::type (&v)[N], uint32_t (&m)[(C * P::kSlotsPerChunk + 31) / 32]) {
+  constexpr int S = P::kSlotsPerChunk;
+#pragma unroll
+  for (int w = 0; w < (C * S + 31) / 32; ++w) m[w] = 0u;
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int e = c * S + j;
+      if constexpr (S == 8) {
+        const bool pos = v[c][j] > (_Float16)0;
+        m[e >> 5] |= (pos ? 1u : 0u) << (e & 31);
+        v[c][j] = pos ? v[c][j] : (_Float16)0;
+      } else {
+        const bool pos = v[c] > 0.f;
+        m[e >> 5] |= (pos ? 1u : 0u) << (e & 31);
+        v[c] = pos ? v[c] : 0.f;
+      }
+    }
+}
+// d pre-activation = d activation where the unit was active (torch: relu'(0) = 0).
+template <class P, int C, int N>
+DFN_DEV void apply_mask(typename FragOf<P>::type (&v)[N], const uint32_t (&m)[(C * P::kSlotsPerChunk + 31) / 32]) {
+  constexpr int S = P::kSlotsPerChunk;
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int e = c * S + j;
+      const bool on = (m[e >> 5] >> (e & 31)) & 1u;
+      if constexpr (S == 8) v[c][j] = on ? v[c][j] : (_Float16)0;
+      else v[c] = on ? v[c] : 0.f;
+    }
+}
+template <class P, int N>
+DFN_DEV void clear(typename FragOf<P>::type (&v)[N]) {
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    if constexpr (P::kSlotsPerChunk == 8) v[c] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    else v[c] = 0.f;
+  }
+}
+
+template <class P, int UMB, int WAVES, int NB> constexpr uint32_t bwd_lds_bytes() { return 2 * bwd_max_unit_bytes<P>(); }
+
+// A plain layer of the backward kernel: a new staging unit, no bias folding, no activation, no pipelining.
+#define DFN_BLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
+  layer<P, UMB, false, NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
+
+template <class P, bool FAST, int WAVES, int UMB, int NB>
+__global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PPT = WAVES * NB * 32;
+  constexpr int HC = chunks_of<P>(64), QC = chunks_of<P>(32), PC = chunks_of<P>(32), SC = chunks_of<P>(16);
+  using F = typename FragOf<P>::type;
+  Stager st;
+  st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
+  st.lds_cur = 0; st.lds_nxt = bwd_max_unit_bytes<P>();
+  st.waves = WAVES;
+  st.skew = 0;
+  st.t_sync = st.t_wait = 0;
+  st.younger_loads = 0;
+  st.trace = nullptr;
+  st.n_trace = 0;
+  st.lane = threadIdx.x & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = st.lane & 31, h = st.lane >> 5;
+  const long long n_pts = (long long)a.n_rays * a.n_samples;
+  const long long n_tiles = (n_pts + PPT - 1) / PPT;
+  long long tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  stage_issue(st, smem, 0, st.lds_cur);
+  st.pf_off = st.tab[st.n_units > 1 ? 2 : 0];
+  st.pf_size = st.tab[st.n_units > 1 ? 3 : 1];
+  for (; tile < n_tiles; tile += gridDim.x) {
+    st.more = tile + gridDim.x < n_tiles;
+    float x[NB][3], g[NB][9];
+    long long pt[NB];
+    uint32_t ray_of[NB];
+    const float* rb_dir[NB];
+    const float* rb_tr[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      pt[nb] = tile * PPT + st.wave * (NB * 32) + nb * 32 + p;
+      const uint32_t q = uint32_t(pt[nb] < n_pts ? pt[nb] : n_pts - 1);
+      ray_of[nb] = q / uint32_t(a.n_samples);
+      const float z = a.z[q];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[nb][c] = add_rn(a.rays_o[ray_of[nb] * 3 + c], mul_rn(a.rays_d[ray_of[nb] * 3 + c], z));
+#pragma unroll
+      for (int c = 0; c < 9; ++c) g[nb][c] = (h == 0 && pt[nb] < n_pts) ? a.graw[size_t(q) * 9 + c] : 0.f;
+      rb_dir[nb] = a.ray_bias + size_t(ray_of[nb]) * kRayBiasFloats;
+      rb_tr[nb] = rb_dir[nb] + kRayBiasFloats / 2;
+    }
+    const float* const norb[NB] = {};
+    f32x16 head[NB], carry[NB];
+    uint32_t mk[8][NB][2], md[NB][1], mt[4][NB][1];
+
+    // ------------------------------------------------------------------ forward (recording ReLU signs)
+    F hid[NB][HC];
+    {
+      F pe[NB][PC], u[NB][HC];
+      posenc_xyz<P, FAST, NB, PC>(x, h, pe);
+      DFN_BLAYER(PC, 4, false, false, pe, u, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(u[nb], mk[0][nb]);
+      DFN_BLAYER(HC, 4, false, false, u, hid, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(hid[nb], mk[1][nb]);
+      DFN_BLAYER(HC, 4, false, false, hid, u, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(u[nb], mk[2][nb]);
+      DFN_BLAYER(HC, 4, false, false, u, hid, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(hid[nb], mk[3][nb]);
+      {
+        F cat[NB][PC + HC];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+          for (int i = 0; i < PC; ++i) cat[nb][i] = pe[nb][i];
+#pragma unroll
+          for (int i = 0; i < HC; ++i) cat[nb][PC + i] = hid[nb][i];
+        }
+        DFN_BLAYER(PC + HC, 4, false, false, cat, u, norb);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(u[nb], mk[4][nb]);
+      DFN_BLAYER(HC, 4, false, false, u, hid, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(hid[nb], mk[5][nb]);
+      DFN_BLAYER(HC, 4, false, false, hid, u, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(u[nb], mk[6][nb]);
+      DFN_BLAYER(HC, 4, false, false, u, hid, norb);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(hid[nb], mk[7][nb]);
+    }
+    // heads; their pre-activation gradients seed the backward pass
+    F dth[NB][SC], drgb[NB][SC], dsig[NB][SC];
+    {
+      F fin[NB][HC], dummy[NB][SC];
+      DFN_BLAYER(HC, 4, true, false, hid, fin, norb);   // xyz_encoding_final + static_sigma (5th M-block)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        clear<P>(dsig[nb]);
+        set_slot<P>(dsig[nb], 0, h == 0 ? g[nb][3] * act_sigmoid<FAST>(head[nb][0]) : 0.f);  // softplus' = sigmoid
+      }
+      {
+        F de[NB][QC];
+        DFN_BLAYER(HC, 2, false, true, fin, de, rb_dir);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(de[nb], md[nb]);
+        DFN_BLAYER(QC, 0, true, false, de, dummy, norb);  // static_rgb
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          clear<P>(drgb[nb]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float y = act_sigmoid<FAST>(head[nb][c]);
+            set_slot<P>(drgb[nb], c, h == 0 ? g[nb][c] * y * (1.f - y) : 0.f);
+          }
+        }
+      }
+      {
+        F t0[NB][QC], t1[NB][QC];
+        DFN_BLAYER(HC, 2, false, true, fin, t0, rb_tr);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(t0[nb], mt[0][nb]);
+        DFN_BLAYER(QC, 2, false, false, t0, t1, norb);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(t1[nb], mt[1][nb]);
+        DFN_BLAYER(QC, 2, false, false, t1, t0, norb);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(t0[nb], mt[2][nb]);
+        DFN_BLAYER(QC, 2, false, false, t0, t1, norb);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(t1[nb], mt[3][nb]);
+        DFN_BLAYER(QC, 0, true, false, t1, dummy, norb);  // transient heads: rows 0..2 rgb, 3 sigma, 8 beta (C reg 4)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          clear<P>(dth[nb]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float y = act_sigmoid<FAST>(head[nb][c]);
+            set_slot<P>(dth[nb], c, h == 0 ? g[nb][4 + c] * y * (1.f - y) : 0.f);
+          }
+          set_slot<P>(dth[nb], 3, h == 0 ? g[nb][7] * act_sigmoid<FAST>(head[nb][3]) : 0.f);
+          set_slot<P>(dth[nb], 4, h == 0 ? g[nb][8] * act_sigmoid<FAST>(head[nb][4]) : 0.f);
+        }
+      }
+    }
+
+    // ------------------------------------------------------------------ backward
+    float gx[NB][3], gv[NB][3];
+    F gh[NB][HC];
+    {
+      F cat[NB][HC];
+      {
+        F g0[NB][QC], g1[NB][QC];
+        DFN_BLAYER(SC, 2, false, false, dth, g1, norb);   // BW_THEAD
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g1[nb], mt[3][nb]);
+        DFN_BLAYER(QC, 2, false, false, g1, g0, norb);    // BW_TE3
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g0[nb], mt[2][nb]);
+        DFN_BLAYER(QC, 2, false, false, g0, g1, norb);    // BW_TE2
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g1[nb], mt[1][nb]);
+        DFN_BLAYER(QC, 2, false, false, g1, g0, norb);    // BW_TE1
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g0[nb], mt[0][nb]);
+        DFN_BLAYER(SC, 2, false, false, drgb, g1, norb);  // BW_RGB
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          apply_mask<P, QC>(g1[nb], md[nb]);
+#pragma unroll
+          for (int i = 0; i < QC; ++i) { cat[nb][i] = g0[nb][i]; cat[nb][QC + i] = g1[nb][i]; }
+        }
+      }
+      F cat2[NB][HC + SC];
+      {
+        F dfin[NB][HC];
+        DFN_BLAYER(HC, 4, true, false, cat, dfin, norb);  // BW_FINCAT: d final + (head) d pe_dir
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          // direction-encoding Jacobian: half h holds frequencies 2h, 2h+1 (pe_dir_feature())
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float v = a.viewdirs[ray_of[nb] * 3 + c];
+            float acc = h == 0 ? head[nb][12 + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const float f = float(1 << k) * (h ? 4.f : 1.f);
+              acc += f * (cosf(v * f) * head[nb][6 * k + c] - sinf(v * f) * head[nb][6 * k + 3 + c]);
+            }
+            gv[nb][c] = acc;
+          }
+#pragma unroll
+          for (int i = 0; i < HC; ++i) cat2[nb][i] = dfin[nb][i];
+#pragma unroll
+          for (int i = 0; i < SC; ++i) cat2[nb][HC + i] = dsig[nb][i];
+        }
+      }
+      DFN_BLAYER(HC + SC, 4, false, false, cat2, gh, norb);  // BW_FIN
+    }
+    F gh2[NB][HC];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[7][nb]);
+    DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L8
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[6][nb]);
+    DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);          // BW_L7
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[5][nb]);
+    DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L6
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[4][nb]);
+    // positional-encoding Jacobian of d pe (slot order pe_xyz_feature()), accumulated into gx
+    auto pe_jacobian = [&](const F (&dpe)[NB][PC], bool first) {
+      float x2[NB][3];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          x2[nb][c] = x[nb][c];
+          asm volatile("" : "+v"(x2[nb][c]));  // recompute sin/cos here instead of keeping 32 slots alive
+        }
+      F pe[NB][PC];
+      posenc_xyz<P, FAST, NB, PC>(x2, h, pe);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float acc = first ? 0.f : gx[nb][c];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const float f = float(1 << k) * (h ? 32.f : 1.f);
+            acc += f * (get_slot<P>(pe[nb], 6 * k + 3 + c) * get_slot<P>(dpe[nb], 6 * k + c) -
+                        get_slot<P>(pe[nb], 6 * k + c) * get_slot<P>(dpe[nb], 6 * k + 3 + c));
+          }
+          gx[nb][c] = acc;
+        }
+        // raw coordinates: half 0 slots 30, 31 = x, y; half 1 slot 30 = z
+        const float r30 = get_slot<P>(dpe[nb], 30), r31 = get_slot<P>(dpe[nb], 31);
+        gx[nb][0] += h == 0 ? r30 : 0.f;
+        gx[nb][1] += h == 0 ? r31 : 0.f;
+        gx[nb][2] += h == 1 ? r30 : 0.f;
+      }
+    };
+    {
+      F big[NB][HC + PC];
+      DFN_BLAYER(HC, 6, false, false, gh2, big, norb);       // BW_L5: d h4 (128) + d pe_xyz (skip connection)
+      F dpe[NB][PC];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int i = 0; i < HC; ++i) gh[nb][i] = big[nb][i];
+#pragma unroll
+        for (int i = 0; i < PC; ++i) dpe[nb][i] = big[nb][HC + i];
+        apply_mask<P, HC>(gh[nb], mk[3][nb]);
+      }
+      pe_jacobian(dpe, true);
+    }
+    DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L4
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[2][nb]);
+    DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);          // BW_L3
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[1][nb]);
+    DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L2
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[0][nb]);
+    {
+      F dpe[NB][PC];
+      DFN_BLAYER(HC, 2, false, false, gh2, dpe, norb);       // BW_L1
+      pe_jacobian(dpe, false);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float o6[6];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o6[c] = gx[nb][c] + __shfl_xor(gx[nb][c], 32, 64);
+        o6[3 + c] = gv[nb][c] + __shfl_xor(gv[nb][c], 32, 64);
+      }
+      if (h == 0 && pt[nb] < n_pts) {
+        float* dst = a.gpts + size_t(pt[nb]) * 6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst[c] = o6[c];
+      }
+    }
+  }
+}
+
+template <class P, bool FAST, int WAVES, int UMB, int NB>
+static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream) {
+  constexpr int PPT = WAVES * NB * 32;
+  const long long n_pts = (long long)a.n_rays * a.n_samples;
+  if (n_pts <= 0) return hipSuccess;
+  if (n_pts >= (1LL << 31)) return hipErrorInvalidValue;
+  const long long n_tiles = (n_pts + PPT - 1) / PPT;
+  const int grid = int(n_tiles < n_cu ? n_tiles : n_cu);
+  const uint32_t lds = bwd_lds_bytes<P, UMB, WAVES, NB>();
+  auto kern = nerfh_fine_backward_kernel<P, FAST, WAVES, UMB, NB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream) {
+  if (prec == 0) return launch_bwd_one<PrecF16, true, 4, 8, 2>(a, n_cu, stream);
+  return launch_bwd_one<PrecF32, false, 4, 1, 1>(a, n_cu, stream);
+}
+
+}  // namespace dfn

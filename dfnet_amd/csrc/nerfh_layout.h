@@ -114,6 +114,48 @@ DFN_HD constexpr uint32_t max_unit_bytes(int umb) {
   return a > b ? a : b;  // (the merged small-layer units, 46 208 / 41 600 / 20 864 bytes, are smaller than L5's)
 }
 
+// ---- input-gradient kernel (nerfh_bwd.hip) ---------------------------------------------------------------
+// The backward pass of a Linear is the same transposed product with W^T as the A operand: the rows of an
+// M-block are INPUT features of the forward layer and the contraction slots are its OUTPUT features, in the
+// C-fragment order the previous backward layer leaves them in (hidden_feature()).
+enum BwdLayerId {
+  BW_THEAD = 0,  // [d rgb_t(3), d sigma_t, d beta] -> d t3 (64)
+  BW_TE3, BW_TE2, BW_TE1,   // transient_encoding.{6,4,2}^T
+  BW_RGB,        // d rgb_s(3) -> d dir_h (64)
+  BW_FINCAT,     // [d t0_pre (64) ; d dir_pre (64)] -> d final (128) + 5th M-block: d pe_dir (27, pe_dir_feature())
+  BW_FIN,        // [d final (128) ; d sigma_s_pre] -> d h8 (128)
+  BW_L8, BW_L7, BW_L6,
+  BW_L5,         // d h5_pre -> d h4 (128) + M-blocks 4,5: d pe_xyz in positional-encoding slot order
+  BW_L4, BW_L3, BW_L2,
+  BW_L1,         // d h1_pre -> d pe_xyz (M-blocks 0,1)
+  BW_COUNT
+};
+DFN_HD constexpr LayerShape bwd_layer_shape(int id) {
+  return id == BW_THEAD || id == BW_RGB ? LayerShape{16, 2}
+       : id <= BW_TE1 ? LayerShape{32, 2}
+       : id == BW_FINCAT ? LayerShape{64, 5}
+       : id == BW_FIN ? LayerShape{80, 4}
+       : id == BW_L5 ? LayerShape{64, 6}
+       : id == BW_L1 ? LayerShape{64, 2}
+       : LayerShape{64, 4};
+}
+// Lane (half h', register r) of a C fragment <-> row i of its M-block, inverted.
+DFN_HD constexpr int mblock_half_of_row(int i) { return (i >> 2) & 1; }
+DFN_HD constexpr int mblock_reg_of_row(int i) { return (i & 3) + 4 * (i >> 3); }
+// Column of the 27-wide direction encoding whose gradient lands in C register r of half h of BW_FINCAT's 5th
+// M-block: half h owns frequencies 2h, 2h+1 (r = 6k'+c: sin of coord c, 6k'+3+c: cos), half 0 also the raw
+// direction in r = 12..14.  -1 = unused.
+DFN_HD constexpr int pe_dir_feature(int h, int r) {
+  return r < 12 ? 3 + 6 * (2 * h + r / 6) + (r % 6) : (h == 0 && r < 15 ? r - 12 : -1);
+}
+// Staging buffer of the backward kernel: its largest unit is BW_L5 (6 M-blocks x 64 slots) / L5 forward.
+template <class P>
+DFN_HD constexpr uint32_t bwd_max_unit_bytes() {
+  const uint32_t a = max_unit_bytes<P>(P::kSlotsPerChunk == 8 ? 8 : 1);
+  const uint32_t b = unit_bytes<P>(64, P::kSlotsPerChunk == 8 ? 6 : 1), c = unit_bytes<P>(80, P::kSlotsPerChunk == 8 ? 4 : 1);
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+
 // Per-ray bias table written by the ray-bias kernel and read by the fine kernel:
 // [ray][table(0 = dir_encoding, 1 = transient_encoding.0)][mb(2)][h(2)][r(16)] fp32.
 constexpr int kRayBiasFloats = 2 * 2 * 2 * 16;

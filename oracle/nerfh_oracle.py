@@ -248,7 +248,7 @@ def render_rays(rows, coarse, fine, emb_a, emb_t, Nc, Ni, netchunk=65536, retraw
     sig = query_coarse_sigma(coarse, pts, netchunk=netchunk)[..., 0]
     _, w = coarse_weights(sig, z)
     mid = .5 * (z[:, 1:] + z[:, :-1])
-    zs = sample_pdf(mid, w[:, 1:-1], Ni, det=True)
+    zs = sample_pdf(mid, w[:, 1:-1], Ni, det=True).detach()  # rendering.py:302: no gradient through the sampler
     zf, _ = torch.sort(torch.cat([z, zs], -1), -1)
     pts_f = o[:, None, :] + d[:, None, :] * zf[..., None]
     raw = query_fine(fine, emb_a, emb_t, pts_f, view, hist, netchunk=netchunk)
@@ -274,6 +274,24 @@ def render(H, W, focal, chunk, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, im
             for i in range(0, rows.shape[0], chunk)]
     cat = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
     return [cat[k].reshape(*sh[:-1], *cat[k].shape[1:]) for k in ("rgb_map", "disp_map", "acc_map")]
+
+
+def render_grad_rays(rays_o, rays_d, G, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx):
+    """d sum(rgb * G) / d (rays_o, rays_d) by autograd through render(rays=...) — viewdirs are derived from
+    rays_d inside render (rendering.py:366-371), so their normalisation is part of the gradient."""
+    o = rays_o.detach().clone().requires_grad_(True)
+    d = rays_d.detach().clone().requires_grad_(True)
+    rgb = render(0, 0, 0., 1 << 30, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx, rays=(o, d))[0]
+    (rgb * G).sum().backward()
+    return rgb.detach(), o.grad, d.grad
+
+
+def render_grad_c2w(H, W, focal, c2w, G, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx):
+    """d sum(rgb * G) / d c2w[:3,:4] by autograd through render(c2w=...) (direct_feature_matching.py:340-376)."""
+    p = torch.as_tensor(c2w, dtype=torch.float32)[:3, :4].detach().clone().requires_grad_(True)
+    rgb = render(H, W, focal, 1 << 30, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx, c2w=p)[0]
+    (rgb * G).sum().backward()
+    return rgb.detach(), p.grad
 
 
 def psnr(rgb, gt):

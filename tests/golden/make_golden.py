@@ -69,7 +69,12 @@ def load_into(module, weights):
     assert not extra and not missing.unexpected_keys, (extra, missing.unexpected_keys)
 
 
+ONLY = os.environ.get("GOLDEN_ONLY", "")  # e.g. GOLDEN_ONLY=g9 rewrites only the fixtures whose name starts with g9
+
+
 def save(name, **arrs):
+    if ONLY and not name.startswith(ONLY):
+        return
     out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
@@ -204,6 +209,33 @@ def main():
         assert extras == {}
         save("g7_render_image", H=H, W=Wd, focal=focal, c2w=c2w, near=0., far=2.5, hist=hist, Nc=64, Ni=128,
              rgb=rgb, disp=disp, acc=acc)
+
+    # ---------------- G9: gradients of the render w.r.t. rays / pose (the autograd path of
+    # feature/direct_feature_matching.py:340-376: loss.backward() through render(c2w=pose_nerf)).
+    # Loss = sum(rgb * G) with a fixed random G, so every ray and channel is weighted differently.
+    grng = np.random.default_rng(77)
+    for tag, R, Nc, Ni in (("a", 24, 8, 16), ("b", 8, 64, 128)):
+        c2w = syn.orbit_pose(5, 8)[:3, :4]
+        ro, rd = ray_utils.get_rays(480, 640, 585.0, t(c2w))
+        sel = grng.choice(480 * 640, R, replace=False)
+        rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).clone().requires_grad_(True)
+        G = grng.standard_normal((R, 3)).astype(np.float32)
+        rgb, disp, acc, _ = rendering.render(480, 640, 585.0, chunk=32768, rays=rays, near=0., far=2.5,
+                                             img_idx=t(hist)[None], **kwargs_for(128, Nc, Ni))
+        (rgb * t(G)).sum().backward()
+        assert all(p.grad is None for p in nets[128][0].parameters())  # the coarse net gets no gradient (z_samples.detach())
+        save(f"g9_render_grad_rays_{tag}", Nc=Nc, Ni=Ni, near=0., far=2.5, hist=hist, rays_o=rays[0], rays_d=rays[1],
+             G=G, rgb=rgb, grad_rays_o=rays.grad[0], grad_rays_d=rays.grad[1])
+        for net in nets[128][:2]:
+            net.zero_grad()
+    H, Wd, focal = 12, 16, 14.6
+    pose = t(syn.orbit_pose(1, 8))[:3, :4].clone().requires_grad_(True)
+    G = grng.standard_normal((H, Wd, 3)).astype(np.float32)
+    rgb, disp, acc, _ = rendering.render(H, Wd, focal, chunk=100, c2w=pose, near=0., far=2.5, img_idx=t(hist)[None],
+                                         **kwargs_for(128, 64, 128))
+    (rgb * t(G)).sum().backward()
+    save("g9_render_grad_c2w", H=H, W=Wd, focal=focal, c2w=pose, near=0., far=2.5, hist=hist, Nc=64, Ni=128, G=G,
+         rgb=rgb, grad_c2w=pose.grad)
 
     # ---------------- G8: DFNet forward (reference feature/dfnet.py on a restated VGG16 stack)
     _install_vgg_stub()

@@ -96,6 +96,24 @@ def test_g7_render_image(gold):
     close(acc, g["acc"], 1e-5, 1e-6)
 
 
+def test_g9_render_gradients(gold):
+    """Autograd through the oracle's render == autograd through the reference's render (pose / ray gradients)."""
+    c, f, ea, et = nets(128)
+    for tag in "ab":
+        g = gold("g9_render_grad_rays_" + tag)
+        rgb, go, gd = orc.render_grad_rays(T(g["rays_o"]), T(g["rays_d"]), T(g["G"]), c, f, ea, et, int(g["Nc"]),
+                                           int(g["Ni"]), float(g["near"]), float(g["far"]), g["hist"])
+        close(rgb, g["rgb"], 1e-5, 1e-6)
+        scale = float(np.abs(g["grad_rays_d"]).max())
+        close(go, g["grad_rays_o"], 1e-4, 1e-5 * scale)
+        close(gd, g["grad_rays_d"], 1e-4, 1e-5 * scale)
+    g = gold("g9_render_grad_c2w")
+    rgb, gc = orc.render_grad_c2w(int(g["H"]), int(g["W"]), float(g["focal"]), g["c2w"], T(g["G"]), c, f, ea, et,
+                                  int(g["Nc"]), int(g["Ni"]), float(g["near"]), float(g["far"]), g["hist"])
+    close(rgb, g["rgb"], 1e-5, 1e-6)
+    close(gc, g["grad_c2w"], 1e-4, 1e-5 * float(np.abs(g["grad_c2w"]).max()))
+
+
 def test_g8_dfnet(gold):
     p = tt(syn.dfnet_weights(seed=3))
     g = gold("g8_dfnet_small")
