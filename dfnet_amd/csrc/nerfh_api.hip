@@ -56,6 +56,7 @@ struct dfn_nerfh_s {
   std::map<std::string, std::vector<float>> params;
   bool committed = false;
   PackedNet net[2][2][kVariants];  // [coarse/fine][prec][kernel variant]
+  PackedNet bwd[2];                // [prec] fine forward units + backward (W^T) units of the gradient kernel
   float* extra = nullptr;  // w_dir^T | b_dir | w_tr^T | b_tr | emb_a | emb_t
   RayBiasWeights rb{};
 };
@@ -121,6 +122,11 @@ static void free_packed(dfn_nerfh_s* h) {
         if (n.tab) (void)hipFree(n.tab);
         n = PackedNet();
       }
+  for (auto& n : h->bwd) {
+    if (n.blob) (void)hipFree(n.blob);
+    if (n.tab) (void)hipFree(n.tab);
+    n = PackedNet();
+  }
   if (h->extra) (void)hipFree(h->extra);
   h->extra = nullptr;
 }
@@ -236,6 +242,79 @@ struct Packer {
         }
     }
   }
+  // Element of the backward (W^T) layer `layer` at row i of M-block mb, contraction slot s of half hh
+  // (nerfh_layout.h: BwdLayerId).  Rows are INPUT features of the forward Linear, slots its OUTPUT features.
+  float bwd_elem(int layer, int mb, int i, int hh, int s) const {
+    const int k = 32 * mb + i;
+    auto W = [](const Mat& m, int row, int col) {
+      return (row >= 0 && row < m.rows && col >= 0 && col < m.cols) ? m.w[size_t(row) * m.cols + col] : 0.f;
+    };
+    auto pe_col = [&](int blk) { return pe_xyz_feature(mblock_half_of_row(i), 16 * blk + mblock_reg_of_row(i)); };
+    const int j = hidden_feature(hh, s);
+    switch (layer) {
+      case BW_THEAD:
+        if (j < 3) return W(mat("transient_rgb.0"), j, k);
+        if (j == 3) return W(mat("transient_sigma.0"), 0, k);
+        if (j == 8) return W(mat("transient_beta.0"), 0, k);
+        return 0.f;
+      case BW_TE3: return W(mat("transient_encoding.6"), j, k);
+      case BW_TE2: return W(mat("transient_encoding.4"), j, k);
+      case BW_TE1: return W(mat("transient_encoding.2"), j, k);
+      case BW_RGB: return j < 3 ? W(mat("static_rgb.0"), j, k) : 0.f;
+      case BW_FINCAT: {
+        const bool dirpart = s >= 32;
+        const int jj = hidden_feature(hh, s & 31);
+        if (mb < 4) return W(mat(dirpart ? "dir_encoding.0" : "transient_encoding.0"), jj, k);
+        if (!dirpart) return 0.f;
+        const int c = pe_dir_feature(mblock_half_of_row(i), mblock_reg_of_row(i));
+        return c >= 0 ? W(mat("dir_encoding.0"), jj, kWidth + c) : 0.f;
+      }
+      case BW_FIN:
+        if (s < 64) return W(mat("xyz_encoding_final"), j, k);
+        return (s == 64 && hh == 0) ? W(mat("static_sigma.0"), 0, k) : 0.f;
+      case BW_L5:
+        if (mb < 4) return W(mat("xyz_encoding_5.0"), j, kChXyz + k);
+        return W(mat("xyz_encoding_5.0"), j, pe_col(mb - 4));
+      case BW_L1: return W(mat("xyz_encoding_1.0"), j, pe_col(mb));
+      default: {  // BW_L8..BW_L6, BW_L4..BW_L2: 128 -> 128
+        const int n = 8 - (layer - BW_L8);
+        return W(mat("xyz_encoding_" + std::to_string(n) + ".0"), j, k);
+      }
+    }
+  }
+  template <class P>
+  void pack_bwd_blocks(int layer, int mb0, int group, uint8_t* base) const {
+    using Elem = typename std::conditional<P::kSlotsPerChunk == 8, _Float16, float>::type;
+    const LayerShape sh = bwd_layer_shape(layer);
+    const int KC = sh.slots / P::kSlotsPerChunk;
+    Elem* frag = reinterpret_cast<Elem*>(base);  // bias fragments after the A fragments stay zero
+    for (int g = 0; g < group; ++g)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int kc = 0; kc < KC; ++kc)
+          for (int j = 0; j < P::kSlotsPerChunk; ++j)
+            frag[((size_t(g) * KC + kc) * 64 + lane) * P::kSlotsPerChunk + j] =
+                Elem(bwd_elem(layer, mb0 + g, lane & 31, lane >> 5, kc * P::kSlotsPerChunk + j));
+  }
+  // Blob of the gradient kernel: the fine net's forward layers, one unit per layer (f16) / per M-block (f32),
+  // then the backward layers the same way.
+  template <class P>
+  void pack_bwd(std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
+    const int umb = P::kSlotsPerChunk == 8 ? 8 : 1;
+    pack<P>(true, umb, false, blob, tab);
+    for (int layer = 0; layer < BW_COUNT; ++layer) {
+      const LayerShape sh = bwd_layer_shape(layer);
+      for (int mb0 = 0; mb0 < sh.mb; mb0 += umb) {
+        const int group = sh.mb - mb0 < umb ? sh.mb - mb0 : umb;
+        const uint32_t bytes = unit_bytes<P>(sh.slots, group);
+        const uint32_t off = uint32_t(blob.size());
+        blob.resize(off + bytes, 0);
+        tab.push_back(off);
+        tab.push_back(bytes);
+        pack_bwd_blocks<P>(layer, mb0, group, blob.data() + off);
+      }
+    }
+  }
+
   template <class P>
   static uint32_t blocks_bytes(int layer, int group) {
     const LayerShape sh = layer_shape(layer);
@@ -245,11 +324,11 @@ struct Packer {
   // The packed blob: staging units in execution order.  umb >= 8: a unit holds whole layers and the small
   // layers of one group (kFineGroup / kCoarseGroup) share a unit; otherwise a unit is <= umb M-blocks of a layer.
   template <class P>
-  void pack(bool fine, int umb, std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
+  void pack(bool fine, int umb, bool merge, std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
     const int* seq = fine ? kFineSeq : kCoarseSeq;
     const int* grp = fine ? kFineGroup : kCoarseGroup;
     const int nl = fine ? kFineLayers : kCoarseLayers;
-    if (umb >= 8) {
+    if (merge) {
       for (int li = 0; li < nl;) {
         int lj = li;
         uint32_t bytes = 0;
@@ -302,8 +381,8 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
         Packer pk{h, f ? "fine." : "coarse."};
         std::vector<uint8_t> blob;
         std::vector<uint32_t> tab;
-        if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, unit_mb<PrecF16>(var), blob, tab);
-        else pk.pack<PrecF32>(f, unit_mb<PrecF32>(var), blob, tab);
+        if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, unit_mb<PrecF16>(var), unit_mb<PrecF16>(var) >= 8, blob, tab);
+        else pk.pack<PrecF32>(f, unit_mb<PrecF32>(var), false, blob, tab);
         PackedNet& n = h->net[f][prec][var];
         int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
         if (rc) return rc;
@@ -311,6 +390,19 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
         if (rc) return rc;
         n.n_units = int(tab.size() / 2);
       }
+  for (int prec = 0; prec < 2; ++prec) {
+    Packer pk{h, "fine."};
+    std::vector<uint8_t> blob;
+    std::vector<uint32_t> tab;
+    if (prec == DFN_PREC_F16) pk.pack_bwd<PrecF16>(blob, tab);
+    else pk.pack_bwd<PrecF32>(blob, tab);
+    PackedNet& n = h->bwd[prec];
+    int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
+    if (rc) return rc;
+    rc = upload(tab.data(), tab.size() * 4, reinterpret_cast<void**>(&n.tab));
+    if (rc) return rc;
+    n.n_units = int(tab.size() / 2);
+  }
   // per-ray-bias weights: transposed tails of dir_encoding.0 / transient_encoding.0 + embeddings
   const dfn_nerfh_desc& d = h->desc;
   const int na = d.hist_bin * d.dim_a, nt = d.hist_bin * d.dim_t, kd = kChDir + na;
@@ -634,4 +726,125 @@ extern "C" int dfn_render_image(dfn_nerfh_t h, int prec, const float* c2w, int H
     return set_error(DFN_ERR_ARG, "dfn_render_image: workspace too small (%zu < %zu)", workspace_bytes, w.total);
   CHECK_HIP(launch_raygen(H, W, focal, c2w, w.o, w.d, w.v, HS(stream)), "dfn_render_image: raygen");
   return render_core(h, prec, w.o, w.d, w.v, hist, 1, n_rays, Nc, Ni, near, far, rgb, disp, acc, nullptr, w, HS(stream));
+}
+
+// ------------------------------------------------------------------------------------------ gradient path
+extern "C" int dfn_composite_fine_backward(const float* raw, const float* z, const float* grad_rgb, size_t n_rays, int Nf,
+                                           float* grad_raw, void* stream) {
+  if (!raw || !z || !grad_rgb || !grad_raw || Nf < 1 || Nf > 512)
+    return set_error(DFN_ERR_ARG, "dfn_composite_fine_backward: bad argument (1 <= Nf <= 512)");
+  CHECK_HIP(launch_composite_fine_backward(raw, z, grad_rgb, n_rays, Nf, grad_raw, HS(stream)), "dfn_composite_fine_backward");
+  return DFN_OK;
+}
+
+extern "C" int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                     const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf,
+                                     const float* grad_raw, float* grad_pts, void* bias_ws, void* stream) {
+  if (int rc = check_net(h, prec, "dfn_mlp_fine_backward")) return rc;
+  if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !grad_raw || !grad_pts || !bias_ws || Nf < 1 ||
+      (hist_rows != 1 && hist_rows != n_rays))
+    return set_error(DFN_ERR_ARG, "dfn_mlp_fine_backward: bad argument (hist_rows must be 1 or n_rays)");
+  float* table = static_cast<float*>(bias_ws);
+  CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine_backward(ray_bias)");
+  const PackedNet& n = h->bwd[prec];
+  BwdArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, viewdirs, z_fine, table, grad_raw, grad_pts, (long long)n_rays, Nf};
+  CHECK_HIP(launch_mlp_fine_backward(prec, a, device_cu_count(), HS(stream)), "dfn_mlp_fine_backward");
+  return DFN_OK;
+}
+
+namespace {
+struct BwdWorkspace {
+  Workspace f;
+  float *graw, *gpts, *go, *gd;
+  size_t total;
+};
+BwdWorkspace carve_bwd(char* base, size_t n_rays, int Nc, int Ni) {
+  BwdWorkspace b{};
+  b.f = carve(base, n_rays, Nc, Ni, true);
+  const size_t chunk = chunk_rays(n_rays), Nf = size_t(Nc) + Ni;
+  size_t off = b.f.total;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return reinterpret_cast<float*>(p); };
+  b.graw = take(chunk * Nf * 9 * 4);
+  b.gpts = take(chunk * Nf * 6 * 4);
+  b.go = take(n_rays * 12);
+  b.gd = take(n_rays * 12);
+  b.total = off;
+  return b;
+}
+
+// Forward recompute (coarse -> sampler -> fine raw) then the gradient kernels, chunk by chunk.
+int render_backward_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const float* v, bool derive_v,
+                         const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far,
+                         const float* grad_rgb, float* go, float* gd, float* gv, const BwdWorkspace& w, hipStream_t s) {
+  const int Nf = Nc + Ni, var = mlp_variant(), cus = device_cu_count();
+  const PackedNet& nc = h->net[0][prec][var];
+  const PackedNet& nf = h->net[1][prec][var];
+  const PackedNet& nb = h->bwd[prec];
+  const size_t chunk = chunk_rays(n_rays);
+  for (size_t r0 = 0; r0 < n_rays; r0 += chunk) {
+    const size_t n = n_rays - r0 < chunk ? n_rays - r0 : chunk;
+    const float* co = o + r0 * 3;
+    const float* cd = d + r0 * 3;
+    const float* cv = v + r0 * 3;
+    const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
+    MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr, 0};
+    CHECK_HIP(launch_mlp(false, prec, var, ac, cus, s), "render backward: coarse MLP");
+    CHECK_HIP(launch_sample_fine(w.f.sigma, n, Nc, Ni, near, far, w.f.z, nullptr, nullptr, s), "render backward: sample_fine");
+    CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.f.bias, s), "render backward: ray_bias");
+    MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr, 0};
+    CHECK_HIP(launch_mlp(true, prec, var, af, cus, s), "render backward: fine MLP");
+    CHECK_HIP(launch_composite_fine_backward(w.f.raw, w.f.z, grad_rgb + r0 * 3, n, Nf, w.graw, s), "render backward: composite");
+    BwdArgs ab{nb.blob, nb.tab, nb.n_units, co, cd, cv, w.f.z, w.f.bias, w.graw, w.gpts, (long long)n, Nf};
+    CHECK_HIP(launch_mlp_fine_backward(prec, ab, cus, s), "render backward: fine MLP gradient");
+    CHECK_HIP(launch_ray_grad_reduce(w.gpts, w.f.z, cd, n, Nf, derive_v ? 1 : 0, go + r0 * 3, gd + r0 * 3,
+                                     gv ? gv + r0 * 3 : nullptr, s),
+              "render backward: ray reduction");
+  }
+  return DFN_OK;
+}
+}  // namespace
+
+extern "C" size_t dfn_render_backward_workspace_bytes(size_t n_rays, int Nc, int Ni) {
+  return carve_bwd(nullptr, n_rays ? n_rays : 1, Nc, Ni).total;
+}
+
+extern "C" int dfn_render_rays_backward(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                        const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near,
+                                        float far, const float* grad_rgb, float* grad_rays_o, float* grad_rays_d,
+                                        float* grad_viewdirs, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_net(h, prec, "dfn_render_rays_backward")) return rc;
+  if (int rc = check_render_args(Nc, Ni, "dfn_render_rays_backward")) return rc;
+  if (!rays_o || !rays_d || !hist || !grad_rgb || !grad_rays_o || !grad_rays_d || !workspace ||
+      (hist_rows != 1 && hist_rows != n_rays))
+    return set_error(DFN_ERR_ARG, "dfn_render_rays_backward: bad argument (hist_rows must be 1 or n_rays)");
+  if (!n_rays) return DFN_OK;
+  const BwdWorkspace w = carve_bwd(static_cast<char*>(workspace), n_rays, Nc, Ni);
+  if (w.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_render_rays_backward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  const float* v = viewdirs;
+  if (!v) {
+    CHECK_HIP(launch_viewdirs(rays_d, n_rays, w.f.v, HS(stream)), "dfn_render_rays_backward: viewdirs");
+    v = w.f.v;
+  }
+  return render_backward_core(h, prec, rays_o, rays_d, v, viewdirs == nullptr, hist, hist_rows, n_rays, Nc, Ni, near, far,
+                              grad_rgb, grad_rays_o, grad_rays_d, viewdirs ? grad_viewdirs : nullptr, w, HS(stream));
+}
+
+extern "C" int dfn_render_image_backward(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, float focal, float near,
+                                         float far, int Nc, int Ni, const float* hist, const float* grad_rgb,
+                                         float* grad_c2w, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_net(h, prec, "dfn_render_image_backward")) return rc;
+  if (int rc = check_render_args(Nc, Ni, "dfn_render_image_backward")) return rc;
+  if (!c2w || !hist || !grad_rgb || !grad_c2w || !workspace || H < 1 || W < 1 || !(focal > 0))
+    return set_error(DFN_ERR_ARG, "dfn_render_image_backward: bad argument");
+  const size_t n_rays = size_t(H) * W;
+  const BwdWorkspace w = carve_bwd(static_cast<char*>(workspace), n_rays, Nc, Ni);
+  if (w.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_render_image_backward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  CHECK_HIP(launch_raygen(H, W, focal, c2w, w.f.o, w.f.d, w.f.v, HS(stream)), "dfn_render_image_backward: raygen");
+  if (int rc = render_backward_core(h, prec, w.f.o, w.f.d, w.f.v, true, hist, 1, n_rays, Nc, Ni, near, far, grad_rgb, w.go,
+                                    w.gd, nullptr, w, HS(stream)))
+    return rc;
+  CHECK_HIP(launch_raygen_backward(H, W, focal, w.go, w.gd, grad_c2w, HS(stream)), "dfn_render_image_backward: raygen");
+  return DFN_OK;
 }

@@ -385,7 +385,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream)
 }
 
 hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream) {
-  if (prec == 0) return launch_bwd_one<PrecF16, true, 4, 8, 2>(a, n_cu, stream);
+  if (prec == 0) return launch_bwd_one<PrecF16, true, 4, 8, 1>(a, n_cu, stream);
   return launch_bwd_one<PrecF32, false, 4, 1, 1>(a, n_cu, stream);
 }
 

@@ -1,0 +1,197 @@
+// nerfh_grad_stages.hip — the HBM-bound stages of the render GRADIENT path (gfx950): compositing backward,
+// per-ray reduction of the per-sample point gradients, and get_rays backward.  Together with
+// nerfh_bwd.hip they are what autograd executes for loss.backward() through render(c2w = pose)
+// (/root/reference/script/feature/direct_feature_matching.py:340-376).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nerfh_device.h"
+#include "nerfh_kernels.h"
+
+namespace dfn {
+
+static inline int grid_for(size_t n, int block, int cap = 256 * 8) {
+  const size_t g = (n + block - 1) / block;
+  return int(g < 1 ? 1 : (g > size_t(cap) ? size_t(cap) : g));
+}
+
+// ------------------------------------------------------------------------------------------ compositing backward
+// rgb = sum_i T_i (a_s,i c_s,i + a_t,i c_t,i),  T_i = prod_{j<i} exp(-delta_j (sigma_s,j + sigma_t,j))
+// (raw2outputs_NeRFW, models/rendering.py:161-230, test_time: the returned rgb_map is the joint composite).
+// With g = d L / d rgb and e_i = T_i g.(a_s c_s + a_t c_t):
+//   d c_s,i = g T_i a_s,i                          d c_t,i = g T_i a_t,i
+//   d sigma_s,i = delta_i [(1 - a_s,i) T_i g.c_s,i - S_i]      S_i = sum_{k>i} e_k  (sigma_i attenuates every later sample)
+//   d sigma_t,i = delta_i [(1 - a_t,i) T_i g.c_t,i - S_i]      d beta_i = 0 (beta does not reach rgb)
+// One wavefront per ray, SPL consecutive samples per lane.
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_fine_backward_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                                      const float* __restrict__ grad_rgb, size_t n_rays,
+                                                                      int Nf, float* __restrict__ graw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < n_rays; ray += size_t(gridDim.x) * 4) {
+    const float* rr = raw + ray * size_t(Nf) * 9;
+    const float* zr = z + ray * size_t(Nf);
+    float* gr = graw + ray * size_t(Nf) * 9;
+    const float g0 = grad_rgb[ray * 3], g1 = grad_rgb[ray * 3 + 1], g2 = grad_rgb[ray * 3 + 2];
+    float v[SPL][9], zz[SPL + 1];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int i = lane * SPL + k;
+      zz[k] = i < Nf ? zr[i] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) v[k][c] = i < Nf ? rr[size_t(i) * 9 + c] : 0.f;
+    }
+    zz[SPL] = __shfl_down(zz[0], 1, 64);
+    float a_s[SPL], a_t[SPL], om[SPL], dl[SPL];
+    float pj = 1.f;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int i = lane * SPL + k;
+      const bool ok = i < Nf;
+      dl[k] = i + 1 < Nf ? sub_rn(zz[k + 1], zz[k]) : 1e2f;
+      a_s[k] = ok ? sub_rn(1.f, expf(-mul_rn(dl[k], v[k][3]))) : 0.f;
+      a_t[k] = ok ? sub_rn(1.f, expf(-mul_rn(dl[k], v[k][7]))) : 0.f;
+      om[k] = ok ? expf(-mul_rn(dl[k], add_rn(v[k][3], v[k][7]))) : 1.f;   // 1 - alpha_joint
+      pj = mul_rn(pj, om[k]);
+    }
+    float Tj = __shfl_up(wave_incl_prod(pj, lane), 1, 64);
+    if (lane == 0) Tj = 1.f;
+    float T[SPL], gcs[SPL], gct[SPL], e[SPL], esum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      T[k] = Tj;
+      gcs[k] = g0 * v[k][0] + g1 * v[k][1] + g2 * v[k][2];
+      gct[k] = g0 * v[k][4] + g1 * v[k][5] + g2 * v[k][6];
+      e[k] = Tj * (a_s[k] * gcs[k] + a_t[k] * gct[k]);
+      esum += e[k];
+      Tj = mul_rn(Tj, om[k]);
+    }
+    const float incl = wave_incl_sum(esum, lane);
+    const float total = __shfl(incl, 63, 64);
+    float S = total - (incl - esum);   // sum over this lane's and all later samples
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int i = lane * SPL + k;
+      S -= e[k];                        // now: samples strictly after i
+      if (i < Nf) {
+        float* o = gr + size_t(i) * 9;
+        const float ws = T[k] * a_s[k], wt = T[k] * a_t[k];
+        o[0] = g0 * ws; o[1] = g1 * ws; o[2] = g2 * ws;
+        o[3] = dl[k] * ((1.f - a_s[k]) * T[k] * gcs[k] - S);
+        o[4] = g0 * wt; o[5] = g1 * wt; o[6] = g2 * wt;
+        o[7] = dl[k] * ((1.f - a_t[k]) * T[k] * gct[k] - S);
+        o[8] = 0.f;
+      }
+    }
+  }
+}
+
+hipError_t launch_composite_fine_backward(const float* raw, const float* z, const float* grad_rgb, size_t n_rays, int Nf,
+                                          float* graw, hipStream_t stream) {
+  if (!n_rays) return hipSuccess;
+  const int spl = (Nf + 63) / 64;
+  const dim3 grid(grid_for((n_rays + 3) / 4, 1, 256 * 16)), block(256);
+#define DFN_COMPB(S) \
+  hipLaunchKernelGGL(composite_fine_backward_kernel<S>, grid, block, 0, stream, raw, z, grad_rgb, n_rays, Nf, graw)
+  if (spl <= 1) DFN_COMPB(1);
+  else if (spl == 2) DFN_COMPB(2);
+  else if (spl == 3) DFN_COMPB(3);
+  else if (spl == 4) DFN_COMPB(4);
+  else if (spl <= 6) DFN_COMPB(6);
+  else if (spl <= 8) DFN_COMPB(8);
+  else return hipErrorInvalidValue;
+#undef DFN_COMPB
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ per-ray reduction
+// pts = o + d z (models/rendering.py:292,305)  =>  d o = sum_i g_i,  d d = sum_i z_i g_i.
+// viewdirs = d / |d| (rendering.py:366-371)    =>  d d += (gv - v (v.gv)) / |d|,  gv = sum_i gv_i.
+__global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __restrict__ gpts, const float* __restrict__ z,
+                                                              const float* __restrict__ rays_d, size_t n_rays, int Nf,
+                                                              int derive_viewdirs, float* __restrict__ grad_o,
+                                                              float* __restrict__ grad_d, float* __restrict__ grad_v) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < n_rays; ray += size_t(gridDim.x) * 4) {
+    float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f}, sv[3] = {0.f, 0.f, 0.f};
+    for (int i = lane; i < Nf; i += 64) {
+      const float* q = gpts + (ray * size_t(Nf) + i) * 6;
+      const float zi = z[ray * size_t(Nf) + i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { so[c] += q[c]; sd[c] += zi * q[c]; sv[c] += q[3 + c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { so[c] = wave_sum(so[c]); sd[c] = wave_sum(sd[c]); sv[c] = wave_sum(sv[c]); }
+    if (lane == 0) {
+      if (derive_viewdirs) {
+        const float d0 = rays_d[ray * 3], d1 = rays_d[ray * 3 + 1], d2 = rays_d[ray * 3 + 2];
+        const float inv = 1.f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        const float v0 = d0 * inv, v1 = d1 * inv, v2 = d2 * inv;
+        const float dot = v0 * sv[0] + v1 * sv[1] + v2 * sv[2];
+        sd[0] += (sv[0] - v0 * dot) * inv;
+        sd[1] += (sv[1] - v1 * dot) * inv;
+        sd[2] += (sv[2] - v2 * dot) * inv;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        grad_o[ray * 3 + c] = so[c];
+        grad_d[ray * 3 + c] = sd[c];
+        if (grad_v) grad_v[ray * 3 + c] = sv[c];
+      }
+    }
+  }
+}
+
+hipError_t launch_ray_grad_reduce(const float* gpts, const float* z, const float* rays_d, size_t n_rays, int Nf,
+                                  int derive_viewdirs, float* grad_o, float* grad_d, float* grad_viewdirs,
+                                  hipStream_t stream) {
+  if (!n_rays) return hipSuccess;
+  hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3(grid_for((n_rays + 3) / 4, 1, 256 * 16)), dim3(256), 0, stream, gpts, z,
+                     rays_d, n_rays, Nf, derive_viewdirs, grad_o, grad_d, grad_viewdirs);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ get_rays backward
+// rays_d[a] = sum_b cam[b] c2w[a][b], rays_o[a] = c2w[a][3] (models/ray_utils.py:5-15)
+//   =>  d c2w[a][b] = sum_rays d rays_d[a] cam[b],  d c2w[a][3] = sum_rays d rays_o[a].
+// One workgroup, fixed summation order (deterministic).
+__global__ __launch_bounds__(1024) void raygen_backward_kernel(int H, int W, float focal, const float* __restrict__ grad_o,
+                                                               const float* __restrict__ grad_d, float* __restrict__ grad_c2w) {
+  __shared__ float red[16][12];
+  const size_t n = size_t(H) * W;
+  const float hw = float(W) * .5f, hh = float(H) * .5f;
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  for (size_t px = threadIdx.x; px < n; px += blockDim.x) {
+    const int j = int(px / W), i = int(px - size_t(j) * W);
+    const float cam[3] = {(float(i) - hw) / focal, -(float(j) - hh) / focal, -1.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float gd = grad_d[px * 3 + a];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[a * 4 + b] += gd * cam[b];
+      acc[a * 4 + 3] += grad_o[px * 3 + a];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    float s = 0.f;
+    for (int w = 0; w < int(blockDim.x >> 6); ++w) s += red[w][threadIdx.x];
+    grad_c2w[threadIdx.x] = s;
+  }
+}
+
+hipError_t launch_raygen_backward(int H, int W, float focal, const float* grad_o, const float* grad_d, float* grad_c2w,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(raygen_backward_kernel, dim3(1), dim3(1024), 0, stream, H, W, focal, grad_o, grad_d, grad_c2w);
+  return hipGetLastError();
+}
+
+}  // namespace dfn

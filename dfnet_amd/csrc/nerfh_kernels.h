@@ -56,6 +56,34 @@ hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays
 // Chains the per-64-sample segment composites written by the fused fine kernel: partial [n_rays, segs, 12].
 hipError_t launch_composite_combine(const float* partial, size_t n_rays, int segs, float beta_min, int flags, float* rgb,
                                     float* disp, float* acc, hipStream_t stream);
+
+// --- gradient path (nerfh_bwd.hip, nerfh_stages.hip)
+struct BwdArgs {
+  const char* blob;        // forward fine units followed by the backward (W^T) units
+  const uint32_t* tab;
+  int n_units;
+  const float* rays_o;     // [n_rays,3]
+  const float* rays_d;     // [n_rays,3]
+  const float* viewdirs;   // [n_rays,3]
+  const float* z;          // [n_rays, n_samples]
+  const float* ray_bias;   // [n_rays, kRayBiasFloats]
+  const float* graw;       // [n_rays, n_samples, 9]  d L / d raw
+  float* gpts;             // [n_rays, n_samples, 6]  d L / d point (3), d L / d viewdir via this sample (3)
+  long long n_rays;
+  int n_samples;
+};
+hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream);
+// d L / d raw from d L / d rgb through the fine compositing (test-time, rgb only).
+hipError_t launch_composite_fine_backward(const float* raw, const float* z, const float* grad_rgb, size_t n_rays, int Nf,
+                                          float* graw, hipStream_t stream);
+// Per-ray reduction of the per-sample gradients: d o = sum g, d d = sum z g (+ viewdir normalisation when
+// `derive_viewdirs`), d viewdirs = sum gv (when grad_viewdirs != nullptr).
+hipError_t launch_ray_grad_reduce(const float* gpts, const float* z, const float* rays_d, size_t n_rays, int Nf,
+                                  int derive_viewdirs, float* grad_o, float* grad_d, float* grad_viewdirs,
+                                  hipStream_t stream);
+// get_rays backward: d c2w[3][4] from d rays_o / d rays_d of an H x W image.
+hipError_t launch_raygen_backward(int H, int W, float focal, const float* grad_o, const float* grad_d, float* grad_c2w,
+                                  hipStream_t stream);
 hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream);
 
 }  // namespace dfn

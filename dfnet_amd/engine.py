@@ -84,6 +84,18 @@ class NerfHEngine:
                                     ctypes.c_void_p(bias.data_ptr()), current_stream()), "dfn_mlp_fine")
         return raw
 
+    def mlp_fine_backward(self, rays_o, rays_d, viewdirs, hist, z_fine, grad_raw, precision=None):
+        """d L/d raw [n,Nf,9] -> [n,Nf,6]: d L/d sample point (3) and d L/d viewdir through that sample (3)."""
+        rays_o, rays_d, viewdirs, z_fine, grad_raw = (_f32c(t) for t in (rays_o, rays_d, viewdirs, z_fine, grad_raw))
+        hist = _f32c(hist).reshape(-1, self.hist_bin)
+        n, Nf = z_fine.shape
+        gpts = torch.empty(n, Nf, 6, device=rays_o.device)
+        bias = torch.empty(self.lib.dfn_fine_bias_bytes(n), dtype=torch.uint8, device=rays_o.device)
+        check(self.lib.dfn_mlp_fine_backward(self.handle, self._prec(precision), ptr(rays_o), ptr(rays_d), ptr(viewdirs),
+                                             ptr(hist), hist.shape[0], n, ptr(z_fine), Nf, ptr(grad_raw), ptr(gpts),
+                                             ctypes.c_void_p(bias.data_ptr()), current_stream()), "dfn_mlp_fine_backward")
+        return gpts
+
     # ------------------------------------------------------------------ whole path
     def render_rays(self, rays_o, rays_d, hist, Nc, Ni, near, far, viewdirs=None, retraw=False, precision=None):
         """Test-time render of a ray batch -> (rgb [n,3], disp [n], acc [n], raw|None)."""
@@ -120,6 +132,42 @@ class NerfHEngine:
                                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
               "dfn_render_image")
         return rgb, disp, acc
+
+
+    # ------------------------------------------------------------------ gradient of the whole path
+    def render_rays_backward(self, rays_o, rays_d, hist, Nc, Ni, near, far, grad_rgb, viewdirs=None, precision=None):
+        """d L/d (rays_o, rays_d[, viewdirs]) of render_rays from d L/d rgb [n,3].  With viewdirs=None they are
+        d/|d| and their gradient is folded into grad_rays_d (what autograd does for render(rays=...))."""
+        rays_o, rays_d = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3)
+        grad_rgb = _f32c(grad_rgb).reshape(-1, 3)
+        n, dev = rays_o.shape[0], rays_o.device
+        hist = _f32c(hist).reshape(-1, self.hist_bin)
+        go, gd = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+        gv = None
+        if viewdirs is not None:
+            viewdirs = _f32c(viewdirs).reshape(-1, 3)
+            gv = torch.empty(n, 3, device=dev)
+        ws = self._workspace(self.lib.dfn_render_backward_workspace_bytes(n, Nc, Ni), dev)
+        check(self.lib.dfn_render_rays_backward(self.handle, self._prec(precision), ptr(rays_o), ptr(rays_d), ptr(viewdirs),
+                                                ptr(hist), hist.shape[0], n, Nc, Ni, float(near), float(far),
+                                                ptr(grad_rgb), ptr(go), ptr(gd), ptr(gv),
+                                                ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
+              "dfn_render_rays_backward")
+        return go, gd, gv
+
+    def render_image_backward(self, c2w, H, W, focal, hist, Nc, Ni, near, far, grad_rgb, precision=None):
+        """d L/d c2w [3,4] of render_image from d L/d rgb [H,W,3]."""
+        c2w = _f32c(c2w)[:3, :4].contiguous()
+        dev = c2w.device
+        hist = _f32c(hist).reshape(-1)[: self.hist_bin].contiguous()
+        grad_rgb = _f32c(grad_rgb).reshape(H, W, 3)
+        gc = torch.empty(3, 4, device=dev)
+        ws = self._workspace(self.lib.dfn_render_backward_workspace_bytes(H * W, Nc, Ni), dev)
+        check(self.lib.dfn_render_image_backward(self.handle, self._prec(precision), ptr(c2w), H, W, float(focal),
+                                                 float(near), float(far), Nc, Ni, ptr(hist), ptr(grad_rgb), ptr(gc),
+                                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
+              "dfn_render_image_backward")
+        return gc
 
 
 class DfnetEngine:
@@ -259,3 +307,13 @@ def upsample_bicubic(img, outH, outW):
     check(lib.dfn_upsample_bicubic(ptr(img), H, W, C, int(outH), int(outW), ptr(out), current_stream()),
           "dfn_upsample_bicubic")
     return out
+
+
+def composite_fine_backward(raw, z, grad_rgb):
+    """d L/d raw [n,Nf,9] from d L/d rgb [n,3] through the test-time fine compositing (rgb only)."""
+    raw, z, grad_rgb = _f32c(raw), _f32c(z), _f32c(grad_rgb)
+    n, Nf = z.shape
+    graw = torch.empty(n, Nf, 9, device=raw.device)
+    check(_lib.load().dfn_composite_fine_backward(ptr(raw), ptr(z), ptr(grad_rgb), n, Nf, ptr(graw), current_stream()),
+          "dfn_composite_fine_backward")
+    return graw

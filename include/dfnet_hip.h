@@ -140,6 +140,39 @@ int dfn_render_image(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, fl
                      float* disp, float* acc, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ------------------------------------------------------------------ gradient of the render
+ * What loss.backward() runs through render(c2w = pose) in the DFNet_dm step
+ * (feature/direct_feature_matching.py:340-376): test-time render, NeRF weights frozen, no gradient through
+ * the importance sampler (z_samples.detach(), rendering.py:302) and hence none into the coarse net.
+ * Only d L / d rgb is propagated (disp / acc are not differentiated); white_bkgd = False. */
+
+/* raw2outputs_NeRFW backward, rgb only: grad_raw [n_rays, Nf, 9] = d L / d raw from grad_rgb [n_rays, 3]. */
+int dfn_composite_fine_backward(const float* raw, const float* z, const float* grad_rgb, size_t n_rays,
+                                int Nf, float* grad_raw, void* stream);
+/* Fine-network input gradient: from grad_raw [n_rays, Nf, 9] to grad_pts [n_rays, Nf, 6] =
+ * [d L / d sample point (3), d L / d viewdir through this sample (3)].  Other arguments as dfn_mlp_fine. */
+int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d,
+                          const float* viewdirs, const float* hist, size_t hist_rows, size_t n_rays,
+                          const float* z_fine, int Nf, const float* grad_raw, float* grad_pts,
+                          void* bias_ws, void* stream);
+/* Scratch needed by dfn_render_rays_backward / dfn_render_image_backward for up to n_rays rays. */
+size_t dfn_render_backward_workspace_bytes(size_t n_rays, int Nc, int Ni);
+/* d L / d rays_o, d L / d rays_d [n_rays, 3] of dfn_render_rays from grad_rgb [n_rays, 3] (recomputes the
+ * forward).  viewdirs == NULL: they are d/|d| and the normalisation is differentiated into grad_rays_d
+ * (render(rays=...), rendering.py:366-371); otherwise they are an independent input and grad_viewdirs
+ * (optional) receives their gradient. */
+int dfn_render_rays_backward(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d,
+                             const float* viewdirs, const float* hist, size_t hist_rows, size_t n_rays,
+                             int Nc, int Ni, float near, float far, const float* grad_rgb,
+                             float* grad_rays_o, float* grad_rays_d, float* grad_viewdirs,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* d L / d c2w [3,4] (device) of dfn_render_image from grad_rgb [H, W, 3]: the above + get_rays backward
+ * (ray_utils.py:5-15). */
+int dfn_render_image_backward(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, float focal,
+                              float near, float far, int Nc, int Ni, const float* hist,
+                              const float* grad_rgb, float* grad_c2w, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* nn.Upsample(size=(outH,outW), mode='bicubic') (align_corners=False) of an [H,W,C] device image: the
  * x`tinyscale` enlargement of a low-resolution render (feature/misc.py:230-237,
  * feature/direct_feature_matching.py:344-346).  out [outH,outW,C]. */

@@ -1,0 +1,147 @@
+"""GPU parity tests of the render GRADIENT path (d L/d rgb -> d L/d rays / pose) — what loss.backward()
+runs through render(c2w = pose) in the DFNet_dm step (feature/direct_feature_matching.py:340-376).
+
+Checkers: the golden gradients captured from the reference's own autograd (tests/golden/g9_*), and
+torch autograd through the CPU oracle.  Tolerances, relative to the largest gradient entry:
+  * exact-fp32 MFMA path (the default of the gradient path): 1e-5 for the network alone, 2e-4 per ray
+    through the whole render, 2e-3 for d c2w — a signed sum over all rays of per-ray terms that largely
+    cancel, so fp32 round-off of the terms is amplified (the oracle and the reference themselves differ
+    by ~1e-4 there, tests/test_oracle_golden.py);
+  * f16-input MFMA path: 1e-1 max / 3e-2 relative L2.  A hidden unit whose pre-activation is within f16
+    rounding of zero flips its ReLU gate, which changes that sample's gradient by O(1/width); this is
+    inherent to f16 activations, not an accumulation error, and is why the host defaults to fp32 here."""
+import numpy as np
+import pytest
+import torch
+
+from dfnet_amd import engine as eng
+from dfnet_amd import synthetic as syn
+from oracle import nerfh_oracle as orc
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+TOL = {"f32": 2e-4, "f16": 1e-1}
+TOL_NET = {"f32": 1e-5, "f16": 1e-1}
+TOL_L2 = {"f32": 1e-5, "f16": 3e-2}
+TOL_C2W = {"f32": 2e-3, "f16": 1e-1}
+
+
+def rel_l2(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm())
+
+
+def relmax(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert not torch.isnan(a).any()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def tt(d):
+    return {k: T(v) for k, v in d.items()}
+
+
+def dev(x):
+    return torch.as_tensor(x).float().to(DEV).contiguous()
+
+
+@pytest.fixture(scope="module")
+def scene():
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
+    return E, tt(cw), tt(fw), T(ea), T(et)
+
+
+def test_composite_backward_vs_autograd(gold):
+    g = gold("g4_composite")
+    rng = np.random.default_rng(5)
+    for raw_np, z_np in ((g["raw"], g["z"]),
+                         (np.abs(rng.standard_normal((37, 192, 9))).astype(np.float32) * 2,
+                          np.sort(rng.uniform(0, 2.5, (37, 192)).astype(np.float32), -1))):
+        raw = T(raw_np.copy()).requires_grad_(True)
+        G = T(rng.standard_normal((raw.shape[0], 3)).astype(np.float32))
+        out = orc.composite_fine(raw, T(z_np))
+        (out["rgb"] * G).sum().backward()
+        got = eng.composite_fine_backward(dev(raw_np), dev(z_np), dev(G))
+        assert relmax(got, raw.grad) < 2e-4  # S_i = total - prefix cancels for the front samples
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("n_rays,Nf", [(5, 24), (9, 192), (3, 70)])
+def test_mlp_fine_backward_vs_autograd(scene, prec, n_rays, Nf):
+    """d sum(raw * G) / d (points, viewdirs) of the fine network, all nine output channels weighted."""
+    E, c, f, ea, et = scene
+    rng = np.random.default_rng(11)
+    o = T(rng.uniform(-.3, .3, (n_rays, 3)).astype(np.float32))
+    d = T(rng.standard_normal((n_rays, 3)).astype(np.float32))
+    v = d / d.norm(dim=-1, keepdim=True)
+    z = T(np.sort(rng.uniform(0, 2.5, (n_rays, Nf)).astype(np.float32), -1))
+    G = T(rng.standard_normal((n_rays, Nf, 9)).astype(np.float32))
+    pts = (o[:, None] + d[:, None] * z[..., None]).requires_grad_(True)
+    vv = v.clone().requires_grad_(True)
+    raw = orc.query_fine(f, ea, et, pts, vv, T(syn.HIST_IDX)[None].repeat(n_rays, 1))
+    (raw * G).sum().backward()
+    got = E.mlp_fine_backward(dev(o), dev(d), dev(v), dev(syn.HIST_IDX), dev(z), dev(G), precision=prec)
+    e_pts, e_v = relmax(got[..., :3], pts.grad), relmax(got[..., 3:].sum(1), vv.grad)
+    l2 = rel_l2(got[..., :3], pts.grad)
+    print(f"{prec} n={n_rays} Nf={Nf}: d pts {e_pts:.2e} (L2 {l2:.2e})  d viewdirs {e_v:.2e}")
+    assert e_pts < TOL_NET[prec] and e_v < TOL_NET[prec] and l2 < TOL_L2[prec]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_render_rays_backward_golden(scene, gold, prec):
+    E = scene[0]
+    for tag in "ab":
+        g = gold("g9_render_grad_rays_" + tag)
+        go, gd, gv = E.render_rays_backward(dev(g["rays_o"]), dev(g["rays_d"]), dev(g["hist"]), int(g["Nc"]), int(g["Ni"]),
+                                            float(g["near"]), float(g["far"]), dev(g["G"]), precision=prec)
+        assert gv is None
+        scale = max(np.abs(g["grad_rays_o"]).max(), np.abs(g["grad_rays_d"]).max())
+        eo = float((go.cpu() - T(g["grad_rays_o"])).abs().max() / scale)
+        ed = float((gd.cpu() - T(g["grad_rays_d"])).abs().max() / scale)
+        print(f"{prec} {tag}: d rays_o {eo:.2e}  d rays_d {ed:.2e}")
+        assert eo < TOL[prec] and ed < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_render_image_backward_golden(scene, gold, prec):
+    E = scene[0]
+    g = gold("g9_render_grad_c2w")
+    gc = E.render_image_backward(dev(g["c2w"]), int(g["H"]), int(g["W"]), float(g["focal"]), dev(g["hist"]), int(g["Nc"]),
+                                 int(g["Ni"]), float(g["near"]), float(g["far"]), dev(g["G"]), precision=prec)
+    e = relmax(gc, g["grad_c2w"])
+    print(f"{prec}: d c2w {e:.2e}")
+    assert e < TOL_C2W[prec]
+
+
+def test_explicit_viewdirs_gradient(scene):
+    """viewdirs passed explicitly are an independent input: their gradient comes back separately and
+    grad_rays_d carries only the point path; folding it through d/|d| reproduces the derived-viewdirs result."""
+    E = scene[0]
+    o, d, v = eng.raygen(6, 8, 9.0, T(syn.orbit_pose(2, 8)).to(DEV))
+    o, d, v = o.reshape(-1, 3), d.reshape(-1, 3), v.reshape(-1, 3)
+    G = dev(np.random.default_rng(3).standard_normal((48, 3)))
+    hist = dev(syn.HIST_IDX)
+    go, gd, _ = E.render_rays_backward(o, d, hist, 64, 128, 0., 2.5, G, precision="f32")
+    go2, gd2, gv2 = E.render_rays_backward(o, d, hist, 64, 128, 0., 2.5, G, viewdirs=v, precision="f32")
+    n = d.norm(dim=-1, keepdim=True)
+    fold = gd2 + (gv2 - v * (v * gv2).sum(-1, keepdim=True)) / n
+    assert torch.equal(go, go2) and relmax(fold, gd.cpu()) < 1e-5
+
+
+def test_quarter_res_pose_gradient_vs_oracle(scene):
+    """The DFNet_dm geometry: 60x80 render (240x320 / 4) at 64+128, d L/d c2w against autograd through the oracle."""
+    E, c, f, ea, et = scene
+    H, W, focal = 60, 80, 585.0 / 8
+    c2w = T(syn.orbit_pose(6, 8))[:3, :4]
+    G = T(np.random.default_rng(9).standard_normal((H, W, 3)).astype(np.float32))
+    _, ref = orc.render_grad_c2w(H, W, focal, c2w, G, c, f, ea, et, 64, 128, 0., 2.5, syn.HIST_IDX)
+    for prec in ("f32", "f16"):
+        gc = E.render_image_backward(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, G.to(DEV), precision=prec)
+        e = relmax(gc, ref)
+        print(f"{prec}: 60x80 d c2w {e:.2e}")
+        assert e < TOL_C2W[prec]
+    gc2 = E.render_image_backward(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, G.to(DEV), precision="f16")
+    assert torch.equal(gc, gc2)  # deterministic
