@@ -46,6 +46,8 @@ struct dfn_dfnet_s {
   bool committed = false;
   std::vector<PackedConv> enc_packed;
   std::vector<PackedConv> ad1, ad5;  // per tap: 1x1 and BN-folded 5x5
+  // input-gradient convolutions: the same layers with in/out channels swapped and taps flipped (dgrad = conv)
+  std::vector<PackedConv> enc_dgrad, ad1_dgrad, ad5_dgrad;
   float* fc = nullptr;               // fc_w [feat_dim,512] | fc_b
 };
 
@@ -98,6 +100,9 @@ static void free_dev(dfn_dfnet_s* h) {
   drop(h->enc_packed);
   drop(h->ad1);
   drop(h->ad5);
+  drop(h->enc_dgrad);
+  drop(h->ad1_dgrad);
+  drop(h->ad5_dgrad);
   if (h->fc) (void)hipFree(h->fc);
   h->fc = nullptr;
 }
@@ -175,6 +180,19 @@ int pack_and_upload(const float* w, const float* b, int cout, int cin, int ks, b
   return upload_bytes(bias.data(), bias.size() * 4, reinterpret_cast<void**>(&pc.bias));
 }
 
+// The data gradient of a stride-1 "same" convolution is itself one: w'[ci][co][ky][kx] = w[co][ci][K-1-ky][K-1-kx].
+// Output channels are padded to a multiple of 64 (two M-blocks, conv_mb()); no bias.
+int pack_dgrad(const float* w, int cout, int cin, int ks, PackedConv& pc) {
+  const int cop = (cin + 63) / 64 * 64;
+  std::vector<float> wt(size_t(cop) * cout * ks * ks, 0.f), zero(cop, 0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx)
+          wt[((size_t(ci) * cout + co) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)] = w[((size_t(co) * cin + ci) * ks + ky) * ks + kx];
+  return pack_and_upload(wt.data(), zero.data(), cop, cout, ks, false, pc);
+}
+
 }  // namespace
 
 extern "C" int dfn_dfnet_commit(dfn_dfnet_t h) {
@@ -208,7 +226,15 @@ extern "C" int dfn_dfnet_commit(dfn_dfnet_t h) {
       b5[co] = (b5[co] - mu[co]) * sc + beta[co];
     }
     if (int rc = pack_and_upload(w5.data(), b5.data(), 128, 64, 5, false, h->ad5[t])) return rc;
+    h->ad1_dgrad.resize(h->n_taps);
+    h->ad5_dgrad.resize(h->n_taps);
+    if (int rc = pack_dgrad(h->params[p + ".0.weight"].data(), 64, h->tap_channels[t], 1, h->ad1_dgrad[t])) return rc;
+    if (int rc = pack_dgrad(w5.data(), 128, 64, 5, h->ad5_dgrad[t])) return rc;  // BN scale is part of the folded weights
   }
+  h->enc_dgrad.resize(h->enc.size());
+  for (size_t i = 0; i < h->enc.size(); ++i)
+    if (int rc = pack_dgrad(h->params[h->enc[i].key + ".weight"].data(), h->enc[i].cout, h->enc[i].cin, 3, h->enc_dgrad[i]))
+      return rc;
   std::vector<float> fc = h->params["fc_pose.weight"];
   const auto& fb = h->params["fc_pose.bias"];
   fc.insert(fc.end(), fb.begin(), fb.end());
@@ -332,6 +358,142 @@ extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B,
     CHECK_HIP(launch_pose_head(prec, last_act, B, last_h, last_w, h->fc, h->fc + size_t(h->feat_dim) * 512, h->feat_dim,
                                pose, s),
               "dfnet: pose head");
+  }
+  return DFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ input gradient
+namespace {
+struct DfBwdWs {
+  char* prep;
+  char* act[13];     // post-ReLU output of every encoder conv (ReLU gates, max-pool routing)
+  char* tap[3];      // pre-ReLU taps (inputs of the adaptation layers)
+  char *pooled, *tmp64, *g128, *g64, *gtap, *gA, *gB;
+  size_t total;
+};
+DfBwdWs carve_df_bwd(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
+  const size_t es = prec == 0 ? 2 : 4, px = size_t(B) * H * W;
+  DfBwdWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  w.prep = take(px * 2 * prep_sb(prec) * es);
+  int ch = H, cw = W;
+  for (size_t i = 0; i < h->enc.size(); ++i) {
+    w.act[i] = take(size_t(B) * ch * cw * h->enc[i].cout * es);
+    if (h->enc[i].tap >= 0) w.tap[h->enc[i].tap] = take(size_t(B) * ch * cw * h->enc[i].cout * es);
+    if (h->enc[i].pool_after) { ch /= 2; cw /= 2; }
+  }
+  w.pooled = take(px * 64 / 4 * es);   // largest pooled tensor: 64 channels at half resolution
+  w.tmp64 = take(px * 64 * es);
+  w.g128 = take(px * 128 * es);
+  w.g64 = take(px * 64 * es);
+  w.gtap = take(px * 64 * es);
+  w.gA = take(px * 64 * es);
+  w.gB = take(px * 64 * es);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t dfn_dfnet_backward_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W) {
+  if (!h || B < 1 || H < 1 || W < 1) return 0;
+  return carve_df_bwd(h, nullptr, prec, B, H, W).total;
+}
+
+extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int upH, int upW,
+                                        const float* grad_features, int level_mask, float* grad_x, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: null handle");
+  if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_backward_input: dfn_dfnet_commit() has not been called");
+  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: unknown precision %d", prec);
+  level_mask &= (1 << h->n_taps) - 1;
+  if (!x || !grad_features || !grad_x || !workspace || B < 1 || H < 32 || W < 32 || upH < 1 || upW < 1 || !level_mask)
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: bad argument (need H,W >= 32 and a non-empty level_mask)");
+  const DfBwdWs w = carve_df_bwd(h, static_cast<char*>(workspace), prec, B, H, W);
+  if (w.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  hipStream_t s = HS(stream);
+  int deepest = 0;
+  for (int t = 0; t < h->n_taps; ++t) if (level_mask >> t & 1) deepest = t;
+  // ---- forward up to the deepest requested tap, keeping every activation
+  CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet bwd: prep");
+  const void* cur = w.prep;
+  int ch = H, cw = W, nblk = 1, last = -1;
+  int lay_h[13], lay_w[13];
+  for (size_t i = 0; i < h->enc.size(); ++i) {
+    const ConvSpec& sp = h->enc[i];
+    lay_h[i] = ch; lay_w[i] = cw;
+    ConvArgs a{};
+    a.in = cur; a.w = h->enc_packed[i].w[prec]; a.bias = h->enc_packed[i].bias;
+    a.out_act = w.act[i];
+    a.out_pre = (sp.tap >= 0 && (level_mask >> sp.tap & 1)) ? w.tap[sp.tap] : nullptr;
+    a.B = B; a.H = ch; a.W = cw; a.nblk_in = nblk; a.cout_blocks = sp.cout / 32; a.relu = 1;
+    CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet bwd: encoder conv");
+    last = int(i);
+    if (sp.tap == deepest) break;
+    cur = w.act[i];
+    nblk = sp.cout / 32;
+    if (sp.pool_after) {
+      CHECK_HIP(launch_maxpool(prec, cur, B, ch, cw, nblk, w.pooled, s), "dfnet bwd: maxpool");
+      cur = w.pooled;
+      ch /= 2; cw /= 2;
+    }
+  }
+  // ---- backward
+  const size_t plane = size_t(128) * upH * upW;
+  // Two gradient buffers: the ReLU gate runs in place on the buffer holding g_act, the conv's data gradient goes to
+  // the other one, and a max-pool's routed gradient reuses the (by then dead) gated buffer.
+  char* gbuf[2] = {w.gA, w.gB};
+  const void* g_act = nullptr;  // gradient w.r.t. the post-ReLU output of conv i (null = none yet)
+  int act_idx = -1;
+  for (int i = last; i >= 0; --i) {
+    const ConvSpec& sp = h->enc[i];
+    const int hh = lay_h[i], ww = lay_w[i];
+    const size_t n_out = size_t(B) * hh * ww * sp.cout;
+    const void* g_tap = nullptr;
+    if (sp.tap >= 0 && (level_mask >> sp.tap & 1)) {
+      const int t = sp.tap;
+      // adaptation layer forward (ReLU gate of its 1x1), then its transposed convolutions
+      ConvArgs a{};
+      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = h->ad1[t].bias; a.out_act = w.tmp64;
+      a.B = B; a.H = hh; a.W = ww; a.nblk_in = sp.cout / 32; a.cout_blocks = 2; a.relu = 1;
+      CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet bwd: adapt 1x1");
+      CHECK_HIP(launch_upsample_backward(prec, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s),
+                "dfnet bwd: upsample");
+      ConvArgs c{};
+      c.in = w.g128; c.w = h->ad5_dgrad[t].w[prec]; c.bias = h->ad5_dgrad[t].bias; c.out_pre = w.g64;
+      c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
+      CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet bwd: adapt 5x5 dgrad");
+      CHECK_HIP(launch_relu_gate(prec, w.g64, w.tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet bwd: adapt gate");
+      ConvArgs d{};
+      d.in = w.g64; d.w = h->ad1_dgrad[t].w[prec]; d.bias = h->ad1_dgrad[t].bias; d.out_pre = w.gtap;
+      d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
+      CHECK_HIP(launch_conv(prec, 1, 16, d, s), "dfnet bwd: adapt 1x1 dgrad");
+      g_tap = w.gtap;
+    }
+    // gradient w.r.t. the conv's pre-activation: ReLU-gated trunk gradient + the tap's
+    const int pre_idx = act_idx < 0 ? 0 : act_idx, in_idx = pre_idx ^ 1;
+    CHECK_HIP(launch_relu_gate(prec, g_act, w.act[i], g_tap, n_out, gbuf[pre_idx], s), "dfnet bwd: relu gate");
+    // data gradient of the conv
+    const int cin_p = (sp.cin + 63) / 64 * 64;
+    ConvArgs e{};
+    e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[prec]; e.bias = h->enc_dgrad[i].bias; e.out_pre = gbuf[in_idx];
+    e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = cin_p / 32; e.relu = 0;
+    CHECK_HIP(launch_conv(prec, 3, 16, e, s), "dfnet bwd: encoder conv dgrad");
+    if (i == 0) {
+      CHECK_HIP(launch_unprep(prec, gbuf[in_idx], B, H, W, cin_p / 32, grad_x, s), "dfnet bwd: unprep");
+      break;
+    }
+    if (h->enc[i - 1].pool_after) {  // the data gradient is w.r.t. the pooled tensor: route it to conv i-1's resolution
+      CHECK_HIP(launch_maxpool_backward(prec, w.act[i - 1], gbuf[in_idx], B, lay_h[i - 1], lay_w[i - 1], h->enc[i - 1].cout / 32,
+                                        gbuf[pre_idx], s),
+                "dfnet bwd: maxpool");
+      g_act = gbuf[pre_idx];
+      act_idx = pre_idx;
+    } else {
+      g_act = gbuf[in_idx];
+      act_idx = in_idx;
+    }
   }
   return DFN_OK;
 }

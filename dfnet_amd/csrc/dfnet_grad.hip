@@ -1,0 +1,162 @@
+// dfnet_grad.hip — HBM-bound stages of DFNet's INPUT gradient (gfx950): what loss.backward() runs through
+// feat_model(cat([data, rgb])) down to the rendered image in the DFNet_dm step
+// (/root/reference/script/feature/direct_feature_matching.py:350-376).  The convolutions of the backward pass are
+// the forward implicit-GEMM kernel (dfnet_conv.hip) on flipped / transposed weights (dfnet_api.hip: dgrad packing);
+// here are the element-wise pieces between them, all on the blocked-permuted NHWC layout of dfnet_kernels.h:
+// ReLU gating (+ the hypercolumn tap's gradient joining the trunk), max-pool routing, the adjoint of the
+// align_corners bilinear upsample, and the adjoint of the input normalisation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dfnet_kernels.h"
+#include "mfma_frag.h"
+
+namespace dfn {
+
+static inline int grid_of(size_t n, int cap = 16384) {
+  const size_t g = (n + 255) / 256;
+  return int(g < 1 ? 1 : (g > size_t(cap) ? size_t(cap) : g));
+}
+
+// out = (act > 0 ? g : 0) + add   (g and/or add may be null: treated as zero).  ReLU'(0) = 0 as in torch.
+template <class T>
+__global__ __launch_bounds__(256) void relu_gate_kernel(const T* __restrict__ g, const T* __restrict__ act,
+                                                        const T* __restrict__ add, size_t n, T* __restrict__ out) {
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    float v = (g && (float)act[i] > 0.f) ? (float)g[i] : 0.f;
+    if (add) v += (float)add[i];
+    out[i] = (T)v;
+  }
+}
+hipError_t launch_relu_gate(int prec, const void* g, const void* act, const void* add, size_t n, void* out, hipStream_t s) {
+  if (!n) return hipSuccess;
+  if (prec == 0)
+    hipLaunchKernelGGL(relu_gate_kernel<_Float16>, dim3(grid_of(n)), dim3(256), 0, s, static_cast<const _Float16*>(g),
+                       static_cast<const _Float16*>(act), static_cast<const _Float16*>(add), n, static_cast<_Float16*>(out));
+  else
+    hipLaunchKernelGGL(relu_gate_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, static_cast<const float*>(g),
+                       static_cast<const float*>(act), static_cast<const float*>(add), n, static_cast<float*>(out));
+  return hipGetLastError();
+}
+
+// 2x2/2 max-pool backward: the gradient of a pooled pixel goes to the FIRST maximum of its window in row-major
+// order (torch's max_pool2d_with_indices).  act [B,H,W,C] (pre-pool), g [B,H/2,W/2,C] -> out [B,H,W,C]; rows /
+// columns beyond 2*(H/2), 2*(W/2) get zero.
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_backward_kernel(const T* __restrict__ act, const T* __restrict__ g, int B, int H,
+                                                               int W, int C, T* __restrict__ out) {
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t n = (size_t)B * H * W * C;
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    const int c = int(i % C);
+    size_t r = i / C;
+    const int x = int(r % W); r /= W;
+    const int y = int(r % H);
+    const size_t b = r / H;
+    const int yo = y >> 1, xo = x >> 1;
+    float v = 0.f;
+    if (yo < Ho && xo < Wo) {
+      const T* s = act + ((b * H + 2 * yo) * (size_t)W + 2 * xo) * C + c;
+      const float a0 = (float)s[0], a1 = (float)s[C], a2 = (float)s[(size_t)W * C], a3 = (float)s[(size_t)W * C + C];
+      const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+      const int first = a0 == m ? 0 : (a1 == m ? 1 : (a2 == m ? 2 : 3));
+      if (first == ((y & 1) * 2 + (x & 1))) v = (float)g[((b * Ho + yo) * (size_t)Wo + xo) * C + c];
+    }
+    out[i] = (T)v;
+  }
+}
+hipError_t launch_maxpool_backward(int prec, const void* act, const void* g, int B, int H, int W, int nblk, void* out,
+                                   hipStream_t s) {
+  const int C = nblk * 32;
+  const size_t n = (size_t)B * H * W * C;
+  if (!n) return hipSuccess;
+  if (prec == 0)
+    hipLaunchKernelGGL(maxpool_backward_kernel<_Float16>, dim3(grid_of(n)), dim3(256), 0, s, static_cast<const _Float16*>(act),
+                       static_cast<const _Float16*>(g), B, H, W, C, static_cast<_Float16*>(out));
+  else
+    hipLaunchKernelGGL(maxpool_backward_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, static_cast<const float*>(act),
+                       static_cast<const float*>(g), B, H, W, C, static_cast<float*>(out));
+  return hipGetLastError();
+}
+
+// Adjoint of upsample_kernel (bilinear, align_corners=True): g_up fp32 NCHW planes [b*bstride + c*UH*UW + Y*UW + X]
+// -> blocked [B,h,w,4,32] T.  Gather form (deterministic): an input pixel collects from every output pixel whose
+// two source rows / columns include it, with exactly the weights the forward kernel used.
+template <class T>
+__global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __restrict__ gup, size_t bstride, int B, int h, int w,
+                                                                int UH, int UW, T* __restrict__ out) {
+  const float sy = UH > 1 ? float(h - 1) / float(UH - 1) : 0.f;
+  const float sx = UW > 1 ? float(w - 1) / float(UW - 1) : 0.f;
+  const size_t n = (size_t)B * h * w * 128;
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    // x fastest so neighbouring lanes read neighbouring output columns
+    const int x = int(i % w);
+    size_t r = i / w;
+    const int y = int(r % h); r /= h;
+    const int e128 = int(r % 128);
+    const size_t b = r / 128;
+    const int blk = e128 >> 5, e = e128 & 31, hh = e >> 4, s = e & 15;
+    const int ch = blk * 32 + 4 * hh + (s & 3) + 8 * (s >> 2);
+    // candidate output rows: sy * Y in (y - 1, y + 1)
+    int Y0 = 0, Y1 = UH - 1, X0 = 0, X1 = UW - 1;
+    if (sy > 0.f) { Y0 = max(0, int(floorf(float(y - 1) / sy)) - 1); Y1 = min(UH - 1, int(ceilf(float(y + 1) / sy)) + 1); }
+    if (sx > 0.f) { X0 = max(0, int(floorf(float(x - 1) / sx)) - 1); X1 = min(UW - 1, int(ceilf(float(x + 1) / sx)) + 1); }
+    const float* plane = gup + b * bstride + (size_t)ch * UH * UW;
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+      const float fy = sy * float(Y);
+      const int yA = int(fy), yB = yA + (yA < h - 1 ? 1 : 0);
+      const float ly = fy - float(yA);
+      const float wy = (yA == y ? 1.f - ly : 0.f) + (yB == y ? ly : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int X = X0; X <= X1; ++X) {
+        const float fx = sx * float(X);
+        const int xA = int(fx), xB = xA + (xA < w - 1 ? 1 : 0);
+        const float lx = fx - float(xA);
+        const float wx = (xA == x ? 1.f - lx : 0.f) + (xB == x ? lx : 0.f);
+        if (wx != 0.f) row += wx * plane[(size_t)Y * UW + X];
+      }
+      acc += wy * row;
+    }
+    out[((b * h + y) * (size_t)w + x) * 128 + e128] = (T)acc;
+  }
+}
+hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, int B, int h, int w, int UH, int UW, void* out,
+                                    hipStream_t s) {
+  const size_t n = (size_t)B * h * w * 128;
+  if (!n) return hipSuccess;
+  if (prec == 0)
+    hipLaunchKernelGGL(upsample_backward_kernel<_Float16>, dim3(grid_of(n)), dim3(256), 0, s, gup, bstride, B, h, w, UH, UW,
+                       static_cast<_Float16*>(out));
+  else
+    hipLaunchKernelGGL(upsample_backward_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, gup, bstride, B, h, w, UH, UW,
+                       static_cast<float*>(out));
+  return hipGetLastError();
+}
+
+// Adjoint of prep_kernel: g wrt the normalised input, blocked [B,H,W,nblk*32] (RGB = elements 0..2 of block 0),
+// -> d L / d x [B,3,H,W] fp32 = g / std (dfnet.py:121-122).
+template <class T>
+__global__ __launch_bounds__(256) void unprep_kernel(const T* __restrict__ g, int B, int H, int W, int C, float* __restrict__ gx) {
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const size_t plane = (size_t)H * W, n = (size_t)B * 3 * plane;
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    const size_t r = i % plane;
+    const int c = int((i / plane) % 3);
+    const size_t b = i / (3 * plane);
+    gx[i] = (float)g[(b * plane + r) * C + c] / stdv[c];
+  }
+}
+hipError_t launch_unprep(int prec, const void* g, int B, int H, int W, int nblk, float* gx, hipStream_t s) {
+  const size_t n = (size_t)B * 3 * H * W;
+  if (!n) return hipSuccess;
+  if (prec == 0)
+    hipLaunchKernelGGL(unprep_kernel<_Float16>, dim3(grid_of(n)), dim3(256), 0, s, static_cast<const _Float16*>(g), B, H, W,
+                       nblk * 32, gx);
+  else
+    hipLaunchKernelGGL(unprep_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, static_cast<const float*>(g), B, H, W, nblk * 32, gx);
+  return hipGetLastError();
+}
+
+}  // namespace dfn

@@ -44,4 +44,17 @@ hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH
 hipError_t launch_pose_head(int prec, const void* act, int B, int h, int w, const float* fc_w, const float* fc_b,
                             int feat_dim, float* pose, hipStream_t stream);
 
+
+// --- input-gradient path (dfnet_grad.hip); all tensors in the blocked layout, element type by `prec`
+// out = (act > 0 ? g : 0) + add; g / add may be null.
+hipError_t launch_relu_gate(int prec, const void* g, const void* act, const void* add, size_t n, void* out, hipStream_t s);
+// act [B,H,W,nblk*32] pre-pool, g [B,H/2,W/2,...] -> out [B,H,W,...]: gradient to the first maximum of each window.
+hipError_t launch_maxpool_backward(int prec, const void* act, const void* g, int B, int H, int W, int nblk, void* out,
+                                   hipStream_t s);
+// adjoint of launch_upsample: fp32 NCHW planes gup[b*bstride + c*UH*UW + ...] -> blocked [B,h,w,4,32].
+hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, int B, int h, int w, int UH, int UW, void* out,
+                                    hipStream_t s);
+// adjoint of launch_dfnet_prep: blocked gradient (RGB = first three elements of a pixel) -> d L/d x [B,3,H,W] fp32.
+hipError_t launch_unprep(int prec, const void* g, int B, int H, int W, int nblk, float* gx, hipStream_t s);
+
 }  // namespace dfn

@@ -578,6 +578,14 @@ extern "C" int dfn_upsample_bicubic(const float* in, int H, int W, int C, int ou
   return DFN_OK;
 }
 
+extern "C" int dfn_upsample_bicubic_backward(const float* grad_out, int H, int W, int C, int outH, int outW, float* grad_in,
+                                             void* stream) {
+  if (!grad_out || !grad_in || H < 1 || W < 1 || C < 1 || outH < 1 || outW < 1)
+    return set_error(DFN_ERR_ARG, "dfn_upsample_bicubic_backward: bad argument");
+  CHECK_HIP(launch_bicubic_backward(grad_out, H, W, C, outH, outW, grad_in, HS(stream)), "dfn_upsample_bicubic_backward");
+  return DFN_OK;
+}
+
 extern "C" size_t dfn_fine_bias_bytes(size_t n_rays) { return (n_rays ? n_rays : 1) * kRayBiasFloats * sizeof(float); }
 
 extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,

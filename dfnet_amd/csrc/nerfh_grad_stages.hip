@@ -194,4 +194,53 @@ hipError_t launch_raygen_backward(int H, int W, float focal, const float* grad_o
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ bicubic resize backward
+// Adjoint of bicubic_kernel (nn.Upsample(mode='bicubic'), align_corners=False, A = -0.75, border-replicated taps):
+// g_out [UH,UW,C] -> g_in [H,W,C].  Gather form (deterministic): an input pixel collects, per axis, the weights of
+// every tap that lands on it (several taps of one output pixel can land on a border pixel).
+DFN_DEV float cubic_b1(float x) { const float A = -0.75f; return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+DFN_DEV float cubic_b2(float x) { const float A = -0.75f; return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+DFN_DEV float bicubic_axis_weight(float scale, int O, int n_in, int target) {
+  const float f = scale * (float(O) + .5f) - .5f;
+  const int i0 = int(floorf(f));
+  const float t = f - float(i0);
+  const float wt[4] = {cubic_b2(t + 1.f), cubic_b1(t), cubic_b1(1.f - t), cubic_b2(2.f - t)};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc += min(max(i0 - 1 + a, 0), n_in - 1) == target ? wt[a] : 0.f;
+  return acc;
+}
+__global__ __launch_bounds__(256) void bicubic_backward_kernel(const float* __restrict__ gout, int H, int W, int C, int UH, int UW,
+                                                               float* __restrict__ gin) {
+  const float sy = float(H) / float(UH), sx = float(W) / float(UW);
+  const size_t n = size_t(H) * W * C;
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    const int c = int(i % C);
+    const int x = int((i / C) % W), y = int(i / (size_t(C) * W));
+    // output rows whose 4-tap window [floor(f)-1, floor(f)+2] can reach y (borders: everything beyond clamps onto them)
+    const int Y0 = y == 0 ? 0 : max(0, int(floorf((float(y) - 2.5f) / sy)) - 1);
+    const int Y1 = y == H - 1 ? UH - 1 : min(UH - 1, int(ceilf((float(y) + 2.5f) / sy)) + 1);
+    const int X0 = x == 0 ? 0 : max(0, int(floorf((float(x) - 2.5f) / sx)) - 1);
+    const int X1 = x == W - 1 ? UW - 1 : min(UW - 1, int(ceilf((float(x) + 2.5f) / sx)) + 1);
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+      const float wy = bicubic_axis_weight(sy, Y, H, y);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int X = X0; X <= X1; ++X) {
+        const float wx = bicubic_axis_weight(sx, X, W, x);
+        if (wx != 0.f) row += wx * gout[(size_t(Y) * UW + X) * C + c];
+      }
+      acc += wy * row;
+    }
+    gin[i] = acc;
+  }
+}
+hipError_t launch_bicubic_backward(const float* gout, int H, int W, int C, int UH, int UW, float* gin, hipStream_t stream) {
+  const size_t n = size_t(H) * W * C;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(bicubic_backward_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, gout, H, W, C, UH, UW, gin);
+  return hipGetLastError();
+}
+
 }  // namespace dfn

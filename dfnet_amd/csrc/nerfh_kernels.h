@@ -84,6 +84,8 @@ hipError_t launch_ray_grad_reduce(const float* gpts, const float* z, const float
 // get_rays backward: d c2w[3][4] from d rays_o / d rays_d of an H x W image.
 hipError_t launch_raygen_backward(int H, int W, float focal, const float* grad_o, const float* grad_d, float* grad_c2w,
                                   hipStream_t stream);
+// adjoint of launch_bicubic: g_out [UH,UW,C] -> g_in [H,W,C].
+hipError_t launch_bicubic_backward(const float* gout, int H, int W, int C, int UH, int UW, float* gin, hipStream_t stream);
 hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream);
 
 }  // namespace dfn

@@ -226,6 +226,23 @@ class DfnetEngine:
             feats = (feats[0], feats[1])
         return feats, pose
 
+    def backward_input(self, x, grad_features, levels=None, precision=None):
+        """d L/d x [B,3,H,W] from d L/d features in the single-stream layout [n_taps,B,128,uH,uW]; `levels` lists the
+        pyramid levels that carry gradient (default: all).  Weights are frozen (DFNet_dm's feat_model)."""
+        x, g = _f32c(x), _f32c(grad_features)
+        B, C, H, W = x.shape
+        assert C == 3 and g.shape[:3] == (self.n_taps, B, 128), (x.shape, g.shape)
+        mask = sum(1 << int(t) for t in (range(self.n_taps) if levels is None else levels))
+        prec = _lib.PRECISIONS[precision or self.precision]
+        gx = torch.empty_like(x)
+        nbytes = self.lib.dfn_dfnet_backward_workspace_bytes(self.handle, prec, B, H, W)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(self.lib.dfn_dfnet_backward_input(self.handle, prec, ptr(x), B, H, W, g.shape[3], g.shape[4], ptr(g), mask,
+                                                ptr(gx), ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),
+                                                current_stream()), "dfn_dfnet_backward_input")
+        return gx
+
 
 # ---------------------------------------------------------------------- weight-free stage wrappers
 def raygen(H, W, focal, c2w, want_viewdirs=True):
@@ -306,6 +323,16 @@ def upsample_bicubic(img, outH, outW):
     out = torch.empty(outH, outW, C, device=img.device)
     check(lib.dfn_upsample_bicubic(ptr(img), H, W, C, int(outH), int(outW), ptr(out), current_stream()),
           "dfn_upsample_bicubic")
+    return out
+
+
+def upsample_bicubic_backward(grad_out, H, W):
+    """Adjoint of upsample_bicubic: [outH,outW,C] -> [H,W,C]."""
+    g = _f32c(grad_out)
+    outH, outW, C = g.shape
+    out = torch.empty(H, W, C, device=g.device)
+    check(_lib.load().dfn_upsample_bicubic_backward(ptr(g), int(H), int(W), C, outH, outW, ptr(out), current_stream()),
+          "dfn_upsample_bicubic_backward")
     return out
 
 

@@ -8,6 +8,12 @@ frame-sharded loop with one gather when torch.distributed is initialised (dfnet_
 
 Only the test-time path is native so far (perturb=0, raw_noise_std=0, test_time=True — what
 `render_kwargs_test` carries); anything else raises NotImplementedError rather than falling back.
+
+Autograd: when grad is enabled and `c2w` / `rays` require grad (the DFNet_dm step,
+feature/direct_feature_matching.py:340-376), `rgb_map` is returned attached to the graph through
+torch.autograd.Function wrappers whose backward is the HIP gradient path (dfn_render_image_backward /
+dfn_render_rays_backward); disp_map / acc_map are returned detached (the reference's losses use rgb only).
+The gradient kernels default to the exact-fp32 MFMA path (`grad_precision`), see tests/test_gpu_grad.py.
 """
 import os
 import time
@@ -29,6 +35,48 @@ def _engine_of(kwargs):
         raise TypeError("render(): render kwargs must come from dfnet_amd.nerfw.create_nerf "
                         "(network_query_fn carries the HIP engine)")
     return eng
+
+
+GRAD_PRECISION = "f32"  # arithmetic of the gradient path (forward recompute + backward)
+
+
+class _RenderImageFn(torch.autograd.Function):
+    """rgb/disp/acc = render(c2w); backward: d L/d c2w from d L/d rgb."""
+
+    @staticmethod
+    def forward(ctx, c2w, eng, H, W, focal, hist, Nc, Ni, near, far):
+        rgb, disp, acc = eng.render_image(c2w.detach(), H, W, focal, hist, Nc, Ni, near, far)
+        ctx.save_for_backward(c2w.detach(), hist)
+        ctx.cfg = (eng, H, W, focal, Nc, Ni, near, far)
+        ctx.mark_non_differentiable(disp, acc)
+        return rgb, disp, acc
+
+    @staticmethod
+    def backward(ctx, g_rgb, _g_disp, _g_acc):
+        c2w, hist = ctx.saved_tensors
+        eng, H, W, focal, Nc, Ni, near, far = ctx.cfg
+        gc = eng.render_image_backward(c2w, H, W, focal, hist, Nc, Ni, near, far, g_rgb.contiguous(),
+                                       precision=GRAD_PRECISION)
+        return (gc,) + (None,) * 9
+
+
+class _RenderRaysFn(torch.autograd.Function):
+    """rgb/disp/acc = render(rays); backward: d L/d rays_o, d L/d rays_d (viewdirs = d/|d| differentiated)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, eng, hist, Nc, Ni, near, far):
+        rgb, disp, acc, _ = eng.render_rays(rays_o.detach(), rays_d.detach(), hist, Nc, Ni, near, far)
+        ctx.save_for_backward(rays_o.detach(), rays_d.detach(), hist)
+        ctx.cfg = (eng, Nc, Ni, near, far)
+        ctx.mark_non_differentiable(disp, acc)
+        return rgb, disp, acc
+
+    @staticmethod
+    def backward(ctx, g_rgb, _g_disp, _g_acc):
+        o, d, hist = ctx.saved_tensors
+        eng, Nc, Ni, near, far = ctx.cfg
+        go, gd, _ = eng.render_rays_backward(o, d, hist, Nc, Ni, near, far, g_rgb.contiguous(), precision=GRAD_PRECISION)
+        return (go, gd) + (None,) * 6
 
 
 def _check_test_time(kw, ndc, c2w_staticcam, use_viewdirs):
@@ -65,14 +113,21 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     index vector, shape [10], [1,10] or [N,10]."""
     eng = _engine_of(kwargs)
     _check_test_time(kwargs, ndc, c2w_staticcam, use_viewdirs)
-    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (c2w, rays) if t is not None):
-        raise NotImplementedError("differentiable render (DFNet_dm inner step) needs the backward kernels: not built yet")
+    def _needs_grad(t):
+        if torch.is_tensor(t):
+            return t.requires_grad
+        return isinstance(t, (tuple, list)) and any(_needs_grad(u) for u in t)
+    track = torch.is_grad_enabled() and (_needs_grad(c2w) or _needs_grad(rays))
     Nc, Ni = int(kwargs['N_samples']), int(kwargs['N_importance'])
     retraw = bool(kwargs.get('retraw', False))
     dev = torch.device("cuda", torch.cuda.current_device())
     hist = torch.as_tensor(img_idx, dtype=torch.float32, device=dev)
     if c2w is not None:
         c2w = torch.as_tensor(c2w, dtype=torch.float32, device=dev)
+        if track and not retraw and hist.numel() == eng.hist_bin:
+            rgb, disp, acc = _RenderImageFn.apply(c2w[:3, :4], eng, int(H), int(W), float(focal), hist.reshape(-1), Nc, Ni,
+                                                  float(near), float(far))
+            return [rgb, disp, acc, {}]
         if retraw or hist.numel() != eng.hist_bin:
             o, d = get_rays(H, W, focal, c2w)
             return render(H, W, focal, chunk, rays=(o, d), ndc=ndc, near=near, far=far, use_viewdirs=use_viewdirs,
@@ -87,9 +142,15 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     hist = hist.reshape(-1, eng.hist_bin)
     if hist.shape[0] not in (1, n):
         raise ValueError(f"img_idx must have 1 or {n} rows of {eng.hist_bin} bins, got {tuple(hist.shape)}")
+    lead = list(sh[:-1])
+    if track:
+        if retraw:
+            raise NotImplementedError("render(): retraw together with autograd (raw is not differentiated natively)")
+        rgb, disp, acc = _RenderRaysFn.apply(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), eng, hist, Nc, Ni, float(near),
+                                             float(far))
+        return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), {}]
     rgb, disp, acc, raw = eng.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), hist, Nc, Ni, near, far,
                                           retraw=retraw)
-    lead = list(sh[:-1])
     extras = {'raw': raw.reshape(lead + list(raw.shape[1:]))} if retraw else {}
     return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), extras]
 

@@ -178,6 +178,10 @@ int dfn_render_image_backward(dfn_nerfh_t h, int prec, const float* c2w, int H, 
  * feature/direct_feature_matching.py:344-346).  out [outH,outW,C]. */
 int dfn_upsample_bicubic(const float* in, int H, int W, int C, int outH, int outW, float* out, void* stream);
 
+/* Adjoint of dfn_upsample_bicubic: grad_out [outH,outW,C] -> grad_in [H,W,C]. */
+int dfn_upsample_bicubic_backward(const float* grad_out, int H, int W, int C, int outH, int outW, float* grad_in,
+                                  void* stream);
+
 /* ------------------------------------------------------------------ DFNet feature extractor
  * Replaces feature/dfnet.py:74-172 (class DFNet / DFNet_s: VGG16 `features` stack, AdaptLayers,
  * UpsamplingBilinear2d, GAP + fc_pose).  n_taps = 3 (DFNet: conv1_2, conv3_3, conv5_3) or 1 (DFNet_s). */
@@ -198,6 +202,16 @@ size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W);
 int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature,
                       int siamese, int return_pose, int upH, int upW, float* features, float* pose,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Input gradient of DFNet.forward's feature maps — what loss.backward() computes for the rendered image in the
+ * DFNet_dm step (feature/direct_feature_matching.py:350-376; the feature extractor's weights are frozen there).
+ * x device [B,3,H,W]; grad_features device, single-stream layout [n_taps, B, 128, upH, upW]; bit t of level_mask
+ * says level t carries gradient (the planes of other levels are not read); grad_x [B,3,H,W].  Recomputes the
+ * forward up to the deepest requested tap. */
+size_t dfn_dfnet_backward_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W);
+int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int upH, int upW,
+                             const float* grad_features, int level_mask, float* grad_x, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* Timing aid for bench.py: average device time in ms of the `which` kernel
  * (0 = coarse MLP, 1 = fine MLP) over the launches since the last reset, measured with HIP

@@ -145,3 +145,88 @@ def test_quarter_res_pose_gradient_vs_oracle(scene):
         assert e < TOL_C2W[prec]
     gc2 = E.render_image_backward(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, G.to(DEV), precision="f16")
     assert torch.equal(gc, gc2)  # deterministic
+
+
+def test_render_autograd_drop_in(scene, gold):
+    """dfnet_amd.rendering.render under autograd: loss.backward() reaches c2w / rays through the HIP gradient path,
+    with the reference's call shapes (direct_feature_matching.py:342-349, run_nerf.py:47-51)."""
+    from dfnet_amd import nerfw, rendering
+    E = scene[0]
+    kw = dict(network_query_fn=nerfw.HipQuery(E, 65536), perturb=False, N_importance=128, N_samples=64, use_viewdirs=True,
+              white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False)
+    g = gold("g9_render_grad_c2w")
+    pose = dev(g["c2w"]).requires_grad_(True)
+    rgb, disp, acc, extras = rendering.render(int(g["H"]), int(g["W"]), float(g["focal"]), c2w=pose, near=0., far=2.5,
+                                              img_idx=dev(g["hist"]), **kw)
+    assert rgb.requires_grad and not disp.requires_grad and extras == {}
+    assert relmax(rgb, g["rgb"]) < 1e-3
+    (rgb * dev(g["G"])).sum().backward()
+    assert relmax(pose.grad, g["grad_c2w"]) < TOL_C2W["f32"]
+    g = gold("g9_render_grad_rays_b")
+    rays = torch.stack([dev(g["rays_o"]), dev(g["rays_d"])]).requires_grad_(True)
+    rgb = rendering.render(480, 640, 585., rays=rays, near=0., far=2.5, img_idx=dev(g["hist"])[None], **kw)[0]
+    (rgb * dev(g["G"])).sum().backward()
+    scale = np.abs(g["grad_rays_d"]).max()
+    assert float((rays.grad[0].cpu() - T(g["grad_rays_o"])).abs().max()) < TOL["f32"] * scale
+    assert float((rays.grad[1].cpu() - T(g["grad_rays_d"])).abs().max()) < TOL["f32"] * scale
+    with torch.no_grad():  # and nothing is tracked without grad
+        assert not rendering.render(12, 16, 14.6, c2w=pose, near=0., far=2.5, img_idx=dev(g["hist"]), **kw)[0].requires_grad
+
+
+# ---------------------------------------------------------------------- DFNet input gradient / bicubic adjoint
+@pytest.fixture(scope="module")
+def dfnet():
+    from oracle import dfnet_oracle  # noqa: F401
+    w = syn.dfnet_weights(3)
+    return eng.DfnetEngine(3, 12).load_numpy(w), {k: T(v) for k, v in w.items()}
+
+
+@pytest.mark.parametrize("levels", [(0,), (0, 1, 2), (2,)])
+@pytest.mark.parametrize("shape,up", [((2, 3, 32, 48), (32, 48)), ((1, 3, 72, 104), (60, 90))])
+def test_dfnet_backward_input_vs_autograd(dfnet, levels, shape, up):
+    """d sum(features * G) / d x against torch autograd through the CPU oracle (frozen weights, eval-mode BN),
+    including odd sizes (max-pool remainders, upsample to a different size).  The f16-input path gates many more
+    units differently (f16 rounding of every activation) and is only held to 0.1 relative L2; fp32 is the default."""
+    from oracle import dfnet_oracle as dor
+    E, p = dfnet
+    # The map is piecewise linear: a pre-activation (or a max-pool pair) within round-off of a tie gates differently
+    # under a different summation order, and ONE such flip at a coarse level moves the whole gradient by percents —
+    # torch's own fp32 and fp64 gradients differ by 7e-2 on some inputs of this very test.  With ~2M gated units a
+    # flip somewhere is common, so: over three seeded inputs the fp32 path must match the oracle (evaluated in fp32
+    # or fp64) to round-off on at least one, and stay within 5e-2 relative L2 on all of them.
+    best = {"f32": 1.0, "f16": 1.0}
+    for seed in (21, 22, 23):
+        rng = np.random.default_rng(seed)
+        x0 = rng.uniform(0, 1, shape).astype(np.float32)
+        G = T(rng.standard_normal((3, shape[0], 128, *up)).astype(np.float32))
+        for t in range(3):
+            if t not in levels:
+                G[t] = 0
+        refs = []
+        for dt in (torch.float32, torch.float64):
+            x = T(x0).to(dt).requires_grad_(True)
+            feats, _ = dor.dfnet_forward({k: v.to(dt) for k, v in p.items()}, x, return_feature=True, isSingleStream=True,
+                                         return_pose=False, upsampleH=up[0], upsampleW=up[1])
+            (feats[0] * G.to(dt)).sum().backward()
+            refs.append(x.grad)
+        for prec, tol_l2 in (("f32", 5e-2), ("f16", 0.15)):
+            gx = E.backward_input(T(x0).to(DEV), G.to(DEV), levels=levels, precision=prec)
+            e = min(relmax(gx, r) for r in refs)
+            l2 = min(rel_l2(gx, r) for r in refs)
+            print(f"{prec} seed {seed} levels={levels} {shape}: d x {e:.2e}  (L2 {l2:.2e})")
+            assert l2 < tol_l2
+            best[prec] = min(best[prec], e)
+        if best["f32"] < 5e-5:
+            break
+    assert best["f32"] < 5e-5
+
+
+def test_bicubic_backward_is_the_adjoint():
+    rng = np.random.default_rng(4)
+    for (H, W, UH, UW) in ((60, 80, 240, 320), (7, 5, 20, 33), (30, 40, 30, 40)):
+        g = T(rng.standard_normal((UH, UW, 3)).astype(np.float32))
+        x = T(rng.standard_normal((H, W, 3)).astype(np.float32)).requires_grad_(True)
+        up = torch.nn.functional.interpolate(x.permute(2, 0, 1)[None], size=(UH, UW), mode="bicubic", align_corners=False)
+        (up[0].permute(1, 2, 0) * g).sum().backward()
+        got = eng.upsample_bicubic_backward(g.to(DEV), H, W)
+        assert relmax(got, x.grad) < 1e-5
