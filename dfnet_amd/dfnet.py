@@ -6,6 +6,12 @@ The modules below are *parameter containers* with the reference's state_dict lay
 convention and is evaluated by the HIP feature-extractor (dfn_dfnet_forward).  BatchNorm runs in
 eval mode on this path (reference: train.py:123, utils.py:30-39).
 
+Autograd: with grad enabled and an input that requires grad (DFNet_dm: feat_model(cat([data, rgb])) with
+the rendered rgb attached to the pose, direct_feature_matching.py:350-376) the feature maps come back
+attached to the graph and their backward is the HIP input-gradient path (dfn_dfnet_backward_input).  The
+module's own weights are treated as frozen there (no weight gradients are produced); training the
+network itself (weight gradients) is not built.
+
 torchvision's pretrained VGG16 weights (dfnet.py:90) are a download and unavailable offline: the
 encoder is created with default Conv2d init; load a checkpoint for real use.
 """
@@ -36,6 +42,31 @@ class AdaptLayers(nn.Module):
             self.add_module("adapt_layer_{}".format(i), nn.Sequential(
                 nn.Conv2d(c, 64, kernel_size=1, stride=1, padding=0), nn.ReLU(),
                 nn.Conv2d(64, output_dim, kernel_size=5, stride=1, padding=2), nn.BatchNorm2d(output_dim)))
+
+
+class _FeatureFn(torch.autograd.Function):
+    """Feature pyramid of a frozen DFNet with d L/d x as its backward."""
+
+    @staticmethod
+    def forward(ctx, x, engine, single, upH, upW):
+        feats, _ = engine.forward(x.detach(), True, single, False, upH, upW)
+        ctx.save_for_backward(x.detach())
+        ctx.cfg = (engine, single)
+        return (feats,) if single else (feats[0], feats[1])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (x,) = ctx.saved_tensors
+        engine, single = ctx.cfg
+        if single:
+            g = grads[0]
+        else:  # siamese halves back into the batch order of x: [target half, render half]
+            shape = next(t for t in grads if t is not None).shape
+            g = torch.cat([t if t is not None else x.new_zeros(shape) for t in grads], 1)
+        levels = [t for t in range(g.shape[0]) if bool((g[t] != 0).any())]
+        if not levels:
+            return torch.zeros_like(x), None, None, None, None
+        return engine.backward_input(x, g.contiguous(), levels=levels), None, None, None, None
 
 
 class _DFNetBase(nn.Module):
@@ -72,9 +103,12 @@ class _DFNetBase(nn.Module):
     def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427):
         """Same contract as dfnet.py:109-172: returns (feature_maps, predict) with feature_maps None,
         [stack] (single stream: 1 x [L,B,128,H,W]) or [stack_t, stack_r] (siamese: 2 x [L,B/2,128,H,W])."""
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
-            raise NotImplementedError("DFNet training (autograd through the HIP convs) is not built: call under "
-                                      "torch.no_grad() / .eval(); only the forward is on the hot path")
+        if torch.is_grad_enabled() and x.requires_grad:
+            if return_pose or not return_feature:
+                raise NotImplementedError("autograd through the pose head (training the regressor itself) is not built; "
+                                          "the feature path (return_feature=True, return_pose=False) is")
+            feats = _FeatureFn.apply(x, self.engine(), bool(isSingleStream), int(upsampleH), int(upsampleW))
+            return list(feats), None
         feats, pose = self.engine().forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW)
         if feats is not None:
             feats = [feats] if isSingleStream else [feats[0], feats[1]]

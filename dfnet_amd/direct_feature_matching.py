@@ -4,14 +4,16 @@
 quarter resolution -> bicubic x4 -> siamese DFNet features -> cosine feature loss (+ photometric / pose terms).
 
 Every arithmetic-heavy stage runs in the HIP library (DFNet forward, render, bicubic); what remains here are
-the few-element reductions of the loss.  The BACKWARD half (loss.backward(), Adam on the pose net) needs
-gradient kernels for render / DFNet and is not built: `matching_step_forward` returns the losses only.
+the few-element reductions of the loss.  `matching_step_forward` returns the losses only; `matching_step_grad`
+also runs loss.backward() down to the PREDICTED POSE: the loss reductions by torch autograd (a few element-wise
+ops on device tensors), everything below them by the HIP gradient kernels (DFNet input gradient, bicubic adjoint,
+render gradient).  What is still not built is the last link of the reference's step: the weight gradients of the
+pose regressor itself (a VGG16 training step) and its Adam update.
 The reference renders only pose 0 of the batch (:342, i.e. batch size 1 in effect); this implementation renders
 every pose of the batch."""
 import torch
 
-from .engine import upsample_bicubic
-from .feature_misc import feature_loss, fix_coord_supp
+from .feature_misc import feature_loss, fix_coord_supp, upsample_bicubic
 from .rendering import render
 
 
@@ -75,3 +77,49 @@ def matching_step_forward(args, data, model, feat_model, pose, img_idx, hwf, hal
             loss = feat_l
         psnr = -10. * torch.log10(photo_l)
     return dict(loss=loss, pose_loss=pose_l, photo_loss=photo_l, feat_loss=feat_l, psnr=psnr, rgb=rgb, pose_pred=pose_)
+
+
+def matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, half_res, device, world_setup_dict,
+                       **render_kwargs_test):
+    """One DFNet_dm step up to and including d loss / d predicted pose (train_on_batch, :322-370, without the
+    regressor's own backward / optimizer.step()).  Returns the dict of matching_step_forward plus
+    `grad_pose` [B,3,4]: the gradient that the reference's loss.backward() hands to the pose regressor's output."""
+    H, W, focal = hwf
+    H, W = int(H), int(W)
+    data = data.to(device)
+    B = data.shape[0]
+    with torch.no_grad():
+        _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
+    pose_ = pose_.detach().requires_grad_(True)
+    with torch.enable_grad():
+        pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
+        img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
+        rgbs = []
+        for b in range(B):
+            if half_res:
+                rgb, _, _, _ = render(H // 4, W // 4, focal / 4, chunk=args.chunk, c2w=pose_nerf[b, :3, :4],
+                                      img_idx=img_idx[b], **render_kwargs_test)
+                rgb = upsample_bicubic(rgb, H, W)
+            else:
+                rgb, _, _, _ = render(H, W, focal, chunk=args.chunk, c2w=pose_nerf[b, :3, :4], img_idx=img_idx[b],
+                                      **render_kwargs_test)
+            rgbs.append(rgb.permute(2, 0, 1))
+        rgb = torch.stack(rgbs)
+        feats, _ = inference_pose_regression(args, torch.cat([data, rgb]), device, feat_model, retFeature=True,
+                                             isSingleStream=False, return_pose=False)
+        idx = torch.tensor(args.feature_matching_lvl, device=device)
+        f_t = preprocess_features_for_loss(torch.index_select(feats[0], 0, idx))
+        f_r = preprocess_features_for_loss(torch.index_select(feats[1], 0, idx))
+        feat_l = torch.stack([feature_loss(f_r[b], f_t[b], per_channel=args.per_channel) for b in range(B)]).mean()
+        photo_l = torch.mean((rgb - data) ** 2)
+        pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
+        if getattr(args, "combine_loss", False):
+            w = args.combine_loss_w
+            loss = w[0] * pose_l + w[1] * photo_l + w[2] * feat_l
+        else:
+            loss = feat_l
+        loss.backward()
+    with torch.no_grad():
+        psnr = -10. * torch.log10(photo_l)
+    return dict(loss=loss.detach(), pose_loss=pose_l.detach(), photo_loss=photo_l.detach(), feat_loss=feat_l.detach(),
+                psnr=psnr, rgb=rgb.detach(), pose_pred=pose_.detach(), grad_pose=pose_.grad)

@@ -3,8 +3,26 @@
 the cosine feature loss of feature/direct_feature_matching.py:114-136."""
 import torch
 
-from .engine import upsample_bicubic
+from . import engine as _engine
 from .rendering import render
+
+
+class _BicubicFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, H, W):
+        ctx.shape = img.shape[:2]
+        return _engine.upsample_bicubic(img.detach(), H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _engine.upsample_bicubic_backward(g.contiguous(), *ctx.shape), None, None
+
+
+def upsample_bicubic(img, H, W):
+    """nn.Upsample(size=(H, W), mode='bicubic') of an [h,w,C] image; differentiable (HIP adjoint kernel)."""
+    if torch.is_grad_enabled() and img.requires_grad:
+        return _BicubicFn.apply(img, int(H), int(W))
+    return _engine.upsample_bicubic(img, int(H), int(W))
 
 
 def fix_coord_supp(args, pose, world_setup_dict, device=None):

@@ -230,3 +230,54 @@ def test_bicubic_backward_is_the_adjoint():
         (up[0].permute(1, 2, 0) * g).sum().backward()
         got = eng.upsample_bicubic_backward(g.to(DEV), H, W)
         assert relmax(got, x.grad) < 1e-5
+
+
+def test_dm_step_pose_gradient_vs_oracle():
+    """C5's metric: d loss / d predicted pose of the DFNet_dm step (direct_feature_matching.py:322-370) — HIP gradient
+    kernels under torch's loss reductions — against autograd through the composition of the two CPU oracles."""
+    from types import SimpleNamespace
+    from dfnet_amd.dfnet import DFNet
+    from dfnet_amd.direct_feature_matching import matching_step_grad
+    from dfnet_amd.nerfw import HipQuery
+    from oracle import dfnet_oracle as dor
+    H, W, focal = 64, 96, 80.0
+    w = syn.dfnet_weights(3)
+    sd = {k: T(v) for k, v in w.items()}
+    model, feat_model = DFNet().eval(), DFNet().eval()
+    model.load_state_dict(sd, strict=False)
+    feat_model.load_state_dict(sd, strict=False)
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine(precision="f32").load_numpy(cw, fw, ea, et)
+    kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=16, N_samples=8, use_viewdirs=True,
+              white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    setup = dict(pose_scale=0.7, pose_scale2=1.2, move_all_cam_vec=[0., 0.1, 1.0])
+    args = SimpleNamespace(svd_reg=True, chunk=32768, feature_matching_lvl=[0], per_channel=False, combine_loss=True,
+                           combine_loss_w=[0.3, 0.2, 1.0])
+    g = torch.Generator().manual_seed(1)
+    data = torch.rand(2, 3, H, W, generator=g)
+    gt = torch.stack([T(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(2)])
+    hist = T(syn.HIST_IDX).repeat(2, 1)
+    out = matching_step_grad(args, data, model, feat_model, gt, hist, [H, W, focal], True, DEV, setup, **kw)
+    assert out["grad_pose"].shape == (2, 3, 4)
+    # oracle composition under autograd, starting from the same predicted pose
+    pose_ = out["pose_pred"].cpu().clone().requires_grad_(True)
+    pn = pose_.clone()
+    pn[:, :3, 3] *= setup["pose_scale"]
+    pn[:, :3, 3] += torch.tensor(setup["move_all_cam_vec"])
+    pn[:, :3, 3] *= setup["pose_scale2"]
+    c, f = {k: T(x) for k, x in cw.items()}, {k: T(x) for k, x in fw.items()}
+    rgbs = []
+    for b in range(2):
+        r = orc.render(H // 4, W // 4, focal / 4, 1 << 30, c, f, T(ea), T(et), 8, 16, 0., 2.5, syn.HIST_IDX, c2w=pn[b])[0]
+        rgbs.append(torch.nn.Upsample(size=(H, W), mode='bicubic')(r.permute(2, 0, 1)[None])[0])
+    rgb = torch.stack(rgbs)
+    feats, _ = dor.dfnet_forward(sd, torch.cat([data, rgb]), True, False, False, H, W)
+    ft, fr = feats[0][[0]].permute(1, 0, 2, 3, 4).reshape(2, 128, H, W), feats[1][[0]].permute(1, 0, 2, 3, 4).reshape(2, 128, H, W)
+    fl = torch.stack([1 - torch.nn.functional.cosine_similarity(fr[b].reshape(128, -1), ft[b].reshape(128, -1), dim=1, eps=1e-6).mean()
+                      for b in range(2)]).mean()
+    loss = 0.3 * torch.nn.functional.mse_loss(pose_.reshape(2, 12), gt) + 0.2 * ((rgb - data) ** 2).mean() + 1.0 * fl
+    loss.backward()
+    assert abs(float(out["loss"]) - float(loss.detach())) < 5e-4 * max(1.0, abs(float(loss.detach())))
+    e = relmax(out["grad_pose"], pose_.grad)
+    print(f"d loss / d pose: {e:.2e}  |grad| max {float(pose_.grad.abs().max()):.3e}")
+    assert e < 2e-3
