@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""DFNet_dm step timing (BASELINE configs[4] shape per GPU: batch 4, 240x320 frames, render 60x80 at 64+128 then
+bicubic x4, level-0 cosine feature loss + photometric + pose terms): forward losses and the backward down to the
+predicted pose, all arithmetic on the HIP path.  Prints one JSON line."""
+import json, os, sys, time
+from types import SimpleNamespace
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dfnet_amd import engine as eng, synthetic as syn
+from dfnet_amd.dfnet import DFNet
+from dfnet_amd.direct_feature_matching import matching_step_forward, matching_step_grad
+from dfnet_amd.nerfw import HipQuery
+
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+H, W, focal = 240, 320, 585.0 / 2
+sd = {k: torch.from_numpy(v) for k, v in syn.dfnet_weights(3).items()}
+model, feat_model = DFNet().eval(), DFNet().eval()
+model.load_state_dict(sd, strict=False)
+feat_model.load_state_dict(sd, strict=False)
+cw, fw, ea, et = syn.nerfh_weights(0)
+E = eng.NerfHEngine(precision="f16").load_numpy(cw, fw, ea, et)
+kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=128, N_samples=64, use_viewdirs=True,
+          white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+setup = dict(pose_scale=1.0, pose_scale2=1.0, move_all_cam_vec=[0., 0., 1.0])
+args = SimpleNamespace(svd_reg=True, chunk=32768, feature_matching_lvl=[0], per_channel=False, combine_loss=True,
+                       combine_loss_w=[0.3, 0.2, 1.0])
+data = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+gt = torch.stack([torch.from_numpy(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(B)])
+hist = torch.from_numpy(syn.HIST_IDX).repeat(B, 1)
+
+
+def timed(fn):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3, out
+
+
+fwd_ms, _ = timed(lambda: matching_step_forward(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
+step_ms, out = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
+print(json.dumps({"workload": f"DFNet_dm step, batch {B}, 240x320, render 60x80 @64+128 + bicubic x4, level-0 feature loss",
+                  "forward_ms": fwd_ms, "forward_backward_to_pose_ms": step_ms, "ms_per_frame": step_ms / B,
+                  "loss": float(out["loss"]), "grad_pose_absmax": float(out["grad_pose"].abs().max()),
+                  "render_precision": "f16 forward / f32 gradient path", "dfnet_precision": "f32"}))
