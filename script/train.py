@@ -3,11 +3,12 @@
 
     python train.py --config config_dfnetdm.txt --eval
 
-Native: the forward half of every step — DFNet pose regression, NeRF-H render at the predicted pose (quarter
-resolution + bicubic x4), siamese DFNet features, cosine feature-matching loss — evaluated over the validation
-split (`--eval` prints the mean losses / PSNR).  The update itself (loss.backward(), Adam on the pose network)
-needs gradient kernels for the render and the conv stack and is not built: without --eval this script stops
-with a clear message.
+Native: every step's forward — DFNet pose regression, NeRF-H render at the predicted pose (quarter resolution +
+bicubic x4), siamese DFNet features, cosine feature-matching loss — and its backward down to the predicted pose
+(HIP gradient kernels for the feature extractor, the bicubic resize and the render).  `--eval` prints the mean
+losses / PSNR over the validation split; without it the script walks the training split and prints the loss and
+the norm of d loss / d pose per batch.  The last link of the reference's update — weight gradients of the pose
+regressor (a VGG16 training step) and its Adam step — is not built, so no parameters change.
 """
 import os
 import sys
@@ -19,7 +20,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 from dfnet_amd.datasets import load_7Scenes_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
-from dfnet_amd.direct_feature_matching import matching_step_forward  # noqa: E402
+from dfnet_amd.direct_feature_matching import matching_step_forward, matching_step_grad  # noqa: E402
 from dfnet_amd.nerfw import create_nerf  # noqa: E402
 from dfnet_amd.options import dm_parser  # noqa: E402
 
@@ -44,8 +45,15 @@ def main(argv=None):
     render_kwargs_test.update({'near': near, 'far': far})
     setup = {k: getattr(train_dl.dataset, k) for k in ('pose_scale', 'pose_scale2', 'move_all_cam_vec')}
     if not args.eval:
-        raise NotImplementedError("DFNet_dm optimisation needs backward kernels (render + conv stack) that are not "
-                                  "built yet; run with --eval for the forward feature-matching losses")
+        print("DFNet_dm: forward + backward to the predicted pose on the HIP path; the pose regressor's own weight "
+              "gradients / Adam step are not built, so this pass reports gradients and changes no parameters")
+        for it, (data, pose, img_idx) in enumerate(train_dl):
+            out = matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, True, device, setup,
+                                     **render_kwargs_test)
+            print('[{}] loss {:.6f} feat {:.6f} photo {:.6f} psnr {:.3f} |dL/dpose| {:.4e}'.format(
+                it, float(out["loss"]), float(out["feat_loss"]), float(out["photo_loss"]), float(out["psnr"]),
+                float(out["grad_pose"].norm())))
+        return
     stats = []
     for data, pose, img_idx in val_dl:
         out = matching_step_forward(args, data, model, feat_model, pose, img_idx, hwf, True, device, setup,
