@@ -333,6 +333,19 @@ struct Packer {
         int lj = li;
         uint32_t bytes = 0;
         while (lj < nl && grp[lj] == grp[li]) bytes += blocks_bytes<P>(seq[lj], layer_shape(seq[lj]).mb), ++lj;
+        if (seq[li] == LY_L5) {  // split so that three staging buffers fit in LDS (nerfh_layout.h: l5_unit_mb)
+          const LayerShape sh = layer_shape(LY_L5);
+          const int g = l5_unit_mb(umb);
+          for (int mb0 = 0; mb0 < sh.mb; mb0 += g) {
+            const uint32_t ub = unit_bytes<P>(sh.slots, g), uo = uint32_t(blob.size());
+            blob.resize(uo + ub, 0);
+            tab.push_back(uo);
+            tab.push_back(ub);
+            pack_blocks<P>(LY_L5, mb0, g, blob.data() + uo);
+          }
+          li = lj;
+          continue;
+        }
         const uint32_t off = uint32_t(blob.size());
         blob.resize(off + align_piece(bytes), 0);
         tab.push_back(off);
@@ -515,15 +528,6 @@ static int mlp_variant() {
 static unsigned long long* g_timing_buf = nullptr;  // DFN_TIMING builds only (tools/gpu_timing.py)
 extern "C" void dfn_debug_set_timing_buffer(void* p) { g_timing_buf = static_cast<unsigned long long*>(p); }
 
-static int mlp_skew() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DFN_MLP_SKEW");
-    v = e ? atoi(e) : 0;
-    if (v < 0 || v > 64) v = 0;
-  }
-  return v;
-}
 
 extern "C" int dfn_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
                           float* viewdirs, void* stream) {
@@ -543,7 +547,7 @@ extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, cons
   if (int rc = check_net(h, prec, "dfn_mlp_coarse")) return rc;
   if (!rays_o || !rays_d || !sigma || Nc < 1) return set_error(DFN_ERR_ARG, "dfn_mlp_coarse: bad argument");
   const PackedNet& n = h->net[0][prec][mlp_variant()];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr, mlp_skew()};
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr};
   ScopedTimer t(0, HS(stream));
   CHECK_HIP(launch_mlp(false, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_coarse");
   return DFN_OK;
@@ -598,7 +602,7 @@ extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const 
   float* table = static_cast<float*>(bias_ws);
   CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine(ray_bias)");
   const PackedNet& n = h->net[1][prec][mlp_variant()];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, nullptr, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf, mlp_skew()};
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, nullptr, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf};
   ScopedTimer t(1, HS(stream));
   CHECK_HIP(launch_mlp(true, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_fine");
   return DFN_OK;
@@ -666,14 +670,14 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
     float* raw = raw_out ? raw_out + r0 * size_t(Nf) * 9 : w.raw;
     {
-      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr, mlp_skew()};
+      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr};
       ScopedTimer t(0, s);
       CHECK_HIP(launch_mlp(false, prec, var, a, cus, s), "render: coarse MLP");
     }
     CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s), "render: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.bias, s), "render: ray_bias");
     {
-      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, fused ? w.partial : nullptr, (long long)n, Nf, 0.f, 0.f, g_timing_buf, mlp_skew()};
+      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, fused ? w.partial : nullptr, (long long)n, Nf, 0.f, 0.f, g_timing_buf};
       ScopedTimer t(1, s);
       CHECK_HIP(launch_mlp(true, prec, var, a, cus, s), "render: fine MLP");
     }
@@ -795,11 +799,11 @@ int render_backward_core(dfn_nerfh_t h, int prec, const float* o, const float* d
     const float* cd = d + r0 * 3;
     const float* cv = v + r0 * 3;
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
-    MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr, 0};
+    MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr};
     CHECK_HIP(launch_mlp(false, prec, var, ac, cus, s), "render backward: coarse MLP");
     CHECK_HIP(launch_sample_fine(w.f.sigma, n, Nc, Ni, near, far, w.f.z, nullptr, nullptr, s), "render backward: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.f.bias, s), "render backward: ray_bias");
-    MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr, 0};
+    MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr};
     CHECK_HIP(launch_mlp(true, prec, var, af, cus, s), "render backward: fine MLP");
     CHECK_HIP(launch_composite_fine_backward(w.f.raw, w.f.z, grad_rgb + r0 * 3, n, Nf, w.graw, s), "render backward: composite");
     BwdArgs ab{nb.blob, nb.tab, nb.n_units, co, cd, cv, w.f.z, w.f.bias, w.graw, w.gpts, (long long)n, Nf};

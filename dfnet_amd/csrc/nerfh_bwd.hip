@@ -72,7 +72,7 @@ DFN_DEV void clear(typename FragOf<P>::type (&v)[N]) {
   }
 }
 
-template <class P, int UMB, int WAVES, int NB> constexpr uint32_t bwd_lds_bytes() { return 2 * bwd_max_unit_bytes<P>(); }
+template <class P, int UMB, int WAVES, int NB> constexpr uint32_t bwd_lds_bytes() { return 3 * bwd_max_unit_bytes<P>(); }
 
 // A plain layer of the backward kernel: a new staging unit, no bias folding, no activation, no pipelining.
 #define DFN_BLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
@@ -86,11 +86,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   using F = typename FragOf<P>::type;
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
-  st.lds_cur = 0; st.lds_nxt = bwd_max_unit_bytes<P>();
   st.waves = WAVES;
-  st.skew = 0;
   st.t_sync = st.t_wait = 0;
-  st.younger_loads = 0;
   st.trace = nullptr;
   st.n_trace = 0;
   st.lane = threadIdx.x & 63;
@@ -100,9 +97,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  stage_issue(st, smem, 0, st.lds_cur);
-  st.pf_off = st.tab[st.n_units > 1 ? 2 : 0];
-  st.pf_size = st.tab[st.n_units > 1 ? 3 : 1];
+  stage_prime(st, smem, bwd_max_unit_bytes<P>());
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3], g[NB][9];

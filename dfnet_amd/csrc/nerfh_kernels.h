@@ -20,7 +20,6 @@ struct MlpArgs {
   int n_samples;
   float near, far;
   unsigned long long* timing;  // DFN_TIMING builds: per-wave cycle counters [total, dma wait, barrier, tile inputs]
-  int skew;                // de-phasing delay of the second wave per SIMD, in 64-clock units (tuning)
 };
 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream);

@@ -108,10 +108,15 @@ DFN_HD constexpr uint32_t unit_bytes(int slots, int nmb) {
 }
 // Largest unit of either network when at most `umb` M-blocks go into one unit (sizes the two LDS
 // staging buffers): the widest layers are L5 (96 slots, 4 M-blocks) and FIN (64 slots, 5 M-blocks).
+// In the merged layout (umb >= 8) layer 5 (48 fragments) is split into two units of 2 M-blocks so that THREE staging
+// buffers fit the 160 KB of LDS; the largest unit is then the merged transient group (44 fragments + 9 bias blocks).
+DFN_HD constexpr int l5_unit_mb(int umb) { return umb >= 8 ? 2 : umb; }
 template <class P>
 DFN_HD constexpr uint32_t max_unit_bytes(int umb) {
-  const uint32_t a = unit_bytes<P>(96, umb < 4 ? umb : 4), b = unit_bytes<P>(64, umb < 5 ? umb : 5);
-  return a > b ? a : b;  // (the merged small-layer units, 46 208 / 41 600 / 20 864 bytes, are smaller than L5's)
+  const int m5 = l5_unit_mb(umb);
+  const uint32_t a = unit_bytes<P>(96, m5 < 4 ? m5 : 4), b = unit_bytes<P>(64, umb < 5 ? umb : 5);
+  const uint32_t g = umb >= 8 ? align_piece(44u * 64 * P::kLaneBytes + 9u * 128) : 0;
+  return a > b ? (a > g ? a : g) : (b > g ? b : g);
 }
 
 // ---- input-gradient kernel (nerfh_bwd.hip) ---------------------------------------------------------------
@@ -151,7 +156,7 @@ DFN_HD constexpr int pe_dir_feature(int h, int r) {
 // Staging buffer of the backward kernel: its largest unit is BW_L5 (6 M-blocks x 64 slots) / L5 forward.
 template <class P>
 DFN_HD constexpr uint32_t bwd_max_unit_bytes() {
-  const uint32_t a = max_unit_bytes<P>(P::kSlotsPerChunk == 8 ? 8 : 1);
+  const uint32_t a = unit_bytes<P>(96, P::kSlotsPerChunk == 8 ? 4 : 1);  // forward layer 5, whole (no merged layout here)
   const uint32_t b = unit_bytes<P>(64, P::kSlotsPerChunk == 8 ? 6 : 1), c = unit_bytes<P>(80, P::kSlotsPerChunk == 8 ? 4 : 1);
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }

@@ -25,9 +25,9 @@
 
 namespace dfn {
 
-// two staging buffers + per-wave next-tile input slots (8 dwords x 64 lanes per 64 points: z, o, d, next z)
+// three staging buffers + per-wave next-tile input slots (8 dwords x 64 lanes per 64 points: z, o, d, next z)
 template <class P, int UMB, int WAVES, int NB> constexpr uint32_t lds_bytes() {
-  return 2 * max_unit_bytes<P>(UMB) + WAVES * ((NB * 32 + 63) / 64) * 8 * 256;
+  return 3 * max_unit_bytes<P>(UMB) + WAVES * ((NB * 32 + 63) / 64) * 8 * 256;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -38,11 +38,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   using F = typename FragOf<P>::type;
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
-  st.lds_cur = 0; st.lds_nxt = max_unit_bytes<P>(UMB);
   st.waves = WAVES;
-  st.skew = WAVES == 8 ? a.skew : 0;
   st.t_sync = st.t_wait = 0;
-  st.younger_loads = 0;
   st.trace = nullptr;
   st.n_trace = 0;
 #ifdef DFN_TIMING
@@ -57,9 +54,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  stage_issue(st, smem, 0, st.lds_cur);
-  st.pf_off = st.tab[st.n_units > 1 ? 2 : 0];
-  st.pf_size = st.tab[st.n_units > 1 ? 3 : 1];
+  stage_prime(st, smem, max_unit_bytes<P>(UMB));
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3];
@@ -98,11 +93,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   using F = typename FragOf<P>::type;
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
-  st.lds_cur = 0; st.lds_nxt = max_unit_bytes<P>(UMB);
   st.waves = WAVES;
-  st.skew = WAVES == 8 ? a.skew : 0;
   st.t_sync = st.t_wait = 0;
-  st.younger_loads = 0;
   st.trace = nullptr;
   st.n_trace = 0;
 #ifdef DFN_TIMING
@@ -117,11 +109,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  stage_issue(st, smem, 0, st.lds_cur);
-  st.pf_off = st.tab[st.n_units > 1 ? 2 : 0];
-  st.pf_size = st.tab[st.n_units > 1 ? 3 : 1];
+  stage_prime(st, smem, max_unit_bytes<P>(UMB));
   // Tile inputs.  The first tile's are loaded normally; every later tile's are PREFETCHED during the
-  // previous tile's small layers with explicit loads (exact count, see Stager::younger_loads) and only
+  // previous tile's small layers with direct-to-LDS loads and only
   // waited for at the end of that tile, so the HBM latency of z / o / d is off the critical path.
   float zin[NB], znext[NB], oin[NB][3], din[NB][3];
   long long pt[NB], ray_of[NB];
@@ -181,26 +171,6 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
     {
       F de[NB][QC], dummy[NB][chunks_of<P>(16)];
       layer<P, UMB, PIPE, NB, HC, 2, true, false, true, true, -1, true, CY>(st, smem, fin, de, head, rb_dir, carry);
-      if (st.more) {
-        // Prefetch the next tile's inputs by LDS-DMA (no destination registers, exact instruction count):
-        // lane l of round r fetches z, o, d and the next sample's z of the wave's point 64 r + l into this wave's LDS slot.
-        const long long base = (tile + gridDim.x) * PPT + st.wave * (NB * 32);
-        char* slot = smem + 2 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 8 * 256);
-#pragma unroll
-        for (int r = 0; r < PF_ROUNDS; ++r) {
-          const long long ptn = base + r * 64 + st.lane;
-          const uint32_t q = uint32_t(ptn < n_pts ? ptn : n_pts - 1);
-          const uint32_t ray = q / uint32_t(a.n_samples);
-          __builtin_amdgcn_global_load_lds((const void*)(a.z + q), DFN_LDS_PTR(slot + (r * 8) * 256), 4, 0, 0);
-          __builtin_amdgcn_global_load_lds((const void*)(a.z + (q + 1 < uint32_t(n_pts) ? q + 1 : q)), DFN_LDS_PTR(slot + (r * 8 + 7) * 256), 4, 0, 0);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            __builtin_amdgcn_global_load_lds((const void*)(a.rays_o + ray * 3 + c), DFN_LDS_PTR(slot + (r * 8 + 1 + c) * 256), 4, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void*)(a.rays_d + ray * 3 + c), DFN_LDS_PTR(slot + (r * 8 + 4 + c) * 256), 4, 0, 0);
-          }
-        }
-        st.younger_loads = 8 * PF_ROUNDS;
-      }
       layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, de, dummy, head, norb, carry);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -211,6 +181,26 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
     {
       F t0[NB][QC], t1[NB][QC], dummy[NB][chunks_of<P>(16)];
       layer<P, UMB, PIPE, NB, HC, 2, true, false, true, true, -1, true, CY>(st, smem, fin, t0, head, rb_tr, carry);
+      if (st.more) {
+        // Prefetch the next tile's inputs by LDS-DMA (no destination registers).  Issued AFTER this unit's mid_sync so
+        // that nothing younger than a weight DMA is ever waited for before the tile's end:
+        // lane l of round r fetches z, o, d and the next sample's z of the wave's point 64 r + l into this wave's LDS slot.
+        const long long base = (tile + gridDim.x) * PPT + st.wave * (NB * 32);
+        char* slot = smem + 3 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 8 * 256);
+#pragma unroll
+        for (int r = 0; r < PF_ROUNDS; ++r) {
+          const long long ptn = base + r * 64 + st.lane;
+          const uint32_t q = uint32_t(ptn < n_pts ? ptn : n_pts - 1);
+          const uint32_t ray = q / uint32_t(a.n_samples);
+          lds_dma_b32(a.z + q, slot + (r * 8) * 256);
+          lds_dma_b32(a.z + (q + 1 < uint32_t(n_pts) ? q + 1 : q), slot + (r * 8 + 7) * 256);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            lds_dma_b32(a.rays_o + ray * 3 + c, slot + (r * 8 + 1 + c) * 256);
+            lds_dma_b32(a.rays_d + ray * 3 + c, slot + (r * 8 + 4 + c) * 256);
+          }
+        }
+      }
       layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
       layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t1, t0, head, norb, carry);
       layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
@@ -272,9 +262,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
         }
     }
     if (st.more) {  // pick up the prefetched inputs of the next tile (this wave's own LDS slot: no barrier needed)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      asm volatile("" ::: "memory");
       tile_coords(tile + gridDim.x);
-      const char* slot = smem + 2 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 8 * 256);
+      const char* slot = smem + 3 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int loc = nb * 32 + p, r = loc >> 6, l = loc & 63;
@@ -332,11 +323,11 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
   if (prec == 0) {
     if (variant == 0) return launch_one<PrecF16, true, 8, 8, 2, 1, true>(fine, a, n_cu, stream);
-    if (variant == 1) return launch_one<PrecF16, true, 4, 2, 2, 2, true>(fine, a, n_cu, stream);
+    if (variant == 1) return launch_one<PrecF16, true, 4, 2, 2, 1, true>(fine, a, n_cu, stream);
     if (variant == 2) return launch_one<PrecF16, true, 4, 8, 3, 1, true>(fine, a, n_cu, stream);
     return launch_one<PrecF16, true, 8, 8, 2, 1, false>(fine, a, n_cu, stream);
   }
-  if (variant == 1) return launch_one<PrecF32, false, 4, 1, 1, 2, false>(fine, a, n_cu, stream);
+  if (variant == 1) return launch_one<PrecF32, false, 4, 1, 1, 1, false>(fine, a, n_cu, stream);
   return launch_one<PrecF32, false, 8, 1, 1, 1, false>(fine, a, n_cu, stream);
 }
 

@@ -26,7 +26,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     e1.record(); torch.cuda.synchronize()
     print("coarse %.3f ms" % (e0.elapsed_time(e1) / 3))
 else:
-    for var in ("0", "1"):
+    for var in ("0",):
         for lib in sorted(glob.glob(os.path.join(ROOT, "dfnet_amd", "libabl_*.so"))):
             env = dict(os.environ, DFN_LIB_PATH=lib, DFN_MLP_VARIANT=var)
             r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
