@@ -10,9 +10,6 @@
 #include "nerfh_kernels.h"
 #include "nerfh_layout.h"
 
-#ifndef DFN_DEFER
-#define DFN_DEFER 1  // stagger the two waves of a SIMD when issuing their weight-DMA shares
-#endif
 #ifndef DFN_PF
 #define DFN_PF 3  // f16 A fragments in flight per wave
 #endif
@@ -41,8 +38,6 @@ struct Stager {
   int lane, wave, waves;
   uint32_t ubase, uoff;      // LDS offset of the open unit / bytes of it consumed by the layers so far
   uint32_t pf_off, pf_size;  // table entry of the unit the NEXT mid_sync() will start streaming (prefetched)
-  uint32_t def_off, def_size, def_dst;  // a DMA share whose issue was deferred to late_issue()
-  bool deferred;
   unsigned long long t_sync, t_wait, t_last;  // DFN_TIMING: cycles in unit waits / barrier
   unsigned long long* trace;
   int n_trace;
@@ -95,9 +90,12 @@ DFN_DEV void stage_issue(const Stager& st, char* smem, int unit, uint32_t lds_of
 //                then start the DMA of the unit after next into the buffer the previous unit occupied.
 // So a wave flows from one layer into the next without stopping, and the barrier falls where both waves of a
 // SIMD still have MFMAs queued on either side of it.
+// What the ablations say about the remaining cost of streaming (fine kernel, one run): no barrier +4 %, no DMA
+// +21 %, same DMA instructions with a quarter of the bytes +19 %, half the pieces +16 %, every piece from one
+// cached KiB +2 %; staggering the two waves of a SIMD, or staging through VGPRs + ds_write_b128 instead of the
+// DMA: no gain / -2.5 %.  The cost follows the BYTES landing in LDS, not instructions, waits or L2.
 DFN_DEV void stage_prime(Stager& st, char* smem, uint32_t unit_stride) {
   st.lds_cur = 0; st.lds_nxt = unit_stride; st.lds_nn = 2 * unit_stride;
-  st.deferred = false;
   st.u = 0;
   stage_issue(st, smem, 0, st.lds_cur);
   stage_issue(st, smem, st.n_units > 1 ? 1 : 0, st.lds_nxt);
@@ -122,11 +120,7 @@ DFN_DEV uint32_t open_unit(Stager& st) {
 }
 
 // Once per unit, between two of its MFMA chunks.  After open_unit(): st.u = the unit after the open one.
-// `defer`: the second wave of each SIMD (waves 4..7 of an 8-wave workgroup) postpones ITS share of the DMA to
-// late_issue(), one M-block later.  Issuing an LDS-DMA piece blocks the issuing wave for 60-185 cycles
-// (MI355X_MICROARCH.md); if both waves of a SIMD do it right after the barrier the SIMD idles, staggered the
-// other wave's MFMAs cover it.
-DFN_DEV void mid_sync(Stager& st, char* smem, bool defer) {
+DFN_DEV void mid_sync(Stager& st, char* smem) {
 #ifdef DFN_ABL_NOSYNC  // ablation: no DMA, no barrier
   return;
 #endif
@@ -160,27 +154,13 @@ DFN_DEV void mid_sync(Stager& st, char* smem, bool defer) {
   bool next_tile = st.u == 0;   // the open unit is the tile's last: both st.u and st.u + 1 belong to the next tile
   if (n2 >= st.n_units) { n2 -= st.n_units; next_tile = true; }
 #ifndef DFN_ABL_NODMA
-  if (!next_tile || st.more) {
-    if (defer && st.waves == 8 && st.wave >= 4) {
-      st.def_off = st.pf_off; st.def_size = st.pf_size; st.def_dst = st.lds_nxt;
-      st.deferred = true;
-    } else {
-      stage_issue_at(st, smem, st.pf_off, st.pf_size, st.lds_nxt);
-    }
-  }
+  if (!next_tile || st.more) stage_issue_at(st, smem, st.pf_off, st.pf_size, st.lds_nxt);
 #endif
   {  // fetch the table entry needed by the next call now, so its scalar-load latency is off the critical path
     int n3 = n2 + 1;
     if (n3 >= st.n_units) n3 -= st.n_units;
     st.pf_off = tab_entry(st, 2 * n3);
     st.pf_size = tab_entry(st, 2 * n3 + 1);
-  }
-}
-
-DFN_DEV void late_issue(Stager& st, char* smem) {
-  if (st.deferred) {
-    stage_issue_at(st, smem, st.def_off, st.def_size, st.def_dst);
-    st.deferred = false;
   }
 }
 
@@ -344,8 +324,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
           const int t = lm * KC + kc;
-          if (NEWUNIT && lm == 0 && kc == (KC > 1 ? KC / 2 : 0)) mid_sync(st, smem, DFN_DEFER && nmb >= 2);
-          if (DFN_DEFER && NEWUNIT && nmb >= 2 && lm == 1 && kc == (KC > 1 ? KC / 2 : 0)) late_issue(st, smem);
+          if (NEWUNIT && lm == 0 && kc == (KC > 1 ? KC / 2 : 0)) mid_sync(st, smem);
           const F cur = a[t % PF];
           if (t + PF < nt) a[t % PF] = DFN_AFRAG(t + PF);
           if (kc == (PIPE ? KC / 2 : 0) && !RAYBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
