@@ -11,7 +11,8 @@ LIB_PATH = os.environ.get("DFN_LIB_PATH") or os.path.join(os.path.dirname(os.pat
 
 DFN_PREC_F16 = 0
 DFN_PREC_F32 = 1
-PRECISIONS = {"f16": DFN_PREC_F16, "fp16": DFN_PREC_F16, "f32": DFN_PREC_F32, "fp32": DFN_PREC_F32}
+DFN_PREC_F16X3 = 2  # DFNet only: split-f16 (fp32-grade results at f16 MFMA rate)
+PRECISIONS = {"f16": DFN_PREC_F16, "fp16": DFN_PREC_F16, "f32": DFN_PREC_F32, "fp32": DFN_PREC_F32, "f16x3": DFN_PREC_F16X3}
 
 COMP_TEST_TIME, COMP_STATIC_ONLY, COMP_WHITE_BKGD = 1, 2, 4
 

@@ -29,9 +29,12 @@ struct ConvSpec {
 };
 
 struct PackedConv {
-  char* w[2] = {nullptr, nullptr};  // per precision
+  char* w[3] = {nullptr, nullptr, nullptr};  // per precision (2 = split-f16: [hi fragments][lo fragments] per slice)
   float* bias = nullptr;            // [cout/32][2][16]
+  float* bias_x3 = nullptr;         // the same, pre-multiplied by the split-f16 operand scale
+  float out_scale = 1.f;            // 2^-(s+4): undoes the split-f16 operand scaling
 };
+inline size_t elem_size(int prec) { return prec == 0 ? 2 : 4; }  // activations in HBM: f16 only on the f16 path
 
 const int kVgg[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, -1, 512, 512, 512, -1, 512, 512, 512, -1};
 
@@ -94,6 +97,7 @@ static void free_dev(dfn_dfnet_s* h) {
     for (auto& p : v) {
       for (auto& w : p.w) if (w) (void)hipFree(w);
       if (p.bias) (void)hipFree(p.bias);
+      if (p.bias_x3) (void)hipFree(p.bias_x3);
     }
     v.clear();
   };
@@ -157,6 +161,32 @@ void pack_conv(const float* w, int cout, int cin, int ks, bool first, int sb, in
                 }
 }
 
+// Split-f16 packing: w * 2^s = hi + lo (both f16); slice layout [cg][blk][ky][hi|lo][mb][kx][kc][lane][8].
+void pack_conv_x3(const float* w, int cout, int cin, int ks, bool first, int sb, int mb, float wscale, std::vector<uint8_t>& blob) {
+  const int nblk = first ? 1 : cin / 32, kcb = sb / 8, groups = cout / 32 / mb;
+  const size_t half_slice = size_t(mb) * ks * kcb * 64 * 8;  // elements
+  blob.assign(size_t(groups) * nblk * ks * 2 * half_slice * 2, 0);
+  _Float16* out = reinterpret_cast<_Float16*>(blob.data());
+  for (int cg = 0; cg < groups; ++cg)
+    for (int blk = 0; blk < nblk; ++blk)
+      for (int ky = 0; ky < ks; ++ky) {
+        _Float16* sl = out + ((size_t(cg) * nblk + blk) * ks + ky) * 2 * half_slice;
+        size_t o = 0;
+        for (int m = 0; m < mb; ++m)
+          for (int kx = 0; kx < ks; ++kx)
+            for (int kc = 0; kc < kcb; ++kc)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j, ++o) {
+                  const int co = 32 * (cg * mb + m) + (lane & 31);
+                  const int ci = in_channel(first, blk, lane >> 5, kc * 8 + j);
+                  const float v = (ci >= 0 && ci < cin ? w[((size_t(co) * cin + ci) * ks + ky) * ks + kx] : 0.f) * wscale;
+                  const _Float16 hi = _Float16(v);
+                  sl[o] = hi;
+                  sl[half_slice + o] = _Float16(v - float(hi));
+                }
+      }
+}
+
 int upload_bytes(const void* src, size_t bytes, void** dst) {
   if (hipMalloc(dst, bytes ? bytes : 16) != hipSuccess) return set_error(DFN_ERR_HIP, "hipMalloc(%zu) failed", bytes);
   if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
@@ -173,10 +203,27 @@ int pack_and_upload(const float* w, const float* b, int cout, int cin, int ks, b
     else pack_conv<PrecF32>(w, cout, cin, ks, first, sb, mb, blob);
     if (int rc = upload_bytes(blob.data(), blob.size(), reinterpret_cast<void**>(&pc.w[prec]))) return rc;
   }
-  std::vector<float> bias(size_t(cout / 32) * 32);
+  // split-f16: scale the weights by a power of two so that the largest is ~2^10 (lo parts stay normal f16)
+  float wmax = 0.f;
+  for (size_t i = 0; i < size_t(cout) * cin * ks * ks; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
+  int sexp = 0;
+  if (wmax > 0.f) sexp = 10 - int(std::ceil(std::log2(wmax)));
+  sexp = sexp < -8 ? -8 : (sexp > 24 ? 24 : sexp);
+  const float wscale = std::ldexp(1.f, sexp);
+  {
+    std::vector<uint8_t> blob;
+    pack_conv_x3(w, cout, cin, ks, first, first ? prep_sb(2) : 16, 2, wscale, blob);
+    if (int rc = upload_bytes(blob.data(), blob.size(), reinterpret_cast<void**>(&pc.w[2]))) return rc;
+  }
+  pc.out_scale = 1.f / (wscale * 16.f);
+  std::vector<float> bias(size_t(cout / 32) * 32), bias3(size_t(cout / 32) * 32);
   for (int m = 0; m < cout / 32; ++m)
     for (int hh = 0; hh < 2; ++hh)
-      for (int r = 0; r < 16; ++r) bias[(m * 2 + hh) * 16 + r] = b[32 * m + mblock_row(hh, r)];
+      for (int r = 0; r < 16; ++r) {
+        bias[(m * 2 + hh) * 16 + r] = b[32 * m + mblock_row(hh, r)];
+        bias3[(m * 2 + hh) * 16 + r] = b[32 * m + mblock_row(hh, r)] * wscale * 16.f;
+      }
+  if (int rc = upload_bytes(bias3.data(), bias3.size() * 4, reinterpret_cast<void**>(&pc.bias_x3))) return rc;
   return upload_bytes(bias.data(), bias.size() * 4, reinterpret_cast<void**>(&pc.bias));
 }
 
@@ -250,7 +297,7 @@ struct DfWs {
   size_t total;
 };
 DfWs carve_df(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
-  const size_t es = prec == 0 ? 2 : 4;
+  const size_t es = elem_size(prec);
   const size_t px = size_t(B) * H * W;
   DfWs w{};
   size_t off = 0;
@@ -284,7 +331,7 @@ extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B,
                                  void* workspace, size_t workspace_bytes, void* stream) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: null handle");
   if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_forward: dfn_dfnet_commit() has not been called");
-  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: unknown precision %d", prec);
+  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: unknown precision %d", prec);
   if (!x || !workspace || B < 1 || H < 32 || W < 32 || (return_feature && (!features || upH < 1 || upW < 1)) ||
       (return_pose && !pose) || (return_feature && siamese && (B & 1)))
     return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: bad argument (need H,W >= 32; even batch for siamese)");
@@ -306,7 +353,7 @@ extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B,
     ConvArgs a{};
     a.in = cur;
     a.w = h->enc_packed[i].w[prec];
-    a.bias = h->enc_packed[i].bias;
+    a.bias = prec == 2 ? h->enc_packed[i].bias_x3 : h->enc_packed[i].bias; a.out_scale = h->enc_packed[i].out_scale;
     a.out_act = stop_here ? nullptr : ping[pp];
     a.out_pre = (sp.tap >= 0 && return_feature) ? w.tap[sp.tap] : nullptr;
     a.B = B; a.H = ch; a.W = cw;
@@ -333,11 +380,11 @@ extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B,
     const size_t plane = size_t(128) * upH * upW;
     for (int t = 0; t < h->n_taps; ++t) {
       ConvArgs a{};
-      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = h->ad1[t].bias; a.out_act = w.tmp64; a.out_pre = nullptr;
+      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale; a.out_act = w.tmp64; a.out_pre = nullptr;
       a.B = B; a.H = tap_h[t]; a.W = tap_w[t]; a.nblk_in = h->tap_channels[t] / 32; a.cout_blocks = 2; a.relu = 1;
       CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet: adapt 1x1");
       ConvArgs c{};
-      c.in = w.tmp64; c.w = h->ad5[t].w[prec]; c.bias = h->ad5[t].bias; c.out_act = w.ad128; c.out_pre = nullptr;
+      c.in = w.tmp64; c.w = h->ad5[t].w[prec]; c.bias = prec == 2 ? h->ad5[t].bias_x3 : h->ad5[t].bias; c.out_scale = h->ad5[t].out_scale; c.out_act = w.ad128; c.out_pre = nullptr;
       c.B = B; c.H = tap_h[t]; c.W = tap_w[t]; c.nblk_in = 2; c.cout_blocks = 4; c.relu = 0;
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet: adapt 5x5");
       if (!siamese) {
@@ -405,7 +452,7 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
                                         size_t workspace_bytes, void* stream) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: null handle");
   if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_backward_input: dfn_dfnet_commit() has not been called");
-  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: unknown precision %d", prec);
+  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: unknown precision %d", prec);
   level_mask &= (1 << h->n_taps) - 1;
   if (!x || !grad_features || !grad_x || !workspace || B < 1 || H < 32 || W < 32 || upH < 1 || upW < 1 || !level_mask)
     return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: bad argument (need H,W >= 32 and a non-empty level_mask)");
@@ -424,7 +471,7 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
     const ConvSpec& sp = h->enc[i];
     lay_h[i] = ch; lay_w[i] = cw;
     ConvArgs a{};
-    a.in = cur; a.w = h->enc_packed[i].w[prec]; a.bias = h->enc_packed[i].bias;
+    a.in = cur; a.w = h->enc_packed[i].w[prec]; a.bias = prec == 2 ? h->enc_packed[i].bias_x3 : h->enc_packed[i].bias; a.out_scale = h->enc_packed[i].out_scale;
     a.out_act = w.act[i];
     a.out_pre = (sp.tap >= 0 && (level_mask >> sp.tap & 1)) ? w.tap[sp.tap] : nullptr;
     a.B = B; a.H = ch; a.W = cw; a.nblk_in = nblk; a.cout_blocks = sp.cout / 32; a.relu = 1;
@@ -439,7 +486,8 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
       ch /= 2; cw /= 2;
     }
   }
-  // ---- backward
+  // ---- backward (split-f16 is a forward-only mode: gradient magnitudes are arbitrary, so its gradient convs run in fp32)
+  const int gprec = prec == 2 ? 1 : prec;
   const size_t plane = size_t(128) * upH * upW;
   // Two gradient buffers: the ReLU gate runs in place on the buffer holding g_act, the conv's data gradient goes to
   // the other one, and a max-pool's routed gradient reuses the (by then dead) gated buffer.
@@ -455,20 +503,20 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
       const int t = sp.tap;
       // adaptation layer forward (ReLU gate of its 1x1), then its transposed convolutions
       ConvArgs a{};
-      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = h->ad1[t].bias; a.out_act = w.tmp64;
+      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale; a.out_act = w.tmp64;
       a.B = B; a.H = hh; a.W = ww; a.nblk_in = sp.cout / 32; a.cout_blocks = 2; a.relu = 1;
       CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet bwd: adapt 1x1");
       CHECK_HIP(launch_upsample_backward(prec, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s),
                 "dfnet bwd: upsample");
       ConvArgs c{};
-      c.in = w.g128; c.w = h->ad5_dgrad[t].w[prec]; c.bias = h->ad5_dgrad[t].bias; c.out_pre = w.g64;
+      c.in = w.g128; c.w = h->ad5_dgrad[t].w[gprec]; c.bias = h->ad5_dgrad[t].bias; c.out_scale = h->ad5_dgrad[t].out_scale; c.out_pre = w.g64;
       c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
-      CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet bwd: adapt 5x5 dgrad");
+      CHECK_HIP(launch_conv(gprec, 5, 16, c, s), "dfnet bwd: adapt 5x5 dgrad");
       CHECK_HIP(launch_relu_gate(prec, w.g64, w.tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet bwd: adapt gate");
       ConvArgs d{};
-      d.in = w.g64; d.w = h->ad1_dgrad[t].w[prec]; d.bias = h->ad1_dgrad[t].bias; d.out_pre = w.gtap;
+      d.in = w.g64; d.w = h->ad1_dgrad[t].w[gprec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
       d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
-      CHECK_HIP(launch_conv(prec, 1, 16, d, s), "dfnet bwd: adapt 1x1 dgrad");
+      CHECK_HIP(launch_conv(gprec, 1, 16, d, s), "dfnet bwd: adapt 1x1 dgrad");
       g_tap = w.gtap;
     }
     // gradient w.r.t. the conv's pre-activation: ReLU-gated trunk gradient + the tap's
@@ -477,9 +525,9 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
     // data gradient of the conv
     const int cin_p = (sp.cin + 63) / 64 * 64;
     ConvArgs e{};
-    e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[prec]; e.bias = h->enc_dgrad[i].bias; e.out_pre = gbuf[in_idx];
+    e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[gprec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale; e.out_pre = gbuf[in_idx];
     e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = cin_p / 32; e.relu = 0;
-    CHECK_HIP(launch_conv(prec, 3, 16, e, s), "dfnet bwd: encoder conv dgrad");
+    CHECK_HIP(launch_conv(gprec, 3, 16, e, s), "dfnet bwd: encoder conv dgrad");
     if (i == 0) {
       CHECK_HIP(launch_unprep(prec, gbuf[in_idx], B, H, W, cin_p / 32, grad_x, s), "dfnet bwd: unprep");
       break;

@@ -17,11 +17,14 @@
 // GAP+FC pose head (:168-170).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dfnet_kernels.h"
 #include "mfma_frag.h"
 
 namespace dfn {
+
+#define DFN_DEV_INLINE __device__ __forceinline__
 
 template <class P> struct ConvGeom;
 template <> struct ConvGeom<PrecF16> { static constexpr int kPad = 16, kVec = 16; };
@@ -164,8 +167,176 @@ static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------ split-f16 ("x3") convolution
+// fp32-grade results at f16 MFMA rate (v_mfma_f32_32x32x16_f16 is 16x faster than v_mfma_f32_32x32x2_f32): every
+// operand is split x = hi + lo with hi = f16(x), lo = f16(x - hi), and a product is accumulated in fp32 as
+// hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-22 relative).  Activations live in HBM as fp32 in the
+// blocked layout and are split while the input patch is staged into two f16 LDS planes; weights are split on the
+// host and staged as [hi fragments][lo fragments].  Both operands are pre-scaled by powers of two (activations
+// x16, weights x2^s per layer, ConvArgs::out_scale = 2^-(s+4) undoes it exactly) so the lo parts stay normal f16.
+// The weight slices (one per input block and kernel row) are double-buffered: the DMA of slice s+1 is in flight
+// while slice s is multiplied.
+DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
+  const uint32_t off = (uint32_t)(size_t)DFN_LDS_PTR(lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(off) : "memory");
+}
+constexpr float kX3ActScale = 16.f;
+
+template <int KS, int SB>
+constexpr int x3_plane_bytes() { return (((kConvTileH + KS - 1) * (kConvTileW + KS - 1) * (2 * SB * 2 + 16)) + 15) & ~15; }
+template <int KS, int SB, int MB>
+constexpr int x3_wslice_bytes() { return 2 * MB * KS * (SB / 8) * 1024; }  // hi + lo fragments of one (block, ky) slice
+
+template <int KS, int SB, int MB, bool DB>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
+  constexpr int KCB = SB / 8;
+  constexpr int TH = kConvTileH, TW = kConvTileW, R = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int PIXG = 2 * SB * 4;        // bytes of a pixel's block in HBM (fp32)
+  constexpr int PS = 2 * SB * 2 + 16;     // padded pixel stride of one f16 plane
+  constexpr int SEG = PIXG / 16;          // 16-byte (4-float) segments per pixel
+  constexpr int PLANE = x3_plane_bytes<KS, SB>();
+  constexpr int WSL = x3_wslice_bytes<KS, SB, MB>();
+  constexpr int WHALF = WSL / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* plane_hi = smem;
+  char* plane_lo = smem + PLANE;
+  char* wst = smem + 2 * PLANE;           // two slices
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int cg = blockIdx.y, b = blockIdx.z;
+
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const f32x4* bq = reinterpret_cast<const f32x4*>(a.bias + ((cg * MB + mb) * 2 + h) * 16);  // pre-scaled bias
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = bq[q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[mb][0][4 * q + i] = v[i]; acc[mb][1][4 * q + i] = v[i]; }
+    }
+  }
+  const char* in = static_cast<const char*>(a.in);
+  const int n_slices = a.nblk_in * KS;
+  auto issue_slice = [&](int sl, int buf) {
+    const char* wsrc = a.w + ((size_t)cg * n_slices + sl) * WSL + lane * 16;
+    for (int q = wave * 1024; q < WSL; q += 4096) conv_lds_dma_b128(wsrc + q, wst + buf * WSL + q);
+  };
+  if (DB) issue_slice(0, 0);
+  int sl = 0;
+  for (int blk = 0; blk < a.nblk_in; ++blk) {
+    __syncthreads();  // everyone is done with the previous patch (and the slice before the one in flight)
+    for (int e = tid; e < PH * PW * SEG; e += 256) {
+      const int pix = e / SEG, seg = e - pix * SEG;
+      const int py = pix / PW, px = pix - py * PW;
+      const int gy = y0 + py - R, gx = x0 + px - R;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const size_t src = ((((size_t)b * a.H + (ok ? gy : 0)) * a.W + (ok ? gx : 0)) * a.nblk_in + blk) * PIXG + seg * 16;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(in + src);
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      half4 hi, lo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xs = v[i] * kX3ActScale;
+        hi[i] = (_Float16)xs;
+        lo[i] = (_Float16)(xs - (float)hi[i]);
+      }
+      *reinterpret_cast<half4*>(plane_hi + pix * PS + seg * 8) = hi;
+      *reinterpret_cast<half4*>(plane_lo + pix * PS + seg * 8) = lo;
+    }
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky, ++sl) {
+      if (!DB) {                           // single slice buffer: two workgroups per CU cover each other's staging
+        if (ky) __syncthreads();           // previous slice fully consumed
+        issue_slice(sl, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my share of slice sl has landed
+      asm volatile("" ::: "memory");
+      __syncthreads();                     // slice sl and the patch are visible; (DB) slice sl-1 is fully consumed
+      if (DB && sl + 1 < n_slices) issue_slice(sl + 1, (sl + 1) & 1);
+      const char* wb = wst + (DB ? (sl & 1) * WSL : 0);
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+        for (int kc = 0; kc < KCB; ++kc) {
+          half8 bh[2], bl[2];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int o = ((2 * wave + nb + ky) * PW + p + kx) * PS + (h * SB + kc * 8) * 2;
+            bh[nb] = *reinterpret_cast<const half8*>(plane_hi + o);
+            bl[nb] = *reinterpret_cast<const half8*>(plane_lo + o);
+          }
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const int fo = (((mb * KS + kx) * KCB + kc) * 64 + lane) * 16;
+            const half8 ah = *reinterpret_cast<const half8*>(wb + fo);
+            const half8 al = *reinterpret_cast<const half8*>(wb + WHALF + fo);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], acc[mb][nb], 0, 0, 0);
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], acc[mb][nb], 0, 0, 0);
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], acc[mb][nb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // epilogue (fp32 activations): undo the operand scaling, write the pre-ReLU tap and/or the ReLU'd activation
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int y = y0 + 2 * wave + nb, x = x0 + p;
+    if (y >= a.H || x >= a.W) continue;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const size_t off = ((((size_t)b * a.H + y) * a.W + x) * a.cout_blocks + (cg * MB + mb)) * 32 + 16 * h;
+      alignas(16) float pre[16];
+      alignas(16) float act[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pre[r] = acc[mb][nb][r] * a.out_scale;
+        act[r] = a.relu ? fmaxf(pre[r], 0.f) : pre[r];
+      }
+      if (a.out_pre) {
+        f32x4* d = reinterpret_cast<f32x4*>(static_cast<float*>(a.out_pre) + off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = reinterpret_cast<const f32x4*>(pre)[q];
+      }
+      if (a.out_act) {
+        f32x4* d = reinterpret_cast<f32x4*>(static_cast<float*>(a.out_act) + off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = reinterpret_cast<const f32x4*>(act)[q];
+      }
+    }
+  }
+}
+
+template <int KS, int SB, int MB, bool DB>
+static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
+  if (a.cout_blocks % MB) return hipErrorInvalidValue;
+  constexpr int lds = 2 * x3_plane_bytes<KS, SB>() + (DB ? 2 : 1) * x3_wslice_bytes<KS, SB, MB>();
+  static_assert(lds <= 160 * 1024, "x3 conv tile does not fit in LDS");
+  auto kern = conv_x3_kernel<KS, SB, MB, DB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int tiles = ((a.H + kConvTileH - 1) / kConvTileH) * ((a.W + kConvTileW - 1) / kConvTileW);
+  hipLaunchKernelGGL(kern, dim3(tiles, a.cout_blocks / MB, a.B), dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+
 int conv_mb(int prec, int cout_blocks) { return (prec == 0 && cout_blocks % 4 == 0) ? 4 : 2; }
-int prep_sb(int prec) { return prec == 0 ? 8 : 4; }
+int prep_sb(int prec) { return prec == 1 ? 4 : 8; }
 
 hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t stream) {
   const bool wide = a.cout_blocks % 4 == 0;
@@ -175,6 +346,15 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
     if (ks == 1) return wide ? launch_conv_t<PrecF16, 1, 16, 4>(a, stream) : launch_conv_t<PrecF16, 1, 16, 2>(a, stream);
     if (ks == 3) return wide ? launch_conv_t<PrecF16, 3, 16, 4>(a, stream) : launch_conv_t<PrecF16, 3, 16, 2>(a, stream);
     if (ks == 5) return wide ? launch_conv_t<PrecF16, 5, 16, 4>(a, stream) : launch_conv_t<PrecF16, 5, 16, 2>(a, stream);
+  } else if (prec == 2) {
+    // 1x1 / 3x3: one slice buffer and two workgroups per CU (they cover each other's staging) measured 13 % faster than
+    // one double-buffered workgroup; the 5x5 tile fits only one workgroup per CU either way, so it double-buffers.
+    static const int db = [] { const char* e = getenv("DFN_X3_DB"); return e ? atoi(e) : 0; }();  // tuning aid
+    if (sb == 8 && ks == 3) return launch_conv_x3_t<3, 8, 2, true>(a, stream);
+    if (sb != 16) return hipErrorInvalidValue;
+    if (ks == 1) return db ? launch_conv_x3_t<1, 16, 2, true>(a, stream) : launch_conv_x3_t<1, 16, 2, false>(a, stream);
+    if (ks == 3) return db ? launch_conv_x3_t<3, 16, 2, true>(a, stream) : launch_conv_x3_t<3, 16, 2, false>(a, stream);
+    if (ks == 5) return launch_conv_x3_t<5, 16, 2, true>(a, stream);
   } else {
     if (sb == 4 && ks == 3) return launch_conv_t<PrecF32, 3, 4, 2>(a, stream);
     if (sb != 16) return hipErrorInvalidValue;
@@ -203,6 +383,7 @@ hipError_t launch_dfnet_prep(int prec, const float* x, int B, int H, int W, void
   const size_t n = (size_t)B * H * W;
   const int grid = int((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   if (prec == 0) hipLaunchKernelGGL((prep_kernel<_Float16, 8>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<_Float16*>(out));
+  else if (prec == 2) hipLaunchKernelGGL((prep_kernel<float, 8>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<float*>(out));
   else hipLaunchKernelGGL((prep_kernel<float, 4>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<float*>(out));
   return hipGetLastError();
 }
@@ -267,19 +448,27 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ in,
     const float wy0 = 1.f - ly, wx0 = 1.f - lx;
     const T* base = in + (b * h * (size_t)w) * 128 + blk * 32;
     const T* p00 = base + ((size_t)yA * w + xA) * 128;
-    const T* p01 = base + ((size_t)yA * w + xB) * 128;
-    const T* p10 = base + ((size_t)yB * w + xA) * 128;
-    const T* p11 = base + ((size_t)yB * w + xB) * 128;
+    // taps with zero weight alias the first one (same cache lines): the identity resize of level 0 reads each source once
+    const T* p01 = lx == 0.f ? p00 : base + ((size_t)yA * w + xB) * 128;
+    const T* p10 = ly == 0.f ? p00 : base + ((size_t)yB * w + xA) * 128;
+    const T* p11 = ly == 0.f ? p01 : (lx == 0.f ? p10 : base + ((size_t)yB * w + xB) * 128);
     float* o = out + b * out_bstride + (size_t)blk * 32 * UH * UW + (size_t)Y * UW + X;
+    constexpr int V = 16 / int(sizeof(T));  // elements per 16-byte vector load
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+    for (int q = 0; q < 32 / V; ++q) {
+      alignas(16) T a00[V], a01[V], a10[V], a11[V];
+      *reinterpret_cast<f32x4*>(a00) = reinterpret_cast<const f32x4*>(p00)[q];
+      *reinterpret_cast<f32x4*>(a01) = reinterpret_cast<const f32x4*>(p01)[q];
+      *reinterpret_cast<f32x4*>(a10) = reinterpret_cast<const f32x4*>(p10)[q];
+      *reinterpret_cast<f32x4*>(a11) = reinterpret_cast<const f32x4*>(p11)[q];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int e = hh * 16 + s;
+      for (int k = 0; k < V; ++k) {
+        const int e = q * V + k, hh = e >> 4, s = e & 15;
         const int ch = 4 * hh + (s & 3) + 8 * (s >> 2);
-        const float v = wy0 * (wx0 * (float)p00[e] + lx * (float)p01[e]) + ly * (wx0 * (float)p10[e] + lx * (float)p11[e]);
+        const float v = wy0 * (wx0 * (float)a00[k] + lx * (float)a01[k]) + ly * (wx0 * (float)a10[k] + lx * (float)a11[k]);
         o[(size_t)ch * UH * UW] = v;
       }
+    }
   }
 }
 hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH, int UW, float* out,

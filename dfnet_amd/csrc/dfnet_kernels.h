@@ -25,9 +25,11 @@ struct ConvArgs {
   int nblk_in;         // input channel blocks
   int cout_blocks;     // Cout/32
   int relu;
+  float out_scale;     // prec 2 (split-f16): accumulators are multiplied by this before the epilogue (2^-(s+4))
 };
 
-// prec: 0 = f16 MFMA inputs / fp32 accumulate, 1 = exact fp32 MFMA.  ks in {1,3,5}; sb = slots per
+// prec: 0 = f16 MFMA inputs / fp32 accumulate, 1 = exact fp32 MFMA, 2 = split-f16 (hi/lo operands, three f16 MFMAs
+// per product, fp32 activations in HBM: fp32-grade results at f16 MFMA rate).  ks in {1,3,5}; sb = slots per
 // half per input block (16, or 8/4 for the zero-padded RGB input of conv1_1).
 hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t stream);
 int conv_mb(int prec, int cout_blocks);  // M-blocks (of 32 output channels) one workgroup computes; fixes the packed layout

@@ -74,7 +74,7 @@ class _DFNetBase(nn.Module):
     mean = [0.485, 0.456, 0.406]
     std = [0.229, 0.224, 0.225]
 
-    def __init__(self, feat_dim=12, places365_model_path='', precision="f32"):
+    def __init__(self, feat_dim=12, places365_model_path='', precision="f16x3"):
         super().__init__()
         self.encoder = _vgg16_features()
         self.hypercolumn_indices = [2, 14, 28][:len(self.tap_channels)]

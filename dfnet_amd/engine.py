@@ -173,7 +173,7 @@ class NerfHEngine:
 class DfnetEngine:
     """DFNet / DFNet_s feature extractor resident on one GPU (convs packed as MFMA fragments)."""
 
-    def __init__(self, n_taps=3, feat_dim=12, precision="f32"):
+    def __init__(self, n_taps=3, feat_dim=12, precision="f16x3"):
         self.lib = _lib.load()
         self.n_taps, self.feat_dim, self.precision = n_taps, feat_dim, precision
         self.handle = ctypes.c_void_p()

@@ -38,7 +38,9 @@ enum {
 /* Arithmetic of the MLP / conv contractions. */
 enum {
   DFN_PREC_F16 = 0, /* f16 MFMA inputs, fp32 accumulate (v_mfma_f32_32x32x16_f16); PE via v_sin/v_cos */
-  DFN_PREC_F32 = 1  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32); PE via full-range sinf/cosf */
+  DFN_PREC_F32 = 1, /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32); PE via full-range sinf/cosf */
+  DFN_PREC_F16X3 = 2 /* DFNet only: split-f16 — operands hi + lo in f16, three f16 MFMAs per product, fp32
+                        activations: fp32-grade results at f16 MFMA rate (forward; its gradient convs run as F32) */
 };
 
 const char* dfn_last_error(void);

@@ -11,10 +11,10 @@ E = eng.DfnetEngine(3, 12).load_numpy(w)
 out = {}
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 x = torch.rand(B, 3, 480, 640, device=dev)
-for prec in ("f16", "f32"):
+for prec in ("f16", "f16x3", "f32"):
     E.forward(x, True, True, False, 480, 640, precision=prec)
     torch.cuda.synchronize()
-    n = 5 if prec == "f16" else 2
+    n = 2 if prec == "f32" else 5
     t0 = time.time()
     for _ in range(n):
         E.forward(x, True, True, False, 480, 640, precision=prec)
