@@ -1,6 +1,10 @@
 """Mirror of the render helpers DFNet training calls: /root/reference/script/feature/misc.py:203-289
-(`render_nerfw_imgs`, `render_virtual_imgs`), dm/direct_pose_model.py:147-167 (`fix_coord_supp`) and
-the cosine feature loss of feature/direct_feature_matching.py:114-136."""
+(`render_nerfw_imgs`, `render_virtual_imgs`), dm/direct_pose_model.py:147-167 (`fix_coord_supp`), the cosine
+feature loss of feature/direct_feature_matching.py:114-136 and the pose-error evaluation of
+feature/misc.py:49-131 (`compute_error_in_q`, `get_error_in_q`; pytorch3d's matrix_to_quaternion restated)."""
+import math
+
+import numpy as np
 import torch
 
 from . import engine as _engine
@@ -82,3 +86,65 @@ def feature_loss(feature_rgb, feature_target, per_channel=False):
     fr, ft = feature_rgb.reshape(C, -1), feature_target.reshape(C, -1)
     cos = torch.nn.CosineSimilarity(dim=0 if per_channel else 1, eps=1e-6)
     return 1 - cos(fr, ft).mean()
+
+
+def matrix_to_quaternion(R):
+    """[...,3,3] rotation matrices -> unit quaternions [...,4], real part first (pytorch3d.transforms convention;
+    the error below only uses |q1.q2|, so the sign / branch choice is immaterial).  Shepperd's method: pick the
+    largest of the four squared components for a stable division."""
+    R = torch.as_tensor(R, dtype=torch.float64)
+    m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+    q_abs = torch.sqrt(torch.clamp(torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22,
+                                                1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1), min=0.))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], -1),
+        torch.stack([R[..., 2, 1] - R[..., 1, 2], q_abs[..., 1] ** 2, R[..., 1, 0] + R[..., 0, 1], R[..., 0, 2] + R[..., 2, 0]], -1),
+        torch.stack([R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] + R[..., 0, 1], q_abs[..., 2] ** 2, R[..., 1, 2] + R[..., 2, 1]], -1),
+        torch.stack([R[..., 1, 0] - R[..., 0, 1], R[..., 2, 0] + R[..., 0, 2], R[..., 2, 1] + R[..., 1, 2], q_abs[..., 3] ** 2], -1),
+    ], -2)
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    best = q_abs.argmax(-1)
+    q = torch.gather(cand, -2, best[..., None, None].expand(*best.shape, 1, 4))[..., 0, :]
+    return (q / q.norm(dim=-1, keepdim=True)).float()
+
+
+def pose_errors(pred, gt):
+    """(translation error, rotation error in degrees) between [N,3,4] poses: ||t - t'|| and 2 acos|q.q'|."""
+    pred, gt = torch.as_tensor(pred, dtype=torch.float32).reshape(-1, 3, 4), torch.as_tensor(gt, dtype=torch.float32).reshape(-1, 3, 4)
+    q1, q2 = matrix_to_quaternion(gt[:, :3, :3]), matrix_to_quaternion(pred[:, :3, :3])
+    d = torch.clamp((q1 * q2).sum(-1).abs(), -1., 1.)
+    return (gt[:, :3, 3] - pred[:, :3, 3]).norm(dim=-1), 2 * torch.acos(d) * 180 / math.pi
+
+
+def compute_error_in_q(args, dl, model, device, results, batch_size=1):
+    """Per-frame [translation error (m), rotation error (deg)] of the pose regressor over `dl` (misc.py:49-116):
+    prediction orthogonalised by SVD, errors from quaternions."""
+    pred_x, gt_x, thetas = [], [], []
+    i = 0
+    for batch in dl:
+        data, pose = batch[0], batch[1]
+        with torch.no_grad():
+            _, predict = model(data.to(device))
+            predict = predict.reshape(-1, 3, 4).cpu()
+            u, s, v = torch.svd(predict[:, :3, :3])
+            predict[:, :3, :3] = torch.matmul(u, v.transpose(-2, -1))
+        pose = torch.as_tensor(pose, dtype=torch.float32).reshape(-1, 3, 4)
+        ex, eq = pose_errors(predict, pose)
+        for k in range(predict.shape[0]):
+            results[i, :] = [float(ex[k]), float(eq[k])]
+            pred_x.append(predict[k, :3, 3].numpy())
+            gt_x.append(pose[k, :3, 3].numpy())
+            thetas.append(float(eq[k]))
+            i += 1
+    return results, {"pose": np.array(pred_x), "pose_gt": np.array(gt_x), "theta": np.array(thetas)}
+
+
+def get_error_in_q(args, dl, model, sample_size, device, batch_size=1):
+    """Median / mean pose error of the regressor over `dl` (misc.py:118-131), printed like the reference."""
+    model.eval()
+    results = np.zeros((sample_size, 2))
+    results, vis_info = compute_error_in_q(args, dl, model, device, results, batch_size)
+    median_result, mean_result = np.median(results, axis=0), np.mean(results, axis=0)
+    print('Median error {}m and {} degrees.'.format(median_result[0], median_result[1]))
+    print('Mean error {}m and {} degrees.'.format(mean_result[0], mean_result[1]))
+    return median_result, mean_result

@@ -7,8 +7,9 @@ dataset poses (render_nerfw_imgs) fed to the DFNet feature extractor.
 Native here: everything `--render_feature_only` executes (run_feature.py:313-346) — render every test
 frame with NeRF-H (quarter resolution + bicubic x4 with --tinyimg), run the siamese DFNet forward on
 [target, render] and save one feature channel of each stream as PNG under ./tmp/<expname>/{target,rgb}/.
-The optimisation loop (run_feature.py:349-422: Adam, triplet loss, random view synthesis) and `--eval`
-(median pose error) are outside the hot path and stop with a clear message.
+`--eval` prints the median / mean pose error of the regressor over the test split (HIP forward + the quaternion
+error of feature/misc.py:49-131).  The optimisation loop (run_feature.py:349-422: Adam, triplet loss, random view
+synthesis) needs weight gradients and stops with a clear message.
 """
 import os
 import sys
@@ -67,9 +68,13 @@ def train_feature(args, train_dl, val_dl, test_dl, hwf, i_split, near, far):
                 _save_channel(features_rgb[0, 0, save_i], os.path.join(out_r, '%04d.png' % i))
         print("render features done")
         return
-    raise NotImplementedError("DFNet optimisation / --eval are outside the render+feature hot path and are not "
-                              "implemented here (use --render_feature_only, or train with the reference and load "
-                              "the checkpoint via --pretrain_model_path)")
+    if args.eval:  # run_feature.py:306-311: pose error of the regressor over the test split
+        from dfnet_amd.feature_misc import get_error_in_q
+        get_error_in_q(args, test_dl, feat_model, len(val_dl.dataset), device, batch_size=1)
+        return
+    raise NotImplementedError("DFNet optimisation (triplet loss, random view synthesis: weight gradients of the conv "
+                              "stack) is not built; use --eval / --render_feature_only, or train with the reference "
+                              "and load the checkpoint via --pretrain_model_path")
 
 
 def main(argv=None):

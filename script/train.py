@@ -5,8 +5,8 @@
 
 Native: every step's forward — DFNet pose regression, NeRF-H render at the predicted pose (quarter resolution +
 bicubic x4), siamese DFNet features, cosine feature-matching loss — and its backward down to the predicted pose
-(HIP gradient kernels for the feature extractor, the bicubic resize and the render).  `--eval` prints the mean
-losses / PSNR over the validation split; without it the script walks the training split and prints the loss and
+(HIP gradient kernels for the feature extractor, the bicubic resize and the render).  `--eval` prints the median /
+mean pose error over the test split (as the reference) and the mean losses / PSNR over the validation split; without it the script walks the training split and prints the loss and
 the norm of d loss / d pose per batch.  The last link of the reference's update — weight gradients of the pose
 regressor (a VGG16 training step) and its Adam step — is not built, so no parameters change.
 """
@@ -54,6 +54,11 @@ def main(argv=None):
                 it, float(out["loss"]), float(out["feat_loss"]), float(out["photo_loss"]), float(out["psnr"]),
                 float(out["grad_pose"].norm())))
         return
+    # train.py:138-157: `--eval` = pose error of the DFNet_dm regressor over the test split ...
+    from dfnet_amd.feature_misc import get_error_in_q
+    print(len(test_dl.dataset))
+    get_error_in_q(args, test_dl, model, len(test_dl.dataset), device, batch_size=1)
+    # ... and, beyond the reference, the feature-matching losses of the forward step over the validation split
     stats = []
     for data, pose, img_idx in val_dl:
         out = matching_step_forward(args, data, model, feat_model, pose, img_idx, hwf, True, device, setup,

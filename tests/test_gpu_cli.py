@@ -79,3 +79,17 @@ def test_run_feature_render_feature_only_cli(tmp_path):
             assert p.exists()
             a = np.asarray(Image.open(p))
             assert a.shape == (64, 80) and a.max() == 255 and a.min() == 0
+
+
+def test_run_feature_eval_cli(tmp_path):
+    """run_feature.py --eval: pose regression over the test split on the HIP path + the reference's error report."""
+    datadir = make_scene(str(tmp_path), n_train=2, n_val=3, H=128, W=160)
+    cli = ["--config", os.path.join(ROOT, "script", "config_dfnet.txt"), "--eval", "--datadir", datadir,
+           "--basedir", str(tmp_path / "logs"), "--N_samples", "16", "--N_importance", "32", "--df", "2", "--testskip", "1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "run_feature.py")] + cli, cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("Median error", "Mean error"))]
+    assert len(lines) == 2 and all("degrees" in l for l in lines)
+    med = float(lines[0].split("error ")[1].split("m and")[0])
+    assert np.isfinite(med) and med >= 0

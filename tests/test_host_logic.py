@@ -132,3 +132,26 @@ def test_gather_frames_gloo_world2(tmp_path, n_frames):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert f"GATHER_OK {n_frames}" in r.stdout
+
+
+def test_pose_error_metrics_match_scipy():
+    """matrix_to_quaternion / pose_errors (feature/misc.py:49-116 without pytorch3d) against scipy's Rotation."""
+    from scipy.spatial.transform import Rotation
+    from dfnet_amd.feature_misc import matrix_to_quaternion, pose_errors
+    rng = np.random.default_rng(0)
+    R1 = Rotation.random(64, random_state=1)
+    R2 = Rotation.from_rotvec(rng.normal(0, 0.2, (64, 3))) * R1
+    q = matrix_to_quaternion(torch.from_numpy(R1.as_matrix())).numpy()
+    ref = R1.as_quat()[:, [3, 0, 1, 2]]  # scipy: (x, y, z, w)
+    assert np.allclose(np.abs((q * ref).sum(-1)), 1.0, atol=1e-6)  # same rotation up to sign
+    a = np.concatenate([R1.as_matrix(), rng.normal(0, 1, (64, 3, 1))], -1)
+    b = np.concatenate([R2.as_matrix(), a[:, :, 3:] + rng.normal(0, 0.1, (64, 3, 1))], -1)
+    ex, eq = pose_errors(torch.from_numpy(b), torch.from_numpy(a))
+    want = np.degrees((R2 * R1.inv()).magnitude())
+    assert np.allclose(eq.numpy(), want, atol=2e-2)  # float32 acos near 1
+    assert np.allclose(ex.numpy(), np.linalg.norm(a[:, :, 3] - b[:, :, 3], axis=-1), atol=1e-6)
+    # a half-turn about each axis exercises every branch of the conversion
+    for axis in np.eye(3):
+        Rh = Rotation.from_rotvec(np.pi * axis).as_matrix()
+        qh = matrix_to_quaternion(torch.from_numpy(Rh)).numpy()
+        assert abs(qh[0]) < 1e-6 and np.allclose(np.abs(qh[1:]), axis, atol=1e-6)
