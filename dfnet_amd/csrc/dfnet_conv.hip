@@ -228,36 +228,61 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     const char* wsrc = a.w + ((size_t)cg * n_slices + sl) * WSL + lane * 16;
     for (int q = wave * 1024; q < WSL; q += 4096) conv_lds_dma_b128(wsrc + q, wst + buf * WSL + q);
   };
+  // The fp32 patch of the NEXT input block is prefetched into registers while the current block is multiplied
+  // (a fixed number of unconditional loads per thread, so the weight DMA can be awaited with a counted vmcnt).
+  constexpr int TOTAL = PH * PW * SEG, NPRE = (TOTAL + 255) / 256;
+  f32x4 pre[NPRE];
+  auto load_patch = [&](int blk) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int e = min(tid + i * 256, TOTAL - 1);
+      const int pix = e / SEG, seg = e - pix * SEG;
+      const int py = pix / PW, px = pix - py * PW;
+      const int gy = min(max(y0 + py - R, 0), a.H - 1), gx = min(max(x0 + px - R, 0), a.W - 1);
+      pre[i] = *reinterpret_cast<const f32x4*>(in + ((((size_t)b * a.H + gy) * a.W + gx) * a.nblk_in + blk) * PIXG + seg * 16);
+    }
+  };
+  auto store_patch = [&]() {
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int e = tid + i * 256;
+      if (e < TOTAL) {
+        const int pix = e / SEG, seg = e - pix * SEG;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = y0 + py - R, gx = x0 + px - R;
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;   // zero padding outside the image
+        half4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xs = ok ? pre[i][k] * kX3ActScale : 0.f;
+          hi[k] = (_Float16)xs;
+          lo[k] = (_Float16)(xs - (float)hi[k]);
+        }
+        *reinterpret_cast<half4*>(plane_hi + pix * PS + seg * 8) = hi;
+        *reinterpret_cast<half4*>(plane_lo + pix * PS + seg * 8) = lo;
+      }
+    }
+  };
+  load_patch(0);
   if (DB) issue_slice(0, 0);
   int sl = 0;
   for (int blk = 0; blk < a.nblk_in; ++blk) {
     __syncthreads();  // everyone is done with the previous patch (and the slice before the one in flight)
-    for (int e = tid; e < PH * PW * SEG; e += 256) {
-      const int pix = e / SEG, seg = e - pix * SEG;
-      const int py = pix / PW, px = pix - py * PW;
-      const int gy = y0 + py - R, gx = x0 + px - R;
-      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      const size_t src = ((((size_t)b * a.H + (ok ? gy : 0)) * a.W + (ok ? gx : 0)) * a.nblk_in + blk) * PIXG + seg * 16;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(in + src);
-      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-      half4 hi, lo;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float xs = v[i] * kX3ActScale;
-        hi[i] = (_Float16)xs;
-        lo[i] = (_Float16)(xs - (float)hi[i]);
-      }
-      *reinterpret_cast<half4*>(plane_hi + pix * PS + seg * 8) = hi;
-      *reinterpret_cast<half4*>(plane_lo + pix * PS + seg * 8) = lo;
-    }
+    store_patch();
+    const bool more = blk + 1 < a.nblk_in;
 #pragma unroll 1
     for (int ky = 0; ky < KS; ++ky, ++sl) {
       if (!DB) {                           // single slice buffer: two workgroups per CU cover each other's staging
         if (ky) __syncthreads();           // previous slice fully consumed
         issue_slice(sl, 0);
       }
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my share of slice sl has landed
+      if (ky == 0 && more) {               // next block's patch: issued AFTER this slice's DMA, allowed to stay in flight
+        load_patch(blk + 1);
+        __builtin_amdgcn_s_waitcnt(NPRE <= 15 ? (0x0F70 | NPRE) : 0x0F70);  // vmcnt(NPRE)
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my share of slice sl has landed
+      }
       asm volatile("" ::: "memory");
       __syncthreads();                     // slice sl and the patch are visible; (DB) slice sl-1 is fully consumed
       if (DB && sl + 1 < n_slices) issue_slice(sl + 1, (sl + 1) & 1);
