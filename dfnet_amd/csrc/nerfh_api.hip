@@ -764,6 +764,25 @@ extern "C" int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_
   return DFN_OK;
 }
 
+extern "C" int dfn_ray_grad_reduce(const float* grad_pts, const float* z_fine, const float* rays_d, size_t n_rays, int Nf,
+                                   int derive_viewdirs, float* grad_rays_o, float* grad_rays_d, float* grad_viewdirs,
+                                   void* stream) {
+  if (!grad_pts || !z_fine || !rays_d || !grad_rays_o || !grad_rays_d || Nf < 1)
+    return set_error(DFN_ERR_ARG, "dfn_ray_grad_reduce: bad argument");
+  CHECK_HIP(launch_ray_grad_reduce(grad_pts, z_fine, rays_d, n_rays, Nf, derive_viewdirs, grad_rays_o, grad_rays_d, grad_viewdirs,
+                                   HS(stream)),
+            "dfn_ray_grad_reduce");
+  return DFN_OK;
+}
+
+extern "C" int dfn_raygen_backward(int H, int W, float focal, const float* grad_rays_o, const float* grad_rays_d, float* grad_c2w,
+                                   void* stream) {
+  if (H < 1 || W < 1 || !(focal > 0) || !grad_rays_o || !grad_rays_d || !grad_c2w)
+    return set_error(DFN_ERR_ARG, "dfn_raygen_backward: bad argument");
+  CHECK_HIP(launch_raygen_backward(H, W, focal, grad_rays_o, grad_rays_d, grad_c2w, HS(stream)), "dfn_raygen_backward");
+  return DFN_OK;
+}
+
 namespace {
 struct BwdWorkspace {
   Workspace f;

@@ -134,6 +134,29 @@ class NerfHEngine:
         return rgb, disp, acc
 
 
+    # ------------------------------------------------------------------ staged render that keeps what backward needs
+    def render_rays_saving(self, rays_o, rays_d, viewdirs, hist, Nc, Ni, near, far, precision=None):
+        """render_rays composed from the stage entry points, returning (rgb, disp, acc, z_fine, raw): the state from
+        which backward_from_saved() differentiates without recomputing the forward."""
+        rays_o, rays_d, viewdirs = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3), _f32c(viewdirs).reshape(-1, 3)
+        sigma = self.mlp_coarse(rays_o, rays_d, Nc, near, far, precision)
+        z = sample_fine(sigma, Ni, near, far)
+        raw = self.mlp_fine(rays_o, rays_d, viewdirs, hist, z, precision)
+        out = composite_fine(raw, z)
+        return out["rgb"], out["disp"], out["acc"], z, raw
+
+    def backward_from_saved(self, rays_o, rays_d, viewdirs, hist, z, raw, grad_rgb, derive_viewdirs=True, precision=None):
+        """d L/d (rays_o, rays_d[, viewdirs]) from the saved (z_fine, raw) of render_rays_saving()."""
+        rays_o, rays_d, viewdirs = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3), _f32c(viewdirs).reshape(-1, 3)
+        graw = composite_fine_backward(raw, z, _f32c(grad_rgb).reshape(-1, 3))
+        gpts = self.mlp_fine_backward(rays_o, rays_d, viewdirs, hist, z, graw, precision)
+        n, Nf = z.shape
+        go, gd = torch.empty(n, 3, device=z.device), torch.empty(n, 3, device=z.device)
+        gv = None if derive_viewdirs else torch.empty(n, 3, device=z.device)
+        check(self.lib.dfn_ray_grad_reduce(ptr(gpts), ptr(z), ptr(rays_d), n, Nf, int(derive_viewdirs), ptr(go), ptr(gd), ptr(gv),
+                                           current_stream()), "dfn_ray_grad_reduce")
+        return go, gd, gv
+
     # ------------------------------------------------------------------ gradient of the whole path
     def render_rays_backward(self, rays_o, rays_d, hist, Nc, Ni, near, far, grad_rgb, viewdirs=None, precision=None):
         """d L/d (rays_o, rays_d[, viewdirs]) of render_rays from d L/d rgb [n,3].  With viewdirs=None they are
@@ -324,6 +347,15 @@ def upsample_bicubic(img, outH, outW):
     check(lib.dfn_upsample_bicubic(ptr(img), H, W, C, int(outH), int(outW), ptr(out), current_stream()),
           "dfn_upsample_bicubic")
     return out
+
+
+def raygen_backward(H, W, focal, grad_o, grad_d):
+    """d L/d c2w [3,4] from d L/d rays_o, rays_d [H*W,3] (get_rays backward)."""
+    grad_o, grad_d = _f32c(grad_o).reshape(-1, 3), _f32c(grad_d).reshape(-1, 3)
+    gc = torch.empty(3, 4, device=grad_o.device)
+    check(_lib.load().dfn_raygen_backward(int(H), int(W), float(focal), ptr(grad_o), ptr(grad_d), ptr(gc), current_stream()),
+          "dfn_raygen_backward")
+    return gc
 
 
 def upsample_bicubic_backward(grad_out, H, W):

@@ -11,9 +11,12 @@ Only the test-time path is native so far (perturb=0, raw_noise_std=0, test_time=
 
 Autograd: when grad is enabled and `c2w` / `rays` require grad (the DFNet_dm step,
 feature/direct_feature_matching.py:340-376), `rgb_map` is returned attached to the graph through
-torch.autograd.Function wrappers whose backward is the HIP gradient path (dfn_render_image_backward /
-dfn_render_rays_backward); disp_map / acc_map are returned detached (the reference's losses use rgb only).
-The gradient kernels default to the exact-fp32 MFMA path (`grad_precision`), see tests/test_gpu_grad.py.
+torch.autograd.Function wrappers: the forward is composed from the stage entry points and keeps (z_fine, raw);
+the backward runs the HIP gradient kernels on that saved state (compositing backward, fused fine-MLP input
+gradient, ray / pose reductions) — the stateless dfn_render_image_backward / dfn_render_rays_backward compute
+the same thing with an internal re-render.  disp_map / acc_map are returned detached (the reference's losses use
+rgb only).  The MLP gradient kernel defaults to the exact-fp32 MFMA path (`GRAD_PRECISION`), see
+tests/test_gpu_grad.py.
 """
 import os
 import time
@@ -37,27 +40,39 @@ def _engine_of(kwargs):
     return eng
 
 
-GRAD_PRECISION = "f32"  # arithmetic of the gradient path (forward recompute + backward)
+GRAD_PRECISION = "f32"  # arithmetic of the MLP gradient kernel
+# Arithmetic of the tracked forward, whose (z_fine, raw) the backward starts from.  None = the engine's own
+# precision (what the user renders with, f16 by default): outputs identical to the untracked render, and in the
+# DFNet_dm step a pose gradient within 7e-6 of the all-fp32 one (tools/gpu_dm_step.py) at 43 instead of 55 ms per
+# step.  "f32" makes the whole tracked path fp32 — needed only where the loss makes d c2w a badly conditioned
+# signed sum (tests/test_gpu_grad.py::test_render_autograd_drop_in: random per-pixel weights on a 12x16 image,
+# where the f16 forward's 1e-4 error is amplified to 1e-2).
+GRAD_FORWARD_PRECISION = None
 
 
 class _RenderImageFn(torch.autograd.Function):
-    """rgb/disp/acc = render(c2w); backward: d L/d c2w from d L/d rgb."""
+    """rgb/disp/acc = render(c2w); backward: d L/d c2w from d L/d rgb.  The forward is composed from the stage
+    entry points and keeps (rays, z_fine, raw), so backward differentiates from the saved state instead of
+    re-rendering (dfn_render_image_backward is the stateless equivalent)."""
 
     @staticmethod
     def forward(ctx, c2w, eng, H, W, focal, hist, Nc, Ni, near, far):
-        rgb, disp, acc = eng.render_image(c2w.detach(), H, W, focal, hist, Nc, Ni, near, far)
-        ctx.save_for_backward(c2w.detach(), hist)
-        ctx.cfg = (eng, H, W, focal, Nc, Ni, near, far)
+        from . import engine as _e
+        o, d, v = _e.raygen(H, W, focal, c2w.detach())
+        rgb, disp, acc, z, raw = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION)
+        ctx.save_for_backward(o, d, v, hist, z, raw)
+        ctx.cfg = (eng, H, W, focal)
+        disp, acc = disp.reshape(H, W), acc.reshape(H, W)
         ctx.mark_non_differentiable(disp, acc)
-        return rgb, disp, acc
+        return rgb.reshape(H, W, 3), disp, acc
 
     @staticmethod
     def backward(ctx, g_rgb, _g_disp, _g_acc):
-        c2w, hist = ctx.saved_tensors
-        eng, H, W, focal, Nc, Ni, near, far = ctx.cfg
-        gc = eng.render_image_backward(c2w, H, W, focal, hist, Nc, Ni, near, far, g_rgb.contiguous(),
-                                       precision=GRAD_PRECISION)
-        return (gc,) + (None,) * 9
+        from . import engine as _e
+        o, d, v, hist, z, raw = ctx.saved_tensors
+        eng, H, W, focal = ctx.cfg
+        go, gd, _ = eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION)
+        return (_e.raygen_backward(H, W, focal, go, gd),) + (None,) * 9
 
 
 class _RenderRaysFn(torch.autograd.Function):
@@ -65,17 +80,18 @@ class _RenderRaysFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, eng, hist, Nc, Ni, near, far):
-        rgb, disp, acc, _ = eng.render_rays(rays_o.detach(), rays_d.detach(), hist, Nc, Ni, near, far)
-        ctx.save_for_backward(rays_o.detach(), rays_d.detach(), hist)
-        ctx.cfg = (eng, Nc, Ni, near, far)
+        o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
+        v = d / torch.norm(d, dim=-1, keepdim=True)
+        rgb, disp, acc, z, raw = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION)
+        ctx.save_for_backward(o, d, v, hist, z, raw)
+        ctx.eng = eng
         ctx.mark_non_differentiable(disp, acc)
         return rgb, disp, acc
 
     @staticmethod
     def backward(ctx, g_rgb, _g_disp, _g_acc):
-        o, d, hist = ctx.saved_tensors
-        eng, Nc, Ni, near, far = ctx.cfg
-        go, gd, _ = eng.render_rays_backward(o, d, hist, Nc, Ni, near, far, g_rgb.contiguous(), precision=GRAD_PRECISION)
+        o, d, v, hist, z, raw = ctx.saved_tensors
+        go, gd, _ = ctx.eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION)
         return (go, gd) + (None,) * 6
 
 

@@ -157,6 +157,15 @@ int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_o, const fl
                           const float* viewdirs, const float* hist, size_t hist_rows, size_t n_rays,
                           const float* z_fine, int Nf, const float* grad_raw, float* grad_pts,
                           void* bias_ws, void* stream);
+/* Per-ray reduction of grad_pts [n_rays, Nf, 6] (pts = o + d z, rendering.py:292,305): grad_rays_o = sum g,
+ * grad_rays_d = sum z g; with derive_viewdirs != 0 the view-direction part is folded into grad_rays_d through
+ * viewdirs = d/|d| (rendering.py:366-371), otherwise grad_viewdirs (optional) receives sum gv. */
+int dfn_ray_grad_reduce(const float* grad_pts, const float* z_fine, const float* rays_d, size_t n_rays, int Nf,
+                        int derive_viewdirs, float* grad_rays_o, float* grad_rays_d, float* grad_viewdirs,
+                        void* stream);
+/* get_rays backward (ray_utils.py:5-15): grad_c2w [3,4] from grad_rays_o / grad_rays_d [H*W, 3]. */
+int dfn_raygen_backward(int H, int W, float focal, const float* grad_rays_o, const float* grad_rays_d,
+                        float* grad_c2w, void* stream);
 /* Scratch needed by dfn_render_rays_backward / dfn_render_image_backward for up to n_rays rays. */
 size_t dfn_render_backward_workspace_bytes(size_t n_rays, int Nc, int Ni);
 /* d L / d rays_o, d L / d rays_d [n_rays, 3] of dfn_render_rays from grad_rgb [n_rays, 3] (recomputes the

@@ -156,6 +156,12 @@ def test_render_autograd_drop_in(scene, gold):
               white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False)
     g = gold("g9_render_grad_c2w")
     pose = dev(g["c2w"]).requires_grad_(True)
+    # default: the tracked forward runs in the engine's precision (f16) and the gradient is that forward's
+    rgb = rendering.render(int(g["H"]), int(g["W"]), float(g["focal"]), c2w=pose, near=0., far=2.5, img_idx=dev(g["hist"]), **kw)[0]
+    (rgb * dev(g["G"])).sum().backward()
+    assert relmax(pose.grad, g["grad_c2w"]) < TOL_C2W["f16"]
+    pose.grad = None
+    rendering.GRAD_FORWARD_PRECISION = "f32"   # everything tracked in fp32: reference-grade pose gradient
     rgb, disp, acc, extras = rendering.render(int(g["H"]), int(g["W"]), float(g["focal"]), c2w=pose, near=0., far=2.5,
                                               img_idx=dev(g["hist"]), **kw)
     assert rgb.requires_grad and not disp.requires_grad and extras == {}
@@ -169,6 +175,7 @@ def test_render_autograd_drop_in(scene, gold):
     scale = np.abs(g["grad_rays_d"]).max()
     assert float((rays.grad[0].cpu() - T(g["grad_rays_o"])).abs().max()) < TOL["f32"] * scale
     assert float((rays.grad[1].cpu() - T(g["grad_rays_d"])).abs().max()) < TOL["f32"] * scale
+    rendering.GRAD_FORWARD_PRECISION = None
     with torch.no_grad():  # and nothing is tracked without grad
         assert not rendering.render(12, 16, 14.6, c2w=pose, near=0., far=2.5, img_idx=dev(g["hist"]), **kw)[0].requires_grad
 
