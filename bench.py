@@ -30,7 +30,7 @@ from dfnet_amd import _lib, dist as ddist, engine as eng, synthetic as syn  # no
 H, W, FOCAL, NEAR, FAR = 480, 640, 585.0, 0.0, 2.5
 NC, NI = 64, 128
 MAC_COARSE, MAC_FINE = 130944, 182720  # algorithmic MAC per sample, SURVEY.md Appendix A
-PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f16x3": 2500.0 / 3}  # dense MFMA peaks, MI355X_MICROARCH.md (split-f16: 3 f16 MFMAs per product)
 
 
 def pmc_traffic(kernel="nerfh_fine_kernel"):
@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32", "f16x3"])
     ap.add_argument("--cpu-sample", type=int, default=8192, help="rays in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -145,11 +145,11 @@ def main():
             "metric": "rendered rays/sec (64+128 samples, 640x480)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic random-weight NeRF-H (D=8, W=128), 640x480, "
                                    "64+128 samples, test-time render_image, 1 frame per step per GPU",
-                       "rays_per_step_per_gpu": rays, "precision": "f16 MFMA inputs / fp32 accumulate"
-                       if args.precision == "f16" else "exact fp32 MFMA",
+                       "rays_per_step_per_gpu": rays, "precision": {"f16": "f16 MFMA inputs / fp32 accumulate", "f32": "exact fp32 MFMA",
+                                     "f16x3": "split-f16: hi/lo f16 operands, 3 f16 MFMAs per product, fp32-grade"}[args.precision],
                        "parallelism": f"frames sharded over {world} GPU(s), gather at end"},
             "roofline": {"bound": "mfma", "kernel": "nerfh_fine_kernel", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,

@@ -181,7 +181,6 @@ DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
   const uint32_t off = (uint32_t)(size_t)DFN_LDS_PTR(lds_dst);
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(off) : "memory");
 }
-constexpr float kX3ActScale = 16.f;
 
 template <int KS, int SB>
 constexpr int x3_plane_bytes() { return (((kConvTileH + KS - 1) * (kConvTileW + KS - 1) * (2 * SB * 2 + 16)) + 15) & ~15; }

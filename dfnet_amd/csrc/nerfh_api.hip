@@ -3,6 +3,7 @@
 // the whole-path dfn_render_rays / dfn_render_image drivers.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -49,13 +50,14 @@ struct PackedNet {
   char* blob = nullptr;
   uint32_t* tab = nullptr;
   int n_units = 0;
+  float in_scale = 1.f;  // split-f16: weight scale x activation scale carried by the accumulators
 };
 
 struct dfn_nerfh_s {
   dfn_nerfh_desc desc;
   std::map<std::string, std::vector<float>> params;
   bool committed = false;
-  PackedNet net[2][2][kVariants];  // [coarse/fine][prec][kernel variant]
+  PackedNet net[2][3][kVariants];  // [coarse/fine][prec][kernel variant]
   PackedNet bwd[2];                // [prec] fine forward units + backward (W^T) units of the gradient kernel
   float* extra = nullptr;  // w_dir^T | b_dir | w_tr^T | b_tr | emb_a | emb_t
   RayBiasWeights rb{};
@@ -210,6 +212,9 @@ struct Packer {
   static bool unit_has_bias(int layer) { return layer != LY_DIR && layer != LY_TE0; }
 
   // One layer's M-blocks [mb0, mb0+group) as [A fragments][bias fragments], appended at `base`.
+  // split-f16 (P::kSplit): a fragment is a hi plane then a lo plane of w * wscale; the bias is pre-multiplied by
+  // wscale * kX3ActScale (what the accumulators carry).
+  float wscale = 1.f;
   template <class P>
   void pack_blocks(int layer, int mb0, int group, uint8_t* base) const {
     using Elem = typename std::conditional<P::kSlotsPerChunk == 8, _Float16, float>::type;
@@ -229,7 +234,14 @@ struct Packer {
           for (int j = 0; j < P::kSlotsPerChunk; ++j) {
             const int col = col_source(layer, hh, kc * P::kSlotsPerChunk + j);
             const float v = (row >= 0 && col >= 0 && col < m.cols) ? m.w[size_t(row) * m.cols + col] : 0.f;
-            frag[((size_t(g) * KC + kc) * 64 + lane) * P::kSlotsPerChunk + j] = Elem(v);
+            if constexpr (P::kSplit) {
+              Elem* fr = frag + (size_t(g) * KC + kc) * 64 * 16;   // 1024 halves per fragment: [hi plane][lo plane]
+              const Elem hi = Elem(v * wscale);
+              fr[lane * 8 + j] = hi;
+              fr[512 + lane * 8 + j] = Elem(v * wscale - float(hi));
+            } else {
+              frag[((size_t(g) * KC + kc) * 64 + lane) * P::kSlotsPerChunk + j] = Elem(v);
+            }
           }
       }
       for (int hh = 0; hh < 2; ++hh)
@@ -238,7 +250,8 @@ struct Packer {
           int row;
           row_source(layer, mb, mblock_row(hh, r), m, row);
           if (row >= m.rows) row = -1;
-          bias[(g * 2 + hh) * 16 + r] = (row >= 0 && unit_has_bias(layer)) ? m.b[row] : 0.f;
+          const float b = (row >= 0 && unit_has_bias(layer)) ? m.b[row] : 0.f;
+          bias[(g * 2 + hh) * 16 + r] = P::kSplit ? b * wscale * kX3ActScale : b;
         }
     }
   }
@@ -389,14 +402,26 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
     if (!h->params.count(kv.first)) return set_error(DFN_ERR_STATE, "dfn_nerfh_commit: parameter '%s' not set", kv.first.c_str());
   free_packed(h);
   for (int f = 0; f < 2; ++f)
-    for (int prec = 0; prec < 2; ++prec)
+    for (int prec = 0; prec < 3; ++prec)
       for (int var = 0; var < kVariants; ++var) {
         Packer pk{h, f ? "fine." : "coarse."};
         std::vector<uint8_t> blob;
         std::vector<uint32_t> tab;
-        if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, unit_mb<PrecF16>(var), unit_mb<PrecF16>(var) >= 8, blob, tab);
-        else pk.pack<PrecF32>(f, unit_mb<PrecF32>(var), false, blob, tab);
         PackedNet& n = h->net[f][prec][var];
+        if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, unit_mb<PrecF16>(var), unit_mb<PrecF16>(var) >= 8, blob, tab);
+        else if (prec == DFN_PREC_F32) pk.pack<PrecF32>(f, unit_mb<PrecF32>(var), false, blob, tab);
+        else {
+          // one power-of-two weight scale per network: the largest |w| lands near 2^10, lo parts stay normal f16
+          float wmax = 0.f;
+          for (const auto& kv : h->params)
+            if (kv.first.compare(0, pk.pre.size(), pk.pre) == 0 && kv.first.find(".weight") != std::string::npos)
+              for (float v : kv.second) wmax = std::fmax(wmax, std::fabs(v));
+          int sexp = wmax > 0.f ? 10 - int(std::ceil(std::log2(wmax))) : 0;
+          sexp = sexp < -8 ? -8 : (sexp > 24 ? 24 : sexp);
+          pk.wscale = std::ldexp(1.f, sexp);
+          n.in_scale = pk.wscale * kX3ActScale;
+          pk.pack<PrecX3>(f, unit_mb<PrecX3>(var), false, blob, tab);
+        }
         int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
         if (rc) return rc;
         rc = upload(tab.data(), tab.size() * 4, reinterpret_cast<void**>(&n.tab));
@@ -508,10 +533,11 @@ extern "C" int dfn_profile_read(int which, double* avg_ms, int* launches) {
     if (e_ != hipSuccess) return set_error(DFN_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
   } while (0)
 
-static int check_net(dfn_nerfh_t h, int prec, const char* fn) {
+static int check_net(dfn_nerfh_t h, int prec, const char* fn, bool allow_x3 = false) {
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_nerfh_commit() has not been called", fn);
-  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32) return set_error(DFN_ERR_ARG, "%s: unknown precision %d", fn, prec);
+  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && !(allow_x3 && prec == DFN_PREC_F16X3))
+    return set_error(DFN_ERR_ARG, "%s: unknown / unsupported precision %d", fn, prec);
   return DFN_OK;
 }
 
@@ -544,10 +570,10 @@ extern "C" int dfn_posenc(const float* x, size_t n, int L, int mode, float* out,
 
 extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, size_t n_rays,
                               int Nc, float near, float far, float* sigma, void* stream) {
-  if (int rc = check_net(h, prec, "dfn_mlp_coarse")) return rc;
+  if (int rc = check_net(h, prec, "dfn_mlp_coarse", true)) return rc;
   if (!rays_o || !rays_d || !sigma || Nc < 1) return set_error(DFN_ERR_ARG, "dfn_mlp_coarse: bad argument");
   const PackedNet& n = h->net[0][prec][mlp_variant()];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr};
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr, n.in_scale};
   ScopedTimer t(0, HS(stream));
   CHECK_HIP(launch_mlp(false, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_coarse");
   return DFN_OK;
@@ -595,14 +621,14 @@ extern "C" size_t dfn_fine_bias_bytes(size_t n_rays) { return (n_rays ? n_rays :
 extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
                             const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf,
                             float* raw, void* bias_ws, void* stream) {
-  if (int rc = check_net(h, prec, "dfn_mlp_fine")) return rc;
+  if (int rc = check_net(h, prec, "dfn_mlp_fine", true)) return rc;
   if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !raw || !bias_ws || Nf < 1 ||
       (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_mlp_fine: bad argument (hist_rows must be 1 or n_rays)");
   float* table = static_cast<float*>(bias_ws);
   CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine(ray_bias)");
   const PackedNet& n = h->net[1][prec][mlp_variant()];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, nullptr, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf};
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, nullptr, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf, n.in_scale};
   ScopedTimer t(1, HS(stream));
   CHECK_HIP(launch_mlp(true, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_fine");
   return DFN_OK;
@@ -670,14 +696,14 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
     float* raw = raw_out ? raw_out + r0 * size_t(Nf) * 9 : w.raw;
     {
-      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr};
+      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale};
       ScopedTimer t(0, s);
       CHECK_HIP(launch_mlp(false, prec, var, a, cus, s), "render: coarse MLP");
     }
     CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s), "render: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.bias, s), "render: ray_bias");
     {
-      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, fused ? w.partial : nullptr, (long long)n, Nf, 0.f, 0.f, g_timing_buf};
+      MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, fused ? w.partial : nullptr, (long long)n, Nf, 0.f, 0.f, g_timing_buf, nf.in_scale};
       ScopedTimer t(1, s);
       CHECK_HIP(launch_mlp(true, prec, var, a, cus, s), "render: fine MLP");
     }
@@ -708,7 +734,7 @@ extern "C" int dfn_render_rays(dfn_nerfh_t h, int prec, const float* rays_o, con
                                const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far,
                                float* rgb, float* disp, float* acc, float* raw, void* workspace, size_t workspace_bytes,
                                void* stream) {
-  if (int rc = check_net(h, prec, "dfn_render_rays")) return rc;
+  if (int rc = check_net(h, prec, "dfn_render_rays", true)) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_rays")) return rc;
   if (!rays_o || !rays_d || !hist || !rgb || !disp || !acc || !workspace || (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_render_rays: bad argument (hist_rows must be 1 or n_rays)");
@@ -728,7 +754,7 @@ extern "C" int dfn_render_rays(dfn_nerfh_t h, int prec, const float* rays_o, con
 extern "C" int dfn_render_image(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, float focal, float near,
                                 float far, int Nc, int Ni, const float* hist, float* rgb, float* disp, float* acc,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-  if (int rc = check_net(h, prec, "dfn_render_image")) return rc;
+  if (int rc = check_net(h, prec, "dfn_render_image", true)) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_image")) return rc;
   if (!c2w || !hist || !rgb || !disp || !acc || !workspace || H < 1 || W < 1 || !(focal > 0))
     return set_error(DFN_ERR_ARG, "dfn_render_image: bad argument");
@@ -818,11 +844,11 @@ int render_backward_core(dfn_nerfh_t h, int prec, const float* o, const float* d
     const float* cd = d + r0 * 3;
     const float* cv = v + r0 * 3;
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
-    MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr};
+    MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale};
     CHECK_HIP(launch_mlp(false, prec, var, ac, cus, s), "render backward: coarse MLP");
     CHECK_HIP(launch_sample_fine(w.f.sigma, n, Nc, Ni, near, far, w.f.z, nullptr, nullptr, s), "render backward: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.f.bias, s), "render backward: ray_bias");
-    MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr};
+    MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr, nf.in_scale};
     CHECK_HIP(launch_mlp(true, prec, var, af, cus, s), "render backward: fine MLP");
     CHECK_HIP(launch_composite_fine_backward(w.f.raw, w.f.z, grad_rgb + r0 * 3, n, Nf, w.graw, s), "render backward: composite");
     BwdArgs ab{nb.blob, nb.tab, nb.n_units, co, cd, cv, w.f.z, w.f.bias, w.graw, w.gpts, (long long)n, Nf};

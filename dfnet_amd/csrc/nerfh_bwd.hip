@@ -87,6 +87,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
+  st.in_scale = 1.f;
+  st.out_scale = 1.f;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;

@@ -20,6 +20,7 @@ struct MlpArgs {
   int n_samples;
   float near, far;
   unsigned long long* timing;  // DFN_TIMING builds: per-wave cycle counters [total, dma wait, barrier, tile inputs]
+  float in_scale;          // split-f16 only: weight scale x activation scale carried by the accumulators (else 1)
 };
 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream);

@@ -83,8 +83,15 @@ DFN_HD constexpr int pe_xyz_feature(int h, int s) {
 }
 
 // Per-precision fragment geometry.
-struct PrecF16 { static constexpr int kSlotsPerChunk = 8, kLaneBytes = 16; };
-struct PrecF32 { static constexpr int kSlotsPerChunk = 1, kLaneBytes = 4; };
+struct PrecF16 { static constexpr int kSlotsPerChunk = 8, kLaneBytes = 16; static constexpr bool kSplit = false; };
+struct PrecF32 { static constexpr int kSlotsPerChunk = 1, kLaneBytes = 4; static constexpr bool kSplit = false; };
+// Split-f16: every operand is hi + lo in f16 (hi = f16(x), lo = f16(x - hi)) and a product is accumulated in fp32
+// as hi*hi + hi*lo + lo*hi — three v_mfma_f32_32x32x16_f16 instead of eight v_mfma_f32_32x32x2_f32 per 16
+// contraction elements, fp32-grade results (the dropped lo*lo term is 2^-22 relative).  A fragment = 8 hi + 8 lo
+// halves per lane.  Operands are pre-scaled by powers of two (activations x kX3ActScale, weights x 2^s per
+// network) so the lo parts stay normal f16 numbers; MlpArgs::{in,out}_scale carry the product and its inverse.
+struct PrecX3 { static constexpr int kSlotsPerChunk = 8, kLaneBytes = 32; static constexpr bool kSplit = true; };
+constexpr float kX3ActScale = 16.f;
 
 // Kernel variants (nerfh_mlp.hip): workgroup width and staging granularity (M-blocks per unit).
 //   variant 0: 8 waves per workgroup, 1 workgroup per CU, a unit = a whole layer (f16) / one M-block (f32)
@@ -93,7 +100,7 @@ struct PrecF32 { static constexpr int kSlotsPerChunk = 1, kLaneBytes = 4; };
 //   variant 2: 4 waves per workgroup x 3 point blocks, 1 workgroup per CU (1 wave per SIMD, 512 VGPRs), unit as variant 0
 constexpr int kVariants = 4;
 template <class P> DFN_HD constexpr int unit_mb(int variant) {
-  return P::kSlotsPerChunk == 1 ? 1 : (variant == 1 ? 2 : 8);
+  return (P::kSlotsPerChunk == 1 || P::kSplit) ? 1 : (variant == 1 ? 2 : 8);
 }
 DFN_HD constexpr int variant_waves(int variant) { return variant == 0 ? 8 : 4; }
 

@@ -39,6 +39,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
+  st.in_scale = a.in_scale;
+  st.out_scale = 1.f / a.in_scale;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
@@ -94,6 +96,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
+  st.in_scale = a.in_scale;
+  st.out_scale = 1.f / a.in_scale;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
@@ -327,6 +331,7 @@ hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_
     if (variant == 2) return launch_one<PrecF16, true, 4, 8, 3, 1, true>(fine, a, n_cu, stream);
     return launch_one<PrecF16, true, 8, 8, 2, 1, false>(fine, a, n_cu, stream);
   }
+  if (prec == 2) return launch_one<PrecX3, false, 8, 1, 1, 1, false>(fine, a, n_cu, stream);
   if (variant == 1) return launch_one<PrecF32, false, 4, 1, 1, 1, false>(fine, a, n_cu, stream);
   return launch_one<PrecF32, false, 8, 1, 1, 1, false>(fine, a, n_cu, stream);
 }

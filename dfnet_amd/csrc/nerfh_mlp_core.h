@@ -21,7 +21,12 @@ template <class P> constexpr int chunks_of(int slots) { return slots / P::kSlots
 
 template <class P, int KC>
 DFN_DEV void set_slot(typename FragOf<P>::type (&arr)[KC], int s, float v) {
-  if constexpr (P::kSlotsPerChunk == 8) arr[s >> 3][s & 7] = (_Float16)v;
+  if constexpr (P::kSplit) {
+    _Float16 hi, lo;
+    x3_split(v, hi, lo);
+    arr[s >> 3].hi[s & 7] = hi;
+    arr[s >> 3].lo[s & 7] = lo;
+  } else if constexpr (P::kSlotsPerChunk == 8) arr[s >> 3][s & 7] = (_Float16)v;
   else arr[s] = v;
 }
 
@@ -42,6 +47,7 @@ struct Stager {
   unsigned long long* trace;
   int n_trace;
   bool more;           // another tile follows this one (wave-uniform)
+  float in_scale, out_scale;  // split-f16: accumulators carry in_scale x the true value (MlpArgs), out_scale = 1 / in_scale
 };
 
 // Direct-to-LDS DMA, issued as inline asm ON PURPOSE.  With the builtin, LLVM cannot tell which LDS bytes a DMA
@@ -173,9 +179,21 @@ DFN_DEV void mblock_mma(const char* smem, uint32_t wb, const typename FragOf<P>:
   using F = typename FragOf<P>::type;
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    const F a = *reinterpret_cast<const F*>(smem + wb + kc * 64 * P::kLaneBytes);
+    const F a = load_afrag<P>(smem + wb + kc * 64 * P::kLaneBytes);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma<P>(a, Bin[nb][kc], acc[nb]);
+  }
+}
+
+template <class P>
+DFN_DEV typename FragOf<P>::type load_afrag(const char* p) {
+  if constexpr (P::kSplit) {
+    half8x2 f;
+    f.hi = *reinterpret_cast<const half8*>(p);
+    f.lo = *reinterpret_cast<const half8*>(p + 1024);
+    return f;
+  } else {
+    return *reinterpret_cast<const typename FragOf<P>::type*>(p);
   }
 }
 
@@ -190,12 +208,24 @@ DFN_DEV f32x16 load16(const float* p) {
 
 // C fragment -> B-operand registers of the next layer (ReLU optional).
 template <class P, bool RELU, int OC>
-DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb) {
+DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, float oscale = 1.f) {
 #ifdef DFN_ABL_NOEPI  // ablation: no conversion/ReLU work (results are garbage, timing only)
   asm volatile("" ::"v"(acc));
   return;
 #endif
-  if constexpr (P::kSlotsPerChunk == 8) {
+  if constexpr (P::kSplit) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = acc[8 * c + j] * oscale;      // true value
+        if (RELU) v = fmaxf(v, 0.f);
+        _Float16 hi, lo;
+        x3_split(v, hi, lo);
+        out[2 * mb + c].hi[j] = hi;
+        out[2 * mb + c].lo[j] = lo;
+      }
+  } else if constexpr (P::kSlotsPerChunk == 8) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       half8 v;
@@ -218,7 +248,9 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
 // pure arithmetic as freely movable and sinks it out from between the MFMAs it is meant to hide behind.
 template <class P, bool RELU, int OC>
 DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, int i) {
-  if constexpr (P::kSlotsPerChunk == 8) {
+  if constexpr (P::kSplit) {
+    // split-f16 never runs the pipelined epilogue (static_assert in layer()); instantiated in dead branches only
+  } else if constexpr (P::kSlotsPerChunk == 8) {
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const int c = i >> 2, j = i & 3;
     // volatile asm = fixed position in the instruction stream (between the MFMAs it hides behind), plain
@@ -265,13 +297,14 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
                    f32x16 (&head)[NB], const float* const (&raybias)[NB], f32x16 (&carry)[NB]) {
   using F = typename FragOf<P>::type;
   constexpr int TOT = MB + (EXTRA ? 1 : 0);
-  constexpr int PF = P::kSlotsPerChunk == 8 ? DFN_PF : 4;  // fragments in flight
+  constexpr int PF = P::kSplit ? 2 : (P::kSlotsPerChunk == 8 ? DFN_PF : 4);  // fragments in flight
   constexpr uint32_t FB = 64 * P::kLaneBytes;         // bytes of one A fragment
   constexpr int PPK = (8 * NB + KC - 1) / KC;         // conversion pieces (8 per point block) interleaved per chunk
   constexpr int PPKI = CIN > 0 ? (8 * NB + CIN - 1) / CIN : 0;  // same for the carried-in M-block
   static_assert(CIN < 0 || (PIPE && P::kSlotsPerChunk == 8 && CIN > 0 && CIN + 1 < KC + 1), "carry-in needs the pipelined f16 path");
   static_assert(!COUT || (PIPE && MB >= 1 && !EXTRA), "carry-out needs a regular last M-block");
   static_assert(NEWUNIT || UMB >= TOT, "a layer that continues a unit must fit in it");
+  static_assert(!(P::kSplit && PIPE), "split-f16 runs the plain (non-pipelined) epilogue");
   const int h = st.lane >> 5;
   constexpr bool RB_ALL = RAYBIAS && NB <= 2;  // fetch all per-ray seeds at entry (latency behind the barrier)
   f32x16 rb[RB_ALL ? TOT : 1][NB];
@@ -279,7 +312,10 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
     for (int mb = 0; mb < TOT; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) rb[mb][nb] = load16(raybias[nb] + (mb * 2 + h) * 16);
+      for (int nb = 0; nb < NB; ++nb) {
+        rb[mb][nb] = load16(raybias[nb] + (mb * 2 + h) * 16);
+        if constexpr (P::kSplit) rb[mb][nb] *= st.in_scale;   // accumulators carry in_scale x the true value
+      }
   }
   f32x16 pend[PIPE ? NB : 1];  // accumulators of M-block mb-1 while M-block mb runs
 #pragma unroll
@@ -290,14 +326,15 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
     if (NEWUNIT) { ub = open_unit(st); st.ubase = ub; st.uoff = 0; }
     else ub = st.ubase + st.uoff;
     st.uoff += nmb * KC * FB + nmb * 128;
-    const char* wl = smem + ub + st.lane * P::kLaneBytes;
+    // split-f16 fragment = a hi plane (64 lanes x 16 B) followed by a lo plane: both reads stay lane-linear 16-byte
+    const char* wl = smem + ub + st.lane * (P::kSplit ? 16 : P::kLaneBytes);
     const char* bl = smem + ub + nmb * KC * FB + h * 64;
     F a[PF];
 #ifdef DFN_ABL_NOLDS
 #define DFN_AFRAG(t) a0_abl
     const F a0_abl = *reinterpret_cast<const F*>(wl);
 #else
-#define DFN_AFRAG(t) (*reinterpret_cast<const F*>(wl + (t) * FB))
+#define DFN_AFRAG(t) load_afrag<P>(wl + (t) * FB)
 #endif
 #pragma unroll
     for (int t = 0; t < PF; ++t)
@@ -319,7 +356,10 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
         f32x16 bias_next = bias;
         if (RAYBIAS) {
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[nb] = RB_ALL ? rb[RB_ALL ? mb : 0][nb] : load16(raybias[nb] + (mb * 2 + h) * 16);
+          for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = RB_ALL ? rb[RB_ALL ? mb : 0][nb] : load16(raybias[nb] + (mb * 2 + h) * 16);
+            if constexpr (P::kSplit && !RB_ALL) acc[nb] *= st.in_scale;
+          }
         }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
@@ -358,11 +398,14 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
           } else {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb);
+            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb, st.out_scale);
           }
         } else {
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) head[nb] = acc[nb];  // (the M-block before a head is converted during the head's MFMAs)
+          for (int nb = 0; nb < NB; ++nb) {  // (the M-block before a head is converted during the head's MFMAs)
+            head[nb] = acc[nb];
+            if constexpr (P::kSplit) head[nb] *= st.out_scale;
+          }
         }
       }
     }
