@@ -58,7 +58,8 @@ struct dfn_nerfh_s {
   std::map<std::string, std::vector<float>> params;
   bool committed = false;
   PackedNet net[2][3][kVariants];  // [coarse/fine][prec][kernel variant]
-  PackedNet bwd[2];                // [prec] fine forward units + backward (W^T) units of the gradient kernel
+  PackedNet bwd[3];                // [prec] fine forward units + backward (W^T) units of the gradient kernel
+                                   // (prec 2: split-f16 forward units, fp32 backward units)
   float* extra = nullptr;  // w_dir^T | b_dir | w_tr^T | b_tr | emb_a | emb_t
   RayBiasWeights rb{};
 };
@@ -310,10 +311,10 @@ struct Packer {
   }
   // Blob of the gradient kernel: the fine net's forward layers, one unit per layer (f16) / per M-block (f32),
   // then the backward layers the same way.
-  template <class P>
+  template <class PF, class P>
   void pack_bwd(std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
+    pack<PF>(true, (PF::kSlotsPerChunk == 8 && !PF::kSplit) ? 8 : 1, false, blob, tab);
     const int umb = P::kSlotsPerChunk == 8 ? 8 : 1;
-    pack<P>(true, umb, false, blob, tab);
     for (int layer = 0; layer < BW_COUNT; ++layer) {
       const LayerShape sh = bwd_layer_shape(layer);
       for (int mb0 = 0; mb0 < sh.mb; mb0 += umb) {
@@ -428,13 +429,18 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
         if (rc) return rc;
         n.n_units = int(tab.size() / 2);
       }
-  for (int prec = 0; prec < 2; ++prec) {
+  for (int prec = 0; prec < 3; ++prec) {
     Packer pk{h, "fine."};
     std::vector<uint8_t> blob;
     std::vector<uint32_t> tab;
-    if (prec == DFN_PREC_F16) pk.pack_bwd<PrecF16>(blob, tab);
-    else pk.pack_bwd<PrecF32>(blob, tab);
     PackedNet& n = h->bwd[prec];
+    if (prec == DFN_PREC_F16) pk.pack_bwd<PrecF16, PrecF16>(blob, tab);
+    else if (prec == DFN_PREC_F32) pk.pack_bwd<PrecF32, PrecF32>(blob, tab);
+    else {
+      n.in_scale = h->net[1][2][0].in_scale;   // same per-network weight scale as the split-f16 forward net
+      pk.wscale = n.in_scale / kX3ActScale;
+      pk.pack_bwd<PrecX3, PrecF32>(blob, tab);
+    }
     int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
     if (rc) return rc;
     rc = upload(tab.data(), tab.size() * 4, reinterpret_cast<void**>(&n.tab));
@@ -778,14 +784,14 @@ extern "C" int dfn_composite_fine_backward(const float* raw, const float* z, con
 extern "C" int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
                                      const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf,
                                      const float* grad_raw, float* grad_pts, void* bias_ws, void* stream) {
-  if (int rc = check_net(h, prec, "dfn_mlp_fine_backward")) return rc;
+  if (int rc = check_net(h, prec, "dfn_mlp_fine_backward", true)) return rc;
   if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !grad_raw || !grad_pts || !bias_ws || Nf < 1 ||
       (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_mlp_fine_backward: bad argument (hist_rows must be 1 or n_rays)");
   float* table = static_cast<float*>(bias_ws);
   CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine_backward(ray_bias)");
   const PackedNet& n = h->bwd[prec];
-  BwdArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, viewdirs, z_fine, table, grad_raw, grad_pts, (long long)n_rays, Nf};
+  BwdArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, viewdirs, z_fine, table, grad_raw, grad_pts, (long long)n_rays, Nf, n.in_scale};
   CHECK_HIP(launch_mlp_fine_backward(prec, a, device_cu_count(), HS(stream)), "dfn_mlp_fine_backward");
   return DFN_OK;
 }
@@ -851,7 +857,7 @@ int render_backward_core(dfn_nerfh_t h, int prec, const float* o, const float* d
     MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr, nf.in_scale};
     CHECK_HIP(launch_mlp(true, prec, var, af, cus, s), "render backward: fine MLP");
     CHECK_HIP(launch_composite_fine_backward(w.f.raw, w.f.z, grad_rgb + r0 * 3, n, Nf, w.graw, s), "render backward: composite");
-    BwdArgs ab{nb.blob, nb.tab, nb.n_units, co, cd, cv, w.f.z, w.f.bias, w.graw, w.gpts, (long long)n, Nf};
+    BwdArgs ab{nb.blob, nb.tab, nb.n_units, co, cd, cv, w.f.z, w.f.bias, w.graw, w.gpts, (long long)n, Nf, nb.in_scale};
     CHECK_HIP(launch_mlp_fine_backward(prec, ab, cus, s), "render backward: fine MLP gradient");
     CHECK_HIP(launch_ray_grad_reduce(w.gpts, w.f.z, cd, n, Nf, derive_v ? 1 : 0, go + r0 * 3, gd + r0 * 3,
                                      gv ? gv + r0 * 3 : nullptr, s),
@@ -869,7 +875,7 @@ extern "C" int dfn_render_rays_backward(dfn_nerfh_t h, int prec, const float* ra
                                         const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near,
                                         float far, const float* grad_rgb, float* grad_rays_o, float* grad_rays_d,
                                         float* grad_viewdirs, void* workspace, size_t workspace_bytes, void* stream) {
-  if (int rc = check_net(h, prec, "dfn_render_rays_backward")) return rc;
+  if (int rc = check_net(h, prec, "dfn_render_rays_backward", true)) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_rays_backward")) return rc;
   if (!rays_o || !rays_d || !hist || !grad_rgb || !grad_rays_o || !grad_rays_d || !workspace ||
       (hist_rows != 1 && hist_rows != n_rays))
@@ -890,7 +896,7 @@ extern "C" int dfn_render_rays_backward(dfn_nerfh_t h, int prec, const float* ra
 extern "C" int dfn_render_image_backward(dfn_nerfh_t h, int prec, const float* c2w, int H, int W, float focal, float near,
                                          float far, int Nc, int Ni, const float* hist, const float* grad_rgb,
                                          float* grad_c2w, void* workspace, size_t workspace_bytes, void* stream) {
-  if (int rc = check_net(h, prec, "dfn_render_image_backward")) return rc;
+  if (int rc = check_net(h, prec, "dfn_render_image_backward", true)) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_image_backward")) return rc;
   if (!c2w || !hist || !grad_rgb || !grad_c2w || !workspace || H < 1 || W < 1 || !(focal > 0))
     return set_error(DFN_ERR_ARG, "dfn_render_image_backward: bad argument");

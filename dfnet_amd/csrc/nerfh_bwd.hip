@@ -23,7 +23,8 @@ namespace dfn {
 
 template <class P, int N>
 DFN_DEV float get_slot(const typename FragOf<P>::type (&arr)[N], int s) {
-  if constexpr (P::kSlotsPerChunk == 8) return (float)arr[s >> 3][s & 7];
+  if constexpr (P::kSplit) return ((float)arr[s >> 3].hi[s & 7] + (float)arr[s >> 3].lo[s & 7]) * (1.f / kX3ActScale);
+  else if constexpr (P::kSlotsPerChunk == 8) return (float)arr[s >> 3][s & 7];
   else return arr[s];
 }
 
@@ -38,7 +39,13 @@ DFN_DEV void relu_mask(typename FragOf<P>::type (&v)[N], uint32_t (&m)[(C * P::k
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       const int e = c * S + j;
-      if constexpr (S == 8) {
+      if constexpr (P::kSplit) {
+        const _Float16 hi = v[c].hi[j], lo = v[c].lo[j];
+        const bool pos = hi > (_Float16)0 || (hi == (_Float16)0 && lo > (_Float16)0);   // hi + lo > 0
+        m[e >> 5] |= (pos ? 1u : 0u) << (e & 31);
+        v[c].hi[j] = pos ? hi : (_Float16)0;
+        v[c].lo[j] = pos ? lo : (_Float16)0;
+      } else if constexpr (S == 8) {
         const bool pos = v[c][j] > (_Float16)0;
         m[e >> 5] |= (pos ? 1u : 0u) << (e & 31);
         v[c][j] = pos ? v[c][j] : (_Float16)0;
@@ -59,6 +66,7 @@ DFN_DEV void apply_mask(typename FragOf<P>::type (&v)[N], const uint32_t (&m)[(C
     for (int j = 0; j < S; ++j) {
       const int e = c * S + j;
       const bool on = (m[e >> 5] >> (e & 31)) & 1u;
+      static_assert(!P::kSplit, "gradients are not carried in split-f16");
       if constexpr (S == 8) v[c][j] = on ? v[c][j] : (_Float16)0;
       else v[c] = on ? v[c] : 0.f;
     }
@@ -67,28 +75,38 @@ template <class P, int N>
 DFN_DEV void clear(typename FragOf<P>::type (&v)[N]) {
 #pragma unroll
   for (int c = 0; c < N; ++c) {
+    static_assert(!P::kSplit, "gradients are not carried in split-f16");
     if constexpr (P::kSlotsPerChunk == 8) v[c] = half8{0, 0, 0, 0, 0, 0, 0, 0};
     else v[c] = 0.f;
   }
 }
 
-template <class P, int UMB, int WAVES, int NB> constexpr uint32_t bwd_lds_bytes() { return 3 * bwd_max_unit_bytes<P>(); }
+template <class PF, class P> constexpr uint32_t bwd_stride() {
+  return bwd_max_unit_bytes<PF>() > bwd_max_unit_bytes<P>() ? bwd_max_unit_bytes<PF>() : bwd_max_unit_bytes<P>();
+}
+template <class PF, class P> constexpr uint32_t bwd_lds_bytes() { return 3 * bwd_stride<PF, P>(); }
 
 // A plain layer of the backward kernel: a new staging unit, no bias folding, no activation, no pipelining.
+#define DFN_FLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
+  layer<PF, UMBF, false, NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
 #define DFN_BLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
   layer<P, UMB, false, NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
 
-template <class P, bool FAST, int WAVES, int UMB, int NB>
+// PF: arithmetic of the forward recompute (activations are O(1): split-f16 is safe there), P: arithmetic of the
+// backward chain (gradient magnitudes are arbitrary: fp32, or f16 for the all-f16 mode).
+template <class PF, class P, bool FAST, int WAVES, int UMBF, int UMB, int NB>
 __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PPT = WAVES * NB * 32;
   constexpr int HC = chunks_of<P>(64), QC = chunks_of<P>(32), PC = chunks_of<P>(32), SC = chunks_of<P>(16);
+  constexpr int FHC = chunks_of<PF>(64), FQC = chunks_of<PF>(32), FPC = chunks_of<PF>(32), FSC = chunks_of<PF>(16);
   using F = typename FragOf<P>::type;
+  using FF = typename FragOf<PF>::type;
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
-  st.in_scale = 1.f;
-  st.out_scale = 1.f;
+  st.in_scale = a.in_scale;
+  st.out_scale = 1.f / a.in_scale;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
@@ -99,7 +117,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  stage_prime(st, smem, bwd_max_unit_bytes<P>());
+  stage_prime(st, smem, bwd_stride<PF, P>());
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3], g[NB][9];
@@ -125,61 +143,61 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
     uint32_t mk[8][NB][2], md[NB][1], mt[4][NB][1];
 
     // ------------------------------------------------------------------ forward (recording ReLU signs)
-    F hid[NB][HC];
+    FF hid[NB][FHC];
     {
-      F pe[NB][PC], u[NB][HC];
-      posenc_xyz<P, FAST, NB, PC>(x, h, pe);
-      DFN_BLAYER(PC, 4, false, false, pe, u, norb);
+      FF pe[NB][FPC], u[NB][FHC];
+      posenc_xyz<PF, FAST, NB, FPC>(x, h, pe);
+      DFN_FLAYER(FPC, 4, false, false, pe, u, norb);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(u[nb], mk[0][nb]);
-      DFN_BLAYER(HC, 4, false, false, u, hid, norb);
+      for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(u[nb], mk[0][nb]);
+      DFN_FLAYER(FHC, 4, false, false, u, hid, norb);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(hid[nb], mk[1][nb]);
-      DFN_BLAYER(HC, 4, false, false, hid, u, norb);
+      for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[1][nb]);
+      DFN_FLAYER(FHC, 4, false, false, hid, u, norb);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(u[nb], mk[2][nb]);
-      DFN_BLAYER(HC, 4, false, false, u, hid, norb);
+      for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(u[nb], mk[2][nb]);
+      DFN_FLAYER(FHC, 4, false, false, u, hid, norb);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(hid[nb], mk[3][nb]);
+      for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[3][nb]);
       {
-        F cat[NB][PC + HC];
+        FF cat[NB][FPC + FHC];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-          for (int i = 0; i < PC; ++i) cat[nb][i] = pe[nb][i];
+          for (int i = 0; i < FPC; ++i) cat[nb][i] = pe[nb][i];
 #pragma unroll
-          for (int i = 0; i < HC; ++i) cat[nb][PC + i] = hid[nb][i];
+          for (int i = 0; i < FHC; ++i) cat[nb][FPC + i] = hid[nb][i];
         }
-        DFN_BLAYER(PC + HC, 4, false, false, cat, u, norb);
+        DFN_FLAYER(FPC + FHC, 4, false, false, cat, u, norb);
       }
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(u[nb], mk[4][nb]);
-      DFN_BLAYER(HC, 4, false, false, u, hid, norb);
+      for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(u[nb], mk[4][nb]);
+      DFN_FLAYER(FHC, 4, false, false, u, hid, norb);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(hid[nb], mk[5][nb]);
-      DFN_BLAYER(HC, 4, false, false, hid, u, norb);
+      for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[5][nb]);
+      DFN_FLAYER(FHC, 4, false, false, hid, u, norb);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(u[nb], mk[6][nb]);
-      DFN_BLAYER(HC, 4, false, false, u, hid, norb);
+      for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(u[nb], mk[6][nb]);
+      DFN_FLAYER(FHC, 4, false, false, u, hid, norb);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) relu_mask<P, HC>(hid[nb], mk[7][nb]);
+      for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[7][nb]);
     }
     // heads; their pre-activation gradients seed the backward pass
     F dth[NB][SC], drgb[NB][SC], dsig[NB][SC];
     {
-      F fin[NB][HC], dummy[NB][SC];
-      DFN_BLAYER(HC, 4, true, false, hid, fin, norb);   // xyz_encoding_final + static_sigma (5th M-block)
+      FF fin[NB][FHC], dummy[NB][FSC];
+      DFN_FLAYER(FHC, 4, true, false, hid, fin, norb);   // xyz_encoding_final + static_sigma (5th M-block)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         clear<P>(dsig[nb]);
         set_slot<P>(dsig[nb], 0, h == 0 ? g[nb][3] * act_sigmoid<FAST>(head[nb][0]) : 0.f);  // softplus' = sigmoid
       }
       {
-        F de[NB][QC];
-        DFN_BLAYER(HC, 2, false, true, fin, de, rb_dir);
+        FF de[NB][FQC];
+        DFN_FLAYER(FHC, 2, false, true, fin, de, rb_dir);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(de[nb], md[nb]);
-        DFN_BLAYER(QC, 0, true, false, de, dummy, norb);  // static_rgb
+        for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(de[nb], md[nb]);
+        DFN_FLAYER(FQC, 0, true, false, de, dummy, norb);  // static_rgb
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           clear<P>(drgb[nb]);
@@ -191,20 +209,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
         }
       }
       {
-        F t0[NB][QC], t1[NB][QC];
-        DFN_BLAYER(HC, 2, false, true, fin, t0, rb_tr);
+        FF t0[NB][FQC], t1[NB][FQC];
+        DFN_FLAYER(FHC, 2, false, true, fin, t0, rb_tr);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(t0[nb], mt[0][nb]);
-        DFN_BLAYER(QC, 2, false, false, t0, t1, norb);
+        for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(t0[nb], mt[0][nb]);
+        DFN_FLAYER(FQC, 2, false, false, t0, t1, norb);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(t1[nb], mt[1][nb]);
-        DFN_BLAYER(QC, 2, false, false, t1, t0, norb);
+        for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(t1[nb], mt[1][nb]);
+        DFN_FLAYER(FQC, 2, false, false, t1, t0, norb);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(t0[nb], mt[2][nb]);
-        DFN_BLAYER(QC, 2, false, false, t0, t1, norb);
+        for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(t0[nb], mt[2][nb]);
+        DFN_FLAYER(FQC, 2, false, false, t0, t1, norb);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) relu_mask<P, QC>(t1[nb], mt[3][nb]);
-        DFN_BLAYER(QC, 0, true, false, t1, dummy, norb);  // transient heads: rows 0..2 rgb, 3 sigma, 8 beta (C reg 4)
+        for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(t1[nb], mt[3][nb]);
+        DFN_FLAYER(FQC, 0, true, false, t1, dummy, norb);  // transient heads: rows 0..2 rgb, 3 sigma, 8 beta (C reg 4)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           clear<P>(dth[nb]);
@@ -294,8 +312,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
           x2[nb][c] = x[nb][c];
           asm volatile("" : "+v"(x2[nb][c]));  // recompute sin/cos here instead of keeping 32 slots alive
         }
-      F pe[NB][PC];
-      posenc_xyz<P, FAST, NB, PC>(x2, h, pe);
+      FF pe[NB][FPC];
+      posenc_xyz<PF, FAST, NB, FPC>(x2, h, pe);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -304,8 +322,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
             const float f = float(1 << k) * (h ? 32.f : 1.f);
-            acc += f * (get_slot<P>(pe[nb], 6 * k + 3 + c) * get_slot<P>(dpe[nb], 6 * k + c) -
-                        get_slot<P>(pe[nb], 6 * k + c) * get_slot<P>(dpe[nb], 6 * k + 3 + c));
+            acc += f * (get_slot<PF>(pe[nb], 6 * k + 3 + c) * get_slot<P>(dpe[nb], 6 * k + c) -
+                        get_slot<PF>(pe[nb], 6 * k + c) * get_slot<P>(dpe[nb], 6 * k + 3 + c));
           }
           gx[nb][c] = acc;
         }
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   }
 }
 
-template <class P, bool FAST, int WAVES, int UMB, int NB>
+template <class PF, class P, bool FAST, int WAVES, int UMBF, int UMB, int NB>
 static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream) {
   constexpr int PPT = WAVES * NB * 32;
   const long long n_pts = (long long)a.n_rays * a.n_samples;
@@ -369,8 +387,8 @@ static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream)
   if (n_pts >= (1LL << 31)) return hipErrorInvalidValue;
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   const int grid = int(n_tiles < n_cu ? n_tiles : n_cu);
-  const uint32_t lds = bwd_lds_bytes<P, UMB, WAVES, NB>();
-  auto kern = nerfh_fine_backward_kernel<P, FAST, WAVES, UMB, NB>;
+  const uint32_t lds = bwd_lds_bytes<PF, P>();
+  auto kern = nerfh_fine_backward_kernel<PF, P, FAST, WAVES, UMBF, UMB, NB>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -382,8 +400,9 @@ static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream)
 }
 
 hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream) {
-  if (prec == 0) return launch_bwd_one<PrecF16, true, 4, 8, 1>(a, n_cu, stream);
-  return launch_bwd_one<PrecF32, false, 4, 1, 1>(a, n_cu, stream);
+  if (prec == 0) return launch_bwd_one<PrecF16, PrecF16, true, 4, 8, 8, 1>(a, n_cu, stream);
+  if (prec == 2) return launch_bwd_one<PrecX3, PrecF32, false, 4, 1, 1, 1>(a, n_cu, stream);  // split-f16 forward, fp32 gradients
+  return launch_bwd_one<PrecF32, PrecF32, false, 4, 1, 1, 1>(a, n_cu, stream);
 }
 
 }  // namespace dfn

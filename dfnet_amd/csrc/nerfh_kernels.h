@@ -71,6 +71,7 @@ struct BwdArgs {
   float* gpts;             // [n_rays, n_samples, 6]  d L / d point (3), d L / d viewdir via this sample (3)
   long long n_rays;
   int n_samples;
+  float in_scale;          // split-f16 forward units: scale carried by the accumulators (else 1)
 };
 hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream);
 // d L / d raw from d L / d rgb through the fine compositing (test-time, rgb only).

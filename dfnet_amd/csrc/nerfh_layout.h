@@ -163,8 +163,9 @@ DFN_HD constexpr int pe_dir_feature(int h, int r) {
 // Staging buffer of the backward kernel: its largest unit is BW_L5 (6 M-blocks x 64 slots) / L5 forward.
 template <class P>
 DFN_HD constexpr uint32_t bwd_max_unit_bytes() {
-  const uint32_t a = unit_bytes<P>(96, P::kSlotsPerChunk == 8 ? 4 : 1);  // forward layer 5, whole (no merged layout here)
-  const uint32_t b = unit_bytes<P>(64, P::kSlotsPerChunk == 8 ? 6 : 1), c = unit_bytes<P>(80, P::kSlotsPerChunk == 8 ? 4 : 1);
+  constexpr bool whole = P::kSlotsPerChunk == 8 && !P::kSplit;  // f16: a unit is a whole layer; f32 / split-f16: one M-block
+  const uint32_t a = unit_bytes<P>(96, whole ? 4 : 1);  // forward layer 5, whole (no merged layout here)
+  const uint32_t b = unit_bytes<P>(64, whole ? 6 : 1), c = unit_bytes<P>(80, whole ? 4 : 1);
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 

@@ -51,12 +51,17 @@ for mode, fp in (("fp32 forward state", "f32"), ("f16 forward state", None)):
 ga, gb = results["fp32 forward state"]["grad_pose"], results["f16 forward state"]["grad_pose"]
 mixed_rel = float((ga - gb).abs().max() / ga.abs().max())
 rendering.GRAD_FORWARD_PRECISION = None
+for gp in ("f32", "f16x3"):
+    rendering.GRAD_PRECISION = gp
+    ms, o = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
+    results["grad kernel " + gp] = {"ms": ms, "rel": float((o["grad_pose"].cpu() - ga).abs().max() / ga.abs().max())}
 fwd_ms, _ = timed(lambda: matching_step_forward(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
 step_ms, out = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
 print(json.dumps({"workload": f"DFNet_dm step, batch {B}, 240x320, render 60x80 @64+128 + bicubic x4, level-0 feature loss",
                   "forward_ms": fwd_ms, "forward_backward_to_pose_ms": step_ms, "ms_per_frame": step_ms / B,
                   "loss": float(out["loss"]), "grad_pose_absmax": float(out["grad_pose"].abs().max()),
+                  "grad_kernel_modes": {k: v for k, v in results.items() if k.startswith("grad kernel")},
                   "all_fp32_tracked_forward_ms": results["fp32 forward state"]["forward_backward_to_pose_ms"],
                   "grad_pose_rel_diff_vs_all_fp32": mixed_rel,
-                  "render_precision": "forward f16 (tracked and untracked); MLP gradient kernel f32",
+                  "render_precision": "forward f16 (tracked and untracked); MLP gradient kernel f16x3 forward recompute + fp32 gradient chain",
                   "dfnet_precision": "f16x3 forward / f32 gradient convs"}))
