@@ -99,7 +99,8 @@ DFN_DEV void stage_issue(const Stager& st, char* smem, int unit, uint32_t lds_of
 // What the ablations say about the remaining cost of streaming (fine kernel, one run): no barrier +4 %, no DMA
 // +21 %, same DMA instructions with a quarter of the bytes +19 %, half the pieces +16 %, every piece from one
 // cached KiB +2 %; staggering the two waves of a SIMD, or staging through VGPRs + ds_write_b128 instead of the
-// DMA: no gain / -2.5 %.  The cost follows the BYTES landing in LDS, not instructions, waits or L2.
+// DMA: no gain / -2.5 %.  The cost follows the BYTES landing in LDS, not instructions, waits or L2; a third of
+// it is shader cycles, two thirds is clock (the traffic is paid in power: DESIGN.md section 3.1).
 DFN_DEV void stage_prime(Stager& st, char* smem, uint32_t unit_stride) {
   st.lds_cur = 0; st.lds_nxt = unit_stride; st.lds_nn = 2 * unit_stride;
   st.u = 0;
@@ -173,6 +174,9 @@ DFN_DEV void mid_sync(Stager& st, char* smem) {
 // ------------------------------------------------------------------------------------------
 // One 32-row M-block: acc[nb] += W_mb * Bin[nb] over KC chunks.  `wb` = LDS byte offset of the
 // block's first A fragment, already including lane * kLaneBytes.
+template <class P>
+DFN_DEV typename FragOf<P>::type load_afrag(const char* p);
+
 template <class P, int NB, int KC>
 DFN_DEV void mblock_mma(const char* smem, uint32_t wb, const typename FragOf<P>::type (&Bin)[NB][KC],
                         f32x16 (&acc)[NB]) {

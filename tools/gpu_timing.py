@@ -3,7 +3,7 @@
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["DFN_LIB_PATH"] = os.path.join(ROOT, "dfnet_amd", "libdfnet_hip_timing.so")
+os.environ["DFN_LIB_PATH"] = os.environ.get("TIMING_LIB") or os.path.join(ROOT, "dfnet_amd", "libdfnet_hip_timing.so")
 sys.path.insert(0, ROOT)
 from dfnet_amd import _lib, engine as eng, synthetic as syn
 lib = _lib.load()
