@@ -577,6 +577,7 @@ extern "C" int dfn_posenc(const float* x, size_t n, int L, int mode, float* out,
 extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, size_t n_rays,
                               int Nc, float near, float far, float* sigma, void* stream) {
   if (int rc = check_net(h, prec, "dfn_mlp_coarse", true)) return rc;
+  if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !sigma || Nc < 1) return set_error(DFN_ERR_ARG, "dfn_mlp_coarse: bad argument");
   const PackedNet& n = h->net[0][prec][mlp_variant()];
   MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr, n.in_scale};
@@ -628,6 +629,7 @@ extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const 
                             const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf,
                             float* raw, void* bias_ws, void* stream) {
   if (int rc = check_net(h, prec, "dfn_mlp_fine", true)) return rc;
+  if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !raw || !bias_ws || Nf < 1 ||
       (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_mlp_fine: bad argument (hist_rows must be 1 or n_rays)");
@@ -742,6 +744,7 @@ extern "C" int dfn_render_rays(dfn_nerfh_t h, int prec, const float* rays_o, con
                                void* stream) {
   if (int rc = check_net(h, prec, "dfn_render_rays", true)) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_rays")) return rc;
+  if (!n_rays) return DFN_OK;  // an empty batch is valid (its buffers may be null)
   if (!rays_o || !rays_d || !hist || !rgb || !disp || !acc || !workspace || (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_render_rays: bad argument (hist_rows must be 1 or n_rays)");
   if (!n_rays) return DFN_OK;
@@ -785,6 +788,7 @@ extern "C" int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_
                                      const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf,
                                      const float* grad_raw, float* grad_pts, void* bias_ws, void* stream) {
   if (int rc = check_net(h, prec, "dfn_mlp_fine_backward", true)) return rc;
+  if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !grad_raw || !grad_pts || !bias_ws || Nf < 1 ||
       (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_mlp_fine_backward: bad argument (hist_rows must be 1 or n_rays)");
@@ -877,6 +881,7 @@ extern "C" int dfn_render_rays_backward(dfn_nerfh_t h, int prec, const float* ra
                                         float* grad_viewdirs, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_net(h, prec, "dfn_render_rays_backward", true)) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_rays_backward")) return rc;
+  if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !hist || !grad_rgb || !grad_rays_o || !grad_rays_d || !workspace ||
       (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_render_rays_backward: bad argument (hist_rows must be 1 or n_rays)");

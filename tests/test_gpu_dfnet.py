@@ -166,3 +166,21 @@ def test_dm_step_forward_vs_oracle():
     assert abs(float(out["feat_loss"]) - float(fl)) < 2e-4 * max(1.0, abs(float(fl)))
     assert abs(float(out["photo_loss"]) - float(photo)) < 1e-4
     assert abs(float(out["loss"]) - float(want)) < 5e-4 * max(1.0, abs(float(want)))
+
+
+def test_dfnet_limits(net):
+    """Smallest supported image (32x32: one pixel after four pools), argument errors, and batch invariance."""
+    E, p = net
+    x = torch.rand(3, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        ref, rpose = dor.dfnet_forward(p, x, True, True, True, 32, 32)
+    got, pose = E.forward(x.to(DEV), True, True, True, 32, 32)
+    for lvl in range(3):
+        assert relmax(got[lvl], ref[0][lvl]) < 2e-5
+    assert relmax(pose, rpose) < 2e-5
+    one, _ = E.forward(x[1:2].to(DEV), True, True, False, 32, 32)
+    assert torch.equal(one[:, 0], got[:, 1])                       # images are independent: same bits alone or in a batch
+    with pytest.raises(Exception, match="32"):
+        E.forward(torch.rand(1, 3, 16, 64, device=DEV), True, True, False, 16, 64)
+    with pytest.raises(Exception, match="even batch"):
+        E.forward(x.to(DEV), True, False, False, 32, 32)           # siamese needs an even batch

@@ -292,6 +292,36 @@ def test_bad_arguments_raise(scene):
         E.render_rays(o, o, torch.zeros(3, 10, device=DEV), 8, 8, 0., 1.)
 
 
+def test_empty_and_extreme_inputs(scene):
+    """No rays, one ray, the largest supported sample count (N_samples + N_importance = 512), and a ray batch that
+    spans several internal passes (> 65 536 rays) with per-ray histograms."""
+    E, c, f, ea, et = scene
+    hist = dev(syn.HIST_IDX)
+    z = torch.zeros(0, 3, device=DEV)
+    rgb, disp, acc, raw = E.render_rays(z, z, hist, 8, 16, 0., 2.5, retraw=True)
+    assert rgb.shape == (0, 3) and disp.shape == (0,) and raw.shape == (0, 24, 9)
+    go, gd, _ = E.render_rays_backward(z, z, hist, 8, 16, 0., 2.5, z)
+    assert go.shape == (0, 3) and gd.shape == (0, 3)
+    o, d, _ = eng.raygen(1, 1, 1.0, T(syn.orbit_pose(0, 8)).to(DEV))
+    one = E.render_rays(o.reshape(1, 3), d.reshape(1, 3), hist, 128, 384, 0., 2.5, precision="f32")
+    rows = orc.pack_ray_rows(o.reshape(1, 3).cpu(), d.reshape(1, 3).cpu(), 0., 2.5, syn.HIST_IDX)
+    with torch.no_grad():
+        ref = orc.render_rays(rows, c, f, ea, et, 128, 384)
+    assert relmax(one[0], ref["rgb_map"]) < 2e-5 and relmax(one[1], ref["disp_map"]) < 2e-5
+    with pytest.raises(Exception, match="512"):
+        E.render_rays(o.reshape(1, 3), d.reshape(1, 3), hist, 128, 385, 0., 2.5)
+    # 70 000 rays = two internal passes; histogram row per ray; the first and last rays equal a 2-ray render of themselves
+    n = 70000
+    oo, dd, _ = eng.raygen(250, 280, 300.0, T(syn.orbit_pose(4, 8)).to(DEV))
+    oo, dd = oo.reshape(-1, 3), dd.reshape(-1, 3)
+    hrows = hist[None].repeat(n, 1).contiguous()
+    hrows[::2, 3] = 7.
+    big = E.render_rays(oo, dd, hrows, 16, 48, 0., 2.5)
+    pick = torch.tensor([0, 1, 65535, 65536, n - 1], device=DEV)
+    small = E.render_rays(oo[pick], dd[pick], hrows[pick], 16, 48, 0., 2.5)
+    assert torch.equal(big[0][pick], small[0]) and torch.equal(big[2][pick], small[2])
+
+
 def test_bicubic_upsample_vs_torch():
     """dfn_upsample_bicubic == nn.Upsample(size, mode='bicubic') (the tinyimg x4 path, misc.py:230-237)."""
     g = torch.Generator().manual_seed(3)
