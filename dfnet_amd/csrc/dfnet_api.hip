@@ -545,3 +545,114 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
   }
   return DFN_OK;
 }
+
+// ------------------------------------------------------------------------------------------ parameter gradients (pose path)
+namespace {
+constexpr size_t kWgradPartFloats = size_t(2048) * 9 * 1024;   // partial sums of launch_conv_wgrad (75.5 MB)
+struct DfParamWs {
+  DfBwdWs b;
+  float *part, *pooled;
+  size_t total;
+};
+DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
+  DfParamWs w{};
+  w.b = carve_df_bwd(h, base, prec, B, H, W);
+  size_t off = w.b.total;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return reinterpret_cast<float*>(p); };
+  w.part = take(kWgradPartFloats * 4);
+  w.pooled = take(size_t(B) * 512 * 4);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t dfn_dfnet_backward_params_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W) {
+  if (!h || B < 1 || H < 1 || W < 1) return 0;
+  return carve_df_params(h, nullptr, prec, B, H, W).total;
+}
+
+extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
+                                         float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: null handle");
+  if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_backward_params: dfn_dfnet_commit() has not been called");
+  if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
+    return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_backward_params: parameter gradients need fp32 activations (precision F32 or F16X3)");
+  const int n_enc = int(h->enc.size());
+  if (!x || !grad_pose || !grads || !workspace || B < 1 || H < 32 || W < 32 || n_grads != 2 * n_enc + 2)
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: bad argument (grads = %d pointers: weight, bias per encoder conv, then fc_pose)",
+                     2 * n_enc + 2);
+  for (int i = 0; i < n_grads; ++i)
+    if (!grads[i]) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: null gradient pointer %d", i);
+  const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
+  if (pw.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: workspace too small (%zu < %zu)", workspace_bytes, pw.total);
+  const DfBwdWs& w = pw.b;
+  hipStream_t s = HS(stream);
+  // ---- forward, keeping every activation (feature/dfnet.py:121-136 with return_pose=True)
+  CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet params: prep");
+  const void* cur = w.prep;
+  int ch = H, cw = W, nblk = 1;
+  int lay_h[13], lay_w[13];
+  for (int i = 0; i < n_enc; ++i) {
+    const ConvSpec& sp = h->enc[i];
+    lay_h[i] = ch; lay_w[i] = cw;
+    ConvArgs a{};
+    a.in = cur; a.w = h->enc_packed[i].w[prec]; a.bias = prec == 2 ? h->enc_packed[i].bias_x3 : h->enc_packed[i].bias;
+    a.out_scale = h->enc_packed[i].out_scale;
+    a.out_act = w.act[i];
+    a.B = B; a.H = ch; a.W = cw; a.nblk_in = nblk; a.cout_blocks = sp.cout / 32; a.relu = 1;
+    CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet params: encoder conv");
+    cur = w.act[i];
+    nblk = sp.cout / 32;
+    if (sp.pool_after && i + 1 < n_enc) {
+      CHECK_HIP(launch_maxpool(prec, cur, B, ch, cw, nblk, w.pooled, s), "dfnet params: maxpool");
+      cur = w.pooled;
+      ch /= 2; cw /= 2;
+    }
+  }
+  if (lay_h[n_enc - 1] < 2 || lay_w[n_enc - 1] < 2) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: image too small for pool5");
+  // ---- pose head: fc gradients, gradient w.r.t. relu5_3
+  char* gbuf[2] = {w.gA, w.gB};
+  CHECK_HIP(launch_pose_head_backward(reinterpret_cast<const float*>(w.act[n_enc - 1]), B, lay_h[n_enc - 1], lay_w[n_enc - 1], h->fc,
+                                      grad_pose, h->feat_dim, pw.pooled, reinterpret_cast<float*>(gbuf[0]), grads[2 * n_enc],
+                                      grads[2 * n_enc + 1], s),
+            "dfnet params: pose head");
+  int act_idx = 0;
+  // ---- encoder, last conv first
+  for (int i = n_enc - 1; i >= 0; --i) {
+    const ConvSpec& sp = h->enc[i];
+    const int hh = lay_h[i], ww = lay_w[i];
+    const int pre_idx = act_idx, in_idx = pre_idx ^ 1;
+    CHECK_HIP(launch_relu_gate(1, gbuf[act_idx], w.act[i], nullptr, size_t(B) * hh * ww * sp.cout, gbuf[pre_idx], s), "dfnet params: relu gate");
+    const float* g_pre = reinterpret_cast<const float*>(gbuf[pre_idx]);
+    CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, grads[2 * i + 1], s), "dfnet params: bias gradient");
+    if (i == 0) {
+      CHECK_HIP(launch_conv0_wgrad(g_pre, reinterpret_cast<const float*>(w.prep), B, hh, ww, 2 * prep_sb(prec), pw.part, kWgradPartFloats,
+                                   grads[0], s),
+                "dfnet params: conv1_1 weight gradient");
+      break;
+    }
+    const void* input = w.act[i - 1];
+    if (h->enc[i - 1].pool_after) {
+      CHECK_HIP(launch_maxpool(prec, w.act[i - 1], B, lay_h[i - 1], lay_w[i - 1], h->enc[i - 1].cout / 32, w.pooled, s),
+                "dfnet params: maxpool (conv input)");
+      input = w.pooled;
+    }
+    CHECK_HIP(launch_conv_wgrad(3, g_pre, reinterpret_cast<const float*>(input), B, hh, ww, sp.cout, sp.cin, pw.part, kWgradPartFloats,
+                                grads[2 * i], s),
+              "dfnet params: conv weight gradient");
+    ConvArgs e{};
+    e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[1]; e.bias = h->enc_dgrad[i].bias; e.out_scale = 1.f; e.out_pre = gbuf[in_idx];
+    e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = ((sp.cin + 63) / 64 * 64) / 32; e.relu = 0;
+    CHECK_HIP(launch_conv(1, 3, 16, e, s), "dfnet params: encoder conv dgrad");
+    if (h->enc[i - 1].pool_after) {
+      CHECK_HIP(launch_maxpool_backward(1, w.act[i - 1], gbuf[in_idx], B, lay_h[i - 1], lay_w[i - 1], h->enc[i - 1].cout / 32,
+                                        gbuf[pre_idx], s),
+                "dfnet params: maxpool backward");
+      act_idx = pre_idx;
+    } else {
+      act_idx = in_idx;
+    }
+  }
+  return DFN_OK;
+}

@@ -59,4 +59,18 @@ hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, 
 // adjoint of launch_dfnet_prep: blocked gradient (RGB = first three elements of a pixel) -> d L/d x [B,3,H,W] fp32.
 hipError_t launch_unprep(int prec, const void* g, int B, int H, int W, int nblk, float* gx, hipStream_t s);
 
+
+// --- parameter gradients of the pose-regression path (dfnet_wgrad.hip); fp32 blocked activations
+// dW[cout][cin][ks][ks] of a stride-1 "same" conv from g (gradient w.r.t. its pre-activation) and its input;
+// `part` is scratch of part_floats floats.  cin, cout multiples of 32; ks 1 or 3.
+hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int H, int W, int cout, int cin, float* part,
+                             size_t part_floats, float* dW, hipStream_t s);
+// conv1_1: input = the prep output (pix_stride floats per pixel, RGB first), g has 64 channels; dW [64][3][3][3].
+hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int W, int pix_stride, float* part, size_t part_floats,
+                              float* dW, hipStream_t s);
+hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* db, hipStream_t s);
+// pose head: relu5_3 activations + d pose -> pooled [B,512] (scratch), gradient w.r.t. the activations, fc gradients.
+hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
+                                     float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s);
+
 }  // namespace dfn

@@ -1,0 +1,257 @@
+// dfnet_wgrad.hip — parameter gradients of DFNet's pose-regression path (gfx950): what loss.backward() leaves in
+// model.parameters() of the pose regressor in the DFNet_dm step (/root/reference/script/feature/
+// direct_feature_matching.py:372-374, optimizer over `model`; feature/dfnet.py:121-170 is the forward being
+// differentiated: VGG16 convs + ReLU + max-pools, pool5 -> AdaptiveAvgPool2d(1) -> fc_pose).
+//
+// The data gradients reuse the forward MFMA convolution on flipped / transposed weights (dfnet_api.hip:
+// pack_dgrad); here are the pieces that produce PARAMETER gradients:
+//   * conv weight gradient   dW[co][ci][ky][kx] = sum_pixels g[p][co] * in[p + (ky-1, kx-1)][ci]
+//     as an fp32 MFMA product (v_mfma_f32_32x32x2_f32): M = 32 output channels, N = 32 input channels, the
+//     contraction runs over PIXELS, two per MFMA.  In the blocked-permuted NHWC layout the 32 channels of a pixel
+//     are contiguous, so both operands are plain coalesced 128-byte loads — no transpose, no LDS staging: lane
+//     (c, k) of the A operand reads channel position c of pixel 2t + k of g, lane (c, k) of B the same of the
+//     shifted input pixel.  One wave keeps the nine taps' accumulators (144 VGPRs) and re-uses the g fragment for
+//     all of them.  Pixel chunks are summed in a fixed order by a second kernel (deterministic), which also
+//     un-permutes into the state_dict layout.
+//   * conv1_1 (3 input channels) and the bias gradients: small reduction kernels.
+//   * the pose head: fc_pose gradients, GAP + pool5 routing back to relu5_3.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dfnet_kernels.h"
+#include "mfma_frag.h"
+
+namespace dfn {
+
+// true channel (within a 32-block) held at stored position e
+__device__ __forceinline__ int chan_of_pos(int e) { return 4 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2); }
+
+// ------------------------------------------------------------------------------------------ conv weight gradient
+// g   [B,H,W,MBLK,32]  gradient w.r.t. the conv's pre-activation (fp32, blocked)
+// in  [B,H,W,NBLK,32]  the conv's input (fp32, blocked)
+// part[chunk][mblk][nblk][KS*KS][32 (co position)][32 (ci position)]  partial sums
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ in, int B, int H,
+                                                            int W, int mblks, int nblks, int n_chunks, float* __restrict__ part) {
+  constexpr int T = KS * KS, R = KS / 2;
+  __shared__ float red[3][16][64];      // waves 1..3 hand their accumulators to wave 0, one tap at a time
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, k = lane >> 5;
+  const int pair = blockIdx.x, chunk = blockIdx.y;
+  const int mblk = pair / nblks, nblk = pair - mblk * nblks;
+  const long long Q = (long long)B * H * W;
+  // this workgroup's pixels: [q0, q1), split evenly over the four waves, each wave walks pixel pairs
+  const long long per = (Q + n_chunks - 1) / n_chunks;
+  const long long q0 = chunk * per, q1 = q0 + per < Q ? q0 + per : Q;
+  const long long wper = ((q1 - q0 + 3) / 4 + 1) & ~1LL;   // even, so pairs never straddle two waves' ranges
+  const long long w0 = q0 + wave * wper, w1 = w0 + wper < q1 ? w0 + wper : q1;
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (long long q = w0 + k; q < w1 + k; q += 2) {   // every lane of the wave runs the same number of iterations
+    const bool live = q < w1;
+    const long long qq = live ? q : w0;
+    const int x = int(qq % W);
+    const long long rr = qq / W;
+    const int y = int(rr % H);
+    const long long b = rr / H;
+    const float a = live ? g[(qq * mblks + mblk) * 32 + c] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int yy = y + ky - R, xx = x + kx - R;
+        const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float bv = ok ? in[(((b * H + yy) * (long long)W + xx) * nblks + nblk) * 32 + c] : 0.f;
+        acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * KS + kx], 0, 0, 0);
+      }
+  }
+  // reduce the four waves (fixed order), tap by tap, then one plain store per partial
+  float* dst = part + (((size_t)chunk * mblks + mblk) * nblks + nblk) * T * 1024;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = ((acc[t][r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * k;   // row of the C fragment = co position
+        dst[(t * 32 + i) * 32 + c] = v;                   // column = lane & 31 = ci position
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Sum the chunks in order and write dW[co][ci][ky][kx] (state_dict layout), un-permuting the channel positions.
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ part, int mblks, int nblks, int T, int n_chunks,
+                                                             int cout, int cin, float* __restrict__ dW) {
+  const size_t n = (size_t)mblks * nblks * T * 1024;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int ch = 0; ch < n_chunks; ++ch) s += part[(size_t)ch * n + i];
+    const int cj = int(i & 31), ci_ = int((i >> 5) & 31);
+    size_t r = i >> 10;
+    const int t = int(r % T); r /= T;
+    const int nblk = int(r % nblks), mblk = int(r / nblks);
+    const int co = 32 * mblk + chan_of_pos(ci_), ci = 32 * nblk + chan_of_pos(cj);
+    if (co < cout && ci < cin) dW[((size_t)co * cin + ci) * T + t] = s;
+  }
+}
+
+hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int H, int W, int cout, int cin, float* part,
+                             size_t part_floats, float* dW, hipStream_t s) {
+  const int mblks = cout / 32, nblks = cin / 32, T = ks * ks;
+  if (cout % 32 || cin % 32 || (ks != 1 && ks != 3)) return hipErrorInvalidValue;
+  const long long Q = (long long)B * H * W;
+  const int pairs = mblks * nblks;
+  long long n_chunks = 2048 / pairs;                      // ~2048 workgroups
+  const long long max_by_work = (Q + 1023) / 1024;        // at least ~1024 pixels per workgroup
+  if (n_chunks > max_by_work) n_chunks = max_by_work;
+  if (n_chunks < 1) n_chunks = 1;
+  while (n_chunks > 1 && (size_t)n_chunks * pairs * T * 1024 > part_floats) --n_chunks;
+  if ((size_t)n_chunks * pairs * T * 1024 > part_floats) return hipErrorInvalidValue;
+  const dim3 grid(pairs, int(n_chunks));
+  if (ks == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), part);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), part);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const size_t n = (size_t)pairs * T * 1024;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(int((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, part, mblks,
+                     nblks, T, int(n_chunks), cout, cin, dW);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ conv1_1 (3 input channels)
+// x_norm: the prep output [B,H,W,2*SB] (RGB = elements 0..2).  dW[co][c][ky][kx], co < 64.  One workgroup per pixel
+// chunk, thread = (co, 4 pixel lanes); partials [chunk][64][27] then a fixed-order sum.
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ xn, int B, int H, int W,
+                                                          int pix_stride, int n_chunks, float* __restrict__ part) {
+  __shared__ float red[4][64][27];
+  const int pos = threadIdx.x & 63, pl = threadIdx.x >> 6;   // stored channel position of g (64 = 2 blocks), pixel lane
+  const long long Q = (long long)B * H * W, per = (Q + n_chunks - 1) / n_chunks;
+  const long long q0 = blockIdx.x * per, q1 = q0 + per < Q ? q0 + per : Q;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  for (long long q = q0 + pl; q < q1; q += 4) {
+    const int x = int(q % W);
+    const long long rr = q / W;
+    const int y = int(rr % H);
+    const long long b = rr / H;
+    const float gv = g[q * 64 + pos];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const float* px = xn + ((b * H + yy) * (long long)W + xx) * pix_stride;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[c * 9 + ky * 3 + kx] += gv * px[c];
+        }
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) red[pl][pos][t] = acc[t];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 27; i += 256) {
+    const int p = i / 27, t = i - p * 27;
+    part[((size_t)blockIdx.x * 64 + p) * 27 + t] = ((red[0][p][t] + red[1][p][t]) + red[2][p][t]) + red[3][p][t];
+  }
+}
+__global__ __launch_bounds__(256) void conv0_finalize_kernel(const float* __restrict__ part, int n_chunks, float* __restrict__ dW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 27) return;
+  float s = 0.f;
+  for (int ch = 0; ch < n_chunks; ++ch) s += part[(size_t)ch * 64 * 27 + i];
+  const int p = i / 27, t = i - p * 27;
+  const int co = 32 * (p >> 5) + chan_of_pos(p & 31);
+  dW[co * 27 + t] = s;   // [co][c][ky][kx]
+}
+hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int W, int pix_stride, float* part, size_t part_floats,
+                              float* dW, hipStream_t s) {
+  const long long Q = (long long)B * H * W;
+  long long n_chunks = (Q + 511) / 512;
+  if (n_chunks > 1024) n_chunks = 1024;
+  if ((size_t)n_chunks * 64 * 27 > part_floats) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(int(n_chunks)), dim3(256), 0, s, g, xn, B, H, W, pix_stride, int(n_chunks), part);
+  hipLaunchKernelGGL(conv0_finalize_kernel, dim3((64 * 27 + 255) / 256), dim3(256), 0, s, part, int(n_chunks), dW);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ bias gradient
+// db[co] = sum over pixels of g[p][co].  One workgroup per 32-channel block: 8 pixel lanes x 32 positions.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, long long Q, int blks, int cout, float* __restrict__ db) {
+  __shared__ float red[8][32];
+  const int pos = threadIdx.x & 31, pl = threadIdx.x >> 5, blk = blockIdx.x;
+  float s = 0.f;
+  for (long long q = pl; q < Q; q += 8) s += g[(q * blks + blk) * 32 + pos];
+  red[pl][pos] = s;
+  __syncthreads();
+  if (pl == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 8; ++i) t += red[i][pos];
+    const int co = 32 * blk + chan_of_pos(pos);
+    if (co < cout) db[co] = t;
+  }
+}
+hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* db, hipStream_t s) {
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(cout / 32), dim3(256), 0, s, g, (long long)B * H * W, cout / 32, cout, db);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ pose head backward
+// forward: relu5_3 act [B,h,w,512] -> pool5 (2x2 max) -> mean over (h/2, w/2) -> fc (feature/dfnet.py:168-170).
+// Given d pose [B,F]: pooled [B,512] (kept for the fc weight gradient), and the gradient w.r.t. act: each pooled
+// pixel's share d_pooled[ch] / (ho wo) goes to the FIRST maximum of its window (torch's max-pool routing).
+__global__ __launch_bounds__(512) void pose_head_backward_kernel(const float* __restrict__ act, int h, int w, const float* __restrict__ fc_w,
+                                                                 const float* __restrict__ gpose, int feat_dim,
+                                                                 float* __restrict__ pooled_out, float* __restrict__ gact) {
+  const int cpos = threadIdx.x;   // stored position 0..511
+  const size_t b = blockIdx.x;
+  const int ho = h / 2, wo = w / 2;
+  const int blk = cpos >> 5, e = cpos & 31;
+  const int ch = blk * 32 + chan_of_pos(e);
+  float dp = 0.f;
+  for (int o = 0; o < feat_dim; ++o) dp += gpose[b * feat_dim + o] * fc_w[o * 512 + ch];
+  dp /= float(ho * wo);
+  float sum = 0.f;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const int yo = y >> 1, xo = x >> 1;
+      float v = 0.f;
+      if (yo < ho && xo < wo) {
+        const float* s = act + ((b * h + 2 * yo) * (size_t)w + 2 * xo) * 512 + cpos;
+        const float a0 = s[0], a1 = s[512], a2 = s[(size_t)w * 512], a3 = s[(size_t)w * 512 + 512];
+        const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+        const int first = a0 == m ? 0 : (a1 == m ? 1 : (a2 == m ? 2 : 3));
+        if (first == ((y & 1) * 2 + (x & 1))) { v = dp; sum += m; }
+      }
+      gact[((b * h + y) * (size_t)w + x) * 512 + cpos] = v;
+    }
+  pooled_out[b * 512 + ch] = sum / float(ho * wo);
+}
+// dW_fc[o][ch] = sum_b gpose[b][o] pooled[b][ch];  db[o] = sum_b gpose[b][o]
+__global__ __launch_bounds__(512) void fc_grad_kernel(const float* __restrict__ gpose, const float* __restrict__ pooled, int B, int feat_dim,
+                                                      float* __restrict__ dW, float* __restrict__ db) {
+  const int ch = threadIdx.x, o = blockIdx.x;
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) { s += gpose[b * feat_dim + o] * pooled[b * 512 + ch]; sb += gpose[b * feat_dim + o]; }
+  dW[o * 512 + ch] = s;
+  if (ch == 0) db[o] = sb;
+}
+hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
+                                     float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s) {
+  hipLaunchKernelGGL(pose_head_backward_kernel, dim3(B), dim3(512), 0, s, act, h, w, fc_w, gpose, feat_dim, pooled, gact);
+  hipLaunchKernelGGL(fc_grad_kernel, dim3(feat_dim), dim3(512), 0, s, gpose, pooled, B, feat_dim, dW_fc, db_fc);
+  return hipGetLastError();
+}
+
+}  // namespace dfn

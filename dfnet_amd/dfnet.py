@@ -8,9 +8,10 @@ eval mode on this path (reference: train.py:123, utils.py:30-39).
 
 Autograd: with grad enabled and an input that requires grad (DFNet_dm: feat_model(cat([data, rgb])) with
 the rendered rgb attached to the pose, direct_feature_matching.py:350-376) the feature maps come back
-attached to the graph and their backward is the HIP input-gradient path (dfn_dfnet_backward_input).  The
-module's own weights are treated as frozen there (no weight gradients are produced); training the
-network itself (weight gradients) is not built.
+attached to the graph and their backward is the HIP input-gradient path (dfn_dfnet_backward_input).  On
+that feature path the module's own weights are treated as frozen.  The POSE path (return_pose=True,
+return_feature=False) is differentiable w.r.t. its parameters instead: encoder convs + fc_pose, by the HIP
+weight-gradient kernels (dfn_dfnet_backward_params) — the regressor DFNet_dm trains.
 
 torchvision's pretrained VGG16 weights (dfnet.py:90) are a download and unavailable offline: the
 encoder is created with default Conv2d init; load a checkpoint for real use.
@@ -69,6 +70,24 @@ class _FeatureFn(torch.autograd.Function):
         return engine.backward_input(x, g.contiguous(), levels=levels), None, None, None, None
 
 
+class _PoseFn(torch.autograd.Function):
+    """Pose regression with the parameter gradients of its path as backward (the regressor being trained in DFNet_dm)."""
+
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        _, pose = module.engine().forward(x.detach(), False, True, True)
+        ctx.save_for_backward(x.detach())
+        ctx.module = module
+        return pose
+
+    @staticmethod
+    def backward(ctx, g_pose):
+        (x,) = ctx.saved_tensors
+        m = ctx.module
+        grads = m.engine().backward_params(x, g_pose.contiguous())
+        return (None, None) + tuple(grads[k] for k in m._pose_param_names())
+
+
 class _DFNetBase(nn.Module):
     tap_channels = (64, 256, 512)
     mean = [0.485, 0.456, 0.406]
@@ -87,6 +106,12 @@ class _DFNetBase(nn.Module):
         self._engine = None
         self._engine_version = None
 
+    def _pose_param_names(self):
+        names = []
+        for idx in DfnetEngine.CONV_INDEX:
+            names += [f"encoder.{idx}.weight", f"encoder.{idx}.bias"]
+        return names + ["fc_pose.weight", "fc_pose.bias"]
+
     def _version(self):
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
@@ -103,10 +128,16 @@ class _DFNetBase(nn.Module):
     def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427):
         """Same contract as dfnet.py:109-172: returns (feature_maps, predict) with feature_maps None,
         [stack] (single stream: 1 x [L,B,128,H,W]) or [stack_t, stack_r] (siamese: 2 x [L,B/2,128,H,W])."""
+        if torch.is_grad_enabled() and return_pose and not return_feature and not x.requires_grad and \
+                any(p.requires_grad for p in self.parameters()):
+            # training the regressor (DFNet_dm): parameter gradients of the pose path come from the HIP wgrad kernels
+            sd = dict(self.named_parameters())
+            return None, _PoseFn.apply(x, self, *[sd[k] for k in self._pose_param_names()])
         if torch.is_grad_enabled() and x.requires_grad:
             if return_pose or not return_feature:
-                raise NotImplementedError("autograd through the pose head (training the regressor itself) is not built; "
-                                          "the feature path (return_feature=True, return_pose=False) is")
+                raise NotImplementedError("autograd w.r.t. the INPUT through the pose head is not built; the feature path "
+                                          "(return_feature=True, return_pose=False) is, and so are the pose path's "
+                                          "parameter gradients (input without grad)")
             feats = _FeatureFn.apply(x, self.engine(), bool(isSingleStream), int(upsampleH), int(upsampleW))
             return list(feats), None
         feats, pose = self.engine().forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW)

@@ -249,6 +249,31 @@ class DfnetEngine:
             feats = (feats[0], feats[1])
         return feats, pose
 
+    CONV_INDEX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)  # encoder positions of the 13 convs (VGG16 cfg "D")
+
+    def backward_params(self, x, grad_pose, precision=None):
+        """Gradients of the pose-regression path w.r.t. its parameters: dict {state_dict key: tensor} for
+        encoder.<k>.weight|bias (13 convs) and fc_pose.weight|bias, from d L/d pose [B, feat_dim]."""
+        x, gp = _f32c(x), _f32c(grad_pose).reshape(x.shape[0], self.feat_dim)
+        B, C, H, W = x.shape
+        prec = _lib.PRECISIONS[precision or self.precision]
+        dev = x.device
+        chans, cin, names, grads = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512], 3, [], []
+        for idx, co in zip(self.CONV_INDEX, chans):
+            names += [f"encoder.{idx}.weight", f"encoder.{idx}.bias"]
+            grads += [torch.empty(co, cin, 3, 3, device=dev), torch.empty(co, device=dev)]
+            cin = co
+        names += ["fc_pose.weight", "fc_pose.bias"]
+        grads += [torch.empty(self.feat_dim, 512, device=dev), torch.empty(self.feat_dim, device=dev)]
+        ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        nbytes = self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(self.lib.dfn_dfnet_backward_params(self.handle, prec, ptr(x), B, H, W, ptr(gp), ptrs, len(grads),
+                                                 ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), current_stream()),
+              "dfn_dfnet_backward_params")
+        return dict(zip(names, grads))
+
     def backward_input(self, x, grad_features, levels=None, precision=None):
         """d L/d x [B,3,H,W] from d L/d features in the single-stream layout [n_taps,B,128,uH,uW]; `levels` lists the
         pyramid levels that carry gradient (default: all).  Weights are frozen (DFNet_dm's feat_model)."""

@@ -224,6 +224,18 @@ int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x, int B, int
                              const float* grad_features, int level_mask, float* grad_x, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* Parameter gradients of the pose-regression path (feature/dfnet.py:121-170 with return_pose=True): what
+ * loss.backward() leaves in the pose regressor's parameters in the DFNet_dm step
+ * (feature/direct_feature_matching.py:372-374).  x device [B,3,H,W]; grad_pose device [B, feat_dim]; `grads` is a
+ * HOST array of n_grads = 2 * 13 + 2 DEVICE pointers in state_dict order: encoder conv weight [co,ci,3,3] and bias
+ * [co] for each of the 13 convs, then fc_pose.weight [feat_dim,512] and fc_pose.bias.  prec: DFN_PREC_F16X3 or
+ * DFN_PREC_F32 (the forward recompute; gradient arithmetic is fp32).  BatchNorm / adaptation layers are not on
+ * this path.  Recomputes the forward. */
+size_t dfn_dfnet_backward_params_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W);
+int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W,
+                              const float* grad_pose, float* const* grads, int n_grads, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* Timing aid for bench.py: average device time in ms of the `which` kernel
  * (0 = coarse MLP, 1 = fine MLP) over the launches since the last reset, measured with HIP
  * events on `stream`.  Enabled by dfn_profile_enable(1); costs a sync when read. */

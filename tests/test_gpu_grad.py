@@ -289,3 +289,61 @@ def test_dm_step_pose_gradient_vs_oracle():
     e = relmax(out["grad_pose"], pose_.grad)
     print(f"d loss / d pose: {e:.2e}  |grad| max {float(pose_.grad.abs().max()):.3e}")
     assert e < 2e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 72, 104)])
+def test_dfnet_parameter_gradients_vs_autograd(dfnet, shape):
+    """Weight / bias gradients of the 13 encoder convs and fc_pose for loss = sum(pose * G): HIP wgrad kernels vs torch
+    autograd through the CPU oracle.  Same gate-flip caveat as the input gradient: three seeds, match on one."""
+    from oracle import dfnet_oracle as dor
+    E, p = dfnet
+    best = 1.0
+    for seed in (31, 32, 33):
+        rng = np.random.default_rng(seed)
+        x = T(rng.uniform(0, 1, shape).astype(np.float32))
+        G = T(rng.standard_normal((shape[0], 12)).astype(np.float32))
+        pp = {k: v.clone().requires_grad_(k.startswith("encoder.") or k.startswith("fc_pose.")) for k, v in p.items()}
+        _, pose = dor.dfnet_forward(pp, x, False, True, True)
+        (pose * G).sum().backward()
+        got = E.backward_params(x.to(DEV), G.to(DEV), precision="f16x3")
+        assert len(got) == 28
+        worst = 0.0
+        for k, g in got.items():
+            e = relmax(g, pp[k].grad)
+            worst = max(worst, e)
+            assert rel_l2(g, pp[k].grad) < 5e-2, k
+        print(f"seed {seed} {shape}: worst parameter-gradient error {worst:.2e}")
+        best = min(best, worst)
+        if best < 5e-5:
+            break
+    assert best < 5e-5
+
+
+def test_dfnet_module_trains_pose_path():
+    """nn.Module surface: loss.backward() fills .grad of the regressor's conv / fc parameters (and only those), and a
+    small gradient step through a torch optimizer lowers the loss of the HIP forward."""
+    from dfnet_amd.dfnet import DFNet
+    from oracle import dfnet_oracle as dor
+    sd = {k: T(v) for k, v in syn.dfnet_weights(3).items()}
+    m = DFNet().to(DEV)
+    m.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+    m.eval()
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(2)).to(DEV)
+    target = torch.zeros(2, 12, device=DEV)
+    _, pose = m(x)
+    loss0 = ((pose - target) ** 2).mean()
+    loss0.backward()
+    with_grad = {k for k, q in m.named_parameters() if q.grad is not None}
+    assert with_grad == set(m._pose_param_names())
+    pp = {k: v.clone().requires_grad_(k in with_grad) for k, v in sd.items()}
+    _, rp = dor.dfnet_forward(pp, x.cpu(), False, True, True)
+    ((rp - target.cpu()) ** 2).mean().backward()
+    assert rel_l2(dict(m.named_parameters())["fc_pose.weight"].grad, pp["fc_pose.weight"].grad) < 1e-4
+    assert rel_l2(dict(m.named_parameters())["encoder.0.weight"].grad, pp["encoder.0.weight"].grad) < 5e-2
+    g2 = sum(float((q.grad ** 2).sum()) for q in m.parameters() if q.grad is not None)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1 * float(loss0) / g2)   # first-order prediction: loss drops by ~10 %
+    opt.step()
+    with torch.no_grad():
+        _, pose1 = m(x)
+    loss1 = float(((pose1 - target) ** 2).mean())
+    assert 0.8 * float(loss0) < loss1 < 0.97 * float(loss0), (float(loss0), loss1)
