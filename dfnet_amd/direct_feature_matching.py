@@ -7,8 +7,11 @@ Every arithmetic-heavy stage runs in the HIP library (DFNet forward, render, bic
 the few-element reductions of the loss.  `matching_step_forward` returns the losses only; `matching_step_grad`
 also runs loss.backward() down to the PREDICTED POSE: the loss reductions by torch autograd (a few element-wise
 ops on device tensors), everything below them by the HIP gradient kernels (DFNet input gradient, bicubic adjoint,
-render gradient).  What is still not built is the last link of the reference's step: the weight gradients of the
-pose regressor itself (a VGG16 training step) and its Adam update.
+render gradient).  `train_on_batch` / `train_on_epoch` are the reference's step itself (:322-410): the pose
+regressor is tracked too, loss.backward() continues through SVD / reshape (torch) into the HIP weight-gradient
+kernels of its conv stack and fc_pose (dfn_dfnet_backward_params), and optimizer.step() (a torch optimizer over
+the module's parameters) updates it.  After a step the module re-packs its weights for the HIP forward on the
+host (~0.7 s): correct but slow — a device-side packer is the missing piece for training throughput.
 The reference renders only pose 0 of the batch (:342, i.e. batch size 1 in effect); this implementation renders
 every pose of the batch."""
 import torch
@@ -123,3 +126,67 @@ def matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, half_r
         psnr = -10. * torch.log10(photo_l)
     return dict(loss=loss.detach(), pose_loss=pose_l.detach(), photo_loss=photo_l.detach(), feat_loss=feat_l.detach(),
                 psnr=psnr, rgb=rgb.detach(), pose_pred=pose_.detach(), grad_pose=pose_.grad)
+
+
+
+def _losses(args, data, rgb, pose_, pose, feat_model, device):
+    """The loss block of train_on_batch (:350-370) on a tracked rendered batch rgb [B,3,H,W]."""
+    B = data.shape[0]
+    feats, _ = inference_pose_regression(args, torch.cat([data, rgb]), device, feat_model, retFeature=True,
+                                         isSingleStream=False, return_pose=False)
+    idx = torch.tensor(args.feature_matching_lvl, device=device)
+    f_t = preprocess_features_for_loss(torch.index_select(feats[0], 0, idx))
+    f_r = preprocess_features_for_loss(torch.index_select(feats[1], 0, idx))
+    feat_l = torch.stack([feature_loss(f_r[b], f_t[b], per_channel=args.per_channel) for b in range(B)]).mean()
+    photo_l = torch.mean((rgb - data) ** 2)
+    pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
+    if getattr(args, "combine_loss", False):
+        w = args.combine_loss_w
+        return w[0] * pose_l + w[1] * photo_l + w[2] * feat_l, photo_l
+    return feat_l, photo_l
+
+
+def train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer, half_res, device, world_setup_dict,
+                   **render_kwargs_test):
+    """One optimisation step of DFNet_dm (:322-390): returns (loss, psnr) as 1-element numpy arrays like the reference."""
+    import numpy as np
+    H, W, focal = hwf
+    H, W = int(H), int(W)
+    data = data.to(device)
+    B = data.shape[0]
+    with torch.enable_grad():
+        _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
+        pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
+        img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
+        rgbs = []
+        for b in range(B):   # the reference renders pose 0 only (:342); every pose of the batch here
+            if half_res:
+                rgb, _, _, _ = render(H // 4, W // 4, focal / 4, chunk=args.chunk, c2w=pose_nerf[b, :3, :4],
+                                      img_idx=img_idx[b], **render_kwargs_test)
+                rgb = upsample_bicubic(rgb, H, W)
+            else:
+                rgb, _, _, _ = render(H, W, focal, chunk=args.chunk, c2w=pose_nerf[b, :3, :4], img_idx=img_idx[b],
+                                      **render_kwargs_test)
+            rgbs.append(rgb.permute(2, 0, 1))
+        rgb = torch.stack(rgbs)
+        loss, photo_l = _losses(args, data, rgb, pose_, pose, feat_model, device)
+        loss.backward()
+    optimizer.step()
+    optimizer.zero_grad()
+    with torch.no_grad():
+        psnr = -10. * torch.log10(photo_l.detach())
+    return np.array([float(loss.detach())]), np.array([float(psnr)])
+
+
+def train_on_epoch(args, data_loaders, model, feat_model, hwf, optimizer, half_res, device, world_setup_dict,
+                   **render_kwargs_test):
+    """One epoch over the training loader (:392-410): mean (loss, psnr).  BatchNorm is not on the regressor's path."""
+    import numpy as np
+    train_dl = data_loaders[0]
+    losses, psnrs = [], []
+    for data, pose, img_idx in train_dl:
+        l, p = train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer, half_res, device,
+                              world_setup_dict, **render_kwargs_test)
+        losses.append(l.item())
+        psnrs.append(p.item())
+    return float(np.mean(losses)), float(np.mean(psnrs))

@@ -3,12 +3,12 @@
 
     python train.py --config config_dfnetdm.txt --eval
 
-Native: every step's forward — DFNet pose regression, NeRF-H render at the predicted pose (quarter resolution +
-bicubic x4), siamese DFNet features, cosine feature-matching loss — and its backward down to the predicted pose
-(HIP gradient kernels for the feature extractor, the bicubic resize and the render).  `--eval` prints the median /
-mean pose error over the test split (as the reference) and the mean losses / PSNR over the validation split; without it the script walks the training split and prints the loss and
-the norm of d loss / d pose per batch.  The last link of the reference's update — weight gradients of the pose
-regressor (a VGG16 training step) and its Adam step — is not built, so no parameters change.
+Native: the whole step — DFNet pose regression, NeRF-H render at the predicted pose (quarter resolution + bicubic
+x4), siamese DFNet features, cosine feature-matching loss — and its backward: HIP gradient kernels for the feature
+extractor's input, the bicubic resize, the render (down to the pose) and the pose regressor's own conv / fc
+weights; Adam (torch.optim over the module's parameters) applies the update.  `--eval` prints the median / mean
+pose error over the test split (as the reference) and the mean losses / PSNR over the validation split.
+Early stopping / TensorBoard callbacks of the reference are not mirrored; checkpoints are written every i_eval epochs.
 """
 import os
 import sys
@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 from dfnet_amd.datasets import load_7Scenes_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
-from dfnet_amd.direct_feature_matching import matching_step_forward, matching_step_grad  # noqa: E402
+from dfnet_amd.direct_feature_matching import matching_step_forward, train_on_epoch  # noqa: E402
 from dfnet_amd.nerfw import create_nerf  # noqa: E402
 from dfnet_amd.options import dm_parser  # noqa: E402
 
@@ -45,14 +45,20 @@ def main(argv=None):
     render_kwargs_test.update({'near': near, 'far': far})
     setup = {k: getattr(train_dl.dataset, k) for k in ('pose_scale', 'pose_scale2', 'move_all_cam_vec')}
     if not args.eval:
-        print("DFNet_dm: forward + backward to the predicted pose on the HIP path; the pose regressor's own weight "
-              "gradients / Adam step are not built, so this pass reports gradients and changes no parameters")
-        for it, (data, pose, img_idx) in enumerate(train_dl):
-            out = matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, True, device, setup,
-                                     **render_kwargs_test)
-            print('[{}] loss {:.6f} feat {:.6f} photo {:.6f} psnr {:.3f} |dL/dpose| {:.4e}'.format(
-                it, float(out["loss"]), float(out["feat_loss"]), float(out["photo_loss"]), float(out["psnr"]),
-                float(out["grad_pose"].norm())))
+        # train_feature_matching (direct_feature_matching.py:412-470): Adam over the pose regressor, NeRF-H and the
+        # feature extractor frozen; every gradient on the HIP path, the optimizer step by torch
+        model.to(device)
+        for q in feat_model.parameters():
+            q.requires_grad_(False)
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate)
+        n_epoch = int(os.environ.get("DFNET_DM_EPOCHS", 2001))   # the reference hard-codes 2001 (:436) and relies on early stopping
+        for epoch in range(n_epoch):
+            loss, psnr = train_on_epoch(args, [train_dl, val_dl, test_dl], model, feat_model, hwf, optimizer, True, device,
+                                        setup, **render_kwargs_test)
+            print('At epoch {0:4d} : train loss: {1:.4f}, train psnr: {2:.4f}'.format(epoch, loss, psnr))
+            if (epoch + 1) % max(int(getattr(args, "i_eval", 50) or 50), 1) == 0 or epoch + 1 == n_epoch:
+                os.makedirs(os.path.join(args.basedir, args.model_name), exist_ok=True)
+                torch.save(model.state_dict(), os.path.join(args.basedir, args.model_name, 'checkpoint-{:04d}.pt'.format(epoch)))
         return
     # train.py:138-157: `--eval` = pose error of the DFNet_dm regressor over the test split ...
     from dfnet_amd.feature_misc import get_error_in_q

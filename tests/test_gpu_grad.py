@@ -347,3 +347,74 @@ def test_dfnet_module_trains_pose_path():
         _, pose1 = m(x)
     loss1 = float(((pose1 - target) ** 2).mean())
     assert 0.8 * float(loss0) < loss1 < 0.97 * float(loss0), (float(loss0), loss1)
+
+
+def test_dm_train_step_parameter_gradients_vs_oracle():
+    """The whole DFNet_dm optimisation step (direct_feature_matching.py:322-376): gradients that reach the pose
+    regressor's parameters through SVD -> scene rescale -> render -> bicubic -> feature extractor -> losses, HIP path vs
+    autograd through the composition of the CPU oracles; then the optimizer step itself."""
+    from types import SimpleNamespace
+    from dfnet_amd.dfnet import DFNet
+    from dfnet_amd.direct_feature_matching import train_on_batch
+    from dfnet_amd.nerfw import HipQuery
+    from oracle import dfnet_oracle as dor
+    H, W, focal = 64, 96, 80.0
+    sd = {k: T(v) for k, v in syn.dfnet_weights(3).items()}
+    model, feat_model = DFNet().to(DEV).eval(), DFNet().to(DEV).eval()
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+    feat_model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+    for q in feat_model.parameters():
+        q.requires_grad_(False)
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine(precision="f16x3").load_numpy(cw, fw, ea, et)
+    kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=16, N_samples=8, use_viewdirs=True,
+              white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    setup = dict(pose_scale=0.7, pose_scale2=1.2, move_all_cam_vec=[0., 0.1, 1.0])
+    args = SimpleNamespace(svd_reg=True, chunk=32768, feature_matching_lvl=[0], per_channel=False, combine_loss=True,
+                           combine_loss_w=[0.3, 0.2, 1.0])
+    data = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(1))
+    gt = torch.stack([T(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(2)])
+    hist = T(syn.HIST_IDX).repeat(2, 1)
+
+    class Capture:  # stands in for the optimizer: keeps the gradients loss.backward() produced
+        def __init__(self, m):
+            self.m, self.grads = m, None
+
+        def step(self):
+            self.grads = {k: q.grad.detach().cpu().clone() for k, q in self.m.named_parameters() if q.grad is not None}
+
+        def zero_grad(self):
+            for q in self.m.parameters():
+                q.grad = None
+
+    cap = Capture(model)
+    loss, psnr = train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], cap, True, DEV, setup, **kw)
+    assert set(cap.grads) == set(model._pose_param_names())
+    # oracle composition, everything tracked from the regressor's parameters on
+    pp = {k: v.clone().requires_grad_(k in cap.grads) for k, v in sd.items()}
+    _, pr = dor.dfnet_forward(pp, data, False, True, True)
+    pose_ = pr.reshape(2, 3, 4).clone()
+    u, s_, v = torch.svd(pose_[:, :3, :3].clone())
+    pose_[:, :3, :3] = u @ v.transpose(-2, -1)
+    pn = pose_.clone()
+    pn[:, :3, 3] *= setup["pose_scale"]
+    pn[:, :3, 3] += torch.tensor(setup["move_all_cam_vec"])
+    pn[:, :3, 3] *= setup["pose_scale2"]
+    c, f = {k: T(x) for k, x in cw.items()}, {k: T(x) for k, x in fw.items()}
+    rgbs = []
+    for b in range(2):
+        r = orc.render(H // 4, W // 4, focal / 4, 1 << 30, c, f, T(ea), T(et), 8, 16, 0., 2.5, syn.HIST_IDX, c2w=pn[b])[0]
+        rgbs.append(torch.nn.Upsample(size=(H, W), mode='bicubic')(r.permute(2, 0, 1)[None])[0])
+    rgb = torch.stack(rgbs)
+    feats, _ = dor.dfnet_forward(sd, torch.cat([data, rgb]), True, False, False, H, W)
+    ft, fr = feats[0][[0]].permute(1, 0, 2, 3, 4).reshape(2, 128, H, W), feats[1][[0]].permute(1, 0, 2, 3, 4).reshape(2, 128, H, W)
+    fl = torch.stack([1 - torch.nn.functional.cosine_similarity(fr[b].reshape(128, -1), ft[b].reshape(128, -1), dim=1, eps=1e-6).mean()
+                      for b in range(2)]).mean()
+    ref_loss = 0.3 * torch.nn.functional.mse_loss(pose_.reshape(2, 12), gt) + 0.2 * ((rgb - data) ** 2).mean() + 1.0 * fl
+    ref_loss.backward()
+    assert abs(float(loss[0]) - float(ref_loss.detach())) < 5e-4 * max(1.0, abs(float(ref_loss.detach())))
+    worst = 0.0
+    for k, g in cap.grads.items():
+        worst = max(worst, rel_l2(g, pp[k].grad))
+    print(f"DFNet_dm step: worst relative-L2 error over the 28 parameter gradients {worst:.2e}")
+    assert worst < 1e-3
