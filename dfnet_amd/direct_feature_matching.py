@@ -16,6 +16,7 @@ The reference renders only pose 0 of the batch (:342, i.e. batch size 1 in effec
 every pose of the batch."""
 import torch
 
+from . import dist as ddist
 from .feature_misc import feature_loss, fix_coord_supp, upsample_bicubic
 from .rendering import render
 
@@ -171,6 +172,7 @@ def train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer,
         rgb = torch.stack(rgbs)
         loss, photo_l = _losses(args, data, rgb, pose_, pose, feat_model, device)
         loss.backward()
+    ddist.allreduce_gradients(model.parameters())   # data-parallel: one all-reduce of the regressor's gradients per step
     optimizer.step()
     optimizer.zero_grad()
     with torch.no_grad():

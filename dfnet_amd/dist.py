@@ -58,6 +58,25 @@ def gather_frames(local, n_frames, dst=0):
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
 
 
+def allreduce_gradients(params):
+    """Data-parallel DFNet_dm: average the pose regressor's gradients over ranks with ONE
+    all-reduce of a flat bucket (15.4 M parameters = 61.6 MB for DFNet; RCCL over xGMI with the nccl backend).
+    Parameters without a gradient are skipped (the same set on every rank).  world == 1: no-op."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
 def max_over_ranks(value, device):
     """MAX all-reduce of a python float (timing)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -18,6 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
+from dfnet_amd import dist as ddist  # noqa: E402
 from dfnet_amd.datasets import load_7Scenes_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
 from dfnet_amd.direct_feature_matching import matching_step_forward, train_on_epoch  # noqa: E402
@@ -29,7 +30,8 @@ def main(argv=None):
     np.random.seed(0)
     torch.manual_seed(0)
     args = dm_parser().parse_args(argv)
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local = ddist.init_from_env()   # torchrun: one process per GPU, gradients averaged over RCCL
+    torch.cuda.set_device(local)
     device = torch.device("cuda", torch.cuda.current_device())
     if args.dataset_type != '7Scenes':
         raise NotImplementedError(f"dataset_type={args.dataset_type}: only the 7Scenes front-end is built")
@@ -51,14 +53,19 @@ def main(argv=None):
         for q in feat_model.parameters():
             q.requires_grad_(False)
         optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate)
+        if world > 1:   # data-parallel over the training frames; weights stay identical on every rank
+            sampler = torch.utils.data.distributed.DistributedSampler(train_dl.dataset, num_replicas=world, rank=rank, shuffle=True)
+            train_dl = torch.utils.data.DataLoader(train_dl.dataset, batch_size=args.batch_size, sampler=sampler)
         n_epoch = int(os.environ.get("DFNET_DM_EPOCHS", 2001))   # the reference hard-codes 2001 (:436) and relies on early stopping
         for epoch in range(n_epoch):
             loss, psnr = train_on_epoch(args, [train_dl, val_dl, test_dl], model, feat_model, hwf, optimizer, True, device,
                                         setup, **render_kwargs_test)
-            print('At epoch {0:4d} : train loss: {1:.4f}, train psnr: {2:.4f}'.format(epoch, loss, psnr))
-            if (epoch + 1) % max(int(getattr(args, "i_eval", 50) or 50), 1) == 0 or epoch + 1 == n_epoch:
+            if rank == 0:
+                print('At epoch {0:4d} : train loss: {1:.4f}, train psnr: {2:.4f}'.format(epoch, loss, psnr))
+            if rank == 0 and ((epoch + 1) % max(int(getattr(args, "i_eval", 50) or 50), 1) == 0 or epoch + 1 == n_epoch):
                 os.makedirs(os.path.join(args.basedir, args.model_name), exist_ok=True)
-                torch.save(model.state_dict(), os.path.join(args.basedir, args.model_name, 'checkpoint-{:04d}.pt'.format(epoch)))
+                ckpt = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+                torch.save(ckpt, os.path.join(args.basedir, args.model_name, 'checkpoint-{:04d}.pt'.format(epoch)))
         return
     # train.py:138-157: `--eval` = pose error of the DFNet_dm regressor over the test split ...
     from dfnet_amd.feature_misc import get_error_in_q

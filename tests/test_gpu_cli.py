@@ -93,3 +93,22 @@ def test_run_feature_eval_cli(tmp_path):
     assert len(lines) == 2 and all("degrees" in l for l in lines)
     med = float(lines[0].split("error ")[1].split("m and")[0])
     assert np.isfinite(med) and med >= 0
+
+
+def test_train_dm_cli(tmp_path):
+    """train.py (DFNet_dm) for one epoch on the synthetic tree: every step's forward, backward and update run, the
+    loss is reported and a checkpoint with the reference's state_dict keys is written."""
+    datadir = make_scene(str(tmp_path), n_train=2, n_val=2, H=128, W=160)
+    basedir = str(tmp_path / "logs")
+    cli = ["--config", os.path.join(ROOT, "script", "config_dfnetdm.txt"), "--datadir", datadir, "--basedir", basedir,
+           "--N_samples", "16", "--N_importance", "32", "--df", "2", "--trainskip", "1", "--testskip", "1",
+           "--learning_rate", "1e-6", "--i_eval", "1"]
+    env = dict(os.environ, DFNET_DM_EPOCHS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "train.py")] + cli, cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("At epoch")]
+    assert len(line) == 1 and "train loss" in line[0] and "nan" not in line[0]
+    import torch
+    ck = torch.load(os.path.join(basedir, "dfnet_dm", "checkpoint-0000.pt"), map_location="cpu")
+    assert "encoder.0.weight" in ck and "fc_pose.bias" in ck and "adaptation_layers.adapt_layer_0.3.running_var" in ck

@@ -155,3 +155,34 @@ def test_pose_error_metrics_match_scipy():
         Rh = Rotation.from_rotvec(np.pi * axis).as_matrix()
         qh = matrix_to_quaternion(torch.from_numpy(Rh)).numpy()
         assert abs(qh[0]) < 1e-6 and np.allclose(np.abs(qh[1:]), axis, atol=1e-6)
+
+
+_GLOO_GRAD_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from dfnet_amd import dist as ddist
+rank, world, _ = ddist.init_from_env(backend="gloo")
+params = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+params[0].grad = torch.full((3, 4), float(rank + 1))
+params[1].grad = torch.arange(5.) * (rank + 1)
+# params[2] has no gradient on any rank (e.g. the adaptation layers of the pose regressor): skipped
+ddist.allreduce_gradients(params)
+mean = sum(range(1, world + 1)) / world
+assert torch.allclose(params[0].grad, torch.full((3, 4), mean)) and torch.allclose(params[1].grad, torch.arange(5.) * mean)
+assert params[2].grad is None
+if rank == 0:
+    print("ALLREDUCE_OK")
+ddist.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_gradient_allreduce_gloo_world2(tmp_path):
+    """Data-parallel DFNet_dm: one flat all-reduce averages the regressor's gradients over ranks."""
+    script = tmp_path / "g.py"
+    script.write_text(_GLOO_GRAD_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641", str(script), ROOT],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ALLREDUCE_OK" in r.stdout

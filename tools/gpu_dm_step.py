@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dfnet_amd import engine as eng, synthetic as syn
 from dfnet_amd.dfnet import DFNet
-from dfnet_amd.direct_feature_matching import matching_step_forward, matching_step_grad
+from dfnet_amd.direct_feature_matching import matching_step_forward, matching_step_grad, train_on_batch
 from dfnet_amd.nerfw import HipQuery
 
 dev = torch.device("cuda:0")
@@ -17,9 +17,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 H, W, focal = 240, 320, 585.0 / 2
 sd = {k: torch.from_numpy(v) for k, v in syn.dfnet_weights(3).items()}
-model, feat_model = DFNet().eval(), DFNet().eval()
-model.load_state_dict(sd, strict=False)
-feat_model.load_state_dict(sd, strict=False)
+model, feat_model = DFNet().to(dev).eval(), DFNet().to(dev).eval()
+model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=False)
+feat_model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=False)
+for q in feat_model.parameters():
+    q.requires_grad_(False)
 cw, fw, ea, et = syn.nerfh_weights(0)
 E = eng.NerfHEngine(precision="f16").load_numpy(cw, fw, ea, et)
 kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=128, N_samples=64, use_viewdirs=True,
@@ -57,8 +59,17 @@ for gp in ("f32", "f16x3"):
     results["grad kernel " + gp] = {"ms": ms, "rel": float((o["grad_pose"].cpu() - ga).abs().max() / ga.abs().max())}
 fwd_ms, _ = timed(lambda: matching_step_forward(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
 step_ms, out = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
+# the full optimisation step: + regressor weight gradients (HIP) + Adam (torch) + host re-pack of the updated weights
+opt = torch.optim.Adam(model.parameters(), lr=1e-7)
+class NoStep:   # gradients only: isolates the weight-gradient kernels from the optimizer / re-pack cost
+    def step(self): pass
+    def zero_grad(self):
+        for q in model.parameters(): q.grad = None
+wg_ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], NoStep(), True, dev, setup, **kw))
+full_ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
 print(json.dumps({"workload": f"DFNet_dm step, batch {B}, 240x320, render 60x80 @64+128 + bicubic x4, level-0 feature loss",
-                  "forward_ms": fwd_ms, "forward_backward_to_pose_ms": step_ms, "ms_per_frame": step_ms / B,
+                  "forward_ms": fwd_ms, "forward_backward_to_pose_ms": step_ms,
+                  "forward_backward_all_gradients_ms": wg_ms, "full_step_with_adam_and_host_repack_ms": full_ms, "ms_per_frame": step_ms / B,
                   "loss": float(out["loss"]), "grad_pose_absmax": float(out["grad_pose"].abs().max()),
                   "grad_kernel_modes": {k: v for k, v in results.items() if k.startswith("grad kernel")},
                   "all_fp32_tracked_forward_ms": results["fp32 forward state"]["forward_backward_to_pose_ms"],
