@@ -656,3 +656,42 @@ extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x
   }
   return DFN_OK;
 }
+
+// ------------------------------------------------------------------------------------------ device-side parameter refresh
+// After optimizer.step() the pose path's fp32 master weights are in device memory: re-pack the 13 encoder convs (forward
+// and data-gradient fragments, all three arithmetic modes) and fc_pose on the device.  `params`: HOST array of
+// 2 * 13 + 2 DEVICE pointers in the order of dfn_dfnet_backward_params.  The split-f16 weight scale of each conv is
+// kept from dfn_dfnet_commit (weights move slowly under fine-tuning; re-commit from the host to re-derive it).
+extern "C" int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_refresh_pose_params_device: null handle");
+  if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_refresh_pose_params_device: dfn_dfnet_commit() has not been called");
+  const int n_enc = int(h->enc.size());
+  if (!params || n_params != 2 * n_enc + 2) return set_error(DFN_ERR_ARG, "dfn_dfnet_refresh_pose_params_device: need %d pointers", 2 * n_enc + 2);
+  for (int i = 0; i < n_params; ++i)
+    if (!params[i]) return set_error(DFN_ERR_ARG, "dfn_dfnet_refresh_pose_params_device: null pointer %d", i);
+  hipStream_t s = HS(stream);
+  for (int i = 0; i < n_enc; ++i) {
+    const ConvSpec& sp = h->enc[i];
+    const bool first = i == 0;
+    PackedConv& f = h->enc_packed[i];
+    PackedConv& d = h->enc_dgrad[i];
+    const float wscale = 1.f / (f.out_scale * 16.f);
+    const int cop = (sp.cin + 63) / 64 * 64;
+    const float dscale = 1.f / (d.out_scale * 16.f);
+    for (int prec = 0; prec < 3; ++prec) {
+      const int sb = first ? prep_sb(prec) : 16;
+      const int mbf = prec == 2 ? 2 : conv_mb(prec, sp.cout / 32);
+      CHECK_HIP(launch_pack_conv(prec, params[2 * i], sp.cout, sp.cin, 3, first, sb, mbf, 0, sp.cout, sp.cin, wscale, f.w[prec], s),
+                "refresh: forward pack");
+      const int mbd = prec == 2 ? 2 : conv_mb(prec, cop / 32);
+      CHECK_HIP(launch_pack_conv(prec, params[2 * i], cop, sp.cout, 3, 0, 16, mbd, 1, sp.cout, sp.cin, dscale, d.w[prec], s),
+                "refresh: dgrad pack");
+    }
+    CHECK_HIP(launch_pack_bias(params[2 * i + 1], sp.cout, 1.f, f.bias, s), "refresh: bias");
+    CHECK_HIP(launch_pack_bias(params[2 * i + 1], sp.cout, wscale * 16.f, f.bias_x3, s), "refresh: bias (split-f16)");
+  }
+  CHECK_HIP(hipMemcpyAsync(h->fc, params[2 * n_enc], size_t(h->feat_dim) * 512 * 4, hipMemcpyDeviceToDevice, s), "refresh: fc weight");
+  CHECK_HIP(hipMemcpyAsync(h->fc + size_t(h->feat_dim) * 512, params[2 * n_enc + 1], size_t(h->feat_dim) * 4, hipMemcpyDeviceToDevice, s),
+            "refresh: fc bias");
+  return DFN_OK;
+}

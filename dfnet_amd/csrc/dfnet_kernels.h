@@ -73,4 +73,10 @@ hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
                                      float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s);
 
+// device-side re-packing of a conv's fp32 master weights (after an optimizer step): same fragment layouts as the host
+// packers of dfnet_api.hip.  mode 0 = forward conv, 1 = its data-gradient conv (w_cout / w_cin = the forward shape).
+hipError_t launch_pack_conv(int prec, const float* w, int cout, int cin, int ks, int first, int sb, int mb, int mode, int w_cout,
+                            int w_cin, float wscale, void* out, hipStream_t s);
+hipError_t launch_pack_bias(const float* b, int cout, float scale, float* out, hipStream_t s);
+
 }  // namespace dfn

@@ -254,4 +254,71 @@ hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, cons
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ device-side weight packer
+// After an optimizer step the fp32 master weights live in device memory; these kernels re-create the packed MFMA
+// fragments (dfnet_api.hip: pack_conv / pack_conv_x3 / pack_dgrad, same index maps) without a host round trip.
+// mode 0: forward conv  w[co][ci][ky][kx];  mode 1: data-gradient conv  w'[co'][ci'][ky][kx] = w[ci'][co'][K-1-ky][K-1-kx]
+// prec 0: f16 fragments, 1: fp32 fragments, 2: split-f16 slices [hi|lo] of w * wscale.
+struct PackGeom { int cout, cin, ks, first, sb, mb, mode, w_cout, w_cin; float wscale; };
+__device__ __forceinline__ float pack_source(const float* w, const PackGeom& g, int co, int ci, int ky, int kx) {
+  if (co >= g.cout || ci < 0 || ci >= g.cin) return 0.f;
+  if (g.mode == 0) return w[(((size_t)co * g.w_cin + ci) * g.ks + ky) * g.ks + kx];
+  if (co >= g.w_cin || ci >= g.w_cout) return 0.f;                         // padded output channels of the dgrad conv
+  return w[(((size_t)ci * g.w_cin + co) * g.ks + (g.ks - 1 - ky)) * g.ks + (g.ks - 1 - kx)];
+}
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, PackGeom g, void* __restrict__ out) {
+  constexpr int SPC = PREC == 1 ? 1 : 8;
+  const int nblk = g.first ? 1 : g.cin / 32, kcb = g.sb / SPC, groups = g.cout / 32 / g.mb;
+  const size_t n = (size_t)groups * nblk * g.ks * g.mb * g.ks * kcb * 64 * SPC;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int j = int(r % SPC); r /= SPC;
+    const int lane = int(r % 64); r /= 64;
+    const int kc = int(r % kcb); r /= kcb;
+    const int kx = int(r % g.ks); r /= g.ks;
+    const int m = int(r % g.mb); r /= g.mb;
+    const int ky = int(r % g.ks); r /= g.ks;
+    const int blk = int(r % nblk);
+    const int cg = int(r / nblk);
+    const int co = 32 * (cg * g.mb + m) + (lane & 31);
+    const int s = kc * SPC + j, hh = lane >> 5;
+    const int ci = g.first ? ((hh == 0 && s < 3) ? s : -1) : 32 * blk + 4 * hh + (s & 3) + 8 * (s >> 2);
+    const float v = pack_source(w, g, co, ci, ky, kx);
+    if (PREC == 0) static_cast<_Float16*>(out)[i] = (_Float16)v;
+    else if (PREC == 1) static_cast<float*>(out)[i] = v;
+    else {
+      // slice layout [cg][blk][ky][hi|lo][mb][kx][kc][lane][8]
+      const size_t half_slice = (size_t)g.mb * g.ks * kcb * 64 * 8;
+      const size_t slice = ((size_t)cg * nblk + blk) * g.ks + ky;
+      const size_t o = ((((size_t)m * g.ks + kx) * kcb + kc) * 64 + lane) * 8 + j;
+      _Float16* sl = static_cast<_Float16*>(out) + slice * 2 * half_slice;
+      const float vs = v * g.wscale;
+      const _Float16 hi = (_Float16)vs;
+      sl[o] = hi;
+      sl[half_slice + o] = (_Float16)(vs - (float)hi);
+    }
+  }
+}
+hipError_t launch_pack_conv(int prec, const float* w, int cout, int cin, int ks, int first, int sb, int mb, int mode, int w_cout,
+                            int w_cin, float wscale, void* out, hipStream_t s) {
+  const PackGeom g{cout, cin, ks, first, sb, mb, mode, w_cout, w_cin, wscale};
+  const dim3 grid(2048), block(256);
+  if (prec == 0) hipLaunchKernelGGL(pack_conv_kernel<0>, grid, block, 0, s, w, g, out);
+  else if (prec == 1) hipLaunchKernelGGL(pack_conv_kernel<1>, grid, block, 0, s, w, g, out);
+  else hipLaunchKernelGGL(pack_conv_kernel<2>, grid, block, 0, s, w, g, out);
+  return hipGetLastError();
+}
+// bias [cout] -> C-fragment order [cout/32][2][16], times `scale`
+__global__ __launch_bounds__(256) void pack_bias_kernel(const float* __restrict__ b, int cout, float scale, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cout) return;
+  const int m = i >> 5, e = i & 31, hh = e >> 4, r = e & 15;
+  out[i] = b[32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh] * scale;
+}
+hipError_t launch_pack_bias(const float* b, int cout, float scale, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pack_bias_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, b, cout, scale, out);
+  return hipGetLastError();
+}
+
 }  // namespace dfn

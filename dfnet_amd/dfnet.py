@@ -113,15 +113,24 @@ class _DFNetBase(nn.Module):
         return names + ["fc_pose.weight", "fc_pose.bias"]
 
     def _version(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return {k: (p.data_ptr(), p._version) for k, p in list(self.named_parameters()) + list(self.named_buffers())}
 
     def engine(self):
-        """The HIP engine holding the current weights (re-packed whenever a parameter tensor changed)."""
+        """The HIP engine holding the current weights.  Re-packed whenever a parameter tensor changed: on the device
+        when only the pose path's parameters moved and they live on the GPU (an optimizer step of DFNet_dm), from the
+        host otherwise."""
         ver = self._version()
         if self._engine is None or ver != self._engine_version:
-            if self._engine is None:
-                self._engine = DfnetEngine(len(self.tap_channels), self.feat_dim, self.precision)
-            self._engine.load_numpy({k: v.detach().cpu().numpy() for k, v in self.state_dict().items()})
+            pose_names = self._pose_param_names()
+            changed = None if self._engine_version is None else {k for k in ver if ver[k] != self._engine_version.get(k)}
+            params = dict(self.named_parameters())
+            if self._engine is not None and changed is not None and changed <= set(pose_names) and \
+                    all(params[k].is_cuda for k in pose_names) and len(self.tap_channels) == 3:
+                self._engine.refresh_pose_params_device([params[k].detach() for k in pose_names])
+            else:
+                if self._engine is None:
+                    self._engine = DfnetEngine(len(self.tap_channels), self.feat_dim, self.precision)
+                self._engine.load_numpy({k: v.detach().cpu().numpy() for k, v in self.state_dict().items()})
             self._engine_version = ver
         return self._engine
 

@@ -10,8 +10,8 @@ ops on device tensors), everything below them by the HIP gradient kernels (DFNet
 render gradient).  `train_on_batch` / `train_on_epoch` are the reference's step itself (:322-410): the pose
 regressor is tracked too, loss.backward() continues through SVD / reshape (torch) into the HIP weight-gradient
 kernels of its conv stack and fc_pose (dfn_dfnet_backward_params), and optimizer.step() (a torch optimizer over
-the module's parameters) updates it.  After a step the module re-packs its weights for the HIP forward on the
-host (~0.7 s): correct but slow — a device-side packer is the missing piece for training throughput.
+the module's parameters) updates it; the module then re-packs the changed weights into MFMA fragments on the
+device (dfn_dfnet_refresh_pose_params_device, ~1 ms; bit-identical to a host commit).
 The reference renders only pose 0 of the batch (:342, i.e. batch size 1 in effect); this implementation renders
 every pose of the batch."""
 import torch

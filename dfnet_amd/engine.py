@@ -274,6 +274,15 @@ class DfnetEngine:
               "dfn_dfnet_backward_params")
         return dict(zip(names, grads))
 
+    def refresh_pose_params_device(self, tensors):
+        """Re-pack the pose path's parameters from device tensors (order: encoder.<k>.weight, .bias for the 13 convs,
+        fc_pose.weight, fc_pose.bias) — the fast path after an optimizer step."""
+        ts = [_f32c(t) for t in tensors]
+        assert len(ts) == 28 and all(t.is_cuda for t in ts)
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        check(self.lib.dfn_dfnet_refresh_pose_params_device(self.handle, ptrs, len(ts), current_stream()),
+              "dfn_dfnet_refresh_pose_params_device")
+
     def backward_input(self, x, grad_features, levels=None, precision=None):
         """d L/d x [B,3,H,W] from d L/d features in the single-stream layout [n_taps,B,128,uH,uW]; `levels` lists the
         pyramid levels that carry gradient (default: all).  Weights are frozen (DFNet_dm's feat_model)."""

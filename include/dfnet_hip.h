@@ -236,6 +236,11 @@ int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, in
                               const float* grad_pose, float* const* grads, int n_grads, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* After an optimizer step: re-pack the pose path's parameters (13 encoder convs + fc_pose, forward and data-gradient
+ * fragments) from DEVICE fp32 master copies, without the host round trip of set_param + commit.  `params`: HOST
+ * array of DEVICE pointers in the order of dfn_dfnet_backward_params.  Adaptation layers are untouched. */
+int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream);
+
 /* Timing aid for bench.py: average device time in ms of the `which` kernel
  * (0 = coarse MLP, 1 = fine MLP) over the launches since the last reset, measured with HIP
  * events on `stream`.  Enabled by dfn_profile_enable(1); costs a sync when read. */

@@ -184,3 +184,34 @@ def test_dfnet_limits(net):
         E.forward(torch.rand(1, 3, 16, 64, device=DEV), True, True, False, 16, 64)
     with pytest.raises(Exception, match="even batch"):
         E.forward(x.to(DEV), True, False, False, 32, 32)           # siamese needs an even batch
+
+
+def test_device_repack_equals_host_commit():
+    """After an in-place update of the pose path's parameters on the GPU the module re-packs them on the device
+    (dfn_dfnet_refresh_pose_params_device); a fresh module committed from the host with the same values gives the same
+    bits for the pose, the features (all three arithmetic modes) and the input gradient."""
+    from dfnet_amd.dfnet import DFNet
+    sd = {k: T(v) for k, v in syn.dfnet_weights(3).items()}
+    m = DFNet().to(DEV).eval()
+    m.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(9)).to(DEV)
+    with torch.no_grad():
+        m(x)                                           # first commit (host)
+        g = torch.Generator(device=DEV).manual_seed(4)
+        for k in m._pose_param_names():                # an "optimizer step": in place, on the device
+            q = dict(m.named_parameters())[k]
+            q.mul_(1 + 0.05 * torch.randn(q.shape, device=DEV, generator=g))
+        calls = []
+        orig = m._engine.refresh_pose_params_device
+        m._engine.refresh_pose_params_device = lambda ts: (calls.append(1), orig(ts))[1]
+        E1 = m.engine()
+        assert calls == [1]                            # took the device path
+    ref = DFNet().eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()}, strict=False)
+    E2 = ref.engine()
+    G = torch.randn(3, 2, 128, 64, 96, generator=torch.Generator().manual_seed(1)).to(DEV)
+    for prec in ("f16x3", "f32", "f16"):
+        a, pa = E1.forward(x, True, True, True, 64, 96, precision=prec)
+        b, pb = E2.forward(x, True, True, True, 64, 96, precision=prec)
+        assert torch.equal(a, b) and torch.equal(pa, pb), prec
+        assert torch.equal(E1.backward_input(x, G, precision=prec), E2.backward_input(x, G, precision=prec)), prec

@@ -59,7 +59,7 @@ for gp in ("f32", "f16x3"):
     results["grad kernel " + gp] = {"ms": ms, "rel": float((o["grad_pose"].cpu() - ga).abs().max() / ga.abs().max())}
 fwd_ms, _ = timed(lambda: matching_step_forward(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
 step_ms, out = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
-# the full optimisation step: + regressor weight gradients (HIP) + Adam (torch) + host re-pack of the updated weights
+# the full optimisation step: + regressor weight gradients (HIP) + Adam (torch) + device-side re-pack of the updated weights
 opt = torch.optim.Adam(model.parameters(), lr=1e-7)
 class NoStep:   # gradients only: isolates the weight-gradient kernels from the optimizer / re-pack cost
     def step(self): pass
@@ -69,7 +69,7 @@ wg_ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist,
 full_ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
 print(json.dumps({"workload": f"DFNet_dm step, batch {B}, 240x320, render 60x80 @64+128 + bicubic x4, level-0 feature loss",
                   "forward_ms": fwd_ms, "forward_backward_to_pose_ms": step_ms,
-                  "forward_backward_all_gradients_ms": wg_ms, "full_step_with_adam_and_host_repack_ms": full_ms, "ms_per_frame": step_ms / B,
+                  "forward_backward_all_gradients_ms": wg_ms, "full_step_with_adam_and_device_repack_ms": full_ms, "ms_per_frame": step_ms / B,
                   "loss": float(out["loss"]), "grad_pose_absmax": float(out["grad_pose"].abs().max()),
                   "grad_kernel_modes": {k: v for k, v in results.items() if k.startswith("grad kernel")},
                   "all_fp32_tracked_forward_ms": results["fp32 forward state"]["forward_backward_to_pose_ms"],
