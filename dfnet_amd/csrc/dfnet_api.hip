@@ -625,7 +625,7 @@ extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x
     const int pre_idx = act_idx, in_idx = pre_idx ^ 1;
     CHECK_HIP(launch_relu_gate(1, gbuf[act_idx], w.act[i], nullptr, size_t(B) * hh * ww * sp.cout, gbuf[pre_idx], s), "dfnet params: relu gate");
     const float* g_pre = reinterpret_cast<const float*>(gbuf[pre_idx]);
-    CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, grads[2 * i + 1], s), "dfnet params: bias gradient");
+    CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, pw.part, kWgradPartFloats, grads[2 * i + 1], s), "dfnet params: bias gradient");
     if (i == 0) {
       CHECK_HIP(launch_conv0_wgrad(g_pre, reinterpret_cast<const float*>(w.prep), B, hh, ww, 2 * prep_sb(prec), pw.part, kWgradPartFloats,
                                    grads[0], s),

@@ -187,23 +187,40 @@ hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int
 }
 
 // ------------------------------------------------------------------------------------------ bias gradient
-// db[co] = sum over pixels of g[p][co].  One workgroup per 32-channel block: 8 pixel lanes x 32 positions.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, long long Q, int blks, int cout, float* __restrict__ db) {
+// db[co] = sum over pixels of g[p][co].  Grid = (32-channel block, pixel chunk): 8 pixel lanes x 32 positions per
+// workgroup write a partial; a second kernel adds the chunks in order (deterministic).
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, long long Q, int blks, int n_chunks,
+                                                        float* __restrict__ part) {
   __shared__ float red[8][32];
-  const int pos = threadIdx.x & 31, pl = threadIdx.x >> 5, blk = blockIdx.x;
+  const int pos = threadIdx.x & 31, pl = threadIdx.x >> 5, blk = blockIdx.x, chunk = blockIdx.y;
+  const long long per = (Q + n_chunks - 1) / n_chunks, q0 = chunk * per, q1 = q0 + per < Q ? q0 + per : Q;
   float s = 0.f;
-  for (long long q = pl; q < Q; q += 8) s += g[(q * blks + blk) * 32 + pos];
+  for (long long q = q0 + pl; q < q1; q += 8) s += g[(q * blks + blk) * 32 + pos];
   red[pl][pos] = s;
   __syncthreads();
   if (pl == 0) {
     float t = 0.f;
     for (int i = 0; i < 8; ++i) t += red[i][pos];
-    const int co = 32 * blk + chan_of_pos(pos);
-    if (co < cout) db[co] = t;
+    part[((size_t)chunk * blks + blk) * 32 + pos] = t;
   }
 }
-hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* db, hipStream_t s) {
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(cout / 32), dim3(256), 0, s, g, (long long)B * H * W, cout / 32, cout, db);
+__global__ __launch_bounds__(256) void bias_grad_finalize_kernel(const float* __restrict__ part, int blks, int n_chunks, int cout,
+                                                                 float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= blks * 32) return;
+  float s = 0.f;
+  for (int ch = 0; ch < n_chunks; ++ch) s += part[(size_t)ch * blks * 32 + i];
+  const int co = 32 * (i >> 5) + chan_of_pos(i & 31);
+  if (co < cout) db[co] = s;
+}
+hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* part, size_t part_floats, float* db, hipStream_t s) {
+  const long long Q = (long long)B * H * W;
+  const int blks = cout / 32;
+  long long n_chunks = (Q + 1023) / 1024;
+  if (n_chunks > 512) n_chunks = 512;
+  if ((size_t)n_chunks * blks * 32 > part_floats) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(blks, int(n_chunks)), dim3(256), 0, s, g, Q, blks, int(n_chunks), part);
+  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((blks * 32 + 255) / 256), dim3(256), 0, s, part, blks, int(n_chunks), cout, db);
   return hipGetLastError();
 }
 

@@ -109,19 +109,7 @@ def matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, half_r
                                       **render_kwargs_test)
             rgbs.append(rgb.permute(2, 0, 1))
         rgb = torch.stack(rgbs)
-        feats, _ = inference_pose_regression(args, torch.cat([data, rgb]), device, feat_model, retFeature=True,
-                                             isSingleStream=False, return_pose=False)
-        idx = torch.tensor(args.feature_matching_lvl, device=device)
-        f_t = preprocess_features_for_loss(torch.index_select(feats[0], 0, idx))
-        f_r = preprocess_features_for_loss(torch.index_select(feats[1], 0, idx))
-        feat_l = torch.stack([feature_loss(f_r[b], f_t[b], per_channel=args.per_channel) for b in range(B)]).mean()
-        photo_l = torch.mean((rgb - data) ** 2)
-        pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
-        if getattr(args, "combine_loss", False):
-            w = args.combine_loss_w
-            loss = w[0] * pose_l + w[1] * photo_l + w[2] * feat_l
-        else:
-            loss = feat_l
+        loss, photo_l, feat_l, pose_l = _losses(args, data, rgb, pose_, pose, feat_model, device, parts=True)
         loss.backward()
     with torch.no_grad():
         psnr = -10. * torch.log10(photo_l)
@@ -130,21 +118,27 @@ def matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, half_r
 
 
 
-def _losses(args, data, rgb, pose_, pose, feat_model, device):
+def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False):
     """The loss block of train_on_batch (:350-370) on a tracked rendered batch rgb [B,3,H,W]."""
     B = data.shape[0]
-    feats, _ = inference_pose_regression(args, torch.cat([data, rgb]), device, feat_model, retFeature=True,
-                                         isSingleStream=False, return_pose=False)
+    # The reference feeds cat([data, rgb]) through the siamese forward (:351); images are independent in this network,
+    # so the target half (no gradient) and the rendered half (tracked) are run as two single-stream calls: the
+    # backward then touches only the B rendered images instead of 2 B.
+    with torch.no_grad():
+        ft, _ = inference_pose_regression(args, data, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
+    fr, _ = inference_pose_regression(args, rgb, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
     idx = torch.tensor(args.feature_matching_lvl, device=device)
-    f_t = preprocess_features_for_loss(torch.index_select(feats[0], 0, idx))
-    f_r = preprocess_features_for_loss(torch.index_select(feats[1], 0, idx))
+    f_t = preprocess_features_for_loss(torch.index_select(ft[0], 0, idx))
+    f_r = preprocess_features_for_loss(torch.index_select(fr[0], 0, idx))
     feat_l = torch.stack([feature_loss(f_r[b], f_t[b], per_channel=args.per_channel) for b in range(B)]).mean()
     photo_l = torch.mean((rgb - data) ** 2)
     pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
     if getattr(args, "combine_loss", False):
         w = args.combine_loss_w
-        return w[0] * pose_l + w[1] * photo_l + w[2] * feat_l, photo_l
-    return feat_l, photo_l
+        loss = w[0] * pose_l + w[1] * photo_l + w[2] * feat_l
+    else:
+        loss = feat_l
+    return (loss, photo_l, feat_l, pose_l) if parts else (loss, photo_l)
 
 
 def train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer, half_res, device, world_setup_dict,
