@@ -416,6 +416,7 @@ struct DfBwdWs {
   char* act[13];     // post-ReLU output of every encoder conv (ReLU gates, max-pool routing)
   char* tap[3];      // pre-ReLU taps (inputs of the adaptation layers)
   char *pooled, *tmp64, *g128, *g64, *gtap, *gA, *gB;
+  float* scl;        // [scale, 1/scale] + 1024 partials of launch_absmax_scale (split-f16 gradient convs)
   size_t total;
 };
 DfBwdWs carve_df_bwd(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
@@ -437,6 +438,7 @@ DfBwdWs carve_df_bwd(const dfn_dfnet_s* h, char* base, int prec, int B, int H, i
   w.gtap = take(px * 64 * es);
   w.gA = take(px * 64 * es);
   w.gB = take(px * 64 * es);
+  w.scl = reinterpret_cast<float*>(take((1024 + 8) * 4));
   w.total = off;
   return w;
 }
@@ -486,8 +488,14 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
       ch /= 2; cw /= 2;
     }
   }
-  // ---- backward (split-f16 is a forward-only mode: gradient magnitudes are arbitrary, so its gradient convs run in fp32)
-  const int gprec = prec == 2 ? 1 : prec;
+  // ---- backward.  In split-f16 mode the gradient convs are split-f16 too: gradient magnitudes are arbitrary, so each
+  // conv's input tensor gets a measured power-of-two operand scale (launch_absmax_scale -> ConvArgs::dyn_scale).
+  const int gprec = prec;
+  auto dyn = [&](const void* t, size_t n) -> const float* {
+    if (gprec != 2) return nullptr;
+    (void)launch_absmax_scale(static_cast<const float*>(t), n, w.scl + 8, w.scl, s);
+    return w.scl;
+  };
   const size_t plane = size_t(128) * upH * upW;
   // Two gradient buffers: the ReLU gate runs in place on the buffer holding g_act, the conv's data gradient goes to
   // the other one, and a max-pool's routed gradient reuses the (by then dead) gated buffer.
@@ -510,11 +518,13 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
                 "dfnet bwd: upsample");
       ConvArgs c{};
       c.in = w.g128; c.w = h->ad5_dgrad[t].w[gprec]; c.bias = h->ad5_dgrad[t].bias; c.out_scale = h->ad5_dgrad[t].out_scale; c.out_pre = w.g64;
+      c.dyn_scale = dyn(w.g128, size_t(B) * hh * ww * 128);
       c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
       CHECK_HIP(launch_conv(gprec, 5, 16, c, s), "dfnet bwd: adapt 5x5 dgrad");
       CHECK_HIP(launch_relu_gate(prec, w.g64, w.tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet bwd: adapt gate");
       ConvArgs d{};
       d.in = w.g64; d.w = h->ad1_dgrad[t].w[gprec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
+      d.dyn_scale = dyn(w.g64, size_t(B) * hh * ww * 64);
       d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
       CHECK_HIP(launch_conv(gprec, 1, 16, d, s), "dfnet bwd: adapt 1x1 dgrad");
       g_tap = w.gtap;
@@ -526,6 +536,7 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
     const int cin_p = (sp.cin + 63) / 64 * 64;
     ConvArgs e{};
     e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[gprec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale; e.out_pre = gbuf[in_idx];
+    e.dyn_scale = dyn(gbuf[pre_idx], n_out);
     e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = cin_p / 32; e.relu = 0;
     CHECK_HIP(launch_conv(gprec, 3, 16, e, s), "dfnet bwd: encoder conv dgrad");
     if (i == 0) {
@@ -642,9 +653,14 @@ extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x
                                 grads[2 * i], s),
               "dfnet params: conv weight gradient");
     ConvArgs e{};
-    e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[1]; e.bias = h->enc_dgrad[i].bias; e.out_scale = 1.f; e.out_pre = gbuf[in_idx];
+    e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[prec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale;
+    e.out_pre = gbuf[in_idx];
     e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = ((sp.cin + 63) / 64 * 64) / 32; e.relu = 0;
-    CHECK_HIP(launch_conv(1, 3, 16, e, s), "dfnet params: encoder conv dgrad");
+    if (prec == 2) {  // split-f16 data gradient with a measured operand scale (see dfn_dfnet_backward_input)
+      CHECK_HIP(launch_absmax_scale(g_pre, size_t(B) * hh * ww * sp.cout, w.scl + 8, w.scl, s), "dfnet params: gradient scale");
+      e.dyn_scale = w.scl;
+    }
+    CHECK_HIP(launch_conv(prec, 3, 16, e, s), "dfnet params: encoder conv dgrad");
     if (h->enc[i - 1].pool_after) {
       CHECK_HIP(launch_maxpool_backward(1, w.act[i - 1], gbuf[in_idx], B, lay_h[i - 1], lay_w[i - 1], h->enc[i - 1].cout / 32,
                                         gbuf[pre_idx], s),

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   }
   const char* in = static_cast<const char*>(a.in);
   const int n_slices = a.nblk_in * KS;
+  // operand scale of the input tensor: the fixed activation scale, or (gradient tensors) a measured power of two
+  const float act_scale = a.dyn_scale ? a.dyn_scale[0] : kX3ActScale;
+  const float out_scale = a.dyn_scale ? a.out_scale * kX3ActScale * a.dyn_scale[1] : a.out_scale;
   auto issue_slice = [&](int sl, int buf) {
     const char* wsrc = a.w + ((size_t)cg * n_slices + sl) * WSL + lane * 16;
     for (int q = wave * 1024; q < WSL; q += 4096) conv_lds_dma_b128(wsrc + q, wst + buf * WSL + q);
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
         half4 hi, lo;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float xs = ok ? pre[i][k] * kX3ActScale : 0.f;
+          const float xs = ok ? pre[i][k] * act_scale : 0.f;
           hi[k] = (_Float16)xs;
           lo[k] = (_Float16)(xs - (float)hi[k]);
         }
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
       alignas(16) float act[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pre[r] = acc[mb][nb][r] * a.out_scale;
+        pre[r] = acc[mb][nb][r] * out_scale;
         act[r] = a.relu ? fmaxf(pre[r], 0.f) : pre[r];
       }
       if (a.out_pre) {
@@ -356,6 +359,49 @@ static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
   }
   const int tiles = ((a.H + kConvTileH - 1) / kConvTileH) * ((a.W + kConvTileW - 1) / kConvTileW);
   hipLaunchKernelGGL(kern, dim3(tiles, a.cout_blocks / MB, a.B), dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ tensor scale for split-f16 gradients
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ part) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void absmax_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float mx = red[0];
+    int k = 0;
+    if (mx > 0.f && mx < 3.0e38f) {
+      int e;
+      frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
+      k = 11 - e;              // mx * 2^k in [2^10, 2^11)
+      k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    }
+    out[0] = ldexpf(1.f, k);
+    out[1] = ldexpf(1.f, -k);
+  }
+}
+hipError_t launch_absmax_scale(const float* x, size_t n, float* part, float* out, hipStream_t s) {
+  const int blocks = int((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, x, n, part);
+  hipLaunchKernelGGL(absmax_finalize_kernel, dim3(1), dim3(256), 0, s, part, blocks > 0 ? blocks : 1, out);
   return hipGetLastError();
 }
 

@@ -26,6 +26,8 @@ struct ConvArgs {
   int cout_blocks;     // Cout/32
   int relu;
   float out_scale;     // prec 2 (split-f16): accumulators are multiplied by this before the epilogue (2^-(s+4))
+  const float* dyn_scale;  // prec 2, optional: device [scale, 1/scale] of the INPUT tensor (launch_absmax_scale) replacing
+                           // the fixed x16 activation scale — gradient tensors have no a-priori magnitude
 };
 
 // prec: 0 = f16 MFMA inputs / fp32 accumulate, 1 = exact fp32 MFMA, 2 = split-f16 (hi/lo operands, three f16 MFMAs
@@ -72,6 +74,10 @@ hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float
 // pose head: relu5_3 activations + d pose -> pooled [B,512] (scratch), gradient w.r.t. the activations, fc gradients.
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
                                      float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s);
+
+// out[0] = 2^k with max|x| * 2^k in [2^10, 2^11) (1 if the tensor is all zero), out[1] = 2^-k.  fp32 tensor of n elements;
+// `part` is scratch of >= 1024 floats.
+hipError_t launch_absmax_scale(const float* x, size_t n, float* part, float* out, hipStream_t s);
 
 // device-side re-packing of a conv's fp32 master weights (after an optimizer step): same fragment layouts as the host
 // packers of dfnet_api.hip.  mode 0 = forward conv, 1 = its data-gradient conv (w_cout / w_cin = the forward shape).

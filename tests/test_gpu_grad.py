@@ -202,7 +202,7 @@ def test_dfnet_backward_input_vs_autograd(dfnet, levels, shape, up):
     # torch's own fp32 and fp64 gradients differ by 7e-2 on some inputs of this very test.  With ~2M gated units a
     # flip somewhere is common, so: over three seeded inputs the fp32 path must match the oracle (evaluated in fp32
     # or fp64) to round-off on at least one, and stay within 5e-2 relative L2 on all of them.
-    best = {"f32": 1.0, "f16": 1.0}
+    best = {"f32": 1.0, "f16x3": 1.0, "f16": 1.0}
     for seed in (21, 22, 23):
         rng = np.random.default_rng(seed)
         x0 = rng.uniform(0, 1, shape).astype(np.float32)
@@ -217,16 +217,17 @@ def test_dfnet_backward_input_vs_autograd(dfnet, levels, shape, up):
                                          return_pose=False, upsampleH=up[0], upsampleW=up[1])
             (feats[0] * G.to(dt)).sum().backward()
             refs.append(x.grad)
-        for prec, tol_l2 in (("f32", 5e-2), ("f16", 0.15)):
+        for prec, tol_l2 in (("f32", 5e-2), ("f16x3", 5e-2), ("f16", 0.15)):
             gx = E.backward_input(T(x0).to(DEV), G.to(DEV), levels=levels, precision=prec)
             e = min(relmax(gx, r) for r in refs)
             l2 = min(rel_l2(gx, r) for r in refs)
             print(f"{prec} seed {seed} levels={levels} {shape}: d x {e:.2e}  (L2 {l2:.2e})")
             assert l2 < tol_l2
             best[prec] = min(best[prec], e)
-        if best["f32"] < 5e-5:
+        if best["f32"] < 5e-5 and best["f16x3"] < 5e-5:
             break
-    assert best["f32"] < 5e-5
+    # "f16x3": forward AND gradient convs in split-f16 (gradient tensors scaled by a measured power of two): fp32-grade
+    assert best["f32"] < 5e-5 and best["f16x3"] < 5e-5
 
 
 def test_bicubic_backward_is_the_adjoint():
