@@ -102,6 +102,10 @@ __global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __r
     if (sy > 0.f) { Y0 = max(0, int(floorf(float(y - 1) / sy)) - 1); Y1 = min(UH - 1, int(ceilf(float(y + 1) / sy)) + 1); }
     if (sx > 0.f) { X0 = max(0, int(floorf(float(x - 1) / sx)) - 1); X1 = min(UW - 1, int(ceilf(float(x + 1) / sx)) + 1); }
     const float* plane = gup + b * bstride + (size_t)ch * UH * UW;
+    if (h == UH && w == UW) {   // level 0: the resize is the identity, its adjoint a layout change
+      out[((b * h + y) * (size_t)w + x) * 128 + e128] = (T)plane[(size_t)y * UW + x];
+      continue;
+    }
     float acc = 0.f;
     for (int Y = Y0; Y <= Y1; ++Y) {
       const float fy = sy * float(Y);

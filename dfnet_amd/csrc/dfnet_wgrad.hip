@@ -50,23 +50,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  for (long long q = w0 + k; q < w1 + k; q += 2) {   // every lane of the wave runs the same number of iterations
+  // Two pixel pairs per iteration: all 2 x (1 + T) loads are issued before the first MFMA, so the second pair's
+  // (and, through the other wave of the SIMD, the next iteration's) latency hides under the first pair's MFMAs.
+  auto fetch = [&](long long q, float& a, float (&bv)[T]) {
     const bool live = q < w1;
     const long long qq = live ? q : w0;
     const int x = int(qq % W);
     const long long rr = qq / W;
     const int y = int(rr % H);
     const long long b = rr / H;
-    const float a = live ? g[(qq * mblks + mblk) * 32 + c] : 0.f;
+    a = live ? g[(qq * mblks + mblk) * 32 + c] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
         const int yy = y + ky - R, xx = x + kx - R;
         const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float bv = ok ? in[(((b * H + yy) * (long long)W + xx) * nblks + nblk) * 32 + c] : 0.f;
-        acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * KS + kx], 0, 0, 0);
+        bv[ky * KS + kx] = ok ? in[(((b * H + yy) * (long long)W + xx) * nblks + nblk) * 32 + c] : 0.f;
       }
+  };
+  for (long long q = w0 + k; q < w1 + k; q += 4) {   // every lane of the wave runs the same number of iterations
+    float a0, a1, b0[T], b1[T];
+    fetch(q, a0, b0);
+    fetch(q + 2, a1, b1);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
   }
   // reduce the four waves (fixed order), tap by tap, then one plain store per partial
   float* dst = part + (((size_t)chunk * mblks + mblk) * nblks + nblk) * T * 1024;
