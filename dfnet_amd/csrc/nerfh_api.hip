@@ -59,7 +59,7 @@ struct dfn_nerfh_s {
   bool committed = false;
   PackedNet net[2][3][kVariants];  // [coarse/fine][prec][kernel variant]
   PackedNet bwd[3];                // [prec] fine forward units + backward (W^T) units of the gradient kernel
-                                   // (prec 2: split-f16 forward units, fp32 backward units)
+                                   // (prec 2: split-f16 forward and backward units)
   float* extra = nullptr;  // w_dir^T | b_dir | w_tr^T | b_tr | emb_a | emb_t
   RayBiasWeights rb{};
 };
@@ -305,16 +305,24 @@ struct Packer {
     for (int g = 0; g < group; ++g)
       for (int lane = 0; lane < 64; ++lane)
         for (int kc = 0; kc < KC; ++kc)
-          for (int j = 0; j < P::kSlotsPerChunk; ++j)
-            frag[((size_t(g) * KC + kc) * 64 + lane) * P::kSlotsPerChunk + j] =
-                Elem(bwd_elem(layer, mb0 + g, lane & 31, lane >> 5, kc * P::kSlotsPerChunk + j));
+          for (int j = 0; j < P::kSlotsPerChunk; ++j) {
+            const float v = bwd_elem(layer, mb0 + g, lane & 31, lane >> 5, kc * P::kSlotsPerChunk + j);
+            if constexpr (P::kSplit) {
+              Elem* fr = frag + (size_t(g) * KC + kc) * 64 * 16;   // [hi plane][lo plane], as pack_blocks
+              const Elem hi = Elem(v * wscale);
+              fr[lane * 8 + j] = hi;
+              fr[512 + lane * 8 + j] = Elem(v * wscale - float(hi));
+            } else {
+              frag[((size_t(g) * KC + kc) * 64 + lane) * P::kSlotsPerChunk + j] = Elem(v);
+            }
+          }
   }
   // Blob of the gradient kernel: the fine net's forward layers, one unit per layer (f16) / per M-block (f32),
   // then the backward layers the same way.
   template <class PF, class P>
   void pack_bwd(std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
     pack<PF>(true, (PF::kSlotsPerChunk == 8 && !PF::kSplit) ? 8 : 1, false, blob, tab);
-    const int umb = P::kSlotsPerChunk == 8 ? 8 : 1;
+    const int umb = (P::kSlotsPerChunk == 8 && !P::kSplit) ? 8 : 1;
     for (int layer = 0; layer < BW_COUNT; ++layer) {
       const LayerShape sh = bwd_layer_shape(layer);
       for (int mb0 = 0; mb0 < sh.mb; mb0 += umb) {
@@ -439,7 +447,7 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
     else {
       n.in_scale = h->net[1][2][0].in_scale;   // same per-network weight scale as the split-f16 forward net
       pk.wscale = n.in_scale / kX3ActScale;
-      pk.pack_bwd<PrecX3, PrecF32>(blob, tab);
+      pk.pack_bwd<PrecX3, PrecX3>(blob, tab);
     }
     int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
     if (rc) return rc;

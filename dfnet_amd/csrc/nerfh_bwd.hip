@@ -66,18 +66,49 @@ DFN_DEV void apply_mask(typename FragOf<P>::type (&v)[N], const uint32_t (&m)[(C
     for (int j = 0; j < S; ++j) {
       const int e = c * S + j;
       const bool on = (m[e >> 5] >> (e & 31)) & 1u;
-      static_assert(!P::kSplit, "gradients are not carried in split-f16");
-      if constexpr (S == 8) v[c][j] = on ? v[c][j] : (_Float16)0;
+      if constexpr (P::kSplit) {
+        v[c].hi[j] = on ? v[c].hi[j] : (_Float16)0;
+        v[c].lo[j] = on ? v[c].lo[j] : (_Float16)0;
+      } else if constexpr (S == 8) v[c][j] = on ? v[c][j] : (_Float16)0;
       else v[c] = on ? v[c] : 0.f;
     }
+}
+template <class P>
+DFN_DEV void clear_one(typename FragOf<P>::type& v) {
+  if constexpr (P::kSplit) { v.hi = half8{0, 0, 0, 0, 0, 0, 0, 0}; v.lo = half8{0, 0, 0, 0, 0, 0, 0, 0}; }
+  else if constexpr (P::kSlotsPerChunk == 8) v = half8{0, 0, 0, 0, 0, 0, 0, 0};
+  else v = 0.f;
 }
 template <class P, int N>
 DFN_DEV void clear(typename FragOf<P>::type (&v)[N]) {
 #pragma unroll
   for (int c = 0; c < N; ++c) {
-    static_assert(!P::kSplit, "gradients are not carried in split-f16");
-    if constexpr (P::kSlotsPerChunk == 8) v[c] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (P::kSplit) { v[c].hi = half8{0, 0, 0, 0, 0, 0, 0, 0}; v[c].lo = half8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    else if constexpr (P::kSlotsPerChunk == 8) v[c] = half8{0, 0, 0, 0, 0, 0, 0, 0};
     else v[c] = 0.f;
+  }
+}
+
+// Split-f16 gradient chain: a point's gradient vector is carried as sp * g with a per-point power of two sp (both
+// halves of a point's lanes hold the same sp); every backward layer is linear, so sp rides through the MFMAs and the
+// masks untouched and is divided out of the final 3 + 3 numbers.  Magnitudes drift from layer to layer, so sp is
+// re-centred now and then: this returns the power of two that brings the largest |hi| of `v` to [8, 16) (= sp * g in
+// [0.5, 1) after the x16 operand scale); it is applied to the NEXT layer's outputs (Stager::lane_mul), one layer lagged.
+template <class P, int C, int N>
+DFN_DEV float renorm_factor(const typename FragOf<P>::type (&v)[N]) {
+  if constexpr (!P::kSplit) return 1.f;
+  else {
+    half8 m = __builtin_elementwise_abs(v[0].hi);
+#pragma unroll
+    for (int c = 1; c < C; ++c) m = __builtin_elementwise_max(m, __builtin_elementwise_abs(v[c].hi));
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)m[j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (!(mx > 0.f)) return 1.f;
+    int e;
+    (void)frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.f, 4 - e);
   }
 }
 
@@ -92,8 +123,9 @@ template <class PF, class P> constexpr uint32_t bwd_lds_bytes() { return 3 * bwd
 #define DFN_BLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
   layer<P, UMB, false, NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
 
-// PF: arithmetic of the forward recompute (activations are O(1): split-f16 is safe there), P: arithmetic of the
-// backward chain (gradient magnitudes are arbitrary: fp32, or f16 for the all-f16 mode).
+// PF: arithmetic of the forward recompute, P: arithmetic of the backward chain.  Split-f16 for both is the default:
+// activations are O(1), and the gradient vector of a point is carried with a per-point power-of-two scale that is
+// re-centred every other layer (renorm_factor), so its hi/lo halves stay in f16's normal range.
 template <class PF, class P, bool FAST, int WAVES, int UMBF, int UMB, int NB>
 __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,6 +139,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   st.waves = WAVES;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
+  st.lane_mul = 1.f;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
@@ -141,6 +174,25 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
     const float* const norb[NB] = {};
     f32x16 head[NB], carry[NB];
     uint32_t mk[8][NB][2], md[NB][1], mt[4][NB][1];
+    // split-f16 gradient chain: per-point power-of-two scale sp of the gradient vector (renorm_factor()); 1 otherwise
+    static_assert(!P::kSplit || NB == 1, "the per-lane renormalisation factor is one float: one point block per wave");
+    float sp[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      sp[nb] = 1.f;
+      if constexpr (P::kSplit) {
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) mx = fmaxf(mx, fabsf(g[nb][c]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx > 0.f) {
+          int e;
+          (void)frexpf(mx, &e);
+          sp[nb] = ldexpf(1.f, -e);     // max |d raw| * sp in [0.5, 1)
+        }
+      }
+    }
+    st.lane_mul = 1.f;
 
     // ------------------------------------------------------------------ forward (recording ReLU signs)
     FF hid[NB][FHC];
@@ -183,14 +235,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[7][nb]);
     }
     // heads; their pre-activation gradients seed the backward pass
-    F dth[NB][SC], drgb[NB][SC], dsig[NB][SC];
+    F dth[NB][SC], drgb[NB][SC];
+    float dsig_true[NB];
     {
       FF fin[NB][FHC], dummy[NB][FSC];
       DFN_FLAYER(FHC, 4, true, false, hid, fin, norb);   // xyz_encoding_final + static_sigma (5th M-block)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        clear<P>(dsig[nb]);
-        set_slot<P>(dsig[nb], 0, h == 0 ? g[nb][3] * act_sigmoid<FAST>(head[nb][0]) : 0.f);  // softplus' = sigmoid
+        dsig_true[nb] = h == 0 ? g[nb][3] * act_sigmoid<FAST>(head[nb][0]) : 0.f;  // softplus' = sigmoid
       }
       {
         FF de[NB][FQC];
@@ -204,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float y = act_sigmoid<FAST>(head[nb][c]);
-            set_slot<P>(drgb[nb], c, h == 0 ? g[nb][c] * y * (1.f - y) : 0.f);
+            set_slot<P>(drgb[nb], c, h == 0 ? g[nb][c] * y * (1.f - y) * sp[nb] : 0.f);
           }
         }
       }
@@ -229,10 +281,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float y = act_sigmoid<FAST>(head[nb][c]);
-            set_slot<P>(dth[nb], c, h == 0 ? g[nb][4 + c] * y * (1.f - y) : 0.f);
+            set_slot<P>(dth[nb], c, h == 0 ? g[nb][4 + c] * y * (1.f - y) * sp[nb] : 0.f);
           }
-          set_slot<P>(dth[nb], 3, h == 0 ? g[nb][7] * act_sigmoid<FAST>(head[nb][3]) : 0.f);
-          set_slot<P>(dth[nb], 4, h == 0 ? g[nb][8] * act_sigmoid<FAST>(head[nb][4]) : 0.f);
+          set_slot<P>(dth[nb], 3, h == 0 ? g[nb][7] * act_sigmoid<FAST>(head[nb][3]) * sp[nb] : 0.f);
+          set_slot<P>(dth[nb], 4, h == 0 ? g[nb][8] * act_sigmoid<FAST>(head[nb][4]) * sp[nb] : 0.f);
         }
       }
     }
@@ -267,7 +319,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       F cat2[NB][HC + SC];
       {
         F dfin[NB][HC];
+        if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(cat[0]);   // the two branches share sp up to here
         DFN_BLAYER(HC, 4, true, false, cat, dfin, norb);  // BW_FINCAT: d final + (head) d pe_dir
+        if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           // direction-encoding Jacobian: half h holds frequencies 2h, 2h+1 (pe_dir_feature())
@@ -280,26 +334,33 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
               const float f = float(1 << k) * (h ? 4.f : 1.f);
               acc += f * (cosf(v * f) * head[nb][6 * k + c] - sinf(v * f) * head[nb][6 * k + 3 + c]);
             }
-            gv[nb][c] = acc;
+            gv[nb][c] = acc / sp[nb];   // back to the true scale
           }
 #pragma unroll
           for (int i = 0; i < HC; ++i) cat2[nb][i] = dfin[nb][i];
 #pragma unroll
-          for (int i = 0; i < SC; ++i) cat2[nb][HC + i] = dsig[nb][i];
+          for (int i = 0; i < SC; ++i) clear_one<P>(cat2[nb][HC + i]);
+          set_slot<P>(cat2[nb], 64, dsig_true[nb] * sp[nb]);   // slot 64 of half 0: d sigma_s pre-activation (h == 1 lanes hold 0)
         }
       }
+      if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(cat2[0]);
       DFN_BLAYER(HC + SC, 4, false, false, cat2, gh, norb);  // BW_FIN
+      if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
     }
     F gh2[NB][HC];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[7][nb]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0]);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L8
+    if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[6][nb]);
     DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);          // BW_L7
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[5][nb]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0]);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L6
+    if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[4][nb]);
     // positional-encoding Jacobian of d pe (slot order pe_xyz_feature()), accumulated into gx
@@ -318,17 +379,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float acc = first ? 0.f : gx[nb][c];
+          float acc = 0.f;
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
             const float f = float(1 << k) * (h ? 32.f : 1.f);
             acc += f * (get_slot<PF>(pe[nb], 6 * k + 3 + c) * get_slot<P>(dpe[nb], 6 * k + c) -
                         get_slot<PF>(pe[nb], 6 * k + c) * get_slot<P>(dpe[nb], 6 * k + 3 + c));
           }
-          gx[nb][c] = acc;
+          gx[nb][c] = (first ? 0.f : gx[nb][c]) + acc / sp[nb];
         }
         // raw coordinates: half 0 slots 30, 31 = x, y; half 1 slot 30 = z
-        const float r30 = get_slot<P>(dpe[nb], 30), r31 = get_slot<P>(dpe[nb], 31);
+        const float r30 = get_slot<P>(dpe[nb], 30) / sp[nb], r31 = get_slot<P>(dpe[nb], 31) / sp[nb];
         gx[nb][0] += h == 0 ? r30 : 0.f;
         gx[nb][1] += h == 0 ? r31 : 0.f;
         gx[nb][2] += h == 1 ? r30 : 0.f;
@@ -348,13 +409,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       }
       pe_jacobian(dpe, true);
     }
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0]);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L4
+    if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[2][nb]);
     DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);          // BW_L3
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[1][nb]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0]);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L2
+    if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[0][nb]);
     {
@@ -401,7 +466,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream)
 
 hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream) {
   if (prec == 0) return launch_bwd_one<PrecF16, PrecF16, true, 4, 8, 8, 1>(a, n_cu, stream);
-  if (prec == 2) return launch_bwd_one<PrecX3, PrecF32, false, 4, 1, 1, 1>(a, n_cu, stream);  // split-f16 forward, fp32 gradients
+  if (prec == 2) return launch_bwd_one<PrecX3, PrecX3, false, 4, 1, 1, 1>(a, n_cu, stream);   // split-f16 forward and gradient chain
   return launch_bwd_one<PrecF32, PrecF32, false, 4, 1, 1, 1>(a, n_cu, stream);
 }
 

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   st.waves = WAVES;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
+  st.lane_mul = 1.f;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   st.waves = WAVES;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
+  st.lane_mul = 1.f;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;

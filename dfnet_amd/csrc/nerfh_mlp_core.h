@@ -48,6 +48,7 @@ struct Stager {
   int n_trace;
   bool more;           // another tile follows this one (wave-uniform)
   float in_scale, out_scale;  // split-f16: accumulators carry in_scale x the true value (MlpArgs), out_scale = 1 / in_scale
+  float lane_mul;             // split-f16: extra per-LANE power-of-two factor on the next layer's outputs (gradient renormalisation)
 };
 
 // Direct-to-LDS DMA, issued as inline asm ON PURPOSE.  With the builtin, LLVM cannot tell which LDS bytes a DMA
@@ -402,13 +403,13 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
           } else {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb, st.out_scale);
+            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb, st.out_scale * st.lane_mul);
           }
         } else {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {  // (the M-block before a head is converted during the head's MFMAs)
             head[nb] = acc[nb];
-            if constexpr (P::kSplit) head[nb] *= st.out_scale;
+            if constexpr (P::kSplit) head[nb] *= st.out_scale * st.lane_mul;
           }
         }
       }

@@ -40,7 +40,8 @@ def _engine_of(kwargs):
     return eng
 
 
-GRAD_PRECISION = "f16x3"  # MLP gradient kernel: forward recompute in split-f16 (fp32-grade), gradient chain in fp32 ("f32": all fp32)
+GRAD_PRECISION = "f16x3"  # MLP gradient kernel: forward recompute AND gradient chain in split-f16 (per-point power-of-two
+                          # gradient scale, fp32-grade: parity 6e-7 vs autograd); "f32": all fp32 MFMA
 # Arithmetic of the tracked forward, whose (z_fine, raw) the backward starts from.  None = the engine's own
 # precision (what the user renders with, f16 by default): outputs identical to the untracked render, and in the
 # DFNet_dm step a pose gradient within 7e-6 of the all-fp32 one (tools/gpu_dm_step.py) at 43 instead of 55 ms per
