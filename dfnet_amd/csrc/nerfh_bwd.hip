@@ -466,7 +466,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream)
 
 hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream) {
   if (prec == 0) return launch_bwd_one<PrecF16, PrecF16, true, 4, 8, 8, 1>(a, n_cu, stream);
-  if (prec == 2) return launch_bwd_one<PrecX3, PrecX3, false, 4, 1, 1, 1>(a, n_cu, stream);   // split-f16 forward and gradient chain
+  if (prec == 2) return launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1>(a, n_cu, stream);   // split-f16 forward and gradient chain
   return launch_bwd_one<PrecF32, PrecF32, false, 4, 1, 1, 1>(a, n_cu, stream);
 }
 
