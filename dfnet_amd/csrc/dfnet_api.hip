@@ -32,7 +32,7 @@ struct PackedConv {
   char* w[3] = {nullptr, nullptr, nullptr};  // per precision (2 = split-f16: [hi fragments][lo fragments] per slice)
   float* bias = nullptr;            // [cout/32][2][16]
   float* bias_x3 = nullptr;         // the same, pre-multiplied by the split-f16 operand scale
-  float out_scale = 1.f;            // 2^-(s+4): undoes the split-f16 operand scaling
+  float out_scale = 1.f;            // 1 / (2^s * kConvActScale): undoes the split-f16 operand scaling
 };
 inline size_t elem_size(int prec) { return prec == 0 ? 2 : 4; }  // activations in HBM: f16 only on the f16 path
 
@@ -215,13 +215,13 @@ int pack_and_upload(const float* w, const float* b, int cout, int cin, int ks, b
     pack_conv_x3(w, cout, cin, ks, first, first ? prep_sb(2) : 16, 2, wscale, blob);
     if (int rc = upload_bytes(blob.data(), blob.size(), reinterpret_cast<void**>(&pc.w[2]))) return rc;
   }
-  pc.out_scale = 1.f / (wscale * 16.f);
+  pc.out_scale = 1.f / (wscale * kConvActScale);
   std::vector<float> bias(size_t(cout / 32) * 32), bias3(size_t(cout / 32) * 32);
   for (int m = 0; m < cout / 32; ++m)
     for (int hh = 0; hh < 2; ++hh)
       for (int r = 0; r < 16; ++r) {
         bias[(m * 2 + hh) * 16 + r] = b[32 * m + mblock_row(hh, r)];
-        bias3[(m * 2 + hh) * 16 + r] = b[32 * m + mblock_row(hh, r)] * wscale * 16.f;
+        bias3[(m * 2 + hh) * 16 + r] = b[32 * m + mblock_row(hh, r)] * wscale * kConvActScale;
       }
   if (int rc = upload_bytes(bias3.data(), bias3.size() * 4, reinterpret_cast<void**>(&pc.bias_x3))) return rc;
   return upload_bytes(bias.data(), bias.size() * 4, reinterpret_cast<void**>(&pc.bias));
@@ -691,9 +691,9 @@ extern "C" int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* 
     const bool first = i == 0;
     PackedConv& f = h->enc_packed[i];
     PackedConv& d = h->enc_dgrad[i];
-    const float wscale = 1.f / (f.out_scale * 16.f);
+    const float wscale = 1.f / (f.out_scale * kConvActScale);
     const int cop = (sp.cin + 63) / 64 * 64;
-    const float dscale = 1.f / (d.out_scale * 16.f);
+    const float dscale = 1.f / (d.out_scale * kConvActScale);
     for (int prec = 0; prec < 3; ++prec) {
       const int sb = first ? prep_sb(prec) : 16;
       const int mbf = prec == 2 ? 2 : conv_mb(prec, sp.cout / 32);
@@ -704,7 +704,7 @@ extern "C" int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* 
                 "refresh: dgrad pack");
     }
     CHECK_HIP(launch_pack_bias(params[2 * i + 1], sp.cout, 1.f, f.bias, s), "refresh: bias");
-    CHECK_HIP(launch_pack_bias(params[2 * i + 1], sp.cout, wscale * 16.f, f.bias_x3, s), "refresh: bias (split-f16)");
+    CHECK_HIP(launch_pack_bias(params[2 * i + 1], sp.cout, wscale * kConvActScale, f.bias_x3, s), "refresh: bias (split-f16)");
   }
   CHECK_HIP(hipMemcpyAsync(h->fc, params[2 * n_enc], size_t(h->feat_dim) * 512 * 4, hipMemcpyDeviceToDevice, s), "refresh: fc weight");
   CHECK_HIP(hipMemcpyAsync(h->fc + size_t(h->feat_dim) * 512, params[2 * n_enc + 1], size_t(h->feat_dim) * 4, hipMemcpyDeviceToDevice, s),

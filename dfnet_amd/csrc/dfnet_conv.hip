@@ -174,7 +174,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t stream) {
 // hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-22 relative).  Activations live in HBM as fp32 in the
 // blocked layout and are split while the input patch is staged into two f16 LDS planes; weights are split on the
 // host and staged as [hi fragments][lo fragments].  Both operands are pre-scaled by powers of two (activations
-// x16, weights x2^s per layer, ConvArgs::out_scale = 2^-(s+4) undoes it exactly) so the lo parts stay normal f16.
+// x kConvActScale, weights x2^s per layer, ConvArgs::out_scale undoes it exactly) so the lo parts stay normal f16.
 // The weight slices (one per input block and kernel row) are double-buffered: the DMA of slice s+1 is in flight
 // while slice s is multiplied.
 DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   const char* in = static_cast<const char*>(a.in);
   const int n_slices = a.nblk_in * KS;
   // operand scale of the input tensor: the fixed activation scale, or (gradient tensors) a measured power of two
-  const float act_scale = a.dyn_scale ? a.dyn_scale[0] : kX3ActScale;
-  const float out_scale = a.dyn_scale ? a.out_scale * kX3ActScale * a.dyn_scale[1] : a.out_scale;
+  const float act_scale = a.dyn_scale ? a.dyn_scale[0] : kConvActScale;
+  const float out_scale = a.dyn_scale ? a.out_scale * kConvActScale * a.dyn_scale[1] : a.out_scale;
   auto issue_slice = [&](int sl, int buf) {
     const char* wsrc = a.w + ((size_t)cg * n_slices + sl) * WSL + lane * 16;
     for (int q = wave * 1024; q < WSL; q += 4096) conv_lds_dma_b128(wsrc + q, wst + buf * WSL + q);
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float xs = ok ? pre[i][k] * act_scale : 0.f;
-          hi[k] = (_Float16)xs;
-          lo[k] = (_Float16)(xs - (float)hi[k]);
+          hi[k] = (_Float16)fminf(fmaxf(xs, -65000.f), 65000.f);   // saturate instead of producing inf: the lo half
+          lo[k] = (_Float16)fminf(fmaxf(xs - (float)hi[k], -65000.f), 65000.f);  // then carries up to another 65 000
         }
         *reinterpret_cast<half4*>(plane_hi + pix * PS + seg * 8) = hi;
         *reinterpret_cast<half4*>(plane_lo + pix * PS + seg * 8) = lo;

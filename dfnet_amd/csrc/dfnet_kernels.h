@@ -13,6 +13,10 @@
 
 namespace dfn {
 
+// Split-f16 activation scale of the DFNet convolutions: x4 represents |x| up to 32 500 (hi saturates at 65 000 and
+// the lo half carries the rest; VGG16 activations of trained checkpoints reach the thousands) while the lo halves of
+// O(0.03+) activations stay normal f16.
+constexpr float kConvActScale = 4.f;
 constexpr int kConvTileH = 8, kConvTileW = 32;  // output pixels per workgroup: 4 waves x 2 rows x 32 columns
 
 struct ConvArgs {

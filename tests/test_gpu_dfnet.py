@@ -215,3 +215,20 @@ def test_device_repack_equals_host_commit():
         b, pb = E2.forward(x, True, True, True, 64, 96, precision=prec)
         assert torch.equal(a, b) and torch.equal(pa, pb), prec
         assert torch.equal(E1.backward_input(x, G, precision=prec), E2.backward_input(x, G, precision=prec)), prec
+
+
+def test_split_f16_survives_large_activations():
+    """Trained VGG16 stacks produce activations in the thousands; the split-f16 convs must neither overflow f16 nor lose
+    accuracy there: scale the first conv's weights so that activations reach ~5e3 and compare with the exact-fp32 path."""
+    w = {k: v.copy() for k, v in syn.dfnet_weights(3).items()}
+    w["encoder.0.weight"] *= 2500.0
+    w["encoder.0.bias"] *= 2500.0
+    E = eng.DfnetEngine(3, 12).load_numpy(w)
+    x = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(6)).to(DEV)
+    a, pa = E.forward(x, True, True, True, 64, 96, precision="f16x3")
+    b, pb = E.forward(x, True, True, True, 64, 96, precision="f32")
+    assert bool(torch.isfinite(a).all()) and float(b.abs().max()) > 100.0
+    print("largest feature", float(b.abs().max()))
+    for lvl in range(3):   # two fp32-grade paths against each other at activation magnitudes of several thousand
+        assert relmax(a[lvl], b[lvl].cpu()) < 1e-4, lvl
+    assert relmax(pa, pb.cpu()) < 1e-4
