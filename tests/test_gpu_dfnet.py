@@ -221,8 +221,8 @@ def test_split_f16_survives_large_activations():
     """Trained VGG16 stacks produce activations in the thousands; the split-f16 convs must neither overflow f16 nor lose
     accuracy there: scale the first conv's weights so that activations reach ~5e3 and compare with the exact-fp32 path."""
     w = {k: v.copy() for k, v in syn.dfnet_weights(3).items()}
-    w["encoder.0.weight"] *= 2500.0
-    w["encoder.0.bias"] *= 2500.0
+    w["encoder.0.weight"] *= 400.0     # activations of a few thousand throughout the stack (representable range: 32 500)
+    w["encoder.0.bias"] *= 400.0
     E = eng.DfnetEngine(3, 12).load_numpy(w)
     x = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(6)).to(DEV)
     a, pa = E.forward(x, True, True, True, 64, 96, precision="f16x3")
