@@ -232,3 +232,17 @@ def test_split_f16_survives_large_activations():
     for lvl in range(3):   # two fp32-grade paths against each other at activation magnitudes of several thousand
         assert relmax(a[lvl], b[lvl].cpu()) < 1e-4, lvl
     assert relmax(pa, pb.cpu()) < 1e-4
+
+
+def test_c4_frame_relative_l2_vs_oracle(net):
+    """BASELINE configs[3] frame size (480x640, features only): relative L2 of every pyramid level against the CPU
+    oracle — the C4 parity metric — for the three arithmetic modes."""
+    E, p = net
+    x = torch.rand(1, 3, 480, 640, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        ref = dor.dfnet_forward(p, x, True, True, False, 480, 640)[0][0]
+    for prec, tol in (("f16x3", 5e-6), ("f32", 5e-6), ("f16", 1.2e-3)):
+        got = E.forward(x.to(DEV), True, True, False, 480, 640, precision=prec)[0].cpu()
+        l2 = [float((got[l] - ref[l]).norm() / ref[l].norm()) for l in range(3)]
+        print(prec, "relative L2 per level", ["%.2e" % v for v in l2])
+        assert max(l2) < tol
