@@ -52,6 +52,7 @@ struct dfn_dfnet_s {
   // input-gradient convolutions: the same layers with in/out channels swapped and taps flipped (dgrad = conv)
   std::vector<PackedConv> enc_dgrad, ad1_dgrad, ad5_dgrad;
   float* fc = nullptr;               // fc_w [feat_dim,512] | fc_b
+  std::vector<float*> ad_sc;         // per tap: eval-mode BatchNorm scale gamma / sqrt(var + eps) [128] (device)
 };
 
 static void build_specs(dfn_dfnet_s* h) {
@@ -109,6 +110,8 @@ static void free_dev(dfn_dfnet_s* h) {
   drop(h->ad5_dgrad);
   if (h->fc) (void)hipFree(h->fc);
   h->fc = nullptr;
+  for (float* p : h->ad_sc) if (p) (void)hipFree(p);
+  h->ad_sc.clear();
 }
 
 extern "C" int dfn_dfnet_destroy(dfn_dfnet_t h) {
@@ -273,6 +276,12 @@ extern "C" int dfn_dfnet_commit(dfn_dfnet_t h) {
       b5[co] = (b5[co] - mu[co]) * sc + beta[co];
     }
     if (int rc = pack_and_upload(w5.data(), b5.data(), 128, 64, 5, false, h->ad5[t])) return rc;
+    {
+      std::vector<float> scv(128);
+      for (int co = 0; co < 128; ++co) scv[co] = g[co] / std::sqrt(var[co] + 1e-5f);
+      h->ad_sc.resize(h->n_taps, nullptr);
+      if (int rc = upload_bytes(scv.data(), 128 * 4, reinterpret_cast<void**>(&h->ad_sc[t]))) return rc;
+    }
     h->ad1_dgrad.resize(h->n_taps);
     h->ad5_dgrad.resize(h->n_taps);
     if (int rc = pack_dgrad(h->params[p + ".0.weight"].data(), 64, h->tap_channels[t], 1, h->ad1_dgrad[t])) return rc;
@@ -582,24 +591,30 @@ extern "C" size_t dfn_dfnet_backward_params_workspace_bytes(dfn_dfnet_t h, int p
   return carve_df_params(h, nullptr, prec, B, H, W).total;
 }
 
-extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
-                                         float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: null handle");
-  if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_backward_params: dfn_dfnet_commit() has not been called");
+namespace {
+// Parameter gradients of DFNet for d L/d pose (optional) and d L/d features (optional, single-stream layout, levels by
+// level_mask).  grads: [0, 2 n_enc) encoder conv weight, bias; then fc_pose weight, bias; then (only when n_grads says
+// so) per tap: adapt 1x1 weight [64,C,1,1], bias, adapt 5x5 weight [128,64,5,5], bias — the 5x5's gradients are w.r.t.
+// the UNFOLDED conv parameters under eval-mode (frozen) BatchNorm: folded gradient x gamma / sqrt(var + eps).
+int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
+                         const float* grad_features, int upH, int upW, int level_mask, float* const* grads, int n_grads,
+                         void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn) {
+  if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
+  if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
-    return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_backward_params: parameter gradients need fp32 activations (precision F32 or F16X3)");
+    return set_error(DFN_ERR_UNSUPPORTED, "%s: parameter gradients need fp32 activations (precision F32 or F16X3)", fn);
   const int n_enc = int(h->enc.size());
-  if (!x || !grad_pose || !grads || !workspace || B < 1 || H < 32 || W < 32 || n_grads != 2 * n_enc + 2)
-    return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: bad argument (grads = %d pointers: weight, bias per encoder conv, then fc_pose)",
-                     2 * n_enc + 2);
+  level_mask = grad_features ? (level_mask & ((1 << h->n_taps) - 1)) : 0;
+  const int want = 2 * n_enc + 2 + (grad_features ? 4 * h->n_taps : 0);
+  if (!x || (!grad_pose && !level_mask) || !grads || !workspace || B < 1 || H < 32 || W < 32 || n_grads != want ||
+      (level_mask && (upH < 1 || upW < 1)))
+    return set_error(DFN_ERR_ARG, "%s: bad argument (%d gradient pointers expected)", fn, want);
   for (int i = 0; i < n_grads; ++i)
-    if (!grads[i]) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: null gradient pointer %d", i);
+    if (!grads[i]) return set_error(DFN_ERR_ARG, "%s: null gradient pointer %d", fn, i);
   const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
-  if (pw.total > workspace_bytes)
-    return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: workspace too small (%zu < %zu)", workspace_bytes, pw.total);
+  if (pw.total > workspace_bytes) return set_error(DFN_ERR_ARG, "%s: workspace too small (%zu < %zu)", fn, workspace_bytes, pw.total);
   const DfBwdWs& w = pw.b;
-  hipStream_t s = HS(stream);
-  // ---- forward, keeping every activation (feature/dfnet.py:121-136 with return_pose=True)
+  // ---- forward, keeping every activation (and the pre-ReLU taps of the levels that carry gradient)
   CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet params: prep");
   const void* cur = w.prep;
   int ch = H, cw = W, nblk = 1;
@@ -611,6 +626,7 @@ extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x
     a.in = cur; a.w = h->enc_packed[i].w[prec]; a.bias = prec == 2 ? h->enc_packed[i].bias_x3 : h->enc_packed[i].bias;
     a.out_scale = h->enc_packed[i].out_scale;
     a.out_act = w.act[i];
+    a.out_pre = (sp.tap >= 0 && (level_mask >> sp.tap & 1)) ? w.tap[sp.tap] : nullptr;
     a.B = B; a.H = ch; a.W = cw; a.nblk_in = nblk; a.cout_blocks = sp.cout / 32; a.relu = 1;
     CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet params: encoder conv");
     cur = w.act[i];
@@ -621,20 +637,73 @@ extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x
       ch /= 2; cw /= 2;
     }
   }
-  if (lay_h[n_enc - 1] < 2 || lay_w[n_enc - 1] < 2) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: image too small for pool5");
-  // ---- pose head: fc gradients, gradient w.r.t. relu5_3
   char* gbuf[2] = {w.gA, w.gB};
-  CHECK_HIP(launch_pose_head_backward(reinterpret_cast<const float*>(w.act[n_enc - 1]), B, lay_h[n_enc - 1], lay_w[n_enc - 1], h->fc,
-                                      grad_pose, h->feat_dim, pw.pooled, reinterpret_cast<float*>(gbuf[0]), grads[2 * n_enc],
-                                      grads[2 * n_enc + 1], s),
-            "dfnet params: pose head");
-  int act_idx = 0;
-  // ---- encoder, last conv first
-  for (int i = n_enc - 1; i >= 0; --i) {
+  int act_idx = -1, last = -1;   // act_idx: buffer holding the gradient w.r.t. conv i's ReLU output (none yet)
+  if (grad_pose) {
+    if (lay_h[n_enc - 1] < 2 || lay_w[n_enc - 1] < 2) return set_error(DFN_ERR_ARG, "%s: image too small for pool5", fn);
+    CHECK_HIP(launch_pose_head_backward(reinterpret_cast<const float*>(w.act[n_enc - 1]), B, lay_h[n_enc - 1], lay_w[n_enc - 1], h->fc,
+                                        grad_pose, h->feat_dim, pw.pooled, reinterpret_cast<float*>(gbuf[0]), grads[2 * n_enc],
+                                        grads[2 * n_enc + 1], s),
+              "dfnet params: pose head");
+    act_idx = 0;
+    last = n_enc - 1;
+  } else {
+    CHECK_HIP(hipMemsetAsync(grads[2 * n_enc], 0, size_t(h->feat_dim) * 512 * 4, s), "dfnet params: zero fc gradient");
+    CHECK_HIP(hipMemsetAsync(grads[2 * n_enc + 1], 0, size_t(h->feat_dim) * 4, s), "dfnet params: zero fc gradient");
+    for (int i = 0; i < n_enc; ++i)
+      if (h->enc[i].tap >= 0 && (level_mask >> h->enc[i].tap & 1)) last = i;
+    for (int i = last + 1; i < n_enc; ++i) {   // convs above the deepest level that carries gradient: zero
+      CHECK_HIP(hipMemsetAsync(grads[2 * i], 0, size_t(h->enc[i].cout) * h->enc[i].cin * 9 * 4, s), "dfnet params: zero");
+      CHECK_HIP(hipMemsetAsync(grads[2 * i + 1], 0, size_t(h->enc[i].cout) * 4, s), "dfnet params: zero");
+    }
+  }
+  const size_t plane = size_t(128) * upH * upW;
+  auto dyn = [&](const void* t, size_t n) -> const float* {   // measured operand scale of a gradient tensor (split-f16 convs)
+    if (prec != 2) return nullptr;
+    (void)launch_absmax_scale(static_cast<const float*>(t), n, w.scl + 8, w.scl, s);
+    return w.scl;
+  };
+  // ---- encoder, last conv first; the adaptation layers of a level join at its tap
+  for (int i = last; i >= 0; --i) {
     const ConvSpec& sp = h->enc[i];
     const int hh = lay_h[i], ww = lay_w[i];
-    const int pre_idx = act_idx, in_idx = pre_idx ^ 1;
-    CHECK_HIP(launch_relu_gate(1, gbuf[act_idx], w.act[i], nullptr, size_t(B) * hh * ww * sp.cout, gbuf[pre_idx], s), "dfnet params: relu gate");
+    const void* g_tap = nullptr;
+    if (sp.tap >= 0 && (level_mask >> sp.tap & 1)) {
+      const int t = sp.tap;
+      float* const* ag = grads + 2 * n_enc + 2 + 4 * t;
+      ConvArgs a{};
+      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale;
+      a.out_act = w.tmp64;
+      a.B = B; a.H = hh; a.W = ww; a.nblk_in = sp.cout / 32; a.cout_blocks = 2; a.relu = 1;
+      CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet params: adapt 1x1");
+      CHECK_HIP(launch_upsample_backward(1, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s),
+                "dfnet params: upsample backward");
+      const float* g128 = reinterpret_cast<const float*>(w.g128);
+      CHECK_HIP(launch_bias_grad(g128, B, hh, ww, 128, pw.part, kWgradPartFloats, ag[3], s), "dfnet params: adapt 5x5 bias gradient");
+      CHECK_HIP(launch_conv_wgrad(5, g128, reinterpret_cast<const float*>(w.tmp64), B, hh, ww, 128, 64, pw.part, kWgradPartFloats, ag[2], s),
+                "dfnet params: adapt 5x5 weight gradient");
+      CHECK_HIP(launch_scale_rows(ag[2], 128, 64 * 25, h->ad_sc[t], s), "dfnet params: BatchNorm fold (weight)");
+      CHECK_HIP(launch_scale_rows(ag[3], 128, 1, h->ad_sc[t], s), "dfnet params: BatchNorm fold (bias)");
+      ConvArgs c{};
+      c.in = w.g128; c.w = h->ad5_dgrad[t].w[prec]; c.bias = h->ad5_dgrad[t].bias; c.out_scale = h->ad5_dgrad[t].out_scale; c.out_pre = w.g64;
+      c.dyn_scale = dyn(w.g128, size_t(B) * hh * ww * 128);
+      c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
+      CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet params: adapt 5x5 dgrad");
+      CHECK_HIP(launch_relu_gate(1, w.g64, w.tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet params: adapt gate");
+      const float* g64 = reinterpret_cast<const float*>(w.g64);
+      CHECK_HIP(launch_bias_grad(g64, B, hh, ww, 64, pw.part, kWgradPartFloats, ag[1], s), "dfnet params: adapt 1x1 bias gradient");
+      CHECK_HIP(launch_conv_wgrad(1, g64, reinterpret_cast<const float*>(w.tap[t]), B, hh, ww, 64, sp.cout, pw.part, kWgradPartFloats, ag[0], s),
+                "dfnet params: adapt 1x1 weight gradient");
+      ConvArgs d{};
+      d.in = w.g64; d.w = h->ad1_dgrad[t].w[prec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
+      d.dyn_scale = dyn(w.g64, size_t(B) * hh * ww * 64);
+      d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
+      CHECK_HIP(launch_conv(prec, 1, 16, d, s), "dfnet params: adapt 1x1 dgrad");
+      g_tap = w.gtap;
+    }
+    const int pre_idx = act_idx < 0 ? 0 : act_idx, in_idx = pre_idx ^ 1;
+    CHECK_HIP(launch_relu_gate(1, act_idx < 0 ? nullptr : gbuf[act_idx], w.act[i], g_tap, size_t(B) * hh * ww * sp.cout, gbuf[pre_idx], s),
+              "dfnet params: relu gate");
     const float* g_pre = reinterpret_cast<const float*>(gbuf[pre_idx]);
     CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, pw.part, kWgradPartFloats, grads[2 * i + 1], s), "dfnet params: bias gradient");
     if (i == 0) {
@@ -655,11 +724,8 @@ extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x
     ConvArgs e{};
     e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[prec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale;
     e.out_pre = gbuf[in_idx];
+    e.dyn_scale = dyn(g_pre, size_t(B) * hh * ww * sp.cout);
     e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = ((sp.cin + 63) / 64 * 64) / 32; e.relu = 0;
-    if (prec == 2) {  // split-f16 data gradient with a measured operand scale (see dfn_dfnet_backward_input)
-      CHECK_HIP(launch_absmax_scale(g_pre, size_t(B) * hh * ww * sp.cout, w.scl + 8, w.scl, s), "dfnet params: gradient scale");
-      e.dyn_scale = w.scl;
-    }
     CHECK_HIP(launch_conv(prec, 3, 16, e, s), "dfnet params: encoder conv dgrad");
     if (h->enc[i - 1].pool_after) {
       CHECK_HIP(launch_maxpool_backward(1, w.act[i - 1], gbuf[in_idx], B, lay_h[i - 1], lay_w[i - 1], h->enc[i - 1].cout / 32,
@@ -671,6 +737,22 @@ extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x
     }
   }
   return DFN_OK;
+}
+}  // namespace
+
+extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
+                                         float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grad_pose) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: null grad_pose");
+  return backward_params_core(h, prec, x, B, H, W, grad_pose, nullptr, 0, 0, 0, grads, n_grads, workspace, workspace_bytes, HS(stream),
+                              "dfn_dfnet_backward_params");
+}
+
+extern "C" int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
+                                             const float* grad_features, int upH, int upW, int level_mask, float* const* grads,
+                                             int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grad_features) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_all_params: null grad_features (use dfn_dfnet_backward_params)");
+  return backward_params_core(h, prec, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, grads, n_grads, workspace,
+                              workspace_bytes, HS(stream), "dfn_dfnet_backward_all_params");
 }
 
 // ------------------------------------------------------------------------------------------ device-side parameter refresh

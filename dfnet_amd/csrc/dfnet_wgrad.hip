@@ -30,10 +30,11 @@ __device__ __forceinline__ int chan_of_pos(int e) { return 4 * (e >> 4) + (e & 3
 // g   [B,H,W,MBLK,32]  gradient w.r.t. the conv's pre-activation (fp32, blocked)
 // in  [B,H,W,NBLK,32]  the conv's input (fp32, blocked)
 // part[chunk][mblk][nblk][KS*KS][32 (co position)][32 (ci position)]  partial sums
-template <int KS>
+// TY kernel rows [ky0, ky0 + TY) per launch: 3x3 keeps all nine taps (144 accumulator registers), 5x5 runs row by row.
+template <int KS, int TY>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ in, int B, int H,
-                                                            int W, int mblks, int nblks, int n_chunks, float* __restrict__ part) {
-  constexpr int T = KS * KS, R = KS / 2;
+                                                            int W, int mblks, int nblks, int n_chunks, int ky0, float* __restrict__ part) {
+  constexpr int T = TY * KS, TT = KS * KS, R = KS / 2;
   __shared__ float red[3][16][64];      // waves 1..3 hand their accumulators to wave 0, one tap at a time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, k = lane >> 5;
@@ -61,12 +62,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
     const long long b = rr / H;
     a = live ? g[(qq * mblks + mblk) * 32 + c] : 0.f;
 #pragma unroll
-    for (int ky = 0; ky < KS; ++ky)
+    for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
-        const int yy = y + ky - R, xx = x + kx - R;
+        const int yy = y + ky0 + ty - R, xx = x + kx - R;
         const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        bv[ky * KS + kx] = ok ? in[(((b * H + yy) * (long long)W + xx) * nblks + nblk) * 32 + c] : 0.f;
+        bv[ty * KS + kx] = ok ? in[(((b * H + yy) * (long long)W + xx) * nblks + nblk) * 32 + c] : 0.f;
       }
   };
   for (long long q = w0 + k; q < w1 + k; q += 4) {   // every lane of the wave runs the same number of iterations
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
     for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
   }
   // reduce the four waves (fixed order), tap by tap, then one plain store per partial
-  float* dst = part + (((size_t)chunk * mblks + mblk) * nblks + nblk) * T * 1024;
+  float* dst = part + ((((size_t)chunk * mblks + mblk) * nblks + nblk) * TT + ky0 * KS) * 1024;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     if (wave > 0) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
 hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int H, int W, int cout, int cin, float* part,
                              size_t part_floats, float* dW, hipStream_t s) {
   const int mblks = cout / 32, nblks = cin / 32, T = ks * ks;
-  if (cout % 32 || cin % 32 || (ks != 1 && ks != 3)) return hipErrorInvalidValue;
+  if (cout % 32 || cin % 32 || (ks != 1 && ks != 3 && ks != 5)) return hipErrorInvalidValue;
   const long long Q = (long long)B * H * W;
   const int pairs = mblks * nblks;
   long long n_chunks = 2048 / pairs;                      // ~2048 workgroups
@@ -128,8 +129,11 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
   while (n_chunks > 1 && (size_t)n_chunks * pairs * T * 1024 > part_floats) --n_chunks;
   if ((size_t)n_chunks * pairs * T * 1024 > part_floats) return hipErrorInvalidValue;
   const dim3 grid(pairs, int(n_chunks));
-  if (ks == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), part);
-  else hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), part);
+  if (ks == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, part);
+  else if (ks == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, part);
+  else
+    for (int ky = 0; ky < 5; ++ky)
+      hipLaunchKernelGGL((conv_wgrad_kernel<5, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), ky, part);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const size_t n = (size_t)pairs * T * 1024;
@@ -278,6 +282,17 @@ hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, cons
                                      float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s) {
   hipLaunchKernelGGL(pose_head_backward_kernel, dim3(B), dim3(512), 0, s, act, h, w, fc_w, gpose, feat_dim, pooled, gact);
   hipLaunchKernelGGL(fc_grad_kernel, dim3(feat_dim), dim3(512), 0, s, gpose, pooled, B, feat_dim, dW_fc, db_fc);
+  return hipGetLastError();
+}
+
+// x[r][:] *= sc[r]  (eval-mode BatchNorm fold of the 5x5 adaptation conv's gradients)
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ x, int rows, int rowlen, const float* __restrict__ sc) {
+  const size_t n = (size_t)rows * rowlen;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= sc[i / rowlen];
+}
+hipError_t launch_scale_rows(float* x, int rows, int rowlen, const float* sc, hipStream_t s) {
+  const size_t n = (size_t)rows * rowlen;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(int((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, s, x, rows, rowlen, sc);
   return hipGetLastError();
 }
 

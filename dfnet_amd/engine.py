@@ -274,6 +274,39 @@ class DfnetEngine:
               "dfn_dfnet_backward_params")
         return dict(zip(names, grads))
 
+    def backward_all_params(self, x, grad_pose, grad_features, levels=None, precision=None):
+        """Gradients of BOTH heads w.r.t. every trained parameter under frozen BatchNorm (run_feature.py --freezeBN):
+        the 28 tensors of backward_params plus adapt_layer_<name>.0.weight|bias and .2.weight|bias per pyramid level.
+        grad_pose [B, feat_dim] or None; grad_features single-stream [n_taps, B, 128, uH, uW]."""
+        x, g = _f32c(x), _f32c(grad_features)
+        B, C, H, W = x.shape
+        assert C == 3 and g.shape[:3] == (self.n_taps, B, 128), (x.shape, g.shape)
+        gp = None if grad_pose is None else _f32c(grad_pose).reshape(B, self.feat_dim)
+        mask = sum(1 << int(t) for t in (range(self.n_taps) if levels is None else levels))
+        prec = _lib.PRECISIONS[precision or self.precision]
+        dev = x.device
+        chans, cin, names, grads = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512], 3, [], []
+        for idx, co in zip(self.CONV_INDEX, chans):
+            names += [f"encoder.{idx}.weight", f"encoder.{idx}.bias"]
+            grads += [torch.empty(co, cin, 3, 3, device=dev), torch.empty(co, device=dev)]
+            cin = co
+        names += ["fc_pose.weight", "fc_pose.bias"]
+        grads += [torch.empty(self.feat_dim, 512, device=dev), torch.empty(self.feat_dim, device=dev)]
+        for t, c in zip(range(self.n_taps), (64, 256, 512)):
+            pre = f"adaptation_layers.adapt_layer_{t}"
+            names += [f"{pre}.0.weight", f"{pre}.0.bias", f"{pre}.2.weight", f"{pre}.2.bias"]
+            grads += [torch.zeros(64, c, 1, 1, device=dev), torch.zeros(64, device=dev), torch.zeros(128, 64, 5, 5, device=dev),
+                      torch.zeros(128, device=dev)]   # zeros: levels outside the mask are not written
+        ptrs = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
+        nbytes = self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(self.lib.dfn_dfnet_backward_all_params(self.handle, prec, ptr(x), B, H, W, ptr(gp) if gp is not None else None,
+                                                     ptr(g), g.shape[3], g.shape[4], mask, ptrs, len(grads),
+                                                     ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), current_stream()),
+              "dfn_dfnet_backward_all_params")
+        return dict(zip(names, grads))
+
     def refresh_pose_params_device(self, tensors):
         """Re-pack the pose path's parameters from device tensors (order: encoder.<k>.weight, .bias for the 13 convs,
         fc_pose.weight, fc_pose.bias) — the fast path after an optimizer step."""

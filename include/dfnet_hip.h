@@ -236,6 +236,17 @@ int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, in
                               const float* grad_pose, float* const* grads, int n_grads, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* The same for BOTH heads of DFNet.forward — what training DFNet itself differentiates (run_feature.py:166-230 with
+ * --freezeBN: pose loss + feature loss): grad_pose [B, feat_dim] (may be NULL), grad_features single-stream layout
+ * [n_taps, B, 128, upH, upW] with level_mask as in dfn_dfnet_backward_input.  n_grads = 2 * 13 + 2 + 4 * n_taps: the
+ * pointers of dfn_dfnet_backward_params followed, per pyramid level, by adapt_layer_<t>.0.weight [64,C,1,1], .0.bias,
+ * .2.weight [128,64,5,5], .2.bias.  BatchNorm is frozen (eval statistics, affine not trained): the 5x5's gradients are
+ * those of the unfolded conv parameters. */
+int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W,
+                                  const float* grad_pose, const float* grad_features, int upH, int upW,
+                                  int level_mask, float* const* grads, int n_grads, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* After an optimizer step: re-pack the pose path's parameters (13 encoder convs + fc_pose, forward and data-gradient
  * fragments) from DEVICE fp32 master copies, without the host round trip of set_param + commit.  `params`: HOST
  * array of DEVICE pointers in the order of dfn_dfnet_backward_params.  Adaptation layers are untouched. */
