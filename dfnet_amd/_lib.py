@@ -71,8 +71,11 @@ SIGNATURES = {
     "dfn_dfnet_backward_input": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
     "dfn_dfnet_backward_params_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dfn_dfnet_backward_params": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, POINTER(c_void_p), c_int, _P, c_size_t, _P]),
-    "dfn_dfnet_backward_all_params": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, POINTER(c_void_p), c_int,
-                                              _P, c_size_t, _P]),
+    "dfn_dfnet_forward_train": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t,
+                                        _P]),
+    "dfn_dfnet_backward_all_params": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, POINTER(c_void_p),
+                                              c_int, _P, c_size_t, _P]),
+    "dfn_dfnet_refresh_train_params_device": (c_int, [_P, POINTER(c_void_p), c_int, _P]),
     "dfn_dfnet_refresh_pose_params_device": (c_int, [_P, POINTER(c_void_p), c_int, _P]),
     "dfn_profile_enable": (c_int, [c_int]),
     "dfn_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),

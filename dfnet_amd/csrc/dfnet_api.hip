@@ -52,7 +52,10 @@ struct dfn_dfnet_s {
   // input-gradient convolutions: the same layers with in/out channels swapped and taps flipped (dgrad = conv)
   std::vector<PackedConv> enc_dgrad, ad1_dgrad, ad5_dgrad;
   float* fc = nullptr;               // fc_w [feat_dim,512] | fc_b
-  std::vector<float*> ad_sc;         // per tap: eval-mode BatchNorm scale gamma / sqrt(var + eps) [128] (device)
+  // training DFNet itself (BatchNorm not folded): the plain 5x5 convs, their data-gradient convs, and per tap the
+  // device block [4][128] = gamma, beta, running_mean, running_var
+  std::vector<PackedConv> ad5_raw, ad5_raw_dgrad;
+  std::vector<float*> bn_dev;
 };
 
 static void build_specs(dfn_dfnet_s* h) {
@@ -110,8 +113,10 @@ static void free_dev(dfn_dfnet_s* h) {
   drop(h->ad5_dgrad);
   if (h->fc) (void)hipFree(h->fc);
   h->fc = nullptr;
-  for (float* p : h->ad_sc) if (p) (void)hipFree(p);
-  h->ad_sc.clear();
+  drop(h->ad5_raw);
+  drop(h->ad5_raw_dgrad);
+  for (float* p : h->bn_dev) if (p) (void)hipFree(p);
+  h->bn_dev.clear();
 }
 
 extern "C" int dfn_dfnet_destroy(dfn_dfnet_t h) {
@@ -277,10 +282,17 @@ extern "C" int dfn_dfnet_commit(dfn_dfnet_t h) {
     }
     if (int rc = pack_and_upload(w5.data(), b5.data(), 128, 64, 5, false, h->ad5[t])) return rc;
     {
-      std::vector<float> scv(128);
-      for (int co = 0; co < 128; ++co) scv[co] = g[co] / std::sqrt(var[co] + 1e-5f);
-      h->ad_sc.resize(h->n_taps, nullptr);
-      if (int rc = upload_bytes(scv.data(), 128 * 4, reinterpret_cast<void**>(&h->ad_sc[t]))) return rc;
+      h->ad5_raw.resize(h->n_taps);
+      h->ad5_raw_dgrad.resize(h->n_taps);
+      h->bn_dev.resize(h->n_taps, nullptr);
+      if (int rc = pack_and_upload(h->params[p + ".2.weight"].data(), h->params[p + ".2.bias"].data(), 128, 64, 5, false, h->ad5_raw[t]))
+        return rc;
+      if (int rc = pack_dgrad(h->params[p + ".2.weight"].data(), 128, 64, 5, h->ad5_raw_dgrad[t])) return rc;
+      std::vector<float> bn(g);
+      bn.insert(bn.end(), beta.begin(), beta.end());
+      bn.insert(bn.end(), mu.begin(), mu.end());
+      bn.insert(bn.end(), var.begin(), var.end());
+      if (int rc = upload_bytes(bn.data(), bn.size() * 4, reinterpret_cast<void**>(&h->bn_dev[t]))) return rc;
     }
     h->ad1_dgrad.resize(h->n_taps);
     h->ad5_dgrad.resize(h->n_taps);
@@ -303,6 +315,8 @@ namespace {
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 struct DfWs {
   char *prep, *actA, *actB, *tap[3], *tmp64, *ad128;
+  double* bn_part;   // BatchNorm reductions (dfn_dfnet_forward_train)
+  float* bn_work;
   size_t total;
 };
 DfWs carve_df(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
@@ -318,6 +332,8 @@ DfWs carve_df(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
   for (int t = 0; t < h->n_taps; ++t) w.tap[t] = take(size_t(B) * (H / div[t]) * (W / div[t]) * h->tap_channels[t] * es);
   w.tmp64 = take(px * 64 * es);
   w.ad128 = take(px * 128 * es);
+  w.bn_part = reinterpret_cast<double*>(take(kBnPartBytes));
+  w.bn_work = reinterpret_cast<float*>(take(kBnWorkFloats * 4));
   w.total = off;
   return w;
 }
@@ -335,9 +351,12 @@ extern "C" size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int 
     if (e_ != hipSuccess) return set_error(DFN_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
   } while (0)
 
-extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature,
-                                 int siamese, int return_pose, int upH, int upW, float* features, float* pose,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+// bn_mode 0: inference (BatchNorm folded into the 5x5 convs).  1, 2: training — the plain 5x5 conv, then BatchNorm as
+// an affine map applied by the upsample kernel: 1 = running statistics (frozen), 2 = batch statistics over all B
+// images, written to bn_stats [n_taps][2][128] (mean, biased variance).
+static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature, int siamese,
+                        int return_pose, int upH, int upW, float* features, float* pose, int bn_mode, float* bn_stats,
+                        void* workspace, size_t workspace_bytes, void* stream) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: null handle");
   if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_forward: dfn_dfnet_commit() has not been called");
   if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: unknown precision %d", prec);
@@ -393,18 +412,29 @@ extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B,
       a.B = B; a.H = tap_h[t]; a.W = tap_w[t]; a.nblk_in = h->tap_channels[t] / 32; a.cout_blocks = 2; a.relu = 1;
       CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet: adapt 1x1");
       ConvArgs c{};
-      c.in = w.tmp64; c.w = h->ad5[t].w[prec]; c.bias = prec == 2 ? h->ad5[t].bias_x3 : h->ad5[t].bias; c.out_scale = h->ad5[t].out_scale; c.out_act = w.ad128; c.out_pre = nullptr;
+      const PackedConv& p5 = bn_mode ? h->ad5_raw[t] : h->ad5[t];
+      c.in = w.tmp64; c.w = p5.w[prec]; c.bias = prec == 2 ? p5.bias_x3 : p5.bias; c.out_scale = p5.out_scale; c.out_act = w.ad128; c.out_pre = nullptr;
       c.B = B; c.H = tap_h[t]; c.W = tap_w[t]; c.nblk_in = 2; c.cout_blocks = 4; c.relu = 0;
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet: adapt 5x5");
+      const float* affine = nullptr;
+      if (bn_mode == 1) {
+        CHECK_HIP(launch_bn_running_stats(h->bn_dev[t], 1e-5f, w.bn_work, s), "dfnet: BatchNorm running statistics");
+        affine = w.bn_work;
+      } else if (bn_mode == 2) {
+        CHECK_HIP(launch_bn_batch_stats(reinterpret_cast<const float*>(w.ad128), (long long)B * tap_h[t] * tap_w[t], h->bn_dev[t], 1e-5f,
+                                        w.bn_part, w.bn_work, bn_stats + size_t(t) * 256, bn_stats + size_t(t) * 256 + 128, s),
+                  "dfnet: BatchNorm batch statistics");
+        affine = w.bn_work;
+      }
       if (!siamese) {
-        CHECK_HIP(launch_upsample(prec, w.ad128, B, tap_h[t], tap_w[t], upH, upW, features + size_t(t) * B * plane, plane, s),
+        CHECK_HIP(launch_upsample(prec, w.ad128, B, tap_h[t], tap_w[t], upH, upW, features + size_t(t) * B * plane, plane, s, affine),
                   "dfnet: upsample");
       } else {
         const int hb = B / 2;
         for (int half = 0; half < 2; ++half) {
           const char* src = w.ad128 + size_t(half) * hb * tap_h[t] * tap_w[t] * 128 * es;
           float* dst = features + (size_t(half) * h->n_taps + t) * hb * plane;
-          CHECK_HIP(launch_upsample(prec, src, hb, tap_h[t], tap_w[t], upH, upW, dst, plane, s), "dfnet: upsample");
+          CHECK_HIP(launch_upsample(prec, src, hb, tap_h[t], tap_w[t], upH, upW, dst, plane, s, affine), "dfnet: upsample");
         }
       }
     }
@@ -418,6 +448,23 @@ extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B,
   return DFN_OK;
 }
 
+extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature,
+                                 int siamese, int return_pose, int upH, int upW, float* features, float* pose,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  return forward_core(h, prec, x, B, H, W, return_feature, siamese, return_pose, upH, upW, features, pose, 0, nullptr, workspace,
+                      workspace_bytes, stream);
+}
+
+extern "C" int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose,
+                                       int bn_batch, int upH, int upW, float* features, float* pose, float* bn_stats,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (bn_batch && !bn_stats) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward_train: null bn_stats");
+  if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
+    return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_forward_train: batch statistics need fp32 activations (precision F32 or F16X3)");
+  return forward_core(h, prec, x, B, H, W, 1, siamese, return_pose, upH, upW, features, pose, bn_batch ? 2 : 1, bn_stats, workspace,
+                      workspace_bytes, stream);
+}
+
 // ------------------------------------------------------------------------------------------ input gradient
 namespace {
 struct DfBwdWs {
@@ -425,6 +472,9 @@ struct DfBwdWs {
   char* act[13];     // post-ReLU output of every encoder conv (ReLU gates, max-pool routing)
   char* tap[3];      // pre-ReLU taps (inputs of the adaptation layers)
   char *pooled, *tmp64, *g128, *g64, *gtap, *gA, *gB;
+  char* z128;        // unfolded 5x5 output of the level being processed (training BatchNorm)
+  double* bn_part;   // fp64 chunk partials of the BatchNorm reductions
+  float* bn_work;    // kBnWorkFloats
   float* scl;        // [scale, 1/scale] + 1024 partials of launch_absmax_scale (split-f16 gradient convs)
   size_t total;
 };
@@ -572,6 +622,9 @@ constexpr size_t kWgradPartFloats = size_t(2048) * 9 * 1024;   // partial sums o
 struct DfParamWs {
   DfBwdWs b;
   float *part, *pooled;
+  float* z128;       // plain 5x5 output of the level being processed (BatchNorm backward)
+  double* bn_part;
+  float* bn_work;
   size_t total;
 };
 DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
@@ -581,6 +634,9 @@ DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return reinterpret_cast<float*>(p); };
   w.part = take(kWgradPartFloats * 4);
   w.pooled = take(size_t(B) * 512 * 4);
+  w.z128 = take(size_t(B) * H * W * 128 * 4);
+  w.bn_part = reinterpret_cast<double*>(take(kBnPartBytes));
+  w.bn_work = take(kBnWorkFloats * 4);
   w.total = off;
   return w;
 }
@@ -594,18 +650,19 @@ extern "C" size_t dfn_dfnet_backward_params_workspace_bytes(dfn_dfnet_t h, int p
 namespace {
 // Parameter gradients of DFNet for d L/d pose (optional) and d L/d features (optional, single-stream layout, levels by
 // level_mask).  grads: [0, 2 n_enc) encoder conv weight, bias; then fc_pose weight, bias; then (only when n_grads says
-// so) per tap: adapt 1x1 weight [64,C,1,1], bias, adapt 5x5 weight [128,64,5,5], bias — the 5x5's gradients are w.r.t.
-// the UNFOLDED conv parameters under eval-mode (frozen) BatchNorm: folded gradient x gamma / sqrt(var + eps).
+// so) per tap: adapt 1x1 weight [64,C,1,1], bias, adapt 5x5 weight [128,64,5,5], bias (the plain conv parameters, not
+// the BatchNorm-folded ones) and, with bn_batch (BatchNorm on batch statistics), BatchNorm weight and bias.
 int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
-                         const float* grad_features, int upH, int upW, int level_mask, float* const* grads, int n_grads,
-                         void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn) {
+                         const float* grad_features, int upH, int upW, int level_mask, int bn_batch, float* const* grads,
+                         int n_grads, void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn) {
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
     return set_error(DFN_ERR_UNSUPPORTED, "%s: parameter gradients need fp32 activations (precision F32 or F16X3)", fn);
   const int n_enc = int(h->enc.size());
   level_mask = grad_features ? (level_mask & ((1 << h->n_taps) - 1)) : 0;
-  const int want = 2 * n_enc + 2 + (grad_features ? 4 * h->n_taps : 0);
+  const int per_tap = bn_batch ? 6 : 4;
+  const int want = 2 * n_enc + 2 + (grad_features ? per_tap * h->n_taps : 0);
   if (!x || (!grad_pose && !level_mask) || !grads || !workspace || B < 1 || H < 32 || W < 32 || n_grads != want ||
       (level_mask && (upH < 1 || upW < 1)))
     return set_error(DFN_ERR_ARG, "%s: bad argument (%d gradient pointers expected)", fn, want);
@@ -670,7 +727,8 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
     const void* g_tap = nullptr;
     if (sp.tap >= 0 && (level_mask >> sp.tap & 1)) {
       const int t = sp.tap;
-      float* const* ag = grads + 2 * n_enc + 2 + 4 * t;
+      float* const* ag = grads + 2 * n_enc + 2 + per_tap * t;
+      const long long Q = (long long)B * hh * ww;
       ConvArgs a{};
       a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale;
       a.out_act = w.tmp64;
@@ -678,14 +736,28 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet params: adapt 1x1");
       CHECK_HIP(launch_upsample_backward(1, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s),
                 "dfnet params: upsample backward");
+      // BatchNorm backward: d L/d y -> d L/d z (z = the plain 5x5 output), in place
+      if (bn_batch) {
+        ConvArgs z{};
+        z.in = w.tmp64; z.w = h->ad5_raw[t].w[prec]; z.bias = prec == 2 ? h->ad5_raw[t].bias_x3 : h->ad5_raw[t].bias;
+        z.out_scale = h->ad5_raw[t].out_scale; z.out_act = pw.z128;
+        z.B = B; z.H = hh; z.W = ww; z.nblk_in = 2; z.cout_blocks = 4; z.relu = 0;
+        CHECK_HIP(launch_conv(prec, 5, 16, z, s), "dfnet params: adapt 5x5");
+        CHECK_HIP(launch_bn_batch_stats(pw.z128, Q, h->bn_dev[t], 1e-5f, pw.bn_part, pw.bn_work, nullptr, nullptr, s),
+                  "dfnet params: BatchNorm batch statistics");
+      } else {
+        CHECK_HIP(launch_bn_running_stats(h->bn_dev[t], 1e-5f, pw.bn_work, s), "dfnet params: BatchNorm running statistics");
+      }
+      CHECK_HIP(launch_bn_backward(bn_batch, reinterpret_cast<float*>(w.g128), pw.z128, Q, pw.bn_part, pw.bn_work, bn_batch ? ag[4] : nullptr,
+                                   bn_batch ? ag[5] : nullptr, s),
+                "dfnet params: BatchNorm backward");
       const float* g128 = reinterpret_cast<const float*>(w.g128);
       CHECK_HIP(launch_bias_grad(g128, B, hh, ww, 128, pw.part, kWgradPartFloats, ag[3], s), "dfnet params: adapt 5x5 bias gradient");
       CHECK_HIP(launch_conv_wgrad(5, g128, reinterpret_cast<const float*>(w.tmp64), B, hh, ww, 128, 64, pw.part, kWgradPartFloats, ag[2], s),
                 "dfnet params: adapt 5x5 weight gradient");
-      CHECK_HIP(launch_scale_rows(ag[2], 128, 64 * 25, h->ad_sc[t], s), "dfnet params: BatchNorm fold (weight)");
-      CHECK_HIP(launch_scale_rows(ag[3], 128, 1, h->ad_sc[t], s), "dfnet params: BatchNorm fold (bias)");
       ConvArgs c{};
-      c.in = w.g128; c.w = h->ad5_dgrad[t].w[prec]; c.bias = h->ad5_dgrad[t].bias; c.out_scale = h->ad5_dgrad[t].out_scale; c.out_pre = w.g64;
+      const PackedConv& d5 = h->ad5_raw_dgrad[t];
+      c.in = w.g128; c.w = d5.w[prec]; c.bias = d5.bias; c.out_scale = d5.out_scale; c.out_pre = w.g64;
       c.dyn_scale = dyn(w.g128, size_t(B) * hh * ww * 128);
       c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet params: adapt 5x5 dgrad");
@@ -743,16 +815,16 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
 extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
                                          float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
   if (!grad_pose) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: null grad_pose");
-  return backward_params_core(h, prec, x, B, H, W, grad_pose, nullptr, 0, 0, 0, grads, n_grads, workspace, workspace_bytes, HS(stream),
-                              "dfn_dfnet_backward_params");
+  return backward_params_core(h, prec, x, B, H, W, grad_pose, nullptr, 0, 0, 0, 0, grads, n_grads, workspace, workspace_bytes,
+                              HS(stream), "dfn_dfnet_backward_params");
 }
 
 extern "C" int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
-                                             const float* grad_features, int upH, int upW, int level_mask, float* const* grads,
-                                             int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
+                                             const float* grad_features, int upH, int upW, int level_mask, int bn_batch,
+                                             float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
   if (!grad_features) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_all_params: null grad_features (use dfn_dfnet_backward_params)");
-  return backward_params_core(h, prec, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, grads, n_grads, workspace,
-                              workspace_bytes, HS(stream), "dfn_dfnet_backward_all_params");
+  return backward_params_core(h, prec, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, bn_batch != 0, grads, n_grads,
+                              workspace, workspace_bytes, HS(stream), "dfn_dfnet_backward_all_params");
 }
 
 // ------------------------------------------------------------------------------------------ device-side parameter refresh
@@ -760,36 +832,56 @@ extern "C" int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const floa
 // and data-gradient fragments, all three arithmetic modes) and fc_pose on the device.  `params`: HOST array of
 // 2 * 13 + 2 DEVICE pointers in the order of dfn_dfnet_backward_params.  The split-f16 weight scale of each conv is
 // kept from dfn_dfnet_commit (weights move slowly under fine-tuning; re-commit from the host to re-derive it).
-extern "C" int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream) {
-  if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_refresh_pose_params_device: null handle");
-  if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_refresh_pose_params_device: dfn_dfnet_commit() has not been called");
+namespace {
+// Re-pack one convolution (forward fragments and data-gradient fragments, all three arithmetic modes) from device fp32
+// master weights; the split-f16 weight scales are kept from dfn_dfnet_commit.
+int refresh_conv(PackedConv& f, PackedConv& d, const float* wt, const float* bias, int cout, int cin, int ks, bool first, hipStream_t s) {
+  const float wscale = 1.f / (f.out_scale * kConvActScale);
+  const int cop = (cin + 63) / 64 * 64;
+  const float dscale = 1.f / (d.out_scale * kConvActScale);
+  for (int prec = 0; prec < 3; ++prec) {
+    const int sb = first ? prep_sb(prec) : 16;
+    const int mbf = prec == 2 ? 2 : conv_mb(prec, cout / 32);
+    CHECK_HIP(launch_pack_conv(prec, wt, cout, cin, ks, first, sb, mbf, 0, cout, cin, wscale, f.w[prec], s), "refresh: forward pack");
+    const int mbd = prec == 2 ? 2 : conv_mb(prec, cop / 32);
+    CHECK_HIP(launch_pack_conv(prec, wt, cop, cout, ks, 0, 16, mbd, 1, cout, cin, dscale, d.w[prec], s), "refresh: dgrad pack");
+  }
+  CHECK_HIP(launch_pack_bias(bias, cout, 1.f, f.bias, s), "refresh: bias");
+  CHECK_HIP(launch_pack_bias(bias, cout, wscale * kConvActScale, f.bias_x3, s), "refresh: bias (split-f16)");
+  return DFN_OK;
+}
+
+int refresh_core(dfn_dfnet_t h, const float* const* params, int n_params, bool with_adapt, hipStream_t s, const char* fn) {
+  if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
+  if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   const int n_enc = int(h->enc.size());
-  if (!params || n_params != 2 * n_enc + 2) return set_error(DFN_ERR_ARG, "dfn_dfnet_refresh_pose_params_device: need %d pointers", 2 * n_enc + 2);
+  const int want = 2 * n_enc + 2 + (with_adapt ? 8 * h->n_taps : 0);
+  if (!params || n_params != want) return set_error(DFN_ERR_ARG, "%s: need %d pointers", fn, want);
   for (int i = 0; i < n_params; ++i)
-    if (!params[i]) return set_error(DFN_ERR_ARG, "dfn_dfnet_refresh_pose_params_device: null pointer %d", i);
-  hipStream_t s = HS(stream);
+    if (!params[i]) return set_error(DFN_ERR_ARG, "%s: null pointer %d", fn, i);
   for (int i = 0; i < n_enc; ++i) {
     const ConvSpec& sp = h->enc[i];
-    const bool first = i == 0;
-    PackedConv& f = h->enc_packed[i];
-    PackedConv& d = h->enc_dgrad[i];
-    const float wscale = 1.f / (f.out_scale * kConvActScale);
-    const int cop = (sp.cin + 63) / 64 * 64;
-    const float dscale = 1.f / (d.out_scale * kConvActScale);
-    for (int prec = 0; prec < 3; ++prec) {
-      const int sb = first ? prep_sb(prec) : 16;
-      const int mbf = prec == 2 ? 2 : conv_mb(prec, sp.cout / 32);
-      CHECK_HIP(launch_pack_conv(prec, params[2 * i], sp.cout, sp.cin, 3, first, sb, mbf, 0, sp.cout, sp.cin, wscale, f.w[prec], s),
-                "refresh: forward pack");
-      const int mbd = prec == 2 ? 2 : conv_mb(prec, cop / 32);
-      CHECK_HIP(launch_pack_conv(prec, params[2 * i], cop, sp.cout, 3, 0, 16, mbd, 1, sp.cout, sp.cin, dscale, d.w[prec], s),
-                "refresh: dgrad pack");
-    }
-    CHECK_HIP(launch_pack_bias(params[2 * i + 1], sp.cout, 1.f, f.bias, s), "refresh: bias");
-    CHECK_HIP(launch_pack_bias(params[2 * i + 1], sp.cout, wscale * kConvActScale, f.bias_x3, s), "refresh: bias (split-f16)");
+    if (int rc = refresh_conv(h->enc_packed[i], h->enc_dgrad[i], params[2 * i], params[2 * i + 1], sp.cout, sp.cin, 3, i == 0, s)) return rc;
   }
   CHECK_HIP(hipMemcpyAsync(h->fc, params[2 * n_enc], size_t(h->feat_dim) * 512 * 4, hipMemcpyDeviceToDevice, s), "refresh: fc weight");
   CHECK_HIP(hipMemcpyAsync(h->fc + size_t(h->feat_dim) * 512, params[2 * n_enc + 1], size_t(h->feat_dim) * 4, hipMemcpyDeviceToDevice, s),
             "refresh: fc bias");
+  if (!with_adapt) return DFN_OK;
+  for (int t = 0; t < h->n_taps; ++t) {
+    const float* const* ap = params + 2 * n_enc + 2 + 8 * t;
+    if (int rc = refresh_conv(h->ad1[t], h->ad1_dgrad[t], ap[0], ap[1], 64, h->tap_channels[t], 1, false, s)) return rc;
+    if (int rc = refresh_conv(h->ad5_raw[t], h->ad5_raw_dgrad[t], ap[2], ap[3], 128, 64, 5, false, s)) return rc;
+    for (int k = 0; k < 4; ++k)   // gamma, beta, running_mean, running_var
+      CHECK_HIP(hipMemcpyAsync(h->bn_dev[t] + 128 * k, ap[4 + k], 128 * 4, hipMemcpyDeviceToDevice, s), "refresh: BatchNorm");
+  }
   return DFN_OK;
+}
+}  // namespace
+
+extern "C" int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream) {
+  return refresh_core(h, params, n_params, false, HS(stream), "dfn_dfnet_refresh_pose_params_device");
+}
+
+extern "C" int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream) {
+  return refresh_core(h, params, n_params, true, HS(stream), "dfn_dfnet_refresh_train_params_device");
 }

@@ -501,7 +501,7 @@ hipError_t launch_maxpool(int prec, const void* in, int B, int H, int W, int nbl
 // output pixel and 32-channel block; lanes run along X so every fp32 NCHW plane row is written coalesced.
 template <class T>
 __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ in, int B, int h, int w, int UH, int UW,
-                                                       float* __restrict__ out, size_t out_bstride) {
+                                                       float* __restrict__ out, size_t out_bstride, const float* __restrict__ affine) {
   const float sy = UH > 1 ? float(h - 1) / float(UH - 1) : 0.f;
   const float sx = UW > 1 ? float(w - 1) / float(UW - 1) : 0.f;
   const size_t n = (size_t)B * 4 * UH * UW;
@@ -535,19 +535,20 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ in,
       for (int k = 0; k < V; ++k) {
         const int e = q * V + k, hh = e >> 4, s = e & 15;
         const int ch = 4 * hh + (s & 3) + 8 * (s >> 2);
-        const float v = wy0 * (wx0 * (float)a00[k] + lx * (float)a01[k]) + ly * (wx0 * (float)a10[k] + lx * (float)a11[k]);
+        float v = wy0 * (wx0 * (float)a00[k] + lx * (float)a01[k]) + ly * (wx0 * (float)a10[k] + lx * (float)a11[k]);
+        if (affine) v = fmaf(v, affine[kBnSc + blk * 32 + e], affine[kBnSh + blk * 32 + e]);
         o[(size_t)ch * UH * UW] = v;
       }
     }
   }
 }
 hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH, int UW, float* out,
-                           size_t out_bstride, hipStream_t stream) {
+                           size_t out_bstride, hipStream_t stream, const float* affine) {
   const size_t n = (size_t)B * 4 * UH * UW;
   if (!n) return hipSuccess;
   const int grid = int((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-  if (prec == 0) hipLaunchKernelGGL(upsample_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, static_cast<const _Float16*>(in), B, h, w, UH, UW, out, out_bstride);
-  else hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<const float*>(in), B, h, w, UH, UW, out, out_bstride);
+  if (prec == 0) hipLaunchKernelGGL(upsample_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, static_cast<const _Float16*>(in), B, h, w, UH, UW, out, out_bstride, affine);
+  else hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<const float*>(in), B, h, w, UH, UW, out, out_bstride, affine);
   return hipGetLastError();
 }
 

@@ -46,8 +46,22 @@ int prep_sb(int prec);
 // 2x2/2 max pooling on the blocked layout: [B,H,W,nblk,32] -> [B,H/2,W/2,nblk,32].
 hipError_t launch_maxpool(int prec, const void* in, int B, int H, int W, int nblk, void* out, hipStream_t stream);
 // bilinear, align_corners=True, blocked [B,h,w,4,32] T -> fp32 NCHW planes out[b*out_bstride + c*UH*UW + Y*UW + X].
+// affine (optional, fp32 paths): device sc[128] | sh[128] in stored-position order, out = resize(in) * sc + sh — the
+// BatchNorm of a training-mode adaptation layer (dfnet_bn.hip); bilinear weights sum to one, so the order is free.
 hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH, int UW, float* out,
-                           size_t out_bstride, hipStream_t stream);
+                           size_t out_bstride, hipStream_t stream, const float* affine = nullptr);
+
+// BatchNorm work block of one pyramid level: device floats in stored-position order.
+constexpr int kBnSc = 0, kBnSh = 128, kBnMean = 256, kBnRstd = 384, kBnMg = 512, kBnMgx = 640, kBnWorkFloats = 768;
+constexpr int kBnMaxChunks = 1024;   // fp64 partials: [chunk][2][128]
+constexpr size_t kBnPartBytes = size_t(kBnMaxChunks) * 2 * 128 * 8;
+// bn: device [4][128] gamma, beta, running_mean, running_var (channel order).  z: blocked [Q,4,32] fp32.
+hipError_t launch_bn_batch_stats(const float* z, long long Q, const float* bn, float eps, double* part, float* bw, float* mean_out,
+                                 float* var_out, hipStream_t s);
+hipError_t launch_bn_running_stats(const float* bn, float eps, float* bw, hipStream_t s);
+// g (d L/d y, blocked) -> d L/d z in place; batch != 0 also writes d gamma, d beta [128] (channel order).
+hipError_t launch_bn_backward(int batch, float* g, const float* z, long long Q, double* part, float* bw, float* dgamma, float* dbeta,
+                              hipStream_t s);
 // pose head: relu'd conv5_3 activations [B,h,w,16,32] -> maxpool2 -> global mean -> fc [feat_dim,512].
 hipError_t launch_pose_head(int prec, const void* act, int B, int h, int w, const float* fc_w, const float* fc_b,
                             int feat_dim, float* pose, hipStream_t stream);
@@ -74,7 +88,6 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
 // conv1_1: input = the prep output (pix_stride floats per pixel, RGB first), g has 64 channels; dW [64][3][3][3].
 hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int W, int pix_stride, float* part, size_t part_floats,
                               float* dW, hipStream_t s);
-hipError_t launch_scale_rows(float* x, int rows, int rowlen, const float* sc, hipStream_t s);
 hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* part, size_t part_floats, float* db, hipStream_t s);
 // pose head: relu5_3 activations + d pose -> pooled [B,512] (scratch), gradient w.r.t. the activations, fc gradients.
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,

@@ -285,17 +285,6 @@ hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, cons
   return hipGetLastError();
 }
 
-// x[r][:] *= sc[r]  (eval-mode BatchNorm fold of the 5x5 adaptation conv's gradients)
-__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ x, int rows, int rowlen, const float* __restrict__ sc) {
-  const size_t n = (size_t)rows * rowlen;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= sc[i / rowlen];
-}
-hipError_t launch_scale_rows(float* x, int rows, int rowlen, const float* sc, hipStream_t s) {
-  const size_t n = (size_t)rows * rowlen;
-  hipLaunchKernelGGL(scale_rows_kernel, dim3(int((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, s, x, rows, rowlen, sc);
-  return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------ device-side weight packer
 // After an optimizer step the fp32 master weights live in device memory; these kernels re-create the packed MFMA
 // fragments (dfnet_api.hip: pack_conv / pack_conv_x3 / pack_dgrad, same index maps) without a host round trip.

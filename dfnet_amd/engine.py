@@ -274,9 +274,48 @@ class DfnetEngine:
               "dfn_dfnet_backward_params")
         return dict(zip(names, grads))
 
-    def backward_all_params(self, x, grad_pose, grad_features, levels=None, precision=None):
-        """Gradients of BOTH heads w.r.t. every trained parameter under frozen BatchNorm (run_feature.py --freezeBN):
-        the 28 tensors of backward_params plus adapt_layer_<name>.0.weight|bias and .2.weight|bias per pyramid level.
+    def forward_train(self, x, isSingleStream=False, return_pose=True, bn_batch=True, upsampleH=240, upsampleW=427,
+                      precision=None):
+        """DFNet.forward while the module is being trained: (features, pose, bn_stats).  bn_batch: BatchNorm on the
+        statistics of this batch (train() mode) — bn_stats [n_taps, 2, 128] = batch mean, biased variance — or on its
+        running statistics (--freezeBN; bn_stats None)."""
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        assert C == 3
+        prec = _lib.PRECISIONS[precision or self.precision]
+        dev = x.device
+        shape = (self.n_taps, B, 128, upsampleH, upsampleW) if isSingleStream else (2, self.n_taps, B // 2, 128, upsampleH, upsampleW)
+        feats = torch.empty(shape, device=dev)
+        pose = torch.empty(B, self.feat_dim, device=dev) if return_pose else None
+        stats = torch.empty(self.n_taps, 2, 128, device=dev) if bn_batch else None
+        nbytes = self.lib.dfn_dfnet_workspace_bytes(self.handle, prec, B, H, W)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(self.lib.dfn_dfnet_forward_train(self.handle, prec, ptr(x), B, H, W, int(not isSingleStream), int(return_pose),
+                                               int(bool(bn_batch)), int(upsampleH), int(upsampleW), ptr(feats), ptr(pose), ptr(stats),
+                                               ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), current_stream()),
+              "dfn_dfnet_forward_train")
+        if not isSingleStream:
+            feats = (feats[0], feats[1])
+        return feats, pose, stats
+
+    def train_param_names(self, bn_affine=True):
+        """state_dict keys in the order of backward_all_params' gradients."""
+        names = []
+        for idx in self.CONV_INDEX:
+            names += [f"encoder.{idx}.weight", f"encoder.{idx}.bias"]
+        names += ["fc_pose.weight", "fc_pose.bias"]
+        for t in range(self.n_taps):
+            pre = f"adaptation_layers.adapt_layer_{t}"
+            names += [f"{pre}.0.weight", f"{pre}.0.bias", f"{pre}.2.weight", f"{pre}.2.bias"]
+            if bn_affine:
+                names += [f"{pre}.3.weight", f"{pre}.3.bias"]
+        return names
+
+    def backward_all_params(self, x, grad_pose, grad_features, levels=None, bn_batch=False, precision=None):
+        """Gradients of BOTH heads w.r.t. every trained parameter (run_feature.py:166-230): dict keyed as
+        train_param_names(bn_affine=bn_batch).  bn_batch False: BatchNorm frozen on its running statistics
+        (--freezeBN); True: batch statistics, with the gradients of BatchNorm's weight and bias.
         grad_pose [B, feat_dim] or None; grad_features single-stream [n_taps, B, 128, uH, uW]."""
         x, g = _f32c(x), _f32c(grad_features)
         B, C, H, W = x.shape
@@ -285,27 +324,35 @@ class DfnetEngine:
         mask = sum(1 << int(t) for t in (range(self.n_taps) if levels is None else levels))
         prec = _lib.PRECISIONS[precision or self.precision]
         dev = x.device
-        chans, cin, names, grads = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512], 3, [], []
-        for idx, co in zip(self.CONV_INDEX, chans):
-            names += [f"encoder.{idx}.weight", f"encoder.{idx}.bias"]
-            grads += [torch.empty(co, cin, 3, 3, device=dev), torch.empty(co, device=dev)]
+        names = self.train_param_names(bn_affine=bn_batch)
+        chans, cin, shapes = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512], 3, []
+        for co in chans:
+            shapes += [(co, cin, 3, 3), (co,)]
             cin = co
-        names += ["fc_pose.weight", "fc_pose.bias"]
-        grads += [torch.empty(self.feat_dim, 512, device=dev), torch.empty(self.feat_dim, device=dev)]
+        shapes += [(self.feat_dim, 512), (self.feat_dim,)]
         for t, c in zip(range(self.n_taps), (64, 256, 512)):
-            pre = f"adaptation_layers.adapt_layer_{t}"
-            names += [f"{pre}.0.weight", f"{pre}.0.bias", f"{pre}.2.weight", f"{pre}.2.bias"]
-            grads += [torch.zeros(64, c, 1, 1, device=dev), torch.zeros(64, device=dev), torch.zeros(128, 64, 5, 5, device=dev),
-                      torch.zeros(128, device=dev)]   # zeros: levels outside the mask are not written
+            shapes += [(64, c, 1, 1), (64,), (128, 64, 5, 5), (128,)] + ([(128,), (128,)] if bn_batch else [])
+        n_pose = 2 * len(chans) + 2
+        # zeros for the adaptation layers: levels outside the mask are not written
+        grads = [torch.empty(sh, device=dev) if i < n_pose else torch.zeros(sh, device=dev) for i, sh in enumerate(shapes)]
         ptrs = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
         nbytes = self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W)
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(self.lib.dfn_dfnet_backward_all_params(self.handle, prec, ptr(x), B, H, W, ptr(gp) if gp is not None else None,
-                                                     ptr(g), g.shape[3], g.shape[4], mask, ptrs, len(grads),
-                                                     ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), current_stream()),
+        check(self.lib.dfn_dfnet_backward_all_params(self.handle, prec, ptr(x), B, H, W, ptr(gp), ptr(g), g.shape[3], g.shape[4], mask,
+                                                     int(bool(bn_batch)), ptrs, len(grads), ctypes.c_void_p(self._ws.data_ptr()),
+                                                     self._ws.numel(), current_stream()),
               "dfn_dfnet_backward_all_params")
         return dict(zip(names, grads))
+
+    def refresh_train_params_device(self, tensors):
+        """Re-pack every tensor the training path reads from device tensors: train_param_names(True) with, per level,
+        .3.running_mean and .3.running_var after .3.bias.  The folded inference weights are NOT updated."""
+        ts = [_f32c(t) for t in tensors]
+        assert len(ts) == 28 + 8 * self.n_taps and all(t.is_cuda for t in ts)
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        check(self.lib.dfn_dfnet_refresh_train_params_device(self.handle, ptrs, len(ts), current_stream()),
+              "dfn_dfnet_refresh_train_params_device")
 
     def refresh_pose_params_device(self, tensors):
         """Re-pack the pose path's parameters from device tensors (order: encoder.<k>.weight, .bias for the 13 convs,

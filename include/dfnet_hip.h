@@ -236,16 +236,40 @@ int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, in
                               const float* grad_pose, float* const* grads, int n_grads, void* workspace,
                               size_t workspace_bytes, void* stream);
 
-/* The same for BOTH heads of DFNet.forward — what training DFNet itself differentiates (run_feature.py:166-230 with
- * --freezeBN: pose loss + feature loss): grad_pose [B, feat_dim] (may be NULL), grad_features single-stream layout
- * [n_taps, B, 128, upH, upW] with level_mask as in dfn_dfnet_backward_input.  n_grads = 2 * 13 + 2 + 4 * n_taps: the
- * pointers of dfn_dfnet_backward_params followed, per pyramid level, by adapt_layer_<t>.0.weight [64,C,1,1], .0.bias,
- * .2.weight [128,64,5,5], .2.bias.  BatchNorm is frozen (eval statistics, affine not trained): the 5x5's gradients are
- * those of the unfolded conv parameters. */
+/* ---- training DFNet itself (run_feature.py:166-230): both heads, BatchNorm not folded.
+ *
+ * dfn_dfnet_forward_train: DFNet.forward while the module is being trained.  Outputs as dfn_dfnet_forward with
+ * return_feature = 1.  The 5x5 adaptation convs run unfolded, followed by the BatchNorm2d:
+ *   bn_batch = 1  train() mode: statistics of this batch (all B images, i.e. both streams of a siamese batch,
+ *                 dfnet.py:131-143); bn_stats [n_taps][2][128] receives batch mean and BIASED batch variance per level
+ *                 (the caller moves running_mean / running_var: momentum 0.1, unbiased variance)
+ *   bn_batch = 0  --freezeBN (BatchNorm modules in eval(), utils.py:30-39): running statistics; bn_stats may be NULL.
+ *                 Same values as dfn_dfnet_forward, but from the weights dfn_dfnet_refresh_train_params_device keeps
+ *                 current.
+ * Workspace: dfn_dfnet_workspace_bytes.  Precision F32 or F16X3. */
+int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese,
+                            int return_pose, int bn_batch, int upH, int upW, float* features, float* pose,
+                            float* bn_stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Parameter gradients of both heads: grad_pose [B, feat_dim] (may be NULL), grad_features single-stream layout
+ * [n_taps, B, 128, upH, upW] with level_mask as in dfn_dfnet_backward_input.  The pointers of
+ * dfn_dfnet_backward_params are followed, per pyramid level, by adapt_layer_<t>.0.weight [64,C,1,1], .0.bias,
+ * .2.weight [128,64,5,5], .2.bias and — bn_batch != 0 only — .3.weight, .3.bias [128]:
+ *   bn_batch = 0  BatchNorm frozen on its running statistics (--freezeBN); n_grads = 2 * 13 + 2 + 4 * n_taps
+ *   bn_batch = 1  batch statistics, the backward of dfn_dfnet_forward_train;  n_grads = 2 * 13 + 2 + 6 * n_taps
+ * Gradients of levels outside level_mask are left untouched (zero them beforehand).  Workspace:
+ * dfn_dfnet_backward_params_workspace_bytes. */
 int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W,
                                   const float* grad_pose, const float* grad_features, int upH, int upW,
-                                  int level_mask, float* const* grads, int n_grads, void* workspace,
+                                  int level_mask, int bn_batch, float* const* grads, int n_grads, void* workspace,
                                   size_t workspace_bytes, void* stream);
+
+/* After an optimizer step of DFNet's own training: re-pack encoder, fc_pose, the adaptation convs (unfolded) and the
+ * BatchNorm tensors from DEVICE tensors — 2 * 13 + 2 + 8 * n_taps pointers: those of dfn_dfnet_backward_params, then
+ * per level .0.weight, .0.bias, .2.weight, .2.bias, .3.weight, .3.bias, .3.running_mean, .3.running_var.  The
+ * BatchNorm-FOLDED inference weights used by dfn_dfnet_forward are
+ * NOT touched: re-commit from the host (dfn_dfnet_set_param + dfn_dfnet_commit) before evaluating. */
+int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream);
 
 /* After an optimizer step: re-pack the pose path's parameters (13 encoder convs + fc_pose, forward and data-gradient
  * fragments) from DEVICE fp32 master copies, without the host round trip of set_param + commit.  `params`: HOST

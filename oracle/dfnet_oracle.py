@@ -45,11 +45,17 @@ def encoder_taps(p, x, taps=(2, 14, 28), stop_after_last_tap=True):
     return feats, x
 
 
-def adapt(p, i, f, eps=1e-5):
-    """Conv1x1 -> ReLU -> Conv5x5(pad 2) -> BatchNorm2d in eval mode (dfnet.py:57-62)."""
+def adapt(p, i, f, eps=1e-5, bn_stats=None):
+    """Conv1x1 -> ReLU -> Conv5x5(pad 2) -> BatchNorm2d (dfnet.py:57-62).  bn_stats None: eval mode (running
+    statistics).  A list: train() mode — batch statistics (nn.BatchNorm2d.forward with training=True); the batch mean
+    and BIASED variance of this level are appended to it (the module then moves running_mean / running_var by
+    momentum 0.1 towards mean / unbiased variance)."""
     pre = f"adaptation_layers.adapt_layer_{i}"
     f = torch.relu(F.conv2d(f, p[pre + ".0.weight"], p[pre + ".0.bias"]))
     f = F.conv2d(f, p[pre + ".2.weight"], p[pre + ".2.bias"], padding=2)
+    if bn_stats is not None:
+        bn_stats.append((f.detach().mean((0, 2, 3)), f.detach().var((0, 2, 3), unbiased=False)))
+        return F.batch_norm(f, None, None, p[pre + ".3.weight"], p[pre + ".3.bias"], training=True, eps=eps)
     return F.batch_norm(f, p[pre + ".3.running_mean"], p[pre + ".3.running_var"],
                         p[pre + ".3.weight"], p[pre + ".3.bias"], training=False, eps=eps)
 
@@ -60,15 +66,15 @@ def upsample(f, H, W):
 
 
 def dfnet_forward(p, x, return_feature=False, isSingleStream=False, return_pose=True,
-                  upsampleH=240, upsampleW=427, taps=(2, 14, 28)):
-    """(feature_maps | None, predict | None) exactly as DFNet.forward (dfnet.py:109-172)."""
+                  upsampleH=240, upsampleW=427, taps=(2, 14, 28), bn_stats=None):
+    """(feature_maps | None, predict | None) exactly as DFNet.forward (dfnet.py:109-172); bn_stats: see adapt()."""
     mean = x.new_tensor(MEAN)[:, None, None]
     std = x.new_tensor(STD)[:, None, None]
     x = (x - mean) / std
     feats, last = encoder_taps(p, x, taps, stop_after_last_tap=not return_pose)
     maps = None
     if return_feature:
-        ad = [adapt(p, i, f) for i, f in enumerate(feats)]
+        ad = [adapt(p, i, f, bn_stats=bn_stats) for i, f in enumerate(feats)]
         if isSingleStream:
             maps = [torch.stack([upsample(f, upsampleH, upsampleW) for f in ad])]
         else:

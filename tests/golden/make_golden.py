@@ -270,6 +270,55 @@ def main():
         fs, ps = net_s(t(x), return_feature=True, isSingleStream=True, return_pose=True, upsampleH=32, upsampleW=48)
         save("g8_dfnet_s_small", x=x, cstride=8, single=fs[0][:, :, ::8], pose=ps, single_l2=nrm(fs[0]))
 
+    # ---------------- G10: one training step of DFNet itself (run_feature.py:166-230): train() mode and --freezeBN
+    def grad_digest(net):
+        out = {}
+        for k, q in net.named_parameters():
+            if q.grad is None:
+                continue
+            flat = q.grad.reshape(-1)
+            out["gn:" + k] = flat.norm()
+            out["gs:" + k] = flat[:: max(1, flat.numel() // 256)][:256].clone()
+        return out
+
+    # --freezeBN (utils/utils.py:18-39; that module's other imports — torchvision.utils, matplotlib — are absent here,
+    # so its two helpers' effect is applied to the reference module directly): BatchNorm affine without grad, and the
+    # BatchNorm modules back in eval() after net.train().
+    def freeze_bn_layer(m):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.requires_grad_(False)
+                mod.bias.requires_grad_(False)
+        return m
+
+    def freeze_bn_layer_train(m):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.eval()
+        return m
+
+    r10 = np.random.default_rng(1010)   # the cotangents are regenerated from this seed by the tests (2.9 MB each)
+    xb = r10.uniform(0, 1, (4, 3, 32, 48)).astype(np.float32)
+    Gt = r10.standard_normal((3, 2, 128, 24, 40)).astype(np.float32)
+    Gr = r10.standard_normal((3, 2, 128, 24, 40)).astype(np.float32)
+    Gp = r10.standard_normal((4, 12)).astype(np.float32)
+    for mode in ("train", "freezebn"):
+        net = ref_dfnet.DFNet()
+        load_into(net, syn.dfnet_weights(seed=3))
+        if mode == "freezebn":
+            net = freeze_bn_layer(net)
+        net.train()
+        if mode == "freezebn":
+            net = freeze_bn_layer_train(net)
+        feats, pose = net(t(xb), return_feature=True, isSingleStream=False, return_pose=True, upsampleH=24, upsampleW=40)
+        ((feats[0] * t(Gt)).sum() + (feats[1] * t(Gr)).sum() + (pose * t(Gp)).sum()).backward()
+        bn = {}
+        for i in range(3):
+            m = getattr(net.adaptation_layers, "adapt_layer_%d" % i)[3]
+            bn["rm%d" % i], bn["rv%d" % i] = m.running_mean.clone(), m.running_var.clone()
+        save("g10_dfnet_train_" + mode, seed=1010, x=xb, Gp=Gp, Gt_l2=np.sqrt((Gt ** 2).sum()), Gr_l2=np.sqrt((Gr ** 2).sum()), cstride=8, feat_t=feats[0][:, :, ::8], feat_r=feats[1][:, :, ::8],
+             pose=pose, **bn, **grad_digest(net))
+
 
 if __name__ == "__main__":
     main()

@@ -11,6 +11,8 @@ torch autograd through the CPU oracle.  Tolerances, relative to the largest grad
   * f16-input MFMA path: 1e-1 max / 3e-2 relative L2.  A hidden unit whose pre-activation is within f16
     rounding of zero flips its ReLU gate, which changes that sample's gradient by O(1/width); this is
     inherent to f16 activations, not an accumulation error, and is why the host defaults to fp32 here."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,6 +24,7 @@ from oracle import nerfh_oracle as orc
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = {"f32": 2e-4, "f16x3": 2e-4, "f16": 1e-1}
 TOL_NET = {"f32": 1e-5, "f16x3": 1e-5, "f16": 1e-1}
 TOL_L2 = {"f32": 1e-5, "f16x3": 1e-5, "f16": 3e-2}
@@ -320,43 +323,97 @@ def test_dfnet_parameter_gradients_vs_autograd(dfnet, shape):
     assert best < 5e-5
 
 
-@pytest.mark.parametrize("with_pose", [True, False])
-def test_dfnet_all_parameter_gradients_vs_autograd(dfnet, with_pose):
-    """Training DFNet itself with frozen BatchNorm (run_feature.py --freezeBN): gradients of every trained tensor (13
-    encoder convs, fc_pose, 1x1 and 5x5 adaptation convs of the three levels) for
+@pytest.mark.parametrize("bn_batch,with_pose", [(False, True), (False, False), (True, True), (True, False)])
+def test_dfnet_all_parameter_gradients_vs_autograd(dfnet, bn_batch, with_pose):
+    """Training DFNet itself (run_feature.py:166-230): train() mode (BatchNorm on batch statistics, affine trained) and
+    --freezeBN.  Features / pose / batch statistics of the training forward and the gradients of every trained tensor
+    (13 encoder convs, fc_pose, 1x1 and 5x5 adaptation convs [+ BatchNorm affine] of the three levels) for
     loss = sum(features * Gf) [+ sum(pose * Gp)], vs torch autograd through the CPU oracle."""
     from oracle import dfnet_oracle as dor
     E, p = dfnet
     shape, uH, uW = (2, 3, 48, 64), 24, 40
     best = 1.0
-    trained = lambda k: k.endswith(("weight", "bias")) and ".3." not in k
+    trained = lambda k: k.endswith(("weight", "bias")) and (bn_batch or ".3." not in k)
     for seed in (41, 42, 43):
         rng = np.random.default_rng(seed)
         x = T(rng.uniform(0, 1, shape).astype(np.float32))
         Gf = T(rng.standard_normal((3, shape[0], 128, uH, uW)).astype(np.float32))
         Gp = T(rng.standard_normal((shape[0], 12)).astype(np.float32)) if with_pose else None
         pp = {k: v.clone().requires_grad_(trained(k)) for k, v in p.items()}
-        maps, pose = dor.dfnet_forward(pp, x, True, True, with_pose, uH, uW)
+        stats = [] if bn_batch else None
+        maps, pose = dor.dfnet_forward(pp, x, True, True, with_pose, uH, uW, bn_stats=stats)
         loss = (maps[0] * Gf).sum()
         if with_pose:
             loss = loss + (pose * Gp).sum()
         loss.backward()
-        got = E.backward_all_params(x.to(DEV), None if Gp is None else Gp.to(DEV), Gf.to(DEV), precision="f16x3")
-        assert len(got) == 40
+        f, po, st = E.forward_train(x.to(DEV), True, with_pose, bn_batch, uH, uW, precision="f16x3")
+        assert rel_l2(f, maps[0].detach()) < 5e-6 and relmax(f, maps[0].detach()) < 2e-5
+        if with_pose:
+            assert relmax(po, pose.detach()) < 1e-5
+        if bn_batch:
+            for t in range(3):
+                assert relmax(st[t, 0], stats[t][0]) < 1e-5 and relmax(st[t, 1], stats[t][1]) < 1e-5
+        else:
+            assert st is None
+        got = E.backward_all_params(x.to(DEV), None if Gp is None else Gp.to(DEV), Gf.to(DEV), bn_batch=bn_batch, precision="f16x3")
+        assert len(got) == (46 if bn_batch else 40)
         worst = 0.0
         for k, g in got.items():
             ref = pp[k].grad if pp[k].grad is not None else torch.zeros_like(pp[k])
             if float(ref.abs().max()) == 0.0:
                 assert float(g.abs().max()) == 0.0, k
                 continue
+            if bn_batch and "adapt" in k and k.endswith(".2.bias"):   # d L/d bias of a conv followed by batch-statistics BatchNorm is exactly 0:
+                assert float(g.abs().max()) < 1e-3 * float(got[k.replace(".2.bias", ".3.bias")].abs().max()), k   # rounding noise only
+                continue
             e = relmax(g, ref)
             worst = max(worst, e)
             assert rel_l2(g, ref) < 5e-2, (k, rel_l2(g, ref))
-        print(f"seed {seed} pose={with_pose}: worst parameter-gradient error {worst:.2e}")
+        print(f"seed {seed} bn_batch={bn_batch} pose={with_pose}: worst parameter-gradient error {worst:.2e}")
         best = min(best, worst)
         if best < 5e-5:
             break
     assert best < 5e-5
+
+
+@pytest.mark.parametrize("mode", ["train", "freezebn"])
+def test_dfnet_training_step_vs_reference_golden(mode):
+    """The same step against the numbers captured from the reference's DFNet module itself (G10: siamese batch, train()
+    and --freezeBN): features, pose, batch statistics -> running-statistics update, gradient norms and samples."""
+    from dfnet_amd.engine import DfnetEngine
+    g = np.load(os.path.join(GOLD, f"g10_dfnet_train_{mode}.npz"))
+    r10 = np.random.default_rng(int(g["seed"]))
+    x = r10.uniform(0, 1, (4, 3, 32, 48)).astype(np.float32)
+    Gt = r10.standard_normal((3, 2, 128, 24, 40)).astype(np.float32)
+    Gr = r10.standard_normal((3, 2, 128, 24, 40)).astype(np.float32)
+    wts = syn.dfnet_weights(seed=3)
+    E = DfnetEngine(3, 12, "f16x3").load_numpy(wts)
+    batch = mode == "train"
+    xd = T(x).to(DEV)
+    (ft, fr), pose, st = E.forward_train(xd, False, True, batch, 24, 40)
+    cs = int(g["cstride"])
+    assert relmax(ft[:, :, ::cs], g["feat_t"]) < 5e-5 and relmax(fr[:, :, ::cs], g["feat_r"]) < 5e-5
+    assert relmax(pose, g["pose"]) < 2e-5
+    for t in range(3):
+        pre = f"adaptation_layers.adapt_layer_{t}.3."
+        rm, rv = T(wts[pre + "running_mean"]), T(wts[pre + "running_var"])
+        if batch:
+            q = 4 * 32 * 48 // 16 ** t
+            rm, rv = 0.9 * rm + 0.1 * st[t, 0].cpu(), 0.9 * rv + 0.1 * st[t, 1].cpu() * q / (q - 1)
+        assert relmax(rm, g[f"rm{t}"]) < 1e-5 and relmax(rv, g[f"rv{t}"]) < 1e-5
+    Gf = torch.cat([T(Gt), T(Gr)], 1).contiguous().to(DEV)   # siamese halves in batch order
+    got = E.backward_all_params(xd, T(g["Gp"]).to(DEV), Gf, bn_batch=batch)
+    n = 0
+    for k, v in got.items():
+        flat = v.reshape(-1).cpu()
+        ref_n = float(g["gn:" + k])
+        if batch and "adapt" in k and k.endswith(".2.bias"):
+            continue   # exactly zero in exact arithmetic; the reference's value is rounding noise too
+        assert abs(float(flat.norm()) - ref_n) <= 5e-4 * ref_n, (k, float(flat.norm()), ref_n)
+        sub = flat[:: max(1, flat.numel() // 256)][:256]
+        assert float((sub - T(g["gs:" + k])).abs().max()) <= 2e-3 * float(np.abs(g["gs:" + k]).max()), k
+        n += 1
+    assert n == (43 if batch else 40)
 
 
 def test_dfnet_module_trains_pose_path():

@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/*.py) to the reference: every comparison here is against
 numbers captured from the reference's own modules by tests/golden/make_golden.py."""
 import numpy as np
+import pytest
 import torch
 
 from dfnet_amd import synthetic as syn
@@ -142,3 +143,47 @@ def test_g8_dfnet(gold):
         maps, pose = dor.dfnet_forward(ps, x, True, True, True, 32, 48, taps=(2,))
         close(maps[0][:, :, ::cs], gs["single"], 1e-4, 1e-5)
         close(pose, gs["pose"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("mode", ["train", "freezebn"])
+def test_g10_dfnet_training_step(gold, mode):
+    """One training step of the reference's DFNet (train() mode: BatchNorm on batch statistics; --freezeBN: running
+    statistics, affine frozen): features, pose, running-statistics update and every parameter gradient."""
+    g = gold("g10_dfnet_train_" + mode)
+    r10 = np.random.default_rng(int(g["seed"]))
+    x = r10.uniform(0, 1, (4, 3, 32, 48)).astype(np.float32)
+    Gt = r10.standard_normal((3, 2, 128, 24, 40)).astype(np.float32)
+    Gr = r10.standard_normal((3, 2, 128, 24, 40)).astype(np.float32)
+    assert np.array_equal(x, g["x"]) and abs(float(np.sqrt((Gt ** 2).sum())) - float(g["Gt_l2"])) < 1e-3
+    p = tt(syn.dfnet_weights(seed=3))
+    frozen = mode == "freezebn"
+    trained = lambda k: k.endswith(("weight", "bias")) and not (frozen and ".3." in k)
+    pp = {k: v.clone().requires_grad_(trained(k)) for k, v in p.items()}
+    stats = None if frozen else []
+    maps, pose = dor.dfnet_forward(pp, T(g["x"]), True, False, True, 24, 40, bn_stats=stats)
+    cs = int(g["cstride"])
+    close(maps[0][:, :, ::cs], g["feat_t"], 1e-4, 2e-5)
+    close(maps[1][:, :, ::cs], g["feat_r"], 1e-4, 2e-5)
+    close(pose, g["pose"], 1e-4, 1e-5)
+    ((maps[0] * T(Gt)).sum() + (maps[1] * T(Gr)).sum() + (pose * T(g["Gp"])).sum()).backward()
+    n = 4 * 32 * 48
+    for i in range(3):
+        rm, rv = p[f"adaptation_layers.adapt_layer_{i}.3.running_mean"], p[f"adaptation_layers.adapt_layer_{i}.3.running_var"]
+        if not frozen:
+            q = n // (16 ** i)
+            mean, var = stats[i]
+            rm, rv = 0.9 * rm + 0.1 * mean, 0.9 * rv + 0.1 * var * q / (q - 1)
+        close(rm, g[f"rm{i}"], 1e-5, 1e-6)
+        close(rv, g[f"rv{i}"], 1e-5, 1e-6)
+    n_checked = 0
+    for k, v in pp.items():
+        if "gn:" + k not in g:
+            assert v.grad is None, k
+            continue
+        flat = v.grad.reshape(-1)
+        ref_n = float(g["gn:" + k])
+        assert abs(float(flat.norm()) - ref_n) <= 2e-4 * ref_n + 1e-6, (k, float(flat.norm()), ref_n)
+        sub = flat[:: max(1, flat.numel() // 256)][:256]
+        close(sub, g["gs:" + k], 0, 3e-4 * max(float(np.abs(g["gs:" + k]).max()), 1e-6))
+        n_checked += 1
+    assert n_checked == (40 if frozen else 46)
