@@ -13,6 +13,13 @@ that feature path the module's own weights are treated as frozen.  The POSE path
 return_feature=False) is differentiable w.r.t. its parameters instead: encoder convs + fc_pose, by the HIP
 weight-gradient kernels (dfn_dfnet_backward_params) — the regressor DFNet_dm trains.
 
+Training DFNet itself (run_feature.py:166-230): with grad enabled, return_feature=True, an input
+without grad and parameters that require grad, both heads are differentiable w.r.t. every trained tensor (encoder,
+fc_pose, adaptation convs, BatchNorm affine) through dfn_dfnet_forward_train / dfn_dfnet_backward_all_params.  The
+BatchNorm layers follow their own train()/eval() flag exactly as nn.BatchNorm2d does: train() = statistics of the
+batch (running statistics updated with momentum 0.1), eval() under model.train() = --freezeBN
+(utils/utils.py:30-39).
+
 torchvision's pretrained VGG16 weights (dfnet.py:90) are a download and unavailable offline: the
 encoder is created with default Conv2d init; load a checkpoint for real use.
 """
@@ -88,6 +95,34 @@ class _PoseFn(torch.autograd.Function):
         return (None, None) + tuple(grads[k] for k in m._pose_param_names())
 
 
+class _TrainFn(torch.autograd.Function):
+    """Both heads of DFNet with the gradients of every trained tensor as backward (training DFNet itself)."""
+
+    @staticmethod
+    def forward(ctx, x, module, bn_batch, return_pose, upH, upW, *params):
+        x = x.detach()
+        E = module.engine(train=True)
+        feats, pose, stats = E.forward_train(x, True, return_pose, bn_batch, upH, upW)
+        if bn_batch:
+            module._update_running_stats(stats, x.shape)
+        ctx.save_for_backward(x)
+        ctx.cfg = (module, bn_batch)
+        return feats, pose
+
+    @staticmethod
+    def backward(ctx, g_feats, g_pose):
+        (x,) = ctx.saved_tensors
+        m, bn_batch = ctx.cfg
+        E = m.engine(train=True)
+        if g_feats is None and g_pose is None:
+            grads = {}
+        elif g_feats is None:
+            grads = E.backward_params(x, g_pose.contiguous())
+        else:
+            grads = E.backward_all_params(x, None if g_pose is None else g_pose.contiguous(), g_feats.contiguous(), bn_batch=bn_batch)
+        return (None,) * 6 + tuple(grads.get(k) for k in E.train_param_names(True))
+
+
 class _DFNetBase(nn.Module):
     tap_channels = (64, 256, 512)
     mean = [0.485, 0.456, 0.406]
@@ -105,6 +140,7 @@ class _DFNetBase(nn.Module):
         self.precision = precision
         self._engine = None
         self._engine_version = None
+        self._folded_stale = False
 
     def _pose_param_names(self):
         names = []
@@ -112,33 +148,84 @@ class _DFNetBase(nn.Module):
             names += [f"encoder.{idx}.weight", f"encoder.{idx}.bias"]
         return names + ["fc_pose.weight", "fc_pose.bias"]
 
+    def _train_param_names(self):
+        names = list(self._pose_param_names())
+        for t in range(len(self.tap_channels)):
+            pre = f"adaptation_layers.adapt_layer_{t}"
+            names += [f"{pre}.0.weight", f"{pre}.0.bias", f"{pre}.2.weight", f"{pre}.2.bias", f"{pre}.3.weight", f"{pre}.3.bias"]
+        return names
+
     def _version(self):
         return {k: (p.data_ptr(), p._version) for k, p in list(self.named_parameters()) + list(self.named_buffers())}
 
-    def engine(self):
-        """The HIP engine holding the current weights.  Re-packed whenever a parameter tensor changed: on the device
-        when only the pose path's parameters moved and they live on the GPU (an optimizer step of DFNet_dm), from the
-        host otherwise."""
+    def _refresh_names(self):
+        """Tensors dfn_dfnet_refresh_train_params_device re-packs, in its order."""
+        names = list(self._pose_param_names())
+        for t in range(len(self.tap_channels)):
+            pre = f"adaptation_layers.adapt_layer_{t}"
+            names += [f"{pre}.0.weight", f"{pre}.0.bias", f"{pre}.2.weight", f"{pre}.2.bias", f"{pre}.3.weight", f"{pre}.3.bias",
+                      f"{pre}.3.running_mean", f"{pre}.3.running_var"]
+        return names
+
+    def _commit_from_host(self):
+        if self._engine is None:
+            self._engine = DfnetEngine(len(self.tap_channels), self.feat_dim, self.precision)
+        self._engine.load_numpy({k: v.detach().cpu().numpy() for k, v in self.state_dict().items()})
+        self._folded_stale = False
+
+    def engine(self, train=False):
+        """The HIP engine holding the current weights, re-packed whenever a tensor of the module changed.
+        train=True (the training forward / backward, which read the unfolded weights): on the device.  Otherwise
+        (inference: BatchNorm folded into the 5x5 convs): on the device when only the pose path's parameters moved
+        (an optimizer step of DFNet_dm), from the host in every other case — including the first inference after
+        training steps, whose device re-packs leave the folded weights stale."""
         ver = self._version()
-        if self._engine is None or ver != self._engine_version:
-            pose_names = self._pose_param_names()
-            changed = None if self._engine_version is None else {k for k in ver if ver[k] != self._engine_version.get(k)}
-            params = dict(self.named_parameters())
-            if self._engine is not None and changed is not None and changed <= set(pose_names) and \
-                    all(params[k].is_cuda for k in pose_names) and len(self.tap_channels) == 3:
-                self._engine.refresh_pose_params_device([params[k].detach() for k in pose_names])
+        if self._engine is None:
+            self._commit_from_host()
+        elif ver != self._engine_version:
+            changed = {k for k in ver if ver[k] != self._engine_version.get(k)}
+            sd = dict(list(self.named_parameters()) + list(self.named_buffers()))
+            pose_names, names = self._pose_param_names(), self._refresh_names()
+            on_gpu = all(sd[k].is_cuda for k in names)
+            if train and on_gpu and all(k in names or k.endswith("num_batches_tracked") for k in changed):
+                self._engine.refresh_train_params_device([sd[k].detach() for k in names])
+                self._folded_stale = True
+            elif not train and not self._folded_stale and on_gpu and changed <= set(pose_names):
+                self._engine.refresh_pose_params_device([sd[k].detach() for k in pose_names])
             else:
-                if self._engine is None:
-                    self._engine = DfnetEngine(len(self.tap_channels), self.feat_dim, self.precision)
-                self._engine.load_numpy({k: v.detach().cpu().numpy() for k, v in self.state_dict().items()})
-            self._engine_version = ver
+                self._commit_from_host()
+        elif not train and self._folded_stale:
+            self._commit_from_host()
+        self._engine_version = ver
         return self._engine
+
+    def _update_running_stats(self, stats, xshape):
+        """nn.BatchNorm2d's train()-mode side effect: running statistics move towards the batch mean / UNBIASED batch
+        variance with the module's momentum; stats [n_taps, 2, 128] = mean, biased variance."""
+        B, _, H, W = xshape
+        with torch.no_grad():
+            for t, scale in enumerate(self.scales):
+                bn = getattr(self.adaptation_layers, "adapt_layer_{}".format(t))[3]
+                n = B * (H // scale) * (W // scale)
+                mom = 0.1 if bn.momentum is None else bn.momentum
+                bn.running_mean.mul_(1 - mom).add_(stats[t, 0].to(bn.running_mean.device), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(stats[t, 1].to(bn.running_var.device), alpha=mom * n / max(n - 1, 1))
+                bn.num_batches_tracked += 1
 
     def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427):
         """Same contract as dfnet.py:109-172: returns (feature_maps, predict) with feature_maps None,
         [stack] (single stream: 1 x [L,B,128,H,W]) or [stack_t, stack_r] (siamese: 2 x [L,B/2,128,H,W])."""
-        if torch.is_grad_enabled() and return_pose and not return_feature and not x.requires_grad and \
-                any(p.requires_grad for p in self.parameters()):
+        bn_batch = self.adaptation_layers.adapt_layer_0[3].training
+        wants_grad = torch.is_grad_enabled() and not x.requires_grad and any(p.requires_grad for p in self.parameters())
+        if return_feature and (wants_grad or bn_batch) and not x.requires_grad:
+            # training DFNet itself: unfolded adaptation layers, BatchNorm by its own mode, every parameter gradient
+            sd = dict(self.named_parameters())
+            names = self._train_param_names()
+            feats, pose = _TrainFn.apply(x, self, bool(bn_batch), bool(return_pose), int(upsampleH), int(upsampleW),
+                                         *[sd[k] for k in names])
+            half = x.shape[0] // 2
+            return ([feats] if isSingleStream else [feats[:, :half], feats[:, half:]]), pose
+        if wants_grad and return_pose and not return_feature:
             # training the regressor (DFNet_dm): parameter gradients of the pose path come from the HIP wgrad kernels
             sd = dict(self.named_parameters())
             return None, _PoseFn.apply(x, self, *[sd[k] for k in self._pose_param_names()])

@@ -29,6 +29,13 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def rank_world():
+    """(rank, world) of the initialised process group, (0, 1) without one."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def frame_block(n_frames, rank, world):
     """Contiguous block [lo, hi) of frame indices owned by `rank` (sizes differ by at most 1;
     keeps PNG numbering trivial: global index = lo + local index)."""

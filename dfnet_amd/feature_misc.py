@@ -88,6 +88,89 @@ def feature_loss(feature_rgb, feature_target, per_channel=False):
     return 1 - cos(fr, ft).mean()
 
 
+def PoseLoss(args, pose_, pose, device):
+    """MSE between predicted and ground-truth [B,12] poses (misc.py:321-325)."""
+    return torch.nn.functional.mse_loss(pose_.to(device), pose)
+
+
+def _triplet(anchor, positive, negative, margin):
+    # nn.TripletMarginLoss(margin, p=2, reduction='mean'): pairwise L2 distance over the LAST axis (eps 1e-6)
+    return torch.nn.functional.triplet_margin_loss(anchor, positive, negative, margin=margin, p=2, reduction='mean')
+
+
+def triplet_loss(f1, f2, margin=1.):
+    """Naive triplet loss on feature stacks [lvl,B,C,H,W]: negative = the next image of the batch (misc.py:355-369)."""
+    return _triplet(f1, f2, torch.roll(f2, shifts=1, dims=1), margin)
+
+
+def triplet_loss_hard_negative_mining(f1, f2, margin=1.):
+    """In-triplet hard negative with anchor swap, two cases (misc.py:371-397)."""
+    a_neg, neg = torch.roll(f1, shifts=1, dims=1), torch.roll(f2, shifts=1, dims=1)
+    with torch.no_grad():
+        case1 = torch.nn.functional.mse_loss(f1, neg)
+        case2 = torch.nn.functional.mse_loss(f2, a_neg)
+    return _triplet(f1, f2, neg, margin) if case1 < case2 else _triplet(f2, f1, a_neg, margin)
+
+
+def triplet_loss_hard_negative_mining_plus(f1, f2, margin=1.):
+    """In-triplet hard negative, four cases: the closest of (anchor, negative), (positive, anchor_negative),
+    (anchor, anchor_negative), (positive, negative) decides which pair anchors the loss (misc.py:399-435)."""
+    anchor, positive = f1, f2
+    a_neg, neg = torch.roll(f1, shifts=1, dims=1), torch.roll(f2, shifts=1, dims=1)
+    mse = torch.nn.functional.mse_loss
+    with torch.no_grad():
+        case = int(torch.argmin(torch.stack([mse(anchor, neg), mse(positive, a_neg), mse(anchor, a_neg), mse(positive, neg)])))
+    if case == 0:
+        return _triplet(anchor, positive, neg, margin)
+    if case == 1:
+        return _triplet(positive, anchor, a_neg, margin)
+    if case == 2:
+        return _triplet(anchor, positive, a_neg, margin)
+    return _triplet(positive, anchor, neg, margin)
+
+
+def perturb_rotation(c2w, theta, phi, psi=0):
+    """Rotate a [3,4] camera-to-world about x (phi), then y (theta), then z (psi), degrees (misc.py:28-47, 437-446;
+    the y rotation has the reference's sign convention: [[c,0,-s],[0,1,0],[s,0,c]])."""
+    import numpy as np
+    ph, th, ps = (np.deg2rad(float(v)) for v in (phi, theta, psi))
+    rx = np.array([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]], dtype=np.float64)
+    ry = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]], dtype=np.float64)
+    rz = np.array([[np.cos(ps), -np.sin(ps), 0, 0], [np.sin(ps), np.cos(ps), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    m = np.concatenate([np.asarray(c2w, dtype=np.float64), [[0, 0, 0, 1]]], 0)
+    return (rz @ (ry @ (rx @ m)))[:3, :4]
+
+
+def perturb_single_render_pose(poses, x, angle):
+    """Random view synthesis: one [3,4] pose -> [1,3,4], rotation uniform in +-angle degrees per axis, camera position
+    = the ORIGINAL position + uniform(+-x) per axis (misc.py:448-483; the rotation does not move the camera)."""
+    import numpy as np
+    c2w = np.asarray(poses, dtype=np.float64)
+    loc = c2w[:, 3].copy()
+    theta, phi, psi = np.random.uniform(-angle, angle, 3)
+    new = perturb_rotation(c2w, theta, phi, psi)
+    new[:, 3] = loc + np.random.uniform(-x, x, 3)
+    return new[None]
+
+
+def freeze_bn_layer(model):
+    """--freezeBN, part 1 (utils/utils.py:18-28): BatchNorm weight / bias stop requiring grad."""
+    print("Freezing BatchNorm Layers...")
+    for module in model.modules():
+        if isinstance(module, torch.nn.BatchNorm2d):
+            module.weight.requires_grad_(False)
+            module.bias.requires_grad_(False)
+    return model
+
+
+def freeze_bn_layer_train(model):
+    """--freezeBN, part 2 (utils/utils.py:30-39): BatchNorm modules back to eval() after model.train()."""
+    for module in model.modules():
+        if isinstance(module, torch.nn.BatchNorm2d):
+            module.eval()
+    return model
+
+
 def matrix_to_quaternion(R):
     """[...,3,3] rotation matrices -> unit quaternions [...,4], real part first (pytorch3d.transforms convention;
     the error below only uses |q1.q2|, so the sign / branch choice is immaterial).  Shepperd's method: pick the

@@ -8,8 +8,13 @@ Native here: everything `--render_feature_only` executes (run_feature.py:313-346
 frame with NeRF-H (quarter resolution + bicubic x4 with --tinyimg), run the siamese DFNet forward on
 [target, render] and save one feature channel of each stream as PNG under ./tmp/<expname>/{target,rgb}/.
 `--eval` prints the median / mean pose error of the regressor over the test split (HIP forward + the quaternion
-error of feature/misc.py:49-131).  The optimisation loop (run_feature.py:349-422: Adam, triplet loss, random view
-synthesis) needs weight gradients and stops with a clear message.
+error of feature/misc.py:49-131).  Without either flag DFNet itself is trained (run_feature.py:100-422): NeRF-H
+renders of the training poses, then per epoch Adam steps on pose loss + feature loss (MSE or the triplet loss with
+in-triplet hard negatives) [+ the pose loss on randomly synthesised views, --random_view_synthesis], validation,
+ReduceLROnPlateau, early stopping with checkpoints.  Every forward and every parameter gradient of DFNet — encoder,
+adaptation layers, BatchNorm on batch statistics or frozen (--freezeBN), pose head — runs on the HIP path
+(dfn_dfnet_forward_train / dfn_dfnet_backward_all_params); the losses on the feature stacks and the optimizer are
+torch tensor ops.  DFNET_FEATURE_EPOCHS caps the epoch count (default: --epochs + 1 like the reference).
 """
 import os
 import sys
@@ -21,7 +26,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 from dfnet_amd.datasets import load_7Scenes_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
-from dfnet_amd.feature_misc import render_nerfw_imgs  # noqa: E402
+from dfnet_amd import dist as ddist  # noqa: E402
+from dfnet_amd.callbacks import EarlyStopping  # noqa: E402
+from dfnet_amd.feature_misc import (PoseLoss, freeze_bn_layer, freeze_bn_layer_train, get_error_in_q,  # noqa: E402
+                                    perturb_single_render_pose, render_nerfw_imgs, render_virtual_imgs,
+                                    triplet_loss_hard_negative_mining_plus)
 from dfnet_amd.nerfw import create_nerf  # noqa: E402
 from dfnet_amd.options import feature_parser  # noqa: E402
 from dfnet_amd.rendering import _write_png  # noqa: E402
@@ -33,6 +42,105 @@ def _save_channel(t, path):
     a = t.detach().float().cpu().numpy()
     a = (a - a.min()) / max(float(a.max() - a.min()), 1e-12)
     _write_png(path, (a * 255 + 0.5).clip(0, 255).astype(np.uint8))
+
+
+def _batches(dset_size, batch_size):
+    """The reference's batching (run_feature.py:108-123): a random permutation cut into FULL batches; a trailing
+    partial batch is dropped."""
+    select_inds = np.random.choice(dset_size, size=[dset_size], replace=False)
+    starts = list(range(0, dset_size - batch_size + 1, batch_size))
+    rank, world = ddist.rank_world()
+    if world > 1:   # data parallel: batches dealt round-robin to the ranks (same seed on every rank), equal step counts
+        starts = starts[:len(starts) // world * world][rank::world]
+    for i_batch in starts:
+        yield select_inds[i_batch:i_batch + batch_size]
+
+
+def _step(feat_model, optimizer, loss):
+    loss.backward()
+    ddist.allreduce_gradients(list(feat_model.parameters()))   # no-op on one GPU; one flat RCCL all-reduce otherwise
+    optimizer.step()
+    optimizer.zero_grad()
+    return loss.item()
+
+
+def _siamese_forward(args, feat_model, target_in, rgb_in, H, W):
+    features, predict_pose = feat_model(torch.cat([target_in, rgb_in]), True, upsampleH=H, upsampleW=W)
+    return features[0], features[1], predict_pose   # [L,B,128,H,W] target / render stacks, [2B,12]
+
+
+def _feature_loss(args, features_rgb, features_target, FeatureLoss):
+    if args.tripletloss:
+        return triplet_loss_hard_negative_mining_plus(features_rgb, features_target, margin=args.triplet_margin)
+    return FeatureLoss(features_rgb, features_target)
+
+
+def train_on_batch(args, targets, rgbs, poses, feat_model, dset_size, FeatureLoss, optimizer, hwf, device):
+    """One epoch over the rendered training set (run_feature.py:100-164)."""
+    feat_model.train()
+    H, W = int(hwf[0]), int(hwf[1])
+    if args.freezeBN:
+        feat_model = freeze_bn_layer_train(feat_model)
+    losses = []
+    batch_size = args.featurenet_batch_size
+    for i_inds in _batches(dset_size, batch_size):
+        target_in = targets[i_inds].permute(0, 3, 1, 2).to(device)
+        rgb_in = rgbs[i_inds].permute(0, 3, 1, 2).to(device)
+        pose = poses[i_inds].reshape(batch_size, 12).to(device)
+        pose = torch.cat([pose, pose])
+        features_target, features_rgb, predict_pose = _siamese_forward(args, feat_model, target_in, rgb_in, H, W)
+        if args.poselossonly:
+            loss = PoseLoss(args, predict_pose, pose, device)
+        elif args.featurelossonly:
+            loss = FeatureLoss(features_rgb, features_target)
+        else:
+            loss = PoseLoss(args, predict_pose, pose, device) + _feature_loss(args, features_rgb, features_target, FeatureLoss)
+        losses.append(_step(feat_model, optimizer, loss))
+    return float(np.mean(losses)) if losses else float("nan")
+
+
+def train_on_batch_with_random_view_synthesis(args, targets, rgbs, poses, virtue_view, poses_perturb, feat_model, dset_size,
+                                              FeatureLoss, optimizer, hwf, device):
+    """One epoch with random view synthesis (run_feature.py:166-230): the siamese step on [target, render] plus the pose
+    loss of the regressor on a NeRF-H render at a perturbed pose."""
+    feat_model.train()
+    H, W = int(hwf[0]), int(hwf[1])
+    if args.freezeBN:
+        feat_model = freeze_bn_layer_train(feat_model)
+    losses = []
+    batch_size = args.featurenet_batch_size
+    for i_inds in _batches(dset_size, batch_size):
+        target_in = targets[i_inds].permute(0, 3, 1, 2).to(device)
+        rgb_in = rgbs[i_inds].permute(0, 3, 1, 2).to(device)
+        pose = poses[i_inds].reshape(batch_size, 12).to(device)
+        rgb_perturb = virtue_view[i_inds].permute(0, 3, 1, 2).to(device)
+        pose_perturb = poses_perturb[i_inds].reshape(batch_size, 12).to(device)
+        pose = torch.cat([pose, pose])
+        features_target, features_rgb, predict_pose = _siamese_forward(args, feat_model, target_in, rgb_in, H, W)
+        loss_pose = PoseLoss(args, predict_pose, pose, device)
+        loss_f = _feature_loss(args, features_rgb, features_target, FeatureLoss)
+        _, virtue_pose = feat_model(rgb_perturb, False)
+        loss_pose_perturb = PoseLoss(args, virtue_pose, pose_perturb, device)
+        loss = args.combine_loss_w[0] * loss_pose + args.combine_loss_w[1] * loss_f + args.combine_loss_w[2] * loss_pose_perturb
+        losses.append(_step(feat_model, optimizer, loss))
+    return float(np.mean(losses)) if losses else float("nan")
+
+
+def _synthesise_views(args, poses, img_idxs, hwf, device, render_kwargs_test, world_setup_dict):
+    """Perturbed poses clipped to the training poses' bounding box + d_max, and their NeRF-H renders
+    (run_feature.py:358-380)."""
+    dset_size = poses.shape[0]
+    b_min = [float(poses[:, j, 3].min()) - args.d_max for j in range(3)]
+    b_max = [float(poses[:, j, 3].max()) + args.d_max for j in range(3)]
+    poses_perturb = poses.clone().numpy()
+    for i in range(dset_size):
+        poses_perturb[i] = perturb_single_render_pose(poses_perturb[i], args.rvs_trans, args.rvs_rotation)
+        for j in range(3):
+            poses_perturb[i, j, 3] = min(max(poses_perturb[i, j, 3], b_min[j]), b_max[j])
+    poses_perturb = torch.Tensor(poses_perturb).to(device)
+    print("renders RVS...")
+    virtue_view = render_virtual_imgs(args, poses_perturb, img_idxs, hwf, device, render_kwargs_test, world_setup_dict)
+    return virtue_view, poses_perturb
 
 
 def train_feature(args, train_dl, val_dl, test_dl, hwf, i_split, near, far):
@@ -69,12 +177,46 @@ def train_feature(args, train_dl, val_dl, test_dl, hwf, i_split, near, far):
         print("render features done")
         return
     if args.eval:  # run_feature.py:306-311: pose error of the regressor over the test split
-        from dfnet_amd.feature_misc import get_error_in_q
         get_error_in_q(args, test_dl, feat_model, len(val_dl.dataset), device, batch_size=1)
         return
-    raise NotImplementedError("DFNet optimisation (triplet loss, random view synthesis: weight gradients of the conv "
-                              "stack) is not built; use --eval / --render_feature_only, or train with the reference "
-                              "and load the checkpoint via --pretrain_model_path")
+    # ---- training (run_feature.py:232-422)
+    if args.freezeBN:
+        feat_model = freeze_bn_layer(feat_model)
+    feat_model.to(device)
+    optimizer = torch.optim.Adam(feat_model.parameters(), lr=args.learning_rate)
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.95, patience=args.patience[1])
+    early_stopping = EarlyStopping(args, patience=args.patience[0], verbose=False)
+    loss_func = torch.nn.MSELoss(reduction='mean')
+    targets, rgbs, poses, img_idxs = render_nerfw_imgs(args, train_dl, hwf, device, render_kwargs_test, world_setup_dict)
+    dset_size = len(train_dl.dataset)
+    n_epoch = int(os.environ.get("DFNET_FEATURE_EPOCHS", args.epochs + 1))
+    virtue_view = poses_perturb = None
+    for epoch in range(n_epoch):
+        if args.random_view_synthesis:
+            if epoch % args.rvs_refresh_rate == 0:
+                virtue_view, poses_perturb = _synthesise_views(args, poses, img_idxs, hwf, device, render_kwargs_test,
+                                                               world_setup_dict)
+            train_loss = train_on_batch_with_random_view_synthesis(args, targets, rgbs, poses, virtue_view, poses_perturb,
+                                                                   feat_model, dset_size, loss_func, optimizer, hwf, device)
+        else:
+            train_loss = train_on_batch(args, targets, rgbs, poses, feat_model, dset_size, loss_func, optimizer, hwf, device)
+        feat_model.eval()
+        val_losses = []
+        with torch.no_grad():
+            for data, pose, _ in val_dl:
+                _, predict = feat_model(data.to(device))
+                val_losses.append(loss_func(predict, pose.to(device)).item())
+        val_loss = float(np.mean(val_losses))
+        scheduler.step(val_loss)
+        print('At epoch {0:6d} : train loss: {1:.4f}, val loss: {2:.4f}'.format(epoch, train_loss, val_loss))
+        early_stopping(val_loss, feat_model, epoch=epoch, save_multiple=(not args.no_save_multiple), save_all=args.save_all_ckpt)
+        if early_stopping.early_stop:
+            print("Early stopping")
+            break
+        if args.featurelossonly:
+            continue
+        if epoch % args.i_eval == 0:
+            get_error_in_q(args, test_dl, feat_model, len(test_dl.dataset), device, batch_size=1)
 
 
 def main(argv=None):
@@ -82,6 +224,7 @@ def main(argv=None):
     torch.manual_seed(0)
     args = feature_parser().parse_args(argv)
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    ddist.init_from_env()   # torchrun: one process per GPU, gradients averaged over RCCL; single process otherwise
     if args.dataset_type != '7Scenes':
         raise NotImplementedError(f"dataset_type={args.dataset_type}: only the 7Scenes front-end is built")
     train_dl, val_dl, test_dl, hwf, i_split, near, far = load_7Scenes_dataloader(args)

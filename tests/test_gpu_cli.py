@@ -112,3 +112,30 @@ def test_train_dm_cli(tmp_path):
     import torch
     ck = torch.load(os.path.join(basedir, "dfnet_dm", "checkpoint-0000.pt"), map_location="cpu")
     assert "encoder.0.weight" in ck and "fc_pose.bias" in ck and "adaptation_layers.adapt_layer_0.3.running_var" in ck
+
+
+@pytest.mark.parametrize("extra", [[], ["--freezeBN"]], ids=["bn_train", "freezeBN"])
+def test_run_feature_training_cli(tmp_path, extra):
+    """run_feature.py without --eval: DFNet itself trained for two epochs on the synthetic tree with the reference's
+    recipe (triplet loss, random view synthesis, BatchNorm in train() mode or --freezeBN): NeRF-H renders, siamese HIP
+    forward / backward of every parameter, Adam, validation, checkpoints."""
+    datadir = make_scene(str(tmp_path), n_train=4, n_val=2, H=128, W=160)
+    basedir = str(tmp_path / "logs")
+    cli = ["--config", os.path.join(ROOT, "script", "config_dfnet.txt"), "--datadir", datadir, "--basedir", basedir,
+           "--N_samples", "16", "--N_importance", "32", "--df", "2", "--trainskip", "1", "--testskip", "1",
+           "--featurenet_batch_size", "2", "--learning_rate", "1e-5", "--i_eval", "1", "--rvs_refresh_rate", "2"] + extra
+    env = dict(os.environ, DFNET_FEATURE_EPOCHS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "run_feature.py")] + cli, cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("At epoch")]
+    assert len(lines) == 2 and all("nan" not in l for l in lines), r.stdout[-2000:]
+    assert r.stdout.count("renders RVS...") == 1 and r.stdout.count("Median error") == 2
+    import glob
+    import torch
+    cks = sorted(glob.glob(os.path.join(basedir, "dfnet", "checkpoint-*.pt")))
+    assert cks, os.listdir(os.path.join(basedir, "dfnet"))
+    ck = torch.load(cks[0], map_location="cpu")
+    assert "encoder.0.weight" in ck and "adaptation_layers.adapt_layer_2.3.running_mean" in ck
+    moved = float((ck["adaptation_layers.adapt_layer_0.3.running_mean"]).abs().max()) > 0
+    assert moved == (not extra)   # train() mode moves the running statistics, --freezeBN leaves them

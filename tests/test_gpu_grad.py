@@ -446,6 +446,63 @@ def test_dfnet_module_trains_pose_path():
     assert 0.8 * float(loss0) < loss1 < 0.97 * float(loss0), (float(loss0), loss1)
 
 
+@pytest.mark.parametrize("mode", ["train", "freezebn"])
+def test_dfnet_module_training_step_vs_reference_golden(mode):
+    """nn.Module surface of DFNet's own training: the reference's recipe line by line (model.train() [+ freeze_bn_layer /
+    freeze_bn_layer_train], siamese forward, loss.backward()) fills .grad of every trained tensor with the values
+    captured from the reference module (G10), moves the running statistics like nn.BatchNorm2d, and an optimizer step
+    followed by eval() re-commits the folded inference weights."""
+    from dfnet_amd.dfnet import DFNet
+    from dfnet_amd.feature_misc import freeze_bn_layer, freeze_bn_layer_train
+    g = np.load(os.path.join(GOLD, f"g10_dfnet_train_{mode}.npz"))
+    r10 = np.random.default_rng(int(g["seed"]))
+    x = T(r10.uniform(0, 1, (4, 3, 32, 48)).astype(np.float32)).to(DEV)
+    Gt = T(r10.standard_normal((3, 2, 128, 24, 40)).astype(np.float32)).to(DEV)
+    Gr = T(r10.standard_normal((3, 2, 128, 24, 40)).astype(np.float32)).to(DEV)
+    m = DFNet()
+    m.load_state_dict({k: T(v) for k, v in syn.dfnet_weights(seed=3).items()}, strict=False)
+    if mode == "freezebn":
+        m = freeze_bn_layer(m)
+    m.to(DEV)
+    m.train()
+    if mode == "freezebn":
+        m = freeze_bn_layer_train(m)
+    feats, pose = m(x, return_feature=True, isSingleStream=False, return_pose=True, upsampleH=24, upsampleW=40)
+    assert relmax(feats[0][:, :, ::8], g["feat_t"]) < 5e-5 and relmax(feats[1][:, :, ::8], g["feat_r"]) < 5e-5
+    loss = (feats[0] * Gt).sum() + (feats[1] * Gr).sum() + (pose * T(g["Gp"]).to(DEV)).sum()
+    loss.backward()
+    n = 0
+    for k, q in m.named_parameters():
+        if "gn:" + k not in g:
+            assert q.grad is None, k
+            continue
+        if mode == "train" and "adapt" in k and k.endswith(".2.bias"):
+            continue
+        ref_n = float(g["gn:" + k])
+        assert abs(float(q.grad.norm()) - ref_n) <= 5e-4 * ref_n, (k, float(q.grad.norm()), ref_n)
+        n += 1
+    assert n == (43 if mode == "train" else 40)
+    sd = m.state_dict()
+    for t in range(3):
+        pre = f"adaptation_layers.adapt_layer_{t}.3."
+        assert relmax(sd[pre + "running_mean"], g[f"rm{t}"]) < 1e-5 and relmax(sd[pre + "running_var"], g[f"rv{t}"]) < 1e-5
+        assert int(sd[pre + "num_batches_tracked"]) == (1 if mode == "train" else 0)
+    # optimizer step, then a second training forward (device re-pack) and an eval forward (host re-commit of the folded
+    # weights): both must agree with the CPU oracle on the UPDATED parameters
+    from oracle import dfnet_oracle as dor
+    torch.optim.SGD([q for q in m.parameters() if q.requires_grad], lr=1e-7).step()
+    p1 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "num_batches" not in k}
+    with torch.no_grad():
+        f2, _ = m(x, return_feature=True, isSingleStream=True, return_pose=False, upsampleH=24, upsampleW=40)
+        ref2, _ = dor.dfnet_forward(p1, x.cpu(), True, True, False, 24, 40, bn_stats=[] if mode == "train" else None)
+        assert rel_l2(f2[0], ref2[0]) < 5e-6
+        m.eval()
+        p2 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "num_batches" not in k}
+        f3, pose3 = m(x, return_feature=True, isSingleStream=True, return_pose=True, upsampleH=24, upsampleW=40)
+        ref3, rp3 = dor.dfnet_forward(p2, x.cpu(), True, True, True, 24, 40)
+        assert rel_l2(f3[0], ref3[0]) < 5e-6 and relmax(pose3, rp3) < 1e-5
+
+
 def test_dm_train_step_parameter_gradients_vs_oracle():
     """The whole DFNet_dm optimisation step (direct_feature_matching.py:322-376): gradients that reach the pose
     regressor's parameters through SVD -> scene rescale -> render -> bicubic -> feature extractor -> losses, HIP path vs

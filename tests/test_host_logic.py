@@ -186,3 +186,74 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ALLREDUCE_OK" in r.stdout
+
+
+def test_triplet_losses_and_view_perturbation(tmp_path):
+    """Training-side host helpers of run_feature.py: the triplet losses against nn.TripletMarginLoss on explicitly built
+    triplets (feature/misc.py:355-435), random-view pose perturbation (misc.py:437-483) and EarlyStopping."""
+    from dfnet_amd import feature_misc as fm
+    from dfnet_amd.callbacks import EarlyStopping
+    gen = torch.Generator().manual_seed(0)
+    f1, f2 = torch.randn(3, 4, 8, 5, 6, generator=gen), torch.randn(3, 4, 8, 5, 6, generator=gen)
+    crit = torch.nn.TripletMarginLoss(margin=0.7, reduction='mean')
+    a_neg, neg = torch.roll(f1, 1, 1), torch.roll(f2, 1, 1)
+    assert torch.allclose(fm.triplet_loss(f1, f2, 0.7), crit(f1, f2, neg))
+    mse = torch.nn.functional.mse_loss
+    cases = [(mse(f1, neg), (f1, f2, neg)), (mse(f2, a_neg), (f2, f1, a_neg)), (mse(f1, a_neg), (f1, f2, a_neg)), (mse(f2, neg), (f2, f1, neg))]
+    want = crit(*min(cases, key=lambda c: float(c[0]))[1])
+    assert torch.allclose(fm.triplet_loss_hard_negative_mining_plus(f1, f2, 0.7), want)
+    want2 = crit(*min(cases[:2], key=lambda c: float(c[0]))[1])
+    assert torch.allclose(fm.triplet_loss_hard_negative_mining(f1, f2, 0.7), want2)
+    # a positive much closer than the negative: zero loss; identical streams: the margin
+    assert float(fm.triplet_loss(f1, f1 + 1e-4, 0.1)) == 0.0
+    np.random.seed(3)
+    pose = syn.orbit_pose(2, 8)[:3]
+    new = fm.perturb_single_render_pose(pose, 0.2, 10.0)
+    assert new.shape == (1, 3, 4)
+    R = new[0, :, :3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+    assert np.abs(new[0, :, 3] - pose[:, 3]).max() <= 0.2   # rotation leaves the camera where it was; +-x on top
+    ang = np.degrees(np.arccos(np.clip((np.trace(R @ pose[:, :3].T) - 1) / 2, -1, 1)))
+    assert 0 < ang <= 10 * np.sqrt(3) + 1e-6
+    np.testing.assert_allclose(fm.perturb_rotation(pose, 0, 90, 0)[:, 3], [pose[0, 3], -pose[2, 3], pose[1, 3]], atol=1e-6)
+
+    class A:
+        val_on_psnr, basedir, model_name = False, str(tmp_path), "m"
+    es = EarlyStopping(A, patience=2)
+    net = torch.nn.Linear(2, 2)
+    for ep, v in enumerate([1.0, 0.5, 0.6, 0.7]):
+        es(v, net, epoch=ep, save_multiple=True)
+    assert es.early_stop and es.val_loss_min == 0.5
+    assert sorted(os.listdir(tmp_path / "m")) == ["checkpoint-0000-1.0000.pt", "checkpoint-0001-0.5000.pt"]
+
+
+_GLOO_BATCH_WORKER = r'''
+import importlib.util, os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from dfnet_amd import dist as ddist
+rank, world, _ = ddist.init_from_env(backend="gloo")
+spec = importlib.util.spec_from_file_location("run_feature", os.path.join(sys.argv[1], "script", "run_feature.py"))
+rf = importlib.util.module_from_spec(spec); spec.loader.exec_module(rf)
+np.random.seed(0)
+mine = [list(map(int, b)) for b in rf._batches(23, 4)]      # 5 full batches -> 2 per rank, one dropped
+out = [None] * world
+torch.distributed.all_gather_object(out, mine)
+if rank == 0:
+    assert all(len(o) == 2 for o in out), out
+    flat = [i for o in out for b in o for i in b]
+    assert len(flat) == len(set(flat)) == 16 and all(len(b) == 4 for o in out for b in o)
+    print("BATCHES_OK")
+ddist.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_feature_training_batches_gloo_world2(tmp_path):
+    """Data-parallel DFNet training: every rank draws the same permutation and takes every world-th full batch."""
+    script = tmp_path / "b.py"
+    script.write_text(_GLOO_BATCH_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29655", str(script), ROOT],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "BATCHES_OK" in r.stdout
