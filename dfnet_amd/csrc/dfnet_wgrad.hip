@@ -51,29 +51,47 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // Addressing: the input pixel of tap (ky, kx) for pixel q is q + (ky-R) W + (kx-R) in the flat [B*H*W] order, so
+  // every load is a uniform base pointer (per workgroup and tap) plus one 32-bit per-lane offset that advances by a
+  // constant; (x, y) are tracked incrementally only for the border masks.  No division in the loop.
+  const float* gbase = g + ((size_t)q0 * mblks + mblk) * 32 + c;       // + (q - q0) * mblks * 32
+  const float* ibase = in + ((size_t)q0 * nblks + nblk) * 32 + c;      // + (q - q0 + tap offset) * nblks * 32
+  const uint32_t gstep = (uint32_t)mblks * 32, istep = (uint32_t)nblks * 32;
+  struct Px { long long q; int x, y; };
+  auto locate = [&](long long q) { Px p; p.q = q; p.x = int(q % W); p.y = int((q / W) % H); return p; };
+  auto advance = [&](Px& p) {   // by four pixels
+    p.q += 4;
+    p.x += 4;
+    while (p.x >= W) { p.x -= W; if (++p.y == H) p.y = 0; }
+  };
   // Two pixel pairs per iteration: all 2 x (1 + T) loads are issued before the first MFMA, so the second pair's
   // (and, through the other wave of the SIMD, the next iteration's) latency hides under the first pair's MFMAs.
-  auto fetch = [&](long long q, float& a, float (&bv)[T]) {
-    const bool live = q < w1;
-    const long long qq = live ? q : w0;
-    const int x = int(qq % W);
-    const long long rr = qq / W;
-    const int y = int(rr % H);
-    const long long b = rr / H;
-    a = live ? g[(qq * mblks + mblk) * 32 + c] : 0.f;
+  auto fetch = [&](const Px& p, float& a, float (&bv)[T]) {
+    const bool live = p.q < w1;
+    const uint32_t d = live ? (uint32_t)(p.q - q0) : 0u;
+    const float av = gbase[(size_t)(d * gstep)];
+    a = live ? av : 0.f;
+    const uint32_t di = d * istep;
 #pragma unroll
-    for (int ty = 0; ty < TY; ++ty)
+    for (int ty = 0; ty < TY; ++ty) {
+      const int dy = ky0 + ty - R;
+      const bool rowok = live && (unsigned)(p.y + dy) < (unsigned)H;
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
-        const int yy = y + ky0 + ty - R, xx = x + kx - R;
-        const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        bv[ty * KS + kx] = ok ? in[(((b * H + yy) * (long long)W + xx) * nblks + nblk) * 32 + c] : 0.f;
+        const int dx = kx - R;
+        const bool ok = rowok && (unsigned)(p.x + dx) < (unsigned)W;
+        const int off = dy * W + dx;                                   // uniform
+        const float v = (ibase + (long long)off * istep)[(size_t)(ok ? di : 0u)];
+        bv[ty * KS + kx] = ok ? v : 0.f;
       }
+    }
   };
-  for (long long q = w0 + k; q < w1 + k; q += 4) {   // every lane of the wave runs the same number of iterations
+  Px pa = locate(w0 + k < Q ? w0 + k : 0), pb = locate(w0 + k + 2 < Q ? w0 + k + 2 : 0);
+  pa.q = w0 + k; pb.q = w0 + k + 2;
+  for (; pa.q < w1 + k; advance(pa), advance(pb)) {   // every lane of the wave runs the same number of iterations
     float a0, a1, b0[T], b1[T];
-    fetch(q, a0, b0);
-    fetch(q + 2, a1, b1);
+    fetch(pa, a0, b0);
+    fetch(pb, a1, b1);
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
 #pragma unroll
@@ -128,6 +146,9 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
   if (n_chunks < 1) n_chunks = 1;
   while (n_chunks > 1 && (size_t)n_chunks * pairs * T * 1024 > part_floats) --n_chunks;
   if ((size_t)n_chunks * pairs * T * 1024 > part_floats) return hipErrorInvalidValue;
+  // 32-bit per-lane offsets inside a workgroup's pixel range (conv_wgrad_kernel)
+  if ((unsigned long long)((Q + n_chunks - 1) / n_chunks + 4) * (unsigned)(mblks > nblks ? mblks : nblks) * 32 >= (1ull << 32))
+    return hipErrorInvalidValue;
   const dim3 grid(pairs, int(n_chunks));
   if (ks == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, part);
   else if (ks == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, part);

@@ -82,7 +82,7 @@ class _PoseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, module, *params):
-        _, pose = module.engine().forward(x.detach(), False, True, True)
+        _, pose = module.engine(train=True).forward(x.detach(), False, True, True)   # the pose path reads no folded weights
         ctx.save_for_backward(x.detach())
         ctx.module = module
         return pose
@@ -91,7 +91,7 @@ class _PoseFn(torch.autograd.Function):
     def backward(ctx, g_pose):
         (x,) = ctx.saved_tensors
         m = ctx.module
-        grads = m.engine().backward_params(x, g_pose.contiguous())
+        grads = m.engine(train=True).backward_params(x, g_pose.contiguous())
         return (None, None) + tuple(grads[k] for k in m._pose_param_names())
 
 
@@ -175,7 +175,8 @@ class _DFNetBase(nn.Module):
 
     def engine(self, train=False):
         """The HIP engine holding the current weights, re-packed whenever a tensor of the module changed.
-        train=True (the training forward / backward, which read the unfolded weights): on the device.  Otherwise
+        train=True (the training forward / backward and the pose path, none of which read BatchNorm-folded weights): on
+        the device.  Otherwise
         (inference: BatchNorm folded into the 5x5 convs): on the device when only the pose path's parameters moved
         (an optimizer step of DFNet_dm), from the host in every other case — including the first inference after
         training steps, whose device re-packs leave the folded weights stale."""
@@ -189,7 +190,7 @@ class _DFNetBase(nn.Module):
             on_gpu = all(sd[k].is_cuda for k in names)
             if train and on_gpu and all(k in names or k.endswith("num_batches_tracked") for k in changed):
                 self._engine.refresh_train_params_device([sd[k].detach() for k in names])
-                self._folded_stale = True
+                self._folded_stale = self._folded_stale or not changed <= set(pose_names)   # folded: adaptation layers only
             elif not train and not self._folded_stale and on_gpu and changed <= set(pose_names):
                 self._engine.refresh_pose_params_device([sd[k].detach() for k in pose_names])
             else:
@@ -236,7 +237,8 @@ class _DFNetBase(nn.Module):
                                           "parameter gradients (input without grad)")
             feats = _FeatureFn.apply(x, self.engine(), bool(isSingleStream), int(upsampleH), int(upsampleW))
             return list(feats), None
-        feats, pose = self.engine().forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW)
+        # pose-only inference reads no BatchNorm-folded weights: the device re-pack of a training step is enough for it
+        feats, pose = self.engine(train=not return_feature).forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW)
         if feats is not None:
             feats = [feats] if isSingleStream else [feats[0], feats[1]]
         return feats, pose
