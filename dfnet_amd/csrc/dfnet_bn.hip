@@ -55,16 +55,26 @@ __global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict
 // MODE 2 (frozen): work block from the running statistics, no partials.
 // bn: device [4][128] = gamma, beta, running_mean, running_var (channel order).
 template <int MODE>
-__global__ __launch_bounds__(128) void bn_finalize_kernel(const double* __restrict__ part, int n_chunks, long long Q,
-                                                          const float* __restrict__ bn, float eps, float* __restrict__ bw,
-                                                          float* __restrict__ out0, float* __restrict__ out1) {
-  const int p = threadIdx.x, ch = chan_of_pos128(p);
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ part, int n_chunks, long long Q,
+                                                           const float* __restrict__ bn, float eps, float* __restrict__ bw,
+                                                           float* __restrict__ out0, float* __restrict__ out1) {
+  // 128 positions x 8 chunk segments, combined in a fixed order (deterministic)
+  __shared__ double seg[2][8][128];
+  const int p = threadIdx.x & 127, sg = threadIdx.x >> 7, ch = chan_of_pos128(p);
   double s0 = 0.0, s1 = 0.0;
-  if (MODE != 2)
-    for (int c = 0; c < n_chunks; ++c) {
+  if (MODE != 2) {
+    const int per = (n_chunks + 7) / 8, c1 = min(n_chunks, (sg + 1) * per);
+    for (int c = sg * per; c < c1; ++c) {
       s0 += part[((size_t)c * 2 + 0) * 128 + p];
       s1 += part[((size_t)c * 2 + 1) * 128 + p];
     }
+    seg[0][sg][p] = s0;
+    seg[1][sg][p] = s1;
+    __syncthreads();
+    s0 = s1 = 0.0;
+    for (int k = 0; k < 8; ++k) { s0 += seg[0][k][p]; s1 += seg[1][k][p]; }
+  }
+  if (sg != 0) return;
   if (MODE == 1) {
     out0[ch] = (float)s1;   // d gamma
     out1[ch] = (float)s0;   // d beta
@@ -99,11 +109,11 @@ hipError_t launch_bn_batch_stats(const float* z, long long Q, const float* bn, f
                                  float* var_out, hipStream_t s) {
   const int nc = chunks_for(Q);
   hipLaunchKernelGGL(bn_moments_kernel<0>, dim3(nc), dim3(256), 0, s, z, nullptr, nullptr, Q, nc, part);
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(1), dim3(128), 0, s, part, nc, Q, bn, eps, bw, mean_out, var_out);
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(1), dim3(1024), 0, s, part, nc, Q, bn, eps, bw, mean_out, var_out);
   return hipGetLastError();
 }
 hipError_t launch_bn_running_stats(const float* bn, float eps, float* bw, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel<2>, dim3(1), dim3(128), 0, s, nullptr, 0, 1, bn, eps, bw, nullptr, nullptr);
+  hipLaunchKernelGGL(bn_finalize_kernel<2>, dim3(1), dim3(1024), 0, s, nullptr, 0, 1, bn, eps, bw, nullptr, nullptr);
   return hipGetLastError();
 }
 
@@ -127,7 +137,7 @@ hipError_t launch_bn_backward(int batch, float* g, const float* z, long long Q, 
   if (batch) {
     const int nc = chunks_for(Q);
     hipLaunchKernelGGL(bn_moments_kernel<1>, dim3(nc), dim3(256), 0, s, g, z, bw, Q, nc, part);
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(1), dim3(128), 0, s, part, nc, Q, nullptr, 0.f, bw, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(1), dim3(1024), 0, s, part, nc, Q, nullptr, 0.f, bw, dgamma, dbeta);
     hipLaunchKernelGGL(bn_backward_kernel<true>, dim3(grid), dim3(256), 0, s, g, z, bw, n);
   } else {
     hipLaunchKernelGGL(bn_backward_kernel<false>, dim3(grid), dim3(256), 0, s, g, z, bw, n);

@@ -126,10 +126,94 @@ __global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __r
     out[((b * h + y) * (size_t)w + x) * 128 + e128] = (T)acc;
   }
 }
+// The same adjoint, fp32, organised for bandwidth.  One workgroup per (image, input row y, 32-channel block); per channel
+//   phase 1: tmp[X] = sum_Y wy(Y) g_up[Y][X]    over the output rows that touch input row y — coalesced along X
+//   phase 2: row[x] = sum_X wx(X) tmp[X]         from LDS
+// and the 32 channels of every pixel leave as one 128-byte store.  Each g_up element is read about twice in total
+// (the gather above reads it (2 scale)^2 times through L2).  Weights are exactly the forward kernel's.
+__global__ __launch_bounds__(256) void upsample_backward_rows_kernel(const float* __restrict__ gup, size_t bstride, int h, int w, int UH,
+                                                                     int UW, float* __restrict__ out) {
+  extern __shared__ float lds[];
+  float* tmp = lds;                    // [UW]
+  float* wyv = tmp + UW;               // [UH] (only Y0..Y1 used)
+  float* row = wyv + UH;               // [w][33]
+  const int tid = threadIdx.x;
+  const int y = blockIdx.x % h, blk = blockIdx.y;
+  const size_t b = blockIdx.x / h;
+  const float sy = UH > 1 ? float(h - 1) / float(UH - 1) : 0.f;
+  const float sx = UW > 1 ? float(w - 1) / float(UW - 1) : 0.f;
+  int Y0 = 0, Y1 = UH - 1;
+  if (sy > 0.f) { Y0 = max(0, int(floorf(float(y - 1) / sy)) - 1); Y1 = min(UH - 1, int(ceilf(float(y + 1) / sy)) + 1); }
+  for (int Y = Y0 + tid; Y <= Y1; Y += 256) {
+    const float fy = sy * float(Y);
+    const int yA = int(fy), yB = yA + (yA < h - 1 ? 1 : 0);
+    const float ly = fy - float(yA);
+    wyv[Y] = (yA == y ? 1.f - ly : 0.f) + (yB == y ? ly : 0.f);
+  }
+  __syncthreads();
+  while (Y0 < Y1 && wyv[Y0] == 0.f) ++Y0;      // uniform: trim the slack rows
+  while (Y1 > Y0 && wyv[Y1] == 0.f) --Y1;
+  for (int e = 0; e < 32; ++e) {
+    const int ch = blk * 32 + 4 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
+    const float* plane = gup + b * bstride + (size_t)ch * UH * UW;
+    for (int X = tid; X < UW; X += 256) {
+      float t = 0.f;
+      for (int Y = Y0; Y <= Y1; ++Y) t = fmaf(wyv[Y], plane[(size_t)Y * UW + X], t);
+      tmp[X] = t;
+    }
+    __syncthreads();
+    for (int x = tid; x < w; x += 256) {
+      int X0 = 0, X1 = UW - 1;
+      if (sx > 0.f) { X0 = max(0, int(floorf(float(x - 1) / sx)) - 1); X1 = min(UW - 1, int(ceilf(float(x + 1) / sx)) + 1); }
+      float acc = 0.f;
+      for (int X = X0; X <= X1; ++X) {
+        const float fx = sx * float(X);
+        const int xA = int(fx), xB = xA + (xA < w - 1 ? 1 : 0);
+        const float lx = fx - float(xA);
+        const float wx = (xA == x ? 1.f - lx : 0.f) + (xB == x ? lx : 0.f);
+        acc = fmaf(wx, tmp[X], acc);
+      }
+      row[x * 33 + e] = acc;
+    }
+    __syncthreads();
+  }
+  float* o = out + ((b * h + y) * (size_t)w) * 128 + blk * 32;
+  for (int i = tid; i < w * 32; i += 256) o[(size_t)(i >> 5) * 128 + (i & 31)] = row[(i >> 5) * 33 + (i & 31)];
+}
+
+// Level 0 (no resize): NCHW planes -> blocked NHWC through an LDS tile of 128 channels x 64 pixels; 256-byte reads,
+// 512-byte writes.
+__global__ __launch_bounds__(256) void upsample_backward_identity_kernel(const float* __restrict__ gup, size_t bstride, size_t plane,
+                                                                         float* __restrict__ out) {
+  __shared__ float tile[128][65];
+  const size_t b = blockIdx.y, p0 = (size_t)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, t4 = threadIdx.x >> 6;
+  const float* src = gup + b * bstride + p0;
+  if (p0 + tx < plane)
+    for (int ch = t4; ch < 128; ch += 4) tile[ch][tx] = src[(size_t)ch * plane + tx];
+  __syncthreads();
+  const int e128 = threadIdx.x & 127, t2 = threadIdx.x >> 7;
+  const int blk = e128 >> 5, e = e128 & 31;
+  const int ch = blk * 32 + 4 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
+  for (int px = t2; px < 64; px += 2)
+    if (p0 + px < plane) out[(b * plane + p0 + px) * 128 + e128] = tile[ch][px];
+}
+
 hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, int B, int h, int w, int UH, int UW, void* out,
                                     hipStream_t s) {
   const size_t n = (size_t)B * h * w * 128;
   if (!n) return hipSuccess;
+  if (prec != 0 && h == UH && w == UW) {
+    const size_t plane = (size_t)h * w;
+    hipLaunchKernelGGL(upsample_backward_identity_kernel, dim3((unsigned)((plane + 63) / 64), B), dim3(256), 0, s, gup, bstride, plane,
+                       static_cast<float*>(out));
+    return hipGetLastError();
+  }
+  const size_t lds = ((size_t)UW + UH + (size_t)w * 33) * 4;
+  if (prec != 0 && lds <= 64 * 1024) {
+    hipLaunchKernelGGL(upsample_backward_rows_kernel, dim3(B * h, 4), dim3(256), lds, s, gup, bstride, h, w, UH, UW, static_cast<float*>(out));
+    return hipGetLastError();
+  }
   if (prec == 0)
     hipLaunchKernelGGL(upsample_backward_kernel<_Float16>, dim3(grid_of(n)), dim3(256), 0, s, gup, bstride, B, h, w, UH, UW,
                        static_cast<_Float16*>(out));
