@@ -1,0 +1,246 @@
+// dfnet_loss.hip — the triplet loss of DFNet's training on the two feature stacks (gfx950), forward and backward.
+// /root/reference/script/feature/misc.py:355-435: anchor f1, positive f2 [lvl, B, C, H, W]; negatives are the stacks
+// rolled by one image along B; nn.TripletMarginLoss(margin, p=2, eps=1e-6, reduction='mean') takes the pairwise L2
+// distance over the LAST axis (W), so one "row" = one (lvl, b, c, h) line of W floats:
+//     loss = mean_rows max(||x - y + eps|| - ||x - z + eps|| + margin, 0)
+// with (x, y, z) chosen by in-triplet hard-negative mining from four full-tensor MSEs.  In torch this is ~20 kernels
+// and ten passes over 630 MB stacks ("HBM-bound reductions worth fusing"); here:
+//   case pass      the four MSE sums in one read of both stacks (each element and its rolled neighbour), fp64 partials
+//   forward pass   one wave per row: both distances, hinge, row statistics kept for the backward (8 bytes per row)
+//   backward pass  element-wise, gather form (deterministic): an element collects its terms as x / y of its own row
+//                  and as the negative z of the next image's row
+// Stacks are addressed as base + lvl * level_stride + b * slab, so the two halves of one siamese [lvl, 2B, ...] tensor
+// work in place, for the inputs and for the gradients.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dfnet_hip.h"
+#include "dfn_common.h"
+#include "dfnet_kernels.h"
+
+namespace dfn {
+
+namespace {
+struct Stack { const float* p; size_t level_stride; };
+struct GStack { float* p; size_t level_stride; };
+
+// roles per mining case (misc.py:424-433): x = anchor of the triplet, y = positive, z = negative = roll(zsrc)
+//   case 0: (f1, f2, roll f2)   1: (f2, f1, roll f1)   2: (f1, f2, roll f1)   3: (f2, f1, roll f2)
+__device__ __forceinline__ bool x_is_f1(int c) { return c == 0 || c == 2; }
+__device__ __forceinline__ bool z_is_f1(int c) { return c == 1 || c == 2; }
+}  // namespace
+
+// part[chunk][4] (fp64): sum (f1 - roll f2)^2, (f2 - roll f1)^2, (f1 - roll f1)^2, (f2 - roll f2)^2
+__global__ __launch_bounds__(256) void triplet_case_kernel(Stack f1, Stack f2, int L, int B, size_t slab, double* __restrict__ part) {
+  __shared__ double red[4][4];
+  // grid: (chunks of one image slab, lvl * B + b) — no index division in the loop
+  const int b = blockIdx.y % B, l = blockIdx.y / B, bm = b == 0 ? B - 1 : b - 1;
+  const size_t per = (slab + gridDim.x - 1) / gridDim.x;
+  const size_t e0 = blockIdx.x * per, e1 = e0 + per < slab ? e0 + per : slab;
+  const float* pa = f1.p + l * f1.level_stride + b * slab;
+  const float* pp = f2.p + l * f2.level_stride + b * slab;
+  const float* pan = f1.p + l * f1.level_stride + bm * slab;
+  const float* ppn = f2.p + l * f2.level_stride + bm * slab;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
+    const float a = pa[e], p = pp[e], an = pan[e], pn = ppn[e];
+    const float d0 = a - pn, d1 = p - an, d2 = a - an, d3 = p - pn;
+    s[0] += (double)(d0 * d0); s[1] += (double)(d1 * d1); s[2] += (double)(d2 * d2); s[3] += (double)(d3 * d3);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// mode 0: naive (case 0); 1: two-case mining (misc.py:371-397); 2: four-case (misc.py:399-435).  torch.argmin: first minimum.
+__global__ void triplet_case_finalize_kernel(const double* __restrict__ part, int n_chunks, int mode, double count, int* __restrict__ case_out,
+                                             float* __restrict__ mse_out) {
+  if (threadIdx.x != 0) return;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < n_chunks; ++c)
+    for (int k = 0; k < 4; ++k) s[k] += part[(size_t)c * 4 + k];
+  float m[4];
+  for (int k = 0; k < 4; ++k) { m[k] = (float)(s[k] / count); if (mse_out) mse_out[k] = m[k]; }
+  int best = 0;
+  if (mode == 1) best = m[0] < m[1] ? 0 : 1;
+  else if (mode == 2)
+    for (int k = 1; k < 4; ++k) if (m[k] < m[best]) best = k;
+  *case_out = best;
+}
+
+// One wave per row.  row_stat[row] = (d_xy, d_xz); d_xz stored NEGATIVE when the hinge is inactive (no gradient).
+__global__ __launch_bounds__(256) void triplet_forward_kernel(Stack f1, Stack f2, int L, int B, int rows, int W, float margin, float eps,
+                                                              const int* __restrict__ case_in, float* __restrict__ row_stat,
+                                                              double* __restrict__ part) {
+  __shared__ double red[4];
+  const int c = *case_in, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t slab = (size_t)rows * W, n_rows = (size_t)L * B * rows;
+  const Stack X = x_is_f1(c) ? f1 : f2, Y = x_is_f1(c) ? f2 : f1, Z = z_is_f1(c) ? f1 : f2;
+  double acc = 0.0;
+  for (size_t row = (size_t)blockIdx.x * 4 + wave; row < n_rows; row += (size_t)gridDim.x * 4) {
+    const size_t r = row % rows, lb = row / rows;
+    const int b = int(lb % B), l = int(lb / B), bm = b == 0 ? B - 1 : b - 1;
+    const float* x = X.p + l * X.level_stride + b * slab + r * W;
+    const float* y = Y.p + l * Y.level_stride + b * slab + r * W;
+    const float* z = Z.p + l * Z.level_stride + bm * slab + r * W;
+    float sy = 0.f, sz = 0.f;
+    for (int w = lane; w < W; w += 64) {
+      const float xv = x[w], dy = xv - y[w] + eps, dz = xv - z[w] + eps;
+      sy = fmaf(dy, dy, sy);
+      sz = fmaf(dz, dz, sz);
+    }
+    for (int o = 32; o > 0; o >>= 1) { sy += __shfl_down(sy, o, 64); sz += __shfl_down(sz, o, 64); }
+    if (lane == 0) {
+      const float dxy = sqrtf(sy), dxz = sqrtf(sz), hinge = dxy - dxz + margin;
+      row_stat[2 * row] = dxy;
+      row_stat[2 * row + 1] = hinge >= 0.f ? dxz : -1.f;   // clamp_min passes the gradient at hinge == 0, as torch
+      if (hinge > 0.f) acc += (double)hinge;
+    }
+  }
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ void triplet_loss_finalize_kernel(const double* __restrict__ part, int n, double n_rows, float* __restrict__ loss) {
+  if (threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += part[i];
+  *loss = (float)(s / n_rows);
+}
+
+// g1 / g2: gradients w.r.t. f1 / f2 (every element written).  scale = grad_loss / n_rows.
+__global__ __launch_bounds__(256) void triplet_backward_kernel(Stack f1, Stack f2, int L, int B, int rows, int W, float eps,
+                                                               const int* __restrict__ case_in, const float* __restrict__ row_stat,
+                                                               const float* __restrict__ grad_loss, double n_rows, GStack g1, GStack g2) {
+  const int c = *case_in;
+  const float scale = (float)((double)*grad_loss / n_rows);
+  const uint32_t slab = (uint32_t)rows * W;
+  const bool xf1 = x_is_f1(c), zf1 = z_is_f1(c);
+  const Stack X = xf1 ? f1 : f2, Y = xf1 ? f2 : f1, Z = zf1 ? f1 : f2;
+  const GStack GX = xf1 ? g1 : g2, GY = xf1 ? g2 : g1;
+  const int b = blockIdx.y % B, l = blockIdx.y / B, bm = b == 0 ? B - 1 : b - 1, bp = b == B - 1 ? 0 : b + 1;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < slab; e += gridDim.x * blockDim.x) {
+    const uint32_t r = e / (uint32_t)W;
+    const size_t row = ((size_t)l * B + b) * rows + r, rowp = ((size_t)l * B + bp) * rows + r;
+    const float dxy = row_stat[2 * row], dxz = row_stat[2 * row + 1];
+    const float xv = X.p[l * X.level_stride + (size_t)b * slab + e], yv = Y.p[l * Y.level_stride + (size_t)b * slab + e];
+    float gx = 0.f, gy = 0.f;
+    if (dxz >= 0.f) {   // hinge active on this row
+      const float zv = Z.p[l * Z.level_stride + (size_t)bm * slab + e];
+      const float ty = dxy > 0.f ? (xv - yv + eps) / dxy : 0.f, tz = dxz > 0.f ? (xv - zv + eps) / dxz : 0.f;
+      gx = scale * (ty - tz);
+      gy = -scale * ty;
+    }
+    // this element as the negative of image b+1's row: z_{b+1} = zsrc[b]
+    const float dxzp = row_stat[2 * rowp + 1];
+    float gz = 0.f;
+    if (dxzp > 0.f) {
+      const float xp = X.p[l * X.level_stride + (size_t)bp * slab + e];
+      const float zself = zf1 == xf1 ? xv : yv;   // Z stack is the same tensor as X (cases 2, 3) or as Y (cases 0, 1)
+      gz = scale * (xp - zself + eps) / dxzp;
+    }
+    if (zf1 == xf1) gx += gz; else gy += gz;
+    GX.p[l * GX.level_stride + (size_t)b * slab + e] = gx;
+    GY.p[l * GY.level_stride + (size_t)b * slab + e] = gy;
+  }
+}
+
+static inline int slab_chunks(size_t slab, int images) {   // ~64K elements per workgroup, <= 4096 workgroups in all
+  size_t c = (slab + 65535) / 65536;
+  const size_t cap = images > 0 ? (size_t)(4096 / images > 0 ? 4096 / images : 1) : 1;
+  if (c > cap) c = cap;
+  return int(c < 1 ? 1 : c);
+}
+
+hipError_t launch_triplet_forward(const float* f1, size_t ls1, const float* f2, size_t ls2, int L, int B, int rows, int W, float margin,
+                                  float eps, int mode, double* part, int* case_out, float* mse_out, float* row_stat, float* loss,
+                                  hipStream_t s) {
+  const Stack a{f1, ls1}, p{f2, ls2};
+  const size_t slab = (size_t)rows * W, n = (size_t)L * B * slab, n_rows = (size_t)L * B * rows;
+  if (mode != 0 || mse_out) {
+    const int nc = slab_chunks(slab, L * B);
+    hipLaunchKernelGGL(triplet_case_kernel, dim3(nc, L * B), dim3(256), 0, s, a, p, L, B, slab, part);
+    hipLaunchKernelGGL(triplet_case_finalize_kernel, dim3(1), dim3(64), 0, s, part, nc * L * B, mode, (double)n, case_out, mse_out);
+  } else {
+    hipError_t e = hipMemsetAsync(case_out, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+  }
+  const int grid = int((n_rows + 3) / 4 < 2048 ? (n_rows + 3) / 4 : 2048);
+  hipLaunchKernelGGL(triplet_forward_kernel, dim3(grid), dim3(256), 0, s, a, p, L, B, rows, W, margin, eps, case_out, row_stat, part);
+  hipLaunchKernelGGL(triplet_loss_finalize_kernel, dim3(1), dim3(64), 0, s, part, grid, (double)n_rows, loss);
+  return hipGetLastError();
+}
+
+hipError_t launch_triplet_backward(const float* f1, size_t ls1, const float* f2, size_t ls2, int L, int B, int rows, int W, float eps,
+                                   const int* case_in, const float* row_stat, const float* grad_loss, float* g1, size_t gs1, float* g2,
+                                   size_t gs2, hipStream_t s) {
+  const Stack a{f1, ls1}, p{f2, ls2};
+  const GStack ga{g1, gs1}, gp{g2, gs2};
+  const size_t slab = (size_t)rows * W, n_rows = (size_t)L * B * rows;
+  if (slab >= (1ull << 32)) return hipErrorInvalidValue;
+  const int grid = slab_chunks(slab, L * B) * 16;   // 4K elements per workgroup pass
+  hipLaunchKernelGGL(triplet_backward_kernel, dim3(grid, L * B), dim3(256), 0, s, a, p, L, B, rows, W, eps, case_in, row_stat, grad_loss,
+                     (double)n_rows, ga, gp);
+  return hipGetLastError();
+}
+
+}  // namespace dfn
+
+// ------------------------------------------------------------------------------------------ C ABI
+using namespace dfn;
+
+extern "C" size_t dfn_triplet_loss_state_bytes(int L, int B, int rows) {
+  if (L < 1 || B < 1 || rows < 1) return 0;
+  // [case:int][4 x mse][pad] | row statistics | fp64 partials
+  return 256 + (((size_t)L * B * rows * 2 * sizeof(float) + 255) & ~size_t(255)) + kTripletPartDoubles * sizeof(double);
+}
+
+namespace {
+struct TripletState { int* case_dev; float* mse; float* row_stat; double* part; };
+TripletState carve_triplet(void* state, int L, int B, int rows) {
+  char* base = static_cast<char*>(state);
+  TripletState t;
+  t.case_dev = reinterpret_cast<int*>(base);
+  t.mse = reinterpret_cast<float*>(base + 16);
+  t.row_stat = reinterpret_cast<float*>(base + 256);
+  t.part = reinterpret_cast<double*>(base + 256 + (((size_t)L * B * rows * 2 * sizeof(float) + 255) & ~size_t(255)));
+  return t;
+}
+bool triplet_args_ok(const void* f1, const void* f2, int L, int B, int rows, int W, size_t ls1, size_t ls2) {
+  const size_t need = (size_t)B * rows * W;
+  return f1 && f2 && L >= 1 && B >= 1 && rows >= 1 && W >= 1 && (L == 1 || (ls1 >= need && ls2 >= need));
+}
+}  // namespace
+
+extern "C" int dfn_triplet_loss_forward(const float* f1, size_t level_stride1, const float* f2, size_t level_stride2, int L, int B,
+                                        int rows, int W, float margin, int mining, float* loss, void* state, size_t state_bytes,
+                                        void* stream) {
+  if (!triplet_args_ok(f1, f2, L, B, rows, W, level_stride1, level_stride2) || !loss || !state || mining < 0 || mining > 2)
+    return set_error(DFN_ERR_ARG, "dfn_triplet_loss_forward: bad argument");
+  if (state_bytes < dfn_triplet_loss_state_bytes(L, B, rows))
+    return set_error(DFN_ERR_ARG, "dfn_triplet_loss_forward: state too small (%zu < %zu)", state_bytes, dfn_triplet_loss_state_bytes(L, B, rows));
+  const TripletState t = carve_triplet(state, L, B, rows);
+  hipError_t e = launch_triplet_forward(f1, level_stride1, f2, level_stride2, L, B, rows, W, margin, 1e-6f, mining, t.part, t.case_dev,
+                                        mining ? t.mse : nullptr, t.row_stat, loss, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_triplet_loss_forward: %s", hipGetErrorString(e));
+  return DFN_OK;
+}
+
+extern "C" int dfn_triplet_loss_backward(const float* f1, size_t level_stride1, const float* f2, size_t level_stride2, int L, int B,
+                                         int rows, int W, const float* grad_loss, const void* state, float* grad_f1,
+                                         size_t grad_stride1, float* grad_f2, size_t grad_stride2, void* stream) {
+  if (!triplet_args_ok(f1, f2, L, B, rows, W, level_stride1, level_stride2) || !grad_loss || !state ||
+      !triplet_args_ok(grad_f1, grad_f2, L, B, rows, W, grad_stride1, grad_stride2))
+    return set_error(DFN_ERR_ARG, "dfn_triplet_loss_backward: bad argument");
+  const TripletState t = carve_triplet(const_cast<void*>(state), L, B, rows);
+  hipError_t e = launch_triplet_backward(f1, level_stride1, f2, level_stride2, L, B, rows, W, 1e-6f, t.case_dev, t.row_stat, grad_loss,
+                                         grad_f1, grad_stride1, grad_f2, grad_stride2, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_triplet_loss_backward: %s", hipGetErrorString(e));
+  return DFN_OK;
+}

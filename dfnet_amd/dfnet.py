@@ -99,28 +99,47 @@ class _TrainFn(torch.autograd.Function):
     """Both heads of DFNet with the gradients of every trained tensor as backward (training DFNet itself)."""
 
     @staticmethod
-    def forward(ctx, x, module, bn_batch, return_pose, upH, upW, *params):
+    def forward(ctx, x, module, bn_batch, return_pose, single, upH, upW, *params):
         x = x.detach()
         E = module.engine(train=True)
         feats, pose, stats = E.forward_train(x, True, return_pose, bn_batch, upH, upW)
         if bn_batch:
             module._update_running_stats(stats, x.shape)
         ctx.save_for_backward(x)
-        ctx.cfg = (module, bn_batch)
-        return feats, pose
+        ctx.cfg = (module, bn_batch, single)
+        if single:
+            return feats, None, pose
+        half = x.shape[0] // 2   # the two streams: halves of ONE [L,2B,128,H,W] tensor (no copy)
+        return feats[:, :half], feats[:, half:], pose
 
     @staticmethod
-    def backward(ctx, g_feats, g_pose):
+    def backward(ctx, g_a, g_b, g_pose):
         (x,) = ctx.saved_tensors
-        m, bn_batch = ctx.cfg
+        m, bn_batch, single = ctx.cfg
         E = m.engine(train=True)
+        if single or (g_a is None and g_b is None):
+            g_feats = g_a
+        else:
+            ref = g_a if g_a is not None else g_b
+            g_a = torch.zeros_like(ref) if g_a is None else g_a
+            g_b = torch.zeros_like(ref) if g_b is None else g_b
+            L, hb = ref.shape[0], ref.shape[1]
+            slab = ref[0, 0].numel()
+            C, H, W = ref.shape[2:]
+            dense = (2 * hb * slab, slab, H * W, W, 1)
+            if g_a.stride() == dense and g_b.stride() == dense and g_b.data_ptr() == g_a.data_ptr() + 4 * hb * slab and \
+                    g_a.dtype == torch.float32:
+                # the halves of one tensor already (the fused triplet loss writes them that way)
+                g_feats = torch.as_strided(g_a, (L, 2 * hb) + tuple(ref.shape[2:]), dense)
+            else:
+                g_feats = torch.cat([g_a, g_b], 1)
         if g_feats is None and g_pose is None:
             grads = {}
         elif g_feats is None:
             grads = E.backward_params(x, g_pose.contiguous())
         else:
             grads = E.backward_all_params(x, None if g_pose is None else g_pose.contiguous(), g_feats.contiguous(), bn_batch=bn_batch)
-        return (None,) * 6 + tuple(grads.get(k) for k in E.train_param_names(True))
+        return (None,) * 7 + tuple(grads.get(k) for k in E.train_param_names(True))
 
 
 class _DFNetBase(nn.Module):
@@ -222,10 +241,9 @@ class _DFNetBase(nn.Module):
             # training DFNet itself: unfolded adaptation layers, BatchNorm by its own mode, every parameter gradient
             sd = dict(self.named_parameters())
             names = self._train_param_names()
-            feats, pose = _TrainFn.apply(x, self, bool(bn_batch), bool(return_pose), int(upsampleH), int(upsampleW),
-                                         *[sd[k] for k in names])
-            half = x.shape[0] // 2
-            return ([feats] if isSingleStream else [feats[:, :half], feats[:, half:]]), pose
+            fa, fb, pose = _TrainFn.apply(x, self, bool(bn_batch), bool(return_pose), bool(isSingleStream), int(upsampleH),
+                                          int(upsampleW), *[sd[k] for k in names])
+            return ([fa] if isSingleStream else [fa, fb]), pose
         if wants_grad and return_pose and not return_feature:
             # training the regressor (DFNet_dm): parameter gradients of the pose path come from the HIP wgrad kernels
             sd = dict(self.named_parameters())

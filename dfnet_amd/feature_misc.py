@@ -93,6 +93,72 @@ def PoseLoss(args, pose_, pose, device):
     return torch.nn.functional.mse_loss(pose_.to(device), pose)
 
 
+def _stack_layout(t):
+    """(level_stride in floats) if t is an fp32 CUDA stack [L,B,C,H,W] whose levels are dense [B,C,H,W] blocks — a
+    contiguous tensor or one half of a siamese [L,2B,C,H,W] tensor — else None."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 5):
+        return None
+    L, B, C, H, W = t.shape
+    if tuple(t.stride()[1:]) != (C * H * W, H * W, W, 1) or t.stride(0) < B * C * H * W:
+        return None
+    return t.stride(0)
+
+
+class _TripletFn(torch.autograd.Function):
+    """The three triplet losses of misc.py:355-435 as one fused HIP forward / backward (dfn_triplet_loss_*)."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, margin, mining):
+        import ctypes
+        from ._lib import check, current_stream, load, ptr
+        lib = load()
+        L, B, C, H, W = f1.shape
+        ls1, ls2 = _stack_layout(f1), _stack_layout(f2)
+        nbytes = lib.dfn_triplet_loss_state_bytes(L, B, C * H)
+        state = torch.empty(nbytes, dtype=torch.uint8, device=f1.device)
+        loss = torch.empty(1, device=f1.device)
+        check(lib.dfn_triplet_loss_forward(ctypes.c_void_p(f1.data_ptr()), ls1, ctypes.c_void_p(f2.data_ptr()), ls2, L, B, C * H, W,
+                                           float(margin), int(mining), ptr(loss), ctypes.c_void_p(state.data_ptr()), nbytes,
+                                           current_stream()), "dfn_triplet_loss_forward")
+        ctx.save_for_backward(f1, f2, state)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from ._lib import check, current_stream, load, ptr
+        f1, f2, state = ctx.saved_tensors
+        lib = load()
+        L, B, C, H, W = f1.shape
+        slab = C * H * W
+        ls1, ls2 = f1.stride(0), f2.stride(0)
+        # the two halves of one siamese tensor: gradients go into the halves of ONE tensor as well, so the consumer
+        # (DFNet's backward) gets d L/d features in its own layout without a concatenation
+        d = (f1.data_ptr() - f2.data_ptr()) // 4
+        if ls1 == ls2 == 2 * B * slab and abs(d) == B * slab:
+            G = torch.empty(L, 2 * B, C, H, W, device=f1.device)
+            g1, g2 = (G[:, B:], G[:, :B]) if d > 0 else (G[:, :B], G[:, B:])
+        else:
+            g1, g2 = torch.empty(L, B, C, H, W, device=f1.device), torch.empty(L, B, C, H, W, device=f1.device)
+        gl = g.detach().reshape(1).to(torch.float32).contiguous()
+        check(lib.dfn_triplet_loss_backward(ctypes.c_void_p(f1.data_ptr()), ls1, ctypes.c_void_p(f2.data_ptr()), ls2, L, B, C * H, W,
+                                            ptr(gl), ctypes.c_void_p(state.data_ptr()), ctypes.c_void_p(g1.data_ptr()), g1.stride(0),
+                                            ctypes.c_void_p(g2.data_ptr()), g2.stride(0), current_stream()),
+              "dfn_triplet_loss_backward")
+        return g1, g2, None, None
+
+
+def _fused_triplet(f1, f2, margin, mining):
+    """The HIP path when both stacks live on the GPU in a layout the kernels address in place; None otherwise (CPU
+    tensors — the torch composition below is then the reference's own code path, not a fallback of a GPU op)."""
+    if f1.shape == f2.shape and _stack_layout(f1) is not None and _stack_layout(f2) is not None:
+        return _TripletFn.apply(f1, f2, float(margin), mining)
+    if f1.is_cuda:
+        raise ValueError("triplet loss on the GPU needs fp32 stacks [L,B,C,H,W] with dense levels, got "
+                         f"{tuple(f1.shape)} {f1.stride()} / {tuple(f2.shape)} {f2.stride()}")
+    return None
+
+
 def _triplet(anchor, positive, negative, margin):
     # nn.TripletMarginLoss(margin, p=2, reduction='mean'): pairwise L2 distance over the LAST axis (eps 1e-6)
     return torch.nn.functional.triplet_margin_loss(anchor, positive, negative, margin=margin, p=2, reduction='mean')
@@ -100,11 +166,17 @@ def _triplet(anchor, positive, negative, margin):
 
 def triplet_loss(f1, f2, margin=1.):
     """Naive triplet loss on feature stacks [lvl,B,C,H,W]: negative = the next image of the batch (misc.py:355-369)."""
+    fused = _fused_triplet(f1, f2, margin, 0)
+    if fused is not None:
+        return fused
     return _triplet(f1, f2, torch.roll(f2, shifts=1, dims=1), margin)
 
 
 def triplet_loss_hard_negative_mining(f1, f2, margin=1.):
     """In-triplet hard negative with anchor swap, two cases (misc.py:371-397)."""
+    fused = _fused_triplet(f1, f2, margin, 1)
+    if fused is not None:
+        return fused
     a_neg, neg = torch.roll(f1, shifts=1, dims=1), torch.roll(f2, shifts=1, dims=1)
     with torch.no_grad():
         case1 = torch.nn.functional.mse_loss(f1, neg)
@@ -115,6 +187,9 @@ def triplet_loss_hard_negative_mining(f1, f2, margin=1.):
 def triplet_loss_hard_negative_mining_plus(f1, f2, margin=1.):
     """In-triplet hard negative, four cases: the closest of (anchor, negative), (positive, anchor_negative),
     (anchor, anchor_negative), (positive, negative) decides which pair anchors the loss (misc.py:399-435)."""
+    fused = _fused_triplet(f1, f2, margin, 2)
+    if fused is not None:
+        return fused
     anchor, positive = f1, f2
     a_neg, neg = torch.roll(f1, shifts=1, dims=1), torch.roll(f2, shifts=1, dims=1)
     mse = torch.nn.functional.mse_loss

@@ -264,6 +264,27 @@ int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const float* x, int B
                                   int level_mask, int bn_batch, float* const* grads, int n_grads, void* workspace,
                                   size_t workspace_bytes, void* stream);
 
+/* ---- the triplet loss of DFNet's training on the two feature stacks (feature/misc.py:355-435), fused.
+ *
+ * f1 (anchor, the rendered stream in run_feature.py:155) and f2 (positive, the target stream): fp32 device stacks
+ * [L][B][rows][W] with rows = C * H; level l of a stack starts at base + l * level_stride (floats), images inside a
+ * level are contiguous — so the two halves of one siamese [L, 2B, C, H, W] tensor are addressed in place.  Negatives
+ * are the stacks rolled by one image (torch.roll(f, 1, dims=1)).  nn.TripletMarginLoss(margin, p = 2, eps = 1e-6,
+ * reduction = 'mean'): pairwise distance over the LAST axis W, mean over the L * B * rows rows.
+ *   mining 0  triplet_loss                            (f1, f2, roll f2)
+ *   mining 1  triplet_loss_hard_negative_mining       anchor swap by two full-tensor MSEs
+ *   mining 2  triplet_loss_hard_negative_mining_plus  the closest of four pairs decides (first minimum, torch.argmin)
+ * loss: device float[1].  state (dfn_triplet_loss_state_bytes, device, caller-owned) carries the chosen case, the four
+ * MSEs (floats at byte offset 16) and two distances per row from the forward to the backward.
+ * Backward: grad_loss device float[1]; grad_f1 / grad_f2 are fully written, addressed like the inputs. */
+size_t dfn_triplet_loss_state_bytes(int L, int B, int rows);
+int dfn_triplet_loss_forward(const float* f1, size_t level_stride1, const float* f2, size_t level_stride2, int L,
+                             int B, int rows, int W, float margin, int mining, float* loss, void* state,
+                             size_t state_bytes, void* stream);
+int dfn_triplet_loss_backward(const float* f1, size_t level_stride1, const float* f2, size_t level_stride2, int L,
+                              int B, int rows, int W, const float* grad_loss, const void* state, float* grad_f1,
+                              size_t grad_stride1, float* grad_f2, size_t grad_stride2, void* stream);
+
 /* After an optimizer step of DFNet's own training: re-pack encoder, fc_pose, the adaptation convs (unfolded) and the
  * BatchNorm tensors from DEVICE tensors — 2 * 13 + 2 + 8 * n_taps pointers: those of dfn_dfnet_backward_params, then
  * per level .0.weight, .0.bias, .2.weight, .2.bias, .3.weight, .3.bias, .3.running_mean, .3.running_var.  The

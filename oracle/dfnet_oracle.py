@@ -85,3 +85,24 @@ def dfnet_forward(p, x, return_feature=False, isSingleStream=False, return_pose=
         return maps, None
     pooled = last.mean((2, 3))  # AdaptiveAvgPool2d(1) after relu5_3 + pool5
     return maps, F.linear(pooled, p["fc_pose.weight"], p["fc_pose.bias"])
+
+
+def triplet_loss_cases(f1, f2):
+    """The four full-tensor MSEs of the in-triplet hard-negative mining (misc.py:414-421): (f1, roll f2), (f2, roll f1),
+    (f1, roll f1), (f2, roll f2); roll = torch.roll(., shifts=1, dims=1) — the previous image of the batch."""
+    a_neg, neg = torch.roll(f1, 1, 1), torch.roll(f2, 1, 1)
+    mse = lambda u, v: ((u - v) ** 2).mean()
+    return torch.stack([mse(f1, neg), mse(f2, a_neg), mse(f1, a_neg), mse(f2, neg)])
+
+
+def triplet_loss(f1, f2, margin=1.0, mining=2, eps=1e-6):
+    """Triplet losses on feature stacks [lvl,B,C,H,W] written out from their definition (misc.py:355-435 call
+    nn.TripletMarginLoss(margin, p=2, eps=1e-6, reduction='mean'), whose pairwise distance ||x - y + eps||_2 runs over
+    the LAST axis): mining 0 = triplet_loss, 1 = ..._hard_negative_mining, 2 = ..._hard_negative_mining_plus."""
+    a_neg, neg = torch.roll(f1, 1, 1), torch.roll(f2, 1, 1)
+    with torch.no_grad():
+        c = triplet_loss_cases(f1, f2)
+        case = 0 if mining == 0 else ((0 if c[0] < c[1] else 1) if mining == 1 else int(torch.argmin(c)))
+    x, y, z = [(f1, f2, neg), (f2, f1, a_neg), (f1, f2, a_neg), (f2, f1, neg)][case]
+    d = lambda u, v: torch.sqrt(((u - v + eps) ** 2).sum(-1))
+    return torch.clamp_min(d(x, y) - d(x, z) + margin, 0).mean(), case

@@ -319,6 +319,42 @@ def main():
         save("g10_dfnet_train_" + mode, seed=1010, x=xb, Gp=Gp, Gt_l2=np.sqrt((Gt ** 2).sum()), Gr_l2=np.sqrt((Gr ** 2).sum()), cstride=8, feat_t=feats[0][:, :, ::8], feat_r=feats[1][:, :, ::8],
              pose=pose, **bn, **grad_digest(net))
 
+    # ---------------- G11: the triplet losses of DFNet's training (feature/misc.py:355-435).  That module cannot be
+    # imported here (pytorch3d, torchvision.utils, matplotlib are absent), so the three function definitions are taken
+    # from its syntax tree and executed as they stand, with torch / nn as their globals.
+    import ast
+    src = open(os.path.join(REF, "feature", "misc.py")).read()
+    wanted = ("triplet_loss", "triplet_loss_hard_negative_mining", "triplet_loss_hard_negative_mining_plus")
+    mod = ast.Module(body=[n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in wanted], type_ignores=[])
+    ns = {"torch": torch, "nn": torch.nn}
+    exec(compile(mod, "reference:feature/misc.py", "exec"), ns)
+    out, seen, seed = {}, set(), 0
+    while len(seen) < 4 and seed < 200:
+        r11 = np.random.default_rng(1100 + seed)
+        f1 = r11.standard_normal((3, 4, 8, 5, 6)).astype(np.float32)
+        f2 = (f1 * r11.uniform(0, 1) + r11.standard_normal((3, 4, 8, 5, 6)) * r11.uniform(0.05, 1.5)).astype(np.float32)
+        if seed % 2:   # make a neighbouring image nearly identical: pushes the minimum to the roll cases
+            f1[:, 1] = f1[:, 0] + 0.01 * f1[:, 1]
+        if seed % 3 == 2:
+            f2[:, 2] = f2[:, 1] + 0.01 * f2[:, 2]
+        a, b = t(f1).requires_grad_(True), t(f2).requires_grad_(True)
+        with torch.no_grad():
+            mse = torch.nn.MSELoss()
+            an, ng = torch.roll(a, 1, 1), torch.roll(b, 1, 1)
+            case = int(torch.argmin(torch.stack([mse(a, ng), mse(b, an), mse(a, an), mse(b, ng)])))
+        if case not in seen:
+            seen.add(case)
+            margin = 0.5 + 0.25 * case
+            for k, fn in enumerate(wanted):
+                a.grad = b.grad = None
+                loss = ns[fn](a, b, margin=margin)
+                loss.backward()
+                out.update({f"c{case}_m{k}_loss": loss.detach(), f"c{case}_m{k}_g1": a.grad.clone(), f"c{case}_m{k}_g2": b.grad.clone()})
+            out.update({f"c{case}_f1": f1, f"c{case}_f2": f2, f"c{case}_margin": margin})
+        seed += 1
+    assert seen == {0, 1, 2, 3}, seen
+    save("g11_triplet_losses", **out)
+
 
 if __name__ == "__main__":
     main()

@@ -246,3 +246,40 @@ def test_c4_frame_relative_l2_vs_oracle(net):
         l2 = [float((got[l] - ref[l]).norm() / ref[l].norm()) for l in range(3)]
         print(prec, "relative L2 per level", ["%.2e" % v for v in l2])
         assert max(l2) < tol
+
+
+def test_triplet_loss_fused_vs_reference_golden_and_oracle():
+    """dfn_triplet_loss_forward / backward (the three losses of feature/misc.py:355-435): values and gradients against
+    the reference's own functions (G11, all four mining cases, contiguous stacks) and — on the two halves of one siamese
+    [L,2B,C,H,W] tensor, addressed in place, W not a multiple of the wave — against autograd through the oracle."""
+    import os
+    from dfnet_amd import feature_misc as fm
+    from oracle import dfnet_oracle as dor
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_triplet_losses.npz"))
+    fns = (fm.triplet_loss, fm.triplet_loss_hard_negative_mining, fm.triplet_loss_hard_negative_mining_plus)
+    for case in range(4):
+        margin = float(g[f"c{case}_margin"])
+        for mining, fn in enumerate(fns):
+            f1 = torch.from_numpy(g[f"c{case}_f1"]).to(DEV).requires_grad_(True)
+            f2 = torch.from_numpy(g[f"c{case}_f2"]).to(DEV).requires_grad_(True)
+            loss = fn(f1, f2, margin=margin)
+            (3.0 * loss).backward()
+            ref = float(g[f"c{case}_m{mining}_loss"])
+            assert abs(float(loss) - ref) <= 2e-6 * max(abs(ref), 1e-3), (case, mining, float(loss), ref)
+            for got, key in ((f1.grad, "g1"), (f2.grad, "g2")):
+                want = 3.0 * g[f"c{case}_m{mining}_{key}"]
+                assert float((got.cpu() - torch.from_numpy(want)).abs().max()) <= 2e-5 * float(np.abs(want).max()) + 1e-9, (case, mining, key)
+    gen = torch.Generator().manual_seed(5)
+    L, B, C, H, W = 3, 3, 16, 7, 101
+    F = torch.randn(L, 2 * B, C, H, W, generator=gen)
+    F[:, B + 1] = F[:, 1] + 0.3 * F[:, B + 1]          # some rows inside the margin, some not
+    Fd = F.to(DEV).requires_grad_(True)
+    loss = fm.triplet_loss_hard_negative_mining_plus(Fd[:, B:], Fd[:, :B], margin=1.0)   # (render, target) as run_feature.py
+    loss.backward()
+    Fc = F.clone().requires_grad_(True)
+    ref, _ = dor.triplet_loss(Fc[:, B:], Fc[:, :B], 1.0, 2)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * float(ref)
+    assert float((Fd.grad.cpu() - Fc.grad).abs().max()) <= 2e-5 * float(Fc.grad.abs().max())
+    with pytest.raises(ValueError):
+        fm.triplet_loss(Fd[:, :B, :, :, ::2], Fd[:, B:, :, :, ::2])

@@ -187,3 +187,20 @@ def test_g10_dfnet_training_step(gold, mode):
         close(sub, g["gs:" + k], 0, 3e-4 * max(float(np.abs(g["gs:" + k]).max()), 1e-6))
         n_checked += 1
     assert n_checked == (40 if frozen else 46)
+
+
+def test_g11_triplet_losses(gold):
+    """Triplet losses of DFNet's training, all four mining cases: the oracle's written-out definition vs the values and
+    autograd gradients of the reference's own three functions."""
+    g = gold("g11_triplet_losses")
+    for case in range(4):
+        margin = float(g[f"c{case}_margin"])
+        for mining in range(3):
+            f1, f2 = T(g[f"c{case}_f1"]).requires_grad_(True), T(g[f"c{case}_f2"]).requires_grad_(True)
+            loss, chosen = dor.triplet_loss(f1, f2, margin, mining)
+            if mining == 2:
+                assert chosen == case
+            loss.backward()
+            close(loss.detach(), g[f"c{case}_m{mining}_loss"], 1e-6, 1e-7)
+            close(f1.grad, g[f"c{case}_m{mining}_g1"], 1e-5, 1e-8)
+            close(f2.grad, g[f"c{case}_m{mining}_g2"], 1e-5, 1e-8)
