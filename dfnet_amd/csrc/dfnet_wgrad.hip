@@ -52,11 +52,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   // Addressing: the input pixel of tap (ky, kx) for pixel q is q + (ky-R) W + (kx-R) in the flat [B*H*W] order, so
-  // every load is a uniform base pointer (per workgroup and tap) plus one 32-bit per-lane offset that advances by a
-  // constant; (x, y) are tracked incrementally only for the border masks.  No division in the loop.
-  const float* gbase = g + ((size_t)q0 * mblks + mblk) * 32 + c;       // + (q - q0) * mblks * 32
-  const float* ibase = in + ((size_t)q0 * nblks + nblk) * 32 + c;      // + (q - q0 + tap offset) * nblks * 32
-  const uint32_t gstep = (uint32_t)mblks * 32, istep = (uint32_t)nblks * 32;
+  // every tap gets its own wave-uniform buffer descriptor (base = the workgroup's first pixel shifted by the tap) and
+  // all taps share ONE 32-bit per-lane byte offset that advances by a constant.  Border handling costs one select per
+  // tap: a masked lane's offset is set past num_records and the hardware bounds check returns 0 — no address
+  // arithmetic, no value select, no division in the loop; (x, y) are tracked incrementally for the masks only.
+  constexpr uint32_t kOob = 0xFFFFFFF0u, kRecords = 0x80000000u;
+  const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g + ((size_t)q0 * mblks + mblk) * 32), 0, kRecords, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_in[T];
+#pragma unroll
+  for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      const long long off = (long long)(ky0 + ty - R) * W + (kx - R);   // uniform; may point before the tensor: masked lanes only
+      rs_in[ty * KS + kx] =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + ((q0 + off) * nblks + nblk) * 32), 0, kRecords, 0x00020000);
+    }
+  const uint32_t gstep = (uint32_t)mblks * 128, istep = (uint32_t)nblks * 128;   // bytes per pixel
   struct Px { long long q; int x, y; };
   auto locate = [&](long long q) { Px p; p.q = q; p.x = int(q % W); p.y = int((q / W) % H); return p; };
   auto advance = [&](Px& p) {   // by four pixels
@@ -68,22 +79,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   // (and, through the other wave of the SIMD, the next iteration's) latency hides under the first pair's MFMAs.
   auto fetch = [&](const Px& p, float& a, float (&bv)[T]) {
     const bool live = p.q < w1;
-    const uint32_t d = live ? (uint32_t)(p.q - q0) : 0u;
-    const float av = gbase[(size_t)(d * gstep)];
-    a = live ? av : 0.f;
-    const uint32_t di = d * istep;
+    const uint32_t d = (uint32_t)(p.q - q0);
+    a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, live ? d * gstep + 4u * c : kOob, 0, 0));
+    const uint32_t vo = d * istep + 4u * c;
+    bool okx[KS];
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) okx[kx] = (unsigned)(p.x + kx - R) < (unsigned)W;
 #pragma unroll
     for (int ty = 0; ty < TY; ++ty) {
-      const int dy = ky0 + ty - R;
-      const bool rowok = live && (unsigned)(p.y + dy) < (unsigned)H;
+      const bool rowok = live && (unsigned)(p.y + ky0 + ty - R) < (unsigned)H;
 #pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-        const int dx = kx - R;
-        const bool ok = rowok && (unsigned)(p.x + dx) < (unsigned)W;
-        const int off = dy * W + dx;                                   // uniform
-        const float v = (ibase + (long long)off * istep)[(size_t)(ok ? di : 0u)];
-        bv[ty * KS + kx] = ok ? v : 0.f;
-      }
+      for (int kx = 0; kx < KS; ++kx)
+        bv[ty * KS + kx] =
+            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in[ty * KS + kx], (rowok && okx[kx]) ? vo : kOob, 0, 0));
     }
   };
   Px pa = locate(w0 + k < Q ? w0 + k : 0), pb = locate(w0 + k + 2 < Q ? w0 + k + 2 : 0);
@@ -146,8 +154,8 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
   if (n_chunks < 1) n_chunks = 1;
   while (n_chunks > 1 && (size_t)n_chunks * pairs * T * 1024 > part_floats) --n_chunks;
   if ((size_t)n_chunks * pairs * T * 1024 > part_floats) return hipErrorInvalidValue;
-  // 32-bit per-lane offsets inside a workgroup's pixel range (conv_wgrad_kernel)
-  if ((unsigned long long)((Q + n_chunks - 1) / n_chunks + 4) * (unsigned)(mblks > nblks ? mblks : nblks) * 32 >= (1ull << 32))
+  // 32-bit per-lane byte offsets inside a workgroup's pixel range, below the descriptors' num_records (conv_wgrad_kernel)
+  if ((unsigned long long)((Q + n_chunks - 1) / n_chunks + 8) * (unsigned)(mblks > nblks ? mblks : nblks) * 128 >= (1ull << 31))
     return hipErrorInvalidValue;
   const dim3 grid(pairs, int(n_chunks));
   if (ks == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, part);
