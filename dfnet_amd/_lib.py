@@ -71,10 +71,10 @@ SIGNATURES = {
     "dfn_dfnet_backward_input": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
     "dfn_dfnet_backward_params_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dfn_dfnet_backward_params": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, POINTER(c_void_p), c_int, _P, c_size_t, _P]),
-    "dfn_dfnet_forward_train": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t,
-                                        _P]),
-    "dfn_dfnet_backward_all_params": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, POINTER(c_void_p),
-                                              c_int, _P, c_size_t, _P]),
+    "dfn_dfnet_forward_train": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
+                                        c_size_t, _P]),
+    "dfn_dfnet_backward_all_params": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                              POINTER(c_void_p), c_int, _P, c_size_t, _P]),
     "dfn_triplet_loss_state_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dfn_triplet_loss_forward": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),
     "dfn_triplet_loss_backward": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P, c_size_t, _P]),

@@ -56,6 +56,8 @@ struct dfn_dfnet_s {
   // device block [4][128] = gamma, beta, running_mean, running_var
   std::vector<PackedConv> ad5_raw, ad5_raw_dgrad;
   std::vector<float*> bn_dev;
+  // dfn_dfnet_forward_train(keep = 1) left its activations in this workspace (consumed by backward_all_params)
+  struct { const void* ws = nullptr; int prec = -1, B = 0, H = 0, W = 0, bn_batch = -1; } kept;
 };
 
 static void build_specs(dfn_dfnet_s* h) {
@@ -455,10 +457,20 @@ extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B,
                       workspace_bytes, stream);
 }
 
+static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose, int bn_batch,
+                              int upH, int upW, float* features, float* pose, float* bn_stats, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 extern "C" int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose,
-                                       int bn_batch, int upH, int upW, float* features, float* pose, float* bn_stats,
+                                       int bn_batch, int keep, int upH, int upW, float* features, float* pose, float* bn_stats,
                                        void* workspace, size_t workspace_bytes, void* stream) {
   if (bn_batch && !bn_stats) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward_train: null bn_stats");
+  if (keep) {
+    if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
+      return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_forward_train: batch statistics need fp32 activations (precision F32 or F16X3)");
+    return forward_train_keep(h, prec, x, B, H, W, siamese, return_pose, bn_batch, upH, upW, features, pose, bn_stats, workspace,
+                              workspace_bytes, stream);
+  }
   if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
     return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_forward_train: batch statistics need fp32 activations (precision F32 or F16X3)");
   return forward_core(h, prec, x, B, H, W, 1, siamese, return_pose, upH, upW, features, pose, bn_batch ? 2 : 1, bn_stats, workspace,
@@ -622,9 +634,10 @@ constexpr size_t kWgradPartFloats = size_t(2048) * 9 * 1024;   // partial sums o
 struct DfParamWs {
   DfBwdWs b;
   float *part, *pooled;
-  float* z128;       // plain 5x5 output of the level being processed (BatchNorm backward)
+  float* lvl_tmp64[3];   // per pyramid level: ReLU'd 1x1 output,
+  float* lvl_z[3];       //   plain 5x5 output (BatchNorm input),
+  float* lvl_bn[3];      //   BatchNorm work block (kBnWorkFloats)
   double* bn_part;
-  float* bn_work;
   size_t total;
 };
 DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
@@ -634,9 +647,14 @@ DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return reinterpret_cast<float*>(p); };
   w.part = take(kWgradPartFloats * 4);
   w.pooled = take(size_t(B) * 512 * 4);
-  w.z128 = take(size_t(B) * H * W * 128 * 4);
+  const int div[3] = {1, 4, 16};
+  for (int t = 0; t < h->n_taps; ++t) {
+    const size_t q = size_t(B) * (H / div[t]) * (W / div[t]);
+    w.lvl_tmp64[t] = take(q * 64 * 4);
+    w.lvl_z[t] = take(q * 128 * 4);
+    w.lvl_bn[t] = take(kBnWorkFloats * 4);
+  }
   w.bn_part = reinterpret_cast<double*>(take(kBnPartBytes));
-  w.bn_work = take(kBnWorkFloats * 4);
   w.total = off;
   return w;
 }
@@ -648,13 +666,66 @@ extern "C" size_t dfn_dfnet_backward_params_workspace_bytes(dfn_dfnet_t h, int p
 }
 
 namespace {
+// Encoder forward keeping every activation (and the pre-ReLU taps of the levels in tap_mask) in the params workspace.
+int encoder_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int tap_mask, const DfParamWs& pw, hipStream_t s,
+                 int* lay_h, int* lay_w) {
+  const DfBwdWs& w = pw.b;
+  const int n_enc = int(h->enc.size());
+  CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet train: prep");
+  const void* cur = w.prep;
+  int ch = H, cw = W, nblk = 1;
+  for (int i = 0; i < n_enc; ++i) {
+    const ConvSpec& sp = h->enc[i];
+    lay_h[i] = ch; lay_w[i] = cw;
+    ConvArgs a{};
+    a.in = cur; a.w = h->enc_packed[i].w[prec]; a.bias = prec == 2 ? h->enc_packed[i].bias_x3 : h->enc_packed[i].bias;
+    a.out_scale = h->enc_packed[i].out_scale;
+    a.out_act = w.act[i];
+    a.out_pre = (sp.tap >= 0 && (tap_mask >> sp.tap & 1)) ? w.tap[sp.tap] : nullptr;
+    a.B = B; a.H = ch; a.W = cw; a.nblk_in = nblk; a.cout_blocks = sp.cout / 32; a.relu = 1;
+    CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet train: encoder conv");
+    cur = w.act[i];
+    nblk = sp.cout / 32;
+    if (sp.pool_after && i + 1 < n_enc) {
+      CHECK_HIP(launch_maxpool(prec, cur, B, ch, cw, nblk, w.pooled, s), "dfnet train: maxpool");
+      cur = w.pooled;
+      ch /= 2; cw /= 2;
+    }
+  }
+  return DFN_OK;
+}
+
+// Adaptation layer of level t on the kept tap: lvl_tmp64 = ReLU(1x1); need_z: lvl_z = plain 5x5; BatchNorm work block
+// from batch (bn_batch, optionally reported) or running statistics.
+int adapt_keep(dfn_dfnet_t h, int prec, int t, int B, int hh, int ww, int cin, bool bn_batch, bool need_z, const DfParamWs& pw,
+               hipStream_t s, float* mean_out, float* var_out) {
+  ConvArgs a{};
+  a.in = pw.b.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale;
+  a.out_act = pw.lvl_tmp64[t];
+  a.B = B; a.H = hh; a.W = ww; a.nblk_in = cin / 32; a.cout_blocks = 2; a.relu = 1;
+  CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet train: adapt 1x1");
+  if (need_z) {
+    ConvArgs z{};
+    z.in = pw.lvl_tmp64[t]; z.w = h->ad5_raw[t].w[prec]; z.bias = prec == 2 ? h->ad5_raw[t].bias_x3 : h->ad5_raw[t].bias;
+    z.out_scale = h->ad5_raw[t].out_scale; z.out_act = pw.lvl_z[t];
+    z.B = B; z.H = hh; z.W = ww; z.nblk_in = 2; z.cout_blocks = 4; z.relu = 0;
+    CHECK_HIP(launch_conv(prec, 5, 16, z, s), "dfnet train: adapt 5x5");
+  }
+  if (bn_batch)
+    CHECK_HIP(launch_bn_batch_stats(pw.lvl_z[t], (long long)B * hh * ww, h->bn_dev[t], 1e-5f, pw.bn_part, pw.lvl_bn[t], mean_out, var_out, s),
+              "dfnet train: BatchNorm batch statistics");
+  else
+    CHECK_HIP(launch_bn_running_stats(h->bn_dev[t], 1e-5f, pw.lvl_bn[t], s), "dfnet train: BatchNorm running statistics");
+  return DFN_OK;
+}
+
 // Parameter gradients of DFNet for d L/d pose (optional) and d L/d features (optional, single-stream layout, levels by
 // level_mask).  grads: [0, 2 n_enc) encoder conv weight, bias; then fc_pose weight, bias; then (only when n_grads says
 // so) per tap: adapt 1x1 weight [64,C,1,1], bias, adapt 5x5 weight [128,64,5,5], bias (the plain conv parameters, not
 // the BatchNorm-folded ones) and, with bn_batch (BatchNorm on batch statistics), BatchNorm weight and bias.
 int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
-                         const float* grad_features, int upH, int upW, int level_mask, int bn_batch, float* const* grads,
-                         int n_grads, void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn) {
+                         const float* grad_features, int upH, int upW, int level_mask, int bn_batch, int have_forward,
+                         float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn) {
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
@@ -671,28 +742,20 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
   const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
   if (pw.total > workspace_bytes) return set_error(DFN_ERR_ARG, "%s: workspace too small (%zu < %zu)", fn, workspace_bytes, pw.total);
   const DfBwdWs& w = pw.b;
-  // ---- forward, keeping every activation (and the pre-ReLU taps of the levels that carry gradient)
-  CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet params: prep");
-  const void* cur = w.prep;
-  int ch = H, cw = W, nblk = 1;
   int lay_h[13], lay_w[13];
-  for (int i = 0; i < n_enc; ++i) {
-    const ConvSpec& sp = h->enc[i];
-    lay_h[i] = ch; lay_w[i] = cw;
-    ConvArgs a{};
-    a.in = cur; a.w = h->enc_packed[i].w[prec]; a.bias = prec == 2 ? h->enc_packed[i].bias_x3 : h->enc_packed[i].bias;
-    a.out_scale = h->enc_packed[i].out_scale;
-    a.out_act = w.act[i];
-    a.out_pre = (sp.tap >= 0 && (level_mask >> sp.tap & 1)) ? w.tap[sp.tap] : nullptr;
-    a.B = B; a.H = ch; a.W = cw; a.nblk_in = nblk; a.cout_blocks = sp.cout / 32; a.relu = 1;
-    CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet params: encoder conv");
-    cur = w.act[i];
-    nblk = sp.cout / 32;
-    if (sp.pool_after && i + 1 < n_enc) {
-      CHECK_HIP(launch_maxpool(prec, cur, B, ch, cw, nblk, w.pooled, s), "dfnet params: maxpool");
-      cur = w.pooled;
-      ch /= 2; cw /= 2;
+  if (have_forward) {
+    // the activations are already in the workspace: dfn_dfnet_forward_train(keep = 1) on this handle, same shape
+    if (h->kept.ws != workspace || h->kept.prec != prec || h->kept.B != B || h->kept.H != H || h->kept.W != W ||
+        (level_mask && h->kept.bn_batch != (bn_batch ? 1 : 0)))
+      return set_error(DFN_ERR_STATE, "%s: the workspace does not hold the state of a matching dfn_dfnet_forward_train(keep = 1)", fn);
+    int ch = H, cw = W;
+    for (int i = 0; i < n_enc; ++i) {
+      lay_h[i] = ch; lay_w[i] = cw;
+      if (h->enc[i].pool_after) { ch /= 2; cw /= 2; }
     }
+  } else {
+    // forward recompute, keeping every activation (and the pre-ReLU taps of the levels that carry gradient)
+    if (int rc = encoder_keep(h, prec, x, B, H, W, level_mask, pw, s, lay_h, lay_w)) return rc;
   }
   char* gbuf[2] = {w.gA, w.gB};
   int act_idx = -1, last = -1;   // act_idx: buffer holding the gradient w.r.t. conv i's ReLU output (none yet)
@@ -729,31 +792,18 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       const int t = sp.tap;
       float* const* ag = grads + 2 * n_enc + 2 + per_tap * t;
       const long long Q = (long long)B * hh * ww;
-      ConvArgs a{};
-      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale;
-      a.out_act = w.tmp64;
-      a.B = B; a.H = hh; a.W = ww; a.nblk_in = sp.cout / 32; a.cout_blocks = 2; a.relu = 1;
-      CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet params: adapt 1x1");
+      if (!have_forward)
+        if (int rc = adapt_keep(h, prec, t, B, hh, ww, sp.cout, bn_batch != 0, bn_batch != 0, pw, s, nullptr, nullptr)) return rc;
+      const float* tmp64 = pw.lvl_tmp64[t];
       CHECK_HIP(launch_upsample_backward(1, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s),
                 "dfnet params: upsample backward");
       // BatchNorm backward: d L/d y -> d L/d z (z = the plain 5x5 output), in place
-      if (bn_batch) {
-        ConvArgs z{};
-        z.in = w.tmp64; z.w = h->ad5_raw[t].w[prec]; z.bias = prec == 2 ? h->ad5_raw[t].bias_x3 : h->ad5_raw[t].bias;
-        z.out_scale = h->ad5_raw[t].out_scale; z.out_act = pw.z128;
-        z.B = B; z.H = hh; z.W = ww; z.nblk_in = 2; z.cout_blocks = 4; z.relu = 0;
-        CHECK_HIP(launch_conv(prec, 5, 16, z, s), "dfnet params: adapt 5x5");
-        CHECK_HIP(launch_bn_batch_stats(pw.z128, Q, h->bn_dev[t], 1e-5f, pw.bn_part, pw.bn_work, nullptr, nullptr, s),
-                  "dfnet params: BatchNorm batch statistics");
-      } else {
-        CHECK_HIP(launch_bn_running_stats(h->bn_dev[t], 1e-5f, pw.bn_work, s), "dfnet params: BatchNorm running statistics");
-      }
-      CHECK_HIP(launch_bn_backward(bn_batch, reinterpret_cast<float*>(w.g128), pw.z128, Q, pw.bn_part, pw.bn_work, bn_batch ? ag[4] : nullptr,
+      CHECK_HIP(launch_bn_backward(bn_batch, reinterpret_cast<float*>(w.g128), pw.lvl_z[t], Q, pw.bn_part, pw.lvl_bn[t], bn_batch ? ag[4] : nullptr,
                                    bn_batch ? ag[5] : nullptr, s),
                 "dfnet params: BatchNorm backward");
       const float* g128 = reinterpret_cast<const float*>(w.g128);
       CHECK_HIP(launch_bias_grad(g128, B, hh, ww, 128, pw.part, kWgradPartFloats, ag[3], s), "dfnet params: adapt 5x5 bias gradient");
-      CHECK_HIP(launch_conv_wgrad(5, g128, reinterpret_cast<const float*>(w.tmp64), B, hh, ww, 128, 64, pw.part, kWgradPartFloats, ag[2], s),
+      CHECK_HIP(launch_conv_wgrad(5, g128, tmp64, B, hh, ww, 128, 64, pw.part, kWgradPartFloats, ag[2], s),
                 "dfnet params: adapt 5x5 weight gradient");
       ConvArgs c{};
       const PackedConv& d5 = h->ad5_raw_dgrad[t];
@@ -761,7 +811,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       c.dyn_scale = dyn(w.g128, size_t(B) * hh * ww * 128);
       c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet params: adapt 5x5 dgrad");
-      CHECK_HIP(launch_relu_gate(1, w.g64, w.tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet params: adapt gate");
+      CHECK_HIP(launch_relu_gate(1, w.g64, tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet params: adapt gate");
       const float* g64 = reinterpret_cast<const float*>(w.g64);
       CHECK_HIP(launch_bias_grad(g64, B, hh, ww, 64, pw.part, kWgradPartFloats, ag[1], s), "dfnet params: adapt 1x1 bias gradient");
       CHECK_HIP(launch_conv_wgrad(1, g64, reinterpret_cast<const float*>(w.tap[t]), B, hh, ww, 64, sp.cout, pw.part, kWgradPartFloats, ag[0], s),
@@ -812,19 +862,67 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
 }
 }  // namespace
 
+// dfn_dfnet_forward_train(keep = 1): the training forward on the params-workspace layout, leaving every activation, the
+// pre-ReLU taps, each level's 1x1 / plain 5x5 outputs and BatchNorm work block in place for the backward.
+static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose, int bn_batch,
+                              int upH, int upW, float* features, float* pose, float* bn_stats, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  const char* fn = "dfn_dfnet_forward_train";
+  if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
+  if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
+  if (!x || !workspace || !features || B < 1 || H < 32 || W < 32 || upH < 1 || upW < 1 || (return_pose && !pose) || (siamese && (B & 1)))
+    return set_error(DFN_ERR_ARG, "%s: bad argument (need H,W >= 32; even batch for siamese)", fn);
+  const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
+  if (pw.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "%s: keep = 1 needs dfn_dfnet_backward_params_workspace_bytes (%zu < %zu)", fn, workspace_bytes, pw.total);
+  hipStream_t s = HS(stream);
+  h->kept.ws = nullptr;
+  int lay_h[13], lay_w[13];
+  if (int rc = encoder_keep(h, prec, x, B, H, W, (1 << h->n_taps) - 1, pw, s, lay_h, lay_w)) return rc;
+  const int n_enc = int(h->enc.size());
+  const size_t plane = size_t(128) * upH * upW;
+  for (int i = 0; i < n_enc; ++i) {
+    const int t = h->enc[i].tap;
+    if (t < 0) continue;
+    const int hh = lay_h[i], ww = lay_w[i];
+    if (int rc = adapt_keep(h, prec, t, B, hh, ww, h->enc[i].cout, bn_batch != 0, true, pw, s, bn_batch ? bn_stats + size_t(t) * 256 : nullptr,
+                            bn_batch ? bn_stats + size_t(t) * 256 + 128 : nullptr))
+      return rc;
+    if (!siamese) {
+      CHECK_HIP(launch_upsample(prec, pw.lvl_z[t], B, hh, ww, upH, upW, features + size_t(t) * B * plane, plane, s, pw.lvl_bn[t]),
+                "dfnet train: upsample");
+    } else {
+      const int hb = B / 2;
+      for (int half = 0; half < 2; ++half)
+        CHECK_HIP(launch_upsample(prec, pw.lvl_z[t] + size_t(half) * hb * hh * ww * 128, hb, hh, ww, upH, upW,
+                                  features + (size_t(half) * h->n_taps + t) * hb * plane, plane, s, pw.lvl_bn[t]),
+                  "dfnet train: upsample");
+    }
+  }
+  if (return_pose) {
+    if (lay_h[n_enc - 1] < 2 || lay_w[n_enc - 1] < 2) return set_error(DFN_ERR_ARG, "%s: image too small for pool5", fn);
+    CHECK_HIP(launch_pose_head(prec, pw.b.act[n_enc - 1], B, lay_h[n_enc - 1], lay_w[n_enc - 1], h->fc, h->fc + size_t(h->feat_dim) * 512,
+                               h->feat_dim, pose, s),
+              "dfnet train: pose head");
+  }
+  h->kept.ws = workspace; h->kept.prec = prec; h->kept.B = B; h->kept.H = H; h->kept.W = W; h->kept.bn_batch = bn_batch ? 1 : 0;
+  return DFN_OK;
+}
+
 extern "C" int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
                                          float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
   if (!grad_pose) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_params: null grad_pose");
-  return backward_params_core(h, prec, x, B, H, W, grad_pose, nullptr, 0, 0, 0, 0, grads, n_grads, workspace, workspace_bytes,
+  return backward_params_core(h, prec, x, B, H, W, grad_pose, nullptr, 0, 0, 0, 0, 0, grads, n_grads, workspace, workspace_bytes,
                               HS(stream), "dfn_dfnet_backward_params");
 }
 
 extern "C" int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
                                              const float* grad_features, int upH, int upW, int level_mask, int bn_batch,
-                                             float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, void* stream) {
+                                             int have_forward, float* const* grads, int n_grads, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
   if (!grad_features) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_all_params: null grad_features (use dfn_dfnet_backward_params)");
-  return backward_params_core(h, prec, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, bn_batch != 0, grads, n_grads,
-                              workspace, workspace_bytes, HS(stream), "dfn_dfnet_backward_all_params");
+  return backward_params_core(h, prec, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, bn_batch != 0, have_forward != 0,
+                              grads, n_grads, workspace, workspace_bytes, HS(stream), "dfn_dfnet_backward_all_params");
 }
 
 // ------------------------------------------------------------------------------------------ device-side parameter refresh

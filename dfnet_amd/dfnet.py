@@ -102,10 +102,15 @@ class _TrainFn(torch.autograd.Function):
     def forward(ctx, x, module, bn_batch, return_pose, single, upH, upW, *params):
         x = x.detach()
         E = module.engine(train=True)
-        feats, pose, stats = E.forward_train(x, True, return_pose, bn_batch, upH, upW)
+        # with a graph being recorded the forward keeps its activations (the "tape") and the backward recomputes nothing
+        keep = any(ctx.needs_input_grad)
+        out = E.forward_train(x, True, return_pose, bn_batch, upH, upW, keep=keep)
+        feats, pose, stats = out[:3]
         if bn_batch:
             module._update_running_stats(stats, x.shape)
         ctx.save_for_backward(x)
+        ctx.tape = out[3] if keep else None
+        ctx.tape_version = module._version() if keep else None
         ctx.cfg = (module, bn_batch, single)
         if single:
             return feats, None, pose
@@ -138,7 +143,11 @@ class _TrainFn(torch.autograd.Function):
         elif g_feats is None:
             grads = E.backward_params(x, g_pose.contiguous())
         else:
-            grads = E.backward_all_params(x, None if g_pose is None else g_pose.contiguous(), g_feats.contiguous(), bn_batch=bn_batch)
+            # the tape is valid only while this was the engine's latest kept forward and no weight moved since
+            tape = ctx.tape if ctx.tape is not None and E.kept_tape is ctx.tape and ctx.tape_version == m._version() else None
+            grads = E.backward_all_params(x, None if g_pose is None else g_pose.contiguous(), g_feats.contiguous(), bn_batch=bn_batch,
+                                          tape=tape)
+            ctx.tape = None
         return (None,) * 7 + tuple(grads.get(k) for k in E.train_param_names(True))
 
 

@@ -199,6 +199,7 @@ class DfnetEngine:
     def __init__(self, n_taps=3, feat_dim=12, precision="f16x3"):
         self.lib = _lib.load()
         self.n_taps, self.feat_dim, self.precision = n_taps, feat_dim, precision
+        self.kept_tape = None
         self.handle = ctypes.c_void_p()
         check(self.lib.dfn_dfnet_create(n_taps, feat_dim, ctypes.byref(self.handle)), "dfn_dfnet_create")
         self._ws = None
@@ -275,10 +276,11 @@ class DfnetEngine:
         return dict(zip(names, grads))
 
     def forward_train(self, x, isSingleStream=False, return_pose=True, bn_batch=True, upsampleH=240, upsampleW=427,
-                      precision=None):
+                      precision=None, keep=False):
         """DFNet.forward while the module is being trained: (features, pose, bn_stats).  bn_batch: BatchNorm on the
         statistics of this batch (train() mode) — bn_stats [n_taps, 2, 128] = batch mean, biased variance — or on its
-        running statistics (--freezeBN; bn_stats None)."""
+        running statistics (--freezeBN; bn_stats None).  keep=True: returns (features, pose, bn_stats, tape) — the tape
+        holds every activation for backward_all_params(tape=...), which then recomputes nothing."""
         x = _f32c(x)
         B, C, H, W = x.shape
         assert C == 3
@@ -288,16 +290,21 @@ class DfnetEngine:
         feats = torch.empty(shape, device=dev)
         pose = torch.empty(B, self.feat_dim, device=dev) if return_pose else None
         stats = torch.empty(self.n_taps, 2, 128, device=dev) if bn_batch else None
-        nbytes = self.lib.dfn_dfnet_workspace_bytes(self.handle, prec, B, H, W)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if keep:
+            ws = torch.empty(self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W), dtype=torch.uint8, device=dev)
+        else:
+            nbytes = self.lib.dfn_dfnet_workspace_bytes(self.handle, prec, B, H, W)
+            if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws = self._ws
         check(self.lib.dfn_dfnet_forward_train(self.handle, prec, ptr(x), B, H, W, int(not isSingleStream), int(return_pose),
-                                               int(bool(bn_batch)), int(upsampleH), int(upsampleW), ptr(feats), ptr(pose), ptr(stats),
-                                               ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), current_stream()),
+                                               int(bool(bn_batch)), int(bool(keep)), int(upsampleH), int(upsampleW), ptr(feats), ptr(pose),
+                                               ptr(stats), ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
               "dfn_dfnet_forward_train")
         if not isSingleStream:
             feats = (feats[0], feats[1])
-        return feats, pose, stats
+        self.kept_tape = ws if keep else None   # the engine remembers ONE kept forward: the latest
+        return (feats, pose, stats, ws) if keep else (feats, pose, stats)
 
     def train_param_names(self, bn_affine=True):
         """state_dict keys in the order of backward_all_params' gradients."""
@@ -312,7 +319,7 @@ class DfnetEngine:
                 names += [f"{pre}.3.weight", f"{pre}.3.bias"]
         return names
 
-    def backward_all_params(self, x, grad_pose, grad_features, levels=None, bn_batch=False, precision=None):
+    def backward_all_params(self, x, grad_pose, grad_features, levels=None, bn_batch=False, precision=None, tape=None):
         """Gradients of BOTH heads w.r.t. every trained parameter (run_feature.py:166-230): dict keyed as
         train_param_names(bn_affine=bn_batch).  bn_batch False: BatchNorm frozen on its running statistics
         (--freezeBN); True: batch statistics, with the gradients of BatchNorm's weight and bias.
@@ -336,12 +343,14 @@ class DfnetEngine:
         # zeros for the adaptation layers: levels outside the mask are not written
         grads = [torch.empty(sh, device=dev) if i < n_pose else torch.zeros(sh, device=dev) for i, sh in enumerate(shapes)]
         ptrs = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
-        nbytes = self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if tape is None:
+            nbytes = self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W)
+            if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = self._ws if tape is None else tape
         check(self.lib.dfn_dfnet_backward_all_params(self.handle, prec, ptr(x), B, H, W, ptr(gp), ptr(g), g.shape[3], g.shape[4], mask,
-                                                     int(bool(bn_batch)), ptrs, len(grads), ctypes.c_void_p(self._ws.data_ptr()),
-                                                     self._ws.numel(), current_stream()),
+                                                     int(bool(bn_batch)), int(tape is not None), ptrs, len(grads),
+                                                     ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
               "dfn_dfnet_backward_all_params")
         return dict(zip(names, grads))
 

@@ -246,10 +246,13 @@ int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, in
  *   bn_batch = 0  --freezeBN (BatchNorm modules in eval(), utils.py:30-39): running statistics; bn_stats may be NULL.
  *                 Same values as dfn_dfnet_forward, but from the weights dfn_dfnet_refresh_train_params_device keeps
  *                 current.
- * Workspace: dfn_dfnet_workspace_bytes.  Precision F32 or F16X3. */
+ * keep = 0: streaming forward, workspace of dfn_dfnet_workspace_bytes.  keep = 1: the workspace (sized by
+ * dfn_dfnet_backward_params_workspace_bytes) keeps every activation for dfn_dfnet_backward_all_params(have_forward =
+ * 1) on the same handle, which then skips its forward recompute; the caller must leave the workspace untouched in
+ * between and commit / refresh no weights.  Precision F32 or F16X3. */
 int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese,
-                            int return_pose, int bn_batch, int upH, int upW, float* features, float* pose,
-                            float* bn_stats, void* workspace, size_t workspace_bytes, void* stream);
+                            int return_pose, int bn_batch, int keep, int upH, int upW, float* features,
+                            float* pose, float* bn_stats, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Parameter gradients of both heads: grad_pose [B, feat_dim] (may be NULL), grad_features single-stream layout
  * [n_taps, B, 128, upH, upW] with level_mask as in dfn_dfnet_backward_input.  The pointers of
@@ -258,11 +261,12 @@ int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int 
  *   bn_batch = 0  BatchNorm frozen on its running statistics (--freezeBN); n_grads = 2 * 13 + 2 + 4 * n_taps
  *   bn_batch = 1  batch statistics, the backward of dfn_dfnet_forward_train;  n_grads = 2 * 13 + 2 + 6 * n_taps
  * Gradients of levels outside level_mask are left untouched (zero them beforehand).  Workspace:
- * dfn_dfnet_backward_params_workspace_bytes. */
+ * dfn_dfnet_backward_params_workspace_bytes; have_forward = 1: it is the workspace a matching
+ * dfn_dfnet_forward_train(keep = 1) filled (DFN_ERR_STATE otherwise) and no forward is recomputed. */
 int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W,
                                   const float* grad_pose, const float* grad_features, int upH, int upW,
-                                  int level_mask, int bn_batch, float* const* grads, int n_grads, void* workspace,
-                                  size_t workspace_bytes, void* stream);
+                                  int level_mask, int bn_batch, int have_forward, float* const* grads, int n_grads,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the triplet loss of DFNet's training on the two feature stacks (feature/misc.py:355-435), fused.
  *

@@ -376,6 +376,29 @@ def test_dfnet_all_parameter_gradients_vs_autograd(dfnet, bn_batch, with_pose):
     assert best < 5e-5
 
 
+@pytest.mark.parametrize("bn_batch", [True, False])
+def test_dfnet_kept_forward_matches_recompute(dfnet, bn_batch):
+    """forward_train(keep) leaves its activations in the caller's workspace; the backward on that tape must give exactly
+    the gradients of the recomputing backward (same kernels, same order), and a tape that does not match is refused."""
+    E, _ = dfnet
+    rng = np.random.default_rng(77)
+    x = T(rng.uniform(0, 1, (2, 3, 64, 80)).astype(np.float32)).to(DEV)
+    Gf = T(rng.standard_normal((3, 2, 128, 32, 40)).astype(np.float32)).to(DEV)
+    Gp = T(rng.standard_normal((2, 12)).astype(np.float32)).to(DEV)
+    f0, p0, s0 = E.forward_train(x, True, True, bn_batch, 32, 40)
+    f1, p1, s1, tape = E.forward_train(x, True, True, bn_batch, 32, 40, keep=True)
+    assert torch.equal(f0, f1) and torch.equal(p0, p1) and (s0 is None or torch.equal(s0, s1))
+    ref = E.backward_all_params(x, Gp, Gf, bn_batch=bn_batch)
+    got = E.backward_all_params(x, Gp, Gf, bn_batch=bn_batch, tape=tape)
+    assert set(ref) == set(got)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
+    with pytest.raises(RuntimeError, match="forward_train"):   # a workspace that no kept forward filled
+        E.backward_all_params(x, Gp, Gf, bn_batch=bn_batch, tape=torch.empty_like(tape))
+    with pytest.raises(RuntimeError, match="forward_train"):   # right tape, other shape
+        E.backward_all_params(x[:1], Gp[:1], Gf[:, :1].contiguous(), bn_batch=bn_batch, tape=tape)
+
+
 @pytest.mark.parametrize("mode", ["train", "freezebn"])
 def test_dfnet_training_step_vs_reference_golden(mode):
     """The same step against the numbers captured from the reference's DFNet module itself (G10: siamese batch, train()
