@@ -57,7 +57,9 @@ struct dfn_dfnet_s {
   std::vector<PackedConv> ad5_raw, ad5_raw_dgrad;
   std::vector<float*> bn_dev;
   // dfn_dfnet_forward_train(keep = 1) left its activations in this workspace (consumed by backward_all_params)
-  struct { const void* ws = nullptr; int prec = -1, B = 0, H = 0, W = 0, bn_batch = -1; } kept;
+  // (a few: a training step may hold the siamese forward and a pose-only forward before its backward runs)
+  struct Kept { const void* ws; int prec, B, H, W, bn_batch; };
+  std::vector<Kept> kept;
 };
 
 static void build_specs(dfn_dfnet_s* h) {
@@ -464,7 +466,8 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
 extern "C" int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose,
                                        int bn_batch, int keep, int upH, int upW, float* features, float* pose, float* bn_stats,
                                        void* workspace, size_t workspace_bytes, void* stream) {
-  if (bn_batch && !bn_stats) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward_train: null bn_stats");
+  if (bn_batch && features && !bn_stats) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward_train: null bn_stats");
+  if (!features && !keep) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward_train: null features (pose only) needs keep = 1");
   if (keep) {
     if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
       return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_forward_train: batch statistics need fp32 activations (precision F32 or F16X3)");
@@ -745,8 +748,9 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
   int lay_h[13], lay_w[13];
   if (have_forward) {
     // the activations are already in the workspace: dfn_dfnet_forward_train(keep = 1) on this handle, same shape
-    if (h->kept.ws != workspace || h->kept.prec != prec || h->kept.B != B || h->kept.H != H || h->kept.W != W ||
-        (level_mask && h->kept.bn_batch != (bn_batch ? 1 : 0)))
+    const dfn_dfnet_s::Kept* k = nullptr;
+    for (const auto& e : h->kept) if (e.ws == workspace) k = &e;
+    if (!k || k->prec != prec || k->B != B || k->H != H || k->W != W || (level_mask && k->bn_batch != (bn_batch ? 1 : 0)))
       return set_error(DFN_ERR_STATE, "%s: the workspace does not hold the state of a matching dfn_dfnet_forward_train(keep = 1)", fn);
     int ch = H, cw = W;
     for (int i = 0; i < n_enc; ++i) {
@@ -870,20 +874,22 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
   const char* fn = "dfn_dfnet_forward_train";
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
-  if (!x || !workspace || !features || B < 1 || H < 32 || W < 32 || upH < 1 || upW < 1 || (return_pose && !pose) || (siamese && (B & 1)))
+  if (!x || !workspace || (!features && !return_pose) || B < 1 || H < 32 || W < 32 || (features && (upH < 1 || upW < 1)) ||
+      (return_pose && !pose) || (features && siamese && (B & 1)))
     return set_error(DFN_ERR_ARG, "%s: bad argument (need H,W >= 32; even batch for siamese)", fn);
   const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
   if (pw.total > workspace_bytes)
     return set_error(DFN_ERR_ARG, "%s: keep = 1 needs dfn_dfnet_backward_params_workspace_bytes (%zu < %zu)", fn, workspace_bytes, pw.total);
   hipStream_t s = HS(stream);
-  h->kept.ws = nullptr;
+  for (size_t i = 0; i < h->kept.size();)   // this workspace is being overwritten
+    if (h->kept[i].ws == workspace) h->kept.erase(h->kept.begin() + i); else ++i;
   int lay_h[13], lay_w[13];
-  if (int rc = encoder_keep(h, prec, x, B, H, W, (1 << h->n_taps) - 1, pw, s, lay_h, lay_w)) return rc;
+  if (int rc = encoder_keep(h, prec, x, B, H, W, features ? (1 << h->n_taps) - 1 : 0, pw, s, lay_h, lay_w)) return rc;
   const int n_enc = int(h->enc.size());
   const size_t plane = size_t(128) * upH * upW;
   for (int i = 0; i < n_enc; ++i) {
     const int t = h->enc[i].tap;
-    if (t < 0) continue;
+    if (t < 0 || !features) continue;   // features == NULL: the pose path only (its backward needs no adaptation layers)
     const int hh = lay_h[i], ww = lay_w[i];
     if (int rc = adapt_keep(h, prec, t, B, hh, ww, h->enc[i].cout, bn_batch != 0, true, pw, s, bn_batch ? bn_stats + size_t(t) * 256 : nullptr,
                             bn_batch ? bn_stats + size_t(t) * 256 + 128 : nullptr))
@@ -905,7 +911,8 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
                                h->feat_dim, pose, s),
               "dfnet train: pose head");
   }
-  h->kept.ws = workspace; h->kept.prec = prec; h->kept.B = B; h->kept.H = H; h->kept.W = W; h->kept.bn_batch = bn_batch ? 1 : 0;
+  if (h->kept.size() >= 8) h->kept.erase(h->kept.begin());
+  h->kept.push_back({workspace, prec, B, H, W, features ? (bn_batch ? 1 : 0) : -1});   // -1: no feature gradients from this state
   return DFN_OK;
 }
 
@@ -920,7 +927,8 @@ extern "C" int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const floa
                                              const float* grad_features, int upH, int upW, int level_mask, int bn_batch,
                                              int have_forward, float* const* grads, int n_grads, void* workspace,
                                              size_t workspace_bytes, void* stream) {
-  if (!grad_features) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_all_params: null grad_features (use dfn_dfnet_backward_params)");
+  if (!grad_features && !have_forward)
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_all_params: null grad_features (use dfn_dfnet_backward_params)");
   return backward_params_core(h, prec, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, bn_batch != 0, have_forward != 0,
                               grads, n_grads, workspace, workspace_bytes, HS(stream), "dfn_dfnet_backward_all_params");
 }

@@ -82,7 +82,9 @@ class _PoseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, module, *params):
-        _, pose = module.engine(train=True).forward(x.detach(), False, True, True)   # the pose path reads no folded weights
+        E = module.engine(train=True)   # the pose path reads no BatchNorm-folded weights
+        pose, ctx.tape = E.forward_pose_keep(x.detach())   # activations kept: the backward recomputes nothing
+        ctx.tape_version = module._version()
         ctx.save_for_backward(x.detach())
         ctx.module = module
         return pose
@@ -91,7 +93,10 @@ class _PoseFn(torch.autograd.Function):
     def backward(ctx, g_pose):
         (x,) = ctx.saved_tensors
         m = ctx.module
-        grads = m.engine(train=True).backward_params(x, g_pose.contiguous())
+        E = m.engine(train=True)
+        tape = ctx.tape if E.holds(ctx.tape) and ctx.tape_version == m._version() else None
+        grads = E.backward_params(x, g_pose.contiguous(), tape=tape)
+        ctx.tape = None
         return (None, None) + tuple(grads[k] for k in m._pose_param_names())
 
 
@@ -144,7 +149,7 @@ class _TrainFn(torch.autograd.Function):
             grads = E.backward_params(x, g_pose.contiguous())
         else:
             # the tape is valid only while this was the engine's latest kept forward and no weight moved since
-            tape = ctx.tape if ctx.tape is not None and E.kept_tape is ctx.tape and ctx.tape_version == m._version() else None
+            tape = ctx.tape if E.holds(ctx.tape) and ctx.tape_version == m._version() else None
             grads = E.backward_all_params(x, None if g_pose is None else g_pose.contiguous(), g_feats.contiguous(), bn_batch=bn_batch,
                                           tape=tape)
             ctx.tape = None

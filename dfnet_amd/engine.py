@@ -199,7 +199,7 @@ class DfnetEngine:
     def __init__(self, n_taps=3, feat_dim=12, precision="f16x3"):
         self.lib = _lib.load()
         self.n_taps, self.feat_dim, self.precision = n_taps, feat_dim, precision
-        self.kept_tape = None
+        self.kept_tapes = []   # data_ptr()s of the workspaces the last kept forwards filled (the handle remembers 8)
         self.handle = ctypes.c_void_p()
         check(self.lib.dfn_dfnet_create(n_taps, feat_dim, ctypes.byref(self.handle)), "dfn_dfnet_create")
         self._ws = None
@@ -252,9 +252,30 @@ class DfnetEngine:
 
     CONV_INDEX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)  # encoder positions of the 13 convs (VGG16 cfg "D")
 
-    def backward_params(self, x, grad_pose, precision=None):
+    def _remember(self, ws):
+        self.kept_tapes = [p for p in self.kept_tapes if p != ws.data_ptr()][-7:] + [ws.data_ptr()]
+
+    def holds(self, tape):
+        """True if `tape` is (still) one of the kept forwards the handle can run a backward from."""
+        return tape is not None and tape.data_ptr() in self.kept_tapes
+
+    def forward_pose_keep(self, x, precision=None):
+        """Pose regression keeping the encoder's activations: (pose [B, feat_dim], tape) for backward_params(tape=...)."""
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        prec = _lib.PRECISIONS[precision or self.precision]
+        pose = torch.empty(B, self.feat_dim, device=x.device)
+        ws = torch.empty(self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W), dtype=torch.uint8, device=x.device)
+        check(self.lib.dfn_dfnet_forward_train(self.handle, prec, ptr(x), B, H, W, 0, 1, 0, 1, 0, 0, None, ptr(pose), None,
+                                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
+              "dfn_dfnet_forward_train")
+        self._remember(ws)
+        return pose, ws
+
+    def backward_params(self, x, grad_pose, precision=None, tape=None):
         """Gradients of the pose-regression path w.r.t. its parameters: dict {state_dict key: tensor} for
-        encoder.<k>.weight|bias (13 convs) and fc_pose.weight|bias, from d L/d pose [B, feat_dim]."""
+        encoder.<k>.weight|bias (13 convs) and fc_pose.weight|bias, from d L/d pose [B, feat_dim].  tape: the state
+        forward_pose_keep / forward_train(keep=True) left (no forward recompute)."""
         x, gp = _f32c(x), _f32c(grad_pose).reshape(x.shape[0], self.feat_dim)
         B, C, H, W = x.shape
         prec = _lib.PRECISIONS[precision or self.precision]
@@ -267,6 +288,11 @@ class DfnetEngine:
         names += ["fc_pose.weight", "fc_pose.bias"]
         grads += [torch.empty(self.feat_dim, 512, device=dev), torch.empty(self.feat_dim, device=dev)]
         ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        if tape is not None:
+            check(self.lib.dfn_dfnet_backward_all_params(self.handle, prec, ptr(x), B, H, W, ptr(gp), None, 0, 0, 0, 0, 1, ptrs, len(grads),
+                                                         ctypes.c_void_p(tape.data_ptr()), tape.numel(), current_stream()),
+                  "dfn_dfnet_backward_all_params")
+            return dict(zip(names, grads))
         nbytes = self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W)
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -303,7 +329,8 @@ class DfnetEngine:
               "dfn_dfnet_forward_train")
         if not isSingleStream:
             feats = (feats[0], feats[1])
-        self.kept_tape = ws if keep else None   # the engine remembers ONE kept forward: the latest
+        if keep:
+            self._remember(ws)
         return (feats, pose, stats, ws) if keep else (feats, pose, stats)
 
     def train_param_names(self, bn_affine=True):

@@ -249,7 +249,9 @@ int dfn_dfnet_backward_params(dfn_dfnet_t h, int prec, const float* x, int B, in
  * keep = 0: streaming forward, workspace of dfn_dfnet_workspace_bytes.  keep = 1: the workspace (sized by
  * dfn_dfnet_backward_params_workspace_bytes) keeps every activation for dfn_dfnet_backward_all_params(have_forward =
  * 1) on the same handle, which then skips its forward recompute; the caller must leave the workspace untouched in
- * between and commit / refresh no weights.  Precision F32 or F16X3. */
+ * between and commit / refresh no weights.  With keep = 1, features may be NULL: the pose path only, for
+ * dfn_dfnet_backward_all_params(grad_features = NULL, have_forward = 1, n_grads = 2 * 13 + 2).  Precision F32 or
+ * F16X3. */
 int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese,
                             int return_pose, int bn_batch, int keep, int upH, int upW, float* features,
                             float* pose, float* bn_stats, void* workspace, size_t workspace_bytes, void* stream);
