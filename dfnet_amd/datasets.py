@@ -1,7 +1,10 @@
 """Dataset front-end producing the hot path's inputs: per frame `(img [1,3,H,W] in [0,1],
 pose [1,12], hist [1,hist_bin])`, plus `hwf` and `[near, far]`.
 
-Host-side I/O only (out of scope for kernels), restated compactly so the
+File I/O and PNG decoding are host work.  The per-frame ARITHMETIC — INTER_AREA downscale, luma,
+histogram, percentages — runs on the GPU when one is present (`dfn_frame_prep`: the decoded 8-bit
+frame goes to HBM once, 3 bytes per source pixel, and the items come out as device tensors); without a GPU (the CPU
+test suite) the same arithmetic is the numpy / torch restatement below.  Restated compactly so the
 drop-in CLIs run: the 7-Scenes on-disk layout (`TrainSplit.txt`, `seq-XX/frame-XXXXXX.color.png`,
 `.pose.txt`; /root/reference/dataset_loaders/seven_scenes.py:185-354), the pose re-centring /
 axis flip / scene rescale of load_7Scenes.py:279-344 (`fix_coord`, including its `M·([R|T]·M)`
@@ -73,7 +76,7 @@ def to_nerf_frame(poses, setup):
 class SevenScenesFrames(torch.utils.data.Dataset):
     """One split of a 7-Scenes scene; items are (img [3,H,W], pose [12], hist [bins])."""
 
-    def __init__(self, frames_root, train, skip=1, df=1., focal=585., hist_bin=10):
+    def __init__(self, frames_root, train, skip=1, df=1., focal=585., hist_bin=10, device_prep=None):
         split = osp.join(frames_root, 'TrainSplit.txt' if train else 'TestSplit.txt')
         with open(split) as fh:
             seqs = [int(l.split('sequence')[-1]) for l in fh if l.strip() and not l.startswith('#')]
@@ -89,11 +92,19 @@ class SevenScenesFrames(torch.utils.data.Dataset):
         self.df = df
         self.H, self.W, self.focal = int(h // df), int(w // df), focal / df
         self.hist_bin = hist_bin
+        # frames are prepared where they are consumed: on the GPU whenever there is one
+        self.device_prep = torch.cuda.is_available() if device_prep is None else bool(device_prep)
 
     def __len__(self):
         return len(self.files)
 
     def __getitem__(self, i):
+        if self.device_prep:
+            from PIL import Image
+            from .engine import frame_prep
+            raw = torch.from_numpy(np.asarray(Image.open(self.files[i]).convert("RGB"), dtype=np.uint8).copy())
+            img, hist = frame_prep(raw.to(torch.device("cuda", torch.cuda.current_device())), self.H, self.W, self.hist_bin)
+            return img, torch.tensor(self.poses[i], dtype=torch.float32), hist
         img = _load_png(self.files[i])
         if self.df != 1.:
             img = _area_downscale(img, self.H, self.W)

@@ -526,3 +526,19 @@ def composite_fine_backward(raw, z, grad_rgb):
     check(_lib.load().dfn_composite_fine_backward(ptr(raw), ptr(z), ptr(grad_rgb), n, Nf, ptr(graw), current_stream()),
           "dfn_composite_fine_backward")
     return graw
+
+
+def frame_prep(rgb_u8, H, W, hist_bins=10):
+    """Dataset front-end of one frame on the device (dfn_frame_prep; seven_scenes.py:324-352): rgb_u8 CUDA uint8
+    [h, w, 3] -> (img fp32 [3, H, W] in [0, 1], INTER_AREA-downscaled; hist fp32 [hist_bins], NeRF-H's histogram index
+    vector)."""
+    assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.dim() == 3 and rgb_u8.shape[2] == 3
+    rgb_u8 = rgb_u8.contiguous()
+    lib = _lib.load()
+    h, w = int(rgb_u8.shape[0]), int(rgb_u8.shape[1])
+    img = torch.empty(3, int(H), int(W), device=rgb_u8.device)
+    hist = torch.empty(int(hist_bins), device=rgb_u8.device)
+    scratch = torch.empty(lib.dfn_frame_prep_scratch_bytes(), dtype=torch.uint8, device=rgb_u8.device)
+    check(lib.dfn_frame_prep(ctypes.c_void_p(rgb_u8.data_ptr()), h, w, int(H), int(W), int(hist_bins), ptr(img), ptr(hist),
+                             ctypes.c_void_p(scratch.data_ptr()), current_stream()), "dfn_frame_prep")
+    return img, hist

@@ -250,7 +250,7 @@ def _drain(dl):
         p[0, 3, 3] = 1.
         poses.append(p)
         idxs.append(img_idx)
-    return torch.cat(imgs, 0).numpy(), torch.cat(poses, 0), torch.cat(idxs, 0)
+    return torch.cat(imgs, 0).cpu().numpy(), torch.cat(poses, 0), torch.cat(idxs, 0)   # gt frames may be device tensors
 
 
 def render_test(args, train_dl, val_dl, hwf, start, render_kwargs_test, decoder_coarse=None, decoder_fine=None):

@@ -270,6 +270,17 @@ int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const float* x, int B
                                   int level_mask, int bn_batch, int have_forward, float* const* grads, int n_grads,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- dataset front-end, per frame (dataset_loaders/seven_scenes.py:324-352).
+ *
+ * rgb_hwc: the decoded 8-bit frame [h, w, 3] in device memory.  Outputs: img_chw fp32 [3, H, W] in [0, 1] =
+ * cv2.resize(img / 255, (W, H), INTER_AREA) followed by ToTensor (H <= h, W <= w; coverage-weighted box mean — exact
+ * integer block sums when h % H == 0 and w % W == 0), and hist fp32 [hist_bins] = round(histc(Y, hist_bins, 0, 1) /
+ * sum * 100) with Y = 0.299 R + 0.587 G + 0.114 B of the resized image: NeRF-H's histogram index vector.  scratch:
+ * dfn_frame_prep_scratch_bytes() of device memory (zeroed by the call). */
+size_t dfn_frame_prep_scratch_bytes(void);
+int dfn_frame_prep(const uint8_t* rgb_hwc, int h, int w, int H, int W, int hist_bins, float* img_chw, float* hist,
+                   void* scratch, void* stream);
+
 /* ---- the triplet loss of DFNet's training on the two feature stacks (feature/misc.py:355-435), fused.
  *
  * f1 (anchor, the rendered stream in run_feature.py:155) and f2 (positive, the target stream): fp32 device stacks

@@ -52,13 +52,13 @@ def test_run_nerf_render_test_cli(tmp_path):
             c2w[:3, :4] = pose.reshape(3, 4)
             with torch.no_grad():
                 rgb, disp, acc = orc.render(120, 160, 585. / 4, 32768, c, f, ea.weight.detach(), et.weight.detach(),
-                                            32, 64, float(bds[0]), float(bds[1]), hist[0].numpy(), c2w=c2w)
+                                            32, 64, float(bds[0]), float(bds[1]), hist[0].cpu().numpy(), c2w=c2w)
             want = (255 * np.clip(rgb.numpy(), 0, 1)).astype(np.uint8)
             got = np.asarray(Image.open(os.path.join(d, "000.png")))
             assert got.shape == want.shape == (120, 160, 3)
             assert int(np.abs(got.astype(int) - want.astype(int)).max()) <= 1  # to8b truncation of a 1e-3 match
             gt = np.asarray(Image.open(os.path.join(d, "000_GT.png")))
-            assert int(np.abs(gt.astype(int) - (255 * img[0].permute(1, 2, 0).numpy()).astype(np.uint8).astype(int)).max()) == 0
+            assert int(np.abs(gt.astype(int) - (255 * img[0].permute(1, 2, 0).cpu().numpy()).astype(np.uint8).astype(int)).max()) == 0
 
 
 def test_run_feature_render_feature_only_cli(tmp_path):

@@ -283,3 +283,44 @@ def test_triplet_loss_fused_vs_reference_golden_and_oracle():
     assert float((Fd.grad.cpu() - Fc.grad).abs().max()) <= 2e-5 * float(Fc.grad.abs().max())
     with pytest.raises(ValueError):
         fm.triplet_loss(Fd[:, :B, :, :, ::2], Fd[:, B:, :, :, ::2])
+
+
+def test_frame_prep_device_vs_oracle(tmp_path):
+    """dfn_frame_prep (dataset front-end on the device): INTER_AREA downscale + luma histogram vs the CPU restatement —
+    integer factor (7-Scenes df=2), no resize, a fractional factor, a flat image (one bin), and the dataset class
+    returning device items."""
+    from dfnet_amd.engine import frame_prep
+    from dfnet_amd import datasets
+    from oracle import frame_oracle as fo
+    rng = np.random.default_rng(12)
+    for (h, w, H, W) in ((48, 64, 24, 32), (30, 40, 30, 40), (45, 64, 20, 28), (480, 640, 240, 320)):
+        raw = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if h == 480:   # a smooth image: populated neighbouring bins like a photograph
+            yy, xx = np.mgrid[0:h, 0:w]
+            raw = np.stack([(yy * 255 // h), (xx * 255 // w), ((yy + xx) * 255 // (h + w))], -1).astype(np.uint8)
+        img, hist = frame_prep(torch.from_numpy(raw).to(DEV), H, W, 10)
+        if h % H == 0 and w % W == 0:
+            want = raw.reshape(H, h // H, W, w // W, 3).astype(np.float64).mean((1, 3)) / 255.0
+        else:
+            want = fo.area_downscale(raw, H, W)
+        got = img.permute(1, 2, 0).cpu().numpy()
+        assert np.abs(got - want).max() < 2e-7, (h, w, H, W, np.abs(got - want).max())
+        ref_hist = fo.luma_histogram(torch.from_numpy(want.transpose(2, 0, 1).astype(np.float32)), 10)
+        assert float(hist.sum()) == pytest.approx(float(ref_hist.sum()), abs=2)
+        assert float((hist.cpu() - ref_hist).abs().max()) <= 1.0, (hist, ref_hist)   # a luma on a bin edge may fall either side
+        if h == 30:
+            assert torch.equal(hist.cpu(), ref_hist)
+    flat = np.full((16, 16, 3), 128, np.uint8)
+    _, hist = frame_prep(torch.from_numpy(flat).to(DEV), 8, 8, 10)
+    assert hist.tolist() == [0, 0, 0, 0, 0, 100, 0, 0, 0, 0]
+    from tests.test_host_logic import make_scene
+    from dfnet_amd import options
+    datadir = make_scene(str(tmp_path))
+    args = options.nerf_parser().parse_args(["--datadir", datadir, "--dataset_type", "7Scenes", "--df", "2", "--load_pose_avg_stats",
+                                             "--render_test"])
+    train_dl, _, hwf, *_ = datasets.load_7Scenes_dataloader_NeRF(args)
+    img, pose, hist = next(iter(train_dl))
+    assert img.is_cuda and hist.is_cuda and img.shape == (1, 3, 24, 32) and hist.shape == (1, 10)
+    host = datasets.SevenScenesFrames(train_dl.dataset.files[0].rsplit("/seq-", 1)[0], True, 1, df=2., hist_bin=10, device_prep=False)
+    himg, _, hhist = host[0]
+    assert float((img[0].cpu() - himg).abs().max()) < 1e-6 and float((hist[0].cpu() - hhist).abs().max()) <= 1.0
