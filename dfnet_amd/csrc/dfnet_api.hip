@@ -807,22 +807,25 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
                 "dfnet params: BatchNorm backward");
       const float* g128 = reinterpret_cast<const float*>(w.g128);
       CHECK_HIP(launch_bias_grad(g128, B, hh, ww, 128, pw.part, kWgradPartFloats, ag[3], s), "dfnet params: adapt 5x5 bias gradient");
-      CHECK_HIP(launch_conv_wgrad(5, g128, tmp64, B, hh, ww, 128, 64, pw.part, kWgradPartFloats, ag[2], s),
+      const float* sc128 = dyn(w.g128, size_t(B) * hh * ww * 128);   // one measured scale for the weight AND data gradient products
+      CHECK_HIP(launch_conv_wgrad(5, g128, tmp64, B, hh, ww, 128, 64, pw.part, kWgradPartFloats, ag[2], s, sc128),
                 "dfnet params: adapt 5x5 weight gradient");
       ConvArgs c{};
       const PackedConv& d5 = h->ad5_raw_dgrad[t];
       c.in = w.g128; c.w = d5.w[prec]; c.bias = d5.bias; c.out_scale = d5.out_scale; c.out_pre = w.g64;
-      c.dyn_scale = dyn(w.g128, size_t(B) * hh * ww * 128);
+      c.dyn_scale = sc128;
       c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet params: adapt 5x5 dgrad");
       CHECK_HIP(launch_relu_gate(1, w.g64, tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet params: adapt gate");
       const float* g64 = reinterpret_cast<const float*>(w.g64);
       CHECK_HIP(launch_bias_grad(g64, B, hh, ww, 64, pw.part, kWgradPartFloats, ag[1], s), "dfnet params: adapt 1x1 bias gradient");
-      CHECK_HIP(launch_conv_wgrad(1, g64, reinterpret_cast<const float*>(w.tap[t]), B, hh, ww, 64, sp.cout, pw.part, kWgradPartFloats, ag[0], s),
+      const float* sc64 = dyn(w.g64, size_t(B) * hh * ww * 64);
+      CHECK_HIP(launch_conv_wgrad(1, g64, reinterpret_cast<const float*>(w.tap[t]), B, hh, ww, 64, sp.cout, pw.part, kWgradPartFloats, ag[0], s,
+                                  sc64),
                 "dfnet params: adapt 1x1 weight gradient");
       ConvArgs d{};
       d.in = w.g64; d.w = h->ad1_dgrad[t].w[prec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
-      d.dyn_scale = dyn(w.g64, size_t(B) * hh * ww * 64);
+      d.dyn_scale = sc64;
       d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
       CHECK_HIP(launch_conv(prec, 1, 16, d, s), "dfnet params: adapt 1x1 dgrad");
       g_tap = w.gtap;
@@ -844,13 +847,14 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
                 "dfnet params: maxpool (conv input)");
       input = w.pooled;
     }
+    const float* sc_pre = dyn(g_pre, size_t(B) * hh * ww * sp.cout);
     CHECK_HIP(launch_conv_wgrad(3, g_pre, reinterpret_cast<const float*>(input), B, hh, ww, sp.cout, sp.cin, pw.part, kWgradPartFloats,
-                                grads[2 * i], s),
+                                grads[2 * i], s, sc_pre),
               "dfnet params: conv weight gradient");
     ConvArgs e{};
     e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[prec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale;
     e.out_pre = gbuf[in_idx];
-    e.dyn_scale = dyn(g_pre, size_t(B) * hh * ww * sp.cout);
+    e.dyn_scale = sc_pre;
     e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = ((sp.cin + 63) / 64 * 64) / 32; e.relu = 0;
     CHECK_HIP(launch_conv(prec, 3, 16, e, s), "dfnet params: encoder conv dgrad");
     if (h->enc[i - 1].pool_after) {

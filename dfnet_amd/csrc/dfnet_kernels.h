@@ -92,8 +92,9 @@ hipError_t launch_unprep(int prec, const void* g, int B, int H, int W, int nblk,
 // --- parameter gradients of the pose-regression path (dfnet_wgrad.hip); fp32 blocked activations
 // dW[cout][cin][ks][ks] of a stride-1 "same" conv from g (gradient w.r.t. its pre-activation) and its input;
 // `part` is scratch of part_floats floats.  cin, cout multiples of 32; ks 1 or 3.
+// gscale != nullptr: split-f16 product (fp32-grade, f16 MFMA rate); device [scale, 1/scale] of g (launch_absmax_scale).
 hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int H, int W, int cout, int cin, float* part,
-                             size_t part_floats, float* dW, hipStream_t s);
+                             size_t part_floats, float* dW, hipStream_t s, const float* gscale = nullptr);
 // conv1_1: input = the prep output (pix_stride floats per pixel, RGB first), g has 64 channels; dW [64][3][3][3].
 hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int W, int pix_stride, float* part, size_t part_floats,
                               float* dW, hipStream_t s);

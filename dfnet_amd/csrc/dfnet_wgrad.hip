@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dfnet_kernels.h"
 #include "mfma_frag.h"
 
@@ -126,10 +128,154 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------ split-f16 weight gradient
+// The same contraction on the f16 matrix cores (v_mfma_f32_32x32x16_f16: 16 pixels per instruction, 16x the rate of
+// the fp32 MFMA) at fp32-grade accuracy: both operands are split x = hi + lo (f16 each) in registers and a product is
+// hi*hi + hi*lo + lo*hi accumulated in fp32, exactly as the split-f16 convolutions do (dfnet_conv.hip).  Operand
+// layout of the 32x32x16 MFMA: lane (c, kg) holds channel position c of pixels 8 kg .. 8 kg + 7 of the group — eight
+// dword loads per lane (each still a coalesced 128-byte row per pixel), converted with packed instructions.
+// Scales: g * gscale[0] (the tensor's measured power of two, launch_absmax_scale — the same one its data-gradient conv
+// uses), activations * kConvActScale with the hi part saturated; the finalize kernel multiplies the product of the
+// inverse scales back.  Borders as in the fp32 kernel (per-tap descriptors, a masked element's offset is pushed out of
+// range), with a wave-uniform fast path for groups that touch no image border.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <bool SAT>
+__device__ __forceinline__ void split8(const f32x8& v, float scale, half8& hi, half8& lo) {
+  const f32x8 xs = v * scale;
+  f32x8 cl = xs;
+  if (SAT) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cl[k] = __builtin_amdgcn_fmed3f(xs[k], -65000.f, 65000.f);
+  }
+  hi = __builtin_convertvector(cl, half8);
+  f32x8 r = xs - __builtin_convertvector(hi, f32x8);
+  if (SAT) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = __builtin_amdgcn_fmed3f(r[k], -65000.f, 65000.f);
+  }
+  lo = __builtin_convertvector(r, half8);
+}
+
+template <int KS, int TY>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __restrict__ g, const float* __restrict__ in, int B, int H,
+                                                               int W, int mblks, int nblks, int n_chunks, int ky0,
+                                                               const float* __restrict__ gscale, float* __restrict__ part) {
+  constexpr int T = TY * KS, TT = KS * KS, R = KS / 2;
+  __shared__ float red[3][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, kg = lane >> 5;
+  const int pair = blockIdx.x, chunk = blockIdx.y;
+  const int mblk = pair / nblks, nblk = pair - mblk * nblks;
+  const long long Q = (long long)B * H * W;
+  const long long per = (Q + n_chunks - 1) / n_chunks;
+  const long long q0 = chunk * per, q1 = q0 + per < Q ? q0 + per : Q;
+  const long long wper = ((q1 - q0 + 3) / 4 + 15) & ~15LL;   // whole 16-pixel groups per wave
+  const long long w0 = q0 + wave * wper, w1 = w0 + wper < q1 ? w0 + wper : q1;
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  constexpr uint32_t kRecords = 0x80000000u;
+  const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g + ((size_t)q0 * mblks + mblk) * 32), 0, kRecords, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_in[T];
+#pragma unroll
+  for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      const long long off = (long long)(ky0 + ty - R) * W + (kx - R);
+      rs_in[ty * KS + kx] =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + ((q0 + off) * nblks + nblk) * 32), 0, kRecords, 0x00020000);
+    }
+  const uint32_t gstep = (uint32_t)mblks * 128, istep = (uint32_t)nblks * 128;   // bytes per pixel
+  const float sg = gscale[0];
+  long long ql = w0 + 8 * kg;                                 // this lane's first pixel of the current group
+  int x = 0, y = 0;
+  if (ql < Q) { x = int(ql % W); y = int((ql / W) % H); }
+  auto group = [&](auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    uint32_t live = 0xFFu, rowm[TY], colm[KS];
+    if (MASKED) {
+      live = 0;
+#pragma unroll
+      for (int ty = 0; ty < TY; ++ty) rowm[ty] = 0;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) colm[kx] = 0;
+      int xt = x, yt = y;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        live |= (uint32_t)(ql + t < w1) << t;
+#pragma unroll
+        for (int ty = 0; ty < TY; ++ty) rowm[ty] |= (uint32_t)((unsigned)(yt + ky0 + ty - R) < (unsigned)H) << t;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) colm[kx] |= (uint32_t)((unsigned)(xt + kx - R) < (unsigned)W) << t;
+        if (++xt == W) { xt = 0; if (++yt == H) yt = 0; }
+      }
+    }
+    const uint32_t d = (uint32_t)(ql - q0);
+    auto fetch8 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t base, uint32_t step, uint32_t m) {
+      f32x8 v;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        uint32_t off = base + (uint32_t)t * step;
+        if (MASKED) off |= (uint32_t)(-(int)((~m >> t) & 1u));   // invalid element: offset out of range -> the load returns 0
+        v[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+      }
+      return v;
+    };
+    // the taps are software-pipelined: tap t+1's eight loads are in flight while tap t is split and multiplied
+    const f32x8 araw = fetch8(rs_g, d * gstep + 4u * c, gstep, live);
+    const uint32_t vo = d * istep + 4u * c;
+    auto tap_mask = [&](int t) -> uint32_t { return MASKED ? (live & rowm[t / KS] & colm[t % KS]) : 0xFFu; };
+    f32x8 nxt = fetch8(rs_in[0], vo, istep, tap_mask(0));
+    half8 ah, al;
+    split8<false>(araw, sg, ah, al);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const f32x8 cur = nxt;
+      if (t + 1 < T) nxt = fetch8(rs_in[t + 1], vo, istep, tap_mask(t + 1));
+      half8 bh, bl;
+      split8<true>(cur, kConvActScale, bh, bl);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+    }
+  };
+  for (long long qg = w0; qg < w1; qg += 16) {
+    // interior: every pixel of this lane's window is live and no tap leaves the image (and the window does not wrap a row)
+    const bool interior = ql + 7 < w1 && x >= R && x + 7 + R < W && y + ky0 - R >= 0 && y + ky0 + TY - 1 - R < H;
+    if (__builtin_amdgcn_ballot_w64(!interior) == 0) group(std::integral_constant<bool, false>{});
+    else group(std::integral_constant<bool, true>{});
+    ql += 16;
+    x += 16;
+    while (x >= W) { x -= W; if (++y == H) y = 0; }
+  }
+  float* dst = part + ((((size_t)chunk * mblks + mblk) * nblks + nblk) * TT + ky0 * KS) * 1024;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = ((acc[t][r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        dst[(t * 32 + i) * 32 + c] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Sum the chunks in order and write dW[co][ci][ky][kx] (state_dict layout), un-permuting the channel positions.
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ part, int mblks, int nblks, int T, int n_chunks,
-                                                             int cout, int cin, float* __restrict__ dW) {
+                                                             int cout, int cin, float* __restrict__ dW, const float* __restrict__ gscale) {
   const size_t n = (size_t)mblks * nblks * T * 1024;
+  const float unscale = gscale ? gscale[1] * (1.f / kConvActScale) : 1.f;   // split-f16 operands were pre-scaled by powers of two
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int ch = 0; ch < n_chunks; ++ch) s += part[(size_t)ch * n + i];
@@ -138,12 +284,12 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
     const int t = int(r % T); r /= T;
     const int nblk = int(r % nblks), mblk = int(r / nblks);
     const int co = 32 * mblk + chan_of_pos(ci_), ci = 32 * nblk + chan_of_pos(cj);
-    if (co < cout && ci < cin) dW[((size_t)co * cin + ci) * T + t] = s;
+    if (co < cout && ci < cin) dW[((size_t)co * cin + ci) * T + t] = s * unscale;
   }
 }
 
 hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int H, int W, int cout, int cin, float* part,
-                             size_t part_floats, float* dW, hipStream_t s) {
+                             size_t part_floats, float* dW, hipStream_t s, const float* gscale) {
   const int mblks = cout / 32, nblks = cin / 32, T = ks * ks;
   if (cout % 32 || cin % 32 || (ks != 1 && ks != 3 && ks != 5)) return hipErrorInvalidValue;
   const long long Q = (long long)B * H * W;
@@ -155,9 +301,18 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
   while (n_chunks > 1 && (size_t)n_chunks * pairs * T * 1024 > part_floats) --n_chunks;
   if ((size_t)n_chunks * pairs * T * 1024 > part_floats) return hipErrorInvalidValue;
   // 32-bit per-lane byte offsets inside a workgroup's pixel range, below the descriptors' num_records (conv_wgrad_kernel)
-  if ((unsigned long long)((Q + n_chunks - 1) / n_chunks + 8) * (unsigned)(mblks > nblks ? mblks : nblks) * 128 >= (1ull << 31))
+  if ((unsigned long long)((Q + n_chunks - 1) / n_chunks + 32) * (unsigned)(mblks > nblks ? mblks : nblks) * 128 >= (1ull << 31))
     return hipErrorInvalidValue;
   const dim3 grid(pairs, int(n_chunks));
+  if (gscale) {   // split-f16 product (fp32-grade): gscale = device [scale, 1 / scale] of g
+    if (ks == 3)
+      for (int ky = 0; ky < 3; ++ky)   // one kernel row per launch: 48 accumulator registers, no spills
+        hipLaunchKernelGGL((conv_wgrad_x3_kernel<3, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), ky, gscale, part);
+    else if (ks == 1) hipLaunchKernelGGL((conv_wgrad_x3_kernel<1, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, gscale, part);
+    else
+      for (int ky = 0; ky < 5; ++ky)
+        hipLaunchKernelGGL((conv_wgrad_x3_kernel<5, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), ky, gscale, part);
+  } else
   if (ks == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, part);
   else if (ks == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, part);
   else
@@ -167,7 +322,7 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
   if (e != hipSuccess) return e;
   const size_t n = (size_t)pairs * T * 1024;
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(int((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, part, mblks,
-                     nblks, T, int(n_chunks), cout, cin, dW);
+                     nblks, T, int(n_chunks), cout, cin, dW, gscale);
   return hipGetLastError();
 }
 

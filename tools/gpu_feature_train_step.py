@@ -65,4 +65,4 @@ breakdown = {k: v / iters for k, v in parts.items()}
 print(json.dumps({"workload": f"DFNet training step (run_feature.py, triplet loss + RVS), featurenet_batch_size {B} -> {2 * B} siamese + {B} "
                               f"synthesised frames at {H}x{W}, BatchNorm {'frozen' if frozen else 'batch statistics'}",
                   "step_ms": full_ms, "frames_per_s": 3 * B / full_ms * 1e3, "breakdown_ms_with_syncs": breakdown, "loss": loss,
-                  "precision": "f16x3 forward / gradient convs, fp32 wgrad", "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+                  "precision": "split-f16 (f16x3) forward, data-gradient AND weight-gradient products; fp32 accumulate", "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
