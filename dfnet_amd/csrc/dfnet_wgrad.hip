@@ -193,6 +193,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
   long long ql = w0 + 8 * kg;                                 // this lane's first pixel of the current group
   int x = 0, y = 0;
   if (ql < Q) { x = int(ql % W); y = int((ql / W) % H); }
+  auto fetch8_plain = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t base, uint32_t step) {
+    f32x8 v;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, base + (uint32_t)t * step, 0, 0));
+    return v;
+  };
   auto group = [&](auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     uint32_t live = 0xFFu, rowm[TY], colm[KS];
@@ -242,14 +248,82 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
     }
   };
+  // Interior groups of a one-row kernel (TY == 1): the KS taps of the row read the SAME pixels shifted by one, so the
+  // lane loads its window once — 8 + KS - 1 pixels — splits each element once, and every tap's fragment is a register
+  // selection: even shifts are whole registers of the packed (hi | lo) rows, odd shifts one v_alignbit per register.
+  constexpr int NROW = 8 + KS - 1 + ((8 + KS - 1) & 1);   // pixels a lane loads for one kernel row (even count)
+  struct RowData { f32x8 a; float raw[NROW]; };
+  auto load_row = [&](long long qlane) {
+    RowData r;
+    const uint32_t d = (uint32_t)(qlane - q0);
+    r.a = fetch8_plain(rs_g, d * gstep + 4u * c, gstep);
+    const uint32_t vo = d * istep + 4u * c;
+#pragma unroll
+    for (int j = 0; j < NROW; ++j)   // tap 0's descriptor starts R pixels to the left of the lane's first pixel
+      r.raw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in[0], vo + (uint32_t)(j < 8 + KS - 1 ? j : j - 1) * istep, 0, 0));
+    return r;
+  };
+  auto mac_row = [&](const RowData& rd) {
+    typedef _Float16 half2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    half8 ah, al;
+    split8<false>(rd.a, sg, ah, al);
+    uint32_t hi[NROW / 2], lo[NROW / 2];
+#pragma unroll
+    for (int j = 0; j < NROW / 2; ++j) {
+      const f32x2 xs = f32x2{rd.raw[2 * j], rd.raw[2 * j + 1]} * kConvActScale;
+      const f32x2 cl = {__builtin_amdgcn_fmed3f(xs[0], -65000.f, 65000.f), __builtin_amdgcn_fmed3f(xs[1], -65000.f, 65000.f)};
+      const half2 h = __builtin_convertvector(cl, half2);
+      f32x2 r = xs - __builtin_convertvector(h, f32x2);
+      r = f32x2{__builtin_amdgcn_fmed3f(r[0], -65000.f, 65000.f), __builtin_amdgcn_fmed3f(r[1], -65000.f, 65000.f)};
+      hi[j] = __builtin_bit_cast(uint32_t, h);
+      lo[j] = __builtin_bit_cast(uint32_t, (half2)__builtin_convertvector(r, half2));
+    }
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 uh, ul;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((kx & 1) == 0) { uh[i] = hi[kx / 2 + i]; ul[i] = lo[kx / 2 + i]; }
+        else {
+          uh[i] = __builtin_amdgcn_alignbit(hi[(kx + 1) / 2 + i], hi[(kx - 1) / 2 + i], 16);
+          ul[i] = __builtin_amdgcn_alignbit(lo[(kx + 1) / 2 + i], lo[(kx - 1) / 2 + i], 16);
+        }
+      }
+      const half8 bh = __builtin_bit_cast(half8, uh), bl = __builtin_bit_cast(half8, ul);
+      acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[kx], 0, 0, 0);
+      acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[kx], 0, 0, 0);
+      acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[kx], 0, 0, 0);
+    }
+  };
+  // interior (wave-uniform): every pixel of every lane's window is live, no tap leaves the image, no window wraps a row
+  auto interior_at = [&](long long qlane, int xx, int yy) {
+    const bool in = qlane + 7 < w1 && xx >= R && xx + 7 + R < W && yy + ky0 - R >= 0 && yy + ky0 + TY - 1 - R < H;
+    return __builtin_amdgcn_ballot_w64(!in) == 0;
+  };
+  constexpr bool kRowPath = TY == 1 && KS > 1;
+  RowData pre;             // the NEXT group's loads, in flight while the current group is split and multiplied
+  bool have_pre = false;   // wave-uniform
   for (long long qg = w0; qg < w1; qg += 16) {
-    // interior: every pixel of this lane's window is live and no tap leaves the image (and the window does not wrap a row)
-    const bool interior = ql + 7 < w1 && x >= R && x + 7 + R < W && y + ky0 - R >= 0 && y + ky0 + TY - 1 - R < H;
-    if (__builtin_amdgcn_ballot_w64(!interior) == 0) group(std::integral_constant<bool, false>{});
-    else group(std::integral_constant<bool, true>{});
+    int xn = x + 16, yn = y;
+    while (xn >= W) { xn -= W; if (++yn == H) yn = 0; }
+    if (interior_at(ql, x, y)) {
+      if constexpr (kRowPath) {
+        RowData cur;
+        if (have_pre) cur = pre; else cur = load_row(ql);
+        have_pre = qg + 16 < w1 && interior_at(ql + 16, xn, yn);
+        if (have_pre) pre = load_row(ql + 16);
+        mac_row(cur);
+      } else {
+        group(std::integral_constant<bool, false>{});
+      }
+    } else {
+      have_pre = false;
+      group(std::integral_constant<bool, true>{});
+    }
     ql += 16;
-    x += 16;
-    while (x >= W) { x -= W; if (++y == H) y = 0; }
+    x = xn; y = yn;
   }
   float* dst = part + ((((size_t)chunk * mblks + mblk) * nblks + nblk) * TT + ky0 * KS) * 1024;
 #pragma unroll
