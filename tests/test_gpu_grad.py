@@ -526,6 +526,42 @@ def test_dfnet_module_training_step_vs_reference_golden(mode):
         assert rel_l2(f3[0], ref3[0]) < 5e-6 and relmax(pose3, rp3) < 1e-5
 
 
+def test_dfnet_s_module_training_step_vs_oracle():
+    """DFNet_s (one pyramid level, dfnet.py:174-207) through the same training path: train()-mode forward and every
+    parameter gradient vs autograd through the oracle, then the device re-pack after an optimizer step."""
+    from dfnet_amd.dfnet import DFNet_s
+    from oracle import dfnet_oracle as dor
+    wts = {k: T(v) for k, v in syn.dfnet_weights(seed=3, taps=(64,)).items()}
+    m = DFNet_s()
+    m.load_state_dict(wts, strict=False)
+    m.to(DEV).train()
+    rng = np.random.default_rng(9)
+    x = T(rng.uniform(0, 1, (4, 3, 48, 64)).astype(np.float32))
+    Gt, Gr = (T(rng.standard_normal((1, 2, 128, 24, 32)).astype(np.float32)) for _ in range(2))
+    Gp = T(rng.standard_normal((4, 12)).astype(np.float32))
+    feats, pose = m(x.to(DEV), return_feature=True, isSingleStream=False, return_pose=True, upsampleH=24, upsampleW=32)
+    ((feats[0] * Gt.to(DEV)).sum() + (feats[1] * Gr.to(DEV)).sum() + (pose * Gp.to(DEV)).sum()).backward()
+    pp = {k: v.clone().requires_grad_(k.endswith(("weight", "bias"))) for k, v in wts.items()}
+    stats = []
+    maps, rp = dor.dfnet_forward(pp, x, True, False, True, 24, 32, taps=(2,), bn_stats=stats)
+    ((maps[0] * Gt).sum() + (maps[1] * Gr).sum() + (rp * Gp).sum()).backward()
+    assert rel_l2(feats[0], maps[0].detach()) < 5e-6 and relmax(pose, rp.detach()) < 1e-5
+    worst = 0.0
+    for k, q in m.named_parameters():
+        ref = pp[k].grad
+        if "adapt" in k and k.endswith(".2.bias"):
+            continue
+        assert q.grad is not None, k
+        worst = max(worst, relmax(q.grad, ref))
+    assert worst < 5e-5, worst
+    torch.optim.SGD(m.parameters(), lr=1e-7).step()
+    p1 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "num_batches" not in k}
+    with torch.no_grad():
+        f2, _ = m(x.to(DEV), return_feature=True, isSingleStream=True, return_pose=False, upsampleH=24, upsampleW=32)
+        ref2, _ = dor.dfnet_forward(p1, x, True, True, False, 24, 32, taps=(2,), bn_stats=[])
+    assert rel_l2(f2[0], ref2[0]) < 5e-6
+
+
 def test_dm_train_step_parameter_gradients_vs_oracle():
     """The whole DFNet_dm optimisation step (direct_feature_matching.py:322-376): gradients that reach the pose
     regressor's parameters through SVD -> scene rescale -> render -> bicubic -> feature extractor -> losses, HIP path vs
