@@ -837,7 +837,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
     CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, pw.part, kWgradPartFloats, grads[2 * i + 1], s), "dfnet params: bias gradient");
     if (i == 0) {
       CHECK_HIP(launch_conv0_wgrad(g_pre, reinterpret_cast<const float*>(w.prep), B, hh, ww, 2 * prep_sb(prec), pw.part, kWgradPartFloats,
-                                   grads[0], s),
+                                   grads[0], s, dyn(g_pre, size_t(B) * hh * ww * sp.cout)),
                 "dfnet params: conv1_1 weight gradient");
       break;
     }

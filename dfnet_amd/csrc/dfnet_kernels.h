@@ -97,7 +97,7 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
                              size_t part_floats, float* dW, hipStream_t s, const float* gscale = nullptr);
 // conv1_1: input = the prep output (pix_stride floats per pixel, RGB first), g has 64 channels; dW [64][3][3][3].
 hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int W, int pix_stride, float* part, size_t part_floats,
-                              float* dW, hipStream_t s);
+                              float* dW, hipStream_t s, const float* gscale = nullptr);
 hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* part, size_t part_floats, float* db, hipStream_t s);
 // pose head: relu5_3 activations + d pose -> pooled [B,512] (scratch), gradient w.r.t. the activations, fc gradients.
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,

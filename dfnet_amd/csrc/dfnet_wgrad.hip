@@ -447,8 +447,110 @@ __global__ __launch_bounds__(256) void conv0_finalize_kernel(const float* __rest
   const int co = 32 * (p >> 5) + chan_of_pos(p & 31);
   dW[co * 27 + t] = s;   // [co][c][ky][kx]
 }
+// The same gradient on the matrix cores (split-f16, as conv_wgrad_x3_kernel): M = the 64 output channels (two blocks),
+// N = the 27 (c, ky, kx) combinations — lane (j, kg) gathers input channel c_j of the pixel shifted by (ky_j, kx_j) for
+// its eight pixels — K = 16 pixels per MFMA.  Six MFMAs per 16 pixels cover the whole layer; the scalar kernel above
+// spends 27 loads and FMAs per pixel and thread.  part[chunk][64 (co position)][32 (combination, 27 used)].
+__global__ __launch_bounds__(256) void conv0_wgrad_x3_kernel(const float* __restrict__ g, const float* __restrict__ xn, int B, int H, int W,
+                                                             int pix_stride, int n_chunks, const float* __restrict__ gscale,
+                                                             float* __restrict__ part) {
+  __shared__ float red[3][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, kg = lane >> 5;
+  const int cj = j / 9, kyj = (j % 9) / 3, kxj = j % 3;
+  const bool combo = j < 27;
+  const long long Q = (long long)B * H * W;
+  const long long per = (Q + n_chunks - 1) / n_chunks;
+  const long long q0 = blockIdx.x * per, q1 = q0 + per < Q ? q0 + per : Q;
+  const long long wper = ((q1 - q0 + 3) / 4 + 15) & ~15LL;
+  const long long w0 = q0 + wave * wper, w1 = w0 + wper < q1 ? w0 + wper : q1;
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  constexpr uint32_t kRecords = 0x80000000u;
+  const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g + (size_t)q0 * 64), 0, kRecords, 0x00020000);
+  // the input descriptor starts one row and one pixel before the chunk: every tap offset is then non-negative
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn + (q0 - W - 1) * (long long)pix_stride), 0, kRecords, 0x00020000);
+  const uint32_t xstep = (uint32_t)pix_stride * 4u;
+  const uint32_t lane_off = (uint32_t)((kyj * W + kxj) * pix_stride + cj) * 4u;   // tap shift + channel, from the descriptor base
+  const float sg = gscale[0];
+  long long ql = w0 + 8 * kg;
+  int x = 0, y = 0;
+  if (ql < Q) { x = int(ql % W); y = int((ql / W) % H); }
+  for (long long qg = w0; qg < w1; qg += 16) {
+    const uint32_t d = (uint32_t)(ql - q0);
+    f32x8 xv, g0, g1;
+    int xt = x, yt = y;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const bool live = ql + t < w1;
+      const bool ok = live && combo && (unsigned)(yt + kyj - 1) < (unsigned)H && (unsigned)(xt + kxj - 1) < (unsigned)W;
+      xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, ok ? (d + t) * xstep + lane_off : 0xFFFFFFF0u, 0, 0));
+      const uint32_t go = live ? (d + t) * 256u + 4u * j : 0xFFFFFFF0u;
+      g0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, go, 0, 0));
+      g1[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, live ? go + 128u : go, 0, 0));
+      if (++xt == W) { xt = 0; if (++yt == H) yt = 0; }
+    }
+    half8 bh, bl, ah, al;
+    split8<true>(xv, kConvActScale, bh, bl);
+    split8<false>(g0, sg, ah, al);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0], 0, 0, 0);
+    split8<false>(g1, sg, ah, al);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[1], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[1], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[1], 0, 0, 0);
+    ql += 16;
+    x += 16;
+    while (x >= W) { x -= W; if (++y == H) y = 0; }
+  }
+  float* dst = part + (size_t)blockIdx.x * 64 * 32;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[m][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = ((acc[m][r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;   // co position within block m
+        dst[(m * 32 + i) * 32 + j] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void conv0_x3_finalize_kernel(const float* __restrict__ part, int n_chunks, const float* __restrict__ gscale,
+                                                                float* __restrict__ dW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 32) return;
+  const int p = i >> 5, t = i & 31;
+  if (t >= 27) return;
+  float s = 0.f;
+  for (int ch = 0; ch < n_chunks; ++ch) s += part[(size_t)ch * 64 * 32 + i];
+  const int co = 32 * (p >> 5) + chan_of_pos(p & 31);
+  dW[co * 27 + t] = s * gscale[1] * (1.f / kConvActScale);   // [co][c][ky][kx]
+}
+
 hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int W, int pix_stride, float* part, size_t part_floats,
-                              float* dW, hipStream_t s) {
+                              float* dW, hipStream_t s, const float* gscale) {
+  if (gscale) {
+    const long long Q = (long long)B * H * W;
+    long long n_chunks = (Q + 1023) / 1024;
+    if (n_chunks > 2048) n_chunks = 2048;
+    if ((size_t)n_chunks * 64 * 32 > part_floats) return hipErrorInvalidValue;
+    if ((unsigned long long)((Q + n_chunks - 1) / n_chunks + W + 64) * 256ull >= (1ull << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv0_wgrad_x3_kernel, dim3(int(n_chunks)), dim3(256), 0, s, g, xn, B, H, W, pix_stride, int(n_chunks), gscale, part);
+    hipLaunchKernelGGL(conv0_x3_finalize_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, s, part, int(n_chunks), gscale, dW);
+    return hipGetLastError();
+  }
+
   const long long Q = (long long)B * H * W;
   long long n_chunks = (Q + 511) / 512;
   if (n_chunks > 1024) n_chunks = 1024;
