@@ -80,8 +80,8 @@ SIGNATURES = {
     "dfn_triplet_loss_state_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dfn_triplet_loss_forward": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),
     "dfn_triplet_loss_backward": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P, c_size_t, _P]),
-    "dfn_dfnet_refresh_train_params_device": (c_int, [_P, POINTER(c_void_p), c_int, _P]),
-    "dfn_dfnet_refresh_pose_params_device": (c_int, [_P, POINTER(c_void_p), c_int, _P]),
+    "dfn_dfnet_refresh_train_params_device": (c_int, [_P, POINTER(c_void_p), c_int, c_int, _P]),
+    "dfn_dfnet_refresh_pose_params_device": (c_int, [_P, POINTER(c_void_p), c_int, c_int, _P]),
     "dfn_profile_enable": (c_int, [c_int]),
     "dfn_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
 }

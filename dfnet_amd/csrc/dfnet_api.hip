@@ -58,6 +58,8 @@ struct dfn_dfnet_s {
   std::vector<float*> bn_dev;
   // dfn_dfnet_forward_train(keep = 1) left its activations in this workspace (consumed by backward_all_params)
   // (a few: a training step may hold the siamese forward and a pose-only forward before its backward runs)
+  // precisions whose packed fragments are current: all three after dfn_dfnet_commit, the requested ones after a device re-pack
+  int fresh_mask = 0;
   struct Kept { const void* ws; int prec, B, H, W, bn_batch; };
   std::vector<Kept> kept;
 };
@@ -312,6 +314,7 @@ extern "C" int dfn_dfnet_commit(dfn_dfnet_t h) {
   fc.insert(fc.end(), fb.begin(), fb.end());
   if (int rc = upload_bytes(fc.data(), fc.size() * 4, reinterpret_cast<void**>(&h->fc))) return rc;
   h->committed = true;
+  h->fresh_mask = 7;
   return DFN_OK;
 }
 
@@ -343,6 +346,14 @@ DfWs carve_df(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
 }
 }  // namespace
 
+// A device re-pack (dfn_dfnet_refresh_*_params_device) renews only the precisions it was asked for.
+static int check_fresh(dfn_dfnet_t h, int prec, const char* fn) {
+  if (prec >= 0 && prec < 3 && !((h->fresh_mask >> prec) & 1))
+    return set_error(DFN_ERR_STATE, "%s: the fragments of precision %d are stale (last device re-pack left them out): re-pack with its bit "
+                     "in prec_mask or dfn_dfnet_commit()", fn, prec);
+  return DFN_OK;
+}
+
 extern "C" size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W) {
   if (!h || B < 1 || H < 1 || W < 1) return 0;
   return carve_df(h, nullptr, prec, B, H, W).total;
@@ -364,6 +375,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: null handle");
   if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_forward: dfn_dfnet_commit() has not been called");
   if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: unknown precision %d", prec);
+  if (int rc = check_fresh(h, prec, "dfn_dfnet_forward")) return rc;
   if (!x || !workspace || B < 1 || H < 32 || W < 32 || (return_feature && (!features || upH < 1 || upW < 1)) ||
       (return_pose && !pose) || (return_feature && siamese && (B & 1)))
     return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: bad argument (need H,W >= 32; even batch for siamese)");
@@ -529,6 +541,8 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
   if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: null handle");
   if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_backward_input: dfn_dfnet_commit() has not been called");
   if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: unknown precision %d", prec);
+  if (h && h->committed)
+    if (int rc = check_fresh(h, prec, "dfn_dfnet_backward_input")) return rc;
   level_mask &= (1 << h->n_taps) - 1;
   if (!x || !grad_features || !grad_x || !workspace || B < 1 || H < 32 || W < 32 || upH < 1 || upW < 1 || !level_mask)
     return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: bad argument (need H,W >= 32 and a non-empty level_mask)");
@@ -733,6 +747,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
     return set_error(DFN_ERR_UNSUPPORTED, "%s: parameter gradients need fp32 activations (precision F32 or F16X3)", fn);
+  if (int rc = check_fresh(h, prec, fn)) return rc;
   const int n_enc = int(h->enc.size());
   level_mask = grad_features ? (level_mask & ((1 << h->n_taps) - 1)) : 0;
   const int per_tap = bn_batch ? 6 : 4;
@@ -881,6 +896,7 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
   if (!x || !workspace || (!features && !return_pose) || B < 1 || H < 32 || W < 32 || (features && (upH < 1 || upW < 1)) ||
       (return_pose && !pose) || (features && siamese && (B & 1)))
     return set_error(DFN_ERR_ARG, "%s: bad argument (need H,W >= 32; even batch for siamese)", fn);
+  if (int rc = check_fresh(h, prec, fn)) return rc;
   const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
   if (pw.total > workspace_bytes)
     return set_error(DFN_ERR_ARG, "%s: keep = 1 needs dfn_dfnet_backward_params_workspace_bytes (%zu < %zu)", fn, workspace_bytes, pw.total);
@@ -945,11 +961,13 @@ extern "C" int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const floa
 namespace {
 // Re-pack one convolution (forward fragments and data-gradient fragments, all three arithmetic modes) from device fp32
 // master weights; the split-f16 weight scales are kept from dfn_dfnet_commit.
-int refresh_conv(PackedConv& f, PackedConv& d, const float* wt, const float* bias, int cout, int cin, int ks, bool first, hipStream_t s) {
+int refresh_conv(PackedConv& f, PackedConv& d, const float* wt, const float* bias, int cout, int cin, int ks, bool first, int prec_mask,
+                 hipStream_t s) {
   const float wscale = 1.f / (f.out_scale * kConvActScale);
   const int cop = (cin + 63) / 64 * 64;
   const float dscale = 1.f / (d.out_scale * kConvActScale);
   for (int prec = 0; prec < 3; ++prec) {
+    if (!((prec_mask >> prec) & 1)) continue;
     const int sb = first ? prep_sb(prec) : 16;
     const int mbf = prec == 2 ? 2 : conv_mb(prec, cout / 32);
     CHECK_HIP(launch_pack_conv(prec, wt, cout, cin, ks, first, sb, mbf, 0, cout, cin, wscale, f.w[prec], s), "refresh: forward pack");
@@ -961,26 +979,28 @@ int refresh_conv(PackedConv& f, PackedConv& d, const float* wt, const float* bia
   return DFN_OK;
 }
 
-int refresh_core(dfn_dfnet_t h, const float* const* params, int n_params, bool with_adapt, hipStream_t s, const char* fn) {
+int refresh_core(dfn_dfnet_t h, const float* const* params, int n_params, bool with_adapt, int prec_mask, hipStream_t s, const char* fn) {
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   const int n_enc = int(h->enc.size());
   const int want = 2 * n_enc + 2 + (with_adapt ? 8 * h->n_taps : 0);
   if (!params || n_params != want) return set_error(DFN_ERR_ARG, "%s: need %d pointers", fn, want);
+  if (prec_mask < 1 || prec_mask > 7) return set_error(DFN_ERR_ARG, "%s: prec_mask must select at least one of the three precisions", fn);
   for (int i = 0; i < n_params; ++i)
     if (!params[i]) return set_error(DFN_ERR_ARG, "%s: null pointer %d", fn, i);
   for (int i = 0; i < n_enc; ++i) {
     const ConvSpec& sp = h->enc[i];
-    if (int rc = refresh_conv(h->enc_packed[i], h->enc_dgrad[i], params[2 * i], params[2 * i + 1], sp.cout, sp.cin, 3, i == 0, s)) return rc;
+    if (int rc = refresh_conv(h->enc_packed[i], h->enc_dgrad[i], params[2 * i], params[2 * i + 1], sp.cout, sp.cin, 3, i == 0, prec_mask, s)) return rc;
   }
   CHECK_HIP(hipMemcpyAsync(h->fc, params[2 * n_enc], size_t(h->feat_dim) * 512 * 4, hipMemcpyDeviceToDevice, s), "refresh: fc weight");
   CHECK_HIP(hipMemcpyAsync(h->fc + size_t(h->feat_dim) * 512, params[2 * n_enc + 1], size_t(h->feat_dim) * 4, hipMemcpyDeviceToDevice, s),
             "refresh: fc bias");
+  h->fresh_mask = prec_mask;   // the weights moved: fragments of the other precisions are stale from here on
   if (!with_adapt) return DFN_OK;
   for (int t = 0; t < h->n_taps; ++t) {
     const float* const* ap = params + 2 * n_enc + 2 + 8 * t;
-    if (int rc = refresh_conv(h->ad1[t], h->ad1_dgrad[t], ap[0], ap[1], 64, h->tap_channels[t], 1, false, s)) return rc;
-    if (int rc = refresh_conv(h->ad5_raw[t], h->ad5_raw_dgrad[t], ap[2], ap[3], 128, 64, 5, false, s)) return rc;
+    if (int rc = refresh_conv(h->ad1[t], h->ad1_dgrad[t], ap[0], ap[1], 64, h->tap_channels[t], 1, false, prec_mask, s)) return rc;
+    if (int rc = refresh_conv(h->ad5_raw[t], h->ad5_raw_dgrad[t], ap[2], ap[3], 128, 64, 5, false, prec_mask, s)) return rc;
     for (int k = 0; k < 4; ++k)   // gamma, beta, running_mean, running_var
       CHECK_HIP(hipMemcpyAsync(h->bn_dev[t] + 128 * k, ap[4 + k], 128 * 4, hipMemcpyDeviceToDevice, s), "refresh: BatchNorm");
   }
@@ -988,10 +1008,10 @@ int refresh_core(dfn_dfnet_t h, const float* const* params, int n_params, bool w
 }
 }  // namespace
 
-extern "C" int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream) {
-  return refresh_core(h, params, n_params, false, HS(stream), "dfn_dfnet_refresh_pose_params_device");
+extern "C" int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, int prec_mask, void* stream) {
+  return refresh_core(h, params, n_params, false, prec_mask, HS(stream), "dfn_dfnet_refresh_pose_params_device");
 }
 
-extern "C" int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream) {
-  return refresh_core(h, params, n_params, true, HS(stream), "dfn_dfnet_refresh_train_params_device");
+extern "C" int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* params, int n_params, int prec_mask, void* stream) {
+  return refresh_core(h, params, n_params, true, prec_mask, HS(stream), "dfn_dfnet_refresh_train_params_device");
 }

@@ -153,13 +153,23 @@ __global__ __launch_bounds__(256) void upsample_backward_rows_kernel(const float
   __syncthreads();
   while (Y0 < Y1 && wyv[Y0] == 0.f) ++Y0;      // uniform: trim the slack rows
   while (Y1 > Y0 && wyv[Y1] == 0.f) --Y1;
-  for (int e = 0; e < 32; ++e) {
+  // gridDim.z splits the 32 channels of the block over workgroups (small levels: more workgroups than CUs)
+  const int per_z = 32 / gridDim.z, e_lo = blockIdx.z * per_z;
+  for (int e = e_lo; e < e_lo + per_z; ++e) {
     const int ch = blk * 32 + 4 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
     const float* plane = gup + b * bstride + (size_t)ch * UH * UW;
     for (int X = tid; X < UW; X += 256) {
-      float t = 0.f;
-      for (int Y = Y0; Y <= Y1; ++Y) t = fmaf(wyv[Y], plane[(size_t)Y * UW + X], t);
-      tmp[X] = t;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;   // four independent chains: four loads in flight per thread
+      int Y = Y0;
+      for (; Y + 3 <= Y1; Y += 4) {
+        const float* pp = plane + (size_t)Y * UW + X;
+        t0 = fmaf(wyv[Y], pp[0], t0);
+        t1 = fmaf(wyv[Y + 1], pp[UW], t1);
+        t2 = fmaf(wyv[Y + 2], pp[2 * (size_t)UW], t2);
+        t3 = fmaf(wyv[Y + 3], pp[3 * (size_t)UW], t3);
+      }
+      for (; Y <= Y1; ++Y) t0 = fmaf(wyv[Y], plane[(size_t)Y * UW + X], t0);
+      tmp[X] = (t0 + t1) + (t2 + t3);
     }
     __syncthreads();
     for (int x = tid; x < w; x += 256) {
@@ -178,7 +188,10 @@ __global__ __launch_bounds__(256) void upsample_backward_rows_kernel(const float
     __syncthreads();
   }
   float* o = out + ((b * h + y) * (size_t)w) * 128 + blk * 32;
-  for (int i = tid; i < w * 32; i += 256) o[(size_t)(i >> 5) * 128 + (i & 31)] = row[(i >> 5) * 33 + (i & 31)];
+  for (int i = tid; i < w * per_z; i += 256) {
+    const int px = i / per_z, e = e_lo + i % per_z;
+    o[(size_t)px * 128 + e] = row[px * 33 + e];
+  }
 }
 
 // Level 0 (no resize): NCHW planes -> blocked NHWC through an LDS tile of 128 channels x 64 pixels; 256-byte reads,
@@ -211,7 +224,8 @@ hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, 
   }
   const size_t lds = ((size_t)UW + UH + (size_t)w * 33) * 4;
   if (prec != 0 && lds <= 64 * 1024) {
-    hipLaunchKernelGGL(upsample_backward_rows_kernel, dim3(B * h, 4), dim3(256), lds, s, gup, bstride, h, w, UH, UW, static_cast<float*>(out));
+    const int zsplit = (size_t)B * h * 4 >= 2048 ? 1 : ((size_t)B * h * 4 >= 1024 ? 2 : 4);
+    hipLaunchKernelGGL(upsample_backward_rows_kernel, dim3(B * h, 4, zsplit), dim3(256), lds, s, gup, bstride, h, w, UH, UW, static_cast<float*>(out));
     return hipGetLastError();
   }
   if (prec == 0)

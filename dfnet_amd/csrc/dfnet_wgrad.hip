@@ -568,9 +568,18 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
   __shared__ float red[8][32];
   const int pos = threadIdx.x & 31, pl = threadIdx.x >> 5, blk = blockIdx.x, chunk = blockIdx.y;
   const long long per = (Q + n_chunks - 1) / n_chunks, q0 = chunk * per, q1 = q0 + per < Q ? q0 + per : Q;
-  float s = 0.f;
-  for (long long q = q0 + pl; q < q1; q += 8) s += g[(q * blks + blk) * 32 + pos];
-  red[pl][pos] = s;
+  const size_t step = (size_t)blks * 32;
+  const float* p = g + (size_t)blk * 32 + pos;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains: four loads in flight per thread
+  long long q = q0 + pl;
+  for (; q + 24 < q1; q += 32) {
+    s0 += p[(size_t)q * step];
+    s1 += p[(size_t)(q + 8) * step];
+    s2 += p[(size_t)(q + 16) * step];
+    s3 += p[(size_t)(q + 24) * step];
+  }
+  for (; q < q1; q += 8) s0 += p[(size_t)q * step];
+  red[pl][pos] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (pl == 0) {
     float t = 0.f;
@@ -578,23 +587,31 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     part[((size_t)chunk * blks + blk) * 32 + pos] = t;
   }
 }
+// One workgroup per 32-channel block: eight chunk lanes per position, combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void bias_grad_finalize_kernel(const float* __restrict__ part, int blks, int n_chunks, int cout,
                                                                  float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= blks * 32) return;
+  __shared__ float red[8][32];
+  const int pos = threadIdx.x & 31, cl = threadIdx.x >> 5, blk = blockIdx.x;
   float s = 0.f;
-  for (int ch = 0; ch < n_chunks; ++ch) s += part[(size_t)ch * blks * 32 + i];
-  const int co = 32 * (i >> 5) + chan_of_pos(i & 31);
-  if (co < cout) db[co] = s;
+  for (int ch = cl; ch < n_chunks; ch += 8) s += part[((size_t)ch * blks + blk) * 32 + pos];
+  red[cl][pos] = s;
+  __syncthreads();
+  if (cl == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 8; ++i) t += red[i][pos];
+    const int co = 32 * blk + chan_of_pos(pos);
+    if (co < cout) db[co] = t;
+  }
 }
 hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* part, size_t part_floats, float* db, hipStream_t s) {
   const long long Q = (long long)B * H * W;
   const int blks = cout / 32;
-  long long n_chunks = (Q + 1023) / 1024;
-  if (n_chunks > 512) n_chunks = 512;
+  long long n_chunks = (Q + 255) / 256;                       // >= 256 pixels per workgroup,
+  const long long cap = 4096 / blks > 8 ? 4096 / blks : 8;    // ~4096 workgroups in all
+  if (n_chunks > cap) n_chunks = cap;
   if ((size_t)n_chunks * blks * 32 > part_floats) return hipErrorInvalidValue;
   hipLaunchKernelGGL(bias_grad_kernel, dim3(blks, int(n_chunks)), dim3(256), 0, s, g, Q, blks, int(n_chunks), part);
-  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((blks * 32 + 255) / 256), dim3(256), 0, s, part, blks, int(n_chunks), cout, db);
+  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(blks), dim3(256), 0, s, part, blks, int(n_chunks), cout, db);
   return hipGetLastError();
 }
 

@@ -381,22 +381,29 @@ class DfnetEngine:
               "dfn_dfnet_backward_all_params")
         return dict(zip(names, grads))
 
-    def refresh_train_params_device(self, tensors):
+    def refresh_train_params_device(self, tensors, precisions=None):
         """Re-pack every tensor the training path reads from device tensors: train_param_names(True) with, per level,
         .3.running_mean and .3.running_var after .3.bias.  The folded inference weights are NOT updated."""
         ts = [_f32c(t) for t in tensors]
         assert len(ts) == 28 + 8 * self.n_taps and all(t.is_cuda for t in ts)
         ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        check(self.lib.dfn_dfnet_refresh_train_params_device(self.handle, ptrs, len(ts), current_stream()),
+        check(self.lib.dfn_dfnet_refresh_train_params_device(self.handle, ptrs, len(ts), self._prec_mask(precisions), current_stream()),
               "dfn_dfnet_refresh_train_params_device")
 
-    def refresh_pose_params_device(self, tensors):
+    def _prec_mask(self, precisions):
+        """Bit mask of the precisions a device re-pack renews: the engine's own by default, 'all', or a list of names."""
+        if precisions == 'all':
+            return 7
+        names = [self.precision] if precisions is None else list(precisions)
+        return sum(1 << _lib.PRECISIONS[p] for p in set(names))
+
+    def refresh_pose_params_device(self, tensors, precisions=None):
         """Re-pack the pose path's parameters from device tensors (order: encoder.<k>.weight, .bias for the 13 convs,
         fc_pose.weight, fc_pose.bias) — the fast path after an optimizer step."""
         ts = [_f32c(t) for t in tensors]
         assert len(ts) == 28 and all(t.is_cuda for t in ts)
         ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        check(self.lib.dfn_dfnet_refresh_pose_params_device(self.handle, ptrs, len(ts), current_stream()),
+        check(self.lib.dfn_dfnet_refresh_pose_params_device(self.handle, ptrs, len(ts), self._prec_mask(precisions), current_stream()),
               "dfn_dfnet_refresh_pose_params_device")
 
     def backward_input(self, x, grad_features, levels=None, precision=None):

@@ -306,13 +306,19 @@ int dfn_triplet_loss_backward(const float* f1, size_t level_stride1, const float
  * BatchNorm tensors from DEVICE tensors — 2 * 13 + 2 + 8 * n_taps pointers: those of dfn_dfnet_backward_params, then
  * per level .0.weight, .0.bias, .2.weight, .2.bias, .3.weight, .3.bias, .3.running_mean, .3.running_var.  The
  * BatchNorm-FOLDED inference weights used by dfn_dfnet_forward are
- * NOT touched: re-commit from the host (dfn_dfnet_set_param + dfn_dfnet_commit) before evaluating. */
-int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream);
+ * NOT touched: re-commit from the host (dfn_dfnet_set_param + dfn_dfnet_commit) before evaluating.
+ * prec_mask: bit p set = renew the fragments of precision p (DFN_PREC_*); a training loop runs in one precision and
+ * has no use for the other two.  Precisions left out are STALE afterwards: calls in them return DFN_ERR_STATE until a
+ * re-pack with their bit or a commit. */
+int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* params, int n_params, int prec_mask,
+                                          void* stream);
 
 /* After an optimizer step: re-pack the pose path's parameters (13 encoder convs + fc_pose, forward and data-gradient
  * fragments) from DEVICE fp32 master copies, without the host round trip of set_param + commit.  `params`: HOST
- * array of DEVICE pointers in the order of dfn_dfnet_backward_params.  Adaptation layers are untouched. */
-int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, void* stream);
+ * array of DEVICE pointers in the order of dfn_dfnet_backward_params.  Adaptation layers are untouched.  prec_mask as
+ * for dfn_dfnet_refresh_train_params_device. */
+int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, int prec_mask,
+                                         void* stream);
 
 /* Timing aid for bench.py: average device time in ms of the `which` kernel
  * (0 = coarse MLP, 1 = fine MLP) over the launches since the last reset, measured with HIP

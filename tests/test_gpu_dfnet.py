@@ -203,18 +203,28 @@ def test_device_repack_equals_host_commit():
             q.mul_(1 + 0.05 * torch.randn(q.shape, device=DEV, generator=g))
         calls = []
         orig = m._engine.refresh_pose_params_device
-        m._engine.refresh_pose_params_device = lambda ts: (calls.append(1), orig(ts))[1]
+        m._engine.refresh_pose_params_device = lambda ts, precisions=None: (calls.append(1), orig(ts, precisions))[1]
         E1 = m.engine()
         assert calls == [1]                            # took the device path
     ref = DFNet().eval()
     ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()}, strict=False)
     E2 = ref.engine()
     G = torch.randn(3, 2, 128, 64, 96, generator=torch.Generator().manual_seed(1)).to(DEV)
-    for prec in ("f16x3", "f32", "f16"):
+
+    def same(prec):
         a, pa = E1.forward(x, True, True, True, 64, 96, precision=prec)
         b, pb = E2.forward(x, True, True, True, 64, 96, precision=prec)
         assert torch.equal(a, b) and torch.equal(pa, pb), prec
         assert torch.equal(E1.backward_input(x, G, precision=prec), E2.backward_input(x, G, precision=prec)), prec
+
+    same("f16x3")                                      # the module re-packed its own precision only ...
+    for prec in ("f32", "f16"):                        # ... the other two are stale and refused, not silently outdated
+        with pytest.raises(RuntimeError, match="stale"):
+            E1.forward(x, True, True, True, 64, 96, precision=prec)
+    pose = [dict(m.named_parameters())[k].detach() for k in m._pose_param_names()]
+    E1.refresh_pose_params_device(pose, precisions="all")
+    for prec in ("f16x3", "f32", "f16"):
+        same(prec)
 
 
 def test_split_f16_survives_large_activations():
