@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   const float out_scale = a.dyn_scale ? a.out_scale * kConvActScale * a.dyn_scale[1] : a.out_scale;
   auto issue_slice = [&](int sl, int buf) {
     const char* wsrc = a.w + ((size_t)cg * n_slices + sl) * WSL + lane * 16;
+#ifndef DFN_CONV_ABL_NODMA
     for (int q = wave * 1024; q < WSL; q += 4096) conv_lds_dma_b128(wsrc + q, wst + buf * WSL + q);
+#endif
   };
   // The fp32 patch of the NEXT input block is prefetched into registers while the current block is multiplied
   // (a fixed number of unconditional loads per thread, so the weight DMA can be awaited with a counted vmcnt).
@@ -261,8 +263,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
           hi[k] = (_Float16)fminf(fmaxf(xs, -65000.f), 65000.f);   // saturate instead of producing inf: the lo half
           lo[k] = (_Float16)fminf(fmaxf(xs - (float)hi[k], -65000.f), 65000.f);  // then carries up to another 65 000
         }
+#ifndef DFN_CONV_ABL_NOSTORE
         *reinterpret_cast<half4*>(plane_hi + pix * PS + seg * 8) = hi;
         *reinterpret_cast<half4*>(plane_lo + pix * PS + seg * 8) = lo;
+#endif
       }
     }
   };
@@ -307,9 +311,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
             const half8 al = *reinterpret_cast<const half8*>(wb + WHALF + fo);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
+#ifdef DFN_CONV_ABL_NOMFMA
+              acc[mb][nb][0] += (float)ah[0] * (float)bh[nb][0] + (float)al[0] * (float)bl[nb][0];
+#else
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], acc[mb][nb], 0, 0, 0);
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], acc[mb][nb], 0, 0, 0);
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], acc[mb][nb], 0, 0, 0);
+#endif
             }
           }
         }
