@@ -182,20 +182,24 @@ DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(off) : "memory");
 }
 
-template <int KS, int SB>
-constexpr int x3_plane_bytes() { return (((kConvTileH + KS - 1) * (kConvTileW + KS - 1) * (2 * SB * 2 + 16)) + 15) & ~15; }
+template <int KS, int SB, int WAVES = 4>
+constexpr int x3_plane_bytes() { return (((2 * WAVES + KS - 1) * (kConvTileW + KS - 1) * (2 * SB * 2 + 16)) + 15) & ~15; }
 template <int KS, int SB, int MB>
 constexpr int x3_wslice_bytes() { return 2 * MB * KS * (SB / 8) * 1024; }  // hi + lo fragments of one (block, ky) slice
 
-template <int KS, int SB, int MB, bool DB>
-__global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
+// WAVES = 4: 8 x 32 output pixels per workgroup, two workgroups per CU.  WAVES = 8: 16 x 32 pixels, ONE workgroup per CU — the
+// same eight waves share every weight slice (half the LDS-DMA per output pixel), the patch halo is amortised over twice
+// the rows, and the slices double-buffer inside the 160 KB.
+template <int KS, int SB, int MB, bool DB, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel(ConvArgs a) {
   constexpr int KCB = SB / 8;
-  constexpr int TH = kConvTileH, TW = kConvTileW, R = KS / 2;
+  constexpr int NT = WAVES * 64;
+  constexpr int TH = 2 * WAVES, TW = kConvTileW, R = KS / 2;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int PIXG = 2 * SB * 4;        // bytes of a pixel's block in HBM (fp32)
   constexpr int PS = 2 * SB * 2 + 16;     // padded pixel stride of one f16 plane
   constexpr int SEG = PIXG / 16;          // 16-byte (4-float) segments per pixel
-  constexpr int PLANE = x3_plane_bytes<KS, SB>();
+  constexpr int PLANE = x3_plane_bytes<KS, SB, WAVES>();
   constexpr int WSL = x3_wslice_bytes<KS, SB, MB>();
   constexpr int WHALF = WSL / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,17 +233,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   auto issue_slice = [&](int sl, int buf) {
     const char* wsrc = a.w + ((size_t)cg * n_slices + sl) * WSL + lane * 16;
 #ifndef DFN_CONV_ABL_NODMA
-    for (int q = wave * 1024; q < WSL; q += 4096) conv_lds_dma_b128(wsrc + q, wst + buf * WSL + q);
+    for (int q = wave * 1024; q < WSL; q += WAVES * 1024) conv_lds_dma_b128(wsrc + q, wst + buf * WSL + q);
 #endif
   };
   // The fp32 patch of the NEXT input block is prefetched into registers while the current block is multiplied
   // (a fixed number of unconditional loads per thread, so the weight DMA can be awaited with a counted vmcnt).
-  constexpr int TOTAL = PH * PW * SEG, NPRE = (TOTAL + 255) / 256;
+  constexpr int TOTAL = PH * PW * SEG, NPRE = (TOTAL + NT - 1) / NT;
   f32x4 pre[NPRE];
   auto load_patch = [&](int blk) {
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int e = min(tid + i * 256, TOTAL - 1);
+      const int e = min(tid + i * NT, TOTAL - 1);
       const int pix = e / SEG, seg = e - pix * SEG;
       const int py = pix / PW, px = pix - py * PW;
       const int gy = min(max(y0 + py - R, 0), a.H - 1), gx = min(max(x0 + px - R, 0), a.W - 1);
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NT;
       if (e < TOTAL) {
         const int pix = e / SEG, seg = e - pix * SEG;
         const int py = pix / PW, px = pix - py * PW;
@@ -353,20 +357,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   }
 }
 
-template <int KS, int SB, int MB, bool DB>
+template <int KS, int SB, int MB, bool DB, int WAVES = 4>
 static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
   if (a.cout_blocks % MB) return hipErrorInvalidValue;
-  constexpr int lds = 2 * x3_plane_bytes<KS, SB>() + (DB ? 2 : 1) * x3_wslice_bytes<KS, SB, MB>();
+  constexpr int lds = 2 * x3_plane_bytes<KS, SB, WAVES>() + (DB ? 2 : 1) * x3_wslice_bytes<KS, SB, MB>();
   static_assert(lds <= 160 * 1024, "x3 conv tile does not fit in LDS");
-  auto kern = conv_x3_kernel<KS, SB, MB, DB>;
+  auto kern = conv_x3_kernel<KS, SB, MB, DB, WAVES>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int tiles = ((a.H + kConvTileH - 1) / kConvTileH) * ((a.W + kConvTileW - 1) / kConvTileW);
-  hipLaunchKernelGGL(kern, dim3(tiles, a.cout_blocks / MB, a.B), dim3(256), lds, stream, a);
+  const int tiles = ((a.H + 2 * WAVES - 1) / (2 * WAVES)) * ((a.W + kConvTileW - 1) / kConvTileW);
+  hipLaunchKernelGGL(kern, dim3(tiles, a.cout_blocks / MB, a.B), dim3(WAVES * 64), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -431,7 +435,11 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
     if (sb == 8 && ks == 3) return launch_conv_x3_t<3, 8, 2, true>(a, stream);
     if (sb != 16) return hipErrorInvalidValue;
     if (ks == 1) return db ? launch_conv_x3_t<1, 16, 2, true>(a, stream) : launch_conv_x3_t<1, 16, 2, false>(a, stream);
-    if (ks == 3) return db ? launch_conv_x3_t<3, 16, 2, true>(a, stream) : launch_conv_x3_t<3, 16, 2, false>(a, stream);
+    if (ks == 3) {
+      static const int w8 = [] { const char* e = getenv("DFN_X3_W8"); return e ? atoi(e) : 0; }();  // tuning aid
+      if (w8) return launch_conv_x3_t<3, 16, 2, true, 8>(a, stream);
+      return db ? launch_conv_x3_t<3, 16, 2, true>(a, stream) : launch_conv_x3_t<3, 16, 2, false>(a, stream);
+    }
     if (ks == 5) return launch_conv_x3_t<5, 16, 2, true>(a, stream);
   } else {
     if (sb == 4 && ks == 3) return launch_conv_t<PrecF32, 3, 4, 2>(a, stream);
