@@ -175,30 +175,32 @@ void pack_conv(const float* w, int cout, int cin, int ks, bool first, int sb, in
                 }
 }
 
-// Split-f16 packing: w * 2^s = hi + lo (both f16); slice layout [cg][blk][ky][hi|lo][mb][kx][kc][lane][8].
+// Split-f16 packing: w * 2^s = hi + lo (both f16); layout [cg][blk][ky][kc][hi|lo][mb][kx][lane][8] — a (blk, ky) slice is
+// contiguous and splits into one sub-slice per K-chunk kc, the unit the kernel double-buffers (dfnet_conv.hip).
 void pack_conv_x3(const float* w, int cout, int cin, int ks, bool first, int sb, int mb, float wscale, std::vector<uint8_t>& blob) {
   const int nblk = first ? 1 : cin / 32, kcb = sb / 8, groups = cout / 32 / mb;
-  const size_t half_slice = size_t(mb) * ks * kcb * 64 * 8;  // elements
-  blob.assign(size_t(groups) * nblk * ks * 2 * half_slice * 2, 0);
+  const size_t frag = 64 * 8;                                   // elements of one fragment
+  const size_t sub = size_t(2) * mb * ks * frag;                // one (blk, ky, kc) sub-slice: hi and lo
+  blob.assign(size_t(groups) * nblk * ks * kcb * sub * 2, 0);
   _Float16* out = reinterpret_cast<_Float16*>(blob.data());
   for (int cg = 0; cg < groups; ++cg)
     for (int blk = 0; blk < nblk; ++blk)
-      for (int ky = 0; ky < ks; ++ky) {
-        _Float16* sl = out + ((size_t(cg) * nblk + blk) * ks + ky) * 2 * half_slice;
-        size_t o = 0;
-        for (int m = 0; m < mb; ++m)
-          for (int kx = 0; kx < ks; ++kx)
-            for (int kc = 0; kc < kcb; ++kc)
+      for (int ky = 0; ky < ks; ++ky)
+        for (int kc = 0; kc < kcb; ++kc) {
+          _Float16* sl = out + (((size_t(cg) * nblk + blk) * ks + ky) * kcb + kc) * sub;
+          for (int m = 0; m < mb; ++m)
+            for (int kx = 0; kx < ks; ++kx)
               for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 8; ++j, ++o) {
+                for (int j = 0; j < 8; ++j) {
                   const int co = 32 * (cg * mb + m) + (lane & 31);
                   const int ci = in_channel(first, blk, lane >> 5, kc * 8 + j);
                   const float v = (ci >= 0 && ci < cin ? w[((size_t(co) * cin + ci) * ks + ky) * ks + kx] : 0.f) * wscale;
                   const _Float16 hi = _Float16(v);
+                  const size_t o = ((size_t(m) * ks + kx) * 64 + lane) * 8 + j;
                   sl[o] = hi;
-                  sl[half_slice + o] = _Float16(v - float(hi));
+                  sl[size_t(mb) * ks * frag + o] = _Float16(v - float(hi));
                 }
-      }
+        }
 }
 
 int upload_bytes(const void* src, size_t bytes, void** dst) {

@@ -175,7 +175,8 @@ static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t stream) {
 // blocked layout and are split while the input patch is staged into two f16 LDS planes; weights are split on the
 // host and staged as [hi fragments][lo fragments].  Both operands are pre-scaled by powers of two (activations
 // x kConvActScale, weights x2^s per layer, ConvArgs::out_scale undoes it exactly) so the lo parts stay normal f16.
-// The weight slices (one per input block and kernel row) are double-buffered: the DMA of slice s+1 is in flight
+// The weight sub-slices (one per input block, kernel row and K-chunk: 12 KB for a 3x3) are double-buffered — small enough
+// that TWO workgroups still fit a CU —: the DMA of sub-slice s+1 is in flight
 // while slice s is multiplied.
 DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
   const uint32_t off = (uint32_t)(size_t)DFN_LDS_PTR(lds_dst);
@@ -185,7 +186,7 @@ DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
 template <int KS, int SB, int WAVES = 4>
 constexpr int x3_plane_bytes() { return (((2 * WAVES + KS - 1) * (kConvTileW + KS - 1) * (2 * SB * 2 + 16)) + 15) & ~15; }
 template <int KS, int SB, int MB>
-constexpr int x3_wslice_bytes() { return 2 * MB * KS * (SB / 8) * 1024; }  // hi + lo fragments of one (block, ky) slice
+constexpr int x3_wslice_bytes() { return 2 * MB * KS * 1024; }  // hi + lo fragments of one (block, ky, kc) sub-slice
 
 // WAVES = 4: 8 x 32 output pixels per workgroup, two workgroups per CU.  WAVES = 8: 16 x 32 pixels, ONE workgroup per CU — the
 // same eight waves share every weight slice (half the LDS-DMA per output pixel), the patch halo is amortised over twice
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
     }
   }
   const char* in = static_cast<const char*>(a.in);
-  const int n_slices = a.nblk_in * KS;
+  const int n_slices = a.nblk_in * KS * KCB;   // one per (block, ky, K-chunk)
   // operand scale of the input tensor: the fixed activation scale, or (gradient tensors) a measured power of two
   const float act_scale = a.dyn_scale ? a.dyn_scale[0] : kConvActScale;
   const float out_scale = a.dyn_scale ? a.out_scale * kConvActScale * a.dyn_scale[1] : a.out_scale;
@@ -282,37 +283,47 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
     store_patch();
     const bool more = blk + 1 < a.nblk_in;
 #pragma unroll 1
-    for (int ky = 0; ky < KS; ++ky, ++sl) {
-      if (!DB) {                           // single slice buffer: two workgroups per CU cover each other's staging
-        if (ky) __syncthreads();           // previous slice fully consumed
-        issue_slice(sl, 0);
-      }
-      if (ky == 0 && more) {               // next block's patch: issued AFTER this slice's DMA, allowed to stay in flight
-        load_patch(blk + 1);
-        __builtin_amdgcn_s_waitcnt(NPRE <= 15 ? (0x0F70 | NPRE) : 0x0F70);  // vmcnt(NPRE)
-      } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my share of slice sl has landed
-      }
-      asm volatile("" ::: "memory");
-      __syncthreads();                     // slice sl and the patch are visible; (DB) slice sl-1 is fully consumed
-      if (DB && sl + 1 < n_slices) issue_slice(sl + 1, (sl + 1) & 1);
-      const char* wb = wst + (DB ? (sl & 1) * WSL : 0);
+    for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
+      for (int kc = 0; kc < KCB; ++kc, ++sl) {
+        if (!DB) {                           // single buffer: two workgroups per CU cover each other's staging
+          if (ky || kc) __syncthreads();     // previous sub-slice fully consumed
+          issue_slice(sl, 0);
+        }
+        if (ky == 0 && kc == 0 && more) {    // next block's patch: issued AFTER this sub-slice's DMA, allowed to stay in flight
+          load_patch(blk + 1);
+          __builtin_amdgcn_s_waitcnt(NPRE <= 15 ? (0x0F70 | NPRE) : 0x0F70);  // vmcnt(NPRE)
+        } else {
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my share of sub-slice sl has landed
+        }
+        asm volatile("" ::: "memory");
+        __syncthreads();                     // sub-slice sl and the patch are visible; (DB) sub-slice sl-1 is fully consumed
+        if (DB && sl + 1 < n_slices) issue_slice(sl + 1, (sl + 1) & 1);
+        const char* wb = wst + (DB ? (sl & 1) * WSL : 0);
 #pragma unroll
-        for (int kc = 0; kc < KCB; ++kc) {
+        for (int kx = 0; kx < KS; ++kx) {
           half8 bh[2], bl[2];
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             const int o = ((2 * wave + nb + ky) * PW + p + kx) * PS + (h * SB + kc * 8) * 2;
+#ifdef DFN_CONV_ABL_NOBREAD
+            bh[nb] = half8{(_Float16)o, 1, 2, 3, 4, 5, 6, 7};
+            bl[nb] = half8{(_Float16)kx, 1, 2, 3, 4, 5, 6, 7};
+#else
             bh[nb] = *reinterpret_cast<const half8*>(plane_hi + o);
             bl[nb] = *reinterpret_cast<const half8*>(plane_lo + o);
+#endif
           }
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
-            const int fo = (((mb * KS + kx) * KCB + kc) * 64 + lane) * 16;
+            const int fo = ((mb * KS + kx) * 64 + lane) * 16;
+#ifdef DFN_CONV_ABL_NOAREAD
+            const half8 ah = half8{(_Float16)fo, 1, 2, 3, 4, 5, 6, 7};
+            const half8 al = half8{(_Float16)mb, 1, 2, 3, 4, 5, 6, 7};
+#else
             const half8 ah = *reinterpret_cast<const half8*>(wb + fo);
             const half8 al = *reinterpret_cast<const half8*>(wb + WHALF + fo);
+#endif
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
 #ifdef DFN_CONV_ABL_NOMFMA
@@ -429,9 +440,9 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
     if (ks == 3) return wide ? launch_conv_t<PrecF16, 3, 16, 4>(a, stream) : launch_conv_t<PrecF16, 3, 16, 2>(a, stream);
     if (ks == 5) return wide ? launch_conv_t<PrecF16, 5, 16, 4>(a, stream) : launch_conv_t<PrecF16, 5, 16, 2>(a, stream);
   } else if (prec == 2) {
-    // 1x1 / 3x3: one slice buffer and two workgroups per CU (they cover each other's staging) measured 13 % faster than
-    // one double-buffered workgroup; the 5x5 tile fits only one workgroup per CU either way, so it double-buffers.
-    static const int db = [] { const char* e = getenv("DFN_X3_DB"); return e ? atoi(e) : 0; }();  // tuning aid
+    // Sub-slices per K-chunk are double-buffered in every kernel: 3x3 / 1x1 keep two workgroups per CU (77 KB of LDS each),
+    // the 5x5 tile fits one.
+    static const int db = [] { const char* e = getenv("DFN_X3_DB"); return e ? atoi(e) : 1; }();  // tuning aid (0: single buffer)
     if (sb == 8 && ks == 3) return launch_conv_x3_t<3, 8, 2, true>(a, stream);
     if (sb != 16) return hipErrorInvalidValue;
     if (ks == 1) return db ? launch_conv_x3_t<1, 16, 2, true>(a, stream) : launch_conv_x3_t<1, 16, 2, false>(a, stream);

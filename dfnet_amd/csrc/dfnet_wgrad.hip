@@ -696,10 +696,10 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
     if (PREC == 0) static_cast<_Float16*>(out)[i] = (_Float16)v;
     else if (PREC == 1) static_cast<float*>(out)[i] = v;
     else {
-      // slice layout [cg][blk][ky][hi|lo][mb][kx][kc][lane][8]
-      const size_t half_slice = (size_t)g.mb * g.ks * kcb * 64 * 8;
-      const size_t slice = ((size_t)cg * nblk + blk) * g.ks + ky;
-      const size_t o = ((((size_t)m * g.ks + kx) * kcb + kc) * 64 + lane) * 8 + j;
+      // layout [cg][blk][ky][kc][hi|lo][mb][kx][lane][8] (dfnet_api.hip: pack_conv_x3)
+      const size_t half_slice = (size_t)g.mb * g.ks * 64 * 8;
+      const size_t slice = (((size_t)cg * nblk + blk) * g.ks + ky) * kcb + kc;
+      const size_t o = (((size_t)m * g.ks + kx) * 64 + lane) * 8 + j;
       _Float16* sl = static_cast<_Float16*>(out) + slice * 2 * half_slice;
       const float vs = v * g.wscale;
       const _Float16 hi = (_Float16)vs;
