@@ -178,6 +178,21 @@ static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t stream) {
 // The weight sub-slices (one per input block, kernel row and K-chunk: 12 KB for a 3x3) are double-buffered — small enough
 // that TWO workgroups still fit a CU —: the DMA of sub-slice s+1 is in flight
 // while slice s is multiplied.
+#ifdef DFN_TIMING
+// Cycle accounting of conv_x3_kernel (timing build only, tools/gpu_conv_timing.py): lane 0 of every wave adds the
+// cycles it spent in [0] DMA/patch wait, [1] barrier, [2] patch split + stores, [3] fragment reads + MFMA issue,
+// [4] epilogue, [5] whole kernel, [6] waves counted.
+__device__ unsigned long long g_conv_cycles[8];
+#define CONV_T_DECL unsigned long long ct_last = __builtin_amdgcn_s_memtime(), ct_begin = ct_last, ct[5] = {0, 0, 0, 0, 0}
+#define CONV_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ct[i] += now_ - ct_last; ct_last = now_; } while (0)
+#define CONV_T_FLUSH do { if (lane == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&g_conv_cycles[i_], ct[i_]); \
+    atomicAdd(&g_conv_cycles[5], __builtin_amdgcn_s_memtime() - ct_begin); atomicAdd(&g_conv_cycles[6], 1ull); } } while (0)
+#else
+#define CONV_T_DECL
+#define CONV_T(i)
+#define CONV_T_FLUSH
+#endif
+
 DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
   const uint32_t off = (uint32_t)(size_t)DFN_LDS_PTR(lds_dst);
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(off) : "memory");
@@ -211,9 +226,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 31, h = lane >> 5;
   const int tiles_x = (a.W + TW - 1) / TW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  int tile = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  if (a.xcd_groups > 0) {
+    // XCD-aware 1-D grid (layers whose packed weights exceed an XCD's 4 MB L2).  Workgroup n is dispatched to XCD n % 8:
+    // give XCD k the k-th contiguous eighth of the (output-channel group)-major order, so that each XCD's L2 holds only
+    // ITS groups' weights (one eighth of the layer) instead of thrashing on all of them.  The grid is padded to a
+    // multiple of eight; the padding workgroups leave at once.  Speed only: any placement computes the same result.
+    const int n8 = (a.xcd_groups + 7) / 8;
+    const int L = (blockIdx.x & 7) * n8 + (blockIdx.x >> 3);
+    if (L >= a.xcd_groups) return;
+    const int tiles = tiles_x * ((a.H + TH - 1) / TH), per_cg = tiles * a.B;
+    cg = L / per_cg;
+    const int rem = L - cg * per_cg;
+    b = rem / tiles;
+    tile = rem - b * tiles;
+  }
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  const int cg = blockIdx.y, b = blockIdx.z;
 
   f32x16 acc[MB][2];
 #pragma unroll
@@ -275,19 +304,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
       }
     }
   };
+  CONV_T_DECL;
   load_patch(0);
   if (DB) issue_slice(0, 0);
   int sl = 0;
   for (int blk = 0; blk < a.nblk_in; ++blk) {
+    CONV_T(3);
     __syncthreads();  // everyone is done with the previous patch (and the slice before the one in flight)
+    CONV_T(1);
     store_patch();
+    CONV_T(2);
     const bool more = blk + 1 < a.nblk_in;
 #pragma unroll 1
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
       for (int kc = 0; kc < KCB; ++kc, ++sl) {
         if (!DB) {                           // single buffer: two workgroups per CU cover each other's staging
-          if (ky || kc) __syncthreads();     // previous sub-slice fully consumed
+          if (ky || kc) { CONV_T(3); __syncthreads(); CONV_T(1); }   // previous sub-slice fully consumed
           issue_slice(sl, 0);
         }
         if (ky == 0 && kc == 0 && more) {    // next block's patch: issued AFTER this sub-slice's DMA, allowed to stay in flight
@@ -297,7 +330,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
           __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my share of sub-slice sl has landed
         }
         asm volatile("" ::: "memory");
+        CONV_T(0);
         __syncthreads();                     // sub-slice sl and the patch are visible; (DB) sub-slice sl-1 is fully consumed
+        CONV_T(1);
         if (DB && sl + 1 < n_slices) issue_slice(sl + 1, (sl + 1) & 1);
         const char* wb = wst + (DB ? (sl & 1) * WSL : 0);
 #pragma unroll
@@ -339,6 +374,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
       }
     }
   }
+  CONV_T(3);
   // epilogue (fp32 activations): undo the operand scaling, write the pre-ReLU tap and/or the ReLU'd activation
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
@@ -366,7 +402,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
       }
     }
   }
+  CONV_T(4);
+  CONV_T_FLUSH;
 }
+
+#ifdef DFN_TIMING
+}  // namespace dfn
+// timing build only: read (and optionally clear) the cycle counters of conv_x3_kernel
+extern "C" int dfn_debug_conv_cycles(unsigned long long* out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(dfn::g_conv_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dfn::g_conv_cycles), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace dfn {
+#endif
 
 template <int KS, int SB, int MB, bool DB, int WAVES = 4>
 static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
@@ -381,6 +433,15 @@ static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
     attr_done = true;
   }
   const int tiles = ((a.H + 2 * WAVES - 1) / (2 * WAVES)) * ((a.W + kConvTileW - 1) / kConvTileW);
+  // weights of the layer in the packed split-f16 form: hi + lo f16 per element
+  const size_t wbytes = size_t(a.cout_blocks) * 32 * a.nblk_in * 32 * KS * KS * 4;
+  static const int xcd_mode = [] { const char* e = getenv("DFN_X3_XCD"); return e ? atoi(e) : 1; }();  // tuning aid: 0 = plain 3-D grid
+  if (xcd_mode && (xcd_mode == 2 || wbytes > (3u << 20)) && a.cout_blocks / MB >= 8) {
+    ConvArgs ax = a;
+    ax.xcd_groups = tiles * (a.cout_blocks / MB) * a.B;
+    hipLaunchKernelGGL(kern, dim3((ax.xcd_groups + 7) / 8 * 8), dim3(WAVES * 64), lds, stream, ax);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(kern, dim3(tiles, a.cout_blocks / MB, a.B), dim3(WAVES * 64), lds, stream, a);
   return hipGetLastError();
 }

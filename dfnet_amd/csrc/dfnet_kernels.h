@@ -30,6 +30,7 @@ struct ConvArgs {
   int cout_blocks;     // Cout/32
   int relu;
   float out_scale;     // prec 2 (split-f16): accumulators are multiplied by this before the epilogue (2^-(s+4))
+  int xcd_groups;      // split-f16 kernel: > 0 = 1-D XCD-aware grid (see conv_x3_kernel); = number of logical workgroups
   const float* dyn_scale;  // prec 2, optional: device [scale, 1/scale] of the INPUT tensor (launch_absmax_scale) replacing
                            // the fixed x16 activation scale — gradient tensors have no a-priori magnitude
 };
