@@ -121,32 +121,47 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     }
   }
 
-  // epilogue: lane (p, h) owns pixel (y0 + 2*wave + nb, x0 + p), 16 results per M-block, contiguous in memory
+  // Epilogue: lane (p, h) owns pixel (y0 + 2*wave + nb, x0 + p), 16 results per M-block = half of the pixel's channel line.
+  // Stored straight from the accumulators every instruction would touch 32 lines partially; each wave turns one
+  // (row, M-block) at a time through LDS (the staging buffers are dead) and stores whole lines (see conv_x3_kernel).
+  constexpr int LINEB = 32 * int(sizeof(T)), ROWB = LINEB + 16, LPL = LINEB / 16;   // lanes per line
+  __syncthreads();
+  char* turn = smem + wave * (32 * ROWB);
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
-    const int y = y0 + 2 * wave + nb, x = x0 + p;
-    if (y >= a.H || x >= a.W) continue;
+    const int y = y0 + 2 * wave + nb;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const size_t off = ((((size_t)b * a.H + y) * a.W + x) * a.cout_blocks + (cg * MB + mb)) * 32 + 16 * h;
       alignas(16) T pre[16];
-      alignas(16) T act[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pre[r] = (T)acc[mb][nb][r];
-        act[r] = (T)(a.relu ? fmaxf(acc[mb][nb][r], 0.f) : acc[mb][nb][r]);
-      }
-      constexpr int NV = 16 * int(sizeof(T)) / 16;
-      if (a.out_pre) {
-        f32x4* d = reinterpret_cast<f32x4*>(static_cast<T*>(a.out_pre) + off);
+      for (int r = 0; r < 16; ++r) pre[r] = (T)acc[mb][nb][r];
+      f32x4* d = reinterpret_cast<f32x4*>(turn + p * ROWB + h * (LINEB / 2));
 #pragma unroll
-        for (int q = 0; q < NV; ++q) d[q] = reinterpret_cast<const f32x4*>(pre)[q];
-      }
-      if (a.out_act) {
-        f32x4* d = reinterpret_cast<f32x4*>(static_cast<T*>(a.out_act) + off);
+      for (int q = 0; q < LINEB / 32; ++q) d[q] = reinterpret_cast<const f32x4*>(pre)[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (y < a.H) {
+        const size_t rowoff = ((((size_t)b * a.H + y) * a.W + x0) * a.cout_blocks + (cg * MB + mb)) * 32;   // elements
 #pragma unroll
-        for (int q = 0; q < NV; ++q) d[q] = reinterpret_cast<const f32x4*>(act)[q];
+        for (int i = 0; i < 32 * LPL / 64; ++i) {
+          const int px = i * (64 / LPL) + lane / LPL, chunk = lane % LPL;
+          if (x0 + px < a.W) {
+            alignas(16) T v[16 / sizeof(T)];
+            *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(turn + px * ROWB + chunk * 16);
+            const size_t off = rowoff + (size_t)px * a.cout_blocks * 32 + chunk * (16 / sizeof(T));
+            if (a.out_pre) *reinterpret_cast<f32x4*>(static_cast<T*>(a.out_pre) + off) = *reinterpret_cast<const f32x4*>(v);
+            if (a.out_act) {
+              if (a.relu) {
+#pragma unroll
+                for (int k = 0; k < int(16 / sizeof(T)); ++k) v[k] = (T)fmaxf((float)v[k], 0.f);
+              }
+              *reinterpret_cast<f32x4*>(static_cast<T*>(a.out_act) + off) = *reinterpret_cast<const f32x4*>(v);
+            }
+          }
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
