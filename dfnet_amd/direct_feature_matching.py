@@ -18,7 +18,7 @@ import torch
 
 from . import dist as ddist
 from .feature_misc import feature_loss, fix_coord_supp, upsample_bicubic
-from .rendering import render
+from .rendering import render, render_frames
 
 
 def preprocess_features_for_loss(feature):
@@ -55,17 +55,7 @@ def matching_step_forward(args, data, model, feat_model, pose, img_idx, hwf, hal
         _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
         pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
         img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
-        rgbs = []
-        for b in range(B):
-            if half_res:
-                rgb, _, _, _ = render(H // 4, W // 4, focal / 4, chunk=args.chunk, c2w=pose_nerf[b, :3, :4],
-                                      img_idx=img_idx[b], **render_kwargs_test)
-                rgb = upsample_bicubic(rgb, H, W)
-            else:
-                rgb, _, _, _ = render(H, W, focal, chunk=args.chunk, c2w=pose_nerf[b, :3, :4], img_idx=img_idx[b],
-                                      **render_kwargs_test)
-            rgbs.append(rgb.permute(2, 0, 1))
-        rgb = torch.stack(rgbs)
+        rgb = _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
         feats, _ = inference_pose_regression(args, torch.cat([data, rgb]), device, feat_model, retFeature=True,
                                              isSingleStream=False, return_pose=False)
         idx = torch.tensor(args.feature_matching_lvl, device=device)
@@ -98,17 +88,7 @@ def matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, half_r
     with torch.enable_grad():
         pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
         img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
-        rgbs = []
-        for b in range(B):
-            if half_res:
-                rgb, _, _, _ = render(H // 4, W // 4, focal / 4, chunk=args.chunk, c2w=pose_nerf[b, :3, :4],
-                                      img_idx=img_idx[b], **render_kwargs_test)
-                rgb = upsample_bicubic(rgb, H, W)
-            else:
-                rgb, _, _, _ = render(H, W, focal, chunk=args.chunk, c2w=pose_nerf[b, :3, :4], img_idx=img_idx[b],
-                                      **render_kwargs_test)
-            rgbs.append(rgb.permute(2, 0, 1))
-        rgb = torch.stack(rgbs)
+        rgb = _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
         loss, photo_l, feat_l, pose_l = _losses(args, data, rgb, pose_, pose, feat_model, device, parts=True)
         loss.backward()
     with torch.no_grad():
@@ -116,6 +96,16 @@ def matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, half_r
     return dict(loss=loss.detach(), pose_loss=pose_l.detach(), photo_loss=photo_l.detach(), feat_loss=feat_l.detach(),
                 psnr=psnr, rgb=rgb.detach(), pose_pred=pose_.detach(), grad_pose=pose_.grad)
 
+
+
+def _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test):
+    """The per-frame render loop of the reference's step (:340-348; it renders only pose_nerf[0], its batch size being 1) for the
+    whole mini-batch: one batched launch per render stage (rendering.render_frames), then the bicubic enlargement per frame.
+    Returns rgb [B,3,H,W], attached to pose_nerf."""
+    if half_res:
+        small = render_frames(H // 4, W // 4, focal / 4, pose_nerf, img_idx, **render_kwargs_test)
+        return torch.stack([upsample_bicubic(small[b], H, W).permute(2, 0, 1) for b in range(small.shape[0])])
+    return render_frames(H, W, focal, pose_nerf, img_idx, **render_kwargs_test).permute(0, 3, 1, 2)
 
 
 def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False):
@@ -153,17 +143,8 @@ def train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer,
         _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
         pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
         img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
-        rgbs = []
-        for b in range(B):   # the reference renders pose 0 only (:342); every pose of the batch here
-            if half_res:
-                rgb, _, _, _ = render(H // 4, W // 4, focal / 4, chunk=args.chunk, c2w=pose_nerf[b, :3, :4],
-                                      img_idx=img_idx[b], **render_kwargs_test)
-                rgb = upsample_bicubic(rgb, H, W)
-            else:
-                rgb, _, _, _ = render(H, W, focal, chunk=args.chunk, c2w=pose_nerf[b, :3, :4], img_idx=img_idx[b],
-                                      **render_kwargs_test)
-            rgbs.append(rgb.permute(2, 0, 1))
-        rgb = torch.stack(rgbs)
+        # the reference renders pose 0 only (:342); every pose of the batch here, as one ray batch
+        rgb = _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
         loss, photo_l = _losses(args, data, rgb, pose_, pose, feat_model, device)
         loss.backward()
     ddist.allreduce_gradients(model.parameters())   # data-parallel: one all-reduce of the regressor's gradients per step

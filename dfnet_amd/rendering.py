@@ -76,6 +76,46 @@ class _RenderImageFn(torch.autograd.Function):
         return (_e.raygen_backward(H, W, focal, go, gd),) + (None,) * 9
 
 
+class _RenderFramesFn(torch.autograd.Function):
+    """rgb [B,H,W,3] = render of B frames (each with its own pose and histogram vector) as ONE ray batch: the DFNet_dm step
+    renders every frame of its mini-batch (direct_feature_matching.py:340-348 loops over them); batching them gives each
+    kernel B times the work per launch.  backward: d L/d c2w [B,3,4] from d L/d rgb."""
+
+    @staticmethod
+    def forward(ctx, c2ws, eng, H, W, focal, hists, Nc, Ni, near, far):
+        from . import engine as _e
+        B = c2ws.shape[0]
+        rays = [_e.raygen(H, W, focal, c2ws[b].detach()) for b in range(B)]
+        o, d, v = (torch.cat([r[k].reshape(-1, 3) for r in rays]) for k in range(3))
+        hist = hists.reshape(B, 1, -1).expand(B, H * W, hists.shape[-1]).reshape(B * H * W, -1).contiguous()   # one row per ray
+        rgb, _, _, z, raw = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION)
+        ctx.save_for_backward(o, d, v, hist, z, raw)
+        ctx.cfg = (eng, B, H, W, focal)
+        return rgb.reshape(B, H, W, 3)
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        from . import engine as _e
+        o, d, v, hist, z, raw = ctx.saved_tensors
+        eng, B, H, W, focal = ctx.cfg
+        go, gd, _ = eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION)
+        go, gd = go.reshape(B, H * W, 3), gd.reshape(B, H * W, 3)
+        gc = torch.stack([_e.raygen_backward(H, W, focal, go[b].contiguous(), gd[b].contiguous()) for b in range(B)])
+        return (gc,) + (None,) * 9
+
+
+def render_frames(H, W, focal, c2ws, img_idx, **kwargs):
+    """rgb [B,H,W,3] of B frames at poses c2ws [B,3,4] with histogram vectors img_idx [B,bins] — render(c2w=...) per frame,
+    batched into one launch per stage, differentiable w.r.t. c2ws.  Same option checks as render()."""
+    near, far = kwargs.pop('near', 0.), kwargs.pop('far', 1.)
+    _check_test_time(kwargs, kwargs.get('ndc', False), None, kwargs.get('use_viewdirs', True))
+    eng = _engine_of(kwargs)
+    c2ws = c2ws[:, :3, :4]
+    hists = torch.as_tensor(img_idx, dtype=torch.float32, device=c2ws.device).reshape(c2ws.shape[0], -1)
+    return _RenderFramesFn.apply(c2ws, eng, int(H), int(W), float(focal), hists, int(kwargs['N_samples']), int(kwargs['N_importance']),
+                                 float(near), float(far))
+
+
 class _RenderRaysFn(torch.autograd.Function):
     """rgb/disp/acc = render(rays); backward: d L/d rays_o, d L/d rays_d (viewdirs = d/|d| differentiated)."""
 

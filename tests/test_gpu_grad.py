@@ -562,6 +562,30 @@ def test_dfnet_s_module_training_step_vs_oracle():
     assert rel_l2(f2[0], ref2[0]) < 5e-6
 
 
+def test_render_frames_equals_per_frame_render():
+    """rendering.render_frames (B frames as one ray batch, the DFNet_dm step's form) gives the frames and pose gradients of
+    B separate render(c2w=...) calls."""
+    from dfnet_amd import rendering
+    from dfnet_amd.nerfw import HipQuery
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine(precision="f16").load_numpy(cw, fw, ea, et)
+    kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=32, N_samples=16, use_viewdirs=True, white_bkgd=False,
+              raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    H, W, focal, B = 12, 16, 14.6, 3
+    poses = torch.stack([T(syn.orbit_pose(k, 8))[:3, :4] for k in range(B)]).to(DEV)
+    hists = torch.stack([T(np.roll(syn.HIST_IDX, k)) for k in range(B)]).to(DEV)
+    G = torch.randn(B, H, W, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+    pa = poses.clone().requires_grad_(True)
+    rgb_a = rendering.render_frames(H, W, focal, pa, hists, **kw)
+    (rgb_a * G).sum().backward()
+    pb = poses.clone().requires_grad_(True)
+    rgb_b = torch.stack([rendering.render(H, W, focal, c2w=pb[b], img_idx=hists[b], **kw)[0] for b in range(B)])
+    (rgb_b * G).sum().backward()
+    e_rgb, e_g = relmax(rgb_a, rgb_b.detach().cpu()), relmax(pa.grad, pb.grad.cpu())
+    print(f"render_frames vs per-frame: rgb {e_rgb:.2e}, d c2w {e_g:.2e}")
+    assert e_rgb < 5e-6 and e_g < 1e-3   # d c2w: a cancelling sum over rays (see the module docstring)
+
+
 def test_dm_train_step_parameter_gradients_vs_oracle():
     """The whole DFNet_dm optimisation step (direct_feature_matching.py:322-376): gradients that reach the pose
     regressor's parameters through SVD -> scene rescale -> render -> bicubic -> feature extractor -> losses, HIP path vs

@@ -45,6 +45,11 @@ def timed(fn):
 
 
 from dfnet_amd import rendering
+if os.environ.get("DM_ONLY"):   # profiling aid: only the full optimisation step (rocprofv3 --stats then shows one step's kernels x iters)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-7)
+    ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
+    print(json.dumps({"full_step_ms": ms, "iters_profiled": iters + 1}))
+    sys.exit(0)
 results = {}
 for mode, fp in (("fp32 forward state", "f32"), ("f16 forward state", None)):
     rendering.GRAD_FORWARD_PRECISION = fp
