@@ -368,7 +368,8 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
   if (cout % 32 || cin % 32 || (ks != 1 && ks != 3 && ks != 5)) return hipErrorInvalidValue;
   const long long Q = (long long)B * H * W;
   const int pairs = mblks * nblks;
-  long long n_chunks = 2048 / pairs;                      // ~2048 workgroups
+  static const int target_wgs = [] { const char* e = getenv("DFN_WGRAD_WGS"); return e ? atoi(e) : 1536; }();   // tuning aid (multiple of the 768 resident workgroups)
+  long long n_chunks = target_wgs / pairs;                // ~1536 workgroups
   const long long max_by_work = (Q + 1023) / 1024;        // at least ~1024 pixels per workgroup
   if (n_chunks > max_by_work) n_chunks = max_by_work;
   if (n_chunks < 1) n_chunks = 1;
