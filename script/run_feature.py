@@ -24,7 +24,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-from dfnet_amd.datasets import load_7Scenes_dataloader  # noqa: E402
+from dfnet_amd.datasets import load_7Scenes_dataloader, load_Cambridge_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
 from dfnet_amd import dist as ddist  # noqa: E402
 from dfnet_amd.callbacks import EarlyStopping  # noqa: E402
@@ -225,9 +225,10 @@ def main(argv=None):
     args = feature_parser().parse_args(argv)
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     ddist.init_from_env()   # torchrun: one process per GPU, gradients averaged over RCCL; single process otherwise
-    if args.dataset_type != '7Scenes':
-        raise NotImplementedError(f"dataset_type={args.dataset_type}: only the 7Scenes front-end is built")
-    train_dl, val_dl, test_dl, hwf, i_split, near, far = load_7Scenes_dataloader(args)
+    if args.dataset_type not in ('7Scenes', 'Cambridge'):
+        raise NotImplementedError(f"dataset_type={args.dataset_type}: the 7Scenes and Cambridge front-ends are built")
+    load_dataloader = load_7Scenes_dataloader if args.dataset_type == '7Scenes' else load_Cambridge_dataloader
+    train_dl, val_dl, test_dl, hwf, i_split, near, far = load_dataloader(args)
     train_feature(args, train_dl, val_dl, test_dl, hwf, i_split, near, far)
 
 

@@ -19,7 +19,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 from dfnet_amd import dist as ddist  # noqa: E402
-from dfnet_amd.datasets import load_7Scenes_dataloader_NeRF  # noqa: E402
+from dfnet_amd.datasets import load_7Scenes_dataloader_NeRF, load_Cambridge_dataloader_NeRF  # noqa: E402
 from dfnet_amd.nerfw import create_nerf  # noqa: E402
 from dfnet_amd.options import config_parser  # noqa: E402
 from dfnet_amd.rendering import render_test  # noqa: E402
@@ -56,9 +56,10 @@ def main(argv=None):
     args = config_parser().parse_args(argv)
     rank, world, local = ddist.init_from_env()
     torch.cuda.set_device(local)
-    if args.dataset_type != '7Scenes':
-        raise NotImplementedError(f"dataset_type={args.dataset_type}: only the 7Scenes front-end is built")
-    train_dl, val_dl, hwf, i_split, bds, render_poses, render_img = load_7Scenes_dataloader_NeRF(args)
+    if args.dataset_type not in ('7Scenes', 'Cambridge'):
+        raise NotImplementedError(f"dataset_type={args.dataset_type}: the 7Scenes and Cambridge front-ends are built")
+    loader = load_7Scenes_dataloader_NeRF if args.dataset_type == '7Scenes' else load_Cambridge_dataloader_NeRF
+    train_dl, val_dl, hwf, i_split, bds, render_poses, render_img = loader(args)
     near, far = float(bds[0]), float(bds[1])
     print('NEAR FAR', near, far)
     train_nerf(args, train_dl, val_dl, hwf, i_split, near, far, render_poses, render_img)

@@ -19,7 +19,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 from dfnet_amd import dist as ddist  # noqa: E402
-from dfnet_amd.datasets import load_7Scenes_dataloader  # noqa: E402
+from dfnet_amd.datasets import load_7Scenes_dataloader, load_Cambridge_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
 from dfnet_amd.direct_feature_matching import matching_step_forward, train_on_epoch  # noqa: E402
 from dfnet_amd.nerfw import create_nerf  # noqa: E402
@@ -33,10 +33,11 @@ def main(argv=None):
     rank, world, local = ddist.init_from_env()   # torchrun: one process per GPU, gradients averaged over RCCL
     torch.cuda.set_device(local)
     device = torch.device("cuda", torch.cuda.current_device())
-    if args.dataset_type != '7Scenes':
-        raise NotImplementedError(f"dataset_type={args.dataset_type}: only the 7Scenes front-end is built")
+    if args.dataset_type not in ('7Scenes', 'Cambridge'):
+        raise NotImplementedError(f"dataset_type={args.dataset_type}: the 7Scenes and Cambridge front-ends are built")
+    load_dataloader = load_7Scenes_dataloader if args.dataset_type == '7Scenes' else load_Cambridge_dataloader
     args.pose_only = 1  # the reference passes the PoseNet loader (dm/prepare_data.py)
-    train_dl, val_dl, test_dl, hwf, i_split, near, far = load_7Scenes_dataloader(args)
+    train_dl, val_dl, test_dl, hwf, i_split, near, far = load_dataloader(args)
     Net = DFNet_s if args.DFNet_s else DFNet
     model, feat_model = Net().eval(), Net().eval()
     if args.pretrain_model_path:

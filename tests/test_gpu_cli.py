@@ -139,3 +139,16 @@ def test_run_feature_training_cli(tmp_path, extra):
     assert "encoder.0.weight" in ck and "adaptation_layers.adapt_layer_2.3.running_mean" in ck
     moved = float((ck["adaptation_layers.adapt_layer_0.3.running_mean"]).abs().max()) > 0
     assert moved == (not extra)   # train() mode moves the running statistics, --freezeBN leaves them
+
+
+def test_run_feature_eval_cambridge_cli(tmp_path):
+    """The Cambridge Landmarks front-end (the reference's default config_dfnet.txt scene) through run_feature.py --eval."""
+    from tests.test_host_logic import make_cambridge_scene
+    datadir = make_cambridge_scene(str(tmp_path), scene="KingsCollege", n_train=3, n_val=3, H=128, W=228)
+    cli = ["--config", os.path.join(ROOT, "script", "config_dfnet.txt"), "--eval", "--dataset_type", "Cambridge", "--datadir", datadir,
+           "--basedir", str(tmp_path / "logs"), "--N_samples", "16", "--N_importance", "32", "--df", "2", "--testskip", "1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "run_feature.py")] + cli, cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("Median error", "Mean error"))]
+    assert len(lines) == 2 and all("degrees" in l for l in lines)

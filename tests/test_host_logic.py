@@ -257,3 +257,50 @@ def test_feature_training_batches_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "BATCHES_OK" in r.stdout
+
+
+def make_cambridge_scene(root, scene="ShopFacade", n_train=44, n_val=3, H=48, W=86, seed=0):
+    """A synthetic tree with the Cambridge layout of the reference: <scene>/{train,test}/{rgb,poses}/, world_setup.json."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    datadir = os.path.join(root, "data", "Cambridge", scene)
+    for split, n in (("train", n_train), ("test", n_val)):
+        os.makedirs(os.path.join(datadir, split, "rgb"))
+        os.makedirs(os.path.join(datadir, split, "poses"))
+        for i in range(n):
+            img = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(datadir, split, "rgb", f"{i:05d}-frame.png"))
+            np.savetxt(os.path.join(datadir, split, "poses", f"{i:05d}-pose.txt"), syn.orbit_pose(i, 50))
+    json.dump({"near": 0, "far": 10, "pose_scale": 0.3, "pose_scale2": 0.5, "move_all_cam_vec": [0.0, 0.0, 1.0]},
+              open(os.path.join(datadir, "world_setup.json"), "w"))
+    np.savetxt(os.path.join(datadir, "pose_avg_stats.txt"), np.eye(4)[:3])
+    return datadir
+
+
+def test_cambridge_front_end(tmp_path):
+    """Cambridge Landmarks layout (cambridge_scenes.py:139-215, load_Cambridge.py fix_coord): file pairing, ShopFacade's two
+    dropped training frames, trainskip, hwf from the image size and COLMAP's focal, and the axis correction written out."""
+    datadir = make_cambridge_scene(str(tmp_path))
+    args = options.nerf_parser().parse_args(["--datadir", datadir, "--dataset_type", "Cambridge", "--df", "2", "--trainskip", "2",
+                                             "--render_test"])
+    train_dl, val_dl, hwf, i_split, bds, _, _ = datasets.load_Cambridge_dataloader_NeRF(args)
+    assert hwf == [24, 43, 744. / 2] and list(bds) == [0, 10]
+    assert len(train_dl) == 21 and len(val_dl) == 3            # 44 - 2 dropped = 42 frames, every second one
+    kept = [i for i in range(44) if i not in (35, 42)][::2]
+    ds = train_dl.dataset
+    assert [int(os.path.basename(f)[:5]) for f in ds.files] == kept
+    img, pose, hist = ds[1] if not ds.device_prep else (None, torch.tensor(ds.poses[1], dtype=torch.float32), None)
+    # the pose of kept frame 1, from its source matrix: centre on the average pose, half turn about x, R <- -R, R <- R diag(-1,1,1), rescale
+    src = np.stack([syn.orbit_pose(i, 50)[:3] for i in kept + [0, 1, 2]]).astype(np.float64)
+    cen, _ = datasets.recentre_poses(src)
+    p4 = np.eye(4); p4[:3] = cen[1]
+    rx = np.diag([1., -1., -1., 1.])
+    want = (rx @ p4)[:3]
+    want[:, :3] = -want[:, :3] @ np.diag([-1., 1., 1.])
+    want[:, 3] = (want[:, 3] * 0.3 + [0, 0, 1.0]) * 0.5
+    np.testing.assert_allclose(pose.reshape(3, 4).numpy(), want, atol=1e-6)
+    R = want[:, :3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+    f = options.feature_parser().parse_args(["--datadir", datadir, "--dataset_type", "Cambridge", "--df", "2", "--pose_only", "1"])
+    tr, va, te, hwf2, _, near, far = datasets.load_Cambridge_dataloader(f)
+    assert hwf2 == hwf and (near, far) == (0.0, 10.0) and tr.dataset.pose_scale == 0.3 and len(te) == 3
