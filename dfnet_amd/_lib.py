@@ -51,6 +51,9 @@ SIGNATURES = {
                                  _P, _P, _P, _P, c_size_t, _P]),
     "dfn_composite_fine_backward": (c_int, [_P, _P, _P, c_size_t, c_int, _P, _P]),
     "dfn_mlp_fine_backward": (c_int, [_P, c_int, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_int, _P, _P, _P, _P]),
+    "dfn_mlp_fine_mask_bytes": (c_size_t, [c_size_t]),
+    "dfn_mlp_fine_saving": (c_int, [_P, c_int, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_int, _P, _P, _P, _P]),
+    "dfn_mlp_fine_backward_saved": (c_int, [_P, c_int, _P, _P, _P, c_size_t, _P, c_int, _P, _P, _P, _P, _P]),
     "dfn_ray_grad_reduce": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, _P, _P, _P, _P]),
     "dfn_raygen_backward": (c_int, [c_int, c_int, c_float, _P, _P, _P, _P]),
     "dfn_render_backward_workspace_bytes": (c_size_t, [c_size_t, c_int, c_int]),

@@ -50,6 +50,7 @@ struct PackedNet {
   char* blob = nullptr;
   uint32_t* tab = nullptr;
   int n_units = 0;
+  int n_fwd_units = 0;   // gradient nets: the forward units come first in the table
   float in_scale = 1.f;  // split-f16: weight scale x activation scale carried by the accumulators
 };
 
@@ -167,6 +168,7 @@ struct Mat {  // a state_dict Linear
 struct Packer {
   const dfn_nerfh_s* h;
   std::string pre;
+  mutable int fwd_units = 0;   // pack_bwd: number of forward units at the head of the table
   Mat mat(const std::string& key) const {
     Mat m;
     const auto& w = h->params.at(pre + key + ".weight");
@@ -322,6 +324,7 @@ struct Packer {
   template <class PF, class P>
   void pack_bwd(std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
     pack<PF>(true, (PF::kSlotsPerChunk == 8 && !PF::kSplit) ? 8 : 1, false, blob, tab);
+    fwd_units = int(tab.size() / 2);
     const int umb = (P::kSlotsPerChunk == 8 && !P::kSplit) ? 8 : 1;
     for (int layer = 0; layer < BW_COUNT; ++layer) {
       const LayerShape sh = bwd_layer_shape(layer);
@@ -454,6 +457,7 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
     rc = upload(tab.data(), tab.size() * 4, reinterpret_cast<void**>(&n.tab));
     if (rc) return rc;
     n.n_units = int(tab.size() / 2);
+    n.n_fwd_units = pk.fwd_units;
   }
   // per-ray-bias weights: transposed tails of dir_encoding.0 / transient_encoding.0 + embeddings
   const dfn_nerfh_desc& d = h->desc;
@@ -805,6 +809,43 @@ extern "C" int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_
   const PackedNet& n = h->bwd[prec];
   BwdArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, viewdirs, z_fine, table, grad_raw, grad_pts, (long long)n_rays, Nf, n.in_scale};
   CHECK_HIP(launch_mlp_fine_backward(prec, a, device_cu_count(), HS(stream)), "dfn_mlp_fine_backward");
+  return DFN_OK;
+}
+
+extern "C" size_t dfn_mlp_fine_mask_bytes(size_t n_points) {
+  return (n_points + kBwdTilePoints - 1) / kBwdTilePoints * (kBwdTilePoints / 32) * kBwdMaskWords * 64 * sizeof(uint32_t);
+}
+
+extern "C" int dfn_mlp_fine_saving(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                   const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf, float* raw,
+                                   void* masks, void* bias_ws, void* stream) {
+  if (int rc = check_net(h, prec, "dfn_mlp_fine_saving", true)) return rc;
+  if (prec != DFN_PREC_F16X3) return set_error(DFN_ERR_UNSUPPORTED, "dfn_mlp_fine_saving: split-f16 (DFN_PREC_F16X3) only");
+  if (!n_rays) return DFN_OK;
+  if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !raw || !masks || !bias_ws || Nf < 1 ||
+      (hist_rows != 1 && hist_rows != n_rays))
+    return set_error(DFN_ERR_ARG, "dfn_mlp_fine_saving: bad argument (hist_rows must be 1 or n_rays)");
+  float* table = static_cast<float*>(bias_ws);
+  CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine_saving(ray_bias)");
+  const PackedNet& n = h->bwd[prec];
+  BwdArgs a{n.blob, n.tab, n.n_fwd_units, rays_o, rays_d, viewdirs, z_fine, table, nullptr, nullptr, (long long)n_rays, Nf, n.in_scale,
+            raw, nullptr, static_cast<uint32_t*>(masks)};
+  CHECK_HIP(launch_mlp_fine_backward(prec, a, device_cu_count(), HS(stream), 1), "dfn_mlp_fine_saving");
+  return DFN_OK;
+}
+
+extern "C" int dfn_mlp_fine_backward_saved(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                           size_t n_rays, const float* z_fine, int Nf, const float* raw, const void* masks,
+                                           const float* grad_raw, float* grad_pts, void* stream) {
+  if (int rc = check_net(h, prec, "dfn_mlp_fine_backward_saved", true)) return rc;
+  if (prec != DFN_PREC_F16X3) return set_error(DFN_ERR_UNSUPPORTED, "dfn_mlp_fine_backward_saved: split-f16 (DFN_PREC_F16X3) only");
+  if (!n_rays) return DFN_OK;
+  if (!rays_o || !rays_d || !viewdirs || !z_fine || !raw || !masks || !grad_raw || !grad_pts || Nf < 1)
+    return set_error(DFN_ERR_ARG, "dfn_mlp_fine_backward_saved: bad argument");
+  const PackedNet& n = h->bwd[prec];
+  BwdArgs a{n.blob, n.tab + 2 * n.n_fwd_units, n.n_units - n.n_fwd_units, rays_o, rays_d, viewdirs, z_fine, nullptr, grad_raw, grad_pts,
+            (long long)n_rays, Nf, n.in_scale, nullptr, raw, static_cast<uint32_t*>(const_cast<void*>(masks))};
+  CHECK_HIP(launch_mlp_fine_backward(prec, a, device_cu_count(), HS(stream), 2), "dfn_mlp_fine_backward_saved");
   return DFN_OK;
 }
 

@@ -126,7 +126,10 @@ template <class PF, class P> constexpr uint32_t bwd_lds_bytes() { return 3 * bwd
 // PF: arithmetic of the forward recompute, P: arithmetic of the backward chain.  Split-f16 for both is the default:
 // activations are O(1), and the gradient vector of a point is carried with a per-point power-of-two scale that is
 // re-centred every other layer (renorm_factor), so its hi/lo halves stay in f16's normal range.
-template <class PF, class P, bool FAST, int WAVES, int UMBF, int UMB, int NB>
+// MODE 0: forward recompute + backward in one pass.  MODE 1: the forward only, writing raw and the ReLU sign masks (the
+// tracked forward of an autograd step).  MODE 2: the backward only, from those masks and raw — the head derivatives follow
+// from the head OUTPUTS (sigmoid' = y (1 - y), softplus' = 1 - exp(-y)), so no activation has to be kept or recomputed.
+template <class PF, class P, bool FAST, int WAVES, int UMBF, int UMB, int NB, int MODE = 0>
 __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PPT = WAVES * NB * 32;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 #pragma unroll
       for (int c = 0; c < 3; ++c) x[nb][c] = add_rn(a.rays_o[ray_of[nb] * 3 + c], mul_rn(a.rays_d[ray_of[nb] * 3 + c], z));
 #pragma unroll
-      for (int c = 0; c < 9; ++c) g[nb][c] = (h == 0 && pt[nb] < n_pts) ? a.graw[size_t(q) * 9 + c] : 0.f;
+      for (int c = 0; c < 9; ++c) g[nb][c] = (MODE != 1 && h == 0 && pt[nb] < n_pts) ? a.graw[size_t(q) * 9 + c] : 0.f;
       rb_dir[nb] = a.ray_bias + size_t(ray_of[nb]) * kRayBiasFloats;
       rb_tr[nb] = rb_dir[nb] + kRayBiasFloats / 2;
     }
@@ -194,6 +197,33 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
     }
     st.lane_mul = 1.f;
 
+    F dth[NB][SC], drgb[NB][SC];
+    float dsig_true[NB];
+    [[maybe_unused]] float o9[NB][9];
+    static_assert(MODE == 0 || NB == 1, "the two-pass form keeps one point block per wave");
+    uint32_t* mwords = MODE ? a.masks + ((size_t)(tile * WAVES + st.wave) * kBwdMaskWords) * 64 + st.lane : nullptr;
+    if constexpr (MODE == 2) {
+      // masks and head derivatives from the saved forward
+#pragma unroll
+      for (int l = 0; l < 8; ++l) { mk[l][0][0] = mwords[(2 * l) * 64]; mk[l][0][1] = mwords[(2 * l + 1) * 64]; }
+      md[0][0] = mwords[16 * 64];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) mt[l][0][0] = mwords[(17 + l) * 64];
+      const uint32_t q = uint32_t(pt[0] < n_pts ? pt[0] : n_pts - 1);
+      const float* rw = a.raw_in + size_t(q) * 9;
+      const bool on = h == 0 && pt[0] < n_pts;
+      clear<P>(drgb[0]);
+      clear<P>(dth[0]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float ys = on ? rw[c] : 0.f, yt = on ? rw[4 + c] : 0.f;
+        set_slot<P>(drgb[0], c, g[0][c] * ys * (1.f - ys) * sp[0]);
+        set_slot<P>(dth[0], c, g[0][4 + c] * yt * (1.f - yt) * sp[0]);
+      }
+      dsig_true[0] = on ? g[0][3] * -expm1f(-rw[3]) : 0.f;
+      set_slot<P>(dth[0], 3, on ? g[0][7] * -expm1f(-rw[7]) * sp[0] : 0.f);
+      set_slot<P>(dth[0], 4, on ? g[0][8] * -expm1f(-rw[8]) * sp[0] : 0.f);
+    } else {
     // ------------------------------------------------------------------ forward (recording ReLU signs)
     FF hid[NB][FHC];
     {
@@ -235,14 +265,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[7][nb]);
     }
     // heads; their pre-activation gradients seed the backward pass
-    F dth[NB][SC], drgb[NB][SC];
-    float dsig_true[NB];
     {
       FF fin[NB][FHC], dummy[NB][FSC];
       DFN_FLAYER(FHC, 4, true, false, hid, fin, norb);   // xyz_encoding_final + static_sigma (5th M-block)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         dsig_true[nb] = h == 0 ? g[nb][3] * act_sigmoid<FAST>(head[nb][0]) : 0.f;  // softplus' = sigmoid
+        if constexpr (MODE == 1) o9[nb][3] = act_softplus<FAST>(head[nb][0]);
       }
       {
         FF de[NB][FQC];
@@ -256,6 +285,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float y = act_sigmoid<FAST>(head[nb][c]);
+            if constexpr (MODE == 1) o9[nb][c] = y;
             set_slot<P>(drgb[nb], c, h == 0 ? g[nb][c] * y * (1.f - y) * sp[nb] : 0.f);
           }
         }
@@ -281,14 +311,30 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float y = act_sigmoid<FAST>(head[nb][c]);
+            if constexpr (MODE == 1) o9[nb][4 + c] = y;
             set_slot<P>(dth[nb], c, h == 0 ? g[nb][4 + c] * y * (1.f - y) * sp[nb] : 0.f);
           }
+          if constexpr (MODE == 1) { o9[nb][7] = act_softplus<FAST>(head[nb][3]); o9[nb][8] = act_softplus<FAST>(head[nb][4]); }
           set_slot<P>(dth[nb], 3, h == 0 ? g[nb][7] * act_sigmoid<FAST>(head[nb][3]) * sp[nb] : 0.f);
           set_slot<P>(dth[nb], 4, h == 0 ? g[nb][8] * act_sigmoid<FAST>(head[nb][4]) * sp[nb] : 0.f);
         }
       }
     }
 
+    }   // MODE != 2
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int l = 0; l < 8; ++l) { mwords[(2 * l) * 64] = mk[l][0][0]; mwords[(2 * l + 1) * 64] = mk[l][0][1]; }
+      mwords[16 * 64] = md[0][0];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) mwords[(17 + l) * 64] = mt[l][0][0];
+      if (h == 0 && pt[0] < n_pts) {
+        float* dst = a.raw_out + size_t(pt[0]) * 9;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) dst[c] = o9[0][c];
+      }
+      continue;
+    }
     // ------------------------------------------------------------------ backward
     float gx[NB][3], gv[NB][3];
     F gh[NB][HC];
@@ -444,7 +490,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   }
 }
 
-template <class PF, class P, bool FAST, int WAVES, int UMBF, int UMB, int NB>
+template <class PF, class P, bool FAST, int WAVES, int UMBF, int UMB, int NB, int MODE = 0>
 static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream) {
   constexpr int PPT = WAVES * NB * 32;
   const long long n_pts = (long long)a.n_rays * a.n_samples;
@@ -453,7 +499,7 @@ static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream)
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   const int grid = int(n_tiles < n_cu ? n_tiles : n_cu);
   const uint32_t lds = bwd_lds_bytes<PF, P>();
-  auto kern = nerfh_fine_backward_kernel<PF, P, FAST, WAVES, UMBF, UMB, NB>;
+  auto kern = nerfh_fine_backward_kernel<PF, P, FAST, WAVES, UMBF, UMB, NB, MODE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -464,7 +510,13 @@ static hipError_t launch_bwd_one(const BwdArgs& a, int n_cu, hipStream_t stream)
   return hipGetLastError();
 }
 
-hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream) {
+hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream, int mode) {
+  if (mode) {   // two-pass form: split-f16 only (exact gates are its point)
+    if (prec != 2) return hipErrorInvalidValue;
+    static_assert(kBwdTilePoints == 8 * 32, "tile geometry of the split-f16 gradient kernel");
+    return mode == 1 ? launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1, 1>(a, n_cu, stream)
+                     : launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1, 2>(a, n_cu, stream);
+  }
   if (prec == 0) return launch_bwd_one<PrecF16, PrecF16, true, 4, 8, 8, 1>(a, n_cu, stream);
   if (prec == 2) return launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1>(a, n_cu, stream);   // split-f16 forward and gradient chain
   return launch_bwd_one<PrecF32, PrecF32, false, 4, 1, 1, 1>(a, n_cu, stream);

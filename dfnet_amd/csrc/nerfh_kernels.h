@@ -72,8 +72,14 @@ struct BwdArgs {
   long long n_rays;
   int n_samples;
   float in_scale;          // split-f16 forward units: scale carried by the accumulators (else 1)
+  // Two-pass form (mode 1 = forward, writing raw and the ReLU masks; mode 2 = backward from them, no forward recompute):
+  float* raw_out;          // mode 1: [n_rays, n_samples, 9]
+  const float* raw_in;     // mode 2
+  uint32_t* masks;         // [tiles][waves][kBwdMaskWords][64 lanes]: written by mode 1, read by mode 2
 };
-hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream);
+constexpr int kBwdMaskWords = 21;    // 8 trunk layers x 128 bits, dir_encoding 64, transient_encoding 4 x 64 — per point
+constexpr int kBwdTilePoints = 256;  // points per workgroup tile of the split-f16 gradient kernel (8 waves x 32)
+hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStream_t stream, int mode = 0);
 // d L / d raw from d L / d rgb through the fine compositing (test-time, rgb only).
 hipError_t launch_composite_fine_backward(const float* raw, const float* z, const float* grad_rgb, size_t n_rays, int Nf,
                                           float* graw, hipStream_t stream);

@@ -96,6 +96,30 @@ class NerfHEngine:
                                              ctypes.c_void_p(bias.data_ptr()), current_stream()), "dfn_mlp_fine_backward")
         return gpts
 
+    def mlp_fine_saving(self, rays_o, rays_d, viewdirs, hist, z_fine):
+        """mlp_fine in split-f16 that also records the ReLU signs: (raw [n,Nf,9], masks) for mlp_fine_backward_saved()."""
+        rays_o, rays_d, viewdirs, z_fine = _f32c(rays_o), _f32c(rays_d), _f32c(viewdirs), _f32c(z_fine)
+        hist = _f32c(hist).reshape(-1, self.hist_bin)
+        n, Nf = z_fine.shape
+        dev = rays_o.device
+        raw = torch.empty(n, Nf, 9, device=dev)
+        masks = torch.empty(self.lib.dfn_mlp_fine_mask_bytes(n * Nf), dtype=torch.uint8, device=dev)
+        bias = torch.empty(self.lib.dfn_fine_bias_bytes(n), dtype=torch.uint8, device=dev)
+        check(self.lib.dfn_mlp_fine_saving(self.handle, _lib.PRECISIONS["f16x3"], ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(hist),
+                                           hist.shape[0], n, ptr(z_fine), Nf, ptr(raw), ctypes.c_void_p(masks.data_ptr()),
+                                           ctypes.c_void_p(bias.data_ptr()), current_stream()), "dfn_mlp_fine_saving")
+        return raw, masks
+
+    def mlp_fine_backward_saved(self, rays_o, rays_d, viewdirs, z_fine, raw, masks, grad_raw):
+        """The gradient of mlp_fine_backward from the saved forward (raw + ReLU masks): no forward recompute."""
+        rays_o, rays_d, viewdirs, z_fine, raw, grad_raw = (_f32c(t) for t in (rays_o, rays_d, viewdirs, z_fine, raw, grad_raw))
+        n, Nf = z_fine.shape
+        gpts = torch.empty(n, Nf, 6, device=rays_o.device)
+        check(self.lib.dfn_mlp_fine_backward_saved(self.handle, _lib.PRECISIONS["f16x3"], ptr(rays_o), ptr(rays_d), ptr(viewdirs), n,
+                                                   ptr(z_fine), Nf, ptr(raw), ctypes.c_void_p(masks.data_ptr()), ptr(grad_raw),
+                                                   ptr(gpts), current_stream()), "dfn_mlp_fine_backward_saved")
+        return gpts
+
     # ------------------------------------------------------------------ whole path
     def render_rays(self, rays_o, rays_d, hist, Nc, Ni, near, far, viewdirs=None, retraw=False, precision=None):
         """Test-time render of a ray batch -> (rgb [n,3], disp [n], acc [n], raw|None)."""
@@ -135,21 +159,29 @@ class NerfHEngine:
 
 
     # ------------------------------------------------------------------ staged render that keeps what backward needs
-    def render_rays_saving(self, rays_o, rays_d, viewdirs, hist, Nc, Ni, near, far, precision=None):
-        """render_rays composed from the stage entry points, returning (rgb, disp, acc, z_fine, raw): the state from
-        which backward_from_saved() differentiates without recomputing the forward."""
+    def render_rays_saving(self, rays_o, rays_d, viewdirs, hist, Nc, Ni, near, far, precision=None, with_masks=False):
+        """render_rays composed from the stage entry points, returning (rgb, disp, acc, z_fine, raw[, masks]): the state
+        from which backward_from_saved() differentiates without recomputing the forward.  with_masks: the fine net runs
+        in split-f16 and records its ReLU signs, so the backward needs no forward pass of its own at all."""
         rays_o, rays_d, viewdirs = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3), _f32c(viewdirs).reshape(-1, 3)
         sigma = self.mlp_coarse(rays_o, rays_d, Nc, near, far, precision)
         z = sample_fine(sigma, Ni, near, far)
+        if with_masks:
+            raw, masks = self.mlp_fine_saving(rays_o, rays_d, viewdirs, hist, z)
+            out = composite_fine(raw, z)
+            return out["rgb"], out["disp"], out["acc"], z, raw, masks
         raw = self.mlp_fine(rays_o, rays_d, viewdirs, hist, z, precision)
         out = composite_fine(raw, z)
         return out["rgb"], out["disp"], out["acc"], z, raw
 
-    def backward_from_saved(self, rays_o, rays_d, viewdirs, hist, z, raw, grad_rgb, derive_viewdirs=True, precision=None):
-        """d L/d (rays_o, rays_d[, viewdirs]) from the saved (z_fine, raw) of render_rays_saving()."""
+    def backward_from_saved(self, rays_o, rays_d, viewdirs, hist, z, raw, grad_rgb, derive_viewdirs=True, precision=None, masks=None):
+        """d L/d (rays_o, rays_d[, viewdirs]) from the saved (z_fine, raw[, masks]) of render_rays_saving()."""
         rays_o, rays_d, viewdirs = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3), _f32c(viewdirs).reshape(-1, 3)
         graw = composite_fine_backward(raw, z, _f32c(grad_rgb).reshape(-1, 3))
-        gpts = self.mlp_fine_backward(rays_o, rays_d, viewdirs, hist, z, graw, precision)
+        if masks is not None:
+            gpts = self.mlp_fine_backward_saved(rays_o, rays_d, viewdirs, z, raw, masks, graw)
+        else:
+            gpts = self.mlp_fine_backward(rays_o, rays_d, viewdirs, hist, z, graw, precision)
         n, Nf = z.shape
         go, gd = torch.empty(n, 3, device=z.device), torch.empty(n, 3, device=z.device)
         gv = None if derive_viewdirs else torch.empty(n, 3, device=z.device)

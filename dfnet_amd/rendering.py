@@ -49,6 +49,31 @@ GRAD_PRECISION = "f16x3"  # MLP gradient kernel: forward recompute AND gradient 
 # signed sum (tests/test_gpu_grad.py::test_render_autograd_drop_in: random per-pixel weights on a 12x16 image,
 # where the f16 forward's 1e-4 error is amplified to 1e-2).
 GRAD_FORWARD_PRECISION = None
+# Two-pass gradient (default with the split-f16 gradient kernel): the tracked forward runs the fine net in split-f16 and
+# records its ReLU signs (dfn_mlp_fine_saving); the backward then starts from (raw, masks) and recomputes NO forward
+# (dfn_mlp_fine_backward_saved) — the gradient kernel was half forward recompute.  The tracked render is fp32-grade as
+# a side effect.  False: the one-pass kernel (forward recompute inside the backward).
+GRAD_TWO_PASS = True
+
+
+def _two_pass():
+    return GRAD_TWO_PASS and GRAD_PRECISION == "f16x3"
+
+
+def _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far):
+    """(rgb, disp, acc, saved tensors for the backward)."""
+    if _two_pass():
+        rgb, disp, acc, z, raw, masks = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION,
+                                                             with_masks=True)
+        return rgb, disp, acc, (o, d, v, hist, z, raw, masks)
+    rgb, disp, acc, z, raw = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION)
+    return rgb, disp, acc, (o, d, v, hist, z, raw)
+
+
+def _saved_backward(eng, saved, g_rgb):
+    o, d, v, hist, z, raw = saved[:6]
+    masks = saved[6] if len(saved) > 6 else None
+    return eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION, masks=masks)
 
 
 class _RenderImageFn(torch.autograd.Function):
@@ -60,8 +85,8 @@ class _RenderImageFn(torch.autograd.Function):
     def forward(ctx, c2w, eng, H, W, focal, hist, Nc, Ni, near, far):
         from . import engine as _e
         o, d, v = _e.raygen(H, W, focal, c2w.detach())
-        rgb, disp, acc, z, raw = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION)
-        ctx.save_for_backward(o, d, v, hist, z, raw)
+        rgb, disp, acc, saved = _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far)
+        ctx.save_for_backward(*saved)
         ctx.cfg = (eng, H, W, focal)
         disp, acc = disp.reshape(H, W), acc.reshape(H, W)
         ctx.mark_non_differentiable(disp, acc)
@@ -70,9 +95,8 @@ class _RenderImageFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, _g_disp, _g_acc):
         from . import engine as _e
-        o, d, v, hist, z, raw = ctx.saved_tensors
         eng, H, W, focal = ctx.cfg
-        go, gd, _ = eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION)
+        go, gd, _ = _saved_backward(eng, ctx.saved_tensors, g_rgb)
         return (_e.raygen_backward(H, W, focal, go, gd),) + (None,) * 9
 
 
@@ -88,17 +112,16 @@ class _RenderFramesFn(torch.autograd.Function):
         rays = [_e.raygen(H, W, focal, c2ws[b].detach()) for b in range(B)]
         o, d, v = (torch.cat([r[k].reshape(-1, 3) for r in rays]) for k in range(3))
         hist = hists.reshape(B, 1, -1).expand(B, H * W, hists.shape[-1]).reshape(B * H * W, -1).contiguous()   # one row per ray
-        rgb, _, _, z, raw = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION)
-        ctx.save_for_backward(o, d, v, hist, z, raw)
+        rgb, _, _, saved = _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far)
+        ctx.save_for_backward(*saved)
         ctx.cfg = (eng, B, H, W, focal)
         return rgb.reshape(B, H, W, 3)
 
     @staticmethod
     def backward(ctx, g_rgb):
         from . import engine as _e
-        o, d, v, hist, z, raw = ctx.saved_tensors
         eng, B, H, W, focal = ctx.cfg
-        go, gd, _ = eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION)
+        go, gd, _ = _saved_backward(eng, ctx.saved_tensors, g_rgb)
         go, gd = go.reshape(B, H * W, 3), gd.reshape(B, H * W, 3)
         gc = torch.stack([_e.raygen_backward(H, W, focal, go[b].contiguous(), gd[b].contiguous()) for b in range(B)])
         return (gc,) + (None,) * 9
@@ -123,16 +146,15 @@ class _RenderRaysFn(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, eng, hist, Nc, Ni, near, far):
         o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
         v = d / torch.norm(d, dim=-1, keepdim=True)
-        rgb, disp, acc, z, raw = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION)
-        ctx.save_for_backward(o, d, v, hist, z, raw)
+        rgb, disp, acc, saved = _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far)
+        ctx.save_for_backward(*saved)
         ctx.eng = eng
         ctx.mark_non_differentiable(disp, acc)
         return rgb, disp, acc
 
     @staticmethod
     def backward(ctx, g_rgb, _g_disp, _g_acc):
-        o, d, v, hist, z, raw = ctx.saved_tensors
-        go, gd, _ = ctx.eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION)
+        go, gd, _ = _saved_backward(ctx.eng, ctx.saved_tensors, g_rgb)
         return (go, gd) + (None,) * 6
 
 

@@ -157,6 +157,19 @@ int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_o, const fl
                           const float* viewdirs, const float* hist, size_t hist_rows, size_t n_rays,
                           const float* z_fine, int Nf, const float* grad_raw, float* grad_pts,
                           void* bias_ws, void* stream);
+
+/* The same gradient in two passes, for an autograd step that runs a forward anyway (split-f16 only).
+ * dfn_mlp_fine_saving: dfn_mlp_fine in split-f16 that also records the ReLU sign of every hidden unit (masks:
+ * dfn_mlp_fine_mask_bytes(n_rays * Nf) of device memory).  dfn_mlp_fine_backward_saved: d L / d (point, viewdir) per
+ * sample from those masks and raw alone — no forward recompute (the head derivatives follow from the head outputs:
+ * sigmoid' = y (1 - y), softplus' = 1 - exp(-y)).  Same outputs as dfn_mlp_fine / dfn_mlp_fine_backward. */
+size_t dfn_mlp_fine_mask_bytes(size_t n_points);
+int dfn_mlp_fine_saving(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
+                        const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf, float* raw,
+                        void* masks, void* bias_ws, void* stream);
+int dfn_mlp_fine_backward_saved(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d,
+                                const float* viewdirs, size_t n_rays, const float* z_fine, int Nf, const float* raw,
+                                const void* masks, const float* grad_raw, float* grad_pts, void* stream);
 /* Per-ray reduction of grad_pts [n_rays, Nf, 6] (pts = o + d z, rendering.py:292,305): grad_rays_o = sum g,
  * grad_rays_d = sum z g; with derive_viewdirs != 0 the view-direction part is folded into grad_rays_d through
  * viewdirs = d/|d| (rendering.py:366-371), otherwise grad_viewdirs (optional) receives sum gv. */

@@ -562,6 +562,28 @@ def test_dfnet_s_module_training_step_vs_oracle():
     assert rel_l2(f2[0], ref2[0]) < 5e-6
 
 
+def test_mlp_two_pass_gradient_equals_one_pass(scene):
+    """dfn_mlp_fine_saving + dfn_mlp_fine_backward_saved (forward recording the ReLU masks, backward from raw + masks) vs the
+    split-f16 forward and the one-pass gradient kernel: same raw, same d L/d (point, viewdir)."""
+    E = scene[0]
+    rng = np.random.default_rng(21)
+    n, Nf = 300, 64       # 19200 points: 75 tiles, the last ray count not a multiple of anything
+    o = T(rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)).to(DEV)
+    d = T(rng.standard_normal((n, 3)).astype(np.float32)).to(DEV)
+    v = d / d.norm(dim=-1, keepdim=True)
+    hist = T(syn.HIST_IDX).to(DEV)
+    z = torch.sort(T(rng.uniform(0.05, 2.4, (n, Nf)).astype(np.float32)), -1)[0].to(DEV)
+    graw = T(rng.standard_normal((n, Nf, 9)).astype(np.float32)).to(DEV)
+    raw1 = E.mlp_fine(o, d, v, hist, z, precision="f16x3")
+    raw2, masks = E.mlp_fine_saving(o, d, v, hist, z)
+    assert relmax(raw2, raw1.cpu()) < 1e-6
+    g1 = E.mlp_fine_backward(o, d, v, hist, z, graw, precision="f16x3")
+    g2 = E.mlp_fine_backward_saved(o, d, v, z, raw2, masks, graw)
+    e = relmax(g2, g1.cpu())
+    print(f"two-pass vs one-pass MLP gradient: {e:.2e}")
+    assert e < 2e-6
+
+
 def test_render_frames_equals_per_frame_render():
     """rendering.render_frames (B frames as one ray batch, the DFNet_dm step's form) gives the frames and pose gradients of
     B separate render(c2w=...) calls."""
