@@ -48,7 +48,7 @@ GRAD_PRECISION = "f16x3"  # MLP gradient kernel: forward recompute AND gradient 
 # step.  "f32" (or "f16x3", 2.7x faster) makes the whole tracked path fp32-grade — needed only where the loss makes d c2w a badly conditioned
 # signed sum (tests/test_gpu_grad.py::test_render_autograd_drop_in: random per-pixel weights on a 12x16 image,
 # where the f16 forward's 1e-4 error is amplified to 1e-2).
-GRAD_FORWARD_PRECISION = None
+GRAD_FORWARD_PRECISION = None   # with GRAD_TWO_PASS (below) this governs the COARSE net only: the fine net is split-f16 then
 # Two-pass gradient (default with the split-f16 gradient kernel): the tracked forward runs the fine net in split-f16 and
 # records its ReLU signs (dfn_mlp_fine_saving); the backward then starts from (raw, masks) and recomputes NO forward
 # (dfn_mlp_fine_backward_saved) — the gradient kernel was half forward recompute.  The tracked render is fp32-grade as
