@@ -501,7 +501,7 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
 namespace {
 struct KernelTimer {
   bool on = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DFN_PROF_SLOTS];
 } g_prof;
 struct ScopedTimer {
   int which;
@@ -530,7 +530,7 @@ extern "C" int dfn_profile_enable(int on) {
   return DFN_OK;
 }
 extern "C" int dfn_profile_read(int which, double* avg_ms, int* launches) {
-  if (which < 0 || which > 1 || !avg_ms || !launches) return set_error(DFN_ERR_ARG, "dfn_profile_read: bad argument");
+  if (which < 0 || which >= DFN_PROF_SLOTS || !avg_ms || !launches) return set_error(DFN_ERR_ARG, "dfn_profile_read: bad argument");
   double tot = 0;
   for (auto& p : g_prof.ev[which]) {
     float ms = 0;
@@ -720,21 +720,30 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
       ScopedTimer t(0, s);
       CHECK_HIP(launch_mlp(false, prec, var, a, cus, s), "render: coarse MLP");
     }
-    CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s), "render: sample_fine");
-    CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.bias, s), "render: ray_bias");
+    {
+      ScopedTimer t(DFN_PROF_SAMPLE_FINE, s);
+      CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s), "render: sample_fine");
+    }
+    {
+      ScopedTimer t(DFN_PROF_RAY_BIAS, s);
+      CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.bias, s), "render: ray_bias");
+    }
     {
       MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, fused ? w.partial : nullptr, (long long)n, Nf, 0.f, 0.f, g_timing_buf, nf.in_scale};
       ScopedTimer t(1, s);
       CHECK_HIP(launch_mlp(true, prec, var, a, cus, s), "render: fine MLP");
     }
-    if (fused)
+    if (fused) {
+      ScopedTimer t(DFN_PROF_COMBINE, s);
       CHECK_HIP(launch_composite_combine(w.partial, n, Nf / 64, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
                                          disp + r0, acc + r0, s),
                 "render: composite combine");
-    else
+    } else {
+      ScopedTimer t(DFN_PROF_COMPOSITE, s);
       CHECK_HIP(launch_composite_fine(raw, w.z, n, Nf, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
                                       disp + r0, acc + r0, nullptr, nullptr, nullptr, s),
                 "render: composite");
+    }
   }
   return DFN_OK;
 }

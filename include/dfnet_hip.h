@@ -333,9 +333,18 @@ int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* par
 int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, int prec_mask,
                                          void* stream);
 
-/* Timing aid for bench.py: average device time in ms of the `which` kernel
- * (0 = coarse MLP, 1 = fine MLP) over the launches since the last reset, measured with HIP
- * events on `stream`.  Enabled by dfn_profile_enable(1); costs a sync when read. */
+/* Timing aid for bench.py: average device time in ms of the `which` kernel of the render path
+ * (DFN_PROF_*) over the launches since the last reset, measured with HIP events recorded on the
+ * launch `stream` around each launch.  Enabled by dfn_profile_enable(1); costs a sync when read. */
+enum {
+  DFN_PROF_COARSE = 0,      /* nerfh_coarse_kernel */
+  DFN_PROF_FINE = 1,        /* nerfh_fine_kernel */
+  DFN_PROF_SAMPLE_FINE = 2, /* sample_fine_kernel (coarse weights + sample_pdf + merge) */
+  DFN_PROF_RAY_BIAS = 3,    /* ray_bias_kernel */
+  DFN_PROF_COMBINE = 4,     /* composite_combine_kernel (fused-compositing path) */
+  DFN_PROF_COMPOSITE = 5,   /* composite_fine_kernel (raw path) */
+  DFN_PROF_SLOTS = 6
+};
 int dfn_profile_enable(int on);
 int dfn_profile_read(int which, double* avg_ms, int* launches);
 

@@ -40,10 +40,16 @@ def main(argv=None):
     train_dl, val_dl, test_dl, hwf, i_split, near, far = load_dataloader(args)
     Net = DFNet_s if args.DFNet_s else DFNet
     model, feat_model = Net().eval(), Net().eval()
-    if args.pretrain_model_path:
-        model.load_state_dict(torch.load(args.pretrain_model_path, map_location="cpu"))
+    # train.py:108-121 of the reference: a pretrained DFNet is REQUIRED for the pose estimator; the feature extractor uses
+    # --pretrain_featurenet_path, or the same DFNet when that is empty.  (Random features would train silently.)
+    if not args.pretrain_model_path:
+        raise SystemExit("train.py: --pretrain_model_path is required (a DFNet checkpoint from run_feature.py)")
+    model.load_state_dict(torch.load(args.pretrain_model_path, map_location="cpu"))
     if args.pretrain_featurenet_path:
         feat_model.load_state_dict(torch.load(args.pretrain_featurenet_path, map_location="cpu"))
+    else:
+        print('Use the same DFNet for Feature Extraction and Pose Regression')
+        feat_model.load_state_dict(torch.load(args.pretrain_model_path, map_location="cpu"))
     _, render_kwargs_test, start, _, _ = create_nerf(args)
     render_kwargs_test.update({'near': near, 'far': far})
     setup = {k: getattr(train_dl.dataset, k) for k in ('pose_scale', 'pose_scale2', 'move_all_cam_vec')}
@@ -59,6 +65,8 @@ def main(argv=None):
             train_dl = torch.utils.data.DataLoader(train_dl.dataset, batch_size=args.batch_size, sampler=sampler)
         n_epoch = int(os.environ.get("DFNET_DM_EPOCHS", 2001))   # the reference hard-codes 2001 (:436) and relies on early stopping
         for epoch in range(n_epoch):
+            if world > 1:
+                sampler.set_epoch(epoch)   # a fresh permutation per epoch, the same on every rank
             loss, psnr = train_on_epoch(args, [train_dl, val_dl, test_dl], model, feat_model, hwf, optimizer, True, device,
                                         setup, **render_kwargs_test)
             if rank == 0:

@@ -103,6 +103,16 @@ def test_train_dm_cli(tmp_path):
     cli = ["--config", os.path.join(ROOT, "script", "config_dfnetdm.txt"), "--datadir", datadir, "--basedir", basedir,
            "--N_samples", "16", "--N_importance", "32", "--df", "2", "--trainskip", "1", "--testskip", "1",
            "--learning_rate", "1e-6", "--i_eval", "1"]
+    import torch
+    from dfnet_amd import synthetic as syn
+    pre = str(tmp_path / "dfnet_pretrained.pt")   # the reference requires a pretrained DFNet (train.py:108)
+    ck0 = {k: torch.from_numpy(v) for k, v in syn.dfnet_weights(3).items()}
+    ck0.update({f"adaptation_layers.adapt_layer_{i}.3.num_batches_tracked": torch.tensor(0) for i in range(3)})
+    torch.save(ck0, pre)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "train.py")] + cli, cwd=str(tmp_path),
+                       env=dict(os.environ, DFNET_DM_EPOCHS="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "pretrain_model_path is required" in (r.stdout + r.stderr)
+    cli += ["--pretrain_model_path", pre]
     env = dict(os.environ, DFNET_DM_EPOCHS="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "train.py")] + cli, cwd=str(tmp_path), env=env,
                        capture_output=True, text=True, timeout=900)

@@ -304,3 +304,25 @@ def test_cambridge_front_end(tmp_path):
     f = options.feature_parser().parse_args(["--datadir", datadir, "--dataset_type", "Cambridge", "--df", "2", "--pose_only", "1"])
     tr, va, te, hwf2, _, near, far = datasets.load_Cambridge_dataloader(f)
     assert hwf2 == hwf and (near, far) == (0.0, 10.0) and tr.dataset.pose_scale == 0.3 and len(te) == 3
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_entry_point_two_ranks_gloo(launcher):
+    """`python bench.py --gpus 2` must start its own two ranks (the form the driver uses on an 8-GPU node), and must also
+    run under an external torch.distributed.run.  --cpu-dry swaps the HIP render for a frame fill so the launch,
+    frame sharding, gather, barrier / max-over-ranks timing and the JSON line are exercised here over gloo."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    tail = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-dry", "--backend", "gloo"]
+    if launcher == "self":
+        cmd = [sys.executable, bench] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29541", bench] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["frames_gathered_in_order"] is True and rec["value"] > 0
