@@ -276,6 +276,114 @@ def render(H, W, focal, chunk, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, im
     return [cat[k].reshape(*sh[:-1], *cat[k].shape[1:]) for k in ("rgb_map", "disp_map", "acc_map")]
 
 
+# --------------------------------------------------------------------------- training mode
+def query_coarse_static(p, pts, viewdirs, L_xyz=10, L_dir=4, netchunk=65536):
+    """run_network_NeRFW, typ='coarse', training (models/nerfw.py:47-60): xyz + direction encodings into the
+    `output_transient=False` branch -> [R,N,4] = [rgb_s(3), sigma_s]."""
+    R, N = pts.shape[:2]
+    flat = pts.reshape(-1, 3)
+    dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)
+    out = []
+    for i in range(0, flat.shape[0], netchunk):
+        sl = slice(i, i + netchunk)
+        out.append(nerfh_static(p, posenc(flat[sl], L_xyz), posenc(dirs[sl], L_dir)))
+    return torch.cat(out, 0).reshape(R, N, 4)
+
+
+def composite_coarse_train(raw4, z, noise=None, white_bkgd=False):
+    """raw2outputs_NeRFW, typ='coarse', test_time=False, output_transient=False (models/rendering.py:150-193,231-243;
+    quirk Q1: render_rays passes white_bkgd into the output_transient slot, False here): alpha = 1-exp(-delta*relu(sigma
+    + noise)), rgb = sum w c, depth = sum w z, disp = 1/max(1e-10, depth / sum w).  `noise` = randn * raw_noise_std."""
+    rgb_s, sig = raw4[..., :3], raw4[..., 3]
+    s = sig if noise is None else sig + noise
+    alpha = 1 - torch.exp(-_deltas(z) * torch.relu(s))
+    w = alpha * _excl_cumprod(1 - alpha)
+    acc = w.sum(-1)
+    rgb = (w[..., None] * rgb_s).sum(-2)
+    if white_bkgd:
+        rgb = rgb + (1 - acc[:, None])
+    depth = (w * z).sum(-1)
+    disp = 1. / torch.max(1e-10 * torch.ones_like(depth), depth / w.sum(-1))
+    return dict(rgb=rgb, disp=disp, acc=acc, weights=w, depth=depth)
+
+
+def stratified_z(z, t_rand):
+    """Stratified jitter of the coarse depths (models/rendering.py:277-285): one draw per interval between midpoints."""
+    mids = .5 * (z[..., 1:] + z[..., :-1])
+    upper = torch.cat([mids, z[..., -1:]], -1)
+    lower = torch.cat([z[..., :1], mids], -1)
+    return lower + (upper - lower) * t_rand
+
+
+def render_rays_train(rows, coarse, fine, emb_a, emb_t, Nc, Ni, t_rand=None, noise=None, u=None, perturb=1.,
+                      raw_noise_std=0., netchunk=65536, stages=None):
+    """Training-mode render of packed ray rows (models/rendering.py:245-337 with test_time=False, lindisp=False,
+    white_bkgd=False).  The three random draws of the reference are inputs so that results are reproducible:
+    t_rand [R,Nc] = torch.rand (stratified jitter, only if perturb > 0), noise [R,Nc] = torch.randn (x raw_noise_std,
+    coarse alpha only), u [R,Ni] = torch.rand (importance sampling, only if perturb > 0; linspace otherwise).  Returns the
+    reference's dict: rgb_map, disp_map, acc_map, raw, rgb0, disp0, acc0, z_std, transient_sigmas, beta."""
+    o, d = rows[:, 0:3], rows[:, 3:6]
+    near, far = rows[:, 6:7], rows[:, 7:8]
+    view, hist = rows[:, 8:11], rows[:, 11:]
+    R = rows.shape[0]
+    z = coarse_z(near, far, Nc, R)
+    if perturb > 0.:
+        if t_rand is None:
+            t_rand = torch.rand(R, Nc)
+        z = stratified_z(z, t_rand)
+    pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    raw_c = query_coarse_static(coarse, pts, view, netchunk=netchunk)
+    if noise is None:
+        noise = torch.randn(R, Nc)   # the reference draws even when raw_noise_std = 0 (quirk Q4)
+    c = composite_coarse_train(raw_c, z, noise * raw_noise_std)
+    mid = .5 * (z[:, 1:] + z[:, :-1])
+    if perturb > 0. and u is None:
+        u = torch.rand(R, Ni)
+    zs = sample_pdf(mid, c["weights"][:, 1:-1], Ni, det=(perturb == 0.), u=u if perturb > 0. else None).detach()
+    zf, _ = torch.sort(torch.cat([z, zs], -1), -1)
+    pts_f = o[:, None, :] + d[:, None, :] * zf[..., None]
+    raw = query_fine(fine, emb_a, emb_t, pts_f, view, hist, netchunk=netchunk)
+    f = composite_fine(raw, zf, test_time=False)
+    if stages is not None:
+        stages.update(z_coarse=z, raw_coarse=raw_c, weights_coarse=c["weights"], z_samples=zs, z_fine=zf, raw=raw,
+                      weights_fine=f["weights"], depth_fine=f["depth"])
+    return dict(rgb_map=f["rgb"], disp_map=f["disp"], acc_map=f["acc"], raw=raw, rgb0=c["rgb"], disp0=c["disp"], acc0=c["acc"],
+                z_std=torch.std(zs, dim=-1, unbiased=False), transient_sigmas=f["transient_sigmas"], beta=f["beta"])
+
+
+def nerfw_loss(results, targets, coef=1., lambda_u=0.01):
+    """NerfWLoss (models/losses.py:19-57): c_l coarse colour, f_l fine colour weighted by 1/(2 beta^2), b_l = 3 + mean log
+    beta, s_l = lambda_u * mean transient sigma.  `results` keys as run_nerf.py:54-58."""
+    ret = {'c_l': 0.5 * ((results['rgb_coarse'] - targets) ** 2).mean(),
+           'f_l': ((results['rgb_fine'] - targets) ** 2 / (2 * results['beta'].unsqueeze(1) ** 2)).mean(),
+           'b_l': 3 + torch.log(results['beta']).mean(),
+           's_l': lambda_u * results['transient_sigmas'].mean()}
+    return {k: coef * v for k, v in ret.items()}
+
+
+def train_step(rows, target, coarse, fine, emb_a, emb_t, Nc, Ni, t_rand, noise, u, perturb=1., raw_noise_std=0.):
+    """One optimisation step's forward + backward (run_nerf.py:50-66): render(retraw=True, **render_kwargs_train) ->
+    NerfWLoss -> sum -> backward.  Returns (loss dict, psnr, {name: gradient}) with names 'coarse.<key>', 'fine.<key>',
+    'embedding_a.weight', 'embedding_t.weight'; parameters the loss does not reach are absent (None in torch)."""
+    P = {"coarse." + k: v.detach().clone().requires_grad_(True) for k, v in coarse.items()}
+    P.update({"fine." + k: v.detach().clone().requires_grad_(True) for k, v in fine.items()})
+    P["embedding_a.weight"] = emb_a.detach().clone().requires_grad_(True)
+    P["embedding_t.weight"] = emb_t.detach().clone().requires_grad_(True)
+    c = {k[7:]: v for k, v in P.items() if k.startswith("coarse.")}
+    f = {k[5:]: v for k, v in P.items() if k.startswith("fine.")}
+    out = render_rays_train(rows, c, f, P["embedding_a.weight"], P["embedding_t.weight"], Nc, Ni, t_rand, noise, u, perturb,
+                            raw_noise_std)
+    ld = nerfw_loss({'rgb_fine': out['rgb_map'], 'rgb_coarse': out['rgb0'], 'beta': out['beta'],
+                     'transient_sigmas': out['transient_sigmas']}, target)
+    loss = sum(ld.values())
+    loss.backward()
+    with torch.no_grad():
+        mse = ((out['rgb_map'] - target) ** 2).mean()
+        ps = -10. * torch.log(mse) / math.log(10.)
+    return {k: v.detach() for k, v in ld.items()}, ps, {k: v.grad for k, v in P.items() if v.grad is not None}, \
+        {k: v.detach() for k, v in out.items()}
+
+
 def render_grad_rays(rays_o, rays_d, G, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx):
     """d sum(rgb * G) / d (rays_o, rays_d) by autograd through render(rays=...) — viewdirs are derived from
     rays_d inside render (rendering.py:366-371), so their normalisation is part of the gradient."""

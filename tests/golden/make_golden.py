@@ -237,6 +237,87 @@ def main():
     save("g9_render_grad_c2w", H=H, W=Wd, focal=focal, c2w=pose, near=0., far=2.5, hist=hist, Nc=64, Ni=128, G=G,
          rgb=rgb, grad_c2w=pose.grad)
 
+    # ---------------- G12: training-mode render_rays (perturb=1, test_time=False; rendering.py:276-331) and
+    # ---------------- G13: one NeRF-H optimisation step (run_nerf.py:50-66: render -> NerfWLoss -> backward).
+    # The reference draws t_rand = torch.rand (stratified jitter), noise = torch.randn_like (coarse alpha) and
+    # u = torch.rand (importance sampling) inside render_rays; the draws are RECORDED here (wrappers around torch.rand /
+    # torch.randn_like while the reference runs) and stored, so the oracle and the HIP path take them as inputs.
+    from models import losses as ref_losses
+    r12 = np.random.default_rng(1212)
+
+    class Recorder:
+        def __enter__(self):
+            self.rec, self.o_rand, self.o_randn = [], torch.rand, torch.randn_like
+            def rand(*a, **k):
+                r = self.o_rand(*a, **k)
+                self.rec.append(("rand", r.clone()))
+                return r
+            def randn_like(*a, **k):
+                r = self.o_randn(*a, **k)
+                self.rec.append(("randn", r.clone()))
+                return r
+            torch.rand, torch.randn_like = rand, randn_like
+            return self
+
+        def __exit__(self, *exc):
+            torch.rand, torch.randn_like = self.o_rand, self.o_randn
+
+    def train_kwargs(Nc, Ni, noise_std):
+        kw = kwargs_for(128, Nc, Ni)
+        kw.update(perturb=1., raw_noise_std=noise_std, test_time=False)
+        return kw
+
+    def digest(flat):
+        flat = flat.reshape(-1)
+        return flat.norm(), flat[:: max(1, flat.numel() // 256)][:256].clone()
+
+    for tag, R, Nc, Ni, noise_std in (("a", 40, 16, 32, 0.), ("b", 24, 64, 128, 1.)):
+        c2w = syn.orbit_pose(2, 8)[:3, :4]
+        ro, rd = ray_utils.get_rays(480, 640, 585.0, t(c2w))
+        sel = r12.choice(480 * 640, R, replace=False)
+        rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        target = t(r12.uniform(0, 1, (R, 3)).astype(np.float32))
+        coarse, fine, emb_a, emb_t = nets[128]
+        for m in (coarse, fine, emb_a, emb_t):
+            m.zero_grad()
+            m.train()
+        torch.manual_seed(100 + R)
+        with Recorder() as rc:
+            rgb, disp, acc, extras = rendering.render(480, 640, 585.0, chunk=32768, rays=rays, near=0., far=2.5,
+                                                       img_idx=t(hist)[None], retraw=True, **train_kwargs(Nc, Ni, noise_std))
+        kinds = [k for k, _ in rc.rec]
+        assert kinds == ["rand", "randn", "rand"], kinds   # t_rand, coarse noise, u — in this order
+        t_rand, noise, u = (r for _, r in rc.rec)
+        assert t_rand.shape == (R, Nc) and noise.shape == (R, Nc) and u.shape == (R, Ni)
+        assert sorted(extras) == sorted(["raw", "rgb0", "disp0", "acc0", "z_std", "transient_sigmas", "beta"])
+        save(f"g12_render_train_{tag}", Nc=Nc, Ni=Ni, near=0., far=2.5, hist=hist, raw_noise_std=noise_std, rays_o=rays[0],
+             rays_d=rays[1], t_rand=t_rand, noise=noise, u=u, rgb=rgb, disp=disp, acc=acc,
+             **{k: v for k, v in extras.items()})
+        # the step: results dict as run_nerf.py:54-58, NerfWLoss(coef=1), loss = sum, backward
+        loss_d = ref_losses.loss_dict['nerfw'](coef=1)({'rgb_fine': rgb, 'rgb_coarse': extras['rgb0'], 'beta': extras['beta'],
+                                                        'transient_sigmas': extras['transient_sigmas']}, target)
+        loss = sum(l for l in loss_d.values())
+        with torch.no_grad():
+            psnr = nerfw.mse2psnr(nerfw.img2mse(rgb, target))
+        loss.backward()
+        out = {"target": target, "psnr": psnr, "loss": loss.detach()}
+        out.update({"loss_" + k: v.detach() for k, v in loss_d.items()})
+        none_grads = []
+        for pre, mod in (("coarse.", coarse), ("fine.", fine), ("embedding_a.", emb_a), ("embedding_t.", emb_t)):
+            for k, q in mod.named_parameters():
+                if q.grad is None:
+                    none_grads.append(pre + k)
+                    continue
+                out["gn:" + pre + k], out["gs:" + pre + k] = digest(q.grad)
+        out["emb_rows"] = np.unique(hist.astype(np.int64))
+        out["ga_rows"] = emb_a.weight.grad[t(out["emb_rows"])]
+        out["gt_rows"] = emb_t.weight.grad[t(out["emb_rows"])]
+        assert none_grads == [], none_grads   # every parameter of both nets and both tables is reached by the loss
+        save(f"g13_train_step_{tag}", **out)
+        for m in (coarse, fine, emb_a, emb_t):
+            m.zero_grad()
+            m.eval()
+
     # ---------------- G8: DFNet forward (reference feature/dfnet.py on a restated VGG16 stack)
     _install_vgg_stub()
     from feature import dfnet as ref_dfnet

@@ -61,6 +61,44 @@ def test_run_nerf_render_test_cli(tmp_path):
             assert int(np.abs(gt.astype(int) - (255 * img[0].permute(1, 2, 0).cpu().numpy()).astype(np.uint8).astype(int)).max()) == 0
 
 
+def test_run_nerf_reloads_reference_checkpoint(tmp_path):
+    """create_nerf's reload branch (models/nerfw.py:452-472): a `000100.tar` in the reference's format (run_nerf.py:150-158
+    keys) with seeded NON-default weights is found under basedir/expname, `start` becomes its global_step (output folder
+    evaluate_*_000100) and frame 0 is the oracle's render with the checkpoint's weights — not the random initialisation."""
+    from PIL import Image
+    from dfnet_amd import datasets, options, synthetic as syn
+    datadir = make_scene(str(tmp_path), n_train=1, n_val=1, H=240, W=320)
+    basedir = str(tmp_path / "logs")
+    os.makedirs(os.path.join(basedir, "nerfh"))
+    cw, fw, ea, et = syn.nerfh_weights(5)
+    T = torch.from_numpy
+    torch.save({'global_step': 100,
+                'network_fn_state_dict': {k: T(v) for k, v in cw.items()},
+                'network_fine_state_dict': {k: T(v) for k, v in fw.items()},
+                'embedding_a_state_dict': {'weight': T(ea)}, 'embedding_t_state_dict': {'weight': T(et)},
+                'optimizer_state_dict': {}}, os.path.join(basedir, "nerfh", "000100.tar"))
+    cli = ["--config", os.path.join(ROOT, "script", "config_nerfh.txt"), "--render_test", "--datadir", datadir,
+           "--basedir", basedir, "--N_samples", "16", "--N_importance", "32", "--testskip", "1", "--trainskip", "1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "run_nerf.py")] + cli, cwd=os.path.join(ROOT, "script"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Reloading from" in r.stdout and "000100.tar" in r.stdout
+    d = os.path.join(basedir, "nerfh", "evaluate_train_test_000100")
+    assert os.path.isdir(d), os.listdir(os.path.join(basedir, "nerfh"))
+    args = options.nerf_parser().parse_args(cli)
+    train_dl, _, hwf, _, bds, _, _ = datasets.load_7Scenes_dataloader_NeRF(args)
+    img, pose, hist = next(iter(train_dl))
+    c2w = torch.eye(4)
+    c2w[:3, :4] = pose.reshape(3, 4)
+    with torch.no_grad():
+        rgb, _, _ = orc.render(hwf[0], hwf[1], hwf[2], 32768, {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()},
+                               T(ea), T(et), 16, 32, float(bds[0]), float(bds[1]), hist[0].cpu().numpy(), c2w=c2w)
+    want = (255 * np.clip(rgb.numpy(), 0, 1)).astype(np.uint8)
+    got = np.asarray(Image.open(os.path.join(d, "000.png")))
+    assert got.shape == want.shape
+    assert int(np.abs(got.astype(int) - want.astype(int)).max()) <= 1
+
+
 def test_run_feature_render_feature_only_cli(tmp_path):
     """run_feature.py --render_feature_only on the synthetic tree: NeRF-H quarter-res renders + bicubic x4,
     siamese DFNet forward, feature PNGs written."""

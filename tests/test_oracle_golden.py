@@ -204,3 +204,46 @@ def test_g11_triplet_losses(gold):
             close(loss.detach(), g[f"c{case}_m{mining}_loss"], 1e-6, 1e-7)
             close(f1.grad, g[f"c{case}_m{mining}_g1"], 1e-5, 1e-8)
             close(f2.grad, g[f"c{case}_m{mining}_g2"], 1e-5, 1e-8)
+
+
+def _train_rows(g):
+    o, d = T(g["rays_o"]), T(g["rays_d"])
+    return orc.pack_ray_rows(o, d, float(g["near"]), float(g["far"]), g["hist"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g12_render_rays_training_mode(gold, tag):
+    """Training-mode render_rays (perturb = 1, test_time = False, raw_noise_std 0 / 1): the reference's own outputs and
+    extras with its recorded random draws as inputs."""
+    g = gold(f"g12_render_train_{tag}")
+    c, f, ea, et = nets(128)
+    with torch.no_grad():
+        out = orc.render_rays_train(_train_rows(g), c, f, ea, et, int(g["Nc"]), int(g["Ni"]), T(g["t_rand"]), T(g["noise"]),
+                                    T(g["u"]), perturb=1., raw_noise_std=float(g["raw_noise_std"]))
+    for k_ref, k in (("rgb", "rgb_map"), ("disp", "disp_map"), ("acc", "acc_map"), ("raw", "raw"), ("rgb0", "rgb0"),
+                     ("disp0", "disp0"), ("acc0", "acc0"), ("z_std", "z_std"), ("transient_sigmas", "transient_sigmas"),
+                     ("beta", "beta")):
+        close(out[k], g[k_ref], 2e-5, 2e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g13_training_step(gold, tag):
+    """One optimisation step (run_nerf.py:50-66): NerfWLoss terms, PSNR and the gradient of every parameter of both
+    networks and both embedding tables (norm + 256 strided samples each, the touched embedding rows in full)."""
+    g12, g = gold(f"g12_render_train_{tag}"), gold(f"g13_train_step_{tag}")
+    c, f, ea, et = nets(128)
+    ld, ps, grads, _ = orc.train_step(_train_rows(g12), T(g["target"]), c, f, ea, et, int(g12["Nc"]), int(g12["Ni"]), T(g12["t_rand"]),
+                                      T(g12["noise"]), T(g12["u"]), perturb=1., raw_noise_std=float(g12["raw_noise_std"]))
+    for k in ("c_l", "f_l", "b_l", "s_l"):
+        close(ld[k], g["loss_" + k], 2e-5, 1e-7)
+    close(ps, g["psnr"][0], 1e-5, 1e-5)
+    names = [k[3:] for k in g if k.startswith("gn:")]
+    assert sorted(names) == sorted(grads), set(names) ^ set(grads)
+    for k in names:
+        flat = grads[k].reshape(-1)
+        gn = float(g["gn:" + k])
+        assert abs(float(flat.norm()) - gn) <= 1e-4 * gn + 1e-12, k
+        close(flat[:: max(1, flat.numel() // 256)][:256], g["gs:" + k], 0, 2e-4 * gn / np.sqrt(flat.numel()) + 1e-9)
+    rows = T(g["emb_rows"])
+    close(grads["embedding_a.weight"][rows], g["ga_rows"], 1e-4, 1e-8)
+    close(grads["embedding_t.weight"][rows], g["gt_rows"], 1e-4, 1e-8)

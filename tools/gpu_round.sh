@@ -1,20 +1,24 @@
 #!/bin/bash
 # One GPU-box pass: parity tests, smoke, bench, rocprof kernel stats, PMC passes.  Outputs under gpurun_out/.
+# usage: tools/gpu_round.sh TAG [notest] [nopmc]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd $R
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-tail -4 gpurun_out/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.json
+if [[ " $* " != *" notest "* ]]; then
+  timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+  tail -6 gpurun_out/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+fi
+timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-3000 gpurun_out/bench.json; tail -3 gpurun_out/bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o $TAG -- python $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o $TAG -- python $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-extras > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err; echo "rocprof rc=$?"
 head -9 $R/gpurun_out/prof/${TAG}_kernel_stats.csv | cut -c1-160
+if [[ " $* " != *" nopmc "* ]]; then
 mkdir -p $R/gpurun_out/pmc
-CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0"
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-extras"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
@@ -36,3 +40,4 @@ json.dump(out, open("$R/gpurun_out/pmc/summary.json", "w"), indent=1)
 for k, d in out.items():
     if "nerfh" in k or "composite" in k or "sample" in k: print(k, {c: (f"{v:.4g}" if isinstance(v, float) else v) for c, v in d.items()})
 PY
+fi
