@@ -251,7 +251,7 @@ def secondary_dfnet(dev):
     x1 = torch.rand(1, 3, 480, 640, generator=torch.Generator().manual_seed(7))
     with torch.no_grad():
         t0 = time.perf_counter()
-        ref = dor.dfnet_forward({k: torch.from_numpy(v) for k, v in w.items()}, x1, True, True, False, 480, 640)[0]
+        ref = dor.dfnet_forward({k: torch.from_numpy(v) for k, v in w.items()}, x1, True, True, False, 480, 640)[0][0]
         cpu_s = time.perf_counter() - t0
     for prec in ("f16x3", "f16", "f32"):
         got = E.forward(x1.to(dev), True, True, False, 480, 640, precision=prec)[0].cpu()
@@ -464,6 +464,8 @@ def main():
                     precs[prec]["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], prec, dev)
             line["precisions"] = precs
             sec = {}
+            if args.cpu_sample > 0:
+                torch.set_num_threads(int(line["cpu_baseline"]["cores"]))   # the oracle legs below: the fastest thread count found
             for name, fn in (("dfnet_forward_c4", secondary_dfnet), ("dfnet_dm_step_c5", secondary_dm_step)):
                 try:
                     sec[name] = fn(dev) if args.cpu_sample > 0 else {"skipped": "--cpu-sample 0"}

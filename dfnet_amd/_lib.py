@@ -85,6 +85,21 @@ SIGNATURES = {
     "dfn_triplet_loss_backward": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P, c_size_t, _P]),
     "dfn_dfnet_refresh_train_params_device": (c_int, [_P, POINTER(c_void_p), c_int, c_int, _P]),
     "dfn_dfnet_refresh_pose_params_device": (c_int, [_P, POINTER(c_void_p), c_int, c_int, _P]),
+    "dfn_nerfh_train_param_count": (c_int, []),
+    "dfn_nerfh_train_param_name": (c_char_p, [c_int]),
+    "dfn_nerfh_train_workspace_bytes": (c_size_t, [_P, c_size_t, c_int, c_int]),
+    "dfn_nerfh_train_forward": (c_int, [_P, POINTER(c_void_p), _P, _P, _P, c_size_t, c_size_t, c_int, c_int, c_float, c_float,
+                                        _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "dfn_nerfw_loss": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
+    "dfn_nerfh_train_backward": (c_int, [_P, POINTER(c_void_p), _P, c_size_t, c_size_t, c_int, c_int, _P, c_float, _P, _P, _P, _P,
+                                         c_float, _P, POINTER(c_void_p), _P, c_size_t, _P]),
+    "dfn_nerfh_generic_workspace_bytes": (c_size_t, [_P, c_size_t, c_int, c_int]),
+    "dfn_nerfh_generic_render_rays": (c_int, [_P, _P, _P, _P, c_size_t, c_size_t, c_int, c_int, c_float, c_float, _P, _P, _P, _P,
+                                              _P, c_size_t, _P]),
+    "dfn_linear_forward": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, c_int, _P]),
+    "dfn_linear_backward_input": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, _P]),
+    "dfn_linear_backward_weight_scratch_bytes": (c_size_t, [c_int, c_int, c_size_t]),
+    "dfn_linear_backward_weight": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "dfn_profile_enable": (c_int, [c_int]),
     "dfn_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
 }

@@ -15,6 +15,7 @@
 
 #include "../../include/dfnet_hip.h"
 #include "dfn_common.h"
+#include "nerfh_handle.h"
 #include "nerfh_kernels.h"
 #include "nerfh_layout.h"
 
@@ -45,26 +46,7 @@ int device_cu_count() {
 extern "C" const char* dfn_last_error(void) { return g_err; }
 extern "C" int dfn_abi_version(void) { return 1; }
 
-// ------------------------------------------------------------------------------------------ handle
-struct PackedNet {
-  char* blob = nullptr;
-  uint32_t* tab = nullptr;
-  int n_units = 0;
-  int n_fwd_units = 0;   // gradient nets: the forward units come first in the table
-  float in_scale = 1.f;  // split-f16: weight scale x activation scale carried by the accumulators
-};
-
-struct dfn_nerfh_s {
-  dfn_nerfh_desc desc;
-  std::map<std::string, std::vector<float>> params;
-  bool committed = false;
-  PackedNet net[2][3][kVariants];  // [coarse/fine][prec][kernel variant]
-  PackedNet bwd[3];                // [prec] fine forward units + backward (W^T) units of the gradient kernel
-                                   // (prec 2: split-f16 forward and backward units)
-  float* extra = nullptr;  // w_dir^T | b_dir | w_tr^T | b_tr | emb_a | emb_t
-  RayBiasWeights rb{};
-};
-
+// ------------------------------------------------------------------------------------------ handle (nerfh_handle.h)
 static std::map<std::string, std::vector<size_t>> expected_shapes(const dfn_nerfh_desc& d) {
   std::map<std::string, std::vector<size_t>> m;
   const size_t W = d.width, na = size_t(d.hist_bin) * d.dim_a, nt = size_t(d.hist_bin) * d.dim_t;
@@ -104,11 +86,14 @@ static std::map<std::string, std::vector<size_t>> expected_shapes(const dfn_nerf
 
 extern "C" int dfn_nerfh_create(const dfn_nerfh_desc* desc, dfn_nerfh_t* out) {
   if (!desc || !out) return set_error(DFN_ERR_ARG, "dfn_nerfh_create: null argument");
-  if (desc->depth != 8 || desc->width != kWidth || desc->multires != kLxyz || desc->multires_views != kLdir)
+  if (desc->depth != 8 || desc->multires != kLxyz || desc->multires_views != kLdir)
     return set_error(DFN_ERR_UNSUPPORTED,
-                     "dfn_nerfh_create: kernels are specialised for netdepth=8 netwidth=%d multires=%d "
-                     "multires_views=%d (got %d/%d/%d/%d)",
-                     kWidth, kLxyz, kLdir, desc->depth, desc->width, desc->multires, desc->multires_views);
+                     "dfn_nerfh_create: kernels are specialised for netdepth=8 multires=%d multires_views=%d (got %d/%d/%d)",
+                     kLxyz, kLdir, desc->depth, desc->multires, desc->multires_views);
+  // netwidth: %d runs on the register-resident MFMA kernels; any other even width runs on the generic layer-by-layer
+  // fp32-MFMA path (nerfh_train_api.hip), which is also the training path.
+  if (desc->width < 2 || desc->width > 1024 || (desc->width & 1))
+    return set_error(DFN_ERR_UNSUPPORTED, "dfn_nerfh_create: netwidth must be even and in [2, 1024] (got %d)", desc->width);
   if (desc->hist_bin <= 0 || desc->dim_a <= 0 || desc->dim_t <= 0 || desc->n_vocab <= 0 ||
       desc->hist_bin * (desc->dim_a + desc->dim_t) > 1024)
     return set_error(DFN_ERR_ARG, "dfn_nerfh_create: bad embedding geometry");
@@ -133,6 +118,10 @@ static void free_packed(dfn_nerfh_s* h) {
   }
   if (h->extra) (void)hipFree(h->extra);
   h->extra = nullptr;
+  if (h->gen_blob) (void)hipFree(h->gen_blob);
+  h->gen_blob = nullptr;
+  h->gen_params.clear();
+  h->fast = false;
 }
 
 extern "C" int dfn_nerfh_destroy(dfn_nerfh_t h) {
@@ -413,6 +402,24 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
   for (const auto& kv : expected_shapes(h->desc))
     if (!h->params.count(kv.first)) return set_error(DFN_ERR_STATE, "dfn_nerfh_commit: parameter '%s' not set", kv.first.c_str());
   free_packed(h);
+  {  // generic-width path: plain device copies in canonical order
+    std::vector<float> all;
+    std::vector<size_t> offs;
+    const int np = dfn_nerfh_train_param_count();
+    for (int i = 0; i < np; ++i) {
+      const auto& v = h->params.at(dfn_nerfh_train_param_name(i));
+      offs.push_back(all.size());
+      all.insert(all.end(), v.begin(), v.end());
+      all.resize((all.size() + 3) & ~size_t(3));
+    }
+    int rc = upload(all.data(), all.size() * 4, reinterpret_cast<void**>(&h->gen_blob));
+    if (rc) return rc;
+    for (size_t o : offs) h->gen_params.push_back(h->gen_blob + o);
+  }
+  if (h->desc.width != kWidth) {
+    h->committed = true;
+    return DFN_OK;
+  }
   for (int f = 0; f < 2; ++f)
     for (int prec = 0; prec < 3; ++prec)
       for (int var = 0; var < kVariants; ++var) {
@@ -494,6 +501,7 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
   h->rb.dim_t = d.dim_t;
   h->rb.n_vocab = d.n_vocab;
   h->committed = true;
+  h->fast = true;
   return DFN_OK;
 }
 
@@ -554,6 +562,9 @@ extern "C" int dfn_profile_read(int which, double* avg_ms, int* launches) {
 static int check_net(dfn_nerfh_t h, int prec, const char* fn, bool allow_x3 = false) {
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_nerfh_commit() has not been called", fn);
+  if (!h->fast)
+    return set_error(DFN_ERR_UNSUPPORTED, "%s: the register-resident kernels are specialised for netwidth %d (this handle: %d); "
+                     "use the generic-width entry points (dfn_nerfh_generic_*)", fn, kWidth, h->desc.width);
   if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && !(allow_x3 && prec == DFN_PREC_F16X3))
     return set_error(DFN_ERR_ARG, "%s: unknown / unsupported precision %d", fn, prec);
   return DFN_OK;

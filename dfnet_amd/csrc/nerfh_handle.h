@@ -1,0 +1,35 @@
+// nerfh_handle.h — the NeRF-H handle behind dfn_nerfh_t, shared by nerfh_api.hip (test-time render path) and
+// nerfh_train_api.hip (training path, generic-width path).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dfnet_hip.h"
+#include "nerfh_kernels.h"
+#include "nerfh_layout.h"
+
+struct PackedNet {
+  char* blob = nullptr;
+  uint32_t* tab = nullptr;
+  int n_units = 0;
+  int n_fwd_units = 0;   // gradient nets: the forward units come first in the table
+  float in_scale = 1.f;  // split-f16: weight scale x activation scale carried by the accumulators
+};
+
+struct dfn_nerfh_s {
+  dfn_nerfh_desc desc;
+  std::map<std::string, std::vector<float>> params;
+  bool committed = false;
+  PackedNet net[2][3][dfn::kVariants];  // [coarse/fine][prec][kernel variant]
+  PackedNet bwd[3];                // [prec] fine forward units + backward (W^T) units of the gradient kernel
+                                   // (prec 2: split-f16 forward and backward units)
+  float* extra = nullptr;  // w_dir^T | b_dir | w_tr^T | b_tr | emb_a | emb_t
+  dfn::RayBiasWeights rb{};
+  bool fast = false;       // the register-resident MFMA kernels are packed (netwidth == dfn::kWidth)
+  // Generic-width path (nerfh_train_api.hip): every parameter as a plain row-major fp32 device tensor, in the canonical
+  // order of dfn_nerfh_train_param_name(); one allocation.
+  float* gen_blob = nullptr;
+  std::vector<const float*> gen_params;
+};
+

@@ -1,0 +1,806 @@
+// nerfh_train.hip — kernels of the NeRF-H TRAINING path (gfx950): generic fp32-MFMA Linear forward / data gradient /
+// weight gradient over point-major activations, and the training-mode stages around them (stratified depths,
+// positional encoding, coarse composite + importance sampling with injected draws, compositing backward, NerfWLoss).
+// See nerfh_train.h for the formulation.
+//
+// Replaces (reference, /root/reference/script/): run_nerf.py:50-66 (one optimisation step's forward + backward),
+// models/rendering.py:245-337 with test_time=False (render_rays), :132-243 (raw2outputs_NeRFW, both typ),
+// models/nerfw.py:47-95 (run_network_NeRFW training branches), :297-354 (NeRFW.forward), models/losses.py:19-57.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mfma_frag.h"
+#include "nerfh_device.h"
+#include "nerfh_layout.h"
+#include "nerfh_train.h"
+
+namespace dfn {
+namespace train {
+
+static inline int grid_for(size_t n, int block, int cap = 256 * 16) {
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  return int(g < size_t(cap) ? g : size_t(cap));
+}
+
+DFN_DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+DFN_DEV float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SIGMOID: return sigmoid(v);
+    case ACT_SOFTPLUS: return softplus(v);
+    default: return v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+// One wave: 32 points x NBLK*32 outputs.  MFMA A operand = activations (rows = points), B = W^T (columns = output
+// features): lane (i = lane & 31, kh = lane >> 5) feeds A[i][kh] and B[kh][i]; the C fragment of a lane is output
+// feature i for the 16 points mblock_row(kh, r), so a store instruction writes two 128-byte row segments.
+// A lane loads 4 consecutive contraction elements per step (k0 + 4 kh .. + 3) from its activation row and from its
+// weight row: the order of the contraction index is free as long as A and B agree.
+struct FwdArgs {
+  Seg seg[3];
+  int nseg;
+  const float* W;
+  int ldw;
+  const float* b;
+  int N, act;
+  float* y;
+  int ldy;
+  long long P;
+};
+
+template <int NBLK>
+__global__ __launch_bounds__(256) void gemm_fwd_kernel(FwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kh = lane >> 5;
+  const long long p0 = ((long long)blockIdx.x * 4 + wave) * 32;
+  if (p0 >= a.P) return;
+  const int n0 = blockIdx.y * NBLK * 32;
+  const long long row = p0 + i < a.P ? p0 + i : a.P - 1;
+  f32x16 acc[NBLK];
+#pragma unroll
+  for (int nb = 0; nb < NBLK; ++nb) {
+    const int n = n0 + nb * 32 + i;
+    const float bv = (a.b && n < a.N) ? a.b[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = bv;
+  }
+  for (int s = 0; s < a.nseg; ++s) {
+    const Seg sg = a.seg[s];
+    const float* x = sg.x + (sg.div == 1 ? row : row / sg.div) * sg.ld;
+    const float* w[NBLK];
+    bool wok[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+      const int n = n0 + nb * 32 + i;
+      wok[nb] = n < a.N;
+      w[nb] = a.W + (size_t)(wok[nb] ? n : 0) * a.ldw + sg.wcol;
+    }
+    for (int k0 = 0; k0 < sg.K; k0 += 8) {
+      const int k = k0 + 4 * kh;
+      float av[4], bv[NBLK][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) av[q] = k + q < sg.K ? x[k + q] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[nb][q] = (wok[nb] && k + q < sg.K) ? w[nb][k + q] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma32(av[q], bv[nb][q], acc[nb]);
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NBLK; ++nb) {
+    const int n = n0 + nb * 32 + i;
+    if (n >= a.N) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long pt = p0 + mblock_row(kh, r);
+      if (pt < a.P) a.y[pt * a.ldy + n] = apply_act(acc[nb][r], a.act);
+    }
+  }
+}
+
+hipError_t gemm_fwd(const Seg* segs, int nseg, const float* W, int ldw, const float* b, int N, int act, float* y, int ldy,
+                    long long P, hipStream_t s) {
+  if (P <= 0 || N <= 0) return hipSuccess;
+  if (nseg < 1 || nseg > 3) return hipErrorInvalidValue;
+  FwdArgs a{};
+  for (int k = 0; k < nseg; ++k) a.seg[k] = segs[k];
+  a.nseg = nseg; a.W = W; a.ldw = ldw; a.b = b; a.N = N; a.act = act; a.y = y; a.ldy = ldy; a.P = P;
+  const unsigned gx = unsigned((P + 127) / 128);
+  if (N <= 32) hipLaunchKernelGGL(gemm_fwd_kernel<1>, dim3(gx, 1), dim3(256), 0, s, a);
+  else if (N <= 64) hipLaunchKernelGGL(gemm_fwd_kernel<2>, dim3(gx, 1), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gemm_fwd_kernel<4>, dim3(gx, (N + 127) / 128), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ data gradient
+// dX = G W: A = G (rows = points, contraction over the layer's outputs n), B[kh][j] = W[n][wcol + k0 + j] — a
+// coalesced read of the weight row, no transposed copy of W is needed.
+struct BwdGemmArgs {
+  const float* G;
+  int ldg, N;
+  const float* W;
+  int ldw, wcol, K;
+  float* dx;
+  int lddx, accumulate;
+  const float* mask;
+  int ldmask;
+  long long P;
+};
+
+template <int KBLK>
+__global__ __launch_bounds__(256) void gemm_bwd_kernel(BwdGemmArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kh = lane >> 5;
+  const long long p0 = ((long long)blockIdx.x * 4 + wave) * 32;
+  if (p0 >= a.P) return;
+  const int kb0 = blockIdx.y * KBLK * 32;
+  const long long row = p0 + i < a.P ? p0 + i : a.P - 1;
+  const float* g = a.G + row * a.ldg;
+  f32x16 acc[KBLK];
+#pragma unroll
+  for (int kb = 0; kb < KBLK; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+  for (int n0 = 0; n0 < a.N; n0 += 8) {
+    const int n = n0 + 4 * kh;
+    float av[4], bv[KBLK][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) av[q] = n + q < a.N ? g[n + q] : 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KBLK; ++kb) {
+      const int col = kb0 + kb * 32 + i;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[kb][q] = (n + q < a.N && col < a.K) ? a.W[(size_t)(n + q) * a.ldw + a.wcol + col] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int kb = 0; kb < KBLK; ++kb) acc[kb] = mfma32(av[q], bv[kb][q], acc[kb]);
+  }
+#pragma unroll
+  for (int kb = 0; kb < KBLK; ++kb) {
+    const int col = kb0 + kb * 32 + i;
+    if (col >= a.K) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long pt = p0 + mblock_row(kh, r);
+      if (pt >= a.P) continue;
+      float v = acc[kb][r];
+      if (a.accumulate) v += a.dx[pt * a.lddx + col];
+      if (a.mask && !(a.mask[pt * a.ldmask + col] > 0.f)) v = 0.f;
+      a.dx[pt * a.lddx + col] = v;
+    }
+  }
+}
+
+hipError_t gemm_bwd(const float* G, int ldg, int N, const float* W, int ldw, int wcol, int K, float* dx, int lddx,
+                    int accumulate, const float* mask_src, int ldmask, long long P, hipStream_t s) {
+  if (P <= 0 || K <= 0) return hipSuccess;
+  BwdGemmArgs a{G, ldg, N, W, ldw, wcol, K, dx, lddx, accumulate, mask_src, ldmask, P};
+  const unsigned gx = unsigned((P + 127) / 128);
+  if (K <= 32) hipLaunchKernelGGL(gemm_bwd_kernel<1>, dim3(gx, 1), dim3(256), 0, s, a);
+  else if (K <= 64) hipLaunchKernelGGL(gemm_bwd_kernel<2>, dim3(gx, 1), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gemm_bwd_kernel<4>, dim3(gx, (K + 127) / 128), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+// dW = G^T X over points: A[i][kh] = G[p + kh'][n0 + i], B[kh][j] = X[p + kh'][k0 + j] — both coalesced reads of
+// point-major rows.  A wave owns one 32-row block of outputs x KBLK 32-column blocks of inputs for one chunk of
+// points; chunk partials are reduced in fixed order by wgrad_reduce_kernel (deterministic).
+constexpr int kWgradK = 4;  // 32-column blocks per wave
+static inline int wgrad_chunk(long long P) {
+  long long ch = 512;
+  while ((P + ch - 1) / ch > 1024) ch *= 2;
+  return int(ch);
+}
+size_t gemm_wgrad_scratch_floats(int N, int K, long long P) {
+  const long long ch = wgrad_chunk(P), chunks = (P + ch - 1) / ch;
+  return size_t(chunks) * (size_t(N) * K + N);
+}
+
+struct WgradArgs {
+  const float* G;
+  int ldg, N;
+  Seg x;
+  float* part;    // [chunks][N][K]
+  float* bpart;   // [chunks][N]
+  long long P;
+  int chunk, kgroups, items;
+};
+
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(WgradArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kh = lane >> 5;
+  const int item = blockIdx.y * 4 + wave;
+  if (item >= a.items) return;
+  const int nblk = item / a.kgroups, kg = item - nblk * a.kgroups;
+  const int n0 = nblk * 32, k0 = kg * kWgradK * 32;
+  const long long c0 = (long long)blockIdx.x * a.chunk;
+  const long long c1 = c0 + a.chunk < a.P ? c0 + a.chunk : a.P;
+  const int K = a.x.K;
+  f32x16 acc[kWgradK];
+#pragma unroll
+  for (int kb = 0; kb < kWgradK; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+  float bsum = 0.f;
+  const bool nok = n0 + i < a.N;
+  for (long long p = c0; p < c1; p += 8) {
+    float av[4], bv[kWgradK][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long pq = p + 4 * kh + q;
+      const bool ok = pq < c1;
+      av[q] = (ok && nok) ? a.G[pq * a.ldg + n0 + i] : 0.f;
+      bsum += av[q];
+      const float* xr = a.x.x + (a.x.div == 1 ? pq : pq / a.x.div) * a.x.ld;
+#pragma unroll
+      for (int kb = 0; kb < kWgradK; ++kb) {
+        const int col = k0 + kb * 32 + i;
+        bv[kb][q] = (ok && col < K) ? xr[col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int kb = 0; kb < kWgradK; ++kb) acc[kb] = mfma32(av[q], bv[kb][q], acc[kb]);
+  }
+  float* part = a.part + (size_t)blockIdx.x * a.N * K;
+#pragma unroll
+  for (int kb = 0; kb < kWgradK; ++kb) {
+    const int col = k0 + kb * 32 + i;
+    if (col >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + mblock_row(kh, r);
+      if (n < a.N) part[(size_t)n * K + col] = acc[kb][r];
+    }
+  }
+  if (kg == 0 && a.bpart) {
+    const float tot = bsum + __shfl_xor(bsum, 32, 64);
+    if (kh == 0 && nok) a.bpart[(size_t)blockIdx.x * a.N + n0 + i] = tot;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int chunks,
+                                                           int N, int K, float* __restrict__ dW, int ldw, int wcol,
+                                                           float* __restrict__ db) {
+  const size_t total = size_t(N) * K + (db ? N : 0);
+  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < total; e += size_t(gridDim.x) * blockDim.x) {
+    float s = 0.f;
+    if (e < size_t(N) * K) {
+      for (int c = 0; c < chunks; ++c) s += part[size_t(c) * N * K + e];
+      const size_t n = e / K, k = e - n * K;
+      dW[n * ldw + wcol + k] = s;
+    } else {
+      const size_t n = e - size_t(N) * K;
+      for (int c = 0; c < chunks; ++c) s += bpart[size_t(c) * N + n];
+      db[n] = s;
+    }
+  }
+}
+
+hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW, int ldw, float* db, float* scratch,
+                      long long P, hipStream_t s) {
+  if (N <= 0 || xseg.K <= 0) return hipSuccess;
+  if (P <= 0) return hipErrorInvalidValue;
+  const int ch = wgrad_chunk(P);
+  const int chunks = int((P + ch - 1) / ch);
+  WgradArgs a{};
+  a.G = G; a.ldg = ldg; a.N = N; a.x = xseg; a.P = P; a.chunk = ch;
+  a.part = scratch;
+  a.bpart = db ? scratch + size_t(chunks) * N * xseg.K : nullptr;
+  a.kgroups = (xseg.K + kWgradK * 32 - 1) / (kWgradK * 32);
+  a.items = ((N + 31) / 32) * a.kgroups;
+  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(chunks, (a.items + 3) / 4), dim3(256), 0, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(size_t(N) * xseg.K + N, 256, 1024)), dim3(256), 0, s, a.part, a.bpart, chunks,
+                     N, xseg.K, dW, ldw, xseg.wcol, db);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ depths / encodings
+__global__ __launch_bounds__(256) void stratified_z_kernel(const float* __restrict__ t_rand, size_t R, int Nc, float near, float far,
+                                                           float* __restrict__ z) {
+  const size_t n = R * size_t(Nc);
+  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+    const int i = int(e % Nc);
+    const float zi = coarse_z_at(i, Nc, near, far);
+    if (!t_rand) { z[e] = zi; continue; }
+    const float zm = i > 0 ? coarse_z_at(i - 1, Nc, near, far) : zi, zp = i + 1 < Nc ? coarse_z_at(i + 1, Nc, near, far) : zi;
+    const float lower = i > 0 ? mul_rn(.5f, add_rn(zi, zm)) : zi;          // cat([z[:1], mids])
+    const float upper = i + 1 < Nc ? mul_rn(.5f, add_rn(zp, zi)) : zi;      // cat([mids, z[-1:]])
+    z[e] = add_rn(lower, mul_rn(sub_rn(upper, lower), t_rand[e]));
+  }
+}
+hipError_t stratified_z(const float* t_rand, size_t R, int Nc, float near, float far, float* z, hipStream_t s) {
+  if (!R) return hipSuccess;
+  hipLaunchKernelGGL(stratified_z_kernel, dim3(grid_for(R * Nc, 256)), dim3(256), 0, s, t_rand, R, Nc, near, far, z);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void posenc_points_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                            const float* __restrict__ z, size_t R, int Ns, float* __restrict__ pe) {
+  // one thread per (point, coordinate-frequency pair): 64 threads per point, column c of the 63-wide encoding each
+  const size_t n = R * size_t(Ns) * 64;
+  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+    const size_t pt = e >> 6;
+    const int c = int(e & 63);
+    const size_t ray = pt / Ns;
+    float v = 0.f;
+    if (c < 63) {
+      const int coord = c < 3 ? c : (c - 3) % 3;
+      const float x = add_rn(rays_o[ray * 3 + coord], mul_rn(rays_d[ray * 3 + coord], z[pt]));
+      if (c < 3) v = x;
+      else {
+        const int k = (c - 3) / 6;
+        const bool is_cos = ((c - 3) % 6) >= 3;
+        const float arg = x * float(1 << k);
+        v = is_cos ? cosf(arg) : sinf(arg);
+      }
+    }
+    pe[e] = v;
+  }
+}
+hipError_t posenc_points(const float* rays_o, const float* rays_d, const float* z, size_t R, int Ns, float* pe, hipStream_t s) {
+  if (!R) return hipSuccess;
+  hipLaunchKernelGGL(posenc_points_kernel, dim3(grid_for(R * Ns * 64, 256, 256 * 32)), dim3(256), 0, s, rays_o, rays_d, z, R, Ns, pe);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(128) void ray_inputs_kernel(const float* __restrict__ viewdirs, const float* __restrict__ hist,
+                                                         size_t hist_rows, const float* __restrict__ emb_a,
+                                                         const float* __restrict__ emb_t, int hist_bin, int dim_a, int dim_t,
+                                                         int n_vocab, size_t R, float* __restrict__ dir_in, int ld_dir,
+                                                         float* __restrict__ t_in, int ld_t) {
+  const int na = emb_a ? hist_bin * dim_a : 0, nt = (emb_t && t_in) ? hist_bin * dim_t : 0;
+  for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
+    const float* hrow = hist ? hist + (hist_rows == 1 ? 0 : ray) * hist_bin : nullptr;
+    for (int c = threadIdx.x; c < ld_dir; c += blockDim.x) {
+      float v = 0.f;
+      if (c < kChDir) {
+        const int coord = c < 3 ? c : (c - 3) % 3;
+        const float x = viewdirs[ray * 3 + coord];
+        if (c < 3) v = x;
+        else {
+          const int k = (c - 3) / 6;
+          const float arg = x * float(1 << k);
+          v = ((c - 3) % 6) >= 3 ? cosf(arg) : sinf(arg);
+        }
+      } else if (c < kChDir + na) {
+        const int j = c - kChDir;
+        long long idx = (long long)hrow[j / dim_a];   // .long() truncation (nerfw.py:69)
+        idx = idx < 0 ? 0 : (idx >= n_vocab ? n_vocab - 1 : idx);
+        v = emb_a[idx * dim_a + j % dim_a];
+      }
+      dir_in[ray * ld_dir + c] = v;
+    }
+    if (t_in)
+      for (int c = threadIdx.x; c < ld_t; c += blockDim.x) {
+        float v = 0.f;
+        if (c < nt) {
+          long long idx = (long long)hrow[c / dim_t];
+          idx = idx < 0 ? 0 : (idx >= n_vocab ? n_vocab - 1 : idx);
+          v = emb_t[idx * dim_t + c % dim_t];
+        }
+        t_in[ray * ld_t + c] = v;
+      }
+  }
+}
+hipError_t ray_inputs(const float* viewdirs, const float* hist, size_t hist_rows, const float* emb_a, const float* emb_t,
+                      int hist_bin, int dim_a, int dim_t, int n_vocab, size_t R, float* dir_in, int ld_dir, float* t_in, int ld_t,
+                      hipStream_t s) {
+  if (!R) return hipSuccess;
+  hipLaunchKernelGGL(ray_inputs_kernel, dim3(grid_for(R, 1)), dim3(128), 0, s, viewdirs, hist, hist_rows, emb_a, emb_t, hist_bin,
+                     dim_a, dim_t, n_vocab, R, dir_in, ld_dir, t_in, ld_t);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ coarse composite + sampler (training)
+// One wave per ray (as nerfh_stages.hip).  alpha_i = 1 - exp(-delta_i relu(sigma_i + noise_i)), w = alpha T,
+// rgb0 = sum w c, depth = sum w z, disp0 = 1 / max(1e-10, depth / sum w) (rendering.py:168-193,231-243); then
+// sample_pdf on the interior weights with the injected u (rendering.py:24-65), z_std, and the sort of cat([z, z_samples]).
+DFN_DEV void ray_weights_from_alpha_input(const float* seff, const float* z, int N, float* w, int lane) {
+  float carry = 1.f;
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int i = c0 + lane;
+    float alpha = 0.f;
+    if (i < N) {
+      const float delta = i + 1 < N ? sub_rn(z[i + 1], z[i]) : 1e2f;
+      alpha = sub_rn(1.f, expf(-mul_rn(delta, fmaxf(seff[i], 0.f))));
+    }
+    const float incl = wave_incl_prod(sub_rn(1.f, alpha), lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.f;
+    if (i < N) w[i] = mul_rn(alpha, mul_rn(carry, excl));
+    carry = mul_rn(carry, __shfl(incl, 63, 64));
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_fine_train_kernel(const float* __restrict__ raw_c, const float* __restrict__ z_c,
+                                                                const float* __restrict__ noise, float noise_std,
+                                                                const float* __restrict__ u, size_t R, int Nc, int Ni,
+                                                                float* __restrict__ z_fine, float* __restrict__ rgb0,
+                                                                float* __restrict__ disp0, float* __restrict__ acc0,
+                                                                float* __restrict__ z_std) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Nf = Nc + Ni;
+  const int per = 4 * Nc + 2 * Nf + Ni;
+  float* s_sig = sm + size_t(wave) * per;   // [Nc] sigma + noise
+  float* s_w = s_sig + Nc;                  // [Nc]
+  float* s_mid = s_w + Nc;                  // [Nc]
+  float* s_cdf = s_mid + Nc;                // [Nc]
+  float* s_all = s_cdf + Nc;                // [Nf] cat([z, z_samples])
+  float* s_out = s_all + Nf;                // [Nf]
+  float* s_u = s_out + Nf;                  // [Ni]
+  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < R; ray += size_t(gridDim.x) * 4) {
+    for (int i = lane; i < Nc; i += 64) {
+      const float sg = raw_c[(ray * Nc + i) * 4 + 3];
+      s_sig[i] = noise ? add_rn(sg, mul_rn(noise[ray * Nc + i], noise_std)) : sg;
+      s_all[i] = z_c[ray * Nc + i];
+    }
+    if (u) for (int i = lane; i < Ni; i += 64) s_u[i] = u[ray * Ni + i];
+    wave_sync();
+    ray_weights_from_alpha_input(s_sig, s_all, Nc, s_w, lane);
+    for (int i = lane; i < Nc - 1; i += 64) s_mid[i] = mul_rn(.5f, add_rn(s_all[i + 1], s_all[i]));
+    wave_sync();
+    // coarse maps
+    float c3[3] = {0.f, 0.f, 0.f}, sa = 0.f, sd = 0.f;
+    for (int i = lane; i < Nc; i += 64) {
+      const float w = s_w[i];
+      const float* rc = raw_c + (ray * Nc + i) * 4;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) c3[c] += mul_rn(w, rc[c]);
+      sa += w;
+      sd += mul_rn(w, s_all[i]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) c3[c] = wave_sum(c3[c]);
+    sa = wave_sum(sa);
+    sd = wave_sum(sd);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb0[ray * 3 + c] = c3[c];
+      acc0[ray] = sa;
+      disp0[ray] = 1.f / fmaxf(1e-10f, sd / sa);
+    }
+    // inverse-CDF sampling on the interior weights
+    {
+      const int nb = Nc - 1, nw = nb - 1;
+      const float* wts = s_w + 1;
+      float part = 0.f;
+      for (int i = lane; i < nw; i += 64) part += add_rn(wts[i], 1e-5f);
+      const float total = wave_sum(part);
+      float carry = 0.f;
+      if (lane == 0) s_cdf[0] = 0.f;
+      for (int c0 = 0; c0 < nw; c0 += 64) {
+        const int i = c0 + lane;
+        const float pdf = i < nw ? add_rn(wts[i], 1e-5f) / total : 0.f;
+        const float incl = wave_incl_sum(pdf, lane);
+        if (i < nw) s_cdf[i + 1] = add_rn(carry, incl);
+        carry = add_rn(carry, __shfl(incl, 63, 64));
+      }
+      wave_sync();
+      for (int j = lane; j < Ni; j += 64) {
+        const float uj = u ? s_u[j] : unit_linspace(j, Ni);
+        int lo = 0, hi = nb;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_cdf[mid] <= uj) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < nb - 1 ? lo : nb - 1;
+        const float cb = s_cdf[below], ca = s_cdf[above];
+        float den = sub_rn(ca, cb);
+        if (den < 1e-5f) den = 1.f;
+        const float t = sub_rn(uj, cb) / den;
+        s_all[Nc + j] = add_rn(s_mid[below], mul_rn(t, sub_rn(s_mid[above], s_mid[below])));
+      }
+    }
+    wave_sync();
+    float* zs = s_all + Nc;
+    {  // z_std = std(z_samples, unbiased=False) (rendering.py:327)
+      float sum = 0.f;
+      for (int i = lane; i < Ni; i += 64) sum += zs[i];
+      const float mean = wave_sum(sum) / float(Ni);
+      float sq = 0.f;
+      for (int i = lane; i < Ni; i += 64) { const float dlt = zs[i] - mean; sq += dlt * dlt; }
+      sq = wave_sum(sq);
+      if (lane == 0) z_std[ray] = sqrtf(sq / float(Ni));
+    }
+    // sort the samples (random u: arbitrary order) by odd-even transposition, then merge with the sorted coarse depths by rank
+    for (int guard = 0; guard < Ni; ++guard) {
+      bool swapped = false;
+      for (int phase = 0; phase < 2; ++phase) {
+        for (int k = 2 * lane + phase; k + 1 < Ni; k += 128) {
+          const float lo = zs[k], hi = zs[k + 1];
+          if (lo > hi) { zs[k] = hi; zs[k + 1] = lo; swapped = true; }
+        }
+        wave_sync();
+      }
+      if (!__any(swapped)) break;
+    }
+    for (int i = lane; i < Nf; i += 64) {
+      const float v = s_all[i];
+      int lo = 0, hi, rank;
+      if (i < Nc) {
+        hi = Ni;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zs[mid] < v) lo = mid + 1; else hi = mid; }
+        rank = i + lo;
+      } else {
+        hi = Nc;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_all[mid] <= v) lo = mid + 1; else hi = mid; }
+        rank = (i - Nc) + lo;
+      }
+      s_out[rank] = v;
+    }
+    wave_sync();
+    for (int i = lane; i < Nf; i += 64) z_fine[ray * Nf + i] = s_out[i];
+    wave_sync();
+  }
+}
+hipError_t sample_fine_train(const float* raw_c, const float* z_c, const float* noise, float noise_std, const float* u, size_t R,
+                             int Nc, int Ni, float* z_fine, float* rgb0, float* disp0, float* acc0, float* z_std, hipStream_t s) {
+  if (!R) return hipSuccess;
+  const int per = 4 * Nc + 2 * (Nc + Ni) + Ni;
+  hipLaunchKernelGGL(sample_fine_train_kernel, dim3(grid_for((R + 3) / 4, 1)), dim3(256), size_t(4) * per * 4, s, raw_c, z_c, noise,
+                     noise_std, u, R, Nc, Ni, z_fine, rgb0, disp0, acc0, z_std);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ compositing backward (training)
+// Coarse: rgb0 = sum_i w_i c_i, w_i = alpha_i T_i, alpha_i = 1 - exp(-delta_i relu(s_i)), s_i = sigma_i + noise_i.
+//   d c_i = g w_i;   d s_i = [s_i > 0] delta_i ((1 - alpha_i) T_i g.c_i - S_i),  S_i = sum_{k>i} w_k g.c_k.
+// Outputs are PRE-activation gradients: x c (1 - c) (Sigmoid head), x (1 - exp(-sigma)) (Softplus head).
+__global__ __launch_bounds__(256) void composite_coarse_backward_kernel(const float* __restrict__ raw_c, const float* __restrict__ z_c,
+                                                                        const float* __restrict__ noise, float noise_std,
+                                                                        const float* __restrict__ g_rgb0, size_t R, int Nc,
+                                                                        float* __restrict__ gpre) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* s_e = sm + size_t(wave) * 3 * Nc;   // e_i = w_i g.c_i
+  float* s_T = s_e + Nc;
+  float* s_al = s_T + Nc;
+  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < R; ray += size_t(gridDim.x) * 4) {
+    const float g0 = g_rgb0[ray * 3], g1 = g_rgb0[ray * 3 + 1], g2 = g_rgb0[ray * 3 + 2];
+    float carry = 1.f;
+    for (int c0 = 0; c0 < Nc; c0 += 64) {
+      const int i = c0 + lane;
+      float alpha = 0.f;
+      if (i < Nc) {
+        const float sg = raw_c[(ray * Nc + i) * 4 + 3];
+        const float se = noise ? add_rn(sg, mul_rn(noise[ray * Nc + i], noise_std)) : sg;
+        const float delta = i + 1 < Nc ? sub_rn(z_c[ray * Nc + i + 1], z_c[ray * Nc + i]) : 1e2f;
+        alpha = sub_rn(1.f, expf(-mul_rn(delta, fmaxf(se, 0.f))));
+      }
+      const float incl = wave_incl_prod(sub_rn(1.f, alpha), lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.f;
+      if (i < Nc) {
+        const float T = mul_rn(carry, excl);
+        const float* rc = raw_c + (ray * Nc + i) * 4;
+        s_T[i] = T;
+        s_al[i] = alpha;
+        s_e[i] = alpha * T * (g0 * rc[0] + g1 * rc[1] + g2 * rc[2]);
+      }
+      carry = mul_rn(carry, __shfl(incl, 63, 64));
+    }
+    wave_sync();
+    // suffix sums S_i = sum_{k>i} e_k, from the back in 64-sample blocks
+    float tail = 0.f;
+    for (int c0 = ((Nc - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+      const int i = c0 + lane;
+      const float e = i < Nc ? s_e[i] : 0.f;
+      const float incl = wave_incl_sum(e, lane);
+      const float blk = __shfl(incl, 63, 64);
+      const float S = tail + (blk - incl);   // strictly after i
+      if (i < Nc) {
+        const float* rc = raw_c + (ray * Nc + i) * 4;
+        const float sg = rc[3];
+        const float se = noise ? add_rn(sg, mul_rn(noise[ray * Nc + i], noise_std)) : sg;
+        const float delta = i + 1 < Nc ? sub_rn(z_c[ray * Nc + i + 1], z_c[ray * Nc + i]) : 1e2f;
+        const float T = s_T[i], al = s_al[i], w = al * T;
+        const float gc = g0 * rc[0] + g1 * rc[1] + g2 * rc[2];
+        float* o = gpre + (ray * Nc + i) * 4;
+        o[0] = g0 * w * rc[0] * (1.f - rc[0]);
+        o[1] = g1 * w * rc[1] * (1.f - rc[1]);
+        o[2] = g2 * w * rc[2] * (1.f - rc[2]);
+        const float ds = se > 0.f ? delta * ((1.f - al) * T * gc - S) : 0.f;
+        o[3] = ds * (1.f - expf(-sg));
+      }
+      tail += blk;
+    }
+    wave_sync();
+  }
+}
+hipError_t composite_coarse_backward(const float* raw_c, const float* z_c, const float* noise, float noise_std, const float* g_rgb0,
+                                     size_t R, int Nc, float* gpre, hipStream_t s) {
+  if (!R) return hipSuccess;
+  hipLaunchKernelGGL(composite_coarse_backward_kernel, dim3(grid_for((R + 3) / 4, 1)), dim3(256), size_t(4) * 3 * Nc * 4, s, raw_c,
+                     z_c, noise, noise_std, g_rgb0, R, Nc, gpre);
+  return hipGetLastError();
+}
+
+// Fine (training compositing, rendering.py:168-209): rgb = sum T (a_s c_s + a_t c_t), beta = sum T a_t b_t + beta_min.
+// With g = d L / d rgb, gb = d L / d beta and e_i = T_i (a_s g.c_s + a_t (g.c_t + gb b_t)):
+//   d c_s = g T a_s,  d c_t = g T a_t,  d b_t = gb T a_t,
+//   d sigma_s = delta ((1 - a_s) T g.c_s - S),  d sigma_t = delta ((1 - a_t) T (g.c_t + gb b_t) - S) + g_tsigma,  S_i = sum_{k>i} e_k.
+__global__ __launch_bounds__(256) void composite_fine_backward_train_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                                            const float* __restrict__ g_rgb,
+                                                                            const float* __restrict__ g_beta, float g_tsigma,
+                                                                            const float* __restrict__ g_ts, size_t R, int Nf,
+                                                                            float* __restrict__ gpre) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* s_e = sm + size_t(wave) * 2 * Nf;
+  float* s_T = s_e + Nf;
+  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < R; ray += size_t(gridDim.x) * 4) {
+    const float g0 = g_rgb[ray * 3], g1 = g_rgb[ray * 3 + 1], g2 = g_rgb[ray * 3 + 2], gb = g_beta[ray];
+    const float* rr = raw + ray * size_t(Nf) * 9;
+    const float* zr = z + ray * size_t(Nf);
+    float carry = 1.f;
+    for (int c0 = 0; c0 < Nf; c0 += 64) {
+      const int i = c0 + lane;
+      float om = 1.f, e = 0.f;
+      if (i < Nf) {
+        const float* v = rr + size_t(i) * 9;
+        const float delta = i + 1 < Nf ? sub_rn(zr[i + 1], zr[i]) : 1e2f;
+        const float a_s = sub_rn(1.f, expf(-mul_rn(delta, v[3]))), a_t = sub_rn(1.f, expf(-mul_rn(delta, v[7])));
+        om = expf(-mul_rn(delta, add_rn(v[3], v[7])));
+        e = a_s * (g0 * v[0] + g1 * v[1] + g2 * v[2]) + a_t * (g0 * v[4] + g1 * v[5] + g2 * v[6] + gb * v[8]);
+      }
+      const float incl = wave_incl_prod(om, lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.f;
+      if (i < Nf) {
+        const float T = carry * excl;
+        s_T[i] = T;
+        s_e[i] = T * e;
+      }
+      carry *= __shfl(incl, 63, 64);
+    }
+    wave_sync();
+    float tail = 0.f;
+    for (int c0 = ((Nf - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+      const int i = c0 + lane;
+      const float e = i < Nf ? s_e[i] : 0.f;
+      const float incl = wave_incl_sum(e, lane);
+      const float blk = __shfl(incl, 63, 64);
+      const float S = tail + (blk - incl);
+      if (i < Nf) {
+        const float* v = rr + size_t(i) * 9;
+        const float delta = i + 1 < Nf ? sub_rn(zr[i + 1], zr[i]) : 1e2f;
+        const float a_s = sub_rn(1.f, expf(-mul_rn(delta, v[3]))), a_t = sub_rn(1.f, expf(-mul_rn(delta, v[7])));
+        const float T = s_T[i], ws = T * a_s, wt = T * a_t;
+        const float gcs = g0 * v[0] + g1 * v[1] + g2 * v[2], gct = g0 * v[4] + g1 * v[5] + g2 * v[6] + gb * v[8];
+        float* o = gpre + (ray * size_t(Nf) + i) * 9;
+        o[0] = g0 * ws * v[0] * (1.f - v[0]);
+        o[1] = g1 * ws * v[1] * (1.f - v[1]);
+        o[2] = g2 * ws * v[2] * (1.f - v[2]);
+        o[3] = delta * ((1.f - a_s) * T * gcs - S) * (1.f - expf(-v[3]));
+        o[4] = g0 * wt * v[4] * (1.f - v[4]);
+        o[5] = g1 * wt * v[5] * (1.f - v[5]);
+        o[6] = g2 * wt * v[6] * (1.f - v[6]);
+        o[7] = (delta * ((1.f - a_t) * T * gct - S) + g_tsigma + (g_ts ? g_ts[ray * size_t(Nf) + i] : 0.f)) * (1.f - expf(-v[7]));
+        o[8] = gb * wt * (1.f - expf(-v[8]));
+      }
+      tail += blk;
+    }
+    wave_sync();
+  }
+}
+hipError_t composite_fine_backward_train(const float* raw, const float* z, const float* g_rgb, const float* g_beta, float g_tsigma,
+                                         const float* g_ts, size_t R, int Nf, float* gpre, hipStream_t s) {
+  if (!R) return hipSuccess;
+  hipLaunchKernelGGL(composite_fine_backward_train_kernel, dim3(grid_for((R + 3) / 4, 1)), dim3(256), size_t(4) * 2 * Nf * 4, s, raw, z,
+                     g_rgb, g_beta, g_tsigma, g_ts, R, Nf, gpre);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ small reductions
+__global__ __launch_bounds__(256) void sum_over_samples_kernel(const float* __restrict__ g, int ld, int C, size_t R, int Ns,
+                                                               float* __restrict__ out, int ldo) {
+  const size_t n = R * size_t(C);
+  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+    const size_t ray = e / C;
+    const int c = int(e - ray * C);
+    float s = 0.f;
+    const float* q = g + ray * size_t(Ns) * ld + c;
+    for (int k = 0; k < Ns; ++k) s += q[size_t(k) * ld];
+    out[ray * ldo + c] = s;
+  }
+}
+hipError_t sum_over_samples(const float* g, int ld, int C, size_t R, int Ns, float* out, int ldo, hipStream_t s) {
+  if (!R) return hipSuccess;
+  hipLaunchKernelGGL(sum_over_samples_kernel, dim3(grid_for(R * C, 256)), dim3(256), 0, s, g, ld, C, R, Ns, out, ldo);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void embedding_scatter_kernel(const float* __restrict__ g_in, int ld, int off,
+                                                                const float* __restrict__ hist, size_t hist_rows, int hist_bin,
+                                                                int dim, int n_vocab, size_t R, float* __restrict__ grad_emb) {
+  const int per = hist_bin * dim;
+  const size_t n = R * size_t(per);
+  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+    const size_t ray = e / per;
+    const int j = int(e - ray * per);
+    long long idx = (long long)hist[(hist_rows == 1 ? 0 : ray) * hist_bin + j / dim];
+    idx = idx < 0 ? 0 : (idx >= n_vocab ? n_vocab - 1 : idx);
+    atomicAdd(grad_emb + idx * dim + j % dim, g_in[ray * ld + off + j]);
+  }
+}
+hipError_t embedding_scatter(const float* g_in, int ld, int off, const float* hist, size_t hist_rows, int hist_bin, int dim,
+                             int n_vocab, size_t R, float* grad_emb, hipStream_t s) {
+  if (!R) return hipSuccess;
+  hipLaunchKernelGGL(embedding_scatter_kernel, dim3(grid_for(R * hist_bin * dim, 256)), dim3(256), 0, s, g_in, ld, off, hist,
+                     hist_rows, hist_bin, dim, n_vocab, R, grad_emb);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ NerfWLoss
+// c_l = 0.5 mean((rgb0 - t)^2), f_l = mean((rgb - t)^2 / (2 beta^2)), b_l = 3 + mean(log beta), s_l = lambda_u mean(sigma_t),
+// all x coef (losses.py:43-57); psnr = -10 log10(mean((rgb - t)^2)).  One workgroup; fp64 accumulators.
+__global__ __launch_bounds__(1024) void nerfw_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0,
+                                                          const float* __restrict__ beta, const float* __restrict__ raw,
+                                                          const float* __restrict__ target, size_t R, int Nf, float coef,
+                                                          float lambda_u, float* __restrict__ loss5, float* __restrict__ g_rgb,
+                                                          float* __restrict__ g_rgb0, float* __restrict__ g_beta) {
+  __shared__ double red[5][16];
+  double acc[5] = {0, 0, 0, 0, 0};   // c, f, log beta, sigma_t, mse
+  const double inv3R = 1.0 / (3.0 * double(R));
+  for (size_t r = threadIdx.x; r < R; r += blockDim.x) {
+    const float b = beta[r];
+    float gb = 0.f;
+    for (int c = 0; c < 3; ++c) {
+      const float t = target[r * 3 + c];
+      const float d0 = rgb0[r * 3 + c] - t, d1 = rgb[r * 3 + c] - t;
+      acc[0] += 0.5 * double(d0) * d0;
+      acc[1] += double(d1) * d1 / (2.0 * double(b) * b);
+      acc[4] += double(d1) * d1;
+      g_rgb0[r * 3 + c] = coef * d0 * float(inv3R);
+      g_rgb[r * 3 + c] = coef * d1 / (b * b) * float(inv3R);
+      gb -= d1 * d1 / (b * b * b);
+    }
+    acc[2] += log(double(b));
+    g_beta[r] = coef * (gb * float(inv3R) + 1.f / (b * float(R)));
+  }
+  for (size_t e = threadIdx.x; e < R * size_t(Nf); e += blockDim.x) acc[3] += raw[e * 9 + 7];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 5; ++k) {
+    double v = acc[k];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane == 0) red[k][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < 5; ++k)
+      for (int w = 0; w < int(blockDim.x >> 6); ++w) t[k] += red[k][w];
+    loss5[0] = float(coef * t[0] * inv3R);
+    loss5[1] = float(coef * t[1] * inv3R);
+    loss5[2] = float(coef * (3.0 + t[2] / double(R)));
+    loss5[3] = float(coef * lambda_u * t[3] / (double(R) * Nf));
+    loss5[4] = float(-10.0 * log10(t[4] * inv3R));
+  }
+}
+hipError_t nerfw_loss(const float* rgb, const float* rgb0, const float* beta, const float* raw, const float* target, size_t R,
+                      int Nf, float coef, float lambda_u, float* loss5, float* g_rgb, float* g_rgb0, float* g_beta, hipStream_t s) {
+  if (!R) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(nerfw_loss_kernel, dim3(1), dim3(1024), 0, s, rgb, rgb0, beta, raw, target, R, Nf, coef, lambda_u, loss5, g_rgb,
+                     g_rgb0, g_beta);
+  return hipGetLastError();
+}
+
+}  // namespace train
+}  // namespace dfn

@@ -28,6 +28,8 @@ class NerfHEngine:
         check(self.lib.dfn_nerfh_create(ctypes.byref(self.desc), ctypes.byref(self.handle)), "dfn_nerfh_create")
         self.precision = precision
         self.hist_bin = hist_bin
+        self.width = width
+        self.fast = width == 128   # register-resident MFMA kernels; other widths run the generic layer-by-layer fp32 path
         self._ws = None
 
     def __del__(self):
@@ -121,8 +123,35 @@ class NerfHEngine:
         return gpts
 
     # ------------------------------------------------------------------ whole path
+    GENERIC_CHUNK = 4096   # rays per pass of the generic path (its activations live in HBM: ~1.2 MB per ray at 64+128, W=128)
+
+    def generic_render_rays(self, rays_o, rays_d, hist, Nc, Ni, near, far, retraw=False):
+        """Test-time render on the generic-width path (dfn_nerfh_generic_render_rays): exact fp32, any netwidth."""
+        rays_o, rays_d = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3)
+        n, dev = rays_o.shape[0], rays_o.device
+        hist = _f32c(hist).reshape(-1, self.hist_bin)
+        rgb, disp, acc = torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+        Nf = Nc + Ni
+        raw_all = torch.empty(n, Nf, 9, device=dev) if retraw else None
+        C = self.GENERIC_CHUNK
+        ws = self._workspace(self.lib.dfn_nerfh_generic_workspace_bytes(self.handle, min(n, C), Nc, Ni), dev)
+        raw_tmp = None if retraw else torch.empty(min(n, C), Nf, 9, device=dev)
+        for r0 in range(0, n, C):
+            m = min(C, n - r0)
+            h = hist if hist.shape[0] == 1 else hist[r0:r0 + m]
+            raw = raw_all[r0:r0 + m] if retraw else raw_tmp[:m]
+            check(self.lib.dfn_nerfh_generic_render_rays(self.handle, ptr(rays_o[r0:r0 + m]), ptr(rays_d[r0:r0 + m]), ptr(h), h.shape[0], m,
+                                                         Nc, Ni, float(near), float(far), ptr(rgb[r0:r0 + m]), ptr(disp[r0:r0 + m]),
+                                                         ptr(acc[r0:r0 + m]), ptr(raw), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                                         current_stream()), "dfn_nerfh_generic_render_rays")
+        return rgb, disp, acc, raw_all
+
     def render_rays(self, rays_o, rays_d, hist, Nc, Ni, near, far, viewdirs=None, retraw=False, precision=None):
         """Test-time render of a ray batch -> (rgb [n,3], disp [n], acc [n], raw|None)."""
+        if not self.fast or precision == "generic":
+            if viewdirs is not None:
+                raise NotImplementedError("explicit viewdirs on the generic-width path")
+            return self.generic_render_rays(rays_o, rays_d, hist, Nc, Ni, near, far, retraw)
         rays_o, rays_d = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3)
         n = rays_o.shape[0]
         dev = rays_o.device
@@ -146,6 +175,15 @@ class NerfHEngine:
         c2w = _f32c(c2w)[:3, :4].contiguous()
         dev = c2w.device
         hist = _f32c(hist).reshape(-1)[: self.hist_bin].contiguous()
+        if not self.fast or precision == "generic":
+            o, d, _ = raygen(H, W, focal, c2w, want_viewdirs=False)
+            rgb, disp, acc, _ = self.generic_render_rays(o.reshape(-1, 3), d.reshape(-1, 3), hist, Nc, Ni, near, far)
+            res = (rgb.reshape(H, W, 3), disp.reshape(H, W), acc.reshape(H, W))
+            if out is not None:
+                for dst, src in zip(out, res):
+                    dst.copy_(src)
+                return out
+            return res
         if out is None:
             out = (torch.empty(H, W, 3, device=dev), torch.empty(H, W, device=dev), torch.empty(H, W, device=dev))
         rgb, disp, acc = out

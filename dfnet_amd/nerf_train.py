@@ -1,0 +1,181 @@
+"""NeRF-H training on the HIP path: host side of dfn_nerfh_train_forward / dfn_nerfw_loss /
+dfn_nerfh_train_backward.
+
+Mirrors what /root/reference/script/run_nerf.py:32-80 does per step — render(**render_kwargs_train) -> NerfWLoss ->
+loss.backward() -> optimizer.step() — with every network product on the exact-fp32 MFMA training kernels.  The
+parameters stay torch's master weights (the kernels read the nn.Module tensors in place and write into .grad), so the
+optimizer (torch.optim.Adam, as the reference) needs no re-pack; the packed test-time engine is refreshed only when a
+validation render is asked for (`HipQuery.refresh`).
+
+Two equivalent surfaces:
+  * NerfHTrainer.train_step(...)  — forward + fused NerfWLoss + backward, three library calls (run_nerf.py uses this);
+  * rendering.render(..., **render_kwargs_train) — returns tensors attached to autograd (`_RenderTrainFn`), so the
+    reference's own loop shape (loss_func(results, target); loss.backward()) runs unchanged.
+The reference's random draws (stratified jitter, coarse-density noise, importance-sampling u) are drawn with torch on
+the device and handed to the library as inputs, which is what makes the path checkable against the reference.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+
+def _f32c(t):
+    return t.contiguous().float()
+
+
+class NerfHTrainer:
+    """Owns the workspace of one training step and the canonical parameter list of (network_fn, network_fine,
+    embedding_a, embedding_t)."""
+
+    def __init__(self, engine, network_fn, network_fine, embedding_a, embedding_t):
+        self.lib = _lib.load()
+        self.engine = engine            # NerfHEngine: the handle carries the network geometry
+        self.hist_bin = engine.hist_bin
+        n = self.lib.dfn_nerfh_train_param_count()
+        names = [self.lib.dfn_nerfh_train_param_name(i).decode() for i in range(n)]
+        lookup = {}
+        for pre, mod in (("coarse.", network_fn), ("fine.", network_fine), ("embedding_a.", embedding_a), ("embedding_t.", embedding_t)):
+            for k, p in mod.named_parameters():
+                lookup[pre + k] = p
+        missing = [k for k in names if k not in lookup]
+        if missing or len(lookup) != len(names):
+            raise ValueError(f"NerfHTrainer: parameter set does not match the NeRF-H layout (missing {missing[:3]}...)")
+        self.names = names
+        self.params = [lookup[k] for k in names]
+        for k, p in zip(names, self.params):
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError(f"NerfHTrainer: parameter {k} must be a contiguous fp32 CUDA tensor")
+        self._ws = None
+        self._saved = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _ptr_array(self, tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def _workspace(self, n, Nc, Ni, dev):
+        nbytes = self.lib.dfn_nerfh_train_workspace_bytes(self.engine.handle, n, Nc, Ni)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    @staticmethod
+    def draw(n, Nc, Ni, perturb, dev, generator=None):
+        """The three draws of one render_rays call, in the reference's order (rendering.py:282, :173, :35)."""
+        t_rand = torch.rand(n, Nc, device=dev, generator=generator) if perturb > 0. else None
+        noise = torch.randn(n, Nc, device=dev, generator=generator)   # drawn even when raw_noise_std = 0 (quirk Q4)
+        u = torch.rand(n, Ni, device=dev, generator=generator) if perturb > 0. else None
+        return t_rand, noise, u
+
+    # ------------------------------------------------------------------ the three calls
+    def forward(self, rays_o, rays_d, hist, Nc, Ni, near, far, t_rand=None, noise=None, raw_noise_std=0., u=None):
+        """Training-mode render_rays -> dict(rgb_map, disp_map, acc_map, raw, rgb0, disp0, acc0, z_std, beta,
+        transient_sigmas); keeps what backward() needs."""
+        rays_o, rays_d = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3)
+        n, dev = rays_o.shape[0], rays_o.device
+        hist = _f32c(hist).reshape(-1, self.hist_bin)
+        if hist.shape[0] not in (1, n):
+            raise ValueError(f"img_idx must have 1 or {n} rows of {self.hist_bin} bins")
+        t_rand, noise, u = (None if t is None else _f32c(t) for t in (t_rand, noise, u))
+        if noise is not None and float(raw_noise_std) == 0.:
+            noise = None   # adds exactly zero: skip the read
+        Nf = Nc + Ni
+        out = {k: torch.empty(n, *sh, device=dev) for k, sh in (("rgb_map", (3,)), ("disp_map", ()), ("acc_map", ()), ("raw", (Nf, 9)),
+                                                                 ("rgb0", (3,)), ("disp0", ()), ("acc0", ()), ("z_std", ()), ("beta", ()))}
+        ws = self._workspace(n, Nc, Ni, dev)
+        check(self.lib.dfn_nerfh_train_forward(self.engine.handle, self._ptr_array(self.params), ptr(rays_o), ptr(rays_d), ptr(hist),
+                                               hist.shape[0], n, Nc, Ni, float(near), float(far), ptr(t_rand), ptr(noise),
+                                               float(raw_noise_std), ptr(u), ptr(out["rgb_map"]), ptr(out["disp_map"]), ptr(out["acc_map"]),
+                                               ptr(out["raw"]), ptr(out["rgb0"]), ptr(out["disp0"]), ptr(out["acc0"]), ptr(out["z_std"]),
+                                               ptr(out["beta"]), ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
+              "dfn_nerfh_train_forward")
+        out["transient_sigmas"] = out["raw"][..., 7]
+        self._saved = dict(hist=hist, n=n, Nc=Nc, Ni=Ni, noise=noise, raw_noise_std=float(raw_noise_std), raw=out["raw"], ws=ws)
+        return out
+
+    def loss(self, out, target, coef=1., lambda_u=0.01):
+        """NerfWLoss forward + gradient in one kernel -> (loss5 tensor [c_l, f_l, b_l, s_l, psnr], (g_rgb, g_rgb0, g_beta),
+        constant d L / d transient_sigma)."""
+        target = _f32c(target).reshape(-1, 3)
+        n, Nf = out["raw"].shape[0], out["raw"].shape[1]
+        dev = target.device
+        loss5 = torch.empty(5, device=dev)
+        g_rgb, g_rgb0, g_beta = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
+        check(self.lib.dfn_nerfw_loss(ptr(out["rgb_map"]), ptr(out["rgb0"]), ptr(out["beta"]), ptr(out["raw"]), ptr(target), n, Nf,
+                                      float(coef), float(lambda_u), ptr(loss5), ptr(g_rgb), ptr(g_rgb0), ptr(g_beta), current_stream()),
+              "dfn_nerfw_loss")
+        return loss5, (g_rgb, g_rgb0, g_beta), float(coef) * float(lambda_u) / (n * Nf)
+
+    def backward(self, g_rgb, g_rgb0, g_beta, g_tsigma=0., g_tsigma_dense=None, grads=None):
+        """Gradients of every parameter from the last forward().  grads=None: written into (freshly allocated) p.grad."""
+        s = self._saved
+        if s is None:
+            raise RuntimeError("NerfHTrainer.backward() without a forward()")
+        if grads is None:
+            for p in self.params:
+                if p.grad is None or not p.grad.is_contiguous():
+                    p.grad = torch.empty_like(p)
+            grads = [p.grad for p in self.params]
+        g_rgb, g_rgb0, g_beta = _f32c(g_rgb).reshape(-1, 3), _f32c(g_rgb0).reshape(-1, 3), _f32c(g_beta).reshape(-1)
+        gd = None if g_tsigma_dense is None else _f32c(g_tsigma_dense).reshape(s["n"], s["Nc"] + s["Ni"])
+        check(self.lib.dfn_nerfh_train_backward(self.engine.handle, self._ptr_array(self.params), ptr(s["hist"]), s["hist"].shape[0], s["n"],
+                                                s["Nc"], s["Ni"], ptr(s["noise"]), s["raw_noise_std"], ptr(s["raw"]), ptr(g_rgb), ptr(g_rgb0),
+                                                ptr(g_beta), float(g_tsigma), ptr(gd), self._ptr_array(grads),
+                                                ctypes.c_void_p(s["ws"].data_ptr()), s["ws"].numel(), current_stream()),
+              "dfn_nerfh_train_backward")
+        return grads
+
+    def train_step(self, rays_o, rays_d, hist, target, Nc, Ni, near, far, perturb=1., raw_noise_std=0., draws=None, coef=1.,
+                   lambda_u=0.01):
+        """run_nerf.py:50-66 without the optimizer: forward, NerfWLoss, backward into p.grad.  Returns (loss dict of 0-dim
+        tensors c_l/f_l/b_l/s_l, psnr, render outputs)."""
+        n = rays_o.reshape(-1, 3).shape[0]
+        t_rand, noise, u = draws if draws is not None else self.draw(n, Nc, Ni, perturb, rays_o.device)
+        out = self.forward(rays_o, rays_d, hist, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u)
+        loss5, (g_rgb, g_rgb0, g_beta), g_ts = self.loss(out, target, coef, lambda_u)
+        self.backward(g_rgb, g_rgb0, g_beta, g_ts)
+        return {k: loss5[i] for i, k in enumerate(("c_l", "f_l", "b_l", "s_l"))}, loss5[4], out
+
+
+class _RenderTrainFn(torch.autograd.Function):
+    """render_rays in training mode as an autograd node: outputs (rgb, disp, acc, raw, rgb0, disp0, acc0, z_std, beta,
+    transient_sigmas); gradients flow from rgb, rgb0, beta and transient_sigmas to every parameter (what NerfWLoss
+    uses, losses.py:43-52); the other outputs are marked non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, trainer, rays_o, rays_d, hist, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u, *params):
+        out = trainer.forward(rays_o, rays_d, hist, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u)
+        ctx.trainer = trainer
+        ctx.saved = trainer._saved
+        ts = out["transient_sigmas"].contiguous()
+        nd = (out["disp_map"], out["acc_map"], out["raw"], out["disp0"], out["acc0"], out["z_std"])
+        ctx.mark_non_differentiable(*nd)
+        return (out["rgb_map"], out["disp_map"], out["acc_map"], out["raw"], out["rgb0"], out["disp0"], out["acc0"], out["z_std"],
+                out["beta"], ts)
+
+    @staticmethod
+    def backward(ctx, g_rgb, _gd, _ga, _graw, g_rgb0, _gd0, _ga0, _gz, g_beta, g_ts):
+        tr = ctx.trainer
+        if tr._saved is not ctx.saved:
+            raise RuntimeError("render(): backward through a training render after another forward reused its workspace")
+        n = ctx.saved["n"]
+        dev = ctx.saved["raw"].device
+        z3, z1 = torch.zeros(n, 3, device=dev), torch.zeros(n, device=dev)
+        grads = [torch.empty_like(p) for p in tr.params]
+        tr.backward(z3 if g_rgb is None else g_rgb, z3 if g_rgb0 is None else g_rgb0, z1 if g_beta is None else g_beta, 0.,
+                    g_ts, grads=grads)
+        return (None,) * 12 + tuple(grads)
+
+
+def render_train(trainer, rays_o, rays_d, hist, Nc, Ni, near, far, perturb, raw_noise_std, retraw, draws=None):
+    """The training branch of rendering.render(): [rgb, disp, acc, extras] with the reference's extras keys."""
+    n = rays_o.reshape(-1, 3).shape[0]
+    t_rand, noise, u = draws if draws is not None else NerfHTrainer.draw(n, Nc, Ni, float(perturb), rays_o.device)
+    (rgb, disp, acc, raw, rgb0, disp0, acc0, z_std, beta, ts) = _RenderTrainFn.apply(
+        trainer, rays_o, rays_d, hist, int(Nc), int(Ni), float(near), float(far), t_rand, noise, float(raw_noise_std), u, *trainer.params)
+    extras = {'rgb0': rgb0, 'disp0': disp0, 'acc0': acc0, 'z_std': z_std, 'transient_sigmas': ts, 'beta': beta}
+    if retraw:
+        extras['raw'] = raw
+    return [rgb, disp, acc, extras]

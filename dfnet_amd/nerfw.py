@@ -69,9 +69,18 @@ class HipQuery:
     """Stands in for the reference's `network_query_fn` lambda (nerfw.py:425-434): carries the engine
     that evaluates both networks.  Calling it with pre-sampled points evaluates the MLP stage."""
 
-    def __init__(self, engine, netchunk=65536):
+    def __init__(self, engine, netchunk=65536, trainer=None, modules=None):
         self.engine = engine
         self.netchunk = netchunk
+        self.trainer = trainer      # NerfHTrainer: the training-mode render and its gradients (nerf_train.py)
+        self.modules = modules      # (network_fn, network_fine, embedding_a, embedding_t) behind the engine's packed weights
+        self.stale = False          # the master weights moved (optimizer step) since the engine was packed
+
+    def refresh(self):
+        """Re-pack the test-time engine from the (trained) modules — before a validation render."""
+        if self.modules is not None and self.stale:
+            self.engine.load_modules(*self.modules)
+            self.stale = False
 
     def __call__(self, *a, **k):
         raise RuntimeError("network_query_fn is fused into the HIP render path; call rendering.render()")
@@ -136,8 +145,12 @@ def create_nerf(args):
                          n_vocab=args.N_vocab, precision=getattr(args, "precision", "f16"))
     engine.load_modules(model, model_fine, embedding_a, embedding_t)
 
+    from .nerf_train import NerfHTrainer
+    query = HipQuery(engine, args.netchunk, modules=(model, model_fine, embedding_a, embedding_t))
+    if not args.no_grad_update:
+        query.trainer = NerfHTrainer(engine, model, model_fine, embedding_a, embedding_t)
     render_kwargs_train = {
-        'network_query_fn': HipQuery(engine, args.netchunk), 'perturb': args.perturb,
+        'network_query_fn': query, 'perturb': args.perturb,
         'N_importance': args.N_importance, 'network_fine': model_fine, 'N_samples': args.N_samples,
         'network_fn': model, 'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd,
         'raw_noise_std': args.raw_noise_std, 'embedding_a': embedding_a, 'embedding_t': embedding_t,

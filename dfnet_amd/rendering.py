@@ -6,8 +6,10 @@ loops, rendering.py:245-351) is one call into libdfnet_hip.so here; `chunk`/`net
 and ignored (tiling is internal).  `render_path`'s serial frame loop (rendering.py:420) becomes a
 frame-sharded loop with one gather when torch.distributed is initialised (dfnet_amd/dist.py).
 
-Only the test-time path is native so far (perturb=0, raw_noise_std=0, test_time=True — what
-`render_kwargs_test` carries); anything else raises NotImplementedError rather than falling back.
+Test-time kwargs (`render_kwargs_test`: perturb=0, raw_noise_std=0, test_time=True) run on the packed MFMA engine;
+training kwargs (`render_kwargs_train`: test_time=False, perturb, raw_noise_std) run on the exact-fp32 training kernels and
+return tensors attached to autograd with the reference's extras (dfnet_amd/nerf_train.py).  Unsupported options (ndc,
+white_bkgd, lindisp, ...) raise NotImplementedError rather than falling back.
 
 Autograd: when grad is enabled and `c2w` / `rays` require grad (the DFNet_dm step,
 feature/direct_feature_matching.py:340-376), `rgb_map` is returned attached to the graph through
@@ -158,16 +160,17 @@ class _RenderRaysFn(torch.autograd.Function):
         return (go, gd) + (None,) * 6
 
 
-def _check_test_time(kw, ndc, c2w_staticcam, use_viewdirs):
+def _check_test_time(kw, ndc, c2w_staticcam, use_viewdirs, training=False):
     bad = []
     if ndc:
         bad.append("ndc=True (LLFF forward-facing rays)")
-    if not kw.get('test_time', False):
-        bad.append("test_time=False (training-mode extras rgb0/beta/transient_sigmas)")
-    if float(kw.get('perturb', 0.) or 0.) > 0.:
-        bad.append("perturb>0 (stratified jitter)")
-    if float(kw.get('raw_noise_std', 0.) or 0.) != 0.:
-        bad.append("raw_noise_std!=0")
+    if not training:
+        if not kw.get('test_time', False):
+            bad.append("test_time=False without a trainer (render kwargs must come from create_nerf with gradient updates enabled)")
+        if float(kw.get('perturb', 0.) or 0.) > 0.:
+            bad.append("perturb>0 at test time")
+        if float(kw.get('raw_noise_std', 0.) or 0.) != 0.:
+            bad.append("raw_noise_std!=0 at test time")
     if kw.get('white_bkgd', False):
         bad.append("white_bkgd")
     if kw.get('lindisp', False):
@@ -191,6 +194,29 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     or a stacked [2,N,3] tensor), outputs shaped like rays_d[..., :1].  `img_idx`: the 10-bin histogram
     index vector, shape [10], [1,10] or [N,10]."""
     eng = _engine_of(kwargs)
+    trainer = getattr(kwargs.get('network_query_fn'), 'trainer', None)
+    if not kwargs.get('test_time', False) and trainer is not None:
+        # training mode (rendering.py:245-337 with test_time=False): stratified depths, coarse rgb + noise, importance sampling
+        # with random u, the training extras — on the exact-fp32 training kernels, attached to autograd (nerf_train.py)
+        _check_test_time(kwargs, ndc, c2w_staticcam, use_viewdirs, training=True)
+        from . import nerf_train
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if c2w is not None:
+            rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w, dtype=torch.float32, device=dev))
+        else:
+            rays_o, rays_d = rays
+        rays_o = torch.as_tensor(rays_o, dtype=torch.float32, device=dev)
+        rays_d = torch.as_tensor(rays_d, dtype=torch.float32, device=dev)
+        lead = list(rays_d.shape[:-1])
+        hist = torch.as_tensor(img_idx, dtype=torch.float32, device=dev).reshape(-1, eng.hist_bin)
+        rgb, disp, acc, extras = nerf_train.render_train(trainer, rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), hist, int(kwargs['N_samples']),
+                                                         int(kwargs['N_importance']), near, far, float(kwargs.get('perturb', 0.) or 0.),
+                                                         float(kwargs.get('raw_noise_std', 0.) or 0.), bool(kwargs.get('retraw', False)),
+                                                         draws=kwargs.get('draws'))
+        extras = {k: v.reshape(lead + list(v.shape[1:])) for k, v in extras.items()}
+        getattr(kwargs.get('network_query_fn'), '__dict__', {}).update(stale=True)
+        return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), extras]
+    kwargs.get('network_query_fn').refresh() if hasattr(kwargs.get('network_query_fn'), 'refresh') else None
     _check_test_time(kwargs, ndc, c2w_staticcam, use_viewdirs)
     def _needs_grad(t):
         if torch.is_tensor(t):

@@ -54,7 +54,7 @@ typedef struct dfn_nerfh_s* dfn_nerfh_t;
 
 typedef struct {
   int depth;          /* args.netdepth        (8)    */
-  int width;          /* args.netwidth        (128)  */
+  int width;          /* args.netwidth        (128: register-resident kernels; other even widths: generic path) */
   int multires;       /* args.multires        (10)   */
   int multires_views; /* args.multires_views  (4)    */
   int hist_bin;       /* args.hist_bin        (10)   */
@@ -332,6 +332,73 @@ int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* par
  * for dfn_dfnet_refresh_train_params_device. */
 int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* params, int n_params, int prec_mask,
                                          void* stream);
+
+/* ------------------------------------------------------------------ NeRF-H training path
+ * One optimisation step of run_nerf.py:50-66 — render(**render_kwargs_train) -> NerfWLoss -> loss.backward() — as
+ * three calls: dfn_nerfh_train_forward, dfn_nerfw_loss, dfn_nerfh_train_backward.  Both networks run layer by layer
+ * on exact-fp32 MFMA products over activations kept in the caller's workspace; the parameters are read IN PLACE
+ * from the caller's fp32 device tensors (torch's master weights, row-major [out, in]) and the gradients are written
+ * to the caller's gradient tensors, so an optimizer step needs no re-pack.  Works for any even netwidth.
+ *
+ * `params` / `grads`: HOST arrays of dfn_nerfh_train_param_count() DEVICE pointers in the order of
+ * dfn_nerfh_train_param_name(i): "coarse.<key>" (24: xyz_encoding_1..8.0, xyz_encoding_final, dir_encoding.0,
+ * static_sigma.0, static_rgb.0 — weight then bias), "fine.<key>" (38: the same + transient_encoding.0/2/4/6,
+ * transient_sigma.0, transient_rgb.0, transient_beta.0), "embedding_a.weight", "embedding_t.weight"
+ * (state_dict order of models/nerfw.py:259-295). */
+int dfn_nerfh_train_param_count(void);
+const char* dfn_nerfh_train_param_name(int i);
+size_t dfn_nerfh_train_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni);
+
+/* models/rendering.py:245-337 render_rays with test_time=False (lindisp=False, white_bkgd=False) on caller rays
+ * (run_nerf.py:50).  The reference's three random draws are INPUTS: t_rand [n_rays, Nc] = torch.rand (stratified
+ * jitter, rendering.py:277-285; NULL = perturb 0), noise [n_rays, Nc] = torch.randn (x raw_noise_std, coarse alpha,
+ * rendering.py:173; NULL = none), u [n_rays, Ni] = torch.rand (sample_pdf, rendering.py:35; NULL = linspace).
+ * Outputs: rgb [n,3], disp, acc [n], raw [n, Nc+Ni, 9] (`retraw`; transient_sigmas = raw[..., 7]) and the training
+ * extras rgb0 [n,3], disp0, acc0, z_std, beta [n] (rendering.py:323-329).  The workspace keeps every activation for
+ * dfn_nerfh_train_backward. */
+int dfn_nerfh_train_forward(dfn_nerfh_t h, const float* const* params, const float* rays_o, const float* rays_d,
+                            const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far,
+                            const float* t_rand, const float* noise, float raw_noise_std, const float* u, float* rgb,
+                            float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
+                            float* beta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* models/losses.py:19-57 NerfWLoss(coef, lambda_u) on (rgb_fine, rgb_coarse, beta, transient_sigmas = raw[..., 7])
+ * vs target [n,3].  loss5 (device, 5 floats): c_l, f_l, b_l, s_l, then the PSNR of rgb (run_nerf.py:62-64).
+ * Gradients of sum(loss): g_rgb [n,3], g_rgb0 [n,3], g_beta [n]; d / d transient_sigma is the constant
+ * coef * lambda_u / (n * Nf) per sample (pass it to dfn_nerfh_train_backward as g_tsigma). */
+int dfn_nerfw_loss(const float* rgb, const float* rgb0, const float* beta, const float* raw, const float* target,
+                   size_t n_rays, int Nf, float coef, float lambda_u, float* loss5, float* g_rgb, float* g_rgb0,
+                   float* g_beta, void* stream);
+
+/* loss.backward() of the step (run_nerf.py:65): from d L / d rgb, d L / d rgb0, d L / d beta and the constant d L / d
+ * transient_sigma to the gradient of EVERY parameter of both networks and both embedding tables (z_samples.detach(),
+ * rendering.py:302, cuts the sampler).  Must follow dfn_nerfh_train_forward on the same workspace, rays and draws;
+ * `raw` is that call's output.  d L / d transient_sigma = g_tsigma (constant) + g_tsigma_dense [n, Nf] (may be NULL).
+ * Gradients are overwritten (not accumulated). */
+int dfn_nerfh_train_backward(dfn_nerfh_t h, const float* const* params, const float* hist, size_t hist_rows, size_t n_rays,
+                             int Nc, int Ni, const float* noise, float raw_noise_std, const float* raw, const float* g_rgb,
+                             const float* g_rgb0, const float* g_beta, float g_tsigma, const float* g_tsigma_dense,
+                             float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Test-time render_rays for ANY netwidth on the same layer-by-layer exact-fp32 path (the register-resident kernels
+ * behind dfn_render_rays are specialised for netwidth 128): models/rendering.py:245-337 with test_time=True, from
+ * the handle's committed parameters.  raw [n_rays, Nc+Ni, 9] is required (output and scratch). */
+size_t dfn_nerfh_generic_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni);
+int dfn_nerfh_generic_render_rays(dfn_nerfh_t h, const float* rays_o, const float* rays_d, const float* hist, size_t hist_rows,
+                                  size_t n_rays, int Nc, int Ni, float near, float far, float* rgb, float* disp, float* acc,
+                                  float* raw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The three fp32-MFMA products of the training path, for parity tests (torch.nn.functional.linear and its autograd):
+ *   y[p, n]  = act(sum_k x[p / x_row_div, k] w[n, wcol + k] + b[n])   act: 0 none, 1 ReLU, 2 Sigmoid, 3 Softplus
+ *   dx[p, k] = sum_n g[p, n] w[n, wcol + k]   (+ dx if accumulate; zeroed where relu_src[p, k] <= 0 if relu_src)
+ *   dw[n, wcol + k] = sum_p g[p, n] x[p / x_row_div, k];  db[n] = sum_p g[p, n] (db may be NULL) */
+int dfn_linear_forward(const float* x, int ldx, int K, const float* w, int ldw, int wcol, const float* b, int N, int act,
+                       float* y, int ldy, size_t n_points, int x_row_div, void* stream);
+int dfn_linear_backward_input(const float* g, int ldg, int N, const float* w, int ldw, int wcol, int K, float* dx, int lddx,
+                              int accumulate, const float* relu_src, int ld_relu, size_t n_points, void* stream);
+size_t dfn_linear_backward_weight_scratch_bytes(int N, int K, size_t n_points);
+int dfn_linear_backward_weight(const float* g, int ldg, int N, const float* x, int ldx, int K, int x_row_div, float* dw, int ldw,
+                               int wcol, float* db, void* scratch, size_t n_points, void* stream);
 
 /* Timing aid for bench.py: average device time in ms of the `which` kernel of the render path
  * (DFN_PROF_*) over the launches since the last reset, measured with HIP events recorded on the

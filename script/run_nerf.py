@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""Drop-in for the reference's script/run_nerf.py on the MI355X render path.
+"""Drop-in for the reference's script/run_nerf.py on the MI355X path.
 
-    python run_nerf.py --config config_nerfh.txt --render_test
+    python run_nerf.py --config config_nerfh.txt [--render_test]
 
-Same flags and config files (dfnet_amd/options.py), same output tree
-(`<basedir>/<expname>/evaluate_{train,val}_test_<step>/NNN.png`, `args.txt`, `config.txt`).
-Single GPU: run as is.  Multi-GPU (frames of render_path sharded over ranks, one RCCL gather):
+Same flags and config files (dfnet_amd/options.py), same output tree (`<basedir>/<expname>/{:06d}.tar` checkpoints in the
+reference's format, `evaluate_{train,val}_test_<step>/NNN.png`, `trainset_/testset_<epoch>` renders, `args.txt`, `config.txt`).
+Without --render_test it trains NeRF-H as run_nerf.py:32-80,127-240 does: per training image N_rand random rays ->
+render(**render_kwargs_train) -> NerfWLoss -> backward -> Adam -> exponential lr decay, every network product and every
+gradient on the HIP training kernels (dfnet_amd/nerf_train.py); validation renders use the packed test-time engine.
+Single GPU: run as is.  Multi-GPU (one process per GPU; training images of an epoch dealt round-robin to the ranks with
+one flat gradient all-reduce per step over RCCL, frames of render_path sharded with one gather):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run_nerf.py ...
-The optimisation loop of the reference (run_nerf.py:32-80,127-240) is not part of the hot path and
-is not implemented: without --render_test this script stops with a clear message.
 """
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -20,12 +23,64 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 from dfnet_amd import dist as ddist  # noqa: E402
 from dfnet_amd.datasets import load_7Scenes_dataloader_NeRF, load_Cambridge_dataloader_NeRF  # noqa: E402
+from dfnet_amd.losses import loss_dict  # noqa: E402
 from dfnet_amd.nerfw import create_nerf  # noqa: E402
 from dfnet_amd.options import config_parser  # noqa: E402
-from dfnet_amd.rendering import render_test  # noqa: E402
+from dfnet_amd.ray_utils import get_rays  # noqa: E402
+from dfnet_amd.rendering import render_path, render_test  # noqa: E402
+
+
+def train_on_epoch_nerfw(args, train_dl, H, W, focal, N_rand, optimizer, loss_func, global_step, render_kwargs_train):
+    """run_nerf.py:32-80.  One step per training image: N_rand rays without replacement (np.random.choice, as the reference),
+    the fused HIP step (forward, NerfWLoss, every gradient), Adam, lr decay.  Returns the last (loss, psnr)."""
+    device = torch.device("cuda", torch.cuda.current_device())
+    trainer = render_kwargs_train['network_query_fn'].trainer
+    rank, world = ddist.rank_world()
+    loss = psnr = None
+    for batch_idx, (target, pose, img_idx) in enumerate(train_dl):
+        select_inds = np.random.choice(H * W, size=[N_rand], replace=False) if N_rand is not None else np.arange(H * W)
+        if batch_idx % world != rank:
+            continue   # the draw above keeps every rank's generator in step
+        target = target[0].permute(1, 2, 0).to(device)
+        pose = pose.reshape(3, 4).to(device)
+        rays_o, rays_d = get_rays(H, W, focal, pose)
+        sel = torch.from_numpy(select_inds).to(device)
+        rays_o, rays_d = rays_o.reshape(-1, 3)[sel], rays_d.reshape(-1, 3)[sel]
+        target_s = target.reshape(-1, 3)[sel]
+        loss_d, psnr, _ = trainer.train_step(rays_o, rays_d, img_idx.to(device), target_s, args.N_samples, args.N_importance,
+                                             render_kwargs_train['near'], render_kwargs_train['far'], perturb=float(args.perturb),
+                                             raw_noise_std=float(args.raw_noise_std), coef=loss_func.coef, lambda_u=loss_func.lambda_u)
+        loss = sum(loss_d.values())
+        ddist.allreduce_gradients(trainer.params)
+        optimizer.step()
+        render_kwargs_train['network_query_fn'].stale = True
+        # NOTE: IMPORTANT!  update learning rate (run_nerf.py:70-76)
+        decay_rate = 0.1
+        decay_steps = args.lrate_decay * 1000
+        new_lrate = args.lrate * (decay_rate ** (global_step / decay_steps))
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = new_lrate
+    return loss, psnr
+
+
+def _holdout(dl, device, skip=1):
+    imgs, poses, idxs = [], [], []
+    for batch_idx, (img, pose, img_idx) in enumerate(dl):
+        if batch_idx % skip != 0:
+            continue
+        imgs.append(img.permute(0, 2, 3, 1))
+        p = torch.zeros(1, 4, 4)
+        p[0, :3, :4] = pose.reshape(3, 4)[:3, :4]
+        p[0, 3, 3] = 1.
+        poses.append(p)
+        idxs.append(img_idx)
+    return torch.cat(imgs, 0).cpu().numpy(), torch.cat(poses, 0).to(device), torch.cat(idxs, 0).to(device)
 
 
 def train_nerf(args, train_dl, val_dl, hwf, i_split, near, far, render_poses=None, render_img=None):
+    H, W, focal = hwf
+    H, W = int(H), int(W)
+    hwf = [H, W, focal]
     basedir, expname = args.basedir, args.expname
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     os.makedirs(os.path.join(basedir, expname), exist_ok=True)
@@ -37,6 +92,7 @@ def train_nerf(args, train_dl, val_dl, hwf, i_split, near, far, render_poses=Non
             with open(os.path.join(basedir, expname, 'config.txt'), 'w') as fh:
                 fh.write(open(args.config, 'r').read())
     render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer = create_nerf(args)
+    global_step = start
     bds = {'near': near, 'far': far}
     render_kwargs_train.update(bds)
     render_kwargs_test.update(bds)
@@ -45,9 +101,42 @@ def train_nerf(args, train_dl, val_dl, hwf, i_split, near, far, render_poses=Non
         print('VAL views are', i_split[1])
         render_test(args, train_dl, val_dl, hwf, start, render_kwargs_test)
         return
-    raise NotImplementedError(
-        "NeRF-H optimisation (run_nerf.py without --render_test) is outside the render hot path and not "
-        "implemented here; train with the reference and render with this tool (checkpoints load unchanged).")
+    if optimizer is None:
+        raise ValueError("--no_grad_update without --render_test: nothing to do")
+    device = torch.device("cuda", torch.cuda.current_device())
+    N_rand = args.N_rand
+    N_epoch = args.epochs + 1
+    print('Begin')
+    print('TRAIN views are', i_split[0])
+    print('VAL views are', i_split[1])
+    loss_func = loss_dict['nerfw'](coef=1)
+    for i in range(start, N_epoch):
+        time0 = time.time()
+        loss, psnr = train_on_epoch_nerfw(args, train_dl, H, W, focal, N_rand, optimizer, loss_func, global_step, render_kwargs_train)
+        dt = time.time() - time0
+        if i % args.i_weights == 0 and i != 0 and rank == 0:
+            path = os.path.join(basedir, expname, '{:06d}.tar'.format(i))
+            torch.save({
+                'global_step': global_step,
+                'network_fn_state_dict': render_kwargs_train['network_fn'].state_dict(),
+                'network_fine_state_dict': render_kwargs_train['network_fine'].state_dict(),
+                'embedding_a_state_dict': render_kwargs_train['embedding_a'].state_dict(),
+                'embedding_t_state_dict': render_kwargs_train['embedding_t'].state_dict(),
+                'optimizer_state_dict': optimizer.state_dict(),
+            }, path)
+            print('Saved checkpoints at', path)
+        if i % args.i_testset == 0 and i > 0:
+            with torch.no_grad():
+                for tag, dl, skip in (('trainset', train_dl, 10), ('testset', val_dl, 1)):
+                    savedir = os.path.join(basedir, expname, '{}_{:06d}'.format(tag, i))
+                    os.makedirs(savedir, exist_ok=True)
+                    images, poses, index = _holdout(dl, device, skip)
+                    print(tag, 'poses shape', poses.shape)
+                    render_path(args, poses, hwf, args.chunk, render_kwargs_test, gt_imgs=images, savedir=savedir, img_ids=index)
+                    print('Saved', tag)
+        if i % args.i_print == 0 and rank == 0 and loss is not None:
+            print(f"[TRAIN] Iter: {i} Loss: {loss.item()}  PSNR: {psnr.item()}  ({dt:.2f} s / epoch)")
+        global_step += 1
 
 
 def main(argv=None):

@@ -28,12 +28,29 @@ def test_header_symbols_exported_and_bound():
     assert lib.dfn_abi_version() == 1
 
 
-def test_create_rejects_unsupported_width():
+def test_create_width_rules():
+    """netwidth 128 = the register-resident kernels; any other even width is accepted (generic layer-by-layer path);
+    odd widths and other depths / encodings are refused loudly."""
     lib = _lib.load()
     h = ctypes.c_void_p()
     d = _lib.NerfhDesc(8, 256, 10, 4, 10, 5, 2, 1000)
-    rc = lib.dfn_nerfh_create(ctypes.byref(d), ctypes.byref(h))
-    assert rc == -4 and b"netwidth" in lib.dfn_last_error()
+    assert lib.dfn_nerfh_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    assert lib.dfn_nerfh_destroy(h) == 0
+    for bad in (_lib.NerfhDesc(8, 127, 10, 4, 10, 5, 2, 1000), _lib.NerfhDesc(6, 128, 10, 4, 10, 5, 2, 1000),
+                _lib.NerfhDesc(8, 128, 8, 4, 10, 5, 2, 1000)):
+        assert lib.dfn_nerfh_create(ctypes.byref(bad), ctypes.byref(h)) == -4 and b"dfn_nerfh_create" in lib.dfn_last_error()
+
+
+def test_train_param_table_matches_state_dict_order():
+    """dfn_nerfh_train_param_name() is the order of the params / grads pointer arrays: the state_dict order of both
+    networks (models/nerfw.py:259-295) then the two embedding tables."""
+    from dfnet_amd import synthetic as syn
+    lib = _lib.load()
+    n = lib.dfn_nerfh_train_param_count()
+    names = [lib.dfn_nerfh_train_param_name(i).decode() for i in range(n)]
+    cw, fw, _, _ = syn.nerfh_weights(0)
+    assert names == ["coarse." + k for k in cw] + ["fine." + k for k in fw] + ["embedding_a.weight", "embedding_t.weight"]
+    assert lib.dfn_nerfh_train_param_name(n) is None
 
 
 def test_set_param_validation_and_commit_needs_all_params():

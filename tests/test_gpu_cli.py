@@ -99,6 +99,42 @@ def test_run_nerf_reloads_reference_checkpoint(tmp_path):
     assert int(np.abs(got.astype(int) - want.astype(int)).max()) <= 1
 
 
+def test_run_nerf_training_cli(tmp_path):
+    """run_nerf.py WITHOUT --render_test: the NeRF-H optimisation loop (run_nerf.py:32-80,127-240) for three epochs on the
+    synthetic tree — every step on the HIP training kernels — then checkpoints in the reference's format, a validation
+    render with the re-packed test-time engine, and a --render_test run that reloads the newest checkpoint."""
+    datadir = make_scene(str(tmp_path), n_train=3, n_val=1, H=240, W=320)
+    basedir = str(tmp_path / "logs")
+    cli = ["--config", os.path.join(ROOT, "script", "config_nerfh.txt"), "--datadir", datadir, "--basedir", basedir,
+           "--N_samples", "16", "--N_importance", "32", "--testskip", "1", "--trainskip", "1", "--N_rand", "512", "--epochs", "2",
+           "--i_weights", "1", "--i_testset", "2", "--i_print", "1", "--lrate", "1e-3"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "script", "run_nerf.py")] + cli, cwd=os.path.join(ROOT, "script"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("[TRAIN] Iter")]
+    assert len(lines) == 3 and all("nan" not in l for l in lines), r.stdout[-2000:]
+    losses = [float(l.split("Loss: ")[1].split()[0]) for l in lines]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses   # 9 Adam steps at lr 1e-3 on 3 images
+    out = os.path.join(basedir, "nerfh")
+    for k in (1, 2):
+        ck = torch.load(os.path.join(out, f"{k:06d}.tar"), map_location="cpu")
+        assert sorted(ck) == sorted(['global_step', 'network_fn_state_dict', 'network_fine_state_dict', 'embedding_a_state_dict',
+                                     'embedding_t_state_dict', 'optimizer_state_dict'])
+        assert "xyz_encoding_5.0.weight" in ck['network_fn_state_dict'] and "transient_beta.0.bias" in ck['network_fine_state_dict']
+    assert os.path.exists(os.path.join(out, "testset_000002", "000.png")) and os.path.exists(os.path.join(out, "trainset_000002", "000_GT.png"))
+    # the trained weights differ from the initialisation, and the validation render used them (engine re-packed after training)
+    from dfnet_amd.nerfw import NeRFW
+    torch.manual_seed(0)
+    torch.nn.Embedding(1000, 5), torch.nn.Embedding(1000, 2)
+    init = NeRFW('coarse', D=8, W=128, skips=[4], in_channels_xyz=63, in_channels_dir=27).state_dict()
+    ck = torch.load(os.path.join(out, "000002.tar"), map_location="cpu")
+    assert float((ck['network_fn_state_dict']["xyz_encoding_1.0.weight"] - init["xyz_encoding_1.0.weight"]).abs().max()) > 1e-4
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "script", "run_nerf.py")] + cli + ["--render_test"],
+                        cwd=os.path.join(ROOT, "script"), capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert "000002.tar" in r2.stdout and os.path.isdir(os.path.join(out, "evaluate_val_test_000002"))
+
+
 def test_run_feature_render_feature_only_cli(tmp_path):
     """run_feature.py --render_feature_only on the synthetic tree: NeRF-H quarter-res renders + bicubic x4,
     siamese DFNet forward, feature PNGs written."""

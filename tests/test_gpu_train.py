@@ -1,0 +1,251 @@
+"""NeRF-H training path on the GPU and the generic-width render path: the three fp32-MFMA products
+against torch, training-mode render_rays against the reference's outputs (G12), one optimisation step against the
+reference's losses and gradients (G13) and against autograd through the oracle at a larger size, the autograd surface
+of rendering.render(**render_kwargs_train), and netwidth 32 / 256 renders against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from dfnet_amd import _lib, engine as eng, nerf_train, synthetic as syn
+from dfnet_amd._lib import check, current_stream, ptr
+from oracle import nerfh_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+T = torch.from_numpy
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def relmax(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def modules(W=128, seed=0):
+    """(engine, coarse, fine, emb_a, emb_t modules on the GPU, numpy weights) with seeded weights."""
+    from dfnet_amd.nerfw import NeRFW
+    cw, fw, ea, et = syn.nerfh_weights(seed, W=W)
+    coarse = NeRFW('coarse', D=8, W=W, skips=[4], in_channels_xyz=63, in_channels_dir=27)
+    fine = NeRFW('fine', D=8, W=W, skips=[4], in_channels_xyz=63, in_channels_dir=27, encode_appearance=True, encode_transient=True,
+                 in_channels_a=50, in_channels_t=20)
+    coarse.load_state_dict({k: T(v) for k, v in cw.items()})
+    fine.load_state_dict({k: T(v) for k, v in fw.items()})
+    emb_a, emb_t = torch.nn.Embedding(1000, 5), torch.nn.Embedding(1000, 2)
+    emb_a.weight.data.copy_(T(ea))
+    emb_t.weight.data.copy_(T(et))
+    mods = [m.to(DEV) for m in (coarse, fine, emb_a, emb_t)]
+    E = eng.NerfHEngine(width=W, precision="f32").load_numpy(cw, fw, ea, et)
+    return E, mods, (cw, fw, ea, et)
+
+
+# ---------------------------------------------------------------------------------------------- the three products
+@pytest.mark.parametrize("P,K,N,ldw,wcol,div,act", [
+    (1000, 63, 128, 63, 0, 1, 1), (777, 128, 128, 191, 63, 1, 1), (4096, 128, 1, 128, 0, 1, 3), (300, 64, 3, 64, 0, 1, 2),
+    (960, 77, 64, 205, 128, 48, 0), (129, 256, 256, 256, 0, 1, 1), (64, 16, 16, 16, 0, 1, 0), (515, 20, 64, 148, 128, 5, 1)])
+def test_linear_products_vs_torch(P, K, N, ldw, wcol, div, act):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(P + K + N)
+    rows = (P + div - 1) // div
+    ldx = K + 3
+    x = torch.randn(rows, ldx, generator=g)
+    w = torch.randn(N, ldw, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    xe = x[:, :K].repeat_interleave(div, 0)[:P]
+    pre = xe.double() @ w[:, wcol:wcol + K].double().T + b.double()
+    ref = {0: pre, 1: pre.relu(), 2: torch.sigmoid(pre), 3: torch.nn.functional.softplus(pre)}[act]
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    ldy = N + 2
+    y = torch.zeros(P, ldy, device=DEV)
+    check(lib.dfn_linear_forward(ptr(xd), ldx, K, ptr(wd), ldw, wcol, ptr(bd), N, act, ptr(y), ldy, P, div, current_stream()), "fwd")
+    assert relmax(y[:, :N], ref) < 5e-6
+    assert float(y[:, N:].abs().max()) == 0.0   # nothing written outside the N columns
+    # data gradient with accumulate + ReLU mask
+    G = torch.randn(P, N + 1, generator=g)
+    base = torch.randn(P, K, generator=g)
+    msrc = torch.randn(P, K, generator=g)
+    want = (G[:, :N].double() @ w[:, wcol:wcol + K].double() + base.double()) * (msrc > 0)
+    dx = base.clone().to(DEV)
+    Gd = G.to(DEV)
+    check(lib.dfn_linear_backward_input(ptr(Gd), N + 1, N, ptr(wd), ldw, wcol, K, ptr(dx), K, 1, ptr(msrc.to(DEV)), K, P, current_stream()), "bwd")
+    assert relmax(dx, want) < 5e-6
+    # weight gradient (+ bias), into a column window of a wider dW
+    dw = torch.full((N, ldw), 7.0, device=DEV)
+    db = torch.empty(N, device=DEV)
+    scratch = torch.empty(lib.dfn_linear_backward_weight_scratch_bytes(N, K, P), dtype=torch.uint8, device=DEV)
+    check(lib.dfn_linear_backward_weight(ptr(Gd), N + 1, N, ptr(xd), ldx, K, div, ptr(dw), ldw, wcol, ptr(db),
+                                         ctypes.c_void_p(scratch.data_ptr()), P, current_stream()), "wgrad")
+    want_w = G[:, :N].double().T @ xe.double()
+    assert relmax(dw[:, wcol:wcol + K], want_w) < 5e-6
+    assert relmax(db, G[:, :N].double().sum(0)) < 5e-6
+    keep = torch.ones(ldw, dtype=torch.bool)
+    keep[wcol:wcol + K] = False
+    assert bool((dw.cpu()[:, keep] == 7.0).all())   # other columns untouched
+
+
+# ---------------------------------------------------------------------------------------------- G12 / G13
+def _g12_inputs(g):
+    o, d = T(g["rays_o"]).to(DEV), T(g["rays_d"]).to(DEV)
+    return o, d, T(g["hist"]).to(DEV), int(g["Nc"]), int(g["Ni"]), T(g["t_rand"]).to(DEV), T(g["noise"]).to(DEV), T(g["u"]).to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_train_forward_vs_reference_golden(gold, tag):
+    """Training-mode render_rays on the HIP path against the REFERENCE's outputs and extras (G12), fed the reference's
+    recorded random draws."""
+    g = gold(f"g12_render_train_{tag}")
+    E, mods, _ = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    o, d, hist, Nc, Ni, t_rand, noise, u = _g12_inputs(g)
+    out = tr.forward(o, d, hist, Nc, Ni, 0., 2.5, t_rand, noise, float(g["raw_noise_std"]), u)
+    for k_ref, k in (("rgb", "rgb_map"), ("disp", "disp_map"), ("acc", "acc_map"), ("raw", "raw"), ("rgb0", "rgb0"), ("disp0", "disp0"),
+                     ("acc0", "acc0"), ("z_std", "z_std"), ("transient_sigmas", "transient_sigmas"), ("beta", "beta")):
+        e = relmax(out[k], T(g[k_ref]))
+        assert e < 3e-5, (k, e)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_train_step_vs_reference_golden(gold, tag):
+    """One optimisation step (forward, fused NerfWLoss, backward) against the reference's loss terms, PSNR and the
+    gradient digests of every parameter (G13)."""
+    g12, g = gold(f"g12_render_train_{tag}"), gold(f"g13_train_step_{tag}")
+    E, mods, _ = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    o, d, hist, Nc, Ni, t_rand, noise, u = _g12_inputs(g12)
+    ld, psnr, _ = tr.train_step(o, d, hist, T(g["target"]).to(DEV), Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=float(g12["raw_noise_std"]),
+                                draws=(t_rand, noise, u))
+    for k in ("c_l", "f_l", "b_l", "s_l"):
+        assert abs(float(ld[k]) - float(g["loss_" + k])) <= 3e-5 * abs(float(g["loss_" + k])) + 1e-7, k
+    assert abs(float(psnr) - float(g["psnr"][0])) < 1e-4
+    worst = 0.0
+    for name, p in zip(tr.names, tr.params):
+        flat = p.grad.reshape(-1).cpu()
+        gn = float(g["gn:" + name])
+        assert abs(float(flat.norm()) - gn) <= 2e-4 * gn + 1e-12, name
+        samp = flat[:: max(1, flat.numel() // 256)][:256]
+        err = float((samp - T(g["gs:" + name])).abs().max()) / (gn / np.sqrt(flat.numel()) + 1e-30)
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)   # sample error relative to the tensor's RMS gradient
+    rows = T(g["emb_rows"])
+    assert relmax(mods[2].weight.grad.cpu()[rows], T(g["ga_rows"])) < 2e-4
+    assert relmax(mods[3].weight.grad.cpu()[rows], T(g["gt_rows"])) < 2e-4
+    print(f"G13-{tag}: worst sampled gradient error / RMS {worst:.2e}")
+
+
+def test_train_step_vs_oracle_autograd_c2_samples():
+    """A 256-ray step at the judged 64+128 samples with per-ray histograms, raw_noise_std 1: every gradient tensor against
+    autograd through the oracle (relative L2), and determinism of the step."""
+    E, mods, (cw, fw, ea, et) = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    R, Nc, Ni = 256, 64, 128
+    rng = np.random.default_rng(5)
+    ro, rd = orc.get_rays(480, 640, 585.0, T(syn.orbit_pose(4, 8))[:3, :4])
+    sel = rng.choice(480 * 640, R, replace=False)
+    o, d = ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous()
+    hist = T(rng.integers(0, 40, (R, 10)).astype(np.float32))
+    target = T(rng.uniform(0, 1, (R, 3)).astype(np.float32))
+    gen = torch.Generator().manual_seed(9)
+    t_rand, noise, u = torch.rand(R, Nc, generator=gen), torch.randn(R, Nc, generator=gen), torch.rand(R, Ni, generator=gen)
+    rows = torch.cat([o, d, torch.zeros(R, 1), torch.full((R, 1), 2.5), d / d.norm(dim=-1, keepdim=True), hist], 1)
+    c, f = {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}
+    ld_ref, ps_ref, g_ref, out_ref = orc.train_step(rows, target, c, f, T(ea), T(et), Nc, Ni, t_rand, noise, u, perturb=1., raw_noise_std=1.)
+    draws = tuple(t.to(DEV) for t in (t_rand, noise, u))
+    ld, psnr, out = tr.train_step(o.to(DEV), d.to(DEV), hist.to(DEV), target.to(DEV), Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=1., draws=draws)
+    for k in ld:
+        assert abs(float(ld[k]) - float(ld_ref[k])) <= 3e-5 * abs(float(ld_ref[k])) + 1e-7, k
+    assert relmax(out["rgb_map"], out_ref["rgb_map"]) < 3e-5 and relmax(out["beta"], out_ref["beta"]) < 3e-5
+    worst, first = 0.0, {}
+    for name, p in zip(tr.names, tr.params):
+        e = rel_l2(p.grad, g_ref[name])
+        worst = max(worst, e)
+        first[name] = p.grad.clone()
+        assert e < 1e-4, (name, e)
+    print(f"train step vs oracle autograd, 256 rays @ 64+128: worst relative L2 over {len(tr.names)} gradients {worst:.2e}")
+    tr.train_step(o.to(DEV), d.to(DEV), hist.to(DEV), target.to(DEV), Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=1., draws=draws)
+    for name, p in zip(tr.names, tr.params):   # fixed-order reductions: bit-identical except the atomically scattered tables
+        if name.startswith("embedding"):
+            assert rel_l2(p.grad, first[name]) < 1e-6
+        else:
+            assert torch.equal(p.grad, first[name]), name
+
+
+def test_render_training_autograd_surface_and_optimizer_step():
+    """rendering.render(**render_kwargs_train) returns tensors attached to autograd: the reference's loop shape
+    (NerfWLoss on the extras, loss.backward(), Adam step; run_nerf.py:50-66) produces the gradients of the fused
+    train_step, and a step changes the training render."""
+    from dfnet_amd import losses, rendering
+    from dfnet_amd.nerfw import HipQuery
+    E, mods, _ = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    R, Nc, Ni = 96, 16, 32
+    rng = np.random.default_rng(6)
+    ro, rd = orc.get_rays(480, 640, 585.0, T(syn.orbit_pose(6, 8))[:3, :4])
+    sel = rng.choice(480 * 640, R, replace=False)
+    o, d = ro.reshape(-1, 3)[sel].contiguous().to(DEV), rd.reshape(-1, 3)[sel].contiguous().to(DEV)
+    hist, target = T(syn.HIST_IDX)[None].to(DEV), T(rng.uniform(0, 1, (R, 3)).astype(np.float32)).to(DEV)
+    draws = nerf_train.NerfHTrainer.draw(R, Nc, Ni, 1., DEV, torch.Generator(device=DEV).manual_seed(3))
+    ld, _, _ = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+    fused = [p.grad.clone() for p in tr.params]
+    kw = dict(network_query_fn=HipQuery(E, trainer=tr), perturb=1., N_importance=Ni, network_fine=mods[1], N_samples=Nc, network_fn=mods[0],
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., embedding_a=mods[2], embedding_t=mods[3], test_time=False, ndc=False,
+              lindisp=False, near=0., far=2.5)
+    opt = torch.optim.Adam(tr.params, lr=5e-4)
+    opt.zero_grad()
+    rgb, disp, acc, extras = rendering.render(480, 640, 585.0, rays=torch.stack([o, d], 0), retraw=True, img_idx=hist, draws=draws, **kw)
+    assert sorted(extras) == sorted(["raw", "rgb0", "disp0", "acc0", "z_std", "transient_sigmas", "beta"])
+    loss_d = losses.loss_dict['nerfw'](coef=1)({'rgb_fine': rgb, 'rgb_coarse': extras['rgb0'], 'beta': extras['beta'],
+                                                'transient_sigmas': extras['transient_sigmas']}, target)
+    for k in ld:
+        assert abs(float(loss_d[k]) - float(ld[k])) <= 2e-6 * abs(float(ld[k])) + 1e-8
+    sum(loss_d.values()).backward()
+    for name, p, g0 in zip(tr.names, tr.params, fused):
+        assert rel_l2(p.grad, g0) < 2e-6, name
+    before = rgb.detach().clone()
+    opt.step()
+    rgb2 = rendering.render(480, 640, 585.0, rays=torch.stack([o, d], 0), img_idx=hist, draws=draws, **kw)[0]
+    assert float((rgb2.detach() - before).abs().max()) > 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- generic-width render
+def test_generic_path_equals_fast_path_w128():
+    E, _, _ = modules()
+    rng = np.random.default_rng(8)
+    ro, rd = orc.get_rays(480, 640, 585.0, T(syn.orbit_pose(2, 8))[:3, :4])
+    sel = rng.choice(480 * 640, 300, replace=False)
+    o, d = ro.reshape(-1, 3)[sel].contiguous().to(DEV), rd.reshape(-1, 3)[sel].contiguous().to(DEV)
+    hist = T(syn.HIST_IDX).to(DEV)
+    a = E.render_rays(o, d, hist, 64, 128, 0., 2.5, retraw=True, precision="f32")
+    b = E.render_rays(o, d, hist, 64, 128, 0., 2.5, retraw=True, precision="generic")
+    for x, y in zip(a, b):
+        assert relmax(y, x) < 2e-5
+
+
+def test_w32_reference_goldens_on_the_hip_path(gold):
+    """The netwidth-32 goldens captured from the reference (G6-c render_rays incl. raw) on the generic-width path."""
+    g = gold("g6_render_rays_c")
+    cw, fw, ea, et = syn.nerfh_weights(0, W=32)
+    E = eng.NerfHEngine(width=32).load_numpy(cw, fw, ea, et)
+    assert not E.fast
+    rgb, disp, acc, raw = E.render_rays(T(g["rays_o"]).to(DEV), T(g["rays_d"]).to(DEV), T(g["hist"]).to(DEV), int(g["Nc"]), int(g["Ni"]),
+                                        float(g["near"]), float(g["far"]), retraw=True)
+    for got, k in ((rgb, "rgb"), (disp, "disp"), (acc, "acc"), (raw, "raw")):
+        assert relmax(got, T(g[k])) < 3e-5, k
+
+
+def test_w256_render_vs_oracle():
+    """netwidth 256 (SURVEY §8(d) 'also report'): image render on the generic-width path against the oracle."""
+    cw, fw, ea, et = syn.nerfh_weights(2, W=256)
+    E = eng.NerfHEngine(width=256).load_numpy(cw, fw, ea, et)
+    H, W, focal = 12, 16, 14.6
+    c2w = T(syn.orbit_pose(1, 8))
+    with torch.no_grad():
+        ref = orc.render(H, W, focal, 32768, {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}, T(ea), T(et), 64, 128,
+                         0., 2.5, syn.HIST_IDX, c2w=c2w)
+    got = E.render_image(c2w.to(DEV), H, W, focal, T(syn.HIST_IDX).to(DEV), 64, 128, 0., 2.5)
+    for a, b in zip(got, ref):
+        assert relmax(a, b) < 3e-5
