@@ -106,10 +106,170 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(FwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ LDS-staged form of both products
+// C[p, m] = sum_c A[p, c] Bs[m, c]: the weight slab Bs (forward: rows = outputs, columns = the concatenated inputs; data
+// gradient: rows = inputs k, columns = outputs n, i.e. W transposed while it is staged) is staged ONCE per workgroup into LDS
+// and the workgroup is persistent over 128-point tiles, so the weights cost one L2 read per workgroup instead of one per wave
+// and the B operand is a conflict-free ds_read_b128 (row stride = 4 mod 32 floats).  A lane's A operand is one 16-byte load of
+// its activation row per 8 contraction elements.
+struct LdsGemmArgs {
+  Seg seg[3];          // forward: input segments; data gradient: seg[0] = {G, ldg, N, 1, 0}
+  int nseg;
+  const float* W;
+  int ldw, wcol;       // data gradient: first weight column of the K window
+  const float* b;
+  int M, act;          // rows of the slab handled in total (forward: N outputs; data gradient: K inputs)
+  float* y;
+  int ldy;
+  int accumulate;
+  const float* mask;
+  int ldmask;
+  long long P;
+  int KP;              // slab row stride (floats)
+  int bwd;
+};
+
+DFN_DEV int seg_koff(const LdsGemmArgs& a, int s) {   // column of segment s inside the slab (segments padded to multiples of 8)
+  int o = 0;
+  for (int t = 0; t < s; ++t) o += (a.seg[t].K + 7) & ~7;
+  return o;
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kh = lane >> 5;
+  const int m0 = blockIdx.y * NBLK * 32;
+  const int KP = a.KP;
+  // ---- stage the slab: rows m0 .. m0 + NBLK*32, zero padded
+  for (int e = threadIdx.x; e < NBLK * 32 * KP; e += 256) slab[e] = 0.f;
+  __syncthreads();
+  if (!a.bwd) {
+    for (int s = 0; s < a.nseg; ++s) {
+      const int K = a.seg[s].K, ko = seg_koff(a, s), wc = a.seg[s].wcol;
+      for (int e = threadIdx.x; e < NBLK * 32 * K; e += 256) {
+        const int r = e / K, k = e - r * K;
+        if (m0 + r < a.M) slab[r * KP + ko + k] = a.W[(size_t)(m0 + r) * a.ldw + wc + k];
+      }
+    }
+  } else {
+    const int N = a.seg[0].K;   // contraction = the layer's outputs; slab[kcol][n] = W[n][wcol + m0 + kcol]
+    for (int e = threadIdx.x; e < NBLK * 32 * N; e += 256) {
+      const int n = e / (NBLK * 32), r = e - n * (NBLK * 32);
+      if (m0 + r < a.M) slab[r * KP + n] = a.W[(size_t)n * a.ldw + a.wcol + m0 + r];
+    }
+  }
+  __syncthreads();
+  const long long n_tiles = (a.P + 127) / 128;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long p0 = (tile * 4 + wave) * 32;
+    if (p0 >= a.P) continue;
+    const long long row = p0 + i < a.P ? p0 + i : a.P - 1;
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+      const int m = m0 + nb * 32 + i;
+      const float bv = (a.b && m < a.M) ? a.b[m] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = bv;
+    }
+    for (int s = 0; s < a.nseg; ++s) {
+      const Seg sg = a.seg[s];
+      const float* x = sg.x + (sg.div == 1 ? row : row / sg.div) * sg.ld;
+      const int ko = seg_koff(a, s);
+      const bool vec = ((reinterpret_cast<uintptr_t>(sg.x) & 15) == 0) && (sg.ld & 3) == 0 && sg.ld >= ((sg.K + 3) & ~3);
+      const float* bl = slab + i * KP + ko + 4 * kh;
+      for (int k0 = 0; k0 < sg.K; k0 += 8) {
+        const int k = k0 + 4 * kh;
+        f32x4 av;
+        if (vec && k + 3 < ((sg.K + 3) & ~3)) {
+          av = *reinterpret_cast<const f32x4*>(x + k);
+          if (k + 3 >= sg.K) {   // the row's own padding may hold anything: zero what lies beyond K
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (k + q >= sg.K) av[q] = 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) av[q] = k + q < sg.K ? x[k + q] : 0.f;
+        }
+        f32x4 bv[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) bv[nb] = *reinterpret_cast<const f32x4*>(bl + nb * 32 * KP + k0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma32(av[q], bv[nb][q], acc[nb]);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+      const int m = m0 + nb * 32 + i;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long pt = p0 + mblock_row(kh, r);
+        if (pt >= a.P) continue;
+        float v = acc[nb][r];
+        if (a.bwd) {
+          if (a.accumulate) v += a.y[pt * a.ldy + m];
+          if (a.mask && !(a.mask[pt * a.ldmask + m] > 0.f)) v = 0.f;
+        } else {
+          v = apply_act(v, a.act);
+        }
+        a.y[pt * a.ldy + m] = v;
+      }
+    }
+  }
+}
+
+// Launch the LDS form if the slab fits; false = caller falls back to the streaming kernels above.
+static bool launch_lds_gemm(LdsGemmArgs a, int Kc_total, hipError_t& err, hipStream_t s) {
+  int KP = (Kc_total + 7) & ~7;
+  while ((KP & 31) != 4) KP += 4;
+  a.KP = KP;
+  constexpr size_t kLdsBudget = 76 * 1024;   // two workgroups per CU
+  int nblk = a.M > 64 ? 4 : (a.M > 32 ? 2 : 1);
+  while (nblk > 1 && size_t(nblk) * 32 * KP * 4 > kLdsBudget) nblk >>= 1;
+  const size_t lds = size_t(nblk) * 32 * KP * 4;
+  if (lds > 150 * 1024) return false;
+  const long long tiles = (a.P + 127) / 128;
+  const int gy = (a.M + nblk * 32 - 1) / (nblk * 32);
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  long long gx = (long long)cus * (lds > kLdsBudget ? 1 : 2) / gy;
+  if (gx < 1) gx = 1;
+  if (gx > tiles) gx = tiles;
+  auto go = [&](auto kern) {
+    if (lds > 64 * 1024) {
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (err != hipSuccess) return;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, s, a);
+    err = hipGetLastError();
+  };
+  if (nblk == 4) go(gemm_lds_kernel<4>);
+  else if (nblk == 2) go(gemm_lds_kernel<2>);
+  else go(gemm_lds_kernel<1>);
+  return true;
+}
+
 hipError_t gemm_fwd(const Seg* segs, int nseg, const float* W, int ldw, const float* b, int N, int act, float* y, int ldy,
                     long long P, hipStream_t s) {
   if (P <= 0 || N <= 0) return hipSuccess;
   if (nseg < 1 || nseg > 3) return hipErrorInvalidValue;
+  if (P >= 1024) {   // persistent LDS-staged form (the weight slab is staged once per workgroup)
+    LdsGemmArgs l{};
+    int kc = 0;
+    for (int k = 0; k < nseg; ++k) { l.seg[k] = segs[k]; kc += (segs[k].K + 7) & ~7; }
+    l.nseg = nseg; l.W = W; l.ldw = ldw; l.wcol = 0; l.b = b; l.M = N; l.act = act; l.y = y; l.ldy = ldy; l.P = P; l.bwd = 0;
+    hipError_t e = hipSuccess;
+    if (launch_lds_gemm(l, kc, e, s)) return e;
+  }
   FwdArgs a{};
   for (int k = 0; k < nseg; ++k) a.seg[k] = segs[k];
   a.nseg = nseg; a.W = W; a.ldw = ldw; a.b = b; a.N = N; a.act = act; a.y = y; a.ldy = ldy; a.P = P;
@@ -184,6 +344,14 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(BwdGemmArgs a) {
 hipError_t gemm_bwd(const float* G, int ldg, int N, const float* W, int ldw, int wcol, int K, float* dx, int lddx,
                     int accumulate, const float* mask_src, int ldmask, long long P, hipStream_t s) {
   if (P <= 0 || K <= 0) return hipSuccess;
+  if (P >= 1024) {
+    LdsGemmArgs l{};
+    l.seg[0] = Seg{G, ldg, N, 1, 0};
+    l.nseg = 1; l.W = W; l.ldw = ldw; l.wcol = wcol; l.b = nullptr; l.M = K; l.act = 0; l.y = dx; l.ldy = lddx;
+    l.accumulate = accumulate; l.mask = mask_src; l.ldmask = ldmask; l.P = P; l.bwd = 1;
+    hipError_t e = hipSuccess;
+    if (launch_lds_gemm(l, (N + 7) & ~7, e, s)) return e;
+  }
   BwdGemmArgs a{G, ldg, N, W, ldw, wcol, K, dx, lddx, accumulate, mask_src, ldmask, P};
   const unsigned gx = unsigned((P + 127) / 128);
   if (K <= 32) hipLaunchKernelGGL(gemm_bwd_kernel<1>, dim3(gx, 1), dim3(256), 0, s, a);
@@ -194,12 +362,14 @@ hipError_t gemm_bwd(const float* G, int ldg, int N, const float* W, int ldw, int
 
 // ------------------------------------------------------------------------------------------ weight gradient
 // dW = G^T X over points: A[i][kh] = G[p + kh'][n0 + i], B[kh][j] = X[p + kh'][k0 + j] — both coalesced reads of
-// point-major rows.  A wave owns one 32-row block of outputs x KBLK 32-column blocks of inputs for one chunk of
-// points; chunk partials are reduced in fixed order by wgrad_reduce_kernel (deterministic).
-constexpr int kWgradK = 4;  // 32-column blocks per wave
+// point-major rows.  A workgroup owns one 32-row block of outputs x KBLK 32-column blocks of inputs for one chunk of
+// points; its four waves take a quarter of the chunk each and are summed through LDS in fixed order; chunk partials are
+// reduced in fixed order by wgrad_reduce_kernel (deterministic).
+constexpr int kWgradK = 4;  // 32-column blocks per workgroup
+// Points per chunk (multiple of 32): ~160 chunks x items workgroups fill the chip while the partial sums stay small.
 static inline int wgrad_chunk(long long P) {
-  long long ch = 512;
-  while ((P + ch - 1) / ch > 1024) ch *= 2;
+  long long ch = 256;
+  while ((P + ch - 1) / ch > 160) ch += 256;
   return int(ch);
 }
 size_t gemm_wgrad_scratch_floats(int N, int K, long long P) {
@@ -218,14 +388,17 @@ struct WgradArgs {
 };
 
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(WgradArgs a) {
+  __shared__ float red[3][kWgradK * 16 * 64 + 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kh = lane >> 5;
-  const int item = blockIdx.y * 4 + wave;
-  if (item >= a.items) return;
+  const int item = blockIdx.y;
   const int nblk = item / a.kgroups, kg = item - nblk * a.kgroups;
   const int n0 = nblk * 32, k0 = kg * kWgradK * 32;
   const long long c0 = (long long)blockIdx.x * a.chunk;
   const long long c1 = c0 + a.chunk < a.P ? c0 + a.chunk : a.P;
+  const int sub = a.chunk / 4;                      // multiple of 8
+  const long long w0 = c0 + (long long)wave * sub;
+  const long long w1 = w0 + sub < c1 ? w0 + sub : c1;
   const int K = a.x.K;
   f32x16 acc[kWgradK];
 #pragma unroll
@@ -234,12 +407,12 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
   float bsum = 0.f;
   const bool nok = n0 + i < a.N;
-  for (long long p = c0; p < c1; p += 8) {
+  for (long long p = w0; p < w1; p += 8) {
     float av[4], bv[kWgradK][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const long long pq = p + 4 * kh + q;
-      const bool ok = pq < c1;
+      const bool ok = pq < w1;
       av[q] = (ok && nok) ? a.G[pq * a.ldg + n0 + i] : 0.f;
       bsum += av[q];
       const float* xr = a.x.x + (a.x.div == 1 ? pq : pq / a.x.div) * a.x.ld;
@@ -253,6 +426,24 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(WgradArgs a) {
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int kb = 0; kb < kWgradK; ++kb) acc[kb] = mfma32(av[q], bv[kb][q], acc[kb]);
+  }
+  if (wave > 0) {
+    float* r = red[wave - 1];
+#pragma unroll
+    for (int kb = 0; kb < kWgradK; ++kb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[(kb * 16 + q) * 64 + lane] = acc[kb][q];
+    r[kWgradK * 16 * 64 + lane] = bsum;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  for (int w = 0; w < 3; ++w) {
+    const float* r = red[w];
+#pragma unroll
+    for (int kb = 0; kb < kWgradK; ++kb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[kb][q] += r[(kb * 16 + q) * 64 + lane];
+    bsum += r[kWgradK * 16 * 64 + lane];
   }
   float* part = a.part + (size_t)blockIdx.x * a.N * K;
 #pragma unroll
@@ -271,20 +462,27 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// dW[e] = sum over chunks (fixed order): 4 threads per element take interleaved chunks and are combined by shuffles.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int chunks,
                                                            int N, int K, float* __restrict__ dW, int ldw, int wcol,
                                                            float* __restrict__ db) {
   const size_t total = size_t(N) * K + (db ? N : 0);
-  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < total; e += size_t(gridDim.x) * blockDim.x) {
+  const int sl = threadIdx.x & 3;
+  for (size_t e = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) >> 2; e < total; e += (size_t(gridDim.x) * blockDim.x) >> 2) {
+    const bool isw = e < size_t(N) * K;
+    const float* src = isw ? part + e : bpart + (e - size_t(N) * K);
+    const size_t stride = isw ? size_t(N) * K : size_t(N);
     float s = 0.f;
-    if (e < size_t(N) * K) {
-      for (int c = 0; c < chunks; ++c) s += part[size_t(c) * N * K + e];
-      const size_t n = e / K, k = e - n * K;
-      dW[n * ldw + wcol + k] = s;
-    } else {
-      const size_t n = e - size_t(N) * K;
-      for (int c = 0; c < chunks; ++c) s += bpart[size_t(c) * N + n];
-      db[n] = s;
+    for (int c = sl; c < chunks; c += 4) s += src[size_t(c) * stride];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (sl == 0) {
+      if (isw) {
+        const size_t n = e / K, k = e - n * K;
+        dW[n * ldw + wcol + k] = s;
+      } else {
+        db[e - size_t(N) * K] = s;
+      }
     }
   }
 }
@@ -301,10 +499,10 @@ hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW
   a.bpart = db ? scratch + size_t(chunks) * N * xseg.K : nullptr;
   a.kgroups = (xseg.K + kWgradK * 32 - 1) / (kWgradK * 32);
   a.items = ((N + 31) / 32) * a.kgroups;
-  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(chunks, (a.items + 3) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(chunks, a.items), dim3(256), 0, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(size_t(N) * xseg.K + N, 256, 1024)), dim3(256), 0, s, a.part, a.bpart, chunks,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t(N) * xseg.K + N) * 4, 256, 2048)), dim3(256), 0, s, a.part, a.bpart, chunks,
                      N, xseg.K, dW, ldw, xseg.wcol, db);
   return hipGetLastError();
 }

@@ -45,14 +45,19 @@ def modules(W=128, seed=0):
 
 
 # ---------------------------------------------------------------------------------------------- the three products
-@pytest.mark.parametrize("P,K,N,ldw,wcol,div,act", [
-    (1000, 63, 128, 63, 0, 1, 1), (777, 128, 128, 191, 63, 1, 1), (4096, 128, 1, 128, 0, 1, 3), (300, 64, 3, 64, 0, 1, 2),
-    (960, 77, 64, 205, 128, 48, 0), (129, 256, 256, 256, 0, 1, 1), (64, 16, 16, 16, 0, 1, 0), (515, 20, 64, 148, 128, 5, 1)])
-def test_linear_products_vs_torch(P, K, N, ldw, wcol, div, act):
+@pytest.mark.parametrize("P,K,N,ldw,wcol,div,act,ldx", [
+    # small point counts: the streaming kernels
+    (1000, 63, 128, 63, 0, 1, 1, 66), (777, 128, 128, 191, 63, 1, 1, 131), (300, 64, 3, 64, 0, 1, 2, 67),
+    (960, 77, 64, 205, 128, 48, 0, 80), (129, 256, 256, 256, 0, 1, 1, 259), (64, 16, 16, 16, 0, 1, 0, 19),
+    (515, 20, 64, 148, 128, 5, 1, 23),
+    # >= 1024 points: the persistent LDS-staged kernels (aligned rows = 16-byte loads, unaligned = scalar loads)
+    (4096, 128, 1, 128, 0, 1, 3, 128), (5000, 63, 128, 63, 0, 1, 1, 64), (3001, 128, 128, 191, 63, 1, 1, 128),
+    (2500, 77, 64, 205, 128, 50, 1, 80), (2048, 256, 256, 319, 63, 1, 1, 256), (1500, 64, 3, 64, 0, 1, 2, 67),
+    (1111, 20, 64, 148, 128, 7, 0, 20), (4000, 32, 16, 32, 0, 1, 1, 35), (6000, 512, 96, 512, 0, 1, 1, 512)])
+def test_linear_products_vs_torch(P, K, N, ldw, wcol, div, act, ldx):
     lib = _lib.load()
     g = torch.Generator().manual_seed(P + K + N)
     rows = (P + div - 1) // div
-    ldx = K + 3
     x = torch.randn(rows, ldx, generator=g)
     w = torch.randn(N, ldw, generator=g) / np.sqrt(K)
     b = torch.randn(N, generator=g)
