@@ -148,17 +148,39 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
   if (!a.bwd) {
     for (int s = 0; s < a.nseg; ++s) {
       const int K = a.seg[s].K, ko = seg_koff(a, s), wc = a.seg[s].wcol;
-      for (int e = threadIdx.x; e < NBLK * 32 * K; e += 256) {
-        const int r = e / K, k = e - r * K;
-        if (m0 + r < a.M) slab[r * KP + ko + k] = a.W[(size_t)(m0 + r) * a.ldw + wc + k];
-      }
+      // a wave per row, 16 rows in flight per thread: coalesced reads, one memory latency per 16 rows
+      for (int k = threadIdx.x & 63; k < K; k += 64)
+        for (int r0 = threadIdx.x >> 6; r0 < NBLK * 32; r0 += 64) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int r = r0 + 4 * u;
+            v[u] = (r < NBLK * 32 && m0 + r < a.M) ? a.W[(size_t)(m0 + r) * a.ldw + wc + k] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int r = r0 + 4 * u;
+            if (r < NBLK * 32) slab[r * KP + ko + k] = v[u];
+          }
+        }
     }
   } else {
     const int N = a.seg[0].K;   // contraction = the layer's outputs; slab[kcol][n] = W[n][wcol + m0 + kcol]
-    for (int e = threadIdx.x; e < NBLK * 32 * N; e += 256) {
-      const int n = e / (NBLK * 32), r = e - n * (NBLK * 32);
-      if (m0 + r < a.M) slab[r * KP + n] = a.W[(size_t)n * a.ldw + a.wcol + m0 + r];
-    }
+    // a wave per weight row (coalesced reads, transposed LDS writes), 16 rows in flight per thread
+    for (int r = threadIdx.x & 63; r < NBLK * 32; r += 64)
+      for (int n0 = threadIdx.x >> 6; n0 < N; n0 += 64) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int n = n0 + 4 * u;
+          v[u] = (n < N && m0 + r < a.M) ? a.W[(size_t)n * a.ldw + a.wcol + m0 + r] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int n = n0 + 4 * u;
+          if (n < N) slab[r * KP + n] = v[u];
+        }
+      }
   }
   __syncthreads();
   const long long n_tiles = (a.P + 127) / 128;
@@ -180,26 +202,38 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
       const int ko = seg_koff(a, s);
       const bool vec = ((reinterpret_cast<uintptr_t>(sg.x) & 15) == 0) && (sg.ld & 3) == 0 && sg.ld >= ((sg.K + 3) & ~3);
       const float* bl = slab + i * KP + ko + 4 * kh;
-      for (int k0 = 0; k0 < sg.K; k0 += 8) {
-        const int k = k0 + 4 * kh;
-        f32x4 av;
-        if (vec && k + 3 < ((sg.K + 3) & ~3)) {
-          av = *reinterpret_cast<const f32x4*>(x + k);
-          if (k + 3 >= sg.K) {   // the row's own padding may hold anything: zero what lies beyond K
+      // The lane's whole share of up to 128 contraction elements is loaded up front (16 x 16 bytes in flight), then the MFMAs run
+      // without a memory wait; the other wave of the SIMD covers the one latency per block.
+      for (int kb0 = 0; kb0 < sg.K; kb0 += 128) {
+        constexpr int STEPS = 16;
+        f32x4 av[STEPS];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (k + q >= sg.K) av[q] = 0.f;
+        for (int t = 0; t < STEPS; ++t) {
+          const int k = kb0 + 8 * t + 4 * kh;
+          if (vec && k + 3 < ((sg.K + 3) & ~3)) {
+            av[t] = *reinterpret_cast<const f32x4*>(x + k);
+            if (k + 3 >= sg.K) {   // the row's own padding may hold anything: zero what lies beyond K
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (k + q >= sg.K) av[t][q] = 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[t][q] = k + q < sg.K ? x[k + q] : 0.f;
           }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) av[q] = k + q < sg.K ? x[k + q] : 0.f;
         }
-        f32x4 bv[NBLK];
 #pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb) bv[nb] = *reinterpret_cast<const f32x4*>(bl + nb * 32 * KP + k0);
+        for (int t = 0; t < STEPS; ++t) {
+          const int k0 = kb0 + 8 * t;
+          if (k0 < sg.K) {
+            f32x4 bv[NBLK];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int nb = 0; nb < NBLK; ++nb) bv[nb] = *reinterpret_cast<const f32x4*>(bl + nb * 32 * KP + k0);
 #pragma unroll
-          for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma32(av[q], bv[nb][q], acc[nb]);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma32(av[t][q], bv[nb][q], acc[nb]);
+          }
+        }
       }
     }
 #pragma unroll
