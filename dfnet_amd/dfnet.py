@@ -97,7 +97,11 @@ class _PoseFn(torch.autograd.Function):
         tape = ctx.tape if E.holds(ctx.tape) and ctx.tape_version == m._version() else None
         grads = E.backward_params(x, g_pose.contiguous(), tape=tape)
         ctx.tape = None
-        return (None, None) + tuple(grads[k] for k in m._pose_param_names())
+        # hand the ONLY reference of each gradient to autograd: AccumulateGrad then adopts the tensor as .grad instead of cloning
+        # it (one device-to-device copy per parameter and step otherwise)
+        out = tuple(grads.pop(k) for k in m._pose_param_names())
+        del grads
+        return (None, None) + out
 
 
 class _TrainFn(torch.autograd.Function):
@@ -153,7 +157,9 @@ class _TrainFn(torch.autograd.Function):
             grads = E.backward_all_params(x, None if g_pose is None else g_pose.contiguous(), g_feats.contiguous(), bn_batch=bn_batch,
                                           tape=tape)
             ctx.tape = None
-        return (None,) * 7 + tuple(grads.get(k) for k in E.train_param_names(True))
+        out = tuple(grads.pop(k, None) for k in E.train_param_names(True))   # sole references: .grad adopts them without a copy
+        del grads
+        return (None,) * 7 + out
 
 
 class _DFNetBase(nn.Module):
