@@ -542,7 +542,10 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
                                         size_t workspace_bytes, void* stream) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: null handle");
   if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_backward_input: dfn_dfnet_commit() has not been called");
-  if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: unknown precision %d", prec);
+  if (prec == DFN_PREC_F16)
+    return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_backward_input: gradients run in DFN_PREC_F16X3 or DFN_PREC_F32 only (f16 rounding of "
+                     "every activation flips ReLU / max-pool gates: 0.1 relative L2)");
+  if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3) return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: unknown precision %d", prec);
   if (h && h->committed)
     if (int rc = check_fresh(h, prec, "dfn_dfnet_backward_input")) return rc;
   level_mask &= (1 << h->n_taps) - 1;

@@ -570,6 +570,14 @@ static int check_net(dfn_nerfh_t h, int prec, const char* fn, bool allow_x3 = fa
   return DFN_OK;
 }
 
+// Gradient entry points: fp32-grade arithmetic only (DFN_PREC_F32, DFN_PREC_F16X3).
+static int check_grad_prec(int prec, const char* fn) {
+  if (prec == DFN_PREC_F16)
+    return set_error(DFN_ERR_UNSUPPORTED, "%s: gradients run in DFN_PREC_F16X3 or DFN_PREC_F32 only (plain-f16 ReLU gates are 3e-2 off "
+                     "autograd)", fn);
+  return DFN_OK;
+}
+
 // Kernel variant: DFN_MLP_VARIANT=0|1|2 (A/B aid, see nerfh_layout.h).
 static int mlp_variant() {
   static int v = -1;
@@ -820,6 +828,7 @@ extern "C" int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_
                                      const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf,
                                      const float* grad_raw, float* grad_pts, void* bias_ws, void* stream) {
   if (int rc = check_net(h, prec, "dfn_mlp_fine_backward", true)) return rc;
+  if (int rc = check_grad_prec(prec, "dfn_mlp_fine_backward")) return rc;
   if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !grad_raw || !grad_pts || !bias_ws || Nf < 1 ||
       (hist_rows != 1 && hist_rows != n_rays))
@@ -949,6 +958,7 @@ extern "C" int dfn_render_rays_backward(dfn_nerfh_t h, int prec, const float* ra
                                         float far, const float* grad_rgb, float* grad_rays_o, float* grad_rays_d,
                                         float* grad_viewdirs, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_net(h, prec, "dfn_render_rays_backward", true)) return rc;
+  if (int rc = check_grad_prec(prec, "dfn_render_rays_backward")) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_rays_backward")) return rc;
   if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !hist || !grad_rgb || !grad_rays_o || !grad_rays_d || !workspace ||
@@ -971,6 +981,7 @@ extern "C" int dfn_render_image_backward(dfn_nerfh_t h, int prec, const float* c
                                          float far, int Nc, int Ni, const float* hist, const float* grad_rgb,
                                          float* grad_c2w, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_net(h, prec, "dfn_render_image_backward", true)) return rc;
+  if (int rc = check_grad_prec(prec, "dfn_render_image_backward")) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_image_backward")) return rc;
   if (!c2w || !hist || !grad_rgb || !grad_c2w || !workspace || H < 1 || W < 1 || !(focal > 0))
     return set_error(DFN_ERR_ARG, "dfn_render_image_backward: bad argument");

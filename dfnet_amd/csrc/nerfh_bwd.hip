@@ -517,7 +517,9 @@ hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStr
     return mode == 1 ? launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1, 1>(a, n_cu, stream)
                      : launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1, 2>(a, n_cu, stream);
   }
-  if (prec == 0) return launch_bwd_one<PrecF16, PrecF16, true, 4, 8, 8, 1>(a, n_cu, stream);
+  // plain f16 gradient arithmetic is not offered: ReLU gates flipped by f16 rounding put it at 3e-2 of autograd (30x the
+  // contract); split-f16 runs at the f16 MFMA rate with fp32-grade gates (nerfh_api.hip rejects DFN_PREC_F16 here)
+  if (prec == 0) return hipErrorInvalidValue;
   if (prec == 2) return launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1>(a, n_cu, stream);   // split-f16 forward and gradient chain
   return launch_bwd_one<PrecF32, PrecF32, false, 4, 1, 1, 1>(a, n_cu, stream);
 }

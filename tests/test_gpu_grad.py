@@ -25,10 +25,10 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 DEV = "cuda:0"
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL = {"f32": 2e-4, "f16x3": 2e-4, "f16": 1e-1}
-TOL_NET = {"f32": 1e-5, "f16x3": 1e-5, "f16": 1e-1}
-TOL_L2 = {"f32": 1e-5, "f16x3": 1e-5, "f16": 3e-2}
-TOL_C2W = {"f32": 2e-3, "f16x3": 2e-3, "f16": 1e-1}
+TOL = {"f32": 2e-4, "f16x3": 2e-4}
+TOL_NET = {"f32": 1e-5, "f16x3": 1e-5}
+TOL_L2 = {"f32": 1e-5, "f16x3": 1e-5}
+TOL_C2W = {"f32": 2e-3, "f16x3": 2e-3}   # d c2w: a signed sum over all rays that cancels (G9: oracle vs reference 1e-4)
 
 
 def rel_l2(a, b):
@@ -72,7 +72,7 @@ def test_composite_backward_vs_autograd(gold):
         assert relmax(got, raw.grad) < 2e-4  # S_i = total - prefix cancels for the front samples
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("n_rays,Nf", [(5, 24), (9, 192), (3, 70)])
 def test_mlp_fine_backward_vs_autograd(scene, prec, n_rays, Nf):
     """d sum(raw * G) / d (points, viewdirs) of the fine network, all nine output channels weighted."""
@@ -94,7 +94,7 @@ def test_mlp_fine_backward_vs_autograd(scene, prec, n_rays, Nf):
     assert e_pts < TOL_NET[prec] and e_v < TOL_NET[prec] and l2 < TOL_L2[prec]
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_render_rays_backward_golden(scene, gold, prec):
     E = scene[0]
     for tag in "ab":
@@ -109,7 +109,7 @@ def test_render_rays_backward_golden(scene, gold, prec):
         assert eo < TOL[prec] and ed < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_render_image_backward_golden(scene, gold, prec):
     E = scene[0]
     g = gold("g9_render_grad_c2w")
@@ -142,13 +142,15 @@ def test_quarter_res_pose_gradient_vs_oracle(scene):
     c2w = T(syn.orbit_pose(6, 8))[:3, :4]
     G = T(np.random.default_rng(9).standard_normal((H, W, 3)).astype(np.float32))
     _, ref = orc.render_grad_c2w(H, W, focal, c2w, G, c, f, ea, et, 64, 128, 0., 2.5, syn.HIST_IDX)
-    for prec in ("f32", "f16"):
+    for prec in ("f32", "f16x3"):
         gc = E.render_image_backward(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, G.to(DEV), precision=prec)
         e = relmax(gc, ref)
         print(f"{prec}: 60x80 d c2w {e:.2e}")
         assert e < TOL_C2W[prec]
-    gc2 = E.render_image_backward(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, G.to(DEV), precision="f16")
+    gc2 = E.render_image_backward(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, G.to(DEV), precision="f16x3")
     assert torch.equal(gc, gc2)  # deterministic
+    with pytest.raises(Exception, match="F16X3 or DFN_PREC_F32"):   # the plain-f16 gradient mode is gone (it was 3e-2 off autograd)
+        E.render_image_backward(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, G.to(DEV), precision="f16")
 
 
 def test_render_autograd_drop_in(scene, gold):
@@ -163,7 +165,8 @@ def test_render_autograd_drop_in(scene, gold):
     # default: the tracked forward runs in the engine's precision (f16) and the gradient is that forward's
     rgb = rendering.render(int(g["H"]), int(g["W"]), float(g["focal"]), c2w=pose, near=0., far=2.5, img_idx=dev(g["hist"]), **kw)[0]
     (rgb * dev(g["G"])).sum().backward()
-    assert relmax(pose.grad, g["grad_c2w"]) < TOL_C2W["f16"]
+    # (f16 coarse net + split-f16 fine net and gradient; random per-pixel weights on a 12x16 image make d c2w a badly conditioned sum)
+    assert relmax(pose.grad, g["grad_c2w"]) < 3e-2
     pose.grad = None
     rendering.GRAD_FORWARD_PRECISION = "f32"   # everything tracked in fp32: reference-grade pose gradient
     rgb, disp, acc, extras = rendering.render(int(g["H"]), int(g["W"]), float(g["focal"]), c2w=pose, near=0., far=2.5,
@@ -196,8 +199,8 @@ def dfnet():
 @pytest.mark.parametrize("shape,up", [((2, 3, 32, 48), (32, 48)), ((1, 3, 72, 104), (60, 90))])
 def test_dfnet_backward_input_vs_autograd(dfnet, levels, shape, up):
     """d sum(features * G) / d x against torch autograd through the CPU oracle (frozen weights, eval-mode BN),
-    including odd sizes (max-pool remainders, upsample to a different size).  The f16-input path gates many more
-    units differently (f16 rounding of every activation) and is only held to 0.1 relative L2; fp32 is the default."""
+    including odd sizes (max-pool remainders, upsample to a different size).  Gradient arithmetic is fp32-grade only
+    (exact fp32 or split-f16); the plain-f16 mode is refused by the library."""
     from oracle import dfnet_oracle as dor
     E, p = dfnet
     # The map is piecewise linear: a pre-activation (or a max-pool pair) within round-off of a tie gates differently
@@ -205,7 +208,7 @@ def test_dfnet_backward_input_vs_autograd(dfnet, levels, shape, up):
     # torch's own fp32 and fp64 gradients differ by 7e-2 on some inputs of this very test.  With ~2M gated units a
     # flip somewhere is common, so: over three seeded inputs the fp32 path must match the oracle (evaluated in fp32
     # or fp64) to round-off on at least one, and stay within 5e-2 relative L2 on all of them.
-    best = {"f32": 1.0, "f16x3": 1.0, "f16": 1.0}
+    best = {"f32": 1.0, "f16x3": 1.0}
     for seed in (21, 22, 23):
         rng = np.random.default_rng(seed)
         x0 = rng.uniform(0, 1, shape).astype(np.float32)
@@ -220,7 +223,7 @@ def test_dfnet_backward_input_vs_autograd(dfnet, levels, shape, up):
                                          return_pose=False, upsampleH=up[0], upsampleW=up[1])
             (feats[0] * G.to(dt)).sum().backward()
             refs.append(x.grad)
-        for prec, tol_l2 in (("f32", 5e-2), ("f16x3", 5e-2), ("f16", 0.15)):
+        for prec, tol_l2 in (("f32", 5e-2), ("f16x3", 5e-2)):
             gx = E.backward_input(T(x0).to(DEV), G.to(DEV), levels=levels, precision=prec)
             e = min(relmax(gx, r) for r in refs)
             l2 = min(rel_l2(gx, r) for r in refs)
@@ -677,3 +680,93 @@ def test_dm_train_step_parameter_gradients_vs_oracle():
         worst = max(worst, rel_l2(g, pp[k].grad))
     print(f"DFNet_dm step: worst relative-L2 error over the 28 parameter gradients {worst:.2e}")
     assert worst < 1e-3
+
+
+def test_dm_train_step_at_c5_size_vs_oracle():
+    """BASELINE configs[4] at its per-GPU shape — batch 4, 240x320 frames, NeRF-H render 60x80 at 64+128 + bicubic x4, level-0
+    feature loss — through train_on_batch with the production precisions (f16 coarse net, split-f16 fine net / gradients /
+    DFNet): the loss, d loss / d predicted pose and all 28 regressor gradients against autograd through the composition of
+    the CPU oracles (frame by frame: the loss is separable over frames, which bounds the oracle's autograd memory)."""
+    from types import SimpleNamespace
+    from dfnet_amd.dfnet import DFNet
+    from dfnet_amd.direct_feature_matching import matching_step_grad, train_on_batch
+    from dfnet_amd.nerfw import HipQuery
+    from oracle import dfnet_oracle as dor
+    B, H, W, focal, Nc, Ni = 4, 240, 320, 585.0 / 2, 64, 128
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    sd = {k: T(v) for k, v in syn.dfnet_weights(3).items()}
+    model, feat_model = DFNet().to(DEV).eval(), DFNet().to(DEV).eval()
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+    feat_model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+    for q in feat_model.parameters():
+        q.requires_grad_(False)
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine(precision="f16").load_numpy(cw, fw, ea, et)
+    kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=Ni, N_samples=Nc, use_viewdirs=True, white_bkgd=False,
+              raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    setup = dict(pose_scale=1.0, pose_scale2=1.0, move_all_cam_vec=[0., 0., 1.0])
+    args = SimpleNamespace(svd_reg=True, chunk=32768, feature_matching_lvl=[0], per_channel=False, combine_loss=True,
+                           combine_loss_w=[0.3, 0.2, 1.0])
+    data = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1))
+    gt = torch.stack([T(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(B)])
+    hist = T(syn.HIST_IDX).repeat(B, 1)
+
+    class Capture:
+        def __init__(self, m):
+            self.m, self.grads = m, None
+
+        def step(self):
+            self.grads = {k: q.grad.detach().cpu().clone() for k, q in self.m.named_parameters() if q.grad is not None}
+
+        def zero_grad(self):
+            for q in self.m.parameters():
+                q.grad = None
+
+    out = matching_step_grad(args, data, model, feat_model, gt, hist, [H, W, focal], True, DEV, setup, **kw)
+    cap = Capture(model)
+    loss, _ = train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], cap, True, DEV, setup, **kw)
+    # ---- oracle composition: regressor (tracked) -> SVD -> rescale -> per frame [render -> bicubic -> features -> losses]
+    pp = {k: v.clone().requires_grad_(k in cap.grads) for k, v in sd.items()}
+    _, pr = dor.dfnet_forward(pp, data, False, True, True)
+    pose_ = pr.reshape(B, 3, 4).clone()
+    u, s_, v = torch.svd(pose_[:, :3, :3].clone())
+    pose_[:, :3, :3] = u @ v.transpose(-2, -1)
+    pose_leaf = pose_.detach().clone().requires_grad_(True)   # d loss / d predicted pose is collected here, frame by frame
+    c, f = {k: T(x) for k, x in cw.items()}, {k: T(x) for k, x in fw.items()}
+    with torch.no_grad():
+        ft_all = dor.dfnet_forward(sd, data, True, True, False, H, W)[0][0][0]   # target features, level 0: [B,128,H,W]
+    total = 0.3 * torch.nn.functional.mse_loss(pose_leaf.reshape(B, 12), gt)
+    total.backward()
+    ref_loss = float(total.detach())
+    for b in range(B):
+        pn = pose_leaf[b].clone()
+        t3 = (pn[:3, 3] * setup["pose_scale"] + torch.tensor(setup["move_all_cam_vec"])) * setup["pose_scale2"]
+        pn = torch.cat([pn[:3, :3], t3[:, None]], 1)
+        r = orc.render(H // 4, W // 4, focal / 4, 1 << 30, c, f, T(ea), T(et), Nc, Ni, 0., 2.5, syn.HIST_IDX, c2w=pn)[0]
+        rgb = torch.nn.Upsample(size=(H, W), mode='bicubic')(r.permute(2, 0, 1)[None])
+        fr = dor.dfnet_forward(sd, rgb, True, True, False, H, W)[0][0][0][0]       # [128,H,W]
+        fl = 1 - torch.nn.functional.cosine_similarity(fr.reshape(128, -1), ft_all[b].reshape(128, -1), dim=1, eps=1e-6).mean()
+        part = 0.2 * ((rgb[0] - data[b]) ** 2).sum() / (B * 3 * H * W) + 1.0 * fl / B
+        part.backward()
+        ref_loss += float(part.detach())
+    assert abs(float(loss[0]) - ref_loss) < 2e-4 * max(1.0, abs(ref_loss)), (float(loss[0]), ref_loss)
+    e_pose = relmax(out["grad_pose"], pose_leaf.grad)
+    pose_.backward(pose_leaf.grad)    # continue into the regressor's parameters (fp32 autograd)
+    # The regressor's backward is piecewise linear in ~10^7 ReLU / max-pool gates at this size: units whose pre-activation is
+    # within round-off of zero gate differently under another summation order.  Yardstick: the same backward in fp64 — the
+    # HIP gradients must stay within 4x of what torch's own fp32 autograd loses against fp64 (measured: conv1_1's weight gradient —
+    # a cancelling sum over 307,200 pixels — 2.0e-3 here vs 5.8e-4 for torch fp32; every other tensor 3e-4..6e-4), never above 5e-3.
+    p64 = {k: v.double().clone().requires_grad_(k in cap.grads) for k, v in sd.items()}
+    _, pr64 = dor.dfnet_forward(p64, data.double(), False, True, True)
+    q64 = pr64.reshape(B, 3, 4).clone()
+    u, s_, v = torch.svd(q64[:, :3, :3].clone())
+    q64[:, :3, :3] = u @ v.transpose(-2, -1)
+    q64.backward(pose_leaf.grad.double())
+    e_hip = {k: min(rel_l2(g, pp[k].grad), rel_l2(g, p64[k].grad)) for k, g in cap.grads.items()}
+    e_t32 = {k: rel_l2(pp[k].grad, p64[k].grad) for k in cap.grads}
+    worst_k = max(e_hip, key=e_hip.get)
+    print(f"C5 size: loss {float(loss[0]):.6f} vs oracle {ref_loss:.6f}; d loss / d pose {e_pose:.2e}; worst relative L2 over the 28 "
+          f"parameter gradients {e_hip[worst_k]:.2e} ({worst_k}); torch fp32 vs fp64 autograd on the same tensor {e_t32[worst_k]:.2e}, "
+          f"worst {max(e_t32.values()):.2e}")
+    assert e_pose < 2e-3
+    assert all(e_hip[k] < max(1e-3, 4 * max(e_t32.values())) and e_hip[k] < 5e-3 for k in e_hip), e_hip
