@@ -21,8 +21,9 @@ Prints ONE JSON line (rank 0):
   roofline              dominant kernel (fine MLP, MFMA bound): algorithmic FLOPs per launch / average launch duration
                         measured with HIP events on the launch stream (dfn_profile_*);
   hbm                   achieved GB/s of the HBM-bound stage kernels (sampling, ray bias, compositing), same events;
-  secondary             BASELINE configs[3] (DFNet forward ms / 480x640 image) and configs[4] (DFNet_dm step ms at the
-                        per-GPU shape), each with its parity number against the oracle;
+  secondary             BASELINE configs[3] (DFNet forward ms / 480x640 image), configs[4] (DFNet_dm step ms at the per-GPU
+                        shape), the NeRF-H optimisation step and a netwidth-256 frame, each with its parity
+                        number against the oracle;
   cpu_baseline          the oracle (torch-CPU port of the reference path) on a bounded ray sample on this box's host
                         cores, best of a thread-count sweep (rank 0, N = 1 only).
 """
@@ -336,6 +337,103 @@ def secondary_dm_step(dev):
             "gradient_parity": "tests/test_gpu_grad.py (pose gradient and the 28 parameter gradients vs oracle autograd)"}
 
 
+def secondary_nerfh_train(dev):
+    """one NeRF-H optimisation step at the reference's defaults (N_rand 1536 rays, 64+128 samples, netwidth 128,
+    perturb 1; run_nerf.py:32-80): forward, fused NerfWLoss, every gradient, Adam.  Parity: a 256-ray step against autograd
+    through the CPU oracle (loss terms and the worst relative L2 over the 64 gradient tensors)."""
+    from dfnet_amd import engine as eng, nerf_train, synthetic as syn
+    from dfnet_amd.nerfw import NeRFW
+    from oracle import nerfh_oracle as orc
+    T = torch.from_numpy
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    coarse = NeRFW('coarse', D=8, W=128, skips=[4], in_channels_xyz=63, in_channels_dir=27)
+    fine = NeRFW('fine', D=8, W=128, skips=[4], in_channels_xyz=63, in_channels_dir=27, encode_appearance=True, encode_transient=True,
+                 in_channels_a=50, in_channels_t=20)
+    coarse.load_state_dict({k: T(v) for k, v in cw.items()})
+    fine.load_state_dict({k: T(v) for k, v in fw.items()})
+    emb_a, emb_t = torch.nn.Embedding(1000, 5), torch.nn.Embedding(1000, 2)
+    emb_a.weight.data.copy_(T(ea))
+    emb_t.weight.data.copy_(T(et))
+    mods = [m.to(dev) for m in (coarse, fine, emb_a, emb_t)]
+    E = eng.NerfHEngine(precision="f32").load_numpy(cw, fw, ea, et)
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    rng = np.random.default_rng(5)
+    ro, rd = orc.get_rays(H, W, FOCAL, T(syn.orbit_pose(4, 8))[:3, :4])
+
+    def batch(R):
+        sel = rng.choice(H * W, R, replace=False)
+        return (ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous(),
+                T(rng.integers(0, 40, (R, 10)).astype(np.float32)), T(rng.uniform(0, 1, (R, 3)).astype(np.float32)))
+
+    # parity at 256 rays
+    R = 256
+    o, d, hist, target = batch(R)
+    gen = torch.Generator().manual_seed(9)
+    draws = (torch.rand(R, NC, generator=gen), torch.randn(R, NC, generator=gen), torch.rand(R, NI, generator=gen))
+    rows = torch.cat([o, d, torch.zeros(R, 1), torch.full((R, 1), FAR), d / d.norm(dim=-1, keepdim=True), hist], 1)
+    c, f = {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}
+    t0 = time.perf_counter()
+    ld_ref, _, g_ref, _ = orc.train_step(rows, target, c, f, T(ea), T(et), NC, NI, *draws, perturb=1., raw_noise_std=1.)
+    cpu_s = time.perf_counter() - t0
+    ld, _, _ = tr.train_step(o.to(dev), d.to(dev), hist.to(dev), target.to(dev), NC, NI, NEAR, FAR, perturb=1., raw_noise_std=1.,
+                             draws=tuple(t.to(dev) for t in draws))
+    worst = max(float((p.grad.cpu().double() - g_ref[k].double()).norm() / g_ref[k].double().norm()) for k, p in zip(tr.names, tr.params))
+    loss_rel = max(abs(float(ld[k]) - float(ld_ref[k])) / abs(float(ld_ref[k])) for k in ld)
+    # timing at the reference's batch
+    R = 1536
+    o, d, hist, target = (t.to(dev) for t in batch(R))
+    opt = torch.optim.Adam(tr.params, lr=5e-4, betas=(0.9, 0.999))
+
+    def step():
+        tr.train_step(o, d, hist[:1], target, NC, NI, NEAR, FAR, perturb=1., raw_noise_std=0.)
+        opt.step()
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    mac_fwd = R * (NC * (MAC_COARSE + 128 * 128 + 64 * (128 + 27) + 64 * 3) + (NC + NI) * MAC_FINE)
+    return {"workload": "one NeRF-H optimisation step (run_nerf.py:32-80): 1536 random rays, 64+128 samples, netwidth 128, perturb 1: "
+                        "training-mode render, NerfWLoss, gradients of all 64 parameter tensors, Adam",
+            "step_ms": ms, "rays_per_s": R / ms * 1e3, "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), reference precision",
+            "algorithmic_TFLOPs": 6.0 * mac_fwd / (ms * 1e-3) / 1e12, "fp32_mfma_frac": 6.0 * mac_fwd / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"],
+            "flops_note": "forward 2 x MAC, data gradients 2 x MAC, weight gradients 2 x MAC",
+            "parity_256_rays_vs_oracle_autograd": {"worst_rel_l2_over_64_gradients": worst, "worst_loss_term_rel_diff": loss_rel,
+                                                   "raw_noise_std": 1.0, "cpu_oracle_step_s": cpu_s}}
+
+
+def secondary_w256(dev):
+    """SURVEY §8(d) 'also report' netwidth 256 (100.1 TFLOP per 640x480 frame): rendered on the generic-width path (layer by layer,
+    exact fp32 MFMA, activations in HBM); the register-resident kernels are specialised for netwidth 128."""
+    from dfnet_amd import engine as eng, synthetic as syn
+    from oracle import nerfh_oracle as orc
+    T = torch.from_numpy
+    cw, fw, ea, et = syn.nerfh_weights(0, W=256)
+    E = eng.NerfHEngine(width=256).load_numpy(cw, fw, ea, et)
+    pose, hist = T(syn.orbit_pose(0, 8)).to(dev), T(syn.HIST_IDX).to(dev)
+    E.render_image(pose, 120, 160, FOCAL / 4, hist, NC, NI, NEAR, FAR)   # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    E.render_image(pose, H, W, FOCAL, hist, NC, NI, NEAR, FAR)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ro, rd = orc.get_rays(H, W, FOCAL, T(syn.orbit_pose(0, 8))[:3, :4])
+    sel = torch.randperm(H * W, generator=torch.Generator().manual_seed(0))[:512]
+    rows = orc.pack_ray_rows(ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], NEAR, FAR, syn.HIST_IDX)
+    with torch.no_grad():
+        ref = orc.render_rays(rows, {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}, T(ea), T(et), NC, NI)
+    rgb, disp, _, _ = E.render_rays(rows[:, 0:3].to(dev), rows[:, 3:6].to(dev), hist, NC, NI, NEAR, FAR)
+    flops = 325.9e6 * H * W
+    return {"workload": "netwidth 256 NeRF-H, one 640x480 frame at 64+128 (100.1 TFLOP algorithmic), generic-width path", "value": H * W / dt,
+            "unit": "rays/s", "ms_per_frame": dt * 1e3, "algorithmic_TFLOPs": flops / dt / 1e12, "fp32_mfma_frac": flops / dt / 1e12 / PEAK_TFLOPS["f32"],
+            "arithmetic": "exact fp32 MFMA",
+            "parity_vs_oracle": {"rgb_max_rel": float((rgb.cpu() - ref["rgb_map"]).abs().max() / ref["rgb_map"].abs().max()),
+                                 "disp_max_rel": float((disp.cpu() - ref["disp_map"]).abs().max() / ref["disp_map"].abs().max()), "rays": 512}}
+
+
 # ---------------------------------------------------------------------------------------------- launch
 def free_port():
     s = socket.socket()
@@ -466,7 +564,8 @@ def main():
             sec = {}
             if args.cpu_sample > 0:
                 torch.set_num_threads(int(line["cpu_baseline"]["cores"]))   # the oracle legs below: the fastest thread count found
-            for name, fn in (("dfnet_forward_c4", secondary_dfnet), ("dfnet_dm_step_c5", secondary_dm_step)):
+            for name, fn in (("dfnet_forward_c4", secondary_dfnet), ("dfnet_dm_step_c5", secondary_dm_step),
+                             ("nerfh_train_step_n1", secondary_nerfh_train), ("nerfh_netwidth_256", secondary_w256)):
                 try:
                     sec[name] = fn(dev) if args.cpu_sample > 0 else {"skipped": "--cpu-sample 0"}
                 except Exception as e:  # a failing secondary must not lose the headline line
