@@ -236,23 +236,40 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
         }
       }
     }
+    // ---- epilogue: the activation / gradient gate is chosen ONCE per tile (wave-uniform), rows addressed from one base pointer
+    const bool full = p0 + 32 <= a.P;
+    float* ybase = a.y + (p0 + 4 * kh) * a.ldy + m0 + i;
+    auto store_all = [&](auto fn) {
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) {
-      const int m = m0 + nb * 32 + i;
-      if (m >= a.M) continue;
+      for (int nb = 0; nb < NBLK; ++nb) {
+        if (m0 + nb * 32 + i >= a.M) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long pt = p0 + mblock_row(kh, r);
-        if (pt >= a.P) continue;
-        float v = acc[nb][r];
-        if (a.bwd) {
-          if (a.accumulate) v += a.y[pt * a.ldy + m];
-          if (a.mask && !(a.mask[pt * a.ldmask + m] > 0.f)) v = 0.f;
-        } else {
-          v = apply_act(v, a.act);
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);     // row of the C fragment relative to 4 kh
+          if (!full && p0 + 4 * kh + dr >= a.P) continue;
+          float* dst = ybase + (size_t)dr * a.ldy + nb * 32;
+          *dst = fn(acc[nb][r], dst, dr, nb);
         }
-        a.y[pt * a.ldy + m] = v;
       }
+    };
+    if (a.bwd) {
+      const float* mbase = a.mask ? a.mask + (p0 + 4 * kh) * a.ldmask + m0 + i : nullptr;
+      if (a.accumulate && mbase)
+        store_all([&](float v, float* dst, int dr, int nb) { v += *dst; return mbase[(size_t)dr * a.ldmask + nb * 32] > 0.f ? v : 0.f; });
+      else if (a.accumulate)
+        store_all([&](float v, float* dst, int, int) { return v + *dst; });
+      else if (mbase)
+        store_all([&](float v, float*, int dr, int nb) { return mbase[(size_t)dr * a.ldmask + nb * 32] > 0.f ? v : 0.f; });
+      else
+        store_all([&](float v, float*, int, int) { return v; });
+    } else if (a.act == ACT_RELU) {
+      store_all([&](float v, float*, int, int) { return fmaxf(v, 0.f); });
+    } else if (a.act == ACT_NONE) {
+      store_all([&](float v, float*, int, int) { return v; });
+    } else if (a.act == ACT_SIGMOID) {
+      store_all([&](float v, float*, int, int) { return sigmoid(v); });
+    } else {
+      store_all([&](float v, float*, int, int) { return softplus(v); });
     }
   }
 }
@@ -421,7 +438,7 @@ struct WgradArgs {
   int chunk, kgroups, items;
 };
 
-__global__ __launch_bounds__(256) void gemm_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs a) {
   __shared__ float red[3][kWgradK * 16 * 64 + 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kh = lane >> 5;
@@ -441,21 +458,26 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
   float bsum = 0.f;
   const bool nok = n0 + i < a.N;
+  bool cok[kWgradK];
+#pragma unroll
+  for (int kb = 0; kb < kWgradK; ++kb) cok[kb] = k0 + kb * 32 + i < K;
+  const float* gp = a.G + (w0 + 4 * kh) * a.ldg + n0 + i;
+  const float* xp = a.x.x + (w0 + 4 * kh) * a.x.ld + k0 + i;     // div == 1 fast path
   for (long long p = w0; p < w1; p += 8) {
     float av[4], bv[kWgradK][4];
+    const bool whole = p + 8 <= w1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const long long pq = p + 4 * kh + q;
-      const bool ok = pq < w1;
-      av[q] = (ok && nok) ? a.G[pq * a.ldg + n0 + i] : 0.f;
+      const bool ok = whole || pq < w1;
+      av[q] = (ok && nok) ? gp[(size_t)q * a.ldg] : 0.f;
       bsum += av[q];
-      const float* xr = a.x.x + (a.x.div == 1 ? pq : pq / a.x.div) * a.x.ld;
+      const float* xr = a.x.div == 1 ? xp + (size_t)q * a.x.ld : a.x.x + (pq / a.x.div) * a.x.ld + k0 + i;
 #pragma unroll
-      for (int kb = 0; kb < kWgradK; ++kb) {
-        const int col = k0 + kb * 32 + i;
-        bv[kb][q] = (ok && col < K) ? xr[col] : 0.f;
-      }
+      for (int kb = 0; kb < kWgradK; ++kb) bv[kb][q] = (ok && cok[kb]) ? xr[kb * 32] : 0.f;
     }
+    gp += (size_t)8 * a.ldg;
+    xp += (size_t)8 * a.x.ld;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
