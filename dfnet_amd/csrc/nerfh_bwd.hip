@@ -28,50 +28,92 @@ DFN_DEV float get_slot(const typename FragOf<P>::type (&arr)[N], int s) {
   else return arr[s];
 }
 
-// ReLU on the first C chunks of v, recording (v > 0) per element: bit e of m, e = chunk * slots_per_chunk + slot.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Sign mask of the first C chunks of v: bit = (v > 0).  f16 / split-f16: v is ALREADY rectified (the producing layer applied ReLU).
+// Bit layout (split-f16 and f16): within a 32-bit word (4 chunks), the even slot of pair w of chunk cc sits at bit 4 cc + w and
+// the odd slot at bit 16 + 4 cc + w — so that a PAIR of elements is handled by a few 32-bit integer instructions: after
+// the ReLU the hi half of a split value is >= 0 and non-zero exactly when the value is positive (values below f16's smallest
+// subnormal / 16 = 3.7e-9 count as zero).  fp32: bit e of word e / 32.
 template <class P, int C, int N>
 DFN_DEV void relu_mask(typename FragOf<P>::type (&v)[N], uint32_t (&m)[(C * P::kSlotsPerChunk + 31) / 32]) {
   constexpr int S = P::kSlotsPerChunk;
 #pragma unroll
   for (int w = 0; w < (C * S + 31) / 32; ++w) m[w] = 0u;
+#ifdef DFN_DBG_OLDMASK
+  if constexpr (S == 8) {
 #pragma unroll
-  for (int c = 0; c < C; ++c)
+    for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const int e = c * S + j;
-      if constexpr (P::kSplit) {
-        const _Float16 hi = v[c].hi[j], lo = v[c].lo[j];
-        const bool pos = hi > (_Float16)0 || (hi == (_Float16)0 && lo > (_Float16)0);   // hi + lo > 0
+      for (int j = 0; j < S; ++j) {
+        const int e = c * S + j;
+        bool pos;
+        if constexpr (P::kSplit) pos = v[c].hi[j] > (_Float16)0;
+        else pos = v[c][j] > (_Float16)0;
         m[e >> 5] |= (pos ? 1u : 0u) << (e & 31);
-        v[c].hi[j] = pos ? hi : (_Float16)0;
-        v[c].lo[j] = pos ? lo : (_Float16)0;
-      } else if constexpr (S == 8) {
-        const bool pos = v[c][j] > (_Float16)0;
-        m[e >> 5] |= (pos ? 1u : 0u) << (e & 31);
-        v[c][j] = pos ? v[c][j] : (_Float16)0;
-      } else {
-        const bool pos = v[c] > 0.f;
-        m[e >> 5] |= (pos ? 1u : 0u) << (e & 31);
-        v[c] = pos ? v[c] : 0.f;
+      }
+  } else
+#endif
+  if constexpr (S == 8) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      u32x4 hw;
+      if constexpr (P::kSplit) hw = __builtin_bit_cast(u32x4, v[c].hi);
+      else hw = __builtin_bit_cast(u32x4, v[c]);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        // 1 per non-zero half, in plain 32-bit arithmetic: (h & 0x7FFF) + 0x7FFF carries into bit 15 iff h is not +-0
+        const uint32_t nz = (((hw[w] & 0x7FFF7FFFu) + 0x7FFF7FFFu) >> 15) & 0x00010001u;
+        m[c >> 2] |= nz << (4 * (c & 3) + w);
       }
     }
+  } else {   // exact fp32: the layer leaves the pre-activation, rectified here
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const bool pos = v[c] > 0.f;
+      m[c >> 5] |= (pos ? 1u : 0u) << (c & 31);
+      v[c] = pos ? v[c] : 0.f;
+    }
+  }
 }
 // d pre-activation = d activation where the unit was active (torch: relu'(0) = 0).
 template <class P, int C, int N>
 DFN_DEV void apply_mask(typename FragOf<P>::type (&v)[N], const uint32_t (&m)[(C * P::kSlotsPerChunk + 31) / 32]) {
   constexpr int S = P::kSlotsPerChunk;
+#ifdef DFN_DBG_OLDMASK
+  if constexpr (S == 8) {
 #pragma unroll
-  for (int c = 0; c < C; ++c)
+    for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const int e = c * S + j;
-      const bool on = (m[e >> 5] >> (e & 31)) & 1u;
+      for (int j = 0; j < S; ++j) {
+        const int e = c * S + j;
+        const bool on = (m[e >> 5] >> (e & 31)) & 1u;
+        if constexpr (P::kSplit) { v[c].hi[j] = on ? v[c].hi[j] : (_Float16)0; v[c].lo[j] = on ? v[c].lo[j] : (_Float16)0; }
+        else v[c][j] = on ? v[c][j] : (_Float16)0;
+      }
+  } else
+#endif
+  if constexpr (S == 8) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      u32x4 keep;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t t = (m[c >> 2] >> (4 * (c & 3) + w)) & 0x00010001u;
+        keep[w] = t * 0xFFFFu;   // 0xFFFF per active half
+      }
       if constexpr (P::kSplit) {
-        v[c].hi[j] = on ? v[c].hi[j] : (_Float16)0;
-        v[c].lo[j] = on ? v[c].lo[j] : (_Float16)0;
-      } else if constexpr (S == 8) v[c][j] = on ? v[c][j] : (_Float16)0;
-      else v[c] = on ? v[c] : 0.f;
+        v[c].hi = __builtin_bit_cast(half8, __builtin_bit_cast(u32x4, v[c].hi) & keep);
+        v[c].lo = __builtin_bit_cast(half8, __builtin_bit_cast(u32x4, v[c].lo) & keep);
+      } else {
+        v[c] = __builtin_bit_cast(half8, __builtin_bit_cast(u32x4, v[c]) & keep);
+      }
     }
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = ((m[c >> 5] >> (c & 31)) & 1u) ? v[c] : 0.f;
+  }
 }
 template <class P>
 DFN_DEV void clear_one(typename FragOf<P>::type& v) {
@@ -94,8 +136,13 @@ DFN_DEV void clear(typename FragOf<P>::type (&v)[N]) {
 // masks untouched and is divided out of the final 3 + 3 numbers.  Magnitudes drift from layer to layer, so sp is
 // re-centred now and then: this returns the power of two that brings the largest |hi| of `v` to [8, 16) (= sp * g in
 // [0.5, 1) after the x16 operand scale); it is applied to the NEXT layer's outputs (Stager::lane_mul), one layer lagged.
+// `sp_now`: the scale the vector already carries.  The total is capped at 2^96: a point whose incoming gradient is ~1e-10 (a
+// near-duplicate sample, delta z ~ 1e-8) and shrinks further along the chain would otherwise push sp past fp32's range, and
+// inf * (d sigma) = NaN poisoned its ray's — and through the pose reduction its frame's — gradient.  Beyond the cap the halves are
+// allowed to underflow: the true value is below 2^-96 of the gradient scale.
+constexpr float kSpCap = 7.9228163e28f;   // 2^96
 template <class P, int C, int N>
-DFN_DEV float renorm_factor(const typename FragOf<P>::type (&v)[N]) {
+DFN_DEV float renorm_factor(const typename FragOf<P>::type (&v)[N], float sp_now) {
   if constexpr (!P::kSplit) return 1.f;
   else {
     half8 m = __builtin_elementwise_abs(v[0].hi);
@@ -108,7 +155,8 @@ DFN_DEV float renorm_factor(const typename FragOf<P>::type (&v)[N]) {
     if (!(mx > 0.f)) return 1.f;
     int e;
     (void)frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
-    return ldexpf(1.f, 4 - e);
+    const float f = ldexpf(1.f, 4 - e);
+    return sp_now * f <= kSpCap ? f : 1.f;
   }
 }
 
@@ -120,6 +168,9 @@ template <class PF, class P> constexpr uint32_t bwd_lds_bytes() { return 3 * bwd
 // A plain layer of the backward kernel: a new staging unit, no bias folding, no activation, no pipelining.
 #define DFN_FLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
   layer<PF, UMBF, false, NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
+// ... whose outputs are rectified by the layer's own epilogue (relu_mask then only reads the signs)
+#define DFN_FLAYER_R(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
+  layer<PF, UMBF, false, NB, KC, MB, (PF::kSlotsPerChunk == 8), EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
 #define DFN_BLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
   layer<P, UMB, false, NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
 
@@ -191,7 +242,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
         if (mx > 0.f) {
           int e;
           (void)frexpf(mx, &e);
-          sp[nb] = ldexpf(1.f, -e);     // max |d raw| * sp in [0.5, 1)
+          sp[nb] = ldexpf(1.f, e < -64 ? 64 : -e);     // max |d raw| * sp in [0.5, 1) (scale capped at 2^64)
         }
       }
     }
@@ -202,13 +253,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
     [[maybe_unused]] float o9[NB][9];
     static_assert(MODE == 0 || NB == 1, "the two-pass form keeps one point block per wave");
     uint32_t* mwords = MODE ? a.masks + ((size_t)(tile * WAVES + st.wave) * kBwdMaskWords) * 64 + st.lane : nullptr;
+    // MODE 2 fetches each layer's sign mask from the saved forward right before the layer that produces the gradient it gates
+    // (the load's latency hides behind that layer's MFMAs) instead of holding all 21 words in registers for the whole chain.
+    auto fetch_mk = [&](int l) { if constexpr (MODE == 2) { mk[l][0][0] = mwords[(2 * l) * 64]; mk[l][0][1] = mwords[(2 * l + 1) * 64]; } };
+    auto fetch_md = [&]() { if constexpr (MODE == 2) md[0][0] = mwords[16 * 64]; };
+    auto fetch_mt = [&](int l) { if constexpr (MODE == 2) mt[l][0][0] = mwords[(17 + l) * 64]; };
     if constexpr (MODE == 2) {
-      // masks and head derivatives from the saved forward
-#pragma unroll
-      for (int l = 0; l < 8; ++l) { mk[l][0][0] = mwords[(2 * l) * 64]; mk[l][0][1] = mwords[(2 * l + 1) * 64]; }
-      md[0][0] = mwords[16 * 64];
-#pragma unroll
-      for (int l = 0; l < 4; ++l) mt[l][0][0] = mwords[(17 + l) * 64];
+      // head derivatives from the saved forward
       const uint32_t q = uint32_t(pt[0] < n_pts ? pt[0] : n_pts - 1);
       const float* rw = a.raw_in + size_t(q) * 9;
       const bool on = h == 0 && pt[0] < n_pts;
@@ -229,18 +280,22 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
     {
       FF pe[NB][FPC], u[NB][FHC];
       posenc_xyz<PF, FAST, NB, FPC>(x, h, pe);
-      DFN_FLAYER(FPC, 4, false, false, pe, u, norb);
+      DFN_FLAYER_R(FPC, 4, false, false, pe, u, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(u[nb], mk[0][nb]);
-      DFN_FLAYER(FHC, 4, false, false, u, hid, norb);
+      if constexpr (MODE == 1) { mwords[0 * 64] = mk[0][0][0]; mwords[1 * 64] = mk[0][0][1]; }
+      DFN_FLAYER_R(FHC, 4, false, false, u, hid, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[1][nb]);
-      DFN_FLAYER(FHC, 4, false, false, hid, u, norb);
+      if constexpr (MODE == 1) { mwords[2 * 64] = mk[1][0][0]; mwords[3 * 64] = mk[1][0][1]; }
+      DFN_FLAYER_R(FHC, 4, false, false, hid, u, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(u[nb], mk[2][nb]);
-      DFN_FLAYER(FHC, 4, false, false, u, hid, norb);
+      if constexpr (MODE == 1) { mwords[4 * 64] = mk[2][0][0]; mwords[5 * 64] = mk[2][0][1]; }
+      DFN_FLAYER_R(FHC, 4, false, false, u, hid, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[3][nb]);
+      if constexpr (MODE == 1) { mwords[6 * 64] = mk[3][0][0]; mwords[7 * 64] = mk[3][0][1]; }
       {
         FF cat[NB][FPC + FHC];
 #pragma unroll
@@ -250,19 +305,23 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 #pragma unroll
           for (int i = 0; i < FHC; ++i) cat[nb][FPC + i] = hid[nb][i];
         }
-        DFN_FLAYER(FPC + FHC, 4, false, false, cat, u, norb);
+        DFN_FLAYER_R(FPC + FHC, 4, false, false, cat, u, norb);
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(u[nb], mk[4][nb]);
-      DFN_FLAYER(FHC, 4, false, false, u, hid, norb);
+      if constexpr (MODE == 1) { mwords[8 * 64] = mk[4][0][0]; mwords[9 * 64] = mk[4][0][1]; }
+      DFN_FLAYER_R(FHC, 4, false, false, u, hid, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[5][nb]);
-      DFN_FLAYER(FHC, 4, false, false, hid, u, norb);
+      if constexpr (MODE == 1) { mwords[10 * 64] = mk[5][0][0]; mwords[11 * 64] = mk[5][0][1]; }
+      DFN_FLAYER_R(FHC, 4, false, false, hid, u, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(u[nb], mk[6][nb]);
-      DFN_FLAYER(FHC, 4, false, false, u, hid, norb);
+      if constexpr (MODE == 1) { mwords[12 * 64] = mk[6][0][0]; mwords[13 * 64] = mk[6][0][1]; }
+      DFN_FLAYER_R(FHC, 4, false, false, u, hid, norb);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FHC>(hid[nb], mk[7][nb]);
+      if constexpr (MODE == 1) { mwords[14 * 64] = mk[7][0][0]; mwords[15 * 64] = mk[7][0][1]; }
     }
     // heads; their pre-activation gradients seed the backward pass
     {
@@ -275,9 +334,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       }
       {
         FF de[NB][FQC];
-        DFN_FLAYER(FHC, 2, false, true, fin, de, rb_dir);
+        DFN_FLAYER_R(FHC, 2, false, true, fin, de, rb_dir);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(de[nb], md[nb]);
+        if constexpr (MODE == 1) mwords[16 * 64] = md[0][0];
         DFN_FLAYER(FQC, 0, true, false, de, dummy, norb);  // static_rgb
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -292,18 +352,22 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       }
       {
         FF t0[NB][FQC], t1[NB][FQC];
-        DFN_FLAYER(FHC, 2, false, true, fin, t0, rb_tr);
+        DFN_FLAYER_R(FHC, 2, false, true, fin, t0, rb_tr);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(t0[nb], mt[0][nb]);
-        DFN_FLAYER(FQC, 2, false, false, t0, t1, norb);
+        if constexpr (MODE == 1) mwords[17 * 64] = mt[0][0][0];
+        DFN_FLAYER_R(FQC, 2, false, false, t0, t1, norb);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(t1[nb], mt[1][nb]);
-        DFN_FLAYER(FQC, 2, false, false, t1, t0, norb);
+        if constexpr (MODE == 1) mwords[18 * 64] = mt[1][0][0];
+        DFN_FLAYER_R(FQC, 2, false, false, t1, t0, norb);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(t0[nb], mt[2][nb]);
-        DFN_FLAYER(FQC, 2, false, false, t0, t1, norb);
+        if constexpr (MODE == 1) mwords[19 * 64] = mt[2][0][0];
+        DFN_FLAYER_R(FQC, 2, false, false, t0, t1, norb);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) relu_mask<PF, FQC>(t1[nb], mt[3][nb]);
+        if constexpr (MODE == 1) mwords[20 * 64] = mt[3][0][0];
         DFN_FLAYER(FQC, 0, true, false, t1, dummy, norb);  // transient heads: rows 0..2 rgb, 3 sigma, 8 beta (C reg 4)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -323,11 +387,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 
     }   // MODE != 2
     if constexpr (MODE == 1) {
-#pragma unroll
-      for (int l = 0; l < 8; ++l) { mwords[(2 * l) * 64] = mk[l][0][0]; mwords[(2 * l + 1) * 64] = mk[l][0][1]; }
-      mwords[16 * 64] = md[0][0];
-#pragma unroll
-      for (int l = 0; l < 4; ++l) mwords[(17 + l) * 64] = mt[l][0][0];
       if (h == 0 && pt[0] < n_pts) {
         float* dst = a.raw_out + size_t(pt[0]) * 9;
 #pragma unroll
@@ -342,18 +401,23 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       F cat[NB][HC];
       {
         F g0[NB][QC], g1[NB][QC];
+        fetch_mt(3);
         DFN_BLAYER(SC, 2, false, false, dth, g1, norb);   // BW_THEAD
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g1[nb], mt[3][nb]);
+        fetch_mt(2);
         DFN_BLAYER(QC, 2, false, false, g1, g0, norb);    // BW_TE3
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g0[nb], mt[2][nb]);
+        fetch_mt(1);
         DFN_BLAYER(QC, 2, false, false, g0, g1, norb);    // BW_TE2
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g1[nb], mt[1][nb]);
+        fetch_mt(0);
         DFN_BLAYER(QC, 2, false, false, g1, g0, norb);    // BW_TE1
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g0[nb], mt[0][nb]);
+        fetch_md();
         DFN_BLAYER(SC, 2, false, false, drgb, g1, norb);  // BW_RGB
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -365,7 +429,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       F cat2[NB][HC + SC];
       {
         F dfin[NB][HC];
-        if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(cat[0]);   // the two branches share sp up to here
+        if constexpr (P::kSplit) {
+          st.lane_mul = renorm_factor<P, HC>(cat[0], sp[0]);   // the two branches share sp up to here
+          // d sigma_s joins the chain after this layer (slot 64 of BW_FIN's input) at the scale chosen HERE: when the colour /
+          // transient gradients of a point are orders of magnitude below its density gradient (near-duplicate samples: alpha ~ 0)
+          // a factor chosen from them alone overflowed that slot's f16 halves (inf -> NaN for the whole ray).  Keep
+          // |d sigma_s| * sp * 16 below 2^11.
+          float ds = fabsf(dsig_true[0]) * sp[0] * kX3ActScale * st.lane_mul;
+          ds = fmaxf(ds, __shfl_xor(ds, 32, 64));
+          if (ds > 2048.f) {
+            int e;
+            (void)frexpf(ds, &e);                 // ds = f * 2^e
+            st.lane_mul *= ldexpf(1.f, 11 - e);
+          }
+        }
         DFN_BLAYER(HC, 4, true, false, cat, dfin, norb);  // BW_FINCAT: d final + (head) d pe_dir
         if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
@@ -375,10 +452,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
           for (int c = 0; c < 3; ++c) {
             const float v = a.viewdirs[ray_of[nb] * 3 + c];
             float acc = h == 0 ? head[nb][12 + c] : 0.f;
+            float vh = 0.f, vl = 0.f;
+            if (P::kSplit) rev_split(v, vh, vl);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
               const float f = float(1 << k) * (h ? 4.f : 1.f);
-              acc += f * (cosf(v * f) * head[nb][6 * k + c] - sinf(v * f) * head[nb][6 * k + 3 + c]);
+              float sn, cs;
+              if (P::kSplit) rev_sincos(vh, vl, f, sn, cs);
+              else { sn = sinf(v * f); cs = cosf(v * f); }
+              acc += f * (cs * head[nb][6 * k + c] - sn * head[nb][6 * k + 3 + c]);
             }
             gv[nb][c] = acc / sp[nb];   // back to the true scale
           }
@@ -389,48 +471,67 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
           set_slot<P>(cat2[nb], 64, dsig_true[nb] * sp[nb]);   // slot 64 of half 0: d sigma_s pre-activation (h == 1 lanes hold 0)
         }
       }
-      if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(cat2[0]);
+      if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC + SC>(cat2[0], sp[0]);   // incl. the d sigma_s slot
+      fetch_mk(7);
       DFN_BLAYER(HC + SC, 4, false, false, cat2, gh, norb);  // BW_FIN
       if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
     }
     F gh2[NB][HC];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[7][nb]);
-    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0]);
+    fetch_mk(6);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L8
     if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[6][nb]);
+    fetch_mk(5);
     DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);          // BW_L7
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[5][nb]);
-    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0]);
+    fetch_mk(4);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L6
     if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[4][nb]);
     // positional-encoding Jacobian of d pe (slot order pe_xyz_feature()), accumulated into gx
+    // The split-f16 kernel evaluates the Jacobian's sin / cos with the exact-fract hardware path (rev_sincos: 4e-7 absolute, far
+    // inside the gradient tolerance): libm's full-range sinf / cosf expand into a large-argument reduction whose temporaries, on
+    // top of the live gradient vectors, were what spilled (152 + 61 registers around the two Jacobians).  Exact fp32 keeps libm.
+#ifdef DFN_DBG_SLOWTRIG
+    constexpr bool JFAST = false;
+#else
+    constexpr bool JFAST = P::kSplit;
+#endif
     auto pe_jacobian = [&](const F (&dpe)[NB][PC], bool first) {
-      float x2[NB][3];
+      [[maybe_unused]] FF pe[NB][FPC];
+      if constexpr (!JFAST) {   // exact fp32: the encoding itself, recomputed (libm sin / cos) instead of kept alive
+        float x2[NB][3];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          x2[nb][c] = x[nb][c];
-          asm volatile("" : "+v"(x2[nb][c]));  // recompute sin/cos here instead of keeping 32 slots alive
-        }
-      FF pe[NB][FPC];
-      posenc_xyz<PF, FAST, NB, FPC>(x2, h, pe);
+          for (int c = 0; c < 3; ++c) {
+            x2[nb][c] = x[nb][c];
+            asm volatile("" : "+v"(x2[nb][c]));
+          }
+        posenc_xyz<PF, FAST, NB, FPC>(x2, h, pe);
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+          const float xc = x[nb][c];
+          float uh = 0.f, ul = 0.f;
+          if (JFAST) rev_split(xc, uh, ul);
           float acc = 0.f;
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
             const float f = float(1 << k) * (h ? 32.f : 1.f);
-            acc += f * (get_slot<PF>(pe[nb], 6 * k + 3 + c) * get_slot<P>(dpe[nb], 6 * k + c) -
-                        get_slot<PF>(pe[nb], 6 * k + c) * get_slot<P>(dpe[nb], 6 * k + 3 + c));
+            float sn, cs;
+            if constexpr (JFAST) rev_sincos(uh, ul, f, sn, cs);
+            else { sn = get_slot<PF>(pe[nb], 6 * k + c); cs = get_slot<PF>(pe[nb], 6 * k + 3 + c); }
+            acc += f * (cs * get_slot<P>(dpe[nb], 6 * k + c) - sn * get_slot<P>(dpe[nb], 6 * k + 3 + c));
           }
           gx[nb][c] = (first ? 0.f : gx[nb][c]) + acc / sp[nb];
         }
@@ -442,28 +543,45 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       }
     };
     {
-      F big[NB][HC + PC];
-      DFN_BLAYER(HC, 6, false, false, gh2, big, norb);       // BW_L5: d h4 (128) + d pe_xyz (skip connection)
-      F dpe[NB][PC];
+      // BW_L5 = d h4 (M-blocks 0..3) + d pe_xyz through the skip connection (M-blocks 4, 5).  Two layer calls on the same input;
+      // as one 6-M-block layer its 96-register output on top of input and masks spilled.
+      fetch_mk(3);
+      if constexpr (UMB == 1) {
+        {   // the d pe M-blocks come FIRST in the blob (Packer::pack_bwd) and are folded to 3 floats while only the input is live
+          F dpe[NB][PC];
+          DFN_BLAYER(HC, 2, false, false, gh2, dpe, norb);   // BW_L5, M-blocks 4, 5
+          pe_jacobian(dpe, true);
+        }
+        DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);      // BW_L5, M-blocks 0..3
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[3][nb]);
+      } else {
+        F big[NB][HC + PC];
+        DFN_BLAYER(HC, 6, false, false, gh2, big, norb);
+        F dpe[NB][PC];
 #pragma unroll
-        for (int i = 0; i < HC; ++i) gh[nb][i] = big[nb][i];
+        for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-        for (int i = 0; i < PC; ++i) dpe[nb][i] = big[nb][HC + i];
-        apply_mask<P, HC>(gh[nb], mk[3][nb]);
+          for (int i = 0; i < HC; ++i) gh[nb][i] = big[nb][i];
+#pragma unroll
+          for (int i = 0; i < PC; ++i) dpe[nb][i] = big[nb][HC + i];
+          apply_mask<P, HC>(gh[nb], mk[3][nb]);
+        }
+        pe_jacobian(dpe, true);
       }
-      pe_jacobian(dpe, true);
     }
-    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0]);
+    fetch_mk(2);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L4
     if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[2][nb]);
+    fetch_mk(1);
     DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);          // BW_L3
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[1][nb]);
-    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0]);
+    fetch_mk(0);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L2
     if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll

@@ -215,7 +215,8 @@ def test_device_repack_equals_host_commit():
         a, pa = E1.forward(x, True, True, True, 64, 96, precision=prec)
         b, pb = E2.forward(x, True, True, True, 64, 96, precision=prec)
         assert torch.equal(a, b) and torch.equal(pa, pb), prec
-        assert torch.equal(E1.backward_input(x, G, precision=prec), E2.backward_input(x, G, precision=prec)), prec
+        if prec != "f16":   # gradients run in split-f16 / exact fp32 only (the library refuses plain f16)
+            assert torch.equal(E1.backward_input(x, G, precision=prec), E2.backward_input(x, G, precision=prec)), prec
 
     same("f16x3")                                      # the module re-packed its own precision only ...
     for prec in ("f32", "f16"):                        # ... the other two are stale and refused, not silently outdated

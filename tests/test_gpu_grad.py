@@ -770,3 +770,27 @@ def test_dm_train_step_at_c5_size_vs_oracle():
           f"worst {max(e_t32.values()):.2e}")
     assert e_pose < 2e-3
     assert all(e_hip[k] < max(1e-3, 4 * max(e_t32.values())) and e_hip[k] < 5e-3 for k in e_hip), e_hip
+
+
+def test_split_f16_gradient_chain_survives_density_only_gradients(scene):
+    """Points whose colour / transient gradients vanish next to their density gradient (near-duplicate samples: alpha ~ 0, so only
+    d sigma is non-zero, and tiny): the per-point power-of-two scale of the split-f16 chain used to be chosen from the colour
+    branches alone and overflowed the d sigma_s slot (inf -> NaN for the whole ray and, through the pose reduction, the frame)."""
+    E = scene[0]
+    g = torch.Generator().manual_seed(4)
+    n, Nf = 7, 64
+    o, d = torch.randn(n, 3, generator=g) * 0.3, torch.randn(n, 3, generator=g)
+    v = d / d.norm(dim=-1, keepdim=True)
+    z = torch.sort(torch.rand(n, Nf, generator=g) * 2.5)[0]
+    G = torch.zeros(n, Nf, 9)
+    G[..., 3] = torch.randn(n, Nf, generator=g) * 2.5e-10        # d sigma_s only ...
+    G[..., 7] = torch.randn(n, Nf, generator=g) * 1.2e-12        # ... and a much smaller d sigma_t
+    G[0, :, :] = torch.randn(Nf, 9, generator=g)                 # one ordinary ray beside them
+    G[1, :, 3] = 1e-30                                           # and one at the edge of fp32
+    args = [t.to(DEV) for t in (o, d, v)] + [dev(syn.HIST_IDX), z.to(DEV), G.to(DEV)]
+    ref = E.mlp_fine_backward(*args, precision="f32")
+    got = E.mlp_fine_backward(*args, precision="f16x3")
+    assert bool(torch.isfinite(got).all())
+    for r in range(n):
+        scale = float(ref[r].abs().max())
+        assert float((got[r] - ref[r]).abs().max()) <= 2e-5 * scale + 1e-37, r
