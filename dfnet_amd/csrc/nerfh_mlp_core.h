@@ -429,8 +429,9 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 // ------------------------------------------------------------------------------------------
 // Positional encoding of a point into the layer-1 B operand (slot map: pe_xyz_feature()).
 // FAST: x/(2pi) in two-term extended precision, exact fract, then v_sin_f32 / v_cos_f32 (which
-// take revolutions).  Otherwise full-range sinf/cosf of the exact product x * 2^k, bit-for-bit
-// the reference's sin(x * freq) up to libm rounding.
+// take revolutions), five octaves per coordinate-half from one evaluation by double-angle steps.  Otherwise: split-f16 takes
+// every octave from the same exact-fract hardware path (4e-7), exact fp32 the full-range sinf/cosf of the exact product
+// x * 2^k, bit-for-bit the reference's sin(x * freq) up to libm rounding.
 template <class P, bool FAST, int NB, int PC>
 DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type (&pe)[NB][PC]) {
 #ifdef DFN_ABL_NOPE  // ablation: no trig (timing only)
@@ -452,6 +453,20 @@ DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type
         for (int k = 0; k < 5; ++k) {
           set_slot<P>(pe[nb], 6 * k + c, sn[k]);
           set_slot<P>(pe[nb], 6 * k + 3 + c, cs[k]);
+        }
+      } else if constexpr (P::kSplit) {
+        // split-f16: every octave from the exact-fract hardware path (x / 2pi in two-term extended precision, exact v_fract,
+        // v_sin / v_cos in revolutions; max abs error 4.1e-7 vs fp64 = fp32 round-off of the encoding).  libm's full-range
+        // sinf / cosf expand to ~60 instructions each (large-argument reduction): 60 of them per point were HALF of this
+        // kernel's instruction stream (7 000 of 16 900 per tile, next to 1 080 MFMAs).
+        float uh, ul;
+        rev_split(xc, uh, ul);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          float sn, cs;
+          rev_sincos(uh, ul, base * float(1 << k), sn, cs);
+          set_slot<P>(pe[nb], 6 * k + c, sn);
+          set_slot<P>(pe[nb], 6 * k + 3 + c, cs);
         }
       } else {
         const float xb = xc * base;

@@ -300,7 +300,7 @@ def test_empty_and_extreme_inputs(scene):
     z = torch.zeros(0, 3, device=DEV)
     rgb, disp, acc, raw = E.render_rays(z, z, hist, 8, 16, 0., 2.5, retraw=True)
     assert rgb.shape == (0, 3) and disp.shape == (0,) and raw.shape == (0, 24, 9)
-    go, gd, _ = E.render_rays_backward(z, z, hist, 8, 16, 0., 2.5, z)
+    go, gd, _ = E.render_rays_backward(z, z, hist, 8, 16, 0., 2.5, z, precision="f16x3")
     assert go.shape == (0, 3) and gd.shape == (0, 3)
     o, d, _ = eng.raygen(1, 1, 1.0, T(syn.orbit_pose(0, 8)).to(DEV))
     one = E.render_rays(o.reshape(1, 3), d.reshape(1, 3), hist, 128, 384, 0., 2.5, precision="f32")
