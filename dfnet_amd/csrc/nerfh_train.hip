@@ -417,15 +417,23 @@ hipError_t gemm_bwd(const float* G, int ldg, int N, const float* W, int ldw, int
 // points; its four waves take a quarter of the chunk each and are summed through LDS in fixed order; chunk partials are
 // reduced in fixed order by wgrad_reduce_kernel (deterministic).
 constexpr int kWgradK = 4;  // 32-column blocks per workgroup
-// Points per chunk (multiple of 32): ~160 chunks x items workgroups fill the chip while the partial sums stay small.
-static inline int wgrad_chunk(long long P) {
-  long long ch = 256;
-  while ((P + ch - 1) / ch > 160) ch += 256;
+// Points per chunk (multiple of 32).  The launch is chunks x items workgroups of 4 waves, two resident per CU: the chunk count
+// is chosen so that ONE wave of workgroups fills the chip (512 slots on 256 CUs) instead of leaving a half-empty second
+// round, and stays <= 256 so that the partial sums remain a small fraction of the product.
+static inline int wgrad_items(int N, int K) { return ((N + 31) / 32) * ((K + kWgradK * 32 - 1) / (kWgradK * 32)); }
+static inline int wgrad_chunk(long long P, int items) {
+  long long chunks = 512 / (items < 1 ? 1 : items);
+  if (chunks < 1) chunks = 1;
+  if (chunks > 256) chunks = 256;
+  long long ch = ((P + chunks - 1) / chunks + 31) / 32 * 32;
+  if (ch < 32) ch = 32;
   return int(ch);
 }
 size_t gemm_wgrad_scratch_floats(int N, int K, long long P) {
-  const long long ch = wgrad_chunk(P), chunks = (P + ch - 1) / ch;
-  return size_t(chunks) * (size_t(N) * K + N);
+  // an upper bound over the segment widths a layer is split into: <= 256 chunks of [N][K] (+ [N])
+  const long long ch = wgrad_chunk(P, wgrad_items(N, K)), chunks = (P + ch - 1) / ch;
+  const long long worst = chunks > 256 ? chunks : 256;
+  return size_t(worst) * (size_t(N) * K + N);
 }
 
 struct WgradArgs {
@@ -463,25 +471,39 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs a) {
   for (int kb = 0; kb < kWgradK; ++kb) cok[kb] = k0 + kb * 32 + i < K;
   const float* gp = a.G + (w0 + 4 * kh) * a.ldg + n0 + i;
   const float* xp = a.x.x + (w0 + 4 * kh) * a.x.ld + k0 + i;     // div == 1 fast path
-  for (long long p = w0; p < w1; p += 8) {
-    float av[4], bv[kWgradK][4];
+  // Two register stages: the loads of points p + 8 .. p + 15 are in flight while the MFMAs of p .. p + 7 run (one HBM latency
+  // per 8 points would otherwise sit in front of every 16 MFMAs).
+  float av[2][4], bv[2][kWgradK][4];
+  auto load_stage = [&](int st, long long p) {
     const bool whole = p + 8 <= w1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const long long pq = p + 4 * kh + q;
       const bool ok = whole || pq < w1;
-      av[q] = (ok && nok) ? gp[(size_t)q * a.ldg] : 0.f;
-      bsum += av[q];
+      av[st][q] = (ok && nok) ? gp[(size_t)q * a.ldg] : 0.f;
       const float* xr = a.x.div == 1 ? xp + (size_t)q * a.x.ld : a.x.x + (pq / a.x.div) * a.x.ld + k0 + i;
 #pragma unroll
-      for (int kb = 0; kb < kWgradK; ++kb) bv[kb][q] = (ok && cok[kb]) ? xr[kb * 32] : 0.f;
+      for (int kb = 0; kb < kWgradK; ++kb) bv[st][kb][q] = (ok && cok[kb]) ? xr[kb * 32] : 0.f;
     }
     gp += (size_t)8 * a.ldg;
     xp += (size_t)8 * a.x.ld;
+  };
+  auto mma_stage = [&](int st) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q) {
+      bsum += av[st][q];
 #pragma unroll
-      for (int kb = 0; kb < kWgradK; ++kb) acc[kb] = mfma32(av[q], bv[kb][q], acc[kb]);
+      for (int kb = 0; kb < kWgradK; ++kb) acc[kb] = mfma32(av[st][q], bv[st][kb][q], acc[kb]);
+    }
+  };
+  if (w0 < w1) load_stage(0, w0);
+  for (long long p = w0; p < w1; p += 16) {
+    if (p + 8 < w1) load_stage(1, p + 8);
+    mma_stage(0);
+    if (p + 8 < w1) {
+      if (p + 16 < w1) load_stage(0, p + 16);
+      mma_stage(1);
+    }
   }
   if (wave > 0) {
     float* r = red[wave - 1];
@@ -547,7 +569,7 @@ hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW
                       long long P, hipStream_t s) {
   if (N <= 0 || xseg.K <= 0) return hipSuccess;
   if (P <= 0) return hipErrorInvalidValue;
-  const int ch = wgrad_chunk(P);
+  const int ch = wgrad_chunk(P, wgrad_items(N, xseg.K));
   const int chunks = int((P + ch - 1) / ch);
   WgradArgs a{};
   a.G = G; a.ldg = ldg; a.N = N; a.x = xseg; a.P = P; a.chunk = ch;
