@@ -221,6 +221,9 @@ def hbm_records(prof, K, E, dev):
                                                      "render composites inside the fine kernel)",
                                     "note": "torch events around 10 back-to-back launches on a 61,440-ray pass"}
     out["peak_GBps"] = HBM_PEAK_GBS
+    out["note"] = ("sample_fine / ray_bias are one-wave-per-ray kernels whose time goes to serial wave scans, binary searches and the "
+                   "sort in LDS (PMC: SQ_WAIT_ANY / SQ_WAVE_CYCLES = 58 %), not to HBM: their GB/s is reported because north_star asks for "
+                   "it; together they are 3 % of a frame")
     return out
 
 
