@@ -157,6 +157,7 @@ struct Mat {  // a state_dict Linear
 struct Packer {
   const dfn_nerfh_s* h;
   std::string pre;
+  int width() const { return h->desc.width; }
   mutable int fwd_units = 0;   // pack_bwd: number of forward units at the head of the table
   Mat mat(const std::string& key) const {
     Mat m;
@@ -176,7 +177,7 @@ struct Packer {
         m = mat("xyz_encoding_" + std::to_string(layer - LY_L1 + 1) + ".0");
         break;
       case LY_FIN:
-        if (mb < 4) m = mat("xyz_encoding_final");
+        if (mb < width() / 32) m = mat("xyz_encoding_final");
         else { m = mat("static_sigma.0"); row = i == 0 ? 0 : -1; }
         break;
       case LY_DIR: m = mat("dir_encoding.0"); break;
@@ -210,7 +211,7 @@ struct Packer {
   template <class P>
   void pack_blocks(int layer, int mb0, int group, uint8_t* base) const {
     using Elem = typename std::conditional<P::kSlotsPerChunk == 8, _Float16, float>::type;
-    const LayerShape sh = layer_shape(layer);
+    const LayerShape sh = layer_shape(layer, width());
     const int KC = sh.slots / P::kSlotsPerChunk;
     Elem* frag = reinterpret_cast<Elem*>(base);
     float* bias = reinterpret_cast<float*>(base + size_t(group) * KC * 64 * P::kLaneBytes);
@@ -333,8 +334,8 @@ struct Packer {
   }
 
   template <class P>
-  static uint32_t blocks_bytes(int layer, int group) {
-    const LayerShape sh = layer_shape(layer);
+  uint32_t blocks_bytes(int layer, int group) const {
+    const LayerShape sh = layer_shape(layer, width());
     return uint32_t(group) * (sh.slots / P::kSlotsPerChunk) * 64 * P::kLaneBytes + uint32_t(group) * 128;
   }
 
@@ -349,9 +350,9 @@ struct Packer {
       for (int li = 0; li < nl;) {
         int lj = li;
         uint32_t bytes = 0;
-        while (lj < nl && grp[lj] == grp[li]) bytes += blocks_bytes<P>(seq[lj], layer_shape(seq[lj]).mb), ++lj;
+        while (lj < nl && grp[lj] == grp[li]) bytes += blocks_bytes<P>(seq[lj], layer_shape(seq[lj], width()).mb), ++lj;
         if (seq[li] == LY_L5) {  // split so that three staging buffers fit in LDS (nerfh_layout.h: l5_unit_mb)
-          const LayerShape sh = layer_shape(LY_L5);
+          const LayerShape sh = layer_shape(LY_L5, width());
           const int g = l5_unit_mb(umb);
           for (int mb0 = 0; mb0 < sh.mb; mb0 += g) {
             const uint32_t ub = unit_bytes<P>(sh.slots, g), uo = uint32_t(blob.size());
@@ -369,15 +370,15 @@ struct Packer {
         tab.push_back(align_piece(bytes));
         uint32_t at = off;
         for (int l = li; l < lj; ++l) {
-          pack_blocks<P>(seq[l], 0, layer_shape(seq[l]).mb, blob.data() + at);
-          at += blocks_bytes<P>(seq[l], layer_shape(seq[l]).mb);
+          pack_blocks<P>(seq[l], 0, layer_shape(seq[l], width()).mb, blob.data() + at);
+          at += blocks_bytes<P>(seq[l], layer_shape(seq[l], width()).mb);
         }
         li = lj;
       }
       return;
     }
     for (int li = 0; li < nl; ++li) {
-      const LayerShape sh = layer_shape(seq[li]);
+      const LayerShape sh = layer_shape(seq[li], width());
       for (int mb0 = 0; mb0 < sh.mb; mb0 += umb) {
         const int group = sh.mb - mb0 < umb ? sh.mb - mb0 : umb;
         const uint32_t bytes = unit_bytes<P>(sh.slots, group);
@@ -419,10 +420,38 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
     if (rc) return rc;
     for (size_t o : offs) h->gen_params.push_back(h->gen_blob + o);
   }
-  if (h->desc.width != kWidth) {
+  const int Wd = h->desc.width;
+  if (Wd != kWidth && Wd != kMaxWidth) {   // generic-width path only
     h->committed = true;
     return DFN_OK;
   }
+  if (Wd == kMaxWidth) {   // netwidth 256: one kernel variant per precision, plain staging units (nerfh_mlp.hip: launch_mlp)
+    for (int f = 0; f < 2; ++f)
+      for (int prec = 0; prec < 3; ++prec) {
+        Packer pk{h, f ? "fine." : "coarse."};
+        std::vector<uint8_t> blob;
+        std::vector<uint32_t> tab;
+        PackedNet& n = h->net[f][prec][0];
+        if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, unit_mb_w256<PrecF16>(), false, blob, tab);
+        else if (prec == DFN_PREC_F32) pk.pack<PrecF32>(f, unit_mb_w256<PrecF32>(), false, blob, tab);
+        else {
+          float wmax = 0.f;
+          for (const auto& kv : h->params)
+            if (kv.first.compare(0, pk.pre.size(), pk.pre) == 0 && kv.first.find(".weight") != std::string::npos)
+              for (float v : kv.second) wmax = std::fmax(wmax, std::fabs(v));
+          int sexp = wmax > 0.f ? 10 - int(std::ceil(std::log2(wmax))) : 0;
+          sexp = sexp < -8 ? -8 : (sexp > 24 ? 24 : sexp);
+          pk.wscale = std::ldexp(1.f, sexp);
+          n.in_scale = pk.wscale * kX3ActScale;
+          pk.pack<PrecX3>(f, unit_mb_w256<PrecX3>(), false, blob, tab);
+        }
+        int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
+        if (rc) return rc;
+        rc = upload(tab.data(), tab.size() * 4, reinterpret_cast<void**>(&n.tab));
+        if (rc) return rc;
+        n.n_units = int(tab.size() / 2);
+      }
+  } else {
   for (int f = 0; f < 2; ++f)
     for (int prec = 0; prec < 3; ++prec)
       for (int var = 0; var < kVariants; ++var) {
@@ -469,9 +498,10 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
     n.n_units = int(tab.size() / 2);
     n.n_fwd_units = pk.fwd_units;
   }
+  }   // netwidth 128
   // per-ray-bias weights: transposed tails of dir_encoding.0 / transient_encoding.0 + embeddings
   const dfn_nerfh_desc& d = h->desc;
-  const int na = d.hist_bin * d.dim_a, nt = d.hist_bin * d.dim_t, kd = kChDir + na;
+  const int na = d.hist_bin * d.dim_a, nt = d.hist_bin * d.dim_t, kd = kChDir + na, NO = Wd / 2;
   const auto& wd = h->params.at("fine.dir_encoding.0.weight");
   const auto& bd = h->params.at("fine.dir_encoding.0.bias");
   const auto& wt = h->params.at("fine.transient_encoding.0.weight");
@@ -479,16 +509,16 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
   const auto& ea = h->params.at("embedding_a.weight");
   const auto& et = h->params.at("embedding_t.weight");
   std::vector<float> ex;
-  const size_t o_wd = 0, o_bd = o_wd + size_t(kd) * 64, o_wt = o_bd + 64, o_bt = o_wt + size_t(nt) * 64,
-               o_ea = o_bt + 64, o_et = o_ea + ea.size();
+  const size_t o_wd = 0, o_bd = o_wd + size_t(kd) * NO, o_wt = o_bd + NO, o_bt = o_wt + size_t(nt) * NO,
+               o_ea = o_bt + NO, o_et = o_ea + ea.size();
   ex.resize(o_et + et.size());
-  const int ld_d = kWidth + kd, ld_t = kWidth + nt;
+  const int ld_d = Wd + kd, ld_t = Wd + nt;
   for (int j = 0; j < kd; ++j)
-    for (int f = 0; f < 64; ++f) ex[o_wd + size_t(j) * 64 + f] = wd[size_t(f) * ld_d + kWidth + j];
+    for (int f = 0; f < NO; ++f) ex[o_wd + size_t(j) * NO + f] = wd[size_t(f) * ld_d + Wd + j];
   for (int j = 0; j < nt; ++j)
-    for (int f = 0; f < 64; ++f) ex[o_wt + size_t(j) * 64 + f] = wt[size_t(f) * ld_t + kWidth + j];
-  std::memcpy(&ex[o_bd], bd.data(), 64 * 4);
-  std::memcpy(&ex[o_bt], bt.data(), 64 * 4);
+    for (int f = 0; f < NO; ++f) ex[o_wt + size_t(j) * NO + f] = wt[size_t(f) * ld_t + Wd + j];
+  std::memcpy(&ex[o_bd], bd.data(), NO * 4);
+  std::memcpy(&ex[o_bt], bt.data(), NO * 4);
   std::memcpy(&ex[o_ea], ea.data(), ea.size() * 4);
   std::memcpy(&ex[o_et], et.data(), et.size() * 4);
   int rc = upload(ex.data(), ex.size() * 4, reinterpret_cast<void**>(&h->extra));
@@ -503,6 +533,7 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
   h->rb.dim_a = d.dim_a;
   h->rb.dim_t = d.dim_t;
   h->rb.n_vocab = d.n_vocab;
+  h->rb.nout = NO;
   h->committed = true;
   h->fast = true;
   return DFN_OK;
@@ -566,14 +597,20 @@ static int check_net(dfn_nerfh_t h, int prec, const char* fn, bool allow_x3 = fa
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_nerfh_commit() has not been called", fn);
   if (!h->fast)
-    return set_error(DFN_ERR_UNSUPPORTED, "%s: the register-resident kernels are specialised for netwidth %d (this handle: %d); "
-                     "use the generic-width entry points (dfn_nerfh_generic_*)", fn, kWidth, h->desc.width);
+    return set_error(DFN_ERR_UNSUPPORTED, "%s: the register-resident kernels exist for netwidth %d and %d (this handle: %d); "
+                     "use the generic-width entry points (dfn_nerfh_generic_*)", fn, kWidth, kMaxWidth, h->desc.width);
   if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && !(allow_x3 && prec == DFN_PREC_F16X3))
     return set_error(DFN_ERR_ARG, "%s: unknown / unsupported precision %d", fn, prec);
   return DFN_OK;
 }
 
 // Gradient entry points: fp32-grade arithmetic only (DFN_PREC_F32, DFN_PREC_F16X3).
+static int check_grad_width(dfn_nerfh_t h, const char* fn) {
+  if (h->desc.width != kWidth)
+    return set_error(DFN_ERR_UNSUPPORTED, "%s: the input-gradient kernels are built for netwidth %d only (this handle: %d)", fn, kWidth,
+                     h->desc.width);
+  return DFN_OK;
+}
 static int check_grad_prec(int prec, const char* fn) {
   if (prec == DFN_PREC_F16)
     return set_error(DFN_ERR_UNSUPPORTED, "%s: gradients run in DFN_PREC_F16X3 or DFN_PREC_F32 only (plain-f16 ReLU gates are 3e-2 off "
@@ -582,7 +619,9 @@ static int check_grad_prec(int prec, const char* fn) {
 }
 
 // Kernel variant: DFN_MLP_VARIANT=0|1|2 (A/B aid, see nerfh_layout.h).
-static int mlp_variant() {
+static int mlp_variant_128();
+static int mlp_variant_of(dfn_nerfh_t h) { return h->desc.width == kWidth ? mlp_variant_128() : 0; }
+static int mlp_variant_128() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DFN_MLP_VARIANT");
@@ -613,10 +652,10 @@ extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, cons
   if (int rc = check_net(h, prec, "dfn_mlp_coarse", true)) return rc;
   if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !sigma || Nc < 1) return set_error(DFN_ERR_ARG, "dfn_mlp_coarse: bad argument");
-  const PackedNet& n = h->net[0][prec][mlp_variant()];
+  const PackedNet& n = h->net[0][prec][mlp_variant_of(h)];
   MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr, n.in_scale};
   ScopedTimer t(0, HS(stream));
-  CHECK_HIP(launch_mlp(false, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_coarse");
+  CHECK_HIP(launch_mlp(false, prec, mlp_variant_of(h), a, device_cu_count(), HS(stream), h->desc.width), "dfn_mlp_coarse");
   return DFN_OK;
 }
 
@@ -657,7 +696,7 @@ extern "C" int dfn_upsample_bicubic_backward(const float* grad_out, int H, int W
   return DFN_OK;
 }
 
-extern "C" size_t dfn_fine_bias_bytes(size_t n_rays) { return (n_rays ? n_rays : 1) * kRayBiasFloats * sizeof(float); }
+extern "C" size_t dfn_fine_bias_bytes(size_t n_rays) { return (n_rays ? n_rays : 1) * ray_bias_floats(kMaxWidth) * sizeof(float); }
 
 extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d, const float* viewdirs,
                             const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf,
@@ -669,10 +708,10 @@ extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const 
     return set_error(DFN_ERR_ARG, "dfn_mlp_fine: bad argument (hist_rows must be 1 or n_rays)");
   float* table = static_cast<float*>(bias_ws);
   CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine(ray_bias)");
-  const PackedNet& n = h->net[1][prec][mlp_variant()];
+  const PackedNet& n = h->net[1][prec][mlp_variant_of(h)];
   MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, nullptr, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf, n.in_scale};
   ScopedTimer t(1, HS(stream));
-  CHECK_HIP(launch_mlp(true, prec, mlp_variant(), a, device_cu_count(), HS(stream)), "dfn_mlp_fine");
+  CHECK_HIP(launch_mlp(true, prec, mlp_variant_of(h), a, device_cu_count(), HS(stream), h->desc.width), "dfn_mlp_fine");
   return DFN_OK;
 }
 
@@ -712,7 +751,7 @@ Workspace carve(char* base, size_t n_rays, int Nc, int Ni, bool own_rays) {
   w.sigma = take(chunk * Nc * 4);
   w.z = take(chunk * Nf * 4);
   w.raw = take(chunk * Nf * 9 * 4);
-  w.bias = take(chunk * kRayBiasFloats * 4);
+  w.bias = take(chunk * ray_bias_floats(kMaxWidth) * 4);
   w.partial = take(chunk * ((Nf + 63) / 64) * 12 * 4);
   w.total = off;
   return w;
@@ -724,8 +763,8 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
   const int Nf = Nc + Ni;
   // Compositing is fused into the fine kernel when a wave's 64 points are one ray segment and raw is not wanted
   // (f16 variants 0/1/3 hold 64 points per wave; the f32 and 3-block variants keep the separate compositor).
-  const int var = mlp_variant();
-  const bool fused = !raw_out && Nf % 64 == 0 && prec == DFN_PREC_F16 && var != 2 && !getenv("DFN_NO_FUSED_COMPOSITE");
+  const int var = mlp_variant_of(h);
+  const bool fused = !raw_out && Nf % 64 == 0 && prec == DFN_PREC_F16 && var != 2 && h->desc.width == kWidth && !getenv("DFN_NO_FUSED_COMPOSITE");
   const PackedNet& nc = h->net[0][prec][var];
   const PackedNet& nf = h->net[1][prec][var];
   const int cus = device_cu_count();
@@ -740,7 +779,7 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     {
       MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale};
       ScopedTimer t(0, s);
-      CHECK_HIP(launch_mlp(false, prec, var, a, cus, s), "render: coarse MLP");
+      CHECK_HIP(launch_mlp(false, prec, var, a, cus, s, h->desc.width), "render: coarse MLP");
     }
     {
       ScopedTimer t(DFN_PROF_SAMPLE_FINE, s);
@@ -753,7 +792,7 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     {
       MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, fused ? w.partial : nullptr, (long long)n, Nf, 0.f, 0.f, g_timing_buf, nf.in_scale};
       ScopedTimer t(1, s);
-      CHECK_HIP(launch_mlp(true, prec, var, a, cus, s), "render: fine MLP");
+      CHECK_HIP(launch_mlp(true, prec, var, a, cus, s, h->desc.width), "render: fine MLP");
     }
     if (fused) {
       ScopedTimer t(DFN_PROF_COMBINE, s);
@@ -832,6 +871,7 @@ extern "C" int dfn_mlp_fine_backward(dfn_nerfh_t h, int prec, const float* rays_
                                      const float* grad_raw, float* grad_pts, void* bias_ws, void* stream) {
   if (int rc = check_net(h, prec, "dfn_mlp_fine_backward", true)) return rc;
   if (int rc = check_grad_prec(prec, "dfn_mlp_fine_backward")) return rc;
+  if (int rc = check_grad_width(h, "dfn_mlp_fine_backward")) return rc;
   if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !grad_raw || !grad_pts || !bias_ws || Nf < 1 ||
       (hist_rows != 1 && hist_rows != n_rays))
@@ -852,6 +892,7 @@ extern "C" int dfn_mlp_fine_saving(dfn_nerfh_t h, int prec, const float* rays_o,
                                    const float* hist, size_t hist_rows, size_t n_rays, const float* z_fine, int Nf, float* raw,
                                    void* masks, void* bias_ws, void* stream) {
   if (int rc = check_net(h, prec, "dfn_mlp_fine_saving", true)) return rc;
+  if (int rc = check_grad_width(h, "dfn_mlp_fine_saving")) return rc;
   if (prec != DFN_PREC_F16X3) return set_error(DFN_ERR_UNSUPPORTED, "dfn_mlp_fine_saving: split-f16 (DFN_PREC_F16X3) only");
   if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !viewdirs || !hist || !z_fine || !raw || !masks || !bias_ws || Nf < 1 ||
@@ -870,6 +911,7 @@ extern "C" int dfn_mlp_fine_backward_saved(dfn_nerfh_t h, int prec, const float*
                                            size_t n_rays, const float* z_fine, int Nf, const float* raw, const void* masks,
                                            const float* grad_raw, float* grad_pts, void* stream) {
   if (int rc = check_net(h, prec, "dfn_mlp_fine_backward_saved", true)) return rc;
+  if (int rc = check_grad_width(h, "dfn_mlp_fine_backward_saved")) return rc;
   if (prec != DFN_PREC_F16X3) return set_error(DFN_ERR_UNSUPPORTED, "dfn_mlp_fine_backward_saved: split-f16 (DFN_PREC_F16X3) only");
   if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !viewdirs || !z_fine || !raw || !masks || !grad_raw || !grad_pts || Nf < 1)
@@ -924,7 +966,7 @@ BwdWorkspace carve_bwd(char* base, size_t n_rays, int Nc, int Ni) {
 int render_backward_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const float* v, bool derive_v,
                          const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far,
                          const float* grad_rgb, float* go, float* gd, float* gv, const BwdWorkspace& w, hipStream_t s) {
-  const int Nf = Nc + Ni, var = mlp_variant(), cus = device_cu_count();
+  const int Nf = Nc + Ni, var = mlp_variant_of(h), cus = device_cu_count();
   const PackedNet& nc = h->net[0][prec][var];
   const PackedNet& nf = h->net[1][prec][var];
   const PackedNet& nb = h->bwd[prec];
@@ -936,11 +978,11 @@ int render_backward_core(dfn_nerfh_t h, int prec, const float* o, const float* d
     const float* cv = v + r0 * 3;
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
     MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale};
-    CHECK_HIP(launch_mlp(false, prec, var, ac, cus, s), "render backward: coarse MLP");
+    CHECK_HIP(launch_mlp(false, prec, var, ac, cus, s, h->desc.width), "render backward: coarse MLP");
     CHECK_HIP(launch_sample_fine(w.f.sigma, n, Nc, Ni, near, far, w.f.z, nullptr, nullptr, s), "render backward: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.f.bias, s), "render backward: ray_bias");
     MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr, nf.in_scale};
-    CHECK_HIP(launch_mlp(true, prec, var, af, cus, s), "render backward: fine MLP");
+    CHECK_HIP(launch_mlp(true, prec, var, af, cus, s, h->desc.width), "render backward: fine MLP");
     CHECK_HIP(launch_composite_fine_backward(w.f.raw, w.f.z, grad_rgb + r0 * 3, n, Nf, w.graw, s), "render backward: composite");
     BwdArgs ab{nb.blob, nb.tab, nb.n_units, co, cd, cv, w.f.z, w.f.bias, w.graw, w.gpts, (long long)n, Nf, nb.in_scale};
     CHECK_HIP(launch_mlp_fine_backward(prec, ab, cus, s), "render backward: fine MLP gradient");
@@ -962,6 +1004,7 @@ extern "C" int dfn_render_rays_backward(dfn_nerfh_t h, int prec, const float* ra
                                         float* grad_viewdirs, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_net(h, prec, "dfn_render_rays_backward", true)) return rc;
   if (int rc = check_grad_prec(prec, "dfn_render_rays_backward")) return rc;
+  if (int rc = check_grad_width(h, "dfn_render_rays_backward")) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_rays_backward")) return rc;
   if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !hist || !grad_rgb || !grad_rays_o || !grad_rays_d || !workspace ||
@@ -985,6 +1028,7 @@ extern "C" int dfn_render_image_backward(dfn_nerfh_t h, int prec, const float* c
                                          float* grad_c2w, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_net(h, prec, "dfn_render_image_backward", true)) return rc;
   if (int rc = check_grad_prec(prec, "dfn_render_image_backward")) return rc;
+  if (int rc = check_grad_width(h, "dfn_render_image_backward")) return rc;
   if (int rc = check_render_args(Nc, Ni, "dfn_render_image_backward")) return rc;
   if (!c2w || !hist || !grad_rgb || !grad_c2w || !workspace || H < 1 || W < 1 || !(focal > 0))
     return set_error(DFN_ERR_ARG, "dfn_render_image_backward: bad argument");

@@ -23,7 +23,7 @@ struct MlpArgs {
   float in_scale;          // split-f16 only: weight scale x activation scale carried by the accumulators (else 1)
 };
 
-hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream);
+hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width = 128);
 
 // --- stages (nerfh_stages.hip)
 hipError_t launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
@@ -32,13 +32,14 @@ hipError_t launch_viewdirs(const float* rays_d, size_t n, float* viewdirs, hipSt
 hipError_t launch_posenc(const float* x, size_t n, int L, int mode, float* out, hipStream_t stream);
 
 struct RayBiasWeights {       // device pointers, fp32
-  const float* w_dir;         // [77][64]  transposed dir_encoding.0.weight[:, 128:205]
-  const float* b_dir;         // [64]
-  const float* w_tr;          // [20][64]  transposed transient_encoding.0.weight[:, 128:148]
-  const float* b_tr;          // [64]
+  const float* w_dir;         // [77][nout]  transposed dir_encoding.0.weight[:, W:W+77]
+  const float* b_dir;         // [nout]
+  const float* w_tr;          // [20][nout]  transposed transient_encoding.0.weight[:, W:W+20]
+  const float* b_tr;          // [nout]
   const float* emb_a;         // [n_vocab, dim_a]
   const float* emb_t;         // [n_vocab, dim_t]
   int hist_bin, dim_a, dim_t, n_vocab;
+  int nout;                   // outputs per table = netwidth / 2 (w_dir, w_tr are [*][nout]; the table row is 2 * nout floats)
 };
 hipError_t launch_ray_bias(const RayBiasWeights& w, const float* viewdirs, const float* hist,
                            size_t hist_rows, size_t n_rays, float* table, hipStream_t stream);

@@ -44,17 +44,18 @@ enum LayerId {
 
 struct LayerShape { int slots; int mb; };  // slots per half (= K/2), number of 32-row M-blocks
 
-DFN_HD constexpr LayerShape layer_shape(int id) {
-  return id == LY_L1 ? LayerShape{32, 4}
-       : id == LY_L5 ? LayerShape{96, 4}
-       : id <= LY_L8 ? LayerShape{64, 4}
-       : id == LY_FIN ? LayerShape{64, 5}
-       : id == LY_DIR ? LayerShape{64, 2}
-       : id == LY_RGB ? LayerShape{32, 1}
-       : id == LY_TE0 ? LayerShape{64, 2}
-       : id <= LY_TE3 ? LayerShape{32, 2}
-       : id == LY_THEAD ? LayerShape{32, 1}
-       : LayerShape{64, 1};  // LY_SIG
+// W = netwidth: 128 (every kernel variant) or 256 (the plain one-M-block-unit variants, nerfh_mlp.hip).
+DFN_HD constexpr LayerShape layer_shape(int id, int W = kWidth) {
+  return id == LY_L1 ? LayerShape{32, W / 32}
+       : id == LY_L5 ? LayerShape{32 + W / 2, W / 32}
+       : id <= LY_L8 ? LayerShape{W / 2, W / 32}
+       : id == LY_FIN ? LayerShape{W / 2, W / 32 + 1}
+       : id == LY_DIR ? LayerShape{W / 2, W / 64}
+       : id == LY_RGB ? LayerShape{W / 4, 1}
+       : id == LY_TE0 ? LayerShape{W / 2, W / 64}
+       : id <= LY_TE3 ? LayerShape{W / 4, W / 64}
+       : id == LY_THEAD ? LayerShape{W / 4, 1}
+       : LayerShape{W / 2, 1};  // LY_SIG
 }
 
 // The layer sequences the kernels execute, in order.
@@ -103,6 +104,8 @@ template <class P> DFN_HD constexpr int unit_mb(int variant) {
   return (P::kSlotsPerChunk == 1 || P::kSplit) ? 1 : (variant == 1 ? 2 : 8);
 }
 DFN_HD constexpr int variant_waves(int variant) { return variant == 0 ? 8 : 4; }
+// netwidth 256: M-blocks per staging unit
+template <class P> DFN_HD constexpr int unit_mb_w256() { return (P::kSlotsPerChunk == 1 || P::kSplit) ? 1 : 2; }
 
 constexpr uint32_t kPiece = 1024;  // staging granule: one wave-wide 16-byte LDS-DMA
 
@@ -119,9 +122,9 @@ DFN_HD constexpr uint32_t unit_bytes(int slots, int nmb) {
 // buffers fit the 160 KB of LDS; the largest unit is then the merged transient group (44 fragments + 9 bias blocks).
 DFN_HD constexpr int l5_unit_mb(int umb) { return umb >= 8 ? 2 : umb; }
 template <class P>
-DFN_HD constexpr uint32_t max_unit_bytes(int umb) {
-  const int m5 = l5_unit_mb(umb);
-  const uint32_t a = unit_bytes<P>(96, m5 < 4 ? m5 : 4), b = unit_bytes<P>(64, umb < 5 ? umb : 5);
+DFN_HD constexpr uint32_t max_unit_bytes(int umb, int W = kWidth) {
+  const int m5 = l5_unit_mb(umb), mbw = W / 32;
+  const uint32_t a = unit_bytes<P>(32 + W / 2, m5 < mbw ? m5 : mbw), b = unit_bytes<P>(W / 2, umb < mbw + 1 ? umb : mbw + 1);
   const uint32_t g = umb >= 8 ? align_piece(44u * 64 * P::kLaneBytes + 9u * 128) : 0;
   return a > b ? (a > g ? a : g) : (b > g ? b : g);
 }
@@ -171,6 +174,8 @@ DFN_HD constexpr uint32_t bwd_max_unit_bytes() {
 
 // Per-ray bias table written by the ray-bias kernel and read by the fine kernel:
 // [ray][table(0 = dir_encoding, 1 = transient_encoding.0)][mb(2)][h(2)][r(16)] fp32.
-constexpr int kRayBiasFloats = 2 * 2 * 2 * 16;
+constexpr int kRayBiasFloats = 2 * 2 * 2 * 16;   // netwidth 128
+DFN_HD constexpr int ray_bias_floats(int W) { return W; }   // 2 tables x (W / 64) M-blocks x 2 halves x 16
+constexpr int kMaxWidth = 256;   // widest netwidth of the register-resident kernels
 
 }  // namespace dfn

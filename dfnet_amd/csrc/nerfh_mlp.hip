@@ -26,13 +26,20 @@
 namespace dfn {
 
 // three staging buffers + per-wave next-tile input slots (8 dwords x 64 lanes per 64 points: z, o, d, next z)
-template <class P, int UMB, int WAVES, int NB> constexpr uint32_t lds_bytes() {
-  return 3 * max_unit_bytes<P>(UMB) + WAVES * ((NB * 32 + 63) / 64) * 8 * 256;
+template <class P, int UMB, int WAVES, int NB, int W = kWidth> constexpr uint32_t lds_bytes() {
+  return 3 * max_unit_bytes<P>(UMB, W) + WAVES * ((NB * 32 + 63) / 64) * 8 * 256;
+}
+
+// Workgroups per CU the register allocation is sized for.  netwidth 256 in split-f16 / exact fp32 holds 2 x 128 registers of
+// activations per point block: four waves per workgroup, ONE workgroup per CU (512 registers per lane).
+template <class P, int WAVES, int NB, int W> constexpr int mlp_min_blocks() {
+  if (W > kWidth && (P::kSplit || P::kSlotsPerChunk == 1)) return 1;
+  return WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1) : 2;
 }
 
 // ------------------------------------------------------------------------------------------
-template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE>
-__global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1) : 2)) void nerfh_coarse_kernel(MlpArgs a) {
+template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE, int W = kWidth>
+__global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) void nerfh_coarse_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PPT = WAVES * NB * 32;
   using F = typename FragOf<P>::type;
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  stage_prime(st, smem, max_unit_bytes<P>(UMB));
+  stage_prime(st, smem, max_unit_bytes<P>(UMB, W));
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3];
@@ -74,24 +81,26 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
         x[nb][c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], z));
     }
     constexpr bool CY = PIPE && P::kSlotsPerChunk == 8, MERGE = UMB >= 8;
-    F hid[NB][chunks_of<P>(64)];
+    F hid[NB][chunks_of<P>(W / 2)];
     f32x16 carry[NB];
-    trunk<P, UMB, PIPE, FAST, NB>(st, smem, x, hid, carry);
+    trunk<P, UMB, PIPE, FAST, NB, W>(st, smem, x, hid, carry);
     f32x16 head[NB];
     F dummy[NB][chunks_of<P>(16)];
     const float* const norb[NB] = {};
-    layer<P, UMB, PIPE, NB, chunks_of<P>(64), 0, false, true, false, !MERGE, (CY ? 6 : -1), true, false>(st, smem, hid, dummy, head, norb, carry);
+    layer<P, UMB, PIPE, NB, chunks_of<P>(W / 2), 0, false, true, false, !MERGE, (CY ? 6 : -1), true, false>(st, smem, hid, dummy, head, norb, carry);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       if (h == 0 && pt[nb] < n_pts) a.out[pt[nb]] = act_softplus<FAST>(head[nb][0]);
   }
 }
 
-template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE>
-__global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1) : 2)) void nerfh_fine_kernel(MlpArgs a) {
+template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE, int W = kWidth>
+__global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) void nerfh_fine_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PPT = WAVES * NB * 32;
-  constexpr int HC = chunks_of<P>(64), QC = chunks_of<P>(32);
+  constexpr int HC = chunks_of<P>(W / 2), QC = chunks_of<P>(W / 4);
+  constexpr int MBW = W / 32, MBQ = W / 64;       // M-blocks of a W-wide / a W/2-wide layer
+  constexpr uint32_t USTRIDE = max_unit_bytes<P>(UMB, W);
   constexpr int PF_ROUNDS = (NB * 32 + 63) / 64;  // 64-point rounds of the next-tile input prefetch
   using F = typename FragOf<P>::type;
   Stager st;
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  stage_prime(st, smem, max_unit_bytes<P>(UMB));
+  stage_prime(st, smem, USTRIDE);
   // Tile inputs.  The first tile's are loaded normally; every later tile's are PREFETCHED during the
   // previous tile's small layers with direct-to-LDS loads and only
   // waited for at the end of that tile, so the HBM latency of z / o / d is off the critical path.
@@ -149,8 +158,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
       pt_cur[nb] = pt[nb];
 #pragma unroll
       for (int c = 0; c < 3; ++c) x[nb][c] = add_rn(oin[nb][c], mul_rn(din[nb][c], zin[nb]));
-      rb_dir[nb] = a.ray_bias + ray_of[nb] * kRayBiasFloats;
-      rb_tr[nb] = rb_dir[nb] + kRayBiasFloats / 2;
+      rb_dir[nb] = a.ray_bias + ray_of[nb] * ray_bias_floats(W);
+      rb_tr[nb] = rb_dir[nb] + ray_bias_floats(W) / 2;
     }
     const float* const norb[NB] = {};
     F hid[NB][HC];
@@ -165,18 +174,18 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
 #endif
     constexpr bool CY = PIPE && P::kSlotsPerChunk == 8, MERGE = UMB >= 8;
     f32x16 carry[NB];
-    trunk<P, UMB, PIPE, FAST, NB>(st, smem, x, hid, carry);
+    trunk<P, UMB, PIPE, FAST, NB, W>(st, smem, x, hid, carry);
     // xyz_encoding_final (no activation) + static_sigma
     F fin[NB][HC];
     f32x16 head[NB];
-    layer<P, UMB, PIPE, NB, HC, 4, false, true, false, true, (CY ? 6 : -1), true, false>(st, smem, hid, fin, head, norb, carry);
+    layer<P, UMB, PIPE, NB, HC, MBW, false, true, false, true, (CY ? 6 : -1), true, false>(st, smem, hid, fin, head, norb, carry);
     float o[NB][9];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o[nb][3] = act_softplus<FAST>(head[nb][0]);
     // dir_encoding (per-ray bias = b + W[:,128:] [pe_dir, a]) -> static_rgb
     {
       F de[NB][QC], dummy[NB][chunks_of<P>(16)];
-      layer<P, UMB, PIPE, NB, HC, 2, true, false, true, true, -1, true, CY>(st, smem, fin, de, head, rb_dir, carry);
+      layer<P, UMB, PIPE, NB, HC, MBQ, true, false, true, true, -1, true, CY>(st, smem, fin, de, head, rb_dir, carry);
       layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, de, dummy, head, norb, carry);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -186,13 +195,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
     // transient branch
     {
       F t0[NB][QC], t1[NB][QC], dummy[NB][chunks_of<P>(16)];
-      layer<P, UMB, PIPE, NB, HC, 2, true, false, true, true, -1, true, CY>(st, smem, fin, t0, head, rb_tr, carry);
+      layer<P, UMB, PIPE, NB, HC, MBQ, true, false, true, true, -1, true, CY>(st, smem, fin, t0, head, rb_tr, carry);
       if (st.more) {
         // Prefetch the next tile's inputs by LDS-DMA (no destination registers).  Issued AFTER this unit's mid_sync so
         // that nothing younger than a weight DMA is ever waited for before the tile's end:
         // lane l of round r fetches z, o, d and the next sample's z of the wave's point 64 r + l into this wave's LDS slot.
         const long long base = (tile + gridDim.x) * PPT + st.wave * (NB * 32);
-        char* slot = smem + 3 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 8 * 256);
+        char* slot = smem + 3 * USTRIDE + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
         for (int r = 0; r < PF_ROUNDS; ++r) {
           const long long ptn = base + r * 64 + st.lane;
@@ -207,9 +216,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
           }
         }
       }
-      layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
-      layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t1, t0, head, norb, carry);
-      layer<P, UMB, PIPE, NB, QC, 2, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
+      layer<P, UMB, PIPE, NB, QC, MBQ, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
+      layer<P, UMB, PIPE, NB, QC, MBQ, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t1, t0, head, norb, carry);
+      layer<P, UMB, PIPE, NB, QC, MBQ, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
       layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, t1, dummy, head, norb, carry);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       asm volatile("" ::: "memory");
       tile_coords(tile + gridDim.x);
-      const char* slot = smem + 3 * max_unit_bytes<P>(UMB) + st.wave * (PF_ROUNDS * 8 * 256);
+      const char* slot = smem + 3 * USTRIDE + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int loc = nb * 32 + p, r = loc >> 6, l = loc & 63;
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1
 }
 
 // ------------------------------------------------------------------------------------------
-template <class P, bool FAST, int WAVES, int UMB, int NB, int WG_PER_CU, bool PIPE>
+template <class P, bool FAST, int WAVES, int UMB, int NB, int WG_PER_CU, bool PIPE, int W = kWidth>
 static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t stream) {
   constexpr int PPT = WAVES * NB * 32;
   const long long n_pts = (long long)a.n_rays * a.n_samples;
@@ -309,8 +318,8 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
   }
   const long long slots = (long long)n_cu * wg_per_cu;  // resident workgroups
   const int grid = int(n_tiles < slots ? n_tiles : slots);
-  const uint32_t lds = lds_bytes<P, UMB, WAVES, NB>();
-  auto kern = fine ? nerfh_fine_kernel<P, FAST, WAVES, UMB, NB, PIPE> : nerfh_coarse_kernel<P, FAST, WAVES, UMB, NB, PIPE>;
+  const uint32_t lds = lds_bytes<P, UMB, WAVES, NB, W>();
+  auto kern = fine ? nerfh_fine_kernel<P, FAST, WAVES, UMB, NB, PIPE, W> : nerfh_coarse_kernel<P, FAST, WAVES, UMB, NB, PIPE, W>;
   static bool attr_done[2] = {false, false};
   if (!attr_done[fine]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -326,7 +335,15 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
 // variant 1: 4 waves x NB 2, 2 WG/CU, unit = 2 M-blocks  (2 waves/SIMD from different workgroups)
 // variant 2: 4 waves x NB 3, 1 WG/CU, unit = layer      (1 wave/SIMD, 512 registers, pipelined epilogue)
 // variant 3: variant 0 without the pipelined epilogue (A/B reference)
-hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
+// netwidth 256: the plain variants (one point block per wave, no pipelined epilogue); staging units of 2 M-blocks (f16) /
+// 1 M-block (f32, split-f16) keep three buffers inside the 160 KB of LDS (a 256 x 256 f16 layer is 128 KB).
+hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width) {
+  if (width == 256) {
+    if (prec == 0) return launch_one<PrecF16, true, 8, unit_mb_w256<PrecF16>(), 1, 1, false, 256>(fine, a, n_cu, stream);
+    if (prec == 2) return launch_one<PrecX3, false, 4, unit_mb_w256<PrecX3>(), 1, 1, false, 256>(fine, a, n_cu, stream);
+    return launch_one<PrecF32, false, 4, unit_mb_w256<PrecF32>(), 1, 1, false, 256>(fine, a, n_cu, stream);
+  }
+  if (width != kWidth) return hipErrorInvalidValue;
   if (prec == 0) {
     if (variant == 0) return launch_one<PrecF16, true, 8, 8, 2, 1, true>(fine, a, n_cu, stream);
     if (variant == 1) return launch_one<PrecF16, true, 4, 2, 2, 1, true>(fine, a, n_cu, stream);

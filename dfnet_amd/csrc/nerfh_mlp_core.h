@@ -485,23 +485,24 @@ DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type
 
 // ------------------------------------------------------------------------------------------
 // The 8-layer trunk (xyz_encoding_1..8, skip concat [pe, h] before layer 5).
-template <class P, int UMB, bool PIPE, bool FAST, int NB>
+template <class P, int UMB, bool PIPE, bool FAST, int NB, int W = kWidth>
 DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
-                   typename FragOf<P>::type (&out)[NB][chunks_of<P>(64)], f32x16 (&carry)[NB]) {
+                   typename FragOf<P>::type (&out)[NB][chunks_of<P>(W / 2)], f32x16 (&carry)[NB]) {
   using F = typename FragOf<P>::type;
-  constexpr int PC = chunks_of<P>(32), HC = chunks_of<P>(64);
+  constexpr int PC = chunks_of<P>(32), HC = chunks_of<P>(W / 2), MBW = W / 32;
   constexpr bool CY = PIPE && P::kSlotsPerChunk == 8;  // hand a layer's last M-block to the next layer unconverted
-  constexpr int CI = CY ? 6 : -1;                      // ... where it lands in chunks 6, 7 of the 128-wide input
+  constexpr int CI = CY ? HC - 2 : -1;                 // ... where it lands in the last two chunks of the W-wide input
+  static_assert(!PIPE || W == kWidth, "the pipelined epilogue is tuned for netwidth 128");
   const int h = st.lane >> 5;
   f32x16 nohead[NB];
   const float* const norb[NB] = {};
   F pe[NB][PC];
   posenc_xyz<P, FAST, NB, PC>(x, h, pe);
   F a[NB][HC], b[NB][HC];
-  layer<P, UMB, PIPE, NB, PC, 4, true, false, false, true, -1, true, CY>(st, smem, pe, a, nohead, norb, carry);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, PC, MBW, true, false, false, true, -1, true, CY>(st, smem, pe, a, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
   {
     F cat[NB][PC + HC];
     if constexpr (P::kSlotsPerChunk == 8 && !PIPE) {  // recompute: cheaper than 32 VGPRs live across 4 layers
@@ -522,11 +523,11 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
 #pragma unroll
       for (int i = 0; i < HC; ++i) cat[nb][PC + i] = b[nb][i];
     }
-    layer<P, l5_unit_mb(UMB), PIPE, NB, PC + HC, 4, true, false, false, true, (CY ? PC + 6 : -1), true, CY>(st, smem, cat, a, nohead, norb, carry);
+    layer<P, l5_unit_mb(UMB), PIPE, NB, PC + HC, MBW, true, false, false, true, (CY ? PC + HC - 2 : -1), true, CY>(st, smem, cat, a, nohead, norb, carry);
   }
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
-  layer<P, UMB, PIPE, NB, HC, 4, true, false, false, true, CI, true, CY>(st, smem, a, out, nohead, norb, carry);  // out's chunks 6, 7 stay in `carry`
+  layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
+  layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, out, nohead, norb, carry);  // out's last two chunks stay in `carry`
 }
 
 }  // namespace dfn

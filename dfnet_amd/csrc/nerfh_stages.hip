@@ -110,21 +110,22 @@ hipError_t launch_posenc(const float* x, size_t n, int L, int mode, float* out, 
 }
 
 // ------------------------------------------------------------------------------------------ per-ray bias
-// table[ray][0] = b_dir + W_dir[:, 128:] . [pe_dir(viewdir) (27), a (hist_bin*dim_a)]
-// table[ray][1] = b_tr  + W_tr [:, 128:] . t (hist_bin*dim_t)
-// stored in C-fragment order [mb][h][r] so the fine kernel's accumulators load it directly.
+// table[ray][0] = b_dir + W_dir[:, W:] . [pe_dir(viewdir) (27), a (hist_bin*dim_a)]     (nout = netwidth / 2 outputs)
+// table[ray][1] = b_tr  + W_tr [:, W:] . t (hist_bin*dim_t)
+// stored in C-fragment order [tbl][mb][h][r] so the fine kernel's accumulators load it directly.
 __global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const float* __restrict__ viewdirs,
                                                        const float* __restrict__ hist, size_t hist_rows,
                                                        size_t n_rays, float* __restrict__ table) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int na = w.hist_bin * w.dim_a, nt = w.hist_bin * w.dim_t;
   const int kd = kChDir + na;  // rows of w_dir
-  float* s_wd = sm;                  // [kd][64]
-  float* s_wt = s_wd + kd * 64;      // [nt][64]
-  float* s_in = s_wt + nt * 64;      // [4 rays][kd + nt]
-  float* s_base = s_in + 4 * (kd + nt);  // [2][64] image-constant part (shared histogram)
-  for (int i = threadIdx.x; i < kd * 64; i += blockDim.x) s_wd[i] = w.w_dir[i];
-  for (int i = threadIdx.x; i < nt * 64; i += blockDim.x) s_wt[i] = w.w_tr[i];
+  const int NO = w.nout, nmb = NO / 32;
+  float* s_wd = sm;                  // [kd][NO]
+  float* s_wt = s_wd + kd * NO;      // [nt][NO]
+  float* s_in = s_wt + nt * NO;      // [4 rays][kd + nt]
+  float* s_base = s_in + 4 * (kd + nt);  // [2][NO] image-constant part (shared histogram)
+  for (int i = threadIdx.x; i < kd * NO; i += blockDim.x) s_wd[i] = w.w_dir[i];
+  for (int i = threadIdx.x; i < nt * NO; i += blockDim.x) s_wt[i] = w.w_tr[i];
   const int stride_in = kd + nt;
   const bool shared = hist_rows == 1;
   auto gather = [&](const float* hrow, float* dst, int i) {  // embedding lookups: a (na) then t (nt)
@@ -138,12 +139,12 @@ __global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const f
   if (shared) {  // one histogram for every ray: fold bias + appearance / transient columns once per block
     for (int i = threadIdx.x; i < na + nt; i += blockDim.x) gather(hist, s_in, i);
     __syncthreads();
-    if (threadIdx.x < 128) {
-      const int tbl = threadIdx.x >> 6, f = threadIdx.x & 63;
+    for (int e = threadIdx.x; e < 2 * NO; e += blockDim.x) {
+      const int tbl = e / NO, f = e - tbl * NO;
       float acc = tbl ? w.b_tr[f] : w.b_dir[f];
-      if (tbl == 0) for (int j = kChDir; j < kd; ++j) acc = fmaf(s_wd[j * 64 + f], s_in[j], acc);
-      else for (int j = 0; j < nt; ++j) acc = fmaf(s_wt[j * 64 + f], s_in[kd + j], acc);
-      s_base[threadIdx.x] = acc;
+      if (tbl == 0) for (int j = kChDir; j < kd; ++j) acc = fmaf(s_wd[j * NO + f], s_in[j], acc);
+      else for (int j = 0; j < nt; ++j) acc = fmaf(s_wt[j * NO + f], s_in[kd + j], acc);
+      s_base[e] = acc;
     }
   }
   const int rpb = shared ? 4 : 2;                         // rays per block iteration
@@ -174,24 +175,28 @@ __global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const f
       auto put = [&](int tbl, int f, float v) {
         const int mb = f >> 5, row = f & 31;
         const int h = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
-        table[ray * kRayBiasFloats + ((tbl * 2 + mb) * 2 + h) * 16 + r] = v;
+        table[ray * size_t(2 * NO) + ((tbl * nmb + mb) * 2 + h) * 16 + r] = v;
       };
       if (shared) {
-        float acc = s_base[o];
-        for (int j = 0; j < kChDir; ++j) acc = fmaf(s_wd[j * 64 + o], my_in[j], acc);
-        put(0, o, acc);
-        put(1, o, s_base[64 + o]);
-      } else {
-        const int tbl = o >> 6, f = o & 63;
-        float acc;
-        if (tbl == 0) {
-          acc = w.b_dir[f];
-          for (int j = 0; j < kd; ++j) acc = fmaf(s_wd[j * 64 + f], my_in[j], acc);
-        } else {
-          acc = w.b_tr[f];
-          for (int j = 0; j < nt; ++j) acc = fmaf(s_wt[j * 64 + f], my_in[kd + j], acc);
+        for (int f = o; f < NO; f += 64) {
+          float acc = s_base[f];
+          for (int j = 0; j < kChDir; ++j) acc = fmaf(s_wd[j * NO + f], my_in[j], acc);
+          put(0, f, acc);
+          put(1, f, s_base[NO + f]);
         }
-        put(tbl, f, acc);
+      } else {
+        for (int e = o; e < 2 * NO; e += 128) {
+          const int tbl = e / NO, f = e - tbl * NO;
+          float acc;
+          if (tbl == 0) {
+            acc = w.b_dir[f];
+            for (int j = 0; j < kd; ++j) acc = fmaf(s_wd[j * NO + f], my_in[j], acc);
+          } else {
+            acc = w.b_tr[f];
+            for (int j = 0; j < nt; ++j) acc = fmaf(s_wt[j * NO + f], my_in[kd + j], acc);
+          }
+          put(tbl, f, acc);
+        }
       }
     }
   }
@@ -201,8 +206,14 @@ hipError_t launch_ray_bias(const RayBiasWeights& w, const float* viewdirs, const
                            size_t hist_rows, size_t n_rays, float* table, hipStream_t stream) {
   if (!n_rays) return hipSuccess;
   const int na = w.hist_bin * w.dim_a, nt = w.hist_bin * w.dim_t;
-  const size_t lds = size_t((kChDir + na) * 64 + nt * 64 + 4 * (kChDir + na + nt) + 128) * 4;
+  const size_t lds = size_t((kChDir + na) * w.nout + nt * w.nout + 4 * (kChDir + na + nt) + 2 * w.nout) * 4;
   const size_t rpb = hist_rows == 1 ? 4 : 2;
+  static bool attr_done = false;
+  if (lds > 64 * 1024 && !attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ray_bias_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
   hipLaunchKernelGGL(ray_bias_kernel, dim3(grid_for((n_rays + rpb - 1) / rpb, 1)), dim3(256), lds, stream, w, viewdirs,
                      hist, hist_rows, n_rays, table);
   return hipGetLastError();

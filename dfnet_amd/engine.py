@@ -29,7 +29,7 @@ class NerfHEngine:
         self.precision = precision
         self.hist_bin = hist_bin
         self.width = width
-        self.fast = width == 128   # register-resident MFMA kernels; other widths run the generic layer-by-layer fp32 path
+        self.fast = width in (128, 256)   # register-resident MFMA kernels; other widths run the generic layer-by-layer fp32 path
         self._ws = None
 
     def __del__(self):

@@ -253,14 +253,33 @@ def test_w32_reference_goldens_on_the_hip_path(gold):
 
 
 def test_w256_render_vs_oracle():
-    """netwidth 256 (SURVEY §8(d) 'also report'): image render on the generic-width path against the oracle."""
+    """netwidth 256 (SURVEY §8(d) 'also report'): image render on the register-resident netwidth-256 kernels (f16, split-f16,
+    exact fp32) and on the generic-width path against the oracle; stage entry points too."""
     cw, fw, ea, et = syn.nerfh_weights(2, W=256)
     E = eng.NerfHEngine(width=256).load_numpy(cw, fw, ea, et)
+    assert E.fast
     H, W, focal = 12, 16, 14.6
     c2w = T(syn.orbit_pose(1, 8))
+    c, f = {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}
     with torch.no_grad():
-        ref = orc.render(H, W, focal, 32768, {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}, T(ea), T(et), 64, 128,
-                         0., 2.5, syn.HIST_IDX, c2w=c2w)
-    got = E.render_image(c2w.to(DEV), H, W, focal, T(syn.HIST_IDX).to(DEV), 64, 128, 0., 2.5)
-    for a, b in zip(got, ref):
-        assert relmax(a, b) < 3e-5
+        ref = orc.render(H, W, focal, 32768, c, f, T(ea), T(et), 64, 128, 0., 2.5, syn.HIST_IDX, c2w=c2w)
+    for prec, tol in (("f32", 3e-5), ("f16x3", 3e-5), ("f16", 1e-3), ("generic", 3e-5)):
+        got = E.render_image(c2w.to(DEV), H, W, focal, T(syn.HIST_IDX).to(DEV), 64, 128, 0., 2.5, precision=prec)
+        for a, b, name in zip(got, ref, ("rgb", "disp", "acc")):
+            e = relmax(a, b)
+            print(f"netwidth 256 {prec} {name}: {e:.2e}")
+            assert e < tol, (prec, name, e)
+    # ray batch with per-ray histograms and retraw (separate compositor), not a multiple of the tile size
+    rng = np.random.default_rng(3)
+    ro, rd = orc.get_rays(480, 640, 585.0, T(syn.orbit_pose(2, 8))[:3, :4])
+    sel = rng.choice(480 * 640, 77, replace=False)
+    o, d = ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous()
+    hist = T(rng.integers(0, 40, (77, 10)).astype(np.float32))
+    rows = torch.cat([o, d, torch.zeros(77, 1), torch.full((77, 1), 2.5), d / d.norm(dim=-1, keepdim=True), hist], 1)
+    with torch.no_grad():
+        ref = orc.render_rays(rows, c, f, T(ea), T(et), 16, 32, retraw=True)
+    for prec, tol in (("f32", 3e-5), ("f16x3", 3e-5), ("f16", 1e-3)):
+        rgb, disp, acc, raw = E.render_rays(o.to(DEV), d.to(DEV), hist.to(DEV), 16, 32, 0., 2.5, retraw=True, precision=prec)
+        assert relmax(raw, ref["raw"]) < tol and relmax(rgb, ref["rgb_map"]) < tol and relmax(disp, ref["disp_map"]) < tol, prec
+    with pytest.raises(Exception, match="netwidth 128 only"):
+        E.render_rays_backward(o.to(DEV), d.to(DEV), hist.to(DEV), 16, 32, 0., 2.5, torch.ones(77, 3, device=DEV), precision="f32")
