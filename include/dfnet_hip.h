@@ -54,7 +54,7 @@ typedef struct dfn_nerfh_s* dfn_nerfh_t;
 
 typedef struct {
   int depth;          /* args.netdepth        (8)    */
-  int width;          /* args.netwidth        (128: register-resident kernels; other even widths: generic path) */
+  int width;          /* args.netwidth        (128, 256: register-resident kernels; other even widths: generic path) */
   int multires;       /* args.multires        (10)   */
   int multires_views; /* args.multires_views  (4)    */
   int hist_bin;       /* args.hist_bin        (10)   */
@@ -381,7 +381,7 @@ int dfn_nerfh_train_backward(dfn_nerfh_t h, const float* const* params, const fl
                              float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Test-time render_rays for ANY netwidth on the same layer-by-layer exact-fp32 path (the register-resident kernels
- * behind dfn_render_rays are specialised for netwidth 128): models/rendering.py:245-337 with test_time=True, from
+ * behind dfn_render_rays exist for netwidth 128 and 256): models/rendering.py:245-337 with test_time=True, from
  * the handle's committed parameters.  raw [n_rays, Nc+Ni, 9] is required (output and scratch). */
 size_t dfn_nerfh_generic_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni);
 int dfn_nerfh_generic_render_rays(dfn_nerfh_t h, const float* rays_o, const float* rays_d, const float* hist, size_t hist_rows,
