@@ -33,7 +33,7 @@ template <class P, int UMB, int WAVES, int NB, int W = kWidth> constexpr uint32_
 // Workgroups per CU the register allocation is sized for.  netwidth 256 in split-f16 / exact fp32 holds 2 x 128 registers of
 // activations per point block: four waves per workgroup, ONE workgroup per CU (512 registers per lane).
 template <class P, int WAVES, int NB, int W> constexpr int mlp_min_blocks() {
-  if (W > kWidth && (P::kSplit || P::kSlotsPerChunk == 1)) return 1;
+  if (W > kWidth && (P::kSplit || P::kSlotsPerChunk == 1 || NB >= 2)) return 1;
   return WAVES * NB >= 12 ? (WAVES == 8 ? 2 : 1) : 2;
 }
 
@@ -339,7 +339,11 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
 // 1 M-block (f32, split-f16) keep three buffers inside the 160 KB of LDS (a 256 x 256 f16 layer is 128 KB).
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width) {
   if (width == 256) {
-    if (prec == 0) return launch_one<PrecF16, true, 8, unit_mb_w256<PrecF16>(), 1, 1, false, 256>(fine, a, n_cu, stream);
+    if (prec == 0) {
+      static const bool nb2 = getenv("DFN_W256_NB2") != nullptr;   // A/B: four waves x two point blocks (512 registers)
+      if (nb2) return launch_one<PrecF16, true, 4, unit_mb_w256<PrecF16>(), 2, 1, false, 256>(fine, a, n_cu, stream);
+      return launch_one<PrecF16, true, 8, unit_mb_w256<PrecF16>(), 1, 1, false, 256>(fine, a, n_cu, stream);
+    }
     if (prec == 2) return launch_one<PrecX3, false, 4, unit_mb_w256<PrecX3>(), 1, 1, false, 256>(fine, a, n_cu, stream);
     return launch_one<PrecF32, false, 4, unit_mb_w256<PrecF32>(), 1, 1, false, 256>(fine, a, n_cu, stream);
   }
