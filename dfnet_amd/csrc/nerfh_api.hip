@@ -313,15 +313,15 @@ struct Packer {
   // then the backward layers the same way.
   template <class PF, class P>
   void pack_bwd(std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
-    pack<PF>(true, (PF::kSlotsPerChunk == 8 && !PF::kSplit) ? 8 : 1, false, blob, tab);
+    pack<PF>(true, bwd_fwd_unit_mb<PF>(), false, blob, tab);
     fwd_units = int(tab.size() / 2);
-    const int umb = (P::kSlotsPerChunk == 8 && !P::kSplit) ? 8 : 1;
+    const int umb = bwd_unit_mb<P>();
     for (int layer = 0; layer < BW_COUNT; ++layer) {
       const LayerShape sh = bwd_layer_shape(layer);
       for (int u0 = 0; u0 < sh.mb; u0 += umb) {
-        // one-M-block units: BW_L5's two d pe M-blocks (4, 5) are staged BEFORE its four d h4 M-blocks — the kernel folds d pe
-        // to three floats while only the layer's input is live (nerfh_bwd.hip)
-        const int mb0 = (umb == 1 && layer == BW_L5) ? (u0 < 2 ? 4 + u0 : u0 - 2) : u0;
+        // units of one or two M-blocks: BW_L5's two d pe M-blocks (4, 5) are staged BEFORE its four d h4 M-blocks — the kernel
+        // folds d pe to three floats while only the layer's input is live (nerfh_bwd.hip)
+        const int mb0 = (umb <= 2 && layer == BW_L5) ? (u0 < 2 ? 4 + u0 : u0 - 2) : u0;
         const int group = sh.mb - mb0 < umb ? sh.mb - mb0 : umb;
         const uint32_t bytes = unit_bytes<P>(sh.slots, group);
         const uint32_t off = uint32_t(blob.size());

@@ -172,7 +172,7 @@ template <class PF, class P> constexpr uint32_t bwd_lds_bytes() { return 3 * bwd
 #define DFN_FLAYER_R(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
   layer<PF, UMBF, false, NB, KC, MB, (PF::kSlotsPerChunk == 8), EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
 #define DFN_BLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
-  layer<P, UMB, false, NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
+  layer<P, UMB, false, NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false, true>(st, smem, IN, OUT, head, RB, carry)
 
 // PF: arithmetic of the forward recompute, P: arithmetic of the backward chain.  Split-f16 for both is the default:
 // activations are O(1), and the gradient vector of a point is carried with a per-point power-of-two scale that is
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       // BW_L5 = d h4 (M-blocks 0..3) + d pe_xyz through the skip connection (M-blocks 4, 5).  Two layer calls on the same input;
       // as one 6-M-block layer its 96-register output on top of input and masks spilled.
       fetch_mk(3);
-      if constexpr (UMB == 1) {
+      if constexpr (UMB <= 2) {
         {   // the d pe M-blocks come FIRST in the blob (Packer::pack_bwd) and are folded to 3 floats while only the input is live
           F dpe[NB][PC];
           DFN_BLAYER(HC, 2, false, false, gh2, dpe, norb);   // BW_L5, M-blocks 4, 5
@@ -632,13 +632,13 @@ hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStr
   if (mode) {   // two-pass form: split-f16 only (exact gates are its point)
     if (prec != 2) return hipErrorInvalidValue;
     static_assert(kBwdTilePoints == 8 * 32, "tile geometry of the split-f16 gradient kernel");
-    return mode == 1 ? launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1, 1>(a, n_cu, stream)
-                     : launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1, 2>(a, n_cu, stream);
+    return mode == 1 ? launch_bwd_one<PrecX3, PrecX3, false, 8, bwd_fwd_unit_mb<PrecX3>(), bwd_unit_mb<PrecX3>(), 1, 1>(a, n_cu, stream)
+                     : launch_bwd_one<PrecX3, PrecX3, false, 8, bwd_fwd_unit_mb<PrecX3>(), bwd_unit_mb<PrecX3>(), 1, 2>(a, n_cu, stream);
   }
   // plain f16 gradient arithmetic is not offered: ReLU gates flipped by f16 rounding put it at 3e-2 of autograd (30x the
   // contract); split-f16 runs at the f16 MFMA rate with fp32-grade gates (nerfh_api.hip rejects DFN_PREC_F16 here)
   if (prec == 0) return hipErrorInvalidValue;
-  if (prec == 2) return launch_bwd_one<PrecX3, PrecX3, false, 8, 1, 1, 1>(a, n_cu, stream);   // split-f16 forward and gradient chain
+  if (prec == 2) return launch_bwd_one<PrecX3, PrecX3, false, 8, bwd_fwd_unit_mb<PrecX3>(), bwd_unit_mb<PrecX3>(), 1>(a, n_cu, stream);   // split-f16 forward and gradient chain
   return launch_bwd_one<PrecF32, PrecF32, false, 4, 1, 1, 1>(a, n_cu, stream);
 }
 

@@ -164,12 +164,20 @@ DFN_HD constexpr int pe_dir_feature(int h, int r) {
   return r < 12 ? 3 + 6 * (2 * h + r / 6) + (r % 6) : (h == 0 && r < 15 ? r - 12 : -1);
 }
 // Staging buffer of the backward kernel: its largest unit is BW_L5 (6 M-blocks x 64 slots) / L5 forward.
+// M-blocks per staging unit of the gradient kernel: a whole layer (f16); exact fp32: one; split-f16: TWO — the per-M-block
+// barrier was 15-21 % of these kernels (ablation without barriers); three 49 KB buffers still fit the 160 KB of LDS.  The
+// backward units only pay off together with the bias-free backward layers (layer<..., NOBIAS>: 32 registers fewer).
+template <class P> DFN_HD constexpr int bwd_fwd_unit_mb() { return (P::kSlotsPerChunk == 8 && !P::kSplit) ? 8 : (P::kSplit ? 2 : 1); }
+template <class P> DFN_HD constexpr int bwd_unit_mb() { return (P::kSlotsPerChunk == 8 && !P::kSplit) ? 8 : (P::kSplit ? 2 : 1); }
 template <class P>
 DFN_HD constexpr uint32_t bwd_max_unit_bytes() {
-  constexpr bool whole = P::kSlotsPerChunk == 8 && !P::kSplit;  // f16: a unit is a whole layer; f32 / split-f16: one M-block
-  const uint32_t a = unit_bytes<P>(96, whole ? 4 : 1);  // forward layer 5, whole (no merged layout here)
-  const uint32_t b = unit_bytes<P>(64, whole ? 6 : 1), c = unit_bytes<P>(80, whole ? 4 : 1);
-  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+  constexpr bool whole = P::kSlotsPerChunk == 8 && !P::kSplit;
+  constexpr int uf = bwd_fwd_unit_mb<P>(), ub = bwd_unit_mb<P>();
+  const uint32_t a = unit_bytes<P>(96, whole ? 4 : uf);  // forward layer 5 (no merged layout here)
+  const uint32_t f5 = unit_bytes<P>(64, whole ? 5 : uf); // forward 128-wide layers / xyz_encoding_final
+  const uint32_t b = unit_bytes<P>(64, whole ? 6 : ub), c = unit_bytes<P>(80, whole ? 4 : ub);
+  const uint32_t m1 = a > f5 ? a : f5, m2 = b > c ? b : c;
+  return m1 > m2 ? m1 : m2;
 }
 
 // Per-ray bias table written by the ray-bias kernel and read by the fine kernel:

@@ -295,8 +295,9 @@ DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&ou
 // M-block m.  CIN >= 0: the previous layer left its LAST M-block unconverted in `carry`; it lands in
 // chunks CIN, CIN+1 of Bin and is converted during this layer's chunks 0..CIN-1 (before they are read).
 // COUT: leave this layer's last M-block in `carry` for the next layer instead of converting it here.
+// NOBIAS: the unit's bias fragments are all zero (backward layers): no bias reads, the first MFMA starts from a zero C operand.
 template <class P, int UMB, bool PIPE, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS, bool NEWUNIT,
-          int CIN, bool CIN_RELU, bool COUT>
+          int CIN, bool CIN_RELU, bool COUT, bool NOBIAS = false>
 DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][KC],
                    typename FragOf<P>::type (&Bout)[NB][(MB ? MB : 1) * chunks_of<P>(16)],
                    f32x16 (&head)[NB], const float* const (&raybias)[NB], f32x16 (&carry)[NB]) {
@@ -345,7 +346,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
     for (int t = 0; t < PF; ++t)
       if (t < nt) a[t] = DFN_AFRAG(t);
     f32x16 bias = {};
-    if (!RAYBIAS) bias = load16(reinterpret_cast<const float*>(bl));
+    if (!RAYBIAS && !NOBIAS) bias = load16(reinterpret_cast<const float*>(bl));
 #pragma unroll
     for (int lm = 0; lm < UMB; ++lm) {
       if (lm < nmb) {
@@ -372,7 +373,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
           if (NEWUNIT && lm == 0 && kc == (KC > 1 ? KC / 2 : 0)) mid_sync(st, smem);
           const F cur = a[t % PF];
           if (t + PF < nt) a[t % PF] = DFN_AFRAG(t + PF);
-          if (kc == (PIPE ? KC / 2 : 0) && !RAYBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
+          if (kc == (PIPE ? KC / 2 : 0) && !RAYBIAS && !NOBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
           __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this chunk's MFMAs (hipcc otherwise sinks it to its use)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
