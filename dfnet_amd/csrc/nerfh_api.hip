@@ -341,8 +341,9 @@ struct Packer {
 
   // The packed blob: staging units in execution order.  umb >= 8: a unit holds whole layers and the small
   // layers of one group (kFineGroup / kCoarseGroup) share a unit; otherwise a unit is <= umb M-blocks of a layer.
+  // l5_umb: M-blocks per unit of layer 5 (< 0: the same as the other layers)
   template <class P>
-  void pack(bool fine, int umb, bool merge, std::vector<uint8_t>& blob, std::vector<uint32_t>& tab) const {
+  void pack(bool fine, int umb, bool merge, std::vector<uint8_t>& blob, std::vector<uint32_t>& tab, int l5_umb = -1) const {
     const int* seq = fine ? kFineSeq : kCoarseSeq;
     const int* grp = fine ? kFineGroup : kCoarseGroup;
     const int nl = fine ? kFineLayers : kCoarseLayers;
@@ -379,8 +380,9 @@ struct Packer {
     }
     for (int li = 0; li < nl; ++li) {
       const LayerShape sh = layer_shape(seq[li], width());
-      for (int mb0 = 0; mb0 < sh.mb; mb0 += umb) {
-        const int group = sh.mb - mb0 < umb ? sh.mb - mb0 : umb;
+      const int lu = (seq[li] == LY_L5 && l5_umb > 0) ? l5_umb : umb;
+      for (int mb0 = 0; mb0 < sh.mb; mb0 += lu) {
+        const int group = sh.mb - mb0 < lu ? sh.mb - mb0 : lu;
         const uint32_t bytes = unit_bytes<P>(sh.slots, group);
         const uint32_t off = uint32_t(blob.size());
         blob.resize(off + bytes, 0);
@@ -471,7 +473,7 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
           sexp = sexp < -8 ? -8 : (sexp > 24 ? 24 : sexp);
           pk.wscale = std::ldexp(1.f, sexp);
           n.in_scale = pk.wscale * kX3ActScale;
-          pk.pack<PrecX3>(f, unit_mb<PrecX3>(var), false, blob, tab);
+          pk.pack<PrecX3>(f, unit_mb<PrecX3>(var), false, blob, tab, l5_unit_mb_p<PrecX3>(unit_mb<PrecX3>(var)));
         }
         int rc = upload(blob.data(), blob.size(), reinterpret_cast<void**>(&n.blob));
         if (rc) return rc;

@@ -101,7 +101,7 @@ constexpr float kX3ActScale = 16.f;
 //   variant 2: 4 waves per workgroup x 3 point blocks, 1 workgroup per CU (1 wave per SIMD, 512 VGPRs), unit as variant 0
 constexpr int kVariants = 4;
 template <class P> DFN_HD constexpr int unit_mb(int variant) {
-  return (P::kSlotsPerChunk == 1 || P::kSplit) ? 1 : (variant == 1 ? 2 : 8);
+  return P::kSlotsPerChunk == 1 ? 1 : (P::kSplit ? 2 : (variant == 1 ? 2 : 8));
 }
 DFN_HD constexpr int variant_waves(int variant) { return variant == 0 ? 8 : 4; }
 // netwidth 256: M-blocks per staging unit
@@ -121,9 +121,12 @@ DFN_HD constexpr uint32_t unit_bytes(int slots, int nmb) {
 // In the merged layout (umb >= 8) layer 5 (48 fragments) is split into two units of 2 M-blocks so that THREE staging
 // buffers fit the 160 KB of LDS; the largest unit is then the merged transient group (44 fragments + 9 bias blocks).
 DFN_HD constexpr int l5_unit_mb(int umb) { return umb >= 8 ? 2 : umb; }
+// ... per precision: split-f16 with two-M-block units keeps layer 5 (96 slots: 25 KB per M-block) in one-M-block units so that
+// three staging buffers + the input-prefetch slots stay inside the LDS.
+template <class P> DFN_HD constexpr int l5_unit_mb_p(int umb) { return (P::kSplit && umb == 2) ? 1 : l5_unit_mb(umb); }
 template <class P>
 DFN_HD constexpr uint32_t max_unit_bytes(int umb, int W = kWidth) {
-  const int m5 = l5_unit_mb(umb), mbw = W / 32;
+  const int m5 = l5_unit_mb_p<P>(umb), mbw = W / 32;
   const uint32_t a = unit_bytes<P>(32 + W / 2, m5 < mbw ? m5 : mbw), b = unit_bytes<P>(W / 2, umb < mbw + 1 ? umb : mbw + 1);
   const uint32_t g = umb >= 8 ? align_piece(44u * 64 * P::kLaneBytes + 9u * 128) : 0;
   return a > b ? (a > g ? a : g) : (b > g ? b : g);

@@ -354,7 +354,7 @@ hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_
     if (variant == 2) return launch_one<PrecF16, true, 4, 8, 3, 1, true>(fine, a, n_cu, stream);
     return launch_one<PrecF16, true, 8, 8, 2, 1, false>(fine, a, n_cu, stream);
   }
-  if (prec == 2) return launch_one<PrecX3, false, 8, 1, 1, 1, false>(fine, a, n_cu, stream);
+  if (prec == 2) return launch_one<PrecX3, false, 8, unit_mb<PrecX3>(0), 1, 1, false>(fine, a, n_cu, stream);
   if (variant == 1) return launch_one<PrecF32, false, 4, 1, 1, 1, false>(fine, a, n_cu, stream);
   return launch_one<PrecF32, false, 8, 1, 1, 1, false>(fine, a, n_cu, stream);
 }

@@ -524,7 +524,7 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
 #pragma unroll
       for (int i = 0; i < HC; ++i) cat[nb][PC + i] = b[nb][i];
     }
-    layer<P, l5_unit_mb(UMB), PIPE, NB, PC + HC, MBW, true, false, false, true, (CY ? PC + HC - 2 : -1), true, CY>(st, smem, cat, a, nohead, norb, carry);
+    layer<P, l5_unit_mb_p<P>(UMB), PIPE, NB, PC + HC, MBW, true, false, false, true, (CY ? PC + HC - 2 : -1), true, CY>(st, smem, cat, a, nohead, norb, carry);
   }
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
