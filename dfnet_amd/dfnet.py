@@ -71,7 +71,9 @@ class _FeatureFn(torch.autograd.Function):
         else:  # siamese halves back into the batch order of x: [target half, render half]
             shape = next(t for t in grads if t is not None).shape
             g = torch.cat([t if t is not None else x.new_zeros(shape) for t in grads], 1)
-        levels = [t for t in range(g.shape[0]) if bool((g[t] != 0).any())]
+        levels = getattr(engine, "grad_levels_hint", None)   # set by the caller who knows which pyramid levels its loss uses
+        if levels is None:   # otherwise: which levels carry gradient at all (a scan of g and a host sync per level)
+            levels = [t for t in range(g.shape[0]) if bool((g[t] != 0).any())]
         if not levels:
             return torch.zeros_like(x), None, None, None, None
         return engine.backward_input(x, g.contiguous(), levels=levels), None, None, None, None

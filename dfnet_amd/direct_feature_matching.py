@@ -116,6 +116,8 @@ def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False):
     # backward then touches only the B rendered images instead of 2 B.
     with torch.no_grad():
         ft, _ = inference_pose_regression(args, data, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
+    if hasattr(feat_model, "engine"):   # the loss reads only these pyramid levels: tell the feature backward (no scan of the gradient stack)
+        feat_model.engine().grad_levels_hint = sorted(set(int(l) for l in args.feature_matching_lvl))
     fr, _ = inference_pose_regression(args, rgb, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
     idx = torch.tensor(args.feature_matching_lvl, device=device)
     f_t = preprocess_features_for_loss(torch.index_select(ft[0], 0, idx))
