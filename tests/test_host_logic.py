@@ -326,3 +326,26 @@ def test_bench_entry_point_two_ranks_gloo(launcher):
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["frames_gathered_in_order"] is True and rec["value"] > 0
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_nerfw_loss_module_matches_reference_golden(tag):
+    """dfnet_amd.losses.NerfWLoss (the host-side mirror of models/losses.py:19-57) on the REFERENCE's training-mode render
+    outputs (G12) reproduces the REFERENCE's loss terms (G13), and ColorLoss / loss_dict keep the reference's surface."""
+    from dfnet_amd import losses
+    gd = os.path.join(ROOT, "tests", "golden")
+    g12, g13 = np.load(os.path.join(gd, f"g12_render_train_{tag}.npz")), np.load(os.path.join(gd, f"g13_train_step_{tag}.npz"))
+    T = torch.from_numpy
+    inputs = {'rgb_fine': T(g12["rgb"]), 'rgb_coarse': T(g12["rgb0"]), 'beta': T(g12["beta"]), 'transient_sigmas': T(g12["transient_sigmas"])}
+    out = losses.loss_dict['nerfw'](coef=1)(inputs, T(g13["target"]))
+    assert sorted(out) == ['b_l', 'c_l', 'f_l', 's_l']
+    for k, v in out.items():
+        assert abs(float(v) - float(g13["loss_" + k])) <= 1e-6 * abs(float(g13["loss_" + k])) + 1e-9, k
+    assert abs(float(sum(out.values())) - float(g13["loss"])) <= 1e-6 * abs(float(g13["loss"]))
+    two = losses.loss_dict['nerfw'](coef=2)(inputs, T(g13["target"]))
+    assert abs(float(two['f_l']) - 2 * float(out['f_l'])) < 1e-6
+    no_beta = losses.NerfWLoss()({k: v for k, v in inputs.items() if k in ('rgb_fine', 'rgb_coarse')}, T(g13["target"]))
+    assert sorted(no_beta) == ['c_l', 'f_l']
+    col = losses.loss_dict['color'](coef=1)(inputs, T(g13["target"]))
+    ref = torch.nn.functional.mse_loss(inputs['rgb_coarse'], T(g13["target"])) + torch.nn.functional.mse_loss(inputs['rgb_fine'], T(g13["target"]))
+    assert abs(float(col) - float(ref)) < 1e-7
