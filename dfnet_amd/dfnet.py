@@ -214,6 +214,14 @@ class _DFNetBase(nn.Module):
         self._engine.load_numpy({k: v.detach().cpu().numpy() for k, v in self.state_dict().items()})
         self._folded_stale = False
 
+    def recommit(self):
+        """Re-pack every fragment from the host, re-deriving the split-f16 power-of-two weight scales.  The device re-packs of a
+        training run keep the scales of the last host commit (max |w| -> 2^10): weights that grew ~64x since then would overflow the
+        f16 hi halves, weights that shrank lose their lo halves.  The training loops call this once per epoch (~0.3 s)."""
+        if self._engine is not None:
+            self._commit_from_host()
+            self._engine_version = self._version()
+
     def engine(self, train=False):
         """The HIP engine holding the current weights, re-packed whenever a tensor of the module changed.
         train=True (the training forward / backward and the pose path, none of which read BatchNorm-folded weights): on

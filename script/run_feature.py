@@ -192,6 +192,8 @@ def train_feature(args, train_dl, val_dl, test_dl, hwf, i_split, near, far):
     n_epoch = int(os.environ.get("DFNET_FEATURE_EPOCHS", args.epochs + 1))
     virtue_view = poses_perturb = None
     for epoch in range(n_epoch):
+        if epoch:
+            feat_model.recommit()   # fresh split-f16 weight scales for the trained weights (dfnet.py: recommit)
         if args.random_view_synthesis:
             if epoch % args.rvs_refresh_rate == 0:
                 virtue_view, poses_perturb = _synthesise_views(args, poses, img_idxs, hwf, device, render_kwargs_test,

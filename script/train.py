@@ -65,6 +65,8 @@ def main(argv=None):
             train_dl = torch.utils.data.DataLoader(train_dl.dataset, batch_size=args.batch_size, sampler=sampler)
         n_epoch = int(os.environ.get("DFNET_DM_EPOCHS", 2001))   # the reference hard-codes 2001 (:436) and relies on early stopping
         for epoch in range(n_epoch):
+            if epoch:
+                model.recommit()   # fresh split-f16 weight scales for the re-packed regressor (dfnet.py: recommit)
             if world > 1:
                 sampler.set_epoch(epoch)   # a fresh permutation per epoch, the same on every rank
             loss, psnr = train_on_epoch(args, [train_dl, val_dl, test_dl], model, feat_model, hwf, optimizer, True, device,
