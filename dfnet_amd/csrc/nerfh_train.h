@@ -69,6 +69,7 @@ hipError_t sum_over_samples(const float* g, int ld, int C, size_t R, int Ns, flo
 // embedding-table gradients: grad_emb[idx(hist[r, b]), j] += g_in[r * ld + off + b * dim + j] (atomic fp32 adds).
 hipError_t embedding_scatter(const float* g_in, int ld, int off, const float* hist, size_t hist_rows, int hist_bin, int dim,
                              int n_vocab, size_t R, float* grad_emb, hipStream_t s);
+constexpr int kNerfwLossFloats = 160;   // loss buffer: 5 results + scratch for the per-block partial sums
 // NerfWLoss (models/losses.py:19-57) forward + gradient.  tsigma = raw + 7 with stride 9.  loss[0..4) = c_l, f_l, b_l,
 // s_l; loss[4] = psnr of rgb (run_nerf.py:62-64).  Gradients of sum(loss) * 1: g_rgb [R,3], g_rgb0 [R,3], g_beta [R];
 // the transient-sigma gradient is the constant coef * lambda_u / (R * Nf) (returned through g_tsigma_const, host float).

@@ -987,26 +987,56 @@ hipError_t composite_fine_backward_train(const float* raw, const float* z, const
 // ------------------------------------------------------------------------------------------ small reductions
 __global__ __launch_bounds__(256) void sum_over_samples_kernel(const float* __restrict__ g, int ld, int C, size_t R, int Ns,
                                                                float* __restrict__ out, int ldo) {
-  const size_t n = R * size_t(C);
-  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
-    const size_t ray = e / C;
-    const int c = int(e - ray * C);
+  // a block per (ray, 64-column group): lane = column (coalesced 256-byte row reads), the four waves take every fourth sample
+  // and are added in fixed order through LDS (deterministic)
+  __shared__ float red[3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cgroups = (C + 63) / 64;
+  for (size_t blk = blockIdx.x; blk < R * cgroups; blk += gridDim.x) {
+    const size_t ray = blk / cgroups;
+    const int c = int(blk - ray * cgroups) * 64 + lane;
     float s = 0.f;
-    const float* q = g + ray * size_t(Ns) * ld + c;
-    for (int k = 0; k < Ns; ++k) s += q[size_t(k) * ld];
-    out[ray * ldo + c] = s;
+    if (c < C) {
+      const float* q = g + ray * size_t(Ns) * ld + c;
+      for (int k = wave; k < Ns; k += 4) s += q[size_t(k) * ld];
+    }
+    if (wave > 0) red[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) out[ray * ldo + c] = ((s + red[0][lane]) + red[1][lane]) + red[2][lane];
+    __syncthreads();
   }
 }
 hipError_t sum_over_samples(const float* g, int ld, int C, size_t R, int Ns, float* out, int ldo, hipStream_t s) {
   if (!R) return hipSuccess;
-  hipLaunchKernelGGL(sum_over_samples_kernel, dim3(grid_for(R * C, 256)), dim3(256), 0, s, g, ld, C, R, Ns, out, ldo);
+  hipLaunchKernelGGL(sum_over_samples_kernel, dim3(grid_for(R * ((C + 63) / 64), 1)), dim3(256), 0, s, g, ld, C, R, Ns, out, ldo);
   return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void embedding_scatter_kernel(const float* __restrict__ g_in, int ld, int off,
                                                                 const float* __restrict__ hist, size_t hist_rows, int hist_bin,
                                                                 int dim, int n_vocab, size_t R, float* __restrict__ grad_emb) {
+  // One histogram for all rays (the usual case: the rays of a step come from one image): every ray adds into the same
+  // hist_bin x dim entries, so a block first sums its rays per entry in LDS and issues ONE global atomic per entry
+  // (1536 rays x 50 values on 50 addresses were 90 us of serialised atomics).  Per-ray histograms: direct atomics.
+  __shared__ float acc[1024];
   const int per = hist_bin * dim;
+  if (hist_rows == 1 && per <= 1024) {
+    for (int j = threadIdx.x; j < per; j += blockDim.x) acc[j] = 0.f;
+    __syncthreads();
+    const size_t r0 = size_t(blockIdx.x) * 64, r1 = r0 + 64 < R ? r0 + 64 : R;
+    for (int j = threadIdx.x; j < per; j += blockDim.x) {
+      float s = 0.f;
+      for (size_t r = r0; r < r1; ++r) s += g_in[r * ld + off + j];
+      acc[j] = s;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < per; j += blockDim.x) {
+      long long idx = (long long)hist[j / dim];
+      idx = idx < 0 ? 0 : (idx >= n_vocab ? n_vocab - 1 : idx);
+      atomicAdd(grad_emb + idx * dim + j % dim, acc[j]);
+    }
+    return;
+  }
   const size_t n = R * size_t(per);
   for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
     const size_t ray = e / per;
@@ -1019,8 +1049,10 @@ __global__ __launch_bounds__(256) void embedding_scatter_kernel(const float* __r
 hipError_t embedding_scatter(const float* g_in, int ld, int off, const float* hist, size_t hist_rows, int hist_bin, int dim,
                              int n_vocab, size_t R, float* grad_emb, hipStream_t s) {
   if (!R) return hipSuccess;
-  hipLaunchKernelGGL(embedding_scatter_kernel, dim3(grid_for(R * hist_bin * dim, 256)), dim3(256), 0, s, g_in, ld, off, hist,
-                     hist_rows, hist_bin, dim, n_vocab, R, grad_emb);
+  const bool shared = hist_rows == 1 && hist_bin * dim <= 1024;
+  const int grid = shared ? int((R + 63) / 64) : grid_for(R * hist_bin * dim, 256);
+  hipLaunchKernelGGL(embedding_scatter_kernel, dim3(grid), dim3(256), 0, s, g_in, ld, off, hist, hist_rows, hist_bin, dim, n_vocab, R,
+                     grad_emb);
   return hipGetLastError();
 }
 
@@ -1031,9 +1063,28 @@ __global__ __launch_bounds__(1024) void nerfw_loss_kernel(const float* __restric
                                                           const float* __restrict__ beta, const float* __restrict__ raw,
                                                           const float* __restrict__ target, size_t R, int Nf, float coef,
                                                           float lambda_u, float* __restrict__ loss5, float* __restrict__ g_rgb,
-                                                          float* __restrict__ g_rgb0, float* __restrict__ g_beta) {
+                                                          float* __restrict__ g_rgb0, float* __restrict__ g_beta,
+                                                          double* __restrict__ part /* [gridDim.x] sigma_t partial sums */) {
   __shared__ double red[5][16];
-  double acc[5] = {0, 0, 0, 0, 0};   // c, f, log beta, sigma_t, mse
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // every block: its slice of sum(transient sigma) -> part[block]
+  {
+    double a = 0;
+    const size_t n = R * size_t(Nf);
+    for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) a += raw[e * 9 + 7];
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+    if (lane == 0) red[0][wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0;
+      for (int w = 0; w < nw; ++w) t += red[0][w];
+      part[blockIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x != 0) return;
+  // block 0: the per-ray terms and their gradient seeds (the sigma partials are folded in by nerfw_loss_finish_kernel)
+  double acc[4] = {0, 0, 0, 0};   // c, f, log beta, mse
   const double inv3R = 1.0 / (3.0 * double(R));
   for (size_t r = threadIdx.x; r < R; r += blockDim.x) {
     const float b = beta[r];
@@ -1043,7 +1094,7 @@ __global__ __launch_bounds__(1024) void nerfw_loss_kernel(const float* __restric
       const float d0 = rgb0[r * 3 + c] - t, d1 = rgb[r * 3 + c] - t;
       acc[0] += 0.5 * double(d0) * d0;
       acc[1] += double(d1) * d1 / (2.0 * double(b) * b);
-      acc[4] += double(d1) * d1;
+      acc[3] += double(d1) * d1;
       g_rgb0[r * 3 + c] = coef * d0 * float(inv3R);
       g_rgb[r * 3 + c] = coef * d1 / (b * b) * float(inv3R);
       gb -= d1 * d1 / (b * b * b);
@@ -1051,30 +1102,40 @@ __global__ __launch_bounds__(1024) void nerfw_loss_kernel(const float* __restric
     acc[2] += log(double(b));
     g_beta[r] = coef * (gb * float(inv3R) + 1.f / (b * float(R)));
   }
-  for (size_t e = threadIdx.x; e < R * size_t(Nf); e += blockDim.x) acc[3] += raw[e * 9 + 7];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < 4; ++k) {
     double v = acc[k];
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     if (lane == 0) red[k][wave] = v;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t[5] = {0, 0, 0, 0, 0};
-    for (int k = 0; k < 5; ++k)
-      for (int w = 0; w < int(blockDim.x >> 6); ++w) t[k] += red[k][w];
+    double t[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k)
+      for (int w = 0; w < nw; ++w) t[k] += red[k][w];
     loss5[0] = float(coef * t[0] * inv3R);
     loss5[1] = float(coef * t[1] * inv3R);
     loss5[2] = float(coef * (3.0 + t[2] / double(R)));
-    loss5[3] = float(coef * lambda_u * t[3] / (double(R) * Nf));
-    loss5[4] = float(-10.0 * log10(t[4] * inv3R));
+    loss5[4] = float(-10.0 * log10(t[3] * inv3R));
   }
+}
+__global__ void nerfw_loss_finish_kernel(const double* __restrict__ part, int nparts, size_t R, int Nf, float coef, float lambda_u,
+                                         float* __restrict__ loss5) {
+  double t = 0;
+  for (int i = 0; i < nparts; ++i) t += part[i];   // fixed order
+  loss5[3] = float(coef * lambda_u * t / (double(R) * Nf));
 }
 hipError_t nerfw_loss(const float* rgb, const float* rgb0, const float* beta, const float* raw, const float* target, size_t R,
                       int Nf, float coef, float lambda_u, float* loss5, float* g_rgb, float* g_rgb0, float* g_beta, hipStream_t s) {
   if (!R) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(nerfw_loss_kernel, dim3(1), dim3(1024), 0, s, rgb, rgb0, beta, raw, target, R, Nf, coef, lambda_u, loss5, g_rgb,
-                     g_rgb0, g_beta);
+  // the per-block sigma partials live in the caller's loss buffer behind the five results (kNerfwLossFloats floats, 16-byte aligned)
+  constexpr int kBlocks = 64;
+  static_assert(8 + 2 * kBlocks <= kNerfwLossFloats, "loss buffer too small for the partial sums");
+  double* part = reinterpret_cast<double*>(loss5 + 8);
+  hipLaunchKernelGGL(nerfw_loss_kernel, dim3(kBlocks), dim3(1024), 0, s, rgb, rgb0, beta, raw, target, R, Nf, coef, lambda_u, loss5, g_rgb,
+                     g_rgb0, g_beta, part);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(nerfw_loss_finish_kernel, dim3(1), dim3(1), 0, s, part, kBlocks, R, Nf, coef, lambda_u, loss5);
   return hipGetLastError();
 }
 

@@ -101,10 +101,11 @@ class NerfHTrainer:
         target = _f32c(target).reshape(-1, 3)
         n, Nf = out["raw"].shape[0], out["raw"].shape[1]
         dev = target.device
-        loss5 = torch.empty(5, device=dev)
+        loss_buf = torch.empty(160, device=dev)   # DFN_NERFW_LOSS_FLOATS: 5 results + reduction scratch
+        loss5 = loss_buf[:5]
         g_rgb, g_rgb0, g_beta = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
         check(self.lib.dfn_nerfw_loss(ptr(out["rgb_map"]), ptr(out["rgb0"]), ptr(out["beta"]), ptr(out["raw"]), ptr(target), n, Nf,
-                                      float(coef), float(lambda_u), ptr(loss5), ptr(g_rgb), ptr(g_rgb0), ptr(g_beta), current_stream()),
+                                      float(coef), float(lambda_u), ptr(loss_buf), ptr(g_rgb), ptr(g_rgb0), ptr(g_beta), current_stream()),
               "dfn_nerfw_loss")
         return loss5, (g_rgb, g_rgb0, g_beta), float(coef) * float(lambda_u) / (n * Nf)
 

@@ -363,9 +363,11 @@ int dfn_nerfh_train_forward(dfn_nerfh_t h, const float* const* params, const flo
                             float* beta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* models/losses.py:19-57 NerfWLoss(coef, lambda_u) on (rgb_fine, rgb_coarse, beta, transient_sigmas = raw[..., 7])
- * vs target [n,3].  loss5 (device, 5 floats): c_l, f_l, b_l, s_l, then the PSNR of rgb (run_nerf.py:62-64).
+ * vs target [n,3].  loss5: DEVICE buffer of DFN_NERFW_LOSS_FLOATS floats, 16-byte aligned; [0..4] = c_l, f_l, b_l, s_l and the PSNR
+ * of rgb (run_nerf.py:62-64), the rest is scratch of the reduction.
  * Gradients of sum(loss): g_rgb [n,3], g_rgb0 [n,3], g_beta [n]; d / d transient_sigma is the constant
  * coef * lambda_u / (n * Nf) per sample (pass it to dfn_nerfh_train_backward as g_tsigma). */
+enum { DFN_NERFW_LOSS_FLOATS = 160 };
 int dfn_nerfw_loss(const float* rgb, const float* rgb0, const float* beta, const float* raw, const float* target,
                    size_t n_rays, int Nf, float coef, float lambda_u, float* loss5, float* g_rgb, float* g_rgb0,
                    float* g_beta, void* stream);
