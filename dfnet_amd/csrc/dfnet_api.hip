@@ -433,7 +433,17 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
       const PackedConv& p5 = bn_mode ? h->ad5_raw[t] : h->ad5[t];
       c.in = w.tmp64; c.w = p5.w[prec]; c.bias = prec == 2 ? p5.bias_x3 : p5.bias; c.out_scale = p5.out_scale; c.out_act = w.ad128; c.out_pre = nullptr;
       c.B = B; c.H = tap_h[t]; c.W = tap_w[t]; c.nblk_in = 2; c.cout_blocks = 4; c.relu = 0;
+      // a level that already has the requested size (level 0 when the features are asked for at the frame size, as every caller of
+      // the reference does): the align_corners resize is the identity, the 5x5 conv writes the caller's NCHW stack itself
+      const bool identity = bn_mode == 0 && tap_h[t] == upH && tap_w[t] == upW;
+      if (identity) {
+        c.out_act = nullptr;
+        c.out_nchw = siamese ? features + size_t(t) * (B / 2) * plane : features + size_t(t) * B * plane;
+        c.nchw_split = siamese ? B / 2 : B;
+        c.nchw_group_stride = size_t(h->n_taps) * (B / 2) * plane;
+      }
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet: adapt 5x5");
+      if (identity) continue;
       const float* affine = nullptr;
       if (bn_mode == 1) {
         CHECK_HIP(launch_bn_running_stats(h->bn_dev[t], 1e-5f, w.bn_work, s), "dfnet: BatchNorm running statistics");

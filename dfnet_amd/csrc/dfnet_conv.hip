@@ -38,6 +38,27 @@ constexpr int conv_patch_bytes() {
 template <class P, int KS, int SB, int MB>
 constexpr int conv_wstage_bytes() { return MB * KS * (SB / P::kSlotsPerChunk) * 64 * P::kLaneBytes; }
 
+// fp32 NCHW planes straight from the accumulators (ConvArgs::out_nchw): for a fixed accumulator register the 32 lanes of a
+// half-wave hold 32 consecutive pixels of ONE channel — a 128-byte run of that channel's plane.  T = the activation type
+// the unfused path would have rounded through.
+template <int MB, class T>
+DFN_DEV_INLINE void store_nchw(const ConvArgs& a, const f32x16 (&acc)[MB][2], float scale, int b, int cg, int yrow, int x0, int p, int h) {
+  const size_t hw = (size_t)a.H * a.W;
+  float* img = a.out_nchw + (size_t)(b / a.nchw_split) * a.nchw_group_stride + (size_t)(b % a.nchw_split) * a.cout_blocks * 32 * hw;
+  if (x0 + p >= a.W) return;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int y = yrow + nb;
+    if (y >= a.H) continue;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      float* o = img + ((size_t)(cg * MB + mb) * 32 + 4 * h) * hw + (size_t)y * a.W + x0 + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * hw] = (float)(T)(acc[mb][nb][r] * scale);
+    }
+  }
+}
+
 template <class P, int KS, int SB, int MB>
 __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
   using T = typename FragOf<P>::elem;
@@ -125,6 +146,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
   // Stored straight from the accumulators every instruction would touch 32 lines partially; each wave turns one
   // (row, M-block) at a time through LDS (the staging buffers are dead) and stores whole lines (see conv_x3_kernel).
   constexpr int LINEB = 32 * int(sizeof(T)), ROWB = LINEB + 16, LPL = LINEB / 16;   // lanes per line
+  if (a.out_nchw) store_nchw<MB, T>(a, acc, 1.f, b, cg, y0 + 2 * wave, x0, p, h);
+  if (!a.out_act && !a.out_pre) return;
   __syncthreads();
   char* turn = smem + wave * (32 * ROWB);
 #pragma unroll
@@ -395,6 +418,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
   // requests per instruction (measured: a fifth of the kernel's time).  Each wave therefore turns its output rows
   // through LDS — the staging buffers are dead by now — and stores whole lines, eight lanes per line.
   constexpr int ROWB = MB * 128 + 16;                 // padded bytes per pixel in the turn buffer
+  if (a.out_nchw) store_nchw<MB, float>(a, acc, out_scale, b, cg, y0 + 2 * wave, x0, p, h);
+  if (!a.out_act && !a.out_pre) { CONV_T(4); CONV_T_FLUSH; return; }
   __syncthreads();                                     // every wave is done with the planes and the weight buffers
   char* turn = smem + wave * (32 * ROWB);
 #pragma unroll
@@ -542,7 +567,13 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
       if (w8) return launch_conv_x3_t<3, 16, 2, true, 8>(a, stream);
       return db ? launch_conv_x3_t<3, 16, 2, true>(a, stream) : launch_conv_x3_t<3, 16, 2, false>(a, stream);
     }
-    if (ks == 5) return launch_conv_x3_t<5, 16, 2, true>(a, stream);
+    if (ks == 5) {
+      // 16 x 32-pixel tiles, eight waves: the 4-wave tile's planes + slices (109 KB) allow one workgroup = ONE wave per SIMD;
+      // eight waves share each weight slice and give every SIMD two waves (measured 1.63 -> 1.22 ms on 4 x 480x640)
+      static const int w8 = [] { const char* e = getenv("DFN_X3_W8_5"); return e ? atoi(e) : 1; }();  // tuning aid (0: 4-wave tile)
+      if (w8) return launch_conv_x3_t<5, 16, 2, true, 8>(a, stream);
+      return launch_conv_x3_t<5, 16, 2, true>(a, stream);
+    }
   } else {
     if (sb == 4 && ks == 3) return launch_conv_t<PrecF32, 3, 4, 2>(a, stream);
     if (sb != 16) return hipErrorInvalidValue;

@@ -31,6 +31,13 @@ struct ConvArgs {
   int relu;
   float out_scale;     // prec 2 (split-f16): accumulators are multiplied by this before the epilogue (2^-(s+4))
   int xcd_groups;      // split-f16 kernel: > 0 = 1-D XCD-aware grid (see conv_x3_kernel); = number of logical workgroups
+  // Optional fused identity "upsample" (the adaptation conv of a pyramid level whose size already is the requested feature size):
+  // the epilogue also/instead writes fp32 NCHW planes, image b at out_nchw + (b / nchw_split) * nchw_group_stride +
+  // (b % nchw_split) * Cout * H * W (nchw_split = B, or B/2 for the siamese two-stack output).  Values are what
+  // launch_upsample would have produced from out_act.
+  float* out_nchw;
+  int nchw_split;
+  size_t nchw_group_stride;
   const float* dyn_scale;  // prec 2, optional: device [scale, 1/scale] of the INPUT tensor (launch_absmax_scale) replacing
                            // the fixed x16 activation scale — gradient tensors have no a-priori magnitude
 };

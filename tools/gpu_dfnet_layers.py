@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-kernel durations of ONE split-f16 DFNet forward (4 x 480x640, features only), from a rocprofv3 kernel trace.
+   run:    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/layers -o l -- python tools/gpu_dfnet_layers.py run
+   report: python tools/gpu_dfnet_layers.py report gpurun_out/layers"""
+import csv, glob, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if sys.argv[1] == "run":
+    import torch
+    sys.path.insert(0, ROOT)
+    from dfnet_amd import engine as eng, synthetic as syn
+    E = eng.DfnetEngine(3, 12).load_numpy(syn.dfnet_weights(3))
+    B = int(os.environ.get("LAYERS_B", "4"))
+    x = torch.rand(B, 3, 480, 640, device="cuda:0")
+    for _ in range(3):
+        E.forward(x, True, True, False, 480, 640, precision=os.environ.get("LAYERS_PREC", "f16x3"))
+    torch.cuda.synchronize()
+else:
+    f = sorted(glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True))[-1]
+    rows = [r for r in csv.DictReader(open(f)) if "dfn::" in r["Kernel_Name"] or "_ZN3dfn" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    n = len(rows) // 3
+    last = rows[-n:]
+    tot = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last)
+    span = int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
+    print(f"{n} kernels, sum {tot / 1e3:.1f} us, span {span / 1e3:.1f} us")
+    for r in last:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        g = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+        print(f"{d / 1e3:9.1f} us  {100 * d / tot:5.1f} %  grid {g:>16s}  {r['Kernel_Name'][:90]}")
