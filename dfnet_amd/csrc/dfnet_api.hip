@@ -406,7 +406,10 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
     a.nblk_in = nblk;
     a.cout_blocks = sp.cout / 32;
     a.relu = 1;
-    if (a.out_act || a.out_pre)
+    // split-f16: a conv followed by the 2x2 max pool writes the pooled activation itself (nothing else reads the full-size one)
+    const bool pool_fused = prec == 2 && i > 0 && !stop_here && sp.pool_after && i + 1 < h->enc.size();
+    if (pool_fused) { a.out_pool = ping[pp]; a.out_act = nullptr; }
+    if (a.out_act || a.out_pre || a.out_pool)
       CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet: encoder conv");
     if (sp.tap >= 0) { tap_h[sp.tap] = ch; tap_w[sp.tap] = cw; }
     if (stop_here) break;
@@ -414,7 +417,9 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
     last_act = cur; last_h = ch; last_w = cw;
     pp ^= 1;
     nblk = sp.cout / 32;
-    if (sp.pool_after && i + 1 < h->enc.size()) {
+    if (pool_fused) {
+      ch /= 2; cw /= 2;
+    } else if (sp.pool_after && i + 1 < h->enc.size()) {
       CHECK_HIP(launch_maxpool(prec, cur, B, ch, cw, nblk, ping[pp], s), "dfnet: maxpool");
       cur = ping[pp];
       pp ^= 1;

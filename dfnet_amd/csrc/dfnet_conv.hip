@@ -419,9 +419,43 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
   // through LDS — the staging buffers are dead by now — and stores whole lines, eight lanes per line.
   constexpr int ROWB = MB * 128 + 16;                 // padded bytes per pixel in the turn buffer
   if (a.out_nchw) store_nchw<MB, float>(a, acc, out_scale, b, cg, y0 + 2 * wave, x0, p, h);
-  if (!a.out_act && !a.out_pre) { CONV_T(4); CONV_T_FLUSH; return; }
+  if (!a.out_act && !a.out_pre && !a.out_pool) { CONV_T(4); CONV_T_FLUSH; return; }
   __syncthreads();                                     // every wave is done with the planes and the weight buffers
   char* turn = smem + wave * (32 * ROWB);
+  if (a.out_pool) {
+    // the wave's two rows are the two rows of its pooling windows: vertical maximum in registers, horizontal through the turn buffer
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      f32x4* d = reinterpret_cast<f32x4*>(turn + p * ROWB + mb * 128 + h * 64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[mb][0][4 * q + k], acc[mb][1][4 * q + k]) * out_scale;
+        d[q] = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int Hp = a.H >> 1, Wp = a.W >> 1, yp = (y0 + 2 * wave) >> 1;
+    if (yp < Hp) {
+      const size_t rowoff = (((size_t)b * Hp + yp) * Wp + (x0 >> 1)) * a.cout_blocks * 32 + (size_t)cg * MB * 32;   // floats
+#pragma unroll
+      for (int i = 0; i < 2 * MB; ++i) {
+        const int line = i * 8 + (lane >> 3), px = line / MB, mbl = line - px * MB, chunk = lane & 7;
+        if ((x0 >> 1) + px < Wp) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(turn + (2 * px) * ROWB + mbl * 128 + chunk * 16);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(turn + (2 * px + 1) * ROWB + mbl * 128 + chunk * 16);
+          f32x4 v = {fmaxf(u[0], w[0]), fmaxf(u[1], w[1]), fmaxf(u[2], w[2]), fmaxf(u[3], w[3])};
+          if (a.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+          *reinterpret_cast<f32x4*>(static_cast<float*>(a.out_pool) + rowoff + ((size_t)px * a.cout_blocks + mbl) * 32 + chunk * 4) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!a.out_act && !a.out_pre) { CONV_T(4); CONV_T_FLUSH; return; }
+  }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
 #ifdef DFN_CONV_ABL_NOEPI

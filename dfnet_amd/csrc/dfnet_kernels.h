@@ -35,6 +35,9 @@ struct ConvArgs {
   // the epilogue also/instead writes fp32 NCHW planes, image b at out_nchw + (b / nchw_split) * nchw_group_stride +
   // (b % nchw_split) * Cout * H * W (nchw_split = B, or B/2 for the siamese two-stack output).  Values are what
   // launch_upsample would have produced from out_act.
+  // Optional fused 2x2/2 max pool (split-f16 kernel): [B,H/2,W/2,Cout/32,2,16] = maxpool(relu?(out)); the tile origin is even, so
+  // every window lies inside one wave's two rows.
+  void* out_pool;
   float* out_nchw;
   int nchw_split;
   size_t nchw_group_stride;
