@@ -64,6 +64,8 @@ struct dfn_dfnet_s {
   std::vector<Kept> kept;
 };
 
+static size_t zeros_offset(int feat_dim) { return (size_t(feat_dim) * 513 + 3) & ~size_t(3); }   // floats into h->fc, 16-byte aligned
+
 static void build_specs(dfn_dfnet_s* h) {
   int cin = 3, idx = 0;
   const int tap_at[3] = {2, 14, 28};
@@ -314,6 +316,7 @@ extern "C" int dfn_dfnet_commit(dfn_dfnet_t h) {
   std::vector<float> fc = h->params["fc_pose.weight"];
   const auto& fb = h->params["fc_pose.bias"];
   fc.insert(fc.end(), fb.begin(), fb.end());
+  fc.resize(zeros_offset(h->feat_dim) + 64, 0.f);   // + 256 bytes of zeros: the DMA source of padding pixels (ConvArgs::zeros)
   if (int rc = upload_bytes(fc.data(), fc.size() * 4, reinterpret_cast<void**>(&h->fc))) return rc;
   h->committed = true;
   h->fresh_mask = 7;
@@ -385,7 +388,12 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   if (w.total > workspace_bytes)
     return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
   hipStream_t s = HS(stream);
-  CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet: prep");
+  // Split-f16 inference keeps every intermediate activation as hi | lo f16 blocks (dfnet_conv.hip, split_piece): same bytes as fp32,
+  // split once by the producer, LDS-DMA staged by the consumer.  Only what leaves the convs stays fp32: the 5x5 adaptation output
+  // (resized / written as NCHW planes) and relu5_3 when the pose head reads it.
+  const bool split = prec == 2 && bn_mode == 0;
+  const void* zeros = h->fc + zeros_offset(h->feat_dim);
+  CHECK_HIP(launch_dfnet_prep(split ? 3 : prec, x, B, H, W, w.prep, s), "dfnet: prep");
   const void* cur = w.prep;
   char* ping[2] = {w.actA, w.actB};
   int pp = 0, ch = H, cw = W, nblk = 1;
@@ -409,6 +417,11 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
     // split-f16: a conv followed by the 2x2 max pool writes the pooled activation itself (nothing else reads the full-size one)
     const bool pool_fused = prec == 2 && i > 0 && !stop_here && sp.pool_after && i + 1 < h->enc.size();
     if (pool_fused) { a.out_pool = ping[pp]; a.out_act = nullptr; }
+    if (split) {
+      const bool last = i + 1 == h->enc.size();          // relu5_3: read by the pose head as fp32
+      a.in_split = 1; a.zeros = zeros;
+      a.out_split = (last ? 0 : 1) | 2 | 4;
+    }
     if (a.out_act || a.out_pre || a.out_pool)
       CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet: encoder conv");
     if (sp.tap >= 0) { tap_h[sp.tap] = ch; tap_w[sp.tap] = cw; }
@@ -433,11 +446,13 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
       ConvArgs a{};
       a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale; a.out_act = w.tmp64; a.out_pre = nullptr;
       a.B = B; a.H = tap_h[t]; a.W = tap_w[t]; a.nblk_in = h->tap_channels[t] / 32; a.cout_blocks = 2; a.relu = 1;
+      if (split) { a.in_split = 1; a.out_split = 1; a.zeros = zeros; }
       CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet: adapt 1x1");
       ConvArgs c{};
       const PackedConv& p5 = bn_mode ? h->ad5_raw[t] : h->ad5[t];
       c.in = w.tmp64; c.w = p5.w[prec]; c.bias = prec == 2 ? p5.bias_x3 : p5.bias; c.out_scale = p5.out_scale; c.out_act = w.ad128; c.out_pre = nullptr;
       c.B = B; c.H = tap_h[t]; c.W = tap_w[t]; c.nblk_in = 2; c.cout_blocks = 4; c.relu = 0;
+      if (split) { c.in_split = 1; c.zeros = zeros; }
       // a level that already has the requested size (level 0 when the features are asked for at the frame size, as every caller of
       // the reference does): the align_corners resize is the identity, the 5x5 conv writes the caller's NCHW stack itself
       const bool identity = bn_mode == 0 && tap_h[t] == upH && tap_w[t] == upW;

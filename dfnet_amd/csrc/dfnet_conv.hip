@@ -41,18 +41,19 @@ constexpr int conv_wstage_bytes() { return MB * KS * (SB / P::kSlotsPerChunk) * 
 // fp32 NCHW planes straight from the accumulators (ConvArgs::out_nchw): for a fixed accumulator register the 32 lanes of a
 // half-wave hold 32 consecutive pixels of ONE channel — a 128-byte run of that channel's plane.  T = the activation type
 // the unfused path would have rounded through.
-template <int MB, class T>
-DFN_DEV_INLINE void store_nchw(const ConvArgs& a, const f32x16 (&acc)[MB][2], float scale, int b, int cg, int yrow, int x0, int p, int h) {
+// (yrow, x) = the lane's pixel in fragment 0; fragment 1 lies RF rows below.
+template <int MB, class T, int RF>
+DFN_DEV_INLINE void store_nchw(const ConvArgs& a, const f32x16 (&acc)[MB][2], float scale, int b, int cg, int yrow, int x, int h) {
   const size_t hw = (size_t)a.H * a.W;
   float* img = a.out_nchw + (size_t)(b / a.nchw_split) * a.nchw_group_stride + (size_t)(b % a.nchw_split) * a.cout_blocks * 32 * hw;
-  if (x0 + p >= a.W) return;
+  if (x >= a.W) return;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
-    const int y = yrow + nb;
+    const int y = yrow + nb * RF;
     if (y >= a.H) continue;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      float* o = img + ((size_t)(cg * MB + mb) * 32 + 4 * h) * hw + (size_t)y * a.W + x0 + p;
+      float* o = img + ((size_t)(cg * MB + mb) * 32 + 4 * h) * hw + (size_t)y * a.W + x;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * hw] = (float)(T)(acc[mb][nb][r] * scale);
     }
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
   // Stored straight from the accumulators every instruction would touch 32 lines partially; each wave turns one
   // (row, M-block) at a time through LDS (the staging buffers are dead) and stores whole lines (see conv_x3_kernel).
   constexpr int LINEB = 32 * int(sizeof(T)), ROWB = LINEB + 16, LPL = LINEB / 16;   // lanes per line
-  if (a.out_nchw) store_nchw<MB, T>(a, acc, 1.f, b, cg, y0 + 2 * wave, x0, p, h);
+  if (a.out_nchw) store_nchw<MB, T, 1>(a, acc, 1.f, b, cg, y0 + 2 * wave, x0 + p, h);
   if (!a.out_act && !a.out_pre) return;
   __syncthreads();
   char* turn = smem + wave * (32 * ROWB);
@@ -231,38 +232,237 @@ __device__ unsigned long long g_conv_cycles[8];
 #define CONV_T_FLUSH
 #endif
 
+// s_waitcnt vmcnt(n) with lgkmcnt / expcnt left alone (gfx9 encoding: vmcnt = bits [3:0] and [15:14])
+#define DFN_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+
 DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
   const uint32_t off = (uint32_t)(size_t)DFN_LDS_PTR(lds_dst);
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(off) : "memory");
 }
 
-template <int KS, int SB, int WAVES = 4>
-constexpr int x3_plane_bytes() { return (((2 * WAVES + KS - 1) * (kConvTileW + KS - 1) * (2 * SB * 2 + 16)) + 15) & ~15; }
+// Split-f16 activation storage (ConvArgs::in_split / out_split): the same bytes as the fp32 tensor, but every value is kept as the
+// two f16 operands the consuming convolution multiplies — hi = f16(x * kConvActScale), lo = f16(x * kConvActScale - hi) — in ROW-PLANAR
+// order [B][H][C/32][K-chunk][hi | lo][lane half h][W][8 slots]: for one image row, (block, K-chunk, plane, half) is a run of W 16-byte
+// pieces.  A consumer stages its patch by LDS-DMA with no conversion, each DMA instruction fetching runs of consecutive pixels
+// (conv_x3s_kernel); a producer's 32 lanes of one half store 512 contiguous bytes per instruction straight from the accumulators.
+// The split is done once by the producer instead of once per (output-channel group, halo overlap) by the consumers.
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+DFN_DEV_INLINE void split4(const f32x4 v, float scale, half4_t& hi, half4_t& lo) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float xs = v[k] * scale;
+    hi[k] = (_Float16)fminf(fmaxf(xs, -65000.f), 65000.f);   // saturate instead of producing inf: the lo half
+    lo[k] = (_Float16)fminf(fmaxf(xs - (float)hi[k], -65000.f), 65000.f);  // then carries up to another 65 000
+  }
+}
+// byte offset of the 16-byte piece (block, K-chunk kc, plane, half h) of pixel (b, y, x) in a split tensor of nblk blocks, kcb K-chunks
+DFN_DEV_INLINE size_t split_piece(int H, int W, int nblk, int kcb, int b, int y, int x, int blk, int kc, int plane, int h) {
+  return ((((((size_t)b * H + y) * nblk + blk) * kcb + kc) * 4 + plane * 2 + h) * W + x) * 16;
+}
+// one 16-byte fp32 chunk (4 of a pixel-block's 32 floats: lane half chunk / 4, slots (chunk % 4) * 4 ..) into a split tensor
+DFN_DEV_INLINE void store_split_chunk(void* base, int H, int W, int nblk, int b, int y, int x, int blk, int chunk, const f32x4 v) {
+  half4_t hi, lo;
+  split4(v, kConvActScale, hi, lo);
+  const int h = chunk >> 2, s0 = (chunk & 3) * 4;
+  char* d = static_cast<char*>(base) + split_piece(H, W, nblk, 2, b, y, x, blk, s0 >> 3, 0, h) + (s0 & 7) * 2;
+  *reinterpret_cast<half4_t*>(d) = hi;
+  *reinterpret_cast<half4_t*>(d + 2 * (size_t)W * 16) = lo;   // plane 1 lies two sub-planes (h = 0, 1) further
+}
+// a lane's 16 accumulator values (pixel (y, x), half h, block blk) into a split tensor: hi / lo of both K-chunks, 16 bytes each
+DFN_DEV_INLINE void store_split_frag(void* base, int H, int W, int nblk, int b, int y, int x, int blk, int h, const f32x16& v, float scale,
+                                     bool relu) {
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    half8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float xs = v[8 * kc + k] * scale;
+      if (relu) xs = fmaxf(xs, 0.f);
+      xs *= kConvActScale;
+      hi[k] = (_Float16)fminf(fmaxf(xs, -65000.f), 65000.f);
+      lo[k] = (_Float16)fminf(fmaxf(xs - (float)hi[k], -65000.f), 65000.f);
+    }
+    char* d = static_cast<char*>(base) + split_piece(H, W, nblk, 2, b, y, x, blk, kc, 0, h);
+    *reinterpret_cast<half8*>(d) = hi;
+    *reinterpret_cast<half8*>(d + 2 * (size_t)W * 16) = lo;
+  }
+}
+
+// Epilogue of the split-f16 convolutions: undo the operand scaling, write the pre-ReLU tap, the ReLU'd activation, the
+// 2x2-pooled activation and / or fp32 NCHW planes.
+template <int MB, int TW>
+DFN_DEV_INLINE void x3_epilogue(const ConvArgs& a, const f32x16 (&acc)[MB][2], float out_scale, char* smem, int wave, int lane,
+                                int b, int cg, int y0, int x0) {
+  constexpr int RF = 32 / TW;
+  const int p = lane & 31, h = lane >> 5, pr = p / TW, pc = p % TW;
+  // A lane
+  // owns 64 bytes of a pixel's 128-byte channel line, so storing straight from the accumulators issues 64 quarter-line
+  // requests per instruction (measured: a fifth of the kernel's time).  Each wave therefore turns its output rows
+  // through LDS — the staging buffers are dead by now — and stores whole lines, eight lanes per line.
+  constexpr int ROWB = MB * 128 + 16;                 // padded bytes per pixel in the turn buffer
+  if (a.out_nchw) store_nchw<MB, float, RF>(a, acc, out_scale, b, cg, y0 + 2 * wave * RF + pr, x0 + pc, h);
+  // split outputs go straight from the accumulators (512-byte runs per half-wave); fp32 outputs take the turn below
+  void* act32 = (a.out_split & 1) ? nullptr : a.out_act;
+  void* pre32 = (a.out_split & 2) ? nullptr : a.out_pre;
+  if ((a.out_act && !act32) || (a.out_pre && !pre32)) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int y = y0 + (2 * wave + nb) * RF + pr, x = x0 + pc;
+      if (y < a.H && x < a.W) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          if (a.out_pre && !pre32) store_split_frag(a.out_pre, a.H, a.W, a.cout_blocks, b, y, x, cg * MB + mb, h, acc[mb][nb], out_scale, false);
+          if (a.out_act && !act32) store_split_frag(a.out_act, a.H, a.W, a.cout_blocks, b, y, x, cg * MB + mb, h, acc[mb][nb], out_scale, a.relu);
+        }
+      }
+    }
+  }
+  if (!act32 && !pre32 && !a.out_pool) return;
+  __syncthreads();                                     // every wave is done with the planes and the weight buffers
+  char* turn = smem + wave * (32 * ROWB);
+  if (a.out_pool) {
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    auto pool_store = [&](int yp, int xp0, int npx, auto src) {   // src(j, mbl, chunk) = 2x2 maximum of pooled pixel j of this pass
+      if (yp >= Hp) return;
+      const size_t rowoff = (((size_t)b * Hp + yp) * Wp + xp0) * a.cout_blocks * 32 + (size_t)cg * MB * 32;   // floats
+#pragma unroll
+      for (int i = 0; i < npx * MB / 8; ++i) {
+        const int line = i * 8 + (lane >> 3), px = line / MB, mbl = line - px * MB, chunk = lane & 7;
+        if (xp0 + px < Wp) {
+          f32x4 v = src(px, mbl, chunk);
+          if (a.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+          if (a.out_split & 4) store_split_chunk(a.out_pool, Hp, Wp, a.cout_blocks, b, yp, xp0 + px, cg * MB + mbl, chunk, v);
+          else *reinterpret_cast<f32x4*>(static_cast<float*>(a.out_pool) + rowoff + ((size_t)px * a.cout_blocks + mbl) * 32 + chunk * 4) = v;
+        }
+      }
+    };
+    auto mx = [](f32x4 u, f32x4 w) { return f32x4{fmaxf(u[0], w[0]), fmaxf(u[1], w[1]), fmaxf(u[2], w[2]), fmaxf(u[3], w[3])}; };
+    auto at = [&](int px, int mbl, int chunk) { return *reinterpret_cast<const f32x4*>(turn + px * ROWB + mbl * 128 + chunk * 16); };
+    if constexpr (RF == 1) {
+      // the wave's two rows are the two rows of its pooling windows: vertical maximum in registers, horizontal through the turn buffer
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        f32x4* d = reinterpret_cast<f32x4*>(turn + p * ROWB + mb * 128 + h * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[mb][0][4 * q + k], acc[mb][1][4 * q + k]) * out_scale;
+          d[q] = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      pool_store((y0 + 2 * wave) >> 1, x0 >> 1, 16, [&](int j, int mbl, int chunk) { return mx(at(2 * j, mbl, chunk), at(2 * j + 1, mbl, chunk)); });
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // a fragment holds both rows of its windows (pixels j and j + TW of the turn buffer): one pooled row of TW / 2 pixels each
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          f32x4* d = reinterpret_cast<f32x4*>(turn + p * ROWB + mb * 128 + h * 64);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            d[q] = f32x4{acc[mb][nb][4 * q] * out_scale, acc[mb][nb][4 * q + 1] * out_scale, acc[mb][nb][4 * q + 2] * out_scale,
+                         acc[mb][nb][4 * q + 3] * out_scale};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        pool_store(((y0 + (2 * wave + nb) * RF) >> 1), x0 >> 1, TW / 2, [&](int j, int mbl, int chunk) {
+          return mx(mx(at(2 * j, mbl, chunk), at(2 * j + 1, mbl, chunk)), mx(at(TW + 2 * j, mbl, chunk), at(TW + 2 * j + 1, mbl, chunk)));
+        });
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (!act32 && !pre32) return;
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+#ifdef DFN_CONV_ABL_NOEPI
+    if (acc[0][nb][0] != 12345.678f) continue;   // keeps the accumulators alive, stores nothing
+#endif
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      f32x4* d = reinterpret_cast<f32x4*>(turn + p * ROWB + mb * 128 + h * 64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        d[q] = f32x4{acc[mb][nb][4 * q] * out_scale, acc[mb][nb][4 * q + 1] * out_scale, acc[mb][nb][4 * q + 2] * out_scale,
+                     acc[mb][nb][4 * q + 3] * out_scale};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-local hand-over: LDS operations of a wave stay in order
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int yf = y0 + (2 * wave + nb) * RF;   // first image row of the fragment
+#pragma unroll
+      for (int i = 0; i < 4 * MB; ++i) {
+        const int line = i * 8 + (lane >> 3), px = line / MB, mbl = line - px * MB, chunk = lane & 7;
+        const int y = yf + px / TW, x = x0 + px % TW;
+        if (y < a.H && x < a.W) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(turn + px * ROWB + mbl * 128 + chunk * 16);
+          const size_t off = ((((size_t)b * a.H + y) * a.W + x) * a.cout_blocks + cg * MB + mbl) * 32;   // first float of the pixel's block
+          if (pre32) *reinterpret_cast<f32x4*>(static_cast<float*>(pre32) + off + chunk * 4) = v;
+          if (act32) {
+            const f32x4 r = a.relu ? f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)} : v;
+            *reinterpret_cast<f32x4*>(static_cast<float*>(act32) + off + chunk * 4) = r;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                   // the second row reuses the turn buffer
+  }
+}
+
+template <int KS, int SB, int WAVES = 4, int TW = 32>
+constexpr int x3_plane_bytes() { return (2 * WAVES * (32 / TW) + KS - 1) * (TW + KS - 1) * SB * 4; }   // [2][SB/8][pixels][8 x f16]
 template <int KS, int SB, int MB>
 constexpr int x3_wslice_bytes() { return 2 * MB * KS * 1024; }  // hi + lo fragments of one (block, ky, kc) sub-slice
 
 // WAVES = 4: 8 x 32 output pixels per workgroup, two workgroups per CU.  WAVES = 8: 16 x 32 pixels, ONE workgroup per CU — the
 // same eight waves share every weight slice (half the LDS-DMA per output pixel), the patch halo is amortised over twice
-// the rows, and the slices double-buffer inside the 160 KB.
-template <int KS, int SB, int MB, bool DB, int WAVES = 4>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel(ConvArgs a) {
+// the rows.
+// Staging.  The patch of one 32-channel input block lives in two f16 planes (hi, lo), each [lane half h][K-chunk][pixel][8 slots]:
+// the B fragment of lane (pixel, h) is 16 contiguous bytes and consecutive lanes read consecutive 16-byte pieces — conflict-free
+// without padding.  Weight sub-slices stream L2 -> LDS by DMA through a RING of buffers: sub-slice s + RING - 1 is issued when
+// sub-slice s starts being multiplied, so a DMA has RING - 1 multiply phases to land (with one phase it was the wave's main
+// wait: DESIGN.md section 7).  Every wave issues the same number of DMA pieces and of patch loads in every iteration (tail
+// iterations repeat the last sub-slice / block: same bytes, dead destination), so the in-order vmcnt can be awaited by count.
+// Tile shape.  An MFMA B fragment is 32 pixels: TW = 32 takes them from one image row (a wave's two fragments = two rows, the
+// workgroup 2*WAVES x 32 pixels), TW = 16 from two rows of 16 (a wave = four rows, the workgroup 4*WAVES x 16) — chosen per layer
+// by which wastes fewer pixels on the image border (launch_conv): 60 x 80 (conv4_x) fills 78 % of its 8 x 32 tiles, 94 % of 16 x 16.
+// Channel tile.  The weights are packed for MBP = 2 M-blocks (64 output channels) per sub-slice; MB = 1 takes one M-block's pieces out
+// of it (32 output channels per workgroup: twice the workgroups, each with half the accumulators and 53 KB of LDS — three per CU).
+// launch_conv picks it for the layers whose 64-channel workgroups would leave the chip's 512 slots badly filled (60 x 80 and below).
+template <int KS, int SB, int MB, int RING, int WAVES = 4, int TW = 32>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? (MB == 1 ? 3 : 2) : 1) void conv_x3_kernel(ConvArgs a) {
+  constexpr int MBP = 2;                  // M-blocks per packed sub-slice (pack_conv_x3)
   constexpr int KCB = SB / 8;
   constexpr int NT = WAVES * 64;
-  constexpr int TH = 2 * WAVES, TW = kConvTileW, R = KS / 2;
-  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int RF = 32 / TW;             // image rows per fragment
+  constexpr int TH = 2 * WAVES * RF, R = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1, NPIX = PH * PW;
   constexpr int PIXG = 2 * SB * 4;        // bytes of a pixel's block in HBM (fp32)
-  constexpr int PS = 2 * SB * 2 + 16;     // padded pixel stride of one f16 plane
   constexpr int SEG = PIXG / 16;          // 16-byte (4-float) segments per pixel
-  constexpr int PLANE = x3_plane_bytes<KS, SB, WAVES>();
-  constexpr int WSL = x3_wslice_bytes<KS, SB, MB>();
+  constexpr int PLANE = x3_plane_bytes<KS, SB, WAVES, TW>();
+  constexpr int WSL = x3_wslice_bytes<KS, SB, MB>();      // what this workgroup stages of a sub-slice
+  constexpr int WSLP = x3_wslice_bytes<KS, SB, MBP>();    // the packed sub-slice
   constexpr int WHALF = WSL / 2;
+  constexpr int NP = WSL / 1024;                      // 1 KB DMA pieces per sub-slice
+  constexpr int PPW = (NP + WAVES - 1) / WAVES;       // pieces each wave issues per sub-slice
+  constexpr int AHEAD = RING - 1;                     // sub-slices in flight beyond the one being multiplied
+  constexpr int SPB = KS * KCB;                       // sub-slices per input block
+  static_assert(RING >= 2 && AHEAD <= SPB, "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* plane_hi = smem;
   char* plane_lo = smem + PLANE;
-  char* wst = smem + 2 * PLANE;           // two slices
+  char* wst = smem + 2 * PLANE;           // RING sub-slices
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 31, h = lane >> 5;
+  const int pr = p / TW, pc = p % TW;   // the lane's pixel inside a fragment: row, column
   const int tiles_x = (a.W + TW - 1) / TW;
   int tile = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
   if (a.xcd_groups > 0) {
@@ -294,21 +494,31 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
     }
   }
   const char* in = static_cast<const char*>(a.in);
-  const int n_slices = a.nblk_in * KS * KCB;   // one per (block, ky, K-chunk)
+  const int n_slices = a.nblk_in * SPB;   // one per (block, ky, K-chunk)
   // operand scale of the input tensor: the fixed activation scale, or (gradient tensors) a measured power of two
   const float act_scale = a.dyn_scale ? a.dyn_scale[0] : kConvActScale;
   const float out_scale = a.dyn_scale ? a.out_scale * kConvActScale * a.dyn_scale[1] : a.out_scale;
-  auto issue_slice = [&](int sl, int buf) {
-    const char* wsrc = a.w + ((size_t)cg * n_slices + sl) * WSL + lane * 16;
+  int ring_w = 0;                          // ring buffer the next issued sub-slice goes to
+  auto issue_slice = [&](int sl) {
+    const char* wsrc = a.w + ((size_t)(cg * MB / MBP) * n_slices + min(sl, n_slices - 1)) * WSLP + lane * 16;
+    const int mbsel = (cg * MB) % MBP;     // first packed M-block this workgroup computes
+    char* dst = wst + ring_w * WSL;
 #ifndef DFN_CONV_ABL_NODMA
-    for (int q = wave * 1024; q < WSL; q += WAVES * 1024) conv_lds_dma_b128(wsrc + q, wst + buf * WSL + q);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int q = min(wave + i * WAVES, NP - 1);                 // piece q of the staged slice = (hi | lo, M-block, kx)
+      const int half = q / (MB * KS), r = q - half * (MB * KS);
+      conv_lds_dma_b128(wsrc + ((half * MBP + mbsel) * KS + r) * 1024, dst + q * 1024);
+    }
 #endif
+    ring_w = ring_w + 1 == RING ? 0 : ring_w + 1;
   };
-  // The fp32 patch of the NEXT input block is prefetched into registers while the current block is multiplied
-  // (a fixed number of unconditional loads per thread, so the weight DMA can be awaited with a counted vmcnt).
-  constexpr int TOTAL = PH * PW * SEG, NPRE = (TOTAL + NT - 1) / NT;
+  // The fp32 patch of the NEXT input block is prefetched into registers while the current block is multiplied.
+  constexpr int TOTAL = NPIX * SEG, NPRE = (TOTAL + NT - 1) / NT;
+  static_assert(AHEAD * PPW + NPRE <= 63, "vmcnt range");
   f32x4 pre[NPRE];
   auto load_patch = [&](int blk) {
+    blk = min(blk, a.nblk_in - 1);
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int e = min(tid + i * NT, TOTAL - 1);
@@ -335,50 +545,58 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
           hi[k] = (_Float16)fminf(fmaxf(xs, -65000.f), 65000.f);   // saturate instead of producing inf: the lo half
           lo[k] = (_Float16)fminf(fmaxf(xs - (float)hi[k], -65000.f), 65000.f);  // then carries up to another 65 000
         }
+        // segment = 4 consecutive slots of half hh: slots s0..s0+3 -> K-chunk s0 / 8, byte (s0 % 8) * 2 of the pixel's 16
+        const int hh = seg / (SB / 4), s0 = (seg - hh * (SB / 4)) * 4;
+        const int o = ((hh * KCB + (s0 >> 3)) * NPIX + pix) * 16 + (s0 & 7) * 2;
 #ifndef DFN_CONV_ABL_NOSTORE
-        *reinterpret_cast<half4*>(plane_hi + pix * PS + seg * 8) = hi;
-        *reinterpret_cast<half4*>(plane_lo + pix * PS + seg * 8) = lo;
+        *reinterpret_cast<half4*>(plane_hi + o) = hi;
+        *reinterpret_cast<half4*>(plane_lo + o) = lo;
 #endif
       }
     }
   };
   CONV_T_DECL;
   load_patch(0);
-  if (DB) issue_slice(0, 0);
-  int sl = 0;
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) issue_slice(i);
+  int sl = 0, ring_r = 0;
   for (int blk = 0; blk < a.nblk_in; ++blk) {
-    CONV_T(3);
-    __syncthreads();  // everyone is done with the previous patch (and the slice before the one in flight)
-    CONV_T(1);
-    store_patch();
-    CONV_T(2);
-    const bool more = blk + 1 < a.nblk_in;
 #pragma unroll 1
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
       for (int kc = 0; kc < KCB; ++kc, ++sl) {
-        if (!DB) {                           // single buffer: two workgroups per CU cover each other's staging
-          if (ky || kc) { CONV_T(3); __syncthreads(); CONV_T(1); }   // previous sub-slice fully consumed
-          issue_slice(sl, 0);
-        }
-        if (ky == 0 && kc == 0 && more) {    // next block's patch: issued AFTER this sub-slice's DMA, allowed to stay in flight
-          load_patch(blk + 1);
-          __builtin_amdgcn_s_waitcnt(NPRE <= 15 ? (0x0F70 | NPRE) : 0x0F70);  // vmcnt(NPRE)
+        // Issue order of a block starting at sub-slice j: ... slice j+AHEAD, patch(next block), slice j+AHEAD+1, ...  Awaiting
+        // sub-slice j+i may leave outstanding what was issued after it: AHEAD-1 sub-slices, and the patch loads while i <= AHEAD.
+        // The block's first iteration needs the patch issued one block ago: only the sub-slices issued after THAT may be out.
+        const int i = ky * KCB + kc;
+        CONV_T(3);
+        if (i == 0) {
+          DFN_VMCNT((AHEAD - 1 < SPB - 1 ? AHEAD - 1 : SPB - 1) * PPW);
+          asm volatile("" ::: "memory");
+          CONV_T(0);
+          __syncthreads();                   // everyone is done with the previous patch and sub-slice sl-1
+          CONV_T(1);
+          store_patch();
+          CONV_T(2);
+        } else if (i <= AHEAD) {
+          DFN_VMCNT((AHEAD - 1) * PPW + NPRE);
         } else {
-          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my share of sub-slice sl has landed
+          DFN_VMCNT((AHEAD - 1) * PPW);
         }
         asm volatile("" ::: "memory");
         CONV_T(0);
-        __syncthreads();                     // sub-slice sl and the patch are visible; (DB) sub-slice sl-1 is fully consumed
+        __syncthreads();                     // sub-slice sl (and the patch) visible; sub-slice sl-1 fully consumed
         CONV_T(1);
-        if (DB && sl + 1 < n_slices) issue_slice(sl + 1, (sl + 1) & 1);
-        const char* wb = wst + (DB ? (sl & 1) * WSL : 0);
+        issue_slice(sl + AHEAD);             // into the buffer sub-slice sl-1 has left
+        if (i == 0) load_patch(blk + 1);
+        const char* wb = wst + ring_r * WSL;
+        ring_r = ring_r + 1 == RING ? 0 : ring_r + 1;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
           half8 bh[2], bl[2];
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
-            const int o = ((2 * wave + nb + ky) * PW + p + kx) * PS + (h * SB + kc * 8) * 2;
+            const int o = ((h * KCB + kc) * NPIX + ((2 * wave + nb) * RF + pr + ky) * PW + pc + kx) * 16;
 #ifdef DFN_CONV_ABL_NOBREAD
             bh[nb] = half8{(_Float16)o, 1, 2, 3, 4, 5, 6, 7};
             bl[nb] = half8{(_Float16)kx, 1, 2, 3, 4, 5, 6, 7};
@@ -412,85 +630,157 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3_kernel
       }
     }
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // the tail's repeated DMA pieces land before the buffers are reused by the epilogue
   CONV_T(3);
-  // Epilogue (fp32 activations): undo the operand scaling, write the pre-ReLU tap and/or the ReLU'd activation.  A lane
-  // owns 64 bytes of a pixel's 128-byte channel line, so storing straight from the accumulators issues 64 quarter-line
-  // requests per instruction (measured: a fifth of the kernel's time).  Each wave therefore turns its output rows
-  // through LDS — the staging buffers are dead by now — and stores whole lines, eight lanes per line.
-  constexpr int ROWB = MB * 128 + 16;                 // padded bytes per pixel in the turn buffer
-  if (a.out_nchw) store_nchw<MB, float>(a, acc, out_scale, b, cg, y0 + 2 * wave, x0, p, h);
-  if (!a.out_act && !a.out_pre && !a.out_pool) { CONV_T(4); CONV_T_FLUSH; return; }
-  __syncthreads();                                     // every wave is done with the planes and the weight buffers
-  char* turn = smem + wave * (32 * ROWB);
-  if (a.out_pool) {
-    // the wave's two rows are the two rows of its pooling windows: vertical maximum in registers, horizontal through the turn buffer
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      f32x4* d = reinterpret_cast<f32x4*>(turn + p * ROWB + mb * 128 + h * 64);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[mb][0][4 * q + k], acc[mb][1][4 * q + k]) * out_scale;
-        d[q] = v;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int Hp = a.H >> 1, Wp = a.W >> 1, yp = (y0 + 2 * wave) >> 1;
-    if (yp < Hp) {
-      const size_t rowoff = (((size_t)b * Hp + yp) * Wp + (x0 >> 1)) * a.cout_blocks * 32 + (size_t)cg * MB * 32;   // floats
-#pragma unroll
-      for (int i = 0; i < 2 * MB; ++i) {
-        const int line = i * 8 + (lane >> 3), px = line / MB, mbl = line - px * MB, chunk = lane & 7;
-        if ((x0 >> 1) + px < Wp) {
-          const f32x4 u = *reinterpret_cast<const f32x4*>(turn + (2 * px) * ROWB + mbl * 128 + chunk * 16);
-          const f32x4 w = *reinterpret_cast<const f32x4*>(turn + (2 * px + 1) * ROWB + mbl * 128 + chunk * 16);
-          f32x4 v = {fmaxf(u[0], w[0]), fmaxf(u[1], w[1]), fmaxf(u[2], w[2]), fmaxf(u[3], w[3])};
-          if (a.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-          *reinterpret_cast<f32x4*>(static_cast<float*>(a.out_pool) + rowoff + ((size_t)px * a.cout_blocks + mbl) * 32 + chunk * 4) = v;
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (!a.out_act && !a.out_pre) { CONV_T(4); CONV_T_FLUSH; return; }
+  x3_epilogue<MB, TW>(a, acc, out_scale, smem, wave, lane, b, cg, y0, x0);
+  CONV_T(4);
+  CONV_T_FLUSH;
+}
+
+// ------------------------------------------------------------------------------------------ split-f16 convolution, split input
+// The same product as conv_x3_kernel on an input already stored as hi | lo f16 (the row-planar split storage above): the patch needs no conversion and
+// is staged by LDS-DMA like the weights — no patch registers, no split VALU, no LDS writes by the waves (the ablations of DESIGN.md
+// section 7 put those at a quarter of conv_x3_kernel's time, paid once per output-channel group and halo overlap).  The
+// contraction runs over HALF-blocks (16 input channels = one K-chunk of both lane halves): the planes of one half-block are 21 KB
+// for an 8 x 32 tile, so two of them ping-pong — half-block hb + 1 lands while hb is multiplied — in the LDS the fp32-input kernel
+// needs for one block.  Planes: [hi | lo][lane half h][pixel][8 slots] f16; a DMA instruction fills 64 consecutive 16-byte slots,
+// each lane fetching its pixel's piece — runs of up to a patch row of consecutive pieces in the row-planar storage — or 16 bytes of
+// zeros outside the image.  One barrier per sub-slice,
+// none extra per half-block.  Sub-slice order (block, K-chunk, ky) over the weights packed as (block, ky, K-chunk).
+template <int KS, int SB, int WAVES = 4, int TW = 32>
+constexpr int x3s_patch_bytes() {
+  return ((2 * 2 * (2 * WAVES * (32 / TW) + KS - 1) * (TW + KS - 1) * 16) + 1023) & ~1023;   // one half-block, whole 1 KB DMA pieces
+}
+
+template <int KS, int SB, int MB, int WAVES = 4, int TW = 32>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kernel(ConvArgs a) {
+  constexpr int KCB = SB / 8;
+  constexpr int RF = 32 / TW;
+  constexpr int TH = 2 * WAVES * RF, R = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1, NPIX = PH * PW;
+  constexpr int PIXG = 2 * SB * 4;        // bytes of a pixel's block in HBM: [hi: 2 x SB f16][lo: 2 x SB f16]
+  constexpr int PBUF = x3s_patch_bytes<KS, SB, WAVES, TW>();
+  constexpr int PPIECES = PBUF / 1024, PPP = (PPIECES + WAVES - 1) / WAVES;   // DMA pieces of a half-block's planes, per wave
+  constexpr int WSL = x3_wslice_bytes<KS, SB, MB>();
+  constexpr int WHALF = WSL / 2;
+  constexpr int NP = WSL / 1024, PPW = (NP + WAVES - 1) / WAVES;
+  static_assert(PPP + PPW <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;                     // two half-block buffers
+  char* wst = smem + 2 * PBUF;            // two sub-slices
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  const int pr = p / TW, pc = p % TW;
+  const int tiles_x = (a.W + TW - 1) / TW;
+  int tile = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  if (a.xcd_groups > 0) {                 // XCD-aware 1-D grid, see conv_x3_kernel
+    const int n8 = (a.xcd_groups + 7) / 8;
+    const int L = (blockIdx.x & 7) * n8 + (blockIdx.x >> 3);
+    if (L >= a.xcd_groups) return;
+    const int tiles = tiles_x * ((a.H + TH - 1) / TH), per_cg = tiles * a.B;
+    cg = L / per_cg;
+    const int rem = L - cg * per_cg;
+    b = rem / tiles;
+    tile = rem - b * tiles;
   }
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+
+  f32x16 acc[MB][2];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-#ifdef DFN_CONV_ABL_NOEPI
-    if (acc[0][nb][0] != 12345.678f) continue;   // keeps the accumulators alive, stores nothing
-#endif
+  for (int mb = 0; mb < MB; ++mb) {
+    const f32x4* bq = reinterpret_cast<const f32x4*>(a.bias + ((cg * MB + mb) * 2 + h) * 16);  // pre-scaled bias
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      f32x4* d = reinterpret_cast<f32x4*>(turn + p * ROWB + mb * 128 + h * 64);
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = bq[q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        d[q] = f32x4{acc[mb][nb][4 * q] * out_scale, acc[mb][nb][4 * q + 1] * out_scale, acc[mb][nb][4 * q + 2] * out_scale,
-                     acc[mb][nb][4 * q + 3] * out_scale};
+      for (int i = 0; i < 4; ++i) { acc[mb][0][4 * q + i] = v[i]; acc[mb][1][4 * q + i] = v[i]; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-local hand-over: LDS operations of a wave stay in order
-    __builtin_amdgcn_wave_barrier();
-    const int y = y0 + 2 * wave + nb;
-    if (y < a.H) {
-      const size_t rowoff = (((size_t)b * a.H + y) * a.W + x0) * a.cout_blocks * 32 + (size_t)cg * MB * 32;   // floats
+  }
+  const int NHB = a.nblk_in * KCB;        // half-blocks
+  const int n_slices = NHB * KS;
+  // Where each of this lane's DMA slots comes from (fixed for the tile): slot = piece * 64 + lane = (plane, h, pixel).
+  const char* psrc[PPP];
+  unsigned inside = 0;                    // bit i: slot i is a pixel of the image (its address advances with the half-block)
 #pragma unroll
-      for (int i = 0; i < 4 * MB; ++i) {
-        const int line = i * 8 + (lane >> 3), px = line / MB, mbl = line - px * MB, chunk = lane & 7;
-        if (x0 + px < a.W) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(turn + px * ROWB + mbl * 128 + chunk * 16);
-          const size_t off = rowoff + ((size_t)px * a.cout_blocks + mbl) * 32 + chunk * 4;
-          if (a.out_pre) *reinterpret_cast<f32x4*>(static_cast<float*>(a.out_pre) + off) = v;
-          if (a.out_act) {
-            const f32x4 r = a.relu ? f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)} : v;
-            *reinterpret_cast<f32x4*>(static_cast<float*>(a.out_act) + off) = r;
+  for (int i = 0; i < PPP; ++i) {
+    const int slot = min(wave + i * WAVES, PPIECES - 1) * 64 + lane;
+    const int q = slot / NPIX, pix = slot - q * NPIX;          // q = plane * 2 + h; q >= 4: padding of the last piece
+    const int py = pix / PW, px = pix - py * PW;
+    const int gy = y0 + py - R, gx = x0 + px - R;
+    const bool ok = q < 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    psrc[i] = ok ? static_cast<const char*>(a.in) + split_piece(a.H, a.W, a.nblk_in, KCB, b, gy, gx, 0, 0, q >> 1, q & 1)
+                 : static_cast<const char*>(a.zeros);
+    inside |= unsigned(ok) << i;
+  }
+  auto issue_patch = [&](int hb, int buf) {
+    hb = min(hb, NHB - 1);
+    const size_t off = (size_t)hb * 4 * a.W * 16;              // the half-block's four sub-planes of the row
+    char* dst = patch + buf * PBUF;
+#pragma unroll
+    for (int i = 0; i < PPP; ++i)
+      conv_lds_dma_b128(psrc[i] + (((inside >> i) & 1) ? off : (size_t)0), dst + min(wave + i * WAVES, PPIECES - 1) * 1024);
+  };
+  auto issue_slice = [&](int sl, int buf) {
+    sl = min(sl, n_slices - 1);
+    const int hb = sl / KS, ky = sl - hb * KS;
+    const int packed = ((hb / KCB) * KS + ky) * KCB + (hb % KCB);
+    const char* wsrc = a.w + ((size_t)cg * n_slices + packed) * WSL + lane * 16;
+    char* dst = wst + buf * WSL;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int q = min(wave + i * WAVES, NP - 1) * 1024;
+      conv_lds_dma_b128(wsrc + q, dst + q);
+    }
+  };
+  const float out_scale = a.out_scale;
+  CONV_T_DECL;
+  issue_patch(0, 0);
+  issue_slice(0, 0);
+  int sl = 0;
+  for (int hb = 0; hb < NHB; ++hb) {
+    const char* pb = patch + (hb & 1) * PBUF;
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky, ++sl) {
+      // issue order: ... slice s, [iteration s:] slice s+1, patch(hb+1) (first iteration of a half-block only), [s+1:] slice s+2 ...
+      CONV_T(3);
+      if (ky == 1) DFN_VMCNT(PPP);         // sub-slice s landed; the next half-block's planes may still be in flight
+      else DFN_VMCNT(0);                   // (ky == 0: the planes of THIS half-block, issued a half-block ago, must be home)
+      asm volatile("" ::: "memory");
+      CONV_T(0);
+      __syncthreads();                     // sub-slice s and the planes visible; sub-slice s-1 (and at ky == 0 the other planes) consumed
+      CONV_T(1);
+      issue_slice(sl + 1, (sl + 1) & 1);
+      if (ky == 0) issue_patch(hb + 1, (hb + 1) & 1);
+      const char* wb = wst + (sl & 1) * WSL;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        half8 bh[2], bl[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int o = (h * NPIX + ((2 * wave + nb) * RF + pr + ky) * PW + pc + kx) * 16;
+          bh[nb] = *reinterpret_cast<const half8*>(pb + o);
+          bl[nb] = *reinterpret_cast<const half8*>(pb + 2 * NPIX * 16 + o);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int fo = ((mb * KS + kx) * 64 + lane) * 16;
+          const half8 ah = *reinterpret_cast<const half8*>(wb + fo);
+          const half8 al = *reinterpret_cast<const half8*>(wb + WHALF + fo);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], acc[mb][nb], 0, 0, 0);
           }
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                   // the second row reuses the turn buffer
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // the tail's repeated DMA pieces land before the buffers are reused by the epilogue
+  CONV_T(3);
+  x3_epilogue<MB, TW>(a, acc, out_scale, smem, wave, lane, b, cg, y0, x0);
   CONV_T(4);
   CONV_T_FLUSH;
 }
@@ -509,23 +799,51 @@ extern "C" int dfn_debug_conv_cycles(unsigned long long* out8, int reset) {
 namespace dfn {
 #endif
 
-template <int KS, int SB, int MB, bool DB, int WAVES = 4>
+template <int KS, int SB, int MB, int RING, int WAVES = 4, int TW = 32>
 static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
   if (a.cout_blocks % MB) return hipErrorInvalidValue;
-  constexpr int lds = 2 * x3_plane_bytes<KS, SB, WAVES>() + (DB ? 2 : 1) * x3_wslice_bytes<KS, SB, MB>();
-  static_assert(lds <= 160 * 1024, "x3 conv tile does not fit in LDS");
-  auto kern = conv_x3_kernel<KS, SB, MB, DB, WAVES>;
+  constexpr int TH = 2 * WAVES * (32 / TW);
+  constexpr int lds = 2 * x3_plane_bytes<KS, SB, WAVES, TW>() + RING * x3_wslice_bytes<KS, SB, MB>();
+  static_assert(lds <= (WAVES == 4 ? (MB == 1 ? 160 * 1024 / 3 : 80 * 1024) : 160 * 1024), "x3 conv tile does not fit in LDS (4-wave tiles: two / three workgroups per CU)");
+  static_assert(lds >= WAVES * 32 * (MB * 128 + 16), "epilogue turn buffers");
+  auto kern = conv_x3_kernel<KS, SB, MB, RING, WAVES, TW>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int tiles = ((a.H + 2 * WAVES - 1) / (2 * WAVES)) * ((a.W + kConvTileW - 1) / kConvTileW);
+  const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
   // weights of the layer in the packed split-f16 form: hi + lo f16 per element
   const size_t wbytes = size_t(a.cout_blocks) * 32 * a.nblk_in * 32 * KS * KS * 4;
   static const int xcd_mode = [] { const char* e = getenv("DFN_X3_XCD"); return e ? atoi(e) : 1; }();  // tuning aid: 0 = plain 3-D grid
   if (xcd_mode && (xcd_mode == 2 || wbytes > (3u << 20)) && a.cout_blocks / MB >= 8) {
+    ConvArgs ax = a;
+    ax.xcd_groups = tiles * (a.cout_blocks / MB) * a.B;
+    hipLaunchKernelGGL(kern, dim3((ax.xcd_groups + 7) / 8 * 8), dim3(WAVES * 64), lds, stream, ax);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles, a.cout_blocks / MB, a.B), dim3(WAVES * 64), lds, stream, a);
+  return hipGetLastError();
+}
+
+template <int KS, int SB, int MB, int WAVES = 4, int TW = 32>
+static hipError_t launch_conv_x3s_t(const ConvArgs& a, hipStream_t stream) {
+  if (a.cout_blocks % MB || !a.zeros || a.dyn_scale) return hipErrorInvalidValue;
+  constexpr int TH = 2 * WAVES * (32 / TW);
+  constexpr int lds = 2 * x3s_patch_bytes<KS, SB, WAVES, TW>() + 2 * x3_wslice_bytes<KS, SB, MB>();
+  static_assert(lds <= (WAVES == 4 ? 80 : 160) * 1024, "x3s conv tile does not fit in LDS (4-wave tiles: two workgroups per CU)");
+  static_assert(lds >= WAVES * 32 * (MB * 128 + 16), "epilogue turn buffers");
+  auto kern = conv_x3s_kernel<KS, SB, MB, WAVES, TW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
+  const size_t wbytes = size_t(a.cout_blocks) * 32 * a.nblk_in * 32 * KS * KS * 4;
+  if (wbytes > (3u << 20) && a.cout_blocks / MB >= 8) {      // XCD-aware grid, as launch_conv_x3_t
     ConvArgs ax = a;
     ax.xcd_groups = tiles * (a.cout_blocks / MB) * a.B;
     hipLaunchKernelGGL(kern, dim3((ax.xcd_groups + 7) / 8 * 8), dim3(WAVES * 64), lds, stream, ax);
@@ -578,6 +896,29 @@ hipError_t launch_absmax_scale(const float* x, size_t n, float* part, float* out
   return hipGetLastError();
 }
 
+constexpr double kMb1Cost = 0.6;   // duration of a 32-channel workgroup relative to a 64-channel one (measured)
+#ifdef DFN_TIMING
+}  // namespace dfn
+// timing build only: resident workgroups per CU of the main split-f16 conv variants (runtime's answer for their LDS / registers)
+extern "C" int dfn_debug_conv_occupancy(int* out, int n) {
+  using namespace dfn;
+  int k = 0;
+  auto q = [&](auto kern, int threads, int lds) {
+    int nb = -1;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess) nb = -2;
+    if (k < n) out[k++] = nb;
+  };
+  q(conv_x3_kernel<3, 16, 2, 2, 4, 32>, 256, 2 * x3_plane_bytes<3, 16, 4, 32>() + 2 * x3_wslice_bytes<3, 16, 2>());
+  q(conv_x3s_kernel<3, 16, 2, 4, 32>, 256, 2 * x3s_patch_bytes<3, 16, 4, 32>() + 2 * x3_wslice_bytes<3, 16, 2>());
+  q(conv_x3_kernel<3, 16, 1, 2, 4, 16>, 256, 2 * x3_plane_bytes<3, 16, 4, 16>() + 2 * x3_wslice_bytes<3, 16, 1>());
+  q(conv_x3s_kernel<1, 16, 2, 4, 32>, 256, 2 * x3s_patch_bytes<1, 16, 4, 32>() + 2 * x3_wslice_bytes<1, 16, 2>());
+  q(conv_kernel<PrecF16, 3, 16, 4>, 256, conv_patch_bytes<PrecF16, 3, 16>() + conv_wstage_bytes<PrecF16, 3, 16, 4>());
+  return k;
+}
+namespace dfn {
+#endif
+
 int conv_mb(int prec, int cout_blocks) { return (prec == 0 && cout_blocks % 4 == 0) ? 4 : 2; }
 int prep_sb(int prec) { return prec == 1 ? 4 : 8; }
 
@@ -589,24 +930,42 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
     if (ks == 1) return wide ? launch_conv_t<PrecF16, 1, 16, 4>(a, stream) : launch_conv_t<PrecF16, 1, 16, 2>(a, stream);
     if (ks == 3) return wide ? launch_conv_t<PrecF16, 3, 16, 4>(a, stream) : launch_conv_t<PrecF16, 3, 16, 2>(a, stream);
     if (ks == 5) return wide ? launch_conv_t<PrecF16, 5, 16, 4>(a, stream) : launch_conv_t<PrecF16, 5, 16, 2>(a, stream);
-  } else if (prec == 2) {
-    // Sub-slices per K-chunk are double-buffered in every kernel: 3x3 / 1x1 keep two workgroups per CU (77 KB of LDS each),
-    // the 5x5 tile fits one.
-    static const int db = [] { const char* e = getenv("DFN_X3_DB"); return e ? atoi(e) : 1; }();  // tuning aid (0: single buffer)
-    if (sb == 8 && ks == 3) return launch_conv_x3_t<3, 8, 2, true>(a, stream);
+  } else if (prec == 2 && a.in_split) {
+    auto padded = [&](int th, int tw) { return double((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw); };
+    if (sb == 8 && ks == 3) return launch_conv_x3s_t<3, 8, 2>(a, stream);
     if (sb != 16) return hipErrorInvalidValue;
-    if (ks == 1) return db ? launch_conv_x3_t<1, 16, 2, true>(a, stream) : launch_conv_x3_t<1, 16, 2, false>(a, stream);
+    if (ks == 1) return launch_conv_x3s_t<1, 16, 2>(a, stream);
+    if (ks == 3) return padded(16, 16) < 0.97 * padded(8, 32) ? launch_conv_x3s_t<3, 16, 2, 4, 16>(a, stream) : launch_conv_x3s_t<3, 16, 2>(a, stream);
+    if (ks == 5) return launch_conv_x3s_t<5, 16, 2, 8>(a, stream);
+  } else if (prec == 2) {
+    // 3x3 / 1x1: 8 x 32-pixel tiles, two workgroups per CU (80 KB of LDS each: planes + a ring of three sub-slices).
+    static const int ring = [] { const char* e = getenv("DFN_X3_RING"); return e ? atoi(e) : 2; }();  // tuning aid (3: ring of three sub-slices — measured equal)
+    if (sb == 8 && ks == 3) return launch_conv_x3_t<3, 8, 2, 3>(a, stream);
+    if (sb != 16) return hipErrorInvalidValue;
+    if (ks == 1) return launch_conv_x3_t<1, 16, 2, 2>(a, stream);
     if (ks == 3) {
       static const int w8 = [] { const char* e = getenv("DFN_X3_W8"); return e ? atoi(e) : 0; }();  // tuning aid
-      if (w8) return launch_conv_x3_t<3, 16, 2, true, 8>(a, stream);
-      return db ? launch_conv_x3_t<3, 16, 2, true>(a, stream) : launch_conv_x3_t<3, 16, 2, false>(a, stream);
+      if (w8) return launch_conv_x3_t<3, 16, 2, 3, 8>(a, stream);
+      // 8 x 32 or 16 x 16 pixel tiles: whichever covers the image with fewer padding pixels (ties: the 128-byte rows of 8 x 32)
+      auto padded = [&](int th, int tw) { return double((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw); };
+      static const int tw_force = [] { const char* e = getenv("DFN_X3_TW"); return e ? atoi(e) : 0; }();  // tuning aid (32 / 16)
+      const bool sq = tw_force ? tw_force == 16 : padded(16, 16) < 0.97 * padded(8, 32);
+      // 32-channel workgroups (three per CU) when the 64-channel ones would fill the 512 slots of the chip badly
+      static const int mb1_force = [] { const char* e = getenv("DFN_X3_MB1"); return e ? atoi(e) : -1; }();  // tuning aid (0 / 1)
+      auto rounds = [](double wgs, double slots) { return double((long long)((wgs + slots - 1) / slots)); };
+      const double wg64 = double((a.H + 15) / 16) * ((a.W + 15) / 16) * (a.cout_blocks / 2) * a.B;
+      const double wg64r = double((a.H + 7) / 8) * ((a.W + 31) / 32) * (a.cout_blocks / 2) * a.B;
+      const bool mb1 = mb1_force >= 0 ? mb1_force == 1
+                                      : rounds(2 * wg64, 768) * kMb1Cost < rounds(sq ? wg64 : wg64r, 512);
+      if (mb1) return launch_conv_x3_t<3, 16, 1, 2, 4, 16>(a, stream);
+      if (sq) return launch_conv_x3_t<3, 16, 2, 2, 4, 16>(a, stream);
+      return ring == 3 ? launch_conv_x3_t<3, 16, 2, 3>(a, stream) : launch_conv_x3_t<3, 16, 2, 2>(a, stream);
     }
     if (ks == 5) {
-      // 16 x 32-pixel tiles, eight waves: the 4-wave tile's planes + slices (109 KB) allow one workgroup = ONE wave per SIMD;
+      // 16 x 32-pixel tiles, eight waves: the 4-wave tile's planes + slices allow one workgroup = ONE wave per SIMD;
       // eight waves share each weight slice and give every SIMD two waves (measured 1.63 -> 1.22 ms on 4 x 480x640)
-      static const int w8 = [] { const char* e = getenv("DFN_X3_W8_5"); return e ? atoi(e) : 1; }();  // tuning aid (0: 4-wave tile)
-      if (w8) return launch_conv_x3_t<5, 16, 2, true, 8>(a, stream);
-      return launch_conv_x3_t<5, 16, 2, true>(a, stream);
+      static const int ring5 = [] { const char* e = getenv("DFN_X3_RING5"); return e ? atoi(e) : 2; }();  // tuning aid
+      return ring5 == 2 ? launch_conv_x3_t<5, 16, 2, 2, 8>(a, stream) : launch_conv_x3_t<5, 16, 2, 3, 8>(a, stream);
     }
   } else {
     if (sb == 4 && ks == 3) return launch_conv_t<PrecF32, 3, 4, 2>(a, stream);
@@ -632,10 +991,34 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
     for (int c = 0; c < 3; ++c) o[c] = (T)((x[(b * 3 + c) * plane + r] - mean[c]) / stdv[c]);  // half 0, slots 0..2
   }
 }
+// the conv1_1 input in split-f16 storage (one block of 2 x 8 slots, one K-chunk): [B,H][hi | lo][h][W][8 f16], RGB in half 0 slots 0..2
+__global__ __launch_bounds__(256) void prep_split_kernel(const float* __restrict__ x, int B, int H, int W, char* __restrict__ out) {
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};  // dfnet.py:79-80
+  const size_t n = (size_t)B * H * W, plane = (size_t)H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / plane, r = i - b * plane;
+    const int y = int(r / W), xx = int(r - (size_t)y * W);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = (x[(b * 3 + c) * plane + r] - mean[c]) / stdv[c];
+    half4_t hi, lo;
+    split4(v, kConvActScale, hi, lo);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {           // q = plane * 2 + h
+      char* d = out + split_piece(H, W, 1, 1, int(b), y, xx, 0, 0, q >> 1, q & 1);
+      *reinterpret_cast<f32x4*>(d) = z;
+      if (q == 0) *reinterpret_cast<half4_t*>(d) = hi;
+      if (q == 2) *reinterpret_cast<half4_t*>(d) = lo;
+    }
+  }
+}
+// prec 3 = the split-f16 storage of prec 2 (inference forward)
 hipError_t launch_dfnet_prep(int prec, const float* x, int B, int H, int W, void* out, hipStream_t stream) {
   const size_t n = (size_t)B * H * W;
   const int grid = int((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  if (prec == 0) hipLaunchKernelGGL((prep_kernel<_Float16, 8>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<_Float16*>(out));
+  if (prec == 3) hipLaunchKernelGGL(prep_split_kernel, dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<char*>(out));
+  else if (prec == 0) hipLaunchKernelGGL((prep_kernel<_Float16, 8>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<_Float16*>(out));
   else if (prec == 2) hipLaunchKernelGGL((prep_kernel<float, 8>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<float*>(out));
   else hipLaunchKernelGGL((prep_kernel<float, 4>), dim3(grid), dim3(256), 0, stream, x, B, H, W, static_cast<float*>(out));
   return hipGetLastError();
@@ -725,8 +1108,102 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ in,
     }
   }
 }
+// Row-tiled variant for source rows of at most kUpRowMax pixels (pyramid levels 1 and 2): a workgroup owns one output row of one
+// 32-channel block.  The two source rows are staged once in LDS, channel-major; every wave then writes whole channel rows as 16-byte
+// stores aligned in memory (1 KB contiguous per instruction; the unaligned head / tail of a row as scalars) — the kernel above
+// writes 256-byte runs interleaved with its gathers and reaches half of this one's write rate.  Same arithmetic, same result.
+constexpr int kUpRowMax = 496;   // 2 x 16 x (w + 1) floats stay under the 64 KB a kernel gets without opting in
+// CPB = channels (stored positions) per workgroup: 32, or 16 for the longer source rows so that the staged rows stay small
+// enough for eight workgroups per CU (the stores need the waves: 3 resident workgroups wrote at 3 TB/s, 8 at 5).
+template <class T, int CPB>
+__global__ __launch_bounds__(256) void upsample_rows_kernel(const T* __restrict__ in, int h, int w, int UH, int UW, float* __restrict__ out,
+                                                            size_t out_bstride, const float* __restrict__ affine) {
+  extern __shared__ float rows[];          // [2][CPB][w + 1]
+  const int ws = w + 1;
+  const int Y = blockIdx.x, blk = blockIdx.y / (32 / CPB), e0 = (blockIdx.y % (32 / CPB)) * CPB;   // stored positions e0 .. e0 + CPB
+  const size_t b = blockIdx.z;
+  const float sy = UH > 1 ? float(h - 1) / float(UH - 1) : 0.f;
+  const float sx = UW > 1 ? float(w - 1) / float(UW - 1) : 0.f;
+  const float fy = sy * float(Y);
+  const int yA = int(fy), yB = yA + (yA < h - 1 ? 1 : 0);
+  const float ly = fy - float(yA), wy0 = 1.f - ly;
+  constexpr int V = 16 / int(sizeof(T));   // elements per 16-byte vector
+  for (int e = threadIdx.x; e < 2 * w * (CPB / V); e += 256) {
+    const int r = e / (w * (CPB / V)), rem = e - r * (w * (CPB / V)), px = rem / (CPB / V), q = rem - px * (CPB / V);
+    alignas(16) T v[V];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(in + ((b * h + (r ? yB : yA)) * (size_t)w + px) * 128 + blk * 32 + e0 + q * V);
+#pragma unroll
+    for (int k = 0; k < V; ++k) rows[(r * CPB + q * V + k) * ws + px] = (float)v[k];
+  }
+  if (threadIdx.x < 2 * CPB) rows[threadIdx.x * ws + w] = 0.f;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // The lane's columns X = head + 4 * lane + 256 * it + k and their horizontal taps are the same for every channel whose row
+  // starts at the same 16-byte phase `head` (all of them when UH * UW is a multiple of four): computed once, kept in registers.
+  constexpr int kIt = 3;                   // up to 768 output columns on the fast path
+  int xa[kIt][4];
+  float lxs[kIt][4];
+  int cached_head = -1;
+  auto taps = [&](int X, int& xA, float& lx) {
+    const float fx = sx * float(X);
+    xA = int(fx);
+    lx = fx - float(xA);
+  };
+  for (int el = wave; el < CPB; el += 4) { // stored position e of the block -> channel
+    const int e = e0 + el, hh = e >> 4, s = e & 15, ch = blk * 32 + 4 * hh + (s & 3) + 8 * (s >> 2);
+    const float* rA = rows + el * ws;
+    const float* rB = rows + (CPB + el) * ws;
+    const float sc = affine ? affine[kBnSc + blk * 32 + e] : 1.f, sh = affine ? affine[kBnSh + blk * 32 + e] : 0.f;
+    float* o = out + b * out_bstride + ((size_t)ch * UH + Y) * UW;
+    // column w of a staged row is zero: the right tap of the last source pixel has weight 0 and reads it
+    auto blend = [&](int xA, float lx) {
+      const float wx0 = 1.f - lx;
+      float v = wy0 * (wx0 * rA[xA] + lx * rA[xA + 1]) + ly * (wx0 * rB[xA] + lx * rB[xA + 1]);
+      if (affine) v = fmaf(v, sc, sh);
+      return v;
+    };
+    auto value = [&](int X) { int xA; float lx; taps(X, xA, lx); return blend(xA, lx); };
+    const int head = int((4 - ((reinterpret_cast<size_t>(o) >> 2) & 3)) & 3);   // floats before the first 16-byte boundary
+    if (lane < head && lane < UW) o[lane] = value(lane);
+    if (head != cached_head) {
+      cached_head = head;
+#pragma unroll
+      for (int it = 0; it < kIt; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) taps(min(head + 4 * lane + 256 * it + k, UW - 1), xa[it][k], lxs[it][k]);
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int X = head + 4 * lane + 256 * it;
+      if (X + 3 < UW) {
+        *reinterpret_cast<f32x4*>(o + X) = f32x4{blend(xa[it][0], lxs[it][0]), blend(xa[it][1], lxs[it][1]), blend(xa[it][2], lxs[it][2]),
+                                                 blend(xa[it][3], lxs[it][3])};
+      } else {
+        for (int k = X; k < UW; ++k) o[k] = value(k);
+      }
+    }
+    for (int X = head + 4 * lane + 256 * kIt; X < UW; X += 256)   // wider rows than the cached taps cover
+      for (int k = X; k < min(X + 4, UW); ++k) o[k] = value(k);
+  }
+}
+
 hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH, int UW, float* out,
                            size_t out_bstride, hipStream_t stream, const float* affine) {
+  if (w <= kUpRowMax && B > 0 && UH > 0 && UW > 0) {
+    const bool narrow = w > 64;            // 16 channels per workgroup: <= 20 KB of rows
+    const size_t lds = size_t(2) * (narrow ? 16 : 32) * (w + 1) * 4;
+    const dim3 grid(UH, narrow ? 8 : 4, B);
+    if (prec == 0) {
+      const _Float16* src = static_cast<const _Float16*>(in);
+      if (narrow) hipLaunchKernelGGL((upsample_rows_kernel<_Float16, 16>), grid, dim3(256), lds, stream, src, h, w, UH, UW, out, out_bstride, affine);
+      else hipLaunchKernelGGL((upsample_rows_kernel<_Float16, 32>), grid, dim3(256), lds, stream, src, h, w, UH, UW, out, out_bstride, affine);
+    } else {
+      const float* src = static_cast<const float*>(in);
+      if (narrow) hipLaunchKernelGGL((upsample_rows_kernel<float, 16>), grid, dim3(256), lds, stream, src, h, w, UH, UW, out, out_bstride, affine);
+      else hipLaunchKernelGGL((upsample_rows_kernel<float, 32>), grid, dim3(256), lds, stream, src, h, w, UH, UW, out, out_bstride, affine);
+    }
+    return hipGetLastError();
+  }
   const size_t n = (size_t)B * 4 * UH * UW;
   if (!n) return hipSuccess;
   const int grid = int((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);

@@ -38,6 +38,11 @@ struct ConvArgs {
   // Optional fused 2x2/2 max pool (split-f16 kernel): [B,H/2,W/2,Cout/32,2,16] = maxpool(relu?(out)); the tile origin is even, so
   // every window lies inside one wave's two rows.
   void* out_pool;
+  // Split-f16 storage (dfnet_conv.hip, split_piece): in_split != 0: `in` holds hi | lo f16 blocks (conv_x3s_kernel, LDS-DMA staged);
+  // out_split bit 0 / 1 / 2: out_act / out_pre / out_pool are written in that storage.  zeros: >= 16 device bytes of zero (the padding
+  // pixels' DMA source), required with in_split.
+  int in_split, out_split;
+  const void* zeros;
   float* out_nchw;
   int nchw_split;
   size_t nchw_group_stride;
