@@ -236,7 +236,7 @@ __device__ unsigned long long g_conv_cycles[8];
 #define DFN_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 
 DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
-  const uint32_t off = (uint32_t)(size_t)DFN_LDS_PTR(lds_dst);
+  const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)DFN_LDS_PTR(lds_dst));   // wave-uniform by construction
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(off) : "memory");
 }
 
@@ -652,7 +652,7 @@ constexpr int x3s_patch_bytes() {
   return ((2 * 2 * (2 * WAVES * (32 / TW) + KS - 1) * (TW + KS - 1) * 16) + 1023) & ~1023;   // one half-block, whole 1 KB DMA pieces
 }
 
-template <int KS, int SB, int MB, int WAVES = 4, int TW = 32>
+template <int KS, int SB, int MB, int WAVES = 4, int TW = 32, bool SPREAD = true>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kernel(ConvArgs a) {
   constexpr int KCB = SB / 8;
   constexpr int RF = 32 / TW;
@@ -714,46 +714,61 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
                  : static_cast<const char*>(a.zeros);
     inside |= unsigned(ok) << i;
   }
-  auto issue_patch = [&](int hb, int buf) {
-    hb = min(hb, NHB - 1);
-    const size_t off = (size_t)hb * 4 * a.W * 16;              // the half-block's four sub-planes of the row
-    char* dst = patch + buf * PBUF;
-#pragma unroll
-    for (int i = 0; i < PPP; ++i)
-      conv_lds_dma_b128(psrc[i] + (((inside >> i) & 1) ? off : (size_t)0), dst + min(wave + i * WAVES, PPIECES - 1) * 1024);
+  // DMA pieces are issued ONE AT A TIME between the MFMA groups of an iteration (an LDS-DMA instruction costs the issuing wave
+  // 60+ cycles, 100-185 in a burst next to the fragment reads: MI355X_MICROARCH.md).  Iteration (hb, ky) issues, in this order, the
+  // PPW pieces of sub-slice s + 1 and then up to PPI pieces of half-block hb + 1's planes.
+  constexpr int PPI = (PPP + KS - 1) / KS;                   // patch pieces per iteration
+  constexpr int GAPS = KS * MB;                              // MFMA groups of an iteration
+  static_assert(PPI <= 4, "vmcnt cases below");
+  auto patch_piece = [&](int hbn, int i) {                   // piece i (compile-time after unrolling) of half-block hbn's planes
+    const size_t off = (size_t)min(hbn, NHB - 1) * 4 * a.W * 16;   // the half-block's four sub-planes of the row
+    conv_lds_dma_b128(psrc[i] + (((inside >> i) & 1) ? off : (size_t)0), patch + (hbn & 1) * PBUF + min(wave + i * WAVES, PPIECES - 1) * 1024);
   };
-  auto issue_slice = [&](int sl, int buf) {
+  auto slice_piece = [&](int sl, int i) {
+    const int buf = sl & 1;
     sl = min(sl, n_slices - 1);
     const int hb = sl / KS, ky = sl - hb * KS;
     const int packed = ((hb / KCB) * KS + ky) * KCB + (hb % KCB);
-    const char* wsrc = a.w + ((size_t)cg * n_slices + packed) * WSL + lane * 16;
-    char* dst = wst + buf * WSL;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int q = min(wave + i * WAVES, NP - 1) * 1024;
-      conv_lds_dma_b128(wsrc + q, dst + q);
-    }
+    const int q = min(wave + i * WAVES, NP - 1) * 1024;
+    conv_lds_dma_b128(a.w + ((size_t)cg * n_slices + packed) * WSL + lane * 16 + q, wst + buf * WSL + q);
   };
   const float out_scale = a.out_scale;
   CONV_T_DECL;
-  issue_patch(0, 0);
-  issue_slice(0, 0);
+#pragma unroll
+  for (int i = 0; i < PPP; ++i) patch_piece(0, i);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) slice_piece(0, i);
   int sl = 0;
   for (int hb = 0; hb < NHB; ++hb) {
     const char* pb = patch + (hb & 1) * PBUF;
-#pragma unroll 1
+#pragma unroll
     for (int ky = 0; ky < KS; ++ky, ++sl) {
-      // issue order: ... slice s, [iteration s:] slice s+1, patch(hb+1) (first iteration of a half-block only), [s+1:] slice s+2 ...
+      // the previous iteration issued [sub-slice s][its share of the next planes]: sub-slice s is home once only that share is out;
+      // the half-block's first iteration needs the planes too
+      const int prev_patch = ky == 0 ? 0 : (min(ky * PPI, PPP) - min((ky - 1) * PPI, PPP));
       CONV_T(3);
-      if (ky == 1) DFN_VMCNT(PPP);         // sub-slice s landed; the next half-block's planes may still be in flight
-      else DFN_VMCNT(0);                   // (ky == 0: the planes of THIS half-block, issued a half-block ago, must be home)
+      if (prev_patch == 1) DFN_VMCNT(1);
+      else if (prev_patch == 2) DFN_VMCNT(2);
+      else if (prev_patch == 3) DFN_VMCNT(3);
+      else if (prev_patch == 4) DFN_VMCNT(4);
+      else DFN_VMCNT(0);
       asm volatile("" ::: "memory");
       CONV_T(0);
       __syncthreads();                     // sub-slice s and the planes visible; sub-slice s-1 (and at ky == 0 the other planes) consumed
       CONV_T(1);
-      issue_slice(sl + 1, (sl + 1) & 1);
-      if (ky == 0) issue_patch(hb + 1, (hb + 1) & 1);
       const char* wb = wst + (sl & 1) * WSL;
+      const int p_lo = min(ky * PPI, PPP), p_n = min((ky + 1) * PPI, PPP) - p_lo;   // this iteration's share of the next planes
+      auto issue = [&](int n) {            // n-th DMA piece of this iteration
+        if (n < PPW) slice_piece(sl + 1, n);
+        else if (n - PPW < p_n) {
+#pragma unroll
+          for (int i = 0; i < PPP; ++i) if (i == p_lo + n - PPW) patch_piece(hb + 1, i);
+        }
+      };
+      if (!SPREAD) {                       // all of the iteration's pieces up front (the 8-wave 5x5 tile measured better this way)
+#pragma unroll
+        for (int n = 0; n < PPW + PPI; ++n) issue(n);
+      }
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
         half8 bh[2], bl[2];
@@ -773,6 +788,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], acc[mb][nb], 0, 0, 0);
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], acc[mb][nb], 0, 0, 0);
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], acc[mb][nb], 0, 0, 0);
+          }
+          const int g = kx * MB + mb;      // after this MFMA group: its DMA piece (the last group takes what is left)
+          if (SPREAD) issue(g);
+          if (SPREAD && g == GAPS - 1) {
+#pragma unroll
+            for (int n = GAPS; n < PPW + PPI; ++n) issue(n);
           }
         }
       }
@@ -827,14 +848,14 @@ static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int KS, int SB, int MB, int WAVES = 4, int TW = 32>
+template <int KS, int SB, int MB, int WAVES = 4, int TW = 32, bool SPREAD = true>
 static hipError_t launch_conv_x3s_t(const ConvArgs& a, hipStream_t stream) {
   if (a.cout_blocks % MB || !a.zeros || a.dyn_scale) return hipErrorInvalidValue;
   constexpr int TH = 2 * WAVES * (32 / TW);
   constexpr int lds = 2 * x3s_patch_bytes<KS, SB, WAVES, TW>() + 2 * x3_wslice_bytes<KS, SB, MB>();
   static_assert(lds <= (WAVES == 4 ? 80 : 160) * 1024, "x3s conv tile does not fit in LDS (4-wave tiles: two workgroups per CU)");
   static_assert(lds >= WAVES * 32 * (MB * 128 + 16), "epilogue turn buffers");
-  auto kern = conv_x3s_kernel<KS, SB, MB, WAVES, TW>;
+  auto kern = conv_x3s_kernel<KS, SB, MB, WAVES, TW, SPREAD>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -935,8 +956,16 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
     if (sb == 8 && ks == 3) return launch_conv_x3s_t<3, 8, 2>(a, stream);
     if (sb != 16) return hipErrorInvalidValue;
     if (ks == 1) return launch_conv_x3s_t<1, 16, 2>(a, stream);
-    if (ks == 3) return padded(16, 16) < 0.97 * padded(8, 32) ? launch_conv_x3s_t<3, 16, 2, 4, 16>(a, stream) : launch_conv_x3s_t<3, 16, 2>(a, stream);
-    if (ks == 5) return launch_conv_x3s_t<5, 16, 2, 8>(a, stream);
+    if (ks == 3) {
+      static const int spread3 = [] { const char* e = getenv("DFN_X3S_SPREAD3"); return e ? atoi(e) : 1; }();  // tuning aid
+      const bool sq = padded(16, 16) < 0.97 * padded(8, 32);
+      if (!spread3) return sq ? launch_conv_x3s_t<3, 16, 2, 4, 16, false>(a, stream) : launch_conv_x3s_t<3, 16, 2, 4, 32, false>(a, stream);
+      return sq ? launch_conv_x3s_t<3, 16, 2, 4, 16>(a, stream) : launch_conv_x3s_t<3, 16, 2>(a, stream);
+    }
+    if (ks == 5) {
+      static const int spread5 = [] { const char* e = getenv("DFN_X3S_SPREAD5"); return e ? atoi(e) : 0; }();  // tuning aid
+      return spread5 ? launch_conv_x3s_t<5, 16, 2, 8, 32, true>(a, stream) : launch_conv_x3s_t<5, 16, 2, 8, 32, false>(a, stream);
+    }
   } else if (prec == 2) {
     // 3x3 / 1x1: 8 x 32-pixel tiles, two workgroups per CU (80 KB of LDS each: planes + a ring of three sub-slices).
     static const int ring = [] { const char* e = getenv("DFN_X3_RING"); return e ? atoi(e) : 2; }();  // tuning aid (3: ring of three sub-slices — measured equal)
@@ -1112,8 +1141,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ in,
 // 32-channel block.  The two source rows are staged once in LDS, channel-major; every wave then writes whole channel rows as 16-byte
 // stores aligned in memory (1 KB contiguous per instruction; the unaligned head / tail of a row as scalars) — the kernel above
 // writes 256-byte runs interleaved with its gathers and reaches half of this one's write rate.  Same arithmetic, same result.
-constexpr int kUpRowMax = 496;   // 2 x 16 x (w + 1) floats stay under the 64 KB a kernel gets without opting in
-// CPB = channels (stored positions) per workgroup: 32, or 16 for the longer source rows so that the staged rows stay small
+constexpr int kUpRowMax = 992;   // 2 x 8 x (w + 1) floats stay under the 64 KB a kernel gets without opting in
+// CPB = channels (stored positions) per workgroup: 32, or 16 / 8 for the longer source rows so that the staged rows stay small
 // enough for eight workgroups per CU (the stores need the waves: 3 resident workgroups wrote at 3 TB/s, 8 at 5).
 template <class T, int CPB>
 __global__ __launch_bounds__(256) void upsample_rows_kernel(const T* __restrict__ in, int h, int w, int UH, int UW, float* __restrict__ out,
@@ -1190,18 +1219,17 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(const T* __restrict_
 hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH, int UW, float* out,
                            size_t out_bstride, hipStream_t stream, const float* affine) {
   if (w <= kUpRowMax && B > 0 && UH > 0 && UW > 0) {
-    const bool narrow = w > 64;            // 16 channels per workgroup: <= 20 KB of rows
-    const size_t lds = size_t(2) * (narrow ? 16 : 32) * (w + 1) * 4;
-    const dim3 grid(UH, narrow ? 8 : 4, B);
+    // channels per workgroup by the source row length: the staged rows stay <= ~20 KB, eight workgroups per CU
+    const int cpb = w > 240 ? 8 : (w > 64 ? 16 : 32);
+    const size_t lds = size_t(2) * cpb * (w + 1) * 4;
+    const dim3 grid(UH, 128 / cpb, B);
+#define DFN_UP_LAUNCH(T, C) hipLaunchKernelGGL((upsample_rows_kernel<T, C>), grid, dim3(256), lds, stream, static_cast<const T*>(in), h, w, UH, UW, out, out_bstride, affine)
     if (prec == 0) {
-      const _Float16* src = static_cast<const _Float16*>(in);
-      if (narrow) hipLaunchKernelGGL((upsample_rows_kernel<_Float16, 16>), grid, dim3(256), lds, stream, src, h, w, UH, UW, out, out_bstride, affine);
-      else hipLaunchKernelGGL((upsample_rows_kernel<_Float16, 32>), grid, dim3(256), lds, stream, src, h, w, UH, UW, out, out_bstride, affine);
+      if (cpb == 8) DFN_UP_LAUNCH(_Float16, 8); else if (cpb == 16) DFN_UP_LAUNCH(_Float16, 16); else DFN_UP_LAUNCH(_Float16, 32);
     } else {
-      const float* src = static_cast<const float*>(in);
-      if (narrow) hipLaunchKernelGGL((upsample_rows_kernel<float, 16>), grid, dim3(256), lds, stream, src, h, w, UH, UW, out, out_bstride, affine);
-      else hipLaunchKernelGGL((upsample_rows_kernel<float, 32>), grid, dim3(256), lds, stream, src, h, w, UH, UW, out, out_bstride, affine);
+      if (cpb == 8) DFN_UP_LAUNCH(float, 8); else if (cpb == 16) DFN_UP_LAUNCH(float, 16); else DFN_UP_LAUNCH(float, 32);
     }
+#undef DFN_UP_LAUNCH
     return hipGetLastError();
   }
   const size_t n = (size_t)B * 4 * UH * UW;
