@@ -251,6 +251,17 @@ def secondary_dfnet(dev):
         out["precisions"][prec] = {"ms_per_image": dt * 1e3, "algorithmic_TFLOPs": 325.3e9 / dt / 1e12,
                                    "mfma_frac": 325.3e9 * mf / dt / 1e12 / (157.3 if prec == "f32" else 2500.0),
                                    "arithmetic": PREC_TEXT[prec]}
+    # the reference's config names "featurenet_batch_size=4 # batch size, 4 or 8" (config_dfnet.txt:17): the other one, default precision
+    x8 = torch.rand(8, 3, 480, 640, generator=torch.Generator().manual_seed(3)).to(dev)
+    E.forward(x8, True, True, False, 480, 640, precision="f16x3")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        E.forward(x8, True, True, False, 480, 640, precision="f16x3")
+    torch.cuda.synchronize()
+    dt8 = (time.perf_counter() - t0) / 5 / 8
+    out["batch_8_f16x3"] = {"ms_per_image": dt8 * 1e3, "mfma_frac": 325.3e9 * 3 / dt8 / 1e12 / 2500.0}
+    del x8
     # parity: one 480x640 frame vs the CPU oracle, relative L2 per pyramid level
     x1 = torch.rand(1, 3, 480, 640, generator=torch.Generator().manual_seed(7))
     with torch.no_grad():
