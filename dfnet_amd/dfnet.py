@@ -112,7 +112,7 @@ class _TrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, bn_batch, return_pose, single, upH, upW, *params):
         x = x.detach()
-        E = module.engine(train=True)
+        E = module.engine(train=True, running_stats=not bn_batch)
         # with a graph being recorded the forward keeps its activations (the "tape") and the backward recomputes nothing
         keep = any(ctx.needs_input_grad)
         out = E.forward_train(x, True, return_pose, bn_batch, upH, upW, keep=keep)
@@ -132,7 +132,7 @@ class _TrainFn(torch.autograd.Function):
     def backward(ctx, g_a, g_b, g_pose):
         (x,) = ctx.saved_tensors
         m, bn_batch, single = ctx.cfg
-        E = m.engine(train=True)
+        E = m.engine(train=True, running_stats=not bn_batch)
         if single or (g_a is None and g_b is None):
             g_feats = g_a
         else:
@@ -182,6 +182,7 @@ class _DFNetBase(nn.Module):
         self._engine = None
         self._engine_version = None
         self._folded_stale = False
+        self._bn_stats_stale = False   # the engine's copy of the BatchNorm running statistics lags the module's (see _update_running_stats)
 
     def _pose_param_names(self):
         names = []
@@ -213,6 +214,7 @@ class _DFNetBase(nn.Module):
             self._engine = DfnetEngine(len(self.tap_channels), self.feat_dim, self.precision)
         self._engine.load_numpy({k: v.detach().cpu().numpy() for k, v in self.state_dict().items()})
         self._folded_stale = False
+        self._bn_stats_stale = False
 
     def recommit(self):
         """Re-pack every fragment from the host, re-deriving the split-f16 power-of-two weight scales.  The device re-packs of a
@@ -222,8 +224,9 @@ class _DFNetBase(nn.Module):
             self._commit_from_host()
             self._engine_version = self._version()
 
-    def engine(self, train=False):
+    def engine(self, train=False, running_stats=False):
         """The HIP engine holding the current weights, re-packed whenever a tensor of the module changed.
+        running_stats=True (a train-mode forward with FROZEN BatchNorm): the engine's copy of the running statistics must be current too.
         train=True (the training forward / backward and the pose path, none of which read BatchNorm-folded weights): on
         the device.  Otherwise
         (inference: BatchNorm folded into the 5x5 convs): on the device when only the pose path's parameters moved
@@ -232,13 +235,14 @@ class _DFNetBase(nn.Module):
         ver = self._version()
         if self._engine is None:
             self._commit_from_host()
-        elif ver != self._engine_version:
+        elif ver != self._engine_version or (train and running_stats and self._bn_stats_stale):
             changed = {k for k in ver if ver[k] != self._engine_version.get(k)}
             sd = dict(list(self.named_parameters()) + list(self.named_buffers()))
             pose_names, names = self._pose_param_names(), self._refresh_names()
             on_gpu = all(sd[k].is_cuda for k in names)
             if train and on_gpu and all(k in names or k.endswith("num_batches_tracked") for k in changed):
                 self._engine.refresh_train_params_device([sd[k].detach() for k in names])
+                self._bn_stats_stale = False
                 self._folded_stale = self._folded_stale or not changed <= set(pose_names)   # folded: adaptation layers only
             elif not train and not self._folded_stale and on_gpu and changed <= set(pose_names):
                 self._engine.refresh_pose_params_device([sd[k].detach() for k in pose_names])
@@ -261,6 +265,15 @@ class _DFNetBase(nn.Module):
                 bn.running_mean.mul_(1 - mom).add_(stats[t, 0].to(bn.running_mean.device), alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(stats[t, 1].to(bn.running_var.device), alpha=mom * n / max(n - 1, 1))
                 bn.num_batches_tracked += 1
+                if self._engine_version is not None:
+                    # Only a frozen-BatchNorm forward and the folded inference weights read the engine's copy of these buffers: mark it
+                    # stale instead of letting the version bump re-pack all 52 tensors before the step's next kernel call.
+                    pre = "adaptation_layers.adapt_layer_{}.3.".format(t)
+                    for name, buf in (("running_mean", bn.running_mean), ("running_var", bn.running_var),
+                                      ("num_batches_tracked", bn.num_batches_tracked)):
+                        self._engine_version[pre + name] = (buf.data_ptr(), buf._version)
+            self._bn_stats_stale = True
+            self._folded_stale = True
 
     def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427):
         """Same contract as dfnet.py:109-172: returns (feature_maps, predict) with feature_maps None,

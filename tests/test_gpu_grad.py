@@ -528,6 +528,36 @@ def test_dfnet_module_training_step_vs_reference_golden(mode):
         ref3, rp3 = dor.dfnet_forward(p2, x.cpu(), True, True, True, 24, 40)
         assert rel_l2(f3[0], ref3[0]) < 5e-6 and relmax(pose3, rp3) < 1e-5
 
+@pytest.mark.gpu
+def test_running_statistics_do_not_repack_the_engine():
+    """A train()-mode forward moves the BatchNorm running statistics.  Nothing in a batch-statistics step reads the engine's copy
+    of them, so that must not trigger the 52-tensor device re-pack before the step's next kernel call; a frozen-BatchNorm forward
+    afterwards does read them and must see the moved values (oracle on the module's current buffers)."""
+    from dfnet_amd.dfnet import DFNet
+    from dfnet_amd.feature_misc import freeze_bn_layer_train
+    from oracle import dfnet_oracle as dor
+    m = DFNet()
+    m.load_state_dict({k: T(v) for k, v in syn.dfnet_weights(seed=3).items()}, strict=False)
+    m.to(DEV).train()
+    x = torch.rand(2, 3, 32, 48, generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def step():
+        feats, pose = m(x, return_feature=True, isSingleStream=True, return_pose=True, upsampleH=24, upsampleW=40)
+        (feats[0].square().mean() + pose.square().mean()).backward()
+
+    step()                                             # commits the engine, moves the running statistics
+    calls = []
+    orig = m._engine.refresh_train_params_device
+    m._engine.refresh_train_params_device = lambda ts, *a, **k: (calls.append(1), orig(ts, *a, **k))[1]
+    step()                                             # no parameter changed: forward and backward re-pack nothing
+    assert calls == []
+    m = freeze_bn_layer_train(m)                       # BatchNorm layers to eval(): the next forward normalises with the running statistics
+    feats, _ = m(x, return_feature=True, isSingleStream=True, return_pose=True, upsampleH=24, upsampleW=40)
+    assert calls == [1]
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "num_batches" not in k}
+    ref, _ = dor.dfnet_forward(sd, x.cpu(), True, True, False, 24, 40)
+    assert rel_l2(feats[0], ref[0]) < 5e-6
+
 
 def test_dfnet_s_module_training_step_vs_oracle():
     """DFNet_s (one pyramid level, dfnet.py:174-207) through the same training path: train()-mode forward and every
