@@ -917,7 +917,6 @@ hipError_t launch_absmax_scale(const float* x, size_t n, float* part, float* out
   return hipGetLastError();
 }
 
-constexpr double kMb1Cost = 0.6;   // duration of a 32-channel workgroup relative to a 64-channel one (measured)
 #ifdef DFN_TIMING
 }  // namespace dfn
 // timing build only: resident workgroups per CU of the main split-f16 conv variants (runtime's answer for their LDS / registers)
@@ -979,13 +978,10 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
       auto padded = [&](int th, int tw) { return double((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw); };
       static const int tw_force = [] { const char* e = getenv("DFN_X3_TW"); return e ? atoi(e) : 0; }();  // tuning aid (32 / 16)
       const bool sq = tw_force ? tw_force == 16 : padded(16, 16) < 0.97 * padded(8, 32);
-      // 32-channel workgroups (three per CU) when the 64-channel ones would fill the 512 slots of the chip badly
-      static const int mb1_force = [] { const char* e = getenv("DFN_X3_MB1"); return e ? atoi(e) : -1; }();  // tuning aid (0 / 1)
-      auto rounds = [](double wgs, double slots) { return double((long long)((wgs + slots - 1) / slots)); };
-      const double wg64 = double((a.H + 15) / 16) * ((a.W + 15) / 16) * (a.cout_blocks / 2) * a.B;
-      const double wg64r = double((a.H + 7) / 8) * ((a.W + 31) / 32) * (a.cout_blocks / 2) * a.B;
-      const bool mb1 = mb1_force >= 0 ? mb1_force == 1
-                                      : rounds(2 * wg64, 768) * kMb1Cost < rounds(sq ? wg64 : wg64r, 512);
+      // 32-channel workgroups, three per CU (twice the workgroups for the layers that fill the chip's 512 slots badly): measured
+      // 10 % SLOWER on every layer of the 4 x 480x640 forward, so only on request
+      static const int mb1_force = [] { const char* e = getenv("DFN_X3_MB1"); return e ? atoi(e) : 0; }();  // tuning aid
+      const bool mb1 = mb1_force == 1;
       if (mb1) return launch_conv_x3_t<3, 16, 1, 2, 4, 16>(a, stream);
       if (sq) return launch_conv_x3_t<3, 16, 2, 2, 4, 16>(a, stream);
       return ring == 3 ? launch_conv_x3_t<3, 16, 2, 3>(a, stream) : launch_conv_x3_t<3, 16, 2, 2>(a, stream);

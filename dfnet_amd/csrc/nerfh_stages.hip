@@ -347,11 +347,17 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
   float* s_cdf = s_mid + Nc;                // [Nc]
   float* s_all = s_cdf + Nc;                // [NfP]  cat([z, z_samples]), 16-byte aligned
   float* s_out = s_all + NfP;               // [Nf]
-  for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < n_rays; ray += size_t(gridDim.x) * 4) {
+  const size_t ray0 = size_t(blockIdx.x) * 4 + wave, stride = size_t(gridDim.x) * 4;
+  // the next ray's first 64 densities are fetched while this ray is processed (a ray is ~50 dependent LDS round trips: the load
+  // latency at its head was a tenth of it)
+  float sig_next = (ray0 < n_rays && lane < Nc) ? sigma[ray0 * Nc + lane] : 0.f;
+  for (size_t ray = ray0; ray < n_rays; ray += stride) {
+    if (lane < Nc) s_sig[lane] = sig_next;
     for (int i = lane; i < Nc; i += 64) {
-      s_sig[i] = sigma[ray * Nc + i];
+      if (i >= 64) s_sig[i] = sigma[ray * Nc + i];
       s_all[i] = coarse_z_at(i, Nc, near, far);
     }
+    if (ray + stride < n_rays && lane < Nc) sig_next = sigma[(ray + stride) * Nc + lane];
     for (int i = Nf + lane; i < NfP; i += 64) s_all[i] = __builtin_inff();
     wave_sync();
     ray_coarse_weights(s_sig, s_all, Nc, s_w, lane);
@@ -366,7 +372,9 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     // passes (repeated until a full pass swaps nothing = sorted) fix them, then the two sorted lists
     // are merged by rank: rank(z_i) = i + #{samples < z_i}, rank(s_j) = j + #{z <= s_j}.
     float* zs = s_all + Nc;
-    for (int guard = 0; guard < Ni; ++guard) {
+    bool unsorted = false;                             // the usual case needs no pass at all: one look at every neighbour pair
+    for (int k = lane; k + 1 < Ni; k += 64) unsorted |= zs[k] > zs[k + 1];
+    for (int guard = 0; __any(unsorted) && guard < Ni; ++guard) {
       bool swapped = false;
       for (int phase = 0; phase < 2; ++phase) {
         for (int k = 2 * lane + phase; k + 1 < Ni; k += 128) {
@@ -377,19 +385,37 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
       }
       if (!__any(swapped)) break;
     }
-    for (int i = lane; i < Nf; i += 64) {
-      const float v = s_all[i];
-      int lo = 0, hi, rank;
-      if (i < Nc) {  // lower bound in the samples
-        hi = Ni;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zs[mid] < v) lo = mid + 1; else hi = mid; }
-        rank = i + lo;
-      } else {       // upper bound in the coarse depths
-        hi = Nc;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_all[mid] <= v) lo = mid + 1; else hi = mid; }
-        rank = (i - Nc) + lo;
+    // Ranks without searching.  The coarse depths are a uniform grid: cnt_j = #{i : z_i <= s_j} is the sample's grid cell (computed,
+    // then made exact against the stored depths), rank(s_j) = j + cnt_j.  A coarse depth is preceded by the samples below it:
+    // s_j < z_i  <=>  cnt_j <= i, so rank(z_i) = i + (inclusive prefix over c <= i of the histogram of cnt), one wave scan.
+    int* hist = reinterpret_cast<int*>(s_sig);       // [Nc + 1] over s_sig | s_w (both dead: the weights were written above)
+    for (int i = lane; i <= Nc; i += 64) hist[i] = 0;
+    wave_sync();
+    const float cell = float(Nc - 1) / (far - near);
+    for (int j = lane; j < Ni; j += 64) {
+      const float v = zs[j];
+      int c = int(floorf((v - near) * cell)) + 1;
+      c = c < 0 ? 0 : (c > Nc ? Nc : c);
+#pragma unroll
+      for (int fix = 0; fix < 2; ++fix) {
+        if (c < Nc && s_all[c] <= v) ++c;
+        if (c > 0 && s_all[c - 1] > v) --c;
       }
-      s_out[rank] = v;
+      s_out[j + c] = v;
+      atomicAdd(&hist[c], 1);
+    }
+    wave_sync();
+    int before = 0;                                   // samples below the chunk's first coarse depth
+    for (int c0 = 0; c0 < Nc; c0 += 64) {
+      const int i = c0 + lane;
+      int incl = i < Nc ? hist[i] : 0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+      }
+      if (i < Nc) s_out[i + before + incl] = s_all[i];
+      before += __shfl(incl, 63, 64);
     }
     wave_sync();
     for (int i = lane; i < Nf; i += 64) z_fine[ray * Nf + i] = s_out[i];
