@@ -400,6 +400,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   int tap_h[3] = {0, 0, 0}, tap_w[3] = {0, 0, 0};
   const void* last_act = nullptr;
   int last_h = 0, last_w = 0;
+  int fused_1x1 = -1;                 // tap whose 1x1 adaptation conv ran inside its encoder conv (its output sits in w.tmp64)
   for (size_t i = 0; i < h->enc.size(); ++i) {
     const ConvSpec& sp = h->enc[i];
     const bool is_last_tap = sp.tap == h->n_taps - 1;
@@ -421,6 +422,14 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
       const bool last = i + 1 == h->enc.size();          // relu5_3: read by the pose head as fp32
       a.in_split = 1; a.zeros = zeros;
       a.out_split = (last ? 0 : 1) | 2 | 4;
+      // a 64-channel tap is one workgroup's channels: its adaptation layer's 1x1 conv + ReLU runs in this conv's epilogue and the
+      // tap itself is never stored (level 0: 315 MB written and read back per 4 frames of 480x640, plus the 1x1 kernel)
+      if (a.out_pre && sp.cout == 64 && h->tap_channels[sp.tap] == 64 && bn_mode == 0) {
+        const PackedConv& p1 = h->ad1[sp.tap];
+        a.fuse_w = p1.w[2]; a.fuse_bias = p1.bias_x3; a.fuse_scale = p1.out_scale; a.fuse_out = w.tmp64;
+        a.out_pre = nullptr;
+        fused_1x1 = sp.tap;
+      }
     }
     if (a.out_act || a.out_pre || a.out_pool)
       CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet: encoder conv");
@@ -447,7 +456,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
       a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale; a.out_act = w.tmp64; a.out_pre = nullptr;
       a.B = B; a.H = tap_h[t]; a.W = tap_w[t]; a.nblk_in = h->tap_channels[t] / 32; a.cout_blocks = 2; a.relu = 1;
       if (split) { a.in_split = 1; a.out_split = 1; a.zeros = zeros; }
-      CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet: adapt 1x1");
+      if (t != fused_1x1) CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet: adapt 1x1");
       ConvArgs c{};
       const PackedConv& p5 = bn_mode ? h->ad5_raw[t] : h->ad5[t];
       c.in = w.tmp64; c.w = p5.w[prec]; c.bias = prec == 2 ? p5.bias_x3 : p5.bias; c.out_scale = p5.out_scale; c.out_act = w.ad128; c.out_pre = nullptr;

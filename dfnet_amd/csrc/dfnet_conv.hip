@@ -301,6 +301,57 @@ DFN_DEV_INLINE void x3_epilogue(const ConvArgs& a, const f32x16 (&acc)[MB][2], f
   // through LDS — the staging buffers are dead by now — and stores whole lines, eight lanes per line.
   constexpr int ROWB = MB * 128 + 16;                 // padded bytes per pixel in the turn buffer
   if (a.out_nchw) store_nchw<MB, float, RF>(a, acc, out_scale, b, cg, y0 + 2 * wave * RF + pr, x0 + pc, h);
+  if constexpr (MB == 2) {
+    if (a.fuse_out) {
+      // Fused 1x1 (64 -> 64) + ReLU: the C fragments of the two M-blocks ARE the B operand of the next product (lane (pixel, half)
+      // holds slots 8 kc .. 8 kc + 7 of block mb in acc[mb][nb][8 kc ..]), split exactly as the stored tap would have been.
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        half8 bh[2][2], bl[2][2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float xs = (acc[blk][nb][8 * kc + k] * out_scale) * kConvActScale;
+              const _Float16 hi = (_Float16)fminf(fmaxf(xs, -65000.f), 65000.f);
+              bh[blk][kc][k] = hi;
+              bl[blk][kc][k] = (_Float16)fminf(fmaxf(xs - (float)hi, -65000.f), 65000.f);
+            }
+        f32x16 acc2[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const f32x4* bq = reinterpret_cast<const f32x4*>(a.fuse_bias + (mb * 2 + h) * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = bq[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc2[mb][4 * q + i] = v[i];
+          }
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc) {
+            const char* sl = a.fuse_w + (blk * 2 + kc) * 4096 + lane * 16;    // sub-slice (block, K-chunk): [hi: mb 0, 1][lo: mb 0, 1]
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+              const half8 ah = *reinterpret_cast<const half8*>(sl + mb * 1024);
+              const half8 al = *reinterpret_cast<const half8*>(sl + 2048 + mb * 1024);
+              acc2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[blk][kc], acc2[mb], 0, 0, 0);
+              acc2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[blk][kc], acc2[mb], 0, 0, 0);
+              acc2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[blk][kc], acc2[mb], 0, 0, 0);
+            }
+          }
+        const int y = y0 + (2 * wave + nb) * RF + pr, x = x0 + pc;
+        if (y < a.H && x < a.W) {
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) store_split_frag(a.fuse_out, a.H, a.W, 2, b, y, x, mb, h, acc2[mb], a.fuse_scale, true);
+        }
+      }
+    }
+  }
   // split outputs go straight from the accumulators (512-byte runs per half-wave); fp32 outputs take the turn below
   void* act32 = (a.out_split & 1) ? nullptr : a.out_act;
   void* pre32 = (a.out_split & 2) ? nullptr : a.out_pre;

@@ -43,6 +43,13 @@ struct ConvArgs {
   // pixels' DMA source), required with in_split.
   int in_split, out_split;
   const void* zeros;
+  // Optional fused 1x1 convolution + ReLU on this conv's PRE-ReLU output (the level-0 adaptation layer's first conv on the conv1_2
+  // tap; needs Cout = 64 = one workgroup's channels, split-f16): fuse_w / fuse_bias / fuse_scale = the 1x1's packed fragments,
+  // pre-scaled bias and out_scale; fuse_out [B,H,W,64] in the split storage.  Same operands, same order, same bits as the two-kernel form.
+  const char* fuse_w;
+  const float* fuse_bias;
+  float fuse_scale;
+  void* fuse_out;
   float* out_nchw;
   int nchw_split;
   size_t nchw_group_stride;
