@@ -1188,30 +1188,32 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ in,
 // 32-channel block.  The two source rows are staged once in LDS, channel-major; every wave then writes whole channel rows as 16-byte
 // stores aligned in memory (1 KB contiguous per instruction; the unaligned head / tail of a row as scalars) — the kernel above
 // writes 256-byte runs interleaved with its gathers and reaches half of this one's write rate.  Same arithmetic, same result.
-constexpr int kUpRowMax = 992;   // 2 x 8 x (w + 1) floats stay under the 64 KB a kernel gets without opting in
+constexpr int kUpRowMax = 640;   // 3 x 8 x (w + 1) floats stay under the 64 KB a kernel gets without opting in
 // CPB = channels (stored positions) per workgroup: 32, or 16 / 8 for the longer source rows so that the staged rows stay small
 // enough for eight workgroups per CU (the stores need the waves: 3 resident workgroups wrote at 3 TB/s, 8 at 5).
-template <class T, int CPB>
+// RY = output rows per workgroup: 4 when the resize enlarges at least ~3x vertically — four consecutive output rows then read at most
+// kUpRows = 3 source rows, staged once (0.75 instead of 2 staged rows per output row) — else 1.
+constexpr int kUpRows = 3;
+template <class T, int CPB, int RY>
 __global__ __launch_bounds__(256) void upsample_rows_kernel(const T* __restrict__ in, int h, int w, int UH, int UW, float* __restrict__ out,
                                                             size_t out_bstride, const float* __restrict__ affine) {
-  extern __shared__ float rows[];          // [2][CPB][w + 1]
+  extern __shared__ float rows[];          // [NR][CPB][w + 1], NR = 2 (RY = 1) or kUpRows
   const int ws = w + 1;
-  const int Y = blockIdx.x, blk = blockIdx.y / (32 / CPB), e0 = (blockIdx.y % (32 / CPB)) * CPB;   // stored positions e0 .. e0 + CPB
+  const int Y0 = blockIdx.x * RY, blk = blockIdx.y / (32 / CPB), e0 = (blockIdx.y % (32 / CPB)) * CPB;   // stored positions e0 .. e0 + CPB
   const size_t b = blockIdx.z;
   const float sy = UH > 1 ? float(h - 1) / float(UH - 1) : 0.f;
   const float sx = UW > 1 ? float(w - 1) / float(UW - 1) : 0.f;
-  const float fy = sy * float(Y);
-  const int yA = int(fy), yB = yA + (yA < h - 1 ? 1 : 0);
-  const float ly = fy - float(yA), wy0 = 1.f - ly;
+  const int y_first = int(sy * float(Y0));                   // first staged source row
+  constexpr int NR = RY == 1 ? 2 : kUpRows;
   constexpr int V = 16 / int(sizeof(T));   // elements per 16-byte vector
-  for (int e = threadIdx.x; e < 2 * w * (CPB / V); e += 256) {
+  for (int e = threadIdx.x; e < NR * w * (CPB / V); e += 256) {
     const int r = e / (w * (CPB / V)), rem = e - r * (w * (CPB / V)), px = rem / (CPB / V), q = rem - px * (CPB / V);
     alignas(16) T v[V];
-    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(in + ((b * h + (r ? yB : yA)) * (size_t)w + px) * 128 + blk * 32 + e0 + q * V);
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(in + ((b * h + min(y_first + r, h - 1)) * (size_t)w + px) * 128 + blk * 32 + e0 + q * V);
 #pragma unroll
     for (int k = 0; k < V; ++k) rows[(r * CPB + q * V + k) * ws + px] = (float)v[k];
   }
-  if (threadIdx.x < 2 * CPB) rows[threadIdx.x * ws + w] = 0.f;
+  if (threadIdx.x < NR * CPB) rows[threadIdx.x * ws + w] = 0.f;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // The lane's columns X = head + 4 * lane + 256 * it + k and their horizontal taps are the same for every channel whose row
@@ -1225,10 +1227,15 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(const T* __restrict_
     xA = int(fx);
     lx = fx - float(xA);
   };
-  for (int el = wave; el < CPB; el += 4) { // stored position e of the block -> channel
+  for (int job = wave; job < RY * CPB; job += 4) {   // (output row, stored position e of the block -> channel)
+    const int Y = Y0 + job / CPB, el = job % CPB;
+    if (Y >= UH) break;
+    const float fy = sy * float(Y);
+    const int yA = int(fy), yB = yA + (yA < h - 1 ? 1 : 0);
+    const float ly = fy - float(yA), wy0 = 1.f - ly;
     const int e = e0 + el, hh = e >> 4, s = e & 15, ch = blk * 32 + 4 * hh + (s & 3) + 8 * (s >> 2);
-    const float* rA = rows + el * ws;
-    const float* rB = rows + (CPB + el) * ws;
+    const float* rA = rows + ((yA - y_first) * CPB + el) * ws;
+    const float* rB = rows + ((yB - y_first) * CPB + el) * ws;
     const float sc = affine ? affine[kBnSc + blk * 32 + e] : 1.f, sh = affine ? affine[kBnSh + blk * 32 + e] : 0.f;
     float* o = out + b * out_bstride + ((size_t)ch * UH + Y) * UW;
     // column w of a staged row is zero: the right tap of the last source pixel has weight 0 and reads it
@@ -1266,16 +1273,20 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(const T* __restrict_
 hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH, int UW, float* out,
                            size_t out_bstride, hipStream_t stream, const float* affine) {
   if (w <= kUpRowMax && B > 0 && UH > 0 && UW > 0) {
-    // channels per workgroup by the source row length: the staged rows stay <= ~20 KB, eight workgroups per CU
-    const int cpb = w > 240 ? 8 : (w > 64 ? 16 : 32);
-    const size_t lds = size_t(2) * cpb * (w + 1) * 4;
-    const dim3 grid(UH, 128 / cpb, B);
-#define DFN_UP_LAUNCH(T, C) hipLaunchKernelGGL((upsample_rows_kernel<T, C>), grid, dim3(256), lds, stream, static_cast<const T*>(in), h, w, UH, UW, out, out_bstride, affine)
-    if (prec == 0) {
-      if (cpb == 8) DFN_UP_LAUNCH(_Float16, 8); else if (cpb == 16) DFN_UP_LAUNCH(_Float16, 16); else DFN_UP_LAUNCH(_Float16, 32);
-    } else {
-      if (cpb == 8) DFN_UP_LAUNCH(float, 8); else if (cpb == 16) DFN_UP_LAUNCH(float, 16); else DFN_UP_LAUNCH(float, 32);
-    }
+    // four output rows per workgroup when they share three source rows; channels per workgroup by the source row length so that the
+    // staged rows stay <= ~20 KB: eight workgroups per CU
+    const float sy = UH > 1 ? float(h - 1) / float(UH - 1) : 0.f;
+    const bool ry4 = 3.f * sy < 0.99f;     // int(sy (Y0 + 3)) - int(sy Y0) <= 1: rows y_first .. y_first + 2 cover the four
+    const int nr = ry4 ? kUpRows : 2;
+    const int cpb = nr * (w + 1) * 4 * 32 <= 20480 ? 32 : (nr * (w + 1) * 4 * 16 <= 20480 ? 16 : 8);
+    const size_t lds = size_t(nr) * cpb * (w + 1) * 4;
+    if (lds > 65536) return hipErrorInvalidValue;
+    const dim3 grid(ry4 ? (UH + 3) / 4 : UH, 128 / cpb, B);
+#define DFN_UP_LAUNCH(T, C, R) hipLaunchKernelGGL((upsample_rows_kernel<T, C, R>), grid, dim3(256), lds, stream, static_cast<const T*>(in), h, w, UH, UW, out, out_bstride, affine)
+#define DFN_UP_CPB(T, R) do { if (cpb == 8) DFN_UP_LAUNCH(T, 8, R); else if (cpb == 16) DFN_UP_LAUNCH(T, 16, R); else DFN_UP_LAUNCH(T, 32, R); } while (0)
+    if (prec == 0) { if (ry4) DFN_UP_CPB(_Float16, 4); else DFN_UP_CPB(_Float16, 1); }
+    else { if (ry4) DFN_UP_CPB(float, 4); else DFN_UP_CPB(float, 1); }
+#undef DFN_UP_CPB
 #undef DFN_UP_LAUNCH
     return hipGetLastError();
   }
