@@ -888,8 +888,7 @@ static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
   const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
   // weights of the layer in the packed split-f16 form: hi + lo f16 per element
   const size_t wbytes = size_t(a.cout_blocks) * 32 * a.nblk_in * 32 * KS * KS * 4;
-  static const int xcd_mode = [] { const char* e = getenv("DFN_X3_XCD"); return e ? atoi(e) : 1; }();  // tuning aid: 0 = plain 3-D grid
-  if (xcd_mode && (xcd_mode == 2 || wbytes > (3u << 20)) && a.cout_blocks / MB >= 8) {
+  if (wbytes > (3u << 20) && a.cout_blocks / MB >= 8) {
     ConvArgs ax = a;
     ax.xcd_groups = tiles * (a.cout_blocks / MB) * a.B;
     hipLaunchKernelGGL(kern, dim3((ax.xcd_groups + 7) / 8 * 8), dim3(WAVES * 64), lds, stream, ax);
@@ -1001,47 +1000,27 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
     if (ks == 1) return wide ? launch_conv_t<PrecF16, 1, 16, 4>(a, stream) : launch_conv_t<PrecF16, 1, 16, 2>(a, stream);
     if (ks == 3) return wide ? launch_conv_t<PrecF16, 3, 16, 4>(a, stream) : launch_conv_t<PrecF16, 3, 16, 2>(a, stream);
     if (ks == 5) return wide ? launch_conv_t<PrecF16, 5, 16, 4>(a, stream) : launch_conv_t<PrecF16, 5, 16, 2>(a, stream);
-  } else if (prec == 2 && a.in_split) {
-    auto padded = [&](int th, int tw) { return double((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw); };
-    if (sb == 8 && ks == 3) return launch_conv_x3s_t<3, 8, 2>(a, stream);
-    if (sb != 16) return hipErrorInvalidValue;
-    if (ks == 1) return launch_conv_x3s_t<1, 16, 2>(a, stream);
-    if (ks == 3) {
-      static const int spread3 = [] { const char* e = getenv("DFN_X3S_SPREAD3"); return e ? atoi(e) : 1; }();  // tuning aid
-      const bool sq = padded(16, 16) < 0.97 * padded(8, 32);
-      if (!spread3) return sq ? launch_conv_x3s_t<3, 16, 2, 4, 16, false>(a, stream) : launch_conv_x3s_t<3, 16, 2, 4, 32, false>(a, stream);
-      return sq ? launch_conv_x3s_t<3, 16, 2, 4, 16>(a, stream) : launch_conv_x3s_t<3, 16, 2>(a, stream);
-    }
-    if (ks == 5) {
-      static const int spread5 = [] { const char* e = getenv("DFN_X3S_SPREAD5"); return e ? atoi(e) : 0; }();  // tuning aid
-      return spread5 ? launch_conv_x3s_t<5, 16, 2, 8, 32, true>(a, stream) : launch_conv_x3s_t<5, 16, 2, 8, 32, false>(a, stream);
-    }
   } else if (prec == 2) {
-    // 3x3 / 1x1: 8 x 32-pixel tiles, two workgroups per CU (80 KB of LDS each: planes + a ring of three sub-slices).
-    static const int ring = [] { const char* e = getenv("DFN_X3_RING"); return e ? atoi(e) : 2; }();  // tuning aid (3: ring of three sub-slices — measured equal)
-    if (sb == 8 && ks == 3) return launch_conv_x3_t<3, 8, 2, 3>(a, stream);
-    if (sb != 16) return hipErrorInvalidValue;
-    if (ks == 1) return launch_conv_x3_t<1, 16, 2, 2>(a, stream);
-    if (ks == 3) {
-      static const int w8 = [] { const char* e = getenv("DFN_X3_W8"); return e ? atoi(e) : 0; }();  // tuning aid
-      if (w8) return launch_conv_x3_t<3, 16, 2, 3, 8>(a, stream);
-      // 8 x 32 or 16 x 16 pixel tiles: whichever covers the image with fewer padding pixels (ties: the 128-byte rows of 8 x 32)
-      auto padded = [&](int th, int tw) { return double((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw); };
-      static const int tw_force = [] { const char* e = getenv("DFN_X3_TW"); return e ? atoi(e) : 0; }();  // tuning aid (32 / 16)
-      const bool sq = tw_force ? tw_force == 16 : padded(16, 16) < 0.97 * padded(8, 32);
-      // 32-channel workgroups, three per CU (twice the workgroups for the layers that fill the chip's 512 slots badly): measured
-      // 10 % SLOWER on every layer of the 4 x 480x640 forward, so only on request
-      static const int mb1_force = [] { const char* e = getenv("DFN_X3_MB1"); return e ? atoi(e) : 0; }();  // tuning aid
-      const bool mb1 = mb1_force == 1;
-      if (mb1) return launch_conv_x3_t<3, 16, 1, 2, 4, 16>(a, stream);
-      if (sq) return launch_conv_x3_t<3, 16, 2, 2, 4, 16>(a, stream);
-      return ring == 3 ? launch_conv_x3_t<3, 16, 2, 3>(a, stream) : launch_conv_x3_t<3, 16, 2, 2>(a, stream);
-    }
-    if (ks == 5) {
-      // 16 x 32-pixel tiles, eight waves: the 4-wave tile's planes + slices allow one workgroup = ONE wave per SIMD;
-      // eight waves share each weight slice and give every SIMD two waves (measured 1.63 -> 1.22 ms on 4 x 480x640)
-      static const int ring5 = [] { const char* e = getenv("DFN_X3_RING5"); return e ? atoi(e) : 2; }();  // tuning aid
-      return ring5 == 2 ? launch_conv_x3_t<5, 16, 2, 2, 8>(a, stream) : launch_conv_x3_t<5, 16, 2, 3, 8>(a, stream);
+    // 8 x 32 or 16 x 16 pixel tiles for the 3x3 layers: whichever covers the image with fewer padding pixels (ties: the 128-byte rows
+    // of 8 x 32).  Variants that were built, measured and dropped (DESIGN.md sections 6 / 7): a ring of three weight sub-slices
+    // (equal), one 8-wave 16 x 32 workgroup per CU for 3x3 (4-11 % slower), 32-channel workgroups three to a CU (10 % slower),
+    // A fragments straight from L2 into registers (12 % slower).
+    auto padded = [&](int th, int tw) { return double((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw); };
+    const bool sq = padded(16, 16) < 0.97 * padded(8, 32);
+    if (a.in_split) {   // split storage in: patch staged by LDS-DMA (inference forward)
+      if (sb == 8 && ks == 3) return launch_conv_x3s_t<3, 8, 2>(a, stream);
+      if (sb != 16) return hipErrorInvalidValue;
+      if (ks == 1) return launch_conv_x3s_t<1, 16, 2>(a, stream);
+      if (ks == 3) return sq ? launch_conv_x3s_t<3, 16, 2, 4, 16>(a, stream) : launch_conv_x3s_t<3, 16, 2>(a, stream);
+      if (ks == 5) return launch_conv_x3s_t<5, 16, 2, 8, 32, false>(a, stream);   // 8-wave tile: DMA pieces in a burst measured better
+    } else {            // fp32 in: patch converted while it is staged (training / gradient paths)
+      if (sb == 8 && ks == 3) return launch_conv_x3_t<3, 8, 2, 2>(a, stream);
+      if (sb != 16) return hipErrorInvalidValue;
+      if (ks == 1) return launch_conv_x3_t<1, 16, 2, 2>(a, stream);
+      if (ks == 3) return sq ? launch_conv_x3_t<3, 16, 2, 2, 4, 16>(a, stream) : launch_conv_x3_t<3, 16, 2, 2>(a, stream);
+      // 5x5: 16 x 32-pixel tiles, eight waves — the 4-wave tile's planes + slices allow one workgroup = ONE wave per SIMD; eight waves
+      // share each weight slice and give every SIMD two waves (measured 1.63 -> 1.22 ms on 4 x 480x640)
+      if (ks == 5) return launch_conv_x3_t<5, 16, 2, 2, 8>(a, stream);
     }
   } else {
     if (sb == 4 && ks == 3) return launch_conv_t<PrecF32, 3, 4, 2>(a, stream);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Split-f16 DFNet forward only (B x 480x640, features): ms per image.  A/B aid for the DFN_X3_* tuning switches."""
+"""Split-f16 DFNet forward only (B x 480x640, features): ms per image (A/B aid: compare builds via DFN_LIB_PATH)."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
