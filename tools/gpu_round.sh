@@ -41,3 +41,13 @@ for k, d in out.items():
     if "nerfh" in k or "composite" in k or "sample" in k: print(k, {c: (f"{v:.4g}" if isinstance(v, float) else v) for c, v in d.items()})
 PY
 fi
+# Secondary workloads: kernel stats of the DFNet_dm step and the NeRF-H training step, per-layer table of the DFNet forward.
+if [[ " $* " != *" noextra "* ]]; then
+  cd /tmp
+  rm -rf $R/gpurun_out/prof_dm $R/gpurun_out/prof_train $R/gpurun_out/prof_layers
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dm -o dm -- python $R/tools/gpu_dm_step.py 4 8 > $R/gpurun_out/dm_step.json 2> $R/gpurun_out/dm_step.err; echo "dm rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -o tr -- python $R/tools/gpu_nerf_train_step.py 1536 128 10 > $R/gpurun_out/train_step.json 2> $R/gpurun_out/train_step.err; echo "train rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_layers -o l -- python $R/tools/gpu_dfnet_layers.py run > /dev/null 2>&1
+  python $R/tools/gpu_dfnet_layers.py report $R/gpurun_out/prof_layers > $R/gpurun_out/dfnet_layers.txt; head -3 $R/gpurun_out/dfnet_layers.txt
+  rm -rf $R/gpurun_out/prof_layers
+fi
