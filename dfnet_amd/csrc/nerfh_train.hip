@@ -135,18 +135,21 @@ DFN_DEV int seg_koff(const LdsGemmArgs& a, int s) {   // column of segment s ins
   return o;
 }
 
-// TR = which operand the points are.  false (forward): points = MFMA A operand, C = [point][channel]: a lane owns ONE channel of 16
-// points and a store instruction writes two whole 128-byte row segments (the best pattern for a kernel that only writes).  true (data
-// gradient): the weights are A, C = [channel][point]: a lane owns four 4-channel groups of ONE point, so the old value and the ReLU mask
-// are read — and the result written — 16 bytes at a time, a quarter of the memory instructions (measured: forward 130 -> 180 us with
-// it, backward 270 -> 190 us without it, per 295 k-point 128 x 128 layer).
-template <int NBLK, bool TR>
+// Epilogue.  The points are the MFMA's A operand: C = [point][channel], a lane owns ONE channel of 16 points.  Written straight from
+// the accumulators that is 64 four-byte stores per lane and tile (and, for the data gradient, as many loads of the old value and of
+// the ReLU mask): an ablation without the epilogue put it at 16 % (forward) to 41 % (data gradient) of these kernels.  Each wave
+// therefore turns its fragment through a small LDS buffer, half a 32 x 32 block at a time, and moves whole 128-byte row segments
+// 16 bytes per lane: a quarter of the memory instructions, every line touched once.
+constexpr int kTurnStride = 36;                      // floats per row of the turn buffer (16-byte aligned rows)
+constexpr int kTurnFloats = 16 * kTurnStride;        // per wave: 16 points x 32 channels
+template <int NBLK>
 __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kh = lane >> 5;
   const int m0 = blockIdx.y * NBLK * 32;
   const int KP = a.KP;
+  float* turn = slab + NBLK * 32 * KP + wave * kTurnFloats;
   // ---- stage the slab: rows m0 .. m0 + NBLK*32, zero padded
   for (int e = threadIdx.x; e < NBLK * 32 * KP; e += 256) slab[e] = 0.f;
   __syncthreads();
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
     for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = TR ? m0 + nb * 32 + 8 * (r >> 2) + 4 * kh + (r & 3) : m0 + nb * 32 + i;   // channel of C register r (see the epilogue)
+        const int m = m0 + nb * 32 + i;
         acc[nb][r] = (a.b && m < a.M) ? a.b[m] : 0.f;
       }
     for (int s = 0; s < a.nseg; ++s) {
@@ -236,94 +239,63 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-              for (int nb = 0; nb < NBLK; ++nb) acc[nb] = TR ? mfma32(bv[nb][q], av[t][q], acc[nb]) : mfma32(av[t][q], bv[nb][q], acc[nb]);
+              for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma32(av[t][q], bv[nb][q], acc[nb]);
           }
         }
       }
     }
-    if constexpr (TR) {
-    // ---- epilogue.  The weights are the MFMA's A operand, so C = [channel][point]: lane (point i, half kh) holds, per 32-channel
-    // block nb, the four 4-channel groups m0 + 32 nb + 8 g + 4 kh + (0..3) in acc[nb][4 g ..]: its point's row is read (old value,
-    // mask) and written 16 bytes at a time — a quarter of the memory instructions of a [point][channel] fragment.
-    if (p0 + i < a.P) {
-      float* yrow = a.y + (size_t)(p0 + i) * a.ldy + m0 + 4 * kh;
-      const bool yvec = ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) && (a.ldy & 3) == 0;
-      const bool acc_old = a.bwd && a.accumulate;
-      const float* mrow = (a.bwd && a.mask) ? a.mask + (size_t)(p0 + i) * a.ldmask + m0 + 4 * kh : nullptr;
-      const bool mvec = mrow && ((reinterpret_cast<uintptr_t>(a.mask) & 15) == 0) && (a.ldmask & 3) == 0;
+    // ---- epilogue (see above): per 32-channel block and half (16 points), fragment -> turn buffer -> rows
+    const bool yvec = ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) && (a.ldy & 3) == 0;
+    const bool acc_old = a.bwd && a.accumulate;
+    const bool mvec = a.mask && ((reinterpret_cast<uintptr_t>(a.mask) & 15) == 0) && (a.ldmask & 3) == 0;
 #pragma unroll
-      for (int nb = 0; nb < NBLK; ++nb) {
+    for (int nb = 0; nb < NBLK; ++nb) {
+      if (m0 + nb * 32 >= a.M) continue;                 // wave-uniform
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = nb * 32 + 8 * g;               // offset inside the row pointers (which carry m0 + 4 kh)
-          const int chan = m0 + c + 4 * kh;
-          if (chan >= a.M) continue;
-          const bool whole = chan + 3 < a.M;
-          f32x4 v = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
-          if (acc_old) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            if (whole && yvec) o = *reinterpret_cast<const f32x4*>(yrow + c);
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)                      // registers 8 hf .. 8 hf + 7 = rows 16 hf + (r & 3) + 8 (r >> 2) + 4 kh
+          turn[((r & 3) + 8 * (r >> 2) + 4 * kh) * kTurnStride + i] = acc[nb][8 * hf + r];
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = 8 * u + (lane >> 3), c4 = (lane & 7) * 4;
+          const long long pt = p0 + 16 * hf + row;
+          const int chan = m0 + nb * 32 + c4;
+          if (pt < a.P && chan < a.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(turn + row * kTurnStride + c4);
+            const bool whole = chan + 3 < a.M;
+            float* yp = a.y + (size_t)pt * a.ldy + chan;
+            if (acc_old) {
+              f32x4 o = {0.f, 0.f, 0.f, 0.f};
+              if (whole && yvec) o = *reinterpret_cast<const f32x4*>(yp);
+              else
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (chan + q < a.M) o[q] = yp[q];
+              v += o;
+            }
+            if (a.bwd && a.mask) {
+              const float* mp = a.mask + (size_t)pt * a.ldmask + chan;
+              f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+              if (whole && mvec) mk = *reinterpret_cast<const f32x4*>(mp);
+              else
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (chan + q < a.M) mk[q] = mp[q];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = mk[q] > 0.f ? v[q] : 0.f;
+            }
+            if (!a.bwd && a.act != ACT_NONE) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
+            }
+            if (whole && yvec) *reinterpret_cast<f32x4*>(yp) = v;
             else
 #pragma unroll
-              for (int q = 0; q < 4; ++q) if (chan + q < a.M) o[q] = yrow[c + q];
-            v += o;
+              for (int q = 0; q < 4; ++q) if (chan + q < a.M) yp[q] = v[q];
           }
-          if (mrow) {
-            f32x4 mk = {1.f, 1.f, 1.f, 1.f};
-            if (whole && mvec) mk = *reinterpret_cast<const f32x4*>(mrow + c);
-            else
-#pragma unroll
-              for (int q = 0; q < 4; ++q) if (chan + q < a.M) mk[q] = mrow[c + q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = mk[q] > 0.f ? v[q] : 0.f;
-          }
-          if (!a.bwd && a.act != ACT_NONE) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act);
-          }
-          if (whole && yvec) *reinterpret_cast<f32x4*>(yrow + c) = v;
-          else
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (chan + q < a.M) yrow[c + q] = v[q];
         }
+        wave_sync();
       }
-    }
-    } else {
-    // ---- epilogue: the activation / gradient gate is chosen ONCE per tile (wave-uniform), rows addressed from one base pointer
-    const bool full = p0 + 32 <= a.P;
-    float* ybase = a.y + (p0 + 4 * kh) * a.ldy + m0 + i;
-    auto store_all = [&](auto fn) {
-#pragma unroll
-      for (int nb = 0; nb < NBLK; ++nb) {
-        if (m0 + nb * 32 + i >= a.M) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);     // row of the C fragment relative to 4 kh
-          if (!full && p0 + 4 * kh + dr >= a.P) continue;
-          float* dst = ybase + (size_t)dr * a.ldy + nb * 32;
-          *dst = fn(acc[nb][r], dst, dr, nb);
-        }
-      }
-    };
-    if (a.bwd) {
-      const float* mbase = a.mask ? a.mask + (p0 + 4 * kh) * a.ldmask + m0 + i : nullptr;
-      if (a.accumulate && mbase)
-        store_all([&](float v, float* dst, int dr, int nb) { v += *dst; return mbase[(size_t)dr * a.ldmask + nb * 32] > 0.f ? v : 0.f; });
-      else if (a.accumulate)
-        store_all([&](float v, float* dst, int, int) { return v + *dst; });
-      else if (mbase)
-        store_all([&](float v, float*, int dr, int nb) { return mbase[(size_t)dr * a.ldmask + nb * 32] > 0.f ? v : 0.f; });
-      else
-        store_all([&](float v, float*, int, int) { return v; });
-    } else if (a.act == ACT_RELU) {
-      store_all([&](float v, float*, int, int) { return fmaxf(v, 0.f); });
-    } else if (a.act == ACT_NONE) {
-      store_all([&](float v, float*, int, int) { return v; });
-    } else if (a.act == ACT_SIGMOID) {
-      store_all([&](float v, float*, int, int) { return sigmoid(v); });
-    } else {
-      store_all([&](float v, float*, int, int) { return softplus(v); });
-    }
     }
   }
 }
@@ -333,10 +305,11 @@ static bool launch_lds_gemm(LdsGemmArgs a, int Kc_total, hipError_t& err, hipStr
   int KP = (Kc_total + 7) & ~7;
   while ((KP & 31) != 4) KP += 4;
   a.KP = KP;
-  constexpr size_t kLdsBudget = 76 * 1024;   // two workgroups per CU
+  constexpr size_t kTurnBytes = 4 * kTurnFloats * 4;   // the four waves' epilogue turn buffers
+  constexpr size_t kLdsBudget = 80 * 1024;              // two workgroups per CU
   int nblk = a.M > 64 ? 4 : (a.M > 32 ? 2 : 1);
-  while (nblk > 1 && size_t(nblk) * 32 * KP * 4 > kLdsBudget) nblk >>= 1;
-  const size_t lds = size_t(nblk) * 32 * KP * 4;
+  while (nblk > 1 && size_t(nblk) * 32 * KP * 4 + kTurnBytes > kLdsBudget) nblk >>= 1;
+  const size_t lds = size_t(nblk) * 32 * KP * 4 + kTurnBytes;
   if (lds > 150 * 1024) return false;
   const long long tiles = (a.P + 127) / 128;
   const int gy = (a.M + nblk * 32 - 1) / (nblk * 32);
@@ -357,15 +330,9 @@ static bool launch_lds_gemm(LdsGemmArgs a, int Kc_total, hipError_t& err, hipStr
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, s, a);
     err = hipGetLastError();
   };
-  if (a.bwd) {
-    if (nblk == 4) go(gemm_lds_kernel<4, true>);
-    else if (nblk == 2) go(gemm_lds_kernel<2, true>);
-    else go(gemm_lds_kernel<1, true>);
-  } else {
-    if (nblk == 4) go(gemm_lds_kernel<4, false>);
-    else if (nblk == 2) go(gemm_lds_kernel<2, false>);
-    else go(gemm_lds_kernel<1, false>);
-  }
+  if (nblk == 4) go(gemm_lds_kernel<4>);
+  else if (nblk == 2) go(gemm_lds_kernel<2>);
+  else go(gemm_lds_kernel<1>);
   return true;
 }
 
