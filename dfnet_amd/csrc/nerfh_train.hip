@@ -204,6 +204,22 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
         const int m = m0 + nb * 32 + i;
         acc[nb][r] = (a.b && m < a.M) ? a.b[m] : 0.f;
       }
+    // data gradient: the ReLU-mask pieces this lane applies in the epilogue are fetched NOW, behind the products (waited for one
+    // turn pass at a time they cost a memory latency each: 16 per tile)
+    const bool mvec = a.bwd && a.mask && ((reinterpret_cast<uintptr_t>(a.mask) & 15) == 0) && (a.ldmask & 3) == 0 && (a.M & 3) == 0;
+    f32x4 mk[NBLK][2][2];
+    if (mvec) {
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const long long pt = p0 + 16 * hf + 8 * u + (lane >> 3);
+            const int chan = m0 + nb * 32 + (lane & 7) * 4;
+            mk[nb][hf][u] = (pt < a.P && chan < a.M) ? *reinterpret_cast<const f32x4*>(a.mask + (size_t)pt * a.ldmask + chan) : f32x4{1.f, 1.f, 1.f, 1.f};
+          }
+    }
     for (int s = 0; s < a.nseg; ++s) {
       const Seg sg = a.seg[s];
       const float* x = sg.x + (sg.div == 1 ? row : row / sg.div) * sg.ld;
@@ -247,7 +263,6 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
     // ---- epilogue (see above): per 32-channel block and half (16 points), fragment -> turn buffer -> rows
     const bool yvec = ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) && (a.ldy & 3) == 0;
     const bool acc_old = a.bwd && a.accumulate;
-    const bool mvec = a.mask && ((reinterpret_cast<uintptr_t>(a.mask) & 15) == 0) && (a.ldmask & 3) == 0;
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb) {
       if (m0 + nb * 32 >= a.M) continue;                 // wave-uniform
@@ -276,13 +291,13 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(LdsGemmArgs a) {
             }
             if (a.bwd && a.mask) {
               const float* mp = a.mask + (size_t)pt * a.ldmask + chan;
-              f32x4 mk = {1.f, 1.f, 1.f, 1.f};
-              if (whole && mvec) mk = *reinterpret_cast<const f32x4*>(mp);
+              f32x4 m4 = {1.f, 1.f, 1.f, 1.f};
+              if (mvec) m4 = mk[nb][hf][u];
               else
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (chan + q < a.M) mk[q] = mp[q];
+                for (int q = 0; q < 4; ++q) if (chan + q < a.M) m4[q] = mp[q];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = mk[q] > 0.f ? v[q] : 0.f;
+              for (int q = 0; q < 4; ++q) v[q] = m4[q] > 0.f ? v[q] : 0.f;
             }
             if (!a.bwd && a.act != ACT_NONE) {
 #pragma unroll
