@@ -459,6 +459,7 @@ hipError_t gemm_bwd(const float* G, int ldg, int N, const float* W, int ldw, int
 // points; its four waves take a quarter of the chunk each and are summed through LDS in fixed order; chunk partials are
 // reduced in fixed order by wgrad_reduce_kernel (deterministic).
 constexpr int kWgradK = 4;  // 32-column blocks per workgroup
+constexpr int kWtPtsC = 32;  // points per staged tile of gemm_wgrad_tile_kernel
 // Points per chunk (multiple of 32).  The launch is chunks x items workgroups of 4 waves, two resident per CU: the chunk count
 // is chosen so that ONE wave of workgroups fills the chip (512 slots on 256 CUs) instead of leaving a half-empty second
 // round, and stays <= 256 so that the partial sums remain a small fraction of the product.
@@ -471,10 +472,18 @@ static inline int wgrad_chunk(long long P, int items) {
   if (ch < 32) ch = 32;
   return int(ch);
 }
+// the tiled kernel: per-point inputs, at most 128 outputs, enough points to give every workgroup whole tiles
+static inline bool wgrad_tiled(int N, const Seg& x, long long P) { return x.div == 1 && N <= 128 && N > 64 && P >= 64 * 1024; }
+static inline int wgrad_tile_chunk(long long P, int K) {
+  long long chunks = 512 / ((K + 127) / 128);      // two workgroups per CU over all column groups
+  if (chunks < 1) chunks = 1;
+  long long ch = ((P + chunks - 1) / chunks + kWtPtsC - 1) / kWtPtsC * kWtPtsC;
+  return int(ch < kWtPtsC ? kWtPtsC : ch);
+}
 size_t gemm_wgrad_scratch_floats(int N, int K, long long P) {
-  // an upper bound over the segment widths a layer is split into: <= 256 chunks of [N][K] (+ [N])
+  // an upper bound over the segment widths a layer is split into: <= 512 chunks of [N][K] (+ [N])
   const long long ch = wgrad_chunk(P, wgrad_items(N, K)), chunks = (P + ch - 1) / ch;
-  const long long worst = chunks > 256 ? chunks : 256;
+  const long long worst = chunks > 512 ? chunks : 512;
   return size_t(worst) * (size_t(N) * K + N);
 }
 
@@ -582,27 +591,145 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// dW[e] = sum over chunks (fixed order): 4 threads per element take interleaved chunks and are combined by shuffles.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int chunks,
+// Tiled form of the weight-gradient product for N <= 128 outputs and per-point inputs (every Linear of the two networks): a
+// workgroup owns a chunk of points and ALL outputs — wave w the 32 outputs n0 = 32 w, each against a 128-column group of X — so the
+// X rows of a 32-point tile are staged once in LDS for the four waves (gemm_wgrad_kernel re-reads them per 32-output item: 2.5x the
+// bytes of this form) and nothing is reduced across waves.  Tile t + 1 (X into registers, the wave's G strip) is fetched while
+// tile t is multiplied; one barrier per tile = 64 MFMAs per wave.
+constexpr int kWtPts = 32, kWtStride = 132;   // staged tile [32 points][128 columns + 4]: 16-byte rows, conflict-free scalar reads
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_tile_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float xt[2][kWtPts * kWtStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kh = lane >> 5;
+  const int k0 = blockIdx.y * 128, n0 = wave * 32;
+  const long long c0 = (long long)blockIdx.x * a.chunk;
+  const long long c1 = c0 + a.chunk < a.P ? c0 + a.chunk : a.P;
+  const int K = a.x.K;
+  f32x16 acc[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+  float bsum = 0.f;
+  const bool nok = n0 + i < a.N;
+  // staging: thread t moves the 16-byte pieces e = t + 256 u (u < 4) of the tile: point e / 32, columns 4 (e % 32) ..
+  const bool xvec = ((reinterpret_cast<uintptr_t>(a.x.x) & 15) == 0) && (a.x.ld & 3) == 0;
+  auto load_x = [&](f32x4 (&xr)[4], long long pt0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + 256 * u, pt = e >> 5, k4 = (e & 31) * 4;
+      const long long p = pt0 + pt;
+      const float* src = a.x.x + (size_t)(p < c1 ? p : c1 - 1) * a.x.ld + k0 + k4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < c1) {
+        if (xvec && ((k0 + k4) & 3) == 0 && k0 + k4 + 3 < K) v = *reinterpret_cast<const f32x4*>(src);
+        else
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k0 + k4 + q < K) v[q] = src[q];
+      }
+      xr[u] = v;
+    }
+  };
+  auto store_x = [&](const f32x4 (&xr)[4], int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + 256 * u, pt = e >> 5, k4 = (e & 31) * 4;
+      *reinterpret_cast<f32x4*>(&xt[buf][pt * kWtStride + k4]) = xr[u];
+    }
+  };
+  auto load_g = [&](float (&g)[16], long long pt0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const long long p = pt0 + 8 * (j >> 2) + 4 * kh + (j & 3);
+      g[j] = (nok && p < c1) ? a.G[(size_t)p * a.ldg + n0 + i] : 0.f;
+    }
+  };
+  f32x4 xr[4];
+  float g[16], gn[16];
+  load_x(xr, c0);
+  load_g(g, c0);
+  store_x(xr, 0);
+  __syncthreads();
+  int cur = 0;
+  for (long long pt0 = c0; pt0 < c1; pt0 += kWtPts) {
+    const bool more = pt0 + kWtPts < c1;
+    if (more) { load_x(xr, pt0 + kWtPts); load_g(gn, pt0 + kWtPts); }
+    const float* xb = xt[cur] + 4 * kh * kWtStride + i;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float bv[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) bv[kb][q] = xb[(8 * st + q) * kWtStride + kb * 32];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bsum += g[4 * st + q];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) acc[kb] = mfma32(g[4 * st + q], bv[kb][q], acc[kb]);
+      }
+    }
+    if (more) {
+      store_x(xr, cur ^ 1);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) g[j] = gn[j];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  float* part = a.part + ((size_t)blockIdx.x) * a.N * K;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const int col = k0 + kb * 32 + i;
+    if (col >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + mblock_row(kh, r);
+      if (n < a.N) part[(size_t)n * K + col] = acc[kb][r];
+    }
+  }
+  if (blockIdx.y == 0 && a.bpart) {
+    const float tot = bsum + __shfl_xor(bsum, 32, 64);
+    if (kh == 0 && nok) a.bpart[(size_t)blockIdx.x * a.N + n0 + i] = tot;
+  }
+}
+
+// dW[e] = sum over chunks in a FIXED order: a workgroup owns 64 consecutive elements; wave s of its eight sums the chunks
+// [s C/8, (s+1) C/8) of them (256-byte coalesced rows, 8 loads in flight), then the eight sums are added in wave order.
+__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int chunks,
                                                            int N, int K, float* __restrict__ dW, int ldw, int wcol,
                                                            float* __restrict__ db) {
-  const size_t total = size_t(N) * K + (db ? N : 0);
-  const int sl = threadIdx.x & 3;
-  for (size_t e = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) >> 2; e < total; e += (size_t(gridDim.x) * blockDim.x) >> 2) {
-    const bool isw = e < size_t(N) * K;
-    const float* src = isw ? part + e : bpart + (e - size_t(N) * K);
-    const size_t stride = isw ? size_t(N) * K : size_t(N);
-    float s = 0.f;
-    for (int c = sl; c < chunks; c += 4) s += src[size_t(c) * stride];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (sl == 0) {
-      if (isw) {
-        const size_t n = e / K, k = e - n * K;
-        dW[n * ldw + wcol + k] = s;
-      } else {
-        db[e - size_t(N) * K] = s;
-      }
+  __shared__ float sums[8][64];
+  const size_t nw = size_t(N) * K, total = nw + (db ? N : 0);
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const size_t e = size_t(blockIdx.x) * 64 + lane;
+  const bool ok = e < total, isw = e < nw;
+  const float* src = isw ? part + e : bpart + (ok ? e - nw : 0);
+  const size_t stride = isw ? nw : size_t(N);
+  const int per = (chunks + 7) / 8, c0 = sl * per, c1 = c0 + per < chunks ? c0 + per : chunks;
+  float s = 0.f;
+  if (ok) {
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[size_t(c + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < c1; ++c) s += src[size_t(c) * stride];
+  }
+  sums[sl][lane] = s;
+  __syncthreads();
+  if (sl == 0 && ok) {
+    float t = sums[0][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) t += sums[w][lane];
+    if (isw) {
+      const size_t n = e / K, k = e - n * K;
+      dW[n * ldw + wcol + k] = t;
+    } else {
+      db[e - nw] = t;
     }
   }
 }
@@ -611,7 +738,8 @@ hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW
                       long long P, hipStream_t s) {
   if (N <= 0 || xseg.K <= 0) return hipSuccess;
   if (P <= 0) return hipErrorInvalidValue;
-  const int ch = wgrad_chunk(P, wgrad_items(N, xseg.K));
+  const bool tiled = wgrad_tiled(N, xseg, P);
+  const int ch = tiled ? wgrad_tile_chunk(P, xseg.K) : wgrad_chunk(P, wgrad_items(N, xseg.K));
   const int chunks = int((P + ch - 1) / ch);
   WgradArgs a{};
   a.G = G; a.ldg = ldg; a.N = N; a.x = xseg; a.P = P; a.chunk = ch;
@@ -619,10 +747,11 @@ hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW
   a.bpart = db ? scratch + size_t(chunks) * N * xseg.K : nullptr;
   a.kgroups = (xseg.K + kWgradK * 32 - 1) / (kWgradK * 32);
   a.items = ((N + 31) / 32) * a.kgroups;
-  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(chunks, a.items), dim3(256), 0, s, a);
+  if (tiled) hipLaunchKernelGGL(gemm_wgrad_tile_kernel, dim3(chunks, (xseg.K + 127) / 128), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(chunks, a.items), dim3(256), 0, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t(N) * xseg.K + N) * 4, 256, 2048)), dim3(256), 0, s, a.part, a.bpart, chunks,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((size_t(N) * xseg.K + (db ? N : 0) + 63) / 64)), dim3(512), 0, s, a.part, a.bpart, chunks,
                      N, xseg.K, dW, ldw, xseg.wcol, db);
   return hipGetLastError();
 }
