@@ -473,7 +473,7 @@ static inline int wgrad_chunk(long long P, int items) {
   return int(ch);
 }
 // the tiled kernel: per-point inputs, at most 128 outputs, enough points to give every workgroup whole tiles
-static inline bool wgrad_tiled(int N, const Seg& x, long long P) { return x.div == 1 && N <= 128 && N > 64 && P >= 64 * 1024; }
+static inline bool wgrad_tiled(int N, const Seg& x, long long P) { return x.div == 1 && N <= 128 && N > 32 && P >= 64 * 1024; }
 static inline int wgrad_tile_chunk(long long P, int K) {
   long long chunks = 512 / ((K + 127) / 128);      // two workgroups per CU over all column groups
   if (chunks < 1) chunks = 1;
@@ -596,18 +596,22 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs a) {
 // X rows of a 32-point tile are staged once in LDS for the four waves (gemm_wgrad_kernel re-reads them per 32-output item: 2.5x the
 // bytes of this form) and nothing is reduced across waves.  Tile t + 1 (X into registers, the wave's G strip) is fetched while
 // tile t is multiplied; one barrier per tile = 64 MFMAs per wave.
+// NBW = 32-output blocks per workgroup: 4 (N <= 128: a wave = one block x all four 32-column blocks of the group) or 2 (N <= 64: a
+// wave = one block x two column blocks).
 constexpr int kWtPts = 32, kWtStride = 132;   // staged tile [32 points][128 columns + 4]: 16-byte rows, conflict-free scalar reads
+template <int NBW>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_tile_kernel(WgradArgs a) {
+  constexpr int KBW = NBW;                    // column blocks per wave: 4 / (4 / NBW)
   __shared__ __attribute__((aligned(16))) float xt[2][kWtPts * kWtStride];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kh = lane >> 5;
-  const int k0 = blockIdx.y * 128, n0 = wave * 32;
+  const int k0 = blockIdx.y * 128, n0 = (wave % NBW) * 32, kbw = (wave / NBW) * KBW;   // first of the wave's column blocks
   const long long c0 = (long long)blockIdx.x * a.chunk;
   const long long c1 = c0 + a.chunk < a.P ? c0 + a.chunk : a.P;
   const int K = a.x.K;
-  f32x16 acc[4];
+  f32x16 acc[KBW];
 #pragma unroll
-  for (int kb = 0; kb < 4; ++kb)
+  for (int kb = 0; kb < KBW; ++kb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
   float bsum = 0.f;
@@ -654,19 +658,19 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tile_kernel(WgradArgs a) {
   for (long long pt0 = c0; pt0 < c1; pt0 += kWtPts) {
     const bool more = pt0 + kWtPts < c1;
     if (more) { load_x(xr, pt0 + kWtPts); load_g(gn, pt0 + kWtPts); }
-    const float* xb = xt[cur] + 4 * kh * kWtStride + i;
+    const float* xb = xt[cur] + 4 * kh * kWtStride + kbw * 32 + i;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      float bv[4][4];
+      float bv[KBW][4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) bv[kb][q] = xb[(8 * st + q) * kWtStride + kb * 32];
+        for (int kb = 0; kb < KBW; ++kb) bv[kb][q] = xb[(8 * st + q) * kWtStride + kb * 32];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         bsum += g[4 * st + q];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) acc[kb] = mfma32(g[4 * st + q], bv[kb][q], acc[kb]);
+        for (int kb = 0; kb < KBW; ++kb) acc[kb] = mfma32(g[4 * st + q], bv[kb][q], acc[kb]);
       }
     }
     if (more) {
@@ -679,8 +683,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tile_kernel(WgradArgs a) {
   }
   float* part = a.part + ((size_t)blockIdx.x) * a.N * K;
 #pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-    const int col = k0 + kb * 32 + i;
+  for (int kb = 0; kb < KBW; ++kb) {
+    const int col = k0 + (kbw + kb) * 32 + i;
     if (col >= K) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tile_kernel(WgradArgs a) {
       if (n < a.N) part[(size_t)n * K + col] = acc[kb][r];
     }
   }
-  if (blockIdx.y == 0 && a.bpart) {
+  if (blockIdx.y == 0 && kbw == 0 && a.bpart) {
     const float tot = bsum + __shfl_xor(bsum, 32, 64);
     if (kh == 0 && nok) a.bpart[(size_t)blockIdx.x * a.N + n0 + i] = tot;
   }
@@ -747,7 +751,8 @@ hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW
   a.bpart = db ? scratch + size_t(chunks) * N * xseg.K : nullptr;
   a.kgroups = (xseg.K + kWgradK * 32 - 1) / (kWgradK * 32);
   a.items = ((N + 31) / 32) * a.kgroups;
-  if (tiled) hipLaunchKernelGGL(gemm_wgrad_tile_kernel, dim3(chunks, (xseg.K + 127) / 128), dim3(256), 0, s, a);
+  if (tiled && N > 64) hipLaunchKernelGGL(gemm_wgrad_tile_kernel<4>, dim3(chunks, (xseg.K + 127) / 128), dim3(256), 0, s, a);
+  else if (tiled) hipLaunchKernelGGL(gemm_wgrad_tile_kernel<2>, dim3(chunks, (xseg.K + 127) / 128), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(chunks, a.items), dim3(256), 0, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
