@@ -78,7 +78,7 @@ def test_dfnet_s_golden(gold):
     assert relmax(fs[0, :, ::int(g["cstride"])], g["single"][0]) < 2e-5 and relmax(pose, g["pose"]) < 2e-5
 
 
-@pytest.mark.parametrize("B,H,W,uH,uW", [(1, 33, 47, 33, 47), (3, 64, 96, 50, 70), (2, 240, 320, 240, 320)])
+@pytest.mark.parametrize("B,H,W,uH,uW", [(1, 33, 47, 33, 47), (3, 64, 96, 50, 70), (2, 240, 320, 240, 320), (2, 120, 213, 120, 213)])
 def test_dfnet_vs_oracle_shapes(net, B, H, W, uH, uW):
     """Ragged sizes (tile remainders, odd pooling) and an upsample that is not the input size."""
     E, p = net

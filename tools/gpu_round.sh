@@ -45,7 +45,7 @@ fi
 if [[ " $* " != *" noextra "* ]]; then
   cd /tmp
   rm -rf $R/gpurun_out/prof_dm $R/gpurun_out/prof_train $R/gpurun_out/prof_layers
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dm -o dm -- python $R/tools/gpu_dm_step.py 4 8 > $R/gpurun_out/dm_step.json 2> $R/gpurun_out/dm_step.err; echo "dm rc=$?"
+  DM_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dm -o dm -- python $R/tools/gpu_dm_step.py 4 24 > $R/gpurun_out/dm_step.json 2> $R/gpurun_out/dm_step.err; echo "dm rc=$?"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -o tr -- python $R/tools/gpu_nerf_train_step.py 1536 128 10 > $R/gpurun_out/train_step.json 2> $R/gpurun_out/train_step.err; echo "train rc=$?"
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_layers -o l -- python $R/tools/gpu_dfnet_layers.py run > /dev/null 2>&1
   python $R/tools/gpu_dfnet_layers.py report $R/gpurun_out/prof_layers > $R/gpurun_out/dfnet_layers.txt; head -3 $R/gpurun_out/dfnet_layers.txt
