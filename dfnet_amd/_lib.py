@@ -96,6 +96,9 @@ SIGNATURES = {
     "dfn_nerfh_generic_workspace_bytes": (c_size_t, [_P, c_size_t, c_int, c_int]),
     "dfn_nerfh_generic_render_rays": (c_int, [_P, _P, _P, _P, c_size_t, c_size_t, c_int, c_int, c_float, c_float, _P, _P, _P, _P,
                                               _P, c_size_t, _P]),
+    "dfn_nerfh_generic_backward_workspace_bytes": (c_size_t, [_P, c_size_t, c_int, c_int]),
+    "dfn_nerfh_generic_render_rays_backward": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_size_t, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P,
+                                               c_size_t, _P]),
     "dfn_linear_forward": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, c_int, _P]),
     "dfn_linear_backward_input": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, _P]),
     "dfn_linear_backward_weight_scratch_bytes": (c_size_t, [c_int, c_int, c_size_t]),

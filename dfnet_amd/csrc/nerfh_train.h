@@ -69,6 +69,14 @@ hipError_t sum_over_samples(const float* g, int ld, int C, size_t R, int Ns, flo
 // embedding-table gradients: grad_emb[idx(hist[r, b]), j] += g_in[r * ld + off + b * dim + j] (atomic fp32 adds).
 hipError_t embedding_scatter(const float* g_in, int ld, int off, const float* hist, size_t hist_rows, int hist_bin, int dim,
                              int n_vocab, size_t R, float* grad_emb, hipStream_t s);
+// Input-gradient pieces of the generic-width render gradient (nerfh_train_api.hip: dfn_nerfh_generic_render_rays_backward).
+// g [P,9] (d L / d raw, the network's OUTPUTS) -> d L / d pre-activation in place: x y (1 - y) for the Sigmoid heads (columns
+// 0-2, 4-6), x (1 - exp(-y)) for the Softplus heads (3, 7, 8); y = raw [P,9].
+hipError_t head_prime(const float* raw, float* g, size_t P, hipStream_t s);
+// Jacobians of the two positional encodings (models/nerfw.py:105-133): g_pe [P,64] (63 used) at x = o + d z and g_dpe [P,ld_d]
+// (27 used) at the ray's viewdir -> gpts [P,6] = d L / d point (3), d L / d viewdir through this sample (3).
+hipError_t posenc_backward(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, const float* g_pe,
+                           const float* g_dpe, int ld_d, size_t R, int Ns, float* gpts, hipStream_t s);
 constexpr int kNerfwLossFloats = 160;   // loss buffer: 5 results + scratch for the per-block partial sums
 // NerfWLoss (models/losses.py:19-57) forward + gradient.  tsigma = raw + 7 with stride 9.  loss[0..4) = c_l, f_l, b_l,
 // s_l; loss[4] = psnr of rgb (run_nerf.py:62-64).  Gradients of sum(loss) * 1: g_rgb [R,3], g_rgb0 [R,3], g_beta [R];

@@ -810,6 +810,56 @@ hipError_t posenc_points(const float* rays_o, const float* rays_d, const float* 
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void head_prime_kernel(const float* __restrict__ raw, float* __restrict__ g, size_t n) {
+  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+    const int c = int(e % 9);
+    const float y = raw[e];
+    const bool softplus_head = c == 3 || c >= 7;
+    g[e] *= softplus_head ? 1.f - expf(-y) : y * (1.f - y);
+  }
+}
+hipError_t head_prime(const float* raw, float* g, size_t P, hipStream_t s) {
+  if (!P) return hipSuccess;
+  hipLaunchKernelGGL(head_prime_kernel, dim3(grid_for(P * 9, 256, 4096)), dim3(256), 0, s, raw, g, P * 9);
+  return hipGetLastError();
+}
+
+// d/dx of [x, sin(2^k x), cos(2^k x)]: g_x + sum_k 2^k (cos(2^k x) g_sin_k - sin(2^k x) g_cos_k); columns as posenc_points_kernel.
+DFN_DEV float posenc_adjoint(const float* g, float x, int coord, int L) {
+  float acc = g[coord];
+  for (int k = 0; k < L; ++k) {
+    const float f = float(1 << k), arg = x * f;
+    acc += f * (cosf(arg) * g[3 + 6 * k + coord] - sinf(arg) * g[3 + 6 * k + 3 + coord]);
+  }
+  return acc;
+}
+__global__ __launch_bounds__(256) void posenc_backward_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                              const float* __restrict__ viewdirs, const float* __restrict__ z,
+                                                              const float* __restrict__ g_pe, const float* __restrict__ g_dpe, int ld_d,
+                                                              size_t R, int Ns, float* __restrict__ gpts) {
+  const size_t n = R * size_t(Ns) * 6;      // one thread per (point, output column)
+  for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+    const size_t pt = e / 6;
+    const int c = int(e - pt * 6);
+    const size_t ray = pt / Ns;
+    float v;
+    if (c < 3) {
+      const float x = add_rn(rays_o[ray * 3 + c], mul_rn(rays_d[ray * 3 + c], z[pt]));
+      v = posenc_adjoint(g_pe + pt * 64, x, c, 10);
+    } else {
+      v = posenc_adjoint(g_dpe + pt * ld_d, viewdirs[ray * 3 + (c - 3)], c - 3, 4);
+    }
+    gpts[e] = v;
+  }
+}
+hipError_t posenc_backward(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, const float* g_pe,
+                           const float* g_dpe, int ld_d, size_t R, int Ns, float* gpts, hipStream_t s) {
+  if (!R) return hipSuccess;
+  hipLaunchKernelGGL(posenc_backward_kernel, dim3(grid_for(R * Ns * 6, 256, 8192)), dim3(256), 0, s, rays_o, rays_d, viewdirs, z, g_pe,
+                     g_dpe, ld_d, R, Ns, gpts);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(128) void ray_inputs_kernel(const float* __restrict__ viewdirs, const float* __restrict__ hist,
                                                          size_t hist_rows, const float* __restrict__ emb_a,
                                                          const float* __restrict__ emb_t, int hist_bin, int dim_a, int dim_t,

@@ -408,6 +408,115 @@ extern "C" int dfn_nerfh_generic_render_rays(dfn_nerfh_t h, const float* rays_o,
   return DFN_OK;
 }
 
+// ------------------------------------------------------------------------------------------ generic-width render gradient
+// dfn_render_rays_backward for ANY even netwidth, exact fp32: the test-time forward of dfn_nerfh_generic_render_rays with every
+// fine activation kept, raw2outputs_NeRFW backward (rgb only), head derivatives, then the fine network's data-gradient chain
+// (net_backward without the weight gradients, plus the two products that reach the encodings) and the encodings' Jacobians.
+namespace {
+struct GenBwdWs { TrainWs t; float *sigma, *raw, *g_pe, *g_dpe, *gpts, *view; size_t total; };
+GenBwdWs carve_gen_bwd(float* base, const Dims& m, size_t R, int Nc, int Ni) {
+  GenBwdWs w{};
+  w.t = carve_train(base, m, R, Nc, Ni, true);
+  size_t off = w.t.total / sizeof(float);
+  const size_t Pf = R * (size_t(Nc) + Ni);
+  auto take = [&](size_t floats) { float* p = base ? base + off : nullptr; off += al64(floats); return p; };
+  w.sigma = take(R * Nc);
+  w.raw = take(Pf * 9);
+  w.g_pe = take(Pf * 64);
+  w.g_dpe = take(Pf * 28);
+  w.gpts = take(Pf * 6);
+  w.view = take(R * 3);
+  w.total = off * sizeof(float);
+  return w;
+}
+}  // namespace
+
+extern "C" size_t dfn_nerfh_generic_backward_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni) {
+  if (!h) return 0;
+  return carve_gen_bwd(nullptr, dims_of(h->desc), n_rays ? n_rays : 1, Nc, Ni).total;
+}
+
+extern "C" int dfn_nerfh_generic_render_rays_backward(dfn_nerfh_t h, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                                      const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near,
+                                                      float far, const float* grad_rgb, float* grad_rays_o, float* grad_rays_d,
+                                                      float* grad_viewdirs, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_train_args(h, Nc, Ni, "dfn_nerfh_generic_render_rays_backward")) return rc;
+  if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_nerfh_generic_render_rays_backward: dfn_nerfh_commit() has not been called");
+  if (!n_rays) return DFN_OK;
+  if (!rays_o || !rays_d || !hist || !grad_rgb || !grad_rays_o || !grad_rays_d || !workspace || (hist_rows != 1 && hist_rows != n_rays))
+    return set_error(DFN_ERR_ARG, "dfn_nerfh_generic_render_rays_backward: bad argument (hist_rows must be 1 or n_rays)");
+  const Dims m = dims_of(h->desc);
+  const GenBwdWs g = carve_gen_bwd(static_cast<float*>(workspace), m, n_rays, Nc, Ni);
+  if (g.total > workspace_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_nerfh_generic_render_rays_backward: workspace too small (%zu < %zu)", workspace_bytes, g.total);
+  hipStream_t s = HS(stream);
+  const TrainWs& w = g.t;
+  const size_t R = n_rays;
+  const int Nf = Nc + Ni, W = m.W, W2 = m.W2;
+  const long long P = (long long)R * Nf;
+  const float* const* params = h->gen_params.data();
+  const Net nc = net_of(params, nullptr, false), nf = net_of(params, nullptr, true);
+  const float* v = viewdirs;
+  if (!v) {
+    CHECK_HIP(launch_viewdirs(rays_d, R, g.view, s), "generic render gradient: viewdirs");
+    v = g.view;
+  }
+  // ---- forward (dfn_nerfh_generic_render_rays), every fine activation kept in the workspace
+  CHECK_HIP(ray_inputs(v, hist, hist_rows, params[kCoarseParams + kFineParams], params[kCoarseParams + kFineParams + 1], m.hist_bin,
+                       m.dim_a, m.dim_t, m.n_vocab, R, w.dir_f, m.ld_df, w.t_in, m.ld_t, s),
+            "generic render gradient: ray inputs");
+  CHECK_HIP(stratified_z(nullptr, R, Nc, near, far, w.z_c, s), "generic render gradient: z");
+  CHECK_HIP(posenc_points(rays_o, rays_d, w.z_c, R, Nc, w.pe_c, s), "generic render gradient: coarse encoding");
+  NetBufs bc = bufs_of(w, m, false, nullptr, R, Nc, Ni);
+  bc.raw = g.sigma;
+  bc.raw_ld = 1;
+  if (int rc = net_forward(nc, m, bc, false, true, s)) return rc;
+  CHECK_HIP(launch_sample_fine(g.sigma, R, Nc, Ni, near, far, w.z_f, nullptr, nullptr, s), "generic render gradient: sample_fine");
+  CHECK_HIP(posenc_points(rays_o, rays_d, w.z_f, R, Nf, w.pe_f, s), "generic render gradient: fine encoding");
+  const NetBufs b = bufs_of(w, m, true, g.raw, R, Nc, Ni);
+  if (int rc = net_forward(nf, m, b, true, false, s)) return rc;
+  // ---- d rgb -> d raw -> d pre-activation (in place)
+  float* gpre = w.gpre_f;
+  CHECK_HIP(launch_composite_fine_backward(g.raw, w.z_f, grad_rgb, R, Nf, gpre, s), "generic render gradient: composite");
+  CHECK_HIP(head_prime(g.raw, gpre, size_t(P), s), "generic render gradient: head derivatives");
+  // ---- data gradients (the calls of net_backward, without the weight gradients)
+  const int C = 9, ldw_dir = W + b.kd, ldw_te0 = W + m.nt;
+  const Net& n = nf;
+  CHECK_HIP(gemm_bwd(gpre + 4, C, 3, n.w[TRGB], W2, 0, W2, w.gt0, W2, 0, nullptr, 0, P, s), "generic render gradient: transient_rgb");
+  CHECK_HIP(gemm_bwd(gpre + 7, C, 1, n.w[TSIG], W2, 0, W2, w.gt0, W2, 1, nullptr, 0, P, s), "generic render gradient: transient_sigma");
+  CHECK_HIP(gemm_bwd(gpre + 8, C, 1, n.w[TBETA], W2, 0, W2, w.gt0, W2, 1, b.te[3], W2, P, s), "generic render gradient: transient_beta");
+  float* cur = w.gt0;
+  float* nxt = w.gt1;
+  for (int j = 3; j >= 1; --j) {
+    CHECK_HIP(gemm_bwd(cur, W2, W2, n.w[TE0 + j], W2, 0, W2, nxt, W2, 0, b.te[j - 1], W2, P, s), "generic render gradient: transient_encoding");
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  CHECK_HIP(gemm_bwd(cur, W2, W2, n.w[TE0], ldw_te0, 0, W, w.gfin, W, 0, nullptr, 0, P, s), "generic render gradient: d final (transient)");
+  CHECK_HIP(gemm_bwd(gpre, C, 3, n.w[RGB], W2, 0, W2, w.gt0, W2, 0, b.dirh, W2, P, s), "generic render gradient: static_rgb");
+  CHECK_HIP(gemm_bwd(w.gt0, W2, W2, n.w[DIR], ldw_dir, W, kChDir, g.g_dpe, 28, 0, nullptr, 0, P, s), "generic render gradient: d pe_dir");
+  CHECK_HIP(gemm_bwd(w.gt0, W2, W2, n.w[DIR], ldw_dir, 0, W, w.gfin, W, 1, nullptr, 0, P, s), "generic render gradient: d final");
+  CHECK_HIP(gemm_bwd(w.gfin, W, W, n.w[FIN], W, 0, W, w.gA, W, 0, nullptr, 0, P, s), "generic render gradient: xyz_encoding_final");
+  CHECK_HIP(gemm_bwd(gpre + 3, C, 1, n.w[SIG], W, 0, W, w.gA, W, 1, b.h[7], W, P, s), "generic render gradient: static_sigma");
+  cur = w.gA;
+  nxt = w.gB;
+  for (int l = 7; l >= 1; --l) {
+    if (l == 4) {
+      CHECK_HIP(gemm_bwd(cur, W, W, n.w[l], W + kChXyz, 0, kChXyz, g.g_pe, 64, 0, nullptr, 0, P, s), "generic render gradient: d pe (skip)");
+      CHECK_HIP(gemm_bwd(cur, W, W, n.w[l], W + kChXyz, kChXyz, W, nxt, W, 0, b.h[3], W, P, s), "generic render gradient: xyz_encoding_5");
+    } else {
+      CHECK_HIP(gemm_bwd(cur, W, W, n.w[l], W, 0, W, nxt, W, 0, b.h[l - 1], W, P, s), "generic render gradient: xyz_encoding");
+    }
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  CHECK_HIP(gemm_bwd(cur, W, W, n.w[0], kChXyz, 0, kChXyz, g.g_pe, 64, 1, nullptr, 0, P, s), "generic render gradient: d pe");
+  // ---- encodings, then the per-ray reduction of dfn_render_rays_backward
+  CHECK_HIP(posenc_backward(rays_o, rays_d, v, w.z_f, g.g_pe, g.g_dpe, 28, R, Nf, g.gpts, s), "generic render gradient: encodings");
+  CHECK_HIP(launch_ray_grad_reduce(g.gpts, w.z_f, rays_d, R, Nf, viewdirs == nullptr, grad_rays_o, grad_rays_d,
+                                   viewdirs ? grad_viewdirs : nullptr, s),
+            "generic render gradient: per-ray reduction");
+  return DFN_OK;
+}
+
 // ------------------------------------------------------------------------------------------ the three products, for parity tests
 extern "C" int dfn_linear_forward(const float* x, int ldx, int K, const float* w, int ldw, int wcol, const float* b, int N, int act,
                                   float* y, int ldy, size_t n_points, int x_row_div, void* stream) {

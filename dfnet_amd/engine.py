@@ -123,6 +123,7 @@ class NerfHEngine:
         return gpts
 
     # ------------------------------------------------------------------ whole path
+    GENERIC_GRAD_CHUNK = 8192   # rays per pass of the generic-width gradient (every fine activation is kept: ~1.3 MB per ray at 64+128, netwidth 256)
     GENERIC_CHUNK = 4096   # rays per pass of the generic path (its activations live in HBM: ~1.2 MB per ray at 64+128, W=128)
 
     def generic_render_rays(self, rays_o, rays_d, hist, Nc, Ni, near, far, retraw=False):
@@ -240,6 +241,19 @@ class NerfHEngine:
         if viewdirs is not None:
             viewdirs = _f32c(viewdirs).reshape(-1, 3)
             gv = torch.empty(n, 3, device=dev)
+        if self.width != 128 or precision == "generic":
+            # the register-resident gradient kernels are netwidth 128; every other width takes the layer-by-layer exact-fp32 path
+            C = self.GENERIC_GRAD_CHUNK
+            ws = self._workspace(self.lib.dfn_nerfh_generic_backward_workspace_bytes(self.handle, min(n, C), Nc, Ni), dev)
+            for r0 in range(0, n, C):
+                m = min(C, n - r0)
+                hh = hist if hist.shape[0] == 1 else hist[r0:r0 + m]
+                check(self.lib.dfn_nerfh_generic_render_rays_backward(
+                    self.handle, ptr(rays_o[r0:r0 + m]), ptr(rays_d[r0:r0 + m]), ptr(None if viewdirs is None else viewdirs[r0:r0 + m]),
+                    ptr(hh), hh.shape[0], m, Nc, Ni, float(near), float(far), ptr(grad_rgb[r0:r0 + m]), ptr(go[r0:r0 + m]), ptr(gd[r0:r0 + m]),
+                    ptr(None if gv is None else gv[r0:r0 + m]), ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
+                    "dfn_nerfh_generic_render_rays_backward")
+            return go, gd, gv
         ws = self._workspace(self.lib.dfn_render_backward_workspace_bytes(n, Nc, Ni), dev)
         check(self.lib.dfn_render_rays_backward(self.handle, self._prec(precision), ptr(rays_o), ptr(rays_d), ptr(viewdirs),
                                                 ptr(hist), hist.shape[0], n, Nc, Ni, float(near), float(far),
@@ -255,6 +269,11 @@ class NerfHEngine:
         hist = _f32c(hist).reshape(-1)[: self.hist_bin].contiguous()
         grad_rgb = _f32c(grad_rgb).reshape(H, W, 3)
         gc = torch.empty(3, 4, device=dev)
+        if self.width != 128 or precision == "generic":   # get_rays, the generic-width ray gradient, get_rays backward
+            o, d, _ = raygen(H, W, focal, c2w, want_viewdirs=False)
+            go, gd, _ = self.render_rays_backward(o.reshape(-1, 3), d.reshape(-1, 3), hist, Nc, Ni, near, far, grad_rgb.reshape(-1, 3),
+                                                  precision="generic")
+            return raygen_backward(H, W, focal, go, gd)
         ws = self._workspace(self.lib.dfn_render_backward_workspace_bytes(H * W, Nc, Ni), dev)
         check(self.lib.dfn_render_image_backward(self.handle, self._prec(precision), ptr(c2w), H, W, float(focal),
                                                  float(near), float(far), Nc, Ni, ptr(hist), ptr(grad_rgb), ptr(gc),

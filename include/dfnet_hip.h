@@ -389,6 +389,16 @@ size_t dfn_nerfh_generic_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, i
 int dfn_nerfh_generic_render_rays(dfn_nerfh_t h, const float* rays_o, const float* rays_d, const float* hist, size_t hist_rows,
                                   size_t n_rays, int Nc, int Ni, float near, float far, float* rgb, float* disp, float* acc,
                                   float* raw, void* workspace, size_t workspace_bytes, void* stream);
+/* The gradient of that render for ANY even netwidth (what dfn_render_rays_backward is for netwidth 128): d L / d rays_o,
+ * d L / d rays_d [n_rays, 3] from grad_rgb [n_rays, 3]; viewdirs == NULL: they are d/|d| and the normalisation is differentiated
+ * into grad_rays_d, otherwise grad_viewdirs (optional) receives their gradient.  Exact fp32; recomputes the forward keeping the
+ * fine activations (workspace: dfn_nerfh_generic_backward_workspace_bytes).  Replaces loss.backward() through
+ * render(c2w = pose) (feature/direct_feature_matching.py:340-376) when --netwidth is not 128. */
+size_t dfn_nerfh_generic_backward_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni);
+int dfn_nerfh_generic_render_rays_backward(dfn_nerfh_t h, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                           const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, float near,
+                                           float far, const float* grad_rgb, float* grad_rays_o, float* grad_rays_d,
+                                           float* grad_viewdirs, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The three fp32-MFMA products of the training path, for parity tests (torch.nn.functional.linear and its autograd):
  *   y[p, n]  = act(sum_k x[p / x_row_div, k] w[n, wcol + k] + b[n])   act: 0 none, 1 ReLU, 2 Sigmoid, 3 Softplus
