@@ -64,6 +64,11 @@ def _two_pass():
 
 def _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far):
     """(rgb, disp, acc, saved tensors for the backward)."""
+    if eng.width != 128:
+        # the register-resident gradient kernels (and their saved state) are netwidth 128: other widths render as usual and the
+        # backward is the stateless generic-width gradient, which recomputes the forward layer by layer in exact fp32
+        rgb, disp, acc, _ = eng.render_rays(o, d, hist, Nc, Ni, near, far)
+        return rgb, disp, acc, (o, d, v, hist, torch.tensor([Nc, Ni, near, far], dtype=torch.float64))
     if _two_pass():
         rgb, disp, acc, z, raw, masks = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION,
                                                              with_masks=True)
@@ -73,6 +78,10 @@ def _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far):
 
 
 def _saved_backward(eng, saved, g_rgb):
+    if len(saved) == 5:   # generic width: (rays, viewdirs = d / |d|, histograms, [Nc, Ni, near, far])
+        o, d, _, hist, cfg = saved
+        Nc, Ni, near, far = cfg.tolist()
+        return eng.render_rays_backward(o, d, hist, int(Nc), int(Ni), near, far, g_rgb.contiguous(), precision="generic")
     o, d, v, hist, z, raw = saved[:6]
     masks = saved[6] if len(saved) > 6 else None
     return eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION, masks=masks)

@@ -334,3 +334,21 @@ def test_generic_width_render_gradient_vs_oracle(width):
     ec = relmax(gc, ref_c)
     print(f"netwidth {width}: d c2w {ec:.2e}")
     assert ec < 5e-3
+
+
+def test_render_autograd_at_netwidth_32():
+    """rendering.render under autograd with a netwidth-32 NeRF-H (the DFNet_dm call shape, direct_feature_matching.py:342-349):
+    loss.backward() reaches the pose through the generic-width gradient; checked against autograd through the oracle."""
+    from dfnet_amd import rendering
+    from dfnet_amd.nerfw import HipQuery
+    E, mods, (cw, fw, ea, et) = modules(W=32, seed=4)
+    kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=False,
+              raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    H, W, focal = 12, 16, 14.6
+    pose = T(syn.orbit_pose(5, 8))[:3, :4].to(DEV).requires_grad_(True)
+    Gi = T(np.random.default_rng(2).standard_normal((H, W, 3)).astype(np.float32))
+    rgb = rendering.render(H, W, focal, c2w=pose, img_idx=T(syn.HIST_IDX).to(DEV), **kw)[0]
+    (rgb * Gi.to(DEV)).sum().backward()
+    c, f = {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}
+    ref_rgb, ref = orc.render_grad_c2w(H, W, focal, pose.detach().cpu(), Gi, c, f, T(ea), T(et), 64, 128, 0., 2.5, syn.HIST_IDX)
+    assert relmax(rgb, ref_rgb) < 3e-5 and relmax(pose.grad, ref) < 5e-3
