@@ -127,6 +127,8 @@ static void free_packed(dfn_nerfh_s* h) {
 extern "C" int dfn_nerfh_destroy(dfn_nerfh_t h) {
   if (!h) return DFN_OK;
   free_packed(h);
+  for (hipEvent_t e : h->side_ev) if (e) (void)hipEventDestroy(e);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
   delete h;
   return DFN_OK;
 }

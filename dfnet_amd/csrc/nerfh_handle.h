@@ -31,5 +31,9 @@ struct dfn_nerfh_s {
   // order of dfn_nerfh_train_param_name(); one allocation.
   float* gen_blob = nullptr;
   std::vector<const float*> gen_params;
+  // Training step: the coarse network's backward runs beside the fine one's on this stream (created on first use), fenced by the
+  // two events (nerfh_train_api.hip: dfn_nerfh_train_backward).
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_ev[2] = {nullptr, nullptr};
 };
 

@@ -96,6 +96,7 @@ struct TrainWs {
   float *z_c, *pe_c, *h_c[8], *fin_c, *dirh_c, *raw_c;  // coarse, per point
   float *z_f, *pe_f, *h_f[8], *fin_f, *dirh_f, *te[4];  // fine, per point
   float *gpre_f, *gpre_c, *gA, *gB, *gfin, *gt0, *gt1, *gsum, *gray, *wscratch;  // backward
+  float *gA_c, *gB_c, *gfin_c, *gt0_c, *gsum_c, *gray_c, *wscratch_c;             // the coarse net's own scratch (it runs beside the fine one)
   size_t total;
 };
 TrainWs carve_train(float* base, const Dims& m, size_t R, int Nc, int Ni, bool with_backward) {
@@ -131,6 +132,13 @@ TrainWs carve_train(float* base, const Dims& m, size_t R, int Nc, int Ni, bool w
     w.gray = take(R * size_t(m.ld_df > m.ld_t ? m.ld_df : m.ld_t));
     const int kmax = m.W + kChXyz;
     w.wscratch = take(gemm_wgrad_scratch_floats(m.W, kmax > m.W ? m.W : kmax, (long long)Pf) + 1024);
+    w.gA_c = take(Pc * m.W);
+    w.gB_c = take(Pc * m.W);
+    w.gfin_c = take(Pc * m.W);
+    w.gt0_c = take(Pc * m.W2);
+    w.gsum_c = take(R * m.W2);
+    w.gray_c = take(R * size_t(m.ld_dc));
+    w.wscratch_c = take(gemm_wgrad_scratch_floats(m.W, kmax > m.W ? m.W : kmax, (long long)Pc) + 1024);
   }
   w.total = off * sizeof(float);
   return w;
@@ -357,12 +365,24 @@ extern "C" int dfn_nerfh_train_backward(dfn_nerfh_t h, const float* const* param
   CHECK_HIP(composite_fine_backward_train(raw, w.z_f, g_rgb, g_beta, g_tsigma, g_tsigma_dense, R, Nf, w.gpre_f, s), "train backward: fine composite");
   CHECK_HIP(composite_coarse_backward(w.raw_c, w.z_c, noise, raw_noise_std, g_rgb0, R, Nc, w.gpre_c, s), "train backward: coarse composite");
   BwdBufs gf{w.gpre_f, w.gA, w.gB, w.gfin, w.gt0, w.gt1, w.gsum, w.gray, w.wscratch};
-  BwdBufs gc{w.gpre_c, w.gA, w.gB, w.gfin, w.gt0, w.gt1, w.gsum, w.gray, w.wscratch};
+  BwdBufs gc{w.gpre_c, w.gA_c, w.gB_c, w.gfin_c, w.gt0_c, nullptr, w.gsum_c, w.gray_c, w.wscratch_c};
+  // The two networks' backward passes share nothing (z_samples.detach(), rendering.py:302): the coarse one — a third of the points,
+  // 1.5 tiles per persistent workgroup, its launches half-empty in their second round — runs on a side stream beside the fine one.
+  if (!h->side_stream) {
+    CHECK_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking), "train backward: side stream");
+    for (hipEvent_t& e : h->side_ev) CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), "train backward: event");
+  }
+  CHECK_HIP(hipEventRecord(h->side_ev[0], s), "train backward: fork");
+  CHECK_HIP(hipStreamWaitEvent(h->side_stream, h->side_ev[0], 0), "train backward: fork");
+  if (int rc = net_backward(net_of(params, grads, false), m, bufs_of(w, m, false, nullptr, R, Nc, Ni), gc, false, hist, hist_rows, nullptr,
+                            nullptr, R, h->side_stream))
+    return rc;
+  CHECK_HIP(hipEventRecord(h->side_ev[1], h->side_stream), "train backward: join");
   if (int rc = net_backward(net_of(params, grads, true), m, bufs_of(w, m, true, const_cast<float*>(raw), R, Nc, Ni), gf, true, hist,
                             hist_rows, g_emb_a, g_emb_t, R, s))
     return rc;
-  return net_backward(net_of(params, grads, false), m, bufs_of(w, m, false, nullptr, R, Nc, Ni), gc, false, hist, hist_rows, nullptr,
-                      nullptr, R, s);
+  CHECK_HIP(hipStreamWaitEvent(s, h->side_ev[1], 0), "train backward: join");
+  return DFN_OK;
 }
 
 // ------------------------------------------------------------------------------------------ generic-width test-time render
