@@ -47,6 +47,28 @@ def timed(fn):
 from dfnet_amd import rendering
 if os.environ.get("DM_ONLY"):   # profiling aid: only the full optimisation step (rocprofv3 --stats then shows one step's kernels x iters)
     opt = torch.optim.Adam(model.parameters(), lr=1e-7)
+    if os.environ.get("DM_TRACE"):   # where the memcpys of a STEADY-STATE step come from (three warm steps first)
+        import collections
+        from torch.profiler import profile, ProfilerActivity
+        step = lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+        c = collections.Counter()
+        for e in prof.events():
+            if "emcpy" in e.name and e.cpu_parent is not None or e.name.startswith("hipMemcpy"):
+                names, p = [], e.cpu_parent
+                while p is not None and len(names) < 5:
+                    names.append(p.name); p = p.cpu_parent
+                st = [x for x in (e.stack or []) if "dfnet_amd" in x or "tools/" in x][:2]
+                c[(e.name[:28], " < ".join(names)[:150], " | ".join(st)[:200])] += 1
+        for k, v in c.most_common(40):
+            print(v / 2, k)
+        sys.exit(0)
     ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
     print(json.dumps({"full_step_ms": ms, "iters_profiled": iters + 1}))
     sys.exit(0)
