@@ -240,12 +240,14 @@ class _DFNetBase(nn.Module):
             sd = dict(list(self.named_parameters()) + list(self.named_buffers()))
             pose_names, names = self._pose_param_names(), self._refresh_names()
             on_gpu = all(sd[k].is_cuda for k in names)
-            if train and on_gpu and all(k in names or k.endswith("num_batches_tracked") for k in changed):
+            if on_gpu and changed and changed <= set(pose_names) and (train or not self._folded_stale):
+                # an optimizer step of DFNet_dm moves the regressor's 28 tensors only: re-pack those (the train-mode re-pack below
+                # would redo the adaptation layers and copy the BatchNorm blocks too: 24 kernels and 12 copies per step)
+                self._engine.refresh_pose_params_device([sd[k].detach() for k in pose_names])
+            elif train and on_gpu and all(k in names or k.endswith("num_batches_tracked") for k in changed):
                 self._engine.refresh_train_params_device([sd[k].detach() for k in names])
                 self._bn_stats_stale = False
                 self._folded_stale = self._folded_stale or not changed <= set(pose_names)   # folded: adaptation layers only
-            elif not train and not self._folded_stale and on_gpu and changed <= set(pose_names):
-                self._engine.refresh_pose_params_device([sd[k].detach() for k in pose_names])
             else:
                 self._commit_from_host()
         elif not train and self._folded_stale:
