@@ -219,16 +219,25 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
   return;
 #endif
   if constexpr (P::kSplit) {
+    // two values per conversion (v_cvt_pkrtz_f16_f32): hi is the TRUNCATED f16 of the scaled value — any f16 within an ulp will do,
+    // the lo half takes the exact remainder — so a pair costs 2 packed converts + 2 mixed-precision subtractions
+    typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
+    const float os = oscale * kX3ActScale;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v = acc[8 * c + j] * oscale;      // true value
-        if (RELU) v = fmaxf(v, 0.f);
-        _Float16 hi, lo;
-        x3_split(v, hi, lo);
-        out[2 * mb + c].hi[j] = hi;
-        out[2 * mb + c].lo[j] = lo;
+      for (int j = 0; j < 8; j += 2) {
+        float x0 = acc[8 * c + j] * os, x1 = acc[8 * c + j + 1] * os;      // true values x the operand scale (one power-of-two product)
+        if (RELU) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+        const pk2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+        // remainders x - hi in fp32 with the f16 halves read in place (v_fma_mix_f32; hipcc converts and subtracts otherwise)
+        const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+        const pk2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        out[2 * mb + c].hi[j] = (_Float16)h[0]; out[2 * mb + c].hi[j + 1] = (_Float16)h[1];
+        out[2 * mb + c].lo[j] = (_Float16)l[0]; out[2 * mb + c].lo[j + 1] = (_Float16)l[1];
       }
   } else if constexpr (P::kSlotsPerChunk == 8) {
 #pragma unroll
