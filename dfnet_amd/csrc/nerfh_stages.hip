@@ -151,26 +151,26 @@ __global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const f
   const int sub = shared ? threadIdx.x >> 6 : threadIdx.x >> 7;
   const int o = shared ? threadIdx.x & 63 : threadIdx.x & 127;
   float* my_in = s_in + sub * stride_in;
+  __syncthreads();   // weights (and the shared-histogram base) staged
   for (size_t base = size_t(blockIdx.x) * rpb; base < n_rays; base += size_t(gridDim.x) * rpb) {
-    __syncthreads();
+    // shared histogram: a ray is ONE wave's work (its inputs live in the wave's own LDS slice), so the waves of a block run free of
+    // each other; per-ray histograms: two waves share a ray's inputs and meet at the block barrier
+    if (shared) wave_sync(); else __syncthreads();
     const size_t ray = base + sub;
     const bool ok = ray < n_rays;
     if (ok) {
-      if (o < 3) {  // pe_dir (27): [v, sin(2^k v), cos(2^k v)]
-        const float v = viewdirs[ray * 3 + o];
-        my_in[o] = v;
-        for (int k = 0; k < kLdir; ++k) {
-          const float f = float(1 << k);
-          my_in[3 + 6 * k + o] = sinf(v * f);
-          my_in[3 + 6 * k + 3 + o] = cosf(v * f);
-        }
+      if (o < 6 * kLdir) {  // pe_dir (27): [v, sin(2^k v), cos(2^k v)] — one lane per (coordinate, octave, sin | cos)
+        const int coord = o % 3, k = (o / 3) % kLdir, is_cos = o / (3 * kLdir);
+        const float v = viewdirs[ray * 3 + coord], arg = v * float(1 << k);
+        if (o < 3) my_in[o] = v;
+        my_in[3 + 6 * k + 3 * is_cos + coord] = is_cos ? cosf(arg) : sinf(arg);
       }
       if (!shared) {
         const float* hrow = hist + ray * w.hist_bin;
         for (int i = o; i < na + nt; i += 128) gather(hrow, my_in, i);
       }
     }
-    __syncthreads();
+    if (shared) wave_sync(); else __syncthreads();
     if (ok) {
       auto put = [&](int tbl, int f, float v) {
         const int mb = f >> 5, row = f & 31;
