@@ -15,6 +15,7 @@ DFN_PREC_F16X3 = 2  # DFNet only: split-f16 (fp32-grade results at f16 MFMA rate
 PRECISIONS = {"f16": DFN_PREC_F16, "fp16": DFN_PREC_F16, "f32": DFN_PREC_F32, "fp32": DFN_PREC_F32, "f16x3": DFN_PREC_F16X3}
 
 COMP_TEST_TIME, COMP_STATIC_ONLY, COMP_WHITE_BKGD = 1, 2, 4
+RENDER_LINDISP = 1
 
 
 class DfnError(RuntimeError):
@@ -35,6 +36,9 @@ SIGNATURES = {
     "dfn_nerfh_destroy": (c_int, [_P]),
     "dfn_nerfh_set_param": (c_int, [_P, c_char_p, _P, c_size_t]),
     "dfn_nerfh_commit": (c_int, [_P]),
+    "dfn_nerfh_set_render_options": (c_int, [_P, c_int]),
+    "dfn_ndc_rays": (c_int, [c_int, c_int, c_float, c_float, _P, _P, c_size_t, _P, _P, _P]),
+    "dfn_sample_fine_opt": (c_int, [_P, c_size_t, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
     "dfn_raygen": (c_int, [c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "dfn_posenc": (c_int, [_P, c_size_t, c_int, c_int, _P, _P]),
     "dfn_mlp_coarse": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_float, c_float, _P, _P]),

@@ -405,6 +405,13 @@ int upload(const void* src, size_t bytes, void** dst) {
 
 }  // namespace
 
+extern "C" int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_render_options: null handle");
+  if (flags & ~DFN_RENDER_LINDISP) return set_error(DFN_ERR_UNSUPPORTED, "dfn_nerfh_set_render_options: unknown option bits 0x%x", flags);
+  h->render_flags = flags;
+  return DFN_OK;
+}
+
 extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_commit: null handle");
   for (const auto& kv : expected_shapes(h->desc))
@@ -657,7 +664,8 @@ extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, cons
   if (!n_rays) return DFN_OK;
   if (!rays_o || !rays_d || !sigma || Nc < 1) return set_error(DFN_ERR_ARG, "dfn_mlp_coarse: bad argument");
   const PackedNet& n = h->net[0][prec][mlp_variant_of(h)];
-  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr, n.in_scale};
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr, n.in_scale,
+            h->render_flags & DFN_RENDER_LINDISP};
   ScopedTimer t(0, HS(stream));
   CHECK_HIP(launch_mlp(false, prec, mlp_variant_of(h), a, device_cu_count(), HS(stream), h->desc.width), "dfn_mlp_coarse");
   return DFN_OK;
@@ -677,12 +685,27 @@ extern "C" int dfn_sample_pdf(const float* bins, const float* weights, size_t n,
   return DFN_OK;
 }
 
-extern "C" int dfn_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
-                               float* z_fine, float* weights_coarse, float* z_samples, void* stream) {
+extern "C" int dfn_sample_fine_opt(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far, int render_flags,
+                                   float* z_fine, float* weights_coarse, float* z_samples, void* stream) {
   if (!sigma || !z_fine || Nc < 3 || Ni < 1 || 6 * Nc + 2 * Ni > 8192)
     return set_error(DFN_ERR_ARG, "dfn_sample_fine: bad argument (need N_samples >= 3, N_importance >= 1)");
-  CHECK_HIP(launch_sample_fine(sigma, n_rays, Nc, Ni, near, far, z_fine, weights_coarse, z_samples, HS(stream)),
+  if ((render_flags & DFN_RENDER_LINDISP) && !(near > 0.f))
+    return set_error(DFN_ERR_ARG, "dfn_sample_fine: lindisp needs near > 0");
+  CHECK_HIP(launch_sample_fine(sigma, n_rays, Nc, Ni, near, far, z_fine, weights_coarse, z_samples, HS(stream),
+                               render_flags & DFN_RENDER_LINDISP),
             "dfn_sample_fine");
+  return DFN_OK;
+}
+extern "C" int dfn_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
+                               float* z_fine, float* weights_coarse, float* z_samples, void* stream) {
+  return dfn_sample_fine_opt(sigma, n_rays, Nc, Ni, near, far, 0, z_fine, weights_coarse, z_samples, stream);
+}
+
+extern "C" int dfn_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, size_t n, float* out_o,
+                            float* out_d, void* stream) {
+  if (!n) return DFN_OK;
+  if (!rays_o || !rays_d || !out_o || !out_d || H < 1 || W < 1 || !(focal > 0.f)) return set_error(DFN_ERR_ARG, "dfn_ndc_rays: bad argument");
+  CHECK_HIP(launch_ndc_rays(H, W, focal, near, rays_o, rays_d, n, out_o, out_d, HS(stream)), "dfn_ndc_rays");
   return DFN_OK;
 }
 
@@ -781,13 +804,15 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
     float* raw = raw_out ? raw_out + r0 * size_t(Nf) * 9 : w.raw;
     {
-      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale};
+      MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale,
+                 h->render_flags & DFN_RENDER_LINDISP};
       ScopedTimer t(0, s);
       CHECK_HIP(launch_mlp(false, prec, var, a, cus, s, h->desc.width), "render: coarse MLP");
     }
     {
       ScopedTimer t(DFN_PROF_SAMPLE_FINE, s);
-      CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s), "render: sample_fine");
+      CHECK_HIP(launch_sample_fine(w.sigma, n, Nc, Ni, near, far, w.z, nullptr, nullptr, s, h->render_flags & DFN_RENDER_LINDISP),
+                "render: sample_fine");
     }
     {
       ScopedTimer t(DFN_PROF_RAY_BIAS, s);
@@ -981,9 +1006,11 @@ int render_backward_core(dfn_nerfh_t h, int prec, const float* o, const float* d
     const float* cd = d + r0 * 3;
     const float* cv = v + r0 * 3;
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
-    MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale};
+    MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale,
+                 h->render_flags & DFN_RENDER_LINDISP};
     CHECK_HIP(launch_mlp(false, prec, var, ac, cus, s, h->desc.width), "render backward: coarse MLP");
-    CHECK_HIP(launch_sample_fine(w.f.sigma, n, Nc, Ni, near, far, w.f.z, nullptr, nullptr, s), "render backward: sample_fine");
+    CHECK_HIP(launch_sample_fine(w.f.sigma, n, Nc, Ni, near, far, w.f.z, nullptr, nullptr, s, h->render_flags & DFN_RENDER_LINDISP),
+              "render backward: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.f.bias, s), "render backward: ray_bias");
     MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr, nf.in_scale};
     CHECK_HIP(launch_mlp(true, prec, var, af, cus, s, h->desc.width), "render backward: fine MLP");

@@ -31,9 +31,12 @@ DFN_DEV float unit_linspace(int i, int n) {
   const float step = n > 1 ? 1.f / float(n - 1) : 0.f;
   return i < n / 2 ? mul_rn(step, float(i)) : fmaf(-step, float(n - 1 - i), 1.f);
 }
-// z = near*(1-t) + far*t without FMA contraction (reference: models/rendering.py:269-271).
-DFN_DEV float coarse_z_at(int i, int n, float near, float far) {
+// z = near*(1-t) + far*t without FMA contraction; lindisp: z = 1/((1/near)(1-t) + (1/far) t), linear in disparity
+// (reference: models/rendering.py:269-273).
+DFN_DEV float coarse_z_at(int i, int n, float near, float far, bool lindisp = false) {
   const float t = unit_linspace(i, n);
+  if (lindisp)
+    return __fdiv_rn(1.f, add_rn(mul_rn(__fdiv_rn(1.f, near), sub_rn(1.f, t)), mul_rn(__fdiv_rn(1.f, far), t)));
   return add_rn(mul_rn(near, sub_rn(1.f, t)), mul_rn(far, t));
 }
 

@@ -33,6 +33,7 @@ struct dfn_nerfh_s {
   std::vector<const float*> gen_params;
   // Training step: the coarse network's backward runs beside the fine one's on this stream (created on first use), fenced by the
   // two events (nerfh_train_api.hip: dfn_nerfh_train_backward).
+  int render_flags = 0;    // DFN_RENDER_* options of every render entry point (dfn_nerfh_set_render_options)
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[2] = {nullptr, nullptr};
 };

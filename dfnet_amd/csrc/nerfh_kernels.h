@@ -21,6 +21,7 @@ struct MlpArgs {
   float near, far;
   unsigned long long* timing;  // DFN_TIMING builds: per-wave cycle counters [total, dma wait, barrier, tile inputs]
   float in_scale;          // split-f16 only: weight scale x activation scale carried by the accumulators (else 1)
+  int lindisp;             // coarse: depths linear in disparity instead of depth (rendering.py:272-273)
 };
 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width = 128);
@@ -29,6 +30,8 @@ hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_
 hipError_t launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
                          float* viewdirs, hipStream_t stream);
 hipError_t launch_viewdirs(const float* rays_d, size_t n, float* viewdirs, hipStream_t stream);
+hipError_t launch_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, size_t n, float* out_o,
+                           float* out_d, hipStream_t stream);
 hipError_t launch_posenc(const float* x, size_t n, int L, int mode, float* out, hipStream_t stream);
 
 struct RayBiasWeights {       // device pointers, fp32
@@ -49,7 +52,7 @@ hipError_t launch_coarse_weights(const float* sigma, const float* z, size_t n, i
 hipError_t launch_sample_pdf(const float* bins, const float* weights, size_t n, int nb, int Ni,
                              const float* u, float* out, hipStream_t stream);
 hipError_t launch_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
-                              float* z_fine, float* weights_coarse, float* z_samples, hipStream_t stream);
+                              float* z_fine, float* weights_coarse, float* z_samples, hipStream_t stream, int lindisp = 0);
 hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays, int Nf, float beta_min,
                                  int flags, float* rgb, float* disp, float* acc, float* depth,
                                  float* weights, float* beta, hipStream_t stream);

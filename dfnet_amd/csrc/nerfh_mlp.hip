@@ -75,7 +75,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
       const uint32_t q = uint32_t(pt[nb] < n_pts ? pt[nb] : n_pts - 1);
       const uint32_t ray = q / uint32_t(a.n_samples);
       const int i = int(q - ray * uint32_t(a.n_samples));
-      const float z = coarse_z_at(i, a.n_samples, a.near, a.far);
+      const float z = coarse_z_at(i, a.n_samples, a.near, a.far, a.lindisp != 0);
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         x[nb][c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], z));

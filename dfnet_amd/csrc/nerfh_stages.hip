@@ -74,6 +74,33 @@ hipError_t launch_viewdirs(const float* rays_d, size_t n, float* viewdirs, hipSt
   return hipGetLastError();
 }
 
+// Normalised device coordinates of forward-facing rays (models/ray_utils.py:27-46), operation by operation in the reference's
+// order: origins to the near plane, then o' = (sx ox/oz, sy oy/oz, 1 + 2 near/oz), d' = (sx (dx/dz - ox/oz), sy (dy/dz - oy/oz),
+// -2 near/oz) with sx = -1 / (W / (2 focal)), sy = -1 / (H / (2 focal)) (Python doubles there, rounded to fp32 at the multiply).
+__global__ __launch_bounds__(256) void ndc_rays_kernel(float sx, float sy, float near, const float* __restrict__ ro,
+                                                       const float* __restrict__ rd, size_t n, float* __restrict__ oo,
+                                                       float* __restrict__ od) {
+  for (size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x; r < n; r += size_t(gridDim.x) * blockDim.x) {
+    const float dx = rd[r * 3], dy = rd[r * 3 + 1], dz = rd[r * 3 + 2];
+    const float t = __fdiv_rn(-add_rn(near, ro[r * 3 + 2]), dz);
+    const float ox = add_rn(ro[r * 3], mul_rn(t, dx)), oy = add_rn(ro[r * 3 + 1], mul_rn(t, dy)), oz = add_rn(ro[r * 3 + 2], mul_rn(t, dz));
+    const float two_n = mul_rn(2.f, near);
+    oo[r * 3] = __fdiv_rn(mul_rn(sx, ox), oz);
+    oo[r * 3 + 1] = __fdiv_rn(mul_rn(sy, oy), oz);
+    oo[r * 3 + 2] = add_rn(1.f, __fdiv_rn(two_n, oz));
+    od[r * 3] = mul_rn(sx, sub_rn(__fdiv_rn(dx, dz), __fdiv_rn(ox, oz)));
+    od[r * 3 + 1] = mul_rn(sy, sub_rn(__fdiv_rn(dy, dz), __fdiv_rn(oy, oz)));
+    od[r * 3 + 2] = __fdiv_rn(-two_n, oz);
+  }
+}
+hipError_t launch_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, size_t n, float* out_o,
+                           float* out_d, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  const float sx = float(-1. / (double(W) / (2. * double(focal)))), sy = float(-1. / (double(H) / (2. * double(focal))));
+  hipLaunchKernelGGL(ndc_rays_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, sx, sy, near, rays_o, rays_d, n, out_o, out_d);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ posenc (test entry)
 __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x, size_t n, int L, int mode,
                                                      float* __restrict__ out) {
@@ -335,7 +362,7 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, size_t n, 
 // rank merge of two sorted lists; ties: coarse depth first, so the result is always a permutation).
 __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ sigma, size_t n_rays, int Nc, int Ni,
                                                           float near, float far, float* __restrict__ z_fine,
-                                                          float* __restrict__ weights_out, float* __restrict__ zs_out) {
+                                                          float* __restrict__ weights_out, float* __restrict__ zs_out, int lindisp) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Nf = Nc + Ni;
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     if (lane < Nc) s_sig[lane] = sig_next;
     for (int i = lane; i < Nc; i += 64) {
       if (i >= 64) s_sig[i] = sigma[ray * Nc + i];
-      s_all[i] = coarse_z_at(i, Nc, near, far);
+      s_all[i] = coarse_z_at(i, Nc, near, far, lindisp != 0);
     }
     if (ray + stride < n_rays && lane < Nc) sig_next = sigma[(ray + stride) * Nc + lane];
     for (int i = Nf + lane; i < NfP; i += 64) s_all[i] = __builtin_inff();
@@ -391,16 +418,15 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     int* hist = reinterpret_cast<int*>(s_sig);       // [Nc + 1] over s_sig | s_w (both dead: the weights were written above)
     for (int i = lane; i <= Nc; i += 64) hist[i] = 0;
     wave_sync();
-    const float cell = float(Nc - 1) / (far - near);
+    // (lindisp: the grid is uniform in 1/z)
+    const float g0 = lindisp ? 1.f / near : near, g1 = lindisp ? 1.f / far : far;
+    const float cell = float(Nc - 1) / (g1 - g0);
     for (int j = lane; j < Ni; j += 64) {
       const float v = zs[j];
-      int c = int(floorf((v - near) * cell)) + 1;
+      int c = int(floorf(((lindisp ? 1.f / v : v) - g0) * cell)) + 1;
       c = c < 0 ? 0 : (c > Nc ? Nc : c);
-#pragma unroll
-      for (int fix = 0; fix < 2; ++fix) {
-        if (c < Nc && s_all[c] <= v) ++c;
-        if (c > 0 && s_all[c - 1] > v) --c;
-      }
+      while (c < Nc && s_all[c] <= v) ++c;           // exact against the stored depths (the estimate is within a cell)
+      while (c > 0 && s_all[c - 1] > v) --c;
       s_out[j + c] = v;
       atomicAdd(&hist[c], 1);
     }
@@ -423,13 +449,13 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
   }
 }
 hipError_t launch_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
-                              float* z_fine, float* weights_coarse, float* z_samples, hipStream_t stream) {
+                              float* z_fine, float* weights_coarse, float* z_samples, hipStream_t stream, int lindisp) {
   if (!n_rays) return hipSuccess;
   const int Nf = Nc + Ni, NfP = (Nf + 3) & ~3;
   int per = 4 * Nc + NfP + Nf;
   per = (per + 3) & ~3;
   hipLaunchKernelGGL(sample_fine_kernel, dim3(grid_for((n_rays + 3) / 4, 1)), dim3(256), size_t(4) * per * 4, stream,
-                     sigma, n_rays, Nc, Ni, near, far, z_fine, weights_coarse, z_samples);
+                     sigma, n_rays, Nc, Ni, near, far, z_fine, weights_coarse, z_samples, lindisp);
   return hipGetLastError();
 }
 

@@ -43,8 +43,9 @@ hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW
                       long long P, hipStream_t s);
 
 // ---- stages
-// z[r, i] = lower + (upper - lower) * t_rand (rendering.py:277-285); t_rand == nullptr: the plain linspace depths.
-hipError_t stratified_z(const float* t_rand, size_t R, int Nc, float near, float far, float* z, hipStream_t s);
+// z[r, i] = lower + (upper - lower) * t_rand (rendering.py:277-285); t_rand == nullptr: the plain linspace depths; lindisp: the
+// depths are linear in disparity (rendering.py:272-273).
+hipError_t stratified_z(const float* t_rand, size_t R, int Nc, float near, float far, float* z, hipStream_t s, int lindisp = 0);
 // pe[p, 0..63) = positional encoding (L = 10) of o + d z; column 63 zero.  [P][64].
 hipError_t posenc_points(const float* rays_o, const float* rays_d, const float* z, size_t R, int Ns, float* pe, hipStream_t s);
 // per-ray inputs: dir_in[r][0..27) = pe_dir(viewdir) (L = 4), then a = embedding_a[hist] (hist_bin*dim_a) when emb_a != nullptr;

@@ -763,21 +763,22 @@ hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW
 
 // ------------------------------------------------------------------------------------------ depths / encodings
 __global__ __launch_bounds__(256) void stratified_z_kernel(const float* __restrict__ t_rand, size_t R, int Nc, float near, float far,
-                                                           float* __restrict__ z) {
+                                                           float* __restrict__ z, int lindisp) {
   const size_t n = R * size_t(Nc);
   for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
     const int i = int(e % Nc);
-    const float zi = coarse_z_at(i, Nc, near, far);
+    const bool ld = lindisp != 0;
+    const float zi = coarse_z_at(i, Nc, near, far, ld);
     if (!t_rand) { z[e] = zi; continue; }
-    const float zm = i > 0 ? coarse_z_at(i - 1, Nc, near, far) : zi, zp = i + 1 < Nc ? coarse_z_at(i + 1, Nc, near, far) : zi;
+    const float zm = i > 0 ? coarse_z_at(i - 1, Nc, near, far, ld) : zi, zp = i + 1 < Nc ? coarse_z_at(i + 1, Nc, near, far, ld) : zi;
     const float lower = i > 0 ? mul_rn(.5f, add_rn(zi, zm)) : zi;          // cat([z[:1], mids])
     const float upper = i + 1 < Nc ? mul_rn(.5f, add_rn(zp, zi)) : zi;      // cat([mids, z[-1:]])
     z[e] = add_rn(lower, mul_rn(sub_rn(upper, lower), t_rand[e]));
   }
 }
-hipError_t stratified_z(const float* t_rand, size_t R, int Nc, float near, float far, float* z, hipStream_t s) {
+hipError_t stratified_z(const float* t_rand, size_t R, int Nc, float near, float far, float* z, hipStream_t s, int lindisp) {
   if (!R) return hipSuccess;
-  hipLaunchKernelGGL(stratified_z_kernel, dim3(grid_for(R * Nc, 256)), dim3(256), 0, s, t_rand, R, Nc, near, far, z);
+  hipLaunchKernelGGL(stratified_z_kernel, dim3(grid_for(R * Nc, 256)), dim3(256), 0, s, t_rand, R, Nc, near, far, z, lindisp);
   return hipGetLastError();
 }
 

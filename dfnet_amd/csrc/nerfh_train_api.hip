@@ -320,7 +320,7 @@ extern "C" int dfn_nerfh_train_forward(dfn_nerfh_t h, const float* const* params
   CHECK_HIP(ray_inputs(w.view, hist, hist_rows, emb_a, emb_t, m.hist_bin, m.dim_a, m.dim_t, m.n_vocab, R, w.dir_f, m.ld_df, w.t_in,
                        m.ld_t, s),
             "train forward: fine ray inputs");
-  CHECK_HIP(stratified_z(t_rand, R, Nc, near, far, w.z_c, s), "train forward: stratified z");
+  CHECK_HIP(stratified_z(t_rand, R, Nc, near, far, w.z_c, s, h->render_flags & DFN_RENDER_LINDISP), "train forward: stratified z");
   CHECK_HIP(posenc_points(rays_o, rays_d, w.z_c, R, Nc, w.pe_c, s), "train forward: coarse encoding");
   if (int rc = net_forward(nc, m, bufs_of(w, m, false, nullptr, R, Nc, Ni), false, false, s)) return rc;
   CHECK_HIP(sample_fine_train(w.raw_c, w.z_c, noise, raw_noise_std, u, R, Nc, Ni, w.z_f, rgb0, disp0, acc0, z_std, s),
@@ -413,13 +413,13 @@ extern "C" int dfn_nerfh_generic_render_rays(dfn_nerfh_t h, const float* rays_o,
   CHECK_HIP(ray_inputs(w.view, hist, hist_rows, params[kCoarseParams + kFineParams], params[kCoarseParams + kFineParams + 1], m.hist_bin,
                        m.dim_a, m.dim_t, m.n_vocab, R, w.dir_f, m.ld_df, w.t_in, m.ld_t, s),
             "generic render: ray inputs");
-  CHECK_HIP(stratified_z(nullptr, R, Nc, near, far, w.z_c, s), "generic render: z");
+  CHECK_HIP(stratified_z(nullptr, R, Nc, near, far, w.z_c, s, h->render_flags & DFN_RENDER_LINDISP), "generic render: z");
   CHECK_HIP(posenc_points(rays_o, rays_d, w.z_c, R, Nc, w.pe_c, s), "generic render: coarse encoding");
   NetBufs bc = bufs_of(w, m, false, nullptr, R, Nc, Ni);
   bc.raw = sigma;   // sigma only: [R, Nc]
   bc.raw_ld = 1;
   if (int rc = net_forward(nc, m, bc, false, true, s)) return rc;
-  CHECK_HIP(launch_sample_fine(sigma, R, Nc, Ni, near, far, w.z_f, nullptr, nullptr, s), "generic render: sample_fine");
+  CHECK_HIP(launch_sample_fine(sigma, R, Nc, Ni, near, far, w.z_f, nullptr, nullptr, s, h->render_flags & DFN_RENDER_LINDISP), "generic render: sample_fine");
   CHECK_HIP(posenc_points(rays_o, rays_d, w.z_f, R, Nf, w.pe_f, s), "generic render: fine encoding");
   if (int rc = net_forward(nf, m, bufs_of(w, m, true, raw, R, Nc, Ni), true, false, s)) return rc;
   CHECK_HIP(launch_composite_fine(raw, w.z_f, R, Nf, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb, disp, acc, nullptr, nullptr,
@@ -485,13 +485,13 @@ extern "C" int dfn_nerfh_generic_render_rays_backward(dfn_nerfh_t h, const float
   CHECK_HIP(ray_inputs(v, hist, hist_rows, params[kCoarseParams + kFineParams], params[kCoarseParams + kFineParams + 1], m.hist_bin,
                        m.dim_a, m.dim_t, m.n_vocab, R, w.dir_f, m.ld_df, w.t_in, m.ld_t, s),
             "generic render gradient: ray inputs");
-  CHECK_HIP(stratified_z(nullptr, R, Nc, near, far, w.z_c, s), "generic render gradient: z");
+  CHECK_HIP(stratified_z(nullptr, R, Nc, near, far, w.z_c, s, h->render_flags & DFN_RENDER_LINDISP), "generic render gradient: z");
   CHECK_HIP(posenc_points(rays_o, rays_d, w.z_c, R, Nc, w.pe_c, s), "generic render gradient: coarse encoding");
   NetBufs bc = bufs_of(w, m, false, nullptr, R, Nc, Ni);
   bc.raw = g.sigma;
   bc.raw_ld = 1;
   if (int rc = net_forward(nc, m, bc, false, true, s)) return rc;
-  CHECK_HIP(launch_sample_fine(g.sigma, R, Nc, Ni, near, far, w.z_f, nullptr, nullptr, s), "generic render gradient: sample_fine");
+  CHECK_HIP(launch_sample_fine(g.sigma, R, Nc, Ni, near, far, w.z_f, nullptr, nullptr, s, h->render_flags & DFN_RENDER_LINDISP), "generic render gradient: sample_fine");
   CHECK_HIP(posenc_points(rays_o, rays_d, w.z_f, R, Nf, w.pe_f, s), "generic render gradient: fine encoding");
   const NetBufs b = bufs_of(w, m, true, g.raw, R, Nc, Ni);
   if (int rc = net_forward(nf, m, b, true, false, s)) return rc;

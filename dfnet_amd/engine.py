@@ -31,6 +31,16 @@ class NerfHEngine:
         self.width = width
         self.fast = width in (128, 256)   # register-resident MFMA kernels; other widths run the generic layer-by-layer fp32 path
         self._ws = None
+        self.lindisp = False
+
+    def set_render_options(self, lindisp=False):
+        """render_rays keyword options that every entry point of this handle applies (dfn_nerfh_set_render_options):
+        lindisp = coarse depths linear in disparity (rendering.py:272-273)."""
+        lindisp = bool(lindisp)
+        if lindisp != self.lindisp:
+            check(self.lib.dfn_nerfh_set_render_options(self.handle, _lib.RENDER_LINDISP if lindisp else 0), "dfn_nerfh_set_render_options")
+            self.lindisp = lindisp
+        return self
 
     def __del__(self):
         try:
@@ -204,7 +214,7 @@ class NerfHEngine:
         in split-f16 and records its ReLU signs, so the backward needs no forward pass of its own at all."""
         rays_o, rays_d, viewdirs = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3), _f32c(viewdirs).reshape(-1, 3)
         sigma = self.mlp_coarse(rays_o, rays_d, Nc, near, far, precision)
-        z = sample_fine(sigma, Ni, near, far)
+        z = sample_fine(sigma, Ni, near, far, lindisp=self.lindisp)
         if with_masks:
             raw, masks = self.mlp_fine_saving(rays_o, rays_d, viewdirs, hist, z)
             out = composite_fine(raw, z)
@@ -553,15 +563,25 @@ def sample_pdf(bins, weights, Ni, u=None):
     return out
 
 
-def sample_fine(sigma, Ni, near, far, want_aux=False):
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """ray_utils.ndc_rays (models/ray_utils.py:27-46) on the device: (rays_o, rays_d) in normalised device coordinates."""
+    lib = _lib.load()
+    o, d = _f32c(rays_o), _f32c(rays_d)
+    oo, od = torch.empty_like(o), torch.empty_like(d)
+    check(lib.dfn_ndc_rays(int(H), int(W), float(focal), float(near), ptr(o), ptr(d), o.numel() // 3, ptr(oo), ptr(od), current_stream()),
+          "dfn_ndc_rays")
+    return oo, od
+
+
+def sample_fine(sigma, Ni, near, far, want_aux=False, lindisp=False):
     lib = _lib.load()
     sigma = _f32c(sigma)
     n, Nc = sigma.shape
     z = torch.empty(n, Nc + Ni, device=sigma.device)
     w = torch.empty(n, Nc, device=sigma.device) if want_aux else None
     zs = torch.empty(n, Ni, device=sigma.device) if want_aux else None
-    check(lib.dfn_sample_fine(ptr(sigma), n, Nc, Ni, float(near), float(far), ptr(z), ptr(w), ptr(zs),
-                              current_stream()), "dfn_sample_fine")
+    check(lib.dfn_sample_fine_opt(ptr(sigma), n, Nc, Ni, float(near), float(far), _lib.RENDER_LINDISP if lindisp else 0, ptr(z), ptr(w),
+                                  ptr(zs), current_stream()), "dfn_sample_fine")
     return (z, w, zs) if want_aux else z
 
 

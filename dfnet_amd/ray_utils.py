@@ -11,3 +11,12 @@ def get_rays(H, W, focal, c2w):
     c2w = torch.as_tensor(c2w, dtype=torch.float32, device=dev)
     o, d, _ = _engine.raygen(int(H), int(W), float(focal), c2w, want_viewdirs=False)
     return o, d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """Forward-facing rays in normalised device coordinates (ray_utils.py:27-46); same shapes as the inputs."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    o = torch.as_tensor(rays_o, dtype=torch.float32, device=dev)
+    d = torch.as_tensor(rays_d, dtype=torch.float32, device=dev)
+    no, nd = _engine.ndc_rays(H, W, focal, near, o.reshape(-1, 3), d.reshape(-1, 3))
+    return no.reshape(o.shape), nd.reshape(d.shape)

@@ -8,8 +8,10 @@ frame-sharded loop with one gather when torch.distributed is initialised (dfnet_
 
 Test-time kwargs (`render_kwargs_test`: perturb=0, raw_noise_std=0, test_time=True) run on the packed MFMA engine;
 training kwargs (`render_kwargs_train`: test_time=False, perturb, raw_noise_std) run on the exact-fp32 training kernels and
-return tensors attached to autograd with the reference's extras (dfnet_amd/nerf_train.py).  Unsupported options (ndc,
-white_bkgd, lindisp, ...) raise NotImplementedError rather than falling back.
+return tensors attached to autograd with the reference's extras (dfnet_amd/nerf_train.py).  `lindisp` works everywhere; `ndc`
+and `c2w_staticcam` at test time without autograd (their only use in the reference: LLFF-style visualisation).  `white_bkgd=True`
+raises: it is not a working option of this path in the reference either (rendering.py:295 passes it to the coarse compositor as
+`output_transient`, which fails with a TypeError at test time and mis-slices the 4-channel coarse output in training).
 
 Autograd: when grad is enabled and `c2w` / `rays` require grad (the DFNet_dm step,
 feature/direct_feature_matching.py:340-376), `rgb_map` is returned attached to the graph through
@@ -28,7 +30,7 @@ import torch
 
 from . import dist as ddist
 from .nerfw import to8b
-from .ray_utils import get_rays  # noqa: F401  (re-exported like the reference's `from models.ray_utils import *`)
+from .ray_utils import get_rays, ndc_rays  # noqa: F401  (re-exported like the reference's `from models.ray_utils import *`)
 
 DEBUG = False
 
@@ -68,7 +70,7 @@ def _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far):
         # the register-resident gradient kernels (and their saved state) are netwidth 128: other widths render as usual and the
         # backward is the stateless generic-width gradient, which recomputes the forward layer by layer in exact fp32
         rgb, disp, acc, _ = eng.render_rays(o, d, hist, Nc, Ni, near, far)
-        return rgb, disp, acc, (o, d, v, hist, torch.tensor([Nc, Ni, near, far], dtype=torch.float64))
+        return rgb, disp, acc, (o, d, v, hist, torch.tensor([Nc, Ni, near, far, float(eng.lindisp)], dtype=torch.float64))
     if _two_pass():
         rgb, disp, acc, z, raw, masks = eng.render_rays_saving(o, d, v, hist, Nc, Ni, near, far, precision=GRAD_FORWARD_PRECISION,
                                                              with_masks=True)
@@ -80,7 +82,8 @@ def _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far):
 def _saved_backward(eng, saved, g_rgb):
     if len(saved) == 5:   # generic width: (rays, viewdirs = d / |d|, histograms, [Nc, Ni, near, far])
         o, d, _, hist, cfg = saved
-        Nc, Ni, near, far = cfg.tolist()
+        Nc, Ni, near, far, lindisp = cfg.tolist()
+        eng.set_render_options(lindisp=bool(lindisp))
         return eng.render_rays_backward(o, d, hist, int(Nc), int(Ni), near, far, g_rgb.contiguous(), precision="generic")
     o, d, v, hist, z, raw = saved[:6]
     masks = saved[6] if len(saved) > 6 else None
@@ -142,8 +145,9 @@ def render_frames(H, W, focal, c2ws, img_idx, **kwargs):
     """rgb [B,H,W,3] of B frames at poses c2ws [B,3,4] with histogram vectors img_idx [B,bins] — render(c2w=...) per frame,
     batched into one launch per stage, differentiable w.r.t. c2ws.  Same option checks as render()."""
     near, far = kwargs.pop('near', 0.), kwargs.pop('far', 1.)
-    _check_test_time(kwargs, kwargs.get('ndc', False), None, kwargs.get('use_viewdirs', True))
+    _check_test_time(kwargs, kwargs.get('ndc', False), None, kwargs.get('use_viewdirs', True), tracked=True)
     eng = _engine_of(kwargs)
+    _set_options(eng, kwargs, near)
     c2ws = c2ws[:, :3, :4]
     hists = torch.as_tensor(img_idx, dtype=torch.float32, device=c2ws.device).reshape(c2ws.shape[0], -1)
     return _RenderFramesFn.apply(c2ws, eng, int(H), int(W), float(focal), hists, int(kwargs['N_samples']), int(kwargs['N_importance']),
@@ -169,10 +173,21 @@ class _RenderRaysFn(torch.autograd.Function):
         return (go, gd) + (None,) * 6
 
 
-def _check_test_time(kw, ndc, c2w_staticcam, use_viewdirs, training=False):
+def _set_options(eng, kw, near):
+    """The render_rays keyword options the handle carries (lindisp, rendering.py:272-273)."""
+    lindisp = bool(kw.get('lindisp', False))
+    if lindisp and not float(near) > 0.:
+        raise ValueError("render(): lindisp=True needs near > 0 (the depths are 1 / ((1 - t) / near + t / far))")
+    eng.set_render_options(lindisp=lindisp)
+
+
+def _check_test_time(kw, ndc, c2w_staticcam, use_viewdirs, training=False, tracked=False):
     bad = []
-    if ndc:
-        bad.append("ndc=True (LLFF forward-facing rays)")
+    if kw.get('white_bkgd', False):
+        raise TypeError("render(): white_bkgd=True is not a working option of the NeRF-H path: the reference hands it to the coarse "
+                        "compositor as output_transient (models/rendering.py:295) and fails the same way")
+    if (ndc or c2w_staticcam is not None) and (training or tracked):
+        bad.append("ndc / c2w_staticcam together with " + ("training-mode rendering" if training else "autograd"))
     if not training:
         if not kw.get('test_time', False):
             bad.append("test_time=False without a trainer (render kwargs must come from create_nerf with gradient updates enabled)")
@@ -180,14 +195,8 @@ def _check_test_time(kw, ndc, c2w_staticcam, use_viewdirs, training=False):
             bad.append("perturb>0 at test time")
         if float(kw.get('raw_noise_std', 0.) or 0.) != 0.:
             bad.append("raw_noise_std!=0 at test time")
-    if kw.get('white_bkgd', False):
-        bad.append("white_bkgd")
-    if kw.get('lindisp', False):
-        bad.append("lindisp")
     if not use_viewdirs:
         bad.append("use_viewdirs=False")
-    if c2w_staticcam is not None:
-        bad.append("c2w_staticcam")
     if int(kw.get('N_importance', 0)) <= 0:
         bad.append("N_importance=0")
     if bad:
@@ -203,6 +212,7 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     or a stacked [2,N,3] tensor), outputs shaped like rays_d[..., :1].  `img_idx`: the 10-bin histogram
     index vector, shape [10], [1,10] or [N,10]."""
     eng = _engine_of(kwargs)
+    _set_options(eng, kwargs, near)
     trainer = getattr(kwargs.get('network_query_fn'), 'trainer', None)
     if not kwargs.get('test_time', False) and trainer is not None:
         # training mode (rendering.py:245-337 with test_time=False): stratified depths, coarse rgb + noise, importance sampling
@@ -226,16 +236,35 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         getattr(kwargs.get('network_query_fn'), '__dict__', {}).update(stale=True)
         return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), extras]
     kwargs.get('network_query_fn').refresh() if hasattr(kwargs.get('network_query_fn'), 'refresh') else None
-    _check_test_time(kwargs, ndc, c2w_staticcam, use_viewdirs)
     def _needs_grad(t):
         if torch.is_tensor(t):
             return t.requires_grad
         return isinstance(t, (tuple, list)) and any(_needs_grad(u) for u in t)
     track = torch.is_grad_enabled() and (_needs_grad(c2w) or _needs_grad(rays))
+    _check_test_time(kwargs, ndc, c2w_staticcam, use_viewdirs, tracked=track)
     Nc, Ni = int(kwargs['N_samples']), int(kwargs['N_importance'])
     retraw = bool(kwargs.get('retraw', False))
     dev = torch.device("cuda", torch.cuda.current_device())
     hist = torch.as_tensor(img_idx, dtype=torch.float32, device=dev)
+    if ndc or c2w_staticcam is not None:
+        # rendering.py:364-376: the view directions come from the given rays / pose; the rays themselves are then replaced by the
+        # static camera's and / or mapped to normalised device coordinates (ndc_rays at near = 1)
+        if c2w is not None:
+            rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w, dtype=torch.float32, device=dev))
+        else:
+            rays_o, rays_d = (torch.as_tensor(t, dtype=torch.float32, device=dev) for t in rays)
+        view = rays_d.reshape(-1, 3)
+        view = view / torch.norm(view, dim=-1, keepdim=True)
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w_staticcam, dtype=torch.float32, device=dev))
+        if ndc:
+            rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
+        hist = hist.reshape(-1, eng.hist_bin)
+        lead = list(rays_d.shape[:-1])
+        rgb, disp, acc, raw = eng.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), hist, Nc, Ni, near, far, viewdirs=view,
+                                              retraw=retraw)
+        extras = {'raw': raw.reshape(lead + list(raw.shape[1:]))} if retraw else {}
+        return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), extras]
     if c2w is not None:
         c2w = torch.as_tensor(c2w, dtype=torch.float32, device=dev)
         if track and not retraw and hist.numel() == eng.hist_bin:

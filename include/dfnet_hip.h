@@ -71,6 +71,12 @@ int dfn_nerfh_destroy(dfn_nerfh_t h);
 int dfn_nerfh_set_param(dfn_nerfh_t h, const char* name, const float* host, size_t numel);
 /* Pack all parameters into the MFMA fragment layouts and upload them (synchronous). */
 int dfn_nerfh_commit(dfn_nerfh_t h);
+/* Options of render_rays that the reference passes as keyword arguments (rendering.py:245-256), applied by every entry point
+ * that takes this handle until changed.  DFN_RENDER_LINDISP: the coarse depths are linear in disparity, z = 1 / ((1 - t) / near +
+ * t / far) (rendering.py:272-273; near must be > 0).  white_bkgd is not offered: in the reference it reaches the coarse compositor
+ * in the output_transient slot (rendering.py:295) and raises TypeError at test time. */
+enum { DFN_RENDER_LINDISP = 1 };
+int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags);
 
 /* ------------------------------------------------------------------ stage-level entry points
  * (each is the production kernel of that stage; exposed so parity tests can check a stage
@@ -80,6 +86,10 @@ int dfn_nerfh_commit(dfn_nerfh_t h);
  * row-major (12 floats).  Outputs [H*W,3] each; viewdirs may be NULL. */
 int dfn_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
                float* viewdirs, void* stream);
+/* models/ray_utils.py:27-46 ndc_rays (render(ndc=True), rendering.py:374-376, calls it with near = 1): rays_o / rays_d [n,3] of an
+ * H x W pinhole camera -> normalised device coordinates, out_o / out_d [n,3] (may alias the inputs). */
+int dfn_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, size_t n, float* out_o,
+                 float* out_d, void* stream);
 
 /* models/nerfw.py:105-133 Embedder.embed.  x [n,3] -> out [n, 3+6L].  mode 0 = full-range
  * sinf/cosf, 1 = the fast v_sin/v_cos path the f16 MLP kernels use. */
@@ -104,6 +114,9 @@ int dfn_sample_pdf(const float* bins, const float* weights, size_t n, int nb, in
  * z_fine [n_rays, Nc+Ni]; weights_coarse / z_samples optional (may be NULL). */
 int dfn_sample_fine(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far,
                     float* z_fine, float* weights_coarse, float* z_samples, void* stream);
+/* The same with the DFN_RENDER_* options (this stage takes no handle): DFN_RENDER_LINDISP = coarse depths linear in disparity. */
+int dfn_sample_fine_opt(const float* sigma, size_t n_rays, int Nc, int Ni, float near, float far, int render_flags,
+                        float* z_fine, float* weights_coarse, float* z_samples, void* stream);
 
 /* Fine query: rendering.py:305-313 + nerfw.py:62-95,297-354.  hist [hist_rows, hist_bin]
  * (float-valued indices; hist_rows is 1 = one image for all rays, or n_rays); raw
@@ -126,8 +139,8 @@ int dfn_composite_fine(const float* raw, const float* z, size_t n_rays, int Nf, 
 /* Scratch needed by dfn_render_rays / dfn_render_image for up to n_rays rays. */
 size_t dfn_render_workspace_bytes(size_t n_rays, int Nc, int Ni);
 
-/* rendering.py:245-337 render_rays at test time (perturb=0, raw_noise_std=0, lindisp=False,
- * white_bkgd=False, test_time=True) over caller-provided rays (rendering.py:361-362).
+/* rendering.py:245-337 render_rays at test time (perturb=0, raw_noise_std=0, white_bkgd=False, test_time=True; lindisp as set
+ * by dfn_nerfh_set_render_options) over caller-provided rays (rendering.py:361-362).
  * viewdirs may be NULL (computed as d/|d|, rendering.py:366-371).  raw (optional)
  * [n_rays, Nc+Ni, 9] is the `retraw` output. */
 int dfn_render_rays(dfn_nerfh_t h, int prec, const float* rays_o, const float* rays_d,
@@ -349,7 +362,7 @@ int dfn_nerfh_train_param_count(void);
 const char* dfn_nerfh_train_param_name(int i);
 size_t dfn_nerfh_train_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni);
 
-/* models/rendering.py:245-337 render_rays with test_time=False (lindisp=False, white_bkgd=False) on caller rays
+/* models/rendering.py:245-337 render_rays with test_time=False (white_bkgd=False; lindisp per the handle's options) on caller rays
  * (run_nerf.py:50).  The reference's three random draws are INPUTS: t_rand [n_rays, Nc] = torch.rand (stratified
  * jitter, rendering.py:277-285; NULL = perturb 0), noise [n_rays, Nc] = torch.randn (x raw_noise_std, coarse alpha,
  * rendering.py:173; NULL = none), u [n_rays, Ni] = torch.rand (sample_pdf, rendering.py:35; NULL = linspace).

@@ -227,15 +227,20 @@ def composite_fine(raw, z, beta_min=0.1, white_bkgd=False, test_time=True, stati
 
 
 # --------------------------------------------------------------------------- render
-def coarse_z(near, far, n, R):
-    """z = near(1-t) + far t, t = linspace(0,1,n) (models/rendering.py:269-275)."""
+def coarse_z(near, far, n, R, lindisp=False):
+    """z = near(1-t) + far t, t = linspace(0,1,n); lindisp: linear in disparity, z = 1/((1-t)/near + t/far)
+    (models/rendering.py:269-275)."""
     t = torch.linspace(0., 1., n)
+    if lindisp:
+        return (1. / (1. / near * (1. - t) + 1. / far * t)).expand(R, n)
     return (near * (1. - t) + far * t).expand(R, n)
 
 
-def render_rays(rows, coarse, fine, emb_a, emb_t, Nc, Ni, netchunk=65536, retraw=False, stages=None):
+def render_rays(rows, coarse, fine, emb_a, emb_t, Nc, Ni, netchunk=65536, retraw=False, stages=None, lindisp=False):
     """Test-time render of packed 21-float ray rows (models/rendering.py:245-337 with
-    perturb=0, raw_noise_std=0, lindisp=False, white_bkgd=False, test_time=True).
+    perturb=0, raw_noise_std=0, white_bkgd=False, test_time=True).  white_bkgd=True is not a working option of this
+    path in the reference: rendering.py:295 hands it to the coarse compositor as `output_transient`, which raises TypeError
+    (tests/golden/make_golden.py, G14, records that).
 
     `stages`, if a dict, receives the intermediate tensors for stage-level parity tests.
     """
@@ -243,7 +248,7 @@ def render_rays(rows, coarse, fine, emb_a, emb_t, Nc, Ni, netchunk=65536, retraw
     near, far = rows[:, 6:7], rows[:, 7:8]
     view, hist = rows[:, 8:11], rows[:, 11:]
     R = rows.shape[0]
-    z = coarse_z(near, far, Nc, R)
+    z = coarse_z(near, far, Nc, R, lindisp)
     pts = o[:, None, :] + d[:, None, :] * z[..., None]
     sig = query_coarse_sigma(coarse, pts, netchunk=netchunk)[..., 0]
     _, w = coarse_weights(sig, z)
@@ -261,16 +266,36 @@ def render_rays(rows, coarse, fine, emb_a, emb_t, Nc, Ni, netchunk=65536, retraw
     return ret
 
 
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """Normalised-device-coordinate rays of a forward-facing scene (models/ray_utils.py:27-46): origins moved to the near
+    plane, then the projective map of the NeRF paper's appendix (o' and d' such that o' + t' d' covers [-1, 1]^3)."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    o = rays_o + t[..., None] * rays_d
+    sx, sy = -1. / (W / (2. * focal)), -1. / (H / (2. * focal))
+    o_ndc = torch.stack([sx * o[..., 0] / o[..., 2], sy * o[..., 1] / o[..., 2], 1. + 2. * near / o[..., 2]], -1)
+    d_ndc = torch.stack([sx * (rays_d[..., 0] / rays_d[..., 2] - o[..., 0] / o[..., 2]),
+                         sy * (rays_d[..., 1] / rays_d[..., 2] - o[..., 1] / o[..., 2]), -2. * near / o[..., 2]], -1)
+    return o_ndc, d_ndc
+
+
 def render(H, W, focal, chunk, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx,
-           c2w=None, rays=None, netchunk=65536):
-    """render() at test time (models/rendering.py:353-400): returns [rgb, disp, acc] shaped like the rays."""
+           c2w=None, rays=None, netchunk=65536, ndc=False, lindisp=False, c2w_staticcam=None):
+    """render() at test time (models/rendering.py:353-400): returns [rgb, disp, acc] shaped like the rays.  View directions
+    come from the rays BEFORE the static-camera substitution and the NDC map (rendering.py:364-376)."""
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w, dtype=torch.float32)[:3, :4])
     else:
         rays_o, rays_d = rays
+    view = rays_d.reshape(-1, 3).float()
+    view = view / torch.norm(view, dim=-1, keepdim=True)
+    if c2w_staticcam is not None:
+        rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w_staticcam, dtype=torch.float32)[:3, :4])
     sh = rays_d.shape
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
     rows = pack_ray_rows(rays_o, rays_d, near, far, img_idx)
-    outs = [render_rays(rows[i:i + chunk], coarse, fine, emb_a, emb_t, Nc, Ni, netchunk)
+    rows[:, 8:11] = view
+    outs = [render_rays(rows[i:i + chunk], coarse, fine, emb_a, emb_t, Nc, Ni, netchunk, lindisp=lindisp)
             for i in range(0, rows.shape[0], chunk)]
     cat = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
     return [cat[k].reshape(*sh[:-1], *cat[k].shape[1:]) for k in ("rgb_map", "disp_map", "acc_map")]
@@ -316,9 +341,8 @@ def stratified_z(z, t_rand):
 
 
 def render_rays_train(rows, coarse, fine, emb_a, emb_t, Nc, Ni, t_rand=None, noise=None, u=None, perturb=1.,
-                      raw_noise_std=0., netchunk=65536, stages=None):
-    """Training-mode render of packed ray rows (models/rendering.py:245-337 with test_time=False, lindisp=False,
-    white_bkgd=False).  The three random draws of the reference are inputs so that results are reproducible:
+                      raw_noise_std=0., netchunk=65536, stages=None, lindisp=False):
+    """Training-mode render of packed ray rows (models/rendering.py:245-337 with test_time=False, white_bkgd=False).  The three random draws of the reference are inputs so that results are reproducible:
     t_rand [R,Nc] = torch.rand (stratified jitter, only if perturb > 0), noise [R,Nc] = torch.randn (x raw_noise_std,
     coarse alpha only), u [R,Ni] = torch.rand (importance sampling, only if perturb > 0; linspace otherwise).  Returns the
     reference's dict: rgb_map, disp_map, acc_map, raw, rgb0, disp0, acc0, z_std, transient_sigmas, beta."""
@@ -326,7 +350,7 @@ def render_rays_train(rows, coarse, fine, emb_a, emb_t, Nc, Ni, t_rand=None, noi
     near, far = rows[:, 6:7], rows[:, 7:8]
     view, hist = rows[:, 8:11], rows[:, 11:]
     R = rows.shape[0]
-    z = coarse_z(near, far, Nc, R)
+    z = coarse_z(near, far, Nc, R, lindisp)
     if perturb > 0.:
         if t_rand is None:
             t_rand = torch.rand(R, Nc)

@@ -436,6 +436,44 @@ def main():
     assert seen == {0, 1, 2, 3}, seen
     save("g11_triplet_losses", **out)
 
+    # ---------------- G14: the remaining render() options of the NeRF-H path (rendering.py:353-400, 269-273):
+    # lindisp=True (depths linear in disparity), ndc=True (ndc_rays at near = 1, rendering.py:374-376) and c2w_staticcam
+    # (rays from one pose, view directions from another, rendering.py:364-371).  white_bkgd=True is NOT a working option of
+    # this path in the reference: render_rays hands it to the coarse compositor in the output_transient slot
+    # (rendering.py:295), which then multiplies by transient_sigmas = None -> TypeError at test time.
+    r14 = np.random.default_rng(1414)
+    with torch.no_grad():
+        c2w = syn.orbit_pose(4, 8)[:3, :4]
+        ro, rd = ray_utils.get_rays(480, 640, 585.0, t(c2w))
+        sel = r14.choice(480 * 640, 48, replace=False)
+        ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
+        kw = kwargs_for(128, 16, 32)
+        kw.update(lindisp=True)
+        rgb, disp, acc, extras = rendering.render(480, 640, 585.0, chunk=32768, rays=torch.stack([ro, rd], 0), near=0.4, far=2.5,
+                                                   img_idx=t(hist)[None], retraw=True, **kw)
+        save("g14_render_lindisp", Nc=16, Ni=32, near=0.4, far=2.5, hist=hist, rays_o=ro, rays_d=rd, rgb=rgb, disp=disp, acc=acc,
+             raw=extras["raw"])
+        try:
+            kw = kwargs_for(128, 16, 32)
+            kw.update(white_bkgd=True)
+            rendering.render(480, 640, 585.0, chunk=32768, rays=torch.stack([ro, rd], 0), near=0.4, far=2.5, img_idx=t(hist)[None], **kw)
+            white = "ok"
+        except TypeError as e:
+            white = "TypeError"
+        assert white == "TypeError"
+        H, Wd, focal = 6, 8, 7.3
+        pose, pose2 = syn.orbit_pose(1, 8)[:3, :4], syn.orbit_pose(2, 8)[:3, :4]
+        o0, d0 = ray_utils.get_rays(H, Wd, focal, t(pose))
+        no, nd = ray_utils.ndc_rays(H, Wd, focal, 1., o0, d0)
+        kw = kwargs_for(128, 16, 32)
+        kw.update(ndc=True)
+        rgb, disp, acc, _ = rendering.render(H, Wd, focal, chunk=100, c2w=t(pose), near=0., far=1., img_idx=t(hist)[None], **kw)
+        rgb_s, disp_s, acc_s, _ = rendering.render(H, Wd, focal, chunk=100, c2w=t(pose), c2w_staticcam=t(pose2), near=0., far=2.5,
+                                                   img_idx=t(hist)[None], **kwargs_for(128, 16, 32))
+        save("g14_render_ndc_staticcam", H=H, W=Wd, focal=focal, c2w=pose, c2w_staticcam=pose2, hist=hist, Nc=16, Ni=32,
+             ndc_rays_o=no, ndc_rays_d=nd, rgb_ndc=rgb, disp_ndc=disp, acc_ndc=acc, rgb_static=rgb_s, disp_static=disp_s,
+             acc_static=acc_s, white_bkgd_raises=white)
+
 
 if __name__ == "__main__":
     main()

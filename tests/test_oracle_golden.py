@@ -247,3 +247,31 @@ def test_g13_training_step(gold, tag):
     rows = T(g["emb_rows"])
     close(grads["embedding_a.weight"][rows], g["ga_rows"], 1e-4, 1e-8)
     close(grads["embedding_t.weight"][rows], g["gt_rows"], 1e-4, 1e-8)
+
+
+def test_g14_render_options(gold):
+    """lindisp, ndc and c2w_staticcam of render() (rendering.py:269-273, 364-376); white_bkgd raises in the reference."""
+    c, f, ea, et = nets(128)
+    g = gold("g14_render_lindisp")
+    rows = orc.pack_ray_rows(T(g["rays_o"]), T(g["rays_d"]), float(g["near"]), float(g["far"]), g["hist"])
+    out = orc.render_rays(rows, c, f, ea, et, int(g["Nc"]), int(g["Ni"]), retraw=True, lindisp=True)
+    close(out["raw"], g["raw"], 2e-5, 2e-6)
+    close(out["rgb_map"], g["rgb"], 1e-5, 1e-6)
+    close(out["disp_map"], g["disp"], 1e-5, 1e-6)
+    close(out["acc_map"], g["acc"], 1e-5, 1e-6)
+    g = gold("g14_render_ndc_staticcam")
+    H, W, focal, Nc, Ni = int(g["H"]), int(g["W"]), float(g["focal"]), int(g["Nc"]), int(g["Ni"])
+    o, d = orc.get_rays(H, W, focal, g["c2w"])
+    no, nd = orc.ndc_rays(H, W, focal, 1., o, d)
+    close(no, g["ndc_rays_o"], 1e-6, 1e-6)
+    close(nd, g["ndc_rays_d"], 1e-6, 1e-6)
+    rgb, disp, acc = orc.render(H, W, focal, 100, c, f, ea, et, Nc, Ni, 0., 1., g["hist"], c2w=g["c2w"], ndc=True)
+    close(rgb, g["rgb_ndc"], 1e-5, 1e-6)
+    close(disp, g["disp_ndc"], 1e-5, 1e-6)
+    close(acc, g["acc_ndc"], 1e-5, 1e-6)
+    rgb, disp, acc = orc.render(H, W, focal, 100, c, f, ea, et, Nc, Ni, 0., 2.5, g["hist"], c2w=g["c2w"],
+                                c2w_staticcam=g["c2w_staticcam"])
+    close(rgb, g["rgb_static"], 1e-5, 1e-6)
+    close(disp, g["disp_static"], 1e-5, 1e-6)
+    close(acc, g["acc_static"], 1e-5, 1e-6)
+    assert str(g["white_bkgd_raises"]) == "TypeError"
