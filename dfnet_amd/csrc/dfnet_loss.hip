@@ -193,6 +193,115 @@ hipError_t launch_triplet_backward(const float* f1, size_t ls1, const float* f2,
 }  // namespace dfn
 
 // ------------------------------------------------------------------------------------------ C ABI
+// ------------------------------------------------------------------------------------------ cosine feature loss (DFNet_dm)
+// feature/direct_feature_matching.py:114-136 feature_loss with per_channel = False — nn.CosineSimilarity(dim=1, eps=1e-6) on
+// [C', H*W]: ONE cosine per feature row over its H*W pixels, loss = 1 - mean — applied per image to the selected pyramid levels
+// (:352-358) and averaged over the batch: altogether 1 - the mean over every (level, image, channel) row.  torch runs it as
+// index_select + permute/reshape copies + two norms, two clones, two divisions, a product, a sum and their backward over
+// 157 MB per stack and level; here: one read of both stacks (row statistics), one element-wise pass for the gradient.
+namespace {
+constexpr int kCosSplit = 4;       // blocks per row
+constexpr int kCosMaxLevels = 8;
+struct CosArgs {
+  const float* fr; const float* ft; float* g;
+  size_t ls_r, ls_t, ls_g, HW;
+  int lv[kCosMaxLevels];
+  int n_levels, B, C;
+};
+__device__ __forceinline__ size_t cos_row_offset(const CosArgs& a, int row, size_t ls) {   // row = (li * B + b) * C + c
+  const int bc = row % (a.B * a.C), li = row / (a.B * a.C);
+  return size_t(a.lv[li]) * ls + size_t(bc) * a.HW;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+}  // namespace
+
+// part[(row * kCosSplit + seg) * 3 + {0,1,2}] = sum fr ft, sum fr^2, sum ft^2 over the segment
+__global__ __launch_bounds__(256) void cosine_stats_kernel(CosArgs a, float* __restrict__ part) {
+  const int row = blockIdx.x, seg = blockIdx.y;
+  const float* __restrict__ x = a.fr + cos_row_offset(a, row, a.ls_r);
+  const float* __restrict__ y = a.ft + cos_row_offset(a, row, a.ls_t);
+  const size_t per = (a.HW / 4 + kCosSplit - 1) / kCosSplit * 4;
+  const size_t lo = size_t(seg) * per, hi = lo + per < a.HW ? lo + per : a.HW;
+  float d = 0.f, nx = 0.f, ny = 0.f;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (vec) {
+    const size_t hi4 = lo + ((hi > lo ? hi - lo : 0) & ~size_t(3));
+    for (size_t i = lo + size_t(threadIdx.x) * 4; i < hi4; i += 1024) {
+      const float4 u = *reinterpret_cast<const float4*>(x + i), v = *reinterpret_cast<const float4*>(y + i);
+      d += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+      nx += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+      ny += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (size_t i = hi4 + threadIdx.x; i < hi; i += 256) { d += x[i] * y[i]; nx += x[i] * x[i]; ny += y[i] * y[i]; }
+  } else {
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) { d += x[i] * y[i]; nx += x[i] * x[i]; ny += y[i] * y[i]; }
+  }
+  __shared__ float red[4][3];
+  d = wave_sum(d); nx = wave_sum(nx); ny = wave_sum(ny);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = d; red[wave][1] = nx; red[wave][2] = ny; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    part[(size_t(row) * kCosSplit + seg) * 3 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// coef[row] = (ca, cb): d cos / d fr = ca ft + cb fr (torch: x / clamp_min(||x||, eps) per operand, then the dot product);
+// loss = 1 - mean cos, fixed-order fp64 reduction.
+__global__ __launch_bounds__(256) void cosine_finish_kernel(const float* __restrict__ part, int rows, float eps, float* __restrict__ coef,
+                                                            float* __restrict__ loss) {
+  double acc = 0.;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    float d = 0.f, nx = 0.f, ny = 0.f;
+    for (int s = 0; s < kCosSplit; ++s) {
+      d += part[(size_t(r) * kCosSplit + s) * 3];
+      nx += part[(size_t(r) * kCosSplit + s) * 3 + 1];
+      ny += part[(size_t(r) * kCosSplit + s) * 3 + 2];
+    }
+    const float nrx = sqrtf(nx), nry = sqrtf(ny);
+    const float cx = fmaxf(nrx, eps), cy = fmaxf(nry, eps);
+    const float c = d / (cx * cy);
+    coef[2 * r] = 1.f / (cx * cy);
+    coef[2 * r + 1] = nrx > eps ? -c / (cx * cx) : 0.f;
+    acc += double(c);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (int(threadIdx.x) < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = float(1. - red[0] / double(rows));
+}
+
+// g[row, i] = -(grad_loss / rows) (ca ft_i + cb fr_i)
+__global__ __launch_bounds__(256) void cosine_backward_kernel(CosArgs a, const float* __restrict__ coef, const float* __restrict__ grad_loss,
+                                                              int rows) {
+  const int row = blockIdx.x, seg = blockIdx.y;
+  const float* __restrict__ x = a.fr + cos_row_offset(a, row, a.ls_r);
+  const float* __restrict__ y = a.ft + cos_row_offset(a, row, a.ls_t);
+  float* __restrict__ g = a.g + cos_row_offset(a, row, a.ls_g);
+  const float s = -grad_loss[0] / float(rows);
+  const float ca = s * coef[2 * row], cb = s * coef[2 * row + 1];
+  const size_t per = (a.HW / 4 + kCosSplit - 1) / kCosSplit * 4;
+  const size_t lo = size_t(seg) * per, hi = lo + per < a.HW ? lo + per : a.HW;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+  if (vec) {
+    const size_t hi4 = lo + ((hi > lo ? hi - lo : 0) & ~size_t(3));
+    for (size_t i = lo + size_t(threadIdx.x) * 4; i < hi4; i += 1024) {
+      const float4 u = *reinterpret_cast<const float4*>(x + i), v = *reinterpret_cast<const float4*>(y + i);
+      *reinterpret_cast<float4*>(g + i) = make_float4(ca * v.x + cb * u.x, ca * v.y + cb * u.y, ca * v.z + cb * u.z, ca * v.w + cb * u.w);
+    }
+    for (size_t i = hi4 + threadIdx.x; i < hi; i += 256) g[i] = ca * y[i] + cb * x[i];
+  } else {
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) g[i] = ca * y[i] + cb * x[i];
+  }
+}
+
 using namespace dfn;
 
 extern "C" size_t dfn_triplet_loss_state_bytes(int L, int B, int rows) {
@@ -242,5 +351,55 @@ extern "C" int dfn_triplet_loss_backward(const float* f1, size_t level_stride1, 
   hipError_t e = launch_triplet_backward(f1, level_stride1, f2, level_stride2, L, B, rows, W, 1e-6f, t.case_dev, t.row_stat, grad_loss,
                                          grad_f1, grad_stride1, grad_f2, grad_stride2, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_triplet_loss_backward: %s", hipGetErrorString(e));
+  return DFN_OK;
+}
+
+// ---- cosine feature loss: state = [rows * kCosSplit * 3 floats partial sums][rows * 2 floats coefficients]
+extern "C" size_t dfn_feature_cosine_state_bytes(int n_levels, int B, int C) {
+  if (n_levels < 1 || B < 1 || C < 1) return 0;
+  return size_t(n_levels) * B * C * (kCosSplit * 3 + 2) * sizeof(float);
+}
+namespace {
+int cos_args(CosArgs& a, const float* fr, size_t ls_r, const float* ft, size_t ls_t, const int* levels, int n_levels, int B, int C, size_t HW,
+             const char* fn) {
+  if (!fr || !ft || !levels || n_levels < 1 || n_levels > kCosMaxLevels || B < 1 || C < 1 || HW < 1)
+    return set_error(DFN_ERR_ARG, "%s: bad argument (1 <= n_levels <= %d)", fn, kCosMaxLevels);
+  a = CosArgs{};
+  a.fr = fr; a.ft = ft; a.ls_r = ls_r; a.ls_t = ls_t; a.HW = HW; a.n_levels = n_levels; a.B = B; a.C = C;
+  for (int i = 0; i < n_levels; ++i) {
+    if (levels[i] < 0) return set_error(DFN_ERR_ARG, "%s: negative level", fn);
+    a.lv[i] = levels[i];
+  }
+  return DFN_OK;
+}
+}  // namespace
+extern "C" int dfn_feature_cosine_forward(const float* fr, size_t level_stride_r, const float* ft, size_t level_stride_t, const int* levels,
+                                          int n_levels, int B, int C, size_t HW, float* loss, void* state, size_t state_bytes, void* stream) {
+  CosArgs a;
+  if (int rc = cos_args(a, fr, level_stride_r, ft, level_stride_t, levels, n_levels, B, C, HW, "dfn_feature_cosine_forward")) return rc;
+  if (!loss || !state || state_bytes < dfn_feature_cosine_state_bytes(n_levels, B, C))
+    return set_error(DFN_ERR_ARG, "dfn_feature_cosine_forward: null loss / state or state too small");
+  const int rows = n_levels * B * C;
+  float* part = static_cast<float*>(state);
+  float* coef = part + size_t(rows) * kCosSplit * 3;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(cosine_stats_kernel, dim3(rows, kCosSplit), dim3(256), 0, s, a, part);
+  hipLaunchKernelGGL(cosine_finish_kernel, dim3(1), dim3(256), 0, s, part, rows, 1e-6f, coef, loss);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_feature_cosine_forward: %s", hipGetErrorString(e));
+  return DFN_OK;
+}
+extern "C" int dfn_feature_cosine_backward(const float* fr, size_t level_stride_r, const float* ft, size_t level_stride_t, const int* levels,
+                                           int n_levels, int B, int C, size_t HW, const float* grad_loss, const void* state, float* grad_fr,
+                                           size_t grad_stride, void* stream) {
+  CosArgs a;
+  if (int rc = cos_args(a, fr, level_stride_r, ft, level_stride_t, levels, n_levels, B, C, HW, "dfn_feature_cosine_backward")) return rc;
+  if (!grad_loss || !state || !grad_fr) return set_error(DFN_ERR_ARG, "dfn_feature_cosine_backward: null argument");
+  a.g = grad_fr; a.ls_g = grad_stride;
+  const int rows = n_levels * B * C;
+  const float* coef = static_cast<const float*>(state) + size_t(rows) * kCosSplit * 3;
+  hipLaunchKernelGGL(cosine_backward_kernel, dim3(rows, kCosSplit), dim3(256), 0, static_cast<hipStream_t>(stream), a, coef, grad_loss, rows);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_feature_cosine_backward: %s", hipGetErrorString(e));
   return DFN_OK;
 }

@@ -17,7 +17,7 @@ every pose of the batch."""
 import torch
 
 from . import dist as ddist
-from .feature_misc import feature_loss, fix_coord_supp, upsample_bicubic
+from .feature_misc import feature_loss, feature_loss_batch, fix_coord_supp, upsample_bicubic
 from .rendering import render, render_frames
 
 
@@ -38,8 +38,10 @@ def inference_pose_regression(args, data, device, model, retFeature=False, isSin
         return features, predict_pose
     pose = predict_pose.reshape(inputs.shape[0], 3, 4)
     if getattr(args, "svd_reg", False):
-        u, s, v = torch.svd(pose[:, :3, :3].clone())
-        pose[:, :3, :3] = torch.matmul(u, v.transpose(-2, -1))
+        # R <- U V^T (:85-88; the reference assigns it into the slice in place: assembled out of place here, same values, without
+        # the CopySlices / AsStrided copies of an in-place update on a tracked view)
+        u, s, v = torch.svd(pose[:, :3, :3])
+        pose = torch.cat([torch.matmul(u, v.transpose(-2, -1)), pose[:, :3, 3:]], -1)
     return features, pose
 
 
@@ -58,10 +60,7 @@ def matching_step_forward(args, data, model, feat_model, pose, img_idx, hwf, hal
         rgb = _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
         feats, _ = inference_pose_regression(args, torch.cat([data, rgb]), device, feat_model, retFeature=True,
                                              isSingleStream=False, return_pose=False)
-        idx = torch.tensor(args.feature_matching_lvl, device=device)
-        f_t = preprocess_features_for_loss(torch.index_select(feats[0], 0, idx))
-        f_r = preprocess_features_for_loss(torch.index_select(feats[1], 0, idx))
-        feat_l = torch.stack([feature_loss(f_r[b], f_t[b], per_channel=args.per_channel) for b in range(B)]).mean()
+        feat_l = feature_loss_batch(feats[1], feats[0], args.feature_matching_lvl, per_channel=args.per_channel)
         photo_l = torch.mean((rgb - data) ** 2)
         pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
         if getattr(args, "combine_loss", False):
@@ -86,7 +85,7 @@ def matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, half_r
         _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
     pose_ = pose_.detach().requires_grad_(True)
     with torch.enable_grad():
-        pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
+        pose_nerf = fix_coord_supp(args, pose_, world_setup_dict, device=device)   # tracked: applied out of place
         img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
         rgb = _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
         loss, photo_l, feat_l, pose_l = _losses(args, data, rgb, pose_, pose, feat_model, device, parts=True)
@@ -104,7 +103,7 @@ def _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
     Returns rgb [B,3,H,W], attached to pose_nerf."""
     if half_res:
         small = render_frames(H // 4, W // 4, focal / 4, pose_nerf, img_idx, **render_kwargs_test)
-        return torch.stack([upsample_bicubic(small[b], H, W).permute(2, 0, 1) for b in range(small.shape[0])])
+        return upsample_bicubic(small, H, W).permute(0, 3, 1, 2)
     return render_frames(H, W, focal, pose_nerf, img_idx, **render_kwargs_test).permute(0, 3, 1, 2)
 
 
@@ -119,10 +118,7 @@ def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False):
     if hasattr(feat_model, "engine"):   # the loss reads only these pyramid levels: tell the feature backward (no scan of the gradient stack)
         feat_model.engine().grad_levels_hint = sorted(set(int(l) for l in args.feature_matching_lvl))
     fr, _ = inference_pose_regression(args, rgb, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
-    idx = torch.tensor(args.feature_matching_lvl, device=device)
-    f_t = preprocess_features_for_loss(torch.index_select(ft[0], 0, idx))
-    f_r = preprocess_features_for_loss(torch.index_select(fr[0], 0, idx))
-    feat_l = torch.stack([feature_loss(f_r[b], f_t[b], per_channel=args.per_channel) for b in range(B)]).mean()
+    feat_l = feature_loss_batch(fr[0], ft[0], args.feature_matching_lvl, per_channel=args.per_channel)
     photo_l = torch.mean((rgb - data) ** 2)
     pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
     if getattr(args, "combine_loss", False):
@@ -143,7 +139,7 @@ def train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer,
     B = data.shape[0]
     with torch.enable_grad():
         _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
-        pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
+        pose_nerf = fix_coord_supp(args, pose_ if pose_.requires_grad else pose_.clone(), world_setup_dict, device=device)
         img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
         # the reference renders pose 0 only (:342); every pose of the batch here, as one ray batch
         rgb = _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)

@@ -604,12 +604,13 @@ def composite_fine(raw, z, beta_min=0.1, test_time=True, static_only=True, white
     return out
 
 
-def upsample_bicubic(img, outH, outW):
+def upsample_bicubic(img, outH, outW, out=None):
     """[H,W,C] -> [outH,outW,C], torch's nn.Upsample(mode='bicubic') semantics (align_corners=False)."""
     lib = _lib.load()
     img = _f32c(img)
     H, W, C = img.shape
-    out = torch.empty(outH, outW, C, device=img.device)
+    if out is None:
+        out = torch.empty(outH, outW, C, device=img.device)
     check(lib.dfn_upsample_bicubic(ptr(img), H, W, C, int(outH), int(outW), ptr(out), current_stream()),
           "dfn_upsample_bicubic")
     return out
@@ -624,11 +625,12 @@ def raygen_backward(H, W, focal, grad_o, grad_d):
     return gc
 
 
-def upsample_bicubic_backward(grad_out, H, W):
+def upsample_bicubic_backward(grad_out, H, W, out=None):
     """Adjoint of upsample_bicubic: [outH,outW,C] -> [H,W,C]."""
     g = _f32c(grad_out)
     outH, outW, C = g.shape
-    out = torch.empty(H, W, C, device=g.device)
+    if out is None:
+        out = torch.empty(H, W, C, device=g.device)
     check(_lib.load().dfn_upsample_bicubic_backward(ptr(g), int(H), int(W), C, outH, outW, ptr(out), current_stream()),
           "dfn_upsample_bicubic_backward")
     return out

@@ -22,16 +22,53 @@ class _BicubicFn(torch.autograd.Function):
         return _engine.upsample_bicubic_backward(g.contiguous(), *ctx.shape), None, None
 
 
+class _BicubicBatchFn(torch.autograd.Function):
+    """[B,h,w,C] -> [B,H,W,C]: the frames of a mini-batch through the same kernels, written into one tensor (no per-frame
+    select / stack nodes in the graph)."""
+
+    @staticmethod
+    def forward(ctx, imgs, H, W):
+        imgs = imgs.detach().contiguous()
+        ctx.shape = imgs.shape[1:3]
+        out = torch.empty(imgs.shape[0], H, W, imgs.shape[3], device=imgs.device)
+        for b in range(imgs.shape[0]):
+            _engine.upsample_bicubic(imgs[b], H, W, out=out[b])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty(g.shape[0], *ctx.shape, g.shape[3], device=g.device)
+        for b in range(g.shape[0]):
+            _engine.upsample_bicubic_backward(g[b], *ctx.shape, out=out[b])
+        return out, None, None
+
+
 def upsample_bicubic(img, H, W):
-    """nn.Upsample(size=(H, W), mode='bicubic') of an [h,w,C] image; differentiable (HIP adjoint kernel)."""
+    """nn.Upsample(size=(H, W), mode='bicubic') of an [h,w,C] image or a batch [B,h,w,C]; differentiable (HIP adjoint kernel)."""
+    if img.dim() == 4:
+        return _BicubicBatchFn.apply(img, int(H), int(W))
     if torch.is_grad_enabled() and img.requires_grad:
         return _BicubicFn.apply(img, int(H), int(W))
     return _engine.upsample_bicubic(img, int(H), int(W))
 
 
+_MOVE_CACHE = {}
+
+
 def fix_coord_supp(args, pose, world_setup_dict, device=None):
-    """t <- ((t * pose_scale) + move_all_cam_vec) * pose_scale2 on [N,3,4] poses, in place."""
-    move = torch.tensor(world_setup_dict['move_all_cam_vec'], dtype=pose.dtype, device=pose.device)
+    """t <- ((t * pose_scale) + move_all_cam_vec) * pose_scale2 on [N,3,4] poses (misc.py fix_coord_supp).  In place like the
+    reference, except on a tensor autograd tracks: there the same three operations are applied out of place and the result is
+    assembled with one concatenation (three in-place slice updates cost six CopySlices copies per step in the DFNet_dm loop)."""
+    vec = world_setup_dict['move_all_cam_vec']
+    key = (tuple(float(v) for v in vec), pose.dtype, pose.device)
+    move = _MOVE_CACHE.get(key)
+    if move is None:
+        move = _MOVE_CACHE[key] = torch.tensor(vec, dtype=pose.dtype, device=pose.device)
+    if pose.requires_grad or pose.grad_fn is not None:
+        t = ((pose[:, :3, 3] * world_setup_dict['pose_scale']) + move) * world_setup_dict['pose_scale2']
+        return torch.cat([pose[:, :3, :3], t[..., None]], -1) if pose.shape[1] == 3 else \
+            torch.cat([torch.cat([pose[:, :3, :3], t[..., None]], -1), pose[:, 3:]], 1)
     pose[:, :3, 3] *= world_setup_dict['pose_scale']
     pose[:, :3, 3] += move
     pose[:, :3, 3] *= world_setup_dict['pose_scale2']
@@ -86,6 +123,64 @@ def feature_loss(feature_rgb, feature_target, per_channel=False):
     fr, ft = feature_rgb.reshape(C, -1), feature_target.reshape(C, -1)
     cos = torch.nn.CosineSimilarity(dim=0 if per_channel else 1, eps=1e-6)
     return 1 - cos(fr, ft).mean()
+
+
+class _FeatureCosineFn(torch.autograd.Function):
+    """mean_b feature_loss(f_r[b], f_t[b]) over the selected pyramid levels of two feature stacks [L,B,C,H,W] as one fused HIP
+    forward / backward (dfn_feature_cosine_*): no index_select / permute copies, no gradient for the target stack."""
+
+    @staticmethod
+    def forward(ctx, fr, ft, levels):
+        import ctypes
+        from ._lib import check, current_stream, load, ptr
+        lib = load()
+        L, B, C, H, W = fr.shape
+        lv = (ctypes.c_int * len(levels))(*levels)
+        nbytes = lib.dfn_feature_cosine_state_bytes(len(levels), B, C)
+        state = torch.empty(nbytes, dtype=torch.uint8, device=fr.device)
+        loss = torch.empty(1, device=fr.device)
+        check(lib.dfn_feature_cosine_forward(ctypes.c_void_p(fr.data_ptr()), fr.stride(0), ctypes.c_void_p(ft.data_ptr()), ft.stride(0), lv,
+                                             len(levels), B, C, H * W, ptr(loss), ctypes.c_void_p(state.data_ptr()), nbytes, current_stream()),
+              "dfn_feature_cosine_forward")
+        ctx.save_for_backward(fr, ft, state)
+        ctx.levels = tuple(levels)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from ._lib import check, current_stream, load, ptr
+        fr, ft, state = ctx.saved_tensors
+        levels = ctx.levels
+        L, B, C, H, W = fr.shape
+        G = torch.empty(L, B, C, H, W, device=fr.device)
+        for l in range(L):          # levels the loss does not read carry no gradient
+            if l not in levels:
+                G[l].zero_()
+        gl = g.detach().reshape(1).to(torch.float32).contiguous()
+        lv = (ctypes.c_int * len(levels))(*levels)
+        check(load().dfn_feature_cosine_backward(ctypes.c_void_p(fr.data_ptr()), fr.stride(0), ctypes.c_void_p(ft.data_ptr()), ft.stride(0),
+                                                 lv, len(levels), B, C, H * W, ptr(gl), ctypes.c_void_p(state.data_ptr()),
+                                                 ctypes.c_void_p(G.data_ptr()), G.stride(0), current_stream()),
+              "dfn_feature_cosine_backward")
+        return G, None, None
+
+
+def feature_loss_batch(fr, ft, levels, per_channel=False):
+    """The feature term of the DFNet_dm step (direct_feature_matching.py:352-358): the selected levels of the rendered and target
+    stacks [L,B,C,H,W] -> [B, l*C, H, W] (preprocess_features_for_loss), feature_loss per image, mean over the batch.  On the
+    GPU (per_channel False, the default) this is one fused kernel pair; per_channel=True and CPU tensors take the reference's own
+    composition of torch ops."""
+    levels = [int(l) for l in levels]
+    if (not per_channel and fr.shape == ft.shape and len(set(levels)) == len(levels) <= 8 and _stack_layout(fr) is not None
+            and _stack_layout(ft) is not None and not ft.requires_grad):
+        return _FeatureCosineFn.apply(fr, ft, tuple(levels))
+    idx = torch.tensor(levels, device=fr.device)
+    def prep(f):
+        f = torch.index_select(f, 0, idx).permute(1, 0, 2, 3, 4)
+        return f.reshape(f.shape[0], -1, f.shape[3], f.shape[4])
+    f_r, f_t = prep(fr), prep(ft)
+    return torch.stack([feature_loss(f_r[b], f_t[b], per_channel=per_channel) for b in range(f_r.shape[0])]).mean()
 
 
 def PoseLoss(args, pose_, pose, device):

@@ -328,6 +328,21 @@ int dfn_triplet_loss_backward(const float* f1, size_t level_stride1, const float
                               int B, int rows, int W, const float* grad_loss, const void* state, float* grad_f1,
                               size_t grad_stride1, float* grad_f2, size_t grad_stride2, void* stream);
 
+/* ---- the cosine feature loss of the DFNet_dm step (feature/direct_feature_matching.py:114-136 feature_loss with per_channel =
+ * False, applied per image at :352-358 and averaged over the batch), fused for the whole mini-batch.
+ * fr (features of the rendered images, differentiated) and ft (features of the target images): fp32 device stacks
+ * [L][B][C][HW]; level l starts at base + l * level_stride (floats).  levels: HOST array of the n_levels (<= 8) pyramid levels the
+ * loss reads (args.feature_matching_lvl).  nn.CosineSimilarity(dim=1, eps=1e-6) on [C', H*W] is one cosine per feature ROW over
+ * its H*W pixels; loss = 1 - mean over every (level, image, channel) row = mean_b feature_loss(f_r[b], f_t[b]).  loss: device
+ * float[1]; state: dfn_feature_cosine_state_bytes() of device memory carrying the row statistics to the backward.
+ * Backward: grad_loss device float[1]; grad_fr is addressed like fr (grad_stride) and written at the selected levels only. */
+size_t dfn_feature_cosine_state_bytes(int n_levels, int B, int C);
+int dfn_feature_cosine_forward(const float* fr, size_t level_stride_r, const float* ft, size_t level_stride_t, const int* levels,
+                               int n_levels, int B, int C, size_t HW, float* loss, void* state, size_t state_bytes, void* stream);
+int dfn_feature_cosine_backward(const float* fr, size_t level_stride_r, const float* ft, size_t level_stride_t, const int* levels,
+                                int n_levels, int B, int C, size_t HW, const float* grad_loss, const void* state, float* grad_fr,
+                                size_t grad_stride, void* stream);
+
 /* After an optimizer step of DFNet's own training: re-pack encoder, fc_pose, the adaptation convs (unfolded) and the
  * BatchNorm tensors from DEVICE tensors — 2 * 13 + 2 + 8 * n_taps pointers: those of dfn_dfnet_backward_params, then
  * per level .0.weight, .0.bias, .2.weight, .2.bias, .3.weight, .3.bias, .3.running_mean, .3.running_var.  The

@@ -824,3 +824,61 @@ def test_split_f16_gradient_chain_survives_density_only_gradients(scene):
     for r in range(n):
         scale = float(ref[r].abs().max())
         assert float((got[r] - ref[r]).abs().max()) <= 2e-5 * scale + 1e-37, r
+
+
+# ---------------------------------------------------------------------- fused cosine feature loss of the DFNet_dm step
+def _feature_loss_reference(fr, ft, levels):
+    """The reference's composition (direct_feature_matching.py:41-50, 114-136, 352-358) in torch on the CPU."""
+    idx = torch.tensor(levels)
+    def prep(f):
+        f = torch.index_select(f, 0, idx).permute(1, 0, 2, 3, 4)
+        return f.reshape(f.shape[0], -1, f.shape[3], f.shape[4])
+    f_r, f_t = prep(fr), prep(ft)
+    cos = torch.nn.CosineSimilarity(dim=1, eps=1e-6)
+    per = []
+    for b in range(f_r.shape[0]):
+        C = f_r.shape[1]
+        per.append(1 - cos(f_r[b].reshape(C, -1), f_t[b].reshape(C, -1)).mean())
+    return torch.stack(per).mean()
+
+
+@pytest.mark.parametrize("shape,levels", [((3, 2, 16, 12, 20), [0, 1, 2]), ((3, 4, 8, 7, 9), [0]), ((2, 1, 5, 3, 5), [1]),
+                                          ((3, 2, 32, 60, 80), [2, 0])])
+def test_feature_cosine_loss_vs_reference_composition(shape, levels):
+    """dfn_feature_cosine_forward / _backward against the reference's torch composition (fp64 on the CPU): value and gradient,
+    vector and scalar paths (H*W not a multiple of 4), level subsets in any order, a zero row (norm below eps)."""
+    from dfnet_amd import feature_misc as fm
+    g = torch.Generator().manual_seed(sum(shape))
+    fr, ft = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+    fr[levels[0], 0, 1] = 0.                                    # ||x|| = 0 <= eps: cos = 0, gradient = y_n / eps
+    ft = 0.3 * fr + ft                                          # correlated, like features of a render and its target
+    ref_in = fr.double().requires_grad_(True)
+    ref = _feature_loss_reference(ref_in, ft.double(), levels)
+    ref.backward()
+    x = fr.to(DEV).requires_grad_(True)
+    loss = fm.feature_loss_batch(x, ft.to(DEV), levels)
+    assert loss.shape == () and abs(float(loss.detach()) - float(ref.detach())) < 2e-6
+    (3. * loss).backward()
+    gref = 3. * ref_in.grad
+    got = x.grad.cpu().double()
+    zr = (levels[0], 0, 1)                                      # the zero row's gradient is 1e6 times the others': compared on its own
+    e0 = float((got[zr] - gref[zr]).abs().max() / gref[zr].abs().max())
+    got[zr], gref[zr] = 0., 0.
+    e = float((got - gref).abs().max() / gref.abs().max())
+    assert e < 2e-6 and e0 < 2e-6, (e, e0)
+    for l in range(shape[0]):
+        if l not in levels:
+            assert float(x.grad[l].abs().max()) == 0.
+    # the two halves of one siamese stack [L, 2B, C, H, W], addressed in place
+    both = torch.cat([ft, fr], 1).to(DEV)
+    B = shape[1]
+    loss2 = fm.feature_loss_batch(both[:, B:], both[:, :B], levels)
+    assert abs(float(loss2) - float(loss.detach())) < 1e-6     # (a half may start unaligned: scalar instead of 16-byte loads)
+    # per_channel=True keeps the reference's own composition (one cosine per pixel over the channels)
+    pc = fm.feature_loss_batch(fr.to(DEV), ft.to(DEV), levels, per_channel=True)
+    cosd0 = torch.nn.CosineSimilarity(dim=0, eps=1e-6)
+    idx = torch.tensor(levels)
+    f_r = torch.index_select(fr, 0, idx).permute(1, 0, 2, 3, 4).reshape(shape[1], -1, shape[3] * shape[4])
+    f_t = torch.index_select(ft, 0, idx).permute(1, 0, 2, 3, 4).reshape(shape[1], -1, shape[3] * shape[4])
+    want = torch.stack([1 - cosd0(f_r[b], f_t[b]).mean() for b in range(shape[1])]).mean()
+    assert abs(float(pc) - float(want)) < 2e-6
