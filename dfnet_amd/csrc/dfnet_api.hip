@@ -628,6 +628,11 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
     (void)launch_absmax_scale(static_cast<const float*>(t), n, w.scl + 8, w.scl, s);
     return w.scl;
   };
+  // the ReLU gate in front of a split-f16 gradient conv measures that conv's operand scale (w.scl) in the same pass
+  auto gate = [&](const void* g, const void* act, const void* add, size_t n, void* out) -> hipError_t {
+    if (gprec == 2) return launch_relu_gate_scale(g, act, add, n, out, w.scl + 8, w.scl, s);
+    return launch_relu_gate(prec, g, act, add, n, out, s);
+  };
   const size_t plane = size_t(128) * upH * upW;
   // Two gradient buffers: the ReLU gate runs in place on the buffer holding g_act, the conv's data gradient goes to
   // the other one, and a max-pool's routed gradient reuses the (by then dead) gated buffer.
@@ -653,22 +658,22 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
       c.dyn_scale = dyn(w.g128, size_t(B) * hh * ww * 128);
       c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
       CHECK_HIP(launch_conv(gprec, 5, 16, c, s), "dfnet bwd: adapt 5x5 dgrad");
-      CHECK_HIP(launch_relu_gate(prec, w.g64, w.tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet bwd: adapt gate");
+      CHECK_HIP(gate(w.g64, w.tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64), "dfnet bwd: adapt gate");
       ConvArgs d{};
       d.in = w.g64; d.w = h->ad1_dgrad[t].w[gprec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
-      d.dyn_scale = dyn(w.g64, size_t(B) * hh * ww * 64);
+      d.dyn_scale = gprec == 2 ? w.scl : nullptr;
       d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
       CHECK_HIP(launch_conv(gprec, 1, 16, d, s), "dfnet bwd: adapt 1x1 dgrad");
       g_tap = w.gtap;
     }
     // gradient w.r.t. the conv's pre-activation: ReLU-gated trunk gradient + the tap's
     const int pre_idx = act_idx < 0 ? 0 : act_idx, in_idx = pre_idx ^ 1;
-    CHECK_HIP(launch_relu_gate(prec, g_act, w.act[i], g_tap, n_out, gbuf[pre_idx], s), "dfnet bwd: relu gate");
+    CHECK_HIP(gate(g_act, w.act[i], g_tap, n_out, gbuf[pre_idx]), "dfnet bwd: relu gate");
     // data gradient of the conv
     const int cin_p = (sp.cin + 63) / 64 * 64;
     ConvArgs e{};
     e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[gprec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale; e.out_pre = gbuf[in_idx];
-    e.dyn_scale = dyn(gbuf[pre_idx], n_out);
+    e.dyn_scale = gprec == 2 ? w.scl : nullptr;
     e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = cin_p / 32; e.relu = 0;
     CHECK_HIP(launch_conv(gprec, 3, 16, e, s), "dfnet bwd: encoder conv dgrad");
     if (i == 0) {
@@ -846,6 +851,11 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
     (void)launch_absmax_scale(static_cast<const float*>(t), n, w.scl + 8, w.scl, s);
     return w.scl;
   };
+  // the ReLU gate in front of split-f16 gradient products measures their operand scale (w.scl) in the same pass
+  auto gate = [&](const void* g, const void* act, const void* add, size_t n, void* out) -> hipError_t {
+    if (prec == 2) return launch_relu_gate_scale(g, act, add, n, out, w.scl + 8, w.scl, s);
+    return launch_relu_gate(1, g, act, add, n, out, s);
+  };
   // ---- encoder, last conv first; the adaptation layers of a level join at its tap
   for (int i = last; i >= 0; --i) {
     const ConvSpec& sp = h->enc[i];
@@ -875,10 +885,10 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       c.dyn_scale = sc128;
       c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet params: adapt 5x5 dgrad");
-      CHECK_HIP(launch_relu_gate(1, w.g64, tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, s), "dfnet params: adapt gate");
+      CHECK_HIP(gate(w.g64, tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64), "dfnet params: adapt gate");
       const float* g64 = reinterpret_cast<const float*>(w.g64);
       CHECK_HIP(launch_bias_grad(g64, B, hh, ww, 64, pw.part, kWgradPartFloats, ag[1], s), "dfnet params: adapt 1x1 bias gradient");
-      const float* sc64 = dyn(w.g64, size_t(B) * hh * ww * 64);
+      const float* sc64 = prec == 2 ? w.scl : nullptr;
       CHECK_HIP(launch_conv_wgrad(1, g64, reinterpret_cast<const float*>(w.tap[t]), B, hh, ww, 64, sp.cout, pw.part, kWgradPartFloats, ag[0], s,
                                   sc64),
                 "dfnet params: adapt 1x1 weight gradient");
@@ -890,13 +900,13 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       g_tap = w.gtap;
     }
     const int pre_idx = act_idx < 0 ? 0 : act_idx, in_idx = pre_idx ^ 1;
-    CHECK_HIP(launch_relu_gate(1, act_idx < 0 ? nullptr : gbuf[act_idx], w.act[i], g_tap, size_t(B) * hh * ww * sp.cout, gbuf[pre_idx], s),
+    CHECK_HIP(gate(act_idx < 0 ? nullptr : gbuf[act_idx], w.act[i], g_tap, size_t(B) * hh * ww * sp.cout, gbuf[pre_idx]),
               "dfnet params: relu gate");
     const float* g_pre = reinterpret_cast<const float*>(gbuf[pre_idx]);
     CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, pw.part, kWgradPartFloats, grads[2 * i + 1], s), "dfnet params: bias gradient");
     if (i == 0) {
       CHECK_HIP(launch_conv0_wgrad(g_pre, reinterpret_cast<const float*>(w.prep), B, hh, ww, 2 * prep_sb(prec), pw.part, kWgradPartFloats,
-                                   grads[0], s, dyn(g_pre, size_t(B) * hh * ww * sp.cout)),
+                                   grads[0], s, prec == 2 ? w.scl : nullptr),
                 "dfnet params: conv1_1 weight gradient");
       break;
     }
@@ -906,7 +916,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
                 "dfnet params: maxpool (conv input)");
       input = w.pooled;
     }
-    const float* sc_pre = dyn(g_pre, size_t(B) * hh * ww * sp.cout);
+    const float* sc_pre = prec == 2 ? w.scl : nullptr;
     CHECK_HIP(launch_conv_wgrad(3, g_pre, reinterpret_cast<const float*>(input), B, hh, ww, sp.cout, sp.cin, pw.part, kWgradPartFloats,
                                 grads[2 * i], s, sc_pre),
               "dfnet params: conv weight gradient");

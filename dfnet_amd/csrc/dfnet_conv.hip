@@ -960,6 +960,10 @@ __global__ __launch_bounds__(256) void absmax_finalize_kernel(const float* __res
     out[1] = ldexpf(1.f, -k);
   }
 }
+hipError_t launch_absmax_finalize(const float* part, int n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(absmax_finalize_kernel, dim3(1), dim3(256), 0, s, part, n, out);
+  return hipGetLastError();
+}
 hipError_t launch_absmax_scale(const float* x, size_t n, float* part, float* out, hipStream_t s) {
   const int blocks = int((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, x, n, part);

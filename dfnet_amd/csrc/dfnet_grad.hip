@@ -39,6 +39,45 @@ hipError_t launch_relu_gate(int prec, const void* g, const void* act, const void
   return hipGetLastError();
 }
 
+// The same gate (fp32) that also leaves the tensor's |max| behind as the power-of-two operand scale [scale, 1/scale] of the split-f16
+// gradient conv that reads `out` next (launch_absmax_scale's result without its extra pass over the tensor).
+__global__ __launch_bounds__(256) void relu_gate_absmax_kernel(const float4* __restrict__ g, const float4* __restrict__ act,
+                                                               const float4* __restrict__ add, size_t n4, float4* __restrict__ out,
+                                                               float* __restrict__ part) {
+  float m = 0.f;
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n4; i += size_t(gridDim.x) * blockDim.x) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g) {
+      const float4 a = act[i], x = g[i];
+      v = make_float4(a.x > 0.f ? x.x : 0.f, a.y > 0.f ? x.y : 0.f, a.z > 0.f ? x.z : 0.f, a.w > 0.f ? x.w : 0.f);
+    }
+    if (add) { const float4 t = add[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    out[i] = v;
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+hipError_t launch_relu_gate_scale(const void* g, const void* act, const void* add, size_t n, void* out, float* part, float* scale,
+                                  hipStream_t s) {
+  if (!n) return hipSuccess;
+  const bool vec = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(add) |
+                                   reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (!vec) {
+    if (hipError_t e = launch_relu_gate(1, g, act, add, n, out, s)) return e;
+    return launch_absmax_scale(static_cast<const float*>(out), n, part, scale, s);
+  }
+  const size_t n4 = n / 4;
+  const int blocks = int((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+  hipLaunchKernelGGL(relu_gate_absmax_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float4*>(g), static_cast<const float4*>(act),
+                     static_cast<const float4*>(add), n4, static_cast<float4*>(out), part);
+  return launch_absmax_finalize(part, blocks, scale, s);
+}
+
 // 2x2/2 max-pool backward: the gradient of a pooled pixel goes to the FIRST maximum of its window in row-major
 // order (torch's max_pool2d_with_indices).  act [B,H,W,C] (pre-pool), g [B,H/2,W/2,C] -> out [B,H,W,C]; rows /
 // columns beyond 2*(H/2), 2*(W/2) get zero.

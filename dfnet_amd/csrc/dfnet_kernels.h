@@ -129,6 +129,10 @@ hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, cons
 // out[0] = 2^k with max|x| * 2^k in [2^10, 2^11) (1 if the tensor is all zero), out[1] = 2^-k.  fp32 tensor of n elements;
 // `part` is scratch of >= 1024 floats.
 hipError_t launch_absmax_scale(const float* x, size_t n, float* part, float* out, hipStream_t s);
+hipError_t launch_absmax_finalize(const float* part, int n, float* out, hipStream_t s);   // the second half alone: part[n] block maxima
+// launch_relu_gate (fp32) + launch_absmax_scale of its output in one pass: part = 1024 floats of scratch, scale = [scale, 1/scale]
+hipError_t launch_relu_gate_scale(const void* g, const void* act, const void* add, size_t n, void* out, float* part, float* scale,
+                                  hipStream_t s);
 
 // device-side re-packing of a conv's fp32 master weights (after an optimizer step): same fragment layouts as the host
 // packers of dfnet_api.hip.  mode 0 = forward conv, 1 = its data-gradient conv (w_cout / w_cin = the forward shape).

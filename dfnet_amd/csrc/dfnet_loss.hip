@@ -193,6 +193,7 @@ hipError_t launch_triplet_backward(const float* f1, size_t ls1, const float* f2,
 }  // namespace dfn
 
 // ------------------------------------------------------------------------------------------ C ABI
+namespace dfn {
 // ------------------------------------------------------------------------------------------ cosine feature loss (DFNet_dm)
 // feature/direct_feature_matching.py:114-136 feature_loss with per_channel = False — nn.CosineSimilarity(dim=1, eps=1e-6) on
 // [C', H*W]: ONE cosine per feature row over its H*W pixels, loss = 1 - mean — applied per image to the selected pyramid levels
@@ -301,6 +302,8 @@ __global__ __launch_bounds__(256) void cosine_backward_kernel(CosArgs a, const f
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) g[i] = ca * y[i] + cb * x[i];
   }
 }
+
+}  // namespace dfn
 
 using namespace dfn;
 

@@ -464,7 +464,7 @@ def test_dfnet_module_trains_pose_path():
     assert rel_l2(dict(m.named_parameters())["fc_pose.weight"].grad, pp["fc_pose.weight"].grad) < 1e-4
     assert rel_l2(dict(m.named_parameters())["encoder.0.weight"].grad, pp["encoder.0.weight"].grad) < 5e-2
     g2 = sum(float((q.grad ** 2).sum()) for q in m.parameters() if q.grad is not None)
-    opt = torch.optim.SGD(m.parameters(), lr=0.1 * float(loss0) / g2)   # first-order prediction: loss drops by ~10 %
+    opt = torch.optim.SGD(m.parameters(), lr=0.1 * float(loss0.detach()) / g2)   # first-order prediction: loss drops by ~10 %
     opt.step()
     with torch.no_grad():
         _, pose1 = m(x)
