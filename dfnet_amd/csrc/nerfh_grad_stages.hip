@@ -210,11 +210,14 @@ DFN_DEV float bicubic_axis_weight(float scale, int O, int n_in, int target) {
   for (int a = 0; a < 4; ++a) acc += min(max(i0 - 1 + a, 0), n_in - 1) == target ? wt[a] : 0.f;
   return acc;
 }
+// Gather form (deterministic): one 8-lane group per input element, the lanes share the rows of the output window that reaches it.
 __global__ __launch_bounds__(256) void bicubic_backward_kernel(const float* __restrict__ gout, int H, int W, int C, int UH, int UW,
                                                                float* __restrict__ gin) {
   const float sy = float(H) / float(UH), sx = float(W) / float(UW);
   const size_t n = size_t(H) * W * C;
-  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+  for (size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x; t < n * 8; t += size_t(gridDim.x) * blockDim.x) {
+    const size_t i = t >> 3;
+    const int sub = int(t & 7);
     const int c = int(i % C);
     const int x = int((i / C) % W), y = int(i / (size_t(C) * W));
     // output rows whose 4-tap window [floor(f)-1, floor(f)+2] can reach y (borders: everything beyond clamps onto them)
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void bicubic_backward_kernel(const float* __re
     const int X0 = x == 0 ? 0 : max(0, int(floorf((float(x) - 2.5f) / sx)) - 1);
     const int X1 = x == W - 1 ? UW - 1 : min(UW - 1, int(ceilf((float(x) + 2.5f) / sx)) + 1);
     float acc = 0.f;
-    for (int Y = Y0; Y <= Y1; ++Y) {
+    for (int Y = Y0 + sub; Y <= Y1; Y += 8) {
       const float wy = bicubic_axis_weight(sy, Y, H, y);
       if (wy == 0.f) continue;
       float row = 0.f;
@@ -233,13 +236,16 @@ __global__ __launch_bounds__(256) void bicubic_backward_kernel(const float* __re
       }
       acc += wy * row;
     }
-    gin[i] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0) gin[i] = acc;
   }
 }
 hipError_t launch_bicubic_backward(const float* gout, int H, int W, int C, int UH, int UW, float* gin, hipStream_t stream) {
   const size_t n = size_t(H) * W * C;
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(bicubic_backward_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, gout, H, W, C, UH, UW, gin);
+  hipLaunchKernelGGL(bicubic_backward_kernel, dim3(grid_for(n * 8, 256)), dim3(256), 0, stream, gout, H, W, C, UH, UW, gin);
   return hipGetLastError();
 }
 
