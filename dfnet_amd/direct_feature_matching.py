@@ -165,3 +165,88 @@ def train_on_epoch(args, data_loaders, model, feat_model, hwf, optimizer, half_r
         losses.append(l.item())
         psnrs.append(p.item())
     return float(np.mean(losses)), float(np.mean(psnrs))
+
+
+def eval_on_batch(args, data, model, feat_model, pose, img_idx, hwf, half_res, device, world_setup_dict, **render_kwargs_test):
+    """One validation step (:178-213): pose regression, then N_rand random rays of the batch's frames rendered at FULL resolution at
+    the predicted poses.  Returns (pose MSE vs the ground truth, PSNR of those rays vs the frames) as 1-element numpy arrays.
+    The reference hands `render` the [B, bins] histogram rows unchanged, which only works for B = 1; here every ray takes the row
+    of the frame it came from."""
+    import numpy as np
+    from . import engine as _engine
+    H, W, focal = int(hwf[0]), int(hwf[1]), hwf[2]
+    with torch.no_grad():
+        data = data.to(device)
+        B = data.shape[0]
+        _, pose_ = inference_pose_regression(args, data, device, model)
+        pose_nerf = fix_coord_supp(args, pose_.clone(), world_setup_dict, device=device)
+        hist = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
+        rays = [_engine.raygen(H, W, float(focal), pose_nerf[b, :3, :4].contiguous(), want_viewdirs=False) for b in range(B)]
+        ro = torch.cat([r[0].reshape(-1, 3) for r in rays])
+        rd = torch.cat([r[1].reshape(-1, 3) for r in rays])
+        target = data.permute(0, 2, 3, 1).reshape(-1, 3)
+        sel = torch.randperm(ro.shape[0], device=device)[:int(args.N_rand)]        # prepare_batch_render: random over all frames (:169-174)
+        rows = hist[sel // (H * W)]
+        rgb = render(H, W, focal, chunk=args.chunk, rays=(ro[sel].contiguous(), rd[sel].contiguous()), img_idx=rows,
+                     **render_kwargs_test)[0]
+        loss = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
+        psnr = -10. * torch.log10(torch.mean((rgb - target[sel]) ** 2))
+    return np.array([float(loss)]), np.array([float(psnr)])
+
+
+def eval_on_epoch(args, data_loaders, model, feat_model, hwf, half_res, device, world_setup_dict, **render_kwargs_test):
+    """Mean validation (pose loss, PSNR) over val_dl (:215-233)."""
+    import numpy as np
+    model.eval()
+    losses, psnrs = [], []
+    for data, pose, img_idx in data_loaders[1]:
+        l, p = eval_on_batch(args, data, model, feat_model, pose, img_idx, hwf, half_res, device, world_setup_dict, **render_kwargs_test)
+        losses.append(l.item())
+        psnrs.append(p.item())
+    return float(np.mean(losses)), float(np.mean(psnrs))
+
+
+def train_feature_matching(args, model, feat_model, optimizer, i_split, hwf, near, far, device, early_stopping, images=None,
+                           poses_train=None, train_dl=None, val_dl=None, test_dl=None, n_epoch=2001):
+    """The DFNet_dm fine-tuning loop (:412-471): per epoch one pass of train_on_epoch over train_dl, a validation pass, the
+    EarlyStopping callback on the validation loss (checkpoint-<epoch>-<val>.pt like the reference), and every i_eval epochs the
+    median pose error over val_dl.  NeRF-H and the feature extractor are frozen; with torch.distributed initialised the training
+    frames are sharded over the ranks (one all-reduce of the regressor's gradients per step, dist.allreduce_gradients), every rank
+    runs the same validation pass, so the replicas stop at the same epoch."""
+    from .feature_misc import get_error_in_q
+    from .nerfw import create_nerf
+    _, render_kwargs_test, start, _, _ = create_nerf(args)
+    render_kwargs_test.update({'near': near, 'far': far})
+    for q in feat_model.parameters():
+        q.requires_grad_(False)
+    world_setup_dict = {k: getattr(train_dl.dataset, k) for k in ('pose_scale', 'pose_scale2', 'move_all_cam_vec')}
+    rank, world = ddist.rank_world()
+    sampler = None
+    if world > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(train_dl.dataset, num_replicas=world, rank=rank, shuffle=True)
+        train_dl = torch.utils.data.DataLoader(train_dl.dataset, batch_size=args.batch_size, sampler=sampler)
+    data_loaders = [train_dl, val_dl, test_dl]
+    half_res = True
+    for epoch in range(n_epoch):
+        if epoch and hasattr(model, "recommit"):
+            model.recommit()             # fresh split-f16 weight scales for the re-packed regressor
+        if sampler is not None:
+            sampler.set_epoch(epoch)     # a fresh permutation per epoch, the same on every rank
+        loss, psnr = train_on_epoch(args, data_loaders, model, feat_model, hwf, optimizer, half_res, device, world_setup_dict,
+                                    **render_kwargs_test)
+        val_loss, val_psnr = eval_on_epoch(args, data_loaders, model, feat_model, hwf, half_res, device, world_setup_dict,
+                                           **render_kwargs_test)
+        if world > 1:                    # the validation PSNR is over random rays: agree on one figure so every replica stops together
+            t = torch.tensor([val_loss, val_psnr], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t)
+            val_loss, val_psnr = (t / world).tolist()
+        if rank == 0:
+            print('At epoch {0:4d} : train loss: {1:.4f}, train psnr: {2:.4f}, val loss: {3:.4f}, val psnr: {4:.4f}'.format(
+                epoch, loss, psnr, val_loss, val_psnr))
+        early_stopping(val_loss, model, epoch=epoch, save_multiple=(not args.no_save_multiple), save_all=args.save_all_ckpt,
+                       val_psnr=val_psnr)
+        if early_stopping.early_stop:
+            print("Early stopping")
+            break
+        if epoch % args.i_eval == 0 and rank == 0:
+            get_error_in_q(args, val_dl, model, len(val_dl.dataset), device, batch_size=1)

@@ -8,7 +8,8 @@ x4), siamese DFNet features, cosine feature-matching loss — and its backward: 
 extractor's input, the bicubic resize, the render (down to the pose) and the pose regressor's own conv / fc
 weights; Adam (torch.optim over the module's parameters) applies the update.  `--eval` prints the median / mean
 pose error over the test split (as the reference) and the mean losses / PSNR over the validation split.
-Early stopping / TensorBoard callbacks of the reference are not mirrored; checkpoints are written every i_eval epochs.
+Training follows the reference's loop (train epoch, validation pass, EarlyStopping with its checkpoint naming, pose error every
+i_eval epochs); the TensorBoard writer is not mirrored.
 """
 import os
 import sys
@@ -21,7 +22,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from dfnet_amd import dist as ddist  # noqa: E402
 from dfnet_amd.datasets import load_7Scenes_dataloader, load_Cambridge_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
-from dfnet_amd.direct_feature_matching import matching_step_forward, train_on_epoch  # noqa: E402
+from dfnet_amd.callbacks import EarlyStopping  # noqa: E402
+from dfnet_amd.direct_feature_matching import matching_step_forward, train_feature_matching  # noqa: E402
 from dfnet_amd.nerfw import create_nerf  # noqa: E402
 from dfnet_amd.options import dm_parser  # noqa: E402
 
@@ -50,34 +52,20 @@ def main(argv=None):
     else:
         print('Use the same DFNet for Feature Extraction and Pose Regression')
         feat_model.load_state_dict(torch.load(args.pretrain_model_path, map_location="cpu"))
+    if not args.eval:
+        # train.py:122-136 of the reference: Adam over the pose regressor, the EarlyStopping callback, train_feature_matching
+        # (direct_feature_matching.py:412-471: train epoch, validation pass, early stopping / checkpoint-<epoch>-<val>.pt, pose
+        # error every i_eval epochs); every gradient on the HIP path, the optimizer step by torch
+        model.to(device)
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate)
+        early_stopping = EarlyStopping(args, patience=args.patience[0], verbose=False)
+        n_epoch = int(os.environ.get("DFNET_DM_EPOCHS", 2001))   # the reference hard-codes 2001 (:437) and relies on early stopping
+        train_feature_matching(args, model, feat_model, optimizer, i_split, hwf, near, far, device, early_stopping, train_dl=train_dl,
+                               val_dl=val_dl, test_dl=test_dl, n_epoch=n_epoch)
+        return
     _, render_kwargs_test, start, _, _ = create_nerf(args)
     render_kwargs_test.update({'near': near, 'far': far})
     setup = {k: getattr(train_dl.dataset, k) for k in ('pose_scale', 'pose_scale2', 'move_all_cam_vec')}
-    if not args.eval:
-        # train_feature_matching (direct_feature_matching.py:412-470): Adam over the pose regressor, NeRF-H and the
-        # feature extractor frozen; every gradient on the HIP path, the optimizer step by torch
-        model.to(device)
-        for q in feat_model.parameters():
-            q.requires_grad_(False)
-        optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate)
-        if world > 1:   # data-parallel over the training frames; weights stay identical on every rank
-            sampler = torch.utils.data.distributed.DistributedSampler(train_dl.dataset, num_replicas=world, rank=rank, shuffle=True)
-            train_dl = torch.utils.data.DataLoader(train_dl.dataset, batch_size=args.batch_size, sampler=sampler)
-        n_epoch = int(os.environ.get("DFNET_DM_EPOCHS", 2001))   # the reference hard-codes 2001 (:436) and relies on early stopping
-        for epoch in range(n_epoch):
-            if epoch:
-                model.recommit()   # fresh split-f16 weight scales for the re-packed regressor (dfnet.py: recommit)
-            if world > 1:
-                sampler.set_epoch(epoch)   # a fresh permutation per epoch, the same on every rank
-            loss, psnr = train_on_epoch(args, [train_dl, val_dl, test_dl], model, feat_model, hwf, optimizer, True, device,
-                                        setup, **render_kwargs_test)
-            if rank == 0:
-                print('At epoch {0:4d} : train loss: {1:.4f}, train psnr: {2:.4f}'.format(epoch, loss, psnr))
-            if rank == 0 and ((epoch + 1) % max(int(getattr(args, "i_eval", 50) or 50), 1) == 0 or epoch + 1 == n_epoch):
-                os.makedirs(os.path.join(args.basedir, args.model_name), exist_ok=True)
-                ckpt = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-                torch.save(ckpt, os.path.join(args.basedir, args.model_name, 'checkpoint-{:04d}.pt'.format(epoch)))
-        return
     # train.py:138-157: `--eval` = pose error of the DFNet_dm regressor over the test split ...
     from dfnet_amd.feature_misc import get_error_in_q
     print(len(test_dl.dataset))

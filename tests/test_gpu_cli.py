@@ -192,9 +192,13 @@ def test_train_dm_cli(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("At epoch")]
-    assert len(line) == 1 and "train loss" in line[0] and "nan" not in line[0]
+    assert len(line) == 1 and "train loss" in line[0] and "val loss" in line[0] and "val psnr" in line[0] and "nan" not in line[0]
+    assert any("Median error" in l for l in r.stdout.splitlines())      # get_error_in_q every i_eval epochs (:469-471)
+    import glob
     import torch
-    ck = torch.load(os.path.join(basedir, "dfnet_dm", "checkpoint-0000.pt"), map_location="cpu")
+    cks = glob.glob(os.path.join(basedir, "dfnet_dm", "checkpoint-0000-*.pt"))   # EarlyStopping's name: checkpoint-<epoch>-<val loss>.pt
+    assert len(cks) == 1, os.listdir(os.path.join(basedir, "dfnet_dm"))
+    ck = torch.load(cks[0], map_location="cpu")
     assert "encoder.0.weight" in ck and "fc_pose.bias" in ck and "adaptation_layers.adapt_layer_0.3.running_var" in ck
 
 
