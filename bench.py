@@ -22,7 +22,7 @@ Prints ONE JSON line (rank 0):
                         measured with HIP events on the launch stream (dfn_profile_*);
   hbm                   achieved GB/s of the HBM-bound stage kernels (sampling, ray bias, compositing), same events;
   secondary             BASELINE configs[3] (DFNet forward ms / 480x640 image), configs[4] (DFNet_dm step ms at the per-GPU
-                        shape), the NeRF-H optimisation step and a netwidth-256 frame, each with its parity
+                        shape), DFNet's own training step (N2), the NeRF-H optimisation step and a netwidth-256 frame, each with its parity
                         number against the oracle;
   cpu_baseline          the oracle (torch-CPU port of the reference path) on a bounded ray sample on this box's host
                         cores, best of a thread-count sweep (rank 0, N = 1 only).
@@ -352,6 +352,64 @@ def secondary_dm_step(dev):
             "gradient_parity": "tests/test_gpu_grad.py (pose gradient and the 28 parameter gradients vs oracle autograd)"}
 
 
+def secondary_dfnet_train(dev):
+    """one optimisation step of DFNet's own training (run_feature.py:166-230 with config_dfnet.txt: triplet loss
+    with in-triplet hard-negative mining, random view synthesis, BatchNorm on batch statistics): siamese forward on [target, render]
+    (2B frames), pose forward on B synthesised views, losses, backward of every parameter, Adam, device re-pack.  Parity = the step's
+    loss against the CPU oracle's forward in train() mode on the same frames."""
+    from dfnet_amd import synthetic as syn
+    from dfnet_amd.dfnet import DFNet
+    from dfnet_amd.feature_misc import PoseLoss, triplet_loss_hard_negative_mining_plus
+    from oracle import dfnet_oracle as dor
+    T = torch.from_numpy
+    B, Hh, Ww = 4, 240, 320
+    w = syn.dfnet_weights(3)
+    m = DFNet()
+    m.load_state_dict({k: T(v) for k, v in w.items()}, strict=False)
+    m.to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-7)
+    g = torch.Generator().manual_seed(1)
+    target, rgb, virt = (torch.rand(B, 3, Hh, Ww, generator=g) for _ in range(3))
+    pose = torch.stack([T(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(B)])
+    dtarget, drgb, dvirt, dpose = (t.to(dev) for t in (target, rgb, virt, pose))
+
+    def step(update=True):
+        feats, pred = m(torch.cat([dtarget, drgb]), True, upsampleH=Hh, upsampleW=Ww)
+        loss = PoseLoss(None, pred, torch.cat([dpose, dpose]), dev) + triplet_loss_hard_negative_mining_plus(feats[1], feats[0], margin=1.0)
+        _, vp = m(dvirt, False)
+        loss = loss + PoseLoss(None, vp, dpose, dev)
+        loss.backward()
+        if update:
+            opt.step()
+        opt.zero_grad()
+        return float(loss.detach())
+
+    loss0 = step(update=False)          # the untouched weights: the figure the oracle reproduces
+    step()
+    torch.cuda.synchronize()
+    iters = 5
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        p = {k: T(v) for k, v in w.items()}
+        feats, pred = dor.dfnet_forward(p, torch.cat([target, rgb]), True, False, True, Hh, Ww, bn_stats=[])
+        _, vp = dor.dfnet_forward(p, virt, False, True, True, Hh, Ww, bn_stats=[])
+        mse = torch.nn.functional.mse_loss
+        ref = float(mse(pred, torch.cat([pose, pose])) + dor.triplet_loss(feats[1], feats[0], margin=1.0, mining=2)[0] + mse(vp, pose))
+        cpu_s = time.perf_counter() - t0
+    return {"workload": f"one DFNet training step (run_feature.py:166-230): featurenet_batch_size {B} -> {2 * B} siamese + {B} synthesised "
+                        f"frames of {Hh}x{Ww}, triplet loss (hard-negative mining, four cases) + pose losses, BatchNorm on batch statistics, "
+                        "every parameter gradient, Adam, device re-pack",
+            "step_ms": ms, "frames_per_s": 3 * B / ms * 1e3,
+            "arithmetic": "split-f16 (f16x3) forward, data-gradient and weight-gradient products; fp32 accumulate (fp32-grade)",
+            "loss": loss0, "oracle_loss": ref, "loss_rel_diff_vs_oracle": abs(loss0 - ref) / max(abs(ref), 1e-12), "cpu_oracle_forward_s": cpu_s,
+            "gradient_parity": "tests/test_gpu_dfnet.py (G10: the reference module's own training step, 46 gradients; G11: its triplet losses)"}
+
+
 def secondary_nerfh_train(dev):
     """one NeRF-H optimisation step at the reference's defaults (N_rand 1536 rays, 64+128 samples, netwidth 128,
     perturb 1; run_nerf.py:32-80): forward, fused NerfWLoss, every gradient, Adam.  Parity: a 256-ray step against autograd
@@ -587,7 +645,7 @@ def main():
             if args.cpu_sample > 0:
                 torch.set_num_threads(int(line["cpu_baseline"]["cores"]))   # the oracle legs below: the fastest thread count found
             for name, fn in (("dfnet_forward_c4", secondary_dfnet), ("dfnet_dm_step_c5", secondary_dm_step),
-                             ("nerfh_train_step_n1", secondary_nerfh_train), ("nerfh_netwidth_256", secondary_w256)):
+                             ("dfnet_train_step_n2", secondary_dfnet_train), ("nerfh_train_step_n1", secondary_nerfh_train), ("nerfh_netwidth_256", secondary_w256)):
                 try:
                     sec[name] = fn(dev) if args.cpu_sample > 0 else {"skipped": "--cpu-sample 0"}
                 except Exception as e:  # a failing secondary must not lose the headline line
