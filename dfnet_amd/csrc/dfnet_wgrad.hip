@@ -140,24 +140,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 // range), with a wave-uniform fast path for groups that touch no image border.
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+// hi | lo halves of two scaled values, packed: hi = the TRUNCATED f16 of x * scale (v_cvt_pkrtz_f16_f32: any f16 within an ulp serves
+// as hi, the lo half takes the exact remainder, and truncation saturates at the largest finite f16 instead of overflowing — the clamps
+// of a rounding conversion are not needed), remainder by v_fma_mix_f32 on the packed halves in place: 5 VALU instructions per PAIR.
+__device__ __forceinline__ void split_pair(float x0, float x1, float scale, uint32_t& hi, uint32_t& lo) {
+  typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
+  x0 *= scale;
+  x1 *= scale;
+  hi = __builtin_bit_cast(uint32_t, (pk2)__builtin_amdgcn_cvt_pkrtz(x0, x1));
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+  lo = __builtin_bit_cast(uint32_t, (pk2)__builtin_amdgcn_cvt_pkrtz(r0, r1));
+}
 template <bool SAT>
 __device__ __forceinline__ void split8(const f32x8& v, float scale, half8& hi, half8& lo) {
-  const f32x8 xs = v * scale;
-  f32x8 cl = xs;
-  if (SAT) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 h, l;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) cl[k] = __builtin_amdgcn_fmed3f(xs[k], -65000.f, 65000.f);
+  for (int k = 0; k < 4; ++k) {
+    uint32_t a, b;
+    split_pair(v[2 * k], v[2 * k + 1], scale, a, b);
+    h[k] = a; l[k] = b;
   }
-  hi = __builtin_convertvector(cl, half8);
-  f32x8 r = xs - __builtin_convertvector(hi, f32x8);
-  if (SAT) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = __builtin_amdgcn_fmed3f(r[k], -65000.f, 65000.f);
-  }
-  lo = __builtin_convertvector(r, half8);
+  hi = __builtin_bit_cast(half8, h);
+  lo = __builtin_bit_cast(half8, l);
 }
 
-template <int KS, int TY>
+// MW = 32-channel output blocks per wave (1 or 2): with two, the input window of a pixel group is loaded and split once for 64
+// output channels — the kernel is bound by the bytes it pulls through L2 (every (output block, input block) pair re-reads both
+// tensors), not by the matrix pipe.
+template <int KS, int TY, int MW = 1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __restrict__ g, const float* __restrict__ in, int B, int H,
                                                                int W, int mblks, int nblks, int n_chunks, int ky0,
                                                                const float* __restrict__ gscale, float* __restrict__ part) {
@@ -166,17 +179,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, kg = lane >> 5;
   const int pair = blockIdx.x, chunk = blockIdx.y;
-  const int mblk = pair / nblks, nblk = pair - mblk * nblks;
+  const int mblk = (pair / nblks) * MW, nblk = pair % nblks;   // this wave's first output block
   const long long Q = (long long)B * H * W;
   const long long per = (Q + n_chunks - 1) / n_chunks;
   const long long q0 = chunk * per, q1 = q0 + per < Q ? q0 + per : Q;
   const long long wper = ((q1 - q0 + 3) / 4 + 15) & ~15LL;   // whole 16-pixel groups per wave
   const long long w0 = q0 + wave * wper, w1 = w0 + wper < q1 ? w0 + wper : q1;
-  f32x16 acc[T];
+  f32x16 acc[MW][T];
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+  for (int m = 0; m < MW; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
   constexpr uint32_t kRecords = 0x80000000u;
   const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g + ((size_t)q0 * mblks + mblk) * 32), 0, kRecords, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_in[T];
@@ -231,32 +246,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
       return v;
     };
     // the taps are software-pipelined: tap t+1's eight loads are in flight while tap t is split and multiplied
-    const f32x8 araw = fetch8(rs_g, d * gstep + 4u * c, gstep, live);
+    f32x8 araw[MW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) araw[m] = fetch8(rs_g, d * gstep + 4u * c + 128u * m, gstep, live);
     const uint32_t vo = d * istep + 4u * c;
     auto tap_mask = [&](int t) -> uint32_t { return MASKED ? (live & rowm[t / KS] & colm[t % KS]) : 0xFFu; };
     f32x8 nxt = fetch8(rs_in[0], vo, istep, tap_mask(0));
-    half8 ah, al;
-    split8<false>(araw, sg, ah, al);
+    half8 ah[MW], al[MW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) split8<false>(araw[m], sg, ah[m], al[m]);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const f32x8 cur = nxt;
       if (t + 1 < T) nxt = fetch8(rs_in[t + 1], vo, istep, tap_mask(t + 1));
       half8 bh, bl;
       split8<true>(cur, kConvActScale, bh, bl);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MW; ++m) {
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m][t], 0, 0, 0);
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m][t], 0, 0, 0);
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m][t], 0, 0, 0);
+      }
     }
   };
   // Interior groups of a one-row kernel (TY == 1): the KS taps of the row read the SAME pixels shifted by one, so the
   // lane loads its window once — 8 + KS - 1 pixels — splits each element once, and every tap's fragment is a register
   // selection: even shifts are whole registers of the packed (hi | lo) rows, odd shifts one v_alignbit per register.
   constexpr int NROW = 8 + KS - 1 + ((8 + KS - 1) & 1);   // pixels a lane loads for one kernel row (even count)
-  struct RowData { f32x8 a; float raw[NROW]; };
+  struct RowData { f32x8 a[MW]; float raw[NROW]; };
   auto load_row = [&](long long qlane) {
     RowData r;
     const uint32_t d = (uint32_t)(qlane - q0);
-    r.a = fetch8_plain(rs_g, d * gstep + 4u * c, gstep);
+#pragma unroll
+    for (int m = 0; m < MW; ++m) r.a[m] = fetch8_plain(rs_g, d * gstep + 4u * c + 128u * m, gstep);
     const uint32_t vo = d * istep + 4u * c;
 #pragma unroll
     for (int j = 0; j < NROW; ++j)   // tap 0's descriptor starts R pixels to the left of the lane's first pixel
@@ -264,21 +286,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
     return r;
   };
   auto mac_row = [&](const RowData& rd) {
-    typedef _Float16 half2 __attribute__((ext_vector_type(2)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    half8 ah, al;
-    split8<false>(rd.a, sg, ah, al);
+    half8 ah[MW], al[MW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) split8<false>(rd.a[m], sg, ah[m], al[m]);
     uint32_t hi[NROW / 2], lo[NROW / 2];
 #pragma unroll
-    for (int j = 0; j < NROW / 2; ++j) {
-      const f32x2 xs = f32x2{rd.raw[2 * j], rd.raw[2 * j + 1]} * kConvActScale;
-      const f32x2 cl = {__builtin_amdgcn_fmed3f(xs[0], -65000.f, 65000.f), __builtin_amdgcn_fmed3f(xs[1], -65000.f, 65000.f)};
-      const half2 h = __builtin_convertvector(cl, half2);
-      f32x2 r = xs - __builtin_convertvector(h, f32x2);
-      r = f32x2{__builtin_amdgcn_fmed3f(r[0], -65000.f, 65000.f), __builtin_amdgcn_fmed3f(r[1], -65000.f, 65000.f)};
-      hi[j] = __builtin_bit_cast(uint32_t, h);
-      lo[j] = __builtin_bit_cast(uint32_t, (half2)__builtin_convertvector(r, half2));
-    }
+    for (int j = 0; j < NROW / 2; ++j) split_pair(rd.raw[2 * j], rd.raw[2 * j + 1], kConvActScale, hi[j], lo[j]);
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -292,9 +305,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
         }
       }
       const half8 bh = __builtin_bit_cast(half8, uh), bl = __builtin_bit_cast(half8, ul);
-      acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[kx], 0, 0, 0);
-      acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[kx], 0, 0, 0);
-      acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[kx], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MW; ++m) {
+        acc[m][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m][kx], 0, 0, 0);
+        acc[m][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m][kx], 0, 0, 0);
+        acc[m][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m][kx], 0, 0, 0);
+      }
     }
   };
   // interior (wave-uniform): every pixel of every lane's window is live, no tap leaves the image, no window wraps a row
@@ -325,23 +341,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
     ql += 16;
     x = xn; y = yn;
   }
-  float* dst = part + ((((size_t)chunk * mblks + mblk) * nblks + nblk) * TT + ky0 * KS) * 1024;
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    if (wave > 0) {
+  for (int m = 0; m < MW; ++m) {
+    float* dst = part + ((((size_t)chunk * mblks + mblk + m) * nblks + nblk) * TT + ky0 * KS) * 1024;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[t][r];
-    }
-    __syncthreads();
-    if (wave == 0) {
+    for (int t = 0; t < T; ++t) {
+      if (wave > 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = ((acc[t][r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        dst[(t * 32 + i) * 32 + c] = v;
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[m][t][r];
       }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = ((acc[m][t][r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;
+          dst[(t * 32 + i) * 32 + c] = v;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -369,7 +388,8 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
   const long long Q = (long long)B * H * W;
   const int pairs = mblks * nblks;
   static const int target_wgs = [] { const char* e = getenv("DFN_WGRAD_WGS"); return e ? atoi(e) : 1536; }();   // tuning aid (multiple of the 768 resident workgroups)
-  long long n_chunks = target_wgs / pairs;                // ~1536 workgroups
+  const int mw = (gscale && ks == 3 && mblks % 2 == 0) ? 2 : 1;   // output blocks per wave (split-f16 3x3: two)
+  long long n_chunks = target_wgs / (pairs / mw);         // ~1536 workgroups
   const long long max_by_work = (Q + 1023) / 1024;        // at least ~1024 pixels per workgroup
   if (n_chunks > max_by_work) n_chunks = max_by_work;
   if (n_chunks < 1) n_chunks = 1;
@@ -380,7 +400,11 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
     return hipErrorInvalidValue;
   const dim3 grid(pairs, int(n_chunks));
   if (gscale) {   // split-f16 product (fp32-grade): gscale = device [scale, 1 / scale] of g
-    if (ks == 3)
+    if (mw == 2) {
+      const dim3 grid2(pairs / 2, int(n_chunks));
+      for (int ky = 0; ky < 3; ++ky)   // one kernel row per launch, two output blocks per wave: 96 accumulator registers
+        hipLaunchKernelGGL((conv_wgrad_x3_kernel<3, 1, 2>), grid2, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), ky, gscale, part);
+    } else if (ks == 3)
       for (int ky = 0; ky < 3; ++ky)   // one kernel row per launch: 48 accumulator registers, no spills
         hipLaunchKernelGGL((conv_wgrad_x3_kernel<3, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), ky, gscale, part);
     else if (ks == 1) hipLaunchKernelGGL((conv_wgrad_x3_kernel<1, 1>), grid, dim3(256), 0, s, g, in, B, H, W, mblks, nblks, int(n_chunks), 0, gscale, part);
