@@ -140,31 +140,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 // range), with a wave-uniform fast path for groups that touch no image border.
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-// hi | lo halves of two scaled values, packed: hi = the TRUNCATED f16 of x * scale (v_cvt_pkrtz_f16_f32: any f16 within an ulp serves
-// as hi, the lo half takes the exact remainder, and truncation saturates at the largest finite f16 instead of overflowing — the clamps
-// of a rounding conversion are not needed), remainder by v_fma_mix_f32 on the packed halves in place: 5 VALU instructions per PAIR.
-__device__ __forceinline__ void split_pair(float x0, float x1, float scale, uint32_t& hi, uint32_t& lo) {
-  typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
-  x0 *= scale;
-  x1 *= scale;
-  hi = __builtin_bit_cast(uint32_t, (pk2)__builtin_amdgcn_cvt_pkrtz(x0, x1));
-  float r0, r1;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
-  lo = __builtin_bit_cast(uint32_t, (pk2)__builtin_amdgcn_cvt_pkrtz(r0, r1));
-}
 template <bool SAT>
 __device__ __forceinline__ void split8(const f32x8& v, float scale, half8& hi, half8& lo) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 h, l;
+  const f32x8 xs = v * scale;
+  f32x8 cl = xs;
+  if (SAT) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    uint32_t a, b;
-    split_pair(v[2 * k], v[2 * k + 1], scale, a, b);
-    h[k] = a; l[k] = b;
+    for (int k = 0; k < 8; ++k) cl[k] = __builtin_amdgcn_fmed3f(xs[k], -65000.f, 65000.f);
   }
-  hi = __builtin_bit_cast(half8, h);
-  lo = __builtin_bit_cast(half8, l);
+  hi = __builtin_convertvector(cl, half8);
+  f32x8 r = xs - __builtin_convertvector(hi, f32x8);
+  if (SAT) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = __builtin_amdgcn_fmed3f(r[k], -65000.f, 65000.f);
+  }
+  lo = __builtin_convertvector(r, half8);
 }
 
 // MW = 32-channel output blocks per wave (1 or 2): with two, the input window of a pixel group is loaded and split once for 64
@@ -289,9 +279,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
     half8 ah[MW], al[MW];
 #pragma unroll
     for (int m = 0; m < MW; ++m) split8<false>(rd.a[m], sg, ah[m], al[m]);
+    typedef _Float16 half2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     uint32_t hi[NROW / 2], lo[NROW / 2];
 #pragma unroll
-    for (int j = 0; j < NROW / 2; ++j) split_pair(rd.raw[2 * j], rd.raw[2 * j + 1], kConvActScale, hi[j], lo[j]);
+    for (int j = 0; j < NROW / 2; ++j) {
+      const f32x2 xs = f32x2{rd.raw[2 * j], rd.raw[2 * j + 1]} * kConvActScale;
+      const f32x2 cl = {__builtin_amdgcn_fmed3f(xs[0], -65000.f, 65000.f), __builtin_amdgcn_fmed3f(xs[1], -65000.f, 65000.f)};
+      const half2 h = __builtin_convertvector(cl, half2);
+      f32x2 r = xs - __builtin_convertvector(h, f32x2);
+      r = f32x2{__builtin_amdgcn_fmed3f(r[0], -65000.f, 65000.f), __builtin_amdgcn_fmed3f(r[1], -65000.f, 65000.f)};
+      hi[j] = __builtin_bit_cast(uint32_t, h);
+      lo[j] = __builtin_bit_cast(uint32_t, (half2)__builtin_convertvector(r, half2));
+    }
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
