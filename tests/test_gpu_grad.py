@@ -8,9 +8,9 @@ torch autograd through the CPU oracle.  Tolerances, relative to the largest grad
     through the whole render, 2e-3 for d c2w — a signed sum over all rays of per-ray terms that largely
     cancel, so fp32 round-off of the terms is amplified (the oracle and the reference themselves differ
     by ~1e-4 there, tests/test_oracle_golden.py);
-  * f16-input MFMA path: 1e-1 max / 3e-2 relative L2.  A hidden unit whose pre-activation is within f16
-    rounding of zero flips its ReLU gate, which changes that sample's gradient by O(1/width); this is
-    inherent to f16 activations, not an accumulation error, and is why the host defaults to fp32 here."""
+  * plain-f16 gradient arithmetic is not offered (round 2): a hidden unit whose pre-activation is within f16 rounding of zero flips
+    its ReLU gate, which put that mode at 3e-2 of autograd; the library refuses DFN_PREC_F16 on every gradient entry point
+    (checked at the end of test_quarter_res_pose_gradient_vs_oracle)."""
 import os
 
 import numpy as np
