@@ -1,0 +1,29 @@
+#!/bin/bash
+# SQ counters per kernel of an arbitrary workload: tools/gpu_pmc.sh NAME cmd...  -> gpurun_out/NAME_pmc.json
+# (counters only with --kernel-trace: the node pool refuses PMC combined with API tracing)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+NAME=$1; shift
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pm_$NAME
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA \
+  --kernel-trace --output-format csv -d /tmp/pm_$NAME -o p -- "$@" > /dev/null 2>&1
+python3 - <<PY
+import csv, collections, json
+rows = list(csv.DictReader(open("/tmp/pm_$NAME/p_counter_collection.csv")))
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+for row in rows:
+    k = row["Kernel_Name"].replace("dfn::", "").replace("void ", "").split("(")[0]
+    agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k].add(row["Dispatch_Id"])
+out = {}
+for k, d in agg.items():
+    w = d["SQ_WAVE_CYCLES"]
+    if w <= 0 or d["SQ_INSTS_MFMA"] <= 0: continue
+    out[k] = {"dispatches": len(n[k]),
+              # SQ_WAVE_CYCLES counts quad-cycles per wave, MFMA_BUSY cycles per SIMD: with W waves per SIMD, busy fraction = ratio * W / 4
+              "mfma_busy_cycles_per_wave_quadcycle": round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / w, 3),
+              "wait_any": round(d["SQ_WAIT_ANY"] / w, 3), "wait_inst_any": round(d["SQ_WAIT_INST_ANY"] / w, 3),
+              "active_inst_any": round(d["SQ_ACTIVE_INST_ANY"] / w, 3), "valu_per_mfma": round(d["SQ_INSTS_VALU"] / max(d["SQ_INSTS_MFMA"], 1), 2),
+              "mfma_insts": d["SQ_INSTS_MFMA"]}
+json.dump(out, open("$R/gpurun_out/${NAME}_pmc.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_insts"])[:14]: print(k[:70], v)
+PY
