@@ -198,7 +198,16 @@ def hbm_records(prof, K, E, dev):
             b = bpr * rays * K / n
             out[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": b, "achieved_GBps": b / (ms * 1e-3) / 1e9,
                          "frac_of_hbm_peak": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_ray": what,
+                         "traffic": pmc_traffic(name),   # HBM bytes per launch from the committed PMC passes (as roofline.traffic)
                          "launches_per_step": n / K}
+    # what the PMC passes say about the two that sit near 10 % of the HBM rate: their traffic is the algorithmic bytes, they are bound
+    # by instruction issue, not by memory (profiles/*_pmc_summary.json: SQ_INSTS_VALU per launch x 4 cycles over the SIMD time)
+    notes = {"sample_fine_kernel": "VALU-issue-bound, not HBM-bound: ~440 vector instructions per ray (inverse-CDF search, scans, rank merge), "
+                                   "about two thirds of the SIMD issue time; HBM traffic = the algorithmic bytes",
+             "ray_bias_kernel": "VALU-bound: 6 208 fp32 MACs per ray for the two per-ray tables (12.4 KFLOP), HBM traffic 1.07x the algorithmic bytes"}
+    for k, v in notes.items():
+        if k in out:
+            out[k]["limited_by"] = v
     # the raw-path compositor (runs when the caller asks for `raw` / on the gradient path): one 61,440-ray pass of random raw
     n, Nf = 61440, NC + NI
     g = torch.Generator(device=dev).manual_seed(0)
