@@ -649,6 +649,23 @@ def main():
                                "arithmetic": PREC_TEXT[prec], "roofline": mlp_roofline(prof2, k2, prec, v2)}
                 if ref_pack is not None:
                     precs[prec]["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], prec, dev)
+            # split-f16 fine network with the coarse network in f16 (DFN_RENDER_COARSE_F16): the coarse pass only places the importance
+            # samples, the pixel is composited from the fp32-grade fine outputs — what the DFNet_dm step's tracked render does by default
+            if args.precision != "f16x3":
+                E.set_render_options(coarse_f16=True)
+                try:
+                    k2 = max(2, min(K, 6))
+                    dt2, prof2 = timed_render(E, lib, "f16x3", poses, hist, rgbs, disps, acc, k2, 1)
+                    v2 = k2 * rays / dt2
+                    precs["f16x3_fine_f16_coarse"] = {
+                        "value": v2, "unit": "rays/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2, "warmup": 1,
+                        "arithmetic": "fine network split-f16 (fp32-grade), coarse network (sample placement only) f16 MFMA inputs",
+                        "roofline": mlp_roofline(prof2, k2, "f16x3", v2)}
+                    precs["f16x3_fine_f16_coarse"]["roofline"].pop("whole_path_mfma_frac", None)   # two peaks on this path: not defined
+                    if ref_pack is not None:
+                        precs["f16x3_fine_f16_coarse"]["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], "f16x3", dev)
+                finally:
+                    E.set_render_options(coarse_f16=False)
             line["precisions"] = precs
             sec = {}
             if args.cpu_sample > 0:

@@ -15,7 +15,7 @@ DFN_PREC_F16X3 = 2  # DFNet only: split-f16 (fp32-grade results at f16 MFMA rate
 PRECISIONS = {"f16": DFN_PREC_F16, "fp16": DFN_PREC_F16, "f32": DFN_PREC_F32, "fp32": DFN_PREC_F32, "f16x3": DFN_PREC_F16X3}
 
 COMP_TEST_TIME, COMP_STATIC_ONLY, COMP_WHITE_BKGD = 1, 2, 4
-RENDER_LINDISP = 1
+RENDER_LINDISP, RENDER_COARSE_F16 = 1, 2
 
 
 class DfnError(RuntimeError):

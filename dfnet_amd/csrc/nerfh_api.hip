@@ -407,7 +407,7 @@ int upload(const void* src, size_t bytes, void** dst) {
 
 extern "C" int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_render_options: null handle");
-  if (flags & ~DFN_RENDER_LINDISP) return set_error(DFN_ERR_UNSUPPORTED, "dfn_nerfh_set_render_options: unknown option bits 0x%x", flags);
+  if (flags & ~(DFN_RENDER_LINDISP | DFN_RENDER_COARSE_F16)) return set_error(DFN_ERR_UNSUPPORTED, "dfn_nerfh_set_render_options: unknown option bits 0x%x", flags);
   h->render_flags = flags;
   return DFN_OK;
 }
@@ -792,7 +792,8 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
   // (f16 variants 0/1/3 hold 64 points per wave; the f32 and 3-block variants keep the separate compositor).
   const int var = mlp_variant_of(h);
   const bool fused = !raw_out && Nf % 64 == 0 && prec == DFN_PREC_F16 && var != 2 && h->desc.width == kWidth && !getenv("DFN_NO_FUSED_COMPOSITE");
-  const PackedNet& nc = h->net[0][prec][var];
+  const int cprec = (h->render_flags & DFN_RENDER_COARSE_F16) ? DFN_PREC_F16 : prec;   // the coarse pass only places the fine samples
+  const PackedNet& nc = h->net[0][cprec][var];
   const PackedNet& nf = h->net[1][prec][var];
   const int cus = device_cu_count();
   const size_t chunk = chunk_rays(n_rays);
@@ -807,7 +808,7 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
       MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale,
                  h->render_flags & DFN_RENDER_LINDISP};
       ScopedTimer t(0, s);
-      CHECK_HIP(launch_mlp(false, prec, var, a, cus, s, h->desc.width), "render: coarse MLP");
+      CHECK_HIP(launch_mlp(false, cprec, var, a, cus, s, h->desc.width), "render: coarse MLP");
     }
     {
       ScopedTimer t(DFN_PROF_SAMPLE_FINE, s);

@@ -32,14 +32,18 @@ class NerfHEngine:
         self.fast = width in (128, 256)   # register-resident MFMA kernels; other widths run the generic layer-by-layer fp32 path
         self._ws = None
         self.lindisp = False
+        self.coarse_f16 = False
 
-    def set_render_options(self, lindisp=False):
-        """render_rays keyword options that every entry point of this handle applies (dfn_nerfh_set_render_options):
-        lindisp = coarse depths linear in disparity (rendering.py:272-273)."""
+    def set_render_options(self, lindisp=False, coarse_f16=None):
+        """render_rays options that every entry point of this handle applies (dfn_nerfh_set_render_options): lindisp = coarse
+        depths linear in disparity (rendering.py:272-273); coarse_f16 (None = leave as is) = the coarse network of the test-time
+        render runs with f16 inputs whatever precision the call names (it only places the fine samples)."""
         lindisp = bool(lindisp)
-        if lindisp != self.lindisp:
-            check(self.lib.dfn_nerfh_set_render_options(self.handle, _lib.RENDER_LINDISP if lindisp else 0), "dfn_nerfh_set_render_options")
-            self.lindisp = lindisp
+        coarse_f16 = self.coarse_f16 if coarse_f16 is None else bool(coarse_f16)
+        if lindisp != self.lindisp or coarse_f16 != self.coarse_f16:
+            flags = (_lib.RENDER_LINDISP if lindisp else 0) | (_lib.RENDER_COARSE_F16 if coarse_f16 else 0)
+            check(self.lib.dfn_nerfh_set_render_options(self.handle, flags), "dfn_nerfh_set_render_options")
+            self.lindisp, self.coarse_f16 = lindisp, coarse_f16
         return self
 
     def __del__(self):

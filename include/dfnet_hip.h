@@ -75,7 +75,11 @@ int dfn_nerfh_commit(dfn_nerfh_t h);
  * that takes this handle until changed.  DFN_RENDER_LINDISP: the coarse depths are linear in disparity, z = 1 / ((1 - t) / near +
  * t / far) (rendering.py:272-273; near must be > 0).  white_bkgd is not offered: in the reference it reaches the coarse compositor
  * in the output_transient slot (rendering.py:295) and raises TypeError at test time. */
-enum { DFN_RENDER_LINDISP = 1 };
+/* DFN_RENDER_COARSE_F16 (not a reference keyword; a precision choice of this library): the COARSE network of the test-time render
+ * runs with f16 MFMA inputs whatever `prec` the call names, the fine network in `prec`.  The coarse pass only places the importance
+ * samples (z_samples are detached, rendering.py:302; its colour is never produced at test time), so with prec = DFN_PREC_F16X3 the pixel
+ * is still composited from fp32-grade fine-network outputs. */
+enum { DFN_RENDER_LINDISP = 1, DFN_RENDER_COARSE_F16 = 2 };
 int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags);
 
 /* ------------------------------------------------------------------ stage-level entry points

@@ -195,3 +195,30 @@ def test_white_bkgd_fails_like_the_reference(scene, gold):
         rendering.render(6, 8, 7.3, c2w=dev(g["c2w"]), near=0., far=2.5, img_idx=dev(g["hist"])[None], **kwargs(E, 16, 32, white_bkgd=True))
     with pytest.raises(DfnError, match="unknown option"):
         check(E.lib.dfn_nerfh_set_render_options(E.handle, 6), "dfn_nerfh_set_render_options")
+
+
+def test_coarse_f16_option_keeps_the_fp32_grade_pixel(scene, gold):
+    """DFN_RENDER_COARSE_F16: the coarse network (sample placement only) in f16, the fine network in split-f16.  The pixel stays
+    within the fp32-grade tolerance of the golden render; the raw samples sit at slightly different depths (f16 densities move the
+    inverse-CDF samples), so they are compared through the composited maps only."""
+    E = scene[0]
+    g = gold("g7_render_image")
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    ref = E.render_image(dev(g["c2w"]), H, W, focal, dev(g["hist"]), int(g["Nc"]), int(g["Ni"]), float(g["near"]), float(g["far"]),
+                         precision="f16x3")[0].clone()
+    E.set_render_options(coarse_f16=True)
+    try:
+        assert E.coarse_f16
+        rgb, disp, acc = E.render_image(dev(g["c2w"]), H, W, focal, dev(g["hist"]), int(g["Nc"]), int(g["Ni"]), float(g["near"]),
+                                        float(g["far"]), precision="f16x3")
+        e = (relmax(rgb, g["rgb"]), relmax(disp, g["disp"]), relmax(acc, g["acc"]))
+        print(f"coarse f16 + fine f16x3 vs the reference's render: {e}")
+        assert max(e) < 2e-5, e
+        assert not torch.equal(rgb, ref)          # the option is live
+        E.set_render_options(lindisp=False)       # other options leave it alone
+        assert E.coarse_f16
+    finally:
+        E.set_render_options(coarse_f16=False)
+    rgb2 = E.render_image(dev(g["c2w"]), H, W, focal, dev(g["hist"]), int(g["Nc"]), int(g["Ni"]), float(g["near"]), float(g["far"]),
+                          precision="f16x3")[0]
+    assert torch.equal(rgb2, ref)
