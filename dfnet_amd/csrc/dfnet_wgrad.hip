@@ -387,7 +387,7 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
   if (cout % 32 || cin % 32 || (ks != 1 && ks != 3 && ks != 5)) return hipErrorInvalidValue;
   const long long Q = (long long)B * H * W;
   const int pairs = mblks * nblks;
-  static const int target_wgs = [] { const char* e = getenv("DFN_WGRAD_WGS"); return e ? atoi(e) : 1536; }();   // tuning aid (multiple of the 768 resident workgroups)
+  constexpr int target_wgs = 1536;   // two rounds of the 768 resident workgroups (384 ... 3072 measure the same within noise)
   const int mw = (gscale && ks == 3 && mblks % 2 == 0) ? 2 : 1;   // output blocks per wave (split-f16 3x3: two)
   long long n_chunks = target_wgs / (pairs / mw);         // ~1536 workgroups
   const long long max_by_work = (Q + 1023) / 1024;        // at least ~1024 pixels per workgroup

@@ -779,7 +779,7 @@ Workspace carve(char* base, size_t n_rays, int Nc, int Ni, bool own_rays) {
   w.z = take(chunk * Nf * 4);
   w.raw = take(chunk * Nf * 9 * 4);
   w.bias = take(chunk * ray_bias_floats(kMaxWidth) * 4);
-  w.partial = take(chunk * ((Nf + 63) / 64) * 12 * 4);
+  w.partial = take(chunk * ((Nf + 31) / 32) * 12 * 4);
   w.total = off;
   return w;
 }
@@ -788,10 +788,12 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
                 size_t hist_rows, size_t n_rays, int Nc, int Ni, float near, float far, float* rgb, float* disp,
                 float* acc, float* raw_out, const Workspace& w, hipStream_t s) {
   const int Nf = Nc + Ni;
-  // Compositing is fused into the fine kernel when a wave's 64 points are one ray segment and raw is not wanted
-  // (f16 variants 0/1/3 hold 64 points per wave; the f32 and 3-block variants keep the separate compositor).
+  // Compositing is fused into the fine kernel when a wave's points are one ray segment and raw is not wanted: 64 samples per wave in
+  // the f16 variants 0/1/3, 32 in the split-f16 and fp32 kernels (one point block per wave); the 3-block f16 variant and netwidth
+  // 256 keep the separate compositor.
   const int var = mlp_variant_of(h);
-  const bool fused = !raw_out && Nf % 64 == 0 && prec == DFN_PREC_F16 && var != 2 && h->desc.width == kWidth && !getenv("DFN_NO_FUSED_COMPOSITE");
+  const int seg = prec == DFN_PREC_F16 ? 64 : 32;
+  const bool fused = !raw_out && Nf % seg == 0 && !(prec == DFN_PREC_F16 && var == 2) && h->desc.width == kWidth;
   const int cprec = (h->render_flags & DFN_RENDER_COARSE_F16) ? DFN_PREC_F16 : prec;   // the coarse pass only places the fine samples
   const PackedNet& nc = h->net[0][cprec][var];
   const PackedNet& nf = h->net[1][prec][var];
@@ -826,7 +828,7 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     }
     if (fused) {
       ScopedTimer t(DFN_PROF_COMBINE, s);
-      CHECK_HIP(launch_composite_combine(w.partial, n, Nf / 64, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
+      CHECK_HIP(launch_composite_combine(w.partial, n, Nf / seg, 0.1f, DFN_COMP_TEST_TIME | DFN_COMP_STATIC_ONLY, rgb + r0 * 3,
                                          disp + r0, acc + r0, s),
                 "render: composite combine");
     } else {

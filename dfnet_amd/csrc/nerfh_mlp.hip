@@ -229,7 +229,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
       }
     }
     if (a.partial) {
-      // Fused compositing (n_samples % 64 == 0): this wave holds 64 consecutive samples of ONE ray, sample
+      // Fused compositing (n_samples % (32 NB) == 0): this wave holds 32 NB consecutive samples of ONE ray, sample
       // 32 nb + p on lane p of half 0.  Transmittance factorises over segments, so the wave composites its
       // segment locally (products P and sums relative to the segment start) and a tiny combine pass chains
       // the segments of a ray (nerfh_stages.hip: composite_combine_kernel).  `raw` never reaches HBM.
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
       for (int c = 0; c < 3; ++c) s_rgb[c] = wave_sum(s_rgb[c]);
       s_acc = wave_sum(s_acc); s_dso = wave_sum(s_dso); s_dj = wave_sum(s_dj); s_beta = wave_sum(s_beta);
       if (st.lane == 0 && pt_cur[0] < n_pts) {
-        f32x4* dst = reinterpret_cast<f32x4*>(a.partial + (size_t)(uint32_t(pt_cur[0]) >> 6) * 12);
+        f32x4* dst = reinterpret_cast<f32x4*>(a.partial + (size_t)(uint32_t(pt_cur[0]) / uint32_t(NB * 32)) * 12);   // one segment per wave
         dst[0] = f32x4{s_rgb[0], s_rgb[1], s_rgb[2], s_acc};
         dst[1] = f32x4{s_dso, s_dj, s_beta, Pj};
         dst[2] = f32x4{Ps, 0.f, 0.f, 0.f};
@@ -311,12 +311,7 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
   if (n_pts <= 0) return hipSuccess;
   if (n_pts >= (1LL << 31)) return hipErrorInvalidValue;  // kernels index points with 32 bits; callers chunk
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
-  static int wg_per_cu = 0;
-  if (!wg_per_cu) {
-    const char* e = getenv("DFN_WG_PER_CU");  // tuning aid
-    wg_per_cu = (e && e[0] >= '1' && e[0] <= '8') ? e[0] - '0' : WG_PER_CU;
-  }
-  const long long slots = (long long)n_cu * wg_per_cu;  // resident workgroups
+  const long long slots = (long long)n_cu * WG_PER_CU;  // resident workgroups
   const int grid = int(n_tiles < slots ? n_tiles : slots);
   const uint32_t lds = lds_bytes<P, UMB, WAVES, NB, W>();
   auto kern = fine ? nerfh_fine_kernel<P, FAST, WAVES, UMB, NB, PIPE, W> : nerfh_coarse_kernel<P, FAST, WAVES, UMB, NB, PIPE, W>;
@@ -340,8 +335,6 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width) {
   if (width == 256) {
     if (prec == 0) {
-      static const bool nb2 = getenv("DFN_W256_NB2") != nullptr;   // A/B: four waves x two point blocks (512 registers)
-      if (nb2) return launch_one<PrecF16, true, 4, unit_mb_w256<PrecF16>(), 2, 1, false, 256>(fine, a, n_cu, stream);
       return launch_one<PrecF16, true, 8, unit_mb_w256<PrecF16>(), 1, 1, false, 256>(fine, a, n_cu, stream);
     }
     if (prec == 2) return launch_one<PrecX3, false, 4, unit_mb_w256<PrecX3>(), 1, 1, false, 256>(fine, a, n_cu, stream);
