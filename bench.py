@@ -13,19 +13,22 @@ already running under a launcher (WORLD_SIZE unset); under `python -m torch.dist
 --gpus N` it reads RANK / LOCAL_RANK / WORLD_SIZE as given.
 
 Prints ONE JSON line (rank 0):
-  value / ms_per_step   the headline: f16 MFMA inputs with fp32 accumulation, gated IN THE SAME RUN by
-                        `cpu_baseline.parity_vs_oracle` (north_star tolerance 1e-3; measured 1e-5);
-  precisions            the same workload on the two fp32-grade paths — "f16x3" (split-f16: hi/lo f16 operands, three
-                        MFMAs per product, fp32 accumulate) and "f32" (exact fp32 MFMA) — each with value, ms_per_step,
-                        the fine kernel's roofline against ITS peak, and parity vs the oracle;
+  value / ms_per_step   the headline, at REFERENCE precision (the reference computes in fp32): `--precision f16x3` (default) =
+                        split-f16, fp32-grade — every operand hi + lo in f16, three f16 MFMAs per product, fp32 accumulate —
+                        admitted IN THE SAME RUN by `cpu_baseline.parity_vs_oracle` and by `config.fp32_grade_check` (the fine
+                        network's 9 raw channels, split-f16 vs the exact-fp32 MFMA kernel on the same samples);
+  precisions            the same workload on the other arithmetic modes — "f32" (exact fp32 MFMA), "f16" (f16 MFMA inputs:
+                        narrower than the reference, the fast option) and split-f16 fine + f16 coarse — each with value,
+                        ms_per_step, the fine kernel's roofline against ITS peak, and parity vs the oracle;
   roofline              dominant kernel (fine MLP, MFMA bound): algorithmic FLOPs per launch / average launch duration
                         measured with HIP events on the launch stream (dfn_profile_*);
   hbm                   achieved GB/s of the HBM-bound stage kernels (sampling, ray bias, compositing), same events;
   secondary             BASELINE configs[3] (DFNet forward ms / 480x640 image), configs[4] (DFNet_dm step ms at the per-GPU
                         shape), DFNet's own training step (N2), the NeRF-H optimisation step and a netwidth-256 frame, each with its parity
                         number against the oracle;
-  cpu_baseline          the oracle (torch-CPU port of the reference path) on a bounded ray sample on this box's host
-                        cores, best of a thread-count sweep (rank 0, N = 1 only).
+  cpu_baseline          the oracle (torch-CPU port of the reference path) on this box's host cores as SURVEY §8(d) defines it:
+                        median of 3 runs over a 16,384-ray subset of the judged frame at the fastest thread count of a sweep,
+                        plus one full 160x120 frame at 32+64 samples (BASELINE configs[0] shape) (rank 0, N = 1 only).
 """
 import argparse
 import ctypes
@@ -49,23 +52,32 @@ PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f16x3": 2500.0 / 3}  # dense MFMA p
 HBM_PEAK_GBS = 8000.0
 PREC_TEXT = {"f16": "f16 MFMA inputs / fp32 accumulate", "f32": "exact fp32 MFMA",
              "f16x3": "split-f16: hi/lo f16 operands, 3 f16 MFMAs per product, fp32 accumulate (fp32-grade)"}
+PREC_GATE = {
+    "f16x3": "split-f16, fp32-grade: the reference computes in fp32; every product here is hi*hi + hi*lo + lo*hi of f16 halves "
+             "accumulated in fp32 (the dropped lo*lo term is 2^-22 relative), checked in this run against the exact-fp32 MFMA kernel "
+             "(config.fp32_grade_check) and against the fp32 oracle (cpu_baseline.parity_vs_oracle)",
+    "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference's own arithmetic",
+    "f16": "NARROWER than the reference (f16 MFMA inputs, fp32 accumulate): admitted only by the in-run parity check against the "
+           "fp32 oracle (north_star tolerance 1e-3); not a reference-precision number"}
 # profile slots of dfn_profile_read (include/dfnet_hip.h: DFN_PROF_*)
 P_COARSE, P_FINE, P_SAMPLE, P_RAYBIAS, P_COMBINE, P_COMPOSITE = range(6)
 
 
-def pmc_traffic(kernel="nerfh_fine_kernel"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/*_pmc_summary.json: separate --pmc passes of this same command, tools/gpu_round.sh).
-    FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
-    (MI355X_MICROARCH.md §HBM), so it is doubled.  None when no summary is committed."""
+PREC_KERNEL_TAG = {"f16": "PrecF16", "f32": "PrecF32", "f16x3": "PrecX3"}
+
+
+def pmc_traffic(kernel="nerfh_fine_kernel", precision=None):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/*_pmc_summary*.json: separate
+    --pmc passes of this same command per precision, tools/gpu_round.sh).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+    FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md §HBM), so it is doubled.
+    `precision` selects the template instantiation (PrecF16 / PrecX3 / PrecF32 in the kernel name).  None when no summary
+    holds the kernel."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
-    for name, c in d.items():
-        if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c and c.get("dispatches"):
-            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / c["dispatches"]
+    tag = PREC_KERNEL_TAG.get(precision)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary*.json")), reverse=True):
+        for name, c in json.load(open(f)).items():
+            if kernel in name and (tag is None or tag in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c and c.get("dispatches"):
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / c["dispatches"]
     return None
 
 
@@ -85,15 +97,17 @@ def oracle_sample(sample_rays):
 
 
 def cpu_baseline(sample_rays):
-    """The oracle on `sample_rays` rays of frame 0.  The thread count is swept on a quarter of the sample (the oracle is
-    one torch-CPU process; 128 threads on 8,192-ray chunks is several times SLOWER than 8) and the best setting is then
-    timed on the whole sample.  Returns (record, reference outputs on the sample)."""
+    """the oracle on a `sample_rays`-ray subset of frame 0 at the judged 64+128 samples — the thread count is swept
+    on an eighth of the sample (the oracle is one torch-CPU process; 128 threads are several times SLOWER than 8-16 here), then
+    the fastest setting is timed three times on the whole subset (`value` = the median) — plus one full 160x120 frame at 32+64
+    samples (BASELINE configs[0] shape).  Returns (record, (rows, reference outputs on the subset))."""
+    from dfnet_amd import synthetic as syn
     from oracle import nerfh_oracle as orc
     rows, (c, f, ea, et) = oracle_sample(sample_rays)
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
     cand = sorted({t for t in (8, 16, 32, 64, ncpu, default_threads) if 1 <= t <= ncpu})
-    sub = rows[: max(512, sample_rays // 4)]
+    sub = rows[: max(512, sample_rays // 8)]
     sweep = {}
     with torch.no_grad():
         for t in cand:
@@ -104,17 +118,47 @@ def cpu_baseline(sample_rays):
             sweep[t] = sub.shape[0] / (time.perf_counter() - t0)
         best = max(sweep, key=sweep.get)
         torch.set_num_threads(best)
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ref = orc.render_rays(rows, c, f, ea, et, NC, NI)
+            runs.append(time.perf_counter() - t0)
+        dt = sorted(runs)[1]
+        # one full frame of BASELINE configs[0]'s shape (160x120, 32+64 samples)
         t0 = time.perf_counter()
-        ref = orc.render_rays(rows, c, f, ea, et, NC, NI)
-        dt = time.perf_counter() - t0
+        orc.render(120, 160, FOCAL / 4, 32768, c, f, ea, et, 32, 64, NEAR, FAR, syn.HIST_IDX, c2w=torch.from_numpy(syn.orbit_pose(0, 8)))
+        dt_frame = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
     rec = {"value": sample_rays / dt, "unit": "rays/s", "cores": best, "kind": "port",
-           "sample": f"{sample_rays} random rays of frame 0 at 64+128 samples, one chunk, {dt:.1f} s "
-                     f"(oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32, autograd anomaly mode off, no_grad)",
+           "sample": f"median of 3 runs over {sample_rays} random rays of frame 0 at 64+128 samples, one chunk each "
+                     f"({', '.join('%.1f' % r for r in runs)} s; oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32, "
+                     "autograd anomaly mode off, no_grad)",
+           "frame_640x480_extrapolated_s": H * W / (sample_rays / dt),
+           "full_frame_160x120_32+64": {"seconds": dt_frame, "rays_per_s": 160 * 120 / dt_frame, "chunk": 32768},
            "host_cpus": ncpu, "torch_default_threads": default_threads,
            "thread_sweep_rays_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
            "sweep_sample": f"{sub.shape[0]} rays per setting; `cores` = the fastest setting, used for `value`"}
     return rec, (rows, ref)
+
+
+def fp32_grade_check(E, dev, n=4096):
+    """What admits split-f16 as reference-precision arithmetic: the fine network's raw output (9 channels per sample) on the SAME
+    samples from the split-f16 kernel and from the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32), n rays x 192 samples."""
+    from dfnet_amd import engine as eng, synthetic as syn
+    o, d, v = eng.raygen(H, W, FOCAL, torch.from_numpy(syn.orbit_pose(0, 8)).to(dev))
+    sel = torch.randperm(H * W, generator=torch.Generator().manual_seed(1))[:n].to(dev)
+    o, d, v = (t.reshape(-1, 3)[sel].contiguous() for t in (o, d, v))
+    hist = torch.from_numpy(syn.HIST_IDX).to(dev)
+    sigma = E.mlp_coarse(o, d, NC, NEAR, FAR, precision="f32")
+    z = eng.sample_fine(sigma, NI, NEAR, FAR)
+    r32 = E.mlp_fine(o, d, v, hist, z, precision="f32").double()
+    r3 = E.mlp_fine(o, d, v, hist, z, precision="f16x3").double()
+    diff = (r3 - r32).abs().reshape(-1, 9)
+    scale = r32.abs().reshape(-1, 9).amax(0).clamp_min(1e-30)
+    return {"raw_max_rel_f16x3_vs_f32": float((diff.amax(0) / scale).max()),
+            "raw_rms_rel_f16x3_vs_f32": float((diff.pow(2).mean(0).sqrt() / scale).max()),
+            "per": "channel: max |f16x3 - f32| / max |f32| over the channel, worst of the 9 raw channels",
+            "rays": n, "samples_per_ray": NC + NI}
 
 
 def parity(engine, rows, ref, precision, dev):
@@ -569,8 +613,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32", "f16x3"], help="arithmetic of the headline value")
-    ap.add_argument("--cpu-sample", type=int, default=8192, help="rays in the CPU baseline sample (0 = skip the oracle legs)")
+    ap.add_argument("--precision", default="f16x3", choices=["f16", "f32", "f16x3"],
+                    help="arithmetic of the headline value (default: split-f16, fp32-grade = the reference's precision)")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="rays in the CPU baseline subset (0 = skip the oracle legs)")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no precisions / hbm / secondary records)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--cpu-dry", action="store_true", help="no GPU work: exercise launch + sharding + gather only (CPU tests)")
@@ -614,10 +659,11 @@ def main():
         rays = H * W
         value = world * K * rays / dt
         roof = mlp_roofline(prof, K, args.precision, value / world)
-        roof["traffic"] = pmc_traffic() if args.precision == "f16" else None
-        roof["traffic_note"] = ("HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) from profiles/; algorithmic bytes per launch = "
-                                "rays * (768 z + 24 o,d + 512 ray-bias + 144 segment composites); raw (6912 B/ray) stays in registers "
-                                "since compositing is fused")
+        roof["traffic"] = pmc_traffic("nerfh_fine_kernel", args.precision)
+        roof["traffic_note"] = ("HBM bytes per launch of this precision's instantiation, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) from "
+                                "profiles/*_pmc_summary*.json; algorithmic bytes per launch = rays * (768 z + 24 o,d + 512 ray-bias + "
+                                "segment composites: 144 at 64-sample segments (f16), 288 at 32-sample segments (f16x3 / f32)); raw "
+                                "(6912 B/ray) stays in registers since compositing is fused")
         line = {
             "metric": "rendered rays/sec (64+128 samples, 640x480)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -626,9 +672,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic random-weight NeRF-H (D=8, W=128), 640x480, "
                                    "64+128 samples, test-time render_image, 1 frame per step per GPU",
                        "rays_per_step_per_gpu": rays, "precision": PREC_TEXT[args.precision],
-                       "precision_gate": "the reference computes in fp32; the headline's f16-input arithmetic is admitted by the in-run "
-                                         "parity check against the fp32 oracle (cpu_baseline.parity_vs_oracle, north_star tolerance "
-                                         "1e-3); the fp32-grade paths are timed in the same run under `precisions`",
+                       "precision_gate": PREC_GATE[args.precision],
                        "parallelism": f"frames sharded over {world} GPU(s), gather at end"},
             "roofline": roof,
         }
@@ -640,18 +684,21 @@ def main():
                 rec["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], args.precision, dev)
                 line["cpu_baseline"] = rec
             precs = {}
-            for prec, k2, w2 in (("f16x3", max(2, min(K, 6)), 1), ("f32", 2, 1)):
+            if args.precision == "f16x3":
+                line["config"]["fp32_grade_check"] = fp32_grade_check(E, dev)
+            for prec, k2, w2 in (("f16x3", max(2, min(K, 6)), 1), ("f32", 2, 1), ("f16", max(2, min(K, 10)), 2)):
                 if prec == args.precision:
                     continue
                 dt2, prof2 = timed_render(E, lib, prec, poses, hist, rgbs, disps, acc, k2, w2)
                 v2 = k2 * rays / dt2
                 precs[prec] = {"value": v2, "unit": "rays/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2, "warmup": w2,
                                "arithmetic": PREC_TEXT[prec], "roofline": mlp_roofline(prof2, k2, prec, v2)}
+                precs[prec]["roofline"]["traffic"] = pmc_traffic("nerfh_fine_kernel", prec)
                 if ref_pack is not None:
                     precs[prec]["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], prec, dev)
             # split-f16 fine network with the coarse network in f16 (DFN_RENDER_COARSE_F16): the coarse pass only places the importance
             # samples, the pixel is composited from the fp32-grade fine outputs — what the DFNet_dm step's tracked render does by default
-            if args.precision != "f16x3":
+            if args.precision != "f16":
                 E.set_render_options(coarse_f16=True)
                 try:
                     k2 = max(2, min(K, 6))

@@ -22,6 +22,7 @@ struct MlpArgs {
   unsigned long long* timing;  // DFN_TIMING builds: per-wave cycle counters [total, dma wait, barrier, tile inputs]
   float in_scale;          // split-f16 only: weight scale x activation scale carried by the accumulators (else 1)
   int lindisp;             // coarse: depths linear in disparity instead of depth (rendering.py:272-273)
+  int dma_waves;           // waves of a workgroup that issue the weight DMA (0 = the kernel geometry's default, launch_one)
 };
 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width = 128);

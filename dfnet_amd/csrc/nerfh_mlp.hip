@@ -46,6 +46,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
+  st.dma_waves = a.dma_waves > 0 && a.dma_waves < WAVES ? a.dma_waves : WAVES;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
   st.lane_mul = 1.f;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
+  st.dma_waves = a.dma_waves > 0 && a.dma_waves < WAVES ? a.dma_waves : WAVES;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
   st.lane_mul = 1.f;
@@ -322,7 +324,13 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
     if (e != hipSuccess) return e;
     attr_done[fine] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+  MlpArgs b = a;
+  if (b.dma_waves == 0) {  // DFN_DMA_WAVES=n: A/B aid
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("DFN_DMA_WAVES"); env = e ? atoi(e) : 0; }
+    b.dma_waves = env > 0 ? env : (WAVES == 8 ? 4 : WAVES);  // 8-wave workgroups: the four older waves idle a third of their time at the unit barriers
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, b);
   return hipGetLastError();
 }
 
@@ -347,7 +355,10 @@ hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_
     if (variant == 2) return launch_one<PrecF16, true, 4, 8, 3, 1, true>(fine, a, n_cu, stream);
     return launch_one<PrecF16, true, 8, 8, 2, 1, false>(fine, a, n_cu, stream);
   }
-  if (prec == 2) return launch_one<PrecX3, false, 8, unit_mb<PrecX3>(0), 1, 1, false>(fine, a, n_cu, stream);
+  if (prec == 2) {  // split-f16: variant 3 = without the pipelined epilogue (A/B reference), every other variant with it
+    if (variant == 3) return launch_one<PrecX3, false, 8, unit_mb<PrecX3>(0), 1, 1, false>(fine, a, n_cu, stream);
+    return launch_one<PrecX3, false, 8, unit_mb<PrecX3>(0), 1, 1, true>(fine, a, n_cu, stream);
+  }
   if (variant == 1) return launch_one<PrecF32, false, 4, 1, 1, 1, false>(fine, a, n_cu, stream);
   return launch_one<PrecF32, false, 8, 1, 1, 1, false>(fine, a, n_cu, stream);
 }

@@ -41,6 +41,7 @@ struct Stager {
   uint32_t lds_nxt;
   uint32_t lds_nn;     // third staging buffer (see open_unit / mid_sync)
   int lane, wave, waves;
+  int dma_waves;       // the first dma_waves waves issue the weight DMA (the older wave of each SIMD idles at the unit barriers anyway)
   uint32_t ubase, uoff;      // LDS offset of the open unit / bytes of it consumed by the layers so far
   uint32_t pf_off, pf_size;  // table entry of the unit the NEXT mid_sync() will start streaming (prefetched)
   unsigned long long t_sync, t_wait, t_last;  // DFN_TIMING: cycles in unit waits / barrier
@@ -69,14 +70,15 @@ DFN_DEV void lds_dma_b32(const void* gptr, const char* lds_dst) {
 
 DFN_DEV void stage_issue_at(const Stager& st, char* smem, uint32_t off, uint32_t size, uint32_t lds_off) {
   const char* src = st.blob + off + st.lane * 16;
+  if (st.wave >= st.dma_waves) return;
 #if defined(DFN_ABL_DMA_SMALL)   // ablation: same instruction count, a quarter of the bytes
-  for (uint32_t p = st.wave * kPiece; p < size; p += st.waves * kPiece) lds_dma_b32(src + p, smem + lds_off + p);
+  for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) lds_dma_b32(src + p, smem + lds_off + p);
 #elif defined(DFN_ABL_DMA_SAMESRC)  // ablation: same count and bytes, one source KiB
-  for (uint32_t p = st.wave * kPiece; p < size; p += st.waves * kPiece) lds_dma_b128(st.blob + st.lane * 16, smem + lds_off + p);
+  for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) lds_dma_b128(st.blob + st.lane * 16, smem + lds_off + p);
 #elif defined(DFN_ABL_DMA_HALF)  // ablation: every second piece only
-  for (uint32_t p = st.wave * kPiece; p < size; p += 2 * st.waves * kPiece) lds_dma_b128(src + p, smem + lds_off + p);
+  for (uint32_t p = st.wave * kPiece; p < size; p += 2 * st.dma_waves * kPiece) lds_dma_b128(src + p, smem + lds_off + p);
 #else
-  for (uint32_t p = st.wave * kPiece; p < size; p += st.waves * kPiece) lds_dma_b128(src + p, smem + lds_off + p);
+  for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) lds_dma_b128(src + p, smem + lds_off + p);
 #endif
 }
 // The unit table is read through the CONSTANT address space so that the loads are scalar (s_load, lgkmcnt): as
@@ -261,9 +263,32 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
 // asm statements anchor the conversion at this point of the instruction stream: without them LLVM treats the
 // pure arithmetic as freely movable and sinks it out from between the MFMAs it is meant to hide behind.
 template <class P, bool RELU, int OC>
-DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, int i) {
+DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, int i, float oscale = 1.f) {
   if constexpr (P::kSplit) {
-    // split-f16 never runs the pipelined epilogue (static_assert in layer()); instantiated in dead branches only
+    // split-f16: piece i = two consecutive results -> one register of the hi plane + one of the lo plane (the arithmetic of
+    // store_hidden: scale, ReLU, truncating hi pair, exact remainders by v_fma_mix_f32, lo pair), as ONE volatile asm block so
+    // that its eight VALU instructions stay between the MFMAs they hide behind.  `oscale` already holds out_scale x kX3ActScale.
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const int c = i >> 2, j = (i & 3) * 2;
+    uint32_t hb, lb;
+    float t0, t1;
+    if (RELU)
+      asm volatile("v_mul_f32 %2, %4, %6\n\tv_mul_f32 %3, %5, %6\n\tv_max_f32 %2, %2, 0\n\tv_max_f32 %3, %3, 0\n\t"
+                   "v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
+                   "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                   "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                   "v_cvt_pkrtz_f16_f32 %1, %2, %3"
+                   : "=&v"(hb), "=&v"(lb), "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]), "v"(oscale));
+    else
+      asm volatile("v_mul_f32 %2, %4, %6\n\tv_mul_f32 %3, %5, %6\n\t"
+                   "v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
+                   "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                   "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                   "v_cvt_pkrtz_f16_f32 %1, %2, %3"
+                   : "=&v"(hb), "=&v"(lb), "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]), "v"(oscale));
+    const half2v hv = __builtin_bit_cast(half2v, hb), lv = __builtin_bit_cast(half2v, lb);
+    out[2 * mb + c].hi[j] = hv[0]; out[2 * mb + c].hi[j + 1] = hv[1];
+    out[2 * mb + c].lo[j] = lv[0]; out[2 * mb + c].lo[j + 1] = lv[1];
   } else if constexpr (P::kSlotsPerChunk == 8) {
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const int c = i >> 2, j = i & 3;
@@ -319,8 +344,8 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
   static_assert(CIN < 0 || (PIPE && P::kSlotsPerChunk == 8 && CIN > 0 && CIN + 1 < KC + 1), "carry-in needs the pipelined f16 path");
   static_assert(!COUT || (PIPE && MB >= 1 && !EXTRA), "carry-out needs a regular last M-block");
   static_assert(NEWUNIT || UMB >= TOT, "a layer that continues a unit must fit in it");
-  static_assert(!(P::kSplit && PIPE), "split-f16 runs the plain (non-pipelined) epilogue");
   const int h = st.lane >> 5;
+  const float pscale = P::kSplit ? st.out_scale * st.lane_mul * kX3ActScale : 1.f;  // split-f16 pieces: accumulator -> operand scale
   constexpr bool RB_ALL = RAYBIAS && NB <= 2;  // fetch all per-ray seeds at entry (latency behind the barrier)
   f32x16 rb[RB_ALL ? TOT : 1][NB];
   if (RB_ALL) {
@@ -393,7 +418,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
             for (int q = 0; q < PPKI; ++q) {
               const int piece = kc * PPKI + q;
-              if (piece < 8 * NB) store_hidden_piece<P, CIN_RELU>(carry[piece >> 3], Bin[piece >> 3], CIN / 2, piece & 7);
+              if (piece < 8 * NB) store_hidden_piece<P, CIN_RELU>(carry[piece >> 3], Bin[piece >> 3], CIN / 2, piece & 7, pscale);
             }
             if (kc == CIN - 1) asm volatile("s_nop 3");  // VALU-written B operand is read by the very next MFMA
           }
@@ -401,7 +426,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
             for (int q = 0; q < PPK; ++q) {
               const int piece = kc * PPK + q;
-              if (piece < 8 * NB) store_hidden_piece<P, RELU>(pend[piece >> 3], Bout[piece >> 3], mb - 1, piece & 7);
+              if (piece < 8 * NB) store_hidden_piece<P, RELU>(pend[piece >> 3], Bout[piece >> 3], mb - 1, piece & 7, pscale);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -431,7 +456,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
       for (int nb = 0; nb < NB; ++nb) carry[nb] = pend[nb];
     } else {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1);
+      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1, st.out_scale * st.lane_mul);
     }
   }
 }
@@ -515,7 +540,7 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
   {
     F cat[NB][PC + HC];
-    if constexpr (P::kSlotsPerChunk == 8 && !PIPE) {  // recompute: cheaper than 32 VGPRs live across 4 layers
+    if constexpr (P::kSlotsPerChunk == 8 && (!PIPE || P::kSplit)) {  // recompute: cheaper than 32 VGPRs live across 4 layers
       float x2[NB][3];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)

@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from dfnet_amd import engine as eng, synthetic as syn
     dev = "cuda:0"
     cw, fw, ea, et = syn.nerfh_weights(0)
-    E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
+    E = eng.NerfHEngine(precision=os.environ.get("PREC", "f16")).load_numpy(cw, fw, ea, et)
     n = 61440
     o, d, v = eng.raygen(480, 640, 585.0, torch.from_numpy(syn.orbit_pose(0, 8)).to(dev))
     o, d, v = o.reshape(-1, 3)[:n].contiguous(), d.reshape(-1, 3)[:n].contiguous(), v.reshape(-1, 3)[:n].contiguous()
@@ -27,7 +27,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("coarse %.3f ms" % (e0.elapsed_time(e1) / 3))
 else:
     for var in ("0",):
-        for lib in sorted(glob.glob(os.path.join(ROOT, "dfnet_amd", "libabl_*.so"))):
+        for lib in [os.path.join(ROOT, "dfnet_amd", "libdfnet_hip.so")] + sorted(glob.glob(os.path.join(ROOT, "dfnet_amd", "libabl_*.so"))):
             env = dict(os.environ, DFN_LIB_PATH=lib, DFN_MLP_VARIANT=var)
             r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
-            print("variant", var, os.path.basename(lib)[7:-3].ljust(28), r.stdout.strip() or r.stderr[-300:])
+            print("variant", var, os.path.basename(lib)[3:-3].ljust(28), r.stdout.strip() or r.stderr[-300:])

@@ -9,7 +9,7 @@ from dfnet_amd import _lib, engine as eng, synthetic as syn
 lib = _lib.load()
 dev = "cuda:0"
 cw, fw, ea, et = syn.nerfh_weights(0)
-E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
+E = eng.NerfHEngine(precision=os.environ.get("PREC", "f16")).load_numpy(cw, fw, ea, et)
 NW = 8192
 buf = torch.zeros(NW * 4 + 8 * 192 + 64, dtype=torch.int64, device=dev)
 c2w = torch.from_numpy(syn.orbit_pose(0, 8)).to(dev)

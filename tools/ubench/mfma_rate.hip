@@ -52,5 +52,7 @@ int main() {
   run<4, true>("4 acc shared A, 1 wave/SIMD", 256, 1);
   run<4, true>("4 acc shared A, 2 waves/SIMD", 512, 1);
   run<2, true>("2 acc shared A, 4 waves/SIMD", 512, 2);
+  run<1, true>("1 acc, 2 waves/SIMD", 512, 1);
+  run<1, true>("1 acc, 4 waves/SIMD", 512, 2);
   return 0;
 }
