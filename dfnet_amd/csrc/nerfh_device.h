@@ -97,6 +97,22 @@ DFN_DEV float sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
 // below the f16 rounding of the layer inputs, a fifth of the instructions.
 DFN_DEV float softplus_fast(float v) { return v > 15.f ? v : __logf(1.f + __expf(v)); }
 DFN_DEV float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+// fp32-grade forms on the hardware transcendentals (split-f16 kernels): e^x = 2^(t + r) with x log2(e) = t + r held as an
+// unevaluated sum (fma remainder + the low word of log2 e) so that v_exp_f32's 1-ulp result is not degraded by the rounding of
+// the product (libm's expf: ~35 instructions; this: 6); 1 / x = v_rcp_f32 + one Newton step.  Max relative error vs fp64
+// ~1.5e-7 (tests/test_gpu_nerfh.py: raw parity of the split-f16 path unchanged at 1e-6).
+DFN_DEV float exp_hw(float x) {
+  const float t = x * 1.44269502f;
+  const float r = fmaf(x, 1.44269502f, -t) + x * 1.92596299e-8f;
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e * r, 0.693147182f, e);
+}
+DFN_DEV float rcp_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return r * fmaf(-x, r, 2.f);
+}
+DFN_DEV float softplus_hw(float v) { return v > 20.f ? v : log1pf(exp_hw(v)); }
+DFN_DEV float sigmoid_hw(float v) { return rcp_nr(1.f + exp_hw(-v)); }
 template <bool FAST> DFN_DEV float act_softplus(float v) { return FAST ? softplus_fast(v) : softplus(v); }
 template <bool FAST> DFN_DEV float act_sigmoid(float v) { return FAST ? sigmoid_fast(v) : sigmoid(v); }
 
@@ -117,6 +133,33 @@ DFN_DEV float wave_incl_sum(float v, int lane) {
   }
   return v;
 }
+// ---- 32-lane scans on the DPP crossbar (gfx9 row_shr / row_bcast:15 / wave_shr): five VALU instructions per scan instead of
+// six ds_bpermute round trips (~100 cycles each, dependent).  Lanes 0..31 hold the data (one point block of an MLP wave);
+// lanes 32..63 must carry the identity.  The scan order differs from wave_incl_* (Hillis-Steele inside 16-lane rows, then one
+// cross-row step): results agree to fp32 round-off, not bit for bit.
+template <int CTRL, int ROW_MASK>
+DFN_DEV float dpp_move(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+DFN_DEV float scan32_prod(float v) {   // inclusive prefix product over lanes 0..31
+  v *= dpp_move<0x111, 0xf>(1.f, v);
+  v *= dpp_move<0x112, 0xf>(1.f, v);
+  v *= dpp_move<0x114, 0xf>(1.f, v);
+  v *= dpp_move<0x118, 0xf>(1.f, v);
+  v *= dpp_move<0x142, 0x2>(1.f, v);   // row_bcast:15: lane 15 into every lane of row 1
+  return v;
+}
+DFN_DEV float scan32_sum(float v) {    // inclusive prefix sum over lanes 0..31 (lane 31 = the total)
+  v += dpp_move<0x111, 0xf>(0.f, v);
+  v += dpp_move<0x112, 0xf>(0.f, v);
+  v += dpp_move<0x114, 0xf>(0.f, v);
+  v += dpp_move<0x118, 0xf>(0.f, v);
+  v += dpp_move<0x142, 0x2>(0.f, v);
+  return v;
+}
+DFN_DEV float lane_shr1(float v, float first) { return dpp_move<0x138, 0xf>(first, v); }   // wave_shr:1: lane l <- lane l-1, lane 0 <- first
+DFN_DEV float read_lane31(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31)); }
+
 DFN_DEV float wave_sum(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);

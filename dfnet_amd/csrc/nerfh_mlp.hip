@@ -25,6 +25,12 @@
 
 namespace dfn {
 
+// Head activations per arithmetic mode: f16 = hardware transcendentals (1e-6), split-f16 = the fp32-grade hardware forms
+// (exp_hw / rcp_nr, 1.5e-7: nerfh_device.h), exact fp32 = libm.
+template <class P, bool FAST> DFN_DEV float head_softplus(float v) { return FAST ? softplus_fast(v) : (P::kSplit ? softplus_hw(v) : softplus(v)); }
+template <class P, bool FAST> DFN_DEV float head_sigmoid(float v) { return FAST ? sigmoid_fast(v) : (P::kSplit ? sigmoid_hw(v) : sigmoid(v)); }
+template <class P, bool FAST> DFN_DEV float head_exp(float v) { return FAST ? __expf(v) : (P::kSplit ? exp_hw(v) : expf(v)); }
+
 // three staging buffers + per-wave next-tile input slots (8 dwords x 64 lanes per 64 points: z, o, d, next z)
 template <class P, int UMB, int WAVES, int NB, int W = kWidth> constexpr uint32_t lds_bytes() {
   return 3 * max_unit_bytes<P>(UMB, W) + WAVES * ((NB * 32 + 63) / 64) * 8 * 256;
@@ -69,11 +75,12 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3];
-    long long pt[NB];
+    uint32_t pt[NB];   // launch_one() bounds a launch to < 2^31 points: 32-bit indices (64-bit ones cost 2 registers each and spilled)
+    const uint32_t npts = uint32_t(n_pts);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      pt[nb] = tile * PPT + st.wave * (NB * 32) + nb * 32 + p;
-      const uint32_t q = uint32_t(pt[nb] < n_pts ? pt[nb] : n_pts - 1);
+      pt[nb] = uint32_t(tile) * uint32_t(PPT) + st.wave * (NB * 32) + nb * 32 + p;
+      const uint32_t q = pt[nb] < npts ? pt[nb] : npts - 1;
       const uint32_t ray = q / uint32_t(a.n_samples);
       const int i = int(q - ray * uint32_t(a.n_samples));
       const float z = coarse_z_at(i, a.n_samples, a.near, a.far, a.lindisp != 0);
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
     layer<P, UMB, PIPE, NB, chunks_of<P>(W / 2), 0, false, true, false, !MERGE, (CY ? 6 : -1), true, false>(st, smem, hid, dummy, head, norb, carry);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-      if (h == 0 && pt[nb] < n_pts) a.out[pt[nb]] = act_softplus<FAST>(head[nb][0]);
+      if (h == 0 && pt[nb] < npts) a.out[pt[nb]] = head_softplus<P, FAST>(head[nb][0]);
   }
 }
 
@@ -131,38 +138,49 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   // previous tile's small layers with direct-to-LDS loads and only
   // waited for at the end of that tile, so the HBM latency of z / o / d is off the critical path.
   float zin[NB], znext[NB], oin[NB][3], din[NB][3];
-  long long pt[NB], ray_of[NB];
-  auto tile_coords = [&](long long t) {  // launch_one() guarantees n_pts < 2^31: 32-bit division
+  // launch_one() guarantees n_pts < 2^31: point / ray indices are 32-bit (as 64-bit values and as per-ray table POINTERS held
+  // across the trunk they cost 16 registers at NB = 2 and the f16 kernel spilled them: any scratch use costs this kernel clock)
+  uint32_t pt[NB], ray_of[NB];
+  const uint32_t npts = uint32_t(n_pts);
+  auto tile_coords = [&](long long t) {
+    uint32_t lp = st.lane;
+    asm volatile("" : "+v"(lp));   // the lane's offset inside the tile is formed here (hoisted as a loop invariant, it was spilled)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      pt[nb] = t * PPT + st.wave * (NB * 32) + nb * 32 + p;
-      const uint32_t q = uint32_t(pt[nb] < n_pts ? pt[nb] : n_pts - 1);
+      pt[nb] = uint32_t(t) * uint32_t(PPT) + st.wave * (NB * 32) + nb * 32 + (lp & 31);
+      const uint32_t q = pt[nb] < npts ? pt[nb] : npts - 1;
       ray_of[nb] = q / uint32_t(a.n_samples);
     }
   };
   tile_coords(tile);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const long long q = pt[nb] < n_pts ? pt[nb] : n_pts - 1;
+    const uint32_t q = pt[nb] < npts ? pt[nb] : npts - 1;
     zin[nb] = a.z[q];
-    znext[nb] = a.z[q + 1 < n_pts ? q + 1 : q];
+    znext[nb] = a.z[q + 1 < npts ? q + 1 : q];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { oin[nb][c] = a.rays_o[ray_of[nb] * 3 + c]; din[nb][c] = a.rays_d[ray_of[nb] * 3 + c]; }
   }
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3];
-    long long pt_cur[NB];
-    const float* rb_dir[NB];
-    const float* rb_tr[NB];
+    uint32_t pt_cur[NB], ray_cur[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       pt_cur[nb] = pt[nb];
+      ray_cur[nb] = ray_of[nb];
 #pragma unroll
       for (int c = 0; c < 3; ++c) x[nb][c] = add_rn(oin[nb][c], mul_rn(din[nb][c], zin[nb]));
-      rb_dir[nb] = a.ray_bias + ray_of[nb] * ray_bias_floats(W);
-      rb_tr[nb] = rb_dir[nb] + ray_bias_floats(W) / 2;
     }
+    // per-ray table rows: the pointers are formed where they are used (opaque ray index: not hoisted above the trunk)
+    auto ray_table = [&](const float* (&rb)[NB], int half_table) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        uint32_t r = ray_cur[nb];
+        asm volatile("" : "+v"(r));
+        rb[nb] = a.ray_bias + (size_t)r * ray_bias_floats(W) + half_table * (ray_bias_floats(W) / 2);
+      }
+    };
     const float* const norb[NB] = {};
     F hid[NB][HC];
 #ifdef DFN_TIMING
@@ -183,34 +201,38 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
     layer<P, UMB, PIPE, NB, HC, MBW, false, true, false, true, (CY ? 6 : -1), true, false>(st, smem, hid, fin, head, norb, carry);
     float o[NB][9];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) o[nb][3] = act_softplus<FAST>(head[nb][0]);
+    for (int nb = 0; nb < NB; ++nb) o[nb][3] = head_softplus<P, FAST>(head[nb][0]);
     // dir_encoding (per-ray bias = b + W[:,128:] [pe_dir, a]) -> static_rgb
     {
       F de[NB][QC], dummy[NB][chunks_of<P>(16)];
+      const float* rb_dir[NB];
+      ray_table(rb_dir, 0);
       layer<P, UMB, PIPE, NB, HC, MBQ, true, false, true, true, -1, true, CY>(st, smem, fin, de, head, rb_dir, carry);
       layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, de, dummy, head, norb, carry);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[nb][c] = act_sigmoid<FAST>(head[nb][c]);
+        for (int c = 0; c < 3; ++c) o[nb][c] = head_sigmoid<P, FAST>(head[nb][c]);
     }
     // transient branch
     {
       F t0[NB][QC], t1[NB][QC], dummy[NB][chunks_of<P>(16)];
+      const float* rb_tr[NB];
+      ray_table(rb_tr, 1);
       layer<P, UMB, PIPE, NB, HC, MBQ, true, false, true, true, -1, true, CY>(st, smem, fin, t0, head, rb_tr, carry);
       if (st.more) {
         // Prefetch the next tile's inputs by LDS-DMA (no destination registers).  Issued AFTER this unit's mid_sync so
         // that nothing younger than a weight DMA is ever waited for before the tile's end:
         // lane l of round r fetches z, o, d and the next sample's z of the wave's point 64 r + l into this wave's LDS slot.
-        const long long base = (tile + gridDim.x) * PPT + st.wave * (NB * 32);
+        const uint32_t base = uint32_t(tile + gridDim.x) * uint32_t(PPT) + st.wave * (NB * 32);
         char* slot = smem + 3 * USTRIDE + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
         for (int r = 0; r < PF_ROUNDS; ++r) {
-          const long long ptn = base + r * 64 + st.lane;
-          const uint32_t q = uint32_t(ptn < n_pts ? ptn : n_pts - 1);
+          const uint32_t ptn = base + r * 64 + st.lane;
+          const uint32_t q = ptn < npts ? ptn : npts - 1;
           const uint32_t ray = q / uint32_t(a.n_samples);
           lds_dma_b32(a.z + q, slot + (r * 8) * 256);
-          lds_dma_b32(a.z + (q + 1 < uint32_t(n_pts) ? q + 1 : q), slot + (r * 8 + 7) * 256);
+          lds_dma_b32(a.z + (q + 1 < npts ? q + 1 : q), slot + (r * 8 + 7) * 256);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             lds_dma_b32(a.rays_o + ray * 3 + c, slot + (r * 8 + 1 + c) * 256);
@@ -225,9 +247,9 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[nb][4 + c] = act_sigmoid<FAST>(head[nb][c]);
-        o[nb][7] = act_softplus<FAST>(head[nb][3]);
-        o[nb][8] = act_softplus<FAST>(head[nb][4]);  // C register 4 of half 0 = row 8 = transient_beta
+        for (int c = 0; c < 3; ++c) o[nb][4 + c] = head_sigmoid<P, FAST>(head[nb][c]);
+        o[nb][7] = head_softplus<P, FAST>(head[nb][3]);
+        o[nb][8] = head_softplus<P, FAST>(head[nb][4]);  // C register 4 of half 0 = row 8 = transient_beta
       }
     }
     if (a.partial) {
@@ -240,15 +262,16 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
       float s_rgb[3] = {0.f, 0.f, 0.f}, s_acc = 0.f, s_dso = 0.f, s_dj = 0.f, s_beta = 0.f;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const uint32_t smp = uint32_t(pt_cur[nb]) % uint32_t(a.n_samples);
+        const uint32_t smp = pt_cur[nb] - ray_cur[nb] * uint32_t(a.n_samples);
         const float delta = smp + 1 == uint32_t(a.n_samples) ? 1e2f : sub_rn(znext[nb], zin[nb]);
         const float sg_s = o[nb][3], sg_t = o[nb][7];
-        const float as = live ? sub_rn(1.f, FAST ? __expf(-mul_rn(delta, sg_s)) : expf(-mul_rn(delta, sg_s))) : 0.f;
-        const float at = live ? sub_rn(1.f, FAST ? __expf(-mul_rn(delta, sg_t)) : expf(-mul_rn(delta, sg_t))) : 0.f;
-        const float aj = live ? sub_rn(1.f, FAST ? __expf(-mul_rn(delta, add_rn(sg_s, sg_t))) : expf(-mul_rn(delta, add_rn(sg_s, sg_t)))) : 0.f;
-        const float ij = wave_incl_prod(1.f - aj, st.lane), is = wave_incl_prod(1.f - as, st.lane);
-        float ej = __shfl_up(ij, 1, 64), es = __shfl_up(is, 1, 64);
-        if (st.lane == 0) { ej = 1.f; es = 1.f; }
+        const float as = live ? sub_rn(1.f, head_exp<P, FAST>(-mul_rn(delta, sg_s))) : 0.f;
+        const float at = live ? sub_rn(1.f, head_exp<P, FAST>(-mul_rn(delta, sg_t))) : 0.f;
+        const float aj = live ? sub_rn(1.f, head_exp<P, FAST>(-mul_rn(delta, add_rn(sg_s, sg_t)))) : 0.f;
+        // scans over the block's 32 samples on the DPP crossbar (lanes 32..63 carry alpha = 0: the identity), five VALU
+        // instructions each instead of six dependent ds_bpermute round trips (nerfh_device.h)
+        const float ij = scan32_prod(1.f - aj), is = scan32_prod(1.f - as);
+        const float ej = lane_shr1(ij, 1.f), es = lane_shr1(is, 1.f);   // exclusive products (lane 0: 1)
         const float Tj = Pj * ej, Ts = Ps * es;
         const float ws = as * Tj, wt = at * Tj, wj = aj * Tj;
 #pragma unroll
@@ -257,14 +280,15 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
         s_dso += as * Ts * zin[nb];
         s_dj += wj * zin[nb];
         s_beta += live ? wt * o[nb][8] : 0.f;
-        Pj *= __shfl(ij, 31, 64);   // lanes 32..63 carry alpha = 0: lane 31 holds the block's full product
-        Ps *= __shfl(is, 31, 64);
+        Pj *= read_lane31(ij);   // lane 31 holds the block's full product
+        Ps *= read_lane31(is);
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) s_rgb[c] = wave_sum(s_rgb[c]);
-      s_acc = wave_sum(s_acc); s_dso = wave_sum(s_dso); s_dj = wave_sum(s_dj); s_beta = wave_sum(s_beta);
-      if (st.lane == 0 && pt_cur[0] < n_pts) {
-        f32x4* dst = reinterpret_cast<f32x4*>(a.partial + (size_t)(uint32_t(pt_cur[0]) / uint32_t(NB * 32)) * 12);   // one segment per wave
+      for (int c = 0; c < 3; ++c) s_rgb[c] = read_lane31(scan32_sum(s_rgb[c]));   // lanes 32..63 contribute zeros
+      s_acc = read_lane31(scan32_sum(s_acc)); s_dso = read_lane31(scan32_sum(s_dso));
+      s_dj = read_lane31(scan32_sum(s_dj)); s_beta = read_lane31(scan32_sum(s_beta));
+      if (st.lane == 0 && pt_cur[0] < npts) {
+        f32x4* dst = reinterpret_cast<f32x4*>(a.partial + (size_t)(pt_cur[0] / uint32_t(NB * 32)) * 12);   // one segment per wave
         dst[0] = f32x4{s_rgb[0], s_rgb[1], s_rgb[2], s_acc};
         dst[1] = f32x4{s_dso, s_dj, s_beta, Pj};
         dst[2] = f32x4{Ps, 0.f, 0.f, 0.f};
@@ -272,8 +296,8 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
     } else {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        if (h == 0 && pt_cur[nb] < n_pts) {
-          float* dst = a.out + pt_cur[nb] * 9;
+        if (h == 0 && pt_cur[nb] < npts) {
+          float* dst = a.out + (size_t)pt_cur[nb] * 9;
 #pragma unroll
           for (int c = 0; c < 9; ++c) dst[c] = o[nb][c];
         }
@@ -285,7 +309,9 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
       const char* slot = smem + 3 * USTRIDE + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int loc = nb * 32 + p, r = loc >> 6, l = loc & 63;
+        int loc = nb * 32 + p;
+        asm volatile("" : "+v"(loc));   // formed here: as a loop invariant it was hoisted to the prologue and spilled
+        const int r = loc >> 6, l = loc & 63;
         const float* f = reinterpret_cast<const float*>(slot + r * 8 * 256) + l;
         zin[nb] = f[0];
         znext[nb] = f[7 * 64];

@@ -191,6 +191,86 @@ template <int NB, int MODE> void run3(const char* name) {
   printf("%-58s %.3f ms  wall %.1f cycles per MFMA per SIMD (ideal 32)\n", name, ms, ms * 1e-3 * 2.4e9 / mfma_per_simd);
   hipFree(in); hipFree(out); hipFree(blob); hipFree(cyc);
 }
+
+// Ping-pong: waves 0-3 and 4-7 of a workgroup (the two waves of each SIMD) alternate a matrix segment (one M-block: 8 chunks x 3 MFMAs,
+// fragments from LDS) with a vector segment (the 64-VALU split epilogue, the weight DMA), one s_barrier between segments.
+// MODE bit 1: DMA (by the lagging group, in its vector segment at unit boundaries); bit 2: fragment prefetch depth 2; bit 4: no VALU
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k4(const float* in, const char* blob, float* out, int units, unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool lag = wave >= 4;
+  half8 bh[8], bl[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const _Float16 vh = (_Float16)in[(threadIdx.x * 3 + c) & 255], vl = (_Float16)in[(threadIdx.x * 5 + c) & 255];
+    bh[c] = half8{vh, vh, vh, vh, vh, vh, vh, vh}; bl[c] = half8{vl, vl, vl, vl, vl, vl, vl, vl};
+  }
+  f32x16 acc0 = {0};
+  float x0 = in[lane], x1 = in[lane + 1], os = in[lane + 2] + 1.f, t0 = 0, t1 = 0;
+  unsigned h = 0, l = 0, sink = 0;
+  for (int i = threadIdx.x; i < 3 * 32768 / 4; i += 512) reinterpret_cast<float*>(smem)[i] = in[i & 255];
+  __syncthreads();
+  const unsigned long long c_begin = __builtin_amdgcn_s_memtime();
+  if (lag) __builtin_amdgcn_s_barrier();
+  for (int u = 0; u < units; ++u) {
+    const char* ub = smem + (u % 3) * 32768 + lane * 16;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      // matrix segment
+      half8 ah[2], al[2];
+      ah[0] = *reinterpret_cast<const half8*>(ub + (mb * 8) * 2048);
+      al[0] = *reinterpret_cast<const half8*>(ub + (mb * 8) * 2048 + 1024);
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        if (kc + 1 < 8) {
+          ah[(kc + 1) & 1] = *reinterpret_cast<const half8*>(ub + (mb * 8 + kc + 1) * 2048);
+          al[(kc + 1) & 1] = *reinterpret_cast<const half8*>(ub + (mb * 8 + kc + 1) * 2048 + 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kc & 1], bh[kc], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kc & 1], bl[kc], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kc & 1], bh[kc], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_barrier();
+      // vector segment
+      if (!(MODE & 4)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { PA(t0, t1, acc0[2 * i], acc0[2 * i + 1], os); PB(h, t0, t1); PC(l, t0, t1); sink += h + l; }
+      }
+      if ((MODE & 1) && mb == 1 && lag) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        for (uint32_t p = (wave - 4) * 1024; p < 32768; p += 4 * 1024)
+          dma128(blob + (size_t)((u * 7 + blockIdx.x) % 24) * 32768 + p + lane * 16, smem + ((u + 2) % 3) * 32768 + p);
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (!lag) __builtin_amdgcn_s_barrier();
+  float s = 0;
+  for (int j = 0; j < 16; ++j) s += acc0[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s + float(sink);
+  if (lane == 0) cyc[blockIdx.x * 8 + wave] = __builtin_amdgcn_s_memtime() - c_begin;
+}
+template <int MODE> void run4(const char* name) {
+  float *in, *out; char* blob; unsigned long long* cyc;
+  hipMalloc(&cyc, 256 * 8 * 8); hipMemset(cyc, 0, 256 * 8 * 8);
+  hipMalloc(&in, 4096); hipMemset(in, 0, 4096);
+  hipMalloc(&blob, 24 * 32768); hipMemset(blob, 0, 24 * 32768);
+  hipMalloc(&out, 256 * 512 * 4);
+  const int units = 4000, lds = 3 * 32768;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k4<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k4<MODE>), dim3(256), dim3(512), lds, 0, in, blob, out, 400, cyc);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k4<MODE>), dim3(256), dim3(512), lds, 0, in, blob, out, units, cyc);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double mfma_per_simd = double(units) * 48 * 2;
+  printf("%-58s %.3f ms  wall %.1f cycles per MFMA per SIMD (ideal 32)\n", name, ms, ms * 1e-3 * 2.4e9 / mfma_per_simd);
+  hipFree(in); hipFree(out); hipFree(blob); hipFree(cyc);
+}
 template <int MODE> void run(const char* name) {
   float *in, *out; char* blob; unsigned long long* cyc;
   hipMalloc(&cyc, 256 * 8 * 8);
@@ -217,6 +297,11 @@ template <int MODE> void run(const char* name) {
 }
 int main() {
   for (int i = 0; i < 10; ++i) run<0>(nullptr);
+  run4<0>("ping-pong, VALU, no DMA");
+  run4<1>("ping-pong, VALU, DMA");
+  run4<4>("ping-pong, no VALU, no DMA");
+  run4<5>("ping-pong, no VALU, DMA");
+  run4<1>("ping-pong, VALU, DMA (again)");
   run<1 | 2 | 16 | 32>("1 acc, VALU block, DMA 8 waves (today)");
   run<1 | 2 | 16 | 64>("1 acc, VALU block, DMA 4 waves");
   run<1 | 2 | 16 | 64 | 1024>("main+corr accs, VALU block, DMA 4 waves");
