@@ -87,6 +87,8 @@ SIGNATURES = {
                                               POINTER(c_void_p), c_int, _P, c_size_t, _P]),
     "dfn_frame_prep_scratch_bytes": (c_size_t, []),
     "dfn_frame_prep": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "dfn_frame_post_scratch_bytes": (c_size_t, [c_int]),
+    "dfn_frame_post": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dfn_triplet_loss_state_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dfn_triplet_loss_forward": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),
     "dfn_triplet_loss_backward": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P, c_size_t, _P]),

@@ -664,3 +664,28 @@ def frame_prep(rgb_u8, H, W, hist_bins=10):
     check(lib.dfn_frame_prep(ctypes.c_void_p(rgb_u8.data_ptr()), h, w, int(H), int(W), int(hist_bins), ptr(img), ptr(hist),
                              ctypes.c_void_p(scratch.data_ptr()), current_stream()), "dfn_frame_prep")
     return img, hist
+
+
+def frame_post(rgb, disp, gt=None, want_gt8=True):
+    """render_path's per-frame back-end on the device (dfn_frame_post; models/rendering.py:423-452): rgb [n,H,W,3], disp [n,H,W]
+    fp32 CUDA, gt None | [n,H,W,3] | [H,W,3] (one ground-truth frame for every render) -> dict(rgb8, disp8 uint8 CUDA,
+    gt8 | None, mse fp32 [n] | None, disp_max fp32 [n])."""
+    lib = _lib.load()
+    rgb, disp = _f32c(rgb), _f32c(disp)
+    n, H, W = disp.shape
+    dev = rgb.device
+    per_frame = gt is not None and gt.dim() == 4
+    if gt is not None:
+        gt = _f32c(gt)
+    rgb8 = torch.empty(n, H, W, 3, dtype=torch.uint8, device=dev)
+    disp8 = torch.empty(n, H, W, dtype=torch.uint8, device=dev)
+    gt8 = None
+    if gt is not None and want_gt8:
+        gt8 = torch.empty((n, H, W, 3) if per_frame else (H, W, 3), dtype=torch.uint8, device=dev)
+    mse = torch.empty(n, device=dev) if gt is not None else None
+    dmax = torch.empty(n, device=dev)
+    scratch = torch.empty(lib.dfn_frame_post_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    raw = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    check(lib.dfn_frame_post(ptr(rgb), ptr(disp), ptr(gt), 1 if per_frame else 0, n, H, W, raw(rgb8), raw(disp8), raw(gt8), ptr(mse),
+                             ptr(dmax), raw(scratch), current_stream()), "dfn_frame_post")
+    return {"rgb8": rgb8, "disp8": disp8, "gt8": gt8, "mse": mse, "disp_max": dmax}

@@ -315,15 +315,35 @@ def _write_png(path, arr8):
                      chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
+POST_BATCH = 16     # frames per dfn_frame_post call / device -> host copy / PNG job
+PNG_WORKERS = 8     # host threads encoding PNGs while the GPU renders on (zlib releases the GIL)
+
+
+def _write_frames(ev, host, savedir, first):
+    """PNG job of one batch (runs on a pool thread): wait for the batch's device -> host copy, then `{:03d}.png`,
+    `{:03d}_GT.png`, `{:03d}_disp.png` per frame, numbered by GLOBAL frame index (rendering.py:438-452)."""
+    ev.synchronize()
+    rgb8, disp8, gt8 = (None if t is None else t.numpy() for t in host)
+    for k in range(rgb8.shape[0]):
+        i = first + k
+        _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), rgb8[k])
+        if gt8 is not None:
+            _write_png(os.path.join(savedir, '{:03d}_GT.png'.format(i)), gt8[k] if gt8.ndim == 4 else gt8)
+        _write_png(os.path.join(savedir, '{:03d}_disp.png'.format(i)), disp8[k])
+
+
 def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0,
                 single_gt_img=False, img_ids=torch.Tensor(0)):
     """Drop-in for rendering.py:403-458: returns (rgbs [N,H,W,3], disps [N,H,W]) as float32 numpy.
 
-    Frames stay in HBM until the end (one D2H copy instead of a sync per frame).  With
-    torch.distributed initialised (world > 1) each rank renders its contiguous block of frames and
-    rank 0 gathers them; ranks != 0 return (None, None).  PSNR / PNG conventions follow the
-    reference: per-frame -10*log10(mean((rgb-gt)^2)) then the mean, `{:03d}.png`, `{:03d}_GT.png`,
-    `{:03d}_disp.png` (disp / max), to8b truncation."""
+    With torch.distributed initialised (world > 1) each rank renders its contiguous block of frames.  The per-frame back-end
+    (to8b truncation, disp / max(disp), the PSNR's mean squared error: rendering.py:423-452) runs on the device in batches
+    of POST_BATCH frames (dfn_frame_post); what comes back to the host is uint8, and EVERY RANK writes the PNGs of its own
+    block (`{:03d}.png`, `{:03d}_GT.png`, `{:03d}_disp.png` by global frame index) on a thread pool while its GPU renders the
+    next batch.  One gather at the end brings the fp32 frames (the returned arrays) and the per-frame errors to rank 0, which
+    prints the mean PSNR; ranks != 0 return (None, None)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import engine as eng
     H, W, focal = hwf
     if render_factor != 0:
         H, W, focal = int(H // render_factor), int(W // render_factor), focal / render_factor
@@ -332,38 +352,66 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
     render_poses = torch.as_tensor(render_poses, dtype=torch.float32, device=dev)
     img_ids = torch.as_tensor(img_ids, dtype=torch.float32, device=dev)
     N = render_poses.shape[0]
-    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
-    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    rank, world = ddist.rank_world()
     lo, hi = ddist.frame_block(N, rank, world)
-    rgbs = torch.empty(hi - lo, H, W, 3, device=dev)
-    disps = torch.empty(hi - lo, H, W, device=dev)
+    n_loc = hi - lo
+    rgbs = torch.empty(n_loc, H, W, 3, device=dev)
+    disps = torch.empty(n_loc, H, W, device=dev)
+    mse = torch.zeros(n_loc, device=dev)
+    gt_one = None
+    if gt_imgs is not None and single_gt_img:
+        gt_one = torch.as_tensor(np.asarray(gt_imgs), dtype=torch.float32).to(dev)
+    pool = ThreadPoolExecutor(max_workers=PNG_WORKERS) if savedir is not None else None
+    jobs = []
     t0 = time.time()
-    for j, i in enumerate(range(lo, hi)):
-        rgb, disp, _, _ = render(H, W, focal, chunk=chunk, c2w=render_poses[i][:3, :4], img_idx=img_ids[i],
-                                 **render_kwargs)
-        rgbs[j].copy_(rgb)
-        disps[j].copy_(disp)
-        if i == 0:
-            print(rgb.shape, disp.shape)
+    t_post = 0.0
+    for j0 in range(0, n_loc, POST_BATCH):
+        j1 = min(n_loc, j0 + POST_BATCH)
+        for j in range(j0, j1):
+            i = lo + j
+            rgb, disp, _, _ = render(H, W, focal, chunk=chunk, c2w=render_poses[i][:3, :4], img_idx=img_ids[i], **render_kwargs)
+            rgbs[j].copy_(rgb)
+            disps[j].copy_(disp)
+            if i == 0:
+                print(rgb.shape, disp.shape)
+        if savedir is None and gt_imgs is None:
+            continue
+        tp = time.time()
+        gt = gt_one
+        if gt_imgs is not None and not single_gt_img:
+            gt = torch.as_tensor(np.asarray(gt_imgs[lo + j0:lo + j1]), dtype=torch.float32).to(dev, non_blocking=True)
+        post = eng.frame_post(rgbs[j0:j1], disps[j0:j1], gt, want_gt8=savedir is not None)
+        if gt is not None:
+            mse[j0:j1].copy_(post["mse"])
+        if savedir is not None:
+            host = []
+            for t in (post["rgb8"], post["disp8"], post["gt8"]):
+                host.append(None if t is None else torch.empty(t.shape, dtype=torch.uint8, pin_memory=True).copy_(t, non_blocking=True))
+            ev = torch.cuda.Event()
+            ev.record()
+            jobs.append(pool.submit(_write_frames, ev, host, savedir, lo + j0))
+        t_post += time.time() - tp
+    torch.cuda.synchronize()
+    t_render = time.time() - t0
     all_rgb = ddist.gather_frames(rgbs, N)
     all_disp = ddist.gather_frames(disps, N)
+    all_mse = ddist.gather_frames(mse, N) if gt_imgs is not None else None
+    tw = time.time()
+    for jb in jobs:
+        jb.result()   # re-raises a failed write
+    if pool is not None:
+        pool.shutdown(wait=True)
+    t_tail = time.time() - tw
     if rank != 0:
         return None, None
     rgbs = all_rgb.cpu().numpy()
     disps = all_disp.cpu().numpy()
-    print(f"rendered {N} frames of {W}x{H} on {world} GPU(s) in {time.time() - t0:.2f} s")
-    psnr = []
-    for i in range(N):
-        if gt_imgs is not None:
-            gt = gt_imgs if single_gt_img else gt_imgs[i]
-            psnr.append(-10. * np.log10(np.mean(np.square(rgbs[i] - gt))))
-        if savedir is not None:
-            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[i]))
-            if gt_imgs is not None:
-                _write_png(os.path.join(savedir, '{:03d}_GT.png'.format(i)), to8b(gt_imgs if single_gt_img else gt_imgs[i]))
-            _write_png(os.path.join(savedir, '{:03d}_disp.png'.format(i)), to8b(disps[i] / np.max(disps[i])))
-    if psnr:
+    print(f"rendered {N} frames of {W}x{H} on {world} GPU(s) in {t_render:.2f} s (post-processing launches {t_post:.2f} s inside it, "
+          f"PNG tail after the last frame {t_tail:.2f} s)")
+    if all_mse is not None:
+        psnr = -10. * np.log10(all_mse.cpu().numpy())
         print("Mean PSNR of this run is:", np.mean(psnr, 0))
+    render_path.last_timing = {"render_s": t_render, "post_launch_s": t_post, "png_tail_s": t_tail, "frames": N, "world": world}
     return rgbs, disps
 
 

@@ -311,6 +311,20 @@ size_t dfn_frame_prep_scratch_bytes(void);
 int dfn_frame_prep(const uint8_t* rgb_hwc, int h, int w, int H, int W, int hist_bins, float* img_chw, float* hist,
                    void* scratch, void* stream);
 
+/* ---- render_path's per-frame back-end (models/rendering.py:423-452 with to8b of models/nerf.py:11).
+ *
+ * A batch of n_frames rendered frames, device fp32: rgb [n, H, W, 3], disp [n, H, W]; gt (optional) [n, H, W, 3] when
+ * gt_per_frame != 0, ONE frame [H, W, 3] compared with every render otherwise (the reference's single_gt_img).  Outputs, device:
+ *   rgb8  [n, H, W, 3] uint8 = (255 * clip(rgb, 0, 1)).astype(uint8)            (truncation, as numpy)
+ *   disp8 [n, H, W]    uint8 = the same of disp / max(disp), the maximum per frame
+ *   gt8   (optional)   uint8 of gt: [n, H, W, 3], or [H, W, 3] for a single ground-truth frame
+ *   mse   (optional, needs gt) fp32 [n] = mean((rgb - gt)^2) per frame (fp32 differences, fp64 sum): PSNR = -10 log10(mse)
+ *   disp_max (optional) fp32 [n]
+ * scratch: dfn_frame_post_scratch_bytes(n_frames) of device memory (zeroed by the call). */
+size_t dfn_frame_post_scratch_bytes(int n_frames);
+int dfn_frame_post(const float* rgb, const float* disp, const float* gt, int gt_per_frame, int n_frames, int H, int W,
+                   uint8_t* rgb8, uint8_t* disp8, uint8_t* gt8, float* mse, float* disp_max, void* scratch, void* stream);
+
 /* ---- the triplet loss of DFNet's training on the two feature stacks (feature/misc.py:355-435), fused.
  *
  * f1 (anchor, the rendered stream in run_feature.py:155) and f2 (positive, the target stream): fp32 device stacks
