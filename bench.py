@@ -195,8 +195,8 @@ def timed_render(E, lib, precision, poses, hist, rgbs, disps, acc, K, Wm, world=
 
     for k in range(Wm):
         step(k)
-    if world > 1:  # warm the collective too
-        ddist.gather_frames(rgbs[:1], world)
+    if ddist.active():  # warm the collective too
+        ddist.gather_frames(rgbs[:world], world)
     torch.cuda.synchronize()
     ddist.barrier()
     lib.dfn_profile_enable(1)
@@ -204,7 +204,7 @@ def timed_render(E, lib, precision, poses, hist, rgbs, disps, acc, K, Wm, world=
     t0 = time.perf_counter()
     for k in range(K):
         step(k)
-    if world > 1:
+    if ddist.active():
         gather()
     torch.cuda.synchronize()
     ddist.barrier()
@@ -673,7 +673,9 @@ def main():
                                    "64+128 samples, test-time render_image, 1 frame per step per GPU",
                        "rays_per_step_per_gpu": rays, "precision": PREC_TEXT[args.precision],
                        "precision_gate": PREC_GATE[args.precision],
-                       "parallelism": f"frames sharded over {world} GPU(s), gather at end"},
+                       "parallelism": f"frames sharded over {world} GPU(s), gather at end",
+                       "collectives": ("RCCL gather of rgb + disp inside the timed region" + (" (forced at world size 1)" if world == 1 else ""))
+                                      if ddist.active() else "none (one rank)"},
             "roofline": roof,
         }
         if world == 1 and not args.no_extras:
@@ -729,7 +731,7 @@ def main():
             rec["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], args.precision, dev)
             line["cpu_baseline"] = rec
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -38,8 +38,9 @@ class EarlyStopping:
         path = self.ckpt_save_path
         if save_multiple:
             path = path[:-3] + f'-{epoch:04d}-{val_loss:.4f}.pt'
-        from .dist import rank_world
-        if rank_world()[0] == 0:   # data-parallel training: the replicas are identical, rank 0 writes
+        from .dist import rank_world, sync_buffers
+        sync_buffers(model)        # data-parallel training: parameters are identical, BatchNorm's running statistics are per rank
+        if rank_world()[0] == 0:   # ... rank 0 writes
             torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)
         if update_best:
             self.val_loss_min = val_loss

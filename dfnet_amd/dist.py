@@ -12,13 +12,25 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives():
+    """DFN_FORCE_COLLECTIVES=1: run every collective of this module even in a process group of ONE rank (the early-outs at
+    world size 1 are skipped and the group is initialised under a launcher that sets WORLD_SIZE=1) — how the one-GPU test box
+    brings RCCL up and pushes real frames / gradients through gather and all-reduce (tests/test_gpu_dist.py)."""
+    return os.environ.get("DFN_FORCE_COLLECTIVES", "0") == "1"
+
+
+def active():
+    """True when the collectives of this module actually run: an initialised group of more than one rank, or a forced one."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives())
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun) if WORLD_SIZE > 1.
     Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (force_collectives() and "WORLD_SIZE" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -51,7 +63,7 @@ def gather_frames(local, n_frames, dst=0):
     world buffers (a direct gather — every peer writes straight to the root, the right shape for
     point-to-point xGMI links; a ring would be bound by one link) and drops the padding.
     Returns the [n_frames, ...] tensor on rank dst, None elsewhere.  world == 1: identity."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [frame_block(n_frames, r, world) for r in range(world)]
@@ -65,18 +77,32 @@ def gather_frames(local, n_frames, dst=0):
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
 
 
-def allreduce_gradients(params):
-    """Data-parallel DFNet_dm: average the pose regressor's gradients over ranks with ONE
+def data_parallel_rounds(n_items, rank, world):
+    """Round-robin schedule of n_items work items (training images) over `world` ranks that keeps EVERY rank on the same number
+    of optimisation steps: items are dealt in rounds of `world`; yields, per item index, (mine, end_of_round, contributors).
+    `mine`: this rank computes the item's gradients; `end_of_round`: every rank now joins ONE gradient all-reduce and steps;
+    `contributors`: items in this round (< world in the last, partial round: ranks without an item contribute zero gradients
+    and the sum is divided by `contributors`, allreduce_gradients(contributors=...)).  Without this, n_items % world != 0 left
+    some ranks one all-reduce short per epoch: their next epoch's first all-reduce paired with the others' last."""
+    for i in range(n_items):
+        start = i - i % world
+        contributors = min(world, n_items - start)
+        yield i % world == rank, (i % world == world - 1) or (i == n_items - 1), contributors
+
+
+def allreduce_gradients(params, contributors=None):
+    """Data-parallel steps (the NeRF-H training loop): average the gradients over ranks with ONE
     all-reduce of a flat bucket (15.4 M parameters = 61.6 MB for DFNet; RCCL over xGMI with the nccl backend).
-    Parameters without a gradient are skipped (the same set on every rank).  world == 1: no-op."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    Parameters without a gradient are skipped (the same set on every rank).  contributors: divide the sum by this many ranks
+    instead of the world size (a partial last round: the idle ranks pass zeros).  world == 1: no-op."""
+    if not active():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= dist.get_world_size()
+    flat /= (contributors if contributors else dist.get_world_size())
     off = 0
     for g in grads:
         n = g.numel()
@@ -86,7 +112,7 @@ def allreduce_gradients(params):
 
 def max_over_ranks(value, device):
     """MAX all-reduce of a python float (timing)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -94,5 +120,20 @@ def max_over_ranks(value, device):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.barrier()
+
+
+def sync_buffers(module, src=0):
+    """Data-parallel training keeps parameters identical through the gradient all-reduce, but BatchNorm's running statistics
+    are updated from each rank's OWN mini-batch: average them (and broadcast the integer step counters) before rank `src`
+    writes a checkpoint, so that the saved model is the one every rank would evaluate.  world == 1: no-op."""
+    if not active():
+        return
+    world = dist.get_world_size()
+    for name, buf in module.named_buffers():
+        if buf.is_floating_point():
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            buf /= world
+        else:
+            dist.broadcast(buf, src=src)

@@ -37,21 +37,31 @@ def train_on_epoch_nerfw(args, train_dl, H, W, focal, N_rand, optimizer, loss_fu
     trainer = render_kwargs_train['network_query_fn'].trainer
     rank, world = ddist.rank_world()
     loss = psnr = None
-    for batch_idx, (target, pose, img_idx) in enumerate(train_dl):
-        select_inds = np.random.choice(H * W, size=[N_rand], replace=False) if N_rand is not None else np.arange(H * W)
-        if batch_idx % world != rank:
-            continue   # the draw above keeps every rank's generator in step
-        target = target[0].permute(1, 2, 0).to(device)
-        pose = pose.reshape(3, 4).to(device)
-        rays_o, rays_d = get_rays(H, W, focal, pose)
-        sel = torch.from_numpy(select_inds).to(device)
-        rays_o, rays_d = rays_o.reshape(-1, 3)[sel], rays_d.reshape(-1, 3)[sel]
-        target_s = target.reshape(-1, 3)[sel]
-        loss_d, psnr, _ = trainer.train_step(rays_o, rays_d, img_idx.to(device), target_s, args.N_samples, args.N_importance,
-                                             render_kwargs_train['near'], render_kwargs_train['far'], perturb=float(args.perturb),
-                                             raw_noise_std=float(args.raw_noise_std), coef=loss_func.coef, lambda_u=loss_func.lambda_u)
-        loss = sum(loss_d.values())
-        ddist.allreduce_gradients(trainer.params)
+    # Images are dealt to the ranks in rounds of `world`; every rank takes ONE optimisation step per round, also in the last,
+    # partial round of an epoch (ranks without an image contribute zero gradients): dist.data_parallel_rounds
+    plan = ddist.data_parallel_rounds(len(train_dl), rank, world)
+    stepped_in_round = False
+    for (target, pose, img_idx), (mine, end_of_round, contributors) in zip(train_dl, plan):
+        select_inds = np.random.choice(H * W, size=[N_rand], replace=False) if N_rand is not None else np.arange(H * W)   # every rank draws: generators stay in step
+        if mine:
+            target = target[0].permute(1, 2, 0).to(device)
+            pose = pose.reshape(3, 4).to(device)
+            rays_o, rays_d = get_rays(H, W, focal, pose)
+            sel = torch.from_numpy(select_inds).to(device)
+            rays_o, rays_d = rays_o.reshape(-1, 3)[sel], rays_d.reshape(-1, 3)[sel]
+            target_s = target.reshape(-1, 3)[sel]
+            loss_d, psnr, _ = trainer.train_step(rays_o, rays_d, img_idx.to(device), target_s, args.N_samples, args.N_importance,
+                                                 render_kwargs_train['near'], render_kwargs_train['far'], perturb=float(args.perturb),
+                                                 raw_noise_std=float(args.raw_noise_std), coef=loss_func.coef, lambda_u=loss_func.lambda_u)
+            loss = sum(loss_d.values())
+            stepped_in_round = True
+        if not end_of_round:
+            continue
+        if not stepped_in_round:   # no image for this rank in the (partial) round: zero gradients into the all-reduce
+            for q in trainer.params:
+                q.grad = torch.zeros_like(q) if q.grad is None else q.grad.zero_()
+        stepped_in_round = False
+        ddist.allreduce_gradients(trainer.params, contributors)
         optimizer.step()
         render_kwargs_train['network_query_fn'].stale = True
         # NOTE: IMPORTANT!  update learning rate (run_nerf.py:70-76)

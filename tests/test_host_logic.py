@@ -188,6 +188,54 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
     assert "ALLREDUCE_OK" in r.stdout
 
 
+_GLOO_ROUNDS_WORKER = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from dfnet_amd import dist as ddist
+rank, world, _ = ddist.init_from_env(backend="gloo")
+# 5 "images" on 2 ranks (the NeRF-H training loop of script/run_nerf.py): every rank must take ceil(5 / 2) = 3 steps,
+# the last one with a single contributor; BatchNorm buffers are averaged before a checkpoint
+p = torch.nn.Parameter(torch.zeros(3))
+steps, seen = 0, []
+done = False
+for epoch in range(2):
+    for i, (mine, end, contrib) in enumerate(ddist.data_parallel_rounds(5, rank, world)):
+        if mine:
+            p.grad = torch.full((3,), float(10 * epoch + i)); done = True
+        if not end:
+            continue
+        if not done:
+            p.grad = torch.zeros(3) if p.grad is None else p.grad.zero_()
+        done = False
+        ddist.allreduce_gradients([p], contrib)
+        seen.append(float(p.grad[0])); steps += 1
+want = [0.5, 2.5, 4.0, 10.5, 12.5, 14.0]
+assert steps == 6 and seen == want, (rank, steps, seen)
+bn = torch.nn.BatchNorm1d(2)
+bn.running_mean.fill_(float(rank)); bn.num_batches_tracked.fill_(7 + rank)
+ddist.sync_buffers(bn)
+assert torch.allclose(bn.running_mean, torch.full((2,), 0.5)) and int(bn.num_batches_tracked) == 7
+if rank == 0: print("ROUNDS_OK")
+ddist.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_data_parallel_rounds_odd_image_count_gloo_world2(tmp_path):
+    """NeRF-H training over ranks with an image count that the world size does not divide: same number of steps on every rank,
+    the partial round averaged over its contributors; BatchNorm buffers synchronised before rank 0 checkpoints."""
+    from dfnet_amd import dist as ddist
+    assert [list(x) for x in ddist.data_parallel_rounds(3, 1, 2)] == [[False, False, 2], [True, True, 2], [False, True, 1]]
+    assert [x[1] for x in ddist.data_parallel_rounds(4, 0, 1)] == [True] * 4
+    script = tmp_path / "r.py"
+    script.write_text(_GLOO_ROUNDS_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29643", str(script), ROOT],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ROUNDS_OK" in r.stdout
+
+
 def test_triplet_losses_and_view_perturbation(tmp_path):
     """Training-side host helpers of run_feature.py: the triplet losses against nn.TripletMarginLoss on explicitly built
     triplets (feature/misc.py:355-435), random-view pose perturbation (misc.py:437-483) and EarlyStopping."""
