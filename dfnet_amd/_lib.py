@@ -40,6 +40,7 @@ SIGNATURES = {
     "dfn_feature_cosine_forward": (c_int, [_P, c_size_t, _P, c_size_t, _P, c_int, c_int, c_int, c_size_t, _P, _P, c_size_t, _P]),
     "dfn_feature_cosine_backward": (c_int, [_P, c_size_t, _P, c_size_t, _P, c_int, c_int, c_int, c_size_t, _P, _P, _P, c_size_t, _P]),
     "dfn_nerfh_set_render_options": (c_int, [_P, c_int]),
+    "dfn_nerfh_range_status": (c_int, [_P, POINTER(c_int), _P]),
     "dfn_ndc_rays": (c_int, [c_int, c_int, c_float, c_float, _P, _P, c_size_t, _P, _P, _P]),
     "dfn_sample_fine_opt": (c_int, [_P, c_size_t, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
     "dfn_raygen": (c_int, [c_int, c_int, c_float, _P, _P, _P, _P, _P]),

@@ -129,6 +129,7 @@ extern "C" int dfn_nerfh_destroy(dfn_nerfh_t h) {
   free_packed(h);
   for (hipEvent_t e : h->side_ev) if (e) (void)hipEventDestroy(e);
   if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+  if (h->range_flag) (void)hipFree(h->range_flag);
   delete h;
   return DFN_OK;
 }
@@ -412,6 +413,25 @@ extern "C" int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags) {
   return DFN_OK;
 }
 
+extern "C" int dfn_nerfh_range_status(dfn_nerfh_t h, int* flags, void* stream) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_range_status: null handle");
+  int v = 0;
+  if (h->range_flag) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(&v, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemsetAsync(h->range_flag, 0, sizeof(int), s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return set_error(DFN_ERR_HIP, "dfn_nerfh_range_status: reading the flag failed");
+  }
+  if (flags) { *flags = v; return DFN_OK; }
+  if (v)
+    return set_error(DFN_ERR_RANGE, "NeRF-H render: activations left the range of the %s arithmetic since the last check (%s); the frames rendered "
+                     "since then are not the network's output: render them with DFN_PREC_F32",
+                     (v & DFN_RANGE_F16_OVERFLOW) ? "f16" : "split-f16",
+                     (v & DFN_RANGE_F16_OVERFLOW) ? "an f16 layer output overflowed to inf: |activation| > 65504"
+                                                  : "a split-f16 hi half saturated: |activation| >= 4094");
+  return DFN_OK;
+}
+
 extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_commit: null handle");
   for (const auto& kv : expected_shapes(h->desc))
@@ -641,6 +661,15 @@ static int mlp_variant_128() {
   return v;
 }
 
+// The handle's range-guard flag (device int), allocated on first use.
+static int* range_flag_of(dfn_nerfh_t h) {
+  if (!h->range_flag) {
+    if (hipMalloc(reinterpret_cast<void**>(&h->range_flag), sizeof(int)) != hipSuccess) { h->range_flag = nullptr; return nullptr; }
+    (void)hipMemset(h->range_flag, 0, sizeof(int));
+  }
+  return h->range_flag;
+}
+
 static unsigned long long* g_timing_buf = nullptr;  // DFN_TIMING builds only (tools/gpu_timing.py)
 extern "C" void dfn_debug_set_timing_buffer(void* p) { g_timing_buf = static_cast<unsigned long long*>(p); }
 
@@ -666,6 +695,7 @@ extern "C" int dfn_mlp_coarse(dfn_nerfh_t h, int prec, const float* rays_o, cons
   const PackedNet& n = h->net[0][prec][mlp_variant_of(h)];
   MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, nullptr, nullptr, sigma, nullptr, (long long)n_rays, Nc, near, far, nullptr, n.in_scale,
             h->render_flags & DFN_RENDER_LINDISP};
+  a.status = range_flag_of(h);
   ScopedTimer t(0, HS(stream));
   CHECK_HIP(launch_mlp(false, prec, mlp_variant_of(h), a, device_cu_count(), HS(stream), h->desc.width), "dfn_mlp_coarse");
   return DFN_OK;
@@ -737,6 +767,7 @@ extern "C" int dfn_mlp_fine(dfn_nerfh_t h, int prec, const float* rays_o, const 
   CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine(ray_bias)");
   const PackedNet& n = h->net[1][prec][mlp_variant_of(h)];
   MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, nullptr, (long long)n_rays, Nf, 0.f, 0.f, g_timing_buf, n.in_scale};
+  a.status = range_flag_of(h);
   ScopedTimer t(1, HS(stream));
   CHECK_HIP(launch_mlp(true, prec, mlp_variant_of(h), a, device_cu_count(), HS(stream), h->desc.width), "dfn_mlp_fine");
   return DFN_OK;
@@ -809,6 +840,7 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     {
       MlpArgs a{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale,
                  h->render_flags & DFN_RENDER_LINDISP};
+      a.status = range_flag_of(h);
       ScopedTimer t(0, s);
       CHECK_HIP(launch_mlp(false, cprec, var, a, cus, s, h->desc.width), "render: coarse MLP");
     }
@@ -823,6 +855,7 @@ int render_core(dfn_nerfh_t h, int prec, const float* o, const float* d, const f
     }
     {
       MlpArgs a{nf.blob, nf.tab, nf.n_units, co, cd, w.z, w.bias, raw, fused ? w.partial : nullptr, (long long)n, Nf, 0.f, 0.f, g_timing_buf, nf.in_scale};
+      a.status = range_flag_of(h);
       ScopedTimer t(1, s);
       CHECK_HIP(launch_mlp(true, prec, var, a, cus, s, h->desc.width), "render: fine MLP");
     }
@@ -1011,11 +1044,13 @@ int render_backward_core(dfn_nerfh_t h, int prec, const float* o, const float* d
     const float* ch = hist_rows == 1 ? hist : hist + r0 * h->desc.hist_bin;
     MlpArgs ac{nc.blob, nc.tab, nc.n_units, co, cd, nullptr, nullptr, w.f.sigma, nullptr, (long long)n, Nc, near, far, nullptr, nc.in_scale,
                  h->render_flags & DFN_RENDER_LINDISP};
+    ac.status = range_flag_of(h);
     CHECK_HIP(launch_mlp(false, prec, var, ac, cus, s, h->desc.width), "render backward: coarse MLP");
     CHECK_HIP(launch_sample_fine(w.f.sigma, n, Nc, Ni, near, far, w.f.z, nullptr, nullptr, s, h->render_flags & DFN_RENDER_LINDISP),
               "render backward: sample_fine");
     CHECK_HIP(launch_ray_bias(h->rb, cv, ch, hist_rows, n, w.f.bias, s), "render backward: ray_bias");
     MlpArgs af{nf.blob, nf.tab, nf.n_units, co, cd, w.f.z, w.f.bias, w.f.raw, nullptr, (long long)n, Nf, 0.f, 0.f, nullptr, nf.in_scale};
+    af.status = range_flag_of(h);
     CHECK_HIP(launch_mlp(true, prec, var, af, cus, s, h->desc.width), "render backward: fine MLP");
     CHECK_HIP(launch_composite_fine_backward(w.f.raw, w.f.z, grad_rgb + r0 * 3, n, Nf, w.graw, s), "render backward: composite");
     BwdArgs ab{nb.blob, nb.tab, nb.n_units, co, cd, cv, w.f.z, w.f.bias, w.graw, w.gpts, (long long)n, Nf, nb.in_scale};

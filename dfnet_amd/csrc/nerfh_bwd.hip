@@ -192,6 +192,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
   st.dma_waves = WAVES;
+  st.rmax = 0;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
   st.lane_mul = 1.f;

@@ -34,6 +34,7 @@ struct dfn_nerfh_s {
   // Training step: the coarse network's backward runs beside the fine one's on this stream (created on first use), fenced by the
   // two events (nerfh_train_api.hip: dfn_nerfh_train_backward).
   int render_flags = 0;    // DFN_RENDER_* options of every render entry point (dfn_nerfh_set_render_options)
+  int* range_flag = nullptr;   // device int the MLP kernels OR their range-guard bits into (dfn_nerfh_range_status)
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[2] = {nullptr, nullptr};
 };

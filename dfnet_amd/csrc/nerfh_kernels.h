@@ -23,6 +23,8 @@ struct MlpArgs {
   float in_scale;          // split-f16 only: weight scale x activation scale carried by the accumulators (else 1)
   int lindisp;             // coarse: depths linear in disparity instead of depth (rendering.py:272-273)
   int dma_waves;           // waves of a workgroup that issue the weight DMA (0 = the kernel geometry's default, launch_one)
+  int* status;             // range guard (device int, may be null): bit 0 = an f16 activation overflowed to inf, bit 1 = a
+                           // split-f16 hi half saturated (DFN_RANGE_*: dfn_nerfh_range_status)
 };
 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width = 128);

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
   st.lane_mul = 1.f;
+  st.rmax = 0;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
     for (int nb = 0; nb < NB; ++nb)
       if (h == 0 && pt[nb] < npts) a.out[pt[nb]] = head_softplus<P, FAST>(head[nb][0]);
   }
+  range_report<P>(st.rmax, a.status);
 }
 
 template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE, int W = kWidth>
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
   st.lane_mul = 1.f;
+  st.rmax = 0;
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
       }
     }
   }
+  range_report<P>(st.rmax, a.status);
 #ifdef DFN_TIMING
   if (a.timing && st.lane == 0) {
     unsigned long long* t = a.timing + (blockIdx.x * WAVES + st.wave) * 4;

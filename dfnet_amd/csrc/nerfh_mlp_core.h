@@ -50,7 +50,26 @@ struct Stager {
   bool more;           // another tile follows this one (wave-uniform)
   float in_scale, out_scale;  // split-f16: accumulators carry in_scale x the true value (MlpArgs), out_scale = 1 / in_scale
   float lane_mul;             // split-f16: extra per-LANE power-of-two factor on the next layer's outputs (gradient renormalisation)
+  uint32_t rmax;              // range guard: running unsigned maximum of the packed f16 activations (hi halves for split-f16) this
+                              // lane has produced, sign bits cleared: >= 0x7c00 = an inf, 0x7bff = the saturation value
 };
+
+// Range guard of the narrow arithmetic modes.  A ReLU output is a non-negative f16, so its bit pattern orders like the value: one
+// v_pk_max_u16 per converted register keeps the largest pattern seen; layers without ReLU clear the sign bits first.  Checked
+// once per kernel (range_report): f16 conversions overflow to inf (0x7c00), the split-f16 hi halves are truncating conversions
+// that saturate at 65504 (0x7bff).
+DFN_DEV void range_track(uint32_t& rmax, uint32_t packed, bool nonneg) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const uint32_t v = nonneg ? packed : (packed & 0x7fff7fffu);
+  rmax = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, rmax), __builtin_bit_cast(us2, v)));
+}
+template <class P>
+DFN_DEV void range_report(uint32_t rmax, int* status) {
+  if constexpr (P::kSlotsPerChunk == 8) {
+    const uint32_t thr = P::kSplit ? 0x7bffu : 0x7c00u;
+    if (status && ((rmax & 0xffffu) >= thr || (rmax >> 16) >= thr)) atomicOr(status, P::kSplit ? 2 : 1);
+  }
+}
 
 // Direct-to-LDS DMA, issued as inline asm ON PURPOSE.  With the builtin, LLVM cannot tell which LDS bytes a DMA
 // writes and makes EVERY later ds_read wait for vmcnt(0) (SIInsertWaitcnts, LDS-DMA aliasing): the first A-fragment
@@ -215,7 +234,7 @@ DFN_DEV f32x16 load16(const float* p) {
 
 // C fragment -> B-operand registers of the next layer (ReLU optional).
 template <class P, bool RELU, int OC>
-DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, float oscale = 1.f) {
+DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, float oscale, uint32_t& rmax) {
 #ifdef DFN_ABL_NOEPI  // ablation: no conversion/ReLU work (results are garbage, timing only)
   asm volatile("" ::"v"(acc));
   return;
@@ -238,6 +257,7 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
         const pk2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        range_track(rmax, hb, RELU);
         out[2 * mb + c].hi[j] = (_Float16)h[0]; out[2 * mb + c].hi[j + 1] = (_Float16)h[1];
         out[2 * mb + c].lo[j] = (_Float16)l[0]; out[2 * mb + c].lo[j + 1] = (_Float16)l[1];
       }
@@ -251,6 +271,12 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
         const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         v = __builtin_elementwise_max(v, zero);
       }
+      {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) range_track(rmax, w[q], RELU);
+      }
       out[2 * mb + c] = v;
     }
   } else {
@@ -259,11 +285,17 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
   }
 }
 
+template <class P, bool RELU, int OC>
+DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, float oscale = 1.f) {
+  uint32_t unused = 0;
+  store_hidden<P, RELU>(acc, out, mb, oscale, unused);
+}
+
 // One eighth of store_hidden: output register pair i (0..7) of an M-block's C fragment.  The two empty
 // asm statements anchor the conversion at this point of the instruction stream: without them LLVM treats the
 // pure arithmetic as freely movable and sinks it out from between the MFMAs it is meant to hide behind.
 template <class P, bool RELU, int OC>
-DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, int i, float oscale = 1.f) {
+DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, int i, float oscale, uint32_t& rmax) {
   if constexpr (P::kSplit) {
     // split-f16: piece i = two consecutive results -> one register of the hi plane + one of the lo plane (the arithmetic of
     // store_hidden: scale, ReLU, truncating hi pair, exact remainders by v_fma_mix_f32, lo pair), as ONE volatile asm block so
@@ -286,6 +318,8 @@ DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&ou
                    "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
                    "v_cvt_pkrtz_f16_f32 %1, %2, %3"
                    : "=&v"(hb), "=&v"(lb), "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]), "v"(oscale));
+    if (RELU) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(rmax) : "v"(hb));   // range guard (range_track), pinned with the piece
+    else range_track(rmax, hb, false);
     const half2v hv = __builtin_bit_cast(half2v, hb), lv = __builtin_bit_cast(half2v, lb);
     out[2 * mb + c].hi[j] = hv[0]; out[2 * mb + c].hi[j + 1] = hv[1];
     out[2 * mb + c].lo[j] = lv[0]; out[2 * mb + c].lo[j + 1] = lv[1];
@@ -300,6 +334,8 @@ DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&ou
       asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(bits) : "v"(acc[8 * c + 2 * j]), "v"(acc[8 * c + 2 * j + 1]));
     else
       asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bits) : "v"(acc[8 * c + 2 * j]), "v"(acc[8 * c + 2 * j + 1]));
+    if (RELU) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(rmax) : "v"(bits));   // range guard (range_track), pinned with the piece
+    else range_track(rmax, bits, false);
     const half2v v = __builtin_bit_cast(half2v, bits);
     out[2 * mb + c][2 * j] = v[0];
     out[2 * mb + c][2 * j + 1] = v[1];
@@ -418,7 +454,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
             for (int q = 0; q < PPKI; ++q) {
               const int piece = kc * PPKI + q;
-              if (piece < 8 * NB) store_hidden_piece<P, CIN_RELU>(carry[piece >> 3], Bin[piece >> 3], CIN / 2, piece & 7, pscale);
+              if (piece < 8 * NB) store_hidden_piece<P, CIN_RELU>(carry[piece >> 3], Bin[piece >> 3], CIN / 2, piece & 7, pscale, st.rmax);
             }
             if (kc == CIN - 1) asm volatile("s_nop 3");  // VALU-written B operand is read by the very next MFMA
           }
@@ -426,7 +462,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
             for (int q = 0; q < PPK; ++q) {
               const int piece = kc * PPK + q;
-              if (piece < 8 * NB) store_hidden_piece<P, RELU>(pend[piece >> 3], Bout[piece >> 3], mb - 1, piece & 7, pscale);
+              if (piece < 8 * NB) store_hidden_piece<P, RELU>(pend[piece >> 3], Bout[piece >> 3], mb - 1, piece & 7, pscale, st.rmax);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -438,7 +474,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
           } else {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb, st.out_scale * st.lane_mul);
+            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb, st.out_scale * st.lane_mul, st.rmax);
           }
         } else {
 #pragma unroll
@@ -456,7 +492,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
       for (int nb = 0; nb < NB; ++nb) carry[nb] = pend[nb];
     } else {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1, st.out_scale * st.lane_mul);
+      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1, st.out_scale * st.lane_mul, st.rmax);
     }
   }
 }

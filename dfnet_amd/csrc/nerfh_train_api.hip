@@ -130,15 +130,26 @@ TrainWs carve_train(float* base, const Dims& m, size_t R, int Nc, int Ni, bool w
     w.gt1 = take(Pf * m.W2);
     w.gsum = take(R * m.W2);
     w.gray = take(R * size_t(m.ld_df > m.ld_t ? m.ld_df : m.ld_t));
-    const int kmax = m.W + kChXyz;
-    w.wscratch = take(gemm_wgrad_scratch_floats(m.W, kmax > m.W ? m.W : kmax, (long long)Pf) + 1024);
+    // weight-gradient partials: the largest over the (outputs N, segment width K) pairs the backward really issues — for
+    // netwidth < 64 the 63-wide encoding and the 27 + hist_bin * dim_a wide direction tail exceed W x W
+    auto wscratch_floats = [&](long long P) {
+      const int pairs[][2] = {{m.W, m.W}, {m.W, kChXyz + 1}, {m.W2, m.W}, {m.W2, m.ld_df}, {m.W2, m.ld_dc}, {m.W2, m.ld_t}, {m.W2, m.W2},
+                              {4, m.W}, {4, m.W2}};
+      size_t best = 0;
+      for (const auto& nk : pairs) {
+        const size_t f = gemm_wgrad_scratch_floats(nk[0], nk[1], P);
+        best = f > best ? f : best;
+      }
+      return best + 1024;
+    };
+    w.wscratch = take(wscratch_floats((long long)Pf));
     w.gA_c = take(Pc * m.W);
     w.gB_c = take(Pc * m.W);
     w.gfin_c = take(Pc * m.W);
     w.gt0_c = take(Pc * m.W2);
     w.gsum_c = take(R * m.W2);
     w.gray_c = take(R * size_t(m.ld_dc));
-    w.wscratch_c = take(gemm_wgrad_scratch_floats(m.W, kmax > m.W ? m.W : kmax, (long long)Pc) + 1024);
+    w.wscratch_c = take(wscratch_floats((long long)Pc));
   }
   w.total = off * sizeof(float);
   return w;

@@ -59,19 +59,21 @@ class _FeatureFn(torch.autograd.Function):
     def forward(ctx, x, engine, single, upH, upW):
         feats, _ = engine.forward(x.detach(), True, single, False, upH, upW)
         ctx.save_for_backward(x.detach())
-        ctx.cfg = (engine, single)
+        # the caller's hint "my loss reads these pyramid levels only" belongs to THIS forward's graph: taken into the context and
+        # cleared on the engine, so that a later backward through the same model with another level set is not cut short
+        ctx.cfg = (engine, single, getattr(engine, "grad_levels_hint", None))
+        engine.grad_levels_hint = None
         return (feats,) if single else (feats[0], feats[1])
 
     @staticmethod
     def backward(ctx, *grads):
         (x,) = ctx.saved_tensors
-        engine, single = ctx.cfg
+        engine, single, levels = ctx.cfg
         if single:
             g = grads[0]
         else:  # siamese halves back into the batch order of x: [target half, render half]
             shape = next(t for t in grads if t is not None).shape
             g = torch.cat([t if t is not None else x.new_zeros(shape) for t in grads], 1)
-        levels = getattr(engine, "grad_levels_hint", None)   # set by the caller who knows which pyramid levels its loss uses
         if levels is None:   # otherwise: which levels carry gradient at all (a scan of g and a host sync per level)
             levels = [t for t in range(g.shape[0]) if bool((g[t] != 0).any())]
         if not levels:
@@ -240,7 +242,8 @@ class _DFNetBase(nn.Module):
             sd = dict(list(self.named_parameters()) + list(self.named_buffers()))
             pose_names, names = self._pose_param_names(), self._refresh_names()
             on_gpu = all(sd[k].is_cuda for k in names)
-            if on_gpu and changed and changed <= set(pose_names) and (train or not self._folded_stale):
+            if on_gpu and changed and changed <= set(pose_names) and (train or not self._folded_stale) and \
+                    not (train and running_stats and self._bn_stats_stale):   # (a stale BatchNorm block needs the full train-mode re-pack)
                 # an optimizer step of DFNet_dm moves the regressor's 28 tensors only: re-pack those (the train-mode re-pack below
                 # would redo the adaptation layers and copy the BatchNorm blocks too: 24 kernels and 12 copies per step)
                 self._engine.refresh_pose_params_device([sd[k].detach() for k in pose_names])

@@ -72,6 +72,17 @@ class NerfHEngine:
         return self.load_numpy(sd(network_fn), sd(network_fine), embedding_a.weight.detach().cpu().numpy(),
                                embedding_t.weight.detach().cpu().numpy())
 
+    def range_flags(self):
+        """DFN_RANGE_* bits raised by the MLP kernels since the last call (waits for the current stream, clears them)."""
+        v = ctypes.c_int(0)
+        check(self.lib.dfn_nerfh_range_status(self.handle, ctypes.byref(v), current_stream()), "dfn_nerfh_range_status")
+        return v.value
+
+    def check_range(self):
+        """Raise DfnError if an f16 / split-f16 activation overflowed / saturated in a render since the last check: such frames
+        are not the network's output (render with precision='f32')."""
+        check(self.lib.dfn_nerfh_range_status(self.handle, None, current_stream()), "NeRF-H range guard")
+
     def _prec(self, precision):
         return _lib.PRECISIONS[precision or self.precision]
 

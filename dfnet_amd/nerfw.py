@@ -75,12 +75,24 @@ class HipQuery:
         self.trainer = trainer      # NerfHTrainer: the training-mode render and its gradients (nerf_train.py)
         self.modules = modules      # (network_fn, network_fine, embedding_a, embedding_t) behind the engine's packed weights
         self.stale = False          # the master weights moved (optimizer step) since the engine was packed
+        self._packed_versions = self._versions()
+
+    def _versions(self):
+        """torch's in-place version counters of every master tensor: they move with optimizer.step() / load_state_dict()."""
+        if self.modules is None:
+            return None
+        return tuple(p._version for m in self.modules for p in m.parameters())
 
     def refresh(self):
-        """Re-pack the test-time engine from the (trained) modules — before a validation render."""
-        if self.modules is not None and self.stale:
+        """Re-pack the test-time engine from the (trained) modules — before a validation render — when they moved: either the
+        training loop said so (`stale`) or their version counters did."""
+        if self.modules is None:
+            return
+        cur = self._versions()
+        if self.stale or cur != self._packed_versions:
             self.engine.load_modules(*self.modules)
             self.stale = False
+            self._packed_versions = cur
 
     def __call__(self, *a, **k):
         raise RuntimeError("network_query_fn is fused into the HIP render path; call rendering.render()")
@@ -142,7 +154,7 @@ def create_nerf(args):
 
     engine = NerfHEngine(depth=args.netdepth, width=args.netwidth, multires=args.multires,
                          multires_views=args.multires_views, hist_bin=args.hist_bin, dim_a=dim_a, dim_t=dim_t,
-                         n_vocab=args.N_vocab, precision=getattr(args, "precision", "f16"))
+                         n_vocab=args.N_vocab, precision=getattr(args, "precision", "f16x3"))
     engine.load_modules(model, model_fine, embedding_a, embedding_t)
 
     from .nerf_train import NerfHTrainer

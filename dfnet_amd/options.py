@@ -67,7 +67,8 @@ _T = [
     ("render_feature_only", "flag", False, "f"), ("feature_matching_lvl", "int+", [0, 1, 2], "d"),
     ("per_channel", "flag", False, "d"), ("featuremetric", "flag", False, "d"),
     # --- additions of this implementation (not in the reference) ---
-    ("precision", "str", "f16", "nfd"),        # MFMA arithmetic of the HIP path: f16 | f32
+    ("precision", "str", "f16x3", "nfd"),      # MFMA arithmetic of the HIP path: f16x3 (split-f16: fp32-grade, the default — the
+                                               # reference computes in fp32) | f32 (exact fp32 MFMA) | f16 (fast; 1e-3 contract)
 ]
 _TYPES = {"int": int, "float": float, "str": str}
 
@@ -129,6 +130,11 @@ def _build(which):
             p.add_argument("--" + name, action="store_true", default=default)
         elif kind.endswith("+"):
             p.add_argument("--" + name, nargs="+", type=_TYPES[kind[:-1]], default=default)
+        elif name == "precision":
+            p.add_argument("--precision", type=str, default=default, choices=["f16x3", "f32", "f16"],
+                           help="MFMA arithmetic of the NeRF-H HIP path: f16x3 = split-f16 (hi + lo f16 operands, fp32 accumulate: fp32-grade, "
+                                "the default since the reference computes in fp32), f32 = exact fp32 MFMA, f16 = f16 inputs (3x faster, "
+                                "1e-3 contract; guarded against overflow by dfn_nerfh_range_status)")
         else:
             p.add_argument("--" + name, type=_TYPES[kind], default=default)
     return p

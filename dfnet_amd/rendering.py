@@ -218,6 +218,12 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         # training mode (rendering.py:245-337 with test_time=False): stratified depths, coarse rgb + noise, importance sampling
         # with random u, the training extras — on the exact-fp32 training kernels, attached to autograd (nerf_train.py)
         _check_test_time(kwargs, ndc, c2w_staticcam, use_viewdirs, training=True)
+        if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in
+                                           ((c2w,) if c2w is not None else tuple(rays) if rays is not None else ())):
+            # the reference's training render is differentiable w.r.t. its rays / pose; this one carries the WEIGHT gradients only:
+            # refuse instead of returning silent zeros (the test-time render has the pose gradient: test_time=True)
+            raise NotImplementedError("render(test_time=False): gradients w.r.t. rays / c2w are not propagated by the training "
+                                      "render (weights only); optimise poses through the test-time render (test_time=True)")
         from . import nerf_train
         dev = torch.device("cuda", torch.cuda.current_device())
         if c2w is not None:
@@ -233,7 +239,8 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
                                                          float(kwargs.get('raw_noise_std', 0.) or 0.), bool(kwargs.get('retraw', False)),
                                                          draws=kwargs.get('draws'))
         extras = {k: v.reshape(lead + list(v.shape[1:])) for k, v in extras.items()}
-        getattr(kwargs.get('network_query_fn'), '__dict__', {}).update(stale=True)
+        # (no `stale` mark here: a render does not move the weights; HipQuery.refresh() sees optimizer steps through the tensors'
+        #  version counters, and the training loop marks them itself)
         return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), extras]
     kwargs.get('network_query_fn').refresh() if hasattr(kwargs.get('network_query_fn'), 'refresh') else None
     def _needs_grad(t):
@@ -393,6 +400,7 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
         t_post += time.time() - tp
     torch.cuda.synchronize()
     t_render = time.time() - t0
+    _engine_of(render_kwargs).check_range()   # loud, not clamped or non-finite frames, if a narrow arithmetic mode overflowed
     all_rgb = ddist.gather_frames(rgbs, N)
     all_disp = ddist.gather_frames(disps, N)
     all_mse = ddist.gather_frames(mse, N) if gt_imgs is not None else None

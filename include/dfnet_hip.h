@@ -32,7 +32,8 @@ enum {
   DFN_ERR_ARG = -1,         /* bad argument (null pointer, size mismatch, unknown name) */
   DFN_ERR_HIP = -2,         /* a HIP runtime call failed */
   DFN_ERR_STATE = -3,       /* handle not committed / parameter missing */
-  DFN_ERR_UNSUPPORTED = -4  /* configuration outside what the kernels implement */
+  DFN_ERR_UNSUPPORTED = -4, /* configuration outside what the kernels implement */
+  DFN_ERR_RANGE = -5        /* activations left the range of a narrow arithmetic mode (dfn_nerfh_range_status) */
 };
 
 /* Arithmetic of the MLP / conv contractions. */
@@ -81,6 +82,16 @@ int dfn_nerfh_commit(dfn_nerfh_t h);
  * is still composited from fp32-grade fine-network outputs. */
 enum { DFN_RENDER_LINDISP = 1, DFN_RENDER_COARSE_F16 = 2 };
 int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags);
+/* Range guard of the narrow arithmetic modes (no counterpart in the reference, which computes in fp32).  DFN_PREC_F16 holds a
+ * layer's outputs as f16 (|x| <= 65504), DFN_PREC_F16X3 as hi + lo f16 halves of 16 x (|x| < 4094); a checkpoint whose hidden
+ * activations leave that range would render clamped or non-finite frames.  Every MLP kernel launched through this handle keeps the
+ * largest activation pattern it converts (one v_pk_max_u16 per converted register) and ORs a bit into a device flag when it
+ * overflowed / saturated.  This call waits for `stream`, reads and clears the flag:
+ *   flags != NULL: *flags = DFN_RANGE_* bits, returns DFN_OK;
+ *   flags == NULL: returns DFN_ERR_RANGE (text in dfn_last_error) when a bit is set, DFN_OK otherwise.
+ * The Python host checks it at the end of every render_path batch and before a checkpoint-driven CLI run reports a PSNR. */
+enum { DFN_RANGE_F16_OVERFLOW = 1, DFN_RANGE_F16X3_SATURATED = 2 };
+int dfn_nerfh_range_status(dfn_nerfh_t h, int* flags, void* stream);
 
 /* ------------------------------------------------------------------ stage-level entry points
  * (each is the production kernel of that stage; exposed so parity tests can check a stage

@@ -283,6 +283,44 @@ def test_sharper_scene_f16_margin():
     assert relmax(got16[0], ref[0]) < 1e-3 and relmax(got16[1], ref[1]) < 1e-3
 
 
+@pytest.mark.parametrize("gain", [1.6, 3.0, 6.0, 16.0])
+def test_range_guard_parity_or_loud_error(gain):
+    """Sharper and sharper networks (every weight matrix x gain) on the three arithmetic modes: a narrow mode either holds its
+    parity contract or raises the range flag (dfn_nerfh_range_status -> DfnError) — never a silently clamped or non-finite
+    frame; exact fp32 always holds."""
+    from dfnet_amd._lib import DfnError
+    cw, fw, ea, et = syn.nerfh_weights(0, gain=gain)
+    E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
+    c, f = tt(cw), tt(fw)
+    H, W, focal = 12, 16, 14.6
+    c2w = T(syn.orbit_pose(3, 8))
+    with torch.no_grad():
+        ref = orc.render(H, W, focal, 32768, c, f, T(ea), T(et), 64, 128, 0., 2.5, syn.HIST_IDX, c2w=c2w)
+    assert E.range_flags() == 0
+    outcomes = {}
+    for prec, tol in (("f32", 5e-4), ("f16x3", 5e-4), ("f16", 5e-3)):
+        got = E.render_image(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, precision=prec)
+        flags = E.range_flags()
+        if flags:
+            assert prec != "f32", "the exact fp32 path has no range to leave"
+            assert flags == (1 if prec == "f16" else 2)
+            E.render_image(c2w.to(DEV), H, W, focal, dev(syn.HIST_IDX), 64, 128, 0., 2.5, precision=prec)
+            with pytest.raises(DfnError, match="range"):
+                E.check_range()
+            assert E.range_flags() == 0                      # cleared by the check
+            outcomes[prec] = "flagged"
+        else:
+            assert all(bool(torch.isfinite(t).all()) for t in got)
+            assert relmax(got[0], ref[0]) < tol and relmax(got[1], ref[1]) < 10 * tol, (prec, gain)
+            outcomes[prec] = "parity"
+    assert outcomes["f32"] == "parity"
+    if gain <= 1.6:
+        assert outcomes == {"f32": "parity", "f16x3": "parity", "f16": "parity"}
+    if gain >= 16.0:
+        assert outcomes["f16"] == "flagged" and outcomes["f16x3"] == "flagged"   # |activation| ~ 1e7: out of both ranges
+    print("gain", gain, outcomes)
+
+
 def test_bad_arguments_raise(scene):
     E = scene[0]
     o = torch.zeros(4, 3, device=DEV)
