@@ -3,7 +3,7 @@
 # usage: tools/gpu_round.sh TAG [notest] [nopmc]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $R
 mkdir -p gpurun_out
 if [[ " $* " != *" notest "* ]]; then
@@ -11,36 +11,39 @@ if [[ " $* " != *" notest "* ]]; then
   tail -6 gpurun_out/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 fi
-timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-3000 gpurun_out/bench.json; tail -3 gpurun_out/bench.err
+timeout 1500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-3000 gpurun_out/bench.json; tail -3 gpurun_out/bench.err
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o $TAG -- python $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-extras > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err; echo "rocprof rc=$?"
-head -9 $R/gpurun_out/prof/${TAG}_kernel_stats.csv | cut -c1-160
-if [[ " $* " != *" nopmc "* ]]; then
-mkdir -p $R/gpurun_out/pmc
-CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-extras"
-i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
-           "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
-  i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc -o pass$i -- $CMD > $R/gpurun_out/pmc/pass$i.log 2>&1
-  echo "pmc pass $i rc=$?"
-done
-python3 - <<PY
+# rocprofv3 kernel stats + three PMC passes of the SAME command per arithmetic mode (the headline's f16x3, exact f32, f16)
+for PREC in f16x3 f32 f16; do
+  rm -rf $R/gpurun_out/prof_$PREC $R/gpurun_out/pmc_$PREC
+  CMD="python $R/bench.py --precision $PREC --steps 3 --warmup 1 --cpu-sample 0 --no-extras"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$PREC -o $TAG -- $CMD > $R/gpurun_out/prof_bench_$PREC.json 2> $R/gpurun_out/prof_$PREC.err; echo "rocprof $PREC rc=$?"
+  head -6 $R/gpurun_out/prof_$PREC/${TAG}_kernel_stats.csv | cut -c1-170
+  if [[ " $* " != *" nopmc "* ]]; then
+    mkdir -p $R/gpurun_out/pmc_$PREC
+    i=0
+    for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+               "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$PREC -o pass$i -- $CMD > $R/gpurun_out/pmc_$PREC/pass$i.log 2>&1
+      echo "pmc $PREC pass $i rc=$?"
+    done
+    python3 - <<PY
 import csv, glob, collections, json
 out = {}
-for f in sorted(glob.glob("$R/gpurun_out/pmc/pass*_counter_collection.csv")):
+for f in sorted(glob.glob("$R/gpurun_out/pmc_$PREC/pass*_counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")[:72]
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k].add(row["Dispatch_Id"])
     for k, d in agg.items():
         out.setdefault(k, {"dispatches": len(n[k])}).update({c: v for c, v in d.items()})
-json.dump(out, open("$R/gpurun_out/pmc/summary.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/pmc_$PREC/summary.json", "w"), indent=1)
 for k, d in out.items():
-    if "nerfh" in k or "composite" in k or "sample" in k: print(k, {c: (f"{v:.4g}" if isinstance(v, float) else v) for c, v in d.items()})
+    if "nerfh" in k: print(k, {c: (f"{v:.4g}" if isinstance(v, float) else v) for c, v in d.items()})
 PY
-fi
+  fi
+done
 # Secondary workloads: kernel stats of the DFNet_dm step and the NeRF-H training step, per-layer table of the DFNet forward.
 if [[ " $* " != *" noextra "* ]]; then
   cd /tmp
