@@ -31,9 +31,12 @@ template <class P, bool FAST> DFN_DEV float head_softplus(float v) { return FAST
 template <class P, bool FAST> DFN_DEV float head_sigmoid(float v) { return FAST ? sigmoid_fast(v) : (P::kSplit ? sigmoid_hw(v) : sigmoid(v)); }
 template <class P, bool FAST> DFN_DEV float head_exp(float v) { return FAST ? __expf(v) : (P::kSplit ? exp_hw(v) : expf(v)); }
 
-// three staging buffers + per-wave next-tile input slots (8 dwords x 64 lanes per 64 points: z, o, d, next z)
+// three staging buffers in the ring (a ring of four with the DMA issued BEFORE the mid-unit barrier by the early waves fits the
+// split-f16 units and was measured: +0.4 %, not kept)
+template <class P, int W> constexpr uint32_t ring_slots() { return 3; }
+// staging ring + per-wave next-tile input slots (8 dwords x 64 lanes per 64 points: z, o, d, next z)
 template <class P, int UMB, int WAVES, int NB, int W = kWidth> constexpr uint32_t lds_bytes() {
-  return 3 * max_unit_bytes<P>(UMB, W) + WAVES * ((NB * 32 + 63) / 64) * 8 * 256;
+  return ring_slots<P, W>() * max_unit_bytes<P>(UMB, W) + WAVES * ((NB * 32 + 63) / 64) * 8 * 256;
 }
 
 // Workgroups per CU the register allocation is sized for.  netwidth 256 in split-f16 / exact fp32 holds 2 x 128 registers of
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  stage_prime(st, smem, max_unit_bytes<P>(UMB, W));
+  stage_prime(st, smem, max_unit_bytes<P>(UMB, W), ring_slots<P, W>());
   for (; tile < n_tiles; tile += gridDim.x) {
     st.more = tile + gridDim.x < n_tiles;
     float x[NB][3];
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
   long long tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  stage_prime(st, smem, USTRIDE);
+  stage_prime(st, smem, USTRIDE, ring_slots<P, W>());
   // Tile inputs.  The first tile's are loaded normally; every later tile's are PREFETCHED during the
   // previous tile's small layers with direct-to-LDS loads and only
   // waited for at the end of that tile, so the HBM latency of z / o / d is off the critical path.
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
         // that nothing younger than a weight DMA is ever waited for before the tile's end:
         // lane l of round r fetches z, o, d and the next sample's z of the wave's point 64 r + l into this wave's LDS slot.
         const uint32_t base = uint32_t(tile + gridDim.x) * uint32_t(PPT) + st.wave * (NB * 32);
-        char* slot = smem + 3 * USTRIDE + st.wave * (PF_ROUNDS * 8 * 256);
+        char* slot = smem + ring_slots<P, W>() * USTRIDE + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
         for (int r = 0; r < PF_ROUNDS; ++r) {
           const uint32_t ptn = base + r * 64 + st.lane;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       asm volatile("" ::: "memory");
       tile_coords(tile + gridDim.x);
-      const char* slot = smem + 3 * USTRIDE + st.wave * (PF_ROUNDS * 8 * 256);
+      const char* slot = smem + ring_slots<P, W>() * USTRIDE + st.wave * (PF_ROUNDS * 8 * 256);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         int loc = nb * 32 + p;

@@ -37,9 +37,9 @@ struct Stager {
   const uint32_t* tab;
   int n_units;
   int u;               // unit that the NEXT open_unit() returns
-  uint32_t lds_cur;    // LDS byte offset holding (or receiving) unit u
-  uint32_t lds_nxt;
-  uint32_t lds_nn;     // third staging buffer (see open_unit / mid_sync)
+  uint32_t slot;       // ring slot holding (or receiving) unit u
+  uint32_t ring;       // staging buffers in the ring (3)
+  uint32_t ustride;    // bytes per ring slot
   int lane, wave, waves;
   int dma_waves;       // the first dma_waves waves issue the weight DMA (the older wave of each SIMD idles at the unit barriers anyway)
   uint32_t ubase, uoff;      // LDS offset of the open unit / bytes of it consumed by the layers so far
@@ -58,10 +58,13 @@ struct Stager {
 // v_pk_max_u16 per converted register keeps the largest pattern seen; layers without ReLU clear the sign bits first.  Checked
 // once per kernel (range_report): f16 conversions overflow to inf (0x7c00), the split-f16 hi halves are truncating conversions
 // that saturate at 65504 (0x7bff).
+DFN_DEV uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 DFN_DEV void range_track(uint32_t& rmax, uint32_t packed, bool nonneg) {
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  const uint32_t v = nonneg ? packed : (packed & 0x7fff7fffu);
-  rmax = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, rmax), __builtin_bit_cast(us2, v)));
+  rmax = pk_max_u16(rmax, nonneg ? packed : (packed & 0x7fff7fffu));
 }
 template <class P>
 DFN_DEV void range_report(uint32_t rmax, int* status) {
@@ -123,11 +126,11 @@ DFN_DEV void stage_issue(const Stager& st, char* smem, int unit, uint32_t lds_of
 // cached KiB +2 %; staggering the two waves of a SIMD, or staging through VGPRs + ds_write_b128 instead of the
 // DMA: no gain / -2.5 %.  The cost follows the BYTES landing in LDS, not instructions, waits or L2; a third of
 // it is shader cycles, two thirds is clock (the traffic is paid in power: DESIGN.md section 3.1).
-DFN_DEV void stage_prime(Stager& st, char* smem, uint32_t unit_stride) {
-  st.lds_cur = 0; st.lds_nxt = unit_stride; st.lds_nn = 2 * unit_stride;
+DFN_DEV void stage_prime(Stager& st, char* smem, uint32_t unit_stride, uint32_t ring = 3) {
+  st.slot = 0; st.ring = ring; st.ustride = unit_stride;
   st.u = 0;
-  stage_issue(st, smem, 0, st.lds_cur);
-  stage_issue(st, smem, st.n_units > 1 ? 1 : 0, st.lds_nxt);
+  stage_issue(st, smem, 0, 0);
+  stage_issue(st, smem, st.n_units > 1 ? 1 : 0, unit_stride);
   const int n2 = st.n_units > 2 ? 2 : 0;
   st.pf_off = tab_entry(st, 2 * n2);
   st.pf_size = tab_entry(st, 2 * n2 + 1);
@@ -138,10 +141,8 @@ DFN_DEV void stage_prime(Stager& st, char* smem, uint32_t unit_stride) {
 
 // Returns the LDS byte offset of unit st.u (already visible) and advances the rotation.
 DFN_DEV uint32_t open_unit(Stager& st) {
-  const uint32_t cur = st.lds_cur;
-  st.lds_cur = st.lds_nxt;   // now: the unit after the one just opened (landing / landed)
-  st.lds_nxt = st.lds_nn;    // now: the buffer of the unit BEFORE the one just opened (free after the next barrier)
-  st.lds_nn = cur;           // now: the unit being computed
+  const uint32_t cur = st.slot * st.ustride;
+  st.slot = st.slot + 1 == st.ring ? 0u : st.slot + 1;   // now: the slot of the unit after the one just opened (landing / landed)
   int nxt = st.u + 1;
   if (nxt == st.n_units) nxt = 0;
   st.u = nxt;
@@ -164,6 +165,12 @@ DFN_DEV void mid_sync(Stager& st, char* smem) {
 #ifdef DFN_TIMING
   const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
+  // unit after next: open unit index is st.u - 1, so this is st.u + 1 (possibly in the next tile); it goes to the slot after
+  // the next unit's, which held the unit BEFORE the open one: free once every wave is inside the open unit, i.e. after the barrier
+  int n2 = st.u + 1;
+  bool next_tile = st.u == 0;   // the open unit is the tile's last: both st.u and st.u + 1 belong to the next tile
+  if (n2 >= st.n_units) { n2 -= st.n_units; next_tile = true; }
+  const uint32_t dst = (st.slot + 1 == st.ring ? 0u : st.slot + 1) * st.ustride;
 #ifndef DFN_ABL_NOBAR
   __builtin_amdgcn_s_barrier();   // every share landed; every wave is inside the open unit
 #endif
@@ -178,12 +185,8 @@ DFN_DEV void mid_sync(Stager& st, char* smem) {
   }
   ++st.n_trace;
 #endif
-  // unit after next: open unit index is st.u - 1, so this is st.u + 1 (possibly in the next tile)
-  int n2 = st.u + 1;
-  bool next_tile = st.u == 0;   // the open unit is the tile's last: both st.u and st.u + 1 belong to the next tile
-  if (n2 >= st.n_units) { n2 -= st.n_units; next_tile = true; }
 #ifndef DFN_ABL_NODMA
-  if (!next_tile || st.more) stage_issue_at(st, smem, st.pf_off, st.pf_size, st.lds_nxt);
+  if (!next_tile || st.more) stage_issue_at(st, smem, st.pf_off, st.pf_size, dst);
 #endif
   {  // fetch the table entry needed by the next call now, so its scalar-load latency is off the critical path
     int n3 = n2 + 1;
@@ -271,11 +274,11 @@ DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC]
         const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         v = __builtin_elementwise_max(v, zero);
       }
-      {
+      {   // range guard: one packed maximum over the four registers, then one update of the running maximum
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 w = __builtin_bit_cast(u32x4, v);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) range_track(rmax, w[q], RELU);
+        u32x4 w = __builtin_bit_cast(u32x4, v);
+        if (!RELU) w &= 0x7fff7fffu;
+        rmax = pk_max_u16(rmax, pk_max_u16(pk_max_u16(w[0], w[1]), pk_max_u16(w[2], w[3])));
       }
       out[2 * mb + c] = v;
     }
