@@ -63,13 +63,13 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
+  st.lane = threadIdx.x & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef DFN_TIMING
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_pro = 0;
   if (a.timing && blockIdx.x == 7) st.trace = a.timing + 8192 * 4 + st.wave * 192;  // after the per-wave totals
 #endif
-  st.lane = threadIdx.x & 63;
-  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = st.lane & 31, h = st.lane >> 5;
   const long long n_pts = (long long)a.n_rays * a.n_samples;
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
@@ -127,13 +127,13 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   st.t_sync = st.t_wait = 0;
   st.trace = nullptr;
   st.n_trace = 0;
+  st.lane = threadIdx.x & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef DFN_TIMING
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_pro = 0;
   if (a.timing && blockIdx.x == 7) st.trace = a.timing + 8192 * 4 + st.wave * 192;  // after the per-wave totals
 #endif
-  st.lane = threadIdx.x & 63;
-  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = st.lane & 31, h = st.lane >> 5;
   const long long n_pts = (long long)a.n_rays * a.n_samples;
   const long long n_tiles = (n_pts + PPT - 1) / PPT;
