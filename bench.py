@@ -196,7 +196,7 @@ def timed_render(E, lib, precision, poses, hist, rgbs, disps, acc, K, Wm, world=
     for k in range(Wm):
         step(k)
     if ddist.active():  # warm the collective too
-        ddist.gather_frames(rgbs[:world], world)
+        ddist.gather_frames(rgbs[:1], world)
     torch.cuda.synchronize()
     ddist.barrier()
     lib.dfn_profile_enable(1)
