@@ -369,15 +369,11 @@ DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&ou
 // chunks CIN, CIN+1 of Bin and is converted during this layer's chunks 0..CIN-1 (before they are read).
 // COUT: leave this layer's last M-block in `carry` for the next layer instead of converting it here.
 // NOBIAS: the unit's bias fragments are all zero (backward layers): no bias reads, the first MFMA starts from a zero C operand.
-// xfn(mb, kc): extra vector work issued after the MFMAs of chunk kc of M-block mb (compile-time arguments after unrolling) — the
-// skip layer's positional encoding rides through layer 4 this way, a few instructions per chunk, instead of standing as a block of
-// ~2 000 cycles between layers 4 and 5 where all eight waves run it at once and the matrix pipe idles.
-struct NoChunkWork { DFN_DEV void operator()(int, int) const {} };
 template <class P, int UMB, bool PIPE, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS, bool NEWUNIT,
-          int CIN, bool CIN_RELU, bool COUT, bool NOBIAS = false, class XFn = NoChunkWork>
+          int CIN, bool CIN_RELU, bool COUT, bool NOBIAS = false>
 DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][KC],
                    typename FragOf<P>::type (&Bout)[NB][(MB ? MB : 1) * chunks_of<P>(16)],
-                   f32x16 (&head)[NB], const float* const (&raybias)[NB], f32x16 (&carry)[NB], XFn&& xfn = XFn()) {
+                   f32x16 (&head)[NB], const float* const (&raybias)[NB], f32x16 (&carry)[NB]) {
   using F = typename FragOf<P>::type;
   constexpr int TOT = MB + (EXTRA ? 1 : 0);
   constexpr int PF = P::kSplit ? 2 : (P::kSlotsPerChunk == 8 ? DFN_PF : 4);  // fragments in flight
@@ -472,7 +468,6 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
               if (piece < 8 * NB) store_hidden_piece<P, RELU>(pend[piece >> 3], Bout[piece >> 3], mb - 1, piece & 7, pscale, st.rmax);
             }
           }
-          xfn(mb, kc);
           __builtin_amdgcn_sched_barrier(0);
         }
         bias = bias_next;
@@ -581,50 +576,10 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
   layer<P, UMB, PIPE, NB, PC, MBW, true, false, false, true, -1, true, CY>(st, smem, pe, a, nohead, norb, carry);
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
-#ifdef DFN_ABL_NOPERIDE
-  constexpr bool PE_RIDES = false;
-#else
-  constexpr bool PE_RIDES = PIPE && P::kSplit && W == kWidth;   // the skip layer's encoding is produced DURING layer 4 (see layer(): xfn)
-#endif
-  if constexpr (PE_RIDES) {
-    float x2[NB][3];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        x2[nb][c] = x[nb][c];
-        asm volatile("" : "+v"(x2[nb][c]));  // opaque copy: stops the compiler from CSE-ing the two encodings
-      }
-    // work item t = 0..14: (coordinate t / 5, octave t % 5) of every point block, t = 15: the raw coordinates; one item every
-    // second chunk of layer 4's 4 x 8 chunks
-    auto pe_item = [&](int mb, int kc) {
-      const int ch = mb * HC + kc;
-      if (ch & 1) return;
-      const int t = ch >> 1;
-      if (t > 15) return;
-      const float base = h ? 32.f : 1.f;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        if (t < 15) {
-          const int c = t / 5, k = t % 5;
-          float uh, ul, sn, cs;
-          rev_split(x2[nb][c], uh, ul);
-          rev_sincos(uh, ul, base * float(1 << k), sn, cs);
-          set_slot<P>(pe[nb], 6 * k + c, sn);
-          set_slot<P>(pe[nb], 6 * k + 3 + c, cs);
-        } else {
-          set_slot<P>(pe[nb], 30, h ? x2[nb][2] : x2[nb][0]);
-          set_slot<P>(pe[nb], 31, h ? 0.f : x2[nb][1]);
-        }
-      }
-    };
-    layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry, pe_item);
-  } else {
-    layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
-  }
+  layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
   {
     F cat[NB][PC + HC];
-    if constexpr (P::kSlotsPerChunk == 8 && (!PIPE || P::kSplit) && !PE_RIDES) {  // recompute: cheaper than 32 VGPRs live across 4 layers
+    if constexpr (P::kSlotsPerChunk == 8 && (!PIPE || P::kSplit)) {  // recompute: cheaper than 32 VGPRs live across 4 layers
       float x2[NB][3];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
