@@ -195,8 +195,8 @@ def timed_render(E, lib, precision, poses, hist, rgbs, disps, acc, K, Wm, world=
 
     for k in range(Wm):
         step(k)
-    if ddist.active():  # warm the collective too
-        ddist.gather_frames(rgbs[:1], world)
+    if ddist.active() and gather is not None:  # warm the collective too: communicator set-up AND the root's receive buffers (the
+        gather()                               # caching allocator then serves the timed gather without a fresh hipMalloc)
     torch.cuda.synchronize()
     ddist.barrier()
     lib.dfn_profile_enable(1)
@@ -204,7 +204,7 @@ def timed_render(E, lib, precision, poses, hist, rgbs, disps, acc, K, Wm, world=
     t0 = time.perf_counter()
     for k in range(K):
         step(k)
-    if ddist.active():
+    if ddist.active() and gather is not None:
         gather()
     torch.cuda.synchronize()
     ddist.barrier()
