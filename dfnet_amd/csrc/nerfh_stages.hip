@@ -17,6 +17,8 @@
 
 namespace dfn {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 static inline int grid_for(size_t n, int block, int cap = 256 * 8) {
   size_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -360,7 +362,10 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, size_t n, 
 // sigma [R,Nc] -> z_fine [R,Nc+Ni]: coarse weights over the linspace depths, z_mid bins,
 // sample_pdf(det) on the interior weights, then an exact sort of cat([z, z_samples]) (fix-up passes +
 // rank merge of two sorted lists; ties: coarse depth first, so the result is always a permutation).
-__global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ sigma, size_t n_rays, int Nc, int Ni,
+#ifndef DFN_SF_WAVES
+#define DFN_SF_WAVES 8
+#endif
+__global__ __launch_bounds__(256, DFN_SF_WAVES) void sample_fine_kernel(const float* __restrict__ sigma, size_t n_rays, int Nc, int Ni,
                                                           float near, float far, float* __restrict__ z_fine,
                                                           float* __restrict__ weights_out, float* __restrict__ zs_out, int lindisp) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -467,20 +472,33 @@ __global__ __launch_bounds__(256) void composite_fine_kernel(const float* __rest
                                                              float* __restrict__ rgb, float* __restrict__ disp,
                                                              float* __restrict__ acc, float* __restrict__ depth,
                                                              float* __restrict__ weights, float* __restrict__ beta) {
+  extern __shared__ __attribute__((aligned(16))) float craw[];   // per wave: one ray's raw [Nf][9] (when staged)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool static_depth = (flags & 1) && (flags & 2);  // test_time && static_only
   const bool white = flags & 4;
+  // A lane owns SPL consecutive samples = 9 SPL floats at a stride of 36 SPL bytes across lanes: read straight from HBM that is 27
+  // four-byte loads per lane, each touching 64 different lines (2.4 TB/s).  The ray's 9 Nf floats are therefore staged through LDS
+  // with 16-byte coalesced loads (a lane stride of 9 SPL floats is odd for SPL = 1, 3: conflict-free reads).
+  const bool staged = (flags & 8) != 0;   // the launcher's decision: 16-byte alignment and the staged rays fit the default dynamic LDS
+  float* sr = craw + size_t(wave) * Nf * 9;
   for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < n_rays; ray += size_t(gridDim.x) * 4) {
     const float* rr = raw + ray * size_t(Nf) * 9;
     const float* zr = z + ray * size_t(Nf);
     float v[SPL][9], zz[SPL + 1];
+    if (staged) {
+      const f32x4_t* src = reinterpret_cast<const f32x4_t*>(rr);
+      f32x4_t* dst = reinterpret_cast<f32x4_t*>(sr);
+      for (int i = lane; i < Nf * 9 / 4; i += 64) dst[i] = src[i];
+      wave_sync();
+    }
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
       const int i = lane * SPL + k;
       zz[k] = i < Nf ? zr[i] : 0.f;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) v[k][c] = i < Nf ? rr[size_t(i) * 9 + c] : 0.f;
+      for (int c = 0; c < 9; ++c) v[k][c] = i < Nf ? (staged ? sr[i * 9 + c] : rr[size_t(i) * 9 + c]) : 0.f;
     }
+    if (staged) wave_sync();   // the next ray's staging overwrites the buffer
     zz[SPL] = __shfl_down(zz[0], 1, 64);
     float a_s[SPL], a_t[SPL], a_j[SPL];
     float pj = 1.f, ps = 1.f;
@@ -535,8 +553,11 @@ hipError_t launch_composite_fine(const float* raw, const float* z, size_t n_rays
   if (!n_rays) return hipSuccess;
   const int spl = (Nf + 63) / 64;
   const dim3 grid(grid_for((n_rays + 3) / 4, 1, 256 * 16)), block(256);
-#define DFN_COMP(S)                                                                                              \
-  hipLaunchKernelGGL(composite_fine_kernel<S>, grid, block, 0, stream, raw, z, n_rays, Nf, beta_min, flags, rgb, \
+  size_t lds = size_t(4) * Nf * 9 * sizeof(float);   // the four waves' staged rays
+  if ((Nf & 3) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0 && lds <= 64 * 1024) flags |= 8;
+  else lds = 0;
+#define DFN_COMP(S)                                                                                                \
+  hipLaunchKernelGGL(composite_fine_kernel<S>, grid, block, lds, stream, raw, z, n_rays, Nf, beta_min, flags, rgb, \
                      disp, acc, depth, weights, beta)
   if (spl <= 1) DFN_COMP(1);
   else if (spl == 2) DFN_COMP(2);
