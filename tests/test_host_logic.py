@@ -397,3 +397,30 @@ def test_nerfw_loss_module_matches_reference_golden(tag):
     col = losses.loss_dict['color'](coef=1)(inputs, T(g13["target"]))
     ref = torch.nn.functional.mse_loss(inputs['rgb_coarse'], T(g13["target"])) + torch.nn.functional.mse_loss(inputs['rgb_fine'], T(g13["target"]))
     assert abs(float(col) - float(ref)) < 1e-7
+
+
+def test_render_path_png_job_numbers_by_global_frame_index(tmp_path):
+    """The PNG job of one back-end batch (dfnet_amd.rendering._write_frames, run on a pool thread by every rank for its own frame
+    block): file names carry the GLOBAL frame index (rendering.py:438-452), one ground-truth image may serve every frame."""
+    from PIL import Image
+    from dfnet_amd import rendering
+
+    class Ev:
+        def __init__(self): self.waited = False
+        def synchronize(self): self.waited = True
+
+    rng = np.random.default_rng(0)
+    rgb8 = torch.from_numpy(rng.integers(0, 256, (3, 5, 7, 3), dtype=np.uint8))
+    disp8 = torch.from_numpy(rng.integers(0, 256, (3, 5, 7), dtype=np.uint8))
+    gt_one = torch.from_numpy(rng.integers(0, 256, (5, 7, 3), dtype=np.uint8))
+    ev = Ev()
+    rendering._write_frames(ev, [rgb8, disp8, gt_one], str(tmp_path), 125)
+    assert ev.waited
+    assert sorted(os.listdir(tmp_path)) == sorted(f"{i:03d}{s}.png" for i in (125, 126, 127) for s in ("", "_GT", "_disp"))
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "126.png")), rgb8[1].numpy())
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "127_disp.png")), disp8[2].numpy())
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "125_GT.png")), gt_one.numpy())
+    # the options table carries this implementation's additions with the reference-precision defaults
+    from dfnet_amd import options
+    ns = options.nerf_parser().parse_known_args([])[0]
+    assert ns.precision == "f16x3" and ns.coarse_precision == "f16"
