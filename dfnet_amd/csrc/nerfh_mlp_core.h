@@ -353,6 +353,39 @@ DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&ou
   }
 }
 
+// The split-f16 conversion piece in three parts, so that a K-chunk can place them BETWEEN its three dependent MFMAs (A after the
+// first, B after the second, C after the third) instead of as one block behind them: the parts of store_hidden_piece<PrecX3>.
+struct X3Piece {
+  uint32_t hb, lb;
+  float t0, t1;
+  template <bool RELU>
+  DFN_DEV void A(const f32x16& acc, int i, float oscale) {
+    const int c = i >> 2, j = (i & 3) * 2;
+    if (RELU)
+      asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4\n\tv_max_f32 %0, %0, 0\n\tv_max_f32 %1, %1, 0"
+                   : "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]), "v"(oscale));
+    else
+      asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]), "v"(oscale));
+  }
+  DFN_DEV void B() {
+    asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2\n\t"
+                 "v_fma_mix_f32 %1, %0, -1.0, %1 op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                 : "=&v"(hb), "+v"(t0), "+v"(t1));
+  }
+  template <bool RELU, int OC>
+  DFN_DEV void C(half8x2 (&out)[OC], int mb, int i, uint32_t& rmax) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const int c = i >> 2, j = (i & 3) * 2;
+    asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(lb) : "v"(t0), "v"(t1));
+    if (RELU) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(rmax) : "v"(hb));
+    else range_track(rmax, hb, false);
+    const half2v hv = __builtin_bit_cast(half2v, hb), lv = __builtin_bit_cast(half2v, lb);
+    out[2 * mb + c].hi[j] = hv[0]; out[2 * mb + c].hi[j + 1] = hv[1];
+    out[2 * mb + c].lo[j] = lv[0]; out[2 * mb + c].lo[j + 1] = lv[1];
+  }
+};
+
 // A layer whose MB output M-blocks feed the next layer, plus (EXTRA) one trailing head M-block
 // whose raw accumulators go back to the caller.  Weights arrive in staging units of UMB M-blocks;
 // NEWUNIT = false continues inside the unit opened by the previous layer (small layers are packed
@@ -448,6 +481,45 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
           if (t + PF < nt) a[t % PF] = DFN_AFRAG(t + PF);
           if (kc == (PIPE ? KC / 2 : 0) && !RAYBIAS && !NOBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
           __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this chunk's MFMAs (hipcc otherwise sinks it to its use)
+#ifndef DFN_X3_NOSPREAD
+          if constexpr (P::kSplit && PIPE && NB == 1) {
+            // split-f16: the conversion pieces of this chunk go BETWEEN its three dependent MFMAs, a third each (the block form
+            // behind them measured 46.5 against 42.7 cycles per MFMA in tools/ubench/x3loop.hip)
+            constexpr int PPKI_ = (CIN > 0) ? (8 * NB + CIN - 1) / CIN : 1, PPK_ = (8 * NB + KC - 1) / KC;
+            constexpr int NPMAX = PPKI_ > PPK_ ? PPKI_ : PPK_;
+            const bool from_carry = CIN > 0 && mb == 0 && kc < CIN, from_pend = mb >= 1;
+            const int np = from_carry ? PPKI_ : (from_pend ? PPK_ : 0), base = kc * np;
+            X3Piece pc[NPMAX];
+            f32x16 c0 = (kc == 0) ? (RAYBIAS ? acc[0] : bias) : acc[0];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, Bin[0][kc].hi, c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NPMAX; ++q)
+              if (q < np && base + q < 8) {
+                if (from_carry) pc[q].template A<CIN_RELU>(carry[0], base + q, pscale);
+                else pc[q].template A<RELU>(pend[0], base + q, pscale);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, Bin[0][kc].lo, c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NPMAX; ++q)
+              if (q < np && base + q < 8) pc[q].B();
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.lo, Bin[0][kc].hi, c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NPMAX; ++q)
+              if (q < np && base + q < 8) {
+                if (from_carry) pc[q].template C<CIN_RELU>(Bin[0], CIN / 2, base + q, st.rmax);
+                else pc[q].template C<RELU>(Bout[0], mb - 1, base + q, st.rmax);
+              }
+            acc[0] = c0;
+            if (from_carry && kc == CIN - 1) asm volatile("s_nop 3");
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
+#endif
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             if (kc == 0) acc[nb] = mfma<P>(cur, Bin[nb][0], RAYBIAS ? acc[nb] : bias);
