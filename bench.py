@@ -184,6 +184,28 @@ def read_profile(lib):
     return out
 
 
+def sustained_mfma(lib, stream=None, seconds=0.4):
+    """What the matrix pipe of THIS box sustains (dfn_probe_mfma_rate: nothing but independent dense-f16 MFMAs on every SIMD): with
+    zero operands the nominal peak, with random operands the rate once power management has settled the clock.  The MLP kernels'
+    MFMA work (x3 for split-f16: three f16 MFMAs per product) is priced against the random-operand figure as `frac_of_sustained`."""
+    from dfnet_amd import _lib
+    out = {}
+    for key, rnd in (("zero_operands_TFLOPs", 0), ("random_operands_TFLOPs", 1)):
+        tf = ctypes.c_double()
+        _lib.check(lib.dfn_probe_mfma_rate(rnd, float(seconds), ctypes.byref(tf), None), "dfn_probe_mfma_rate")
+        out[key] = tf.value
+    out["note"] = ("dense f16 v_mfma_f32_32x32x16_f16 back to back on all SIMDs for %.1f s each, measured in this run; roofline.peak is the "
+                   "nominal 2.4 GHz figure, which this part reaches only with operands that do not toggle" % seconds)
+    return out
+
+
+def add_sustained(roof, sus, precision):
+    """frac_of_sustained: the kernel's f16-MFMA work rate / the random-operand MFMA rate of this box (f32 kernels: not power-limited, skipped)."""
+    if precision in ("f16", "f16x3") and sus.get("random_operands_TFLOPs"):
+        mult = 3.0 if precision == "f16x3" else 1.0
+        roof["frac_of_sustained_mfma"] = roof["achieved"] * mult / sus["random_operands_TFLOPs"]
+
+
 def timed_render(E, lib, precision, poses, hist, rgbs, disps, acc, K, Wm, world=1, gather=None):
     """Wm untimed + K timed frames; returns (seconds for the K frames, max over ranks; per-kernel HIP-event averages)."""
     from dfnet_amd import dist as ddist
@@ -710,6 +732,9 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_extras:
+            sus = sustained_mfma(lib)
+            roof["sustained_mfma"] = sus
+            add_sustained(roof, sus, args.precision)
             line["hbm"] = hbm_records(prof, K, E, dev)
             ref_pack = None
             if args.cpu_sample > 0:
@@ -727,6 +752,7 @@ def main():
                 precs[prec] = {"value": v2, "unit": "rays/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2, "warmup": w2,
                                "arithmetic": PREC_TEXT[prec], "roofline": mlp_roofline(prof2, k2, prec, v2)}
                 precs[prec]["roofline"]["traffic"] = pmc_traffic("nerfh_fine_kernel", prec)
+                add_sustained(precs[prec]["roofline"], sus, prec)
                 if ref_pack is not None:
                     precs[prec]["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], prec, dev)
             # split-f16 fine network with the coarse network in f16 (DFN_RENDER_COARSE_F16): the coarse pass only places the importance
@@ -742,6 +768,7 @@ def main():
                         "arithmetic": "fine network split-f16 (fp32-grade), coarse network (sample placement only) f16 MFMA inputs",
                         "roofline": mlp_roofline(prof2, k2, "f16x3", v2)}
                     precs["f16x3_fine_f16_coarse"]["roofline"].pop("whole_path_mfma_frac", None)   # two peaks on this path: not defined
+                    add_sustained(precs["f16x3_fine_f16_coarse"]["roofline"], sus, "f16x3")
                     if ref_pack is not None:
                         precs["f16x3_fine_f16_coarse"]["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], "f16x3", dev)
                 finally:
