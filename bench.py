@@ -199,6 +199,15 @@ def sustained_mfma(lib, stream=None, seconds=0.4):
     return out
 
 
+SUSTAINED = {}   # filled by main() from sustained_mfma(): the secondary records price their f16 MFMA work against it too
+
+
+def of_sustained(f16_mfma_tflops):
+    """f16-MFMA TFLOP/s of a workload / the random-operand MFMA rate measured in this run (None before the probe ran)."""
+    r = SUSTAINED.get("random_operands_TFLOPs")
+    return f16_mfma_tflops / r if r else None
+
+
 def add_sustained(roof, sus, precision):
     """frac_of_sustained: the kernel's f16-MFMA work rate / the random-operand MFMA rate of this box (f32 kernels: not power-limited, skipped)."""
     if precision in ("f16", "f16x3") and sus.get("random_operands_TFLOPs"):
@@ -342,6 +351,8 @@ def secondary_dfnet(dev):
         out["precisions"][prec] = {"ms_per_image": dt * 1e3, "algorithmic_TFLOPs": 325.3e9 / dt / 1e12,
                                    "mfma_frac": 325.3e9 * mf / dt / 1e12 / (157.3 if prec == "f32" else 2500.0),
                                    "arithmetic": PREC_TEXT[prec]}
+        if prec != "f32":
+            out["precisions"][prec]["mfma_frac_of_sustained"] = of_sustained(325.3e9 * mf / dt / 1e12)
     # the whole stream, default arithmetic
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -350,7 +361,8 @@ def secondary_dfnet(dev):
     torch.cuda.synchronize()
     dts = time.perf_counter() - t0
     out["stream_256_frames_f16x3"] = {"seconds": dts, "frames_per_s": NF / dts, "ms_per_image": dts / NF * 1e3,
-                                      "mfma_frac": 325.3e9 * 3 * NF / dts / 1e12 / 2500.0}
+                                      "mfma_frac": 325.3e9 * 3 * NF / dts / 1e12 / 2500.0,
+                                      "mfma_frac_of_sustained": of_sustained(325.3e9 * 3 * NF / dts / 1e12)}
     # the reference's config names "featurenet_batch_size=4 # batch size, 4 or 8" (config_dfnet.txt:17): the other one
     t0 = time.perf_counter()
     for k in range(0, 64, 8):
@@ -733,6 +745,7 @@ def main():
         }
         if world == 1 and not args.no_extras:
             sus = sustained_mfma(lib)
+            SUSTAINED.update(sus)
             roof["sustained_mfma"] = sus
             add_sustained(roof, sus, args.precision)
             line["hbm"] = hbm_records(prof, K, E, dev)
