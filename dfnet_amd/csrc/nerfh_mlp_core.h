@@ -490,24 +490,34 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             const bool from_carry = CIN > 0 && mb == 0 && kc < CIN, from_pend = mb >= 1;
             const int np = from_carry ? PPKI_ : (from_pend ? PPK_ : 0), base = kc * np;
             X3Piece pc[NPMAX];
+            // kc == 0: the accumulators the pieces read (pend / carry) were written by the MFMA issued just before this chunk; an
+            // XDL result is not interlocked against VALU reads from inline asm, so the first chunk keeps the block form -- all three
+            // parts behind its third MFMA, >= 3 MFMA issues after the producer (read one issue later, the last correction product
+            // of some results was missing: 1e-6 instead of 2.4e-7 against exact fp32).
+            const bool late = kc == 0;
             f32x16 c0 = (kc == 0) ? (RAYBIAS ? acc[0] : bias) : acc[0];
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, Bin[0][kc].hi, c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NPMAX; ++q)
-              if (q < np && base + q < 8) {
-                if (from_carry) pc[q].template A<CIN_RELU>(carry[0], base + q, pscale);
-                else pc[q].template A<RELU>(pend[0], base + q, pscale);
+#define DFN_X3_PARTS_A \
+            _Pragma("unroll") for (int q = 0; q < NPMAX; ++q) \
+              if (q < np && base + q < 8) { \
+                if (from_carry) pc[q].template A<CIN_RELU>(carry[0], base + q, pscale); \
+                else pc[q].template A<RELU>(pend[0], base + q, pscale); \
               }
+#define DFN_X3_PARTS_B \
+            _Pragma("unroll") for (int q = 0; q < NPMAX; ++q) \
+              if (q < np && base + q < 8) pc[q].B();
+            if (!late) { DFN_X3_PARTS_A }
             __builtin_amdgcn_sched_barrier(0);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, Bin[0][kc].lo, c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NPMAX; ++q)
-              if (q < np && base + q < 8) pc[q].B();
+            if (!late) { DFN_X3_PARTS_B }
             __builtin_amdgcn_sched_barrier(0);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.lo, Bin[0][kc].hi, c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (late) { DFN_X3_PARTS_A DFN_X3_PARTS_B }
+#undef DFN_X3_PARTS_A
+#undef DFN_X3_PARTS_B
 #pragma unroll
             for (int q = 0; q < NPMAX; ++q)
               if (q < np && base + q < 8) {

@@ -397,3 +397,19 @@ def test_render_nerfw_imgs_helper(scene):
     a, b = torch.rand(8, 5, 6), torch.rand(8, 5, 6)
     want = 1 - torch.nn.functional.cosine_similarity(a.reshape(8, -1), b.reshape(8, -1), dim=1, eps=1e-6).mean()
     assert abs(float(fm.feature_loss(a, b)) - float(want)) < 1e-7
+
+
+def test_split_f16_raw_outputs_are_fp32_grade():
+    """The split-f16 fine network against the exact-fp32 MFMA kernel on the SAME samples (bench.py's fp32_grade_check): 2.4e-7 of a
+    channel's range when every product carries its two correction terms.  Tight on purpose: a conversion piece that read an MFMA
+    result one issue too early (no interlock for inline-asm reads of an XDL result) cost the last correction product of a few
+    values — 1.0e-6 here, invisible at the 2e-5 oracle tolerance of the render tests."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine(precision="f16x3").load_numpy(cw, fw, ea, et)
+    rec = bench.fp32_grade_check(E, torch.device("cuda:0"), n=2048)
+    assert rec["raw_max_rel_f16x3_vs_f32"] < 5e-7, rec
+    assert rec["raw_rms_rel_f16x3_vs_f32"] < 1.5e-7, rec
