@@ -715,8 +715,7 @@ def main():
     acc = torch.empty(H, W, device=dev)
 
     def gather():
-        ddist.gather_frames(rgbs, n_frames)
-        ddist.gather_frames(disps, n_frames)
+        ddist.gather_frames_packed([rgbs, disps], n_frames)   # one collective: rgb + disp side by side per frame
 
     dt, prof = timed_render(E, lib, args.precision, poses, hist, rgbs, disps, acc, K, Wm, world, gather)
 

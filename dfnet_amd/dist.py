@@ -1,6 +1,6 @@
 """Multi-GPU sharding of a render_path batch: one process per GPU, NeRF-H weights replicated,
-frames block-partitioned over ranks, ONE gather of rgb+disp at the end (RCCL over xGMI when the
-backend is "nccl"; "gloo" on CPU for tests).
+frames block-partitioned over ranks, ONE gather of rgb+disp(+per-frame errors) at the end (gather_frames_packed: RCCL over
+xGMI when the backend is "nccl"; "gloo" on CPU for tests).
 
 Replaces the serial `for i, c2w in enumerate(render_poses)` loop of
 /root/reference/script/models/rendering.py:420-452 — the reference has no collective at all.
@@ -75,6 +75,25 @@ def gather_frames(local, n_frames, dst=0):
     if rank != dst:
         return None
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
+
+
+def gather_frames_packed(tensors, n_frames, dst=0):
+    """ONE collective for several per-frame float32 stacks of the same local length (rgb [n,H,W,3], disp [n,H,W], per-frame
+    errors [n], ...): each frame's pieces are laid side by side in one [n_local, floats-per-frame] buffer, gathered once
+    (gather_frames), and split again on rank `dst`.  Returns the list of [n_frames, ...] tensors on rank dst, a list of None
+    elsewhere.  world == 1: the inputs themselves."""
+    tensors = list(tensors)
+    if not active():
+        return tensors
+    n_loc = tensors[0].shape[0]
+    widths = [int(t[0].numel()) if n_loc else int(torch.Size(t.shape[1:]).numel()) for t in tensors]
+    packed = torch.cat([t.reshape(n_loc, w).to(torch.float32) for t, w in zip(tensors, widths)], 1) if n_loc else \
+        tensors[0].new_zeros((0, sum(widths)), dtype=torch.float32)
+    out = gather_frames(packed, n_frames, dst)
+    if out is None:
+        return [None] * len(tensors)
+    parts = torch.split(out, widths, 1)
+    return [p.reshape((n_frames,) + tuple(t.shape[1:])) for p, t in zip(parts, tensors)]
 
 
 def data_parallel_rounds(n_items, rank, world):

@@ -401,9 +401,9 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
     torch.cuda.synchronize()
     t_render = time.time() - t0
     _engine_of(render_kwargs).check_range()   # loud, not clamped or non-finite frames, if a narrow arithmetic mode overflowed
-    all_rgb = ddist.gather_frames(rgbs, N)
-    all_disp = ddist.gather_frames(disps, N)
-    all_mse = ddist.gather_frames(mse, N) if gt_imgs is not None else None
+    all_rgb, all_disp, all_mse = ddist.gather_frames_packed([rgbs, disps, mse], N)   # the path's ONE collective
+    if gt_imgs is None:
+        all_mse = None
     tw = time.time()
     for jb in jobs:
         jb.result()   # re-raises a failed write

@@ -111,12 +111,19 @@ local = torch.stack([torch.full((3, 4, 3), float(i)) for i in range(lo, hi)]) if
 out = ddist.gather_frames(local, n_frames)
 t = ddist.max_over_ranks(float(rank + 1), torch.device("cpu"))
 assert t == float(world)
+# the packed form: rgb-like, disp-like and per-frame scalars in ONE collective
+n_loc = hi - lo
+disp = torch.stack([torch.full((3, 4), 100.0 + i) for i in range(lo, hi)]) if n_loc else torch.zeros(0, 3, 4)
+err = torch.tensor([1000.0 + i for i in range(lo, hi)])
+p_rgb, p_disp, p_err = ddist.gather_frames_packed([local, disp, err], n_frames)
 if rank == 0:
     assert out.shape == (n_frames, 3, 4, 3), out.shape
     assert all(float(out[i, 0, 0, 0]) == i and float(out[i].min()) == i for i in range(n_frames))
+    assert torch.equal(p_rgb, out) and p_disp.shape == (n_frames, 3, 4) and p_err.shape == (n_frames,)
+    assert all(float(p_disp[i].min()) == 100.0 + i == float(p_disp[i].max()) and float(p_err[i]) == 1000.0 + i for i in range(n_frames))
     print("GATHER_OK", n_frames)
 else:
-    assert out is None
+    assert out is None and p_rgb is None and p_disp is None and p_err is None
 ddist.barrier()
 torch.distributed.destroy_process_group()
 '''
