@@ -99,6 +99,8 @@ DFN_DEV void stage_issue_at(const Stager& st, char* smem, uint32_t off, uint32_t
   for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) lds_dma_b128(st.blob + st.lane * 16, smem + lds_off + p);
 #elif defined(DFN_ABL_DMA_HALF)  // ablation: every second piece only
   for (uint32_t p = st.wave * kPiece; p < size; p += 2 * st.dma_waves * kPiece) lds_dma_b128(src + p, smem + lds_off + p);
+#elif defined(DFN_ABL_ADD_DMA)  // ADDITIVE ablation (results stay correct): every piece streamed twice -> energy share of the weight stream
+  for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) { lds_dma_b128(src + p, smem + lds_off + p); lds_dma_b128(src + p, smem + lds_off + p); }
 #else
   for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) lds_dma_b128(src + p, smem + lds_off + p);
 #endif
@@ -372,6 +374,10 @@ struct X3Piece {
                  "v_fma_mix_f32 %1, %0, -1.0, %1 op_sel_hi:[1,0,0]\n\t"
                  "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
                  : "=&v"(hb), "+v"(t0), "+v"(t1));
+#ifdef DFN_ABL_ADD_VALU  // ADDITIVE ablation: four more vector instructions per conversion piece (9 -> 13), values untouched
+    float dummy;
+    asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %0, %1\n\tv_mov_b32 %0, %2" : "=&v"(dummy) : "v"(t0), "v"(t1));
+#endif
   }
   template <bool RELU, int OC>
   DFN_DEV void C(half8x2 (&out)[OC], int mb, int i, uint32_t& rmax) {
@@ -495,6 +501,12 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             // parts behind its third MFMA, >= 3 MFMA issues after the producer (read one issue later, the last correction product
             // of some results was missing: 1e-6 instead of 2.4e-7 against exact fp32).
             const bool late = kc == 0;
+#ifdef DFN_ABL_ADD_LDS  // ADDITIVE ablation: one more 16-byte fragment read per lane and chunk (2 -> 3), result unused
+            {
+              const half8 extra = *reinterpret_cast<const volatile half8*>(wl + t * FB);
+              asm volatile("" ::"v"(extra));
+            }
+#endif
             f32x16 c0 = (kc == 0) ? (RAYBIAS ? acc[0] : bias) : acc[0];
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, Bin[0][kc].hi, c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
