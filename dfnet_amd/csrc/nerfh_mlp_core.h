@@ -448,6 +448,9 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
     const char* wl = smem + ub + st.lane * (P::kSplit ? 16 : P::kLaneBytes);
     const char* bl = smem + ub + nmb * KC * FB + h * 64;
     F a[PF];
+#ifdef DFN_ABL_ADD_LDS
+    half8 abl_extra = {};
+#endif
 #ifdef DFN_ABL_NOLDS
 #define DFN_AFRAG(t) a0_abl
     const F a0_abl = *reinterpret_cast<const F*>(wl);
@@ -501,10 +504,10 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             // parts behind its third MFMA, >= 3 MFMA issues after the producer (read one issue later, the last correction product
             // of some results was missing: 1e-6 instead of 2.4e-7 against exact fp32).
             const bool late = kc == 0;
-#ifdef DFN_ABL_ADD_LDS  // ADDITIVE ablation: one more 16-byte fragment read per lane and chunk (2 -> 3), result unused
-            {
-              const half8 extra = *reinterpret_cast<const volatile half8*>(wl + t * FB);
-              asm volatile("" ::"v"(extra));
+#ifdef DFN_ABL_ADD_LDS  // ADDITIVE ablation: one more 16-byte fragment read per lane and chunk (2 -> 3), result unused; consumed one
+            {                    // chunk later, like the real prefetches (consumed at once it measures the LDS LATENCY, not the port)
+              asm volatile("" ::"v"(abl_extra));
+              abl_extra = *reinterpret_cast<const half8*>(wl + t * FB);
             }
 #endif
             f32x16 c0 = (kc == 0) ? (RAYBIAS ? acc[0] : bias) : acc[0];
