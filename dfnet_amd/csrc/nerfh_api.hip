@@ -15,6 +15,7 @@
 
 #include "../../include/dfnet_hip.h"
 #include "dfn_common.h"
+#include "nerfh_fused_train.h"
 #include "nerfh_handle.h"
 #include "nerfh_kernels.h"
 #include "nerfh_layout.h"
@@ -127,6 +128,7 @@ static void free_packed(dfn_nerfh_s* h) {
 extern "C" int dfn_nerfh_destroy(dfn_nerfh_t h) {
   if (!h) return DFN_OK;
   free_packed(h);
+  dfn::fused::destroy_state(h);
   for (hipEvent_t e : h->side_ev) if (e) (void)hipEventDestroy(e);
   if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
   if (h->range_flag) (void)hipFree(h->range_flag);
@@ -406,6 +408,8 @@ int upload(const void* src, size_t bytes, void** dst) {
 
 }  // namespace
 
+__global__ void range_fetch_kernel(int* flag) { flag[1] = atomicExch(flag, 0); }
+
 extern "C" int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_render_options: null handle");
   if (flags & ~(DFN_RENDER_LINDISP | DFN_RENDER_COARSE_F16)) return set_error(DFN_ERR_UNSUPPORTED, "dfn_nerfh_set_render_options: unknown option bits 0x%x", flags);
@@ -417,8 +421,11 @@ extern "C" int dfn_nerfh_range_status(dfn_nerfh_t h, int* flags, void* stream) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_range_status: null handle");
   int v = 0;
   if (h->range_flag) {
+    // read-and-clear in ONE atomic exchange on the device: bits raised by kernels of another stream between a copy and a
+    // separate clear would be lost
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemcpyAsync(&v, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemsetAsync(h->range_flag, 0, sizeof(int), s) != hipSuccess ||
+    hipLaunchKernelGGL(range_fetch_kernel, dim3(1), dim3(1), 0, s, h->range_flag);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&v, h->range_flag + 1, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
       return set_error(DFN_ERR_HIP, "dfn_nerfh_range_status: reading the flag failed");
   }
@@ -437,6 +444,14 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
   for (const auto& kv : expected_shapes(h->desc))
     if (!h->params.count(kv.first)) return set_error(DFN_ERR_STATE, "dfn_nerfh_commit: parameter '%s' not set", kv.first.c_str());
   free_packed(h);
+  dfn::fused::destroy_state(h);   // its tables follow the handle's geometry and scales: rebuilt on the next training step
+  if (!h->range_flag) {   // range guard of the narrow arithmetic modes: two device ints (flag, fetch slot), cleared here
+    if (hipMalloc(reinterpret_cast<void**>(&h->range_flag), 2 * sizeof(int)) != hipSuccess) {
+      h->range_flag = nullptr;
+      return set_error(DFN_ERR_HIP, "dfn_nerfh_commit: allocating the range-guard flag failed");
+    }
+    if (hipMemset(h->range_flag, 0, 2 * sizeof(int)) != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_nerfh_commit: clearing the range-guard flag failed");
+  }
   {  // generic-width path: plain device copies in canonical order
     std::vector<float> all;
     std::vector<size_t> offs;
@@ -661,14 +676,9 @@ static int mlp_variant_128() {
   return v;
 }
 
-// The handle's range-guard flag (device int), allocated on first use.
-static int* range_flag_of(dfn_nerfh_t h) {
-  if (!h->range_flag) {
-    if (hipMalloc(reinterpret_cast<void**>(&h->range_flag), sizeof(int)) != hipSuccess) { h->range_flag = nullptr; return nullptr; }
-    (void)hipMemset(h->range_flag, 0, sizeof(int));
-  }
-  return h->range_flag;
-}
+// The handle's range-guard flag (device int): allocated and cleared by dfn_nerfh_commit, which fails loudly when it cannot be —
+// every kernel launch that carries the guard runs on a committed handle.
+static int* range_flag_of(dfn_nerfh_t h) { return h->range_flag; }
 
 static unsigned long long* g_timing_buf = nullptr;  // DFN_TIMING builds only (tools/gpu_timing.py)
 extern "C" void dfn_debug_set_timing_buffer(void* p) { g_timing_buf = static_cast<unsigned long long*>(p); }

@@ -1,0 +1,638 @@
+// nerfh_fused_api.hip — host side of the fused NeRF-H training step (netwidth 128): the unit / destination tables that tie the
+// master parameter tensors to the chain kernels' staging units and to the weight-gradient blocks, the workspace layout, and the
+// two passes dfn_nerfh_train_forward / dfn_nerfh_train_backward run when the handle is on the register-resident kernels
+// (nerfh_train_api.hip routes here; every other netwidth keeps the layer-by-layer path of nerfh_train.hip).
+//
+// Replaces (reference, /root/reference/script/): run_nerf.py:50-66, models/rendering.py:245-337 (render_rays, test_time=False),
+// models/nerfw.py:47-95,297-354.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/dfnet_hip.h"
+#include "dfn_common.h"
+#include "nerfh_fused_train.h"
+#include "nerfh_handle.h"
+#include "nerfh_kernels.h"
+#include "nerfh_layout.h"
+#include "nerfh_train.h"
+
+using namespace dfn;
+using namespace dfn::fused;
+using namespace dfn::train;
+
+#define CHECK_HIP(expr, what)                                                                   \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return set_error(DFN_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+// canonical parameter order (dfn_nerfh_train_param_name): coarse layers 0..11, fine layers 0..18, embeddings
+enum LayerIx { L1 = 0, L8 = 7, FIN = 8, DIR = 9, SIG = 10, RGB = 11, TE0 = 12, TE3 = 15, TSIG = 16, TRGB = 17, TBETA = 18 };
+constexpr int kCoarseLayers_ = 12, kFineLayers_ = 19;
+constexpr int kCoarseParams = 2 * kCoarseLayers_, kFineParams = 2 * kFineLayers_;
+using P = PrecX3;
+constexpr int UMB = 2;
+
+struct Geo { int na, nt, kd_c, kd_f, ld_dc, ld_df, ld_t; };
+inline int r4(int v) { return (v + 3) & ~3; }
+Geo geo_of(const dfn_nerfh_desc& d) {
+  Geo g{};
+  g.na = d.hist_bin * d.dim_a; g.nt = d.hist_bin * d.dim_t;
+  g.kd_c = kChDir; g.kd_f = kChDir + g.na;
+  g.ld_dc = r4(g.kd_c); g.ld_df = r4(g.kd_f); g.ld_t = r4(g.nt);
+  return g;
+}
+
+// ---- where an element of a staging unit / a weight-gradient block lives in the parameter tensors
+struct Row { int layer; int row; };   // LayerIx of the Linear, row of its weight (row < 0: none)
+int cols_of(int layer, bool fine, const Geo& g) {
+  switch (layer) {
+    case 0: return kChXyz;
+    case 4: return kWidth + kChXyz;
+    case DIR: return kWidth + (fine ? g.kd_f : g.kd_c);
+    case RGB: case TSIG: case TRGB: case TBETA: return kWidth / 2;
+    case TE0: return kWidth + g.nt;
+    case 13: case 14: case 15: return kWidth / 2;
+    default: return kWidth;   // xyz_encoding_2..4, 6..8, final, static_sigma
+  }
+}
+int rows_of(int layer) {
+  switch (layer) {
+    case DIR: case TE0: case 13: case 14: case 15: return kWidth / 2;
+    case SIG: case TSIG: case TBETA: return 1;
+    case RGB: case TRGB: return 3;
+    default: return kWidth;
+  }
+}
+int weight_param(bool fine, int layer) { return (fine ? kCoarseParams : 0) + 2 * layer; }
+int32_t enc(int param, int index) { return int32_t((param << 20) | index); }
+
+// forward layer `ly` (nerfh_layout.h: LayerId), M-block mb, row i of the block -> Linear + row (Packer::row_source)
+Row fwd_row(int ly, int mb, int i) {
+  const int row = 32 * mb + i;
+  if (ly >= LY_L1 && ly <= LY_L8) return {ly - LY_L1, row};
+  switch (ly) {
+    case LY_FIN: return mb < kWidth / 32 ? Row{FIN, row} : Row{SIG, i == 0 ? 0 : -1};
+    case LY_DIR: return {DIR, row};
+    case LY_RGB: return {RGB, i < 3 ? i : -1};
+    case LY_TE0: return {TE0, row};
+    case LY_TE1: return {13, row};
+    case LY_TE2: return {14, row};
+    case LY_TE3: return {15, row};
+    case LY_THEAD: return i < 3 ? Row{TRGB, i} : (i == 3 ? Row{TSIG, 0} : (i == 8 ? Row{TBETA, 0} : Row{TBETA, -1}));
+  }
+  return {0, -1};
+}
+int fwd_col(int ly, int hh, int s) {   // Packer::col_source
+  if (ly == LY_L1) return pe_xyz_feature(hh, s);
+  if (ly == LY_L5) return s < 32 ? pe_xyz_feature(hh, s) : kChXyz + hidden_feature(hh, s - 32);
+  return hidden_feature(hh, s);
+}
+
+// backward layers of the training chain (the transposed Linears; rows = INPUT features of the forward layer, contraction slots =
+// its OUTPUT features in C-fragment order).  TBW_CAT: fine [transient_encoding.0 ; dir_encoding.0]^T on the `final` columns, coarse
+// dir_encoding.0^T.  No layer-1 / encoding-column products: the rays carry no gradient in the optimisation step.
+enum TBwd { TBW_THEAD = 0, TBW_TE3, TBW_TE2, TBW_TE1, TBW_RGB, TBW_CAT, TBW_FIN, TBW_L8, TBW_L7, TBW_L6, TBW_L5, TBW_L4, TBW_L3, TBW_L2, TBW_COUNT };
+LayerShape tbwd_shape(int id, bool fine) {
+  if (id == TBW_THEAD || id == TBW_RGB) return {16, 2};
+  if (id <= TBW_TE1) return {32, 2};
+  if (id == TBW_CAT) return {fine ? 64 : 32, 4};
+  if (id == TBW_FIN) return {80, 4};
+  return {64, 4};
+}
+// (Linear, row, column) of the backward element at input feature k, slot (hh, s); row < 0: zero
+struct Elem3 { int layer, row, col; };
+Elem3 tbwd_elem(int id, bool fine, int k, int hh, int s) {
+  const int j = hidden_feature(hh, s);
+  switch (id) {
+    case TBW_THEAD: return j < 3 ? Elem3{TRGB, j, k} : (j == 3 ? Elem3{TSIG, 0, k} : (j == 8 ? Elem3{TBETA, 0, k} : Elem3{0, -1, 0}));
+    case TBW_TE3: return {15, j, k};
+    case TBW_TE2: return {14, j, k};
+    case TBW_TE1: return {13, j, k};
+    case TBW_RGB: return j < 3 ? Elem3{RGB, j, k} : Elem3{0, -1, 0};
+    case TBW_CAT:
+      if (!fine) return {DIR, j, k};
+      return s < 32 ? Elem3{TE0, hidden_feature(hh, s), k} : Elem3{DIR, hidden_feature(hh, s - 32), k};
+    case TBW_FIN:
+      if (s < 64) return {FIN, j, k};
+      return (s == 64 && hh == 0) ? Elem3{SIG, 0, k} : Elem3{0, -1, 0};
+    case TBW_L5: return {4, j, kChXyz + k};
+    default: return {8 - (id - TBW_L8) - 1, j, k};   // TBW_L8 -> xyz_encoding_8 (LayerIx 7) ... TBW_L2 -> LayerIx 1
+  }
+}
+
+struct BlobPlan {
+  std::vector<uint32_t> tab;        // (offset, bytes) per unit
+  std::vector<PackElem> welem, belem;
+  uint32_t bytes = 0;
+};
+BlobPlan plan_forward(bool fine, const Geo& g) {
+  BlobPlan bp;
+  const int seq_f[] = {LY_L1, LY_L2, LY_L3, LY_L4, LY_L5, LY_L6, LY_L7, LY_L8, LY_FIN, LY_DIR, LY_RGB, LY_TE0, LY_TE1, LY_TE2, LY_TE3, LY_THEAD};
+  const int nl = fine ? 16 : 11;
+  for (int li = 0; li < nl; ++li) {
+    const int ly = seq_f[li];
+    const LayerShape sh = layer_shape(ly);
+    const int KC = sh.slots / 8;
+    for (int u0 = 0; u0 < sh.mb; u0 += UMB) {
+      const int group = sh.mb - u0 < UMB ? sh.mb - u0 : UMB;
+      const uint32_t ub = unit_bytes<P>(sh.slots, group), off = bp.bytes;
+      bp.tab.push_back(off);
+      bp.tab.push_back(ub);
+      bp.bytes += ub;
+      for (int gi = 0; gi < group; ++gi) {
+        const int mb = u0 + gi;
+        for (int lane = 0; lane < 64; ++lane) {
+          const Row rw = fwd_row(ly, mb, lane & 31);
+          if (rw.row < 0 || rw.row >= rows_of(rw.layer)) continue;
+          const int cols = cols_of(rw.layer, fine, g);
+          for (int kc = 0; kc < KC; ++kc)
+            for (int jj = 0; jj < 8; ++jj) {
+              const int col = fwd_col(ly, lane >> 5, kc * 8 + jj);
+              if (col < 0 || col >= cols) continue;
+              bp.welem.push_back({off + uint32_t((gi * KC + kc) * 2048 + lane * 16 + jj * 2), enc(weight_param(fine, rw.layer), rw.row * cols + col)});
+            }
+        }
+        if (ly == LY_DIR || ly == LY_TE0) continue;   // these biases are folded into the per-ray table
+        for (int hh = 0; hh < 2; ++hh)
+          for (int r = 0; r < 16; ++r) {
+            const Row rw = fwd_row(ly, mb, mblock_row(hh, r));
+            if (rw.row < 0 || rw.row >= rows_of(rw.layer)) continue;
+            bp.belem.push_back({off + uint32_t(group * KC * 2048 + ((gi * 2 + hh) * 16 + r) * 4), enc(weight_param(fine, rw.layer) + 1, rw.row)});
+          }
+      }
+    }
+  }
+  return bp;
+}
+BlobPlan plan_backward(bool fine, const Geo& g) {
+  BlobPlan bp;
+  for (int id = fine ? TBW_THEAD : TBW_RGB; id < TBW_COUNT; ++id) {
+    const LayerShape sh = tbwd_shape(id, fine);
+    const int KC = sh.slots / 8;
+    for (int u0 = 0; u0 < sh.mb; u0 += UMB) {
+      const int group = sh.mb - u0 < UMB ? sh.mb - u0 : UMB;
+      const uint32_t ub = unit_bytes<P>(sh.slots, group), off = bp.bytes;
+      bp.tab.push_back(off);
+      bp.tab.push_back(ub);
+      bp.bytes += ub;
+      for (int gi = 0; gi < group; ++gi)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int kc = 0; kc < KC; ++kc)
+            for (int jj = 0; jj < 8; ++jj) {
+              const Elem3 e = tbwd_elem(id, fine, 32 * (u0 + gi) + (lane & 31), lane >> 5, kc * 8 + jj);
+              if (e.row < 0 || e.row >= rows_of(e.layer)) continue;
+              const int cols = cols_of(e.layer, fine, g);
+              if (e.col >= cols) continue;
+              bp.welem.push_back({off + uint32_t((gi * KC + kc) * 2048 + lane * 16 + jj * 2), enc(weight_param(fine, e.layer), e.row * cols + e.col)});
+            }
+    }
+  }
+  return bp;
+}
+
+// ---- weight-gradient jobs
+struct JobPlan { int garr, x0, x1; };
+const JobPlan kJobsFine[] = {{GA_L1, XA_PE, -1}, {GA_L2, XA_H1, -1}, {GA_L3, XA_H2, -1}, {GA_L4, XA_H3, -1}, {GA_L5, XA_PE, XA_H4},
+                             {GA_L6, XA_H5, -1}, {GA_L7, XA_H6, -1}, {GA_L8, XA_H7, -1}, {GA_CAT2, XA_H8, -1}, {GA_CAT, XA_FIN, -1},
+                             {GA_DRGB, XA_DE, -1}, {GA_T1, XA_T0, -1}, {GA_T2, XA_T1, -1}, {GA_T3, XA_T2, -1}, {GA_DTH, XA_T3, -1}};
+constexpr int kNumJobsFine = 15, kNumJobsCoarse = 11;
+// G-side slot (hh, s) of array `garr` -> Linear + row
+Row g_row(int garr, bool fine, int hh, int s) {
+  const int j = hidden_feature(hh, s & 31);   // feature inside a 64-wide (two M-block) vector
+  if (garr <= GA_L8) return {garr - GA_L1, hidden_feature(hh, s)};
+  switch (garr) {
+    case GA_CAT2: return s < 64 ? Row{FIN, hidden_feature(hh, s)} : ((s == 64 && hh == 0) ? Row{SIG, 0} : Row{0, -1});
+    case GA_CAT:
+      if (!fine) return {DIR, hidden_feature(hh, s)};
+      return s < 32 ? Row{TE0, j} : Row{DIR, j};
+    case GA_DRGB: return j < 3 && s < 16 ? Row{RGB, j} : Row{0, -1};
+    case GA_T1: return {13, hidden_feature(hh, s)};
+    case GA_T2: return {14, hidden_feature(hh, s)};
+    case GA_T3: return {15, hidden_feature(hh, s)};
+    case GA_DTH: return s >= 16 ? Row{0, -1} : (j < 3 ? Row{TRGB, j} : (j == 3 ? Row{TSIG, 0} : (j == 8 ? Row{TBETA, 0} : Row{0, -1})));
+  }
+  return {0, -1};
+}
+// X-side slot (hh, s) of the job's concatenated X chunks -> weight column
+int x_col(const JobPlan& jp, int hh, int s) {
+  if (jp.x1 >= 0) return s < 32 ? pe_xyz_feature(hh, s) : kChXyz + hidden_feature(hh, s - 32);   // layer 5: cat([pe, h4])
+  if (jp.x0 == XA_PE) return pe_xyz_feature(hh, s);
+  return hidden_feature(hh, s);
+}
+int job_kcx(const JobPlan& jp) { return kXChunks[jp.x0] + (jp.x1 >= 0 ? kXChunks[jp.x1] : 0); }
+// destination map of one job: [nb_g * (nb_x + 1)][1024], index r * 64 + lane
+void job_map(const JobPlan& jp, bool fine, const Geo& g, std::vector<int32_t>& out) {
+  const int kcg = (fine ? kGChunksFine : kGChunksCoarse)[jp.garr], kcx = job_kcx(jp);
+  const int nb_g = kcg / 2, nb_x = kcx / 2;
+  for (int gb = 0; gb < nb_g; ++gb)
+    for (int xb = 0; xb <= nb_x; ++xb)
+      for (int r = 0; r < 16; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = mblock_row(lane >> 5, r), n = lane & 31;
+          const int sg = 8 * (2 * gb + (m >> 4)) + (m & 7), hg = (m >> 3) & 1;
+          const Row rw = g_row(jp.garr, fine, hg, sg);
+          int32_t dst = -1;
+          if (rw.row >= 0 && rw.row < rows_of(rw.layer)) {
+            if (xb == nb_x) {
+              if (n == 0) dst = enc(weight_param(fine, rw.layer) + 1, rw.row);
+            } else {
+              const int sx = 8 * (2 * xb + (n >> 4)) + (n & 7), hx = (n >> 3) & 1;
+              const int col = x_col(jp, hx, sx), cols = cols_of(rw.layer, fine, g);
+              if (col >= 0 && col < cols) dst = enc(weight_param(fine, rw.layer), rw.row * cols + col);
+            }
+          }
+          out.push_back(dst);
+        }
+}
+
+struct DevBlob { char* blob = nullptr; uint32_t* tab = nullptr; PackElem* welem = nullptr; PackElem* belem = nullptr; int n_units = 0, n_w = 0, n_b = 0; uint32_t bytes = 0; };
+}  // namespace
+
+namespace dfn {
+namespace fused {
+struct State {
+  DevBlob blob[2][2];      // [coarse / fine][forward / backward]
+  int32_t* map = nullptr;  // destination maps: coarse jobs then fine jobs
+  int map_off[2][16] = {};
+};
+}  // namespace fused
+}  // namespace dfn
+
+namespace {
+template <class T>
+int upload_vec(const std::vector<T>& v, T** dst) {
+  const size_t bytes = v.size() * sizeof(T);
+  if (hipMalloc(reinterpret_cast<void**>(dst), bytes ? bytes : 16) != hipSuccess) return set_error(DFN_ERR_HIP, "fused training: hipMalloc(%zu) failed", bytes);
+  if (bytes && hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return set_error(DFN_ERR_HIP, "fused training: upload failed");
+  return DFN_OK;
+}
+int build_state(dfn_nerfh_s* h) {
+  auto* st = new State();
+  h->fused = st;
+  const Geo g = geo_of(h->desc);
+  for (int f = 0; f < 2; ++f)
+    for (int pass = 0; pass < 2; ++pass) {
+      const BlobPlan bp = pass ? plan_backward(f, g) : plan_forward(f, g);
+      DevBlob& d = st->blob[f][pass];
+      d.bytes = bp.bytes;
+      d.n_units = int(bp.tab.size() / 2);
+      d.n_w = int(bp.welem.size());
+      d.n_b = int(bp.belem.size());
+      if (hipMalloc(reinterpret_cast<void**>(&d.blob), bp.bytes) != hipSuccess || hipMemset(d.blob, 0, bp.bytes) != hipSuccess)
+        return set_error(DFN_ERR_HIP, "fused training: blob allocation failed");
+      if (int rc = upload_vec(bp.tab, &d.tab)) return rc;
+      if (int rc = upload_vec(bp.welem, &d.welem)) return rc;
+      if (int rc = upload_vec(bp.belem, &d.belem)) return rc;
+    }
+  std::vector<int32_t> maps;
+  for (int f = 0; f < 2; ++f)
+    for (int j = 0; j < (f ? kNumJobsFine : kNumJobsCoarse); ++j) {
+      st->map_off[f][j] = int(maps.size());
+      job_map(kJobsFine[j], f, g, maps);
+    }
+  return upload_vec(maps, &st->map);
+}
+}  // namespace
+
+// Host-only consistency check of the tables above (no GPU work): every weight / bias element the chains read is packed exactly
+// once per pass, and every gradient element the stream owns is written by exactly one (job, block, lane, register).
+extern "C" int dfn_nerfh_train_tables_selfcheck(const dfn_nerfh_desc* desc) {
+  if (!desc || desc->width != kWidth) return set_error(DFN_ERR_ARG, "dfn_nerfh_train_tables_selfcheck: netwidth 128 only");
+  const Geo g = geo_of(*desc);
+  for (int f = 0; f < 2; ++f) {
+    const int nl = f ? kFineLayers_ : kCoarseLayers_;
+    // expected coverage per Linear: columns [c0, c1) of every row
+    auto expect = [&](int pass, int layer, int& c0, int& c1) {   // pass 0 forward blob, 1 backward blob, 2 gradient maps
+      const int cols = cols_of(layer, f, g);
+      c0 = 0; c1 = cols;
+      if (layer == DIR || layer == TE0) c1 = kWidth;                 // the tail columns are per-ray work
+      if (pass == 1 && layer == 0) c1 = 0;                           // no data gradient through layer 1
+      if (pass == 1 && layer == 4) c0 = kChXyz;                      // ... nor through the encoding columns of layer 5
+    };
+    for (int pass = 0; pass < 3; ++pass) {
+      std::vector<std::vector<int>> cnt(2 * nl);
+      for (int l = 0; l < nl; ++l) {
+        cnt[2 * l].assign(size_t(rows_of(l)) * cols_of(l, f, g), 0);
+        cnt[2 * l + 1].assign(rows_of(l), 0);
+      }
+      auto hit = [&](int32_t src) {
+        const int pid = (src >> 20) - (f ? kCoarseParams : 0), idx = src & 0xfffff;
+        if (pid < 0 || pid >= 2 * nl || idx >= int(cnt[pid].size())) return false;
+        ++cnt[pid][idx];
+        return true;
+      };
+      if (pass < 2) {
+        const BlobPlan bp = pass ? plan_backward(f, g) : plan_forward(f, g);
+        if (bp.tab.empty()) return set_error(DFN_ERR_STATE, "selfcheck: empty plan");
+        for (const auto& e : bp.welem) if (e.off + 1024 + 2 > bp.bytes || !hit(e.src)) return set_error(DFN_ERR_STATE, "selfcheck: bad weight element (net %d pass %d)", f, pass);
+        for (const auto& e : bp.belem) if (e.off + 4 > bp.bytes || !hit(e.src)) return set_error(DFN_ERR_STATE, "selfcheck: bad bias element (net %d pass %d)", f, pass);
+      } else {
+        std::vector<int32_t> maps;
+        for (int j = 0; j < (f ? kNumJobsFine : kNumJobsCoarse); ++j) job_map(kJobsFine[j], f, g, maps);
+        for (int32_t m : maps) if (m >= 0 && !hit(m)) return set_error(DFN_ERR_STATE, "selfcheck: bad gradient destination (net %d)", f);
+      }
+      for (int l = 0; l < nl; ++l) {
+        int c0, c1;
+        expect(pass, l, c0, c1);
+        const int cols = cols_of(l, f, g);
+        for (int r = 0; r < rows_of(l); ++r)
+          for (int c = 0; c < cols; ++c) {
+            const int want = (c >= c0 && c < c1) ? 1 : 0;
+            if (cnt[2 * l][size_t(r) * cols + c] != want)
+              return set_error(DFN_ERR_STATE, "selfcheck: net %d pass %d layer %d weight[%d][%d] covered %d times, expected %d", f, pass, l, r, c,
+                               cnt[2 * l][size_t(r) * cols + c], want);
+          }
+        const int want_b = pass == 0 ? ((l == DIR || l == TE0) ? 0 : 1) : (pass == 1 ? 0 : 1);
+        for (int r = 0; r < rows_of(l); ++r)
+          if (cnt[2 * l + 1][r] != want_b)
+            return set_error(DFN_ERR_STATE, "selfcheck: net %d pass %d layer %d bias[%d] covered %d times, expected %d", f, pass, l, r, cnt[2 * l + 1][r], want_b);
+      }
+    }
+  }
+  return DFN_OK;
+}
+
+namespace dfn {
+namespace fused {
+
+void destroy_state(dfn_nerfh_s* h) {
+  auto* st = static_cast<State*>(h->fused);
+  if (!st) return;
+  for (auto& a : st->blob)
+    for (auto& d : a) {
+      if (d.blob) (void)hipFree(d.blob);
+      if (d.tab) (void)hipFree(d.tab);
+      if (d.welem) (void)hipFree(d.welem);
+      if (d.belem) (void)hipFree(d.belem);
+    }
+  if (st->map) (void)hipFree(st->map);
+  delete st;
+  h->fused = nullptr;
+}
+
+bool available(const dfn_nerfh_s* h) { return h && h->fast && h->desc.width == kWidth; }
+
+namespace {
+inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+struct NetWs {
+  char* x;  size_t x_off[XA_COUNT];
+  char* g;  size_t g_off[GA_COUNT];
+  float* gscale; uint32_t* masks; float* ray_bias; float* gpre; float* z;
+  size_t n_wt; long long P;
+};
+struct Ws {
+  float *view, *dir_c, *dir_f, *t_in, *raw_c, *gsum_f, *gsum_c, *gray, *wscratch, *partial;
+  NetWs net[2];
+  size_t partial_floats, total;
+};
+size_t tail_scratch_floats(const Geo& g, size_t R) {
+  const int pairs[][2] = {{kWidth / 2, g.ld_df}, {kWidth / 2, g.ld_dc}, {kWidth / 2, g.ld_t}};
+  size_t best = 0;
+  for (const auto& nk : pairs) {
+    const size_t f = gemm_wgrad_scratch_floats(nk[0], nk[1], (long long)R);
+    best = f > best ? f : best;
+  }
+  return best + 1024;
+}
+// job list of one network against a carved workspace; returns the number of workgroups it adds
+int make_jobs(bool fine, const NetWs& n, const State& st, size_t total_stage_bytes, float*& partial, WJob* jobs, int first_wg, int& n_jobs) {
+  const int* kcgs = fine ? kGChunksFine : kGChunksCoarse;
+  int wgs = 0;
+  for (int j = 0; j < (fine ? kNumJobsFine : kNumJobsCoarse); ++j) {
+    const JobPlan& jp = kJobsFine[j];
+    WJob& w = jobs[n_jobs++];
+    w.kcg = kcgs[jp.garr];
+    w.kcx0 = kXChunks[jp.x0];
+    w.kcx1 = jp.x1 >= 0 ? kXChunks[jp.x1] : 0;
+    w.g = n.g + n.g_off[jp.garr];
+    w.x0 = n.x + n.x_off[jp.x0];
+    w.x1 = jp.x1 >= 0 ? n.x + n.x_off[jp.x1] : nullptr;
+    w.gscale = n.gscale + size_t(jp.garr) * n.n_wt;
+    w.nb_g = w.kcg / 2;
+    w.nb_x = (w.kcx0 + w.kcx1) / 2;
+    w.wt_per_chunk = wgrad_wt_per_chunk(w.kcg + w.kcx0 + w.kcx1, n.n_wt, total_stage_bytes);
+    w.n_chunks = int((n.n_wt + w.wt_per_chunk - 1) / w.wt_per_chunk);
+    w.first_wg = first_wg + wgs;
+    w.map_off = st.map_off[fine][j];
+    w.partial = partial;
+    if (partial) partial += size_t(w.n_chunks) * w.nb_g * (w.nb_x + 1) * 1024;
+    wgs += w.n_chunks;
+  }
+  return wgs;
+}
+size_t stage_bytes_of(bool fine, size_t n_wt) {
+  const int* kcgs = fine ? kGChunksFine : kGChunksCoarse;
+  size_t b = 0;
+  for (int j = 0; j < (fine ? kNumJobsFine : kNumJobsCoarse); ++j)
+    b += size_t(kcgs[kJobsFine[j].garr] + job_kcx(kJobsFine[j])) * kChunkBytes * n_wt;
+  return b;
+}
+Ws carve(char* base, const dfn_nerfh_desc& d, size_t R, int Nc, int Ni) {
+  Ws w{};
+  const Geo g = geo_of(d);
+  const size_t Nf = size_t(Nc) + Ni;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  auto takef = [&](size_t floats) { return reinterpret_cast<float*>(take(floats * 4)); };
+  w.view = takef(R * 3);
+  w.dir_c = takef(R * g.ld_dc);
+  w.dir_f = takef(R * g.ld_df);
+  w.t_in = takef(R * g.ld_t);
+  w.raw_c = takef(R * Nc * 4);
+  w.gsum_f = takef(R * kWidth);
+  w.gsum_c = takef(R * (kWidth / 2));
+  w.gray = takef(R * size_t(g.ld_df > g.ld_t ? g.ld_df : g.ld_t));
+  w.wscratch = takef(tail_scratch_floats(g, R));
+  for (int f = 0; f < 2; ++f) {
+    NetWs& n = w.net[f];
+    n.P = (long long)R * (f ? Nf : Nc);
+    n.n_wt = chain_wave_tiles(n.P);
+    n.z = takef(size_t(n.P));
+    n.gpre = takef(size_t(n.P) * (f ? 9 : 4));
+    n.ray_bias = takef(R * kRayBiasFloats);
+    n.masks = reinterpret_cast<uint32_t*>(take(n.n_wt * kMaskWords * 64 * 4));
+    n.gscale = takef(size_t(GA_COUNT) * n.n_wt);
+    size_t xb = 0, gb = 0;
+    for (int a = 0; a < (f ? int(XA_COUNT) : kXCountCoarse); ++a) { n.x_off[a] = xb; xb += n.n_wt * kXChunks[a] * kChunkBytes; }
+    for (int a = 0; a < (f ? int(GA_COUNT) : kGCountCoarse); ++a) { n.g_off[a] = gb; gb += n.n_wt * (f ? kGChunksFine : kGChunksCoarse)[a] * kChunkBytes; }
+    n.x = take(xb);
+    n.g = take(gb);
+  }
+  // weight-gradient partials
+  {
+    State dummy;
+    WJob jobs[kMaxJobs];
+    int nj = 0;
+    float* part = nullptr;
+    const size_t tsb = stage_bytes_of(false, w.net[0].n_wt) + stage_bytes_of(true, w.net[1].n_wt);
+    size_t floats = 0;
+    for (int f = 0; f < 2; ++f) {
+      nj = 0;
+      make_jobs(f, w.net[f], dummy, tsb, part, jobs, 0, nj);
+      for (int j = 0; j < nj; ++j) floats += size_t(jobs[j].n_chunks) * jobs[j].nb_g * (jobs[j].nb_x + 1) * 1024;
+    }
+    w.partial_floats = floats;
+    w.partial = takef(floats);
+  }
+  w.total = off;
+  return w;
+}
+
+int pack_blob(const DevBlob& d, const float* const* params, float in_scale, int* status, hipStream_t s) {
+  PackArgs a{};
+  a.welem = d.welem; a.n_welem = d.n_w;
+  a.belem = d.belem; a.n_belem = d.n_b;
+  a.blob = d.blob;
+  a.wscale = in_scale / kX3ActScale;
+  a.bscale = in_scale;
+  for (int i = 0; i < 64; ++i) a.params[i] = params[i];
+  a.status = status;
+  CHECK_HIP(launch_pack(a, s), "fused training: weight packing");
+  return DFN_OK;
+}
+ChainArgs chain_args(const dfn_nerfh_s* h, const State& st, bool fine, int pass, const NetWs& n, const float* o, const float* d, size_t R,
+                     int Ns) {
+  ChainArgs a{};
+  const DevBlob& b = st.blob[fine][pass];
+  a.blob = b.blob; a.tab = b.tab; a.n_units = b.n_units;
+  a.rays_o = o; a.rays_d = d; a.z = n.z; a.ray_bias = n.ray_bias;
+  a.masks = n.masks;
+  a.arrays = pass ? n.g : n.x;
+  for (int i = 0; i < 16; ++i) a.arr_off[i] = pass ? (i < GA_COUNT ? n.g_off[i] : 0) : (i < XA_COUNT ? n.x_off[i] : 0);
+  a.gscale = n.gscale;
+  a.gpre = n.gpre;
+  a.n_rays = (long long)R;
+  a.n_samples = Ns;
+  a.in_scale = h->net[fine][2][0].in_scale;
+  a.status = h->range_flag;
+  return a;
+}
+}  // namespace
+
+size_t workspace_bytes(const dfn_nerfh_s* h, size_t R, int Nc, int Ni) { return carve(nullptr, h->desc, R, Nc, Ni).total; }
+
+int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_o, const float* rays_d, const float* hist, size_t hist_rows,
+                  size_t R, int Nc, int Ni, float near, float far, const float* t_rand, const float* noise, float raw_noise_std,
+                  const float* u, float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
+                  float* beta, void* workspace, size_t workspace_bytes_, hipStream_t s) {
+  if (!h->fused)
+    if (int rc = build_state(h)) return rc;
+  const State& st = *static_cast<State*>(h->fused);
+  const Ws w = carve(static_cast<char*>(workspace), h->desc, R, Nc, Ni);
+  if (w.total > workspace_bytes_) return set_error(DFN_ERR_ARG, "dfn_nerfh_train_forward: workspace too small (%zu < %zu)", workspace_bytes_, w.total);
+  const Geo g = geo_of(h->desc);
+  const dfn_nerfh_desc& d = h->desc;
+  const int Nf = Nc + Ni, W = kWidth;
+  const float* const* pc = params;
+  const float* const* pf = params + kCoarseParams;
+  const float* emb_a = params[kCoarseParams + kFineParams];
+  const float* emb_t = params[kCoarseParams + kFineParams + 1];
+  const int n_cu = device_cu_count();
+  CHECK_HIP(launch_viewdirs(rays_d, R, w.view, s), "train forward: viewdirs");
+  CHECK_HIP(ray_inputs(w.view, nullptr, 1, nullptr, nullptr, d.hist_bin, d.dim_a, d.dim_t, d.n_vocab, R, w.dir_c, g.ld_dc, nullptr, 0, s),
+            "train forward: coarse ray inputs");
+  CHECK_HIP(ray_inputs(w.view, hist, hist_rows, emb_a, emb_t, d.hist_bin, d.dim_a, d.dim_t, d.n_vocab, R, w.dir_f, g.ld_df, w.t_in, g.ld_t, s),
+            "train forward: fine ray inputs");
+  // the step's weights -> staging units of the four chain passes (hi | lo split at the handle's operand scale)
+  for (int f = 0; f < 2; ++f)
+    for (int pass = 0; pass < 2; ++pass)
+      if (int rc = pack_blob(st.blob[f][pass], params, h->net[f][2][0].in_scale, h->range_flag, s)) return rc;
+  CHECK_HIP(launch_ray_bias_train(pc[2 * DIR], pc[2 * DIR + 1], W + g.kd_c, g.kd_c, w.dir_c, g.ld_dc, nullptr, nullptr, 0, 0, nullptr, 0, R,
+                                  w.net[0].ray_bias, s),
+            "train forward: coarse per-ray bias");
+  CHECK_HIP(launch_ray_bias_train(pf[2 * DIR], pf[2 * DIR + 1], W + g.kd_f, g.kd_f, w.dir_f, g.ld_df, pf[2 * TE0], pf[2 * TE0 + 1], W + g.nt,
+                                  g.nt, w.t_in, g.ld_t, R, w.net[1].ray_bias, s),
+            "train forward: fine per-ray bias");
+  CHECK_HIP(stratified_z(t_rand, R, Nc, near, far, w.net[0].z, s, h->render_flags & DFN_RENDER_LINDISP), "train forward: stratified z");
+  {
+    ChainArgs a = chain_args(h, st, false, 0, w.net[0], rays_o, rays_d, R, Nc);
+    a.raw_out = w.raw_c;
+    CHECK_HIP(launch_train_forward_chain(false, a, n_cu, s), "train forward: coarse chain");
+  }
+  CHECK_HIP(sample_fine_train(w.raw_c, w.net[0].z, noise, raw_noise_std, u, R, Nc, Ni, w.net[1].z, rgb0, disp0, acc0, z_std, s),
+            "train forward: coarse composite + sampling");
+  {
+    ChainArgs a = chain_args(h, st, true, 0, w.net[1], rays_o, rays_d, R, Nf);
+    a.raw_out = raw;
+    CHECK_HIP(launch_train_forward_chain(true, a, n_cu, s), "train forward: fine chain");
+  }
+  CHECK_HIP(launch_composite_fine(raw, w.net[1].z, R, Nf, 0.1f, 0, rgb, disp, acc, nullptr, nullptr, beta, s), "train forward: fine composite");
+  return DFN_OK;
+}
+
+int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist, size_t hist_rows, size_t R, int Nc, int Ni,
+                   const float* noise, float raw_noise_std, const float* raw, const float* g_rgb, const float* g_rgb0, const float* g_beta,
+                   float g_tsigma, const float* g_tsigma_dense, float* const* grads, void* workspace, size_t workspace_bytes_, hipStream_t s) {
+  if (!h->fused) return set_error(DFN_ERR_STATE, "dfn_nerfh_train_backward: no forward pass on this handle");
+  const State& st = *static_cast<State*>(h->fused);
+  const Ws w = carve(static_cast<char*>(workspace), h->desc, R, Nc, Ni);
+  if (w.total > workspace_bytes_) return set_error(DFN_ERR_ARG, "dfn_nerfh_train_backward: workspace too small (%zu < %zu)", workspace_bytes_, w.total);
+  const Geo g = geo_of(h->desc);
+  const dfn_nerfh_desc& d = h->desc;
+  const int Nf = Nc + Ni, W = kWidth, W2 = kWidth / 2;
+  const float* const* pc = params;
+  const float* const* pf = params + kCoarseParams;
+  float* const* gc = grads;
+  float* const* gf = grads + kCoarseParams;
+  float* g_emb_a = grads[kCoarseParams + kFineParams];
+  float* g_emb_t = grads[kCoarseParams + kFineParams + 1];
+  const int n_cu = device_cu_count();
+  CHECK_HIP(hipMemsetAsync(g_emb_a, 0, size_t(d.n_vocab) * d.dim_a * 4, s), "train backward: zero embedding_a grad");
+  CHECK_HIP(hipMemsetAsync(g_emb_t, 0, size_t(d.n_vocab) * d.dim_t * 4, s), "train backward: zero embedding_t grad");
+  CHECK_HIP(composite_fine_backward_train(raw, w.net[1].z, g_rgb, g_beta, g_tsigma, g_tsigma_dense, R, Nf, w.net[1].gpre, s), "train backward: fine composite");
+  CHECK_HIP(composite_coarse_backward(w.raw_c, w.net[0].z, noise, raw_noise_std, g_rgb0, R, Nc, w.net[0].gpre, s), "train backward: coarse composite");
+  // data-gradient chains: every pre-activation gradient stored once, in the operand layout the weight-gradient stream reads
+  {
+    ChainArgs a = chain_args(h, st, true, 1, w.net[1], nullptr, nullptr, R, Nf);
+    CHECK_HIP(launch_train_backward_chain(true, a, n_cu, s), "train backward: fine chain");
+  }
+  {
+    ChainArgs a = chain_args(h, st, false, 1, w.net[0], nullptr, nullptr, R, Nc);
+    CHECK_HIP(launch_train_backward_chain(false, a, n_cu, s), "train backward: coarse chain");
+  }
+  // weight gradients: one stream launch over the jobs of both networks, then the fixed-order reduction into the .grad tensors
+  {
+    WgradArgs wa{};
+    wa.n_jobs = 0;
+    float* part = w.partial;
+    const size_t tsb = stage_bytes_of(false, w.net[0].n_wt) + stage_bytes_of(true, w.net[1].n_wt);
+    // the two networks have different wave-tile counts: one launch each (n_wt is a launch constant), the fine one first
+    for (int f = 1; f >= 0; --f) {
+      wa.n_jobs = 0;
+      const int wgs = make_jobs(f, w.net[f], st, tsb, part, wa.job, 0, wa.n_jobs);
+      wa.n_wt = int(w.net[f].n_wt);
+      CHECK_HIP(launch_wgrad_stream(wa, wgs, s), "train backward: weight-gradient stream");
+      ReduceArgs ra{};
+      std::memcpy(ra.job, wa.job, sizeof(wa.job));
+      ra.n_jobs = wa.n_jobs;
+      ra.map = st.map;
+      for (int i = 0; i < 64; ++i) ra.grads[i] = grads[i];
+      CHECK_HIP(launch_wgrad_reduce(ra, s), "train backward: weight-gradient reduction");
+    }
+  }
+  // columns beyond `final` of dir_encoding.0 / transient_encoding.0 multiply per-ray inputs: per-ray sums of the stored gradients,
+  // then the small products of the layer-by-layer path (nerfh_train.hip) over rays
+  CHECK_HIP(launch_frag_ray_sum(w.net[1].g + w.net[1].g_off[GA_CAT], 8, w.net[1].gscale + size_t(GA_CAT) * w.net[1].n_wt, R, Nf, w.gsum_f, W, s),
+            "train backward: per-ray sums (fine)");
+  CHECK_HIP(launch_frag_ray_sum(w.net[0].g + w.net[0].g_off[GA_CAT], 4, w.net[0].gscale + size_t(GA_CAT) * w.net[0].n_wt, R, Nc, w.gsum_c, W2, s),
+            "train backward: per-ray sums (coarse)");
+  const int ldw_dir_f = W + g.kd_f, ldw_dir_c = W + g.kd_c, ldw_te0 = W + g.nt;
+  // transient_encoding.0 tail: gsum_f[:, 0:64]
+  CHECK_HIP(gemm_wgrad(w.gsum_f, W, W2, Seg{w.t_in, g.ld_t, g.nt, 1, W}, gf[2 * TE0], ldw_te0, nullptr, w.wscratch, (long long)R, s), "train wgrad: transient tail");
+  CHECK_HIP(gemm_bwd(w.gsum_f, W, W2, pf[2 * TE0], ldw_te0, W, g.nt, w.gray, g.ld_t, 0, nullptr, 0, (long long)R, s), "train backward: d t");
+  CHECK_HIP(embedding_scatter(w.gray, g.ld_t, 0, hist, hist_rows, d.hist_bin, d.dim_t, d.n_vocab, R, g_emb_t, s), "train: embedding_t grad");
+  // dir_encoding.0 tail (fine): gsum_f[:, 64:128]
+  CHECK_HIP(gemm_wgrad(w.gsum_f + W2, W, W2, Seg{w.dir_f, g.ld_df, g.kd_f, 1, W}, gf[2 * DIR], ldw_dir_f, nullptr, w.wscratch, (long long)R, s), "train wgrad: dir tail");
+  CHECK_HIP(gemm_bwd(w.gsum_f + W2, W, W2, pf[2 * DIR], ldw_dir_f, W + kChDir, g.na, w.gray, g.ld_df, 0, nullptr, 0, (long long)R, s), "train backward: d a");
+  CHECK_HIP(embedding_scatter(w.gray, g.ld_df, 0, hist, hist_rows, d.hist_bin, d.dim_a, d.n_vocab, R, g_emb_a, s), "train: embedding_a grad");
+  // dir_encoding.0 tail (coarse)
+  CHECK_HIP(gemm_wgrad(w.gsum_c, W2, W2, Seg{w.dir_c, g.ld_dc, g.kd_c, 1, W}, gc[2 * DIR], ldw_dir_c, nullptr, w.wscratch, (long long)R, s), "train wgrad: coarse dir tail");
+  return DFN_OK;
+}
+
+}  // namespace fused
+}  // namespace dfn

@@ -1,0 +1,142 @@
+// nerfh_fused_train.h — the register-resident NeRF-H TRAINING chain (netwidth 128): launch interface and data layout shared by
+// nerfh_fused_chain.hip (forward / data-gradient chains), nerfh_fused_wgrad.hip (weight-gradient stream, reductions, per-step
+// weight packing) and nerfh_train_api.hip (orchestration).
+//
+// What one optimisation step of the reference needs (script/run_nerf.py:32-80, loss.backward() over models/nerfw.py:297-354) and
+// how it is laid out here:
+//   * forward chain  — both networks exactly as the test-time kernels run them (nerfh_mlp_core.h: weights = MFMA A operand,
+//     32 points per wavefront carried through every layer in registers, split-f16 products = fp32-grade), additionally storing
+//     every layer INPUT X_l as the split-f16 B-operand registers it already is, plus one ReLU sign bit per hidden unit;
+//   * backward chain — the transposed chain of nerfh_bwd.hip from the pre-activation gradients of the heads, ReLU gates from the
+//     sign bits, storing every layer's pre-activation gradient G_l as the B-operand registers it already is; a wavefront's 32
+//     points share ONE power-of-two scale per stored array (recorded per wave-tile), so the halves stay in f16's range whatever
+//     the gradient magnitude;
+//   * weight gradients — dW_l[n, k] = sum_p G_l[p, n] X_l[p, k] as a pure stream: the stored arrays are DMA-ed into LDS and read
+//     back TRANSPOSED (ds_read_b64_tr_b16: [point][feature] image -> [feature][point] MFMA operands), three f16 MFMAs per
+//     product, fp32 accumulation per wave-tile folded into a master accumulator at the tile's scale; fixed point chunks ->
+//     partial sums -> fixed-order reduction (deterministic) scattered straight into the torch .grad tensors.
+// Nothing but X_l / G_l (4 bytes per element, written once, read once) and 84 bytes of sign bits per point touches HBM.
+//
+// Stored array layout ("wave-tile" wt = 32 consecutive points = one wavefront of a chain tile):
+//   array[wt][chunk c][plane 0 = hi | 1 = lo][point p (32)][half h (2)][slot j (8)]   f16, 2048 bytes per chunk
+// chunk c, half h, slot j = contraction slot s = 8 c + j of half h of the B operand (nerfh_layout.h: hidden_feature /
+// pe_xyz_feature give the feature index).  A plane is 1 KiB = one wave-wide 16-byte store / LDS-DMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+struct dfn_nerfh_s;
+
+namespace dfn {
+namespace fused {
+
+constexpr int kTilePoints = 256;   // points per workgroup tile of the chain kernels (8 waves x 32)
+constexpr int kWaveTile = 32;
+constexpr int kMaskWords = 21;     // as nerfh_kernels.h: 8 x 128 + 64 + 4 x 64 sign bits per point
+constexpr int kChunkBytes = 2048;  // hi plane + lo plane of one chunk of one wave-tile
+
+// ---- stored arrays
+// X arrays (forward-layer inputs).  Coarse net: XA_PE .. XA_DE.
+enum XArr { XA_PE = 0, XA_H1, XA_H2, XA_H3, XA_H4, XA_H5, XA_H6, XA_H7, XA_H8, XA_FIN, XA_DE, XA_T0, XA_T1, XA_T2, XA_T3, XA_COUNT };
+constexpr int kXChunks[XA_COUNT] = {4, 8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4, 4, 4, 4};
+constexpr int kXCountCoarse = XA_DE + 1;
+// G arrays (pre-activation gradients = inputs of the backward layers).  GA_L1..GA_L8: d h_l (pre-activation); GA_CAT2:
+// [d final (8 chunks); slot 64 of half 0 = d sigma_s]; GA_CAT: fine [d t0 (4); d dir_h (4)], coarse [d dir_h (4)];
+// GA_DRGB: d rgb_s; GA_T1..GA_T3: d t1..t3; GA_DTH: [d rgb_t(3), d sigma_t, -, -, -, -, d beta].
+enum GArr { GA_L1 = 0, GA_L2, GA_L3, GA_L4, GA_L5, GA_L6, GA_L7, GA_L8, GA_CAT2, GA_CAT, GA_DRGB, GA_T1, GA_T2, GA_T3, GA_DTH, GA_COUNT };
+constexpr int kGChunksFine[GA_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 10, 8, 2, 4, 4, 4, 2};
+constexpr int kGChunksCoarse[GA_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 10, 4, 2, 0, 0, 0, 0};
+constexpr int kGCountCoarse = GA_DRGB + 1;
+
+struct ChainArgs {
+  const char* blob;        // packed units of this pass (forward or backward) in execution order
+  const uint32_t* tab;     // [n_units][2] = (byte offset, bytes)
+  int n_units;
+  const float* rays_o;     // [n_rays,3]
+  const float* rays_d;     // [n_rays,3]
+  const float* z;          // [n_rays, n_samples]
+  const float* ray_bias;   // [n_rays, kRayBiasFloats] C-fragment order (coarse: table 0 only)
+  float* raw_out;          // forward: [P, 9] (fine) / [P, 4] (coarse: rgb, sigma)
+  const float* gpre;       // backward: [P, 9] / [P, 4] d L / d PRE-activation head outputs
+  uint32_t* masks;         // [n_wt][kMaskWords][64]
+  char* arrays;            // base of the stored arrays (forward: X, backward: G)
+  size_t arr_off[16];      // byte offset of each array (forward: XArr, backward: GArr)
+  float* gscale;           // backward: [GA_COUNT][n_wt] scale carried by each stored wave-tile (stored = true x scale)
+  long long n_rays;
+  int n_samples;
+  float in_scale;          // split-f16: weight scale x activation scale carried by the accumulators
+  int* status;             // range guard (as MlpArgs::status)
+};
+hipError_t launch_train_forward_chain(bool fine, const ChainArgs& a, int n_cu, hipStream_t s);
+hipError_t launch_train_backward_chain(bool fine, const ChainArgs& a, int n_cu, hipStream_t s);
+size_t chain_wave_tiles(long long n_points);   // wave-tiles the chain kernels write (whole tiles)
+
+// ---- weight-gradient stream
+struct WJob {
+  const char* g;           // G array: [n_wt][kcg][2048]
+  const char* x0;          // X array(s): [n_wt][kcx0][2048] (, [n_wt][kcx1][2048])
+  const char* x1;
+  const float* gscale;     // [n_wt]
+  float* partial;          // [n_chunks][n_blocks][1024]
+  int kcg, kcx0, kcx1;
+  int nb_g, nb_x;          // 32-feature blocks on either side; blocks = nb_g x (nb_x + 1): the extra column block = bias sums
+  int wt_per_chunk, n_chunks;
+  int first_wg;            // first workgroup of this job in the launch
+  int map_off;             // offset (ints) of this job's destination map inside the map table
+};
+constexpr int kMaxJobs = 16;
+struct WgradArgs {
+  WJob job[kMaxJobs];
+  int n_jobs;
+  int n_wt;
+};
+struct ReduceArgs {
+  WJob job[kMaxJobs];
+  int n_jobs;
+  const int* map;          // per job: [n_blocks][1024] destination (param << 20 | offset) or -1, index r * 64 + lane
+  float* grads[64];        // the step's gradient tensors in canonical order (dfn_nerfh_train_param_name)
+};
+hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, hipStream_t s);
+hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t s);
+constexpr uint32_t kWgradLdsBytes = 155648;   // staging ring of the stream kernel (152 KiB)
+// Points chunking of one job (deterministic: depends on the batch shape only).
+int wgrad_wt_per_chunk(int stage_chunks, size_t n_wt, size_t total_stage_bytes_all_jobs);
+
+// ---- per-step packing of the master weights into the chain kernels' staging units
+struct PackElem { uint32_t off; int32_t src; };    // f16 element: hi at blob + off, lo at + 1024; src = param << 20 | index, < 0: zero
+struct PackArgs {
+  const PackElem* welem; int n_welem;
+  const PackElem* belem; int n_belem;              // fp32 bias element at blob + off
+  char* blob;
+  float wscale, bscale;
+  const float* params[64];
+  int* status;
+};
+hipError_t launch_pack(const PackArgs& a, hipStream_t s);
+
+// table[ray][tbl][mb][h][r] (C-fragment order, nerfh_layout.h) = b[f] + sum_j W[f, 128 + j] in[ray, j]; tbl 0 = dir_encoding.0
+// on dir_in [R, ld_dir] (kd columns), tbl 1 = transient_encoding.0 on t_in (nt columns; w_te == nullptr: table 0 only).
+hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw_dir, int kd, const float* dir_in, int ld_dir,
+                                 const float* w_te, const float* b_te, int ldw_te, int nt, const float* t_in, int ld_t, size_t R,
+                                 float* table, hipStream_t s);
+// out[r][feat] (feat < 16 kc) = sum over the ray's samples of the stored gradient array (true scale), feature order = slot order
+// mapped through hidden_feature() per 32-slot group: out[r][64 (s >> 5) + hidden_feature(h, s & 31)].
+hipError_t launch_frag_ray_sum(const char* arr, int kc, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s);
+
+
+// ---- host side (nerfh_fused_api.hip), called by dfn_nerfh_train_* when the handle runs the register-resident kernels
+struct State;
+bool available(const dfn_nerfh_s* h);
+size_t workspace_bytes(const dfn_nerfh_s* h, size_t n_rays, int Nc, int Ni);
+int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_o, const float* rays_d, const float* hist, size_t hist_rows,
+                  size_t n_rays, int Nc, int Ni, float near, float far, const float* t_rand, const float* noise, float raw_noise_std,
+                  const float* u, float* rgb, float* disp, float* acc, float* raw, float* rgb0, float* disp0, float* acc0, float* z_std,
+                  float* beta, void* workspace, size_t workspace_bytes, hipStream_t s);
+int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni,
+                   const float* noise, float raw_noise_std, const float* raw, const float* g_rgb, const float* g_rgb0, const float* g_beta,
+                   float g_tsigma, const float* g_tsigma_dense, float* const* grads, void* workspace, size_t workspace_bytes, hipStream_t s);
+void destroy_state(dfn_nerfh_s* h);
+
+}  // namespace fused
+}  // namespace dfn

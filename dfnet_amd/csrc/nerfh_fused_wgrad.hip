@@ -1,0 +1,341 @@
+// nerfh_fused_wgrad.hip — weight gradients of the fused NeRF-H training step as a stream over the stored operand arrays, plus
+// the small kernels around the chains: per-step weight packing, per-ray bias tables from the master weights, per-ray sums of a
+// stored gradient array (gfx950 only).  Layouts and the scheme: nerfh_fused_train.h.
+//
+// Replaces the weight-gradient third of loss.backward() in /root/reference/script/run_nerf.py:64 for the Linear layers of
+// models/nerfw.py:259-295: dW_l[n, k] = sum_p G_l[p, n] X_l[p, k], db_l[n] = sum_p G_l[p, n].
+//
+// wgrad_stream_kernel: one workgroup = (job, chunk of wave-tiles).  Per wave-tile the job's G and X chunks (2 KiB each, already
+// split hi | lo by the chain kernels) are DMA-ed L2/HBM -> LDS into a ring of 3-4 stages (global_load_lds_dwordx4, no registers);
+// the [point][feature] image is read back as [feature][point] MFMA operands by ds_read_b64_tr_b16 (a 16-lane group reads
+// 4 points x 16 features = 128 contiguous bytes: conflict-free), three v_mfma_f32_32x32x16_f16 per product and 16-point half;
+// the wave-tile's fp32 block is folded into the master accumulator at the tile's power-of-two scale.  The kernel is bound by
+// the stream (4 bytes per stored element, read once): a 128 x 128 layer moves 32 KiB per 32 points against 120 MFMAs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nerfh_fused_train.h"
+#include "nerfh_mlp_core.h"
+
+namespace dfn {
+namespace fused {
+
+namespace {
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int WAVES = 8, MAXB = 4;
+
+template <int OFF>
+DFN_DEV u32x2 ds_tr16(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// 32 features (a chunk pair at LDS address cb; cb already holds the lane's part) x 16 points (P0 = 0 / 16) -> MFMA operand
+// (hi, lo): lane (feature = lane & 31, k-half = lane >> 5) receives points P0 + 8 (lane >> 5) + 0..7.
+struct Frag { u32x2 h0, h1, l0, l1; };
+template <int P0>
+DFN_DEV Frag issue_frag(uint32_t cb) {
+  Frag f;
+  f.h0 = ds_tr16<P0 * 32>(cb);
+  f.h1 = ds_tr16<P0 * 32 + 128>(cb);
+  f.l0 = ds_tr16<P0 * 32 + 1024>(cb);
+  f.l1 = ds_tr16<P0 * 32 + 1024 + 128>(cb);
+  return f;
+}
+DFN_DEV half8 join(u32x2 a, u32x2 b) { return __builtin_bit_cast(half8, u32x4{a[0], a[1], b[0], b[1]}); }
+
+DFN_DEV void wait_vmcnt(int n) {   // s_waitcnt vmcnt(n), n wave-uniform (gfx9 encoding: vmcnt[3:0] in bits 3:0, lgkmcnt / expcnt left open)
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
+    case 11: __builtin_amdgcn_s_waitcnt(0x0F7B); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+    case 13: __builtin_amdgcn_s_waitcnt(0x0F7D); break;
+    case 14: __builtin_amdgcn_s_waitcnt(0x0F7E); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0F7F); break;
+  }
+  asm volatile("" ::: "memory");
+}
+typedef const float __attribute__((address_space(4))) const_f32;
+DFN_DEV float scalar_f32(const float* p) { return *reinterpret_cast<const_f32*>(reinterpret_cast<uint64_t>(p)); }
+}  // namespace
+
+int wgrad_wt_per_chunk(int stage_chunks, size_t n_wt, size_t total_stage_bytes_all_jobs) {
+  // ~4 workgroups per CU over the whole launch, every workgroup the same number of bytes
+  const double target = double(total_stage_bytes_all_jobs) / 1024.0;
+  long long wpc = (long long)(target / (double(stage_chunks) * kChunkBytes) + 0.5);
+  if (wpc < 8) wpc = 8;
+  if (wpc > (long long)n_wt) wpc = (long long)n_wt;
+  return int(wpc);
+}
+
+__global__ __launch_bounds__(WAVES * 64, 1) void wgrad_stream_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int j = 0;
+  while (j + 1 < a.n_jobs && int(blockIdx.x) >= a.job[j + 1].first_wg) ++j;
+  const WJob& jb = a.job[j];
+  const int kcg = jb.kcg, kcx0 = jb.kcx0, kcx1 = jb.kcx1;
+  const int kc_all = kcg + kcx0 + kcx1;
+  const uint32_t stage_bytes = uint32_t(kc_all) * kChunkBytes;
+  int D = int(kWgradLdsBytes / stage_bytes);
+  D = D > 4 ? 4 : D;
+  const int chunk = int(blockIdx.x) - jb.first_wg;
+  const int wt0 = chunk * jb.wt_per_chunk;
+  int n_it = a.n_wt - wt0;
+  n_it = n_it > jb.wt_per_chunk ? jb.wt_per_chunk : n_it;
+  if (n_it <= 0) return;
+  const int np = kc_all * 2;                       // 1 KiB pieces per stage
+  const int my_np = (np - wave + WAVES - 1) / WAVES;
+  auto issue = [&](int it) {
+    const size_t wt = size_t(wt0 + it);
+    char* dst = smem + uint32_t(it % D) * stage_bytes;
+    for (int i = wave; i < np; i += WAVES) {
+      const char* src;
+      if (i < 2 * kcg) src = jb.g + (wt * size_t(2 * kcg) + i) * 1024;
+      else if (i < 2 * (kcg + kcx0)) src = jb.x0 + (wt * size_t(2 * kcx0) + (i - 2 * kcg)) * 1024;
+      else src = jb.x1 + (wt * size_t(2 * kcx1) + (i - 2 * (kcg + kcx0))) * 1024;
+      lds_dma_b128(src + lane * 16, dst + i * 1024);
+    }
+  };
+  for (int it = 0; it < D - 1 && it < n_it; ++it) issue(it);
+
+  // this wave's output blocks: b = wave + 8 i -> (gb, xb); xb == nb_x: the bias column block (B operand = ones)
+  const int nbx1 = jb.nb_x + 1, nblk = jb.nb_g * nbx1;
+  const int g = lane >> 4, t = lane & 15;
+  const uint32_t lane_part = uint32_t(g & 1) * kChunkBytes + uint32_t(8 * (g >> 1) + (t >> 2)) * 32u + uint32_t(t & 3) * 8u;
+  uint32_t goff[MAXB], xoff[MAXB];
+  bool valid[MAXB], is_bias[MAXB];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int b = wave + WAVES * i;
+    valid[i] = b < nblk;
+    const int gb = b / nbx1, xb = b - gb * nbx1;
+    is_bias[i] = xb == jb.nb_x;
+    goff[i] = uint32_t(2 * gb) * kChunkBytes + lane_part;
+    xoff[i] = uint32_t(kcg + 2 * xb) * kChunkBytes + lane_part;   // X chunks follow the G chunks in a stage (x0 then x1)
+  }
+  f32x16 master[MAXB];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) master[i][r] = 0.f;
+  const half8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+
+  for (int it = 0; it < n_it; ++it) {
+    int ahead = n_it - 1 - it;
+    ahead = ahead > D - 2 ? D - 2 : ahead;
+    wait_vmcnt(ahead * my_np);
+    __builtin_amdgcn_s_barrier();   // stage `it` landed for every wave; every wave has left stage it - 1
+    asm volatile("" ::: "memory");
+    if (it + D - 1 < n_it) issue(it + D - 1);
+    const float inv = 1.f / scalar_f32(jb.gscale + wt0 + it);
+    const uint32_t sb = uint32_t(size_t(DFN_LDS_PTR(smem))) + uint32_t(it % D) * stage_bytes;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+      if (!valid[i]) continue;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      Frag a0 = issue_frag<0>(sb + goff[i]), a1 = issue_frag<16>(sb + goff[i]);
+      if (!is_bias[i]) {
+        Frag b0 = issue_frag<0>(sb + xoff[i]), b1 = issue_frag<16>(sb + xoff[i]);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a0.h0), "+v"(a0.h1), "+v"(a0.l0), "+v"(a0.l1), "+v"(a1.h0), "+v"(a1.h1), "+v"(a1.l0), "+v"(a1.l1),
+                       "+v"(b0.h0), "+v"(b0.h1), "+v"(b0.l0), "+v"(b0.l1), "+v"(b1.h0), "+v"(b1.h1), "+v"(b1.l0), "+v"(b1.l1)
+                     :: "memory");
+        const half8 ah0 = join(a0.h0, a0.h1), al0 = join(a0.l0, a0.l1), ah1 = join(a1.h0, a1.h1), al1 = join(a1.l0, a1.l1);
+        const half8 bh0 = join(b0.h0, b0.h1), bl0 = join(b0.l0, b0.l1), bh1 = join(b1.h0, b1.h1), bl1 = join(b1.l0, b1.l1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc, 0, 0, 0);
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a0.h0), "+v"(a0.h1), "+v"(a0.l0), "+v"(a0.l1), "+v"(a1.h0), "+v"(a1.h1), "+v"(a1.l0), "+v"(a1.l1)
+                     :: "memory");
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(a0.h0, a0.h1), ones, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(a1.h0, a1.h1), ones, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(a0.l0, a0.l1), ones, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(a1.l0, a1.l1), ones, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) master[i][r] = fmaf(acc[r], inv, master[i][r]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    if (!valid[i]) continue;
+    float* dst = jb.partial + (size_t(chunk) * nblk + (wave + WAVES * i)) * 1024 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r * 64] = master[i][r];
+  }
+}
+
+hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, hipStream_t s) {
+  if (total_wgs <= 0) return hipSuccess;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(kWgradLdsBytes));
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_stream_kernel, dim3(total_wgs), dim3(WAVES * 64), kWgradLdsBytes, s, a);
+  return hipGetLastError();
+}
+
+// Fixed-order sum of a job's chunk partials, scattered into the gradient tensors: weight blocks carry the X operand scale (16),
+// the bias column block does not.  One thread per block element; blockIdx -> (job, block, quarter).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs a, int total_quarters) {
+  int q = blockIdx.x;
+  int j = 0;
+  for (; j < a.n_jobs; ++j) {
+    const int nq = a.job[j].nb_g * (a.job[j].nb_x + 1) * 4;
+    if (q < nq) break;
+    q -= nq;
+  }
+  if (j >= a.n_jobs) return;
+  const WJob& jb = a.job[j];
+  const int nbx1 = jb.nb_x + 1, nblk = jb.nb_g * nbx1;
+  const int b = q >> 2, e = (q & 3) * 256 + threadIdx.x;
+  const int m = a.map[jb.map_off + b * 1024 + e];
+  if (m < 0) return;
+  const float* src = jb.partial + size_t(b) * 1024 + e;
+  float sum = 0.f;
+  for (int c = 0; c < jb.n_chunks; ++c) sum += src[size_t(c) * nblk * 1024];
+  const bool bias = (b % nbx1) == jb.nb_x;
+  a.grads[m >> 20][m & 0xfffff] = bias ? sum : sum * (1.f / kX3ActScale);
+}
+
+hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t s) {
+  int total = 0;
+  for (int j = 0; j < a.n_jobs; ++j) total += a.job[j].nb_g * (a.job[j].nb_x + 1) * 4;
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total), dim3(256), 0, s, a, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ per-step weight packing
+// Every f16 fragment element of a chain blob is one master weight (or zero): hi = f16(w x wscale), lo = f16(w x wscale - hi), as
+// the host packer of nerfh_api.hip writes them at commit; the bias fragments are fp32 x bscale.
+__global__ __launch_bounds__(256) void pack_units_kernel(PackArgs a) {
+  const int stride = gridDim.x * blockDim.x;
+  bool over = false;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_welem; i += stride) {
+    const PackElem e = a.welem[i];
+    const float v = e.src >= 0 ? a.params[e.src >> 20][e.src & 0xfffff] * a.wscale : 0.f;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    over |= !(fabsf(v) < 65504.f);
+    *reinterpret_cast<_Float16*>(a.blob + e.off) = hi;
+    *reinterpret_cast<_Float16*>(a.blob + e.off + 1024) = lo;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_belem; i += stride) {
+    const PackElem e = a.belem[i];
+    *reinterpret_cast<float*>(a.blob + e.off) = e.src >= 0 ? a.params[e.src >> 20][e.src & 0xfffff] * a.bscale : 0.f;
+  }
+  if (over && a.status) atomicOr(a.status, 2);   // a weight left the range of the split-f16 operand scale (DFN_RANGE_X3_SATURATED)
+}
+hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
+  const int n = a.n_welem > a.n_belem ? a.n_welem : a.n_belem;
+  if (n <= 0) return hipSuccess;
+  int grid = (n + 255) / 256;
+  grid = grid > 1024 ? 1024 : grid;
+  hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ per-ray bias tables from the master weights
+// What launch_ray_bias (nerfh_stages.hip) computes from the committed copies, here from the step's own parameters and the per-ray
+// inputs the training path already forms (nerfh_train.hip: ray_inputs).  64 outputs per table (netwidth 128).
+__global__ __launch_bounds__(128) void ray_bias_train_kernel(const float* __restrict__ w_dir, const float* __restrict__ b_dir, int ldw_dir,
+                                                             int kd, const float* __restrict__ dir_in, int ld_dir,
+                                                             const float* __restrict__ w_te, const float* __restrict__ b_te, int ldw_te,
+                                                             int nt, const float* __restrict__ t_in, int ld_t, size_t R,
+                                                             float* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_wd = sm;               // [kd][64]
+  float* s_wt = sm + kd * 64;     // [nt][64]
+  for (int i = threadIdx.x; i < kd * 64; i += blockDim.x) s_wd[i] = w_dir[size_t(i & 63) * ldw_dir + kWidth + (i >> 6)];
+  if (w_te)
+    for (int i = threadIdx.x; i < nt * 64; i += blockDim.x) s_wt[i] = w_te[size_t(i & 63) * ldw_te + kWidth + (i >> 6)];
+  __syncthreads();
+  const int tbl = threadIdx.x >> 6, f = threadIdx.x & 63;
+  const int mb = f >> 5, row = f & 31, hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+  const int slot = ((tbl * 2 + mb) * 2 + hh) * 16 + r;
+  for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
+    float acc = 0.f;
+    if (tbl == 0) {
+      acc = b_dir[f];
+      const float* in = dir_in + ray * ld_dir;
+      for (int jj = 0; jj < kd; ++jj) acc = fmaf(s_wd[jj * 64 + f], in[jj], acc);
+    } else if (w_te) {
+      acc = b_te[f];
+      const float* in = t_in + ray * ld_t;
+      for (int jj = 0; jj < nt; ++jj) acc = fmaf(s_wt[jj * 64 + f], in[jj], acc);
+    }
+    table[ray * kRayBiasFloats + slot] = acc;
+  }
+}
+hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw_dir, int kd, const float* dir_in, int ld_dir,
+                                 const float* w_te, const float* b_te, int ldw_te, int nt, const float* t_in, int ld_t, size_t R,
+                                 float* table, hipStream_t s) {
+  if (!R) return hipSuccess;
+  const size_t lds = size_t(kd + (w_te ? nt : 0)) * 64 * sizeof(float);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  const int grid = int(R < 512 ? R : 512);
+  hipLaunchKernelGGL(ray_bias_train_kernel, dim3(grid), dim3(128), lds, s, w_dir, b_dir, ldw_dir, kd, dir_in, ld_dir, w_te, b_te, ldw_te,
+                     nt, t_in, ld_t, R, table);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ per-ray sums of a stored gradient array
+// The columns of dir_encoding.0 / transient_encoding.0 beyond `final` multiply per-RAY inputs (direction encoding, embeddings):
+// their gradients need sum_samples G[p, :] per ray (models/nerfw.py:62-95).  One block per ray; fixed summation order.
+__global__ __launch_bounds__(256) void frag_ray_sum_kernel(const char* __restrict__ arr, int kc, const float* __restrict__ gscale, int Ns,
+                                                           float* __restrict__ out, int ldo) {
+  __shared__ float red[256];
+  const size_t ray = blockIdx.x;
+  const int nf = 16 * kc, groups = 256 / nf;
+  const int fl = threadIdx.x % nf, sg = threadIdx.x / nf;
+  const int c = fl >> 4, hh = (fl >> 3) & 1, jj = fl & 7;
+  float acc = 0.f;
+  if (sg < groups)
+    for (int smp = sg; smp < Ns; smp += groups) {
+      const size_t pt = ray * Ns + smp;
+      const size_t wt = pt >> 5;
+      const char* p = arr + (wt * kc + c) * kChunkBytes + (2 * (pt & 31) + hh) * 16 + jj * 2;
+      const float v = float(*reinterpret_cast<const _Float16*>(p)) + float(*reinterpret_cast<const _Float16*>(p + 1024));
+      acc += v / gscale[wt];
+    }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sg == 0) {
+    for (int k = 1; k < groups; ++k) acc += red[k * nf + fl];
+    const int slot = 8 * c + jj;
+    out[ray * ldo + 64 * (slot >> 5) + hidden_feature(hh, slot & 31)] = acc;
+  }
+}
+hipError_t launch_frag_ray_sum(const char* arr, int kc, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s) {
+  if (!R) return hipSuccess;
+  if (kc != 4 && kc != 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(frag_ray_sum_kernel, dim3(unsigned(R)), dim3(256), 0, s, arr, kc, gscale, Ns, out, ldo);
+  return hipGetLastError();
+}
+
+}  // namespace fused
+}  // namespace dfn

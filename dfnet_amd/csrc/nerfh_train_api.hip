@@ -12,6 +12,7 @@
 
 #include "../../include/dfnet_hip.h"
 #include "dfn_common.h"
+#include "nerfh_fused_train.h"
 #include "nerfh_handle.h"
 #include "nerfh_kernels.h"
 #include "nerfh_layout.h"
@@ -300,9 +301,23 @@ int check_train_args(dfn_nerfh_t h, int Nc, int Ni, const char* fn) {
 extern "C" int dfn_nerfh_train_param_count(void) { return kParamCount; }
 extern "C" const char* dfn_nerfh_train_param_name(int i) { return (i >= 0 && i < kParamCount) ? names()[i].c_str() : nullptr; }
 
+// netwidth 128 on the register-resident kernels: the fused chain of nerfh_fused_*.hip; otherwise (any other netwidth, or
+// dfn_nerfh_set_train_mode(h, DFN_TRAIN_EXACT)) the layer-by-layer exact-fp32 products below.
+static bool use_fused(dfn_nerfh_t h) { return fused::available(h) && !h->train_exact; }
+
+extern "C" int dfn_nerfh_set_train_mode(dfn_nerfh_t h, int mode) {
+  if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_train_mode: null handle");
+  if (mode != DFN_TRAIN_FUSED && mode != DFN_TRAIN_EXACT) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_train_mode: unknown mode %d", mode);
+  h->train_exact = mode == DFN_TRAIN_EXACT;
+  return DFN_OK;
+}
+
 extern "C" size_t dfn_nerfh_train_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni) {
   if (!h) return 0;
-  return carve_train(nullptr, dims_of(h->desc), n_rays ? n_rays : 1, Nc, Ni, true).total;
+  const size_t exact = carve_train(nullptr, dims_of(h->desc), n_rays ? n_rays : 1, Nc, Ni, true).total;
+  if (!fused::available(h)) return exact;
+  const size_t fz = fused::workspace_bytes(h, n_rays ? n_rays : 1, Nc, Ni);
+  return fz > exact ? fz : exact;   // either mode fits
 }
 
 extern "C" int dfn_nerfh_train_forward(dfn_nerfh_t h, const float* const* params, const float* rays_o, const float* rays_d,
@@ -315,6 +330,9 @@ extern "C" int dfn_nerfh_train_forward(dfn_nerfh_t h, const float* const* params
   if (!params || !rays_o || !rays_d || !hist || !rgb || !disp || !acc || !raw || !rgb0 || !disp0 || !acc0 || !z_std || !beta ||
       !workspace || (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_nerfh_train_forward: bad argument (hist_rows must be 1 or n_rays)");
+  if (use_fused(h))
+    return fused::train_forward(h, params, rays_o, rays_d, hist, hist_rows, n_rays, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u, rgb,
+                                disp, acc, raw, rgb0, disp0, acc0, z_std, beta, workspace, workspace_bytes, HS(stream));
   const Dims m = dims_of(h->desc);
   const TrainWs w = carve_train(static_cast<float*>(workspace), m, n_rays, Nc, Ni, true);
   if (w.total > workspace_bytes)
@@ -362,6 +380,9 @@ extern "C" int dfn_nerfh_train_backward(dfn_nerfh_t h, const float* const* param
     return set_error(DFN_ERR_ARG, "dfn_nerfh_train_backward: bad argument");
   for (int i = 0; i < kParamCount; ++i)
     if (!params[i] || !grads[i]) return set_error(DFN_ERR_ARG, "dfn_nerfh_train_backward: params[%d] / grads[%d] is null", i, i);
+  if (use_fused(h))
+    return fused::train_backward(h, params, hist, hist_rows, n_rays, Nc, Ni, noise, raw_noise_std, raw, g_rgb, g_rgb0, g_beta, g_tsigma,
+                                 g_tsigma_dense, grads, workspace, workspace_bytes, HS(stream));
   const Dims m = dims_of(h->desc);
   const TrainWs w = carve_train(static_cast<float*>(workspace), m, n_rays, Nc, Ni, true);
   if (w.total > workspace_bytes)

@@ -392,10 +392,14 @@ int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* para
 
 /* ------------------------------------------------------------------ NeRF-H training path
  * One optimisation step of run_nerf.py:50-66 — render(**render_kwargs_train) -> NerfWLoss -> loss.backward() — as
- * three calls: dfn_nerfh_train_forward, dfn_nerfw_loss, dfn_nerfh_train_backward.  Both networks run layer by layer
- * on exact-fp32 MFMA products over activations kept in the caller's workspace; the parameters are read IN PLACE
- * from the caller's fp32 device tensors (torch's master weights, row-major [out, in]) and the gradients are written
- * to the caller's gradient tensors, so an optimizer step needs no re-pack.  Works for any even netwidth.
+ * three calls: dfn_nerfh_train_forward, dfn_nerfw_loss, dfn_nerfh_train_backward.  The parameters are read from the
+ * caller's fp32 device tensors (torch's master weights, row-major [out, in]) and the gradients are written to the caller's
+ * gradient tensors, so an optimizer step needs no host round trip.  Two implementations behind the same calls:
+ *   DFN_TRAIN_FUSED (default at netwidth 128): both networks as register-resident chains on split-f16 MFMA products
+ *     (fp32-grade), forward and data-gradient; only the layer inputs / pre-activation gradients the WEIGHT gradients need
+ *     are stored (as pre-split MFMA operands) and streamed once through the weight-gradient kernel; the step's weights are
+ *     re-packed on the device at the start of the forward (csrc/nerfh_fused_*.hip);
+ *   DFN_TRAIN_EXACT (any even netwidth): layer by layer on exact-fp32 MFMA products over activations kept in the workspace.
  *
  * `params` / `grads`: HOST arrays of dfn_nerfh_train_param_count() DEVICE pointers in the order of
  * dfn_nerfh_train_param_name(i): "coarse.<key>" (24: xyz_encoding_1..8.0, xyz_encoding_final, dir_encoding.0,
@@ -405,6 +409,13 @@ int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* para
 int dfn_nerfh_train_param_count(void);
 const char* dfn_nerfh_train_param_name(int i);
 size_t dfn_nerfh_train_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni);
+/* Selects the implementation of the training step for this handle (the workspace size above covers both). */
+enum { DFN_TRAIN_FUSED = 0, DFN_TRAIN_EXACT = 1 };
+int dfn_nerfh_set_train_mode(dfn_nerfh_t h, int mode);
+/* Host-only consistency check of the fused step's tables for a netwidth-128 geometry (no device work): every parameter element
+ * the chain kernels read is packed exactly once per pass and every gradient element is written by exactly one accumulator of the
+ * weight-gradient stream (tests/test_host_logic.py).  DFN_OK or DFN_ERR_STATE with the first inconsistency in dfn_last_error(). */
+int dfn_nerfh_train_tables_selfcheck(const dfn_nerfh_desc* desc);
 
 /* models/rendering.py:245-337 render_rays with test_time=False (white_bkgd=False; lindisp per the handle's options) on caller rays
  * (run_nerf.py:50).  The reference's three random draws are INPUTS: t_rand [n_rays, Nc] = torch.rand (stratified

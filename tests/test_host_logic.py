@@ -431,3 +431,21 @@ def test_render_path_png_job_numbers_by_global_frame_index(tmp_path):
     from dfnet_amd import options
     ns = options.nerf_parser().parse_known_args([])[0]
     assert ns.precision == "f16x3" and ns.coarse_precision == "f16"
+
+
+def test_fused_training_tables_selfcheck():
+    """The fused NeRF-H training step (csrc/nerfh_fused_api.hip) ties the master parameter tensors to the chain kernels' staging units
+    and to the accumulators of the weight-gradient stream through host-built tables: every parameter element must be packed exactly
+    once per pass and every gradient element written exactly once.  Host-only (no device work)."""
+    import ctypes
+    from dfnet_amd import _lib
+    lib = _lib.load()
+
+    class Desc(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_int) for k in "depth width multires multires_views hist_bin dim_a dim_t n_vocab".split()]
+
+    for hist_bin, dim_a, dim_t in ((10, 5, 2), (8, 3, 1), (1, 1, 1)):
+        d = Desc(8, 128, 10, 4, hist_bin, dim_a, dim_t, 1000)
+        assert lib.dfn_nerfh_train_tables_selfcheck(ctypes.byref(d)) == 0, lib.dfn_last_error().decode()
+    d = Desc(8, 64, 10, 4, 10, 5, 2, 1000)
+    assert lib.dfn_nerfh_train_tables_selfcheck(ctypes.byref(d)) != 0   # netwidth 128 only
