@@ -195,11 +195,18 @@ BlobPlan plan_backward(bool fine, const Geo& g) {
 }
 
 // ---- weight-gradient jobs
-struct JobPlan { int garr, x0, x1; };
-const JobPlan kJobsFine[] = {{GA_L1, XA_PE, -1}, {GA_L2, XA_H1, -1}, {GA_L3, XA_H2, -1}, {GA_L4, XA_H3, -1}, {GA_L5, XA_PE, XA_H4},
-                             {GA_L6, XA_H5, -1}, {GA_L7, XA_H6, -1}, {GA_L8, XA_H7, -1}, {GA_CAT2, XA_H8, -1}, {GA_CAT, XA_FIN, -1},
-                             {GA_DRGB, XA_DE, -1}, {GA_T1, XA_T0, -1}, {GA_T2, XA_T1, -1}, {GA_T3, XA_T2, -1}, {GA_DTH, XA_T3, -1}};
-constexpr int kNumJobsFine = 15, kNumJobsCoarse = 11;
+// One job = one stored gradient array against one stored input array.  Layer 5 reads cat([pe, h4]): two jobs on the same gradients
+// (the encoding columns, then the h4 columns at weight column 63; the second without the bias sums).
+// (GA_CAT2 = [d final (chunks 0..7) ; d sigma_s (chunks 8, 9)] is read by two jobs as well, so that no job has more than 20 blocks:
+// five per wave of the stream kernel.)  gc0 / gkc: the chunks of the gradient array the job reads.
+struct JobPlan { int garr, gc0, gkc, x0; int col0; bool bias; };
+const JobPlan kJobsFine[] = {{GA_L1, 0, 8, XA_PE, 0, true}, {GA_L2, 0, 8, XA_H1, 0, true}, {GA_L3, 0, 8, XA_H2, 0, true}, {GA_L4, 0, 8, XA_H3, 0, true},
+                             {GA_L5, 0, 8, XA_PE, 0, true}, {GA_L5, 0, 8, XA_H4, kChXyz, false}, {GA_L6, 0, 8, XA_H5, 0, true}, {GA_L7, 0, 8, XA_H6, 0, true},
+                             {GA_L8, 0, 8, XA_H7, 0, true}, {GA_CAT2, 0, 8, XA_H8, 0, true}, {GA_CAT2, 8, 2, XA_H8, 0, true}, {GA_CAT, 0, 0, XA_FIN, 0, true},
+                             {GA_DRGB, 0, 2, XA_DE, 0, true},
+                             {GA_T1, 0, 4, XA_T0, 0, true}, {GA_T2, 0, 4, XA_T1, 0, true}, {GA_T3, 0, 4, XA_T2, 0, true}, {GA_DTH, 0, 2, XA_T3, 0, true}};
+constexpr int kNumJobsFine = 17, kNumJobsCoarse = 13;
+int job_kcg(const JobPlan& jp, bool fine) { return jp.gkc ? jp.gkc : (fine ? kGChunksFine : kGChunksCoarse)[jp.garr]; }   // GA_CAT: 8 fine / 4 coarse
 // G-side slot (hh, s) of array `garr` -> Linear + row
 Row g_row(int garr, bool fine, int hh, int s) {
   const int j = hidden_feature(hh, s & 31);   // feature inside a 64-wide (two M-block) vector
@@ -219,21 +226,20 @@ Row g_row(int garr, bool fine, int hh, int s) {
 }
 // X-side slot (hh, s) of the job's concatenated X chunks -> weight column
 int x_col(const JobPlan& jp, int hh, int s) {
-  if (jp.x1 >= 0) return s < 32 ? pe_xyz_feature(hh, s) : kChXyz + hidden_feature(hh, s - 32);   // layer 5: cat([pe, h4])
   if (jp.x0 == XA_PE) return pe_xyz_feature(hh, s);
-  return hidden_feature(hh, s);
+  return jp.col0 + hidden_feature(hh, s);
 }
-int job_kcx(const JobPlan& jp) { return kXChunks[jp.x0] + (jp.x1 >= 0 ? kXChunks[jp.x1] : 0); }
+int job_kcx(const JobPlan& jp) { return kXChunks[jp.x0]; }
 // destination map of one job: [nb_g * (nb_x + 1)][1024], index r * 64 + lane
 void job_map(const JobPlan& jp, bool fine, const Geo& g, std::vector<int32_t>& out) {
-  const int kcg = (fine ? kGChunksFine : kGChunksCoarse)[jp.garr], kcx = job_kcx(jp);
+  const int kcg = job_kcg(jp, fine), kcx = job_kcx(jp);
   const int nb_g = kcg / 2, nb_x = kcx / 2;
   for (int gb = 0; gb < nb_g; ++gb)
-    for (int xb = 0; xb <= nb_x; ++xb)
+    for (int xb = 0; xb < nb_x + (jp.bias ? 1 : 0); ++xb)
       for (int r = 0; r < 16; ++r)
         for (int lane = 0; lane < 64; ++lane) {
           const int m = mblock_row(lane >> 5, r), n = lane & 31;
-          const int sg = 8 * (2 * gb + (m >> 4)) + (m & 7), hg = (m >> 3) & 1;
+          const int sg = 8 * (jp.gc0 + 2 * gb + (m >> 4)) + (m & 7), hg = (m >> 3) & 1;
           const Row rw = g_row(jp.garr, fine, hg, sg);
           int32_t dst = -1;
           if (rw.row >= 0 && rw.row < rows_of(rw.layer)) {
@@ -398,38 +404,54 @@ size_t tail_scratch_floats(const Geo& g, size_t R) {
   }
   return best + 1024;
 }
-// job list of one network against a carved workspace; returns the number of workgroups it adds
-int make_jobs(bool fine, const NetWs& n, const State& st, size_t total_stage_bytes, float*& partial, WJob* jobs, int first_wg, int& n_jobs) {
+// Point chunking of one network's jobs: `target` workgroups per launch (a whole number of rounds of the 2 x CU resident
+// workgroups), shared among the jobs in proportion to the bytes they stream.  Depends on the batch shape only (deterministic).
+void plan_chunks(bool fine, size_t n_wt, int target, int* wpc, int* n_chunks) {
   const int* kcgs = fine ? kGChunksFine : kGChunksCoarse;
+  const int nj = fine ? kNumJobsFine : kNumJobsCoarse;
+  double total = 0;
+  for (int j = 0; j < nj; ++j) total += job_kcg(kJobsFine[j], fine) + job_kcx(kJobsFine[j]);
+  for (int j = 0; j < nj; ++j) {
+    const double share = (job_kcg(kJobsFine[j], fine) + job_kcx(kJobsFine[j])) / total;
+    long long c = (long long)(share * target);
+    if (c < 1) c = 1;
+    if (c > (long long)n_wt) c = (long long)n_wt;
+    wpc[j] = int((n_wt + c - 1) / c);
+    n_chunks[j] = int((n_wt + wpc[j] - 1) / wpc[j]);
+  }
+}
+constexpr int kStreamCus = 256;   // the chunking is sized for MI355X's 256 CUs (a shape constant: the sums must not depend on the device)
+int launch_target(bool fine) { return (fine ? 4 : 2) * kStreamCus; }   // fine: two rounds of 2 workgroups per CU, coarse: one
+// job list of one network against a carved workspace; returns the number of workgroups of the launch
+int make_jobs(bool fine, const NetWs& n, const State& st, float*& partial, WJob* jobs, int& n_jobs) {
+  const int* kcgs = fine ? kGChunksFine : kGChunksCoarse;
+  int wpc[kMaxJobs], nch[kMaxJobs];
+  plan_chunks(fine, n.n_wt, launch_target(fine), wpc, nch);
   int wgs = 0;
   for (int j = 0; j < (fine ? kNumJobsFine : kNumJobsCoarse); ++j) {
     const JobPlan& jp = kJobsFine[j];
     WJob& w = jobs[n_jobs++];
-    w.kcg = kcgs[jp.garr];
+    w.kcg = job_kcg(jp, fine);
+    w.g_stride = kcgs[jp.garr];
+    w.g_chunk0 = jp.gc0;
     w.kcx0 = kXChunks[jp.x0];
-    w.kcx1 = jp.x1 >= 0 ? kXChunks[jp.x1] : 0;
+    w.kcx1 = 0;
     w.g = n.g + n.g_off[jp.garr];
     w.x0 = n.x + n.x_off[jp.x0];
-    w.x1 = jp.x1 >= 0 ? n.x + n.x_off[jp.x1] : nullptr;
+    w.x1 = nullptr;
     w.gscale = n.gscale + size_t(jp.garr) * n.n_wt;
     w.nb_g = w.kcg / 2;
-    w.nb_x = (w.kcx0 + w.kcx1) / 2;
-    w.wt_per_chunk = wgrad_wt_per_chunk(w.kcg + w.kcx0 + w.kcx1, n.n_wt, total_stage_bytes);
-    w.n_chunks = int((n.n_wt + w.wt_per_chunk - 1) / w.wt_per_chunk);
-    w.first_wg = first_wg + wgs;
+    w.nb_x = w.kcx0 / 2;
+    w.has_bias = jp.bias ? 1 : 0;
+    w.wt_per_chunk = wpc[j];
+    w.n_chunks = nch[j];
+    w.first_wg = wgs;
     w.map_off = st.map_off[fine][j];
     w.partial = partial;
-    if (partial) partial += size_t(w.n_chunks) * w.nb_g * (w.nb_x + 1) * 1024;
+    if (partial) partial += size_t(w.n_chunks) * w.nb_g * (w.nb_x + w.has_bias) * 1024;
     wgs += w.n_chunks;
   }
   return wgs;
-}
-size_t stage_bytes_of(bool fine, size_t n_wt) {
-  const int* kcgs = fine ? kGChunksFine : kGChunksCoarse;
-  size_t b = 0;
-  for (int j = 0; j < (fine ? kNumJobsFine : kNumJobsCoarse); ++j)
-    b += size_t(kcgs[kJobsFine[j].garr] + job_kcx(kJobsFine[j])) * kChunkBytes * n_wt;
-  return b;
 }
 Ws carve(char* base, const dfn_nerfh_desc& d, size_t R, int Nc, int Ni) {
   Ws w{};
@@ -468,12 +490,11 @@ Ws carve(char* base, const dfn_nerfh_desc& d, size_t R, int Nc, int Ni) {
     WJob jobs[kMaxJobs];
     int nj = 0;
     float* part = nullptr;
-    const size_t tsb = stage_bytes_of(false, w.net[0].n_wt) + stage_bytes_of(true, w.net[1].n_wt);
     size_t floats = 0;
     for (int f = 0; f < 2; ++f) {
       nj = 0;
-      make_jobs(f, w.net[f], dummy, tsb, part, jobs, 0, nj);
-      for (int j = 0; j < nj; ++j) floats += size_t(jobs[j].n_chunks) * jobs[j].nb_g * (jobs[j].nb_x + 1) * 1024;
+      make_jobs(f, w.net[f], dummy, part, jobs, nj);
+      for (int j = 0; j < nj; ++j) floats += size_t(jobs[j].n_chunks) * jobs[j].nb_g * (jobs[j].nb_x + jobs[j].has_bias) * 1024;
     }
     w.partial_floats = floats;
     w.partial = takef(floats);
@@ -599,11 +620,10 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
     WgradArgs wa{};
     wa.n_jobs = 0;
     float* part = w.partial;
-    const size_t tsb = stage_bytes_of(false, w.net[0].n_wt) + stage_bytes_of(true, w.net[1].n_wt);
     // the two networks have different wave-tile counts: one launch each (n_wt is a launch constant), the fine one first
     for (int f = 1; f >= 0; --f) {
       wa.n_jobs = 0;
-      const int wgs = make_jobs(f, w.net[f], st, tsb, part, wa.job, 0, wa.n_jobs);
+      const int wgs = make_jobs(f, w.net[f], st, part, wa.job, wa.n_jobs);
       wa.n_wt = int(w.net[f].n_wt);
       CHECK_HIP(launch_wgrad_stream(wa, wgs, s), "train backward: weight-gradient stream");
       ReduceArgs ra{};

@@ -80,16 +80,21 @@ struct WJob {
   const float* gscale;     // [n_wt]
   float* partial;          // [n_chunks][n_blocks][1024]
   int kcg, kcx0, kcx1;
-  int nb_g, nb_x;          // 32-feature blocks on either side; blocks = nb_g x (nb_x + 1): the extra column block = bias sums
+  int g_stride;            // chunks per wave-tile of the G array (the job reads chunks [g_chunk0, g_chunk0 + kcg) of them)
+  int g_chunk0;
+  int nb_g, nb_x;          // 32-feature blocks on either side; blocks = nb_g x (nb_x + has_bias): the extra column block = bias sums
+  int has_bias;
   int wt_per_chunk, n_chunks;
   int first_wg;            // first workgroup of this job in the launch
   int map_off;             // offset (ints) of this job's destination map inside the map table
 };
-constexpr int kMaxJobs = 16;
+constexpr int kMaxJobs = 20;
 struct WgradArgs {
   WJob job[kMaxJobs];
   int n_jobs;
   int n_wt;
+  int debug_nt, debug_depth;
+  int debug_mode;          // 0; tuning aid (DFN_WGRAD_MODE): 1 = stream without the products, 2 = products without the stream
 };
 struct ReduceArgs {
   WJob job[kMaxJobs];
@@ -99,9 +104,7 @@ struct ReduceArgs {
 };
 hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, hipStream_t s);
 hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t s);
-constexpr uint32_t kWgradLdsBytes = 155648;   // staging ring of the stream kernel (152 KiB)
-// Points chunking of one job (deterministic: depends on the batch shape only).
-int wgrad_wt_per_chunk(int stage_chunks, size_t n_wt, size_t total_stage_bytes_all_jobs);
+constexpr uint32_t kWgradLdsBytes = 81920;    // staging ring of one stream workgroup (two per CU)
 
 // ---- per-step packing of the master weights into the chain kernels' staging units
 struct PackElem { uint32_t off; int32_t src; };    // f16 element: hi at blob + off, lo at + 1024; src = param << 20 | index, < 0: zero

@@ -13,6 +13,7 @@
 // the stream (4 bytes per stored element, read once): a 128 x 128 layer moves 32 KiB per 32 points against 120 MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "nerfh_fused_train.h"
 #include "nerfh_mlp_core.h"
@@ -23,7 +24,10 @@ namespace fused {
 namespace {
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int WAVES = 8, MAXB = 4;
+constexpr int WAVES = 4, MAXB = 5;   // two 4-wave workgroups per CU run unsynchronised: one's barrier / LDS waits under the other's MFMAs
+// LDS image of a stage: chunk c at c * kLdsChunk.  The 128-byte skew puts the two chunks of a 32-feature pair on different bank
+// halves: the two 16-lane groups of a transposed read then touch 2 x 128 distinct bytes of a 256-byte bank row (conflict-free).
+constexpr uint32_t kLdsChunk = kChunkBytes + 128;
 
 template <int OFF>
 DFN_DEV u32x2 ds_tr16(uint32_t addr) {
@@ -66,20 +70,48 @@ DFN_DEV void wait_vmcnt(int n) {   // s_waitcnt vmcnt(n), n wave-uniform (gfx9 e
   }
   asm volatile("" ::: "memory");
 }
+DFN_DEV void lds_dma_b128_nt(const void* gptr, const char* lds_dst) {   // streamed once: non-temporal
+  const uint32_t off = (uint32_t)(size_t)DFN_LDS_PTR(lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gptr), "s"(off) : "memory");
+}
 typedef const float __attribute__((address_space(4))) const_f32;
 DFN_DEV float scalar_f32(const float* p) { return *reinterpret_cast<const_f32*>(reinterpret_cast<uint64_t>(p)); }
 }  // namespace
 
-int wgrad_wt_per_chunk(int stage_chunks, size_t n_wt, size_t total_stage_bytes_all_jobs) {
-  // ~4 workgroups per CU over the whole launch, every workgroup the same number of bytes
-  const double target = double(total_stage_bytes_all_jobs) / 1024.0;
-  long long wpc = (long long)(target / (double(stage_chunks) * kChunkBytes) + 0.5);
-  if (wpc < 8) wpc = 8;
-  if (wpc > (long long)n_wt) wpc = (long long)n_wt;
-  return int(wpc);
+namespace {
+// Operands of one output block of one wave-tile: G chunk pair (A) and X chunk pair (B), both 16-point halves, hi | lo.
+struct BlockOps { Frag a0, a1, b0, b1; };
+DFN_DEV void issue_block(BlockOps& o, uint32_t ga, uint32_t xa) {
+  o.a0 = issue_frag<0>(ga);
+  o.a1 = issue_frag<16>(ga);
+  o.b0 = issue_frag<0>(xa);
+  o.b1 = issue_frag<16>(xa);
 }
+DFN_DEV void wait_block(BlockOps& o) {   // every LDS read issued so far has returned (the asm ties the registers to the wait)
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(o.a0.h0), "+v"(o.a0.h1), "+v"(o.a0.l0), "+v"(o.a0.l1), "+v"(o.a1.h0), "+v"(o.a1.h1), "+v"(o.a1.l0), "+v"(o.a1.l1),
+                 "+v"(o.b0.h0), "+v"(o.b0.h1), "+v"(o.b0.l0), "+v"(o.b0.l1), "+v"(o.b1.h0), "+v"(o.b1.h1), "+v"(o.b1.l0), "+v"(o.b1.l1)
+               :: "memory");
+}
+// hi*hi + hi*lo + lo*hi over the tile's 32 points, folded into the master accumulator at the tile's scale
+DFN_DEV void mma_block(const BlockOps& o, bool bias, float inv, f32x16& master) {
+  const half8 ones = {1, 1, 1, 1, 1, 1, 1, 1}, zeros = {0, 0, 0, 0, 0, 0, 0, 0};
+  const half8 ah0 = join(o.a0.h0, o.a0.h1), al0 = join(o.a0.l0, o.a0.l1), ah1 = join(o.a1.h0, o.a1.h1), al1 = join(o.a1.l0, o.a1.l1);
+  const half8 bh0 = bias ? ones : join(o.b0.h0, o.b0.h1), bl0 = bias ? zeros : join(o.b0.l0, o.b0.l1);
+  const half8 bh1 = bias ? ones : join(o.b1.h0, o.b1.h1), bl1 = bias ? zeros : join(o.b1.l0, o.b1.l1);
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) master[r] = fmaf(acc[r], inv, master[r]);
+}
+}  // namespace
 
-__global__ __launch_bounds__(WAVES * 64, 1) void wgrad_stream_kernel(WgradArgs a) {
+__global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,9 +120,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void wgrad_stream_kernel(WgradArgs a
   const WJob& jb = a.job[j];
   const int kcg = jb.kcg, kcx0 = jb.kcx0, kcx1 = jb.kcx1;
   const int kc_all = kcg + kcx0 + kcx1;
-  const uint32_t stage_bytes = uint32_t(kc_all) * kChunkBytes;
+  const uint32_t stage_bytes = uint32_t(kc_all) * kLdsChunk;
   int D = int(kWgradLdsBytes / stage_bytes);
   D = D > 4 ? 4 : D;
+  if (a.debug_depth >= 2 && a.debug_depth < D) D = a.debug_depth;
   const int chunk = int(blockIdx.x) - jb.first_wg;
   const int wt0 = chunk * jb.wt_per_chunk;
   int n_it = a.n_wt - wt0;
@@ -103,35 +136,37 @@ __global__ __launch_bounds__(WAVES * 64, 1) void wgrad_stream_kernel(WgradArgs a
     char* dst = smem + uint32_t(it % D) * stage_bytes;
     for (int i = wave; i < np; i += WAVES) {
       const char* src;
-      if (i < 2 * kcg) src = jb.g + (wt * size_t(2 * kcg) + i) * 1024;
+      if (i < 2 * kcg) src = jb.g + ((wt * size_t(jb.g_stride) + jb.g_chunk0) * 2 + i) * 1024;
       else if (i < 2 * (kcg + kcx0)) src = jb.x0 + (wt * size_t(2 * kcx0) + (i - 2 * kcg)) * 1024;
       else src = jb.x1 + (wt * size_t(2 * kcx1) + (i - 2 * (kcg + kcx0))) * 1024;
-      lds_dma_b128(src + lane * 16, dst + i * 1024);
+      if (a.debug_nt) lds_dma_b128_nt(src + lane * 16, dst + (i >> 1) * kLdsChunk + (i & 1) * 1024);
+      else lds_dma_b128(src + lane * 16, dst + (i >> 1) * kLdsChunk + (i & 1) * 1024);
     }
   };
-  for (int it = 0; it < D - 1 && it < n_it; ++it) issue(it);
+  for (int it = 0; it < D - 1 && it < n_it; ++it) issue(it);   // (debug_mode 2 still primes the ring once)
 
-  // this wave's output blocks: b = wave + 8 i -> (gb, xb); xb == nb_x: the bias column block (B operand = ones)
-  const int nbx1 = jb.nb_x + 1, nblk = jb.nb_g * nbx1;
+  // this wave's output blocks: a contiguous run of `per` blocks b = gb * (nb_x + 1) + xb; xb == nb_x: the bias column block
+  // (B operand = ones)
+  const int nbx1 = jb.nb_x + jb.has_bias, nblk = jb.nb_g * nbx1;
+  const int per = (nblk + WAVES - 1) / WAVES;
   const int g = lane >> 4, t = lane & 15;
-  const uint32_t lane_part = uint32_t(g & 1) * kChunkBytes + uint32_t(8 * (g >> 1) + (t >> 2)) * 32u + uint32_t(t & 3) * 8u;
+  const uint32_t lane_part = uint32_t(g & 1) * kLdsChunk + uint32_t(8 * (g >> 1) + (t >> 2)) * 32u + uint32_t(t & 3) * 8u;
   uint32_t goff[MAXB], xoff[MAXB];
   bool valid[MAXB], is_bias[MAXB];
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
-    const int b = wave + WAVES * i;
-    valid[i] = b < nblk;
+    const int b = wave * per + i;
+    valid[i] = i < per && b < nblk;
     const int gb = b / nbx1, xb = b - gb * nbx1;
     is_bias[i] = xb == jb.nb_x;
-    goff[i] = uint32_t(2 * gb) * kChunkBytes + lane_part;
-    xoff[i] = uint32_t(kcg + 2 * xb) * kChunkBytes + lane_part;   // X chunks follow the G chunks in a stage (x0 then x1)
+    goff[i] = uint32_t(2 * gb) * kLdsChunk + lane_part;
+    xoff[i] = is_bias[i] ? goff[i] : uint32_t(kcg + 2 * xb) * kLdsChunk + lane_part;   // X chunks follow the G chunks in a stage (x0 then x1)
   }
   f32x16 master[MAXB];
 #pragma unroll
   for (int i = 0; i < MAXB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) master[i][r] = 0.f;
-  const half8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 
   for (int it = 0; it < n_it; ++it) {
     int ahead = n_it - 1 - it;
@@ -139,47 +174,26 @@ __global__ __launch_bounds__(WAVES * 64, 1) void wgrad_stream_kernel(WgradArgs a
     wait_vmcnt(ahead * my_np);
     __builtin_amdgcn_s_barrier();   // stage `it` landed for every wave; every wave has left stage it - 1
     asm volatile("" ::: "memory");
-    if (it + D - 1 < n_it) issue(it + D - 1);
+    if (it + D - 1 < n_it && a.debug_mode != 2) issue(it + D - 1);
+    if (a.debug_mode == 1) continue;
     const float inv = 1.f / scalar_f32(jb.gscale + wt0 + it);
     const uint32_t sb = uint32_t(size_t(DFN_LDS_PTR(smem))) + uint32_t(it % D) * stage_bytes;
+    // block pipeline: while block i's MFMAs run, block i + 1's operands are read (transposed) into the other register set — the
+    // eight waves leave the barrier together, so without this every wave reads, then every wave multiplies
+    BlockOps S[2];
+    if (valid[0]) issue_block(S[0], sb + goff[0], sb + xoff[0]);
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
-      if (!valid[i]) continue;
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      Frag a0 = issue_frag<0>(sb + goff[i]), a1 = issue_frag<16>(sb + goff[i]);
-      if (!is_bias[i]) {
-        Frag b0 = issue_frag<0>(sb + xoff[i]), b1 = issue_frag<16>(sb + xoff[i]);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(a0.h0), "+v"(a0.h1), "+v"(a0.l0), "+v"(a0.l1), "+v"(a1.h0), "+v"(a1.h1), "+v"(a1.l0), "+v"(a1.l1),
-                       "+v"(b0.h0), "+v"(b0.h1), "+v"(b0.l0), "+v"(b0.l1), "+v"(b1.h0), "+v"(b1.h1), "+v"(b1.l0), "+v"(b1.l1)
-                     :: "memory");
-        const half8 ah0 = join(a0.h0, a0.h1), al0 = join(a0.l0, a0.l1), ah1 = join(a1.h0, a1.h1), al1 = join(a1.l0, a1.l1);
-        const half8 bh0 = join(b0.h0, b0.h1), bl0 = join(b0.l0, b0.l1), bh1 = join(b1.h0, b1.h1), bl1 = join(b1.l0, b1.l1);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc, 0, 0, 0);
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(a0.h0), "+v"(a0.h1), "+v"(a0.l0), "+v"(a0.l1), "+v"(a1.h0), "+v"(a1.h1), "+v"(a1.l0), "+v"(a1.l1)
-                     :: "memory");
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(a0.h0, a0.h1), ones, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(a1.h0, a1.h1), ones, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(a0.l0, a0.l1), ones, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(a1.l0, a1.l1), ones, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) master[i][r] = fmaf(acc[r], inv, master[i][r]);
+      if (!valid[i]) break;
+      wait_block(S[i & 1]);
+      if (i + 1 < MAXB && valid[i + 1]) issue_block(S[(i + 1) & 1], sb + goff[i + 1], sb + xoff[i + 1]);
+      mma_block(S[i & 1], is_bias[i], inv, master[i]);
     }
   }
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     if (!valid[i]) continue;
-    float* dst = jb.partial + (size_t(chunk) * nblk + (wave + WAVES * i)) * 1024 + lane;
+    float* dst = jb.partial + (size_t(chunk) * nblk + (wave * per + i)) * 1024 + lane;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[r * 64] = master[i][r];
   }
@@ -194,7 +208,17 @@ hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, hipStream_t s)
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_stream_kernel, dim3(total_wgs), dim3(WAVES * 64), kWgradLdsBytes, s, a);
+  WgradArgs b = a;
+  {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("DFN_WGRAD_MODE"); mode = e ? atoi(e) : 0; }
+    b.debug_mode = mode;
+    static int nt = -1, depth = -1;
+    if (nt < 0) { const char* e = getenv("DFN_WGRAD_NT"); nt = e ? atoi(e) : 1; }
+    if (depth < 0) { const char* e = getenv("DFN_WGRAD_D"); depth = e ? atoi(e) : 0; }
+    b.debug_nt = nt; b.debug_depth = depth;
+  }
+  hipLaunchKernelGGL(wgrad_stream_kernel, dim3(total_wgs), dim3(WAVES * 64), kWgradLdsBytes, s, b);
   return hipGetLastError();
 }
 
@@ -204,13 +228,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs a, int tot
   int q = blockIdx.x;
   int j = 0;
   for (; j < a.n_jobs; ++j) {
-    const int nq = a.job[j].nb_g * (a.job[j].nb_x + 1) * 4;
+    const int nq = a.job[j].nb_g * (a.job[j].nb_x + a.job[j].has_bias) * 4;
     if (q < nq) break;
     q -= nq;
   }
   if (j >= a.n_jobs) return;
   const WJob& jb = a.job[j];
-  const int nbx1 = jb.nb_x + 1, nblk = jb.nb_g * nbx1;
+  const int nbx1 = jb.nb_x + jb.has_bias, nblk = jb.nb_g * nbx1;
   const int b = q >> 2, e = (q & 3) * 256 + threadIdx.x;
   const int m = a.map[jb.map_off + b * 1024 + e];
   if (m < 0) return;
@@ -223,7 +247,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs a, int tot
 
 hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t s) {
   int total = 0;
-  for (int j = 0; j < a.n_jobs; ++j) total += a.job[j].nb_g * (a.job[j].nb_x + 1) * 4;
+  for (int j = 0; j < a.n_jobs; ++j) total += a.job[j].nb_g * (a.job[j].nb_x + a.job[j].has_bias) * 4;
   if (!total) return hipSuccess;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total), dim3(256), 0, s, a, total);
   return hipGetLastError();
