@@ -215,8 +215,92 @@ def add_sustained(roof, sus, precision):
         roof["frac_of_sustained_mfma"] = roof["achieved"] * mult / sus["random_operands_TFLOPs"]
 
 
+class GpuSampler:
+    """Package power (W) and shader clock (MHz) of ONE device, sampled on a thread while the timed region runs (what explains a
+    bent scaling curve: a node of eight MI355X at their 1.4 kW caps).  sysfs hwmon of the device's PCI function when it is there
+    (power1_average in microwatts, freq1_input in Hz), `rocm-smi -d i --json` otherwise; every field None when neither answers."""
+
+    def __init__(self, index, period=0.05):
+        import glob
+        import threading
+        self.index, self.period = index, period
+        self.power, self.sclk = [], []
+        self._stop = threading.Event()
+        self._hw = None
+        try:
+            p = torch.cuda.get_device_properties(index)
+            bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hw and (os.path.exists(hw[0] + "/power1_average") or os.path.exists(hw[0] + "/power1_input")):
+                self._hw = hw[0]
+        except Exception:   # noqa: BLE001 - the sampler is telemetry: never the reason a bench fails
+            self._hw = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read_sysfs(self):
+        def num(name):
+            try:
+                with open(f"{self._hw}/{name}") as f:
+                    return float(f.read().strip())
+            except OSError:
+                return None
+        pw = num("power1_average")
+        if pw is None:
+            pw = num("power1_input")
+        fq = num("freq1_input")
+        return (None if pw is None else pw / 1e6), (None if fq is None else fq / 1e6)
+
+    def _read_smi(self):
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showpower", "--showclocks", "--json"], capture_output=True,
+                                 text=True, timeout=5).stdout
+            card = next(iter(json.loads(out).values()))
+            pw = next((float(v) for k, v in card.items() if "power" in k.lower() and "max" not in k.lower()), None)
+            ck = next((v for k, v in card.items() if "sclk" in k.lower()), None)
+            fq = float("".join(ch for ch in str(ck).split("Mhz")[0] if ch.isdigit() or ch == ".")) if ck else None
+            return pw, fq
+        except Exception:   # noqa: BLE001
+            return None, None
+
+    def _run(self):
+        while not self._stop.is_set():
+            pw, fq = self._read_sysfs() if self._hw else self._read_smi()
+            if pw is not None:
+                self.power.append(pw)
+            if fq is not None:
+                self.sclk.append(fq)
+            self._stop.wait(self.period if self._hw else 0.5)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def means(self):
+        m = lambda v: (sum(v) / len(v)) if v else float("nan")
+        return m(self.power), m(self.sclk), float(len(self.power))
+
+
+def per_rank_record(stats, gathered_bytes):
+    """The N-rank run explained: per-rank render / gather seconds and mean clock / power over the timed region."""
+    cols = ("render_s", "gather_s", "power_w", "sclk_mhz", "samples")
+    rec = {}
+    for i, c in enumerate(cols[:4]):
+        v = [float(x) for x in stats[:, i]]
+        ok = [x for x in v if x == x]
+        rec[c] = {"per_rank": [None if x != x else round(x, 5) for x in v], "min": min(ok) if ok else None, "max": max(ok) if ok else None,
+                  "mean": sum(ok) / len(ok) if ok else None}
+    rec["samples_per_rank"] = [int(x) for x in stats[:, 4]]
+    rec["gathered_bytes"] = int(gathered_bytes)
+    return rec
+
+
 def timed_render(E, lib, precision, poses, hist, rgbs, disps, acc, K, Wm, world=1, gather=None):
-    """Wm untimed + K timed frames; returns (seconds for the K frames, max over ranks; per-kernel HIP-event averages)."""
+    """Wm untimed + K timed frames; returns (seconds for the K frames, max over ranks; per-kernel HIP-event averages; [world, 5]
+    per-rank record: this rank's render seconds, gather seconds, mean package power, mean shader clock, sample count)."""
     from dfnet_amd import dist as ddist
     nf = poses.shape[0]
 
@@ -226,24 +310,30 @@ def timed_render(E, lib, precision, poses, hist, rgbs, disps, acc, K, Wm, world=
 
     for k in range(Wm):
         step(k)
-    if ddist.active() and gather is not None:  # warm the collective too: communicator set-up AND the root's receive buffers (the
-        gather()                               # caching allocator then serves the timed gather without a fresh hipMalloc)
+    if ddist.active() and gather is not None:  # warm the collective too: communicator set-up (the root's receive buffers exist already)
+        gather()
     torch.cuda.synchronize()
     ddist.barrier()
     lib.dfn_profile_enable(1)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(K):
-        step(k)
-    if ddist.active() and gather is not None:
-        gather()
-    torch.cuda.synchronize()
-    ddist.barrier()
-    dt = time.perf_counter() - t0
+    with GpuSampler(rgbs.device.index or 0) as smp:
+        t0 = time.perf_counter()
+        for k in range(K):
+            step(k)
+        torch.cuda.synchronize()
+        t_render = time.perf_counter() - t0
+        if ddist.active() and gather is not None:
+            gather()
+            torch.cuda.synchronize()
+        t_gather = time.perf_counter() - t0 - t_render
+        ddist.barrier()
+        dt = time.perf_counter() - t0
     dt = ddist.max_over_ranks(dt, rgbs.device)
     prof = read_profile(lib)
     lib.dfn_profile_enable(0)
-    return dt, prof
+    pw, ck, ns = smp.means()
+    stats = ddist.all_gather_floats([t_render, t_gather, pw, ck, ns], rgbs.device)
+    return dt, prof, stats
 
 
 def mlp_roofline(prof, K, precision, value_per_gpu):
@@ -660,16 +750,25 @@ def dry_main(args, rank, world):
     n_frames = K * world
     lo, hi = ddist.frame_block(n_frames, rank, world)
     h, w = 6, 8
-    rgbs = torch.stack([torch.full((h, w, 3), float(lo + k)) for k in range(K)])
+    outs, (rgbs, disps) = ddist.root_buffers([(h, w, 3), (h, w)], n_frames, dev)
     ddist.barrier()
     t0 = time.perf_counter()
-    all_rgb = ddist.gather_frames(rgbs, n_frames)
+    for k in range(K):   # the "render": frame lo + k filled with its global index
+        rgbs[k].fill_(float(lo + k))
+        disps[k].fill_(float(lo + k) + .5)
+    t_render = time.perf_counter() - t0
+    (all_rgb, all_disp), _ = ddist.gather_frames_direct([rgbs, disps], n_frames, outs=outs)
+    t_gather = time.perf_counter() - t0 - t_render
     ddist.barrier()
     dt = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+    stats = ddist.all_gather_floats([t_render, t_gather, float("nan"), float("nan"), 0.], dev)
     if rank == 0:
-        ok = bool((all_rgb[:, 0, 0, 0] == torch.arange(n_frames, dtype=torch.float32)).all())
+        ok = bool((all_rgb[:, 0, 0, 0] == torch.arange(n_frames, dtype=torch.float32)).all()) and \
+            bool((all_disp[:, 0, 0] == torch.arange(n_frames, dtype=torch.float32) + .5).all())
+        in_place = world == 1 or all_rgb.data_ptr() == outs[0].data_ptr()
         print(json.dumps({"metric": "dry run (no GPU work)", "value": world * K * h * w / dt, "unit": "rays/s", "n_gpus": world,
                           "steps": K, "warmup": args.warmup, "scaling": "weak", "frames_gathered_in_order": ok,
+                          "received_in_place": bool(in_place), "ranks": per_rank_record(stats, ddist.gathered_bytes([rgbs, disps], n_frames)),
                           "data": "synthetic", "dtype": "none"}), flush=True)
 
 
@@ -710,14 +809,14 @@ def main():
     lo, _ = ddist.frame_block(n_frames, rank, world)
     poses = torch.stack([torch.from_numpy(syn.orbit_pose(lo + k, n_frames)) for k in range(K)]).to(dev)
     hist = torch.from_numpy(syn.HIST_IDX).to(dev)
-    rgbs = torch.empty(K, H, W, 3, device=dev)
-    disps = torch.empty(K, H, W, device=dev)
+    # rank 0 renders into its block of the final [n_frames, ...] tensors; the gather receives the peers' blocks in place
+    outs, (rgbs, disps) = ddist.root_buffers([(H, W, 3), (H, W)], n_frames, dev)
     acc = torch.empty(H, W, device=dev)
 
     def gather():
-        ddist.gather_frames_packed([rgbs, disps], n_frames)   # one collective: rgb + disp side by side per frame
+        ddist.gather_frames_direct([rgbs, disps], n_frames, outs=outs)   # one grouped exchange: every peer sends rgb + disp to rank 0
 
-    dt, prof = timed_render(E, lib, args.precision, poses, hist, rgbs, disps, acc, K, Wm, world, gather)
+    dt, prof, stats = timed_render(E, lib, args.precision, poses, hist, rgbs, disps, acc, K, Wm, world, gather)
 
     if rank == 0:
         rays = H * W
@@ -738,9 +837,10 @@ def main():
                        "rays_per_step_per_gpu": rays, "precision": PREC_TEXT[args.precision],
                        "precision_gate": PREC_GATE[args.precision],
                        "parallelism": f"frames sharded over {world} GPU(s), gather at end",
-                       "collectives": ("RCCL gather of rgb + disp inside the timed region" + (" (forced at world size 1)" if world == 1 else ""))
+                       "collectives": ("one grouped RCCL send / receive batch of rgb + disp into rank 0's final tensors, inside the timed region" + (" (forced at world size 1: padded gather)" if world == 1 else ""))
                                       if ddist.active() else "none (one rank)"},
             "roofline": roof,
+            "ranks": per_rank_record(stats, ddist.gathered_bytes([rgbs, disps], n_frames)),
         }
         if world == 1 and not args.no_extras:
             sus = sustained_mfma(lib)
@@ -759,7 +859,7 @@ def main():
             for prec, k2, w2 in (("f16x3", max(2, min(K, 6)), 1), ("f32", 2, 1), ("f16", max(2, min(K, 10)), 2)):
                 if prec == args.precision:
                     continue
-                dt2, prof2 = timed_render(E, lib, prec, poses, hist, rgbs, disps, acc, k2, w2)
+                dt2, prof2, _ = timed_render(E, lib, prec, poses, hist, rgbs, disps, acc, k2, w2)
                 v2 = k2 * rays / dt2
                 precs[prec] = {"value": v2, "unit": "rays/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2, "warmup": w2,
                                "arithmetic": PREC_TEXT[prec], "roofline": mlp_roofline(prof2, k2, prec, v2)}
@@ -773,7 +873,7 @@ def main():
                 E.set_render_options(coarse_f16=True)
                 try:
                     k2 = max(2, min(K, 6))
-                    dt2, prof2 = timed_render(E, lib, "f16x3", poses, hist, rgbs, disps, acc, k2, 1)
+                    dt2, prof2, _ = timed_render(E, lib, "f16x3", poses, hist, rgbs, disps, acc, k2, 1)
                     v2 = k2 * rays / dt2
                     precs["f16x3_fine_f16_coarse"] = {
                         "value": v2, "unit": "rays/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2, "warmup": 1,

@@ -112,7 +112,9 @@ DFN_DEV float rcp_nr(float x) {
   return r * fmaf(-x, r, 2.f);
 }
 DFN_DEV float softplus_hw(float v) { return v > 20.f ? v : log1pf(exp_hw(v)); }
-DFN_DEV float sigmoid_hw(float v) { return rcp_nr(1.f + exp_hw(-v)); }
+// (the exponent is clamped: beyond e^80 the sum is inf, and rcp_nr(inf) = 0 x fma(-inf, 0, 2) = NaN where sigmoid is 0 — a single
+// saturated colour logit would poison its pixel; with the clamp a logit below -80 gives 1 / (1 + e^80) = 1.8e-35)
+DFN_DEV float sigmoid_hw(float v) { return rcp_nr(1.f + exp_hw(fminf(-v, 80.f))); }
 template <bool FAST> DFN_DEV float act_softplus(float v) { return FAST ? softplus_fast(v) : softplus(v); }
 template <bool FAST> DFN_DEV float act_sigmoid(float v) { return FAST ? sigmoid_fast(v) : sigmoid(v); }
 

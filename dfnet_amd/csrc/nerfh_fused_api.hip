@@ -263,7 +263,7 @@ namespace fused {
 struct State {
   DevBlob blob[2][2];      // [coarse / fine][forward / backward]
   int32_t* map = nullptr;  // destination maps: coarse jobs then fine jobs
-  int map_off[2][16] = {};
+  int map_off[2][kMaxJobs] = {};
 };
 }  // namespace fused
 }  // namespace dfn

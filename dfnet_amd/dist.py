@@ -1,6 +1,6 @@
 """Multi-GPU sharding of a render_path batch: one process per GPU, NeRF-H weights replicated,
-frames block-partitioned over ranks, ONE gather of rgb+disp(+per-frame errors) at the end (gather_frames_packed: RCCL over
-xGMI when the backend is "nccl"; "gloo" on CPU for tests).
+frames block-partitioned over ranks, ONE gather of rgb+disp(+per-frame errors) at the end (gather_frames_direct: a grouped
+send / receive batch into rank 0's final tensors, RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for tests).
 
 Replaces the serial `for i, c2w in enumerate(render_poses)` loop of
 /root/reference/script/models/rendering.py:420-452 — the reference has no collective at all.
@@ -94,6 +94,84 @@ def gather_frames_packed(tensors, n_frames, dst=0):
         return [None] * len(tensors)
     parts = torch.split(out, widths, 1)
     return [p.reshape((n_frames,) + tuple(t.shape[1:])) for p, t in zip(parts, tensors)]
+
+
+def root_buffers(tails, n_frames, device, dst=0):
+    """Where a rank renders its frames so that the end gather needs no staging copy: rank `dst` allocates the FINAL
+    [n_frames, ...] tensors and renders into its own block's views; every other rank gets plain local tensors.
+    tails: per-frame shapes, e.g. [(H, W, 3), (H, W), ()].  Returns (outs | None, local tensors)."""
+    rank, world = rank_world()
+    lo, hi = frame_block(n_frames, rank, world)
+    if rank == dst and active() and world > 1:
+        outs = [torch.empty((n_frames,) + tuple(t), device=device) for t in tails]
+        return outs, [o[lo:hi] for o in outs]
+    return None, [torch.empty((hi - lo,) + tuple(t), device=device) for t in tails]
+
+
+def gather_frames_direct(tensors, n_frames, dst=0, outs=None, extra=None):
+    """The end gather as ONE grouped point-to-point exchange: rank `dst` posts a receive for every peer's block straight into
+    views of the final [n_frames, ...] tensors (`outs`, root_buffers(); allocated here when None) and every peer sends its
+    local tensors as they are — no padding to a common length, no packing, no concatenation: the root holds each frame once.
+    On the nccl backend the batch is one ncclGroup of sends / receives (every peer writes over its own xGMI link to the root);
+    gloo runs the same operations one by one.  `extra`: an optional small per-rank float tensor (range flags, timings) gathered
+    in the same batch -> returned as [world, len] on rank dst.  Returns (list of full tensors | list of None, extras | None).
+    A forced one-rank group (DFN_FORCE_COLLECTIVES) has no peer to send to: it runs the padded dist.gather of gather_frames so
+    that the communicator is still exercised."""
+    tensors = list(tensors)
+    if not active():
+        return tensors, (None if extra is None else extra[None])
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        full = [gather_frames(t, n_frames, dst) for t in tensors]
+        return full, (None if extra is None else gather_frames(extra[None], 1, dst))
+    sizes = [frame_block(n_frames, r, world) for r in range(world)]
+    ops, ext = [], None
+    if rank == dst:
+        if outs is None:
+            outs = [t.new_empty((n_frames,) + tuple(t.shape[1:])) for t in tensors]
+        lo, hi = sizes[dst]
+        if extra is not None:
+            ext = extra.new_empty((world,) + tuple(extra.shape))
+            ext[dst].copy_(extra)
+        for t, o in zip(tensors, outs):
+            if hi > lo and o[lo:hi].data_ptr() != t.data_ptr():
+                o[lo:hi].copy_(t)
+        for r, (a, b) in enumerate(sizes):   # per peer: its tensors in order, then its extras — the order the peer sends them in
+            if r == dst:
+                continue
+            if b > a:
+                ops += [dist.P2POp(dist.irecv, o[a:b], r) for o in outs]
+            if extra is not None:
+                ops.append(dist.P2POp(dist.irecv, ext[r], r))
+    else:
+        if tensors[0].shape[0] > 0:
+            ops += [dist.P2POp(dist.isend, t.contiguous(), dst) for t in tensors]
+        if extra is not None:
+            ops.append(dist.P2POp(dist.isend, extra.contiguous(), dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != dst:
+        return [None] * len(tensors), None
+    return outs, ext
+
+
+def gathered_bytes(tensors, n_frames, dst=0):
+    """Bytes that cross links in gather_frames_direct(tensors): every frame not owned by rank dst."""
+    rank, world = rank_world()
+    lo, hi = frame_block(n_frames, dst, world)
+    per_frame = sum(int(torch.Size(t.shape[1:]).numel()) * t.element_size() for t in tensors)
+    return (n_frames - (hi - lo)) * per_frame
+
+
+def all_gather_floats(values, device):
+    """[world, len(values)] float64 tensor of every rank's small record (timings, clocks); world 1: the record itself."""
+    v = torch.tensor([list(values)], dtype=torch.float64, device=device)
+    if not active():
+        return v.cpu()
+    out = [torch.empty_like(v[0]) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, v[0])
+    return torch.stack(out).cpu()
 
 
 def data_parallel_rounds(n_items, rank, world):

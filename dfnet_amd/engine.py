@@ -83,6 +83,16 @@ class NerfHEngine:
         are not the network's output (render with precision='f32')."""
         check(self.lib.dfn_nerfh_range_status(self.handle, None, current_stream()), "NeRF-H range guard")
 
+    def raise_range(self, flags, where=""):
+        """The range guard's error for flags already fetched with range_flags() (render_path carries them through its gather so that
+        every rank leaves the collective before anyone raises)."""
+        if flags:
+            narrow = "f16" if flags & 1 else "split-f16"
+            why = ("an f16 layer output overflowed to inf: |activation| > 65504" if flags & 1
+                   else "a split-f16 hi half saturated: |activation| >= 4094")
+            raise _lib.DfnError(f"NeRF-H range guard ({where}): activations left the range of the {narrow} arithmetic ({why}); the frames "
+                                "rendered since the last check are not the network's output: render them with precision='f32'")
+
     def _prec(self, precision):
         return _lib.PRECISIONS[precision or self.precision]
 

@@ -362,9 +362,9 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
     rank, world = ddist.rank_world()
     lo, hi = ddist.frame_block(N, rank, world)
     n_loc = hi - lo
-    rgbs = torch.empty(n_loc, H, W, 3, device=dev)
-    disps = torch.empty(n_loc, H, W, device=dev)
-    mse = torch.zeros(n_loc, device=dev)
+    # rank 0 renders straight into its block of the final [N, ...] tensors: the end gather receives the other blocks in place
+    outs, (rgbs, disps, mse) = ddist.root_buffers([(H, W, 3), (H, W), ()], N, dev)
+    mse.zero_()
     gt_one = None
     if gt_imgs is not None and single_gt_img:
         gt_one = torch.as_tensor(np.asarray(gt_imgs), dtype=torch.float32).to(dev)
@@ -400,16 +400,35 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
         t_post += time.time() - tp
     torch.cuda.synchronize()
     t_render = time.time() - t0
-    _engine_of(render_kwargs).check_range()   # loud, not clamped or non-finite frames, if a narrow arithmetic mode overflowed
-    all_rgb, all_disp, all_mse = ddist.gather_frames_packed([rgbs, disps, mse], N)   # the path's ONE collective
+    # The range guard of the narrow arithmetic modes travels WITH the gather (one more small receive per peer in the same batch):
+    # a rank that raised before the collective would leave the others waiting in it.  Every rank learns its own flags, rank 0
+    # everybody's; the errors are raised after the collective and after the PNG pool has been drained.
+    eng_h = _engine_of(render_kwargs)
+    flags = torch.tensor([float(eng_h.range_flags())], device=dev)
+    tg = time.time()
+    try:
+        (all_rgb, all_disp, all_mse), all_flags = ddist.gather_frames_direct([rgbs, disps, mse], N, outs=outs, extra=flags)   # the path's ONE collective
+        torch.cuda.synchronize()
+    finally:
+        t_gather = time.time() - tg
+        tw = time.time()
+        errs = []
+        for jb in jobs:
+            try:
+                jb.result()
+            except Exception as e:   # noqa: BLE001 - re-raised below, after the pool is shut down
+                errs.append(e)
+        if pool is not None:
+            pool.shutdown(wait=True)
+        t_tail = time.time() - tw
+    if errs:
+        raise errs[0]
+    bad = int(flags.item()) if all_flags is None else int(all_flags.max().item())
+    if bad:
+        eng_h.raise_range(bad, where=f"render_path: frames {lo}..{hi - 1} of rank {rank}" if all_flags is None else
+                          "render_path: ranks " + ", ".join(str(r) for r in range(all_flags.shape[0]) if all_flags[r].item()))
     if gt_imgs is None:
         all_mse = None
-    tw = time.time()
-    for jb in jobs:
-        jb.result()   # re-raises a failed write
-    if pool is not None:
-        pool.shutdown(wait=True)
-    t_tail = time.time() - tw
     if rank != 0:
         return None, None
     rgbs = all_rgb.cpu().numpy()
@@ -419,7 +438,8 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
     if all_mse is not None:
         psnr = -10. * np.log10(all_mse.cpu().numpy())
         print("Mean PSNR of this run is:", np.mean(psnr, 0))
-    render_path.last_timing = {"render_s": t_render, "post_launch_s": t_post, "png_tail_s": t_tail, "frames": N, "world": world}
+    render_path.last_timing = {"render_s": t_render, "post_launch_s": t_post, "gather_s": t_gather, "png_tail_s": t_tail, "frames": N, "world": world,
+                               "gathered_bytes": ddist.gathered_bytes([rgbs, disps, mse], N)}
     return rgbs, disps
 
 

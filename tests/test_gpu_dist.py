@@ -22,6 +22,12 @@ dev = torch.device("cuda", local)
 frames = torch.arange(5, dtype=torch.float32, device=dev)[:, None, None, None].expand(5, 6, 8, 3).contiguous() + 0.25
 out = ddist.gather_frames(frames, 5)                      # a real RCCL gather (not the world-1 early-out)
 assert out is not frames and out.shape == frames.shape and torch.equal(out, frames)
+# the direct form of render_path / bench.py in the one-rank group (falls back to the padded gather: no peer to send to) + its record
+outs, (v_rgb, v_err) = ddist.root_buffers([(6, 8, 3), ()], 5, dev)
+v_rgb.copy_(frames); v_err.copy_(torch.arange(5, device=dev, dtype=torch.float32))
+(d_rgb, d_err), extra = ddist.gather_frames_direct([v_rgb, v_err], 5, outs=outs, extra=torch.tensor([2.0], device=dev))
+assert torch.equal(d_rgb, frames) and torch.equal(d_err, v_err) and extra.shape == (1, 1) and float(extra[0, 0]) == 2.0
+assert ddist.all_gather_floats([1.0, 2.0], dev).tolist() == [[1.0, 2.0]]
 p = torch.nn.Parameter(torch.ones(1 << 20, device=dev)); p.grad = torch.full_like(p, 3.0)
 ddist.allreduce_gradients([p]); assert float(p.grad.mean()) == 3.0
 ddist.allreduce_gradients([p], contributors=1); assert float(p.grad.mean()) == 3.0
@@ -55,3 +61,8 @@ def test_bench_under_torchrun_with_rccl_gather(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 1e5
     assert "forced" in line["config"]["collectives"] and line["dtype"] == "f16x3"
+    # the per-rank record that will explain the N-GPU runs: render / gather seconds, package power and shader clock over the timed region
+    ranks = line["ranks"]
+    assert len(ranks["render_s"]["per_rank"]) == 1 and ranks["render_s"]["max"] > 0 and ranks["gather_s"]["max"] >= 0
+    assert ranks["gathered_bytes"] == 0   # one rank: every frame is the root's own
+    assert ranks["samples_per_rank"][0] > 0 and 100 < ranks["power_w"]["mean"] < 1600 and 300 < ranks["sclk_mhz"]["mean"] < 2600, ranks

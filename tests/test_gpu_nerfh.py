@@ -126,6 +126,32 @@ def test_mlp_fine(scene, prec, tol, n_rays, Nf, per_ray_hist):
         assert relmax(got[..., ch], ref[..., ch]) < tol, ch
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
+def test_saturated_head_logits_stay_finite(prec):
+    """Colour heads with logits of -120 .. +100 (biases pushed out): torch.sigmoid gives 0 / 1 there; the hardware-transcendental forms
+    of the split-f16 / f16 kernels must too (1 / (1 + e^x) through v_rcp + a Newton step returned NaN beyond e^88, poisoning the
+    pixel)."""
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    fw = {k: v.copy() for k, v in fw.items()}
+    fw["static_rgb.0.bias"][:] = np.array([-100., -89., 100.], np.float32)
+    fw["transient_rgb.0.bias"][:] = np.array([89., -95., -120.], np.float32)
+    E = eng.NerfHEngine().load_numpy(cw, fw, ea, et)
+    g = torch.Generator().manual_seed(3)
+    n, Nf = 33, 40
+    o = torch.rand(n, 3, generator=g) - .5
+    d = torch.randn(n, 3, generator=g) * .7
+    v = d / d.norm(dim=-1, keepdim=True)
+    z = torch.sort(torch.rand(n, Nf, generator=g) * 2.5, -1)[0]
+    hist = T(syn.HIST_IDX)[None]
+    with torch.no_grad():
+        ref = orc.query_fine(tt(fw), T(ea), T(et), o[:, None] + d[:, None] * z[..., None], v, hist.expand(n, 10))
+    got = E.mlp_fine(o.to(DEV), d.to(DEV), v.to(DEV), hist.to(DEV), z.to(DEV), precision=prec).cpu()
+    assert bool(torch.isfinite(got).all())
+    assert float((got - ref).abs().max()) < (1e-3 if prec == "f16" else 2e-5)   # saturated channels: 0 or 1 to 1e-30
+    rgb, disp, acc = E.render_rays(o.to(DEV), d.to(DEV), hist.to(DEV), 16, 24, 0., 2.5, precision=prec)[:3]
+    assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(disp).all())
+
+
 def test_sample_fine_vs_oracle(scene):
     """Fused sampler vs oracle.  Inverse-CDF sampling is ill-conditioned where the pdf is ~1e-5 (a last-ulp
     difference in the cdf moves a sample by ~1% of a bin), so rows with (near-)empty bins are checked by bin

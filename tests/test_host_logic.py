@@ -124,6 +124,19 @@ if rank == 0:
     print("GATHER_OK", n_frames)
 else:
     assert out is None and p_rgb is None and p_disp is None and p_err is None
+# the direct form (render_path / bench.py): rank 0 owns the FINAL tensors, renders into its block's views and receives every peer's
+# block in place — one grouped send / receive batch, no padding, no packing, plus a small per-rank record in the same batch
+outs, (v_rgb, v_disp, v_err) = ddist.root_buffers([(3, 4, 3), (3, 4), ()], n_frames, torch.device("cpu"))
+v_rgb.copy_(local); v_disp.copy_(disp); v_err.copy_(err)
+(d_rgb, d_disp, d_err), extra = ddist.gather_frames_direct([v_rgb, v_disp, v_err], n_frames, outs=outs, extra=torch.tensor([float(rank) + .25]))
+if rank == 0:
+    assert d_rgb.data_ptr() == outs[0].data_ptr() and v_rgb.data_ptr() == outs[0][lo:hi].data_ptr()   # received / rendered in place
+    assert torch.equal(d_rgb, out) and torch.equal(d_disp, p_disp) and torch.equal(d_err, p_err)
+    assert extra.shape == (world, 1) and [float(x) for x in extra[:, 0]] == [r + .25 for r in range(world)]
+    assert ddist.gathered_bytes([v_rgb, v_disp, v_err], n_frames) == (n_frames - (hi - lo)) * (36 + 12 + 1) * 4
+    print("DIRECT_OK", n_frames)
+else:
+    assert d_rgb is None and d_disp is None and d_err is None and extra is None and outs is None
 ddist.barrier()
 torch.distributed.destroy_process_group()
 '''
@@ -138,7 +151,7 @@ def test_gather_frames_gloo_world2(tmp_path, n_frames):
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(n_frames)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert f"GATHER_OK {n_frames}" in r.stdout
+    assert f"GATHER_OK {n_frames}" in r.stdout and f"DIRECT_OK {n_frames}" in r.stdout
 
 
 def test_pose_error_metrics_match_scipy():
@@ -381,6 +394,13 @@ def test_bench_entry_point_two_ranks_gloo(launcher):
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["frames_gathered_in_order"] is True and rec["value"] > 0
+    # what will explain the 8-GPU number: per-rank render / gather seconds, clocks and power, bytes gathered; frames received in place
+    ranks = rec["ranks"]
+    assert rec["received_in_place"] is True and ranks["gathered_bytes"] == 3 * 6 * 8 * 4 * 4
+    for k in ("render_s", "gather_s", "power_w", "sclk_mhz"):
+        assert len(ranks[k]["per_rank"]) == 2
+    assert ranks["render_s"]["min"] <= ranks["render_s"]["mean"] <= ranks["render_s"]["max"]
+    assert ranks["power_w"]["per_rank"] == [None, None]   # no device to sample in the dry run
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
