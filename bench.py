@@ -184,15 +184,28 @@ def read_profile(lib):
     return out
 
 
+def load_probe():
+    """tools/probe/libdfn_probe.so: the bench-only helper library with the bare MFMA loop (built by `make -C dfnet_amd/csrc`, NOT part
+    of libdfnet_hip.so)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "probe", "libdfn_probe.so")
+    lib = ctypes.CDLL(path)
+    lib.dfn_probe_mfma_rate.restype = ctypes.c_int
+    lib.dfn_probe_mfma_rate.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+    lib.dfn_probe_last_error.restype = ctypes.c_char_p
+    return lib
+
+
 def sustained_mfma(lib, stream=None, seconds=0.4):
     """What the matrix pipe of THIS box sustains (dfn_probe_mfma_rate: nothing but independent dense-f16 MFMAs on every SIMD): with
     zero operands the nominal peak, with random operands the rate once power management has settled the clock.  The MLP kernels'
     MFMA work (x3 for split-f16: three f16 MFMAs per product) is priced against the random-operand figure as `frac_of_sustained`."""
-    from dfnet_amd import _lib
+    probe = load_probe()
     out = {}
     for key, rnd in (("zero_operands_TFLOPs", 0), ("random_operands_TFLOPs", 1)):
         tf = ctypes.c_double()
-        _lib.check(lib.dfn_probe_mfma_rate(rnd, float(seconds), ctypes.byref(tf), None), "dfn_probe_mfma_rate")
+        rc = probe.dfn_probe_mfma_rate(rnd, float(seconds), ctypes.byref(tf), None)
+        if rc != 0:
+            raise RuntimeError(f"dfn_probe_mfma_rate failed ({rc}): {probe.dfn_probe_last_error().decode()}")
         out[key] = tf.value
     out["note"] = ("dense f16 v_mfma_f32_32x32x16_f16 back to back on all SIMDs for %.1f s each, measured in this run; roofline.peak is the "
                    "nominal 2.4 GHz figure, which this part reaches only with operands that do not toggle" % seconds)

@@ -116,7 +116,6 @@ SIGNATURES = {
     "dfn_linear_backward_weight_scratch_bytes": (c_size_t, [c_int, c_int, c_size_t]),
     "dfn_linear_backward_weight": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "dfn_profile_enable": (c_int, [c_int]),
-    "dfn_probe_mfma_rate": (c_int, [c_int, c_double, POINTER(c_double), c_void_p]),
     "dfn_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
 }
 

@@ -432,9 +432,6 @@ DFN_DEV_INLINE void x3_epilogue(const ConvArgs& a, const f32x16 (&acc)[MB][2], f
   }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
-#ifdef DFN_CONV_ABL_NOEPI
-    if (acc[0][nb][0] != 12345.678f) continue;   // keeps the accumulators alive, stores nothing
-#endif
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       f32x4* d = reinterpret_cast<f32x4*>(turn + p * ROWB + mb * 128 + h * 64);
@@ -554,14 +551,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? (MB == 1 ? 3 : 2) : 1) voi
     const char* wsrc = a.w + ((size_t)(cg * MB / MBP) * n_slices + min(sl, n_slices - 1)) * WSLP + lane * 16;
     const int mbsel = (cg * MB) % MBP;     // first packed M-block this workgroup computes
     char* dst = wst + ring_w * WSL;
-#ifndef DFN_CONV_ABL_NODMA
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int q = min(wave + i * WAVES, NP - 1);                 // piece q of the staged slice = (hi | lo, M-block, kx)
       const int half = q / (MB * KS), r = q - half * (MB * KS);
       conv_lds_dma_b128(wsrc + ((half * MBP + mbsel) * KS + r) * 1024, dst + q * 1024);
     }
-#endif
     ring_w = ring_w + 1 == RING ? 0 : ring_w + 1;
   };
   // The fp32 patch of the NEXT input block is prefetched into registers while the current block is multiplied.
@@ -599,10 +594,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? (MB == 1 ? 3 : 2) : 1) voi
         // segment = 4 consecutive slots of half hh: slots s0..s0+3 -> K-chunk s0 / 8, byte (s0 % 8) * 2 of the pixel's 16
         const int hh = seg / (SB / 4), s0 = (seg - hh * (SB / 4)) * 4;
         const int o = ((hh * KCB + (s0 >> 3)) * NPIX + pix) * 16 + (s0 & 7) * 2;
-#ifndef DFN_CONV_ABL_NOSTORE
         *reinterpret_cast<half4*>(plane_hi + o) = hi;
         *reinterpret_cast<half4*>(plane_lo + o) = lo;
-#endif
       }
     }
   };
@@ -648,33 +641,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? (MB == 1 ? 3 : 2) : 1) voi
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             const int o = ((h * KCB + kc) * NPIX + ((2 * wave + nb) * RF + pr + ky) * PW + pc + kx) * 16;
-#ifdef DFN_CONV_ABL_NOBREAD
-            bh[nb] = half8{(_Float16)o, 1, 2, 3, 4, 5, 6, 7};
-            bl[nb] = half8{(_Float16)kx, 1, 2, 3, 4, 5, 6, 7};
-#else
             bh[nb] = *reinterpret_cast<const half8*>(plane_hi + o);
             bl[nb] = *reinterpret_cast<const half8*>(plane_lo + o);
-#endif
           }
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
             const int fo = ((mb * KS + kx) * 64 + lane) * 16;
-#ifdef DFN_CONV_ABL_NOAREAD
-            const half8 ah = half8{(_Float16)fo, 1, 2, 3, 4, 5, 6, 7};
-            const half8 al = half8{(_Float16)mb, 1, 2, 3, 4, 5, 6, 7};
-#else
             const half8 ah = *reinterpret_cast<const half8*>(wb + fo);
             const half8 al = *reinterpret_cast<const half8*>(wb + WHALF + fo);
-#endif
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-#ifdef DFN_CONV_ABL_NOMFMA
-              acc[mb][nb][0] += (float)ah[0] * (float)bh[nb][0] + (float)al[0] * (float)bl[nb][0];
-#else
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], acc[mb][nb], 0, 0, 0);
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], acc[mb][nb], 0, 0, 0);
               acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], acc[mb][nb], 0, 0, 0);
-#endif
             }
           }
         }

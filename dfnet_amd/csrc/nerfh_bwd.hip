@@ -363,11 +363,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
     // The split-f16 kernel evaluates the Jacobian's sin / cos with the exact-fract hardware path (rev_sincos: 4e-7 absolute, far
     // inside the gradient tolerance): libm's full-range sinf / cosf expand into a large-argument reduction whose temporaries, on
     // top of the live gradient vectors, were what spilled (152 + 61 registers around the two Jacobians).  Exact fp32 keeps libm.
-#ifdef DFN_DBG_SLOWTRIG
-    constexpr bool JFAST = false;
-#else
     constexpr bool JFAST = P::kSplit;
-#endif
     auto pe_jacobian = [&](const F (&dpe)[NB][PC], bool first) {
       [[maybe_unused]] FF pe[NB][FPC];
       if constexpr (!JFAST) {   // exact fp32: the encoding itself, recomputed (libm sin / cos) instead of kept alive

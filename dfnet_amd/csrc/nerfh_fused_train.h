@@ -93,8 +93,6 @@ struct WgradArgs {
   WJob job[kMaxJobs];
   int n_jobs;
   int n_wt;
-  int debug_nt, debug_depth;
-  int debug_mode;          // 0; tuning aid (DFN_WGRAD_MODE): 1 = stream without the products, 2 = products without the stream
 };
 struct ReduceArgs {
   WJob job[kMaxJobs];

@@ -6,14 +6,13 @@
 // models/nerfw.py:259-295: dW_l[n, k] = sum_p G_l[p, n] X_l[p, k], db_l[n] = sum_p G_l[p, n].
 //
 // wgrad_stream_kernel: one workgroup = (job, chunk of wave-tiles).  Per wave-tile the job's G and X chunks (2 KiB each, already
-// split hi | lo by the chain kernels) are DMA-ed L2/HBM -> LDS into a ring of 3-4 stages (global_load_lds_dwordx4, no registers);
+// split hi | lo by the chain kernels) are DMA-ed HBM -> LDS into a ring of 2-4 stages (global_load_lds_dwordx4 nt, no registers);
 // the [point][feature] image is read back as [feature][point] MFMA operands by ds_read_b64_tr_b16 (a 16-lane group reads
 // 4 points x 16 features = 128 contiguous bytes: conflict-free), three v_mfma_f32_32x32x16_f16 per product and 16-point half;
 // the wave-tile's fp32 block is folded into the master accumulator at the tile's power-of-two scale.  The kernel is bound by
 // the stream (4 bytes per stored element, read once): a 128 x 128 layer moves 32 KiB per 32 points against 120 MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "nerfh_fused_train.h"
 #include "nerfh_mlp_core.h"
@@ -70,7 +69,9 @@ DFN_DEV void wait_vmcnt(int n) {   // s_waitcnt vmcnt(n), n wave-uniform (gfx9 e
   }
   asm volatile("" ::: "memory");
 }
-DFN_DEV void lds_dma_b128_nt(const void* gptr, const char* lds_dst) {   // streamed once: non-temporal
+// The stored operands are read exactly once: non-temporal (measured on one box: 2.27 -> 2.15 ms for the backward pass; the stream
+// alone 4.5 TB/s, the products alone about as long — the two overlap once two workgroups share a CU).
+DFN_DEV void lds_dma_b128_nt(const void* gptr, const char* lds_dst) {
   const uint32_t off = (uint32_t)(size_t)DFN_LDS_PTR(lds_dst);
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gptr), "s"(off) : "memory");
 }
@@ -123,7 +124,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a
   const uint32_t stage_bytes = uint32_t(kc_all) * kLdsChunk;
   int D = int(kWgradLdsBytes / stage_bytes);
   D = D > 4 ? 4 : D;
-  if (a.debug_depth >= 2 && a.debug_depth < D) D = a.debug_depth;
   const int chunk = int(blockIdx.x) - jb.first_wg;
   const int wt0 = chunk * jb.wt_per_chunk;
   int n_it = a.n_wt - wt0;
@@ -139,11 +139,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a
       if (i < 2 * kcg) src = jb.g + ((wt * size_t(jb.g_stride) + jb.g_chunk0) * 2 + i) * 1024;
       else if (i < 2 * (kcg + kcx0)) src = jb.x0 + (wt * size_t(2 * kcx0) + (i - 2 * kcg)) * 1024;
       else src = jb.x1 + (wt * size_t(2 * kcx1) + (i - 2 * (kcg + kcx0))) * 1024;
-      if (a.debug_nt) lds_dma_b128_nt(src + lane * 16, dst + (i >> 1) * kLdsChunk + (i & 1) * 1024);
-      else lds_dma_b128(src + lane * 16, dst + (i >> 1) * kLdsChunk + (i & 1) * 1024);
+      lds_dma_b128_nt(src + lane * 16, dst + (i >> 1) * kLdsChunk + (i & 1) * 1024);
     }
   };
-  for (int it = 0; it < D - 1 && it < n_it; ++it) issue(it);   // (debug_mode 2 still primes the ring once)
+  for (int it = 0; it < D - 1 && it < n_it; ++it) issue(it);
 
   // this wave's output blocks: a contiguous run of `per` blocks b = gb * (nb_x + 1) + xb; xb == nb_x: the bias column block
   // (B operand = ones)
@@ -174,8 +173,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a
     wait_vmcnt(ahead * my_np);
     __builtin_amdgcn_s_barrier();   // stage `it` landed for every wave; every wave has left stage it - 1
     asm volatile("" ::: "memory");
-    if (it + D - 1 < n_it && a.debug_mode != 2) issue(it + D - 1);
-    if (a.debug_mode == 1) continue;
+    if (it + D - 1 < n_it) issue(it + D - 1);
     const float inv = 1.f / scalar_f32(jb.gscale + wt0 + it);
     const uint32_t sb = uint32_t(size_t(DFN_LDS_PTR(smem))) + uint32_t(it % D) * stage_bytes;
     // block pipeline: while block i's MFMAs run, block i + 1's operands are read (transposed) into the other register set — the
@@ -208,17 +206,7 @@ hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, hipStream_t s)
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  WgradArgs b = a;
-  {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("DFN_WGRAD_MODE"); mode = e ? atoi(e) : 0; }
-    b.debug_mode = mode;
-    static int nt = -1, depth = -1;
-    if (nt < 0) { const char* e = getenv("DFN_WGRAD_NT"); nt = e ? atoi(e) : 1; }
-    if (depth < 0) { const char* e = getenv("DFN_WGRAD_D"); depth = e ? atoi(e) : 0; }
-    b.debug_nt = nt; b.debug_depth = depth;
-  }
-  hipLaunchKernelGGL(wgrad_stream_kernel, dim3(total_wgs), dim3(WAVES * 64), kWgradLdsBytes, s, b);
+  hipLaunchKernelGGL(wgrad_stream_kernel, dim3(total_wgs), dim3(WAVES * 64), kWgradLdsBytes, s, a);
   return hipGetLastError();
 }
 

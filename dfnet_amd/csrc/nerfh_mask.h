@@ -29,20 +29,6 @@ DFN_DEV void relu_mask(typename FragOf<P>::type (&v)[N], uint32_t (&m)[(C * P::k
   constexpr int S = P::kSlotsPerChunk;
 #pragma unroll
   for (int w = 0; w < (C * S + 31) / 32; ++w) m[w] = 0u;
-#ifdef DFN_DBG_OLDMASK
-  if constexpr (S == 8) {
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        const int e = c * S + j;
-        bool pos;
-        if constexpr (P::kSplit) pos = v[c].hi[j] > (_Float16)0;
-        else pos = v[c][j] > (_Float16)0;
-        m[e >> 5] |= (pos ? 1u : 0u) << (e & 31);
-      }
-  } else
-#endif
   if constexpr (S == 8) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -69,19 +55,6 @@ DFN_DEV void relu_mask(typename FragOf<P>::type (&v)[N], uint32_t (&m)[(C * P::k
 template <class P, int C, int N>
 DFN_DEV void apply_mask(typename FragOf<P>::type (&v)[N], const uint32_t (&m)[(C * P::kSlotsPerChunk + 31) / 32]) {
   constexpr int S = P::kSlotsPerChunk;
-#ifdef DFN_DBG_OLDMASK
-  if constexpr (S == 8) {
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        const int e = c * S + j;
-        const bool on = (m[e >> 5] >> (e & 31)) & 1u;
-        if constexpr (P::kSplit) { v[c].hi[j] = on ? v[c].hi[j] : (_Float16)0; v[c].lo[j] = on ? v[c].lo[j] : (_Float16)0; }
-        else v[c][j] = on ? v[c][j] : (_Float16)0;
-      }
-  } else
-#endif
   if constexpr (S == 8) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {

@@ -93,17 +93,7 @@ DFN_DEV void lds_dma_b32(const void* gptr, const char* lds_dst) {
 DFN_DEV void stage_issue_at(const Stager& st, char* smem, uint32_t off, uint32_t size, uint32_t lds_off) {
   const char* src = st.blob + off + st.lane * 16;
   if (st.wave >= st.dma_waves) return;
-#if defined(DFN_ABL_DMA_SMALL)   // ablation: same instruction count, a quarter of the bytes
-  for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) lds_dma_b32(src + p, smem + lds_off + p);
-#elif defined(DFN_ABL_DMA_SAMESRC)  // ablation: same count and bytes, one source KiB
-  for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) lds_dma_b128(st.blob + st.lane * 16, smem + lds_off + p);
-#elif defined(DFN_ABL_DMA_HALF)  // ablation: every second piece only
-  for (uint32_t p = st.wave * kPiece; p < size; p += 2 * st.dma_waves * kPiece) lds_dma_b128(src + p, smem + lds_off + p);
-#elif defined(DFN_ABL_ADD_DMA)  // ADDITIVE ablation (results stay correct): every piece streamed twice -> energy share of the weight stream
-  for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) { lds_dma_b128(src + p, smem + lds_off + p); lds_dma_b128(src + p, smem + lds_off + p); }
-#else
   for (uint32_t p = st.wave * kPiece; p < size; p += st.dma_waves * kPiece) lds_dma_b128(src + p, smem + lds_off + p);
-#endif
 }
 // The unit table is read through the CONSTANT address space so that the loads are scalar (s_load, lgkmcnt): as
 // vector loads they would sit in the vmcnt queue behind the DMA and every wait for them would wait for the DMA too.
@@ -153,9 +143,6 @@ DFN_DEV uint32_t open_unit(Stager& st) {
 
 // Once per unit, between two of its MFMA chunks.  After open_unit(): st.u = the unit after the open one.
 DFN_DEV void mid_sync(Stager& st, char* smem) {
-#ifdef DFN_ABL_NOSYNC  // ablation: no DMA, no barrier
-  return;
-#endif
 #ifdef DFN_TIMING
   const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -173,9 +160,7 @@ DFN_DEV void mid_sync(Stager& st, char* smem) {
   bool next_tile = st.u == 0;   // the open unit is the tile's last: both st.u and st.u + 1 belong to the next tile
   if (n2 >= st.n_units) { n2 -= st.n_units; next_tile = true; }
   const uint32_t dst = (st.slot + 1 == st.ring ? 0u : st.slot + 1) * st.ustride;
-#ifndef DFN_ABL_NOBAR
   __builtin_amdgcn_s_barrier();   // every share landed; every wave is inside the open unit
-#endif
   asm volatile("" ::: "memory");
 #ifdef DFN_TIMING
   const unsigned long long c2 = __builtin_amdgcn_s_memtime();
@@ -187,9 +172,7 @@ DFN_DEV void mid_sync(Stager& st, char* smem) {
   }
   ++st.n_trace;
 #endif
-#ifndef DFN_ABL_NODMA
   if (!next_tile || st.more) stage_issue_at(st, smem, st.pf_off, st.pf_size, dst);
-#endif
   {  // fetch the table entry needed by the next call now, so its scalar-load latency is off the critical path
     int n3 = n2 + 1;
     if (n3 >= st.n_units) n3 -= st.n_units;
@@ -240,10 +223,6 @@ DFN_DEV f32x16 load16(const float* p) {
 // C fragment -> B-operand registers of the next layer (ReLU optional).
 template <class P, bool RELU, int OC>
 DFN_DEV void store_hidden(const f32x16& acc, typename FragOf<P>::type (&out)[OC], int mb, float oscale, uint32_t& rmax) {
-#ifdef DFN_ABL_NOEPI  // ablation: no conversion/ReLU work (results are garbage, timing only)
-  asm volatile("" ::"v"(acc));
-  return;
-#endif
   if constexpr (P::kSplit) {
     // two values per conversion (v_cvt_pkrtz_f16_f32): hi is the TRUNCATED f16 of the scaled value — any f16 within an ulp will do,
     // the lo half takes the exact remainder — so a pair costs 2 packed converts + 2 mixed-precision subtractions
@@ -374,10 +353,6 @@ struct X3Piece {
                  "v_fma_mix_f32 %1, %0, -1.0, %1 op_sel_hi:[1,0,0]\n\t"
                  "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
                  : "=&v"(hb), "+v"(t0), "+v"(t1));
-#ifdef DFN_ABL_ADD_VALU  // ADDITIVE ablation: four more vector instructions per conversion piece (9 -> 13), values untouched
-    float dummy;
-    asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %0, %1\n\tv_mov_b32 %0, %2" : "=&v"(dummy) : "v"(t0), "v"(t1));
-#endif
   }
   template <bool RELU, int OC>
   DFN_DEV void C(half8x2 (&out)[OC], int mb, int i, uint32_t& rmax) {
@@ -448,15 +423,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
     const char* wl = smem + ub + st.lane * (P::kSplit ? 16 : P::kLaneBytes);
     const char* bl = smem + ub + nmb * KC * FB + h * 64;
     F a[PF];
-#ifdef DFN_ABL_ADD_LDS
-    half8 abl_extra = {};
-#endif
-#ifdef DFN_ABL_NOLDS
-#define DFN_AFRAG(t) a0_abl
-    const F a0_abl = *reinterpret_cast<const F*>(wl);
-#else
 #define DFN_AFRAG(t) load_afrag<P>(wl + (t) * FB)
-#endif
 #pragma unroll
     for (int t = 0; t < PF; ++t)
       if (t < nt) a[t] = DFN_AFRAG(t);
@@ -466,13 +433,6 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
     for (int lm = 0; lm < UMB; ++lm) {
       if (lm < nmb) {
         const int mb = u0 + lm;
-#ifdef DFN_PRIO
-        // time-slice the two waves of a SIMD (w and w+4): alternate issue priority per M-block, in antiphase
-        if (PIPE && st.waves == 8) {
-          if (((lm & 1) != 0) == (st.wave >= 4)) __builtin_amdgcn_s_setprio(DFN_PRIO);
-          else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
         f32x16 acc[NB];
         f32x16 bias_next = bias;
         if (RAYBIAS) {
@@ -490,7 +450,6 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
           if (t + PF < nt) a[t % PF] = DFN_AFRAG(t + PF);
           if (kc == (PIPE ? KC / 2 : 0) && !RAYBIAS && !NOBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
           __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this chunk's MFMAs (hipcc otherwise sinks it to its use)
-#ifndef DFN_X3_NOSPREAD
           if constexpr (P::kSplit && PIPE && NB == 1) {
             // split-f16: the conversion pieces of this chunk go BETWEEN its three dependent MFMAs, a third each (the block form
             // behind them measured 46.5 against 42.7 cycles per MFMA in tools/ubench/x3loop.hip)
@@ -504,12 +463,6 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             // parts behind its third MFMA, >= 3 MFMA issues after the producer (read one issue later, the last correction product
             // of some results was missing: 1e-6 instead of 2.4e-7 against exact fp32).
             const bool late = kc == 0;
-#ifdef DFN_ABL_ADD_LDS  // ADDITIVE ablation: one more 16-byte fragment read per lane and chunk (2 -> 3), result unused; consumed one
-            {                    // chunk later, like the real prefetches (consumed at once it measures the LDS LATENCY, not the port)
-              asm volatile("" ::"v"(abl_extra));
-              abl_extra = *reinterpret_cast<const half8*>(wl + t * FB);
-            }
-#endif
             f32x16 c0 = (kc == 0) ? (RAYBIAS ? acc[0] : bias) : acc[0];
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, Bin[0][kc].hi, c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -544,7 +497,6 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             __builtin_amdgcn_sched_barrier(0);
             continue;
           }
-#endif
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             if (kc == 0) acc[nb] = mfma<P>(cur, Bin[nb][0], RAYBIAS ? acc[nb] : bias);
@@ -605,11 +557,6 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 // x * 2^k, bit-for-bit the reference's sin(x * freq) up to libm rounding.
 template <class P, bool FAST, int NB, int PC>
 DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type (&pe)[NB][PC]) {
-#ifdef DFN_ABL_NOPE  // ablation: no trig (timing only)
-  for (int nb = 0; nb < NB; ++nb)
-    for (int s = 0; s < 32; ++s) set_slot<P>(pe[nb], s, x[nb][s % 3]);
-  return;
-#endif
   const float base = h ? 32.f : 1.f;  // half h owns frequencies 2^(5h) .. 2^(5h+4)
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {

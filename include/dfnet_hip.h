@@ -495,11 +495,6 @@ enum {
 int dfn_profile_enable(int on);
 int dfn_profile_read(int which, double* avg_ms, int* launches);
 
-/* Measurement aid for bench.py (csrc/mfma_probe.hip; no reference counterpart): the dense-f16 MFMA rate in TFLOP/s that the
- * current device SUSTAINS over `seconds` (0 < seconds <= 5) of back-to-back independent v_mfma_f32_32x32x16_f16 on every SIMD,
- * with all-zero operands (random_operands = 0: the nominal peak) or with uniformly random ones (1: what real data allows once
- * power management has settled the clock).  Synchronises `stream`. */
-int dfn_probe_mfma_rate(int random_operands, double seconds, double* tflops, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,3 +82,22 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdfnet_hip.so")
     with pytest.raises(RuntimeError, match="no fallback"):
         _lib.load()
+
+
+def test_product_library_carries_no_bench_scaffolding():
+    """The MFMA-rate probe of bench.py lives in its own helper library (tools/probe/libdfn_probe.so), and the shipped kernels carry
+    no compile-time ablation switches: libdfnet_hip.so exports nothing named *probe*, the kernel sources have no DFN_ABL_ / DFN_DBG_ /
+    DFN_CONV_ABL_ token."""
+    import glob
+    import subprocess
+    so = os.path.join(ROOT, "dfnet_amd", "libdfnet_hip.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "probe" not in syms.lower()
+    for path in glob.glob(os.path.join(ROOT, "dfnet_amd", "csrc", "*.h*")):
+        text = open(path).read()
+        for tok in ("DFN_ABL_", "DFN_DBG_", "DFN_CONV_ABL_", "DFN_X3_NOSPREAD", "DFN_PRIO"):
+            assert tok not in text, (os.path.basename(path), tok)
+    probe = os.path.join(ROOT, "tools", "probe", "libdfn_probe.so")
+    assert os.path.exists(probe)
+    psyms = subprocess.run(["nm", "-D", "--defined-only", probe], capture_output=True, text=True, check=True).stdout
+    assert "dfn_probe_mfma_rate" in psyms and "dfn_probe_last_error" in psyms

@@ -445,11 +445,11 @@ def test_mfma_rate_probe():
     """bench.py's measurement aid: the bare dense-f16 MFMA loop — a plausible rate, argument checking, and operands that toggle
     never run faster than zeros (on MI355X they sustain about two thirds of the zero-operand rate)."""
     import ctypes
-    from dfnet_amd import _lib
-    lib = _lib.load()
+    import bench
+    lib = bench.load_probe()   # tools/probe/libdfn_probe.so: a bench-only library, not libdfnet_hip.so
     tf0, tf1 = ctypes.c_double(), ctypes.c_double()
     assert lib.dfn_probe_mfma_rate(0, 0.2, ctypes.byref(tf0), None) == 0
     assert lib.dfn_probe_mfma_rate(1, 0.2, ctypes.byref(tf1), None) == 0
     assert 500.0 < tf1.value <= tf0.value * 1.02 and tf0.value < 2600.0, (tf0.value, tf1.value)
-    assert lib.dfn_probe_mfma_rate(1, 0.0, ctypes.byref(tf1), None) != 0
+    assert lib.dfn_probe_mfma_rate(1, 0.0, ctypes.byref(tf1), None) != 0 and b"seconds" in lib.dfn_probe_last_error()
     assert lib.dfn_probe_mfma_rate(1, 0.2, None, None) != 0

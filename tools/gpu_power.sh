@@ -33,8 +33,8 @@ for rnd in 1 0; do
   python - <<PY &
 import sys, ctypes
 sys.path.insert(0, "$R")
-from dfnet_amd import _lib
-lib = _lib.load(); tf = ctypes.c_double()
+import bench
+lib = bench.load_probe(); tf = ctypes.c_double()
 lib.dfn_probe_mfma_rate($rnd, 4.5, ctypes.byref(tf), None); lib.dfn_probe_mfma_rate($rnd, 4.5, ctypes.byref(tf), None)
 print("probe random=$rnd TFLOP/s", tf.value)
 PY

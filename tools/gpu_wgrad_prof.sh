@@ -2,9 +2,9 @@
 # kernel-trace durations of the fused step's kernels per tuning mode (DFN_WGRAD_MODE)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for m in ${MODES:-0 1 2}; do
+for m in 0; do
   rm -rf $R/gpurun_out/prof_w$m
-  DFN_WGRAD_MODE=$m timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_w$m -o w -- python $R/tools/gpu_nerf_train_step.py 1536 128 10 > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_w$m -o w -- python $R/tools/gpu_nerf_train_step.py 1536 128 10 > /dev/null 2>&1
   echo "== mode $m"
   python3 - <<PY
 import csv

@@ -1,12 +1,12 @@
-// mfma_probe.hip — measurement aid, not part of the render path: the dense f16 MFMA rate this GPU SUSTAINS (power management
+// mfma_probe.hip -> tools/probe/libdfn_probe.so — a bench-only helper library, NOT part of libdfnet_hip.so (bench.py and
+// tools/gpu_power.sh load it by path): the dense f16 MFMA rate this GPU SUSTAINS (power management
 // included) for a loop of nothing but independent v_mfma_f32_32x32x16_f16, with all-zero operands and with operands that toggle
 // like real data.  bench.py reports it next to roofline.peak: on MI355X the nominal 2.5 PFLOP/s holds for zero operands only —
 // with random operands the clock settles near 1.6 GHz (tools/ubench/mfma_power.hip is the stand-alone form, fp32 MFMA included).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <vector>
-#include "dfn_common.h"
-#include "../../include/dfnet_hip.h"
+#include <cstdio>
 
 namespace dfn {
 namespace {
@@ -36,9 +36,24 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(const float* in, float*
 }  // namespace
 }  // namespace dfn
 
+namespace {
+thread_local char g_probe_err[256] = "";
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  snprintf(g_probe_err, sizeof(g_probe_err), "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+  return code;
+}
+constexpr int DFN_OK = 0, DFN_ERR_ARG = -1, DFN_ERR_HIP = -2;
+}  // namespace
+
+// Text of the last failure of this library on the calling thread.
+extern "C" const char* dfn_probe_last_error(void) { return g_probe_err; }
+
+// Dense-f16 MFMA rate in TFLOP/s over `seconds` (0 < seconds <= 5) of back-to-back launches on `stream`; random_operands: operands
+// that toggle like real data (0: all zero).  Assumes one 512-thread block per CU (grid = CU count, 8 resident waves each).
+// Returns 0, -1 (bad argument) or -2 (a HIP call failed); dfn_probe_last_error() has the text.
 extern "C" int dfn_probe_mfma_rate(int random_operands, double seconds, double* tflops, void* stream) {
   using namespace dfn;
-  if (!tflops || !(seconds > 0.0) || seconds > 5.0) return DFN_ERR_ARG;
+  if (!tflops || !(seconds > 0.0) || seconds > 5.0) return fail(DFN_ERR_ARG, "dfn_probe_mfma_rate: need tflops != NULL and 0 < seconds <= 5");
   hipStream_t s = static_cast<hipStream_t>(stream);
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
@@ -49,13 +64,13 @@ extern "C" int dfn_probe_mfma_rate(int random_operands, double seconds, double* 
     for (float& v : host) { x = x * 1664525u + 1013904223u; v = float(x >> 8) * (2.f / 16777216.f) - 1.f; }   // uniform [-1, 1)
   }
   float *in = nullptr, *out = nullptr;
-  if (hipMalloc(&in, host.size() * 4) != hipSuccess) return DFN_ERR_HIP;
-  if (hipMalloc(&out, size_t(cus) * 512 * 4) != hipSuccess) { (void)hipFree(in); return DFN_ERR_HIP; }
+  if (hipMalloc(&in, host.size() * 4) != hipSuccess) return fail(DFN_ERR_HIP, "dfn_probe_mfma_rate: hipMalloc");
+  if (hipMalloc(&out, size_t(cus) * 512 * 4) != hipSuccess) { (void)hipFree(in); return fail(DFN_ERR_HIP, "dfn_probe_mfma_rate: hipMalloc"); }
   hipEvent_t e0, e1;
   int rc = DFN_OK;
   if (hipMemcpy(in, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     (void)hipFree(in); (void)hipFree(out);
-    return DFN_ERR_HIP;
+    return fail(DFN_ERR_HIP, "dfn_probe_mfma_rate: upload / event creation failed");
   }
   // 16 MFMAs per iteration and wave, 8 waves per CU; one launch ~ 0.1 s at the nominal rate, the clock settles within the first
   const int iters = 300000;
@@ -63,9 +78,11 @@ extern "C" int dfn_probe_mfma_rate(int random_operands, double seconds, double* 
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(512), 0, s, in, out, iters);   // settle
   (void)hipEventRecord(e0, s);
   for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(512), 0, s, in, out, iters);
+  const hipError_t le = hipGetLastError();
   (void)hipEventRecord(e1, s);
   float ms = 0.f;
-  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) rc = DFN_ERR_HIP;
+  if (le != hipSuccess) rc = fail(DFN_ERR_HIP, "dfn_probe_mfma_rate: kernel launch", le);
+  else if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) rc = fail(DFN_ERR_HIP, "dfn_probe_mfma_rate: timing the launches failed");
   else *tflops = double(launches) * iters * 16.0 * 8.0 * cus * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(in); (void)hipFree(out);
