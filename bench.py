@@ -96,49 +96,91 @@ def oracle_sample(sample_rays):
     return rows, (c, f, T(ea), T(et))
 
 
-def cpu_baseline(sample_rays):
-    """the oracle on a `sample_rays`-ray subset of frame 0 at the judged 64+128 samples — the thread count is swept
-    on an eighth of the sample (the oracle is one torch-CPU process; 128 threads are several times SLOWER than 8-16 here), then
-    the fastest setting is timed three times on the whole subset (`value` = the median) — plus one full 160x120 frame at 32+64
-    samples (BASELINE configs[0] shape).  Returns (record, (rows, reference outputs on the subset))."""
+def numa0_cpus():
+    """CPU ids of NUMA node 0 (the baseline's threads are pinned there: one memory domain, no migration); all CPUs if unknown."""
+    try:
+        txt = open("/sys/devices/system/node/node0/cpulist").read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        return sorted(cpus) if cpus else sorted(allowed)
+    except OSError:
+        return sorted(os.sched_getaffinity(0))
+
+
+def cpu_baseline_worker(sample_rays, out_path):
+    """Runs in its own process (cpu_baseline() below), pinned to NUMA node 0 with OMP_PROC_BIND=close / OMP_PLACES=cores: the
+    oracle on a `sample_rays`-ray subset of frame 0 at the judged 64+128 samples.  Thread count swept on an eighth of the sample
+    (the oracle is one torch-CPU process: 128 threads are several times SLOWER than 8-16 here); then ONE untimed full pass at the
+    fastest setting (allocator, thread pool and caches warm — without it three timed runs fell monotonically 11.8 -> 7.2 s) and three
+    timed passes: `value` = the median, the minimum reported beside it.  Plus one full 160x120 frame at 32+64 samples (BASELINE
+    configs[0] shape).  Writes {record, rows, reference outputs} to out_path."""
     from dfnet_amd import synthetic as syn
     from oracle import nerfh_oracle as orc
+    ncpu = int(os.environ.get("DFN_CPU_PIN_COUNT", "0")) or len(os.sched_getaffinity(0))   # the parent pinned this process before exec
     rows, (c, f, ea, et) = oracle_sample(sample_rays)
-    ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    cand = sorted({t for t in (8, 16, 32, 64, ncpu, default_threads) if 1 <= t <= ncpu})
+    cand = sorted({t for t in (8, 16, 32, 64, ncpu) if 1 <= t <= ncpu})
     sub = rows[: max(512, sample_rays // 8)]
     sweep = {}
     with torch.no_grad():
         for t in cand:
             torch.set_num_threads(t)
-            orc.render_rays(rows[:256], c, f, ea, et, NC, NI)  # warm-up (thread pool, allocator)
+            orc.render_rays(sub[:256], c, f, ea, et, NC, NI)  # warm-up (thread pool, allocator)
             t0 = time.perf_counter()
             orc.render_rays(sub, c, f, ea, et, NC, NI)
             sweep[t] = sub.shape[0] / (time.perf_counter() - t0)
         best = max(sweep, key=sweep.get)
         torch.set_num_threads(best)
+        t0 = time.perf_counter()
+        orc.render_rays(rows, c, f, ea, et, NC, NI)      # the untimed full pass
+        warm = time.perf_counter() - t0
         runs = []
         for _ in range(3):
             t0 = time.perf_counter()
             ref = orc.render_rays(rows, c, f, ea, et, NC, NI)
             runs.append(time.perf_counter() - t0)
         dt = sorted(runs)[1]
-        # one full frame of BASELINE configs[0]'s shape (160x120, 32+64 samples)
+        # one full frame of BASELINE configs[0]'s shape (160x120, 32+64 samples), second of two passes
+        pose0 = torch.from_numpy(syn.orbit_pose(0, 8))
+        orc.render(120, 160, FOCAL / 4, 32768, c, f, ea, et, 32, 64, NEAR, FAR, syn.HIST_IDX, c2w=pose0)
         t0 = time.perf_counter()
-        orc.render(120, 160, FOCAL / 4, 32768, c, f, ea, et, 32, 64, NEAR, FAR, syn.HIST_IDX, c2w=torch.from_numpy(syn.orbit_pose(0, 8)))
+        orc.render(120, 160, FOCAL / 4, 32768, c, f, ea, et, 32, 64, NEAR, FAR, syn.HIST_IDX, c2w=pose0)
         dt_frame = time.perf_counter() - t0
-    torch.set_num_threads(default_threads)
-    rec = {"value": sample_rays / dt, "unit": "rays/s", "cores": best, "kind": "port",
-           "sample": f"median of 3 runs over {sample_rays} random rays of frame 0 at 64+128 samples, one chunk each "
-                     f"({', '.join('%.1f' % r for r in runs)} s; oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32, "
-                     "autograd anomaly mode off, no_grad)",
+    rec = {"value": sample_rays / dt, "min_time_value": sample_rays / min(runs), "unit": "rays/s", "cores": best, "kind": "port",
+           "sample": f"median of 3 runs over {sample_rays} random rays of frame 0 at 64+128 samples, one chunk each, after one untimed full "
+                     f"pass ({warm:.1f} s): {', '.join('%.2f' % r for r in runs)} s, spread {(max(runs) - min(runs)) / dt * 100:.1f} % of the median "
+                     f"(oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32, autograd anomaly mode off, no_grad)",
+           "pinning": f"own process, affinity = the {ncpu} CPUs of NUMA node 0 (set before exec), OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} "
+                      f"OMP_PLACES={os.environ.get('OMP_PLACES')}",
+           "runs_s": [round(r, 3) for r in runs],
            "frame_640x480_extrapolated_s": H * W / (sample_rays / dt),
            "full_frame_160x120_32+64": {"seconds": dt_frame, "rays_per_s": 160 * 120 / dt_frame, "chunk": 32768},
-           "host_cpus": ncpu, "torch_default_threads": default_threads,
+           "host_cpus": os.cpu_count(), "numa0_cpus": ncpu, "torch_default_threads": default_threads,
            "thread_sweep_rays_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
            "sweep_sample": f"{sub.shape[0]} rays per setting; `cores` = the fastest setting, used for `value`"}
-    return rec, (rows, ref)
+    torch.save({"rec": rec, "rows": rows, "ref": ref}, out_path)
+
+
+def cpu_baseline(sample_rays):
+    """SURVEY §8(d) CPU leg, in a child process pinned to one NUMA node (cpu_baseline_worker).  Returns (record, (rows, reference
+    outputs on the subset))."""
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="dfn_cpu_"), "cpu.pt")
+    cpus = numa0_cpus()
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="",
+               DFN_CPU_PIN_COUNT=str(len(cpus)))
+    env.pop("OMP_NUM_THREADS", None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(sample_rays), out], env=env, capture_output=True, text=True,
+                       preexec_fn=lambda: os.sched_setaffinity(0, cpus))   # affinity set before exec: the OpenMP runtime binds inside it
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline worker failed:\n" + r.stderr[-2000:])
+    d = torch.load(out, weights_only=False)
+    os.remove(out)
+    return d["rec"], (d["rows"], d["ref"])
 
 
 def fp32_grade_check(E, dev, n=4096):
@@ -796,7 +838,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only (no precisions / hbm / secondary records)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--cpu-dry", action="store_true", help="no GPU work: exercise launch + sharding + gather only (CPU tests)")
+    ap.add_argument("--cpu-worker", nargs=2, metavar=("RAYS", "OUT"), help="internal: the pinned child process of the CPU baseline")
     args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_baseline_worker(int(args.cpu_worker[0]), args.cpu_worker[1])
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))

@@ -99,6 +99,9 @@ SIGNATURES = {
     "dfn_nerfh_train_param_name": (c_char_p, [c_int]),
     "dfn_nerfh_train_workspace_bytes": (c_size_t, [_P, c_size_t, c_int, c_int]),
     "dfn_nerfh_set_train_mode": (c_int, [_P, c_int]),
+    "dfn_nerfh_train_backward_rays_scratch_bytes": (c_size_t, [c_size_t, c_int, c_int]),
+    "dfn_nerfh_train_backward_rays": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_size_t, c_int, c_int, _P, c_float, _P, _P, _P, _P, c_float, _P, _P, _P,
+                                      _P, c_size_t, _P, c_size_t, _P]),
     "dfn_nerfh_train_tables_selfcheck": (c_int, [_P]),
     "dfn_nerfh_train_forward": (c_int, [_P, POINTER(c_void_p), _P, _P, _P, c_size_t, c_size_t, c_int, c_int, c_float, c_float,
                                         _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

@@ -110,7 +110,7 @@ hipError_t launch_composite_fine_backward(const float* raw, const float* z, cons
 __global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __restrict__ gpts, const float* __restrict__ z,
                                                               const float* __restrict__ rays_d, size_t n_rays, int Nf,
                                                               int derive_viewdirs, float* __restrict__ grad_o,
-                                                              float* __restrict__ grad_d, float* __restrict__ grad_v) {
+                                                              float* __restrict__ grad_d, float* __restrict__ grad_v, int accumulate) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (size_t ray = size_t(blockIdx.x) * 4 + wave; ray < n_rays; ray += size_t(gridDim.x) * 4) {
     float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f}, sv[3] = {0.f, 0.f, 0.f};
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __res
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        grad_o[ray * 3 + c] = so[c];
-        grad_d[ray * 3 + c] = sd[c];
+        grad_o[ray * 3 + c] = so[c] + (accumulate ? grad_o[ray * 3 + c] : 0.f);
+        grad_d[ray * 3 + c] = sd[c] + (accumulate ? grad_d[ray * 3 + c] : 0.f);
         if (grad_v) grad_v[ray * 3 + c] = sv[c];
       }
     }
@@ -144,10 +144,10 @@ __global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __res
 
 hipError_t launch_ray_grad_reduce(const float* gpts, const float* z, const float* rays_d, size_t n_rays, int Nf,
                                   int derive_viewdirs, float* grad_o, float* grad_d, float* grad_viewdirs,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int accumulate) {
   if (!n_rays) return hipSuccess;
   hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3(grid_for((n_rays + 3) / 4, 1, 256 * 16)), dim3(256), 0, stream, gpts, z,
-                     rays_d, n_rays, Nf, derive_viewdirs, grad_o, grad_d, grad_viewdirs);
+                     rays_d, n_rays, Nf, derive_viewdirs, grad_o, grad_d, grad_viewdirs, accumulate);
   return hipGetLastError();
 }
 

@@ -36,6 +36,7 @@ struct dfn_nerfh_s {
   int render_flags = 0;    // DFN_RENDER_* options of every render entry point (dfn_nerfh_set_render_options)
   int* range_flag = nullptr;   // device int the MLP kernels OR their range-guard bits into (dfn_nerfh_range_status)
   void* fused = nullptr;       // dfn::fused::State: staging-unit / destination tables of the fused training step (nerfh_fused_api.hip)
+  bool train_forward_exact = false;   // which implementation the last dfn_nerfh_train_forward ran (dfn_nerfh_train_backward_rays needs the exact one)
   bool train_exact = false;    // dfn_nerfh_set_train_mode: run the training step on the layer-by-layer exact-fp32 products even at netwidth 128
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[2] = {nullptr, nullptr};

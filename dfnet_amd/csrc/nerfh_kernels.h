@@ -91,10 +91,10 @@ hipError_t launch_mlp_fine_backward(int prec, const BwdArgs& a, int n_cu, hipStr
 hipError_t launch_composite_fine_backward(const float* raw, const float* z, const float* grad_rgb, size_t n_rays, int Nf,
                                           float* graw, hipStream_t stream);
 // Per-ray reduction of the per-sample gradients: d o = sum g, d d = sum z g (+ viewdir normalisation when
-// `derive_viewdirs`), d viewdirs = sum gv (when grad_viewdirs != nullptr).
+// `derive_viewdirs`), d viewdirs = sum gv (when grad_viewdirs != nullptr).  accumulate: add to what grad_o / grad_d hold.
 hipError_t launch_ray_grad_reduce(const float* gpts, const float* z, const float* rays_d, size_t n_rays, int Nf,
                                   int derive_viewdirs, float* grad_o, float* grad_d, float* grad_viewdirs,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int accumulate = 0);
 // get_rays backward: d c2w[3][4] from d rays_o / d rays_d of an H x W image.
 hipError_t launch_raygen_backward(int H, int W, float focal, const float* grad_o, const float* grad_d, float* grad_c2w,
                                   hipStream_t stream);

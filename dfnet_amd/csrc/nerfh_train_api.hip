@@ -208,12 +208,14 @@ int net_forward(const Net& n, const Dims& m, const NetBufs& b, bool fine, bool s
 struct BwdBufs { float *gpre, *gA, *gB, *gfin, *gt0, *gt1, *gsum, *gray, *wscratch; };
 
 // Gradients of every parameter of one network from the pre-activation gradients of its outputs (gpre, raw_ld wide).
+// weights == false (dfn_nerfh_train_backward_rays): the data-gradient chain alone, continued into the encodings — g_pe [P,64]
+// (d L / d pe_xyz: layer 1 + the skip columns of layer 5) and g_dpe [P,28] (d L / d pe_dir: dir_encoding.0's direction columns).
 int net_backward(const Net& n, const Dims& m, const NetBufs& b, const BwdBufs& g, bool fine, const float* hist, size_t hist_rows,
-                 float* g_emb_a, float* g_emb_t, size_t R, hipStream_t s) {
+                 float* g_emb_a, float* g_emb_t, size_t R, hipStream_t s, bool weights = true, float* g_pe = nullptr, float* g_dpe = nullptr) {
   const int W = m.W, W2 = m.W2, C = b.raw_ld;
   const long long P = b.P;
   auto wg = [&](const float* G, int ldg, int N, Seg x, float* dW, int ldw, float* db, long long PP) {
-    return gemm_wgrad(G, ldg, N, x, dW, ldw, db, g.wscratch, PP, s);
+    return weights ? gemm_wgrad(G, ldg, N, x, dW, ldw, db, g.wscratch, PP, s) : hipSuccess;
   };
   const int ldw_dir = W + b.kd, ldw_te0 = W + m.nt;
   if (fine) {
@@ -235,19 +237,24 @@ int net_backward(const Net& n, const Dims& m, const NetBufs& b, const BwdBufs& g
     }
     // transient_encoding.0 on cat([final, t])
     CHECK_HIP(wg(cur, W2, W2, Seg{b.fin, W, W, 1, 0}, n.gw[TE0], ldw_te0, n.gb[TE0], P), "train wgrad: transient_encoding.0");
-    CHECK_HIP(sum_over_samples(cur, W2, W2, R, b.Ns, g.gsum, W2, s), "train backward: per-ray sum");
-    CHECK_HIP(wg(g.gsum, W2, W2, Seg{b.t_in, m.ld_t, m.nt, 1, W}, n.gw[TE0], ldw_te0, nullptr, (long long)R), "train wgrad: transient tail");
-    CHECK_HIP(gemm_bwd(g.gsum, W2, W2, n.w[TE0], ldw_te0, W, m.nt, g.gray, m.ld_t, 0, nullptr, 0, (long long)R, s), "train backward: d t");
-    CHECK_HIP(embedding_scatter(g.gray, m.ld_t, 0, hist, hist_rows, m.hist_bin, m.dim_t, m.n_vocab, R, g_emb_t, s), "train: embedding_t grad");
+    if (weights) {
+      CHECK_HIP(sum_over_samples(cur, W2, W2, R, b.Ns, g.gsum, W2, s), "train backward: per-ray sum");
+      CHECK_HIP(wg(g.gsum, W2, W2, Seg{b.t_in, m.ld_t, m.nt, 1, W}, n.gw[TE0], ldw_te0, nullptr, (long long)R), "train wgrad: transient tail");
+      CHECK_HIP(gemm_bwd(g.gsum, W2, W2, n.w[TE0], ldw_te0, W, m.nt, g.gray, m.ld_t, 0, nullptr, 0, (long long)R, s), "train backward: d t");
+      CHECK_HIP(embedding_scatter(g.gray, m.ld_t, 0, hist, hist_rows, m.hist_bin, m.dim_t, m.n_vocab, R, g_emb_t, s), "train: embedding_t grad");
+    }
     CHECK_HIP(gemm_bwd(cur, W2, W2, n.w[TE0], ldw_te0, 0, W, g.gfin, W, 0, nullptr, 0, P, s), "train backward: d final (transient)");
   }
   // static_rgb -> dir_encoding output
   CHECK_HIP(gemm_bwd(g.gpre, C, 3, n.w[RGB], W2, 0, W2, g.gt0, W2, 0, b.dirh, W2, P, s), "train backward: static_rgb");
   CHECK_HIP(wg(g.gpre, C, 3, Seg{b.dirh, W2, W2, 1, 0}, n.gw[RGB], W2, n.gb[RGB], P), "train wgrad: static_rgb");
   CHECK_HIP(wg(g.gt0, W2, W2, Seg{b.fin, W, W, 1, 0}, n.gw[DIR], ldw_dir, n.gb[DIR], P), "train wgrad: dir_encoding");
-  CHECK_HIP(sum_over_samples(g.gt0, W2, W2, R, b.Ns, g.gsum, W2, s), "train backward: per-ray sum");
-  CHECK_HIP(wg(g.gsum, W2, W2, Seg{b.dir_in, b.ld_dir, b.kd, 1, W}, n.gw[DIR], ldw_dir, nullptr, (long long)R), "train wgrad: dir tail");
-  if (fine) {
+  if (g_dpe) CHECK_HIP(gemm_bwd(g.gt0, W2, W2, n.w[DIR], ldw_dir, W, kChDir, g_dpe, 28, 0, nullptr, 0, P, s), "train backward: d pe_dir");
+  if (weights) {
+    CHECK_HIP(sum_over_samples(g.gt0, W2, W2, R, b.Ns, g.gsum, W2, s), "train backward: per-ray sum");
+    CHECK_HIP(wg(g.gsum, W2, W2, Seg{b.dir_in, b.ld_dir, b.kd, 1, W}, n.gw[DIR], ldw_dir, nullptr, (long long)R), "train wgrad: dir tail");
+  }
+  if (fine && weights) {
     CHECK_HIP(gemm_bwd(g.gsum, W2, W2, n.w[DIR], ldw_dir, W + kChDir, m.na, g.gray, m.ld_df, 0, nullptr, 0, (long long)R, s), "train backward: d a");
     CHECK_HIP(embedding_scatter(g.gray, m.ld_df, 0, hist, hist_rows, m.hist_bin, m.dim_a, m.n_vocab, R, g_emb_a, s), "train: embedding_a grad");
   }
@@ -265,6 +272,7 @@ int net_backward(const Net& n, const Dims& m, const NetBufs& b, const BwdBufs& g
     if (l == 4) {
       CHECK_HIP(wg(cur, W, W, pe, n.gw[l], W + kChXyz, n.gb[l], P), "train wgrad: xyz_encoding_5 (xyz)");
       CHECK_HIP(wg(cur, W, W, Seg{b.h[3], W, W, 1, kChXyz}, n.gw[l], W + kChXyz, nullptr, P), "train wgrad: xyz_encoding_5 (h)");
+      if (g_pe) CHECK_HIP(gemm_bwd(cur, W, W, n.w[l], W + kChXyz, 0, kChXyz, g_pe, 64, 0, nullptr, 0, P, s), "train backward: d pe (skip)");
       CHECK_HIP(gemm_bwd(cur, W, W, n.w[l], W + kChXyz, kChXyz, W, nxt, W, 0, b.h[3], W, P, s), "train backward: xyz_encoding_5");
     } else {
       CHECK_HIP(wg(cur, W, W, Seg{b.h[l - 1], W, W, 1, 0}, n.gw[l], W, n.gb[l], P), "train wgrad: xyz_encoding");
@@ -273,6 +281,7 @@ int net_backward(const Net& n, const Dims& m, const NetBufs& b, const BwdBufs& g
     float* t = cur; cur = nxt; nxt = t;
   }
   CHECK_HIP(wg(cur, W, W, pe, n.gw[0], kChXyz, n.gb[0], P), "train wgrad: xyz_encoding_1");
+  if (g_pe) CHECK_HIP(gemm_bwd(cur, W, W, n.w[0], kChXyz, 0, kChXyz, g_pe, 64, 1, nullptr, 0, P, s), "train backward: d pe");
   return DFN_OK;
 }
 
@@ -330,6 +339,7 @@ extern "C" int dfn_nerfh_train_forward(dfn_nerfh_t h, const float* const* params
   if (!params || !rays_o || !rays_d || !hist || !rgb || !disp || !acc || !raw || !rgb0 || !disp0 || !acc0 || !z_std || !beta ||
       !workspace || (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_nerfh_train_forward: bad argument (hist_rows must be 1 or n_rays)");
+  h->train_forward_exact = !use_fused(h);
   if (use_fused(h))
     return fused::train_forward(h, params, rays_o, rays_d, hist, hist_rows, n_rays, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u, rgb,
                                 disp, acc, raw, rgb0, disp0, acc0, z_std, beta, workspace, workspace_bytes, HS(stream));
@@ -414,6 +424,57 @@ extern "C" int dfn_nerfh_train_backward(dfn_nerfh_t h, const float* const* param
                             hist_rows, g_emb_a, g_emb_t, R, s))
     return rc;
   CHECK_HIP(hipStreamWaitEvent(s, h->side_ev[1], 0), "train backward: join");
+  return DFN_OK;
+}
+
+// The reference's training render is differentiable with respect to its rays as well (models/rendering.py:245-337 under autograd:
+// pts = o + d z enter both networks; z itself carries no gradient — near / far bounds, z_samples.detach()).  d L / d rays from the
+// same output gradients as dfn_nerfh_train_backward, on the layer-by-layer exact-fp32 products: the data-gradient chains of BOTH
+// networks continued into the positional encodings, their Jacobians, the per-ray reduction.  Needs the activations of an
+// exact-mode forward (dfn_nerfh_set_train_mode(h, DFN_TRAIN_EXACT)) in `workspace`.
+extern "C" size_t dfn_nerfh_train_backward_rays_scratch_bytes(size_t n_rays, int Nc, int Ni) {
+  const size_t Pf = (n_rays ? n_rays : 1) * (size_t(Nc) + Ni);
+  return (al64(Pf * 64) + al64(Pf * 28) + al64(Pf * 6)) * sizeof(float);
+}
+extern "C" int dfn_nerfh_train_backward_rays(dfn_nerfh_t h, const float* const* params, const float* rays_o, const float* rays_d,
+                                             const float* hist, size_t hist_rows, size_t n_rays, int Nc, int Ni, const float* noise,
+                                             float raw_noise_std, const float* raw, const float* g_rgb, const float* g_rgb0,
+                                             const float* g_beta, float g_tsigma, const float* g_tsigma_dense, float* grad_rays_o,
+                                             float* grad_rays_d, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                             void* stream) {
+  if (int rc = check_train_args(h, Nc, Ni, "dfn_nerfh_train_backward_rays")) return rc;
+  if (!n_rays) return DFN_OK;
+  if (!params || !rays_o || !rays_d || !hist || !raw || !g_rgb || !g_rgb0 || !g_beta || !grad_rays_o || !grad_rays_d || !workspace || !scratch ||
+      (hist_rows != 1 && hist_rows != n_rays))
+    return set_error(DFN_ERR_ARG, "dfn_nerfh_train_backward_rays: bad argument");
+  if (!h->train_forward_exact)
+    return set_error(DFN_ERR_STATE, "dfn_nerfh_train_backward_rays: the last dfn_nerfh_train_forward of this handle ran the fused chain, which keeps no "
+                                    "activations: call dfn_nerfh_set_train_mode(h, DFN_TRAIN_EXACT) before the forward");
+  const Dims m = dims_of(h->desc);
+  const TrainWs w = carve_train(static_cast<float*>(workspace), m, n_rays, Nc, Ni, true);
+  if (w.total > workspace_bytes || dfn_nerfh_train_backward_rays_scratch_bytes(n_rays, Nc, Ni) > scratch_bytes)
+    return set_error(DFN_ERR_ARG, "dfn_nerfh_train_backward_rays: workspace / scratch too small");
+  hipStream_t s = HS(stream);
+  const size_t R = n_rays;
+  const int Nf = Nc + Ni;
+  const size_t Pf = R * size_t(Nf);
+  float* g_pe = static_cast<float*>(scratch);
+  float* g_dpe = g_pe + al64(Pf * 64);
+  float* gpts = g_dpe + al64(Pf * 28);
+  CHECK_HIP(composite_fine_backward_train(raw, w.z_f, g_rgb, g_beta, g_tsigma, g_tsigma_dense, R, Nf, w.gpre_f, s), "train backward (rays): fine composite");
+  CHECK_HIP(composite_coarse_backward(w.raw_c, w.z_c, noise, raw_noise_std, g_rgb0, R, Nc, w.gpre_c, s), "train backward (rays): coarse composite");
+  BwdBufs gf{w.gpre_f, w.gA, w.gB, w.gfin, w.gt0, w.gt1, w.gsum, w.gray, w.wscratch};
+  BwdBufs gc{w.gpre_c, w.gA_c, w.gB_c, w.gfin_c, w.gt0_c, nullptr, w.gsum_c, w.gray_c, w.wscratch_c};
+  if (int rc = net_backward(net_of(params, nullptr, true), m, bufs_of(w, m, true, const_cast<float*>(raw), R, Nc, Ni), gf, true, hist, hist_rows,
+                            nullptr, nullptr, R, s, false, g_pe, g_dpe))
+    return rc;
+  CHECK_HIP(posenc_backward(rays_o, rays_d, w.view, w.z_f, g_pe, g_dpe, 28, R, Nf, gpts, s), "train backward (rays): fine encodings");
+  CHECK_HIP(launch_ray_grad_reduce(gpts, w.z_f, rays_d, R, Nf, 1, grad_rays_o, grad_rays_d, nullptr, s), "train backward (rays): fine reduction");
+  if (int rc = net_backward(net_of(params, nullptr, false), m, bufs_of(w, m, false, nullptr, R, Nc, Ni), gc, false, hist, hist_rows, nullptr, nullptr,
+                            R, s, false, g_pe, g_dpe))
+    return rc;
+  CHECK_HIP(posenc_backward(rays_o, rays_d, w.view, w.z_c, g_pe, g_dpe, 28, R, Nc, gpts, s), "train backward (rays): coarse encodings");
+  CHECK_HIP(launch_ray_grad_reduce(gpts, w.z_c, rays_d, R, Nc, 1, grad_rays_o, grad_rays_d, nullptr, s, 1), "train backward (rays): coarse reduction");
   return DFN_OK;
 }
 

@@ -50,6 +50,7 @@ class NerfHTrainer:
                 raise ValueError(f"NerfHTrainer: parameter {k} must be a contiguous fp32 CUDA tensor")
         self._ws = None
         self._saved = None
+        self.exact = False   # default implementation of the step (fused at netwidth 128; other widths always run the exact one)
 
     # ------------------------------------------------------------------ plumbing
     def _ptr_array(self, tensors):
@@ -70,9 +71,16 @@ class NerfHTrainer:
         return t_rand, noise, u
 
     # ------------------------------------------------------------------ the three calls
-    def forward(self, rays_o, rays_d, hist, Nc, Ni, near, far, t_rand=None, noise=None, raw_noise_std=0., u=None):
+    def set_mode(self, exact):
+        """DFN_TRAIN_FUSED (netwidth 128: the register-resident chains of csrc/nerfh_fused_*.hip) or DFN_TRAIN_EXACT (layer by layer,
+        exact fp32, activations kept: what backward_rays() needs)."""
+        check(self.lib.dfn_nerfh_set_train_mode(self.engine.handle, 1 if exact else 0), "dfn_nerfh_set_train_mode")
+
+    def forward(self, rays_o, rays_d, hist, Nc, Ni, near, far, t_rand=None, noise=None, raw_noise_std=0., u=None, exact=None):
         """Training-mode render_rays -> dict(rgb_map, disp_map, acc_map, raw, rgb0, disp0, acc0, z_std, beta,
-        transient_sigmas); keeps what backward() needs."""
+        transient_sigmas); keeps what backward() needs.  exact: force the layer-by-layer exact-fp32 step (None: `self.exact`)."""
+        exact = self.exact if exact is None else bool(exact)
+        self.set_mode(exact)
         rays_o, rays_d = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3)
         n, dev = rays_o.shape[0], rays_o.device
         hist = _f32c(hist).reshape(-1, self.hist_bin)
@@ -92,7 +100,8 @@ class NerfHTrainer:
                                                ptr(out["beta"]), ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
               "dfn_nerfh_train_forward")
         out["transient_sigmas"] = out["raw"][..., 7]
-        self._saved = dict(hist=hist, n=n, Nc=Nc, Ni=Ni, noise=noise, raw_noise_std=float(raw_noise_std), raw=out["raw"], ws=ws)
+        self._saved = dict(hist=hist, n=n, Nc=Nc, Ni=Ni, noise=noise, raw_noise_std=float(raw_noise_std), raw=out["raw"], ws=ws, exact=exact,
+                           rays_o=rays_o, rays_d=rays_d)
         return out
 
     def loss(self, out, target, coef=1., lambda_u=0.01):
@@ -121,12 +130,33 @@ class NerfHTrainer:
             grads = [p.grad for p in self.params]
         g_rgb, g_rgb0, g_beta = _f32c(g_rgb).reshape(-1, 3), _f32c(g_rgb0).reshape(-1, 3), _f32c(g_beta).reshape(-1)
         gd = None if g_tsigma_dense is None else _f32c(g_tsigma_dense).reshape(s["n"], s["Nc"] + s["Ni"])
+        self.set_mode(s["exact"])   # the workspace was laid out by the forward's implementation
         check(self.lib.dfn_nerfh_train_backward(self.engine.handle, self._ptr_array(self.params), ptr(s["hist"]), s["hist"].shape[0], s["n"],
                                                 s["Nc"], s["Ni"], ptr(s["noise"]), s["raw_noise_std"], ptr(s["raw"]), ptr(g_rgb), ptr(g_rgb0),
                                                 ptr(g_beta), float(g_tsigma), ptr(gd), self._ptr_array(grads),
                                                 ctypes.c_void_p(s["ws"].data_ptr()), s["ws"].numel(), current_stream()),
               "dfn_nerfh_train_backward")
         return grads
+
+    def backward_rays(self, g_rgb, g_rgb0, g_beta, g_tsigma=0., g_tsigma_dense=None):
+        """(d L / d rays_o, d L / d rays_d) [n,3] of the last forward(exact=True): the reference's training render is differentiable
+        w.r.t. its rays under autograd (rendering.py:245-337); both networks contribute."""
+        s = self._saved
+        if s is None or not s["exact"]:
+            raise RuntimeError("NerfHTrainer.backward_rays() needs a forward(exact=True): the fused chain keeps no activations")
+        g_rgb, g_rgb0, g_beta = _f32c(g_rgb).reshape(-1, 3), _f32c(g_rgb0).reshape(-1, 3), _f32c(g_beta).reshape(-1)
+        gd = None if g_tsigma_dense is None else _f32c(g_tsigma_dense).reshape(s["n"], s["Nc"] + s["Ni"])
+        dev = s["raw"].device
+        go, gdir = torch.empty(s["n"], 3, device=dev), torch.empty(s["n"], 3, device=dev)
+        nb = self.lib.dfn_nerfh_train_backward_rays_scratch_bytes(s["n"], s["Nc"], s["Ni"])
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        check(self.lib.dfn_nerfh_train_backward_rays(self.engine.handle, self._ptr_array(self.params), ptr(s["rays_o"]), ptr(s["rays_d"]),
+                                                     ptr(s["hist"]), s["hist"].shape[0], s["n"], s["Nc"], s["Ni"], ptr(s["noise"]),
+                                                     s["raw_noise_std"], ptr(s["raw"]), ptr(g_rgb), ptr(g_rgb0), ptr(g_beta), float(g_tsigma), ptr(gd),
+                                                     ptr(go), ptr(gdir), ctypes.c_void_p(s["ws"].data_ptr()), s["ws"].numel(),
+                                                     ctypes.c_void_p(scratch.data_ptr()), scratch.numel(), current_stream()),
+              "dfn_nerfh_train_backward_rays")
+        return go, gdir
 
     def train_step(self, rays_o, rays_d, hist, target, Nc, Ni, near, far, perturb=1., raw_noise_std=0., draws=None, coef=1.,
                    lambda_u=0.01):
@@ -147,7 +177,9 @@ class _RenderTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, trainer, rays_o, rays_d, hist, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u, *params):
-        out = trainer.forward(rays_o, rays_d, hist, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u)
+        # gradients w.r.t. the rays (pose optimisation through the training render) come from the exact step, which keeps activations
+        ctx.want_rays = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        out = trainer.forward(rays_o, rays_d, hist, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u, exact=True if ctx.want_rays else None)
         ctx.trainer = trainer
         ctx.saved = trainer._saved
         ts = out["transient_sigmas"].contiguous()
@@ -165,9 +197,15 @@ class _RenderTrainFn(torch.autograd.Function):
         dev = ctx.saved["raw"].device
         z3, z1 = torch.zeros(n, 3, device=dev), torch.zeros(n, device=dev)
         grads = [torch.empty_like(p) for p in tr.params]
-        tr.backward(z3 if g_rgb is None else g_rgb, z3 if g_rgb0 is None else g_rgb0, z1 if g_beta is None else g_beta, 0.,
-                    g_ts, grads=grads)
-        return (None,) * 12 + tuple(grads)
+        gs = (z3 if g_rgb is None else g_rgb, z3 if g_rgb0 is None else g_rgb0, z1 if g_beta is None else g_beta)
+        g_o = g_d = None
+        if ctx.want_rays:   # before the weight gradients: they reuse the gradient buffers of the workspace
+            g_o, g_d = tr.backward_rays(*gs, 0., g_ts)
+        if any(ctx.needs_input_grad[12:]):
+            tr.backward(*gs, 0., g_ts, grads=grads)
+        else:
+            grads = [None] * len(tr.params)
+        return (None, g_o if ctx.needs_input_grad[1] else None, g_d if ctx.needs_input_grad[2] else None) + (None,) * 9 + tuple(grads)
 
 
 def render_train(trainer, rays_o, rays_d, hist, Nc, Ni, near, far, perturb, raw_noise_std, retraw, draws=None):

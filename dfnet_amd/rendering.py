@@ -114,6 +114,25 @@ class _RenderImageFn(torch.autograd.Function):
         return (_e.raygen_backward(H, W, focal, go, gd),) + (None,) * 9
 
 
+class _RaygenFn(torch.autograd.Function):
+    """get_rays as an autograd node (ray_utils.py:5-15): (rays_o, rays_d) [H*W,3] of a pose; backward: d L / d c2w [3,4] from the
+    ray gradients (dfn_raygen_backward).  What lets a pose that requires grad reach the training render's ray gradients."""
+
+    @staticmethod
+    def forward(ctx, c2w, H, W, focal):
+        from . import engine as _e
+        o, d, _ = _e.raygen(H, W, focal, c2w.detach(), want_viewdirs=False)
+        ctx.cfg = (H, W, focal)
+        return o.reshape(-1, 3), d.reshape(-1, 3)
+
+    @staticmethod
+    def backward(ctx, go, gd):
+        from . import engine as _e
+        H, W, focal = ctx.cfg
+        z = lambda g: torch.zeros(H * W, 3, device=(go if go is not None else gd).device) if g is None else g.contiguous()
+        return _e.raygen_backward(H, W, focal, z(go), z(gd)), None, None, None
+
+
 class _RenderFramesFn(torch.autograd.Function):
     """rgb [B,H,W,3] = render of B frames (each with its own pose and histogram vector) as ONE ray batch: the DFNet_dm step
     renders every frame of its mini-batch (direct_feature_matching.py:340-348 loops over them); batching them gives each
@@ -218,16 +237,17 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         # training mode (rendering.py:245-337 with test_time=False): stratified depths, coarse rgb + noise, importance sampling
         # with random u, the training extras — on the exact-fp32 training kernels, attached to autograd (nerf_train.py)
         _check_test_time(kwargs, ndc, c2w_staticcam, use_viewdirs, training=True)
-        if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in
-                                           ((c2w,) if c2w is not None else tuple(rays) if rays is not None else ())):
-            # the reference's training render is differentiable w.r.t. its rays / pose; this one carries the WEIGHT gradients only:
-            # refuse instead of returning silent zeros (the test-time render has the pose gradient: test_time=True)
-            raise NotImplementedError("render(test_time=False): gradients w.r.t. rays / c2w are not propagated by the training "
-                                      "render (weights only); optimise poses through the test-time render (test_time=True)")
+        # The reference's training render is differentiable w.r.t. its rays / pose too: rays that require grad make the autograd node
+        # run the exact-fp32 step and return d L / d rays (nerf_train._RenderTrainFn); c2w reaches them through get_rays' own node.
         from . import nerf_train
         dev = torch.device("cuda", torch.cuda.current_device())
         if c2w is not None:
-            rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w, dtype=torch.float32, device=dev))
+            c2w = torch.as_tensor(c2w, dtype=torch.float32, device=dev)
+            if torch.is_grad_enabled() and c2w.requires_grad:
+                rays_o, rays_d = _RaygenFn.apply(c2w[:3, :4].contiguous(), int(H), int(W), float(focal))
+                rays_o, rays_d = rays_o.reshape(int(H), int(W), 3), rays_d.reshape(int(H), int(W), 3)
+            else:
+                rays_o, rays_d = get_rays(H, W, focal, c2w)
         else:
             rays_o, rays_d = rays
         rays_o = torch.as_tensor(rays_o, dtype=torch.float32, device=dev)
@@ -429,6 +449,7 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
                           "render_path: ranks " + ", ".join(str(r) for r in range(all_flags.shape[0]) if all_flags[r].item()))
     if gt_imgs is None:
         all_mse = None
+    n_gathered = ddist.gathered_bytes([rgbs, disps, mse], N)
     if rank != 0:
         return None, None
     rgbs = all_rgb.cpu().numpy()
@@ -439,7 +460,7 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
         psnr = -10. * np.log10(all_mse.cpu().numpy())
         print("Mean PSNR of this run is:", np.mean(psnr, 0))
     render_path.last_timing = {"render_s": t_render, "post_launch_s": t_post, "gather_s": t_gather, "png_tail_s": t_tail, "frames": N, "world": world,
-                               "gathered_bytes": ddist.gathered_bytes([rgbs, disps, mse], N)}
+                               "gathered_bytes": n_gathered}
     return rgbs, disps
 
 

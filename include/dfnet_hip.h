@@ -450,6 +450,19 @@ int dfn_nerfh_train_backward(dfn_nerfh_t h, const float* const* params, const fl
                              const float* g_rgb0, const float* g_beta, float g_tsigma, const float* g_tsigma_dense,
                              float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
 
+/* d L / d rays of the TRAINING render (the reference's render(test_time=False) is differentiable w.r.t. its rays / pose under autograd,
+ * models/rendering.py:245-337: pts = o + d z enter both networks, the view direction the two dir_encodings; z carries no gradient —
+ * near / far bounds, z_samples.detach()): same output gradients as dfn_nerfh_train_backward, the data-gradient chains of BOTH
+ * networks continued through the encodings' Jacobians and reduced per ray.  Layer by layer on the exact-fp32 products: the forward
+ * must have run in DFN_TRAIN_EXACT mode on the same workspace (DFN_ERR_STATE otherwise).  grad_rays_o / grad_rays_d [n,3] are
+ * overwritten; scratch: dfn_nerfh_train_backward_rays_scratch_bytes. */
+size_t dfn_nerfh_train_backward_rays_scratch_bytes(size_t n_rays, int Nc, int Ni);
+int dfn_nerfh_train_backward_rays(dfn_nerfh_t h, const float* const* params, const float* rays_o, const float* rays_d, const float* hist,
+                                  size_t hist_rows, size_t n_rays, int Nc, int Ni, const float* noise, float raw_noise_std,
+                                  const float* raw, const float* g_rgb, const float* g_rgb0, const float* g_beta, float g_tsigma,
+                                  const float* g_tsigma_dense, float* grad_rays_o, float* grad_rays_d, void* workspace,
+                                  size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
 /* Test-time render_rays for ANY netwidth on the same layer-by-layer exact-fp32 path (the register-resident kernels
  * behind dfn_render_rays exist for netwidth 128 and 256): models/rendering.py:245-337 with test_time=True, from
  * the handle's committed parameters.  raw [n_rays, Nc+Ni, 9] is required (output and scratch). */

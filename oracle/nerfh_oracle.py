@@ -408,6 +408,21 @@ def train_step(rows, target, coarse, fine, emb_a, emb_t, Nc, Ni, t_rand, noise, 
         {k: v.detach() for k, v in out.items()}
 
 
+def train_step_grad_rays(rays_o, rays_d, near, far, img_idx, target, coarse, fine, emb_a, emb_t, Nc, Ni, t_rand, noise, u, perturb=1.,
+                         raw_noise_std=0.):
+    """d sum(NerfWLoss) / d (rays_o, rays_d) of the TRAINING render by autograd (models/rendering.py:245-337 with test_time=False
+    under loss.backward(): pts = o + d z enter both networks, viewdirs = d / |d| both direction encodings; z carries none —
+    z_samples.detach()).  Returns (g_o, g_d) [R,3]."""
+    o = rays_o.detach().clone().requires_grad_(True)
+    d = rays_d.detach().clone().requires_grad_(True)
+    out = render_rays_train(pack_ray_rows(o, d, near, far, img_idx), coarse, fine, emb_a, emb_t, Nc, Ni, t_rand, noise, u, perturb,
+                            raw_noise_std)
+    ld = nerfw_loss({'rgb_fine': out['rgb_map'], 'rgb_coarse': out['rgb0'], 'beta': out['beta'],
+                     'transient_sigmas': out['transient_sigmas']}, target)
+    sum(ld.values()).backward()
+    return o.grad, d.grad
+
+
 def render_grad_rays(rays_o, rays_d, G, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx):
     """d sum(rgb * G) / d (rays_o, rays_d) by autograd through render(rays=...) — viewdirs are derived from
     rays_d inside render (rendering.py:366-371), so their normalisation is part of the gradient."""

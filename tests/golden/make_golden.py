@@ -275,7 +275,8 @@ def main():
         c2w = syn.orbit_pose(2, 8)[:3, :4]
         ro, rd = ray_utils.get_rays(480, 640, 585.0, t(c2w))
         sel = r12.choice(480 * 640, R, replace=False)
-        rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        # the rays carry gradient: the reference's training render is differentiable w.r.t. them too (G13 `g_rays`)
+        rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).clone().requires_grad_(True)
         target = t(r12.uniform(0, 1, (R, 3)).astype(np.float32))
         coarse, fine, emb_a, emb_t = nets[128]
         for m in (coarse, fine, emb_a, emb_t):
@@ -290,9 +291,9 @@ def main():
         t_rand, noise, u = (r for _, r in rc.rec)
         assert t_rand.shape == (R, Nc) and noise.shape == (R, Nc) and u.shape == (R, Ni)
         assert sorted(extras) == sorted(["raw", "rgb0", "disp0", "acc0", "z_std", "transient_sigmas", "beta"])
-        save(f"g12_render_train_{tag}", Nc=Nc, Ni=Ni, near=0., far=2.5, hist=hist, raw_noise_std=noise_std, rays_o=rays[0],
-             rays_d=rays[1], t_rand=t_rand, noise=noise, u=u, rgb=rgb, disp=disp, acc=acc,
-             **{k: v for k, v in extras.items()})
+        save(f"g12_render_train_{tag}", Nc=Nc, Ni=Ni, near=0., far=2.5, hist=hist, raw_noise_std=noise_std, rays_o=rays[0].detach(),
+             rays_d=rays[1].detach(), t_rand=t_rand, noise=noise, u=u, rgb=rgb.detach(), disp=disp.detach(), acc=acc.detach(),
+             **{k: v.detach() for k, v in extras.items()})
         # the step: results dict as run_nerf.py:54-58, NerfWLoss(coef=1), loss = sum, backward
         loss_d = ref_losses.loss_dict['nerfw'](coef=1)({'rgb_fine': rgb, 'rgb_coarse': extras['rgb0'], 'beta': extras['beta'],
                                                         'transient_sigmas': extras['transient_sigmas']}, target)
@@ -300,7 +301,7 @@ def main():
         with torch.no_grad():
             psnr = nerfw.mse2psnr(nerfw.img2mse(rgb, target))
         loss.backward()
-        out = {"target": target, "psnr": psnr, "loss": loss.detach()}
+        out = {"target": target, "psnr": psnr, "loss": loss.detach(), "g_rays": rays.grad.clone()}   # d loss / d (rays_o, rays_d) [2,R,3]
         out.update({"loss_" + k: v.detach() for k, v in loss_d.items()})
         none_grads = []
         for pre, mod in (("coarse.", coarse), ("fine.", fine), ("embedding_a.", emb_a), ("embedding_t.", emb_t)):

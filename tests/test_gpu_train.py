@@ -226,6 +226,80 @@ def test_render_training_autograd_surface_and_optimizer_step():
     assert float((rgb2.detach() - before).abs().max()) > 1e-5
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_training_render_ray_gradients(gold, tag):
+    """render(test_time=False) with rays that require grad: the reference's training render is differentiable w.r.t. its rays
+    (rendering.py:245-337 under loss.backward()).  d sum(NerfWLoss) / d (rays_o, rays_d) on the HIP path (the autograd node switches
+    to the exact-fp32 step, dfn_nerfh_train_backward_rays) against the REFERENCE's own gradients (G13 `g_rays`) with its recorded
+    draws, and — on 64 rays at 64+128 — against autograd through the oracle.  The weight gradients of the same backward are checked
+    against the fused step's."""
+    from dfnet_amd import losses, rendering
+    from dfnet_amd.nerfw import HipQuery
+    g12, g = gold(f"g12_render_train_{tag}"), gold(f"g13_train_step_{tag}")
+    E, mods, (cw, fw, ea, et) = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    o, d, hist, Nc, Ni, t_rand, noise, u = _g12_inputs(g12)
+    target = T(g["target"]).to(DEV)
+    std = float(g12["raw_noise_std"])
+    tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=std, draws=(t_rand, noise, u))   # fused: weights only
+    fused = [p.grad.clone() for p in tr.params]
+    for p in tr.params:
+        p.grad = None
+    kw = dict(network_query_fn=HipQuery(E, trainer=tr), perturb=1., N_importance=Ni, network_fine=mods[1], N_samples=Nc, network_fn=mods[0],
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=std, embedding_a=mods[2], embedding_t=mods[3], test_time=False, ndc=False,
+              lindisp=False, near=0., far=2.5)
+    rays = torch.stack([o, d], 0).clone().requires_grad_(True)
+    rgb, disp, acc, extras = rendering.render(480, 640, 585.0, rays=rays, retraw=True, img_idx=hist, draws=(t_rand, noise, u), **kw)
+    loss_d = losses.loss_dict['nerfw'](coef=1)({'rgb_fine': rgb, 'rgb_coarse': extras['rgb0'], 'beta': extras['beta'],
+                                                'transient_sigmas': extras['transient_sigmas']}, target)
+    sum(loss_d.values()).backward()
+    ref = T(g["g_rays"])
+    eo, ed = rel_l2(rays.grad[0], ref[0]), rel_l2(rays.grad[1], ref[1])
+    per = ((rays.grad.cpu() - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-30)).median()
+    print(f"training-render ray gradients vs the reference (G13-{tag}): d rays_o {eo:.2e}, d rays_d {ed:.2e}, median per-ray {float(per):.2e}")
+    # Criterion of test_generic_width_render_gradient_vs_oracle: the median per-ray error (< 1e-3) and the relative L2 over the batch
+    # (< 1e-2).  Single rays sit further off in ANY fp32 implementation: autograd of torch.cumprod divides by the factors 1 - alpha,
+    # which vanish on opaque samples (64+128 samples, raw_noise_std 1: 1.5e-3 over the batch; 16+32: 2-4e-4); the kernels use the
+    # division-free suffix sums.  The oracle's own autograd sits 1-2e-4 from the reference's (tests/test_oracle_golden.py).
+    assert eo < 1e-2 and ed < 1e-2 and float(per) < 1e-3
+    for name, p, g0 in zip(tr.names, tr.params, fused):   # exact step (this backward) vs fused step: the same weight gradients
+        assert rel_l2(p.grad, g0) < 5e-4, name
+    # a pose that requires grad reaches the rays through get_rays' own node
+    pose = T(syn.orbit_pose(2, 8)[:3, :4].copy()).to(DEV).requires_grad_(True)
+    rgb2 = rendering.render(6, 8, 7.3, c2w=pose, img_idx=hist, draws=None, **dict(kw, N_samples=8, N_importance=8, perturb=0.))[0]
+    rgb2.sum().backward()
+    assert pose.grad is not None and pose.grad.shape == (3, 4) and bool(torch.isfinite(pose.grad).all()) and float(pose.grad.abs().max()) > 0
+
+
+def test_training_render_ray_gradients_vs_oracle_64_rays():
+    E, mods, (cw, fw, ea, et) = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    R, Nc, Ni = 64, 64, 128
+    rng = np.random.default_rng(15)
+    ro, rd = orc.get_rays(480, 640, 585.0, T(syn.orbit_pose(3, 8))[:3, :4])
+    sel = rng.choice(480 * 640, R, replace=False)
+    o, d = ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous()
+    hist = T(rng.integers(0, 40, (R, 10)).astype(np.float32))
+    target = T(rng.uniform(0, 1, (R, 3)).astype(np.float32))
+    gen = torch.Generator().manual_seed(19)
+    t_rand, noise, u = torch.rand(R, Nc, generator=gen), torch.randn(R, Nc, generator=gen), torch.rand(R, Ni, generator=gen)
+    c, f = {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}
+    go_ref, gd_ref = orc.train_step_grad_rays(o, d, 0., 2.5, hist, target, c, f, T(ea), T(et), Nc, Ni, t_rand, noise, u, perturb=1., raw_noise_std=1.)
+    draws = tuple(t.to(DEV) for t in (t_rand, noise, u))
+    out = tr.forward(o.to(DEV), d.to(DEV), hist.to(DEV), Nc, Ni, 0., 2.5, *draws[:2], 1., draws[2], exact=True)
+    loss5, gs, gts = tr.loss(out, target.to(DEV))
+    go, gd = tr.backward_rays(*gs, gts)
+    eo, ed = rel_l2(go, go_ref), rel_l2(gd, gd_ref)
+    per = (torch.cat([go.cpu() - go_ref, gd.cpu() - gd_ref], -1).norm(dim=-1) / torch.cat([go_ref, gd_ref], -1).norm(dim=-1).clamp_min(1e-30)).median()
+    print(f"training-render ray gradients vs oracle autograd, 64 rays @ 64+128: d rays_o {eo:.2e}, d rays_d {ed:.2e}, median per-ray {float(per):.2e}")
+    assert eo < 1e-2 and ed < 1e-2 and float(per) < 1e-3
+    go2, gd2 = tr.backward_rays(*gs, gts)
+    assert torch.equal(go, go2) and torch.equal(gd, gd2)   # deterministic
+    tr.forward(o.to(DEV), d.to(DEV), hist.to(DEV), Nc, Ni, 0., 2.5, *draws[:2], 1., draws[2])   # fused forward keeps no activations
+    with pytest.raises(RuntimeError):
+        tr.backward_rays(*gs, gts)
+
+
 # ---------------------------------------------------------------------------------------------- generic-width render
 def test_generic_path_equals_fast_path_w128():
     E, _, _ = modules()

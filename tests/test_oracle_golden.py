@@ -247,6 +247,13 @@ def test_g13_training_step(gold, tag):
     rows = T(g["emb_rows"])
     close(grads["embedding_a.weight"][rows], g["ga_rows"], 1e-4, 1e-8)
     close(grads["embedding_t.weight"][rows], g["gt_rows"], 1e-4, 1e-8)
+    # the same step's gradient w.r.t. the RAYS (the reference's training render is differentiable w.r.t. them): pins the oracle's
+    # autograd for tests/test_gpu_train.py::test_training_render_ray_gradients
+    go, gd = orc.train_step_grad_rays(T(g12["rays_o"]), T(g12["rays_d"]), float(g12["near"]), float(g12["far"]), g12["hist"], T(g["target"]),
+                                      c, f, ea, et, int(g12["Nc"]), int(g12["Ni"]), T(g12["t_rand"]), T(g12["noise"]), T(g12["u"]), perturb=1.,
+                                      raw_noise_std=float(g12["raw_noise_std"]))
+    ref = T(g["g_rays"])
+    assert float((go - ref[0]).norm() / ref[0].norm()) < 2e-4 and float((gd - ref[1]).norm() / ref[1].norm()) < 2e-4
 
 
 def test_g14_render_options(gold):
