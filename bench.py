@@ -701,7 +701,8 @@ def secondary_nerfh_train(dev):
         return (ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous(),
                 T(rng.integers(0, 40, (R, 10)).astype(np.float32)), T(rng.uniform(0, 1, (R, 3)).astype(np.float32)))
 
-    # parity at 256 rays
+    # parity at 256 rays, both implementations of the step (fused register-resident chains = the default at netwidth 128; the
+    # layer-by-layer exact-fp32 step)
     R = 256
     o, d, hist, target = batch(R)
     gen = torch.Generator().manual_seed(9)
@@ -711,10 +712,15 @@ def secondary_nerfh_train(dev):
     t0 = time.perf_counter()
     ld_ref, _, g_ref, _ = orc.train_step(rows, target, c, f, T(ea), T(et), NC, NI, *draws, perturb=1., raw_noise_std=1.)
     cpu_s = time.perf_counter() - t0
-    ld, _, _ = tr.train_step(o.to(dev), d.to(dev), hist.to(dev), target.to(dev), NC, NI, NEAR, FAR, perturb=1., raw_noise_std=1.,
-                             draws=tuple(t.to(dev) for t in draws))
-    worst = max(float((p.grad.cpu().double() - g_ref[k].double()).norm() / g_ref[k].double().norm()) for k, p in zip(tr.names, tr.params))
-    loss_rel = max(abs(float(ld[k]) - float(ld_ref[k])) / abs(float(ld_ref[k])) for k in ld)
+    par = {}
+    for tag, exact in (("fused", False), ("exact", True)):
+        tr.exact = exact
+        ld, _, _ = tr.train_step(o.to(dev), d.to(dev), hist.to(dev), target.to(dev), NC, NI, NEAR, FAR, perturb=1., raw_noise_std=1.,
+                                 draws=tuple(t.to(dev) for t in draws))
+        par[tag] = {"worst_rel_l2_over_64_gradients": max(float((p.grad.cpu().double() - g_ref[k].double()).norm() / g_ref[k].double().norm())
+                                                           for k, p in zip(tr.names, tr.params)),
+                    "worst_loss_term_rel_diff": max(abs(float(ld[k]) - float(ld_ref[k])) / abs(float(ld_ref[k])) for k in ld)}
+    range_flags = E.range_flags()
     # timing at the reference's batch
     R = 1536
     o, d, hist, target = (t.to(dev) for t in batch(R))
@@ -724,21 +730,43 @@ def secondary_nerfh_train(dev):
         tr.train_step(o, d, hist[:1], target, NC, NI, NEAR, FAR, perturb=1., raw_noise_std=0.)
         opt.step()
 
-    step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 10 * 1e3
+    def timed(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    draws_t = tr.draw(R, NC, NI, 1., dev)
+    ms = {}
+    for tag, exact in (("exact", True), ("fused", False)):
+        tr.exact = exact
+        ms[tag] = timed(step)
+        ms[tag + "_forward"] = timed(lambda: tr.forward(o, d, hist[:1], NC, NI, NEAR, FAR, draws_t[0], None, 0., draws_t[2]))
     mac_fwd = R * (NC * (MAC_COARSE + 128 * 128 + 64 * (128 + 27) + 64 * 3) + (NC + NI) * MAC_FINE)
+    # what the fused step moves through HBM: every layer input X_l and every pre-activation gradient G_l as split-f16 operands
+    # (4 bytes per element), written once by the chains and read once by the weight-gradient stream
+    wt_f, wt_c = -(-R * (NC + NI) // 256) * 8, -(-R * NC // 256) * 8
+    stored = (wt_f * (96 + 98) + wt_c * (80 + 80)) * 2048
+    tf = 6.0 * mac_fwd / (ms["fused"] * 1e-3) / 1e12
     return {"workload": "one NeRF-H optimisation step (run_nerf.py:32-80): 1536 random rays, 64+128 samples, netwidth 128, perturb 1: "
                         "training-mode render, NerfWLoss, gradients of all 64 parameter tensors, Adam",
-            "step_ms": ms, "rays_per_s": R / ms * 1e3, "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), reference precision",
-            "algorithmic_TFLOPs": 6.0 * mac_fwd / (ms * 1e-3) / 1e12, "fp32_mfma_frac": 6.0 * mac_fwd / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"],
-            "flops_note": "forward 2 x MAC, data gradients 2 x MAC, weight gradients 2 x MAC",
-            "parity_256_rays_vs_oracle_autograd": {"worst_rel_l2_over_64_gradients": worst, "worst_loss_term_rel_diff": loss_rel,
-                                                   "raw_noise_std": 1.0, "cpu_oracle_step_s": cpu_s}}
+            "step_ms": ms["fused"], "forward_ms": ms["fused_forward"], "rays_per_s": R / ms["fused"] * 1e3,
+            "arithmetic": "split-f16 MFMA (three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation: fp32-grade), register-resident forward "
+                          "and data-gradient chains, weight gradients streamed over the stored operands (csrc/nerfh_fused_*.hip)",
+            "algorithmic_TFLOPs": tf, "f16_mfma_frac_of_nominal": 3.0 * tf / PEAK_TFLOPS["f16"], "frac_of_sustained_mfma": of_sustained(3.0 * tf),
+            "flops_note": "forward 2 x MAC, data gradients 2 x MAC, weight gradients 2 x MAC; x 3 f16 MFMAs per product against the 2.5 PFLOP/s peak",
+            "stored_operand_bytes_per_step": stored,
+            "hbm_GBps_floor_over_the_step": 2.0 * stored / (ms["fused"] * 1e-3) / 1e9,
+            "hbm_note": "X_l and G_l written once (chains) and read once (weight-gradient stream): 2 x stored bytes over the WHOLE step time — "
+                        "a floor; per kernel: profiles/r04_train_step_kernel_stats.csv",
+            "range_flags_after_the_steps": range_flags,
+            "exact_fp32_step": {"step_ms": ms["exact"], "forward_ms": ms["exact_forward"], "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), layer by layer, "
+                                "activations in HBM (DFN_TRAIN_EXACT; any netwidth)",
+                                "fp32_mfma_frac": 6.0 * mac_fwd / (ms["exact"] * 1e-3) / 1e12 / PEAK_TFLOPS["f32"]},
+            "parity_256_rays_vs_oracle_autograd": {"fused": par["fused"], "exact": par["exact"], "raw_noise_std": 1.0, "cpu_oracle_step_s": cpu_s}}
 
 
 def secondary_w256(dev):

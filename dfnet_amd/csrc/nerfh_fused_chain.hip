@@ -55,9 +55,9 @@ DFN_DEV void init_stager(Stager& st, const ChainArgs& a) {
 template <int KC, int N>
 DFN_DEV void store_array(char* base, const F (&v)[N]) {
 #pragma unroll
-  for (int c = 0; c < KC; ++c) {
-    *reinterpret_cast<half8*>(base + c * kChunkBytes) = v[c].hi;
-    *reinterpret_cast<half8*>(base + c * kChunkBytes + 1024) = v[c].lo;
+  for (int c = 0; c < KC; ++c) {   // written once, read once by another kernel: non-temporal
+    __builtin_nontemporal_store(v[c].hi, reinterpret_cast<half8*>(base + c * kChunkBytes));
+    __builtin_nontemporal_store(v[c].lo, reinterpret_cast<half8*>(base + c * kChunkBytes + 1024));
   }
 }
 

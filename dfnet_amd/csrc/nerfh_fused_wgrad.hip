@@ -320,26 +320,35 @@ hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw
 // their gradients need sum_samples G[p, :] per ray (models/nerfw.py:62-95).  One block per ray; fixed summation order.
 __global__ __launch_bounds__(256) void frag_ray_sum_kernel(const char* __restrict__ arr, int kc, const float* __restrict__ gscale, int Ns,
                                                            float* __restrict__ out, int ldo) {
-  __shared__ float red[256];
+  // a lane owns one 16-byte piece (8 slots of one half of one chunk) and walks the ray's samples 256 / (2 kc) at a time: 16-byte loads
+  // of the hi and the lo plane instead of one 2-byte load per value
+  __shared__ float red[256 * 8];
   const size_t ray = blockIdx.x;
-  const int nf = 16 * kc, groups = 256 / nf;
-  const int fl = threadIdx.x % nf, sg = threadIdx.x / nf;
-  const int c = fl >> 4, hh = (fl >> 3) & 1, jj = fl & 7;
-  float acc = 0.f;
-  if (sg < groups)
-    for (int smp = sg; smp < Ns; smp += groups) {
-      const size_t pt = ray * Ns + smp;
-      const size_t wt = pt >> 5;
-      const char* p = arr + (wt * kc + c) * kChunkBytes + (2 * (pt & 31) + hh) * 16 + jj * 2;
-      const float v = float(*reinterpret_cast<const _Float16*>(p)) + float(*reinterpret_cast<const _Float16*>(p + 1024));
-      acc += v / gscale[wt];
-    }
-  red[threadIdx.x] = acc;
+  const int np = 2 * kc;                       // pieces per point
+  const int groups = 256 / np;                 // samples in flight per pass
+  const int piece = threadIdx.x % np, sg = threadIdx.x / np;
+  const int c = piece >> 1, hh = piece & 1;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int smp = sg; smp < Ns; smp += groups) {
+    const size_t pt = ray * Ns + smp;
+    const size_t wt = pt >> 5;
+    const char* p = arr + (wt * kc + c) * kChunkBytes + (2 * (pt & 31) + hh) * 16;
+    const half8 hi = *reinterpret_cast<const half8*>(p), lo = *reinterpret_cast<const half8*>(p + 1024);
+    const float inv = 1.f / gscale[wt];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += (float(hi[j]) + float(lo[j])) * inv;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
   __syncthreads();
   if (sg == 0) {
-    for (int k = 1; k < groups; ++k) acc += red[k * nf + fl];
-    const int slot = 8 * c + jj;
-    out[ray * ldo + 64 * (slot >> 5) + hidden_feature(hh, slot & 31)] = acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s = acc[j];
+      for (int k = 1; k < groups; ++k) s += red[(k * np + piece) * 8 + j];   // fixed order: deterministic
+      const int slot = 8 * c + j;
+      out[ray * ldo + 64 * (slot >> 5) + hidden_feature(hh, slot & 31)] = s;
+    }
   }
 }
 hipError_t launch_frag_ray_sum(const char* arr, int kc, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s) {

@@ -26,7 +26,7 @@ draws = tr.draw(R, Nc, Ni, 1., dev, torch.Generator(device=dev).manual_seed(1))
 
 
 def run(mode):
-    tr.lib.dfn_nerfh_set_train_mode(E.handle, mode)
+    tr.exact = bool(mode)   # 1: layer-by-layer exact fp32, 0: fused chains
     for p in tr.params:
         p.grad = None
     ld, psnr, out = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=1., draws=draws)
@@ -64,7 +64,7 @@ def timed(fn, iters=10):
 
 res = {}
 for mode, tag in ((1, "exact"), (0, "fused")):
-    tr.lib.dfn_nerfh_set_train_mode(E.handle, mode)
+    tr.exact = bool(mode)
     fwd = timed(lambda: tr.forward(o, d, hist, Nc, Ni, 0., 2.5, *draws[:2], 0., draws[2]))
     out = tr.forward(o, d, hist, Nc, Ni, 0., 2.5, *draws[:2], 0., draws[2])
     loss5, gs, gts = tr.loss(out, target)

@@ -17,6 +17,7 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 Nc, Ni = 64, 128
 E, mods, _ = modules(W=W)
 tr = nerf_train.NerfHTrainer(E, *mods)
+tr.exact = os.environ.get("DFN_TRAIN_EXACT", "0") == "1"   # DFN_TRAIN_EXACT=1: time the layer-by-layer exact-fp32 step instead
 opt = torch.optim.Adam(tr.params, lr=5e-4, betas=(0.9, 0.999))
 rng = np.random.default_rng(0)
 ro, rd = orc.get_rays(480, 640, 585.0, torch.from_numpy(syn.orbit_pose(0, 8))[:3, :4])
@@ -50,4 +51,5 @@ macs = R * (Nc * (130944 + 16384 + 64 * (W + 27) + 192) + (Nc + Ni) * 182720) * 
 print(json.dumps({"workload": f"NeRF-H optimisation step: {R} rays, {Nc}+{Ni} samples, netwidth {W}, perturb 1", "forward_ms": fwd_ms,
                   "backward_ms": bwd_ms, "step_ms_with_adam": step_ms, "rays_per_s": R / step_ms * 1e3,
                   "approx_forward_TFLOPs": 2 * macs / fwd_ms / 1e9, "approx_step_TFLOPs": 6 * macs / step_ms / 1e9,
-                  "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s"}))
+                  "arithmetic": ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32), layer by layer" if tr.exact or W != 128 else
+                                 "split-f16 MFMA, fused register-resident chains + weight-gradient stream")}))
