@@ -309,7 +309,8 @@ hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw
   if (!R) return hipSuccess;
   const size_t lds = size_t(kd + (w_te ? nt : 0)) * 64 * sizeof(float);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  const int grid = int(R < 512 ? R : 512);
+  // every block stages the two weight tails (25 KB) once: few blocks of many rays, not one block per ray
+  const int grid = int(R < 1024 ? (R + 7) / 8 : 128);
   hipLaunchKernelGGL(ray_bias_train_kernel, dim3(grid), dim3(128), lds, s, w_dir, b_dir, ldw_dir, kd, dir_in, ld_dir, w_te, b_te, ldw_te,
                      nt, t_in, ld_t, R, table);
   return hipGetLastError();
