@@ -111,76 +111,105 @@ def numa0_cpus():
         return sorted(os.sched_getaffinity(0))
 
 
-def cpu_baseline_worker(sample_rays, out_path):
-    """Runs in its own process (cpu_baseline() below), pinned to NUMA node 0 with OMP_PROC_BIND=close / OMP_PLACES=cores: the
-    oracle on a `sample_rays`-ray subset of frame 0 at the judged 64+128 samples.  Thread count swept on an eighth of the sample
-    (the oracle is one torch-CPU process: 128 threads are several times SLOWER than 8-16 here); then ONE untimed full pass at the
-    fastest setting (allocator, thread pool and caches warm — without it three timed runs fell monotonically 11.8 -> 7.2 s) and three
-    timed passes: `value` = the median, the minimum reported beside it.  Plus one full 160x120 frame at 32+64 samples (BASELINE
-    configs[0] shape).  Writes {record, rows, reference outputs} to out_path."""
+def physical_cores(cpus):
+    """One CPU id per physical core among `cpus` (SMT siblings dropped), in id order."""
+    seen, out = set(), []
+    for c in sorted(cpus):
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(c)
+    return out
+
+
+def cpu_baseline_worker(mode, sample_rays, out_path):
+    """Runs in its own process (cpu_baseline() below; the parent sets the affinity before exec, OMP_PROC_BIND=close / OMP_PLACES=cores).
+    mode "sweep": the oracle's rays/s on an eighth of the sample per thread count (the oracle is one torch-CPU process: 128 threads are
+    several times SLOWER than 8-16 here) -> {threads: rays/s}.  mode "run": this process owns exactly as many physical cores as
+    threads (none of them among the first eight of the node, where the OS and the parent live): ONE untimed full pass over the
+    `sample_rays`-ray subset of frame 0 at the judged 64+128 samples (allocator, thread pool, caches: without it three timed runs
+    fell monotonically 11.8 -> 7.2 s), then five timed passes — `value` = the median, the minimum beside it — plus one full 160x120
+    frame at 32+64 samples (BASELINE configs[0] shape).  Writes its record (and rows / reference outputs) to out_path."""
     from dfnet_amd import synthetic as syn
     from oracle import nerfh_oracle as orc
-    ncpu = int(os.environ.get("DFN_CPU_PIN_COUNT", "0")) or len(os.sched_getaffinity(0))   # the parent pinned this process before exec
+    ncpu = int(os.environ.get("DFN_CPU_PIN_COUNT", "0")) or len(os.sched_getaffinity(0))
     rows, (c, f, ea, et) = oracle_sample(sample_rays)
-    default_threads = torch.get_num_threads()
-    cand = sorted({t for t in (8, 16, 32, 64, ncpu) if 1 <= t <= ncpu})
-    sub = rows[: max(512, sample_rays // 8)]
-    sweep = {}
+    if mode == "sweep":
+        cand = sorted({t for t in (4, 8, 16, 32, 64) if 1 <= t <= ncpu} | {min(ncpu, 8)})
+        sub = rows[: max(512, sample_rays // 8)]
+        sweep = {}
+        with torch.no_grad():
+            for t in cand:
+                torch.set_num_threads(t)
+                orc.render_rays(sub[:256], c, f, ea, et, NC, NI)  # warm-up (thread pool, allocator)
+                t0 = time.perf_counter()
+                orc.render_rays(sub, c, f, ea, et, NC, NI)
+                sweep[t] = sub.shape[0] / (time.perf_counter() - t0)
+        torch.save({"sweep": sweep, "sub": sub.shape[0]}, out_path)
+        return
+    threads = ncpu
+    torch.set_num_threads(threads)
     with torch.no_grad():
-        for t in cand:
-            torch.set_num_threads(t)
-            orc.render_rays(sub[:256], c, f, ea, et, NC, NI)  # warm-up (thread pool, allocator)
-            t0 = time.perf_counter()
-            orc.render_rays(sub, c, f, ea, et, NC, NI)
-            sweep[t] = sub.shape[0] / (time.perf_counter() - t0)
-        best = max(sweep, key=sweep.get)
-        torch.set_num_threads(best)
         t0 = time.perf_counter()
         orc.render_rays(rows, c, f, ea, et, NC, NI)      # the untimed full pass
         warm = time.perf_counter() - t0
         runs = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             ref = orc.render_rays(rows, c, f, ea, et, NC, NI)
             runs.append(time.perf_counter() - t0)
-        dt = sorted(runs)[1]
+        dt = sorted(runs)[2]
         # one full frame of BASELINE configs[0]'s shape (160x120, 32+64 samples), second of two passes
         pose0 = torch.from_numpy(syn.orbit_pose(0, 8))
         orc.render(120, 160, FOCAL / 4, 32768, c, f, ea, et, 32, 64, NEAR, FAR, syn.HIST_IDX, c2w=pose0)
         t0 = time.perf_counter()
         orc.render(120, 160, FOCAL / 4, 32768, c, f, ea, et, 32, 64, NEAR, FAR, syn.HIST_IDX, c2w=pose0)
         dt_frame = time.perf_counter() - t0
-    rec = {"value": sample_rays / dt, "min_time_value": sample_rays / min(runs), "unit": "rays/s", "cores": best, "kind": "port",
-           "sample": f"median of 3 runs over {sample_rays} random rays of frame 0 at 64+128 samples, one chunk each, after one untimed full "
-                     f"pass ({warm:.1f} s): {', '.join('%.2f' % r for r in runs)} s, spread {(max(runs) - min(runs)) / dt * 100:.1f} % of the median "
-                     f"(oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32, autograd anomaly mode off, no_grad)",
-           "pinning": f"own process, affinity = the {ncpu} CPUs of NUMA node 0 (set before exec), OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} "
-                      f"OMP_PLACES={os.environ.get('OMP_PLACES')}",
+    mid3 = sorted(runs)[1:4]
+    rec = {"value": sample_rays / dt, "min_time_value": sample_rays / min(runs), "unit": "rays/s", "cores": threads, "kind": "port",
+           "sample": f"median of 5 runs over {sample_rays} random rays of frame 0 at 64+128 samples, one chunk each, after one untimed full "
+                     f"pass ({warm:.1f} s): {', '.join('%.2f' % r for r in runs)} s; the middle three within "
+                     f"{(mid3[2] - mid3[0]) / dt * 100:.1f} % of the median (oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32, autograd "
+                     "anomaly mode off, no_grad)",
+           "pinning": f"own process, affinity = {threads} physical cores of NUMA node 0 (set before exec; not the node's first eight), "
+                      f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
            "runs_s": [round(r, 3) for r in runs],
            "frame_640x480_extrapolated_s": H * W / (sample_rays / dt),
            "full_frame_160x120_32+64": {"seconds": dt_frame, "rays_per_s": 160 * 120 / dt_frame, "chunk": 32768},
-           "host_cpus": os.cpu_count(), "numa0_cpus": ncpu, "torch_default_threads": default_threads,
-           "thread_sweep_rays_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
-           "sweep_sample": f"{sub.shape[0]} rays per setting; `cores` = the fastest setting, used for `value`"}
+           "host_cpus": os.cpu_count()}
     torch.save({"rec": rec, "rows": rows, "ref": ref}, out_path)
 
 
 def cpu_baseline(sample_rays):
-    """SURVEY §8(d) CPU leg, in a child process pinned to one NUMA node (cpu_baseline_worker).  Returns (record, (rows, reference
-    outputs on the subset))."""
+    """SURVEY §8(d) CPU leg in child processes pinned inside one NUMA node (cpu_baseline_worker): a thread-count sweep, then the timed
+    runs in a process that owns exactly the fastest count of physical cores.  Returns (record, (rows, reference outputs on the subset))."""
     import tempfile
     out = os.path.join(tempfile.mkdtemp(prefix="dfn_cpu_"), "cpu.pt")
-    cpus = numa0_cpus()
-    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="",
-               DFN_CPU_PIN_COUNT=str(len(cpus)))
-    env.pop("OMP_NUM_THREADS", None)
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(sample_rays), out], env=env, capture_output=True, text=True,
-                       preexec_fn=lambda: os.sched_setaffinity(0, cpus))   # affinity set before exec: the OpenMP runtime binds inside it
-    if r.returncode != 0:
-        raise RuntimeError("cpu baseline worker failed:\n" + r.stderr[-2000:])
-    d = torch.load(out, weights_only=False)
-    os.remove(out)
-    return d["rec"], (d["rows"], d["ref"])
+    cores = physical_cores(numa0_cpus())
+    pool = cores[8:] if len(cores) >= 16 else cores     # leave the node's first cores to the OS, IRQs and this process
+
+    def child(mode, cpus):
+        env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="",
+                   DFN_CPU_PIN_COUNT=str(len(cpus)))
+        env.pop("OMP_NUM_THREADS", None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", mode, str(sample_rays), out], env=env, capture_output=True,
+                           text=True, preexec_fn=lambda: os.sched_setaffinity(0, cpus))   # set before exec: the OpenMP runtime binds inside it
+        if r.returncode != 0:
+            raise RuntimeError(f"cpu baseline worker ({mode}) failed:\n" + r.stderr[-2000:])
+        d = torch.load(out, weights_only=False)
+        os.remove(out)
+        return d
+
+    sw = child("sweep", pool)
+    best = max(sw["sweep"], key=sw["sweep"].get)
+    d = child("run", pool[:best])
+    rec = d["rec"]
+    rec.update({"numa0_physical_cores": len(cores), "thread_sweep_rays_per_s": {str(k): round(v, 1) for k, v in sw["sweep"].items()},
+                "sweep_sample": f"{sw['sub']} rays per setting in a process pinned to {len(pool)} cores; `cores` = the fastest setting, used for `value`"})
+    return rec, (d["rows"], d["ref"])
 
 
 def fp32_grade_check(E, dev, n=4096):
@@ -866,10 +895,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only (no precisions / hbm / secondary records)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--cpu-dry", action="store_true", help="no GPU work: exercise launch + sharding + gather only (CPU tests)")
-    ap.add_argument("--cpu-worker", nargs=2, metavar=("RAYS", "OUT"), help="internal: the pinned child process of the CPU baseline")
+    ap.add_argument("--cpu-worker", nargs=3, metavar=("MODE", "RAYS", "OUT"), help="internal: the pinned child process of the CPU baseline")
     args = ap.parse_args()
     if args.cpu_worker:
-        cpu_baseline_worker(int(args.cpu_worker[0]), args.cpu_worker[1])
+        cpu_baseline_worker(args.cpu_worker[0], int(args.cpu_worker[1]), args.cpu_worker[2])
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of the last tools/gpu_round.sh pass from gpurun_out/ (scratch) into profiles/ (tracked): usage tools/collect_profiles.sh r03
-T=${1:-r03}; cd "$(dirname "$0")/.."; G=gpurun_out; P=profiles
+T=${1:-r04}; cd "$(dirname "$0")/.."; G=gpurun_out; P=profiles
 for prec in f16x3 f32 f16; do
   [ -f $G/prof_$prec/${T}_kernel_stats.csv ] && cp $G/prof_$prec/${T}_kernel_stats.csv $P/${T}_kernel_stats_$prec.csv
   [ -f $G/pmc_$prec/summary.json ] && cp $G/pmc_$prec/summary.json $P/${T}_pmc_summary_$prec.json

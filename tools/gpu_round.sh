@@ -3,7 +3,7 @@
 # usage: tools/gpu_round.sh TAG [notest] [nopmc]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $R
 mkdir -p gpurun_out
 if [[ " $* " != *" notest "* ]]; then
