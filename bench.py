@@ -154,7 +154,8 @@ def cpu_baseline_worker(mode, sample_rays, out_path):
     torch.set_num_threads(threads)
     with torch.no_grad():
         t0 = time.perf_counter()
-        orc.render_rays(rows, c, f, ea, et, NC, NI)      # the untimed full pass
+        orc.render_rays(rows, c, f, ea, et, NC, NI)      # two untimed full passes (after one, the first two of five timed runs were
+        orc.render_rays(rows, c, f, ea, et, NC, NI)      # still 15-18 % slower than the last three)
         warm = time.perf_counter() - t0
         runs = []
         for _ in range(5):
@@ -170,8 +171,8 @@ def cpu_baseline_worker(mode, sample_rays, out_path):
         dt_frame = time.perf_counter() - t0
     mid3 = sorted(runs)[1:4]
     rec = {"value": sample_rays / dt, "min_time_value": sample_rays / min(runs), "unit": "rays/s", "cores": threads, "kind": "port",
-           "sample": f"median of 5 runs over {sample_rays} random rays of frame 0 at 64+128 samples, one chunk each, after one untimed full "
-                     f"pass ({warm:.1f} s): {', '.join('%.2f' % r for r in runs)} s; the middle three within "
+           "sample": f"median of 5 runs over {sample_rays} random rays of frame 0 at 64+128 samples, one chunk each, after two untimed full "
+                     f"passes ({warm:.1f} s): {', '.join('%.2f' % r for r in runs)} s; the middle three within "
                      f"{(mid3[2] - mid3[0]) / dt * 100:.1f} % of the median (oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32, autograd "
                      "anomaly mode off, no_grad)",
            "pinning": f"own process, affinity = {threads} physical cores of NUMA node 0 (set before exec; not the node's first eight), "

@@ -380,7 +380,11 @@ void destroy_state(dfn_nerfh_s* h) {
   h->fused = nullptr;
 }
 
-bool available(const dfn_nerfh_s* h) { return h && h->fast && h->desc.width == kWidth; }
+bool available(const dfn_nerfh_s* h) {
+  if (!h || !h->fast || h->desc.width != kWidth) return false;
+  const Geo g = geo_of(h->desc);
+  return size_t(g.kd_f + g.nt) * 64 * sizeof(float) <= 64 * 1024;   // the per-ray bias kernel stages both weight tails in LDS
+}
 
 namespace {
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }

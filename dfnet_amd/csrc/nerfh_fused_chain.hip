@@ -39,7 +39,10 @@ constexpr uint32_t kBwdStride = unit_bytes<P>(80, UMB);   // largest backward un
 DFN_DEV void init_stager(Stager& st, const ChainArgs& a) {
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
-  st.dma_waves = WAVES;
+#ifndef DFN_CHAIN_DMA_WAVES
+#define DFN_CHAIN_DMA_WAVES WAVES
+#endif
+  st.dma_waves = DFN_CHAIN_DMA_WAVES;
   st.rmax = 0;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;

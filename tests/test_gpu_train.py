@@ -226,6 +226,43 @@ def test_render_training_autograd_surface_and_optimizer_step():
     assert float((rgb2.detach() - before).abs().max()) > 1e-5
 
 
+@pytest.mark.parametrize("perturb,per_ray_hist,lindisp", [(0., False, False), (1., True, True), (0., True, False)])
+def test_fused_step_equals_exact_step(perturb, per_ray_hist, lindisp):
+    """The two implementations of the training step behind dfn_nerfh_train_forward / _backward (fused register-resident chains,
+    layer-by-layer exact fp32) on the same rays: outputs to 1e-6, every gradient tensor to 5e-4 relative L2 — without random draws
+    (perturb 0: linspace depths and u), with per-ray histograms, with depths linear in disparity, on a ray count that leaves the last
+    tile of both networks ragged."""
+    E, mods, _ = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    R, Nc, Ni = 77, 24, 40
+    rng = np.random.default_rng(21)
+    ro, rd = orc.get_rays(480, 640, 585.0, T(syn.orbit_pose(5, 8))[:3, :4])
+    sel = rng.choice(480 * 640, R, replace=False)
+    o, d = ro.reshape(-1, 3)[sel].contiguous().to(DEV), rd.reshape(-1, 3)[sel].contiguous().to(DEV)
+    hist = (T(rng.integers(0, 40, (R, 10)).astype(np.float32)) if per_ray_hist else T(syn.HIST_IDX)[None]).to(DEV)
+    target = T(rng.uniform(0, 1, (R, 3)).astype(np.float32)).to(DEV)
+    draws = nerf_train.NerfHTrainer.draw(R, Nc, Ni, perturb, DEV, torch.Generator(device=DEV).manual_seed(4))
+    E.set_render_options(lindisp=lindisp)
+    try:
+        res = {}
+        for tag, exact in (("exact", True), ("fused", False)):
+            tr.exact = exact
+            for p in tr.params:
+                p.grad = None
+            ld, _, out = tr.train_step(o, d, hist, target, Nc, Ni, 0.05 if lindisp else 0., 2.5, perturb=perturb, raw_noise_std=0.5, draws=draws)
+            res[tag] = ({k: float(v) for k, v in ld.items()}, {k: v.clone() for k, v in out.items()}, [p.grad.clone() for p in tr.params])
+    finally:
+        E.set_render_options(lindisp=False)
+    assert E.range_flags() == 0
+    for k in res["exact"][1]:
+        assert relmax(res["fused"][1][k], res["exact"][1][k].cpu()) < (1e-4 if k in ("raw", "transient_sigmas") else 3e-6), k
+    for k in res["exact"][0]:
+        assert abs(res["fused"][0][k] - res["exact"][0][k]) <= 3e-6 * abs(res["exact"][0][k]) + 1e-8, k
+    worst = max(rel_l2(a, b.cpu()) for a, b in zip(res["fused"][2], res["exact"][2]))
+    print(f"fused vs exact step (perturb {perturb}, per-ray hist {per_ray_hist}, lindisp {lindisp}): worst gradient rel L2 {worst:.2e}")
+    assert worst < 5e-4
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_training_render_ray_gradients(gold, tag):
     """render(test_time=False) with rays that require grad: the reference's training render is differentiable w.r.t. its rays
