@@ -39,10 +39,7 @@ constexpr uint32_t kBwdStride = unit_bytes<P>(80, UMB);   // largest backward un
 DFN_DEV void init_stager(Stager& st, const ChainArgs& a) {
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
-#ifndef DFN_CHAIN_DMA_WAVES
-#define DFN_CHAIN_DMA_WAVES WAVES
-#endif
-  st.dma_waves = DFN_CHAIN_DMA_WAVES;
+  st.dma_waves = 4;   // the four older waves issue the weight DMA (they idle at the unit barriers anyway): 2.49 -> 2.47 ms per step, three alternations
   st.rmax = 0;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;

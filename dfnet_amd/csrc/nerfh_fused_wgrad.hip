@@ -282,9 +282,10 @@ __global__ __launch_bounds__(128) void ray_bias_train_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_wd = sm;               // [kd][64]
   float* s_wt = sm + kd * 64;     // [nt][64]
-  for (int i = threadIdx.x; i < kd * 64; i += blockDim.x) s_wd[i] = w_dir[size_t(i & 63) * ldw_dir + kWidth + (i >> 6)];
+  // consecutive threads read consecutive columns of a weight row (coalesced); the transposition happens in the LDS store
+  for (int i = threadIdx.x; i < kd * 64; i += blockDim.x) { const int f = i / kd, jj = i - f * kd; s_wd[jj * 64 + f] = w_dir[size_t(f) * ldw_dir + kWidth + jj]; }
   if (w_te)
-    for (int i = threadIdx.x; i < nt * 64; i += blockDim.x) s_wt[i] = w_te[size_t(i & 63) * ldw_te + kWidth + (i >> 6)];
+    for (int i = threadIdx.x; i < nt * 64; i += blockDim.x) { const int f = i / nt, jj = i - f * nt; s_wt[jj * 64 + f] = w_te[size_t(f) * ldw_te + kWidth + jj]; }
   __syncthreads();
   const int tbl = threadIdx.x >> 6, f = threadIdx.x & 63;
   const int mb = f >> 5, row = f & 31, hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
@@ -309,8 +310,7 @@ hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw
   if (!R) return hipSuccess;
   const size_t lds = size_t(kd + (w_te ? nt : 0)) * 64 * sizeof(float);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  // every block stages the two weight tails (25 KB) once: few blocks of many rays, not one block per ray
-  const int grid = int(R < 1024 ? (R + 7) / 8 : 128);
+  const int grid = int(R < 512 ? R : 512);
   hipLaunchKernelGGL(ray_bias_train_kernel, dim3(grid), dim3(128), lds, s, w_dir, b_dir, ldw_dir, kd, dir_in, ld_dir, w_te, b_te, ldw_te,
                      nt, t_in, ld_t, R, table);
   return hipGetLastError();

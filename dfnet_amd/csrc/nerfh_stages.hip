@@ -362,6 +362,10 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, size_t n, 
 // sigma [R,Nc] -> z_fine [R,Nc+Ni]: coarse weights over the linspace depths, z_mid bins,
 // sample_pdf(det) on the interior weights, then an exact sort of cat([z, z_samples]) (fix-up passes +
 // rank merge of two sorted lists; ties: coarse depth first, so the result is always a permutation).
+// __launch_bounds__'s second argument is waves per SIMD: 8 caps the kernel at 64 registers and costs 140 bytes of scratch per lane
+// (-Rpass-analysis), and is still the fastest setting — a ray is ~50 dependent LDS round trips, so resident waves count for more than
+// the spills: 61 440 rays in 71.9 us at 8, 78.0 at 6 (76 B of scratch), 78.5 at 4 (none); same box, three alternations each
+// (tools/build_variant.sh + tools/gpu_ab_libs.sh "python tools/gpu_stage_timing.py").
 #ifndef DFN_SF_WAVES
 #define DFN_SF_WAVES 8
 #endif
