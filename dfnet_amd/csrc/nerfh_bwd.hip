@@ -22,6 +22,11 @@
 
 namespace dfn {
 
+// Head activations of the forward recompute: split-f16 = the fp32-grade hardware forms of the inference kernel (exp_hw / rcp_nr,
+// 1.5e-7: nerfh_device.h), exact fp32 = libm.
+template <class PF, bool FAST> DFN_DEV float bwd_sigmoid(float v) { return PF::kSplit ? sigmoid_hw(v) : act_sigmoid<FAST>(v); }
+template <class PF, bool FAST> DFN_DEV float bwd_softplus(float v) { return PF::kSplit ? softplus_hw(v) : act_softplus<FAST>(v); }
+
 template <class PF, class P> constexpr uint32_t bwd_stride() {
   return bwd_max_unit_bytes<PF>() > bwd_max_unit_bytes<P>() ? bwd_max_unit_bytes<PF>() : bwd_max_unit_bytes<P>();
 }
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
   Stager st;
   st.blob = a.blob; st.tab = a.tab; st.n_units = a.n_units; st.u = 0;
   st.waves = WAVES;
-  st.dma_waves = WAVES;
+  st.dma_waves = WAVES == 8 ? 4 : WAVES;   // 8-wave workgroups: the four older waves idle at the unit barriers anyway (as launch_one, nerfh_mlp.hip)
   st.rmax = 0;
   st.in_scale = a.in_scale;
   st.out_scale = 1.f / a.in_scale;
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       DFN_FLAYER(FHC, 4, true, false, hid, fin, norb);   // xyz_encoding_final + static_sigma (5th M-block)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        dsig_true[nb] = h == 0 ? g[nb][3] * act_sigmoid<FAST>(head[nb][0]) : 0.f;  // softplus' = sigmoid
-        if constexpr (MODE == 1) o9[nb][3] = act_softplus<FAST>(head[nb][0]);
+        dsig_true[nb] = h == 0 ? g[nb][3] * bwd_sigmoid<PF, FAST>(head[nb][0]) : 0.f;  // softplus' = sigmoid
+        if constexpr (MODE == 1) o9[nb][3] = bwd_softplus<PF, FAST>(head[nb][0]);
       }
       {
         FF de[NB][FQC];
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
           clear<P>(drgb[nb]);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float y = act_sigmoid<FAST>(head[nb][c]);
+            const float y = bwd_sigmoid<PF, FAST>(head[nb][c]);
             if constexpr (MODE == 1) o9[nb][c] = y;
             set_slot<P>(drgb[nb], c, h == 0 ? g[nb][c] * y * (1.f - y) * sp[nb] : 0.f);
           }
@@ -238,13 +243,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
           clear<P>(dth[nb]);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float y = act_sigmoid<FAST>(head[nb][c]);
+            const float y = bwd_sigmoid<PF, FAST>(head[nb][c]);
             if constexpr (MODE == 1) o9[nb][4 + c] = y;
             set_slot<P>(dth[nb], c, h == 0 ? g[nb][4 + c] * y * (1.f - y) * sp[nb] : 0.f);
           }
-          if constexpr (MODE == 1) { o9[nb][7] = act_softplus<FAST>(head[nb][3]); o9[nb][8] = act_softplus<FAST>(head[nb][4]); }
-          set_slot<P>(dth[nb], 3, h == 0 ? g[nb][7] * act_sigmoid<FAST>(head[nb][3]) * sp[nb] : 0.f);
-          set_slot<P>(dth[nb], 4, h == 0 ? g[nb][8] * act_sigmoid<FAST>(head[nb][4]) * sp[nb] : 0.f);
+          if constexpr (MODE == 1) { o9[nb][7] = bwd_softplus<PF, FAST>(head[nb][3]); o9[nb][8] = bwd_softplus<PF, FAST>(head[nb][4]); }
+          set_slot<P>(dth[nb], 3, h == 0 ? g[nb][7] * bwd_sigmoid<PF, FAST>(head[nb][3]) * sp[nb] : 0.f);
+          set_slot<P>(dth[nb], 4, h == 0 ? g[nb][8] * bwd_sigmoid<PF, FAST>(head[nb][4]) * sp[nb] : 0.f);
         }
       }
     }
