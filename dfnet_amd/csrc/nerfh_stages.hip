@@ -181,6 +181,10 @@ __global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const f
   const int o = shared ? threadIdx.x & 63 : threadIdx.x & 127;
   float* my_in = s_in + sub * stride_in;
   __syncthreads();   // weights (and the shared-histogram base) staged
+  // the next ray's view direction is fetched while this ray is processed: a ray is a handful of dependent LDS round trips, and the
+  // HBM latency of its 12 input bytes at the head of every iteration was most of the kernel's time
+  float v_next = 0.f;
+  if (o < 6 * kLdir && size_t(blockIdx.x) * rpb + sub < n_rays) v_next = viewdirs[(size_t(blockIdx.x) * rpb + sub) * 3 + o % 3];
   for (size_t base = size_t(blockIdx.x) * rpb; base < n_rays; base += size_t(gridDim.x) * rpb) {
     // shared histogram: a ray is ONE wave's work (its inputs live in the wave's own LDS slice), so the waves of a block run free of
     // each other; per-ray histograms: two waves share a ray's inputs and meet at the block barrier
@@ -190,7 +194,9 @@ __global__ __launch_bounds__(256) void ray_bias_kernel(RayBiasWeights w, const f
     if (ok) {
       if (o < 6 * kLdir) {  // pe_dir (27): [v, sin(2^k v), cos(2^k v)] — one lane per (coordinate, octave, sin | cos)
         const int coord = o % 3, k = (o / 3) % kLdir, is_cos = o / (3 * kLdir);
-        const float v = viewdirs[ray * 3 + coord], arg = v * float(1 << k);
+        const float v = v_next, arg = v * float(1 << k);
+        const size_t rn = ray + size_t(gridDim.x) * rpb;
+        if (rn < n_rays) v_next = viewdirs[rn * 3 + coord];
         if (o < 3) my_in[o] = v;
         my_in[3 + 6 * k + 3 * is_cos + coord] = is_cos ? cosf(arg) : sinf(arg);
       }
