@@ -35,7 +35,8 @@ __device__ __forceinline__ f32x16 mfma<PrecX3>(half8x2 a, half8x2 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
 }
 // x (true scale) -> (hi, lo) halves of x * kX3ActScale.  No saturation here (it costs 6 % of the split-f16 render):
-// the MLP's activations are O(1..100), hi overflows only beyond |x| = 4 094.
+// the MLP's activations are O(1..100), hi overflows only beyond |x| = 4 094 (the pipelined render kernels narrow their accumulators
+// before scaling them: 4 094 x the network's largest |weight| there — nerfh_mlp_core.h: X3Piece; guarded either way).
 __device__ __forceinline__ void x3_split(float x, _Float16& hi, _Float16& lo) {
   const float xs = x * kX3ActScale;
   hi = (_Float16)xs;

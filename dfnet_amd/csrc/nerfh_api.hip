@@ -435,7 +435,8 @@ extern "C" int dfn_nerfh_range_status(dfn_nerfh_t h, int* flags, void* stream) {
                      "since then are not the network's output: render them with DFN_PREC_F32",
                      (v & DFN_RANGE_F16_OVERFLOW) ? "f16" : "split-f16",
                      (v & DFN_RANGE_F16_OVERFLOW) ? "an f16 layer output overflowed to inf: |activation| > 65504"
-                                                  : "a split-f16 hi half saturated: |activation| >= 4094");
+                                                  : "a split-f16 hi half saturated: |activation| >= 4094 (hidden layers of the render kernels: "
+                                                    ">= 4094 x the network's largest |weight|, the accumulators are narrowed before they are scaled)");
   return DFN_OK;
 }
 
@@ -485,7 +486,7 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
           for (const auto& kv : h->params)
             if (kv.first.compare(0, pk.pre.size(), pk.pre) == 0 && kv.first.find(".weight") != std::string::npos)
               for (float v : kv.second) wmax = std::fmax(wmax, std::fabs(v));
-          int sexp = wmax > 0.f ? 10 - int(std::ceil(std::log2(wmax))) : 0;
+          int sexp = wmax > 0.f ? -int(std::ceil(std::log2(wmax))) : 0;
           sexp = sexp < -8 ? -8 : (sexp > 24 ? 24 : sexp);
           pk.wscale = std::ldexp(1.f, sexp);
           n.in_scale = pk.wscale * kX3ActScale;
@@ -508,12 +509,15 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
         if (prec == DFN_PREC_F16) pk.pack<PrecF16>(f, unit_mb<PrecF16>(var), unit_mb<PrecF16>(var) >= 8, blob, tab);
         else if (prec == DFN_PREC_F32) pk.pack<PrecF32>(f, unit_mb<PrecF32>(var), false, blob, tab);
         else {
-          // one power-of-two weight scale per network: the largest |w| lands near 2^10, lo parts stay normal f16
+          // one power-of-two weight scale per network: the largest |w| lands in (0.5, 1].  The lo halves of most weights are then f16
+          // subnormals — still exact to 2^-24 of the largest weight (the matrix cores do not flush f16 denormals), which is fp32's
+          // resolution — and the accumulators (in_scale x the value = 16 x value / max|w|) fit f16 up to |value| = 4094 max|w|: that is
+          // what lets the render kernels narrow BEFORE they scale (X3Piece: one packed multiply per result pair instead of two)
           float wmax = 0.f;
           for (const auto& kv : h->params)
             if (kv.first.compare(0, pk.pre.size(), pk.pre) == 0 && kv.first.find(".weight") != std::string::npos)
               for (float v : kv.second) wmax = std::fmax(wmax, std::fabs(v));
-          int sexp = wmax > 0.f ? 10 - int(std::ceil(std::log2(wmax))) : 0;
+          int sexp = wmax > 0.f ? -int(std::ceil(std::log2(wmax))) : 0;
           sexp = sexp < -8 ? -8 : (sexp > 24 ? 24 : sexp);
           pk.wscale = std::ldexp(1.f, sexp);
           n.in_scale = pk.wscale * kX3ActScale;
@@ -533,7 +537,9 @@ extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
     if (prec == DFN_PREC_F16) pk.pack_bwd<PrecF16, PrecF16>(blob, tab);
     else if (prec == DFN_PREC_F32) pk.pack_bwd<PrecF32, PrecF32>(blob, tab);
     else {
-      n.in_scale = h->net[1][2][0].in_scale;   // same per-network weight scale as the split-f16 forward net
+      // the gradient kernels scale their accumulators in fp32 BEFORE narrowing them (store_hidden), so their weights can sit where
+      // every lo half is a normal f16 (largest |w| near 2^10: 22 bits per weight) instead of at the render kernels' unit scale
+      n.in_scale = h->net[1][2][0].in_scale * 1024.f;
       pk.wscale = n.in_scale / kX3ActScale;
       pk.pack_bwd<PrecX3, PrecX3>(blob, tab);
     }

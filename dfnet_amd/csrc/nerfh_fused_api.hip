@@ -507,6 +507,10 @@ Ws carve(char* base, const dfn_nerfh_desc& d, size_t R, int Nc, int Ni) {
   return w;
 }
 
+// Operand scale of the training chains: 2^10 above the render kernels' (whose pipelined conversion narrows before it scales and
+// therefore keeps the largest |w| at ~1): the chains scale in fp32 first, so their weights sit where every lo half is a normal f16.
+float train_scale(const dfn_nerfh_s* h, bool fine) { return h->net[fine][2][0].in_scale * 1024.f; }
+
 int pack_blob(const DevBlob& d, const float* const* params, float in_scale, int* status, hipStream_t s) {
   PackArgs a{};
   a.welem = d.welem; a.n_welem = d.n_w;
@@ -532,7 +536,7 @@ ChainArgs chain_args(const dfn_nerfh_s* h, const State& st, bool fine, int pass,
   a.gpre = n.gpre;
   a.n_rays = (long long)R;
   a.n_samples = Ns;
-  a.in_scale = h->net[fine][2][0].in_scale;
+  a.in_scale = train_scale(h, fine);
   a.status = h->range_flag;
   return a;
 }
@@ -565,7 +569,7 @@ int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_
   // the step's weights -> staging units of the four chain passes (hi | lo split at the handle's operand scale)
   for (int f = 0; f < 2; ++f)
     for (int pass = 0; pass < 2; ++pass)
-      if (int rc = pack_blob(st.blob[f][pass], params, h->net[f][2][0].in_scale, h->range_flag, s)) return rc;
+      if (int rc = pack_blob(st.blob[f][pass], params, train_scale(h, f), h->range_flag, s)) return rc;
   CHECK_HIP(launch_ray_bias_train(pc[2 * DIR], pc[2 * DIR + 1], W + g.kd_c, g.kd_c, w.dir_c, g.ld_dc, nullptr, nullptr, 0, 0, nullptr, 0, R,
                                   w.net[0].ray_bias, s),
             "train forward: coarse per-ray bias");

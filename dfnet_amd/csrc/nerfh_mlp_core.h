@@ -337,31 +337,33 @@ DFN_DEV void store_hidden_piece(const f32x16& acc, typename FragOf<P>::type (&ou
 // The split-f16 conversion piece in three parts, so that a K-chunk can place them BETWEEN its three dependent MFMAs (A after the
 // first, B after the second, C after the third) instead of as one block behind them: the parts of store_hidden_piece<PrecX3>.
 struct X3Piece {
-  uint32_t hb, lb;
+  uint32_t hb, hs, lb;
   float t0, t1;
+  // A: ReLU on the UNSCALED accumulators (they carry in_scale x the value: the packer keeps in_scale x |activation| inside f16).
   template <bool RELU>
-  DFN_DEV void A(const f32x16& acc, int i, float oscale) {
+  DFN_DEV void A(const f32x16& acc, int i) {
     const int c = i >> 2, j = (i & 3) * 2;
-    if (RELU)
-      asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4\n\tv_max_f32 %0, %0, 0\n\tv_max_f32 %1, %1, 0"
-                   : "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]), "v"(oscale));
-    else
-      asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]), "v"(oscale));
+    if (RELU) asm volatile("v_max_f32 %0, %2, 0\n\tv_max_f32 %1, %3, 0" : "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]));
+    else asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(t0), "=&v"(t1) : "v"(acc[8 * c + j]), "v"(acc[8 * c + j + 1]));
   }
-  DFN_DEV void B() {
-    asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2\n\t"
-                 "v_fma_mix_f32 %1, %0, -1.0, %1 op_sel_hi:[1,0,0]\n\t"
-                 "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                 : "=&v"(hb), "+v"(t0), "+v"(t1));
+  // B: truncated hi pair of the unscaled values, scaled as a PACKED f16 product (a power of two: exact), then the two remainders
+  // t x s - hi' in one mixed-precision FMA each — the accumulator -> operand scale costs one instruction per PAIR instead of two.
+  DFN_DEV void B(float s, uint32_t s2) {
+    asm volatile("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
+                 "v_pk_mul_f16 %1, %0, %5\n\t"
+                 "v_fma_mix_f32 %2, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
+                 "v_fma_mix_f32 %3, %3, %4, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                 : "=&v"(hb), "=&v"(hs), "+v"(t0), "+v"(t1) : "v"(s), "v"(s2));
   }
   template <bool RELU, int OC>
   DFN_DEV void C(half8x2 (&out)[OC], int mb, int i, uint32_t& rmax) {
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const int c = i >> 2, j = (i & 3) * 2;
     asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(lb) : "v"(t0), "v"(t1));
+    // range guard on the UNSCALED hi pair: that conversion is the one that saturates
     if (RELU) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(rmax) : "v"(hb));
     else range_track(rmax, hb, false);
-    const half2v hv = __builtin_bit_cast(half2v, hb), lv = __builtin_bit_cast(half2v, lb);
+    const half2v hv = __builtin_bit_cast(half2v, hs), lv = __builtin_bit_cast(half2v, lb);
     out[2 * mb + c].hi[j] = hv[0]; out[2 * mb + c].hi[j + 1] = hv[1];
     out[2 * mb + c].lo[j] = lv[0]; out[2 * mb + c].lo[j + 1] = lv[1];
   }
@@ -399,6 +401,8 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
   static_assert(NEWUNIT || UMB >= TOT, "a layer that continues a unit must fit in it");
   const int h = st.lane >> 5;
   const float pscale = P::kSplit ? st.out_scale * st.lane_mul * kX3ActScale : 1.f;  // split-f16 pieces: accumulator -> operand scale
+  uint32_t pscale2 = 0;   // ... the same factor as a packed f16 pair (X3Piece::B)
+  if constexpr (P::kSplit) asm("v_cvt_pkrtz_f16_f32 %0, %1, %1" : "=v"(pscale2) : "v"(pscale));
   constexpr bool RB_ALL = RAYBIAS && NB <= 2;  // fetch all per-ray seeds at entry (latency behind the barrier)
   f32x16 rb[RB_ALL ? TOT : 1][NB];
   if (RB_ALL) {
@@ -469,12 +473,12 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #define DFN_X3_PARTS_A \
             _Pragma("unroll") for (int q = 0; q < NPMAX; ++q) \
               if (q < np && base + q < 8) { \
-                if (from_carry) pc[q].template A<CIN_RELU>(carry[0], base + q, pscale); \
-                else pc[q].template A<RELU>(pend[0], base + q, pscale); \
+                if (from_carry) pc[q].template A<CIN_RELU>(carry[0], base + q); \
+                else pc[q].template A<RELU>(pend[0], base + q); \
               }
 #define DFN_X3_PARTS_B \
             _Pragma("unroll") for (int q = 0; q < NPMAX; ++q) \
-              if (q < np && base + q < 8) pc[q].B();
+              if (q < np && base + q < 8) pc[q].B(pscale, pscale2);
             if (!late) { DFN_X3_PARTS_A }
             __builtin_amdgcn_sched_barrier(0);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, Bin[0][kc].lo, c0, 0, 0, 0);

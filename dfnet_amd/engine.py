@@ -89,7 +89,7 @@ class NerfHEngine:
         if flags:
             narrow = "f16" if flags & 1 else "split-f16"
             why = ("an f16 layer output overflowed to inf: |activation| > 65504" if flags & 1
-                   else "a split-f16 hi half saturated: |activation| >= 4094")
+                   else "a split-f16 hi half saturated: |activation| >= 4094 (hidden layers of the render kernels: 4094 x the largest |weight|)")
             raise _lib.DfnError(f"NeRF-H range guard ({where}): activations left the range of the {narrow} arithmetic ({why}); the frames "
                                 "rendered since the last check are not the network's output: render them with precision='f32'")
 

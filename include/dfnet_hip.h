@@ -83,7 +83,7 @@ int dfn_nerfh_commit(dfn_nerfh_t h);
 enum { DFN_RENDER_LINDISP = 1, DFN_RENDER_COARSE_F16 = 2 };
 int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags);
 /* Range guard of the narrow arithmetic modes (no counterpart in the reference, which computes in fp32).  DFN_PREC_F16 holds a
- * layer's outputs as f16 (|x| <= 65504), DFN_PREC_F16X3 as hi + lo f16 halves of 16 x (|x| < 4094); a checkpoint whose hidden
+ * layer's outputs as f16 (|x| <= 65504), DFN_PREC_F16X3 as hi + lo f16 halves of 16 x (|x| < 4094; hidden layers of the render kernels: < 4094 max|w|, a few hundred to a few thousand for a NeRF-H checkpoint); a checkpoint whose hidden
  * activations leave that range would render clamped or non-finite frames.  Every MLP kernel launched through this handle keeps the
  * largest activation pattern it converts (one v_pk_max_u16 per converted register) and ORs a bit into a device flag when it
  * overflowed / saturated.  This call waits for `stream`, reads and clears the flag:
