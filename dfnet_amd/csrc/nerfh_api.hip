@@ -981,10 +981,12 @@ extern "C" int dfn_mlp_fine_saving(dfn_nerfh_t h, int prec, const float* rays_o,
     return set_error(DFN_ERR_ARG, "dfn_mlp_fine_saving: bad argument (hist_rows must be 1 or n_rays)");
   float* table = static_cast<float*>(bias_ws);
   CHECK_HIP(launch_ray_bias(h->rb, viewdirs, hist, hist_rows, n_rays, table, HS(stream)), "dfn_mlp_fine_saving(ray_bias)");
-  const PackedNet& n = h->bwd[prec];
-  BwdArgs a{n.blob, n.tab, n.n_fwd_units, rays_o, rays_d, viewdirs, z_fine, table, nullptr, nullptr, (long long)n_rays, Nf, n.in_scale,
-            raw, nullptr, static_cast<uint32_t*>(masks)};
-  CHECK_HIP(launch_mlp_fine_backward(prec, a, device_cu_count(), HS(stream), 1), "dfn_mlp_fine_saving");
+  // the test-time fine kernel itself (pipelined epilogue, unit-scale weights), recording the ReLU signs as it goes
+  const PackedNet& n = h->net[1][prec][0];
+  MlpArgs a{n.blob, n.tab, n.n_units, rays_o, rays_d, z_fine, table, raw, nullptr, (long long)n_rays, Nf, 0.f, 0.f, nullptr, n.in_scale};
+  a.status = range_flag_of(h);
+  a.masks = static_cast<uint32_t*>(masks);
+  CHECK_HIP(launch_mlp(true, prec, 0, a, device_cu_count(), HS(stream), h->desc.width), "dfn_mlp_fine_saving");
   return DFN_OK;
 }
 

@@ -25,6 +25,8 @@ struct MlpArgs {
   int dma_waves;           // waves of a workgroup that issue the weight DMA (0 = the kernel geometry's default, launch_one)
   int* status;             // range guard (device int, may be null): bit 0 = an f16 activation overflowed to inf, bit 1 = a
                            // split-f16 hi half saturated (DFN_RANGE_*: dfn_nerfh_range_status)
+  uint32_t* masks;         // fine, split-f16, raw output: also record the ReLU signs of every hidden unit for the gradient kernel's
+                           // backward-only pass ([tiles][waves][kBwdMaskWords][64 lanes], as BwdArgs::masks); null otherwise
 };
 
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width = 128);

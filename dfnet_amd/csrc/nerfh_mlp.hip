@@ -22,6 +22,7 @@
 #include "mfma_frag.h"
 
 #include "nerfh_mlp_core.h"
+#include "nerfh_mask.h"
 
 namespace dfn {
 
@@ -107,8 +108,12 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
   range_report<P>(st.rmax, a.status);
 }
 
-template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE, int W = kWidth>
+// MASKS: the saving forward of the gradient path (dfn_mlp_fine_saving): the same kernel, recording one ReLU sign bit per hidden unit
+// for nerfh_fine_backward_kernel's backward-only pass (its own forward-only mode ran without the pipelined conversion: 3.64 ms for the
+// DFNet_dm step's 3.7 M points against this kernel's 3.1).
+template <class P, bool FAST, int WAVES, int UMB, int NB, bool PIPE, int W = kWidth, bool MASKS = false>
 __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) void nerfh_fine_kernel(MlpArgs a) {
+  static_assert(!MASKS || (P::kSplit && NB == 1 && WAVES == 8 && W == kWidth), "the sign masks follow the gradient kernel's tile geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PPT = WAVES * NB * 32;
   constexpr int HC = chunks_of<P>(W / 2), QC = chunks_of<P>(W / 4);
@@ -200,11 +205,31 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
 #endif
     constexpr bool CY = PIPE && P::kSlotsPerChunk == 8, MERGE = UMB >= 8;
     f32x16 carry[NB];
-    trunk<P, UMB, PIPE, FAST, NB, W>(st, smem, x, hid, carry);
+    [[maybe_unused]] uint32_t* mwords = nullptr;
+    if constexpr (MASKS) mwords = a.masks + (size_t(tile) * WAVES + st.wave) * (kBwdMaskWords * 64) + st.lane;
+    // sign words: trunk layer l -> 2l, 2l + 1; dir_encoding 16; transient_encoding.{0,2,4,6} 17..20 (nerfh_bwd.hip reads them back)
+    auto sign128 = [&](int l, F (&h)[HC]) {
+      if constexpr (MASKS) {
+        uint32_t m[2];
+        relu_mask<P, HC>(h, m);
+        mwords[(2 * l) * 64] = m[0];
+        mwords[(2 * l + 1) * 64] = m[1];
+      }
+    };
+    auto sign64 = [&](int word, F (&h)[QC]) {
+      if constexpr (MASKS) {
+        uint32_t m[1];
+        relu_mask<P, QC>(h, m);
+        mwords[word * 64] = m[0];
+      }
+    };
+    if constexpr (MASKS) trunk<P, UMB, PIPE, FAST, NB, W>(st, smem, x, hid, carry, sign128);
+    else trunk<P, UMB, PIPE, FAST, NB, W>(st, smem, x, hid, carry);
     // xyz_encoding_final (no activation) + static_sigma
     F fin[NB][HC];
     f32x16 head[NB];
     layer<P, UMB, PIPE, NB, HC, MBW, false, true, false, true, (CY ? 6 : -1), true, false>(st, smem, hid, fin, head, norb, carry);
+    sign128(7, hid[0]);   // layer 8's output, completed inside the layer above
     float o[NB][9];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o[nb][3] = head_softplus<P, FAST>(head[nb][0]);
@@ -215,6 +240,7 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
       ray_table(rb_dir, 0);
       layer<P, UMB, PIPE, NB, HC, MBQ, true, false, true, true, -1, true, CY>(st, smem, fin, de, head, rb_dir, carry);
       layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, de, dummy, head, norb, carry);
+      sign64(16, de[0]);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -247,9 +273,13 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<P, WAVES, NB, W>())) vo
         }
       }
       layer<P, UMB, PIPE, NB, QC, MBQ, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
+      sign64(17, t0[0]);
       layer<P, UMB, PIPE, NB, QC, MBQ, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t1, t0, head, norb, carry);
+      sign64(18, t1[0]);
       layer<P, UMB, PIPE, NB, QC, MBQ, true, false, false, !MERGE, (CY ? 2 : -1), true, CY>(st, smem, t0, t1, head, norb, carry);
+      sign64(19, t0[0]);
       layer<P, UMB, PIPE, NB, QC, 0, false, true, false, !MERGE, (CY ? 2 : -1), true, false>(st, smem, t1, dummy, head, norb, carry);
+      sign64(20, t1[0]);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -350,12 +380,16 @@ static hipError_t launch_one(bool fine, const MlpArgs& a, int n_cu, hipStream_t 
   const int grid = int(n_tiles < slots ? n_tiles : slots);
   const uint32_t lds = lds_bytes<P, UMB, WAVES, NB, W>();
   auto kern = fine ? nerfh_fine_kernel<P, FAST, WAVES, UMB, NB, PIPE, W> : nerfh_coarse_kernel<P, FAST, WAVES, UMB, NB, PIPE, W>;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[fine]) {
+  int slot = fine ? 1 : 0;
+  if constexpr (P::kSplit && NB == 1 && WAVES == 8 && W == kWidth && PIPE) {
+    if (fine && a.masks) { kern = nerfh_fine_kernel<P, FAST, WAVES, UMB, NB, PIPE, W, true>; slot = 2; }
+  } else if (a.masks) return hipErrorInvalidValue;
+  static bool attr_done[3] = {false, false, false};
+  if (!attr_done[slot]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
-    attr_done[fine] = true;
+    attr_done[slot] = true;
   }
   MlpArgs b = a;
   if (b.dma_waves == 0) {  // DFN_DMA_WAVES=n: A/B aid

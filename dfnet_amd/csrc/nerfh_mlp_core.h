@@ -607,9 +607,15 @@ DFN_DEV void posenc_xyz(const float (&x)[NB][3], int h, typename FragOf<P>::type
 
 // ------------------------------------------------------------------------------------------
 // The 8-layer trunk (xyz_encoding_1..8, skip concat [pe, h] before layer 5).
-template <class P, int UMB, bool PIPE, bool FAST, int NB, int W = kWidth>
+// `hook(l, h)` (optional) is called once per trunk layer l = 0..6 with that layer's COMPLETE output operand (point block 0) — one
+// layer late, because a pipelined layer hands its last M-block to the next layer unconverted; layer 7's output (`out`) completes in
+// the caller's next layer.  The saving forward of the gradient path records the ReLU signs there (nerfh_mlp.hip).
+struct NoTrunkHook {
+  template <class A> DFN_DEV void operator()(int, A&) const {}
+};
+template <class P, int UMB, bool PIPE, bool FAST, int NB, int W = kWidth, class Hook = NoTrunkHook>
 DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
-                   typename FragOf<P>::type (&out)[NB][chunks_of<P>(W / 2)], f32x16 (&carry)[NB]) {
+                   typename FragOf<P>::type (&out)[NB][chunks_of<P>(W / 2)], f32x16 (&carry)[NB], Hook hook = Hook()) {
   using F = typename FragOf<P>::type;
   constexpr int PC = chunks_of<P>(32), HC = chunks_of<P>(W / 2), MBW = W / 32;
   constexpr bool CY = PIPE && P::kSlotsPerChunk == 8;  // hand a layer's last M-block to the next layer unconverted
@@ -623,8 +629,11 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
   F a[NB][HC], b[NB][HC];
   layer<P, UMB, PIPE, NB, PC, MBW, true, false, false, true, -1, true, CY>(st, smem, pe, a, nohead, norb, carry);
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
+  hook(0, a[0]);
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
+  hook(1, b[0]);
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
+  hook(2, a[0]);
   {
     F cat[NB][PC + HC];
     if constexpr (P::kSlotsPerChunk == 8 && (!PIPE || P::kSplit)) {  // recompute: cheaper than 32 VGPRs live across 4 layers
@@ -646,10 +655,14 @@ DFN_DEV void trunk(Stager& st, char* smem, const float (&x)[NB][3],
       for (int i = 0; i < HC; ++i) cat[nb][PC + i] = b[nb][i];
     }
     layer<P, l5_unit_mb_p<P>(UMB), PIPE, NB, PC + HC, MBW, true, false, false, true, (CY ? PC + HC - 2 : -1), true, CY>(st, smem, cat, a, nohead, norb, carry);
+    hook(3, reinterpret_cast<F(&)[HC]>(cat[0][PC]));   // layer 4's output: the h part of the skip concat, completed inside layer 5
   }
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, b, nohead, norb, carry);
+  hook(4, a[0]);
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, b, a, nohead, norb, carry);
+  hook(5, b[0]);
   layer<P, UMB, PIPE, NB, HC, MBW, true, false, false, true, CI, true, CY>(st, smem, a, out, nohead, norb, carry);  // out's last two chunks stay in `carry`
+  hook(6, a[0]);
 }
 
 }  // namespace dfn

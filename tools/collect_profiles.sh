@@ -12,4 +12,5 @@ done
 [ -f $G/dfnet_layers.txt ] && cp $G/dfnet_layers.txt $P/${T}_dfnet_layers.txt
 [ -f $G/dm_step.json ] && cp $G/dm_step.json $P/${T}_dm_step.json
 [ -f $G/train_step.json ] && cp $G/train_step.json $P/${T}_train_step.json
+[ -f $G/train_step_pmc.json ] && cp $G/train_step_pmc.json $P/${T}_train_step_pmc.json
 ls -la $P | grep $T

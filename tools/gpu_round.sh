@@ -50,6 +50,8 @@ if [[ " $* " != *" noextra "* ]]; then
   rm -rf $R/gpurun_out/prof_dm $R/gpurun_out/prof_train $R/gpurun_out/prof_layers
   DM_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dm -o dm -- python $R/tools/gpu_dm_step.py 4 24 > $R/gpurun_out/dm_step.json 2> $R/gpurun_out/dm_step.err; echo "dm rc=$?"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -o tr -- python $R/tools/gpu_nerf_train_step.py 1536 128 10 > $R/gpurun_out/train_step.json 2> $R/gpurun_out/train_step.err; echo "train rc=$?"
+  rm -f $R/gpurun_out/train_step_pmc.json; timeout -k 5 900 $R/tools/gpu_train_pmc.sh > $R/gpurun_out/train_step_pmc.log 2>&1; echo "train pmc rc=$?"
+  cd /tmp
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_layers -o l -- python $R/tools/gpu_dfnet_layers.py run > /dev/null 2>&1
   python $R/tools/gpu_dfnet_layers.py report $R/gpurun_out/prof_layers > $R/gpurun_out/dfnet_layers.txt; head -3 $R/gpurun_out/dfnet_layers.txt
   rm -rf $R/gpurun_out/prof_layers
