@@ -62,6 +62,10 @@ struct dfn_dfnet_s {
   int fresh_mask = 0;
   struct Kept { const void* ws; int prec, B, H, W, bn_batch; };
   std::vector<Kept> kept;
+  // split-f16 inference: the adaptation branches of pyramid levels >= 1 (1x1, 5x5, bilinear resize: mostly HBM writes) run on this
+  // stream beside the rest of the encoder (forward_core); created on first use
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static size_t zeros_offset(int feat_dim) { return (size_t(feat_dim) * 513 + 3) & ~size_t(3); }   // floats into h->fc, 16-byte aligned
@@ -130,6 +134,9 @@ static void free_dev(dfn_dfnet_s* h) {
 extern "C" int dfn_dfnet_destroy(dfn_dfnet_t h) {
   if (!h) return DFN_OK;
   free_dev(h);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
   return DFN_OK;
 }
@@ -401,6 +408,67 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   const void* last_act = nullptr;
   int last_h = 0, last_w = 0;
   int fused_1x1 = -1;                 // tap whose 1x1 adaptation conv ran inside its encoder conv (its output sits in w.tmp64)
+  // One pyramid level's adaptation branch: [1x1 + ReLU unless it ran inside the tap's conv] -> BN-folded 5x5 -> align_corners resize into
+  // the caller's NCHW stack (or written there by the 5x5 itself when the level already has the requested size).
+  const size_t es = prec == 0 ? 2 : 4;
+  const size_t plane = size_t(128) * upH * upW;
+  auto adapt_level = [&](int t, hipStream_t st, char* tmp64, char* ad128) -> int {
+    ConvArgs a{};
+    a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale; a.out_act = tmp64; a.out_pre = nullptr;
+    a.B = B; a.H = tap_h[t]; a.W = tap_w[t]; a.nblk_in = h->tap_channels[t] / 32; a.cout_blocks = 2; a.relu = 1;
+    if (split) { a.in_split = 1; a.out_split = 1; a.zeros = zeros; }
+    if (t != fused_1x1) CHECK_HIP(launch_conv(prec, 1, 16, a, st), "dfnet: adapt 1x1");
+    ConvArgs c{};
+    const PackedConv& p5 = bn_mode ? h->ad5_raw[t] : h->ad5[t];
+    c.in = tmp64; c.w = p5.w[prec]; c.bias = prec == 2 ? p5.bias_x3 : p5.bias; c.out_scale = p5.out_scale; c.out_act = ad128; c.out_pre = nullptr;
+    c.B = B; c.H = tap_h[t]; c.W = tap_w[t]; c.nblk_in = 2; c.cout_blocks = 4; c.relu = 0;
+    if (split) { c.in_split = 1; c.zeros = zeros; }
+    // a level that already has the requested size (level 0 when the features are asked for at the frame size, as every caller of
+    // the reference does): the align_corners resize is the identity, the 5x5 conv writes the caller's NCHW stack itself
+    const bool identity = bn_mode == 0 && tap_h[t] == upH && tap_w[t] == upW;
+    if (identity) {
+      c.out_act = nullptr;
+      c.out_nchw = siamese ? features + size_t(t) * (B / 2) * plane : features + size_t(t) * B * plane;
+      c.nchw_split = siamese ? B / 2 : B;
+      c.nchw_group_stride = size_t(h->n_taps) * (B / 2) * plane;
+    }
+    CHECK_HIP(launch_conv(prec, 5, 16, c, st), "dfnet: adapt 5x5");
+    if (identity) return DFN_OK;
+    const float* affine = nullptr;
+    if (bn_mode == 1) {
+      CHECK_HIP(launch_bn_running_stats(h->bn_dev[t], 1e-5f, w.bn_work, st), "dfnet: BatchNorm running statistics");
+      affine = w.bn_work;
+    } else if (bn_mode == 2) {
+      CHECK_HIP(launch_bn_batch_stats(reinterpret_cast<const float*>(ad128), (long long)B * tap_h[t] * tap_w[t], h->bn_dev[t], 1e-5f,
+                                      w.bn_part, w.bn_work, bn_stats + size_t(t) * 256, bn_stats + size_t(t) * 256 + 128, st),
+                "dfnet: BatchNorm batch statistics");
+      affine = w.bn_work;
+    }
+    if (!siamese) {
+      CHECK_HIP(launch_upsample(prec, ad128, B, tap_h[t], tap_w[t], upH, upW, features + size_t(t) * B * plane, plane, st, affine),
+                "dfnet: upsample");
+    } else {
+      const int hb = B / 2;
+      for (int half = 0; half < 2; ++half) {
+        const char* src = ad128 + size_t(half) * hb * tap_h[t] * tap_w[t] * 128 * es;
+        float* dst = features + (size_t(half) * h->n_taps + t) * hb * plane;
+        CHECK_HIP(launch_upsample(prec, src, hb, tap_h[t], tap_w[t], upH, upW, dst, plane, st, affine), "dfnet: upsample");
+      }
+    }
+    return DFN_OK;
+  };
+  // Split-f16 inference with level 0 at the requested size (every caller of the reference): level 0's 5x5 writes the caller's stack
+  // itself and leaves w.ad128 unused, so the branches of levels >= 1 — two small convs and a resize that is pure HBM writes (629 MB
+  // per level for 4 frames of 480x640) — get their buffers out of it and run on the handle's side stream as soon as their tap is
+  // written, beside the matrix-bound encoder layers whose grids leave CUs idle (conv4_x: 1.25 rounds, conv5_x: 0.4).
+  const bool side_levels = split && return_feature && h->n_taps > 1 && H == upH && W == upW;
+  char* side_tmp64 = w.ad128;
+  char* side_ad128 = w.ad128 + al256(size_t(B) * (H / 4) * (W / 4) * 64 * es);
+  if (side_levels && !h->side) {
+    CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), "dfnet: side stream");
+    CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming), "dfnet: side stream");
+    CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming), "dfnet: side stream");
+  }
   for (size_t i = 0; i < h->enc.size(); ++i) {
     const ConvSpec& sp = h->enc[i];
     const bool is_last_tap = sp.tap == h->n_taps - 1;
@@ -434,6 +502,11 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
     if (a.out_act || a.out_pre || a.out_pool)
       CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet: encoder conv");
     if (sp.tap >= 0) { tap_h[sp.tap] = ch; tap_w[sp.tap] = cw; }
+    if (side_levels && sp.tap >= 1) {     // this level's tap is on its way: its branch follows it on the side stream
+      CHECK_HIP(hipEventRecord(h->ev_fork, s), "dfnet: side stream");
+      CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0), "dfnet: side stream");
+      if (int rc = adapt_level(sp.tap, h->side, side_tmp64, side_ad128)) return rc;
+    }
     if (stop_here) break;
     cur = ping[pp];
     last_act = cur; last_h = ch; last_w = cw;
@@ -449,51 +522,13 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
     }
   }
   if (return_feature) {
-    const size_t es = prec == 0 ? 2 : 4;
-    const size_t plane = size_t(128) * upH * upW;
-    for (int t = 0; t < h->n_taps; ++t) {
-      ConvArgs a{};
-      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale; a.out_act = w.tmp64; a.out_pre = nullptr;
-      a.B = B; a.H = tap_h[t]; a.W = tap_w[t]; a.nblk_in = h->tap_channels[t] / 32; a.cout_blocks = 2; a.relu = 1;
-      if (split) { a.in_split = 1; a.out_split = 1; a.zeros = zeros; }
-      if (t != fused_1x1) CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet: adapt 1x1");
-      ConvArgs c{};
-      const PackedConv& p5 = bn_mode ? h->ad5_raw[t] : h->ad5[t];
-      c.in = w.tmp64; c.w = p5.w[prec]; c.bias = prec == 2 ? p5.bias_x3 : p5.bias; c.out_scale = p5.out_scale; c.out_act = w.ad128; c.out_pre = nullptr;
-      c.B = B; c.H = tap_h[t]; c.W = tap_w[t]; c.nblk_in = 2; c.cout_blocks = 4; c.relu = 0;
-      if (split) { c.in_split = 1; c.zeros = zeros; }
-      // a level that already has the requested size (level 0 when the features are asked for at the frame size, as every caller of
-      // the reference does): the align_corners resize is the identity, the 5x5 conv writes the caller's NCHW stack itself
-      const bool identity = bn_mode == 0 && tap_h[t] == upH && tap_w[t] == upW;
-      if (identity) {
-        c.out_act = nullptr;
-        c.out_nchw = siamese ? features + size_t(t) * (B / 2) * plane : features + size_t(t) * B * plane;
-        c.nchw_split = siamese ? B / 2 : B;
-        c.nchw_group_stride = size_t(h->n_taps) * (B / 2) * plane;
+    for (int t = 0; t < h->n_taps; ++t)
+      if (!(side_levels && t >= 1)) {
+        if (int rc = adapt_level(t, s, w.tmp64, w.ad128)) return rc;
       }
-      CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet: adapt 5x5");
-      if (identity) continue;
-      const float* affine = nullptr;
-      if (bn_mode == 1) {
-        CHECK_HIP(launch_bn_running_stats(h->bn_dev[t], 1e-5f, w.bn_work, s), "dfnet: BatchNorm running statistics");
-        affine = w.bn_work;
-      } else if (bn_mode == 2) {
-        CHECK_HIP(launch_bn_batch_stats(reinterpret_cast<const float*>(w.ad128), (long long)B * tap_h[t] * tap_w[t], h->bn_dev[t], 1e-5f,
-                                        w.bn_part, w.bn_work, bn_stats + size_t(t) * 256, bn_stats + size_t(t) * 256 + 128, s),
-                  "dfnet: BatchNorm batch statistics");
-        affine = w.bn_work;
-      }
-      if (!siamese) {
-        CHECK_HIP(launch_upsample(prec, w.ad128, B, tap_h[t], tap_w[t], upH, upW, features + size_t(t) * B * plane, plane, s, affine),
-                  "dfnet: upsample");
-      } else {
-        const int hb = B / 2;
-        for (int half = 0; half < 2; ++half) {
-          const char* src = w.ad128 + size_t(half) * hb * tap_h[t] * tap_w[t] * 128 * es;
-          float* dst = features + (size_t(half) * h->n_taps + t) * hb * plane;
-          CHECK_HIP(launch_upsample(prec, src, hb, tap_h[t], tap_w[t], upH, upW, dst, plane, s, affine), "dfnet: upsample");
-        }
-      }
+    if (side_levels) {                  // the branches launched beside the encoder rejoin the caller's stream
+      CHECK_HIP(hipEventRecord(h->ev_join, h->side), "dfnet: side stream");
+      CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0), "dfnet: side stream");
     }
   }
   if (return_pose) {

@@ -235,6 +235,18 @@ __device__ unsigned long long g_conv_cycles[8];
 // s_waitcnt vmcnt(n) with lgkmcnt / expcnt left alone (gfx9 encoding: vmcnt = bits [3:0] and [15:14])
 #define DFN_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 
+DFN_DEV_INLINE void vmcnt_upto(int n) {     // s_waitcnt vmcnt(n) for a value known after unrolling
+  switch (n) {
+#define DFN_VMC(k) case k: DFN_VMCNT(k); break;
+    DFN_VMC(0) DFN_VMC(1) DFN_VMC(2) DFN_VMC(3) DFN_VMC(4) DFN_VMC(5) DFN_VMC(6) DFN_VMC(7) DFN_VMC(8) DFN_VMC(9) DFN_VMC(10) DFN_VMC(11)
+    DFN_VMC(12) DFN_VMC(13) DFN_VMC(14) DFN_VMC(15) DFN_VMC(16) DFN_VMC(17) DFN_VMC(18) DFN_VMC(19) DFN_VMC(20) DFN_VMC(21) DFN_VMC(22)
+    DFN_VMC(23) DFN_VMC(24) DFN_VMC(25) DFN_VMC(26) DFN_VMC(27) DFN_VMC(28) DFN_VMC(29) DFN_VMC(30) DFN_VMC(31) DFN_VMC(32) DFN_VMC(33)
+    DFN_VMC(34) DFN_VMC(35) DFN_VMC(36) DFN_VMC(37) DFN_VMC(38) DFN_VMC(39) DFN_VMC(40)
+#undef DFN_VMC
+    default: DFN_VMCNT(0);
+  }
+}
+
 DFN_DEV_INLINE void conv_lds_dma_b128(const void* gptr, const char* lds_dst) {
   const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)DFN_LDS_PTR(lds_dst));   // wave-uniform by construction
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(off) : "memory");
@@ -677,12 +689,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? (MB == 1 ? 3 : 2) : 1) voi
 // each lane fetching its pixel's piece — runs of up to a patch row of consecutive pieces in the row-planar storage — or 16 bytes of
 // zeros outside the image.  One barrier per sub-slice,
 // none extra per half-block.  Sub-slice order (block, K-chunk, ky) over the weights packed as (block, ky, K-chunk).
+// RING = number of weight sub-slice buffers.  2: sub-slice s + 1 is issued while s is multiplied and awaited at the next barrier —
+// its last pieces have the tail of one multiply phase to land, and the waves' cycle counters (make conv_timing) put 30 % of the 3x3
+// layers' wave time into that wait.  3 (the 3x3 layers; exactly 80 KB with the two plane buffers, still two workgroups per CU):
+// sub-slice s + 2 is issued during s, the planes of half-block hb + 1 during (hb, ky = 0 .. KS - 2), and a wave arrives at barrier s
+// with everything its PREVIOUS iteration issued still allowed in flight (in-order vmcnt) — the wait halves (16 %).
 template <int KS, int SB, int WAVES = 4, int TW = 32>
 constexpr int x3s_patch_bytes() {
   return ((2 * 2 * (2 * WAVES * (32 / TW) + KS - 1) * (TW + KS - 1) * 16) + 1023) & ~1023;   // one half-block, whole 1 KB DMA pieces
 }
 
-template <int KS, int SB, int MB, int WAVES = 4, int TW = 32, bool SPREAD = true>
+template <int KS, int SB, int MB, int WAVES = 4, int TW = 32, bool SPREAD = true, int RING = 2>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kernel(ConvArgs a) {
   constexpr int KCB = SB / 8;
   constexpr int RF = 32 / TW;
@@ -697,7 +714,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
   static_assert(PPP + PPW <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* patch = smem;                     // two half-block buffers
-  char* wst = smem + 2 * PBUF;            // two sub-slices
+  char* wst = smem + 2 * PBUF;            // RING sub-slices
+  static_assert(RING == 2 || (RING == 3 && KS >= 3), "RING = 3 spreads a half-block's planes over its first KS - 1 iterations");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 31, h = lane >> 5;
@@ -747,15 +765,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
   // DMA pieces are issued ONE AT A TIME between the MFMA groups of an iteration (an LDS-DMA instruction costs the issuing wave
   // 60+ cycles, 100-185 in a burst next to the fragment reads: MI355X_MICROARCH.md).  Iteration (hb, ky) issues, in this order, the
   // PPW pieces of sub-slice s + 1 and then up to PPI pieces of half-block hb + 1's planes.
-  constexpr int PPI = (PPP + KS - 1) / KS;                   // patch pieces per iteration
+  constexpr int PPI = RING == 3 ? (PPP + KS - 2) / (KS - 1) : (PPP + KS - 1) / KS;   // patch pieces per iteration (RING = 3: none in the last)
   constexpr int GAPS = KS * MB;                              // MFMA groups of an iteration
-  static_assert(PPI <= 4, "vmcnt cases below");
+  static_assert(PPW + PPI <= 40, "vmcnt_upto range");
   auto patch_piece = [&](int hbn, int i) {                   // piece i (compile-time after unrolling) of half-block hbn's planes
     const size_t off = (size_t)min(hbn, NHB - 1) * 4 * a.W * 16;   // the half-block's four sub-planes of the row
     conv_lds_dma_b128(psrc[i] + (((inside >> i) & 1) ? off : (size_t)0), patch + (hbn & 1) * PBUF + min(wave + i * WAVES, PPIECES - 1) * 1024);
   };
-  auto slice_piece = [&](int sl, int i) {
-    const int buf = sl & 1;
+  auto slice_piece = [&](int sl, int buf, int i) {
     sl = min(sl, n_slices - 1);
     const int hb = sl / KS, ky = sl - hb * KS;
     const int packed = ((hb / KCB) * KS + ky) * KCB + (hb % KCB);
@@ -767,29 +784,33 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
 #pragma unroll
   for (int i = 0; i < PPP; ++i) patch_piece(0, i);
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) slice_piece(0, i);
-  int sl = 0;
+  for (int i = 0; i < PPW; ++i) slice_piece(0, 0, i);
+  if (RING == 3) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) slice_piece(1, 1, i);
+  }
+  int sl = 0, rb = 0;                       // rb: ring slot of sub-slice sl
   for (int hb = 0; hb < NHB; ++hb) {
     const char* pb = patch + (hb & 1) * PBUF;
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky, ++sl) {
       // the previous iteration issued [sub-slice s][its share of the next planes]: sub-slice s is home once only that share is out;
       // the half-block's first iteration needs the planes too
+      // RING = 3: sub-slice s was issued TWO iterations ago (and the planes' last share at ky = KS - 2): everything the previous
+      // iteration issued may still be in flight — a DMA has a whole multiply phase to land instead of the tail of one
       const int prev_patch = ky == 0 ? 0 : (min(ky * PPI, PPP) - min((ky - 1) * PPI, PPP));
       CONV_T(3);
-      if (prev_patch == 1) DFN_VMCNT(1);
-      else if (prev_patch == 2) DFN_VMCNT(2);
-      else if (prev_patch == 3) DFN_VMCNT(3);
-      else if (prev_patch == 4) DFN_VMCNT(4);
-      else DFN_VMCNT(0);
+      vmcnt_upto(RING == 3 ? PPW + prev_patch : prev_patch);
       asm volatile("" ::: "memory");
       CONV_T(0);
       __syncthreads();                     // sub-slice s and the planes visible; sub-slice s-1 (and at ky == 0 the other planes) consumed
       CONV_T(1);
-      const char* wb = wst + (sl & 1) * WSL;
+      const char* wb = wst + rb * WSL;
+      const int rbn = RING == 3 ? (rb == 0 ? 2 : rb - 1) : (rb ^ 1);   // slot of sub-slice s + RING - 1: read last in iteration s - 1
+      rb = rb + 1 == RING ? 0 : rb + 1;
       const int p_lo = min(ky * PPI, PPP), p_n = min((ky + 1) * PPI, PPP) - p_lo;   // this iteration's share of the next planes
       auto issue = [&](int n) {            // n-th DMA piece of this iteration
-        if (n < PPW) slice_piece(sl + 1, n);
+        if (n < PPW) slice_piece(sl + RING - 1, rbn, n);
         else if (n - PPW < p_n) {
 #pragma unroll
           for (int i = 0; i < PPP; ++i) if (i == p_lo + n - PPW) patch_piece(hb + 1, i);
@@ -877,14 +898,14 @@ static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int KS, int SB, int MB, int WAVES = 4, int TW = 32, bool SPREAD = true>
+template <int KS, int SB, int MB, int WAVES = 4, int TW = 32, bool SPREAD = true, int RING = 2>
 static hipError_t launch_conv_x3s_t(const ConvArgs& a, hipStream_t stream) {
   if (a.cout_blocks % MB || !a.zeros || a.dyn_scale) return hipErrorInvalidValue;
   constexpr int TH = 2 * WAVES * (32 / TW);
-  constexpr int lds = 2 * x3s_patch_bytes<KS, SB, WAVES, TW>() + 2 * x3_wslice_bytes<KS, SB, MB>();
+  constexpr int lds = 2 * x3s_patch_bytes<KS, SB, WAVES, TW>() + RING * x3_wslice_bytes<KS, SB, MB>();
   static_assert(lds <= (WAVES == 4 ? 80 : 160) * 1024, "x3s conv tile does not fit in LDS (4-wave tiles: two workgroups per CU)");
   static_assert(lds >= WAVES * 32 * (MB * 128 + 16), "epilogue turn buffers");
-  auto kern = conv_x3s_kernel<KS, SB, MB, WAVES, TW, SPREAD>;
+  auto kern = conv_x3s_kernel<KS, SB, MB, WAVES, TW, SPREAD, RING>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -963,7 +984,7 @@ extern "C" int dfn_debug_conv_occupancy(int* out, int n) {
     if (k < n) out[k++] = nb;
   };
   q(conv_x3_kernel<3, 16, 2, 2, 4, 32>, 256, 2 * x3_plane_bytes<3, 16, 4, 32>() + 2 * x3_wslice_bytes<3, 16, 2>());
-  q(conv_x3s_kernel<3, 16, 2, 4, 32>, 256, 2 * x3s_patch_bytes<3, 16, 4, 32>() + 2 * x3_wslice_bytes<3, 16, 2>());
+  q(conv_x3s_kernel<3, 16, 2, 4, 32, true, 3>, 256, 2 * x3s_patch_bytes<3, 16, 4, 32>() + 3 * x3_wslice_bytes<3, 16, 2>());
   q(conv_x3_kernel<3, 16, 1, 2, 4, 16>, 256, 2 * x3_plane_bytes<3, 16, 4, 16>() + 2 * x3_wslice_bytes<3, 16, 1>());
   q(conv_x3s_kernel<1, 16, 2, 4, 32>, 256, 2 * x3s_patch_bytes<1, 16, 4, 32>() + 2 * x3_wslice_bytes<1, 16, 2>());
   q(conv_kernel<PrecF16, 3, 16, 4>, 256, conv_patch_bytes<PrecF16, 3, 16>() + conv_wstage_bytes<PrecF16, 3, 16, 4>());
@@ -994,7 +1015,9 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
       if (sb == 8 && ks == 3) return launch_conv_x3s_t<3, 8, 2>(a, stream);
       if (sb != 16) return hipErrorInvalidValue;
       if (ks == 1) return launch_conv_x3s_t<1, 16, 2>(a, stream);
-      if (ks == 3) return sq ? launch_conv_x3s_t<3, 16, 2, 4, 16>(a, stream) : launch_conv_x3s_t<3, 16, 2>(a, stream);
+      // 3x3: ring of three weight sub-slices (a DMA piece has a whole multiply phase to land: -5 ... -12 % per layer, conv5_x most);
+      // the 8-wave 5x5 tile measured 3 % slower with it and keeps two
+      if (ks == 3) return sq ? launch_conv_x3s_t<3, 16, 2, 4, 16, true, 3>(a, stream) : launch_conv_x3s_t<3, 16, 2, 4, 32, true, 3>(a, stream);
       if (ks == 5) return launch_conv_x3s_t<5, 16, 2, 8, 32, false>(a, stream);   // 8-wave tile: DMA pieces in a burst measured better
     } else {            // fp32 in: patch converted while it is staged (training / gradient paths)
       if (sb == 8 && ks == 3) return launch_conv_x3_t<3, 8, 2, 2>(a, stream);
