@@ -66,6 +66,7 @@ struct dfn_dfnet_s {
   // stream beside the rest of the encoder (forward_core); created on first use
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_buf[3] = {nullptr, nullptr, nullptr};   // backward_params_core: the side stream's last read of a gradient buffer
 };
 
 static size_t zeros_offset(int feat_dim) { return (size_t(feat_dim) * 513 + 3) & ~size_t(3); }   // floats into h->fc, 16-byte aligned
@@ -136,6 +137,7 @@ extern "C" int dfn_dfnet_destroy(dfn_dfnet_t h) {
   free_dev(h);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  for (hipEvent_t e : h->ev_buf) if (e) (void)hipEventDestroy(e);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
   return DFN_OK;
@@ -372,6 +374,7 @@ extern "C" size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int 
 }
 
 #define HS(s) reinterpret_cast<hipStream_t>(s)
+static int ensure_side(dfn_dfnet_s* h);
 #define CHECK_HIP(expr, what)                                                                   \
   do {                                                                                          \
     hipError_t e_ = (expr);                                                                     \
@@ -381,6 +384,16 @@ extern "C" size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int 
 // bn_mode 0: inference (BatchNorm folded into the 5x5 convs).  1, 2: training — the plain 5x5 conv, then BatchNorm as
 // an affine map applied by the upsample kernel: 1 = running statistics (frozen), 2 = batch statistics over all B
 // images, written to bn_stats [n_taps][2][128] (mean, biased variance).
+// the handle's side stream and its events, created on first use
+static int ensure_side(dfn_dfnet_s* h) {
+  if (h->side) return DFN_OK;
+  CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), "dfnet: side stream");
+  CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming), "dfnet: side stream");
+  CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming), "dfnet: side stream");
+  for (hipEvent_t& e : h->ev_buf) CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), "dfnet: side stream");
+  return DFN_OK;
+}
+
 static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature, int siamese,
                         int return_pose, int upH, int upW, float* features, float* pose, int bn_mode, float* bn_stats,
                         void* workspace, size_t workspace_bytes, void* stream) {
@@ -464,11 +477,8 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   const bool side_levels = split && return_feature && h->n_taps > 1 && H == upH && W == upW;
   char* side_tmp64 = w.ad128;
   char* side_ad128 = w.ad128 + al256(size_t(B) * (H / 4) * (W / 4) * 64 * es);
-  if (side_levels && !h->side) {
-    CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), "dfnet: side stream");
-    CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming), "dfnet: side stream");
-    CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming), "dfnet: side stream");
-  }
+  if (side_levels)
+    if (int rc = ensure_side(h)) return rc;
   for (size_t i = 0; i < h->enc.size(); ++i) {
     const ConvSpec& sp = h->enc[i];
     const bool is_last_tap = sp.tap == h->n_taps - 1;
@@ -735,6 +745,8 @@ constexpr size_t kWgradPartFloats = size_t(2048) * 9 * 1024;   // partial sums o
 struct DfParamWs {
   DfBwdWs b;
   float *part, *pooled;
+  char* gC;              // third gradient buffer (the side stream may still read the one a layer's gate wrote)
+  float* scl_layer;      // [13][8]: per encoder conv [scale, 1/scale] of its gated gradient (read by the side stream's weight gradient)
   float* lvl_tmp64[3];   // per pyramid level: ReLU'd 1x1 output,
   float* lvl_z[3];       //   plain 5x5 output (BatchNorm input),
   float* lvl_bn[3];      //   BatchNorm work block (kBnWorkFloats)
@@ -748,6 +760,8 @@ DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return reinterpret_cast<float*>(p); };
   w.part = take(kWgradPartFloats * 4);
   w.pooled = take(size_t(B) * 512 * 4);
+  w.gC = reinterpret_cast<char*>(take(size_t(B) * H * W * 64 * (prec == 0 ? 2 : 4)));
+  w.scl_layer = take(13 * 8 * 4);
   const int div[3] = {1, 4, 16};
   for (int t = 0; t < h->n_taps; ++t) {
     const size_t q = size_t(B) * (H / div[t]) * (W / div[t]);
@@ -860,7 +874,41 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
     // forward recompute, keeping every activation (and the pre-ReLU taps of the levels that carry gradient)
     if (int rc = encoder_keep(h, prec, x, B, H, W, level_mask, pw, s, lay_h, lay_w)) return rc;
   }
-  char* gbuf[2] = {w.gA, w.gB};
+  // Three gradient buffers and the handle's side stream: a layer's bias gradient, the re-pooled conv input and its weight gradient
+  // read the gated gradient g_pre(i) and nothing the data-gradient chain waits for, so they run on the side stream beside the
+  // data-gradient conv of the same and of the next layer (small grids at training resolutions: both leave CUs idle).  The chain
+  // picks its output buffers among those the side stream is done with (ev_buf[k] = its last read of buffer k); pw.part and w.pooled
+  // belong to the side stream, a per-layer [scale, 1/scale] slot replaces the shared one.  Same kernels, same operands, same
+  // summation order as the one-stream form: bit-identical gradients.
+  if (int rc = ensure_side(h)) return rc;
+  hipStream_t side = h->side;
+  char* gbuf[3] = {w.gA, w.gB, pw.gC};
+  bool side_reads[3] = {false, false, false};
+  int side_seq[3] = {0, 0, 0}, seq = 0;      // which of the side stream's reads is the oldest
+  auto fork_side = [&]() -> hipError_t {       // the side stream continues after what the chain has launched so far
+    hipError_t e = hipEventRecord(h->ev_fork, s);
+    return e != hipSuccess ? e : hipStreamWaitEvent(side, h->ev_fork, 0);
+  };
+  auto side_done_with = [&](int k) -> hipError_t {   // the chain is about to overwrite buffer k
+    if (!side_reads[k]) return hipSuccess;
+    side_reads[k] = false;
+    return hipStreamWaitEvent(s, h->ev_buf[k], 0);
+  };
+  auto join_side = [&]() -> hipError_t {
+    hipError_t e = hipEventRecord(h->ev_join, side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, h->ev_join, 0);
+    side_reads[0] = side_reads[1] = side_reads[2] = false;
+    return e;
+  };
+  auto pick_out = [&](int not_a, int not_b) {  // an output buffer: one the side stream is not reading if there is one
+    int k = -1;
+    for (int c = 0; c < 3; ++c) {
+      if (c == not_a || c == not_b) continue;
+      if (k < 0 || (side_reads[k] && (!side_reads[c] || side_seq[c] < side_seq[k]))) k = c;
+    }
+    return k;
+  };
+  CHECK_HIP(fork_side(), "dfnet params: side stream");   // pw.part / w.pooled: after whatever used them before this call
   int act_idx = -1, last = -1;   // act_idx: buffer holding the gradient w.r.t. conv i's ReLU output (none yet)
   if (grad_pose) {
     if (lay_h[n_enc - 1] < 2 || lay_w[n_enc - 1] < 2) return set_error(DFN_ERR_ARG, "%s: image too small for pool5", fn);
@@ -886,9 +934,9 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
     (void)launch_absmax_scale(static_cast<const float*>(t), n, w.scl + 8, w.scl, s);
     return w.scl;
   };
-  // the ReLU gate in front of split-f16 gradient products measures their operand scale (w.scl) in the same pass
-  auto gate = [&](const void* g, const void* act, const void* add, size_t n, void* out) -> hipError_t {
-    if (prec == 2) return launch_relu_gate_scale(g, act, add, n, out, w.scl + 8, w.scl, s);
+  // the ReLU gate in front of split-f16 gradient products measures their operand scale (slot) in the same pass
+  auto gate = [&](const void* g, const void* act, const void* add, size_t n, void* out, float* slot) -> hipError_t {
+    if (prec == 2) return launch_relu_gate_scale(g, act, add, n, out, w.scl + 8, slot, s);
     return launch_relu_gate(1, g, act, add, n, out, s);
   };
   // ---- encoder, last conv first; the adaptation layers of a level join at its tap
@@ -900,6 +948,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       const int t = sp.tap;
       float* const* ag = grads + 2 * n_enc + 2 + per_tap * t;
       const long long Q = (long long)B * hh * ww;
+      CHECK_HIP(join_side(), "dfnet params: side stream");   // this block's reductions use pw.part on the chain's stream
       if (!have_forward)
         if (int rc = adapt_keep(h, prec, t, B, hh, ww, sp.cout, bn_batch != 0, bn_batch != 0, pw, s, nullptr, nullptr)) return rc;
       const float* tmp64 = pw.lvl_tmp64[t];
@@ -920,7 +969,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       c.dyn_scale = sc128;
       c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet params: adapt 5x5 dgrad");
-      CHECK_HIP(gate(w.g64, tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64), "dfnet params: adapt gate");
+      CHECK_HIP(gate(w.g64, tmp64, nullptr, size_t(B) * hh * ww * 64, w.g64, w.scl), "dfnet params: adapt gate");
       const float* g64 = reinterpret_cast<const float*>(w.g64);
       CHECK_HIP(launch_bias_grad(g64, B, hh, ww, 64, pw.part, kWgradPartFloats, ag[1], s), "dfnet params: adapt 1x1 bias gradient");
       const float* sc64 = prec == 2 ? w.scl : nullptr;
@@ -933,28 +982,39 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
       CHECK_HIP(launch_conv(prec, 1, 16, d, s), "dfnet params: adapt 1x1 dgrad");
       g_tap = w.gtap;
+      CHECK_HIP(fork_side(), "dfnet params: side stream");   // pw.part is the side stream's again, after this block's reductions
     }
-    const int pre_idx = act_idx < 0 ? 0 : act_idx, in_idx = pre_idx ^ 1;
-    CHECK_HIP(gate(act_idx < 0 ? nullptr : gbuf[act_idx], w.act[i], g_tap, size_t(B) * hh * ww * sp.cout, gbuf[pre_idx]),
+    const int pre_idx = act_idx < 0 ? 0 : act_idx;
+    float* slot = pw.scl_layer + 8 * i;
+    if (act_idx < 0) CHECK_HIP(side_done_with(pre_idx), "dfnet params: side stream");
+    CHECK_HIP(gate(act_idx < 0 ? nullptr : gbuf[act_idx], w.act[i], g_tap, size_t(B) * hh * ww * sp.cout, gbuf[pre_idx], slot),
               "dfnet params: relu gate");
     const float* g_pre = reinterpret_cast<const float*>(gbuf[pre_idx]);
-    CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, pw.part, kWgradPartFloats, grads[2 * i + 1], s), "dfnet params: bias gradient");
+    const float* sc_pre = prec == 2 ? slot : nullptr;
+    // ---- side stream: bias gradient, re-pooled input, weight gradient of conv i
+    CHECK_HIP(fork_side(), "dfnet params: side stream");
+    CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, pw.part, kWgradPartFloats, grads[2 * i + 1], side), "dfnet params: bias gradient");
     if (i == 0) {
       CHECK_HIP(launch_conv0_wgrad(g_pre, reinterpret_cast<const float*>(w.prep), B, hh, ww, 2 * prep_sb(prec), pw.part, kWgradPartFloats,
-                                   grads[0], s, prec == 2 ? w.scl : nullptr),
+                                   grads[0], side, sc_pre),
                 "dfnet params: conv1_1 weight gradient");
       break;
     }
     const void* input = w.act[i - 1];
     if (h->enc[i - 1].pool_after) {
-      CHECK_HIP(launch_maxpool(prec, w.act[i - 1], B, lay_h[i - 1], lay_w[i - 1], h->enc[i - 1].cout / 32, w.pooled, s),
+      CHECK_HIP(launch_maxpool(prec, w.act[i - 1], B, lay_h[i - 1], lay_w[i - 1], h->enc[i - 1].cout / 32, w.pooled, side),
                 "dfnet params: maxpool (conv input)");
       input = w.pooled;
     }
-    const float* sc_pre = prec == 2 ? w.scl : nullptr;
     CHECK_HIP(launch_conv_wgrad(3, g_pre, reinterpret_cast<const float*>(input), B, hh, ww, sp.cout, sp.cin, pw.part, kWgradPartFloats,
-                                grads[2 * i], s, sc_pre),
+                                grads[2 * i], side, sc_pre),
               "dfnet params: conv weight gradient");
+    CHECK_HIP(hipEventRecord(h->ev_buf[pre_idx], side), "dfnet params: side stream");
+    side_reads[pre_idx] = true;
+    side_seq[pre_idx] = ++seq;
+    // ---- the chain: data gradient of conv i
+    const int in_idx = pick_out(pre_idx, -1);
+    CHECK_HIP(side_done_with(in_idx), "dfnet params: side stream");
     ConvArgs e{};
     e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[prec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale;
     e.out_pre = gbuf[in_idx];
@@ -962,14 +1022,17 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
     e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = ((sp.cin + 63) / 64 * 64) / 32; e.relu = 0;
     CHECK_HIP(launch_conv(prec, 3, 16, e, s), "dfnet params: encoder conv dgrad");
     if (h->enc[i - 1].pool_after) {
+      const int up_idx = pick_out(in_idx, -1);
+      CHECK_HIP(side_done_with(up_idx), "dfnet params: side stream");
       CHECK_HIP(launch_maxpool_backward(1, w.act[i - 1], gbuf[in_idx], B, lay_h[i - 1], lay_w[i - 1], h->enc[i - 1].cout / 32,
-                                        gbuf[pre_idx], s),
+                                        gbuf[up_idx], s),
                 "dfnet params: maxpool backward");
-      act_idx = pre_idx;
+      act_idx = up_idx;
     } else {
       act_idx = in_idx;
     }
   }
+  CHECK_HIP(join_side(), "dfnet params: side stream");
   return DFN_OK;
 }
 }  // namespace
