@@ -31,6 +31,8 @@ constexpr int HC = 8, QC = 4, PC = 4, SC = 2;   // chunks of a 128- / 64- / enco
 constexpr uint32_t kFwdStride = unit_bytes<P>(96, UMB);   // largest forward unit: two M-blocks of layer 5 (96 slots)
 constexpr uint32_t kBwdStride = unit_bytes<P>(80, UMB);   // largest backward unit: two M-blocks of final^T + sigma (80 slots)
 
+// (the pipelined conversion of the render kernels — layer<..., PIPE> in its SCALE_FIRST form, which nerfh_bwd.hip's backward chain uses —
+// measured +-0 here: these chains wait on their operand stores, not on the conversion)
 #define TF_LAYER(KC, MB, RELU, EXTRA, RAYBIAS, IN, OUT, RB) \
   layer<P, UMB, false, NB, KC, MB, RELU, EXTRA, RAYBIAS, true, -1, true, false>(st, smem, IN, OUT, head, RB, carry)
 #define TB_LAYER(KC, MB, IN, OUT) \

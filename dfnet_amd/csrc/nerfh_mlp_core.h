@@ -385,8 +385,11 @@ struct X3Piece {
 // chunks CIN, CIN+1 of Bin and is converted during this layer's chunks 0..CIN-1 (before they are read).
 // COUT: leave this layer's last M-block in `carry` for the next layer instead of converting it here.
 // NOBIAS: the unit's bias fragments are all zero (backward layers): no bias reads, the first MFMA starts from a zero C operand.
+// SCALE_FIRST (split-f16, PIPE): the pipelined conversion in its scale-in-fp32-first form (store_hidden_piece, a block of pieces behind
+// each chunk's MFMAs) instead of the three-part X3Piece form, which converts the UNSCALED accumulators and so needs the render
+// kernels' unit weight scale — the gradient kernels keep the 2^10 scale and per-point renormalisation factors (Stager::lane_mul).
 template <class P, int UMB, bool PIPE, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS, bool NEWUNIT,
-          int CIN, bool CIN_RELU, bool COUT, bool NOBIAS = false>
+          int CIN, bool CIN_RELU, bool COUT, bool NOBIAS = false, bool SCALE_FIRST = false>
 DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][KC],
                    typename FragOf<P>::type (&Bout)[NB][(MB ? MB : 1) * chunks_of<P>(16)],
                    f32x16 (&head)[NB], const float* const (&raybias)[NB], f32x16 (&carry)[NB]) {
@@ -454,7 +457,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
           if (t + PF < nt) a[t % PF] = DFN_AFRAG(t + PF);
           if (kc == (PIPE ? KC / 2 : 0) && !RAYBIAS && !NOBIAS && lm + 1 < nmb) bias_next = load16(reinterpret_cast<const float*>(bl + (lm + 1) * 128));
           __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this chunk's MFMAs (hipcc otherwise sinks it to its use)
-          if constexpr (P::kSplit && PIPE && NB == 1) {
+          if constexpr (P::kSplit && PIPE && NB == 1 && !SCALE_FIRST) {
             // split-f16: the conversion pieces of this chunk go BETWEEN its three dependent MFMAs, a third each (the block form
             // behind them measured 46.5 against 42.7 cycles per MFMA in tools/ubench/x3loop.hip)
             constexpr int PPKI_ = (CIN > 0) ? (8 * NB + CIN - 1) / CIN : 1, PPK_ = (8 * NB + KC - 1) / KC;
