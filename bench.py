@@ -591,6 +591,7 @@ def secondary_dm_step(dev):
     from types import SimpleNamespace
     from dfnet_amd import engine as eng, synthetic as syn
     from dfnet_amd.dfnet import DFNet
+    import dfnet_amd.direct_feature_matching as dfm
     from dfnet_amd.direct_feature_matching import matching_step_grad, train_on_batch
     from dfnet_amd.nerfw import HipQuery
     from oracle import dfnet_oracle as dor, nerfh_oracle as orc
@@ -626,7 +627,16 @@ def secondary_dm_step(dev):
 
     pose_ms, out = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, hwf, True, dev, setup, **kw))
     opt = torch.optim.Adam(model.parameters(), lr=1e-7)
-    full_ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, hwf, opt, True, dev, setup, **kw))
+    step = lambda: train_on_batch(args, data, model, feat_model, gt, hist, hwf, opt, True, dev, setup, **kw)
+    # the reference's form first: every pyramid level computed, the loss's level index_selected afterwards; then the shipped default,
+    # which computes only the level(s) of feature_matching_lvl (bit-identical loss and gradients: tests/test_gpu_grad.py), alternated
+    all_ms, pruned_ms = [], []
+    for _ in range(3):
+        dfm.PRUNE_FEATURE_LEVELS = False
+        all_ms.append(timed(step)[0])
+        dfm.PRUNE_FEATURE_LEVELS = True
+        pruned_ms.append(timed(step)[0])
+    full_ms, full_all_ms = sorted(pruned_ms)[1], sorted(all_ms)[1]
     # oracle composition (forward only) from the same predicted pose
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -651,8 +661,12 @@ def secondary_dm_step(dev):
         cpu_s = time.perf_counter() - t0
     return {"workload": "BASELINE configs[4] per-GPU shape: DFNet_dm step, batch 4, 240x320 frames, NeRF-H render 60x80 at 64+128 "
                         "+ bicubic x4, level-0 cosine feature loss + photometric + pose terms",
-            "forward_backward_to_pose_ms": pose_ms, "full_step_ms": full_ms,
-            "full_step_is": "all 28 regressor gradients + Adam (torch.optim) + device-side re-pack of the updated weights",
+            "forward_backward_to_pose_ms": pose_ms, "full_step_ms": full_ms, "full_step_all_levels_ms": full_all_ms,
+            "full_step_is": "all 28 regressor gradients + Adam (torch.optim) + device-side re-pack of the updated weights; full_step_ms = the "
+                            "shipped default: the frozen feature extractor computes only the pyramid level(s) of feature_matching_lvl = [0] "
+                            "(the loss reads no other: the reference computes all three and index_selects, direct_feature_matching.py:354-357); "
+                            "full_step_all_levels_ms = all three levels computed as the reference does; same loss and gradients bit for bit; "
+                            "medians of three alternations",
             "loss": float(out["loss"]), "oracle_loss": ref_loss,
             "loss_rel_diff_vs_oracle": abs(float(out["loss"]) - ref_loss) / max(abs(ref_loss), 1e-12),
             "cpu_oracle_forward_s": cpu_s,

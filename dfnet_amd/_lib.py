@@ -77,6 +77,7 @@ SIGNATURES = {
     "dfn_dfnet_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dfn_dfnet_forward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P,
                                   _P, c_size_t, _P]),
+    "dfn_dfnet_forward_levels": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "dfn_upsample_bicubic_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dfn_dfnet_backward_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dfn_dfnet_backward_input": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),

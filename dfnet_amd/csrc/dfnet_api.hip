@@ -394,9 +394,11 @@ static int ensure_side(dfn_dfnet_s* h) {
   return DFN_OK;
 }
 
+// level_mask: bit t = pyramid level t is computed (its planes of `features` written).  Levels outside the mask are left untouched, and
+// with return_pose == 0 the encoder stops after the deepest level asked for.
 static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature, int siamese,
                         int return_pose, int upH, int upW, float* features, float* pose, int bn_mode, float* bn_stats,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        void* workspace, size_t workspace_bytes, void* stream, int level_mask = ~0) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: null handle");
   if (!h->committed) return set_error(DFN_ERR_STATE, "dfn_dfnet_forward: dfn_dfnet_commit() has not been called");
   if (prec != DFN_PREC_F16 && prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: unknown precision %d", prec);
@@ -474,6 +476,11 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   // itself and leaves w.ad128 unused, so the branches of levels >= 1 — two small convs and a resize that is pure HBM writes (629 MB
   // per level for 4 frames of 480x640) — get their buffers out of it and run on the handle's side stream as soon as their tap is
   // written, beside the matrix-bound encoder layers whose grids leave CUs idle (conv4_x: 1.25 rounds, conv5_x: 0.4).
+  level_mask &= (1 << h->n_taps) - 1;
+  if (return_feature && !level_mask) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: empty level mask");
+  int deepest = 0;
+  for (int t = 0; t < h->n_taps; ++t) if (level_mask >> t & 1) deepest = t;
+  auto wanted = [&](int t) { return return_feature && (level_mask >> t & 1); };
   const bool side_levels = split && return_feature && h->n_taps > 1 && H == upH && W == upW;
   char* side_tmp64 = w.ad128;
   char* side_ad128 = w.ad128 + al256(size_t(B) * (H / 4) * (W / 4) * 64 * es);
@@ -481,14 +488,14 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
     if (int rc = ensure_side(h)) return rc;
   for (size_t i = 0; i < h->enc.size(); ++i) {
     const ConvSpec& sp = h->enc[i];
-    const bool is_last_tap = sp.tap == h->n_taps - 1;
+    const bool is_last_tap = sp.tap == (return_feature ? deepest : h->n_taps - 1);
     const bool stop_here = is_last_tap && !return_pose;
     ConvArgs a{};
     a.in = cur;
     a.w = h->enc_packed[i].w[prec];
     a.bias = prec == 2 ? h->enc_packed[i].bias_x3 : h->enc_packed[i].bias; a.out_scale = h->enc_packed[i].out_scale;
     a.out_act = stop_here ? nullptr : ping[pp];
-    a.out_pre = (sp.tap >= 0 && return_feature) ? w.tap[sp.tap] : nullptr;
+    a.out_pre = (sp.tap >= 0 && wanted(sp.tap)) ? w.tap[sp.tap] : nullptr;
     a.B = B; a.H = ch; a.W = cw;
     a.nblk_in = nblk;
     a.cout_blocks = sp.cout / 32;
@@ -509,10 +516,10 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
         fused_1x1 = sp.tap;
       }
     }
-    if (a.out_act || a.out_pre || a.out_pool)
+    if (a.out_act || a.out_pre || a.out_pool || a.fuse_out)
       CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet: encoder conv");
     if (sp.tap >= 0) { tap_h[sp.tap] = ch; tap_w[sp.tap] = cw; }
-    if (side_levels && sp.tap >= 1) {     // this level's tap is on its way: its branch follows it on the side stream
+    if (side_levels && sp.tap >= 1 && wanted(sp.tap)) {     // this level's tap is on its way: its branch follows it on the side stream
       CHECK_HIP(hipEventRecord(h->ev_fork, s), "dfnet: side stream");
       CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0), "dfnet: side stream");
       if (int rc = adapt_level(sp.tap, h->side, side_tmp64, side_ad128)) return rc;
@@ -533,7 +540,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   }
   if (return_feature) {
     for (int t = 0; t < h->n_taps; ++t)
-      if (!(side_levels && t >= 1)) {
+      if (wanted(t) && !(side_levels && t >= 1)) {
         if (int rc = adapt_level(t, s, w.tmp64, w.ad128)) return rc;
       }
     if (side_levels) {                  // the branches launched beside the encoder rejoin the caller's stream
@@ -555,6 +562,13 @@ extern "C" int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B,
                                  void* workspace, size_t workspace_bytes, void* stream) {
   return forward_core(h, prec, x, B, H, W, return_feature, siamese, return_pose, upH, upW, features, pose, 0, nullptr, workspace,
                       workspace_bytes, stream);
+}
+
+extern "C" int dfn_dfnet_forward_levels(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int level_mask,
+                                        int upH, int upW, float* features, void* workspace, size_t workspace_bytes, void* stream) {
+  if (h && !(level_mask & ((1 << h->n_taps) - 1))) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward_levels: empty level mask");
+  return forward_core(h, prec, x, B, H, W, 1, siamese, 0, upH, upW, features, nullptr, 0, nullptr, workspace, workspace_bytes, stream,
+                      level_mask);
 }
 
 static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose, int bn_batch,

@@ -57,7 +57,9 @@ class _FeatureFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, engine, single, upH, upW):
-        feats, _ = engine.forward(x.detach(), True, single, False, upH, upW)
+        # a caller's "only these pyramid levels are read" (feature_levels_hint, set for THIS call) prunes the forward
+        fl, engine.feature_levels_hint = getattr(engine, "feature_levels_hint", None), None
+        feats, _ = engine.forward(x.detach(), True, single, False, upH, upW, levels=fl)
         ctx.save_for_backward(x.detach())
         # the caller's hint "my loss reads these pyramid levels only" belongs to THIS forward's graph: taken into the context and
         # cleared on the engine, so that a later backward through the same model with another level set is not cut short
@@ -304,7 +306,11 @@ class _DFNetBase(nn.Module):
             feats = _FeatureFn.apply(x, self.engine(), bool(isSingleStream), int(upsampleH), int(upsampleW))
             return list(feats), None
         # pose-only inference reads no BatchNorm-folded weights: the device re-pack of a training step is enough for it
-        feats, pose = self.engine(train=not return_feature).forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW)
+        E = self.engine(train=not return_feature)
+        levels = None
+        if return_feature and not return_pose:   # a caller's "only these levels are read" hint, for this call only (see _FeatureFn)
+            levels, E.feature_levels_hint = getattr(E, "feature_levels_hint", None), None
+        feats, pose = E.forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW, levels=levels)
         if feats is not None:
             feats = [feats] if isSingleStream else [feats[0], feats[1]]
         return feats, pose

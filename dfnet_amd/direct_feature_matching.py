@@ -20,6 +20,8 @@ from . import dist as ddist
 from .feature_misc import feature_loss, feature_loss_batch, fix_coord_supp, upsample_bicubic
 from .rendering import render, render_frames
 
+PRUNE_FEATURE_LEVELS = True   # _losses: compute only the pyramid levels the feature loss reads (False: all three, like the reference)
+
 
 def preprocess_features_for_loss(feature):
     """[L,B,C,H,W] -> [B, L*C, H, W] (:41-50)."""
@@ -113,10 +115,19 @@ def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False):
     # The reference feeds cat([data, rgb]) through the siamese forward (:351); images are independent in this network,
     # so the target half (no gradient) and the rendered half (tracked) are run as two single-stream calls: the
     # backward then touches only the B rendered images instead of 2 B.
+    # The loss reads only the levels of args.feature_matching_lvl (the reference computes all three and index_selects, :354-357): the
+    # feature extractor is told so — the forwards stop after the deepest of them and skip the other adaptation branches (their planes
+    # come back as zeros), the backward starts from them without scanning the gradient stack.  PRUNE_FEATURE_LEVELS = False computes
+    # every level like the reference; loss and gradients are bit-identical either way (tests/test_gpu_grad.py).
+    lv = sorted(set(int(l) for l in args.feature_matching_lvl))
+    if hasattr(feat_model, "engine") and PRUNE_FEATURE_LEVELS:
+        feat_model.engine().feature_levels_hint = lv
     with torch.no_grad():
         ft, _ = inference_pose_regression(args, data, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
-    if hasattr(feat_model, "engine"):   # the loss reads only these pyramid levels: tell the feature backward (no scan of the gradient stack)
-        feat_model.engine().grad_levels_hint = sorted(set(int(l) for l in args.feature_matching_lvl))
+    if hasattr(feat_model, "engine"):
+        feat_model.engine().grad_levels_hint = lv
+        if PRUNE_FEATURE_LEVELS:
+            feat_model.engine().feature_levels_hint = lv
     fr, _ = inference_pose_regression(args, rgb, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
     feat_l = feature_loss_batch(fr[0], ft[0], args.feature_matching_lvl, per_channel=args.per_channel)
     photo_l = torch.mean((rgb - data) ** 2)

@@ -348,9 +348,12 @@ class DfnetEngine:
         return self
 
     def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427,
-                precision=None):
+                precision=None, levels=None):
         """(features, pose): features is None, [n_taps,B,128,uH,uW] (single stream) or a (target, render) pair of
-        [n_taps,B/2,128,uH,uW]; pose is None or [B, feat_dim]."""
+        [n_taps,B/2,128,uH,uW]; pose is None or [B, feat_dim].
+        levels (features without pose only): the pyramid levels the caller will read (the reference's
+        index_select(features, 0, args.feature_matching_lvl)): only those are computed (dfn_dfnet_forward_levels), the planes of
+        the others are zeros."""
         x = _f32c(x)
         B, C, H, W = x.shape
         assert C == 3
@@ -360,12 +363,19 @@ class DfnetEngine:
         if return_feature:
             shape = (self.n_taps, B, 128, upsampleH, upsampleW) if isSingleStream else \
                 (2, self.n_taps, B // 2, 128, upsampleH, upsampleW)
-            feats = torch.empty(shape, device=dev)
+            pruned = levels is not None and not return_pose and set(int(t) for t in levels) != set(range(self.n_taps))
+            feats = torch.zeros(shape, device=dev) if pruned else torch.empty(shape, device=dev)
         if return_pose:
             pose = torch.empty(B, self.feat_dim, device=dev)
         nbytes = self.lib.dfn_dfnet_workspace_bytes(self.handle, prec, B, H, W)
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if return_feature and pruned:
+            mask = sum(1 << int(t) for t in set(levels))
+            check(self.lib.dfn_dfnet_forward_levels(self.handle, prec, ptr(x), B, H, W, int(not isSingleStream), mask, int(upsampleH),
+                                                    int(upsampleW), ptr(feats), ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),
+                                                    current_stream()), "dfn_dfnet_forward_levels")
+            return ((feats[0], feats[1]) if not isSingleStream else feats), None
         check(self.lib.dfn_dfnet_forward(self.handle, prec, ptr(x), B, H, W, int(return_feature),
                                          int(not isSingleStream), int(return_pose), int(upsampleH), int(upsampleW),
                                          ptr(feats), ptr(pose), ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),

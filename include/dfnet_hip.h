@@ -254,6 +254,14 @@ size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W);
 int dfn_dfnet_forward(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_feature,
                       int siamese, int return_pose, int upH, int upW, float* features, float* pose,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The feature pyramid restricted to the levels a caller reads: DFNet.forward(return_feature=True, return_pose=False)
+ * followed by the reference's torch.index_select(features, 0, args.feature_matching_lvl)
+ * (feature/direct_feature_matching.py:354-357) — bit t of level_mask = level t is computed.  `features` has the layout of
+ * dfn_dfnet_forward; the planes of levels outside the mask are NOT written, the encoder stops after the deepest level asked
+ * for and the adaptation branches of the others do not run.  The planes that are written hold the same bits as
+ * dfn_dfnet_forward's. */
+int dfn_dfnet_forward_levels(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int level_mask,
+                             int upH, int upW, float* features, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Input gradient of DFNet.forward's feature maps — what loss.backward() computes for the rendered image in the
  * DFNet_dm step (feature/direct_feature_matching.py:350-376; the feature extractor's weights are frozen there).

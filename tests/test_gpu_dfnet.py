@@ -335,3 +335,41 @@ def test_frame_prep_device_vs_oracle(tmp_path):
     host = datasets.SevenScenesFrames(train_dl.dataset.files[0].rsplit("/seq-", 1)[0], True, 1, df=2., hist_bin=10, device_prep=False)
     himg, _, hhist = host[0]
     assert float((img[0].cpu() - himg).abs().max()) < 1e-6 and float((hist[0].cpu() - hhist).abs().max()) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels", [(0,), (1,), (0, 2), (2,)])
+@pytest.mark.parametrize("single,shape,up", [(True, (2, 3, 64, 96), (64, 96)), (False, (2, 3, 72, 104), (60, 90)), (True, (4, 3, 240, 320), (240, 320))])
+def test_forward_levels_equals_full_forward_on_the_levels_asked_for(levels, single, shape, up):
+    """dfn_dfnet_forward_levels (the reference's index_select(features, 0, feature_matching_lvl) folded into the forward,
+    direct_feature_matching.py:354-357): the planes of the requested levels hold the SAME BITS as the full forward's, the others
+    stay zero — split-f16 (side-stream schedule when level 0 has the requested size) and the exact-fp32 path."""
+    import torch
+    from dfnet_amd import engine as eng, synthetic as syn
+    E = eng.DfnetEngine(3, 12).load_numpy(syn.dfnet_weights(3))
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(5)).to("cuda:0")
+    for prec in ("f16x3", "f32"):
+        full, _ = E.forward(x, True, single, False, up[0], up[1], precision=prec)
+        full = [t.clone() for t in ((full,) if single else full)]
+        part, pose = E.forward(x, True, single, False, up[0], up[1], precision=prec, levels=levels)
+        assert pose is None
+        for f, p in zip(full, (part,) if single else part):
+            for t in range(3):
+                if t in levels:
+                    assert torch.equal(p[t], f[t]), (prec, t)
+                else:
+                    assert not bool(p[t].any()), (prec, t)
+
+
+@pytest.mark.gpu
+def test_dfnet_s_features_without_pose_launch_the_tap_conv():
+    """DFNet_s, features only: conv1_2 is the last tap and the encoder stops there — its only output is the fused 1x1's (the conv used
+    to be skipped when it had no other output and the features came from whatever the buffer held).  Fresh engine, first call."""
+    import torch
+    from dfnet_amd import engine as eng, synthetic as syn
+    w = {k: v for k, v in syn.dfnet_weights(3).items() if not k.startswith("adaptation_layers.adapt_layer_1") and
+         not k.startswith("adaptation_layers.adapt_layer_2")}
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(9)).to("cuda:0")
+    a, _ = eng.DfnetEngine(1, 12).load_numpy(w).forward(x, True, True, False, 64, 96, precision="f16x3")
+    b, pose = eng.DfnetEngine(1, 12).load_numpy(w).forward(x, True, True, True, 64, 96, precision="f16x3")
+    assert pose is not None and torch.equal(a, b) and bool(a.abs().sum() > 0)

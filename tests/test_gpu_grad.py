@@ -712,6 +712,59 @@ def test_dm_train_step_parameter_gradients_vs_oracle():
     assert worst < 1e-3
 
 
+def test_dm_train_step_is_identical_with_and_without_level_pruning():
+    """direct_feature_matching.PRUNE_FEATURE_LEVELS: the feature extractor computes only the levels of args.feature_matching_lvl — the
+    step's loss, PSNR and all 28 regressor gradients are bit-identical to the all-levels form (what the reference computes and then
+    index_selects, direct_feature_matching.py:354-357)."""
+    from types import SimpleNamespace
+    import dfnet_amd.direct_feature_matching as dfm
+    from dfnet_amd.dfnet import DFNet
+    from dfnet_amd.nerfw import HipQuery
+    H, W, focal = 64, 96, 80.0
+    sd = {k: T(v) for k, v in syn.dfnet_weights(3).items()}
+    cw, fw, ea, et = syn.nerfh_weights(0)
+    E = eng.NerfHEngine(precision="f16x3").load_numpy(cw, fw, ea, et)
+    kw = dict(network_query_fn=HipQuery(E), perturb=False, N_importance=16, N_samples=8, use_viewdirs=True,
+              white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    setup = dict(pose_scale=0.7, pose_scale2=1.2, move_all_cam_vec=[0., 0.1, 1.0])
+    data = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(1))
+    gt = torch.stack([T(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(2)])
+    hist = T(syn.HIST_IDX).repeat(2, 1)
+
+    class Capture:
+        def __init__(self, m):
+            self.m, self.grads = m, None
+
+        def step(self):
+            self.grads = {k: q.grad.detach().cpu().clone() for k, q in self.m.named_parameters() if q.grad is not None}
+
+        def zero_grad(self):
+            for q in self.m.parameters():
+                q.grad = None
+
+    for lvl in ([0], [1], [0, 2]):
+        args = SimpleNamespace(svd_reg=True, chunk=32768, feature_matching_lvl=lvl, per_channel=False, combine_loss=True,
+                               combine_loss_w=[0.3, 0.2, 1.0])
+        out = {}
+        for prune in (True, False):
+            model, feat_model = DFNet().to(DEV).eval(), DFNet().to(DEV).eval()
+            model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+            feat_model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+            for q in feat_model.parameters():
+                q.requires_grad_(False)
+            cap = Capture(model)
+            dfm.PRUNE_FEATURE_LEVELS = prune
+            try:
+                loss, psnr = dfm.train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], cap, True, DEV, setup, **kw)
+            finally:
+                dfm.PRUNE_FEATURE_LEVELS = True
+            out[prune] = (float(loss[0]), float(psnr[0]), cap.grads)
+        assert out[True][0] == out[False][0] and out[True][1] == out[False][1], lvl
+        assert set(out[True][2]) == set(out[False][2])
+        for k in out[True][2]:
+            assert torch.equal(out[True][2][k], out[False][2][k]), (lvl, k)
+
+
 def test_dm_train_step_at_c5_size_vs_oracle():
     """BASELINE configs[4] at its per-GPU shape — batch 4, 240x320 frames, NeRF-H render 60x80 at 64+128 + bicubic x4, level-0
     feature loss — through train_on_batch with the production precisions (f16 coarse net, split-f16 fine net / gradients /
