@@ -23,6 +23,9 @@ else:
     tot = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last)
     span = int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
     print(f"{n} kernels, sum {tot / 1e3:.1f} us, span {span / 1e3:.1f} us")
+    if tot > 1.05 * span:
+        print("(the adaptation branches of pyramid levels 1-2 — 1x1, 5x5, upsample_rows — run on a side stream beside the encoder and the level-0 5x5:\n"
+              " the durations of kernels that overlap are each inflated by the other; `span` is the forward's wall time, kernels listed by start time)")
     for r in last:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         g = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
