@@ -415,9 +415,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   // (resized / written as NCHW planes) and relu5_3 when the pose head reads it.
   const bool split = prec == 2 && bn_mode == 0;
   const void* zeros = h->fc + zeros_offset(h->feat_dim);
-  // split inference: conv1_1 reads the caller's image itself (conv0_direct_x3_kernel) — no prepared copy
-  const bool direct0 = split && h->enc[0].cout == 64 && h->enc[0].tap < 0 && !h->enc[0].pool_after && h->enc.size() > 1;
-  if (!direct0) CHECK_HIP(launch_dfnet_prep(split ? 3 : prec, x, B, H, W, w.prep, s), "dfnet: prep");
+  CHECK_HIP(launch_dfnet_prep(split ? 3 : prec, x, B, H, W, w.prep, s), "dfnet: prep");
   const void* cur = w.prep;
   char* ping[2] = {w.actA, w.actB};
   int pp = 0, ch = H, cw = W, nblk = 1;
@@ -518,9 +516,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
         fused_1x1 = sp.tap;
       }
     }
-    if (direct0 && i == 0)
-      CHECK_HIP(launch_conv0_direct_x3(x, B, H, W, a.w, a.bias, a.out_scale, a.out_act, s), "dfnet: conv1_1");
-    else if (a.out_act || a.out_pre || a.out_pool || a.fuse_out)
+    if (a.out_act || a.out_pre || a.out_pool || a.fuse_out)
       CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet: encoder conv");
     if (sp.tap >= 0) { tap_h[sp.tap] = ch; tap_w[sp.tap] = cw; }
     if (side_levels && sp.tap >= 1 && wanted(sp.tap)) {     // this level's tap is on its way: its branch follows it on the side stream

@@ -1074,103 +1074,6 @@ __global__ __launch_bounds__(256) void prep_split_kernel(const float* __restrict
     }
   }
 }
-// ------------------------------------------------------------------------------------------ conv1_1, direct (split-f16 inference)
-// conv1_1 has 27 contraction elements (3 channels x 3 x 3 taps).  The generic kernel runs it as nine K-chunks of 16 with 13 zero
-// slots each — 108 MFMAs per wave and tile, a prepared copy of the image (prep_split_kernel), plane and weight DMA — for what is one
-// K = 32 product: here a lane gathers its pixel's 27 normalised inputs straight from the caller's [B,3,H,W] image (im2col in
-// registers: element k = 9 c + 3 ky + kx of K-chunk k / 16, lane half (k / 8) % 2, slot k % 8), splits them exactly as
-// prep_split_kernel does, and multiplies with the layer's 64 x 32 weight block held in registers for the wave's lifetime (gathered once
-// from the layer's ordinary packed fragments: no second packed form, device re-packs stay valid): 24 MFMAs per 64 pixels, no LDS, no
-// staging.  Same operands as the two-kernel form (the summation order over k differs); output = ReLU, split storage, 64 channels.
-__global__ __launch_bounds__(256) void conv0_direct_x3_kernel(const float* __restrict__ x, int B, int H, int W, const char* __restrict__ wpk,
-                                                              const float* __restrict__ bias, float out_scale, void* __restrict__ out) {
-  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};  // dfnet.py:79-80
-  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-  // A fragments: row m = p (output channel 32 mb + p), element j of K-chunk kc = contraction index k = 16 kc + 8 h + j
-  half8 ah[2][2], al[2][2];
-  {
-    const _Float16* w16 = reinterpret_cast<const _Float16*>(wpk);   // [ky][hi | lo][mb][kx][lane][8]; RGB = slots 0..2 of lanes 0..31
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = 16 * kc + 8 * h + j;
-          _Float16 vh = (_Float16)0.f, vl = (_Float16)0.f;
-          if (k < 27) {
-            const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
-            const size_t o = size_t(ky) * 6144 + (size_t(mb * 3 + kx) * 64 + p) * 8 + c;
-            vh = w16[o];
-            vl = w16[o + 3072];
-          }
-          ah[mb][kc][j] = vh;
-          al[mb][kc][j] = vl;
-        }
-  }
-  f32x16 b0[2];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const f32x4* bq = reinterpret_cast<const f32x4*>(bias + (mb * 2 + h) * 16);   // pre-scaled bias, C-fragment order
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = bq[q];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) b0[mb][4 * q + i] = v[i];
-    }
-  }
-  const int tiles_x = (W + 31) / 32;
-  const long long n_frag = (long long)B * H * tiles_x;
-  const size_t plane = (size_t)H * W;
-  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * (blockDim.x >> 6);
-  for (long long f = wave0; f < n_frag; f += n_waves) {
-    const int b = int(f / ((long long)H * tiles_x));
-    const int r = int(f - (long long)b * H * tiles_x);
-    const int y = r / tiles_x, xq = (r - y * tiles_x) * 32 + p;
-    half8 bh[2], bl[2];
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // (compile-time k for h = 0 and h = 1 both: the half picks its own)
-        const int k0 = 16 * kc + j, k1 = k0 + 8;
-        float v = 0.f;
-        const int k = h ? k1 : k0;
-        if (k < 27) {
-          const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
-          const int gy = y + ky - 1, gx = xq + kx - 1;
-          if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (x[((size_t)b * 3 + c) * plane + (size_t)gy * W + gx] - mean[c]) / stdv[c];
-        }
-        const float xs = v * kConvActScale;
-        const _Float16 hi = (_Float16)fminf(fmaxf(xs, -65000.f), 65000.f);
-        bh[kc][j] = hi;
-        bl[kc][j] = (_Float16)fminf(fmaxf(xs - (float)hi, -65000.f), 65000.f);
-      }
-    }
-    f32x16 acc[2] = {b0[0], b0[1]};
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb][kc], bh[kc], acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb][kc], bl[kc], acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb][kc], bh[kc], acc[mb], 0, 0, 0);
-      }
-    if (xq < W) {
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) store_split_frag(out, H, W, 2, b, y, xq, mb, h, acc[mb], out_scale, true);
-    }
-  }
-}
-hipError_t launch_conv0_direct_x3(const float* x, int B, int H, int W, const char* wpk, const float* bias_x3, float out_scale, void* out,
-                                  hipStream_t stream) {
-  const long long n_frag = (long long)B * H * ((W + 31) / 32);
-  const long long want = (n_frag + 3) / 4;
-  const int grid = int(want < 2048 ? want : 2048);       // 8 waves per SIMD-quad: persistent waves keep their weight block
-  hipLaunchKernelGGL(conv0_direct_x3_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, stream, x, B, H, W, wpk, bias_x3, out_scale, out);
-  return hipGetLastError();
-}
-
 // prec 3 = the split-f16 storage of prec 2 (inference forward)
 hipError_t launch_dfnet_prep(int prec, const float* x, int B, int H, int W, void* out, hipStream_t stream) {
   const size_t n = (size_t)B * H * W;

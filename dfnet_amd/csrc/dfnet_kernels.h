@@ -65,10 +65,6 @@ int conv_mb(int prec, int cout_blocks);  // M-blocks (of 32 output channels) one
 
 // x [B,3,H,W] fp32 in [0,1] -> (x-mean)/std in the conv1_1 input layout [B,H,W,1,2,SB0].
 hipError_t launch_dfnet_prep(int prec, const float* x, int B, int H, int W, void* out, hipStream_t stream);
-// conv1_1 of the split-f16 inference forward straight from the caller's image (no prepared copy): x [B,3,H,W] in [0,1]; wpk / bias_x3 /
-// out_scale = the layer's ordinary split-f16 packing; out = ReLU'd activation [B,H,W,64] in the split storage.
-hipError_t launch_conv0_direct_x3(const float* x, int B, int H, int W, const char* wpk, const float* bias_x3, float out_scale, void* out,
-                                  hipStream_t stream);
 int prep_sb(int prec);
 // 2x2/2 max pooling on the blocked layout: [B,H,W,nblk,32] -> [B,H/2,W/2,nblk,32].
 hipError_t launch_maxpool(int prec, const void* in, int B, int H, int W, int nblk, void* out, hipStream_t stream);
