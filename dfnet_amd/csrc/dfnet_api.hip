@@ -375,6 +375,16 @@ extern "C" size_t dfn_dfnet_workspace_bytes(dfn_dfnet_t h, int prec, int B, int 
 
 #define HS(s) reinterpret_cast<hipStream_t>(s)
 static int ensure_side(dfn_dfnet_s* h);
+// A function that has put work on the handle's side stream leaves through this: whatever the exit (an error return included), the
+// caller's stream waits for the side stream — nothing the caller may free or reuse afterwards is still being read or written there.
+struct SideJoin {
+  dfn_dfnet_s* h;
+  hipStream_t s;
+  bool armed = false;
+  ~SideJoin() {
+    if (armed && h->side && hipEventRecord(h->ev_join, h->side) == hipSuccess) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+  }
+};
 #define CHECK_HIP(expr, what)                                                                   \
   do {                                                                                          \
     hipError_t e_ = (expr);                                                                     \
@@ -486,6 +496,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   char* side_ad128 = w.ad128 + al256(size_t(B) * (H / 4) * (W / 4) * 64 * es);
   if (side_levels)
     if (int rc = ensure_side(h)) return rc;
+  SideJoin side_join{h, s};
   for (size_t i = 0; i < h->enc.size(); ++i) {
     const ConvSpec& sp = h->enc[i];
     const bool is_last_tap = sp.tap == (return_feature ? deepest : h->n_taps - 1);
@@ -520,6 +531,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
       CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet: encoder conv");
     if (sp.tap >= 0) { tap_h[sp.tap] = ch; tap_w[sp.tap] = cw; }
     if (side_levels && sp.tap >= 1 && wanted(sp.tap)) {     // this level's tap is on its way: its branch follows it on the side stream
+      side_join.armed = true;
       CHECK_HIP(hipEventRecord(h->ev_fork, s), "dfnet: side stream");
       CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0), "dfnet: side stream");
       if (int rc = adapt_level(sp.tap, h->side, side_tmp64, side_ad128)) return rc;
@@ -543,7 +555,8 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
       if (wanted(t) && !(side_levels && t >= 1)) {
         if (int rc = adapt_level(t, s, w.tmp64, w.ad128)) return rc;
       }
-    if (side_levels) {                  // the branches launched beside the encoder rejoin the caller's stream
+    if (side_join.armed) {              // the branches launched beside the encoder rejoin the caller's stream
+      side_join.armed = false;
       CHECK_HIP(hipEventRecord(h->ev_join, h->side), "dfnet: side stream");
       CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0), "dfnet: side stream");
     }
@@ -896,6 +909,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
   // summation order as the one-stream form: bit-identical gradients.
   if (int rc = ensure_side(h)) return rc;
   hipStream_t side = h->side;
+  SideJoin side_join{h, s, true};
   char* gbuf[3] = {w.gA, w.gB, pw.gC};
   bool side_reads[3] = {false, false, false};
   int side_seq[3] = {0, 0, 0}, seq = 0;      // which of the side stream's reads is the oldest
@@ -1046,6 +1060,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       act_idx = in_idx;
     }
   }
+  side_join.armed = false;
   CHECK_HIP(join_side(), "dfnet params: side stream");
   return DFN_OK;
 }
