@@ -157,10 +157,11 @@ def cpu_baseline_worker(mode, sample_rays, out_path):
     threads = ncpu
     torch.set_num_threads(threads)
     # The host is shared (other tenants' jobs come and go on the same sockets): five 4-7 s passes over the whole sample spread 2.7 ... 7.1 s
-    # on one box.  Interference only ever slows a pass down, so the sample is timed as sixteen short passes (a quarter of the rows each,
+    # on one box.  Interference only ever slows a pass down, so the sample is timed as twenty-four short passes (a quarter of the rows each,
     # the four quarters in turn, ~1-2 s) and `value` is the median of the FASTEST FIVE — the estimator `timeit` uses, stated here; every
-    # pass time is in the record, and so is the plain median over all sixteen.
+    # pass time is in the record, and so is the plain median over all of them.
     q = sample_rays // 4
+    N_PASS = 24
     with torch.no_grad():
         t0 = time.perf_counter()
         parts = [orc.render_rays(rows[k * q:(k + 1) * q], c, f, ea, et, NC, NI) for k in range(4)]   # untimed: warm-up + the reference outputs
@@ -168,14 +169,14 @@ def cpu_baseline_worker(mode, sample_rays, out_path):
         ref = {k: torch.cat([p_[k] for p_ in parts]) for k in parts[0]}
         rows = rows[:4 * q]
         runs = []
-        for i in range(16):
+        for i in range(N_PASS):
             k = i % 4
             t0 = time.perf_counter()
             orc.render_rays(rows[k * q:(k + 1) * q], c, f, ea, et, NC, NI)
             runs.append(time.perf_counter() - t0)
         best5 = sorted(runs)[:5]
         dt = best5[2]
-        dt_all = sorted(runs)[8]
+        dt_all = sorted(runs)[N_PASS // 2]
         # one full frame of BASELINE configs[0]'s shape (160x120, 32+64 samples), fastest of three passes after a warm-up
         pose0 = torch.from_numpy(syn.orbit_pose(0, 8))
         orc.render(120, 160, FOCAL / 4, 32768, c, f, ea, et, 32, 64, NEAR, FAR, syn.HIST_IDX, c2w=pose0)
@@ -187,10 +188,10 @@ def cpu_baseline_worker(mode, sample_rays, out_path):
         dt_frame = min(fr)
     rec = {"value": q / dt, "min_time_value": q / min(runs), "median_of_all_passes_value": q / dt_all, "unit": "rays/s", "cores": threads,
            "kind": "port",
-           "sample": f"sixteen passes of {q} rays each (the four quarters of {sample_rays} random rays of frame 0 in turn, 64+128 samples, one "
+           "sample": f"{N_PASS} passes of {q} rays each (the four quarters of {sample_rays} random rays of frame 0 in turn, 64+128 samples, one "
                      f"chunk per pass) after one untimed pass over all of them ({warm:.1f} s); value = the median of the FASTEST FIVE passes "
                      f"({', '.join('%.2f' % r for r in best5)} s: spread {(best5[4] - best5[0]) / dt * 100:.1f} % of their median) — the host is "
-                     f"shared and interference only slows a pass; all sixteen: {', '.join('%.2f' % r for r in runs)} s "
+                     f"shared and interference only slows a pass; all {N_PASS}: {', '.join('%.2f' % r for r in runs)} s "
                      f"(oracle/nerfh_oracle.py, torch {torch.__version__} CPU fp32, autograd anomaly mode off, no_grad)",
            "pinning": f"own process, affinity = {threads} physical cores of NUMA node 0 (set before exec; not the node's first eight), "
                       f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
