@@ -21,6 +21,8 @@ from .feature_misc import feature_loss, feature_loss_batch, fix_coord_supp, upsa
 from .rendering import render, render_frames
 
 PRUNE_FEATURE_LEVELS = True   # _losses: compute only the pyramid levels the feature loss reads (False: all three, like the reference)
+OVERLAP_TARGET_FEATURES = True   # train_on_batch: the target frames' features (independent of the predicted pose) on a side stream
+_SIDE_STREAMS = {}
 
 
 def preprocess_features_for_loss(feature):
@@ -109,8 +111,41 @@ def _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
     return render_frames(H, W, focal, pose_nerf, img_idx, **render_kwargs_test).permute(0, 3, 1, 2)
 
 
-def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False):
-    """The loss block of train_on_batch (:350-370) on a tracked rendered batch rgb [B,3,H,W]."""
+def _target_features(args, data, feat_model, device):
+    """Features of the target frames (no gradient): the levels the loss reads when PRUNE_FEATURE_LEVELS."""
+    if hasattr(feat_model, "engine") and PRUNE_FEATURE_LEVELS:
+        feat_model.engine().feature_levels_hint = sorted(set(int(l) for l in args.feature_matching_lvl))
+    with torch.no_grad():
+        ft, _ = inference_pose_regression(args, data, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
+    return ft
+
+
+def _target_features_async(args, data, feat_model, device):
+    """The same on a side stream, started before the pose regression: the target features depend on nothing the step computes, and both
+    DFNet forwards leave most of the chip idle at training resolutions (conv5_x of a 4 x 240x320 batch is 64 workgroups).  Returns a
+    thunk that makes the current stream wait for them and hands them over.  CPU tensors / no engine: computed in place."""
+    if not (OVERLAP_TARGET_FEATURES and data.is_cuda and hasattr(feat_model, "engine")):
+        return None
+    side = _SIDE_STREAMS.get(data.device)
+    if side is None:
+        side = _SIDE_STREAMS[data.device] = torch.cuda.Stream(device=data.device)
+    side.wait_stream(torch.cuda.current_stream(data.device))
+    with torch.cuda.stream(side):
+        ft = _target_features(args, data, feat_model, device)
+    data.record_stream(side)
+
+    def take():
+        cur = torch.cuda.current_stream(data.device)
+        cur.wait_stream(side)          # also orders the rendered frames' forward after it: both use the extractor's workspace
+        for t in ft:
+            t.record_stream(cur)
+        return ft
+    return take
+
+
+def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False, target_features=None):
+    """The loss block of train_on_batch (:350-370) on a tracked rendered batch rgb [B,3,H,W].  target_features: the thunk of
+    _target_features_async, if the caller started them early."""
     B = data.shape[0]
     # The reference feeds cat([data, rgb]) through the siamese forward (:351); images are independent in this network,
     # so the target half (no gradient) and the rendered half (tracked) are run as two single-stream calls: the
@@ -120,10 +155,7 @@ def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False):
     # come back as zeros), the backward starts from them without scanning the gradient stack.  PRUNE_FEATURE_LEVELS = False computes
     # every level like the reference; loss and gradients are bit-identical either way (tests/test_gpu_grad.py).
     lv = sorted(set(int(l) for l in args.feature_matching_lvl))
-    if hasattr(feat_model, "engine") and PRUNE_FEATURE_LEVELS:
-        feat_model.engine().feature_levels_hint = lv
-    with torch.no_grad():
-        ft, _ = inference_pose_regression(args, data, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
+    ft = target_features() if target_features is not None else _target_features(args, data, feat_model, device)
     if hasattr(feat_model, "engine"):
         feat_model.engine().grad_levels_hint = lv
         if PRUNE_FEATURE_LEVELS:
@@ -148,13 +180,14 @@ def train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer,
     H, W = int(H), int(W)
     data = data.to(device)
     B = data.shape[0]
+    target_features = _target_features_async(args, data, feat_model, device)   # side stream, beside the pose regression
     with torch.enable_grad():
         _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
         pose_nerf = fix_coord_supp(args, pose_ if pose_.requires_grad else pose_.clone(), world_setup_dict, device=device)
         img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
         # the reference renders pose 0 only (:342); every pose of the batch here, as one ray batch
         rgb = _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
-        loss, photo_l = _losses(args, data, rgb, pose_, pose, feat_model, device)
+        loss, photo_l = _losses(args, data, rgb, pose_, pose, feat_model, device, target_features=target_features)
         loss.backward()
     ddist.allreduce_gradients(model.parameters())   # data-parallel: one all-reduce of the regressor's gradients per step
     optimizer.step()

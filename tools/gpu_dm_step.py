@@ -45,6 +45,11 @@ def timed(fn):
 
 
 from dfnet_amd import rendering
+import dfnet_amd.direct_feature_matching as _dfm
+if os.environ.get("DM_NO_OVERLAP"):   # A/B aids: the target features in line / every pyramid level computed
+    _dfm.OVERLAP_TARGET_FEATURES = False
+if os.environ.get("DM_ALL_LEVELS"):
+    _dfm.PRUNE_FEATURE_LEVELS = False
 if os.environ.get("DM_ONLY"):   # profiling aid: only the full optimisation step (rocprofv3 --stats then shows one step's kernels x iters)
     opt = torch.optim.Adam(model.parameters(), lr=1e-7)
     if os.environ.get("DM_TRACE"):   # where the memcpys of a STEADY-STATE step come from (three warm steps first)
