@@ -138,16 +138,19 @@ def cpu_baseline_worker(mode, sample_rays, out_path):
     ncpu = int(os.environ.get("DFN_CPU_PIN_COUNT", "0")) or len(os.sched_getaffinity(0))
     rows, (c, f, ea, et) = oracle_sample(sample_rays)
     if mode == "sweep":
-        cand = sorted({t for t in (4, 8, 16, 32, 64) if 1 <= t <= ncpu} | {min(ncpu, 8)})
-        sub = rows[: max(768, 3 * (sample_rays // 16))]
+        # passes of the SAME size as the timed ones (a quarter of the sample): the oracle's rays/s depends on the chunk (1 024-ray passes
+        # ranked 8 threads above 16, 4 096-ray passes the other way round by 1.5 x)
+        cand = sorted({t for t in (8, 16, 32) if 1 <= t <= ncpu} | {min(ncpu, 8)})
+        q = max(64, sample_rays // 4)
+        sub = rows[: 2 * q]
         sweep = {}
         with torch.no_grad():
             for t in cand:
                 torch.set_num_threads(t)
                 orc.render_rays(sub[:256], c, f, ea, et, NC, NI)  # warm-up (thread pool, allocator)
                 best = float("inf")
-                for k in range(3):                                # fastest of three thirds: one pass per setting let the shared host pick the count
-                    part = sub[k * (sub.shape[0] // 3):(k + 1) * (sub.shape[0] // 3)]
+                for k in range(2):                                # the faster of two passes: one pass per setting let the shared host pick the count
+                    part = sub[k * q:(k + 1) * q]
                     t0 = time.perf_counter()
                     orc.render_rays(part, c, f, ea, et, NC, NI)
                     best = min(best, (time.perf_counter() - t0) / part.shape[0])
@@ -228,8 +231,8 @@ def cpu_baseline(sample_rays):
     d = child("run", pool[:best])
     rec = d["rec"]
     rec.update({"numa0_physical_cores": len(cores), "thread_sweep_rays_per_s": {str(k): round(v, 1) for k, v in sw["sweep"].items()},
-                "sweep_sample": f"fastest of three passes of {sw['sub'] // 3} rays per setting in a process pinned to {len(pool)} cores; `cores` = the "
-                                "fastest setting, used for `value`"})
+                "sweep_sample": f"the faster of two passes of {sw['sub'] // 2} rays (the timed passes' size) per setting in a process pinned to "
+                                f"{len(pool)} cores; `cores` = the fastest setting, used for `value`"})
     return rec, (d["rows"], d["ref"])
 
 
