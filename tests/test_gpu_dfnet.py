@@ -373,3 +373,22 @@ def test_dfnet_s_features_without_pose_launch_the_tap_conv():
     a, _ = eng.DfnetEngine(1, 12).load_numpy(w).forward(x, True, True, False, 64, 96, precision="f16x3")
     b, pose = eng.DfnetEngine(1, 12).load_numpy(w).forward(x, True, True, True, 64, 96, precision="f16x3")
     assert pose is not None and torch.equal(a, b) and bool(a.abs().sum() > 0)
+
+
+@pytest.mark.gpu
+def test_side_stream_forward_is_repeatable():
+    """The split-f16 forward forks the adaptation branches of levels 1-2 onto the handle's side stream (and the level-restricted
+    forward skips some of them): interleaved calls at two sizes on one engine — shared workspace, shared events — must return the same
+    bits every time."""
+    import torch
+    from dfnet_amd import engine as eng, synthetic as syn
+    E = eng.DfnetEngine(3, 12).load_numpy(syn.dfnet_weights(3))
+    xa = torch.rand(4, 3, 240, 320, generator=torch.Generator().manual_seed(2)).to("cuda:0")
+    xb = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(3)).to("cuda:0")
+    ra = E.forward(xa, True, True, False, 240, 320)[0].clone()
+    rb = E.forward(xb, True, True, False, 96, 128)[0].clone()
+    for _ in range(8):
+        assert torch.equal(E.forward(xa, True, True, False, 240, 320)[0], ra)
+        assert torch.equal(E.forward(xb, True, True, False, 96, 128)[0], rb)
+        assert torch.equal(E.forward(xa, True, True, False, 240, 320, levels=[0])[0][0], ra[0])
+        assert torch.equal(E.forward(xa, True, True, False, 240, 320, levels=[1, 2])[0][1:], ra[1:])
