@@ -276,9 +276,9 @@ int upload_vec(const std::vector<T>& v, T** dst) {
   if (bytes && hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return set_error(DFN_ERR_HIP, "fused training: upload failed");
   return DFN_OK;
 }
-int build_state(dfn_nerfh_s* h) {
-  auto* st = new State();
-  h->fused = st;
+// h->fused is published only when every allocation and upload has succeeded: a failure frees what was built and leaves the handle
+// without a state, so the next dfn_nerfh_train_forward builds again instead of launching on null blobs.
+int build_state_into(dfn_nerfh_s* h, State* st) {
   const Geo g = geo_of(h->desc);
   for (int f = 0; f < 2; ++f)
     for (int pass = 0; pass < 2; ++pass) {
@@ -301,6 +301,17 @@ int build_state(dfn_nerfh_s* h) {
       job_map(kJobsFine[j], f, g, maps);
     }
   return upload_vec(maps, &st->map);
+}
+int build_state(dfn_nerfh_s* h) {
+  auto* st = new State();
+  const int rc = build_state_into(h, st);
+  if (rc != DFN_OK) {
+    h->fused = st;                       // destroy_state frees the partial state through the handle
+    dfn::fused::destroy_state(h);        // ... and leaves h->fused null
+    return rc;
+  }
+  h->fused = st;
+  return DFN_OK;
 }
 }  // namespace
 

@@ -390,6 +390,11 @@ extern "C" int dfn_nerfh_train_backward(dfn_nerfh_t h, const float* const* param
     return set_error(DFN_ERR_ARG, "dfn_nerfh_train_backward: bad argument");
   for (int i = 0; i < kParamCount; ++i)
     if (!params[i] || !grads[i]) return set_error(DFN_ERR_ARG, "dfn_nerfh_train_backward: params[%d] / grads[%d] is null", i, i);
+  // the workspace was laid out by the implementation that ran the forward: the other one's carve() would read foreign bytes
+  if (h->train_forward_exact != !use_fused(h))
+    return set_error(DFN_ERR_STATE, "dfn_nerfh_train_backward: the last dfn_nerfh_train_forward ran the %s step, the handle is now in the %s "
+                     "mode (dfn_nerfh_set_train_mode between forward and backward)", h->train_forward_exact ? "exact" : "fused",
+                     use_fused(h) ? "fused" : "exact");
   if (use_fused(h))
     return fused::train_backward(h, params, hist, hist_rows, n_rays, Nc, Ni, noise, raw_noise_std, raw, g_rgb, g_rgb0, g_beta, g_tsigma,
                                  g_tsigma_dense, grads, workspace, workspace_bytes, HS(stream));

@@ -56,15 +56,13 @@ class _FeatureFn(torch.autograd.Function):
     """Feature pyramid of a frozen DFNet with d L/d x as its backward."""
 
     @staticmethod
-    def forward(ctx, x, engine, single, upH, upW):
-        # a caller's "only these pyramid levels are read" (feature_levels_hint, set for THIS call) prunes the forward
-        fl, engine.feature_levels_hint = getattr(engine, "feature_levels_hint", None), None
-        feats, _ = engine.forward(x.detach(), True, single, False, upH, upW, levels=fl)
+    def forward(ctx, x, engine, single, upH, upW, feature_levels=None, grad_levels=None):
+        # feature_levels: the caller's "only these pyramid levels are read" for THIS call (prunes the forward); grad_levels: "my loss
+        # reads these levels only", which belongs to THIS forward's graph.  Both arrive as explicit arguments (module.forward pops the
+        # engine's one-shot hints in every branch), so neither can leak into a later, unrelated forward.
+        feats, _ = engine.forward(x.detach(), True, single, False, upH, upW, levels=feature_levels)
         ctx.save_for_backward(x.detach())
-        # the caller's hint "my loss reads these pyramid levels only" belongs to THIS forward's graph: taken into the context and
-        # cleared on the engine, so that a later backward through the same model with another level set is not cut short
-        ctx.cfg = (engine, single, getattr(engine, "grad_levels_hint", None))
-        engine.grad_levels_hint = None
+        ctx.cfg = (engine, single, grad_levels)
         return (feats,) if single else (feats[0], feats[1])
 
     @staticmethod
@@ -79,8 +77,8 @@ class _FeatureFn(torch.autograd.Function):
         if levels is None:   # otherwise: which levels carry gradient at all (a scan of g and a host sync per level)
             levels = [t for t in range(g.shape[0]) if bool((g[t] != 0).any())]
         if not levels:
-            return torch.zeros_like(x), None, None, None, None
-        return engine.backward_input(x, g.contiguous(), levels=levels), None, None, None, None
+            return torch.zeros_like(x), None, None, None, None, None, None
+        return engine.backward_input(x, g.contiguous(), levels=levels), None, None, None, None, None, None
 
 
 class _PoseFn(torch.autograd.Function):
@@ -285,6 +283,13 @@ class _DFNetBase(nn.Module):
     def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427):
         """Same contract as dfnet.py:109-172: returns (feature_maps, predict) with feature_maps None,
         [stack] (single stream: 1 x [L,B,128,H,W]) or [stack_t, stack_r] (siamese: 2 x [L,B/2,128,H,W])."""
+        # One-shot hints a caller left on the engine for THIS call (direct_feature_matching._losses / _target_features): popped before
+        # any branch — a call that routes through _TrainFn / _PoseFn, or raises, must not leave them for the next, unrelated forward
+        # (which would silently get zero planes for the unlisted levels).
+        feature_levels = grad_levels = None
+        if self._engine is not None:
+            feature_levels, self._engine.feature_levels_hint = getattr(self._engine, "feature_levels_hint", None), None
+            grad_levels, self._engine.grad_levels_hint = getattr(self._engine, "grad_levels_hint", None), None
         bn_batch = self.adaptation_layers.adapt_layer_0[3].training
         wants_grad = torch.is_grad_enabled() and not x.requires_grad and any(p.requires_grad for p in self.parameters())
         if return_feature and (wants_grad or bn_batch) and not x.requires_grad:
@@ -303,13 +308,11 @@ class _DFNetBase(nn.Module):
                 raise NotImplementedError("autograd w.r.t. the INPUT through the pose head is not built; the feature path "
                                           "(return_feature=True, return_pose=False) is, and so are the pose path's "
                                           "parameter gradients (input without grad)")
-            feats = _FeatureFn.apply(x, self.engine(), bool(isSingleStream), int(upsampleH), int(upsampleW))
+            feats = _FeatureFn.apply(x, self.engine(), bool(isSingleStream), int(upsampleH), int(upsampleW), feature_levels, grad_levels)
             return list(feats), None
         # pose-only inference reads no BatchNorm-folded weights: the device re-pack of a training step is enough for it
         E = self.engine(train=not return_feature)
-        levels = None
-        if return_feature and not return_pose:   # a caller's "only these levels are read" hint, for this call only (see _FeatureFn)
-            levels, E.feature_levels_hint = getattr(E, "feature_levels_hint", None), None
+        levels = feature_levels if (return_feature and not return_pose) else None   # the caller's "only these levels are read"
         feats, pose = E.forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW, levels=levels)
         if feats is not None:
             feats = [feats] if isSingleStream else [feats[0], feats[1]]

@@ -77,25 +77,6 @@ def gather_frames(local, n_frames, dst=0):
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
 
 
-def gather_frames_packed(tensors, n_frames, dst=0):
-    """ONE collective for several per-frame float32 stacks of the same local length (rgb [n,H,W,3], disp [n,H,W], per-frame
-    errors [n], ...): each frame's pieces are laid side by side in one [n_local, floats-per-frame] buffer, gathered once
-    (gather_frames), and split again on rank `dst`.  Returns the list of [n_frames, ...] tensors on rank dst, a list of None
-    elsewhere.  world == 1: the inputs themselves."""
-    tensors = list(tensors)
-    if not active():
-        return tensors
-    n_loc = tensors[0].shape[0]
-    widths = [int(t[0].numel()) if n_loc else int(torch.Size(t.shape[1:]).numel()) for t in tensors]
-    packed = torch.cat([t.reshape(n_loc, w).to(torch.float32) for t, w in zip(tensors, widths)], 1) if n_loc else \
-        tensors[0].new_zeros((0, sum(widths)), dtype=torch.float32)
-    out = gather_frames(packed, n_frames, dst)
-    if out is None:
-        return [None] * len(tensors)
-    parts = torch.split(out, widths, 1)
-    return [p.reshape((n_frames,) + tuple(t.shape[1:])) for p, t in zip(parts, tensors)]
-
-
 def root_buffers(tails, n_frames, device, dst=0):
     """Where a rank renders its frames so that the end gather needs no staging copy: rank `dst` allocates the FINAL
     [n_frames, ...] tensors and renders into its own block's views; every other rank gets plain local tensors.
@@ -162,6 +143,18 @@ def gathered_bytes(tensors, n_frames, dst=0):
     lo, hi = frame_block(n_frames, dst, world)
     per_frame = sum(int(torch.Size(t.shape[1:]).numel()) * t.element_size() for t in tensors)
     return (n_frames - (hi - lo)) * per_frame
+
+
+def all_gather_flags(value, device):
+    """Every rank's integer flag word (the NeRF-H range-guard bits) on EVERY rank: list of `world` ints.  An int32 all-gather, not a
+    float MAX: bits 1 and 2 from different ranks must OR, and every rank must see the same words so that all of them raise the same
+    error after the collective instead of some returning into the caller's next collective.  world 1: [value]."""
+    if not active():
+        return [int(value)]
+    v = torch.tensor([int(value)], dtype=torch.int32, device=device)
+    out = [torch.empty_like(v) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, v)
+    return [int(t.item()) for t in out]
 
 
 def all_gather_floats(values, device):

@@ -13,6 +13,26 @@ from . import _lib
 from ._lib import check, current_stream, ptr
 
 
+def _grow_workspace(old, nbytes, device):
+    """A persistent byte workspace of >= nbytes on `device` (the old one if it fits).  Engines keep one workspace across calls that
+    may come from different torch streams (direct_feature_matching runs the target features on a side stream), so a new block is
+    always taken from the DEFAULT stream's pool — never tied to a side stream — the calling stream waits for whatever the default
+    stream still has queued on a recycled block, and the block being replaced is marked in use by the calling stream: the allocator
+    hands it out again only after the kernels queued there have finished."""
+    if old is not None and old.device == device and old.numel() >= nbytes:
+        return old
+    if device.type != "cuda":
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    cur, default = torch.cuda.current_stream(device), torch.cuda.default_stream(device)
+    if old is not None and old.is_cuda:
+        old.record_stream(cur)
+    with torch.cuda.stream(default):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if cur != default:
+        cur.wait_stream(default)
+    return ws
+
+
 def _f32c(t):
     return t.contiguous().float()
 
@@ -97,8 +117,7 @@ class NerfHEngine:
         return _lib.PRECISIONS[precision or self.precision]
 
     def _workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._ws = _grow_workspace(self._ws, nbytes, device)
         return self._ws
 
     # ------------------------------------------------------------------ stages
@@ -368,8 +387,7 @@ class DfnetEngine:
         if return_pose:
             pose = torch.empty(B, self.feat_dim, device=dev)
         nbytes = self.lib.dfn_dfnet_workspace_bytes(self.handle, prec, B, H, W)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._ws = _grow_workspace(self._ws, nbytes, dev)
         if return_feature and pruned:
             mask = sum(1 << int(t) for t in set(levels))
             check(self.lib.dfn_dfnet_forward_levels(self.handle, prec, ptr(x), B, H, W, int(not isSingleStream), mask, int(upsampleH),
@@ -428,8 +446,7 @@ class DfnetEngine:
                   "dfn_dfnet_backward_all_params")
             return dict(zip(names, grads))
         nbytes = self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._ws = _grow_workspace(self._ws, nbytes, dev)
         check(self.lib.dfn_dfnet_backward_params(self.handle, prec, ptr(x), B, H, W, ptr(gp), ptrs, len(grads),
                                                  ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), current_stream()),
               "dfn_dfnet_backward_params")
@@ -454,8 +471,7 @@ class DfnetEngine:
             ws = torch.empty(self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W), dtype=torch.uint8, device=dev)
         else:
             nbytes = self.lib.dfn_dfnet_workspace_bytes(self.handle, prec, B, H, W)
-            if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
-                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws = _grow_workspace(self._ws, nbytes, dev)
             ws = self._ws
         check(self.lib.dfn_dfnet_forward_train(self.handle, prec, ptr(x), B, H, W, int(not isSingleStream), int(return_pose),
                                                int(bool(bn_batch)), int(bool(keep)), int(upsampleH), int(upsampleW), ptr(feats), ptr(pose),
@@ -506,8 +522,7 @@ class DfnetEngine:
         ptrs = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
         if tape is None:
             nbytes = self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W)
-            if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
-                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws = _grow_workspace(self._ws, nbytes, dev)
         ws = self._ws if tape is None else tape
         check(self.lib.dfn_dfnet_backward_all_params(self.handle, prec, ptr(x), B, H, W, ptr(gp), ptr(g), g.shape[3], g.shape[4], mask,
                                                      int(bool(bn_batch)), int(tape is not None), ptrs, len(grads),
@@ -550,8 +565,7 @@ class DfnetEngine:
         prec = _lib.PRECISIONS[precision or self.precision]
         gx = torch.empty_like(x)
         nbytes = self.lib.dfn_dfnet_backward_workspace_bytes(self.handle, prec, B, H, W)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        self._ws = _grow_workspace(self._ws, nbytes, x.device)
         check(self.lib.dfn_dfnet_backward_input(self.handle, prec, ptr(x), B, H, W, g.shape[3], g.shape[4], ptr(g), mask,
                                                 ptr(gx), ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),
                                                 current_stream()), "dfn_dfnet_backward_input")

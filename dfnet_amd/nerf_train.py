@@ -15,6 +15,7 @@ The reference's random draws (stratified jitter, coarse-density noise, importanc
 the device and handed to the library as inputs, which is what makes the path checkable against the reference.
 """
 import ctypes
+import warnings
 
 import torch
 
@@ -51,6 +52,12 @@ class NerfHTrainer:
         self._ws = None
         self._saved = None
         self.exact = False   # default implementation of the step (fused at netwidth 128; other widths always run the exact one)
+        # The fused step splits the LIVE master weights at the operand scale of the last dfn_nerfh_commit (64x headroom): a weight that
+        # outgrows it saturates in the packed blob and the chains only OR a bit into the handle's range flag.  train_step() reads the
+        # flag every `range_check_every` steps (0: never) and, if raised, re-commits at the live weights and repeats the step.
+        self.range_check_every = 1
+        self.range_recoveries = 0
+        self._steps = 0
 
     # ------------------------------------------------------------------ plumbing
     def _ptr_array(self, tensors):
@@ -118,9 +125,10 @@ class NerfHTrainer:
               "dfn_nerfw_loss")
         return loss5, (g_rgb, g_rgb0, g_beta), float(coef) * float(lambda_u) / (n * Nf)
 
-    def backward(self, g_rgb, g_rgb0, g_beta, g_tsigma=0., g_tsigma_dense=None, grads=None):
-        """Gradients of every parameter from the last forward().  grads=None: written into (freshly allocated) p.grad."""
-        s = self._saved
+    def backward(self, g_rgb, g_rgb0, g_beta, g_tsigma=0., g_tsigma_dense=None, grads=None, saved=None):
+        """Gradients of every parameter from the last forward() (or from `saved`, the state an autograd node took from its own
+        forward).  grads=None: written into (freshly allocated) p.grad."""
+        s = self._saved if saved is None else saved
         if s is None:
             raise RuntimeError("NerfHTrainer.backward() without a forward()")
         if grads is None:
@@ -138,10 +146,10 @@ class NerfHTrainer:
               "dfn_nerfh_train_backward")
         return grads
 
-    def backward_rays(self, g_rgb, g_rgb0, g_beta, g_tsigma=0., g_tsigma_dense=None):
+    def backward_rays(self, g_rgb, g_rgb0, g_beta, g_tsigma=0., g_tsigma_dense=None, saved=None):
         """(d L / d rays_o, d L / d rays_d) [n,3] of the last forward(exact=True): the reference's training render is differentiable
         w.r.t. its rays under autograd (rendering.py:245-337); both networks contribute."""
-        s = self._saved
+        s = self._saved if saved is None else saved
         if s is None or not s["exact"]:
             raise RuntimeError("NerfHTrainer.backward_rays() needs a forward(exact=True): the fused chain keeps no activations")
         g_rgb, g_rgb0, g_beta = _f32c(g_rgb).reshape(-1, 3), _f32c(g_rgb0).reshape(-1, 3), _f32c(g_beta).reshape(-1)
@@ -158,15 +166,43 @@ class NerfHTrainer:
               "dfn_nerfh_train_backward_rays")
         return go, gdir
 
+    def recommit(self):
+        """Re-pack the engine from the live master weights: dfn_nerfh_commit re-derives the split-f16 operand scales, which is also
+        what the fused training chains scale the step's weights by (csrc/nerfh_fused_api.hip: train_scale)."""
+        sd = {k: p.detach().cpu().numpy() for k, p in zip(self.names, self.params)}
+        cut = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        self.engine.load_numpy(cut("coarse."), cut("fine."), sd["embedding_a.weight"], sd["embedding_t.weight"])
+
     def train_step(self, rays_o, rays_d, hist, target, Nc, Ni, near, far, perturb=1., raw_noise_std=0., draws=None, coef=1.,
                    lambda_u=0.01):
         """run_nerf.py:50-66 without the optimizer: forward, NerfWLoss, backward into p.grad.  Returns (loss dict of 0-dim
-        tensors c_l/f_l/b_l/s_l, psnr, render outputs)."""
+        tensors c_l/f_l/b_l/s_l, psnr, render outputs).  A fused step whose operands left the split-f16 range (range flag) is
+        repeated — at a re-derived operand scale, then, if that does not clear it, on the exact-fp32 step — so p.grad never holds
+        clamped gradients."""
         n = rays_o.reshape(-1, 3).shape[0]
         t_rand, noise, u = draws if draws is not None else self.draw(n, Nc, Ni, perturb, rays_o.device)
-        out = self.forward(rays_o, rays_d, hist, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u)
-        loss5, (g_rgb, g_rgb0, g_beta), g_ts = self.loss(out, target, coef, lambda_u)
-        self.backward(g_rgb, g_rgb0, g_beta, g_ts)
+
+        def run(exact):
+            out = self.forward(rays_o, rays_d, hist, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u, exact=exact)
+            loss5, (g_rgb, g_rgb0, g_beta), g_ts = self.loss(out, target, coef, lambda_u)
+            self.backward(g_rgb, g_rgb0, g_beta, g_ts)
+            return out, loss5
+
+        out, loss5 = run(None)
+        every = int(self.range_check_every or 0)
+        if not self._saved["exact"] and every > 0 and self._steps % every == 0:
+            flags = self.engine.range_flags()
+            if flags:
+                self.range_recoveries += 1
+                warnings.warn(f"NerfHTrainer: the fused step left the split-f16 operand range (flags {flags:#x}): re-committing the "
+                              "operand scale at the live weights and repeating the step", RuntimeWarning)
+                self.recommit()
+                out, loss5 = run(None)
+                if self.engine.range_flags():
+                    warnings.warn("NerfHTrainer: still out of range after the re-commit: this step runs on the exact-fp32 path",
+                                  RuntimeWarning)
+                    out, loss5 = run(True)
+        self._steps += 1
         return {k: loss5[i] for i, k in enumerate(("c_l", "f_l", "b_l", "s_l"))}, loss5[4], out
 
 
@@ -200,9 +236,14 @@ class _RenderTrainFn(torch.autograd.Function):
         gs = (z3 if g_rgb is None else g_rgb, z3 if g_rgb0 is None else g_rgb0, z1 if g_beta is None else g_beta)
         g_o = g_d = None
         if ctx.want_rays:   # before the weight gradients: they reuse the gradient buffers of the workspace
-            g_o, g_d = tr.backward_rays(*gs, 0., g_ts)
+            g_o, g_d = tr.backward_rays(*gs, 0., g_ts, saved=ctx.saved)
         if any(ctx.needs_input_grad[12:]):
-            tr.backward(*gs, 0., g_ts, grads=grads)
+            tr.backward(*gs, 0., g_ts, grads=grads, saved=ctx.saved)
+            if not ctx.saved["exact"] and tr.range_check_every:
+                flags = tr.engine.range_flags()   # an autograd node cannot repeat its forward: fail loudly instead of clamped gradients
+                if flags:
+                    raise _lib.DfnError(f"render(): the fused training step left the split-f16 operand range (flags {flags:#x}); call "
+                                        "trainer.recommit() (weights outgrew the committed scale) or set trainer.exact = True")
         else:
             grads = [None] * len(tr.params)
         return (None, g_o if ctx.needs_input_grad[1] else None, g_d if ctx.needs_input_grad[2] else None) + (None,) * 9 + tuple(grads)

@@ -420,14 +420,17 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
         t_post += time.time() - tp
     torch.cuda.synchronize()
     t_render = time.time() - t0
-    # The range guard of the narrow arithmetic modes travels WITH the gather (one more small receive per peer in the same batch):
-    # a rank that raised before the collective would leave the others waiting in it.  Every rank learns its own flags, rank 0
-    # everybody's; the errors are raised after the collective and after the PNG pool has been drained.
+    # The range guard of the narrow arithmetic modes: a rank that raised before the collective would leave the others waiting in
+    # it, and a rank that did NOT raise after it would walk into the caller's next collective alone.  So every rank's flag word goes
+    # to EVERY rank (a 4-byte int32 all-gather behind the frame gather: bits OR, nothing is lost to a float MAX) and all of them raise
+    # the same error, after the collective and after the PNG pool has been drained.
     eng_h = _engine_of(render_kwargs)
-    flags = torch.tensor([float(eng_h.range_flags())], device=dev)
+    my_flags = eng_h.range_flags()
+    all_flags = [my_flags]
     tg = time.time()
     try:
-        (all_rgb, all_disp, all_mse), all_flags = ddist.gather_frames_direct([rgbs, disps, mse], N, outs=outs, extra=flags)   # the path's ONE collective
+        (all_rgb, all_disp, all_mse), _ = ddist.gather_frames_direct([rgbs, disps, mse], N, outs=outs)   # the path's ONE data collective
+        all_flags = ddist.all_gather_flags(my_flags, dev)
         torch.cuda.synchronize()
     finally:
         t_gather = time.time() - tg
@@ -443,10 +446,12 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
         t_tail = time.time() - tw
     if errs:
         raise errs[0]
-    bad = int(flags.item()) if all_flags is None else int(all_flags.max().item())
-    if bad:
-        eng_h.raise_range(bad, where=f"render_path: frames {lo}..{hi - 1} of rank {rank}" if all_flags is None else
-                          "render_path: ranks " + ", ".join(str(r) for r in range(all_flags.shape[0]) if all_flags[r].item()))
+    bad = 0
+    for f in all_flags:
+        bad |= int(f)
+    if bad:   # the same message on every rank
+        eng_h.raise_range(bad, where=f"render_path: frames {lo}..{hi - 1}" if len(all_flags) == 1 else
+                          "render_path: ranks " + ", ".join(f"{r} (flags {f:#x})" for r, f in enumerate(all_flags) if f))
     if gt_imgs is None:
         all_mse = None
     n_gathered = ddist.gathered_bytes([rgbs, disps, mse], N)

@@ -263,6 +263,63 @@ def test_fused_step_equals_exact_step(perturb, per_ray_hist, lindisp):
     assert worst < 5e-4
 
 
+def _small_step_inputs(R=64, Nc=16, Ni=24, seed=33):
+    rng = np.random.default_rng(seed)
+    ro, rd = orc.get_rays(480, 640, 585.0, T(syn.orbit_pose(4, 8))[:3, :4])
+    sel = rng.choice(480 * 640, R, replace=False)
+    o, d = ro.reshape(-1, 3)[sel].contiguous().to(DEV), rd.reshape(-1, 3)[sel].contiguous().to(DEV)
+    hist = T(syn.HIST_IDX)[None].to(DEV)
+    target = T(rng.uniform(0, 1, (R, 3)).astype(np.float32)).to(DEV)
+    draws = nerf_train.NerfHTrainer.draw(R, Nc, Ni, 1., DEV, torch.Generator(device=DEV).manual_seed(seed))
+    return o, d, hist, target, Nc, Ni, draws
+
+
+def test_fused_step_recovers_when_weights_outgrow_the_committed_scale():
+    """The fused step splits the LIVE weights at the operand scale of the last commit (64x headroom).  A weight that outgrows it
+    saturates in the packed blob and raises the range flag; train_step() must notice, re-commit at the live weights and repeat the
+    step, so that p.grad equals the exact step's gradients instead of clamped / NaN ones (round-4 advisor finding)."""
+    E, mods, _ = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    o, d, hist, target, Nc, Ni, draws = _small_step_inputs()
+    with torch.no_grad():   # 100x on a few weights of one hidden layer AFTER the commit: beyond the 64x headroom of the split
+        w = dict(zip(tr.names, tr.params))["fine.xyz_encoding_3.0.weight"]
+        w[:4, :4] *= 100.
+    tr.exact = True
+    ld_e, _, _ = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+    exact = [p.grad.clone() for p in tr.params]
+    for p in tr.params:
+        p.grad = None
+    tr.exact = False
+    with pytest.warns(RuntimeWarning, match="operand range"):
+        ld_f, _, _ = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+    assert tr.range_recoveries == 1 and E.range_flags() == 0
+    assert all(bool(torch.isfinite(p.grad).all()) for p in tr.params)
+    worst = max(rel_l2(p.grad, g) for p, g in zip(tr.params, exact))
+    print(f"fused step after the forced re-commit vs exact step: worst gradient rel L2 {worst:.2e}")
+    assert worst < 5e-4
+    for k in ld_e:
+        assert abs(float(ld_f[k]) - float(ld_e[k])) <= 1e-5 * abs(float(ld_e[k])) + 1e-8, k
+    import warnings as _w
+    with _w.catch_warnings():   # the next step runs at the new scale: no warning, no recovery
+        _w.simplefilter("error")
+        tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+    assert tr.range_recoveries == 1
+
+
+def test_train_backward_refuses_a_mode_switch_after_the_forward():
+    """dfn_nerfh_train_backward must not carve a workspace the OTHER implementation laid out (round-4 advisor finding)."""
+    E, mods, _ = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    o, d, hist, target, Nc, Ni, draws = _small_step_inputs(R=32)
+    out = tr.forward(o, d, hist, Nc, Ni, 0., 2.5, *draws[:2], 0., draws[2], exact=False)
+    _, gs, gts = tr.loss(out, target)
+    saved = dict(tr._saved, exact=True)   # pretend the trainer remembered the wrong mode: the library must notice
+    with pytest.raises(_lib.DfnError, match="set_train_mode between forward and backward"):
+        tr.backward(*gs, gts, saved=saved)
+    tr.backward(*gs, gts)   # the right mode still works
+    assert all(bool(torch.isfinite(p.grad).all()) for p in tr.params)
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_training_render_ray_gradients(gold, tag):
     """render(test_time=False) with rays that require grad: the reference's training render is differentiable w.r.t. its rays

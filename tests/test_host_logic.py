@@ -107,51 +107,66 @@ from dfnet_amd import dist as ddist
 rank, world, _ = ddist.init_from_env(backend="gloo")
 n_frames = int(sys.argv[2])
 lo, hi = ddist.frame_block(n_frames, rank, world)
-local = torch.stack([torch.full((3, 4, 3), float(i)) for i in range(lo, hi)]) if hi > lo else torch.zeros(0, 3, 4, 3)
-out = ddist.gather_frames(local, n_frames)
-t = ddist.max_over_ranks(float(rank + 1), torch.device("cpu"))
-assert t == float(world)
-# the packed form: rgb-like, disp-like and per-frame scalars in ONE collective
 n_loc = hi - lo
+local = torch.stack([torch.full((3, 4, 3), float(i)) for i in range(lo, hi)]) if n_loc else torch.zeros(0, 3, 4, 3)
 disp = torch.stack([torch.full((3, 4), 100.0 + i) for i in range(lo, hi)]) if n_loc else torch.zeros(0, 3, 4)
 err = torch.tensor([1000.0 + i for i in range(lo, hi)])
-p_rgb, p_disp, p_err = ddist.gather_frames_packed([local, disp, err], n_frames)
+out = ddist.gather_frames(local, n_frames)            # the padded dist.gather (what a forced one-rank group runs)
+t = ddist.max_over_ranks(float(rank + 1), torch.device("cpu"))
+assert t == float(world)
 if rank == 0:
     assert out.shape == (n_frames, 3, 4, 3), out.shape
     assert all(float(out[i, 0, 0, 0]) == i and float(out[i].min()) == i for i in range(n_frames))
-    assert torch.equal(p_rgb, out) and p_disp.shape == (n_frames, 3, 4) and p_err.shape == (n_frames,)
-    assert all(float(p_disp[i].min()) == 100.0 + i == float(p_disp[i].max()) and float(p_err[i]) == 1000.0 + i for i in range(n_frames))
     print("GATHER_OK", n_frames)
 else:
-    assert out is None and p_rgb is None and p_disp is None and p_err is None
+    assert out is None
 # the direct form (render_path / bench.py): rank 0 owns the FINAL tensors, renders into its block's views and receives every peer's
-# block in place — one grouped send / receive batch, no padding, no packing, plus a small per-rank record in the same batch
+# block in place: one grouped send / receive batch, no padding, no packing, plus a small per-rank record in the same batch.
+# Blocks may be uneven and a rank may own NO frame (n_frames < world): it posts no frame operation, only its record.
 outs, (v_rgb, v_disp, v_err) = ddist.root_buffers([(3, 4, 3), (3, 4), ()], n_frames, torch.device("cpu"))
+assert v_rgb.shape[0] == n_loc
 v_rgb.copy_(local); v_disp.copy_(disp); v_err.copy_(err)
 (d_rgb, d_disp, d_err), extra = ddist.gather_frames_direct([v_rgb, v_disp, v_err], n_frames, outs=outs, extra=torch.tensor([float(rank) + .25]))
 if rank == 0:
-    assert d_rgb.data_ptr() == outs[0].data_ptr() and v_rgb.data_ptr() == outs[0][lo:hi].data_ptr()   # received / rendered in place
-    assert torch.equal(d_rgb, out) and torch.equal(d_disp, p_disp) and torch.equal(d_err, p_err)
+    assert d_rgb.data_ptr() == outs[0].data_ptr() and (n_loc == 0 or v_rgb.data_ptr() == outs[0][lo:hi].data_ptr())   # received / rendered in place
+    assert torch.equal(d_rgb, out)
+    assert all(float(d_disp[i].min()) == 100.0 + i == float(d_disp[i].max()) and float(d_err[i]) == 1000.0 + i for i in range(n_frames))
     assert extra.shape == (world, 1) and [float(x) for x in extra[:, 0]] == [r + .25 for r in range(world)]
     assert ddist.gathered_bytes([v_rgb, v_disp, v_err], n_frames) == (n_frames - (hi - lo)) * (36 + 12 + 1) * 4
     print("DIRECT_OK", n_frames)
 else:
     assert d_rgb is None and d_disp is None and d_err is None and extra is None and outs is None
+# range-guard words: every rank learns every rank's bits (bit 1 on rank 0, bit 2 on the last rank: they must OR, not max)
+flags = ddist.all_gather_flags(1 if rank == 0 else (2 if rank == world - 1 else 0), torch.device("cpu"))
+want = [1] + [0] * (world - 2) + [2] if world > 1 else [1]
+assert flags == want, (rank, flags)
+if rank == 0:
+    print("FLAGS_OK", world)
 ddist.barrier()
 torch.distributed.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("n_frames", [5, 8])
-def test_gather_frames_gloo_world2(tmp_path, n_frames):
+def _run_gather_worker(tmp_path, world, n_frames, port):
     script = tmp_path / "w.py"
     script.write_text(_GLOO_WORKER)
-    port = 29611 + n_frames
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(n_frames)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert f"GATHER_OK {n_frames}" in r.stdout and f"DIRECT_OK {n_frames}" in r.stdout
+    assert f"GATHER_OK {n_frames}" in r.stdout and f"DIRECT_OK {n_frames}" in r.stdout and f"FLAGS_OK {world}" in r.stdout
+
+
+@pytest.mark.parametrize("n_frames", [5, 8])
+def test_gather_frames_gloo_world2(tmp_path, n_frames):
+    _run_gather_worker(tmp_path, 2, n_frames, 29611 + n_frames)
+
+
+@pytest.mark.parametrize("n_frames", [7, 2])
+def test_gather_frames_gloo_world3_uneven_and_empty_rank(tmp_path, n_frames):
+    """World 3 with an uneven block split (7 = 3 + 2 + 2) and with fewer frames than ranks (2: the last rank owns nothing and
+    takes part in the gather with its per-rank record only): the in-place receive of render_path's end gather."""
+    _run_gather_worker(tmp_path, 3, n_frames, 29631 + n_frames)
 
 
 def test_pose_error_metrics_match_scipy():
