@@ -115,6 +115,10 @@ SIGNATURES = {
     "dfn_nerfh_generic_backward_workspace_bytes": (c_size_t, [_P, c_size_t, c_int, c_int]),
     "dfn_nerfh_generic_render_rays_backward": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_size_t, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P,
                                                c_size_t, _P]),
+    "dfn_pose_orthogonalize": (c_int, [_P, c_int, _P, _P]),
+    "dfn_pose_orthogonalize_backward": (c_int, [_P, _P, c_int, _P, _P]),
+    "dfn_conv_wgrad_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dfn_conv_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "dfn_linear_forward": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, c_int, _P]),
     "dfn_linear_backward_input": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, _P]),
     "dfn_linear_backward_weight_scratch_bytes": (c_size_t, [c_int, c_int, c_size_t]),

@@ -1196,3 +1196,52 @@ extern "C" int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* 
 extern "C" int dfn_dfnet_refresh_train_params_device(dfn_dfnet_t h, const float* const* params, int n_params, int prec_mask, void* stream) {
   return refresh_core(h, params, n_params, true, prec_mask, HS(stream), "dfn_dfnet_refresh_train_params_device");
 }
+
+// ------------------------------------------------------------------------------------------ conv weight gradient, stage level
+// The weight / bias gradient of ONE convolution from torch-shaped tensors (parity tests against F.conv2d's autograd): the operands
+// are split once (g at its measured power-of-two scale, the input at kConvActScale) into the row-planar storage and streamed by
+// conv_wgrad_s_kernel (dfnet_wgrad_s.hip) — the kernel the training steps run on their stored activations and gated gradients.
+namespace {
+struct WgStageWs { char *g, *in, *zeros; float *scl, *part, *part_b; size_t part_floats, part_b_floats, total; };
+WgStageWs carve_wg_stage(char* base, int B, int H, int W, int cout, int cin, int ks) {
+  WgStageWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  const size_t q = size_t(B) * H * W;
+  w.g = take(q * cout * 4);
+  w.in = take(q * cin * 4);
+  w.zeros = take(256);
+  w.scl = reinterpret_cast<float*>(take((1024 + 8) * 4));
+  conv_wgrad_split_scratch(ks, B, H, W, cout, cin, &w.part_floats, &w.part_b_floats);
+  w.part = reinterpret_cast<float*>(take(w.part_floats * 4));
+  w.part_b = reinterpret_cast<float*>(take(w.part_b_floats * 4));
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t dfn_conv_wgrad_scratch_bytes(int B, int H, int W, int cout, int cin, int ks) {
+  if (B < 1 || H < 1 || W < 1 || cout < 64 || cin < 64 || cout % 64 || cin % 64 || (ks != 1 && ks != 3 && ks != 5)) return 0;
+  return carve_wg_stage(nullptr, B, H, W, cout, cin, ks).total;
+}
+
+extern "C" int dfn_conv_wgrad(const float* grad_out, const float* input, int B, int H, int W, int cout, int cin, int ks, float* dW,
+                              float* db, void* scratch, size_t scratch_bytes, void* stream) {
+  const char* fn = "dfn_conv_wgrad";
+  if (!grad_out || !input || !dW || !scratch || B < 1 || H < 1 || W < 1)
+    return set_error(DFN_ERR_ARG, "%s: bad argument", fn);
+  if (cout < 64 || cin < 64 || cout % 64 || cin % 64 || (ks != 1 && ks != 3 && ks != 5))
+    return set_error(DFN_ERR_UNSUPPORTED, "%s: channel counts must be multiples of 64, kernel size 1, 3 or 5", fn);
+  const WgStageWs w = carve_wg_stage(static_cast<char*>(scratch), B, H, W, cout, cin, ks);
+  if (w.total > scratch_bytes) return set_error(DFN_ERR_ARG, "%s: scratch too small (%zu < %zu)", fn, scratch_bytes, w.total);
+  hipStream_t s = HS(stream);
+  const size_t q = size_t(B) * H * W;
+  CHECK_HIP(hipMemsetAsync(w.zeros, 0, 256, s), "dfn_conv_wgrad: zeros");
+  CHECK_HIP(launch_absmax_scale(grad_out, q * cout, w.scl + 8, w.scl, s), "dfn_conv_wgrad: gradient scale");
+  CHECK_HIP(launch_nchw_to_split(grad_out, B, cout, H, W, 1.f, w.scl, w.g, s), "dfn_conv_wgrad: split gradient");
+  CHECK_HIP(launch_nchw_to_split(input, B, cin, H, W, kConvActScale, nullptr, w.in, s), "dfn_conv_wgrad: split input");
+  CHECK_HIP(launch_conv_wgrad_split(ks, w.g, w.in, w.zeros, B, H, W, cout, cin, w.part, w.part_floats, w.part_b, w.part_b_floats, dW, db,
+                                    w.scl, s),
+            "dfn_conv_wgrad: weight-gradient stream");
+  return DFN_OK;
+}

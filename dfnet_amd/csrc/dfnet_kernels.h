@@ -126,6 +126,16 @@ hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
                                      float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s);
 
+// --- weight gradients over PRE-SPLIT operands (dfnet_wgrad_s.hip): g / in in the split row-planar storage of dfnet_conv.hip
+// (hi | lo f16 planes; g scaled by gscale[0], in by kConvActScale), cout and cin multiples of 64, ks in {1, 3, 5}.  db may be null.
+void conv_wgrad_split_scratch(int ks, int B, int H, int W, int cout, int cin, size_t* part_floats, size_t* part_b_floats);
+hipError_t launch_conv_wgrad_split(int ks, const void* g, const void* in, const void* zeros, int B, int H, int W, int cout, int cin,
+                                   float* part, size_t part_floats, float* part_b, size_t part_b_floats, float* dW, float* db,
+                                   const float* gscale, hipStream_t s);
+// fp32 blocked [B,H,W,nblk,32] / fp32 NCHW [B,C,H,W] -> split row-planar storage, scale = scale_dev[0] (device) or `scale`
+hipError_t launch_split_rows(const float* x, int B, int H, int W, int nblk, float scale, const float* scale_dev, void* out, hipStream_t s);
+hipError_t launch_nchw_to_split(const float* x, int B, int C, int H, int W, float scale, const float* scale_dev, void* out, hipStream_t s);
+
 // out[0] = 2^k with max|x| * 2^k in [2^10, 2^11) (1 if the tensor is all zero), out[1] = 2^-k.  fp32 tensor of n elements;
 // `part` is scratch of >= 1024 floats.
 hipError_t launch_absmax_scale(const float* x, size_t n, float* part, float* out, hipStream_t s);

@@ -17,7 +17,7 @@ every pose of the batch."""
 import torch
 
 from . import dist as ddist
-from .feature_misc import feature_loss, feature_loss_batch, fix_coord_supp, upsample_bicubic
+from .feature_misc import feature_loss, feature_loss_batch, fix_coord_supp, orthogonalize_pose, upsample_bicubic
 from .rendering import render, render_frames
 
 PRUNE_FEATURE_LEVELS = True   # _losses: compute only the pyramid levels the feature loss reads (False: all three, like the reference)
@@ -42,10 +42,9 @@ def inference_pose_regression(args, data, device, model, retFeature=False, isSin
         return features, predict_pose
     pose = predict_pose.reshape(inputs.shape[0], 3, 4)
     if getattr(args, "svd_reg", False):
-        # R <- U V^T (:85-88; the reference assigns it into the slice in place: assembled out of place here, same values, without
-        # the CopySlices / AsStrided copies of an in-place update on a tracked view)
-        u, s, v = torch.svd(pose[:, :3, :3])
-        pose = torch.cat([torch.matmul(u, v.transpose(-2, -1)), pose[:, :3, 3:]], -1)
+        # R <- U V^T (:85-88) = the orthogonal polar factor of R: one closed-form kernel forward, one backward (csrc/pose_polar.hip)
+        # instead of rocSOLVER's SVD, two BLAS products and the slice / cat copies around them
+        pose = orthogonalize_pose(pose)
     return features, pose
 
 

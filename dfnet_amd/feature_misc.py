@@ -7,7 +7,8 @@ import math
 import numpy as np
 import torch
 
-from . import engine as _engine
+from . import _lib, engine as _engine
+from ._lib import check, current_stream, ptr
 from .rendering import render
 
 
@@ -323,6 +324,37 @@ def perturb_single_render_pose(poses, x, angle):
     return new[None]
 
 
+class _PoseOrthoFn(torch.autograd.Function):
+    """pose [B,3,4] -> [U V^T | t] of the rotation block's SVD, as the orthogonal polar factor (csrc/pose_polar.hip)."""
+
+    @staticmethod
+    def forward(ctx, pose):
+        p = pose.detach().contiguous().float()
+        out = torch.empty_like(p)
+        check(_lib.load().dfn_pose_orthogonalize(ptr(p), p.shape[0], ptr(out), current_stream()), "dfn_pose_orthogonalize")
+        ctx.save_for_backward(p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        gin = torch.empty_like(p)
+        check(_lib.load().dfn_pose_orthogonalize_backward(ptr(p), ptr(g), p.shape[0], ptr(gin), current_stream()),
+              "dfn_pose_orthogonalize_backward")
+        return gin
+
+
+def orthogonalize_pose(pose):
+    """The reference's `svd_reg` (direct_feature_matching.py:85-92, misc.py:68-72): pose[:, :3, :3] <- U V^T of its SVD, for a
+    pose batch [B,3,4].  GPU tensors: one closed-form kernel per direction (no rocSOLVER / BLAS call, differentiable); CPU
+    tensors (the evaluation loop's host-side copies): torch.svd, as the reference."""
+    if pose.is_cuda:
+        return _PoseOrthoFn.apply(pose.reshape(-1, 3, 4))
+    u, s, v = torch.svd(pose[:, :3, :3])
+    return torch.cat([torch.matmul(u, v.transpose(-2, -1)), pose[:, :3, 3:]], -1)
+
+
 def freeze_bn_layer(model):
     """--freezeBN, part 1 (utils/utils.py:18-28): BatchNorm weight / bias stop requiring grad."""
     print("Freezing BatchNorm Layers...")
@@ -378,9 +410,7 @@ def compute_error_in_q(args, dl, model, device, results, batch_size=1):
         data, pose = batch[0], batch[1]
         with torch.no_grad():
             _, predict = model(data.to(device))
-            predict = predict.reshape(-1, 3, 4).cpu()
-            u, s, v = torch.svd(predict[:, :3, :3])
-            predict[:, :3, :3] = torch.matmul(u, v.transpose(-2, -1))
+            predict = orthogonalize_pose(predict.reshape(-1, 3, 4)).cpu()   # on the device, before the host copy
         pose = torch.as_tensor(pose, dtype=torch.float32).reshape(-1, 3, 4)
         ex, eq = pose_errors(predict, pose)
         for k in range(predict.shape[0]):

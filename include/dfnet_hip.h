@@ -380,6 +380,26 @@ int dfn_feature_cosine_backward(const float* fr, size_t level_stride_r, const fl
                                 int n_levels, int B, int C, size_t HW, const float* grad_loss, const void* state, float* grad_fr,
                                 size_t grad_stride, void* stream);
 
+/* The pose regressor's rotation re-orthogonalisation (feature/direct_feature_matching.py:85-92, feature/misc.py:68-72:
+ * `u, s, v = torch.svd(pose[:, :3, :3]); pose[:, :3, :3] = u @ v^T`) and its adjoint, closed form: U V^T is the orthogonal polar
+ * factor of the 3x3 block (scaled Newton iteration in fp64, one thread per pose) — no SVD / GEMM library call in the DFNet_dm step.
+ * pose_in / pose_out / grad_out / grad_in: device [B,3,4] fp32 (row-major [B,12]); the translation column is copied / passed
+ * through.  A singular rotation block (the factor is not unique) yields NaN, as torch.svd's gradient does. */
+int dfn_pose_orthogonalize(const float* pose_in, int B, float* pose_out, void* stream);
+int dfn_pose_orthogonalize_backward(const float* pose_in, const float* grad_out, int B, float* grad_in, void* stream);
+
+/* Weight and bias gradient of ONE stride-1 "same" convolution from torch-shaped fp32 device tensors, for parity tests against
+ * autograd of torch.nn.functional.conv2d — the kernel behind the conv parameter gradients of dfn_dfnet_backward_params /
+ * dfn_dfnet_backward_all_params (what loss.backward() leaves in the Conv2d parameters of feature/dfnet.py:8-40, :57-62 under
+ * feature/direct_feature_matching.py:372-374 and run_feature.py:166-230):
+ *   dW[co][ci][ky][kx] = sum_{b,y,x} grad_out[b,co,y,x] * input[b,ci,y+ky-ks/2,x+kx-ks/2],   db[co] = sum grad_out[b,co,y,x]
+ * grad_out [B,cout,H,W], input [B,cin,H,W], dW [cout,cin,ks,ks], db [cout] (may be NULL).  cout, cin multiples of 64, ks 1, 3 or 5.
+ * Split-f16 products (fp32-grade): operands split once into hi | lo f16 planes, three f16 MFMAs per product, fp32 accumulation,
+ * chunk partials summed in a fixed order (bit-identical reruns). */
+size_t dfn_conv_wgrad_scratch_bytes(int B, int H, int W, int cout, int cin, int ks);
+int dfn_conv_wgrad(const float* grad_out, const float* input, int B, int H, int W, int cout, int cin, int ks, float* dW,
+                   float* db, void* scratch, size_t scratch_bytes, void* stream);
+
 /* After an optimizer step of DFNet's own training: re-pack encoder, fc_pose, the adaptation convs (unfolded) and the
  * BatchNorm tensors from DEVICE tensors — 2 * 13 + 2 + 8 * n_taps pointers: those of dfn_dfnet_backward_params, then
  * per level .0.weight, .0.bias, .2.weight, .2.bias, .3.weight, .3.bias, .3.running_mean, .3.running_var.  The

@@ -281,9 +281,9 @@ def test_fused_step_recovers_when_weights_outgrow_the_committed_scale():
     E, mods, _ = modules()
     tr = nerf_train.NerfHTrainer(E, *mods)
     o, d, hist, target, Nc, Ni, draws = _small_step_inputs()
-    with torch.no_grad():   # 100x on a few weights of one hidden layer AFTER the commit: beyond the 64x headroom of the split
+    with torch.no_grad():   # 1000x on a few weights of one hidden layer AFTER the commit: beyond the 64x headroom of the split
         w = dict(zip(tr.names, tr.params))["fine.xyz_encoding_3.0.weight"]
-        w[:4, :4] *= 100.
+        w[:4, :4] *= 1000.
     tr.exact = True
     ld_e, _, _ = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
     exact = [p.grad.clone() for p in tr.params]
@@ -296,7 +296,7 @@ def test_fused_step_recovers_when_weights_outgrow_the_committed_scale():
     assert all(bool(torch.isfinite(p.grad).all()) for p in tr.params)
     worst = max(rel_l2(p.grad, g) for p, g in zip(tr.params, exact))
     print(f"fused step after the forced re-commit vs exact step: worst gradient rel L2 {worst:.2e}")
-    assert worst < 5e-4
+    assert worst < 2e-3   # (weights spanning 1000:1 after the growth: the split keeps 2^-24 of the LARGEST weight)
     for k in ld_e:
         assert abs(float(ld_f[k]) - float(ld_e[k])) <= 1e-5 * abs(float(ld_e[k])) + 1e-8, k
     import warnings as _w
