@@ -423,9 +423,12 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   // Split-f16 inference keeps every intermediate activation as hi | lo f16 blocks (dfnet_conv.hip, split_piece): same bytes as fp32,
   // split once by the producer, LDS-DMA staged by the consumer.  Only what leaves the convs stays fp32: the 5x5 adaptation output
   // (resized / written as NCHW planes) and relu5_3 when the pose head reads it.
-  const bool split = prec == 2 && bn_mode == 0;
+  // The training-mode forward (bn_mode != 0) does the same, conv for conv, as the activation-keeping forward of the training path
+  // (encoder_keep / adapt_keep: conv1_1 from the fp32 prepared frame, its weight gradient gathers from it) — bit-identical results.
+  const bool split = prec == 2;
+  const bool split_in0 = split && bn_mode == 0;          // conv1_1's input in the split storage too (inference)
   const void* zeros = h->fc + zeros_offset(h->feat_dim);
-  CHECK_HIP(launch_dfnet_prep(split ? 3 : prec, x, B, H, W, w.prep, s), "dfnet: prep");
+  CHECK_HIP(launch_dfnet_prep(split_in0 ? 3 : prec, x, B, H, W, w.prep, s), "dfnet: prep");
   const void* cur = w.prep;
   char* ping[2] = {w.actA, w.actB};
   int pp = 0, ch = H, cw = W, nblk = 1;
@@ -491,7 +494,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   int deepest = 0;
   for (int t = 0; t < h->n_taps; ++t) if (level_mask >> t & 1) deepest = t;
   auto wanted = [&](int t) { return return_feature && (level_mask >> t & 1); };
-  const bool side_levels = split && return_feature && h->n_taps > 1 && H == upH && W == upW;
+  const bool side_levels = split && bn_mode == 0 && return_feature && h->n_taps > 1 && H == upH && W == upW;
   char* side_tmp64 = w.ad128;
   char* side_ad128 = w.ad128 + al256(size_t(B) * (H / 4) * (W / 4) * 64 * es);
   if (side_levels)
@@ -516,7 +519,7 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
     if (pool_fused) { a.out_pool = ping[pp]; a.out_act = nullptr; }
     if (split) {
       const bool last = i + 1 == h->enc.size();          // relu5_3: read by the pose head as fp32
-      a.in_split = 1; a.zeros = zeros;
+      a.in_split = (i > 0 || split_in0) ? 1 : 0; a.zeros = zeros;
       a.out_split = (last ? 0 : 1) | 2 | 4;
       // a 64-channel tap is one workgroup's channels: its adaptation layer's 1x1 conv + ReLU runs in this conv's epilogue and the
       // tap itself is never stored (level 0: 315 MB written and read back per 4 frames of 480x640, plus the 1x1 kernel)
@@ -778,6 +781,13 @@ struct DfParamWs {
   float* lvl_z[3];       //   plain 5x5 output (BatchNorm input),
   float* lvl_bn[3];      //   BatchNorm work block (kBnWorkFloats)
   double* bn_part;
+  // split-f16 training path (prec 2): activations / taps / 1x1 outputs above are kept in the split row-planar storage, and
+  char* pooledS[13];     //   the 2x2-pooled activation of every conv a max-pool follows (input of the next conv and of its weight gradient),
+  char* g128S;           //   the split copy of a level's BatchNorm-backward output (operand of the 5x5 weight / data gradient),
+  float* part_b;         //   bias-gradient partials of the weight-gradient stream,
+  unsigned* amax;        //   [64] |max| words the producers of gradient tensors leave behind (zeroed once per backward),
+  float* scl_lvl;        //   [3][16]: per level [scale, 1/scale] of the split g128 and g64
+  size_t part_floats, part_b_floats;
   size_t total;
 };
 DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
@@ -785,11 +795,32 @@ DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int
   w.b = carve_df_bwd(h, base, prec, B, H, W);
   size_t off = w.b.total;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return reinterpret_cast<float*>(p); };
-  w.part = take(kWgradPartFloats * 4);
+  // weight-gradient partials: the fixed allowance of the fp32-input kernels, or what the split stream's chunk plan asks for
+  w.part_floats = kWgradPartFloats;
+  w.part_b_floats = 0;
+  const int div[3] = {1, 4, 16};
+  if (prec == 2) {
+    auto need = [&](int ks, int hh, int ww, int cout, int cin) {
+      if (cout % 64 || cin % 64) return;
+      size_t pf, pb;
+      conv_wgrad_split_scratch(ks, B, hh, ww, cout, cin, &pf, &pb);
+      if (pf > w.part_floats) w.part_floats = pf;
+      if (pb > w.part_b_floats) w.part_b_floats = pb;
+    };
+    int ch = H, cw = W;
+    for (size_t i = 0; i < h->enc.size(); ++i) {
+      if (i > 0) need(3, ch, cw, h->enc[i].cout, h->enc[i].cin);
+      if (h->enc[i].pool_after) { ch /= 2; cw /= 2; }
+    }
+    for (int t = 0; t < h->n_taps; ++t) {
+      need(5, H / div[t], W / div[t], 128, 64);
+      need(1, H / div[t], W / div[t], 64, h->tap_channels[t]);
+    }
+  }
+  w.part = take(w.part_floats * 4);
   w.pooled = take(size_t(B) * 512 * 4);
   w.gC = reinterpret_cast<char*>(take(size_t(B) * H * W * 64 * (prec == 0 ? 2 : 4)));
   w.scl_layer = take(13 * 8 * 4);
-  const int div[3] = {1, 4, 16};
   for (int t = 0; t < h->n_taps; ++t) {
     const size_t q = size_t(B) * (H / div[t]) * (W / div[t]);
     w.lvl_tmp64[t] = take(q * 64 * 4);
@@ -797,6 +828,19 @@ DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int
     w.lvl_bn[t] = take(kBnWorkFloats * 4);
   }
   w.bn_part = reinterpret_cast<double*>(take(kBnPartBytes));
+  if (prec == 2) {
+    int ch = H, cw = W;
+    for (size_t i = 0; i < h->enc.size(); ++i) {
+      if (h->enc[i].pool_after) {
+        w.pooledS[i] = reinterpret_cast<char*>(take(size_t(B) * (ch / 2) * (cw / 2) * h->enc[i].cout * 4));
+        ch /= 2; cw /= 2;
+      }
+    }
+    w.g128S = reinterpret_cast<char*>(take(size_t(B) * H * W * 128 * 4));
+    w.part_b = take((w.part_b_floats ? w.part_b_floats : 64) * 4);
+    w.amax = reinterpret_cast<unsigned*>(take(64 * 4));
+    w.scl_lvl = take(3 * 16 * 4);
+  }
   w.total = off;
   return w;
 }
@@ -809,10 +853,16 @@ extern "C" size_t dfn_dfnet_backward_params_workspace_bytes(dfn_dfnet_t h, int p
 
 namespace {
 // Encoder forward keeping every activation (and the pre-ReLU taps of the levels in tap_mask) in the params workspace.
+// prec 2 (split-f16): everything between the convs is kept in the split row-planar storage (dfnet_conv.hip: split_piece) — the
+// operands the next conv, the data-gradient chain and the weight-gradient stream multiply, split once by the producing epilogue —
+// except conv1_1's fp32 input (its weight gradient gathers RGB taps) and relu5_3 (the pose head reads fp32); a conv followed by
+// the 2x2 max pool also writes the pooled activation (pw.pooledS).
 int encoder_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int tap_mask, const DfParamWs& pw, hipStream_t s,
                  int* lay_h, int* lay_w) {
   const DfBwdWs& w = pw.b;
   const int n_enc = int(h->enc.size());
+  const bool split = prec == 2;
+  const void* zeros = h->fc + zeros_offset(h->feat_dim);
   CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet train: prep");
   const void* cur = w.prep;
   int ch = H, cw = W, nblk = 1;
@@ -825,12 +875,21 @@ int encoder_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, i
     a.out_act = w.act[i];
     a.out_pre = (sp.tap >= 0 && (tap_mask >> sp.tap & 1)) ? w.tap[sp.tap] : nullptr;
     a.B = B; a.H = ch; a.W = cw; a.nblk_in = nblk; a.cout_blocks = sp.cout / 32; a.relu = 1;
+    const bool pool_next = sp.pool_after && i + 1 < n_enc;
+    if (split) {
+      a.in_split = i > 0; a.zeros = zeros;
+      a.out_split = (i + 1 == n_enc ? 0 : 1) | 2 | 4;
+      if (pool_next) a.out_pool = pw.pooledS[i];
+    }
     CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet train: encoder conv");
     cur = w.act[i];
     nblk = sp.cout / 32;
-    if (sp.pool_after && i + 1 < n_enc) {
-      CHECK_HIP(launch_maxpool(prec, cur, B, ch, cw, nblk, w.pooled, s), "dfnet train: maxpool");
-      cur = w.pooled;
+    if (pool_next) {
+      if (split) cur = pw.pooledS[i];
+      else {
+        CHECK_HIP(launch_maxpool(prec, cur, B, ch, cw, nblk, w.pooled, s), "dfnet train: maxpool");
+        cur = w.pooled;
+      }
       ch /= 2; cw /= 2;
     }
   }
@@ -838,19 +897,23 @@ int encoder_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, i
 }
 
 // Adaptation layer of level t on the kept tap: lvl_tmp64 = ReLU(1x1); need_z: lvl_z = plain 5x5; BatchNorm work block
-// from batch (bn_batch, optionally reported) or running statistics.
+// from batch (bn_batch, optionally reported) or running statistics.  prec 2: tap and lvl_tmp64 in the split storage, lvl_z fp32.
 int adapt_keep(dfn_dfnet_t h, int prec, int t, int B, int hh, int ww, int cin, bool bn_batch, bool need_z, const DfParamWs& pw,
                hipStream_t s, float* mean_out, float* var_out) {
+  const bool split = prec == 2;
+  const void* zeros = h->fc + zeros_offset(h->feat_dim);
   ConvArgs a{};
   a.in = pw.b.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = prec == 2 ? h->ad1[t].bias_x3 : h->ad1[t].bias; a.out_scale = h->ad1[t].out_scale;
   a.out_act = pw.lvl_tmp64[t];
   a.B = B; a.H = hh; a.W = ww; a.nblk_in = cin / 32; a.cout_blocks = 2; a.relu = 1;
+  if (split) { a.in_split = 1; a.out_split = 1; a.zeros = zeros; }
   CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet train: adapt 1x1");
   if (need_z) {
     ConvArgs z{};
     z.in = pw.lvl_tmp64[t]; z.w = h->ad5_raw[t].w[prec]; z.bias = prec == 2 ? h->ad5_raw[t].bias_x3 : h->ad5_raw[t].bias;
     z.out_scale = h->ad5_raw[t].out_scale; z.out_act = pw.lvl_z[t];
     z.B = B; z.H = hh; z.W = ww; z.nblk_in = 2; z.cout_blocks = 4; z.relu = 0;
+    if (split) { z.in_split = 1; z.zeros = zeros; }
     CHECK_HIP(launch_conv(prec, 5, 16, z, s), "dfnet train: adapt 5x5");
   }
   if (bn_batch)
@@ -858,6 +921,162 @@ int adapt_keep(dfn_dfnet_t h, int prec, int t, int B, int hh, int ww, int cin, b
               "dfnet train: BatchNorm batch statistics");
   else
     CHECK_HIP(launch_bn_running_stats(h->bn_dev[t], 1e-5f, pw.lvl_bn[t], s), "dfnet train: BatchNorm running statistics");
+  return DFN_OK;
+}
+
+// The backward of backward_params_core on the SPLIT storage (prec 2, the default): every gradient w.r.t. a conv's pre-activation is
+// written once by gate_split_kernel — ReLU gate, max-pool routing and the tap's gradient in one pass — as the hi | lo f16 operand
+// planes that BOTH consumers multiply: the data-gradient conv (conv_x3s_kernel: LDS-DMA staged, no conversion) and the
+// weight-gradient stream (dfnet_wgrad_s.hip: no conversion, bias gradient as an extra column).  Its power-of-two operand scale comes
+// from the |max| word the PRODUCER of the incoming gradient left behind (a conv epilogue's atomicMax, pw.amax), so no extra pass
+// measures anything.  The old chain wrote fp32, measured it, and re-split it per (block pair, kernel row) in every consumer.
+int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, const float* grad_pose, const float* grad_features, int upH,
+                          int upW, int level_mask, int bn_batch, int have_forward, float* const* grads, const DfParamWs& pw,
+                          const int* lay_h, const int* lay_w, hipStream_t s, const char* fn) {
+  constexpr int prec = 2;
+  const DfBwdWs& w = pw.b;
+  const int n_enc = int(h->enc.size());
+  const int per_tap = bn_batch ? 6 : 4;
+  const void* zeros = h->fc + zeros_offset(h->feat_dim);
+  if (int rc = ensure_side(h)) return rc;
+  hipStream_t side = h->side;
+  SideJoin side_join{h, s, true};
+  char* gbuf[3] = {w.gA, w.gB, pw.gC};
+  bool side_reads[3] = {false, false, false};
+  int side_seq[3] = {0, 0, 0}, seq = 0;
+  auto fork_side = [&]() -> hipError_t {
+    hipError_t e = hipEventRecord(h->ev_fork, s);
+    return e != hipSuccess ? e : hipStreamWaitEvent(side, h->ev_fork, 0);
+  };
+  auto side_done_with = [&](int k) -> hipError_t {
+    if (k < 0 || !side_reads[k]) return hipSuccess;
+    side_reads[k] = false;
+    return hipStreamWaitEvent(s, h->ev_buf[k], 0);
+  };
+  auto join_side = [&]() -> hipError_t {
+    hipError_t e = hipEventRecord(h->ev_join, side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, h->ev_join, 0);
+    side_reads[0] = side_reads[1] = side_reads[2] = false;
+    return e;
+  };
+  auto pick_out = [&](int not_a, int not_b) {
+    int k = -1;
+    for (int c = 0; c < 3; ++c) {
+      if (c == not_a || c == not_b) continue;
+      if (k < 0 || (side_reads[k] && (!side_reads[c] || side_seq[c] < side_seq[k]))) k = c;
+    }
+    return k;
+  };
+  // |max| words: [i] = bound of the gradient w.r.t. conv i's (pooled) output, [16 + 4 t + {0, 1, 2}] = level t's d z, g64, g tap
+  CHECK_HIP(hipMemsetAsync(pw.amax, 0, 64 * sizeof(unsigned), s), "dfnet params: clear |max| words");
+  CHECK_HIP(fork_side(), "dfnet params: side stream");
+  int act_idx = -1, last = -1;
+  bool g_pooled = false;   // the gradient in gbuf[act_idx] is w.r.t. the POOLED output of conv i
+  if (grad_pose) {
+    if (lay_h[n_enc - 1] < 2 || lay_w[n_enc - 1] < 2) return set_error(DFN_ERR_ARG, "%s: image too small for pool5", fn);
+    CHECK_HIP(launch_pose_head_backward(reinterpret_cast<const float*>(w.act[n_enc - 1]), B, lay_h[n_enc - 1], lay_w[n_enc - 1], h->fc,
+                                        grad_pose, h->feat_dim, pw.pooled, reinterpret_cast<float*>(gbuf[0]), grads[2 * n_enc],
+                                        grads[2 * n_enc + 1], s, pw.amax + (n_enc - 1)),
+              "dfnet params: pose head");
+    act_idx = 0;
+    last = n_enc - 1;
+  } else {
+    CHECK_HIP(hipMemsetAsync(grads[2 * n_enc], 0, size_t(h->feat_dim) * 512 * 4, s), "dfnet params: zero fc gradient");
+    CHECK_HIP(hipMemsetAsync(grads[2 * n_enc + 1], 0, size_t(h->feat_dim) * 4, s), "dfnet params: zero fc gradient");
+    for (int i = 0; i < n_enc; ++i)
+      if (h->enc[i].tap >= 0 && (level_mask >> h->enc[i].tap & 1)) last = i;
+    for (int i = last + 1; i < n_enc; ++i) {
+      CHECK_HIP(hipMemsetAsync(grads[2 * i], 0, size_t(h->enc[i].cout) * h->enc[i].cin * 9 * 4, s), "dfnet params: zero");
+      CHECK_HIP(hipMemsetAsync(grads[2 * i + 1], 0, size_t(h->enc[i].cout) * 4, s), "dfnet params: zero");
+    }
+  }
+  const size_t plane = size_t(128) * upH * upW;
+  for (int i = last; i >= 0; --i) {
+    const ConvSpec& sp = h->enc[i];
+    const int hh = lay_h[i], ww = lay_w[i];
+    const float* g_tap = nullptr;
+    const unsigned* am_tap = nullptr;
+    if (sp.tap >= 0 && (level_mask >> sp.tap & 1)) {
+      const int t = sp.tap;
+      float* const* ag = grads + 2 * n_enc + 2 + per_tap * t;
+      const long long Q = (long long)B * hh * ww;
+      unsigned* am = pw.amax + 16 + 4 * t;
+      float* sl128 = pw.scl_lvl + 16 * t, * sl64 = sl128 + 8;
+      CHECK_HIP(join_side(), "dfnet params: side stream");   // this block's weight gradients use pw.part on the chain's stream
+      if (!have_forward)
+        if (int rc = adapt_keep(h, prec, t, B, hh, ww, sp.cout, bn_batch != 0, bn_batch != 0, pw, s, nullptr, nullptr)) return rc;
+      CHECK_HIP(launch_upsample_backward(1, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s),
+                "dfnet params: upsample backward");
+      // BatchNorm backward: d L/d y -> d L/d z (z = the plain 5x5 output), in place; leaves max |d z| behind
+      CHECK_HIP(launch_bn_backward(bn_batch, reinterpret_cast<float*>(w.g128), pw.lvl_z[t], Q, pw.bn_part, pw.lvl_bn[t], bn_batch ? ag[4] : nullptr,
+                                   bn_batch ? ag[5] : nullptr, s, am),
+                "dfnet params: BatchNorm backward");
+      CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g128), 0, nullptr, 0, nullptr, B, hh, ww, 4, am, nullptr, pw.g128S, 1, sl128, s),
+                "dfnet params: split d z");
+      CHECK_HIP(launch_conv_wgrad_split(5, pw.g128S, pw.lvl_tmp64[t], zeros, B, hh, ww, 128, 64, pw.part, pw.part_floats, pw.part_b,
+                                        pw.part_b_floats, ag[2], ag[3], sl128, s),
+                "dfnet params: adapt 5x5 weight gradient");
+      ConvArgs c{};
+      const PackedConv& d5 = h->ad5_raw_dgrad[t];
+      c.in = pw.g128S; c.w = d5.w[prec]; c.bias = d5.bias; c.out_scale = d5.out_scale; c.out_pre = w.g64;
+      c.in_split = 1; c.zeros = zeros; c.dyn_scale = sl128; c.absmax_out = am + 1;
+      c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
+      CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet params: adapt 5x5 dgrad");
+      // ReLU gate of the 1x1's output into the split storage (w.tmp64 is free: the kept 1x1 output lives in pw.lvl_tmp64)
+      CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g64), 0, pw.lvl_tmp64[t], 1, nullptr, B, hh, ww, 2, am + 1, nullptr, w.tmp64, 1,
+                                  sl64, s),
+                "dfnet params: adapt gate");
+      CHECK_HIP(launch_conv_wgrad_split(1, w.tmp64, w.tap[t], zeros, B, hh, ww, 64, sp.cout, pw.part, pw.part_floats, pw.part_b,
+                                        pw.part_b_floats, ag[0], ag[1], sl64, s),
+                "dfnet params: adapt 1x1 weight gradient");
+      ConvArgs d{};
+      d.in = w.tmp64; d.w = h->ad1_dgrad[t].w[prec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
+      d.in_split = 1; d.zeros = zeros; d.dyn_scale = sl64; d.absmax_out = am + 2;
+      d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
+      CHECK_HIP(launch_conv(prec, 1, 16, d, s), "dfnet params: adapt 1x1 dgrad");
+      g_tap = reinterpret_cast<const float*>(w.gtap);
+      am_tap = am + 2;
+      CHECK_HIP(fork_side(), "dfnet params: side stream");   // pw.part is the side stream's again, after this block's weight gradients
+    }
+    // ---- gate: gradient w.r.t. conv i's pre-activation, split (fp32 for conv1_1, whose weight gradient gathers from fp32)
+    const int pre_idx = pick_out(act_idx, -1);
+    CHECK_HIP(side_done_with(pre_idx), "dfnet params: side stream");
+    float* slot = pw.scl_layer + 8 * i;
+    const bool act_is_split = i + 1 < n_enc;
+    CHECK_HIP(launch_gate_split(act_idx < 0 ? nullptr : reinterpret_cast<const float*>(gbuf[act_idx]), g_pooled ? 1 : 0, w.act[i], act_is_split,
+                                g_tap, B, hh, ww, sp.cout / 32, act_idx < 0 ? nullptr : pw.amax + i, am_tap, gbuf[pre_idx], i > 0, slot, s),
+              "dfnet params: gate");
+    // ---- side stream: weight + bias gradient of conv i
+    CHECK_HIP(fork_side(), "dfnet params: side stream");
+    if (i == 0) {
+      const float* g_pre = reinterpret_cast<const float*>(gbuf[pre_idx]);
+      CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, pw.part, pw.part_floats, grads[1], side), "dfnet params: bias gradient");
+      CHECK_HIP(launch_conv0_wgrad(g_pre, reinterpret_cast<const float*>(w.prep), B, hh, ww, 2 * prep_sb(prec), pw.part, pw.part_floats,
+                                   grads[0], side, slot),
+                "dfnet params: conv1_1 weight gradient");
+      break;
+    }
+    const void* input = h->enc[i - 1].pool_after ? pw.pooledS[i - 1] : w.act[i - 1];
+    CHECK_HIP(launch_conv_wgrad_split(3, gbuf[pre_idx], input, zeros, B, hh, ww, sp.cout, sp.cin, pw.part, pw.part_floats, pw.part_b,
+                                      pw.part_b_floats, grads[2 * i], grads[2 * i + 1], slot, side),
+              "dfnet params: conv weight gradient");
+    CHECK_HIP(hipEventRecord(h->ev_buf[pre_idx], side), "dfnet params: side stream");
+    side_reads[pre_idx] = true;
+    side_seq[pre_idx] = ++seq;
+    // ---- the chain: data gradient of conv i (w.r.t. its input: conv i-1's output, pooled if a max-pool sits between)
+    const int in_idx = pick_out(pre_idx, -1);
+    CHECK_HIP(side_done_with(in_idx), "dfnet params: side stream");
+    ConvArgs e{};
+    e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[prec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale;
+    e.out_pre = gbuf[in_idx];
+    e.in_split = 1; e.zeros = zeros; e.dyn_scale = slot; e.absmax_out = pw.amax + (i - 1);
+    e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = ((sp.cin + 63) / 64 * 64) / 32; e.relu = 0;
+    CHECK_HIP(launch_conv(prec, 3, 16, e, s), "dfnet params: encoder conv dgrad");
+    act_idx = in_idx;
+    g_pooled = h->enc[i - 1].pool_after;
+  }
+  side_join.armed = false;
+  CHECK_HIP(join_side(), "dfnet params: side stream");
   return DFN_OK;
 }
 
@@ -901,7 +1120,10 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
     // forward recompute, keeping every activation (and the pre-ReLU taps of the levels that carry gradient)
     if (int rc = encoder_keep(h, prec, x, B, H, W, level_mask, pw, s, lay_h, lay_w)) return rc;
   }
-  // Three gradient buffers and the handle's side stream: a layer's bias gradient, the re-pooled conv input and its weight gradient
+  if (prec == 2)
+    return backward_params_split(h, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, bn_batch, have_forward, grads, pw, lay_h, lay_w,
+                                 s, fn);
+  // (exact fp32) Three gradient buffers and the handle's side stream: a layer's bias gradient, the re-pooled conv input and its weight gradient
   // read the gated gradient g_pre(i) and nothing the data-gradient chain waits for, so they run on the side stream beside the
   // data-gradient conv of the same and of the next layer (small grids at training resolutions: both leave CUs idle).  The chain
   // picks its output buffers among those the side stream is done with (ev_buf[k] = its last read of buffer k); pw.part and w.pooled

@@ -120,17 +120,25 @@ hipError_t launch_bn_running_stats(const float* bn, float eps, float* bw, hipStr
 // d L/d z in place of g (blocked [Q,128]).  batch: sc * (g - mg - xhat * mgx); frozen: sc * g.
 template <bool BATCH>
 __global__ __launch_bounds__(256) void bn_backward_kernel(float* __restrict__ g, const float* __restrict__ z,
-                                                          const float* __restrict__ bw, size_t n) {
+                                                          const float* __restrict__ bw, size_t n, unsigned* __restrict__ absmax_out) {
+  float m = 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int p = int(i & 127);
     float v = g[i];
     if (BATCH) v = v - bw[kBnMg + p] - (z[i] - bw[kBnMean + p]) * bw[kBnRstd + p] * bw[kBnMgx + p];
-    g[i] = v * bw[kBnSc + p];
+    v *= bw[kBnSc + p];
+    g[i] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  if (absmax_out) {   // max |d L / d z| for the split of this tensor (gate_split): one atomicMax per wave on the float's bit pattern
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax_out, __float_as_uint(m));
   }
 }
 
 hipError_t launch_bn_backward(int batch, float* g, const float* z, long long Q, double* part, float* bw, float* dgamma, float* dbeta,
-                              hipStream_t s) {
+                              hipStream_t s, unsigned* absmax_out) {
   const size_t n = (size_t)Q * 128;
   if (!n) return hipSuccess;
   const int grid = int((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
@@ -138,9 +146,9 @@ hipError_t launch_bn_backward(int batch, float* g, const float* z, long long Q, 
     const int nc = chunks_for(Q);
     hipLaunchKernelGGL(bn_moments_kernel<1>, dim3(nc), dim3(256), 0, s, g, z, bw, Q, nc, part);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(1), dim3(1024), 0, s, part, nc, Q, nullptr, 0.f, bw, dgamma, dbeta);
-    hipLaunchKernelGGL(bn_backward_kernel<true>, dim3(grid), dim3(256), 0, s, g, z, bw, n);
+    hipLaunchKernelGGL(bn_backward_kernel<true>, dim3(grid), dim3(256), 0, s, g, z, bw, n, absmax_out);
   } else {
-    hipLaunchKernelGGL(bn_backward_kernel<false>, dim3(grid), dim3(256), 0, s, g, z, bw, n);
+    hipLaunchKernelGGL(bn_backward_kernel<false>, dim3(grid), dim3(256), 0, s, g, z, bw, n, absmax_out);
   }
   return hipGetLastError();
 }

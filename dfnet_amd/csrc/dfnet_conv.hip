@@ -312,6 +312,24 @@ DFN_DEV_INLINE void x3_epilogue(const ConvArgs& a, const f32x16 (&acc)[MB][2], f
   // requests per instruction (measured: a fifth of the kernel's time).  Each wave therefore turns its output rows
   // through LDS — the staging buffers are dead by now — and stores whole lines, eight lanes per line.
   constexpr int ROWB = MB * 128 + 16;                 // padded bytes per pixel in the turn buffer
+  if (a.absmax_out) {
+    // max |output| over the pixels of the image (tile padding excluded): one atomicMax per wave on the float's bit pattern
+    float m = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int y = y0 + (2 * wave + nb) * RF + pr, x = x0 + pc;
+      if (y < a.H && x < a.W) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[mb][nb][r]));
+      }
+    }
+    m *= fabsf(out_scale);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if (lane == 0 && m > 0.f) atomicMax(a.absmax_out, __float_as_uint(m));
+  }
   if (a.out_nchw) store_nchw<MB, float, RF>(a, acc, out_scale, b, cg, y0 + 2 * wave * RF + pr, x0 + pc, h);
   if constexpr (MB == 2) {
     if (a.fuse_out) {
@@ -779,7 +797,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
     const int q = min(wave + i * WAVES, NP - 1) * 1024;
     conv_lds_dma_b128(a.w + ((size_t)cg * n_slices + packed) * WSL + lane * 16 + q, wst + buf * WSL + q);
   };
-  const float out_scale = a.out_scale;
+  // a gradient tensor was stored at its own measured power-of-two scale (dyn_scale[0]) instead of kConvActScale: undo that one
+  const float out_scale = a.dyn_scale ? a.out_scale * kConvActScale * a.dyn_scale[1] : a.out_scale;
   CONV_T_DECL;
 #pragma unroll
   for (int i = 0; i < PPP; ++i) patch_piece(0, i);
@@ -900,7 +919,7 @@ static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
 
 template <int KS, int SB, int MB, int WAVES = 4, int TW = 32, bool SPREAD = true, int RING = 2>
 static hipError_t launch_conv_x3s_t(const ConvArgs& a, hipStream_t stream) {
-  if (a.cout_blocks % MB || !a.zeros || a.dyn_scale) return hipErrorInvalidValue;
+  if (a.cout_blocks % MB || !a.zeros) return hipErrorInvalidValue;
   constexpr int TH = 2 * WAVES * (32 / TW);
   constexpr int lds = 2 * x3s_patch_bytes<KS, SB, WAVES, TW>() + RING * x3_wslice_bytes<KS, SB, MB>();
   static_assert(lds <= (WAVES == 4 ? 80 : 160) * 1024, "x3s conv tile does not fit in LDS (4-wave tiles: two workgroups per CU)");

@@ -118,6 +118,150 @@ hipError_t launch_maxpool_backward(int prec, const void* act, const void* g, int
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ gate into the split storage
+// The backward chain of the split-f16 training path (dfnet_api.hip: backward_params_core): the gradient w.r.t. a conv's
+// pre-activation is written ONCE, already split into the hi | lo f16 planes that both of its consumers multiply — the data-gradient
+// conv (conv_x3s_kernel, LDS-DMA staged) and the weight-gradient stream (dfnet_wgrad_s.hip) — in the row-planar order of
+// dfnet_conv.hip (split_piece):
+//     out = split(2^k * ((act > 0 ? route(g) : 0) + add))
+//   g     fp32 blocked [B, H, W, nblk, 32], or with POOL [B, H/2, W/2, nblk, 32]: the gradient w.r.t. the 2x2 max-pooled activation,
+//         routed to the FIRST maximum of each window in row-major order (torch's max_pool2d_with_indices), zero elsewhere;
+//   act   the conv's ReLU'd output at [B, H, W]: split storage (ACT_SPLIT) or fp32 blocked; null = no gate;
+//   add   fp32 blocked [B, H, W, nblk, 32] or null (the hypercolumn tap's gradient joining the trunk);
+//   2^k   from the bounds the producers left behind: absmax_g / absmax_add = bit patterns of max |g|, max |add| (upper bounds are
+//         fine: 2^k * (|g|max + |add|max) lands in [2^10, 2^11), a factor 32 under the f16 range); [2^k, 2^-k] goes to scale_out.
+// OUT_SPLIT = false writes fp32 blocked instead (conv1_1's weight gradient gathers RGB taps from an fp32 tensor).
+// A thread owns 8 consecutive stored positions of one pixel: one 16-byte hi piece and one 16-byte lo piece.
+namespace {
+__device__ __forceinline__ float pow2_scale(const unsigned* absmax_g, const unsigned* absmax_add, float* inv) {
+  float u = absmax_g ? __uint_as_float(*absmax_g) : 0.f;
+  if (absmax_add) u += __uint_as_float(*absmax_add);
+  int k = 0;
+  if (u > 0.f && u < 3.0e38f) {
+    int e;
+    frexpf(u, &e);           // u = f * 2^e, f in [0.5, 1)
+    k = 11 - e;              // u * 2^k in [2^10, 2^11)
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+  }
+  *inv = ldexpf(1.f, -k);
+  return ldexpf(1.f, k);
+}
+struct Piece8 { f32x4 a, b; };
+// the 8 values (stored positions 16 h + 8 kc + 0..7 of block blk) of pixel (row, x) of a split tensor, hi + lo, unscaled by `inv`
+__device__ __forceinline__ Piece8 load_split8(const char* t, size_t row, int W, int nblk, int blk, int kc, int h, int x, float inv) {
+  const char* p = t + ((((row * nblk + blk) * 2 + kc) * 4 + h) * W + x) * 16;
+  const half8 hi = *reinterpret_cast<const half8*>(p), lo = *reinterpret_cast<const half8*>(p + 2 * (size_t)W * 16);
+  Piece8 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { r.a[k] = ((float)hi[k] + (float)lo[k]) * inv; r.b[k] = ((float)hi[4 + k] + (float)lo[4 + k]) * inv; }
+  return r;
+}
+__device__ __forceinline__ Piece8 load_f32x8(const float* t, size_t pix, int nblk, int blk, int kc, int h) {
+  const float* p = t + (pix * nblk + blk) * 32 + 16 * h + 8 * kc;
+  return Piece8{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
+}
+}  // namespace
+
+template <bool POOL, bool ACT_SPLIT, bool OUT_SPLIT>
+__global__ __launch_bounds__(256) void gate_split_kernel(const float* __restrict__ g, const void* __restrict__ act, const float* __restrict__ add,
+                                                         int B, int H, int W, int nblk, const unsigned* __restrict__ absmax_g,
+                                                         const unsigned* __restrict__ absmax_add, void* __restrict__ out,
+                                                         float* __restrict__ scale_out) {
+  float inv;
+  const float sc = pow2_scale(absmax_g, absmax_add, &inv);
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = sc; scale_out[1] = inv; }
+  const int Ho = H >> 1, Wo = W >> 1;
+  const size_t n = (size_t)B * H * nblk * W * 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    // i = ((row * nblk + blk) * W + x) * 4 + hk: a wave covers 16 pixels x the 4 (K-chunk, half) parts of one block — 2 KB of
+    // contiguous fp32 reads, four 256-byte runs of split writes
+    const int hk = int(i & 3), kc = hk >> 1, h = hk & 1;
+    size_t r = i >> 2;
+    const int x = int(r % W); r /= W;
+    const int blk = int(r % nblk);
+    const size_t row = r / nblk;
+    const int y = int(row % H);
+    const size_t b = row / H;
+    Piece8 v{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (g) {
+      if (!POOL) {
+        v = load_f32x8(g, row * W + x, nblk, blk, kc, h);
+        if (act) {
+          const Piece8 a = ACT_SPLIT ? load_split8(static_cast<const char*>(act), row, W, nblk, blk, kc, h, x, 1.f)
+                                     : load_f32x8(static_cast<const float*>(act), row * W + x, nblk, blk, kc, h);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v.a[k] = a.a[k] > 0.f ? v.a[k] : 0.f; v.b[k] = a.b[k] > 0.f ? v.b[k] : 0.f; }
+        }
+      } else {
+        const int yo = y >> 1, xo = x >> 1;
+        if (yo < Ho && xo < Wo) {
+          const Piece8 gp = load_f32x8(g, (b * Ho + yo) * (size_t)Wo + xo, nblk, blk, kc, h);
+          Piece8 a[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const size_t rq = b * H + 2 * yo + (q >> 1);
+            const int xq = 2 * xo + (q & 1);
+            a[q] = ACT_SPLIT ? load_split8(static_cast<const char*>(act), rq, W, nblk, blk, kc, h, xq, 1.f)
+                             : load_f32x8(static_cast<const float*>(act), rq * W + xq, nblk, blk, kc, h);
+          }
+          const int me = (y & 1) * 2 + (x & 1);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float a0 = k < 4 ? a[0].a[k] : a[0].b[k - 4], a1 = k < 4 ? a[1].a[k] : a[1].b[k - 4];
+            const float a2 = k < 4 ? a[2].a[k] : a[2].b[k - 4], a3 = k < 4 ? a[3].a[k] : a[3].b[k - 4];
+            const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+            const int first = a0 == m ? 0 : (a1 == m ? 1 : (a2 == m ? 2 : 3));
+            const float mine = me == 0 ? a0 : (me == 1 ? a1 : (me == 2 ? a2 : a3));
+            const float gv = k < 4 ? gp.a[k] : gp.b[k - 4];
+            const float o = (first == me && mine > 0.f) ? gv : 0.f;   // the window's first maximum, gated by ReLU'(act)
+            if (k < 4) v.a[k] = o; else v.b[k - 4] = o;
+          }
+        }
+      }
+    }
+    if (add) {
+      const Piece8 t = load_f32x8(add, row * W + x, nblk, blk, kc, h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v.a[k] += t.a[k]; v.b[k] += t.b[k]; }
+    }
+    if (OUT_SPLIT) {
+      half8 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xs = (k < 4 ? v.a[k] : v.b[k - 4]) * sc;
+        hi[k] = (_Float16)fminf(fmaxf(xs, -65000.f), 65000.f);
+        lo[k] = (_Float16)fminf(fmaxf(xs - (float)hi[k], -65000.f), 65000.f);
+      }
+      char* d = static_cast<char*>(out) + ((((row * nblk + blk) * 2 + kc) * 4 + h) * W + x) * 16;
+      *reinterpret_cast<half8*>(d) = hi;
+      *reinterpret_cast<half8*>(d + 2 * (size_t)W * 16) = lo;
+    } else {
+      float* d = static_cast<float*>(out) + ((row * W + x) * nblk + blk) * 32 + 16 * h + 8 * kc;
+      *reinterpret_cast<f32x4*>(d) = v.a;
+      *reinterpret_cast<f32x4*>(d + 4) = v.b;
+    }
+  }
+}
+
+hipError_t launch_gate_split(const float* g, int pooled_g, const void* act, int act_split, const float* add, int B, int H, int W, int nblk,
+                             const unsigned* absmax_g, const unsigned* absmax_add, void* out, int out_split, float* scale_out,
+                             hipStream_t s) {
+  const size_t n = (size_t)B * H * nblk * W * 4;
+  if (!n) return hipSuccess;
+  if (pooled_g && !act) return hipErrorInvalidValue;
+  const dim3 grid(grid_of(n)), block(256);
+#define DFN_GS(P, A, O) hipLaunchKernelGGL((gate_split_kernel<P, A, O>), grid, block, 0, s, g, act, add, B, H, W, nblk, absmax_g, absmax_add, out, scale_out)
+  if (pooled_g) {
+    if (act_split) { if (out_split) DFN_GS(true, true, true); else DFN_GS(true, true, false); }
+    else { if (out_split) DFN_GS(true, false, true); else DFN_GS(true, false, false); }
+  } else {
+    if (act_split) { if (out_split) DFN_GS(false, true, true); else DFN_GS(false, true, false); }
+    else { if (out_split) DFN_GS(false, false, true); else DFN_GS(false, false, false); }
+  }
+#undef DFN_GS
+  return hipGetLastError();
+}
+
 // Adjoint of upsample_kernel (bilinear, align_corners=True): g_up fp32 NCHW planes [b*bstride + c*UH*UW + Y*UW + X]
 // -> blocked [B,h,w,4,32] T.  Gather form (deterministic): an input pixel collects from every output pixel whose
 // two source rows / columns include it, with exactly the weights the forward kernel used.

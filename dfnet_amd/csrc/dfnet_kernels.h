@@ -55,6 +55,9 @@ struct ConvArgs {
   size_t nchw_group_stride;
   const float* dyn_scale;  // prec 2, optional: device [scale, 1/scale] of the INPUT tensor (launch_absmax_scale) replacing
                            // the fixed x16 activation scale — gradient tensors have no a-priori magnitude
+  // prec 2, optional: device word that receives max |output| over the image's pixels (unsigned atomicMax on the bit pattern of
+  // the non-negative float; the caller zeroes it).  A data-gradient conv leaves the bound its consumer's split needs (gate_split).
+  unsigned* absmax_out;
 };
 
 // prec: 0 = f16 MFMA inputs / fp32 accumulate, 1 = exact fp32 MFMA, 2 = split-f16 (hi/lo operands, three f16 MFMAs
@@ -92,8 +95,9 @@ hipError_t launch_bn_batch_stats(const float* z, long long Q, const float* bn, f
                                  float* var_out, hipStream_t s);
 hipError_t launch_bn_running_stats(const float* bn, float eps, float* bw, hipStream_t s);
 // g (d L/d y, blocked) -> d L/d z in place; batch != 0 also writes d gamma, d beta [128] (channel order).
+// absmax_out (optional): device word receiving max |d L / d z| (atomicMax on the bit pattern; the caller zeroes it)
 hipError_t launch_bn_backward(int batch, float* g, const float* z, long long Q, double* part, float* bw, float* dgamma, float* dbeta,
-                              hipStream_t s);
+                              hipStream_t s, unsigned* absmax_out = nullptr);
 // pose head: relu'd conv5_3 activations [B,h,w,16,32] -> maxpool2 -> global mean -> fc [feat_dim,512].
 hipError_t launch_pose_head(int prec, const void* act, int B, int h, int w, const float* fc_w, const float* fc_b,
                             int feat_dim, float* pose, hipStream_t stream);
@@ -105,6 +109,11 @@ hipError_t launch_relu_gate(int prec, const void* g, const void* act, const void
 // act [B,H,W,nblk*32] pre-pool, g [B,H/2,W/2,...] -> out [B,H,W,...]: gradient to the first maximum of each window.
 hipError_t launch_maxpool_backward(int prec, const void* act, const void* g, int B, int H, int W, int nblk, void* out,
                                    hipStream_t s);
+// ReLU gate (+ max-pool routing, + tap gradient) of the split-f16 training chain, written straight into the split storage at a
+// power-of-two scale derived from the producers' |max| bounds (dfnet_grad.hip: gate_split_kernel); scale_out = [2^k, 2^-k].
+hipError_t launch_gate_split(const float* g, int pooled_g, const void* act, int act_split, const float* add, int B, int H, int W, int nblk,
+                             const unsigned* absmax_g, const unsigned* absmax_add, void* out, int out_split, float* scale_out,
+                             hipStream_t s);
 // adjoint of launch_upsample: fp32 NCHW planes gup[b*bstride + c*UH*UW + ...] -> blocked [B,h,w,4,32].
 hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, int B, int h, int w, int UH, int UW, void* out,
                                     hipStream_t s);
@@ -123,8 +132,10 @@ hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int
                               float* dW, hipStream_t s, const float* gscale = nullptr);
 hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* part, size_t part_floats, float* db, hipStream_t s);
 // pose head: relu5_3 activations + d pose -> pooled [B,512] (scratch), gradient w.r.t. the activations, fc gradients.
+// absmax_out (optional): device word that receives a bound of max |gact| (atomicMax on the float's bit pattern; caller zeroes it)
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
-                                     float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s);
+                                     float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s,
+                                     unsigned* absmax_out = nullptr);
 
 // --- weight gradients over PRE-SPLIT operands (dfnet_wgrad_s.hip): g / in in the split row-planar storage of dfnet_conv.hip
 // (hi | lo f16 planes; g scaled by gscale[0], in by kConvActScale), cout and cin multiples of 64, ks in {1, 3, 5}.  db may be null.

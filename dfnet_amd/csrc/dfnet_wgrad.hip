@@ -646,7 +646,8 @@ hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float
 // pixel's share d_pooled[ch] / (ho wo) goes to the FIRST maximum of its window (torch's max-pool routing).
 __global__ __launch_bounds__(512) void pose_head_backward_kernel(const float* __restrict__ act, int h, int w, const float* __restrict__ fc_w,
                                                                  const float* __restrict__ gpose, int feat_dim,
-                                                                 float* __restrict__ pooled_out, float* __restrict__ gact) {
+                                                                 float* __restrict__ pooled_out, float* __restrict__ gact,
+                                                                 unsigned* __restrict__ absmax_out) {
   const int cpos = threadIdx.x;   // stored position 0..511
   const size_t b = blockIdx.x;
   const int ho = h / 2, wo = w / 2;
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(512) void pose_head_backward_kernel(const float* __
   float dp = 0.f;
   for (int o = 0; o < feat_dim; ++o) dp += gpose[b * feat_dim + o] * fc_w[o * 512 + ch];
   dp /= float(ho * wo);
+  if (absmax_out && dp != 0.f) atomicMax(absmax_out, __float_as_uint(fabsf(dp)));   // bound of |gact| for the split of the gated gradient
   float sum = 0.f;
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {
@@ -681,8 +683,8 @@ __global__ __launch_bounds__(512) void fc_grad_kernel(const float* __restrict__ 
   if (ch == 0) db[o] = sb;
 }
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
-                                     float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s) {
-  hipLaunchKernelGGL(pose_head_backward_kernel, dim3(B), dim3(512), 0, s, act, h, w, fc_w, gpose, feat_dim, pooled, gact);
+                                     float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s, unsigned* absmax_out) {
+  hipLaunchKernelGGL(pose_head_backward_kernel, dim3(B), dim3(512), 0, s, act, h, w, fc_w, gpose, feat_dim, pooled, gact, absmax_out);
   hipLaunchKernelGGL(fc_grad_kernel, dim3(feat_dim), dim3(512), 0, s, gpose, pooled, B, feat_dim, dW_fc, db_fc);
   return hipGetLastError();
 }
