@@ -1365,7 +1365,7 @@ namespace {
 // Re-pack one convolution (forward fragments and data-gradient fragments, all three arithmetic modes) from device fp32
 // master weights; the split-f16 weight scales are kept from dfn_dfnet_commit.
 int refresh_conv(PackedConv& f, PackedConv& d, const float* wt, const float* bias, int cout, int cin, int ks, bool first, int prec_mask,
-                 hipStream_t s) {
+                 std::vector<PackJob>& jobs) {
   const float wscale = 1.f / (f.out_scale * kConvActScale);
   const int cop = (cin + 63) / 64 * 64;
   const float dscale = 1.f / (d.out_scale * kConvActScale);
@@ -1373,12 +1373,12 @@ int refresh_conv(PackedConv& f, PackedConv& d, const float* wt, const float* bia
     if (!((prec_mask >> prec) & 1)) continue;
     const int sb = first ? prep_sb(prec) : 16;
     const int mbf = prec == 2 ? 2 : conv_mb(prec, cout / 32);
-    CHECK_HIP(launch_pack_conv(prec, wt, cout, cin, ks, first, sb, mbf, 0, cout, cin, wscale, f.w[prec], s), "refresh: forward pack");
+    jobs.push_back(PackJob{wt, f.w[prec], PackGeom{cout, cin, ks, first ? 1 : 0, sb, mbf, 0, cout, cin, wscale}, prec, 0});
     const int mbd = prec == 2 ? 2 : conv_mb(prec, cop / 32);
-    CHECK_HIP(launch_pack_conv(prec, wt, cop, cout, ks, 0, 16, mbd, 1, cout, cin, dscale, d.w[prec], s), "refresh: dgrad pack");
+    jobs.push_back(PackJob{wt, d.w[prec], PackGeom{cop, cout, ks, 0, 16, mbd, 1, cout, cin, dscale}, prec, 0});
   }
-  CHECK_HIP(launch_pack_bias(bias, cout, 1.f, f.bias, s), "refresh: bias");
-  CHECK_HIP(launch_pack_bias(bias, cout, wscale * kConvActScale, f.bias_x3, s), "refresh: bias (split-f16)");
+  jobs.push_back(PackJob{bias, f.bias, PackGeom{cout, 0, 0, 0, 0, 0, 0, 0, 0, 1.f}, 0, 1});
+  jobs.push_back(PackJob{bias, f.bias_x3, PackGeom{cout, 0, 0, 0, 0, 0, 0, 0, 0, wscale * kConvActScale}, 0, 1});
   return DFN_OK;
 }
 
@@ -1391,10 +1391,19 @@ int refresh_core(dfn_dfnet_t h, const float* const* params, int n_params, bool w
   if (prec_mask < 1 || prec_mask > 7) return set_error(DFN_ERR_ARG, "%s: prec_mask must select at least one of the three precisions", fn);
   for (int i = 0; i < n_params; ++i)
     if (!params[i]) return set_error(DFN_ERR_ARG, "%s: null pointer %d", fn, i);
+  // every tensor's fragments in a few multi-tensor launches (launch_pack_multi) instead of four launches per convolution
+  std::vector<PackJob> jobs;
   for (int i = 0; i < n_enc; ++i) {
     const ConvSpec& sp = h->enc[i];
-    if (int rc = refresh_conv(h->enc_packed[i], h->enc_dgrad[i], params[2 * i], params[2 * i + 1], sp.cout, sp.cin, 3, i == 0, prec_mask, s)) return rc;
+    if (int rc = refresh_conv(h->enc_packed[i], h->enc_dgrad[i], params[2 * i], params[2 * i + 1], sp.cout, sp.cin, 3, i == 0, prec_mask, jobs)) return rc;
   }
+  if (with_adapt)
+    for (int t = 0; t < h->n_taps; ++t) {
+      const float* const* ap = params + 2 * n_enc + 2 + 8 * t;
+      if (int rc = refresh_conv(h->ad1[t], h->ad1_dgrad[t], ap[0], ap[1], 64, h->tap_channels[t], 1, false, prec_mask, jobs)) return rc;
+      if (int rc = refresh_conv(h->ad5_raw[t], h->ad5_raw_dgrad[t], ap[2], ap[3], 128, 64, 5, false, prec_mask, jobs)) return rc;
+    }
+  CHECK_HIP(launch_pack_multi(jobs.data(), int(jobs.size()), s), "refresh: multi-tensor pack");
   CHECK_HIP(hipMemcpyAsync(h->fc, params[2 * n_enc], size_t(h->feat_dim) * 512 * 4, hipMemcpyDeviceToDevice, s), "refresh: fc weight");
   CHECK_HIP(hipMemcpyAsync(h->fc + size_t(h->feat_dim) * 512, params[2 * n_enc + 1], size_t(h->feat_dim) * 4, hipMemcpyDeviceToDevice, s),
             "refresh: fc bias");
@@ -1402,8 +1411,6 @@ int refresh_core(dfn_dfnet_t h, const float* const* params, int n_params, bool w
   if (!with_adapt) return DFN_OK;
   for (int t = 0; t < h->n_taps; ++t) {
     const float* const* ap = params + 2 * n_enc + 2 + 8 * t;
-    if (int rc = refresh_conv(h->ad1[t], h->ad1_dgrad[t], ap[0], ap[1], 64, h->tap_channels[t], 1, false, prec_mask, s)) return rc;
-    if (int rc = refresh_conv(h->ad5_raw[t], h->ad5_raw_dgrad[t], ap[2], ap[3], 128, 64, 5, false, prec_mask, s)) return rc;
     for (int k = 0; k < 4; ++k)   // gamma, beta, running_mean, running_var
       CHECK_HIP(hipMemcpyAsync(h->bn_dev[t] + 128 * k, ap[4 + k], 128 * 4, hipMemcpyDeviceToDevice, s), "refresh: BatchNorm");
   }

@@ -130,10 +130,17 @@ __global__ __launch_bounds__(256) void bn_backward_kernel(float* __restrict__ g,
     g[i] = v;
     m = fmaxf(m, fabsf(v));
   }
-  if (absmax_out) {   // max |d L / d z| for the split of this tensor (gate_split): one atomicMax per wave on the float's bit pattern
+  if (absmax_out) {   // max |d L / d z| for the split of this tensor (gate_split): at most one atomicMax per workgroup on the float's
+                      // bit pattern, skipped when the word already covers it (65 536 same-address atomics cost 1.3 ms per step)
+    __shared__ float red[4];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax_out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      if (m > __uint_as_float(__hip_atomic_load(absmax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicMax(absmax_out, __float_as_uint(m));
+    }
   }
 }
 
@@ -141,7 +148,7 @@ hipError_t launch_bn_backward(int batch, float* g, const float* z, long long Q, 
                               hipStream_t s, unsigned* absmax_out) {
   const size_t n = (size_t)Q * 128;
   if (!n) return hipSuccess;
-  const int grid = int((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  const int grid = int((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   if (batch) {
     const int nc = chunks_for(Q);
     hipLaunchKernelGGL(bn_moments_kernel<1>, dim3(nc), dim3(256), 0, s, g, z, bw, Q, nc, part);

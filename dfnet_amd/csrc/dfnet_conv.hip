@@ -328,7 +328,9 @@ DFN_DEV_INLINE void x3_epilogue(const ConvArgs& a, const f32x16 (&acc)[MB][2], f
     m *= fabsf(out_scale);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-    if (lane == 0 && m > 0.f) atomicMax(a.absmax_out, __float_as_uint(m));
+    // (the word only grows: a wave whose maximum is already covered skips the atomic — thousands of same-address atomics serialise)
+    if (lane == 0 && m > __uint_as_float(__hip_atomic_load(a.absmax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+      atomicMax(a.absmax_out, __float_as_uint(m));
   }
   if (a.out_nchw) store_nchw<MB, float, RF>(a, acc, out_scale, b, cg, y0 + 2 * wave * RF + pr, x0 + pc, h);
   if constexpr (MB == 2) {

@@ -160,5 +160,10 @@ hipError_t launch_relu_gate_scale(const void* g, const void* act, const void* ad
 hipError_t launch_pack_conv(int prec, const float* w, int cout, int cin, int ks, int first, int sb, int mb, int mode, int w_cout,
                             int w_cin, float wscale, void* out, hipStream_t s);
 hipError_t launch_pack_bias(const float* b, int cout, float scale, float* out, hipStream_t s);
+// The same, many tensors per launch.  kind 0: conv fragments of precision `prec` (g as for launch_pack_conv); kind 1: bias
+// (g.cout = channels, g.wscale = scale).
+struct PackGeom { int cout, cin, ks, first, sb, mb, mode, w_cout, w_cin; float wscale; };
+struct PackJob { const float* w; void* out; PackGeom g; int prec, kind; };
+hipError_t launch_pack_multi(const PackJob* jobs, int n_jobs, hipStream_t s);
 
 }  // namespace dfn

@@ -656,7 +656,12 @@ __global__ __launch_bounds__(512) void pose_head_backward_kernel(const float* __
   float dp = 0.f;
   for (int o = 0; o < feat_dim; ++o) dp += gpose[b * feat_dim + o] * fc_w[o * 512 + ch];
   dp /= float(ho * wo);
-  if (absmax_out && dp != 0.f) atomicMax(absmax_out, __float_as_uint(fabsf(dp)));   // bound of |gact| for the split of the gated gradient
+  if (absmax_out) {   // bound of |gact| for the split of the gated gradient: one atomicMax per wave
+    float m = fabsf(dp);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax_out, __float_as_uint(m));
+  }
   float sum = 0.f;
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {
@@ -694,7 +699,6 @@ hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, cons
 // fragments (dfnet_api.hip: pack_conv / pack_conv_x3 / pack_dgrad, same index maps) without a host round trip.
 // mode 0: forward conv  w[co][ci][ky][kx];  mode 1: data-gradient conv  w'[co'][ci'][ky][kx] = w[ci'][co'][K-1-ky][K-1-kx]
 // prec 0: f16 fragments, 1: fp32 fragments, 2: split-f16 slices [hi|lo] of w * wscale.
-struct PackGeom { int cout, cin, ks, first, sb, mb, mode, w_cout, w_cin; float wscale; };
 __device__ __forceinline__ float pack_source(const float* w, const PackGeom& g, int co, int ci, int ky, int kx) {
   if (co >= g.cout || ci < 0 || ci >= g.cin) return 0.f;
   if (g.mode == 0) return w[(((size_t)co * g.w_cin + ci) * g.ks + ky) * g.ks + kx];
@@ -702,11 +706,11 @@ __device__ __forceinline__ float pack_source(const float* w, const PackGeom& g, 
   return w[(((size_t)ci * g.w_cin + co) * g.ks + (g.ks - 1 - ky)) * g.ks + (g.ks - 1 - kx)];
 }
 template <int PREC>
-__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, PackGeom g, void* __restrict__ out) {
+__device__ __forceinline__ void pack_conv_range(const float* __restrict__ w, const PackGeom& g, void* __restrict__ out, size_t first_i, size_t stride) {
   constexpr int SPC = PREC == 1 ? 1 : 8;
   const int nblk = g.first ? 1 : g.cin / 32, kcb = g.sb / SPC, groups = g.cout / 32 / g.mb;
   const size_t n = (size_t)groups * nblk * g.ks * g.mb * g.ks * kcb * 64 * SPC;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = first_i; i < n; i += stride) {
     size_t r = i;
     const int j = int(r % SPC); r /= SPC;
     const int lane = int(r % 64); r /= 64;
@@ -735,6 +739,39 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
     }
   }
 }
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, PackGeom g, void* __restrict__ out) {
+  pack_conv_range<PREC>(w, g, out, blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+// bias [cout] -> C-fragment order [cout/32][2][16], times `scale`
+__device__ __forceinline__ void pack_bias_range(const float* __restrict__ b, int cout, float scale, float* __restrict__ out, size_t first_i,
+                                                size_t stride) {
+  for (size_t i = first_i; i < (size_t)cout; i += stride) {
+    const int m = int(i >> 5), e = int(i & 31), hh = e >> 4, r = e & 15;
+    out[i] = b[32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh] * scale;
+  }
+}
+// Every tensor of a device re-pack in ONE launch (the optimizer step of a training loop re-packs 13-19 convolutions, forward and
+// data-gradient fragments, plus their biases: 50-72 small launches per step otherwise).  blockIdx.y = job.
+constexpr int kPackJobsPerLaunch = 24;
+struct PackJobs { PackJob job[kPackJobsPerLaunch]; int n; };
+__global__ __launch_bounds__(256) void pack_multi_kernel(PackJobs js) {
+  const PackJob& j = js.job[blockIdx.y];
+  const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (j.kind == 1) { pack_bias_range(j.w, j.g.cout, j.g.wscale, static_cast<float*>(j.out), i0, stride); return; }
+  if (j.prec == 0) pack_conv_range<0>(j.w, j.g, j.out, i0, stride);
+  else if (j.prec == 1) pack_conv_range<1>(j.w, j.g, j.out, i0, stride);
+  else pack_conv_range<2>(j.w, j.g, j.out, i0, stride);
+}
+hipError_t launch_pack_multi(const PackJob* jobs, int n_jobs, hipStream_t s) {
+  for (int at = 0; at < n_jobs; at += kPackJobsPerLaunch) {
+    PackJobs js{};
+    js.n = n_jobs - at < kPackJobsPerLaunch ? n_jobs - at : kPackJobsPerLaunch;
+    for (int i = 0; i < js.n; ++i) js.job[i] = jobs[at + i];
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(512, js.n), dim3(256), 0, s, js);
+  }
+  return hipGetLastError();
+}
 hipError_t launch_pack_conv(int prec, const float* w, int cout, int cin, int ks, int first, int sb, int mb, int mode, int w_cout,
                             int w_cin, float wscale, void* out, hipStream_t s) {
   const PackGeom g{cout, cin, ks, first, sb, mb, mode, w_cout, w_cin, wscale};
@@ -744,12 +781,8 @@ hipError_t launch_pack_conv(int prec, const float* w, int cout, int cin, int ks,
   else hipLaunchKernelGGL(pack_conv_kernel<2>, grid, block, 0, s, w, g, out);
   return hipGetLastError();
 }
-// bias [cout] -> C-fragment order [cout/32][2][16], times `scale`
 __global__ __launch_bounds__(256) void pack_bias_kernel(const float* __restrict__ b, int cout, float scale, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cout) return;
-  const int m = i >> 5, e = i & 31, hh = e >> 4, r = e & 15;
-  out[i] = b[32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh] * scale;
+  pack_bias_range(b, cout, scale, out, blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 hipError_t launch_pack_bias(const float* b, int cout, float scale, float* out, hipStream_t s) {
   hipLaunchKernelGGL(pack_bias_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, b, cout, scale, out);
