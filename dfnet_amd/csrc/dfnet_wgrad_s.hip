@@ -157,29 +157,38 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_s_kernel(WgradSArgs a) {
   const char* g_frame = a.g + (size_t)b_lo * a.H * g_row_bytes;
   // ring slots: input row r -> (r - rin0) mod NIN with rin0 = the first row of step 0's window; gradient row y -> (y - ya) mod NG
   const int rin0 = ya + a.ky0 - R;
-  auto dma_in_row = [&](int r) {
+  auto dma_in_piece = [&](int r, int i) {                   // piece i (compile-time after unrolling) of input row r
     const bool row_ok = r >= 0 && r < a.H;                  // rows outside the image: zeros (their products vanish)
     const char* base = in_frame + (size_t)(row_ok ? r : 0) * in_row_bytes;
     const uint32_t dst = lds_in + uint32_t((r - rin0) % G::NIN) * G::IN_ROW;
 #pragma unroll
-    for (int i = 0; i < G::PPI; ++i)
-      lds_dma_b128((row_ok && ((in_ok >> i) & 1)) ? base + in_off[i] : a.zeros, dst + min(wave + 8 * i, G::NPI - 1) * 1024);
+    for (int k = 0; k < G::PPI; ++k)
+      if (k == i) lds_dma_b128((row_ok && ((in_ok >> k) & 1)) ? base + in_off[k] : a.zeros, dst + min(wave + 8 * k, G::NPI - 1) * 1024);
   };
-  auto dma_g_row = [&](int y) {
+  auto dma_g_piece = [&](int y, int i) {
     const bool row_ok = y < yb;                             // the odd phase's row past the strip: zeros
     const char* base = g_frame + (size_t)(row_ok ? y : 0) * g_row_bytes;
     const uint32_t dst = lds_g + uint32_t((y - ya) % G::NG) * G::G_ROW;
 #pragma unroll
-    for (int i = 0; i < G::PPG; ++i)
-      lds_dma_b128((row_ok && ((g_ok >> i) & 1)) ? base + g_off[i] : a.zeros, dst + min(wave + 8 * i, G::NPG - 1) * 1024);
+    for (int k = 0; k < G::PPG; ++k)
+      if (k == i) lds_dma_b128((row_ok && ((g_ok >> k) & 1)) ? base + g_off[k] : a.zeros, dst + min(wave + 8 * k, G::NPG - 1) * 1024);
   };
-  // stage s = what step s needs beyond step s - 1: the last two rows of its input window, its two gradient rows
-  auto issue_stage = [&](int s) {
+  auto dma_in_row = [&](int r) {
+#pragma unroll
+    for (int i = 0; i < G::PPI; ++i) dma_in_piece(r, i);
+  };
+  // stage s = what step s needs beyond step s - 1: the last two rows of its input window, its two gradient rows; piece n of
+  // STAGE_DMAS: [input row A][input row B][gradient row A][gradient row B]
+  auto issue_stage_piece = [&](int s, int n) {
     const int y = ya + 2 * s;
-    dma_in_row(y + a.ky0 - R + TY - 1);
-    dma_in_row(y + a.ky0 - R + TY);
-    dma_g_row(y);
-    dma_g_row(y + 1);
+    if (n < G::PPI) dma_in_piece(y + a.ky0 - R + TY - 1, n);
+    else if (n < 2 * G::PPI) dma_in_piece(y + a.ky0 - R + TY, n - G::PPI);
+    else if (n < 2 * G::PPI + G::PPG) dma_g_piece(y, n - 2 * G::PPI);
+    else dma_g_piece(y + 1, n - 2 * G::PPI - G::PPG);
+  };
+  auto issue_stage = [&](int s) {
+#pragma unroll
+    for (int n = 0; n < G::STAGE_DMAS; ++n) issue_stage_piece(s, n);
   };
   f32x16 acc[TAPS], acc_b;
 #pragma unroll
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_s_kernel(WgradSArgs a) {
     wait_vmcnt_upto(ahead * G::STAGE_DMAS);
     __builtin_amdgcn_s_barrier();          // ... and every wave has left step s - 1: its rows' ring slots are free
     asm volatile("" ::: "memory");
-    if (s + PD < nsteps) issue_stage(s + PD);
+    const bool more = s + PD < nsteps;     // a later stage is issued during this step
     const int y = ya + 2 * s + grp;        // this phase's gradient row
     if (y < yb) {
       const uint32_t ga = a_lane + uint32_t((y - ya) % G::NG) * G::G_ROW;
@@ -224,21 +233,25 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_s_kernel(WgradSArgs a) {
       uint32_t brow[TY];
 #pragma unroll
       for (int ty = 0; ty < TY; ++ty) brow[ty] = b_lane + uint32_t((y + a.ky0 - R + ty - rin0) % G::NIN) * G::IN_ROW;
-      // units u = (ty, ks, kx), software-pipelined: unit u + 1's reads are issued before unit u's are awaited
-      constexpr int NU = TY * NKX * KS;
-      Frag bf[2];
-      issue_frag<0, G::IN_IMG>(bf[0], brow[0]);
+      // units u = (ty, ks, kx), software-pipelined: the reads of units u + 1 and u + 2 are in flight while unit u is multiplied;
+      // the DMA pieces of the stage issued during this step go out one at a time between the units' MFMA groups (an LDS-DMA
+      // instruction stalls its wave 60-185 cycles); measured equal to a burst behind the barrier, kept for the shorter ramp after it
+      constexpr int NU = TY * NKX * KS, DEPTH = NU > 2 ? 2 : NU - 1;
+      constexpr int DMA_EVERY = G::STAGE_DMAS >= NU ? 1 : NU / G::STAGE_DMAS;
+      auto unit_addr = [&](int u) { return brow[u / (NKX * KS)] + uint32_t(((u / KS) % NKX) * 16 + u % KS) * 64u; };
+      Frag bf[3];
+#pragma unroll
+      for (int u = 0; u < DEPTH && u < NU; ++u) issue_frag<0, G::IN_IMG>(bf[u], unit_addr(u));
       half8 ah[NKX], al[NKX];
+      int next_dma = 0;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int ty = u / (NKX * KS), ks = (u / KS) % NKX, kx = u % KS;
-        if (u + 1 < NU) {
-          const int ty1 = (u + 1) / (NKX * KS), ks1 = ((u + 1) / KS) % NKX, kx1 = (u + 1) % KS;
-          issue_frag<0, G::IN_IMG>(bf[(u + 1) & 1], brow[ty1] + uint32_t(ks1 * 16 + kx1) * 64u);
-          wait_frag<4>(bf[u & 1]);
-        } else {
-          wait_frag<0>(bf[u & 1]);
-        }
+        if (u + DEPTH < NU) issue_frag<0, G::IN_IMG>(bf[(u + DEPTH) % 3], unit_addr(u + DEPTH));
+        const int newer = (NU - 1 - u) < DEPTH ? (NU - 1 - u) : DEPTH;   // fragments issued after unit u's
+        if (newer == 2) wait_frag<8>(bf[u % 3]);
+        else if (newer == 1) wait_frag<4>(bf[u % 3]);
+        else wait_frag<0>(bf[u % 3]);
         if (u == 0) {   // the A fragments were issued before every B fragment: they have returned as well
 #pragma unroll
           for (int k2 = 0; k2 < NKX; ++k2) {
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_s_kernel(WgradSArgs a) {
             al[k2] = join(af[k2].l0, af[k2].l1);
           }
         }
-        const half8 bh = join(bf[u & 1].h0, bf[u & 1].h1), bl = join(bf[u & 1].l0, bf[u & 1].l1);
+        const half8 bh = join(bf[u % 3].h0, bf[u % 3].h1), bl = join(bf[u % 3].l0, bf[u % 3].l1);
         const int t = ty * KS + kx;
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc[t], 0, 0, 0);
@@ -256,7 +269,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_s_kernel(WgradSArgs a) {
           acc_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], ones, acc_b, 0, 0, 0);
           acc_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], ones, acc_b, 0, 0, 0);
         }
+        if (more && u % DMA_EVERY == 0 && u / DMA_EVERY < G::STAGE_DMAS) {
+#pragma unroll
+          for (int n = 0; n < G::STAGE_DMAS; ++n) if (n == u / DMA_EVERY) issue_stage_piece(s + PD, n);
+          next_dma = u / DMA_EVERY + 1;
+        }
       }
+      if (more) {   // what the unit loop did not reach
+#pragma unroll
+        for (int n = 0; n < G::STAGE_DMAS; ++n) if (n >= next_dma) issue_stage_piece(s + PD, n);
+      }
+    } else if (more) {
+      issue_stage(s + PD);
     }
   }
   }   // frames
