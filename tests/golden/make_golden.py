@@ -475,6 +475,44 @@ def main():
              ndc_rays_o=no, ndc_rays_d=nd, rgb_ndc=rgb, disp_ndc=disp, acc_ndc=acc, rgb_static=rgb_s, disp_static=disp_s,
              acc_static=acc_s, white_bkgd_raises=white)
 
+    # ---------------- G15: the reference on TRAINED-LIKE weights.  tests/golden/trained_nerfh_weights.npz holds NeRF-H weights trained
+    # natively (tools/gpu_train_scene.py: 20 000 fused HIP steps on a synthetic scene with real occupancy — three shaded spheres in
+    # front of a checkered wall — held-out PSNR 28.5 dB): numbers only.  SURVEY section 7: random-init weights are contractive, trained
+    # checkpoints (sharp sigma) amplify error — here the REFERENCE's own render_rays / render run on such weights: 64 rays and a
+    # 12 x 16 frame at 64 + 128 samples of the training scene's cameras.
+    wpath = os.path.join(HERE, "trained_nerfh_weights.npz")
+    if os.path.exists(wpath):
+        tw = np.load(wpath)
+        cw = {k[len("coarse."):]: tw[k] for k in tw.files if k.startswith("coarse.")}
+        fw = {k[len("fine."):]: tw[k] for k in tw.files if k.startswith("fine.")}
+        coarse = nerfw.NeRFW("coarse", D=8, W=128, skips=[4], in_channels_xyz=63, in_channels_dir=27)
+        fine = nerfw.NeRFW("fine", D=8, W=128, skips=[4], in_channels_xyz=63, in_channels_dir=27,
+                           encode_appearance=True, encode_transient=True, in_channels_a=50, in_channels_t=20)
+        load_into(coarse, cw)
+        load_into(fine, fw)
+        emb_a = torch.nn.Embedding(1000, 5)
+        emb_t = torch.nn.Embedding(1000, 2)
+        emb_a.weight.data.copy_(t(tw["embedding_a.weight"]))
+        emb_t.weight.data.copy_(t(tw["embedding_t.weight"]))
+        nets["trained"] = (coarse.eval(), fine.eval(), emb_a, emb_t)
+        r15 = np.random.default_rng(1515)
+        Ht, Wt, ft = 60, 80, 585.0 / 8          # the training cameras (tools/gpu_train_scene.py)
+        with torch.no_grad():
+            c2w = syn.orbit_pose(7, 16)[:3, :4]
+            ro, rd = ray_utils.get_rays(Ht, Wt, ft, t(c2w))
+            sel = r15.choice(Ht * Wt, 64, replace=False)
+            ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
+            rgb, disp, acc, extras = rendering.render(Ht, Wt, ft, chunk=32768, rays=torch.stack([ro, rd], 0), near=0., far=2.5,
+                                                       img_idx=t(hist)[None], retraw=True, **kwargs_for("trained", 64, 128))
+            save("g15_trained_render_rays", Nc=64, Ni=128, near=0., far=2.5, hist=hist, rays_o=ro, rays_d=rd, rgb=rgb, disp=disp, acc=acc,
+                 raw=extras["raw"])
+            H, Wd, focal = 12, 16, 585.0 / 40   # the same field of view at a fifth of the training resolution
+            c2w = syn.orbit_pose(11, 40)
+            rgb, disp, acc, _ = rendering.render(H, Wd, focal, chunk=100, c2w=t(c2w)[:3, :4], near=0., far=2.5, img_idx=t(hist)[None],
+                                                 **kwargs_for("trained", 64, 128))
+            save("g15_trained_render_image", H=H, W=Wd, focal=focal, c2w=c2w, near=0., far=2.5, hist=hist, Nc=64, Ni=128,
+                 rgb=rgb, disp=disp, acc=acc)
+
 
 if __name__ == "__main__":
     main()

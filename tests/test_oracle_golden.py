@@ -97,6 +97,34 @@ def test_g7_render_image(gold):
     close(acc, g["acc"], 1e-5, 1e-6)
 
 
+def trained_nets():
+    """The trained-like NeRF-H weights of tests/golden/trained_nerfh_weights.npz (tools/gpu_train_scene.py) as oracle inputs."""
+    import os
+    tw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_nerfh_weights.npz"))
+    c = {k[len("coarse."):]: T(tw[k]) for k in tw.files if k.startswith("coarse.")}
+    f = {k[len("fine."):]: T(tw[k]) for k in tw.files if k.startswith("fine.")}
+    return c, f, T(tw["embedding_a.weight"]), T(tw["embedding_t.weight"])
+
+
+def test_g15_trained_weights(gold):
+    """The oracle against the REFERENCE on trained-like weights (sharp occupancy: sigma up to the hundreds, saturated alphas)."""
+    c, f, ea, et = trained_nets()
+    g = gold("g15_trained_render_rays")
+    rows = orc.pack_ray_rows(T(g["rays_o"]), T(g["rays_d"]), float(g["near"]), float(g["far"]), g["hist"])
+    out = orc.render_rays(rows, c, f, ea, et, int(g["Nc"]), int(g["Ni"]), retraw=True)
+    assert float(np.max(g["raw"][..., 3])) > 20.0 and float(np.min(g["acc"])) > 0.99      # an occupied scene, not the 0.7-density fog of random init
+    close(out["raw"], g["raw"], 5e-5, 5e-5)
+    close(out["rgb_map"], g["rgb"], 1e-5, 2e-6)
+    close(out["disp_map"], g["disp"], 1e-5, 2e-6)
+    close(out["acc_map"], g["acc"], 1e-5, 2e-6)
+    g = gold("g15_trained_render_image")
+    rgb, disp, acc = orc.render(int(g["H"]), int(g["W"]), float(g["focal"]), 100, c, f, ea, et, int(g["Nc"]), int(g["Ni"]),
+                                float(g["near"]), float(g["far"]), g["hist"], c2w=g["c2w"])
+    close(rgb, g["rgb"], 1e-5, 2e-6)
+    close(disp, g["disp"], 1e-5, 2e-6)
+    close(acc, g["acc"], 1e-5, 2e-6)
+
+
 def test_g9_render_gradients(gold):
     """Autograd through the oracle's render == autograd through the reference's render (pose / ray gradients)."""
     c, f, ea, et = nets(128)
