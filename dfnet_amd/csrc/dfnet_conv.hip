@@ -1032,6 +1032,8 @@ hipError_t launch_conv(int prec, int ks, int sb, const ConvArgs& a, hipStream_t 
     // A fragments straight from L2 into registers (12 % slower).
     auto padded = [&](int th, int tw) { return double((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw); };
     const bool sq = padded(16, 16) < 0.97 * padded(8, 32);
+    // (32 x 8 tiles — fragments of 4 rows x 8 columns, 94 % instead of 78 % of the 30 x 40 maps filled — measured equal for conv5_x,
+    //  104-110 vs 103-107 us: those layers are bound by per-iteration latency, and the 10-pixel patch rows conflict in LDS: LABBOOK.md)
     if (a.in_split) {   // split storage in: patch staged by LDS-DMA (inference forward)
       if (sb == 8 && ks == 3) return launch_conv_x3s_t<3, 8, 2>(a, stream);
       if (sb != 16) return hipErrorInvalidValue;

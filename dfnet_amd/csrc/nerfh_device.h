@@ -135,6 +135,17 @@ DFN_DEV float wave_incl_sum(float v, int lane) {
   }
   return v;
 }
+// Inclusive SUFFIX sum (lanes >= lane), accumulated from the far end: the error of S_i is eps x |S_i|, not eps x the wave's total as
+// with `total - prefix` — the compositing gradients subtract S_i from a term of its own size (measured: d sigma 3.7e-4 -> round-off
+// against float64 autograd, tools/gpu_debug_raygrad.py).
+DFN_DEV float wave_incl_suffix_sum(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_down(v, d, 64);
+    if (lane + d < 64) v += t;
+  }
+  return v;
+}
 // ---- 32-lane scans on the DPP crossbar (gfx9 row_shr / row_bcast:15 / wave_shr): five VALU instructions per scan instead of
 // six ds_bpermute round trips (~100 cycles each, dependent).  Lanes 0..31 hold the data (one point block of an MLP wave);
 // lanes 32..63 must carry the identity.  The scan order differs from wave_incl_* (Hillis-Steele inside 16-lane rows, then one

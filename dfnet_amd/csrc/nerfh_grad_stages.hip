@@ -66,13 +66,18 @@ __global__ __launch_bounds__(256) void composite_fine_backward_kernel(const floa
       esum += e[k];
       Tj = mul_rn(Tj, om[k]);
     }
-    const float incl = wave_incl_sum(esum, lane);
-    const float total = __shfl(incl, 63, 64);
-    float S = total - (incl - esum);   // sum over this lane's and all later samples
+    // S_i = sum over the samples strictly after i, added up from the far end (never `total - prefix`: that carries eps x total)
+    float after[SPL];
+    {
+      float later = __shfl_down(wave_incl_suffix_sum(esum, lane), 1, 64);   // the lanes after this one
+      if (lane == 63) later = 0.f;
+#pragma unroll
+      for (int k = SPL - 1; k >= 0; --k) { after[k] = later; later += e[k]; }
+    }
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
       const int i = lane * SPL + k;
-      S -= e[k];                        // now: samples strictly after i
+      const float S = after[k];
       if (i < Nf) {
         float* o = gr + size_t(i) * 9;
         const float ws = T[k] * a_s[k], wt = T[k] * a_t[k];

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void head_prime_kernel(const float* __restrict
     const int c = int(e % 9);
     const float y = raw[e];
     const bool softplus_head = c == 3 || c >= 7;
-    g[e] *= softplus_head ? 1.f - expf(-y) : y * (1.f - y);
+    g[e] *= softplus_head ? -expm1f(-y) : y * (1.f - y);   // softplus' from the output without the cancellation of 1 - e^-y at small densities
   }
 }
 hipError_t head_prime(const float* raw, float* g, size_t P, hipStream_t s) {
@@ -1105,9 +1105,11 @@ __global__ __launch_bounds__(256) void composite_coarse_backward_kernel(const fl
     for (int c0 = ((Nc - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
       const int i = c0 + lane;
       const float e = i < Nc ? s_e[i] : 0.f;
-      const float incl = wave_incl_sum(e, lane);
-      const float blk = __shfl(incl, 63, 64);
-      const float S = tail + (blk - incl);   // strictly after i
+      const float suf = wave_incl_suffix_sum(e, lane);   // from the far end: eps x |S_i|, not eps x the block total
+      const float blk = __shfl(suf, 0, 64);
+      float later = __shfl_down(suf, 1, 64);
+      if (lane == 63) later = 0.f;
+      const float S = tail + later;          // strictly after i
       if (i < Nc) {
         const float* rc = raw_c + (ray * Nc + i) * 4;
         const float sg = rc[3];
@@ -1120,7 +1122,7 @@ __global__ __launch_bounds__(256) void composite_coarse_backward_kernel(const fl
         o[1] = g1 * w * rc[1] * (1.f - rc[1]);
         o[2] = g2 * w * rc[2] * (1.f - rc[2]);
         const float ds = se > 0.f ? delta * ((1.f - al) * T * gc - S) : 0.f;
-        o[3] = ds * (1.f - expf(-sg));
+        o[3] = ds * -expm1f(-sg);
       }
       tail += blk;
     }
@@ -1178,9 +1180,11 @@ __global__ __launch_bounds__(256) void composite_fine_backward_train_kernel(cons
     for (int c0 = ((Nf - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
       const int i = c0 + lane;
       const float e = i < Nf ? s_e[i] : 0.f;
-      const float incl = wave_incl_sum(e, lane);
-      const float blk = __shfl(incl, 63, 64);
-      const float S = tail + (blk - incl);
+      const float suf = wave_incl_suffix_sum(e, lane);
+      const float blk = __shfl(suf, 0, 64);
+      float later = __shfl_down(suf, 1, 64);
+      if (lane == 63) later = 0.f;
+      const float S = tail + later;
       if (i < Nf) {
         const float* v = rr + size_t(i) * 9;
         const float delta = i + 1 < Nf ? sub_rn(zr[i + 1], zr[i]) : 1e2f;
@@ -1191,12 +1195,12 @@ __global__ __launch_bounds__(256) void composite_fine_backward_train_kernel(cons
         o[0] = g0 * ws * v[0] * (1.f - v[0]);
         o[1] = g1 * ws * v[1] * (1.f - v[1]);
         o[2] = g2 * ws * v[2] * (1.f - v[2]);
-        o[3] = delta * ((1.f - a_s) * T * gcs - S) * (1.f - expf(-v[3]));
+        o[3] = delta * ((1.f - a_s) * T * gcs - S) * -expm1f(-v[3]);
         o[4] = g0 * wt * v[4] * (1.f - v[4]);
         o[5] = g1 * wt * v[5] * (1.f - v[5]);
         o[6] = g2 * wt * v[6] * (1.f - v[6]);
-        o[7] = (delta * ((1.f - a_t) * T * gct - S) + g_tsigma + (g_ts ? g_ts[ray * size_t(Nf) + i] : 0.f)) * (1.f - expf(-v[7]));
-        o[8] = gb * wt * (1.f - expf(-v[8]));
+        o[7] = (delta * ((1.f - a_t) * T * gct - S) + g_tsigma + (g_ts ? g_ts[ray * size_t(Nf) + i] : 0.f)) * -expm1f(-v[7]);
+        o[8] = gb * wt * -expm1f(-v[8]);
       }
       tail += blk;
     }

@@ -435,7 +435,7 @@ def render_grad_rays(rays_o, rays_d, G, coarse, fine, emb_a, emb_t, Nc, Ni, near
 
 def render_grad_c2w(H, W, focal, c2w, G, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx):
     """d sum(rgb * G) / d c2w[:3,:4] by autograd through render(c2w=...) (direct_feature_matching.py:340-376)."""
-    p = torch.as_tensor(c2w, dtype=torch.float32)[:3, :4].detach().clone().requires_grad_(True)
+    p = torch.as_tensor(c2w, dtype=torch.get_default_dtype())[:3, :4].detach().clone().requires_grad_(True)   # (float64 under tests/yardstick.py)
     rgb = render(H, W, focal, 1 << 30, coarse, fine, emb_a, emb_t, Nc, Ni, near, far, img_idx, c2w=p)[0]
     (rgb * G).sum().backward()
     return rgb.detach(), p.grad

@@ -116,10 +116,19 @@ def test_lindisp_drop_in_render_and_gradient(scene, gold):
     (out["rgb_map"] * G).sum().backward()
     # (torch's cumprod backward divides by 1 - alpha: on this saturating scene single rays of the ORACLE's gradient are off by a percent,
     #  tests/test_gpu_train.py::test_generic_width_render_gradient_vs_oracle; hence relative L2 over the batch)
-    for got, ref in ((rays_t.grad[0].cpu(), o_ref.grad), (rays_t.grad[1].cpu(), d_ref.grad)):
-        e = float((got - ref).norm() / ref.norm())
-        print(f"lindisp d loss / d rays: relative L2 {e:.2e}")
-        assert e < 5e-3
+    # measured tolerance (tests/yardstick.py): the same gradient through the oracle in float64; the HIP gradient within 1.5 x the distance
+    # torch's own fp32 autograd sits from it (+ 2e-4)
+    from tests.yardstick import float64_default, to64
+    with float64_default():
+        o64, d64 = T(g["rays_o"]).double().requires_grad_(True), T(g["rays_d"]).double().requires_grad_(True)
+        view64 = d64 / torch.norm(d64, dim=-1, keepdim=True)
+        rows64 = torch.cat([o64, d64, torch.full((n, 1), near), torch.full((n, 1), far), view64, T(g["hist"]).double()[None].repeat(n, 1)], 1)
+        out64 = orc.render_rays(rows64, *to64((cw, fw, ea, et)), Nc, Ni, lindisp=True)
+        (out64["rgb_map"] * G.double()).sum().backward()
+    for name, got, ref, r64 in (("o", rays_t.grad[0].cpu(), o_ref.grad, o64.grad), ("d", rays_t.grad[1].cpu(), d_ref.grad, d64.grad)):
+        yard, e = float((ref.double() - r64).norm() / r64.norm()), float((got.double() - r64).norm() / r64.norm())
+        print(f"lindisp d loss / d rays_{name} vs float64: relative L2 {e:.2e} (torch fp32: {yard:.2e})")
+        assert e <= 1.5 * yard + 2e-4
     with pytest.raises(ValueError, match="near > 0"):
         rendering.render(480, 640, 585., rays=rays, near=0., far=far, img_idx=dev(g["hist"])[None], **kw)
     rendering.render(480, 640, 585., rays=rays, near=near, far=far, img_idx=dev(g["hist"])[None], **kwargs(E, Nc, Ni))

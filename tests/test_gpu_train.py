@@ -348,14 +348,32 @@ def test_training_render_ray_gradients(gold, tag):
                                                 'transient_sigmas': extras['transient_sigmas']}, target)
     sum(loss_d.values()).backward()
     ref = T(g["g_rays"])
-    eo, ed = rel_l2(rays.grad[0], ref[0]), rel_l2(rays.grad[1], ref[1])
+    # Yardstick (tests/yardstick.py): the same gradient through the oracle in float64.  Single rays are ill-conditioned in ANY fp32
+    # implementation — autograd of torch.cumprod divides by the factors 1 - alpha, which vanish on opaque samples; the kernels use
+    # division-free suffix sums — so the bound is measured: the REFERENCE's own fp32 gradient sits `yard` from float64, the HIP
+    # gradient must not sit further than 1.5 x that (+ 2e-4), and the typical ray (median) within 2e-4 of the reference.
+    from tests.yardstick import float64_default, to64
+    with float64_default():
+        go64, gd64 = orc.train_step_grad_rays(*to64((o, d)), 0., 2.5, *to64((hist, target)), to64({k: T(v) for k, v in cw.items()}),
+                                              to64({k: T(v) for k, v in fw.items()}), *to64((T(ea), T(et))), Nc, Ni,
+                                              *to64((t_rand, noise, u)), perturb=1., raw_noise_std=std)
+    from tests.yardstick import rays_off_a_gate
+
+    def single64(i, delta):   # float64 gradient of ray i alone with its origin shifted (the loss's 1 / R factors cancel in the relative change)
+        with float64_default():
+            a, b = orc.train_step_grad_rays(to64(o)[i:i + 1] + delta, to64(d)[i:i + 1], 0., 2.5, to64(hist), to64(target)[i:i + 1],
+                                            to64({k: T(v) for k, v in cw.items()}), to64({k: T(v) for k, v in fw.items()}), *to64((T(ea), T(et))),
+                                            Nc, Ni, *[t[i:i + 1] for t in to64((t_rand, noise, u))], perturb=1., raw_noise_std=std)
+        return torch.cat([a[0], b[0]])
+    got = torch.cat([rays.grad[0], rays.grad[1]], -1)
+    tru = torch.cat([go64, gd64], -1)
+    keep = rays_off_a_gate(got, tru, lambda i, dl: single64(i, dl) * float(tru[i].norm() / single64(i, dl * 0).norm()))   # (batch of R rays: 1 / R of the lone ray's gradient)
+    yo, yd = rel_l2(ref[0][keep], go64[keep]), rel_l2(ref[1][keep], gd64[keep])
+    eo, ed = rel_l2(rays.grad[0].cpu()[keep], go64[keep]), rel_l2(rays.grad[1].cpu()[keep], gd64[keep])
     per = ((rays.grad.cpu() - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-30)).median()
-    print(f"training-render ray gradients vs the reference (G13-{tag}): d rays_o {eo:.2e}, d rays_d {ed:.2e}, median per-ray {float(per):.2e}")
-    # Criterion of test_generic_width_render_gradient_vs_oracle: the median per-ray error (< 1e-3) and the relative L2 over the batch
-    # (< 1e-2).  Single rays sit further off in ANY fp32 implementation: autograd of torch.cumprod divides by the factors 1 - alpha,
-    # which vanish on opaque samples (64+128 samples, raw_noise_std 1: 1.5e-3 over the batch; 16+32: 2-4e-4); the kernels use the
-    # division-free suffix sums.  The oracle's own autograd sits 1-2e-4 from the reference's (tests/test_oracle_golden.py).
-    assert eo < 1e-2 and ed < 1e-2 and float(per) < 1e-3
+    print(f"training-render ray gradients (G13-{tag}) vs float64: d rays_o {eo:.2e} (reference: {yo:.2e}), d rays_d {ed:.2e} (reference: {yd:.2e}), "
+          f"median per ray vs the reference {float(per):.2e}; rays on a gate (left out): {int((~keep).sum())} of {keep.numel()}")
+    assert eo <= 1.5 * yo + 2e-4 and ed <= 1.5 * yd + 2e-4 and float(per) < 2e-4
     for name, p, g0 in zip(tr.names, tr.params, fused):   # exact step (this backward) vs fused step: the same weight gradients
         assert rel_l2(p.grad, g0) < 5e-4, name
     # a pose that requires grad reaches the rays through get_rays' own node
@@ -383,10 +401,30 @@ def test_training_render_ray_gradients_vs_oracle_64_rays():
     out = tr.forward(o.to(DEV), d.to(DEV), hist.to(DEV), Nc, Ni, 0., 2.5, *draws[:2], 1., draws[2], exact=True)
     loss5, gs, gts = tr.loss(out, target.to(DEV))
     go, gd = tr.backward_rays(*gs, gts)
-    eo, ed = rel_l2(go, go_ref), rel_l2(gd, gd_ref)
+    # the float64 yardstick (tests/yardstick.py): torch's own fp32 autograd of this step sits 3.6e-3 / 2.7e-3 (batch relative L2)
+    # from the float64 autograd at 64 + 128 samples with raw_noise_std 1 — the HIP gradient must not sit further than 1.5 x that
+    from tests.yardstick import float64_default, to64
+    with float64_default():
+        go64, gd64 = orc.train_step_grad_rays(*to64((o, d)), 0., 2.5, *to64((hist, target, c, f, T(ea), T(et))), Nc, Ni,
+                                              *to64((t_rand, noise, u)), perturb=1., raw_noise_std=1.)
+    from tests.yardstick import rays_off_a_gate
+    tru = torch.cat([go64, gd64], -1)
+
+    def single64(i, delta):
+        with float64_default():
+            a, b = orc.train_step_grad_rays(to64(o)[i:i + 1] + delta, to64(d)[i:i + 1], 0., 2.5, to64(hist)[i:i + 1], to64(target)[i:i + 1],
+                                            *to64((c, f, T(ea), T(et))), Nc, Ni, *[t[i:i + 1] for t in to64((t_rand, noise, u))], perturb=1.,
+                                            raw_noise_std=1.)
+        g = torch.cat([a[0], b[0]])
+        return g
+    scale = lambda i: float(tru[i].norm() / single64(i, torch.zeros(3, dtype=torch.float64)).norm())
+    keep = rays_off_a_gate(torch.cat([go, gd], -1), tru, lambda i, dl: single64(i, dl) * scale(i))
+    yo, yd = rel_l2(go_ref[keep], go64[keep]), rel_l2(gd_ref[keep], gd64[keep])
+    eo, ed = rel_l2(go.cpu()[keep], go64[keep]), rel_l2(gd.cpu()[keep], gd64[keep])
     per = (torch.cat([go.cpu() - go_ref, gd.cpu() - gd_ref], -1).norm(dim=-1) / torch.cat([go_ref, gd_ref], -1).norm(dim=-1).clamp_min(1e-30)).median()
-    print(f"training-render ray gradients vs oracle autograd, 64 rays @ 64+128: d rays_o {eo:.2e}, d rays_d {ed:.2e}, median per-ray {float(per):.2e}")
-    assert eo < 1e-2 and ed < 1e-2 and float(per) < 1e-3
+    print(f"training-render ray gradients, 64 rays @ 64+128, vs float64: d rays_o {eo:.2e} (torch fp32: {yo:.2e}), d rays_d {ed:.2e} "
+          f"(torch fp32: {yd:.2e}), median per ray vs the fp32 oracle {float(per):.2e}; rays on a gate (left out): {int((~keep).sum())} of {keep.numel()}")
+    assert eo <= 1.5 * yo + 2e-4 and ed <= 1.5 * yd + 2e-4 and float(per) < 2e-4
     go2, gd2 = tr.backward_rays(*gs, gts)
     assert torch.equal(go, go2) and torch.equal(gd, gd2)   # deterministic
     tr.forward(o.to(DEV), d.to(DEV), hist.to(DEV), Nc, Ni, 0., 2.5, *draws[:2], 1., draws[2])   # fused forward keeps no activations
@@ -480,10 +518,25 @@ def test_generic_width_render_gradient_vs_oracle(width):
     G = T(rng.standard_normal((n, 3)).astype(np.float32))
     _, ref_o, ref_d = orc.render_grad_rays(o, d, G, c, f, T(ea), T(et), 16, 32, 0., 2.5, hist)
     go, gd, _ = E.render_rays_backward(o.to(DEV), d.to(DEV), hist.to(DEV), 16, 32, 0., 2.5, G.to(DEV), precision="generic")
-    eo, ed = _rel_l2(go, ref_o), _rel_l2(gd, ref_d)
-    per = ((go.cpu() - ref_o).norm(dim=1) / ref_o.norm(dim=1).clamp_min(1e-20)).median()
-    print(f"netwidth {width}: d rays_o {eo:.2e}, d rays_d {ed:.2e} (relative L2), median per-ray {float(per):.2e}")
-    assert eo < 1e-2 and ed < 1e-2 and float(per) < 1e-3
+    # measured tolerance (tests/yardstick.py): the same gradient through the oracle in float64 is the truth; torch's own fp32 autograd
+    # sits `yard` from it (percents on single opaque rays), the HIP gradient must sit within 1.5 x yard + 2e-4, the typical ray within 2e-4
+    from tests.yardstick import float64_default, to64
+    with float64_default():
+        _, o64, d64 = orc.render_grad_rays(*to64((o, d, G, c, f, T(ea), T(et))), 16, 32, 0., 2.5, to64(hist))
+    from tests.yardstick import rays_off_a_gate
+
+    def single64(i, delta):
+        with float64_default():
+            _, a, b = orc.render_grad_rays(to64(o)[i:i + 1] + delta, to64(d)[i:i + 1], to64(G)[i:i + 1], *to64((c, f, T(ea), T(et))), 16, 32, 0.,
+                                           2.5, to64(hist)[i:i + 1])
+        return torch.cat([a[0], b[0]])
+    keep = rays_off_a_gate(torch.cat([go, gd], -1), torch.cat([o64, d64], -1), single64)
+    yo, yd = _rel_l2(ref_o[keep], o64[keep]), _rel_l2(ref_d[keep], d64[keep])
+    eo, ed = _rel_l2(go.cpu()[keep], o64[keep]), _rel_l2(gd.cpu()[keep], d64[keep])
+    per = ((go.cpu().double() - o64).norm(dim=1) / o64.norm(dim=1).clamp_min(1e-20)).median()
+    print(f"netwidth {width} vs float64: d rays_o {eo:.2e} (torch fp32: {yo:.2e}), d rays_d {ed:.2e} (torch fp32: {yd:.2e}), median per-ray {float(per):.2e}; "
+          f"rays on a gate (left out): {int((~keep).sum())} of {keep.numel()}")
+    assert eo <= 1.5 * yo + 2e-4 and ed <= 1.5 * yd + 2e-4 and float(per) < 2e-4
     go2, gd2, _ = E.render_rays_backward(o.to(DEV), d.to(DEV), hist.to(DEV), 16, 32, 0., 2.5, G.to(DEV), precision="generic")
     assert torch.equal(go, go2) and torch.equal(gd, gd2)   # deterministic
     if width == 128:   # the same gradient from the register-resident exact-fp32 kernels
@@ -499,9 +552,11 @@ def test_generic_width_render_gradient_vs_oracle(width):
     Gi = T(rng.standard_normal((H, W, 3)).astype(np.float32))
     _, ref_c = orc.render_grad_c2w(H, W, focal, c2w, Gi, c, f, T(ea), T(et), 64, 128, 0., 2.5, syn.HIST_IDX)
     gc = E.render_image_backward(c2w.to(DEV), H, W, focal, T(syn.HIST_IDX).to(DEV), 64, 128, 0., 2.5, Gi.to(DEV), precision="generic")
-    ec = relmax(gc, ref_c)
-    print(f"netwidth {width}: d c2w {ec:.2e}")
-    assert ec < 5e-3
+    with float64_default():   # d c2w is a signed sum over the frame's rays that cancels: measured against float64 as well
+        _, c64 = orc.render_grad_c2w(H, W, focal, c2w.double(), Gi.double(), *to64((c, f, T(ea), T(et))), 64, 128, 0., 2.5, syn.HIST_IDX.astype(np.float64))
+    yc, ec = relmax(ref_c, c64), relmax(gc, c64)
+    print(f"netwidth {width} vs float64: d c2w {ec:.2e} (torch fp32: {yc:.2e})")
+    assert ec <= 3 * yc + 2e-4
 
 
 def test_render_autograd_at_netwidth_32():
@@ -519,4 +574,10 @@ def test_render_autograd_at_netwidth_32():
     (rgb * Gi.to(DEV)).sum().backward()
     c, f = {k: T(v) for k, v in cw.items()}, {k: T(v) for k, v in fw.items()}
     ref_rgb, ref = orc.render_grad_c2w(H, W, focal, pose.detach().cpu(), Gi, c, f, T(ea), T(et), 64, 128, 0., 2.5, syn.HIST_IDX)
-    assert relmax(rgb, ref_rgb) < 3e-5 and relmax(pose.grad, ref) < 5e-3
+    from tests.yardstick import float64_default, to64
+    with float64_default():
+        _, ref64 = orc.render_grad_c2w(H, W, focal, pose.detach().cpu().double(), Gi.double(), *to64((c, f, T(ea), T(et))), 64, 128, 0., 2.5,
+                                       syn.HIST_IDX.astype(np.float64))
+    yard, err = relmax(ref, ref64), relmax(pose.grad, ref64)
+    print(f"netwidth 32 render autograd vs float64: d c2w {err:.2e} (torch fp32: {yard:.2e})")
+    assert relmax(rgb, ref_rgb) < 3e-5 and err <= 3 * yard + 2e-4
