@@ -83,6 +83,56 @@ def orbit_pose(k, K):
     return m
 
 
+# ----------------------------------------------------------------------------- a scene with real occupancy
+# Three shaded spheres in front of a checkered wall, seen from the orbit_pose cameras: ground truth by analytic ray casting.  NeRF-H
+# trained on it (tools/gpu_train_scene.py) is the "trained-like weights" fixture tests/golden/trained_nerfh_weights.npz.
+SCENE_SPHERES = (((-0.32, 0.05, -0.05), 0.26, (0.85, 0.25, 0.2)), ((0.30, -0.08, 0.10), 0.22, (0.2, 0.7, 0.3)),
+                 ((0.02, 0.22, -0.35), 0.18, (0.25, 0.35, 0.9)))
+SCENE_WALL_Z = -0.75
+SCENE_LIGHT = np.array([0.4, 0.7, 0.6]) / np.linalg.norm([0.4, 0.7, 0.6])
+
+
+def analytic_scene_image(c2w, H, W, focal, far=2.5):
+    """[H,W,3] float32 image of the scene from pose c2w [3,4] (the reference's camera convention, models/ray_utils.py:5-15): the
+    nearest sphere (Lambert + ambient), else the checkered wall z = SCENE_WALL_Z."""
+    c2w = np.asarray(c2w, dtype=np.float64)
+    i, j = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64), indexing="xy")
+    dirs = np.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -np.ones_like(i)], -1)
+    d = dirs @ c2w[:3, :3].T
+    o = c2w[:3, 3]
+    best = np.full((H, W), np.inf)
+    rgb = np.zeros((H, W, 3))
+    tw = (SCENE_WALL_Z - o[2]) / d[..., 2]
+    pw = o + tw[..., None] * d
+    chk = ((np.floor(pw[..., 0] * 5) + np.floor(pw[..., 1] * 5)) % 2)[..., None]
+    wall = chk * np.array([0.9, 0.85, 0.6]) + (1 - chk) * np.array([0.25, 0.25, 0.3])
+    ok = (tw > 0) & (tw < far)
+    rgb[ok], best[ok] = wall[ok], tw[ok]
+    for c, r, col in SCENE_SPHERES:
+        oc = o - np.array(c)
+        a = (d * d).sum(-1)
+        b = 2 * (d * oc).sum(-1)
+        cc = (oc * oc).sum() - r * r
+        disc = b * b - 4 * a * cc
+        t = (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a)
+        hit = (disc > 0) & (t > 0) & (t < best)
+        n = (o + t[..., None] * d - np.array(c)) / r
+        shade = 0.25 + 0.75 * np.clip((n * SCENE_LIGHT).sum(-1), 0, 1)
+        rgb[hit] = (shade[..., None] * np.array(col))[hit]
+        best[hit] = t[hit]
+    return rgb.astype(np.float32)
+
+
+def trained_nerfh_weights(path=None):
+    """(coarse, fine, embedding_a, embedding_t) of the trained-like fixture (numbers only; see tools/gpu_train_scene.py)."""
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "trained_nerfh_weights.npz")
+    tw = np.load(path)
+    coarse = {k[len("coarse."):]: tw[k] for k in tw.files if k.startswith("coarse.")}
+    fine = {k[len("fine."):]: tw[k] for k in tw.files if k.startswith("fine.")}
+    return coarse, fine, tw["embedding_a.weight"], tw["embedding_t.weight"]
+
+
 # ----------------------------------------------------------------------------- DFNet
 VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
 

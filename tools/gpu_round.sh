@@ -3,7 +3,7 @@
 # usage: tools/gpu_round.sh TAG [notest] [nopmc]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd $R
 mkdir -p gpurun_out
 if [[ " $* " != *" notest "* ]]; then
@@ -55,4 +55,15 @@ if [[ " $* " != *" noextra "* ]]; then
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_layers -o l -- python $R/tools/gpu_dfnet_layers.py run > /dev/null 2>&1
   python $R/tools/gpu_dfnet_layers.py report $R/gpurun_out/prof_layers > $R/gpurun_out/dfnet_layers.txt; head -3 $R/gpurun_out/dfnet_layers.txt
   rm -rf $R/gpurun_out/prof_layers
+  # round 5: the N2 step (DFNet's own training) — kernel stats and SQ counters — the DFNet_dm step's counters, the split weight-gradient
+  # stream layer by layer
+  cd /tmp
+  rm -rf $R/gpurun_out/prof_ft
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ft -o ft -- python $R/tools/gpu_feature_train_step.py 4 20 240 320 > $R/gpurun_out/ft_step.json 2> $R/gpurun_out/ft_step.err; echo "ft rc=$?"
+  timeout 600 $R/tools/gpu_pmc.sh ft_step python $R/tools/gpu_feature_train_step.py 4 6 240 320 > $R/gpurun_out/ft_step_pmc.log 2>&1; echo "ft pmc rc=$?"
+  DM_ONLY=1 timeout 600 $R/tools/gpu_pmc.sh dm_step python $R/tools/gpu_dm_step.py 4 8 > $R/gpurun_out/dm_step_pmc.log 2>&1; echo "dm pmc rc=$?"
+  cd /tmp; rm -rf $R/gpurun_out/prof_wgl
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_wgl -o w -- python $R/tools/gpu_wgrad_layers.py run > /dev/null 2>&1
+  python $R/tools/gpu_wgrad_layers.py report $R/gpurun_out/prof_wgl > $R/gpurun_out/wgrad_layers.txt; tail -1 $R/gpurun_out/wgrad_layers.txt
+  rm -rf $R/gpurun_out/prof_wgl
 fi

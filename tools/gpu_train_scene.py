@@ -20,37 +20,11 @@ out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out"
 H, W, focal, near, far = 60, 80, 585.0 / 8, 0., 2.5
 K_TRAIN, N_RAND, NC, NI = 40, 1536, 64, 64
 
-SPHERES = [((-0.32, 0.05, -0.05), 0.26, (0.85, 0.25, 0.2)), ((0.30, -0.08, 0.10), 0.22, (0.2, 0.7, 0.3)), ((0.02, 0.22, -0.35), 0.18, (0.25, 0.35, 0.9))]
-WALL_Z, LIGHT = -0.75, np.array([0.4, 0.7, 0.6]) / np.linalg.norm([0.4, 0.7, 0.6])
 
 
 def ground_truth(c2w):
-    """Analytic image of the scene from pose c2w [3,4]: nearest sphere (Lambert + ambient), else the checkered wall z = WALL_Z."""
-    i, j = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64), indexing="xy")
-    dirs = np.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -np.ones_like(i)], -1)
-    d = dirs @ c2w[:3, :3].T.astype(np.float64)
-    o = c2w[:3, 3].astype(np.float64)
-    best = np.full((H, W), np.inf)
-    rgb = np.zeros((H, W, 3))
-    tw = (WALL_Z - o[2]) / d[..., 2]
-    pw = o + tw[..., None] * d
-    chk = ((np.floor(pw[..., 0] * 5) + np.floor(pw[..., 1] * 5)) % 2)[..., None]
-    wall = chk * np.array([0.9, 0.85, 0.6]) + (1 - chk) * np.array([0.25, 0.25, 0.3])
-    ok = (tw > 0) & (tw < far)
-    rgb[ok], best[ok] = wall[ok], tw[ok]
-    for c, r, col in SPHERES:
-        oc = o - np.array(c)
-        a = (d * d).sum(-1)
-        b = 2 * (d * oc).sum(-1)
-        cc = (oc * oc).sum() - r * r
-        disc = b * b - 4 * a * cc
-        t = (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a)
-        hit = (disc > 0) & (t > 0) & (t < best)
-        n = (o + t[..., None] * d - np.array(c)) / r
-        shade = 0.25 + 0.75 * np.clip((n * LIGHT).sum(-1), 0, 1)
-        rgb[hit] = (shade[..., None] * np.array(col))[hit]
-        best[hit] = t[hit]
-    return rgb.astype(np.float32)
+    """Analytic image of the scene (dfnet_amd/synthetic.py: analytic_scene_image) at the training resolution."""
+    return syn.analytic_scene_image(c2w, H, W, focal, far)
 
 
 def main():
