@@ -60,10 +60,14 @@ __global__ __launch_bounds__(256) void triplet_case_kernel(Stack f1, Stack f2, i
 // mode 0: naive (case 0); 1: two-case mining (misc.py:371-397); 2: four-case (misc.py:399-435).  torch.argmin: first minimum.
 __global__ void triplet_case_finalize_kernel(const double* __restrict__ part, int n_chunks, int mode, double count, int* __restrict__ case_out,
                                              float* __restrict__ mse_out) {
-  if (threadIdx.x != 0) return;
+  // one wave: lane l adds the chunks c = l, l + 64, ... in order, then a fixed shuffle tree (deterministic; a single thread walking
+  // thousands of partials one dependent load at a time took 250 us per step)
   double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int c = 0; c < n_chunks; ++c)
+  for (int c = threadIdx.x; c < n_chunks; c += 64)
     for (int k = 0; k < 4; ++k) s[k] += part[(size_t)c * 4 + k];
+  for (int o = 32; o > 0; o >>= 1)
+    for (int k = 0; k < 4; ++k) s[k] += __shfl_down(s[k], o, 64);
+  if (threadIdx.x != 0) return;
   float m[4];
   for (int k = 0; k < 4; ++k) { m[k] = (float)(s[k] / count); if (mse_out) mse_out[k] = m[k]; }
   int best = 0;
@@ -108,10 +112,10 @@ __global__ __launch_bounds__(256) void triplet_forward_kernel(Stack f1, Stack f2
 }
 
 __global__ void triplet_loss_finalize_kernel(const double* __restrict__ part, int n, double n_rows, float* __restrict__ loss) {
-  if (threadIdx.x != 0) return;
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += part[i];
-  *loss = (float)(s / n_rows);
+  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (threadIdx.x == 0) *loss = (float)(s / n_rows);
 }
 
 // g1 / g2: gradients w.r.t. f1 / f2 (every element written).  scale = grad_loss / n_rows.

@@ -557,8 +557,14 @@ __global__ __launch_bounds__(256) void conv0_x3_finalize_kernel(const float* __r
   if (i >= 64 * 32) return;
   const int p = i >> 5, t = i & 31;
   if (t >= 27) return;
-  float s = 0.f;
-  for (int ch = 0; ch < n_chunks; ++ch) s += part[(size_t)ch * 64 * 32 + i];
+  // eight interleaved chains, then a fixed tree (deterministic): up to 2 048 chunk partials per element, one dependent load each before
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int ch = 0;
+  for (; ch + 8 <= n_chunks; ch += 8)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s8[k] += part[(size_t)(ch + k) * 64 * 32 + i];
+  for (int k = 0; ch < n_chunks; ++ch, ++k) s8[k] += part[(size_t)ch * 64 * 32 + i];
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   const int co = 32 * (p >> 5) + chan_of_pos(p & 31);
   dW[co * 27 + t] = s * gscale[1] * (1.f / kConvActScale);   // [co][c][ky][kx]
 }

@@ -432,7 +432,7 @@ hipError_t launch_nchw_to_split(const float* x, int B, int C, int H, int W, floa
 
 namespace {
 template <int KS, int TY, int NKX, int PD>
-hipError_t launch_wgs_t(WgradSArgs a, int n_launch_rows, hipStream_t s) {
+hipError_t launch_wgs_t(WgradSArgs a, int n_launch_rows, hipStream_t s, int ky0_first = 0) {
   using G = WgsGeom<KS, TY, NKX, PD>;
   auto kern = conv_wgrad_s_kernel<KS, TY, NKX, PD>;
   static bool attr_done = false;
@@ -442,8 +442,8 @@ hipError_t launch_wgs_t(WgradSArgs a, int n_launch_rows, hipStream_t s) {
     attr_done = true;
   }
   for (int ky = 0; ky < n_launch_rows; ++ky) {
-    a.ky0 = ky * TY;
-    if (ky > 0) a.part_b = nullptr;   // the bias column rides with the first kernel row only
+    a.ky0 = ky0_first + ky * TY;
+    if (a.ky0 > 0) a.part_b = nullptr;   // the bias column rides with the first kernel row only
     hipLaunchKernelGGL(kern, dim3((a.n_wgs + 7) / 8 * 8), dim3(512), G::LDS, s, a);
   }
   return hipGetLastError();
@@ -505,7 +505,10 @@ hipError_t launch_conv_wgrad_split(int ks, const void* g, const void* in, const 
   hipError_t e;
   if (ks == 3) e = p.nkx == 3 ? launch_wgs_t<3, 3, 3, 1>(a, 1, s) : launch_wgs_t<3, 3, 2, 2>(a, 1, s);
   else if (ks == 1) e = p.nkx == 3 ? launch_wgs_t<1, 1, 3, 2>(a, 1, s) : launch_wgs_t<1, 1, 2, 2>(a, 1, s);
-  else e = launch_wgs_t<5, 1, 2, 2>(a, 5, s);   // one kernel row per launch: five tap accumulators
+  else {   // 5x5: kernel rows (0, 1), (2, 3), (4) — ten tap accumulators per wave, the gradient rows streamed three times instead of five
+    e = launch_wgs_t<5, 2, 2, 2>(a, 2, s);
+    if (e == hipSuccess) e = launch_wgs_t<5, 1, 2, 2>(a, 1, s, 4);
+  }
   if (e != hipSuccess) return e;
   const size_t n = (size_t)mblks * nblks * T * 1024 + (db ? (size_t)mblks * 32 : 0);
   hipLaunchKernelGGL(wgrad_s_finalize_kernel, dim3(int((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, part, a.part_b, mblks,

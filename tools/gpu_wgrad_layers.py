@@ -57,7 +57,7 @@ def main():
     tot = 0.0
     print(f"{'layer':12s} {'shape':>22s} {'stream us':>10s} {'finalize us':>11s} {'TFLOP/s x3':>10s} {'frac':>6s}")
     for nm, b, h, w, cout, cin, ks in L:
-        per = 5 if ks == 5 else 1
+        per = 3 if ks == 5 else 1   # 5x5: kernel rows (0, 1), (2, 3), (4)
         s = stream[i:i + REPS * per]; i += REPS * per
         f = fin[j:j + REPS]; j += REPS
         if len(s) < REPS * per or len(f) < REPS:
