@@ -601,7 +601,7 @@ def secondary_dm_step(dev):
     from dfnet_amd import engine as eng, synthetic as syn
     from dfnet_amd.dfnet import DFNet
     import dfnet_amd.direct_feature_matching as dfm
-    from dfnet_amd.direct_feature_matching import matching_step_grad, train_on_batch
+    from dfnet_amd.direct_feature_matching import matching_step_grad, train_on_batch, train_on_batch_device
     from dfnet_amd.nerfw import HipQuery
     from oracle import dfnet_oracle as dor, nerfh_oracle as orc
     T = torch.from_numpy
@@ -636,7 +636,10 @@ def secondary_dm_step(dev):
 
     pose_ms, out = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, hwf, True, dev, setup, **kw))
     opt = torch.optim.Adam(model.parameters(), lr=1e-7)
-    step = lambda: train_on_batch(args, data, model, feat_model, gt, hist, hwf, opt, True, dev, setup, **kw)
+    # the step as train_on_epoch runs it (losses stay on the device, one wait per epoch); train_on_batch itself returns host floats
+    # like the reference and so waits for the device every step: timed separately below
+    step = lambda: train_on_batch_device(args, data, model, feat_model, gt, hist, hwf, opt, True, dev, setup, **kw)
+    step_host = lambda: train_on_batch(args, data, model, feat_model, gt, hist, hwf, opt, True, dev, setup, **kw)
     # the reference's form first: every pyramid level computed, the loss's level index_selected afterwards; then the shipped default,
     # which computes only the level(s) of feature_matching_lvl (bit-identical loss and gradients: tests/test_gpu_grad.py), alternated
     all_ms, pruned_ms = [], []
@@ -646,6 +649,7 @@ def secondary_dm_step(dev):
         dfm.PRUNE_FEATURE_LEVELS = True
         pruned_ms.append(timed(step)[0])
     full_ms, full_all_ms = sorted(pruned_ms)[1], sorted(all_ms)[1]
+    host_ms = timed(step_host)[0]
     # oracle composition (forward only) from the same predicted pose
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -671,7 +675,11 @@ def secondary_dm_step(dev):
     return {"workload": "BASELINE configs[4] per-GPU shape: DFNet_dm step, batch 4, 240x320 frames, NeRF-H render 60x80 at 64+128 "
                         "+ bicubic x4, level-0 cosine feature loss + photometric + pose terms",
             "forward_backward_to_pose_ms": pose_ms, "full_step_ms": full_ms, "full_step_all_levels_ms": full_all_ms,
-            "full_step_is": "all 28 regressor gradients + Adam (torch.optim) + device-side re-pack of the updated weights; full_step_ms = the "
+            "full_step_returning_host_floats_ms": host_ms,
+            "full_step_is": "all 28 regressor gradients + Adam (torch.optim) + device-side re-pack of the updated weights, as train_on_epoch runs "
+                            "it: the step's loss / PSNR stay on the device and the host waits once per epoch (train_on_batch_device); "
+                            "full_step_returning_host_floats_ms = train_on_batch with the reference's signature (numpy floats: one device wait "
+                            "per step).  full_step_ms = the "
                             "shipped default: the frozen feature extractor computes only the pyramid level(s) of feature_matching_lvl = [0] "
                             "(the loss reads no other: the reference computes all three and index_selects, direct_feature_matching.py:354-357); "
                             "full_step_all_levels_ms = all three levels computed as the reference does; same loss and gradients bit for bit; "
@@ -782,13 +790,14 @@ def secondary_nerfh_train(dev):
     ld_ref, _, g_ref, _ = orc.train_step(rows, target, c, f, T(ea), T(et), NC, NI, *draws, perturb=1., raw_noise_std=1.)
     cpu_s = time.perf_counter() - t0
     par = {}
-    for tag, exact in (("fused", False), ("exact", True)):
-        tr.exact = exact
+    for tag, exact, split in (("fused", False, False), ("fused_split", False, True), ("exact", True, False)):
+        tr.exact, tr.fused_split = exact, split
         ld, _, _ = tr.train_step(o.to(dev), d.to(dev), hist.to(dev), target.to(dev), NC, NI, NEAR, FAR, perturb=1., raw_noise_std=1.,
                                  draws=tuple(t.to(dev) for t in draws))
         par[tag] = {"worst_rel_l2_over_64_gradients": max(float((p.grad.cpu().double() - g_ref[k].double()).norm() / g_ref[k].double().norm())
                                                            for k, p in zip(tr.names, tr.params)),
                     "worst_loss_term_rel_diff": max(abs(float(ld[k]) - float(ld_ref[k])) / abs(float(ld_ref[k])) for k in ld)}
+    tr.flush_range_check()
     range_flags = E.range_flags()
     # timing at the reference's batch
     R = 1536
@@ -810,15 +819,16 @@ def secondary_nerfh_train(dev):
 
     draws_t = tr.draw(R, NC, NI, 1., dev)
     ms = {}
-    for tag, exact in (("exact", True), ("fused", False)):
-        tr.exact = exact
+    for tag, exact, split in (("exact", True, False), ("fused_split", False, True), ("fused", False, False)):
+        tr.exact, tr.fused_split = exact, split
         ms[tag] = timed(step)
         ms[tag + "_forward"] = timed(lambda: tr.forward(o, d, hist[:1], NC, NI, NEAR, FAR, draws_t[0], None, 0., draws_t[2]))
     mac_fwd = R * (NC * (MAC_COARSE + 128 * 128 + 64 * (128 + 27) + 64 * 3) + (NC + NI) * MAC_FINE)
-    # what the fused step moves through HBM: every layer input X_l and every pre-activation gradient G_l as split-f16 operands
-    # (4 bytes per element), written once by the chains and read once by the weight-gradient stream
+    # what the fused step moves through HBM: every layer input X_l and every pre-activation gradient G_l, written once by the chains
+    # and read once by the weight-gradient stream — the fine network's as ONE f16 plane (2 bytes per element), the coarse network's
+    # as hi | lo planes (4 bytes): csrc/nerfh_fused_train.h planes_of()
     wt_f, wt_c = -(-R * (NC + NI) // 256) * 8, -(-R * NC // 256) * 8
-    stored = (wt_f * (96 + 98) + wt_c * (80 + 80)) * 2048
+    stored = wt_f * (96 + 98) * 1024 + wt_c * (80 + 80) * 2048
     tf = 6.0 * mac_fwd / (ms["fused"] * 1e-3) / 1e12
     return {"workload": "one NeRF-H optimisation step (run_nerf.py:32-80): 1536 random rays, 64+128 samples, netwidth 128, perturb 1: "
                         "training-mode render, NerfWLoss, gradients of all 64 parameter tensors, Adam",
@@ -828,14 +838,18 @@ def secondary_nerfh_train(dev):
             "algorithmic_TFLOPs": tf, "f16_mfma_frac_of_nominal": 3.0 * tf / PEAK_TFLOPS["f16"], "frac_of_sustained_mfma": of_sustained(3.0 * tf),
             "flops_note": "forward 2 x MAC, data gradients 2 x MAC, weight gradients 2 x MAC; x 3 f16 MFMAs per product against the 2.5 PFLOP/s peak",
             "stored_operand_bytes_per_step": stored,
+            "fused_split_step": {"step_ms": ms["fused_split"], "stored_operand_bytes_per_step": (wt_f * (96 + 98) + wt_c * (80 + 80)) * 2048,
+                                 "what": "DFN_TRAIN_FUSED_SPLIT: the fine network's stored operands as hi | lo planes too (the round-4 layout)"},
             "hbm_GBps_floor_over_the_step": 2.0 * stored / (ms["fused"] * 1e-3) / 1e9,
             "hbm_note": "X_l and G_l written once (chains) and read once (weight-gradient stream): 2 x stored bytes over the WHOLE step time — "
-                        "a floor; per kernel: profiles/r04_train_step_kernel_stats.csv",
+                        "a floor; per kernel: profiles/r05_train_step_kernel_stats.csv.  Fine network: one f16 plane per stored operand "
+                        "(round 4: hi | lo, 4.67 GB per step), coarse network: hi | lo",
+            "range_check": "NerfHTrainer.range_check = 'skip': the range flag is read without draining the stream; a flagged step leaves zero gradients",
             "range_flags_after_the_steps": range_flags,
             "exact_fp32_step": {"step_ms": ms["exact"], "forward_ms": ms["exact_forward"], "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), layer by layer, "
                                 "activations in HBM (DFN_TRAIN_EXACT; any netwidth)",
                                 "fp32_mfma_frac": 6.0 * mac_fwd / (ms["exact"] * 1e-3) / 1e12 / PEAK_TFLOPS["f32"]},
-            "parity_256_rays_vs_oracle_autograd": {"fused": par["fused"], "exact": par["exact"], "raw_noise_std": 1.0, "cpu_oracle_step_s": cpu_s}}
+            "parity_256_rays_vs_oracle_autograd": {"fused": par["fused"], "fused_split": par["fused_split"], "exact": par["exact"], "raw_noise_std": 1.0, "cpu_oracle_step_s": cpu_s}}
 
 
 def secondary_trained_weights(dev):

@@ -39,11 +39,16 @@ SIGNATURES = {
     "dfn_feature_cosine_state_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dfn_feature_cosine_forward": (c_int, [_P, c_size_t, _P, c_size_t, _P, c_int, c_int, c_int, c_size_t, _P, _P, c_size_t, _P]),
     "dfn_feature_cosine_backward": (c_int, [_P, c_size_t, _P, c_size_t, _P, c_int, c_int, c_int, c_size_t, _P, _P, _P, c_size_t, _P]),
+    "dfn_dm_loss_scratch_bytes": (c_size_t, []),
+    "dfn_dm_loss_forward": (c_int, [_P, _P, c_size_t, _P, _P, c_int, _P, c_float, c_float, c_float, _P, _P, _P]),
+    "dfn_dm_loss_backward": (c_int, [_P, _P, c_size_t, _P, _P, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
     "dfn_nerfh_set_render_options": (c_int, [_P, c_int]),
     "dfn_nerfh_range_status": (c_int, [_P, POINTER(c_int), _P]),
+    "dfn_nerfh_range_status_async": (c_int, [_P, _P, _P]),
     "dfn_ndc_rays": (c_int, [c_int, c_int, c_float, c_float, _P, _P, c_size_t, _P, _P, _P]),
     "dfn_sample_fine_opt": (c_int, [_P, c_size_t, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
     "dfn_raygen": (c_int, [c_int, c_int, c_float, _P, _P, _P, _P, _P]),
+    "dfn_raygen_frames": (c_int, [c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "dfn_posenc": (c_int, [_P, c_size_t, c_int, c_int, _P, _P]),
     "dfn_mlp_coarse": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_float, c_float, _P, _P]),
     "dfn_coarse_weights": (c_int, [_P, _P, c_size_t, c_int, _P, _P]),
@@ -64,12 +69,14 @@ SIGNATURES = {
     "dfn_mlp_fine_backward_saved": (c_int, [_P, c_int, _P, _P, _P, c_size_t, _P, c_int, _P, _P, _P, _P, _P]),
     "dfn_ray_grad_reduce": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, _P, _P, _P, _P]),
     "dfn_raygen_backward": (c_int, [c_int, c_int, c_float, _P, _P, _P, _P]),
+    "dfn_raygen_frames_backward": (c_int, [c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     "dfn_render_backward_workspace_bytes": (c_size_t, [c_size_t, c_int, c_int]),
     "dfn_render_rays_backward": (c_int, [_P, c_int, _P, _P, _P, _P, c_size_t, c_size_t, c_int, c_int, c_float, c_float,
                                          _P, _P, _P, _P, _P, c_size_t, _P]),
     "dfn_render_image_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_float, c_float, c_float, c_int, c_int, _P,
                                           _P, _P, _P, c_size_t, _P]),
     "dfn_upsample_bicubic": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dfn_upsample_bicubic_frames": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dfn_dfnet_create": (c_int, [c_int, c_int, POINTER(c_void_p)]),
     "dfn_dfnet_destroy": (c_int, [_P]),
     "dfn_dfnet_set_param": (c_int, [_P, c_char_p, _P, c_size_t]),
@@ -79,6 +86,7 @@ SIGNATURES = {
                                   _P, c_size_t, _P]),
     "dfn_dfnet_forward_levels": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "dfn_upsample_bicubic_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dfn_upsample_bicubic_frames_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dfn_dfnet_backward_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dfn_dfnet_backward_input": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
     "dfn_dfnet_backward_params_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),

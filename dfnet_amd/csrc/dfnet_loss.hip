@@ -410,3 +410,93 @@ extern "C" int dfn_feature_cosine_backward(const float* fr, size_t level_stride_
   if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_feature_cosine_backward: %s", hipGetErrorString(e));
   return DFN_OK;
 }
+
+// ------------------------------------------------------------------------------------------ DFNet_dm loss block
+// feature/direct_feature_matching.py:359-370: photo_loss = mean((rgb - target)^2) over the [B,3,H,W] frames, pose_loss =
+// mse_loss(pose_, pose) over [B,12], loss = w[0] pose_loss + w[1] photo_loss + w[2] feat_loss (combine_loss).  As torch ops this is
+// three reductions, five scalar products / sums and ~15 autograd nodes of one tiny kernel each — 0.5 ms of an otherwise idle GPU
+// per step (the host cannot enqueue them faster).  Here: one partial-sum pass + one finishing block forward, one element-wise pass
+// backward.  Sums in fp64 over fixed chunks in a fixed order (deterministic).
+namespace dfn {
+namespace {
+constexpr int kDmBlocks = 256;
+__global__ __launch_bounds__(256) void dm_loss_partial_kernel(const float* __restrict__ rgb, const float* __restrict__ tgt, size_t n,
+                                                             double* __restrict__ part) {
+  __shared__ double red[4];
+  const size_t per = (n + gridDim.x - 1) / gridDim.x;
+  const size_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double acc = 0.;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float d = rgb[i] - tgt[i];
+    acc += double(d * d);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// out[0..3] = loss, photo_loss, pose_loss, feat_loss
+__global__ __launch_bounds__(64) void dm_loss_finish_kernel(const double* __restrict__ part, int n_part, size_t n, const float* __restrict__ pose,
+                                                           const float* __restrict__ pose_gt, int n_pose, const float* __restrict__ feat,
+                                                           float w_pose, float w_photo, float w_feat, float* __restrict__ out) {
+  double s = 0.;
+  for (int i = threadIdx.x; i < n_part; i += 64) s += part[i];
+  double p = 0.;
+  for (int i = threadIdx.x; i < n_pose; i += 64) {
+    const float d = pose[i] - pose_gt[i];
+    p += double(d * d);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d, 64); p += __shfl_xor(p, d, 64); }
+  if (threadIdx.x == 0) {
+    const float photo = float(s / double(n)), pl = float(p / double(n_pose)), fl = feat ? feat[0] : 0.f;
+    out[1] = photo; out[2] = pl; out[3] = fl;
+    out[0] = w_pose * pl + w_photo * photo + w_feat * fl;   // left to right, as the reference's expression
+  }
+}
+__global__ __launch_bounds__(256) void dm_loss_backward_kernel(const float* __restrict__ rgb, const float* __restrict__ tgt, size_t n,
+                                                              const float* __restrict__ pose, const float* __restrict__ pose_gt, int n_pose,
+                                                              float w_pose, float w_photo, float w_feat, const float* __restrict__ g,
+                                                              float* __restrict__ grad_rgb, float* __restrict__ grad_pose,
+                                                              float* __restrict__ grad_feat) {
+  const float gl = g[0];
+  const float cr = gl * w_photo * 2.f / float(n);
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+    grad_rgb[i] = cr * (rgb[i] - tgt[i]);
+  if (blockIdx.x == 0) {
+    const float cp = gl * w_pose * 2.f / float(n_pose);
+    for (int i = threadIdx.x; i < n_pose; i += blockDim.x) grad_pose[i] = cp * (pose[i] - pose_gt[i]);
+    if (threadIdx.x == 0 && grad_feat) grad_feat[0] = gl * w_feat;
+  }
+}
+}  // namespace
+}  // namespace dfn
+
+extern "C" size_t dfn_dm_loss_scratch_bytes(void) { return dfn::kDmBlocks * sizeof(double); }
+extern "C" int dfn_dm_loss_forward(const float* rgb, const float* target, size_t n, const float* pose, const float* pose_gt, int n_pose,
+                                   const float* feat_loss, float w_pose, float w_photo, float w_feat, float* out4, void* scratch,
+                                   void* stream) {
+  if (!rgb || !target || !n || !pose || !pose_gt || n_pose < 1 || !out4 || !scratch)
+    return set_error(DFN_ERR_ARG, "dfn_dm_loss_forward: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* part = static_cast<double*>(scratch);
+  hipLaunchKernelGGL(dfn::dm_loss_partial_kernel, dim3(dfn::kDmBlocks), dim3(256), 0, s, rgb, target, n, part);
+  hipLaunchKernelGGL(dfn::dm_loss_finish_kernel, dim3(1), dim3(64), 0, s, part, dfn::kDmBlocks, n, pose, pose_gt, n_pose, feat_loss, w_pose,
+                     w_photo, w_feat, out4);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_dm_loss_forward: %s", hipGetErrorString(e));
+  return DFN_OK;
+}
+extern "C" int dfn_dm_loss_backward(const float* rgb, const float* target, size_t n, const float* pose, const float* pose_gt, int n_pose,
+                                    float w_pose, float w_photo, float w_feat, const float* grad_loss, float* grad_rgb, float* grad_pose,
+                                    float* grad_feat, void* stream) {
+  if (!rgb || !target || !n || !pose || !pose_gt || n_pose < 1 || !grad_loss || !grad_rgb || !grad_pose)
+    return set_error(DFN_ERR_ARG, "dfn_dm_loss_backward: bad argument");
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(dfn::dm_loss_backward_kernel, dim3(unsigned(blocks < 2048 ? blocks : 2048)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     rgb, target, n, pose, pose_gt, n_pose, w_pose, w_photo, w_feat, grad_loss, grad_rgb, grad_pose, grad_feat);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_dm_loss_backward: %s", hipGetErrorString(e));
+  return DFN_OK;
+}

@@ -440,18 +440,28 @@ extern "C" int dfn_nerfh_range_status(dfn_nerfh_t h, int* flags, void* stream) {
   return DFN_OK;
 }
 
+extern "C" int dfn_nerfh_range_status_async(dfn_nerfh_t h, int* host_flags, void* stream) {
+  if (!h || !host_flags) return set_error(DFN_ERR_ARG, "dfn_nerfh_range_status_async: null handle / destination");
+  if (!h->range_flag) { *host_flags = 0; return DFN_OK; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(range_fetch_kernel, dim3(1), dim3(1), 0, s, h->range_flag);   // read-and-clear, as dfn_nerfh_range_status
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(host_flags, h->range_flag + 1, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess)
+    return set_error(DFN_ERR_HIP, "dfn_nerfh_range_status_async: enqueueing the read failed");
+  return DFN_OK;
+}
+
 extern "C" int dfn_nerfh_commit(dfn_nerfh_t h) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_commit: null handle");
   for (const auto& kv : expected_shapes(h->desc))
     if (!h->params.count(kv.first)) return set_error(DFN_ERR_STATE, "dfn_nerfh_commit: parameter '%s' not set", kv.first.c_str());
   free_packed(h);
   dfn::fused::destroy_state(h);   // its tables follow the handle's geometry and scales: rebuilt on the next training step
-  if (!h->range_flag) {   // range guard of the narrow arithmetic modes: two device ints (flag, fetch slot), cleared here
-    if (hipMalloc(reinterpret_cast<void**>(&h->range_flag), 2 * sizeof(int)) != hipSuccess) {
+  if (!h->range_flag) {   // range guard of the narrow arithmetic modes: three device ints (flag, fetch slot, the training step's own word), cleared here
+    if (hipMalloc(reinterpret_cast<void**>(&h->range_flag), 3 * sizeof(int)) != hipSuccess) {
       h->range_flag = nullptr;
       return set_error(DFN_ERR_HIP, "dfn_nerfh_commit: allocating the range-guard flag failed");
     }
-    if (hipMemset(h->range_flag, 0, 2 * sizeof(int)) != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_nerfh_commit: clearing the range-guard flag failed");
+    if (hipMemset(h->range_flag, 0, 3 * sizeof(int)) != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_nerfh_commit: clearing the range-guard flag failed");
   }
   {  // generic-width path: plain device copies in canonical order
     std::vector<float> all;
@@ -761,6 +771,20 @@ extern "C" int dfn_upsample_bicubic(const float* in, int H, int W, int C, int ou
   return DFN_OK;
 }
 
+extern "C" int dfn_upsample_bicubic_frames(const float* in, int B, int H, int W, int C, int outH, int outW, int out_nchw, float* out,
+                                           void* stream) {
+  if (!in || !out || B < 1 || H < 1 || W < 1 || C < 1 || outH < 1 || outW < 1) return set_error(DFN_ERR_ARG, "dfn_upsample_bicubic_frames: bad argument");
+  CHECK_HIP(launch_bicubic(in, H, W, C, outH, outW, out, HS(stream), B, out_nchw != 0), "dfn_upsample_bicubic_frames");
+  return DFN_OK;
+}
+extern "C" int dfn_upsample_bicubic_frames_backward(const float* grad_out, int B, int H, int W, int C, int outH, int outW, int out_nchw,
+                                                    float* grad_in, void* stream) {
+  if (!grad_out || !grad_in || B < 1 || H < 1 || W < 1 || C < 1 || outH < 1 || outW < 1)
+    return set_error(DFN_ERR_ARG, "dfn_upsample_bicubic_frames_backward: bad argument");
+  CHECK_HIP(launch_bicubic_backward(grad_out, H, W, C, outH, outW, grad_in, HS(stream), B, out_nchw != 0), "dfn_upsample_bicubic_frames_backward");
+  return DFN_OK;
+}
+
 extern "C" int dfn_upsample_bicubic_backward(const float* grad_out, int H, int W, int C, int outH, int outW, float* grad_in,
                                              void* stream) {
   if (!grad_out || !grad_in || H < 1 || W < 1 || C < 1 || outH < 1 || outW < 1)
@@ -1014,6 +1038,20 @@ extern "C" int dfn_ray_grad_reduce(const float* grad_pts, const float* z_fine, c
   CHECK_HIP(launch_ray_grad_reduce(grad_pts, z_fine, rays_d, n_rays, Nf, derive_viewdirs, grad_rays_o, grad_rays_d, grad_viewdirs,
                                    HS(stream)),
             "dfn_ray_grad_reduce");
+  return DFN_OK;
+}
+
+extern "C" int dfn_raygen_frames(int B, int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d, float* viewdirs,
+                                 void* stream) {
+  if (B < 1 || H < 0 || W < 0 || !c2w || !rays_o || !rays_d || !(focal > 0)) return set_error(DFN_ERR_ARG, "dfn_raygen_frames: bad argument");
+  CHECK_HIP(launch_raygen(H, W, focal, c2w, rays_o, rays_d, viewdirs, HS(stream), B), "dfn_raygen_frames");
+  return DFN_OK;
+}
+extern "C" int dfn_raygen_frames_backward(int B, int H, int W, float focal, const float* grad_rays_o, const float* grad_rays_d,
+                                          float* grad_c2w, void* stream) {
+  if (B < 1 || H < 1 || W < 1 || !grad_rays_o || !grad_rays_d || !grad_c2w || !(focal > 0))
+    return set_error(DFN_ERR_ARG, "dfn_raygen_frames_backward: bad argument");
+  CHECK_HIP(launch_raygen_backward(H, W, focal, grad_rays_o, grad_rays_d, grad_c2w, HS(stream), B), "dfn_raygen_frames_backward");
   return DFN_OK;
 }
 

@@ -468,7 +468,7 @@ int make_jobs(bool fine, const NetWs& n, const State& st, float*& partial, WJob*
   }
   return wgs;
 }
-Ws carve(char* base, const dfn_nerfh_desc& d, size_t R, int Nc, int Ni) {
+Ws carve(char* base, const dfn_nerfh_desc& d, size_t R, int Nc, int Ni, bool split_fine) {
   Ws w{};
   const Geo g = geo_of(d);
   const size_t Nf = size_t(Nc) + Ni;
@@ -494,8 +494,8 @@ Ws carve(char* base, const dfn_nerfh_desc& d, size_t R, int Nc, int Ni) {
     n.masks = reinterpret_cast<uint32_t*>(take(n.n_wt * kMaskWords * 64 * 4));
     n.gscale = takef(size_t(GA_COUNT) * n.n_wt);
     size_t xb = 0, gb = 0;
-    for (int a = 0; a < (f ? int(XA_COUNT) : kXCountCoarse); ++a) { n.x_off[a] = xb; xb += n.n_wt * kXChunks[a] * kChunkBytes; }
-    for (int a = 0; a < (f ? int(GA_COUNT) : kGCountCoarse); ++a) { n.g_off[a] = gb; gb += n.n_wt * (f ? kGChunksFine : kGChunksCoarse)[a] * kChunkBytes; }
+    for (int a = 0; a < (f ? int(XA_COUNT) : kXCountCoarse); ++a) { n.x_off[a] = xb; xb += n.n_wt * kXChunks[a] * size_t(1024 * planes_of(f, split_fine)); }
+    for (int a = 0; a < (f ? int(GA_COUNT) : kGCountCoarse); ++a) { n.g_off[a] = gb; gb += n.n_wt * (f ? kGChunksFine : kGChunksCoarse)[a] * size_t(1024 * planes_of(f, split_fine)); }
     n.x = take(xb);
     n.g = take(gb);
   }
@@ -548,12 +548,13 @@ ChainArgs chain_args(const dfn_nerfh_s* h, const State& st, bool fine, int pass,
   a.n_rays = (long long)R;
   a.n_samples = Ns;
   a.in_scale = train_scale(h, fine);
-  a.status = h->range_flag;
+  a.status = h->range_flag + 2;   // the step's own word (GuardArgs)
   return a;
 }
 }  // namespace
 
-size_t workspace_bytes(const dfn_nerfh_s* h, size_t R, int Nc, int Ni) { return carve(nullptr, h->desc, R, Nc, Ni).total; }
+// (sized for the larger layout, so that a workspace stays valid across dfn_nerfh_set_train_mode)
+size_t workspace_bytes(const dfn_nerfh_s* h, size_t R, int Nc, int Ni) { return carve(nullptr, h->desc, R, Nc, Ni, true).total; }
 
 int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_o, const float* rays_d, const float* hist, size_t hist_rows,
                   size_t R, int Nc, int Ni, float near, float far, const float* t_rand, const float* noise, float raw_noise_std,
@@ -562,7 +563,7 @@ int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_
   if (!h->fused)
     if (int rc = build_state(h)) return rc;
   const State& st = *static_cast<State*>(h->fused);
-  const Ws w = carve(static_cast<char*>(workspace), h->desc, R, Nc, Ni);
+  const Ws w = carve(static_cast<char*>(workspace), h->desc, R, Nc, Ni, h->train_split_fine);
   if (w.total > workspace_bytes_) return set_error(DFN_ERR_ARG, "dfn_nerfh_train_forward: workspace too small (%zu < %zu)", workspace_bytes_, w.total);
   const Geo g = geo_of(h->desc);
   const dfn_nerfh_desc& d = h->desc;
@@ -577,10 +578,11 @@ int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_
             "train forward: coarse ray inputs");
   CHECK_HIP(ray_inputs(w.view, hist, hist_rows, emb_a, emb_t, d.hist_bin, d.dim_a, d.dim_t, d.n_vocab, R, w.dir_f, g.ld_df, w.t_in, g.ld_t, s),
             "train forward: fine ray inputs");
+  CHECK_HIP(hipMemsetAsync(h->range_flag + 2, 0, sizeof(int), s), "train forward: clearing the step's range word");
   // the step's weights -> staging units of the four chain passes (hi | lo split at the handle's operand scale)
   for (int f = 0; f < 2; ++f)
     for (int pass = 0; pass < 2; ++pass)
-      if (int rc = pack_blob(st.blob[f][pass], params, train_scale(h, f), h->range_flag, s)) return rc;
+      if (int rc = pack_blob(st.blob[f][pass], params, train_scale(h, f), h->range_flag + 2, s)) return rc;
   CHECK_HIP(launch_ray_bias_train(pc[2 * DIR], pc[2 * DIR + 1], W + g.kd_c, g.kd_c, w.dir_c, g.ld_dc, nullptr, nullptr, 0, 0, nullptr, 0, R,
                                   w.net[0].ray_bias, s),
             "train forward: coarse per-ray bias");
@@ -591,14 +593,14 @@ int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_
   {
     ChainArgs a = chain_args(h, st, false, 0, w.net[0], rays_o, rays_d, R, Nc);
     a.raw_out = w.raw_c;
-    CHECK_HIP(launch_train_forward_chain(false, a, n_cu, s), "train forward: coarse chain");
+    CHECK_HIP(launch_train_forward_chain(false, planes_of(false, h->train_split_fine), a, n_cu, s), "train forward: coarse chain");
   }
   CHECK_HIP(sample_fine_train(w.raw_c, w.net[0].z, noise, raw_noise_std, u, R, Nc, Ni, w.net[1].z, rgb0, disp0, acc0, z_std, s),
             "train forward: coarse composite + sampling");
   {
     ChainArgs a = chain_args(h, st, true, 0, w.net[1], rays_o, rays_d, R, Nf);
     a.raw_out = raw;
-    CHECK_HIP(launch_train_forward_chain(true, a, n_cu, s), "train forward: fine chain");
+    CHECK_HIP(launch_train_forward_chain(true, planes_of(true, h->train_split_fine), a, n_cu, s), "train forward: fine chain");
   }
   CHECK_HIP(launch_composite_fine(raw, w.net[1].z, R, Nf, 0.1f, 0, rgb, disp, acc, nullptr, nullptr, beta, s), "train forward: fine composite");
   return DFN_OK;
@@ -609,7 +611,7 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
                    float g_tsigma, const float* g_tsigma_dense, float* const* grads, void* workspace, size_t workspace_bytes_, hipStream_t s) {
   if (!h->fused) return set_error(DFN_ERR_STATE, "dfn_nerfh_train_backward: no forward pass on this handle");
   const State& st = *static_cast<State*>(h->fused);
-  const Ws w = carve(static_cast<char*>(workspace), h->desc, R, Nc, Ni);
+  const Ws w = carve(static_cast<char*>(workspace), h->desc, R, Nc, Ni, h->train_split_fine);
   if (w.total > workspace_bytes_) return set_error(DFN_ERR_ARG, "dfn_nerfh_train_backward: workspace too small (%zu < %zu)", workspace_bytes_, w.total);
   const Geo g = geo_of(h->desc);
   const dfn_nerfh_desc& d = h->desc;
@@ -628,11 +630,11 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
   // data-gradient chains: every pre-activation gradient stored once, in the operand layout the weight-gradient stream reads
   {
     ChainArgs a = chain_args(h, st, true, 1, w.net[1], nullptr, nullptr, R, Nf);
-    CHECK_HIP(launch_train_backward_chain(true, a, n_cu, s), "train backward: fine chain");
+    CHECK_HIP(launch_train_backward_chain(true, planes_of(true, h->train_split_fine), a, n_cu, s), "train backward: fine chain");
   }
   {
     ChainArgs a = chain_args(h, st, false, 1, w.net[0], nullptr, nullptr, R, Nc);
-    CHECK_HIP(launch_train_backward_chain(false, a, n_cu, s), "train backward: coarse chain");
+    CHECK_HIP(launch_train_backward_chain(false, planes_of(false, h->train_split_fine), a, n_cu, s), "train backward: coarse chain");
   }
   // weight gradients: one stream launch over the jobs of both networks, then the fixed-order reduction into the .grad tensors
   {
@@ -644,7 +646,7 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
       wa.n_jobs = 0;
       const int wgs = make_jobs(f, w.net[f], st, part, wa.job, wa.n_jobs);
       wa.n_wt = int(w.net[f].n_wt);
-      CHECK_HIP(launch_wgrad_stream(wa, wgs, s), "train backward: weight-gradient stream");
+      CHECK_HIP(launch_wgrad_stream(wa, wgs, planes_of(f, h->train_split_fine), s), "train backward: weight-gradient stream");
       ReduceArgs ra{};
       std::memcpy(ra.job, wa.job, sizeof(wa.job));
       ra.n_jobs = wa.n_jobs;
@@ -655,9 +657,9 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
   }
   // columns beyond `final` of dir_encoding.0 / transient_encoding.0 multiply per-ray inputs: per-ray sums of the stored gradients,
   // then the small products of the layer-by-layer path (nerfh_train.hip) over rays
-  CHECK_HIP(launch_frag_ray_sum(w.net[1].g + w.net[1].g_off[GA_CAT], 8, w.net[1].gscale + size_t(GA_CAT) * w.net[1].n_wt, R, Nf, w.gsum_f, W, s),
+  CHECK_HIP(launch_frag_ray_sum(w.net[1].g + w.net[1].g_off[GA_CAT], 8, planes_of(true, h->train_split_fine), w.net[1].gscale + size_t(GA_CAT) * w.net[1].n_wt, R, Nf, w.gsum_f, W, s),
             "train backward: per-ray sums (fine)");
-  CHECK_HIP(launch_frag_ray_sum(w.net[0].g + w.net[0].g_off[GA_CAT], 4, w.net[0].gscale + size_t(GA_CAT) * w.net[0].n_wt, R, Nc, w.gsum_c, W2, s),
+  CHECK_HIP(launch_frag_ray_sum(w.net[0].g + w.net[0].g_off[GA_CAT], 4, planes_of(false, h->train_split_fine), w.net[0].gscale + size_t(GA_CAT) * w.net[0].n_wt, R, Nc, w.gsum_c, W2, s),
             "train backward: per-ray sums (coarse)");
   const int ldw_dir_f = W + g.kd_f, ldw_dir_c = W + g.kd_c, ldw_te0 = W + g.nt;
   // transient_encoding.0 tail: gsum_f[:, 0:64]
@@ -670,6 +672,22 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
   CHECK_HIP(embedding_scatter(w.gray, g.ld_df, 0, hist, hist_rows, d.hist_bin, d.dim_a, d.n_vocab, R, g_emb_a, s), "train: embedding_a grad");
   // dir_encoding.0 tail (coarse)
   CHECK_HIP(gemm_wgrad(w.gsum_c, W2, W2, Seg{w.dir_c, g.ld_dc, g.kd_c, 1, W}, gc[2 * DIR], ldw_dir_c, nullptr, w.wscratch, (long long)R, s), "train wgrad: coarse dir tail");
+  {   // a step whose operands left the split-f16 range leaves zeros, not clamped gradients (GuardArgs)
+    GuardArgs ga{};
+    for (int f = 0; f < 2; ++f)
+      for (int l = 0; l < (f ? kFineLayers_ : kCoarseLayers_); ++l) {
+        const int p = weight_param(f, l);
+        ga.grads[p] = grads[p]; ga.numel[p] = uint32_t(rows_of(l)) * uint32_t(cols_of(l, f, g));
+        ga.grads[p + 1] = grads[p + 1]; ga.numel[p + 1] = uint32_t(rows_of(l));
+      }
+    const int pe = kCoarseParams + kFineParams;
+    ga.grads[pe] = g_emb_a; ga.numel[pe] = uint32_t(d.n_vocab) * uint32_t(d.dim_a);
+    ga.grads[pe + 1] = g_emb_t; ga.numel[pe + 1] = uint32_t(d.n_vocab) * uint32_t(d.dim_t);
+    ga.n = pe + 2;
+    ga.step_flag = h->range_flag + 2;
+    ga.range_flag = h->range_flag;
+    CHECK_HIP(launch_grads_guard(ga, s), "train backward: range guard");
+  }
   return DFN_OK;
 }
 

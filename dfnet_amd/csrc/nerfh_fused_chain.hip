@@ -54,12 +54,17 @@ DFN_DEV void init_stager(Stager& st, const ChainArgs& a) {
 }
 
 // One stored array of this wavefront's tile: chunk c -> [hi plane | lo plane], lane (p, h) at 16-byte slot 2 p + h.
-template <int KC, int N>
+template <int KC, int PL, int N>
 DFN_DEV void store_array(char* base, const F (&v)[N]) {
 #pragma unroll
   for (int c = 0; c < KC; ++c) {   // written once, read once by another kernel: non-temporal
-    __builtin_nontemporal_store(v[c].hi, reinterpret_cast<half8*>(base + c * kChunkBytes));
-    __builtin_nontemporal_store(v[c].lo, reinterpret_cast<half8*>(base + c * kChunkBytes + 1024));
+    if constexpr (PL == 2) {
+      __builtin_nontemporal_store(v[c].hi, reinterpret_cast<half8*>(base + c * 2048));
+      __builtin_nontemporal_store(v[c].lo, reinterpret_cast<half8*>(base + c * 2048 + 1024));
+    } else {   // one plane: hi is the TRUNCATED half of the value (store_hidden); hi + lo in f16 arithmetic rounds the exact sum to nearest
+      const half8 r = v[c].hi + v[c].lo;
+      __builtin_nontemporal_store(r, reinterpret_cast<half8*>(base + c * 1024));
+    }
   }
 }
 
@@ -91,7 +96,7 @@ size_t chain_wave_tiles(long long n_points) {
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <bool FINE>
+template <bool FINE, int PL>
 __global__ __launch_bounds__(WAVES * 64, 1) void train_fwd_chain_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RAWC = FINE ? 9 : 4;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_fwd_chain_kernel(ChainArg
     const float* const norb[NB] = {};
     const size_t wt = size_t(tile) * WAVES + st.wave;
     uint32_t* mwords = a.masks + wt * (kMaskWords * 64) + st.lane;
-    auto arr = [&](int id, int kc) { return a.arrays + a.arr_off[id] + wt * size_t(kc) * kChunkBytes + lane_slot; };
+    auto arr = [&](int id, int kc) { return a.arrays + a.arr_off[id] + wt * size_t(kc) * (1024 * PL) + lane_slot; };
     f32x16 head[NB], carry[NB];
     uint32_t m2[2], m1[1];
     float o[RAWC];
@@ -128,19 +133,19 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_fwd_chain_kernel(ChainArg
     {
       F pe[NB][PC], u[NB][HC];
       posenc_xyz<P, false, NB, PC>(x, h, pe);
-      store_array<PC>(arr(XA_PE, PC), pe[0]);
+      store_array<PC, PL>(arr(XA_PE, PC), pe[0]);
       TF_LAYER(PC, 4, true, false, false, pe, u, norb);
       relu_mask<P, HC>(u[0], m2); mwords[0 * 64] = m2[0]; mwords[1 * 64] = m2[1];
-      store_array<HC>(arr(XA_H1, HC), u[0]);
+      store_array<HC, PL>(arr(XA_H1, HC), u[0]);
       TF_LAYER(HC, 4, true, false, false, u, hid, norb);
       relu_mask<P, HC>(hid[0], m2); mwords[2 * 64] = m2[0]; mwords[3 * 64] = m2[1];
-      store_array<HC>(arr(XA_H2, HC), hid[0]);
+      store_array<HC, PL>(arr(XA_H2, HC), hid[0]);
       TF_LAYER(HC, 4, true, false, false, hid, u, norb);
       relu_mask<P, HC>(u[0], m2); mwords[4 * 64] = m2[0]; mwords[5 * 64] = m2[1];
-      store_array<HC>(arr(XA_H3, HC), u[0]);
+      store_array<HC, PL>(arr(XA_H3, HC), u[0]);
       TF_LAYER(HC, 4, true, false, false, u, hid, norb);
       relu_mask<P, HC>(hid[0], m2); mwords[6 * 64] = m2[0]; mwords[7 * 64] = m2[1];
-      store_array<HC>(arr(XA_H4, HC), hid[0]);
+      store_array<HC, PL>(arr(XA_H4, HC), hid[0]);
       {
         F cat[NB][PC + HC];   // torch.cat([input_xyz, xyz_], -1) (nerfw.py:328-330)
         {   // the encoding is recomputed here (bit-identical): cheaper than 32 registers live across four layers
@@ -159,27 +164,27 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_fwd_chain_kernel(ChainArg
         TF_LAYER(PC + HC, 4, true, false, false, cat, u, norb);
       }
       relu_mask<P, HC>(u[0], m2); mwords[8 * 64] = m2[0]; mwords[9 * 64] = m2[1];
-      store_array<HC>(arr(XA_H5, HC), u[0]);
+      store_array<HC, PL>(arr(XA_H5, HC), u[0]);
       TF_LAYER(HC, 4, true, false, false, u, hid, norb);
       relu_mask<P, HC>(hid[0], m2); mwords[10 * 64] = m2[0]; mwords[11 * 64] = m2[1];
-      store_array<HC>(arr(XA_H6, HC), hid[0]);
+      store_array<HC, PL>(arr(XA_H6, HC), hid[0]);
       TF_LAYER(HC, 4, true, false, false, hid, u, norb);
       relu_mask<P, HC>(u[0], m2); mwords[12 * 64] = m2[0]; mwords[13 * 64] = m2[1];
-      store_array<HC>(arr(XA_H7, HC), u[0]);
+      store_array<HC, PL>(arr(XA_H7, HC), u[0]);
       TF_LAYER(HC, 4, true, false, false, u, hid, norb);
       relu_mask<P, HC>(hid[0], m2); mwords[14 * 64] = m2[0]; mwords[15 * 64] = m2[1];
-      store_array<HC>(arr(XA_H8, HC), hid[0]);
+      store_array<HC, PL>(arr(XA_H8, HC), hid[0]);
     }
     {
       F fin[NB][HC], dummy[NB][SC];
       TF_LAYER(HC, 4, false, true, false, hid, fin, norb);   // xyz_encoding_final (no activation) + static_sigma (5th M-block, row 0)
       o[3] = softplus(head[0][0]);
-      store_array<HC>(arr(XA_FIN, HC), fin[0]);
+      store_array<HC, PL>(arr(XA_FIN, HC), fin[0]);
       {
         F de[NB][QC];
         TF_LAYER(HC, 2, true, false, true, fin, de, rb_dir);  // dir_encoding: per-ray bias = b + W[:, 128:] [pe_dir (, a)]
         relu_mask<P, QC>(de[0], m1); mwords[16 * 64] = m1[0];
-        store_array<QC>(arr(XA_DE, QC), de[0]);
+        store_array<QC, PL>(arr(XA_DE, QC), de[0]);
         TF_LAYER(QC, 0, false, true, false, de, dummy, norb); // static_rgb
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = sigmoid(head[0][c]);
@@ -188,16 +193,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_fwd_chain_kernel(ChainArg
         F t0[NB][QC], t1[NB][QC];
         TF_LAYER(HC, 2, true, false, true, fin, t0, rb_tr);   // transient_encoding.0: per-ray bias = b + W[:, 128:] t
         relu_mask<P, QC>(t0[0], m1); mwords[17 * 64] = m1[0];
-        store_array<QC>(arr(XA_T0, QC), t0[0]);
+        store_array<QC, PL>(arr(XA_T0, QC), t0[0]);
         TF_LAYER(QC, 2, true, false, false, t0, t1, norb);
         relu_mask<P, QC>(t1[0], m1); mwords[18 * 64] = m1[0];
-        store_array<QC>(arr(XA_T1, QC), t1[0]);
+        store_array<QC, PL>(arr(XA_T1, QC), t1[0]);
         TF_LAYER(QC, 2, true, false, false, t1, t0, norb);
         relu_mask<P, QC>(t0[0], m1); mwords[19 * 64] = m1[0];
-        store_array<QC>(arr(XA_T2, QC), t0[0]);
+        store_array<QC, PL>(arr(XA_T2, QC), t0[0]);
         TF_LAYER(QC, 2, true, false, false, t0, t1, norb);
         relu_mask<P, QC>(t1[0], m1); mwords[20 * 64] = m1[0];
-        store_array<QC>(arr(XA_T3, QC), t1[0]);
+        store_array<QC, PL>(arr(XA_T3, QC), t1[0]);
         TF_LAYER(QC, 0, false, true, false, t1, dummy, norb); // transient heads: rows 0..2 rgb, 3 sigma, 8 (C register 4) beta
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[4 + c] = sigmoid(head[0][c]);
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_fwd_chain_kernel(ChainArg
 }
 
 // ------------------------------------------------------------------------------------------ backward
-template <bool FINE>
+template <bool FINE, int PL>
 __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RAWC = FINE ? 9 : 4;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArg
     const float* const norb[NB] = {};
     const size_t wt = size_t(tile) * WAVES + st.wave;
     const uint32_t* mwords = a.masks + wt * (kMaskWords * 64) + st.lane;
-    auto arr = [&](int id, int kc) { return a.arrays + a.arr_off[id] + wt * size_t(kc) * kChunkBytes + lane_slot; };
+    auto arr = [&](int id, int kc) { return a.arrays + a.arr_off[id] + wt * size_t(kc) * (1024 * PL) + lane_slot; };
     // stored value = true gradient x 16 sp (x3_split's operand scale x the wave's running scale)
     auto note_scale = [&](int id, float sp_) { if (st.lane == 0) a.gscale[size_t(id) * n_wt + wt] = kX3ActScale * sp_; };
     f32x16 head[NB], carry[NB];
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArg
       clear<P>(drgb[0]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) set_slot<P>(drgb[0], c, g[c] * sp);
-      store_array<SC>(arr(GA_DRGB, SC), drgb[0]);
+      store_array<SC, PL>(arr(GA_DRGB, SC), drgb[0]);
       note_scale(GA_DRGB, sp);
       if constexpr (FINE) {
         F g0[NB][QC], g1[NB][QC];
@@ -279,23 +284,23 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArg
           for (int c = 0; c < 3; ++c) set_slot<P>(dth[0], c, g[4 + c] * sp);
           set_slot<P>(dth[0], 3, g[7] * sp);
           set_slot<P>(dth[0], 4, g[8] * sp);    // slot 4 of half 0 = row 8 = transient_beta
-          store_array<SC>(arr(GA_DTH, SC), dth[0]);
+          store_array<SC, PL>(arr(GA_DTH, SC), dth[0]);
           note_scale(GA_DTH, sp);
           m1[0] = mwords[20 * 64];
           TB_LAYER(SC, 2, dth, g1);              // transient heads^T -> d t3
         }
         apply_mask<P, QC>(g1[0], m1);
-        store_array<QC>(arr(GA_T3, QC), g1[0]);
+        store_array<QC, PL>(arr(GA_T3, QC), g1[0]);
         note_scale(GA_T3, sp);
         m1[0] = mwords[19 * 64];
         TB_LAYER(QC, 2, g1, g0);                 // transient_encoding.6^T -> d t2
         apply_mask<P, QC>(g0[0], m1);
-        store_array<QC>(arr(GA_T2, QC), g0[0]);
+        store_array<QC, PL>(arr(GA_T2, QC), g0[0]);
         note_scale(GA_T2, sp);
         m1[0] = mwords[18 * 64];
         TB_LAYER(QC, 2, g0, g1);                 // transient_encoding.4^T -> d t1
         apply_mask<P, QC>(g1[0], m1);
-        store_array<QC>(arr(GA_T1, QC), g1[0]);
+        store_array<QC, PL>(arr(GA_T1, QC), g1[0]);
         note_scale(GA_T1, sp);
         m1[0] = mwords[17 * 64];
         TB_LAYER(QC, 2, g1, g0);                 // transient_encoding.2^T -> d t0
@@ -305,12 +310,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArg
         apply_mask<P, QC>(g1[0], m1);
 #pragma unroll
         for (int i = 0; i < QC; ++i) { cat[0][i] = g0[0][i]; cat[0][QC + i] = g1[0][i]; }
-        store_array<HC>(arr(GA_CAT, HC), cat[0]);
+        store_array<HC, PL>(arr(GA_CAT, HC), cat[0]);
       } else {
         m1[0] = mwords[16 * 64];
         TB_LAYER(SC, 2, drgb, cat);              // static_rgb^T -> d dir_h
         apply_mask<P, QC>(cat[0], m1);
-        store_array<QC>(arr(GA_CAT, QC), cat[0]);
+        store_array<QC, PL>(arr(GA_CAT, QC), cat[0]);
       }
       note_scale(GA_CAT, sp);
       {
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArg
         set_slot<P>(cat2[0], 64, g[3] * sp);     // slot 64 of half 0: d sigma_s (pre-activation); half 1 holds 0
       }
     }
-    store_array<HC + SC>(arr(GA_CAT2, HC + SC), cat2[0]);
+    store_array<HC + SC, PL>(arr(GA_CAT2, HC + SC), cat2[0]);
     note_scale(GA_CAT2, sp);
     F gh[NB][HC], gh2[NB][HC];
     st.lane_mul = renorm_wave<HC + SC>(cat2[0], sp);
@@ -343,50 +348,50 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArg
     TB_LAYER(HC + SC, 4, cat2, gh);              // [xyz_encoding_final ; static_sigma]^T -> d h8
     sp *= st.lane_mul; st.lane_mul = 1.f;
     apply_mask<P, HC>(gh[0], mk);
-    store_array<HC>(arr(GA_L8, HC), gh[0]);
+    store_array<HC, PL>(arr(GA_L8, HC), gh[0]);
     note_scale(GA_L8, sp);
     st.lane_mul = renorm_wave<HC>(gh[0], sp);
     mk[0] = mwords[12 * 64]; mk[1] = mwords[13 * 64];
     TB_LAYER(HC, 4, gh, gh2);                    // xyz_encoding_8^T -> d h7
     sp *= st.lane_mul; st.lane_mul = 1.f;
     apply_mask<P, HC>(gh2[0], mk);
-    store_array<HC>(arr(GA_L7, HC), gh2[0]);
+    store_array<HC, PL>(arr(GA_L7, HC), gh2[0]);
     note_scale(GA_L7, sp);
     mk[0] = mwords[10 * 64]; mk[1] = mwords[11 * 64];
     TB_LAYER(HC, 4, gh2, gh);                    // xyz_encoding_7^T -> d h6
     apply_mask<P, HC>(gh[0], mk);
-    store_array<HC>(arr(GA_L6, HC), gh[0]);
+    store_array<HC, PL>(arr(GA_L6, HC), gh[0]);
     note_scale(GA_L6, sp);
     st.lane_mul = renorm_wave<HC>(gh[0], sp);
     mk[0] = mwords[8 * 64]; mk[1] = mwords[9 * 64];
     TB_LAYER(HC, 4, gh, gh2);                    // xyz_encoding_6^T -> d h5
     sp *= st.lane_mul; st.lane_mul = 1.f;
     apply_mask<P, HC>(gh2[0], mk);
-    store_array<HC>(arr(GA_L5, HC), gh2[0]);
+    store_array<HC, PL>(arr(GA_L5, HC), gh2[0]);
     note_scale(GA_L5, sp);
     mk[0] = mwords[6 * 64]; mk[1] = mwords[7 * 64];
     TB_LAYER(HC, 4, gh2, gh);                    // xyz_encoding_5^T, the h columns -> d h4 (the encoding columns need no gradient)
     apply_mask<P, HC>(gh[0], mk);
-    store_array<HC>(arr(GA_L4, HC), gh[0]);
+    store_array<HC, PL>(arr(GA_L4, HC), gh[0]);
     note_scale(GA_L4, sp);
     st.lane_mul = renorm_wave<HC>(gh[0], sp);
     mk[0] = mwords[4 * 64]; mk[1] = mwords[5 * 64];
     TB_LAYER(HC, 4, gh, gh2);                    // xyz_encoding_4^T -> d h3
     sp *= st.lane_mul; st.lane_mul = 1.f;
     apply_mask<P, HC>(gh2[0], mk);
-    store_array<HC>(arr(GA_L3, HC), gh2[0]);
+    store_array<HC, PL>(arr(GA_L3, HC), gh2[0]);
     note_scale(GA_L3, sp);
     mk[0] = mwords[2 * 64]; mk[1] = mwords[3 * 64];
     TB_LAYER(HC, 4, gh2, gh);                    // xyz_encoding_3^T -> d h2
     apply_mask<P, HC>(gh[0], mk);
-    store_array<HC>(arr(GA_L2, HC), gh[0]);
+    store_array<HC, PL>(arr(GA_L2, HC), gh[0]);
     note_scale(GA_L2, sp);
     st.lane_mul = renorm_wave<HC>(gh[0], sp);
     mk[0] = mwords[0 * 64]; mk[1] = mwords[1 * 64];
     TB_LAYER(HC, 4, gh, gh2);                    // xyz_encoding_2^T -> d h1
     sp *= st.lane_mul; st.lane_mul = 1.f;
     apply_mask<P, HC>(gh2[0], mk);
-    store_array<HC>(arr(GA_L1, HC), gh2[0]);
+    store_array<HC, PL>(arr(GA_L1, HC), gh2[0]);
     note_scale(GA_L1, sp);
   }
   range_report<P>(st.rmax, a.status);
@@ -409,15 +414,19 @@ static hipError_t launch_chain(K kern, bool& attr_done, uint32_t lds, const Chai
   return hipGetLastError();
 }
 
-hipError_t launch_train_forward_chain(bool fine, const ChainArgs& a, int n_cu, hipStream_t s) {
-  static bool done[2] = {false, false};
-  return fine ? launch_chain(train_fwd_chain_kernel<true>, done[1], 3 * kFwdStride, a, n_cu, s)
-              : launch_chain(train_fwd_chain_kernel<false>, done[0], 3 * kFwdStride, a, n_cu, s);
+hipError_t launch_train_forward_chain(bool fine, int planes, const ChainArgs& a, int n_cu, hipStream_t s) {
+  static bool done[3] = {false, false, false};
+  if (!fine) return planes == 2 ? launch_chain(train_fwd_chain_kernel<false, 2>, done[0], 3 * kFwdStride, a, n_cu, s) : hipErrorInvalidValue;
+  if (planes == 1) return launch_chain(train_fwd_chain_kernel<true, 1>, done[1], 3 * kFwdStride, a, n_cu, s);
+  if (planes == 2) return launch_chain(train_fwd_chain_kernel<true, 2>, done[2], 3 * kFwdStride, a, n_cu, s);
+  return hipErrorInvalidValue;
 }
-hipError_t launch_train_backward_chain(bool fine, const ChainArgs& a, int n_cu, hipStream_t s) {
-  static bool done[2] = {false, false};
-  return fine ? launch_chain(train_bwd_chain_kernel<true>, done[1], 3 * kBwdStride, a, n_cu, s)
-              : launch_chain(train_bwd_chain_kernel<false>, done[0], 3 * kBwdStride, a, n_cu, s);
+hipError_t launch_train_backward_chain(bool fine, int planes, const ChainArgs& a, int n_cu, hipStream_t s) {
+  static bool done[3] = {false, false, false};
+  if (!fine) return planes == 2 ? launch_chain(train_bwd_chain_kernel<false, 2>, done[0], 3 * kBwdStride, a, n_cu, s) : hipErrorInvalidValue;
+  if (planes == 1) return launch_chain(train_bwd_chain_kernel<true, 1>, done[1], 3 * kBwdStride, a, n_cu, s);
+  if (planes == 2) return launch_chain(train_bwd_chain_kernel<true, 2>, done[2], 3 * kBwdStride, a, n_cu, s);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace fused

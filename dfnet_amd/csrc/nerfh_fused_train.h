@@ -15,10 +15,12 @@
 //     back TRANSPOSED (ds_read_b64_tr_b16: [point][feature] image -> [feature][point] MFMA operands), three f16 MFMAs per
 //     product, fp32 accumulation per wave-tile folded into a master accumulator at the tile's scale; fixed point chunks ->
 //     partial sums -> fixed-order reduction (deterministic) scattered straight into the torch .grad tensors.
-// Nothing but X_l / G_l (4 bytes per element, written once, read once) and 84 bytes of sign bits per point touches HBM.
+// Nothing but X_l / G_l (2 bytes per element for the fine network, 4 for the coarse one; written once, read once) and 84 bytes
+// of sign bits per point touches HBM.
 //
 // Stored array layout ("wave-tile" wt = 32 consecutive points = one wavefront of a chain tile):
-//   array[wt][chunk c][plane 0 = hi | 1 = lo][point p (32)][half h (2)][slot j (8)]   f16, 2048 bytes per chunk
+//   array[wt][chunk c][plane 0 = hi | 1 = lo][point p (32)][half h (2)][slot j (8)]   f16, 1024 bytes per plane and chunk
+// (fine network: ONE plane = f16(hi + lo) unless DFN_TRAIN_FUSED_SPLIT; coarse network: both — planes_of() below)
 // chunk c, half h, slot j = contraction slot s = 8 c + j of half h of the B operand (nerfh_layout.h: hidden_feature /
 // pe_xyz_feature give the feature index).  A plane is 1 KiB = one wave-wide 16-byte store / LDS-DMA.
 #pragma once
@@ -34,7 +36,18 @@ namespace fused {
 constexpr int kTilePoints = 256;   // points per workgroup tile of the chain kernels (8 waves x 32)
 constexpr int kWaveTile = 32;
 constexpr int kMaskWords = 21;     // as nerfh_kernels.h: 8 x 128 + 64 + 4 x 64 sign bits per point
-constexpr int kChunkBytes = 2048;  // hi plane + lo plane of one chunk of one wave-tile
+// Planes stored per chunk: 2 = hi | lo (the chains' split-f16 operand registers as they are, 4 bytes per element); 1 = ONE f16
+// plane, round-to-nearest of hi + lo (2 bytes per element).  The weight gradient is a sum over ~10^5 points of products whose f16
+// rounding errors are unbiased and independent.  Measured against the exact-fp32 step (tools/gpu_n1_planes.sh, LABBOOK R5.6):
+//   * FINE network (295 k points per 1 536-ray step, gradients from every loss term): random-init weights — every gradient tensor
+//     stays where two planes had it (worst 2.6e-5 against 2.4e-5); trained-like weights (gradients cancel to a small residual) —
+//     hidden-layer tensors move from 3e-5 to 3e-4 of their norm, under the tensors both forms already have at 2e-3 (gate flips)
+//     and under the 5e-4 the tests hold the random-weight step to -> ONE plane by default (DFN_TRAIN_FUSED), both on request
+//     (DFN_TRAIN_FUSED_SPLIT);
+//   * COARSE network (its gradient arrives only through the rgb0 term and cancels to ~1e-3 of its terms even at random init): one
+//     plane moved the worst tensor from 1.5e-4 to 3.0e-4 (7e-4 at perturb 0, over the tests' 5e-4) -> always BOTH planes.
+constexpr int kPlanesCoarse = 2;
+inline int planes_of(bool fine, bool split_fine) { return fine ? (split_fine ? 2 : 1) : kPlanesCoarse; }
 
 // ---- stored arrays
 // X arrays (forward-layer inputs).  Coarse net: XA_PE .. XA_DE.
@@ -68,14 +81,14 @@ struct ChainArgs {
   float in_scale;          // split-f16: weight scale x activation scale carried by the accumulators
   int* status;             // range guard (as MlpArgs::status)
 };
-hipError_t launch_train_forward_chain(bool fine, const ChainArgs& a, int n_cu, hipStream_t s);
-hipError_t launch_train_backward_chain(bool fine, const ChainArgs& a, int n_cu, hipStream_t s);
+hipError_t launch_train_forward_chain(bool fine, int planes, const ChainArgs& a, int n_cu, hipStream_t s);
+hipError_t launch_train_backward_chain(bool fine, int planes, const ChainArgs& a, int n_cu, hipStream_t s);
 size_t chain_wave_tiles(long long n_points);   // wave-tiles the chain kernels write (whole tiles)
 
 // ---- weight-gradient stream
 struct WJob {
-  const char* g;           // G array: [n_wt][kcg][2048]
-  const char* x0;          // X array(s): [n_wt][kcx0][2048] (, [n_wt][kcx1][2048])
+  const char* g;           // G array: [n_wt][kcg][chunk bytes]
+  const char* x0;          // X array(s): [n_wt][kcx0][chunk bytes] (, [n_wt][kcx1][chunk bytes])
   const char* x1;
   const float* gscale;     // [n_wt]
   float* partial;          // [n_chunks][n_blocks][1024]
@@ -100,7 +113,7 @@ struct ReduceArgs {
   const int* map;          // per job: [n_blocks][1024] destination (param << 20 | offset) or -1, index r * 64 + lane
   float* grads[64];        // the step's gradient tensors in canonical order (dfn_nerfh_train_param_name)
 };
-hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, hipStream_t s);
+hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, int planes, hipStream_t s);
 hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t s);
 constexpr uint32_t kWgradLdsBytes = 81920;    // staging ring of one stream workgroup (two per CU)
 
@@ -116,6 +129,19 @@ struct PackArgs {
 };
 hipError_t launch_pack(const PackArgs& a, hipStream_t s);
 
+// The step's range word (dfn_nerfh_s::range_flag + 2: raised by this step's pack / chain kernels only) decides what the step leaves in
+// the gradient tensors: non-zero -> every gradient is ZEROED (a skipped step, as a loss scaler skips a step whose gradients
+// overflowed: the optimizer sees zeros, never clamped or NaN gradients) and the bits are ORed into the handle's range flag, where
+// dfn_nerfh_range_status(_async) finds them.  Last launch of the backward pass.
+struct GuardArgs {
+  float* grads[64];
+  uint32_t numel[64];
+  int n;
+  int* step_flag;
+  int* range_flag;
+};
+hipError_t launch_grads_guard(const GuardArgs& a, hipStream_t s);
+
 // table[ray][tbl][mb][h][r] (C-fragment order, nerfh_layout.h) = b[f] + sum_j W[f, 128 + j] in[ray, j]; tbl 0 = dir_encoding.0
 // on dir_in [R, ld_dir] (kd columns), tbl 1 = transient_encoding.0 on t_in (nt columns; w_te == nullptr: table 0 only).
 hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw_dir, int kd, const float* dir_in, int ld_dir,
@@ -123,7 +149,7 @@ hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw
                                  float* table, hipStream_t s);
 // out[r][feat] (feat < 16 kc) = sum over the ray's samples of the stored gradient array (true scale), feature order = slot order
 // mapped through hidden_feature() per 32-slot group: out[r][64 (s >> 5) + hidden_feature(h, s & 31)].
-hipError_t launch_frag_ray_sum(const char* arr, int kc, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s);
+hipError_t launch_frag_ray_sum(const char* arr, int kc, int planes, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s);
 
 
 // ---- host side (nerfh_fused_api.hip), called by dfn_nerfh_train_* when the handle runs the register-resident kernels

@@ -5,8 +5,8 @@
 // Replaces the weight-gradient third of loss.backward() in /root/reference/script/run_nerf.py:64 for the Linear layers of
 // models/nerfw.py:259-295: dW_l[n, k] = sum_p G_l[p, n] X_l[p, k], db_l[n] = sum_p G_l[p, n].
 //
-// wgrad_stream_kernel: one workgroup = (job, chunk of wave-tiles).  Per wave-tile the job's G and X chunks (2 KiB each, already
-// split hi | lo by the chain kernels) are DMA-ed HBM -> LDS into a ring of 2-4 stages (global_load_lds_dwordx4 nt, no registers);
+// wgrad_stream_kernel<PL>: one workgroup = (job, chunk of wave-tiles).  Per wave-tile the job's G and X chunks (PL planes of 1 KiB
+// each: hi | lo as the chain kernels split them, or the one f16 plane of the fine network) are DMA-ed HBM -> LDS into a ring of 2-4 stages (global_load_lds_dwordx4 nt, no registers);
 // the [point][feature] image is read back as [feature][point] MFMA operands by ds_read_b64_tr_b16 (a 16-lane group reads
 // 4 points x 16 features = 128 contiguous bytes: conflict-free), three v_mfma_f32_32x32x16_f16 per product and 16-point half;
 // the wave-tile's fp32 block is folded into the master accumulator at the tile's power-of-two scale.  The kernel is bound by
@@ -26,7 +26,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WAVES = 4, MAXB = 5;   // two 4-wave workgroups per CU run unsynchronised: one's barrier / LDS waits under the other's MFMAs
 // LDS image of a stage: chunk c at c * kLdsChunk.  The 128-byte skew puts the two chunks of a 32-feature pair on different bank
 // halves: the two 16-lane groups of a transposed read then touch 2 x 128 distinct bytes of a 256-byte bank row (conflict-free).
-constexpr uint32_t kLdsChunk = kChunkBytes + 128;
+template <int PL> constexpr uint32_t lds_chunk() { return 1024u * PL + 128u; }
 
 template <int OFF>
 DFN_DEV u32x2 ds_tr16(uint32_t addr) {
@@ -37,13 +37,17 @@ DFN_DEV u32x2 ds_tr16(uint32_t addr) {
 // 32 features (a chunk pair at LDS address cb; cb already holds the lane's part) x 16 points (P0 = 0 / 16) -> MFMA operand
 // (hi, lo): lane (feature = lane & 31, k-half = lane >> 5) receives points P0 + 8 (lane >> 5) + 0..7.
 struct Frag { u32x2 h0, h1, l0, l1; };
-template <int P0>
+template <int P0, int PL>
 DFN_DEV Frag issue_frag(uint32_t cb) {
   Frag f;
   f.h0 = ds_tr16<P0 * 32>(cb);
   f.h1 = ds_tr16<P0 * 32 + 128>(cb);
-  f.l0 = ds_tr16<P0 * 32 + 1024>(cb);
-  f.l1 = ds_tr16<P0 * 32 + 1024 + 128>(cb);
+  if constexpr (PL == 2) {
+    f.l0 = ds_tr16<P0 * 32 + 1024>(cb);
+    f.l1 = ds_tr16<P0 * 32 + 1024 + 128>(cb);
+  } else {
+    f.l0 = f.h0; f.l1 = f.h1;   // unused
+  }
   return f;
 }
 DFN_DEV half8 join(u32x2 a, u32x2 b) { return __builtin_bit_cast(half8, u32x4{a[0], a[1], b[0], b[1]}); }
@@ -82,19 +86,27 @@ DFN_DEV float scalar_f32(const float* p) { return *reinterpret_cast<const_f32*>(
 namespace {
 // Operands of one output block of one wave-tile: G chunk pair (A) and X chunk pair (B), both 16-point halves, hi | lo.
 struct BlockOps { Frag a0, a1, b0, b1; };
+template <int PL>
 DFN_DEV void issue_block(BlockOps& o, uint32_t ga, uint32_t xa) {
-  o.a0 = issue_frag<0>(ga);
-  o.a1 = issue_frag<16>(ga);
-  o.b0 = issue_frag<0>(xa);
-  o.b1 = issue_frag<16>(xa);
+  o.a0 = issue_frag<0, PL>(ga);
+  o.a1 = issue_frag<16, PL>(ga);
+  o.b0 = issue_frag<0, PL>(xa);
+  o.b1 = issue_frag<16, PL>(xa);
 }
+template <int PL>
 DFN_DEV void wait_block(BlockOps& o) {   // every LDS read issued so far has returned (the asm ties the registers to the wait)
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(o.a0.h0), "+v"(o.a0.h1), "+v"(o.a0.l0), "+v"(o.a0.l1), "+v"(o.a1.h0), "+v"(o.a1.h1), "+v"(o.a1.l0), "+v"(o.a1.l1),
-                 "+v"(o.b0.h0), "+v"(o.b0.h1), "+v"(o.b0.l0), "+v"(o.b0.l1), "+v"(o.b1.h0), "+v"(o.b1.h1), "+v"(o.b1.l0), "+v"(o.b1.l1)
-               :: "memory");
+  if constexpr (PL == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(o.a0.h0), "+v"(o.a0.h1), "+v"(o.a0.l0), "+v"(o.a0.l1), "+v"(o.a1.h0), "+v"(o.a1.h1), "+v"(o.a1.l0), "+v"(o.a1.l1),
+                   "+v"(o.b0.h0), "+v"(o.b0.h1), "+v"(o.b0.l0), "+v"(o.b0.l1), "+v"(o.b1.h0), "+v"(o.b1.h1), "+v"(o.b1.l0), "+v"(o.b1.l1)
+                 :: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(o.a0.h0), "+v"(o.a0.h1), "+v"(o.a1.h0), "+v"(o.a1.h1), "+v"(o.b0.h0), "+v"(o.b0.h1), "+v"(o.b1.h0), "+v"(o.b1.h1)
+                 :: "memory");
 }
-// hi*hi + hi*lo + lo*hi over the tile's 32 points, folded into the master accumulator at the tile's scale
+// hi*hi + hi*lo + lo*hi (one plane: the single product) over the tile's 32 points, folded into the master accumulator at the tile's scale
+template <int PL>
 DFN_DEV void mma_block(const BlockOps& o, bool bias, float inv, f32x16& master) {
   const half8 ones = {1, 1, 1, 1, 1, 1, 1, 1}, zeros = {0, 0, 0, 0, 0, 0, 0, 0};
   const half8 ah0 = join(o.a0.h0, o.a0.h1), al0 = join(o.a0.l0, o.a0.l1), ah1 = join(o.a1.h0, o.a1.h1), al1 = join(o.a1.l0, o.a1.l1);
@@ -103,17 +115,21 @@ DFN_DEV void mma_block(const BlockOps& o, bool bias, float inv, f32x16& master) 
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc, 0, 0, 0);
+  if constexpr (PL == 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc, 0, 0, 0);
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) master[r] = fmaf(acc[r], inv, master[r]);
 }
 }  // namespace
 
+template <int PL>
 __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr uint32_t kLdsChunk = lds_chunk<PL>();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int j = 0;
@@ -129,17 +145,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a
   int n_it = a.n_wt - wt0;
   n_it = n_it > jb.wt_per_chunk ? jb.wt_per_chunk : n_it;
   if (n_it <= 0) return;
-  const int np = kc_all * 2;                       // 1 KiB pieces per stage
+  const int np = kc_all * PL;                      // 1 KiB pieces per stage
   const int my_np = (np - wave + WAVES - 1) / WAVES;
   auto issue = [&](int it) {
     const size_t wt = size_t(wt0 + it);
     char* dst = smem + uint32_t(it % D) * stage_bytes;
     for (int i = wave; i < np; i += WAVES) {
       const char* src;
-      if (i < 2 * kcg) src = jb.g + ((wt * size_t(jb.g_stride) + jb.g_chunk0) * 2 + i) * 1024;
-      else if (i < 2 * (kcg + kcx0)) src = jb.x0 + (wt * size_t(2 * kcx0) + (i - 2 * kcg)) * 1024;
-      else src = jb.x1 + (wt * size_t(2 * kcx1) + (i - 2 * (kcg + kcx0))) * 1024;
-      lds_dma_b128_nt(src + lane * 16, dst + (i >> 1) * kLdsChunk + (i & 1) * 1024);
+      if (i < PL * kcg) src = jb.g + ((wt * size_t(jb.g_stride) + jb.g_chunk0) * PL + i) * 1024;
+      else if (i < PL * (kcg + kcx0)) src = jb.x0 + (wt * size_t(PL * kcx0) + (i - PL * kcg)) * 1024;
+      else src = jb.x1 + (wt * size_t(PL * kcx1) + (i - PL * (kcg + kcx0))) * 1024;
+      lds_dma_b128_nt(src + lane * 16, dst + (i / PL) * kLdsChunk + (i % PL) * 1024);
     }
   };
   for (int it = 0; it < D - 1 && it < n_it; ++it) issue(it);
@@ -179,13 +195,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a
     // block pipeline: while block i's MFMAs run, block i + 1's operands are read (transposed) into the other register set — the
     // eight waves leave the barrier together, so without this every wave reads, then every wave multiplies
     BlockOps S[2];
-    if (valid[0]) issue_block(S[0], sb + goff[0], sb + xoff[0]);
+    if (valid[0]) issue_block<PL>(S[0], sb + goff[0], sb + xoff[0]);
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
       if (!valid[i]) break;
-      wait_block(S[i & 1]);
-      if (i + 1 < MAXB && valid[i + 1]) issue_block(S[(i + 1) & 1], sb + goff[i + 1], sb + xoff[i + 1]);
-      mma_block(S[i & 1], is_bias[i], inv, master[i]);
+      wait_block<PL>(S[i & 1]);
+      if (i + 1 < MAXB && valid[i + 1]) issue_block<PL>(S[(i + 1) & 1], sb + goff[i + 1], sb + xoff[i + 1]);
+      mma_block<PL>(S[i & 1], is_bias[i], inv, master[i]);
     }
   }
 #pragma unroll
@@ -197,17 +213,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a
   }
 }
 
-hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, hipStream_t s) {
-  if (total_wgs <= 0) return hipSuccess;
+template <int PL>
+static hipError_t launch_wgrad_stream_t(const WgradArgs& a, int total_wgs, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_stream_kernel<PL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(kWgradLdsBytes));
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_stream_kernel, dim3(total_wgs), dim3(WAVES * 64), kWgradLdsBytes, s, a);
+  hipLaunchKernelGGL(wgrad_stream_kernel<PL>, dim3(total_wgs), dim3(WAVES * 64), kWgradLdsBytes, s, a);
   return hipGetLastError();
+}
+hipError_t launch_wgrad_stream(const WgradArgs& a, int total_wgs, int planes, hipStream_t s) {
+  if (total_wgs <= 0) return hipSuccess;
+  if (planes == 1) return launch_wgrad_stream_t<1>(a, total_wgs, s);
+  if (planes == 2) return launch_wgrad_stream_t<2>(a, total_wgs, s);
+  return hipErrorInvalidValue;
 }
 
 // Fixed-order sum of a job's chunk partials, scattered into the gradient tensors: weight blocks carry the X operand scale (16),
@@ -238,6 +260,21 @@ hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t s) {
   for (int j = 0; j < a.n_jobs; ++j) total += a.job[j].nb_g * (a.job[j].nb_x + a.job[j].has_bias) * 4;
   if (!total) return hipSuccess;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total), dim3(256), 0, s, a, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ the step's range guard
+__global__ __launch_bounds__(256) void grads_guard_kernel(GuardArgs a) {
+  const int v = *a.step_flag;   // written by kernels that finished before this launch: uniform
+  if (!v) return;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(a.range_flag, v);
+  float* g = a.grads[blockIdx.y];
+  const uint32_t n = a.numel[blockIdx.y];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) g[i] = 0.f;
+}
+hipError_t launch_grads_guard(const GuardArgs& a, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(grads_guard_kernel, dim3(8, a.n), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -319,6 +356,7 @@ hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw
 // ------------------------------------------------------------------------------------------ per-ray sums of a stored gradient array
 // The columns of dir_encoding.0 / transient_encoding.0 beyond `final` multiply per-RAY inputs (direction encoding, embeddings):
 // their gradients need sum_samples G[p, :] per ray (models/nerfw.py:62-95).  One block per ray; fixed summation order.
+template <int PL>
 __global__ __launch_bounds__(256) void frag_ray_sum_kernel(const char* __restrict__ arr, int kc, const float* __restrict__ gscale, int Ns,
                                                            float* __restrict__ out, int ldo) {
   // a lane owns one 16-byte piece (8 slots of one half of one chunk) and walks the ray's samples 256 / (2 kc) at a time: 16-byte loads
@@ -333,8 +371,10 @@ __global__ __launch_bounds__(256) void frag_ray_sum_kernel(const char* __restric
   for (int smp = sg; smp < Ns; smp += groups) {
     const size_t pt = ray * Ns + smp;
     const size_t wt = pt >> 5;
-    const char* p = arr + (wt * kc + c) * kChunkBytes + (2 * (pt & 31) + hh) * 16;
-    const half8 hi = *reinterpret_cast<const half8*>(p), lo = *reinterpret_cast<const half8*>(p + 1024);
+    const char* p = arr + (wt * kc + c) * (1024 * PL) + (2 * (pt & 31) + hh) * 16;
+    const half8 hi = *reinterpret_cast<const half8*>(p);
+    half8 lo = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (PL == 2) lo = *reinterpret_cast<const half8*>(p + 1024);
     const float inv = 1.f / gscale[wt];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] += (float(hi[j]) + float(lo[j])) * inv;
@@ -352,10 +392,11 @@ __global__ __launch_bounds__(256) void frag_ray_sum_kernel(const char* __restric
     }
   }
 }
-hipError_t launch_frag_ray_sum(const char* arr, int kc, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s) {
+hipError_t launch_frag_ray_sum(const char* arr, int kc, int planes, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s) {
   if (!R) return hipSuccess;
-  if (kc != 4 && kc != 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(frag_ray_sum_kernel, dim3(unsigned(R)), dim3(256), 0, s, arr, kc, gscale, Ns, out, ldo);
+  if ((kc != 4 && kc != 8) || (planes != 1 && planes != 2)) return hipErrorInvalidValue;
+  if (planes == 1) hipLaunchKernelGGL(frag_ray_sum_kernel<1>, dim3(unsigned(R)), dim3(256), 0, s, arr, kc, gscale, Ns, out, ldo);
+  else hipLaunchKernelGGL(frag_ray_sum_kernel<2>, dim3(unsigned(R)), dim3(256), 0, s, arr, kc, gscale, Ns, out, ldo);
   return hipGetLastError();
 }
 

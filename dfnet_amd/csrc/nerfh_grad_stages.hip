@@ -164,6 +164,9 @@ __global__ __launch_bounds__(1024) void raygen_backward_kernel(int H, int W, flo
                                                                const float* __restrict__ grad_d, float* __restrict__ grad_c2w) {
   __shared__ float red[16][12];
   const size_t n = size_t(H) * W;
+  grad_o += size_t(blockIdx.x) * n * 3;   // one workgroup per frame of a batch (dfn_raygen_frames_backward)
+  grad_d += size_t(blockIdx.x) * n * 3;
+  grad_c2w += size_t(blockIdx.x) * 12;
   const float hw = float(W) * .5f, hh = float(H) * .5f;
   float acc[12];
 #pragma unroll
@@ -194,8 +197,9 @@ __global__ __launch_bounds__(1024) void raygen_backward_kernel(int H, int W, flo
 }
 
 hipError_t launch_raygen_backward(int H, int W, float focal, const float* grad_o, const float* grad_d, float* grad_c2w,
-                                  hipStream_t stream) {
-  hipLaunchKernelGGL(raygen_backward_kernel, dim3(1), dim3(1024), 0, stream, H, W, focal, grad_o, grad_d, grad_c2w);
+                                  hipStream_t stream, int frames) {
+  if (frames < 1) return hipSuccess;
+  hipLaunchKernelGGL(raygen_backward_kernel, dim3(frames), dim3(1024), 0, stream, H, W, focal, grad_o, grad_d, grad_c2w);
   return hipGetLastError();
 }
 
@@ -216,10 +220,14 @@ DFN_DEV float bicubic_axis_weight(float scale, int O, int n_in, int target) {
   return acc;
 }
 // Gather form (deterministic): one 8-lane group per input element, the lanes share the rows of the output window that reaches it.
+// NCHW: g_out is planar, [C, UH, UW] per frame (launch_bicubic's NCHW output).
+template <bool NCHW>
 __global__ __launch_bounds__(256) void bicubic_backward_kernel(const float* __restrict__ gout, int H, int W, int C, int UH, int UW,
                                                                float* __restrict__ gin) {
   const float sy = float(H) / float(UH), sx = float(W) / float(UW);
   const size_t n = size_t(H) * W * C;
+  gout += size_t(blockIdx.y) * UH * UW * C;   // blockIdx.y = frame of a batch
+  gin += size_t(blockIdx.y) * n;
   for (size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x; t < n * 8; t += size_t(gridDim.x) * blockDim.x) {
     const size_t i = t >> 3;
     const int sub = int(t & 7);
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void bicubic_backward_kernel(const float* __re
       float row = 0.f;
       for (int X = X0; X <= X1; ++X) {
         const float wx = bicubic_axis_weight(sx, X, W, x);
-        if (wx != 0.f) row += wx * gout[(size_t(Y) * UW + X) * C + c];
+        if (wx != 0.f) row += wx * (NCHW ? gout[(size_t(c) * UH + Y) * UW + X] : gout[(size_t(Y) * UW + X) * C + c]);
       }
       acc += wy * row;
     }
@@ -247,10 +255,12 @@ __global__ __launch_bounds__(256) void bicubic_backward_kernel(const float* __re
     if (sub == 0) gin[i] = acc;
   }
 }
-hipError_t launch_bicubic_backward(const float* gout, int H, int W, int C, int UH, int UW, float* gin, hipStream_t stream) {
+hipError_t launch_bicubic_backward(const float* gout, int H, int W, int C, int UH, int UW, float* gin, hipStream_t stream, int frames,
+                                   bool nchw) {
   const size_t n = size_t(H) * W * C;
-  if (!n) return hipSuccess;
-  hipLaunchKernelGGL(bicubic_backward_kernel, dim3(grid_for(n * 8, 256)), dim3(256), 0, stream, gout, H, W, C, UH, UW, gin);
+  if (!n || frames < 1) return hipSuccess;
+  if (nchw) hipLaunchKernelGGL(bicubic_backward_kernel<true>, dim3(grid_for(n * 8, 256), frames), dim3(256), 0, stream, gout, H, W, C, UH, UW, gin);
+  else hipLaunchKernelGGL(bicubic_backward_kernel<false>, dim3(grid_for(n * 8, 256), frames), dim3(256), 0, stream, gout, H, W, C, UH, UW, gin);
   return hipGetLastError();
 }
 

@@ -37,6 +37,8 @@ struct dfn_nerfh_s {
   int* range_flag = nullptr;   // device int the MLP kernels OR their range-guard bits into (dfn_nerfh_range_status)
   void* fused = nullptr;       // dfn::fused::State: staging-unit / destination tables of the fused training step (nerfh_fused_api.hip)
   bool train_forward_exact = false;   // which implementation the last dfn_nerfh_train_forward ran (dfn_nerfh_train_backward_rays needs the exact one)
+  bool train_split_fine = false;   // DFN_TRAIN_FUSED_SPLIT: the fused step stores the fine network's operands as hi | lo planes too (nerfh_fused_train.h)
+  bool train_forward_split = false; // ... as the last dfn_nerfh_train_forward laid the workspace out
   bool train_exact = false;    // dfn_nerfh_set_train_mode: run the training step on the layer-by-layer exact-fp32 products even at netwidth 128
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[2] = {nullptr, nullptr};

@@ -32,8 +32,9 @@ struct MlpArgs {
 hipError_t launch_mlp(bool fine, int prec, int variant, const MlpArgs& a, int n_cu, hipStream_t stream, int width = 128);
 
 // --- stages (nerfh_stages.hip)
+// (frames > 1: c2w [frames,3,4], outputs [frames,H,W,3] — one launch for the frames of a mini-batch)
 hipError_t launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
-                         float* viewdirs, hipStream_t stream);
+                         float* viewdirs, hipStream_t stream, int frames = 1);
 hipError_t launch_viewdirs(const float* rays_d, size_t n, float* viewdirs, hipStream_t stream);
 hipError_t launch_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, size_t n, float* out_o,
                            float* out_d, hipStream_t stream);
@@ -99,9 +100,12 @@ hipError_t launch_ray_grad_reduce(const float* gpts, const float* z, const float
                                   hipStream_t stream, int accumulate = 0);
 // get_rays backward: d c2w[3][4] from d rays_o / d rays_d of an H x W image.
 hipError_t launch_raygen_backward(int H, int W, float focal, const float* grad_o, const float* grad_d, float* grad_c2w,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int frames = 1);
 // adjoint of launch_bicubic: g_out [UH,UW,C] -> g_in [H,W,C].
-hipError_t launch_bicubic_backward(const float* gout, int H, int W, int C, int UH, int UW, float* gin, hipStream_t stream);
-hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream);
+// (frames > 1: a batch of frames per launch; nchw: the enlarged frames — g_out for the adjoint — are planar [C,UH,UW] per frame)
+hipError_t launch_bicubic_backward(const float* gout, int H, int W, int C, int UH, int UW, float* gin, hipStream_t stream, int frames = 1,
+                                   bool nchw = false);
+hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream, int frames = 1,
+                          bool nchw = false);
 
 }  // namespace dfn

@@ -30,6 +30,11 @@ __global__ __launch_bounds__(256) void raygen_kernel(int H, int W, float focal, 
                                                      float* __restrict__ rays_o, float* __restrict__ rays_d,
                                                      float* __restrict__ viewdirs) {
   const size_t n = size_t(H) * W;
+  // blockIdx.y = frame of a batch (dfn_raygen_frames): its own pose, its own slice of the outputs
+  c2w += size_t(blockIdx.y) * 12;
+  rays_o += size_t(blockIdx.y) * n * 3;
+  rays_d += size_t(blockIdx.y) * n * 3;
+  if (viewdirs) viewdirs += size_t(blockIdx.y) * n * 3;
   float R[3][3], t[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -58,10 +63,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(int H, int W, float focal, 
 }
 
 hipError_t launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
-                         float* viewdirs, hipStream_t stream) {
+                         float* viewdirs, hipStream_t stream, int frames) {
   const size_t n = size_t(H) * W;
-  if (!n) return hipSuccess;
-  hipLaunchKernelGGL(raygen_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, H, W, focal, c2w, rays_o, rays_d, viewdirs);
+  if (!n || frames < 1) return hipSuccess;
+  hipLaunchKernelGGL(raygen_kernel, dim3(grid_for(n, 256), frames), dim3(256), 0, stream, H, W, focal, c2w, rays_o, rays_d, viewdirs);
   return hipGetLastError();
 }
 
@@ -618,13 +623,19 @@ hipError_t launch_composite_combine(const float* partial, size_t n_rays, int seg
 DFN_DEV float cubic_w1(float x) { const float A = -0.75f; return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }       // |x| <= 1
 DFN_DEV float cubic_w2(float x) { const float A = -0.75f; return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }  // 1 < |x| < 2
 
+// NCHW: the output is written planar, [C, UH, UW] per frame (what DFNet.forward takes: the permute(0, 3, 1, 2) of
+// direct_feature_matching.py:346 folded into the store) instead of [UH, UW, C].
+template <bool NCHW>
 __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ in, int H, int W, int C, int UH, int UW,
                                                       float* __restrict__ out) {
   const float sy = float(H) / float(UH), sx = float(W) / float(UW);
   const size_t n = size_t(UH) * UW * C;
+  in += size_t(blockIdx.y) * H * W * C;   // blockIdx.y = frame of a batch
+  out += size_t(blockIdx.y) * n;
   for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
-    const int c = int(i % C);
-    const int X = int((i / C) % UW), Y = int(i / (size_t(C) * UW));
+    int c, X, Y;
+    if (NCHW) { X = int(i % UW); Y = int((i / UW) % UH); c = int(i / (size_t(UW) * UH)); }
+    else { c = int(i % C); X = int((i / C) % UW); Y = int(i / (size_t(C) * UW)); }
     const float fy = sy * (float(Y) + .5f) - .5f, fx = sx * (float(X) + .5f) - .5f;
     const int iy = int(floorf(fy)), ix = int(floorf(fx));
     const float ty = fy - float(iy), tx = fx - float(ix);
@@ -645,10 +656,11 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
     out[i] = acc;
   }
 }
-hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream) {
+hipError_t launch_bicubic(const float* in, int H, int W, int C, int UH, int UW, float* out, hipStream_t stream, int frames, bool nchw) {
   const size_t n = size_t(UH) * UW * C;
-  if (!n) return hipSuccess;
-  hipLaunchKernelGGL(bicubic_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, in, H, W, C, UH, UW, out);
+  if (!n || frames < 1) return hipSuccess;
+  if (nchw) hipLaunchKernelGGL(bicubic_kernel<true>, dim3(grid_for(n, 256), frames), dim3(256), 0, stream, in, H, W, C, UH, UW, out);
+  else hipLaunchKernelGGL(bicubic_kernel<false>, dim3(grid_for(n, 256), frames), dim3(256), 0, stream, in, H, W, C, UH, UW, out);
   return hipGetLastError();
 }
 

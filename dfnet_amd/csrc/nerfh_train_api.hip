@@ -316,8 +316,10 @@ static bool use_fused(dfn_nerfh_t h) { return fused::available(h) && !h->train_e
 
 extern "C" int dfn_nerfh_set_train_mode(dfn_nerfh_t h, int mode) {
   if (!h) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_train_mode: null handle");
-  if (mode != DFN_TRAIN_FUSED && mode != DFN_TRAIN_EXACT) return set_error(DFN_ERR_ARG, "dfn_nerfh_set_train_mode: unknown mode %d", mode);
+  if (mode != DFN_TRAIN_FUSED && mode != DFN_TRAIN_EXACT && mode != DFN_TRAIN_FUSED_SPLIT)
+    return set_error(DFN_ERR_ARG, "dfn_nerfh_set_train_mode: unknown mode %d", mode);
   h->train_exact = mode == DFN_TRAIN_EXACT;
+  if (mode != DFN_TRAIN_EXACT) h->train_split_fine = mode == DFN_TRAIN_FUSED_SPLIT;
   return DFN_OK;
 }
 
@@ -340,6 +342,7 @@ extern "C" int dfn_nerfh_train_forward(dfn_nerfh_t h, const float* const* params
       !workspace || (hist_rows != 1 && hist_rows != n_rays))
     return set_error(DFN_ERR_ARG, "dfn_nerfh_train_forward: bad argument (hist_rows must be 1 or n_rays)");
   h->train_forward_exact = !use_fused(h);
+  h->train_forward_split = h->train_split_fine;
   if (use_fused(h))
     return fused::train_forward(h, params, rays_o, rays_d, hist, hist_rows, n_rays, Nc, Ni, near, far, t_rand, noise, raw_noise_std, u, rgb,
                                 disp, acc, raw, rgb0, disp0, acc0, z_std, beta, workspace, workspace_bytes, HS(stream));
@@ -395,6 +398,9 @@ extern "C" int dfn_nerfh_train_backward(dfn_nerfh_t h, const float* const* param
     return set_error(DFN_ERR_STATE, "dfn_nerfh_train_backward: the last dfn_nerfh_train_forward ran the %s step, the handle is now in the %s "
                      "mode (dfn_nerfh_set_train_mode between forward and backward)", h->train_forward_exact ? "exact" : "fused",
                      use_fused(h) ? "fused" : "exact");
+  if (use_fused(h) && h->train_forward_split != h->train_split_fine)
+    return set_error(DFN_ERR_STATE, "dfn_nerfh_train_backward: DFN_TRAIN_FUSED / DFN_TRAIN_FUSED_SPLIT changed between forward and backward "
+                     "(dfn_nerfh_set_train_mode between forward and backward): the stored operands have the other layout");
   if (use_fused(h))
     return fused::train_backward(h, params, hist, hist_rows, n_rays, Nc, Ni, noise, raw_noise_std, raw, g_rgb, g_rgb0, g_beta, g_tsigma,
                                  g_tsigma_dense, grads, workspace, workspace_bytes, HS(stream));

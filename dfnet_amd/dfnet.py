@@ -60,7 +60,7 @@ class _FeatureFn(torch.autograd.Function):
         # feature_levels: the caller's "only these pyramid levels are read" for THIS call (prunes the forward); grad_levels: "my loss
         # reads these levels only", which belongs to THIS forward's graph.  Both arrive as explicit arguments (module.forward pops the
         # engine's one-shot hints in every branch), so neither can leak into a later, unrelated forward.
-        feats, _ = engine.forward(x.detach(), True, single, False, upH, upW, levels=feature_levels)
+        feats, _ = engine.forward(x.detach(), True, single, False, upH, upW, levels=feature_levels, zero_unread=False)
         ctx.save_for_backward(x.detach())
         ctx.cfg = (engine, single, grad_levels)
         return (feats,) if single else (feats[0], feats[1])
@@ -285,7 +285,7 @@ class _DFNetBase(nn.Module):
         [stack] (single stream: 1 x [L,B,128,H,W]) or [stack_t, stack_r] (siamese: 2 x [L,B/2,128,H,W])."""
         # One-shot hints a caller left on the engine for THIS call (direct_feature_matching._losses / _target_features): popped before
         # any branch — a call that routes through _TrainFn / _PoseFn, or raises, must not leave them for the next, unrelated forward
-        # (which would silently get zero planes for the unlisted levels).
+        # (which would silently get unwritten planes for the unlisted levels).
         feature_levels = grad_levels = None
         if self._engine is not None:
             feature_levels, self._engine.feature_levels_hint = getattr(self._engine, "feature_levels_hint", None), None
@@ -313,7 +313,7 @@ class _DFNetBase(nn.Module):
         # pose-only inference reads no BatchNorm-folded weights: the device re-pack of a training step is enough for it
         E = self.engine(train=not return_feature)
         levels = feature_levels if (return_feature and not return_pose) else None   # the caller's "only these levels are read"
-        feats, pose = E.forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW, levels=levels)
+        feats, pose = E.forward(x, return_feature, isSingleStream, return_pose, upsampleH, upsampleW, levels=levels, zero_unread=False)
         if feats is not None:
             feats = [feats] if isSingleStream else [feats[0], feats[1]]
         return feats, pose

@@ -17,7 +17,7 @@ every pose of the batch."""
 import torch
 
 from . import dist as ddist
-from .feature_misc import feature_loss, feature_loss_batch, fix_coord_supp, orthogonalize_pose, upsample_bicubic
+from .feature_misc import dm_combined_loss, feature_loss, feature_loss_batch, fix_coord_supp, orthogonalize_pose, upsample_bicubic
 from .rendering import render, render_frames
 
 PRUNE_FEATURE_LEVELS = True   # _losses: compute only the pyramid levels the feature loss reads (False: all three, like the reference)
@@ -100,13 +100,40 @@ def matching_step_grad(args, data, model, feat_model, pose, img_idx, hwf, half_r
 
 
 
+_PINNED = {}
+
+
+def _to_device_async(t, device, dtype=torch.float32):
+    """A small host tensor (ground-truth poses, histogram vectors) onto `device` WITHOUT stalling the host: a pageable host-to-device copy
+    waits for everything queued on the stream before it, which in the middle of a step leaves the GPU idle while the host catches up
+    (two such copies cost 0.15 ms of the 13.6 ms DFNet_dm step).  Staged through a small ring of page-locked buffers instead."""
+    t = torch.as_tensor(t)
+    if t.is_cuda or not torch.device(device).type == "cuda":
+        return t.to(device=device, dtype=dtype)
+    t = t.to(dtype)
+    key = (tuple(t.shape), dtype, torch.device(device))
+    ring = _PINNED.get(key)
+    if ring is None:
+        ring = _PINNED[key] = {"bufs": [torch.empty(t.shape, dtype=dtype).pin_memory() for _ in range(4)], "evs": [None] * 4, "i": 0}
+    k = ring["i"] % 4
+    ring["i"] += 1
+    if ring["evs"][k] is not None:
+        ring["evs"][k].synchronize()      # the copy that last used this buffer (four steps ago) has long finished
+    ring["bufs"][k].copy_(t)
+    out = ring["bufs"][k].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ring["evs"][k] = ev
+    return out
+
+
 def _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test):
     """The per-frame render loop of the reference's step (:340-348; it renders only pose_nerf[0], its batch size being 1) for the
     whole mini-batch: one batched launch per render stage (rendering.render_frames), then the bicubic enlargement per frame.
     Returns rgb [B,3,H,W], attached to pose_nerf."""
     if half_res:
         small = render_frames(H // 4, W // 4, focal / 4, pose_nerf, img_idx, **render_kwargs_test)
-        return upsample_bicubic(small, H, W).permute(0, 3, 1, 2)
+        return upsample_bicubic(small, H, W, nchw=True)
     return render_frames(H, W, focal, pose_nerf, img_idx, **render_kwargs_test).permute(0, 3, 1, 2)
 
 
@@ -155,35 +182,52 @@ def _losses(args, data, rgb, pose_, pose, feat_model, device, parts=False, targe
     # every level like the reference; loss and gradients are bit-identical either way (tests/test_gpu_grad.py).
     lv = sorted(set(int(l) for l in args.feature_matching_lvl))
     ft = target_features() if target_features is not None else _target_features(args, data, feat_model, device)
+    hinted = hasattr(feat_model, "engine") and rgb.requires_grad and torch.is_grad_enabled()
     if hasattr(feat_model, "engine"):
         feat_model.engine().grad_levels_hint = lv
         if PRUNE_FEATURE_LEVELS:
             feat_model.engine().feature_levels_hint = lv
     fr, _ = inference_pose_regression(args, rgb, device, feat_model, retFeature=True, isSingleStream=True, return_pose=False)
-    feat_l = feature_loss_batch(fr[0], ft[0], args.feature_matching_lvl, per_channel=args.per_channel)
-    photo_l = torch.mean((rgb - data) ** 2)
-    pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), torch.as_tensor(pose, device=device).reshape(B, 12).float())
-    if getattr(args, "combine_loss", False):
-        w = args.combine_loss_w
-        loss = w[0] * pose_l + w[1] * photo_l + w[2] * feat_l
+    # (hinted: the extractor's backward was just told to read the gradient of levels `lv` only, so the loss need not zero the others)
+    feat_l = feature_loss_batch(fr[0], ft[0], args.feature_matching_lvl, per_channel=args.per_channel,
+                                lazy_grad=hinted and sorted(set(int(l) for l in args.feature_matching_lvl)) == lv)
+    pose_gt = (pose if torch.is_tensor(pose) and pose.is_cuda else _to_device_async(pose, device)).reshape(B, 12).float()
+    if getattr(args, "combine_loss", False):   # (:359-368) one fused forward / backward pair on the GPU
+        loss, photo_l, pose_l = dm_combined_loss(rgb, data, pose_.reshape(B, 12), pose_gt, feat_l, args.combine_loss_w)
     else:
+        with torch.no_grad():   # reported only
+            photo_l = torch.mean((rgb - data) ** 2)
+            pose_l = torch.nn.functional.mse_loss(pose_.reshape(B, 12), pose_gt)
         loss = feat_l
     return (loss, photo_l, feat_l, pose_l) if parts else (loss, photo_l)
 
 
 def train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer, half_res, device, world_setup_dict,
                    **render_kwargs_test):
-    """One optimisation step of DFNet_dm (:322-390): returns (loss, psnr) as 1-element numpy arrays like the reference."""
+    """One optimisation step of DFNet_dm (:322-390): returns (loss, psnr) as 1-element numpy arrays like the reference (which means
+    waiting for the device: train_on_epoch uses train_on_batch_device and waits once per epoch)."""
     import numpy as np
+    loss, psnr = train_on_batch_device(args, data, model, feat_model, pose, img_idx, hwf, optimizer, half_res, device, world_setup_dict,
+                                       **render_kwargs_test)
+    return np.array([float(loss)]), np.array([float(psnr)])
+
+
+def train_on_batch_device(args, data, model, feat_model, pose, img_idx, hwf, optimizer, half_res, device, world_setup_dict,
+                          **render_kwargs_test):
+    """train_on_batch without the host round trip: (loss, psnr) as 0-dim device tensors.  Converting them to Python floats after
+    every step (the reference's `.item()`, :376-390) drains the stream and leaves the GPU idle while the host enqueues the next
+    step's ~190 launches (0.4 ms of a 14 ms step at batch 4)."""
     H, W, focal = hwf
     H, W = int(H), int(W)
     data = data.to(device)
     B = data.shape[0]
+    # the step's small host inputs go up first, through page-locked staging: no host-to-device copy waits in the middle of the step
+    img_idx = _to_device_async(img_idx, device).reshape(B, -1)
+    pose = _to_device_async(pose, device)
     target_features = _target_features_async(args, data, feat_model, device)   # side stream, beside the pose regression
     with torch.enable_grad():
         _, pose_ = inference_pose_regression(args, data, device, model, retFeature=False)
         pose_nerf = fix_coord_supp(args, pose_ if pose_.requires_grad else pose_.clone(), world_setup_dict, device=device)
-        img_idx = torch.as_tensor(img_idx, dtype=torch.float32, device=device).reshape(B, -1)
         # the reference renders pose 0 only (:342); every pose of the batch here, as one ray batch
         rgb = _render_batch(H, W, focal, pose_nerf, img_idx, half_res, render_kwargs_test)
         loss, photo_l = _losses(args, data, rgb, pose_, pose, feat_model, device, target_features=target_features)
@@ -193,7 +237,7 @@ def train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer,
     optimizer.zero_grad()
     with torch.no_grad():
         psnr = -10. * torch.log10(photo_l.detach())
-    return np.array([float(loss.detach())]), np.array([float(psnr)])
+    return loss.detach(), psnr
 
 
 def train_on_epoch(args, data_loaders, model, feat_model, hwf, optimizer, half_res, device, world_setup_dict,
@@ -203,11 +247,15 @@ def train_on_epoch(args, data_loaders, model, feat_model, hwf, optimizer, half_r
     train_dl = data_loaders[0]
     losses, psnrs = [], []
     for data, pose, img_idx in train_dl:
-        l, p = train_on_batch(args, data, model, feat_model, pose, img_idx, hwf, optimizer, half_res, device,
-                              world_setup_dict, **render_kwargs_test)
-        losses.append(l.item())
-        psnrs.append(p.item())
-    return float(np.mean(losses)), float(np.mean(psnrs))
+        l, p = train_on_batch_device(args, data, model, feat_model, pose, img_idx, hwf, optimizer, half_res, device,
+                                     world_setup_dict, **render_kwargs_test)
+        losses.append(l.reshape(1))
+        psnrs.append(p.reshape(1))
+    if not losses:
+        return float("nan"), float("nan")
+    # one wait per epoch; the means in float64 on the host like np.mean over the reference's per-step floats
+    return (float(np.mean(torch.cat(losses).cpu().numpy().astype(np.float64))),
+            float(np.mean(torch.cat(psnrs).cpu().numpy().astype(np.float64))))
 
 
 def eval_on_batch(args, data, model, feat_model, pose, img_idx, hwf, half_res, device, world_setup_dict, **render_kwargs_test):

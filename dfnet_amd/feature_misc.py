@@ -24,31 +24,25 @@ class _BicubicFn(torch.autograd.Function):
 
 
 class _BicubicBatchFn(torch.autograd.Function):
-    """[B,h,w,C] -> [B,H,W,C]: the frames of a mini-batch through the same kernels, written into one tensor (no per-frame
-    select / stack nodes in the graph)."""
+    """[B,h,w,C] -> [B,H,W,C]: the frames of a mini-batch in one launch each way (dfn_upsample_bicubic_frames)."""
 
     @staticmethod
-    def forward(ctx, imgs, H, W):
+    def forward(ctx, imgs, H, W, nchw=False):
         imgs = imgs.detach().contiguous()
         ctx.shape = imgs.shape[1:3]
-        out = torch.empty(imgs.shape[0], H, W, imgs.shape[3], device=imgs.device)
-        for b in range(imgs.shape[0]):
-            _engine.upsample_bicubic(imgs[b], H, W, out=out[b])
-        return out
+        ctx.nchw = bool(nchw)
+        return _engine.upsample_bicubic_frames(imgs, H, W, nchw=ctx.nchw)
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
-        out = torch.empty(g.shape[0], *ctx.shape, g.shape[3], device=g.device)
-        for b in range(g.shape[0]):
-            _engine.upsample_bicubic_backward(g[b], *ctx.shape, out=out[b])
-        return out, None, None
+        return _engine.upsample_bicubic_frames_backward(g.contiguous(), *ctx.shape, nchw=ctx.nchw), None, None, None
 
 
-def upsample_bicubic(img, H, W):
-    """nn.Upsample(size=(H, W), mode='bicubic') of an [h,w,C] image or a batch [B,h,w,C]; differentiable (HIP adjoint kernel)."""
+def upsample_bicubic(img, H, W, nchw=False):
+    """nn.Upsample(size=(H, W), mode='bicubic') of an [h,w,C] image or a batch [B,h,w,C]; differentiable (HIP adjoint kernel).
+    nchw (batches only): the result as a contiguous [B,C,H,W] tensor — `.permute(0, 3, 1, 2)` folded into the kernel's store."""
     if img.dim() == 4:
-        return _BicubicBatchFn.apply(img, int(H), int(W))
+        return _BicubicBatchFn.apply(img, int(H), int(W), bool(nchw))
     if torch.is_grad_enabled() and img.requires_grad:
         return _BicubicFn.apply(img, int(H), int(W))
     return _engine.upsample_bicubic(img, int(H), int(W))
@@ -131,7 +125,7 @@ class _FeatureCosineFn(torch.autograd.Function):
     forward / backward (dfn_feature_cosine_*): no index_select / permute copies, no gradient for the target stack."""
 
     @staticmethod
-    def forward(ctx, fr, ft, levels):
+    def forward(ctx, fr, ft, levels, lazy_grad=False):
         import ctypes
         from ._lib import check, current_stream, load, ptr
         lib = load()
@@ -145,6 +139,7 @@ class _FeatureCosineFn(torch.autograd.Function):
               "dfn_feature_cosine_forward")
         ctx.save_for_backward(fr, ft, state)
         ctx.levels = tuple(levels)
+        ctx.lazy_grad = bool(lazy_grad)
         return loss.reshape(())
 
     @staticmethod
@@ -155,19 +150,66 @@ class _FeatureCosineFn(torch.autograd.Function):
         levels = ctx.levels
         L, B, C, H, W = fr.shape
         G = torch.empty(L, B, C, H, W, device=fr.device)
-        for l in range(L):          # levels the loss does not read carry no gradient
-            if l not in levels:
-                G[l].zero_()
+        if not ctx.lazy_grad:       # levels the loss does not read carry no gradient (lazy_grad: the consumer was told which levels
+            for l in range(L):      # to read — the feature extractor's grad_levels hint — and the unread planes stay unwritten)
+                if l not in levels:
+                    G[l].zero_()
         gl = g.detach().reshape(1).to(torch.float32).contiguous()
         lv = (ctypes.c_int * len(levels))(*levels)
         check(load().dfn_feature_cosine_backward(ctypes.c_void_p(fr.data_ptr()), fr.stride(0), ctypes.c_void_p(ft.data_ptr()), ft.stride(0),
                                                  lv, len(levels), B, C, H * W, ptr(gl), ctypes.c_void_p(state.data_ptr()),
                                                  ctypes.c_void_p(G.data_ptr()), G.stride(0), current_stream()),
               "dfn_feature_cosine_backward")
-        return G, None, None
+        return G, None, None, None
 
 
-def feature_loss_batch(fr, ft, levels, per_channel=False):
+class _DmLossFn(torch.autograd.Function):
+    """The rest of the DFNet_dm loss block (direct_feature_matching.py:359-370) as one HIP forward / backward pair
+    (dfn_dm_loss_*): photo_loss = mean((rgb - target)^2), pose_loss = mse_loss(pose_, pose), loss = w[0] pose_loss + w[1] photo_loss
+    + w[2] feat_loss.  Returns (loss, photo_loss, pose_loss); only `loss` carries gradient (to rgb, pose_ and feat_loss)."""
+
+    @staticmethod
+    def forward(ctx, rgb, target, pose_, pose_gt, feat_l, w_pose, w_photo, w_feat):
+        import ctypes
+        from ._lib import check, current_stream, load, ptr
+        lib = load()
+        rgb, target = rgb.detach().contiguous(), target.detach().contiguous()
+        pose_, pose_gt = pose_.detach().contiguous(), pose_gt.detach().contiguous()
+        feat = feat_l.detach().reshape(1).contiguous()
+        out = torch.empty(4, device=rgb.device)
+        scratch = torch.empty(lib.dfn_dm_loss_scratch_bytes(), dtype=torch.uint8, device=rgb.device)
+        check(lib.dfn_dm_loss_forward(ptr(rgb), ptr(target), rgb.numel(), ptr(pose_), ptr(pose_gt), pose_.numel(), ptr(feat), float(w_pose),
+                                      float(w_photo), float(w_feat), ptr(out), ctypes.c_void_p(scratch.data_ptr()), current_stream()),
+              "dfn_dm_loss_forward")
+        ctx.save_for_backward(rgb, target, pose_, pose_gt)
+        ctx.w = (float(w_pose), float(w_photo), float(w_feat))
+        ctx.pose_shape = pose_.shape
+        photo, pl = out[1], out[2]
+        ctx.mark_non_differentiable(photo, pl)
+        return out[0], photo, pl
+
+    @staticmethod
+    def backward(ctx, g, _gp, _gq):
+        from ._lib import check, current_stream, load, ptr
+        rgb, target, pose_, pose_gt = ctx.saved_tensors
+        g_rgb, g_pose = torch.empty_like(rgb), torch.empty_like(pose_)
+        g_feat = torch.empty(1, device=rgb.device)
+        gl = g.detach().reshape(1).to(torch.float32).contiguous()
+        check(load().dfn_dm_loss_backward(ptr(rgb), ptr(target), rgb.numel(), ptr(pose_), ptr(pose_gt), pose_.numel(), *ctx.w, ptr(gl),
+                                          ptr(g_rgb), ptr(g_pose), ptr(g_feat), current_stream()), "dfn_dm_loss_backward")
+        return g_rgb, None, g_pose, None, g_feat.reshape(()), None, None, None
+
+
+def dm_combined_loss(rgb, target, pose_, pose_gt, feat_l, w):
+    """(loss, photo_loss, pose_loss) of the combine_loss branch (:359-368) — fused on the GPU, the reference's torch expression elsewhere."""
+    if rgb.is_cuda and rgb.dtype == torch.float32 and rgb.shape == target.shape and pose_.shape == pose_gt.shape:
+        return _DmLossFn.apply(rgb, target, pose_, pose_gt, feat_l, w[0], w[1], w[2])
+    photo_l = torch.mean((rgb - target) ** 2)
+    pose_l = torch.nn.functional.mse_loss(pose_, pose_gt)
+    return w[0] * pose_l + w[1] * photo_l + w[2] * feat_l, photo_l, pose_l
+
+
+def feature_loss_batch(fr, ft, levels, per_channel=False, lazy_grad=False):
     """The feature term of the DFNet_dm step (direct_feature_matching.py:352-358): the selected levels of the rendered and target
     stacks [L,B,C,H,W] -> [B, l*C, H, W] (preprocess_features_for_loss), feature_loss per image, mean over the batch.  On the
     GPU (per_channel False, the default) this is one fused kernel pair; per_channel=True and CPU tensors take the reference's own
@@ -175,7 +217,7 @@ def feature_loss_batch(fr, ft, levels, per_channel=False):
     levels = [int(l) for l in levels]
     if (not per_channel and fr.shape == ft.shape and len(set(levels)) == len(levels) <= 8 and _stack_layout(fr) is not None
             and _stack_layout(ft) is not None and not ft.requires_grad):
-        return _FeatureCosineFn.apply(fr, ft, tuple(levels))
+        return _FeatureCosineFn.apply(fr, ft, tuple(levels), bool(lazy_grad))
     idx = torch.tensor(levels, device=fr.device)
     def prep(f):
         f = torch.index_select(f, 0, idx).permute(1, 0, 2, 3, 4)

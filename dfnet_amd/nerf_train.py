@@ -52,12 +52,24 @@ class NerfHTrainer:
         self._ws = None
         self._saved = None
         self.exact = False   # default implementation of the step (fused at netwidth 128; other widths always run the exact one)
+        self.fused_split = False   # fused step: keep hi | lo planes of the FINE network's stored operands too (DFN_TRAIN_FUSED_SPLIT)
         # The fused step splits the LIVE master weights at the operand scale of the last dfn_nerfh_commit (64x headroom): a weight that
-        # outgrows it saturates in the packed blob and the chains only OR a bit into the handle's range flag.  train_step() reads the
-        # flag every `range_check_every` steps (0: never) and, if raised, re-commits at the live weights and repeats the step.
+        # outgrows it saturates in the packed blob and the chains OR a bit into the step's range word.  The library then leaves
+        # ZEROS in every gradient tensor of that step (csrc/nerfh_fused_train.h: GuardArgs — a skipped step, as a loss scaler skips
+        # one) and passes the bits on to the handle's range flag.  What train_step() does about it (`range_check`):
+        #   "skip"   (default) reads the flag WITHOUT draining the stream (dfn_nerfh_range_status_async into pinned memory, looked at
+        #            one or two steps later): the flagged step stays skipped, the operand scale is re-committed at the live weights
+        #            (the exact-fp32 step takes over if a step right after a re-commit is flagged again);
+        #   "repeat" waits for the stream after every `range_check_every`-th step and, if flagged, re-commits and REPEATS the step
+        #            (then on the exact-fp32 path if that does not clear it): p.grad always holds the step's gradients;
+        #   None     never looks (flagged steps are still skipped by the library).
+        self.range_check = "skip"
         self.range_check_every = 1
         self.range_recoveries = 0
         self._steps = 0
+        self._pending = []          # ("skip"): [(event, pinned int32 slot)] of flag reads still in flight
+        self._slots = None
+        self._last_recommit_step = -10
 
     # ------------------------------------------------------------------ plumbing
     def _ptr_array(self, tensors):
@@ -81,7 +93,7 @@ class NerfHTrainer:
     def set_mode(self, exact):
         """DFN_TRAIN_FUSED (netwidth 128: the register-resident chains of csrc/nerfh_fused_*.hip) or DFN_TRAIN_EXACT (layer by layer,
         exact fp32, activations kept: what backward_rays() needs)."""
-        check(self.lib.dfn_nerfh_set_train_mode(self.engine.handle, 1 if exact else 0), "dfn_nerfh_set_train_mode")
+        check(self.lib.dfn_nerfh_set_train_mode(self.engine.handle, 1 if exact else (2 if self.fused_split else 0)), "dfn_nerfh_set_train_mode")
 
     def forward(self, rays_o, rays_d, hist, Nc, Ni, near, far, t_rand=None, noise=None, raw_noise_std=0., u=None, exact=None):
         """Training-mode render_rays -> dict(rgb_map, disp_map, acc_map, raw, rgb0, disp0, acc0, z_std, beta,
@@ -173,12 +185,58 @@ class NerfHTrainer:
         cut = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
         self.engine.load_numpy(cut("coarse."), cut("fine."), sd["embedding_a.weight"], sd["embedding_t.weight"])
 
+    def _post_flag_read(self, dev):
+        """Enqueue a read-and-clear of the range flag behind this step's kernels (no wait): pinned slot + event."""
+        if self._slots is None:
+            self._slots = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(4)]
+        slot = self._slots[self._steps % len(self._slots)]
+        check(self.lib.dfn_nerfh_range_status_async(self.engine.handle, ctypes.c_void_p(slot.data_ptr()), current_stream()),
+              "dfn_nerfh_range_status_async")
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((ev, slot, self._steps))
+
+    def _drain_flags(self, block_beyond=0):
+        """Look at the flag reads that have landed; wait for the oldest ones while more than `block_beyond` are in flight."""
+        flagged = None
+        while self._pending:
+            ev, slot, step = self._pending[0]
+            if not ev.query():
+                if len(self._pending) <= block_beyond:
+                    break
+                ev.synchronize()
+            self._pending.pop(0)
+            if int(slot[0]):
+                flagged = (int(slot[0]), step)
+        if flagged is None:
+            return
+        flags, step = flagged
+        self.range_recoveries += 1
+        if step - self._last_recommit_step <= 3:
+            warnings.warn(f"NerfHTrainer: step {step} left the split-f16 operand range again (flags {flags:#x}) right after a re-commit: "
+                          "its gradients were zeroed; the following steps run on the exact-fp32 path", RuntimeWarning)
+            self.exact = True
+            return
+        warnings.warn(f"NerfHTrainer: step {step} of the fused training path left the split-f16 operand range (flags {flags:#x}): its "
+                      "gradients were zeroed (a skipped step); re-committing the operand scale at the live weights", RuntimeWarning)
+        torch.cuda.current_stream().synchronize()
+        self._pending.clear()
+        self.recommit()
+        self.engine.range_flags()   # the steps enqueued between the flagged one and this re-commit ran at the old scale too
+        self._last_recommit_step = self._steps
+
+    def flush_range_check(self):
+        """Wait for the flag reads in flight and act on them (end of a training loop / before a checkpoint)."""
+        self._drain_flags(block_beyond=0)
+        return self.range_recoveries
+
     def train_step(self, rays_o, rays_d, hist, target, Nc, Ni, near, far, perturb=1., raw_noise_std=0., draws=None, coef=1.,
                    lambda_u=0.01):
         """run_nerf.py:50-66 without the optimizer: forward, NerfWLoss, backward into p.grad.  Returns (loss dict of 0-dim
-        tensors c_l/f_l/b_l/s_l, psnr, render outputs).  A fused step whose operands left the split-f16 range (range flag) is
-        repeated — at a re-derived operand scale, then, if that does not clear it, on the exact-fp32 step — so p.grad never holds
-        clamped gradients."""
+        tensors c_l/f_l/b_l/s_l, psnr, render outputs).  A fused step whose operands left the split-f16 range (range flag) leaves
+        ZERO gradients (the library's guard); `self.range_check` decides whether it is then skipped ("skip": found out without
+        draining the stream, re-commit for the following steps) or repeated ("repeat": at a re-derived operand scale, then, if that
+        does not clear it, on the exact-fp32 step) — p.grad never holds clamped gradients."""
         n = rays_o.reshape(-1, 3).shape[0]
         t_rand, noise, u = draws if draws is not None else self.draw(n, Nc, Ni, perturb, rays_o.device)
 
@@ -188,9 +246,14 @@ class NerfHTrainer:
             self.backward(g_rgb, g_rgb0, g_beta, g_ts)
             return out, loss5
 
+        if self.range_check == "skip":
+            self._drain_flags(block_beyond=1)
         out, loss5 = run(None)
         every = int(self.range_check_every or 0)
-        if not self._saved["exact"] and every > 0 and self._steps % every == 0:
+        if self.range_check == "skip":
+            if not self._saved["exact"]:
+                self._post_flag_read(rays_o.device)
+        elif self.range_check == "repeat" and not self._saved["exact"] and every > 0 and self._steps % every == 0:
             flags = self.engine.range_flags()
             if flags:
                 self.range_recoveries += 1
@@ -239,7 +302,7 @@ class _RenderTrainFn(torch.autograd.Function):
             g_o, g_d = tr.backward_rays(*gs, 0., g_ts, saved=ctx.saved)
         if any(ctx.needs_input_grad[12:]):
             tr.backward(*gs, 0., g_ts, grads=grads, saved=ctx.saved)
-            if not ctx.saved["exact"] and tr.range_check_every:
+            if not ctx.saved["exact"] and tr.range_check:
                 flags = tr.engine.range_flags()   # an autograd node cannot repeat its forward: fail loudly instead of clamped gradients
                 if flags:
                     raise _lib.DfnError(f"render(): the fused training step left the split-f16 operand range (flags {flags:#x}); call "

@@ -142,8 +142,7 @@ class _RenderFramesFn(torch.autograd.Function):
     def forward(ctx, c2ws, eng, H, W, focal, hists, Nc, Ni, near, far):
         from . import engine as _e
         B = c2ws.shape[0]
-        rays = [_e.raygen(H, W, focal, c2ws[b].detach()) for b in range(B)]
-        o, d, v = (torch.cat([r[k].reshape(-1, 3) for r in rays]) for k in range(3))
+        o, d, v = (t.reshape(-1, 3) for t in _e.raygen_frames(H, W, focal, c2ws.detach()))
         hist = hists.reshape(B, 1, -1).expand(B, H * W, hists.shape[-1]).reshape(B * H * W, -1).contiguous()   # one row per ray
         rgb, _, _, saved = _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far)
         ctx.save_for_backward(*saved)
@@ -155,8 +154,7 @@ class _RenderFramesFn(torch.autograd.Function):
         from . import engine as _e
         eng, B, H, W, focal = ctx.cfg
         go, gd, _ = _saved_backward(eng, ctx.saved_tensors, g_rgb)
-        go, gd = go.reshape(B, H * W, 3), gd.reshape(B, H * W, 3)
-        gc = torch.stack([_e.raygen_backward(H, W, focal, go[b].contiguous(), gd[b].contiguous()) for b in range(B)])
+        gc = _e.raygen_frames_backward(H, W, focal, go.reshape(B, H * W, 3), gd.reshape(B, H * W, 3))
         return (gc,) + (None,) * 9
 
 

@@ -92,6 +92,12 @@ int dfn_nerfh_set_render_options(dfn_nerfh_t h, int flags);
  * The Python host checks it at the end of every render_path batch and before a checkpoint-driven CLI run reports a PSNR. */
 enum { DFN_RANGE_F16_OVERFLOW = 1, DFN_RANGE_F16X3_SATURATED = 2 };
 int dfn_nerfh_range_status(dfn_nerfh_t h, int* flags, void* stream);
+/* The same read-and-clear ENQUEUED on `stream` without waiting: *host_flags (page-locked host memory — hipHostMalloc /
+ * torch.Tensor.pin_memory — else the copy is synchronous) holds the DFN_RANGE_* bits once the stream has passed this point (record
+ * an event behind the call).  For training loops (run_nerf.py:32-80), which must not drain the stream every step: the fused
+ * training step (dfn_nerfh_train_backward) leaves ZEROS in every gradient tensor of a step whose operands left the split-f16
+ * range — a skipped step, never clamped gradients — so the host may learn of it a step or two late, re-commit and carry on. */
+int dfn_nerfh_range_status_async(dfn_nerfh_t h, int* host_flags, void* stream);
 
 /* ------------------------------------------------------------------ stage-level entry points
  * (each is the production kernel of that stage; exposed so parity tests can check a stage
@@ -101,6 +107,9 @@ int dfn_nerfh_range_status(dfn_nerfh_t h, int* flags, void* stream);
  * row-major (12 floats).  Outputs [H*W,3] each; viewdirs may be NULL. */
 int dfn_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d,
                float* viewdirs, void* stream);
+/* The same for the B frames of a mini-batch in ONE launch (direct_feature_matching.py:340-348 renders the frames of its batch in a
+ * loop): c2w [B,3,4] -> rays_o, rays_d (, viewdirs) [B,H,W,3]. */
+int dfn_raygen_frames(int B, int H, int W, float focal, const float* c2w, float* rays_o, float* rays_d, float* viewdirs, void* stream);
 /* models/ray_utils.py:27-46 ndc_rays (render(ndc=True), rendering.py:374-376, calls it with near = 1): rays_o / rays_d [n,3] of an
  * H x W pinhole camera -> normalised device coordinates, out_o / out_d [n,3] (may alias the inputs). */
 int dfn_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, size_t n, float* out_o,
@@ -207,6 +216,9 @@ int dfn_ray_grad_reduce(const float* grad_pts, const float* z_fine, const float*
 /* get_rays backward (ray_utils.py:5-15): grad_c2w [3,4] from grad_rays_o / grad_rays_d [H*W, 3]. */
 int dfn_raygen_backward(int H, int W, float focal, const float* grad_rays_o, const float* grad_rays_d,
                         float* grad_c2w, void* stream);
+/* ... and its batched form: grad_rays_o / grad_rays_d [B,H*W,3] -> grad_c2w [B,3,4]. */
+int dfn_raygen_frames_backward(int B, int H, int W, float focal, const float* grad_rays_o, const float* grad_rays_d, float* grad_c2w,
+                               void* stream);
 /* Scratch needed by dfn_render_rays_backward / dfn_render_image_backward for up to n_rays rays. */
 size_t dfn_render_backward_workspace_bytes(size_t n_rays, int Nc, int Ni);
 /* d L / d rays_o, d L / d rays_d [n_rays, 3] of dfn_render_rays from grad_rgb [n_rays, 3] (recomputes the
@@ -233,6 +245,12 @@ int dfn_upsample_bicubic(const float* in, int H, int W, int C, int outH, int out
 /* Adjoint of dfn_upsample_bicubic: grad_out [outH,outW,C] -> grad_in [H,W,C]. */
 int dfn_upsample_bicubic_backward(const float* grad_out, int H, int W, int C, int outH, int outW, float* grad_in,
                                   void* stream);
+/* Both for a batch of frames in one launch: in [B,H,W,C] -> out [B,outH,outW,C]; grad_out [B,outH,outW,C] -> grad_in [B,H,W,C].
+ * out_nchw != 0: the enlarged frames (and grad_out) are planar [B,C,outH,outW] — the layout DFNet.forward takes, i.e. the
+ * `.permute(0, 3, 1, 2)` of direct_feature_matching.py:346 folded into the store. */
+int dfn_upsample_bicubic_frames(const float* in, int B, int H, int W, int C, int outH, int outW, int out_nchw, float* out, void* stream);
+int dfn_upsample_bicubic_frames_backward(const float* grad_out, int B, int H, int W, int C, int outH, int outW, int out_nchw,
+                                         float* grad_in, void* stream);
 
 /* ------------------------------------------------------------------ DFNet feature extractor
  * Replaces feature/dfnet.py:74-172 (class DFNet / DFNet_s: VGG16 `features` stack, AdaptLayers,
@@ -380,6 +398,18 @@ int dfn_feature_cosine_backward(const float* fr, size_t level_stride_r, const fl
                                 int n_levels, int B, int C, size_t HW, const float* grad_loss, const void* state, float* grad_fr,
                                 size_t grad_stride, void* stream);
 
+/* The rest of the DFNet_dm loss block (feature/direct_feature_matching.py:359-370): photo_loss = mean((rgb - target)^2) over the n
+ * elements of the [B,3,H,W] frames, pose_loss = mse_loss(pose, pose_gt) over n_pose = 12 B floats, loss = w_pose pose_loss +
+ * w_photo photo_loss + w_feat feat_loss (args.combine_loss_w; feat_loss: the device scalar dfn_feature_cosine_forward wrote, NULL = 0).
+ * out4 (device) = loss, photo_loss, pose_loss, feat_loss.  Backward: grad_rgb [n], grad_pose [n_pose], grad_feat [1] (may be NULL)
+ * from the device scalar grad_loss.  Sums in fp64 over fixed chunks (deterministic).  scratch: dfn_dm_loss_scratch_bytes() device bytes. */
+size_t dfn_dm_loss_scratch_bytes(void);
+int dfn_dm_loss_forward(const float* rgb, const float* target, size_t n, const float* pose, const float* pose_gt, int n_pose,
+                        const float* feat_loss, float w_pose, float w_photo, float w_feat, float* out4, void* scratch, void* stream);
+int dfn_dm_loss_backward(const float* rgb, const float* target, size_t n, const float* pose, const float* pose_gt, int n_pose,
+                         float w_pose, float w_photo, float w_feat, const float* grad_loss, float* grad_rgb, float* grad_pose,
+                         float* grad_feat, void* stream);
+
 /* The pose regressor's rotation re-orthogonalisation (feature/direct_feature_matching.py:85-92, feature/misc.py:68-72:
  * `u, s, v = torch.svd(pose[:, :3, :3]); pose[:, :3, :3] = u @ v^T`) and its adjoint, closed form: U V^T is the orthogonal polar
  * factor of the 3x3 block (scaled Newton iteration in fp64, one thread per pose) — no SVD / GEMM library call in the DFNet_dm step.
@@ -425,8 +455,12 @@ int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* para
  * gradient tensors, so an optimizer step needs no host round trip.  Two implementations behind the same calls:
  *   DFN_TRAIN_FUSED (default at netwidth 128): both networks as register-resident chains on split-f16 MFMA products
  *     (fp32-grade), forward and data-gradient; only the layer inputs / pre-activation gradients the WEIGHT gradients need
- *     are stored (as pre-split MFMA operands) and streamed once through the weight-gradient kernel; the step's weights are
- *     re-packed on the device at the start of the forward (csrc/nerfh_fused_*.hip);
+ *     are stored (as MFMA operands) and streamed once through the weight-gradient kernel; the step's weights are
+ *     re-packed on the device at the start of the forward (csrc/nerfh_fused_*.hip).  The coarse network's stored operands are
+ *     hi | lo f16 planes (4 bytes per element), the fine network's ONE f16 plane (2 bytes: half the step's HBM traffic; its weight
+ *     gradients are sums over ~3e5 points whose f16 rounding errors average out — within 3e-5 of two planes at random-init weights,
+ *     3e-4 on trained-like weights, csrc/nerfh_fused_train.h);
+ *   DFN_TRAIN_FUSED_SPLIT: the same with hi | lo planes for BOTH networks (round-4 layout, 4.67 GB per 1 536-ray step);
  *   DFN_TRAIN_EXACT (any even netwidth): layer by layer on exact-fp32 MFMA products over activations kept in the workspace.
  *
  * `params` / `grads`: HOST arrays of dfn_nerfh_train_param_count() DEVICE pointers in the order of
@@ -437,8 +471,10 @@ int dfn_dfnet_refresh_pose_params_device(dfn_dfnet_t h, const float* const* para
 int dfn_nerfh_train_param_count(void);
 const char* dfn_nerfh_train_param_name(int i);
 size_t dfn_nerfh_train_workspace_bytes(dfn_nerfh_t h, size_t n_rays, int Nc, int Ni);
-/* Selects the implementation of the training step for this handle (the workspace size above covers both). */
-enum { DFN_TRAIN_FUSED = 0, DFN_TRAIN_EXACT = 1 };
+/* Selects the implementation of the training step for this handle (the workspace size above covers all of them).  A step whose
+ * split-f16 operands left their range (weights that outgrew the committed scale) leaves ZEROS in every gradient tensor and raises
+ * the range flag (dfn_nerfh_range_status / _async): a skipped step, never clamped gradients. */
+enum { DFN_TRAIN_FUSED = 0, DFN_TRAIN_EXACT = 1, DFN_TRAIN_FUSED_SPLIT = 2 };
 int dfn_nerfh_set_train_mode(dfn_nerfh_t h, int mode);
 /* Host-only consistency check of the fused step's tables for a netwidth-128 geometry (no device work): every parameter element
  * the chain kernels read is packed exactly once per pass and every gradient element is written by exactly one accumulator of the

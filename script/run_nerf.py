@@ -70,6 +70,7 @@ def train_on_epoch_nerfw(args, train_dl, H, W, focal, N_rand, optimizer, loss_fu
         new_lrate = args.lrate * (decay_rate ** (global_step / decay_steps))
         for param_group in optimizer.param_groups:
             param_group['lr'] = new_lrate
+    trainer.flush_range_check()   # range-flag reads still in flight (NerfHTrainer.range_check = "skip"): act on them before a checkpoint / render
     return loss, psnr
 
 

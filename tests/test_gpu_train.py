@@ -226,14 +226,17 @@ def test_render_training_autograd_surface_and_optimizer_step():
     assert float((rgb2.detach() - before).abs().max()) > 1e-5
 
 
-@pytest.mark.parametrize("perturb,per_ray_hist,lindisp", [(0., False, False), (1., True, True), (0., True, False)])
-def test_fused_step_equals_exact_step(perturb, per_ray_hist, lindisp):
-    """The two implementations of the training step behind dfn_nerfh_train_forward / _backward (fused register-resident chains,
-    layer-by-layer exact fp32) on the same rays: outputs to 1e-6, every gradient tensor to 5e-4 relative L2 — without random draws
+@pytest.mark.parametrize("perturb,per_ray_hist,lindisp,split", [(0., False, False, False), (1., True, True, False), (0., True, False, False),
+                                                                  (0., False, False, True), (1., True, True, True)])
+def test_fused_step_equals_exact_step(perturb, per_ray_hist, lindisp, split):
+    """The implementations of the training step behind dfn_nerfh_train_forward / _backward (fused register-resident chains — the
+    fine network's stored operands as one f16 plane, DFN_TRAIN_FUSED, or as hi | lo planes, DFN_TRAIN_FUSED_SPLIT — and layer-by-layer
+    exact fp32) on the same rays: outputs to 1e-6, every gradient tensor to 5e-4 relative L2 — without random draws
     (perturb 0: linspace depths and u), with per-ray histograms, with depths linear in disparity, on a ray count that leaves the last
     tile of both networks ragged."""
     E, mods, _ = modules()
     tr = nerf_train.NerfHTrainer(E, *mods)
+    tr.fused_split = split
     R, Nc, Ni = 77, 24, 40
     rng = np.random.default_rng(21)
     ro, rd = orc.get_rays(480, 640, 585.0, T(syn.orbit_pose(5, 8))[:3, :4])
@@ -259,7 +262,8 @@ def test_fused_step_equals_exact_step(perturb, per_ray_hist, lindisp):
     for k in res["exact"][0]:
         assert abs(res["fused"][0][k] - res["exact"][0][k]) <= 3e-6 * abs(res["exact"][0][k]) + 1e-8, k
     worst = max(rel_l2(a, b.cpu()) for a, b in zip(res["fused"][2], res["exact"][2]))
-    print(f"fused vs exact step (perturb {perturb}, per-ray hist {per_ray_hist}, lindisp {lindisp}): worst gradient rel L2 {worst:.2e}")
+    print(f"fused vs exact step (perturb {perturb}, per-ray hist {per_ray_hist}, lindisp {lindisp}, fine operands {'hi|lo' if split else 'one f16 plane'}): "
+          f"worst gradient rel L2 {worst:.2e}")
     assert worst < 5e-4
 
 
@@ -274,22 +278,30 @@ def _small_step_inputs(R=64, Nc=16, Ni=24, seed=33):
     return o, d, hist, target, Nc, Ni, draws
 
 
-def test_fused_step_recovers_when_weights_outgrow_the_committed_scale():
-    """The fused step splits the LIVE weights at the operand scale of the last commit (64x headroom).  A weight that outgrows it
-    saturates in the packed blob and raises the range flag; train_step() must notice, re-commit at the live weights and repeat the
-    step, so that p.grad equals the exact step's gradients instead of clamped / NaN ones (round-4 advisor finding)."""
+def _outgrown_trainer():
     E, mods, _ = modules()
     tr = nerf_train.NerfHTrainer(E, *mods)
-    o, d, hist, target, Nc, Ni, draws = _small_step_inputs()
+    inputs = _small_step_inputs()
     with torch.no_grad():   # 1000x on a few weights of one hidden layer AFTER the commit: beyond the 64x headroom of the split
         w = dict(zip(tr.names, tr.params))["fine.xyz_encoding_3.0.weight"]
         w[:4, :4] *= 1000.
+    o, d, hist, target, Nc, Ni, draws = inputs
     tr.exact = True
     ld_e, _, _ = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
     exact = [p.grad.clone() for p in tr.params]
     for p in tr.params:
         p.grad = None
     tr.exact = False
+    return E, tr, inputs, ld_e, exact
+
+
+def test_fused_step_repeats_when_weights_outgrow_the_committed_scale():
+    """The fused step splits the LIVE weights at the operand scale of the last commit (64x headroom).  A weight that outgrows it
+    saturates in the packed blob and raises the step's range word.  range_check = "repeat": train_step() notices, re-commits at the
+    live weights and repeats the step, so that p.grad equals the exact step's gradients instead of clamped / NaN ones (round-4
+    advisor finding)."""
+    E, tr, (o, d, hist, target, Nc, Ni, draws), ld_e, exact = _outgrown_trainer()
+    tr.range_check = "repeat"
     with pytest.warns(RuntimeWarning, match="operand range"):
         ld_f, _, _ = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
     assert tr.range_recoveries == 1 and E.range_flags() == 0
@@ -304,6 +316,58 @@ def test_fused_step_recovers_when_weights_outgrow_the_committed_scale():
         _w.simplefilter("error")
         tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
     assert tr.range_recoveries == 1
+
+
+def test_fused_step_is_skipped_when_weights_outgrow_the_committed_scale():
+    """range_check = "skip" (the default: no stream drain per step).  The library itself zeroes EVERY gradient tensor of a step whose
+    operands left the split-f16 range (csrc/nerfh_fused_train.h: GuardArgs) — the optimizer sees a skipped step, never clamped
+    gradients; the trainer finds the flag one or two steps later, re-commits, and the steps after that are the exact step's again."""
+    import warnings as _w
+    E, tr, (o, d, hist, target, Nc, Ni, draws), ld_e, exact = _outgrown_trainer()
+    assert tr.range_check == "skip"
+    with _w.catch_warnings():   # the flagged step itself returns without draining the stream: nothing to warn about yet
+        _w.simplefilter("error")
+        tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+    torch.cuda.synchronize()
+    assert all(float(p.grad.abs().max()) == 0. for p in tr.params), "a flagged step must leave zeros in every gradient tensor"
+    with pytest.warns(RuntimeWarning, match="skipped step"):
+        assert tr.flush_range_check() == 1
+    assert E.range_flags() == 0
+    with _w.catch_warnings():   # re-committed: this step runs at the new scale and matches the exact step
+        _w.simplefilter("error")
+        ld_f, _, _ = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+        assert tr.flush_range_check() == 1
+    worst = max(rel_l2(p.grad, g) for p, g in zip(tr.params, exact))
+    print(f"fused step after the skipped one vs exact step: worst gradient rel L2 {worst:.2e}")
+    assert worst < 2e-3
+    for k in ld_e:
+        assert abs(float(ld_f[k]) - float(ld_e[k])) <= 1e-5 * abs(float(ld_e[k])) + 1e-8, k
+
+
+def test_a_render_flag_left_unfetched_does_not_skip_training_steps():
+    """The guard looks at the STEP's own range word: a flag a render left behind (an overflowing f16 frame the host has not asked
+    about yet) must not zero the gradients of the training steps that follow on the same handle."""
+    E, mods, (cw, fw, ea, et) = modules()
+    tr = nerf_train.NerfHTrainer(E, *mods)
+    o, d, hist, target, Nc, Ni, draws = _small_step_inputs()
+    tr.range_check = None
+    tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+    ref = [p.grad.clone() for p in tr.params]
+    assert E.range_flags() == 0 and any(float(g.abs().max()) > 0 for g in ref)
+    # an f16 render of a network with one layer blown up overflows f16 and raises the handle's flag ...
+    E2w = {k: v.copy() for k, v in fw.items()}
+    for k in ("xyz_encoding_2.0.weight", "xyz_encoding_3.0.weight"):   # activations ~3e2 after layer 2, ~4e5 after layer 3: beyond f16
+        E2w[k] = E2w[k] * 2e3
+    E.load_numpy(cw, E2w, ea, et)
+    E.render_rays(o, d, hist, Nc, Ni, 0., 2.5, precision="f16")
+    # ... which nobody fetches; the trainer's own (sane) weights step through the fused path at that commit's operand scale
+    tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+    torch.cuda.synchronize()
+    worst = max(rel_l2(p.grad, g) for p, g in zip(tr.params, ref))
+    flags = E.range_flags()
+    print(f"step after an unfetched render flag ({flags:#x}): worst gradient rel L2 vs the clean step {worst:.2e}")
+    assert flags & 1, "the f16 render of the blown-up network should have raised DFN_RANGE_F16_OVERFLOW"
+    assert worst < 5e-3   # (operand scale of a commit with 2e3 x larger weights: the live weights keep fewer lo bits)
 
 
 def test_train_backward_refuses_a_mode_switch_after_the_forward():

@@ -10,7 +10,22 @@ done
 [ -f $G/prof_dm/dm_kernel_stats.csv ] && cp $G/prof_dm/dm_kernel_stats.csv $P/${T}_dm_step_kernel_stats.csv
 [ -f $G/prof_train/tr_kernel_stats.csv ] && cp $G/prof_train/tr_kernel_stats.csv $P/${T}_train_step_kernel_stats.csv
 [ -f $G/dfnet_layers.txt ] && cp $G/dfnet_layers.txt $P/${T}_dfnet_layers.txt
-[ -f $G/dm_step.json ] && cp $G/dm_step.json $P/${T}_dm_step.json
+[ -f $G/dm_step.json ] && python3 - $G/dm_step.json $G/prof_dm/dm_kernel_stats.csv $P/${T}_dm_step.json <<'PY'
+# the step's JSON + launches per step and library-kernel census from the kernel trace of the same run
+import csv, json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+try:
+    rows = list(csv.DictReader(open(sys.argv[2])))
+    it = int(d.get("iters_profiled", 25))
+    d["launches_per_step"] = round(sum(int(r["Calls"]) for r in rows) / it, 1)
+    d["launches_under_10us_per_step"] = round(sum(int(r["Calls"]) for r in rows if float(r["AverageNs"]) < 1e4) / it, 1)
+    d["kernel_ms_per_step"] = round(sum(float(r["TotalDurationNs"]) for r in rows) / 1e6 / it, 3)
+    d["vendor_library_kernels"] = sorted({r["Name"][:60] for r in rows if any(k in r["Name"] for k in ("Cijk_", "rocsolver", "rocblas"))})
+    d["source"] = "tools/gpu_dm_step.py 4 24 under rocprofv3 --kernel-trace --stats (profiles/%s_dm_step_kernel_stats.csv)" % sys.argv[3].split("/")[-1].split("_")[0]
+except Exception as e:
+    d["launch_census_error"] = str(e)
+json.dump(d, open(sys.argv[3], "w"), indent=1)
+PY
 [ -f $G/train_step.json ] && cp $G/train_step.json $P/${T}_train_step.json
 [ -f $G/train_step_pmc.json ] && cp $G/train_step_pmc.json $P/${T}_train_step_pmc.json
 [ -f $G/prof_ft/ft_kernel_stats.csv ] && cp $G/prof_ft/ft_kernel_stats.csv $P/${T}_feature_train_kernel_stats.csv

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dfnet_amd import engine as eng, synthetic as syn
 from dfnet_amd.dfnet import DFNet
-from dfnet_amd.direct_feature_matching import matching_step_forward, matching_step_grad, train_on_batch
+from dfnet_amd.direct_feature_matching import matching_step_forward, matching_step_grad, train_on_batch, train_on_batch_device
 from dfnet_amd.nerfw import HipQuery
 
 dev = torch.device("cuda:0")
@@ -73,9 +73,23 @@ if os.environ.get("DM_ONLY"):   # profiling aid: only the full optimisation step
                 c[(e.name[:28], " < ".join(names)[:150], " | ".join(st)[:200])] += 1
         for k, v in c.most_common(40):
             print(v / 2, k)
+        # every top-level aten op of a step (each is one or more launches) with the package frame that issued it
+        c2 = collections.Counter()
+        for e in prof.events():
+            if not e.name.startswith("aten::"):
+                continue
+            p = e.cpu_parent
+            if p is not None and (p.name.startswith("aten::") or "autograd" in p.name.lower() and False):
+                continue
+            st = [x for x in (e.stack or []) if "dfnet_amd" in x or "tools/" in x or "optim" in x][:1]
+            c2[(e.name, (st[0] if st else (p.name if p is not None else "-"))[-110:])] += 1
+        print("---- top-level aten ops per step")
+        for k, v in c2.most_common(70):
+            print(v / 2, k)
         sys.exit(0)
-    ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
-    print(json.dumps({"full_step_ms": ms, "iters_profiled": iters + 1}))
+    fn = train_on_batch if os.environ.get("DM_HOST_FLOATS") else train_on_batch_device   # the epoch loop keeps the losses on the device
+    ms, _ = timed(lambda: fn(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
+    print(json.dumps({"full_step_ms": ms, "iters_profiled": iters + 1, "host_floats_per_step": bool(os.environ.get("DM_HOST_FLOATS"))}))
     sys.exit(0)
 results = {}
 for mode, fp in (("fp32 forward state", "f32"), ("f16 forward state", None)):
@@ -98,10 +112,12 @@ class NoStep:   # gradients only: isolates the weight-gradient kernels from the 
     def zero_grad(self):
         for q in model.parameters(): q.grad = None
 wg_ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], NoStep(), True, dev, setup, **kw))
-full_ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
+full_ms, _ = timed(lambda: train_on_batch_device(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
+host_ms, _ = timed(lambda: train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], opt, True, dev, setup, **kw))
 print(json.dumps({"workload": f"DFNet_dm step, batch {B}, 240x320, render 60x80 @64+128 + bicubic x4, level-0 feature loss",
                   "forward_ms": fwd_ms, "forward_backward_to_pose_ms": step_ms,
-                  "forward_backward_all_gradients_ms": wg_ms, "full_step_with_adam_and_device_repack_ms": full_ms, "ms_per_frame": step_ms / B,
+                  "forward_backward_all_gradients_ms": wg_ms, "full_step_with_adam_and_device_repack_ms": full_ms,
+                  "full_step_returning_host_floats_ms": host_ms, "ms_per_frame": step_ms / B,
                   "loss": float(out["loss"]), "grad_pose_absmax": float(out["grad_pose"].abs().max()),
                   "grad_kernel_modes": {k: v for k, v in results.items() if k.startswith("grad kernel")},
                   "all_fp32_tracked_forward_ms": results["fp32 forward state"]["forward_backward_to_pose_ms"],

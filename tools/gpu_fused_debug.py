@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Fused NeRF-H training step (csrc/nerfh_fused_*.hip) against the layer-by-layer exact-fp32 step on the same rays, weights and draws:
-forward outputs and every gradient tensor (relative L2), then timing of both.  usage: gpu_fused_debug.py [rays] [Nc] [Ni]"""
+forward outputs and every gradient tensor (relative L2), then timing of both.  usage: gpu_fused_debug.py [rays] [Nc] [Ni] [trained]
+("trained": the trained-like weights of tests/golden/trained_nerfh_weights.npz on the scene they were trained on, targets = its
+analytic images: small, cancelling gradients — the regime a converged run spends its time in — instead of seeded random weights)"""
 import json, os, sys, time
 import numpy as np
 import torch
@@ -14,14 +16,30 @@ dev = torch.device("cuda:0")
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 Nc = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 Ni = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+TRAINED = len(sys.argv) > 4 and sys.argv[4] == "trained"
 E, mods, _ = modules()
-tr = nerf_train.NerfHTrainer(E, *mods)
 rng = np.random.default_rng(0)
-ro, rd = orc.get_rays(480, 640, 585.0, torch.from_numpy(syn.orbit_pose(0, 8))[:3, :4])
-sel = rng.choice(480 * 640, R, replace=False)
+if TRAINED:
+    cw, fw, ea, et = syn.trained_nerfh_weights()
+    mods[0].load_state_dict({k: torch.from_numpy(v) for k, v in cw.items()})
+    mods[1].load_state_dict({k: torch.from_numpy(v) for k, v in fw.items()})
+    mods[2].weight.data.copy_(torch.from_numpy(ea))
+    mods[3].weight.data.copy_(torch.from_numpy(et))
+    E.load_numpy(cw, fw, ea, et)
+    H, W, focal = 60, 80, 585.0 / 8
+    pose = syn.orbit_pose(7, 16)[:3, :4]
+    ro, rd = orc.get_rays(H, W, focal, torch.from_numpy(pose))
+    sel = rng.choice(H * W, R, replace=False)
+    target = torch.from_numpy(syn.analytic_scene_image(pose, H, W, focal, 2.5)).reshape(-1, 3)[sel].contiguous().to(dev)
+    hist = torch.from_numpy(syn.HIST_IDX)[None].repeat(R, 1).contiguous().to(dev)
+else:
+    ro, rd = orc.get_rays(480, 640, 585.0, torch.from_numpy(syn.orbit_pose(0, 8))[:3, :4])
+    sel = rng.choice(480 * 640, R, replace=False)
+    hist = torch.from_numpy(rng.integers(0, 40, (R, 10)).astype(np.float32)).to(dev)
+    target = torch.rand(R, 3, device=dev)
+tr = nerf_train.NerfHTrainer(E, *mods)
+tr.range_check = "repeat"
 o, d = ro.reshape(-1, 3)[sel].contiguous().to(dev), rd.reshape(-1, 3)[sel].contiguous().to(dev)
-hist = torch.from_numpy(rng.integers(0, 40, (R, 10)).astype(np.float32)).to(dev)
-target = torch.rand(R, 3, device=dev)
 draws = tr.draw(R, Nc, Ni, 1., dev, torch.Generator(device=dev).manual_seed(1))
 
 

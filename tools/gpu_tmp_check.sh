@@ -1,7 +1,20 @@
-R=$GRAFT_REPO_ROOT; cd $R
-timeout 1500 python -m pytest tests/test_gpu_wgrad.py tests/test_gpu_dfnet.py tests/test_gpu_grad.py -q -k "wgrad or triplet or all_parameter or training_step or kept_forward or conv0 or parameter_gradients" 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof_wgl
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_wgl -o w -- python $R/tools/gpu_wgrad_layers.py run > /dev/null 2>&1
-python $R/tools/gpu_wgrad_layers.py report $R/gpurun_out/prof_wgl | tail -4
-cd $R
-for i in 1 2; do python tools/gpu_feature_train_step.py 4 20 240 320 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ft', round(d['step_ms'],3), {k: round(v,2) for k,v in d['breakdown_ms_with_syncs'].items()})"; done
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+timeout 1500 python -m pytest tests/test_gpu_dm_pieces.py tests/test_gpu_train.py tests/test_abi.py tests/test_gpu_grad.py tests/test_gpu_cli.py -q -x 2>&1 | tail -15
+timeout 600 python tools/gpu_dm_step.py 4 10 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print({k:(round(v,3) if isinstance(v,float) else v) for k,v in d.items() if 'ms' in k or k=='loss'})"
+for i in 1 2; do DM_ONLY=1 timeout 600 python tools/gpu_dm_step.py 4 24 2>&1 | tail -1; DM_ONLY=1 DM_HOST_FLOATS=1 timeout 600 python tools/gpu_dm_step.py 4 24 2>&1 | tail -1; done
+DM_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dm_b -o dm -- python tools/gpu_dm_step.py 4 24 > /dev/null 2>&1
+python - <<'PY'
+import csv
+rows=list(csv.DictReader(open('gpurun_out/prof_dm_b/dm_kernel_trace.csv')))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+names=[r['Kernel_Name'] for r in rows]
+idx=[i for i,n in enumerate(names) if 'nerfh_coarse_kernel' in n]
+print('launches per steady step', [idx[i+1]-idx[i] for i in range(len(idx)-1)][-5:])
+a,b=idx[-3],idx[-2]
+t0=int(rows[a]['Start_Timestamp'])
+busy=sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in rows[a:b])
+print('step span us', (int(rows[b]['Start_Timestamp'])-t0)/1e3, 'kernel time sum us', busy/1e3)
+PY
