@@ -32,10 +32,15 @@ pose2 = torch.cat([pose, pose])
 parts = {}
 
 
+LOOP = bool(os.environ.get("FT_LOOP"))   # the shipped epoch loop: no waits inside or between the steps (losses stay on the device)
+
+
 def step(update=True, rvs=True):
     t = [time.perf_counter()]
     def mark():
-        torch.cuda.synchronize(); t.append(time.perf_counter())
+        if not LOOP:
+            torch.cuda.synchronize()
+        t.append(time.perf_counter())
     feats, pred = m(torch.cat([target, rgb]), True, upsampleH=H, upsampleW=W); mark()
     loss = PoseLoss(None, pred, pose2, dev) + triplet_loss_hard_negative_mining_plus(feats[1], feats[0], margin=1.0)
     if rvs:
@@ -48,7 +53,7 @@ def step(update=True, rvs=True):
     opt.zero_grad(); mark()
     for k, a, b in (("forward_siamese", 0, 1), ("losses_and_rvs_forward", 1, 2), ("backward", 2, 3), ("adam", 3, 4)):
         parts[k] = parts.get(k, 0.0) + (t[b + 0] - t[a]) * 1e3
-    return float(loss)
+    return loss.detach() if LOOP else float(loss)
 
 
 def timed(fn):
@@ -61,8 +66,9 @@ def timed(fn):
     return (time.perf_counter() - t0) / iters * 1e3, out
 
 full_ms, loss = timed(step)
+loss = float(loss)
 breakdown = {k: v / iters for k, v in parts.items()}
 print(json.dumps({"workload": f"DFNet training step (run_feature.py, triplet loss + RVS), featurenet_batch_size {B} -> {2 * B} siamese + {B} "
                               f"synthesised frames at {H}x{W}, BatchNorm {'frozen' if frozen else 'batch statistics'}",
-                  "step_ms": full_ms, "frames_per_s": 3 * B / full_ms * 1e3, "breakdown_ms_with_syncs": breakdown, "loss": loss,
+                  "step_ms": full_ms, "epoch_loop_without_per_step_waits": LOOP, "frames_per_s": 3 * B / full_ms * 1e3, "breakdown_ms_with_syncs": breakdown, "loss": loss,
                   "precision": "split-f16 (f16x3) forward, data-gradient AND weight-gradient products; fp32 accumulate", "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))

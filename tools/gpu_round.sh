@@ -59,8 +59,8 @@ if [[ " $* " != *" noextra "* ]]; then
   # stream layer by layer
   cd /tmp
   rm -rf $R/gpurun_out/prof_ft
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ft -o ft -- python $R/tools/gpu_feature_train_step.py 4 20 240 320 > $R/gpurun_out/ft_step.json 2> $R/gpurun_out/ft_step.err; echo "ft rc=$?"
-  timeout 600 $R/tools/gpu_pmc.sh ft_step python $R/tools/gpu_feature_train_step.py 4 6 240 320 > $R/gpurun_out/ft_step_pmc.log 2>&1; echo "ft pmc rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ft -o ft -- env FT_LOOP=1 python $R/tools/gpu_feature_train_step.py 4 20 240 320 > $R/gpurun_out/ft_step.json 2> $R/gpurun_out/ft_step.err; echo "ft rc=$?"
+  timeout 600 $R/tools/gpu_pmc.sh ft_step env FT_LOOP=1 python $R/tools/gpu_feature_train_step.py 4 6 240 320 > $R/gpurun_out/ft_step_pmc.log 2>&1; echo "ft pmc rc=$?"
   DM_ONLY=1 timeout 600 $R/tools/gpu_pmc.sh dm_step python $R/tools/gpu_dm_step.py 4 8 > $R/gpurun_out/dm_step_pmc.log 2>&1; echo "dm pmc rc=$?"
   cd /tmp; rm -rf $R/gpurun_out/prof_wgl
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_wgl -o w -- python $R/tools/gpu_wgrad_layers.py run > /dev/null 2>&1
