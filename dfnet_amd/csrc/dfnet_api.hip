@@ -619,9 +619,13 @@ struct DfBwdWs {
   double* bn_part;   // fp64 chunk partials of the BatchNorm reductions
   float* bn_work;    // kBnWorkFloats
   float* scl;        // [scale, 1/scale] + 1024 partials of launch_absmax_scale (split-f16 gradient convs)
+  // split-storage input gradient (backward_input_split): split copy of a level's d z, a third trunk buffer, |max| words, scale slots
+  char *g128S, *gC;
+  unsigned* amax;    // [64]
+  float* slots;      // [32][2]
   size_t total;
 };
-DfBwdWs carve_df_bwd(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W) {
+DfBwdWs carve_df_bwd(const dfn_dfnet_s* h, char* base, int prec, int B, int H, int W, bool input_split = false) {
   const size_t es = prec == 0 ? 2 : 4, px = size_t(B) * H * W;
   DfBwdWs w{};
   size_t off = 0;
@@ -641,6 +645,12 @@ DfBwdWs carve_df_bwd(const dfn_dfnet_s* h, char* base, int prec, int B, int H, i
   w.gA = take(px * 64 * es);
   w.gB = take(px * 64 * es);
   w.scl = reinterpret_cast<float*>(take((1024 + 8) * 4));
+  if (input_split) {
+    w.g128S = take(px * 128 * 4);
+    w.gC = take(px * 64 * 4);
+    w.amax = reinterpret_cast<unsigned*>(take(64 * 4));
+    w.slots = reinterpret_cast<float*>(take(64 * 4));
+  }
   w.total = off;
   return w;
 }
@@ -648,7 +658,111 @@ DfBwdWs carve_df_bwd(const dfn_dfnet_s* h, char* base, int prec, int B, int H, i
 
 extern "C" size_t dfn_dfnet_backward_workspace_bytes(dfn_dfnet_t h, int prec, int B, int H, int W) {
   if (!h || B < 1 || H < 1 || W < 1) return 0;
-  return carve_df_bwd(h, nullptr, prec, B, H, W).total;
+  return carve_df_bwd(h, nullptr, prec, B, H, W, prec == 2).total;
+}
+
+// The input gradient on the SPLIT storage (prec 2): the forward recompute keeps every activation as the hi | lo f16 operand planes
+// the next conv stages by LDS-DMA (the 2x2 max pool fused into the producing conv's epilogue), and every gradient w.r.t. a conv's
+// pre-activation is written once by gate_split_kernel (ReLU gate + max-pool routing + the tap's gradient + split) at a power-of-two
+// scale bounded by the |max| word its producer left behind (a conv epilogue, the upsampling adjoint) — the chain of
+// backward_params_split without the weight gradients.  Replaces fp32 tensors re-split inside every conv, three relu_gate_absmax
+// passes and the absmax_partial / finalize pairs.
+static int backward_input_split(dfn_dfnet_t h, const float* x, int B, int H, int W, int upH, int upW, const float* grad_features,
+                                int level_mask, float* grad_x, const DfBwdWs& w, hipStream_t s) {
+  constexpr int prec = 2;
+  const int n_enc = int(h->enc.size());
+  const void* zeros = h->fc + zeros_offset(h->feat_dim);
+  int deepest = 0;
+  for (int t = 0; t < h->n_taps; ++t) if (level_mask >> t & 1) deepest = t;
+  // ---- forward up to the deepest requested tap
+  CHECK_HIP(launch_dfnet_prep(prec, x, B, H, W, w.prep, s), "dfnet bwd: prep");
+  const void* cur = w.prep;
+  int ch = H, cw = W, nblk = 1, last = -1;
+  int lay_h[13], lay_w[13];
+  for (int i = 0; i < n_enc; ++i) {
+    const ConvSpec& sp = h->enc[i];
+    lay_h[i] = ch; lay_w[i] = cw;
+    const bool is_last = sp.tap == deepest;
+    ConvArgs a{};
+    a.in = cur; a.w = h->enc_packed[i].w[prec]; a.bias = h->enc_packed[i].bias_x3; a.out_scale = h->enc_packed[i].out_scale;
+    a.out_act = w.act[i];
+    a.out_pre = (sp.tap >= 0 && (level_mask >> sp.tap & 1)) ? w.tap[sp.tap] : nullptr;
+    a.B = B; a.H = ch; a.W = cw; a.nblk_in = nblk; a.cout_blocks = sp.cout / 32; a.relu = 1;
+    a.in_split = i > 0; a.zeros = zeros;
+    a.out_split = 1 | 2 | 4;
+    const bool pool_next = sp.pool_after && !is_last;
+    if (pool_next) a.out_pool = w.pooled;   // (no two consecutive convs of the VGG stack are followed by a pool: one transient buffer)
+    CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet bwd: encoder conv");
+    last = i;
+    if (is_last) break;
+    cur = w.act[i];
+    nblk = sp.cout / 32;
+    if (pool_next) { cur = w.pooled; ch /= 2; cw /= 2; }
+  }
+  CHECK_HIP(hipMemsetAsync(w.amax, 0, 64 * sizeof(unsigned), s), "dfnet bwd: clear |max| words");
+  const size_t plane = size_t(128) * upH * upW;
+  char* gbuf[3] = {w.gA, w.gB, w.gC};
+  int act_idx = -1;
+  bool g_pooled = false;
+  for (int i = last; i >= 0; --i) {
+    const ConvSpec& sp = h->enc[i];
+    const int hh = lay_h[i], ww = lay_w[i];
+    const float* g_tap = nullptr;
+    const unsigned* am_tap = nullptr;
+    if (sp.tap >= 0 && (level_mask >> sp.tap & 1)) {
+      const int t = sp.tap;
+      unsigned* am = w.amax + 16 + 4 * t;
+      float* sl128 = w.slots + 32 + 4 * t, * sl64 = sl128 + 2;
+      // adaptation layer forward (ReLU gate of its 1x1) on the split tap, kept split
+      ConvArgs a{};
+      a.in = w.tap[t]; a.w = h->ad1[t].w[prec]; a.bias = h->ad1[t].bias_x3; a.out_scale = h->ad1[t].out_scale; a.out_act = w.tmp64;
+      a.B = B; a.H = hh; a.W = ww; a.nblk_in = sp.cout / 32; a.cout_blocks = 2; a.relu = 1;
+      a.in_split = 1; a.out_split = 1; a.zeros = zeros;
+      CHECK_HIP(launch_conv(prec, 1, 16, a, s), "dfnet bwd: adapt 1x1");
+      CHECK_HIP(launch_upsample_backward(1, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s, am),
+                "dfnet bwd: upsample");
+      CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g128), 0, nullptr, 0, nullptr, B, hh, ww, 4, am, nullptr, w.g128S, 1, sl128, s),
+                "dfnet bwd: split d features");
+      ConvArgs c{};
+      c.in = w.g128S; c.w = h->ad5_dgrad[t].w[prec]; c.bias = h->ad5_dgrad[t].bias; c.out_scale = h->ad5_dgrad[t].out_scale; c.out_pre = w.g64;
+      c.in_split = 1; c.zeros = zeros; c.dyn_scale = sl128; c.absmax_out = am + 1;
+      c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
+      CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet bwd: adapt 5x5 dgrad");
+      // ReLU gate of the 1x1's output; the split result goes where d z's split copy was (dead by now: 64 of its 128 channels' worth)
+      CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g64), 0, w.tmp64, 1, nullptr, B, hh, ww, 2, am + 1, nullptr, w.g128S, 1, sl64, s),
+                "dfnet bwd: adapt gate");
+      ConvArgs d{};
+      d.in = w.g128S; d.w = h->ad1_dgrad[t].w[prec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
+      d.in_split = 1; d.zeros = zeros; d.dyn_scale = sl64; d.absmax_out = am + 2;
+      d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
+      CHECK_HIP(launch_conv(prec, 1, 16, d, s), "dfnet bwd: adapt 1x1 dgrad");
+      g_tap = reinterpret_cast<const float*>(w.gtap);
+      am_tap = am + 2;
+    }
+    // gate: gradient w.r.t. conv i's pre-activation (ReLU gate, max-pool routing, + the tap's), split
+    const int pre_idx = act_idx == 0 ? 1 : 0;
+    float* slot = w.slots + 2 * i;
+    CHECK_HIP(launch_gate_split(act_idx < 0 ? nullptr : reinterpret_cast<const float*>(gbuf[act_idx]), g_pooled ? 1 : 0, w.act[i], 1, g_tap, B, hh,
+                                ww, sp.cout / 32, act_idx < 0 ? nullptr : w.amax + i, am_tap, gbuf[pre_idx], 1, slot, s),
+              "dfnet bwd: gate");
+    // data gradient of conv i (w.r.t. conv i-1's output, pooled if a max pool sits between)
+    int in_idx = 0;
+    while (in_idx == pre_idx || in_idx == act_idx) ++in_idx;
+    const int cin_p = (sp.cin + 63) / 64 * 64;
+    ConvArgs e{};
+    e.in = gbuf[pre_idx]; e.w = h->enc_dgrad[i].w[prec]; e.bias = h->enc_dgrad[i].bias; e.out_scale = h->enc_dgrad[i].out_scale;
+    e.out_pre = gbuf[in_idx];
+    e.in_split = 1; e.zeros = zeros; e.dyn_scale = slot; if (i > 0) e.absmax_out = w.amax + (i - 1);
+    e.B = B; e.H = hh; e.W = ww; e.nblk_in = sp.cout / 32; e.cout_blocks = cin_p / 32; e.relu = 0;
+    CHECK_HIP(launch_conv(prec, 3, 16, e, s), "dfnet bwd: encoder conv dgrad");
+    if (i == 0) {
+      CHECK_HIP(launch_unprep(prec, gbuf[in_idx], B, H, W, cin_p / 32, grad_x, s), "dfnet bwd: unprep");
+      break;
+    }
+    act_idx = in_idx;
+    g_pooled = h->enc[i - 1].pool_after;
+  }
+  return DFN_OK;
 }
 
 extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int upH, int upW,
@@ -665,10 +779,11 @@ extern "C" int dfn_dfnet_backward_input(dfn_dfnet_t h, int prec, const float* x,
   level_mask &= (1 << h->n_taps) - 1;
   if (!x || !grad_features || !grad_x || !workspace || B < 1 || H < 32 || W < 32 || upH < 1 || upW < 1 || !level_mask)
     return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: bad argument (need H,W >= 32 and a non-empty level_mask)");
-  const DfBwdWs w = carve_df_bwd(h, static_cast<char*>(workspace), prec, B, H, W);
+  const DfBwdWs w = carve_df_bwd(h, static_cast<char*>(workspace), prec, B, H, W, prec == 2);
   if (w.total > workspace_bytes)
     return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_input: workspace too small (%zu < %zu)", workspace_bytes, w.total);
   hipStream_t s = HS(stream);
+  if (prec == 2) return backward_input_split(h, x, B, H, W, upH, upW, grad_features, level_mask, grad_x, w, s);
   int deepest = 0;
   for (int t = 0; t < h->n_taps; ++t) if (level_mask >> t & 1) deepest = t;
   // ---- forward up to the deepest requested tap, keeping every activation

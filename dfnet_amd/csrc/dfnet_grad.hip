@@ -162,6 +162,20 @@ __device__ __forceinline__ Piece8 load_f32x8(const float* t, size_t pix, int nbl
 }
 }  // namespace
 
+// max |v| over the workgroup into the float-bits word `out` (bound of a gradient tensor for the split that follows, gate_split_kernel):
+// one atomic per workgroup at most, skipped when the word already covers the value.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void publish_absmax(float m, unsigned* out) {
+  __shared__ float s_amax[16];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) s_amax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < int((blockDim.x + 63) >> 6); ++i) m = fmaxf(m, s_amax[i]);
+    if (m > 0.f && m > __uint_as_float(__hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicMax(out, __float_as_uint(m));
+  }
+}
+
 template <bool POOL, bool ACT_SPLIT, bool OUT_SPLIT>
 __global__ __launch_bounds__(256) void gate_split_kernel(const float* __restrict__ g, const void* __restrict__ act, const float* __restrict__ add,
                                                          int B, int H, int W, int nblk, const unsigned* __restrict__ absmax_g,
@@ -267,7 +281,8 @@ hipError_t launch_gate_split(const float* g, int pooled_g, const void* act, int 
 // two source rows / columns include it, with exactly the weights the forward kernel used.
 template <class T>
 __global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __restrict__ gup, size_t bstride, int B, int h, int w,
-                                                                int UH, int UW, T* __restrict__ out) {
+                                                                int UH, int UW, T* __restrict__ out, unsigned* __restrict__ absmax_out) {
+  float amax = 0.f;
   const float sy = UH > 1 ? float(h - 1) / float(UH - 1) : 0.f;
   const float sx = UW > 1 ? float(w - 1) / float(UW - 1) : 0.f;
   const size_t n = (size_t)B * h * w * 128;
@@ -286,7 +301,9 @@ __global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __r
     if (sx > 0.f) { X0 = max(0, int(floorf(float(x - 1) / sx)) - 1); X1 = min(UW - 1, int(ceilf(float(x + 1) / sx)) + 1); }
     const float* plane = gup + b * bstride + (size_t)ch * UH * UW;
     if (h == UH && w == UW) {   // level 0: the resize is the identity, its adjoint a layout change
-      out[((b * h + y) * (size_t)w + x) * 128 + e128] = (T)plane[(size_t)y * UW + x];
+      const float v = plane[(size_t)y * UW + x];
+      amax = fmaxf(amax, fabsf(v));
+      out[((b * h + y) * (size_t)w + x) * 128 + e128] = (T)v;
       continue;
     }
     float acc = 0.f;
@@ -306,8 +323,10 @@ __global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __r
       }
       acc += wy * row;
     }
+    amax = fmaxf(amax, fabsf(acc));
     out[((b * h + y) * (size_t)w + x) * 128 + e128] = (T)acc;
   }
+  if (absmax_out) publish_absmax(amax, absmax_out);
 }
 // The same adjoint, fp32, organised for bandwidth.  One workgroup per (image, input row y, 32-channel block); per channel
 //   phase 1: tmp[X] = sum_Y wy(Y) g_up[Y][X]    over the output rows that touch input row y — coalesced along X
@@ -315,7 +334,7 @@ __global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __r
 // and the 32 channels of every pixel leave as one 128-byte store.  Each g_up element is read about twice in total
 // (the gather above reads it (2 scale)^2 times through L2).  Weights are exactly the forward kernel's.
 __global__ __launch_bounds__(256) void upsample_backward_rows_kernel(const float* __restrict__ gup, size_t bstride, int h, int w, int UH,
-                                                                     int UW, float* __restrict__ out) {
+                                                                     int UW, float* __restrict__ out, unsigned* __restrict__ absmax_out) {
   extern __shared__ float lds[];
   float* tmp = lds;                    // [UW]
   float* wyv = tmp + UW;               // [UH] (only Y0..Y1 used)
@@ -371,16 +390,20 @@ __global__ __launch_bounds__(256) void upsample_backward_rows_kernel(const float
     __syncthreads();
   }
   float* o = out + ((b * h + y) * (size_t)w) * 128 + blk * 32;
+  float amax = 0.f;
   for (int i = tid; i < w * per_z; i += 256) {
     const int px = i / per_z, e = e_lo + i % per_z;
-    o[(size_t)px * 128 + e] = row[px * 33 + e];
+    const float v = row[px * 33 + e];
+    amax = fmaxf(amax, fabsf(v));
+    o[(size_t)px * 128 + e] = v;
   }
+  if (absmax_out) publish_absmax(amax, absmax_out);
 }
 
 // Level 0 (no resize): NCHW planes -> blocked NHWC through an LDS tile of 128 channels x 64 pixels; 256-byte reads,
 // 512-byte writes.
 __global__ __launch_bounds__(256) void upsample_backward_identity_kernel(const float* __restrict__ gup, size_t bstride, size_t plane,
-                                                                         float* __restrict__ out) {
+                                                                         float* __restrict__ out, unsigned* __restrict__ absmax_out) {
   __shared__ float tile[128][65];
   const size_t b = blockIdx.y, p0 = (size_t)blockIdx.x * 64;
   const int tx = threadIdx.x & 63, t4 = threadIdx.x >> 6;
@@ -391,32 +414,38 @@ __global__ __launch_bounds__(256) void upsample_backward_identity_kernel(const f
   const int e128 = threadIdx.x & 127, t2 = threadIdx.x >> 7;
   const int blk = e128 >> 5, e = e128 & 31;
   const int ch = blk * 32 + 4 * (e >> 4) + (e & 3) + 8 * ((e & 15) >> 2);
+  float amax = 0.f;
   for (int px = t2; px < 64; px += 2)
-    if (p0 + px < plane) out[(b * plane + p0 + px) * 128 + e128] = tile[ch][px];
+    if (p0 + px < plane) {
+      const float v = tile[ch][px];
+      amax = fmaxf(amax, fabsf(v));
+      out[(b * plane + p0 + px) * 128 + e128] = v;
+    }
+  if (absmax_out) publish_absmax(amax, absmax_out);
 }
 
 hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, int B, int h, int w, int UH, int UW, void* out,
-                                    hipStream_t s) {
+                                    hipStream_t s, unsigned* absmax_out) {
   const size_t n = (size_t)B * h * w * 128;
   if (!n) return hipSuccess;
   if (prec != 0 && h == UH && w == UW) {
     const size_t plane = (size_t)h * w;
     hipLaunchKernelGGL(upsample_backward_identity_kernel, dim3((unsigned)((plane + 63) / 64), B), dim3(256), 0, s, gup, bstride, plane,
-                       static_cast<float*>(out));
+                       static_cast<float*>(out), absmax_out);
     return hipGetLastError();
   }
   const size_t lds = ((size_t)UW + UH + (size_t)w * 33) * 4;
   if (prec != 0 && lds <= 64 * 1024) {
     const int zsplit = (size_t)B * h * 4 >= 2048 ? 1 : ((size_t)B * h * 4 >= 1024 ? 2 : 4);
-    hipLaunchKernelGGL(upsample_backward_rows_kernel, dim3(B * h, 4, zsplit), dim3(256), lds, s, gup, bstride, h, w, UH, UW, static_cast<float*>(out));
+    hipLaunchKernelGGL(upsample_backward_rows_kernel, dim3(B * h, 4, zsplit), dim3(256), lds, s, gup, bstride, h, w, UH, UW, static_cast<float*>(out), absmax_out);
     return hipGetLastError();
   }
   if (prec == 0)
     hipLaunchKernelGGL(upsample_backward_kernel<_Float16>, dim3(grid_of(n)), dim3(256), 0, s, gup, bstride, B, h, w, UH, UW,
-                       static_cast<_Float16*>(out));
+                       static_cast<_Float16*>(out), absmax_out);
   else
     hipLaunchKernelGGL(upsample_backward_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, gup, bstride, B, h, w, UH, UW,
-                       static_cast<float*>(out));
+                       static_cast<float*>(out), absmax_out);
   return hipGetLastError();
 }
 

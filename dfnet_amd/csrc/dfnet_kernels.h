@@ -116,7 +116,7 @@ hipError_t launch_gate_split(const float* g, int pooled_g, const void* act, int 
                              hipStream_t s);
 // adjoint of launch_upsample: fp32 NCHW planes gup[b*bstride + c*UH*UW + ...] -> blocked [B,h,w,4,32].
 hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, int B, int h, int w, int UH, int UW, void* out,
-                                    hipStream_t s);
+                                    hipStream_t s, unsigned* absmax_out = nullptr);
 // adjoint of launch_dfnet_prep: blocked gradient (RGB = first three elements of a pixel) -> d L/d x [B,3,H,W] fp32.
 hipError_t launch_unprep(int prec, const void* g, int B, int H, int W, int nblk, float* gx, hipStream_t s);
 
