@@ -78,13 +78,13 @@ hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH
                            size_t out_bstride, hipStream_t stream, const float* affine = nullptr);
 
 // Triplet loss of DFNet's training on two feature stacks [L,B,rows,W] (dfnet_loss.hip); ls = level stride in floats.
-constexpr size_t kTripletPartDoubles = 4096 * 4 + 2048;
+constexpr size_t kTripletPartDoubles = 2048 * 8;   // [blocks of triplet_rows_kernel][4 mining sums + 4 hinge sums]
 hipError_t launch_triplet_forward(const float* f1, size_t ls1, const float* f2, size_t ls2, int L, int B, int rows, int W, float margin,
-                                  float eps, int mode, double* part, int* case_out, float* mse_out, float* row_stat, float* loss,
-                                  hipStream_t s);
+                                  float eps, int mode, double* part, int* case_out, float* mse_out, float* margin_out, float* row_stat,
+                                  float* loss, hipStream_t s);
 hipError_t launch_triplet_backward(const float* f1, size_t ls1, const float* f2, size_t ls2, int L, int B, int rows, int W, float eps,
-                                   const int* case_in, const float* row_stat, const float* grad_loss, float* g1, size_t gs1, float* g2,
-                                   size_t gs2, hipStream_t s);
+                                   const int* case_in, const float* row_stat, const float* margin_in, const float* grad_loss, float* g1,
+                                   size_t gs1, float* g2, size_t gs2, hipStream_t s);
 
 // BatchNorm work block of one pyramid level: device floats in stored-position order.
 constexpr int kBnSc = 0, kBnSh = 128, kBnMean = 256, kBnRstd = 384, kBnMg = 512, kBnMgx = 640, kBnWorkFloats = 768;

@@ -30,43 +30,72 @@ __device__ __forceinline__ bool x_is_f1(int c) { return c == 0 || c == 2; }
 __device__ __forceinline__ bool z_is_f1(int c) { return c == 1 || c == 2; }
 }  // namespace
 
-// part[chunk][4] (fp64): sum (f1 - roll f2)^2, (f2 - roll f1)^2, (f1 - roll f1)^2, (f2 - roll f2)^2
-__global__ __launch_bounds__(256) void triplet_case_kernel(Stack f1, Stack f2, int L, int B, size_t slab, double* __restrict__ part) {
-  __shared__ double red[4][4];
-  // grid: (chunks of one image slab, lvl * B + b) — no index division in the loop
-  const int b = blockIdx.y % B, l = blockIdx.y / B, bm = b == 0 ? B - 1 : b - 1;
-  const size_t per = (slab + gridDim.x - 1) / gridDim.x;
-  const size_t e0 = blockIdx.x * per, e1 = e0 + per < slab ? e0 + per : slab;
-  const float* pa = f1.p + l * f1.level_stride + b * slab;
-  const float* pp = f2.p + l * f2.level_stride + b * slab;
-  const float* pan = f1.p + l * f1.level_stride + bm * slab;
-  const float* ppn = f2.p + l * f2.level_stride + bm * slab;
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
-    const float a = pa[e], p = pp[e], an = pan[e], pn = ppn[e];
-    const float d0 = a - pn, d1 = p - an, d2 = a - an, d3 = p - pn;
-    s[0] += (double)(d0 * d0); s[1] += (double)(d1 * d1); s[2] += (double)(d2 * d2); s[3] += (double)(d3 * d3);
+// ONE pass over both stacks for the whole forward: one wave per feature row reads its four vectors — f1[b], f2[b] and the rolled
+// f1[b-1], f2[b-1] — once and leaves
+//   row_stat[row][6] = d(f1, f2), d(f2, f1)  (the positive pair seen from either anchor: |x - y + eps| is not symmetric)
+//                      d(f1, roll f2), d(f2, roll f1), d(f1, roll f1), d(f2, roll f2)   (anchor - negative of the four cases)
+//   part[block][8] (fp64) = the four mining sums  sum (f1 - roll f2)^2, (f2 - roll f1)^2, (f1 - roll f1)^2, (f2 - roll f2)^2
+//                           and the four cases' hinge sums  sum max(d_xy - d_xz + margin, 0)
+// so that the case (a global argmin, misc.py:424-433) is picked AFTERWARDS by the finalize kernel from the same pass: the separate
+// mining pass (a second read of both stacks, 0.22 ms per DFNet training step) is gone.
+__global__ __launch_bounds__(256) void triplet_rows_kernel(Stack f1, Stack f2, int L, int B, int rows, int W, float margin, float eps,
+                                                           float* __restrict__ row_stat, double* __restrict__ part) {
+  __shared__ double red[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t slab = (size_t)rows * W, n_rows = (size_t)L * B * rows;
+  double mse[4] = {0.0, 0.0, 0.0, 0.0}, hin[4] = {0.0, 0.0, 0.0, 0.0};
+  for (size_t row = (size_t)blockIdx.x * 4 + wave; row < n_rows; row += (size_t)gridDim.x * 4) {
+    const size_t r = row % rows, lb = row / rows;
+    const int b = int(lb % B), l = int(lb / B), bm = b == 0 ? B - 1 : b - 1;
+    const float* pa = f1.p + l * f1.level_stride + b * slab + r * W;
+    const float* pp = f2.p + l * f2.level_stride + b * slab + r * W;
+    const float* pan = f1.p + l * f1.level_stride + bm * slab + r * W;
+    const float* ppn = f2.p + l * f2.level_stride + bm * slab + r * W;
+    float sxy0 = 0.f, sxy1 = 0.f, sz0 = 0.f, sz1 = 0.f, sz2 = 0.f, sz3 = 0.f;
+    for (int w = lane; w < W; w += 64) {
+      const float a = pa[w], p = pp[w], an = pan[w], pn = ppn[w];
+      const float d0 = a - pn, d1 = p - an, d2 = a - an, d3 = p - pn;
+      mse[0] += (double)(d0 * d0); mse[1] += (double)(d1 * d1); mse[2] += (double)(d2 * d2); mse[3] += (double)(d3 * d3);
+      const float exy0 = a - p + eps, exy1 = p - a + eps;
+      const float e0 = d0 + eps, e1 = d1 + eps, e2 = d2 + eps, e3 = d3 + eps;   // (x - z) + eps, as torch's pairwise_distance
+      sxy0 = fmaf(exy0, exy0, sxy0); sxy1 = fmaf(exy1, exy1, sxy1);
+      sz0 = fmaf(e0, e0, sz0); sz1 = fmaf(e1, e1, sz1); sz2 = fmaf(e2, e2, sz2); sz3 = fmaf(e3, e3, sz3);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      sxy0 += __shfl_down(sxy0, o, 64); sxy1 += __shfl_down(sxy1, o, 64);
+      sz0 += __shfl_down(sz0, o, 64); sz1 += __shfl_down(sz1, o, 64); sz2 += __shfl_down(sz2, o, 64); sz3 += __shfl_down(sz3, o, 64);
+    }
+    if (lane == 0) {
+      const float dxy[2] = {sqrtf(sxy0), sqrtf(sxy1)}, dxz[4] = {sqrtf(sz0), sqrtf(sz1), sqrtf(sz2), sqrtf(sz3)};
+      float* st = row_stat + 6 * row;
+      st[0] = dxy[0]; st[1] = dxy[1]; st[2] = dxz[0]; st[3] = dxz[1]; st[4] = dxz[2]; st[5] = dxz[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float hinge = dxy[x_is_f1(c) ? 0 : 1] - dxz[c] + margin;
+        if (hinge > 0.f) hin[c] += (double)hinge;
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    double v = s[k];
+    double v = mse[k];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    if (lane == 0) { red[wave][k] = v; red[wave][4 + k] = hin[k]; }
   }
   __syncthreads();
-  if (threadIdx.x < 4) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  if (threadIdx.x < 8) part[(size_t)blockIdx.x * 8 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 // mode 0: naive (case 0); 1: two-case mining (misc.py:371-397); 2: four-case (misc.py:399-435).  torch.argmin: first minimum.
-__global__ void triplet_case_finalize_kernel(const double* __restrict__ part, int n_chunks, int mode, double count, int* __restrict__ case_out,
-                                             float* __restrict__ mse_out) {
-  // one wave: lane l adds the chunks c = l, l + 64, ... in order, then a fixed shuffle tree (deterministic; a single thread walking
-  // thousands of partials one dependent load at a time took 250 us per step)
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int c = threadIdx.x; c < n_chunks; c += 64)
-    for (int k = 0; k < 4; ++k) s[k] += part[(size_t)c * 4 + k];
+// One wave: lane l adds the blocks l, l + 64, ... in order, then a fixed shuffle tree (deterministic).
+__global__ void triplet_finalize_kernel(const double* __restrict__ part, int n_blocks, int mode, double count, double n_rows, float margin,
+                                        int* __restrict__ case_out, float* __restrict__ mse_out, float* __restrict__ margin_out,
+                                        float* __restrict__ loss) {
+  double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int c = threadIdx.x; c < n_blocks; c += 64)
+    for (int k = 0; k < 8; ++k) s[k] += part[(size_t)c * 8 + k];
   for (int o = 32; o > 0; o >>= 1)
-    for (int k = 0; k < 4; ++k) s[k] += __shfl_down(s[k], o, 64);
+    for (int k = 0; k < 8; ++k) s[k] += __shfl_down(s[k], o, 64);
   if (threadIdx.x != 0) return;
   float m[4];
   for (int k = 0; k < 4; ++k) { m[k] = (float)(s[k] / count); if (mse_out) mse_out[k] = m[k]; }
@@ -75,54 +104,18 @@ __global__ void triplet_case_finalize_kernel(const double* __restrict__ part, in
   else if (mode == 2)
     for (int k = 1; k < 4; ++k) if (m[k] < m[best]) best = k;
   *case_out = best;
-}
-
-// One wave per row.  row_stat[row] = (d_xy, d_xz); d_xz stored NEGATIVE when the hinge is inactive (no gradient).
-__global__ __launch_bounds__(256) void triplet_forward_kernel(Stack f1, Stack f2, int L, int B, int rows, int W, float margin, float eps,
-                                                              const int* __restrict__ case_in, float* __restrict__ row_stat,
-                                                              double* __restrict__ part) {
-  __shared__ double red[4];
-  const int c = *case_in, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t slab = (size_t)rows * W, n_rows = (size_t)L * B * rows;
-  const Stack X = x_is_f1(c) ? f1 : f2, Y = x_is_f1(c) ? f2 : f1, Z = z_is_f1(c) ? f1 : f2;
-  double acc = 0.0;
-  for (size_t row = (size_t)blockIdx.x * 4 + wave; row < n_rows; row += (size_t)gridDim.x * 4) {
-    const size_t r = row % rows, lb = row / rows;
-    const int b = int(lb % B), l = int(lb / B), bm = b == 0 ? B - 1 : b - 1;
-    const float* x = X.p + l * X.level_stride + b * slab + r * W;
-    const float* y = Y.p + l * Y.level_stride + b * slab + r * W;
-    const float* z = Z.p + l * Z.level_stride + bm * slab + r * W;
-    float sy = 0.f, sz = 0.f;
-    for (int w = lane; w < W; w += 64) {
-      const float xv = x[w], dy = xv - y[w] + eps, dz = xv - z[w] + eps;
-      sy = fmaf(dy, dy, sy);
-      sz = fmaf(dz, dz, sz);
-    }
-    for (int o = 32; o > 0; o >>= 1) { sy += __shfl_down(sy, o, 64); sz += __shfl_down(sz, o, 64); }
-    if (lane == 0) {
-      const float dxy = sqrtf(sy), dxz = sqrtf(sz), hinge = dxy - dxz + margin;
-      row_stat[2 * row] = dxy;
-      row_stat[2 * row + 1] = hinge >= 0.f ? dxz : -1.f;   // clamp_min passes the gradient at hinge == 0, as torch
-      if (hinge > 0.f) acc += (double)hinge;
-    }
-  }
-  if (lane == 0) red[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-}
-
-__global__ void triplet_loss_finalize_kernel(const double* __restrict__ part, int n, double n_rows, float* __restrict__ loss) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-  if (threadIdx.x == 0) *loss = (float)(s / n_rows);
+  *margin_out = margin;
+  *loss = (float)(s[4 + best] / n_rows);
 }
 
 // g1 / g2: gradients w.r.t. f1 / f2 (every element written).  scale = grad_loss / n_rows.
 __global__ __launch_bounds__(256) void triplet_backward_kernel(Stack f1, Stack f2, int L, int B, int rows, int W, float eps,
                                                                const int* __restrict__ case_in, const float* __restrict__ row_stat,
-                                                               const float* __restrict__ grad_loss, double n_rows, GStack g1, GStack g2) {
+                                                               const float* __restrict__ margin_in, const float* __restrict__ grad_loss,
+                                                               double n_rows, GStack g1, GStack g2) {
   const int c = *case_in;
+  const float margin = *margin_in;
+  const int ixy = x_is_f1(c) ? 0 : 1, ixz = 2 + c;   // this case's columns of row_stat (triplet_rows_kernel)
   const float scale = (float)((double)*grad_loss / n_rows);
   const uint32_t slab = (uint32_t)rows * W;
   const bool xf1 = x_is_f1(c), zf1 = z_is_f1(c);
@@ -132,7 +125,8 @@ __global__ __launch_bounds__(256) void triplet_backward_kernel(Stack f1, Stack f
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < slab; e += gridDim.x * blockDim.x) {
     const uint32_t r = e / (uint32_t)W;
     const size_t row = ((size_t)l * B + b) * rows + r, rowp = ((size_t)l * B + bp) * rows + r;
-    const float dxy = row_stat[2 * row], dxz = row_stat[2 * row + 1];
+    const float dxy = row_stat[6 * row + ixy], dxz_raw = row_stat[6 * row + ixz];
+    const float dxz = dxy - dxz_raw + margin >= 0.f ? dxz_raw : -1.f;   // clamp_min passes the gradient at hinge == 0, as torch
     const float xv = X.p[l * X.level_stride + (size_t)b * slab + e], yv = Y.p[l * Y.level_stride + (size_t)b * slab + e];
     float gx = 0.f, gy = 0.f;
     if (dxz >= 0.f) {   // hinge active on this row
@@ -142,7 +136,8 @@ __global__ __launch_bounds__(256) void triplet_backward_kernel(Stack f1, Stack f
       gy = -scale * ty;
     }
     // this element as the negative of image b+1's row: z_{b+1} = zsrc[b]
-    const float dxzp = row_stat[2 * rowp + 1];
+    const float dxzp_raw = row_stat[6 * rowp + ixz];
+    const float dxzp = row_stat[6 * rowp + ixy] - dxzp_raw + margin >= 0.f ? dxzp_raw : -1.f;
     float gz = 0.f;
     if (dxzp > 0.f) {
       const float xp = X.p[l * X.level_stride + (size_t)bp * slab + e];
@@ -163,34 +158,27 @@ static inline int slab_chunks(size_t slab, int images) {   // ~64K elements per 
 }
 
 hipError_t launch_triplet_forward(const float* f1, size_t ls1, const float* f2, size_t ls2, int L, int B, int rows, int W, float margin,
-                                  float eps, int mode, double* part, int* case_out, float* mse_out, float* row_stat, float* loss,
-                                  hipStream_t s) {
+                                  float eps, int mode, double* part, int* case_out, float* mse_out, float* margin_out, float* row_stat,
+                                  float* loss, hipStream_t s) {
   const Stack a{f1, ls1}, p{f2, ls2};
   const size_t slab = (size_t)rows * W, n = (size_t)L * B * slab, n_rows = (size_t)L * B * rows;
-  if (mode != 0 || mse_out) {
-    const int nc = slab_chunks(slab, L * B);
-    hipLaunchKernelGGL(triplet_case_kernel, dim3(nc, L * B), dim3(256), 0, s, a, p, L, B, slab, part);
-    hipLaunchKernelGGL(triplet_case_finalize_kernel, dim3(1), dim3(64), 0, s, part, nc * L * B, mode, (double)n, case_out, mse_out);
-  } else {
-    hipError_t e = hipMemsetAsync(case_out, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
-  }
   const int grid = int((n_rows + 3) / 4 < 2048 ? (n_rows + 3) / 4 : 2048);
-  hipLaunchKernelGGL(triplet_forward_kernel, dim3(grid), dim3(256), 0, s, a, p, L, B, rows, W, margin, eps, case_out, row_stat, part);
-  hipLaunchKernelGGL(triplet_loss_finalize_kernel, dim3(1), dim3(64), 0, s, part, grid, (double)n_rows, loss);
+  hipLaunchKernelGGL(triplet_rows_kernel, dim3(grid), dim3(256), 0, s, a, p, L, B, rows, W, margin, eps, row_stat, part);
+  hipLaunchKernelGGL(triplet_finalize_kernel, dim3(1), dim3(64), 0, s, part, grid, mode, (double)n, (double)n_rows, margin, case_out, mse_out,
+                     margin_out, loss);
   return hipGetLastError();
 }
 
 hipError_t launch_triplet_backward(const float* f1, size_t ls1, const float* f2, size_t ls2, int L, int B, int rows, int W, float eps,
-                                   const int* case_in, const float* row_stat, const float* grad_loss, float* g1, size_t gs1, float* g2,
-                                   size_t gs2, hipStream_t s) {
+                                   const int* case_in, const float* row_stat, const float* margin_in, const float* grad_loss, float* g1,
+                                   size_t gs1, float* g2, size_t gs2, hipStream_t s) {
   const Stack a{f1, ls1}, p{f2, ls2};
   const GStack ga{g1, gs1}, gp{g2, gs2};
   const size_t slab = (size_t)rows * W, n_rows = (size_t)L * B * rows;
   if (slab >= (1ull << 32)) return hipErrorInvalidValue;
   const int grid = slab_chunks(slab, L * B) * 16;   // 4K elements per workgroup pass
-  hipLaunchKernelGGL(triplet_backward_kernel, dim3(grid, L * B), dim3(256), 0, s, a, p, L, B, rows, W, eps, case_in, row_stat, grad_loss,
-                     (double)n_rows, ga, gp);
+  hipLaunchKernelGGL(triplet_backward_kernel, dim3(grid, L * B), dim3(256), 0, s, a, p, L, B, rows, W, eps, case_in, row_stat, margin_in,
+                     grad_loss, (double)n_rows, ga, gp);
   return hipGetLastError();
 }
 
@@ -313,19 +301,20 @@ using namespace dfn;
 
 extern "C" size_t dfn_triplet_loss_state_bytes(int L, int B, int rows) {
   if (L < 1 || B < 1 || rows < 1) return 0;
-  // [case:int][4 x mse][pad] | row statistics | fp64 partials
-  return 256 + (((size_t)L * B * rows * 2 * sizeof(float) + 255) & ~size_t(255)) + kTripletPartDoubles * sizeof(double);
+  // [case:int][4 x mse][margin][pad] | row statistics (6 floats per row) | fp64 partials
+  return 256 + (((size_t)L * B * rows * 6 * sizeof(float) + 255) & ~size_t(255)) + kTripletPartDoubles * sizeof(double);
 }
 
 namespace {
-struct TripletState { int* case_dev; float* mse; float* row_stat; double* part; };
+struct TripletState { int* case_dev; float* mse; float* margin; float* row_stat; double* part; };
 TripletState carve_triplet(void* state, int L, int B, int rows) {
   char* base = static_cast<char*>(state);
   TripletState t;
   t.case_dev = reinterpret_cast<int*>(base);
   t.mse = reinterpret_cast<float*>(base + 16);
+  t.margin = reinterpret_cast<float*>(base + 32);
   t.row_stat = reinterpret_cast<float*>(base + 256);
-  t.part = reinterpret_cast<double*>(base + 256 + (((size_t)L * B * rows * 2 * sizeof(float) + 255) & ~size_t(255)));
+  t.part = reinterpret_cast<double*>(base + 256 + (((size_t)L * B * rows * 6 * sizeof(float) + 255) & ~size_t(255)));
   return t;
 }
 bool triplet_args_ok(const void* f1, const void* f2, int L, int B, int rows, int W, size_t ls1, size_t ls2) {
@@ -343,7 +332,7 @@ extern "C" int dfn_triplet_loss_forward(const float* f1, size_t level_stride1, c
     return set_error(DFN_ERR_ARG, "dfn_triplet_loss_forward: state too small (%zu < %zu)", state_bytes, dfn_triplet_loss_state_bytes(L, B, rows));
   const TripletState t = carve_triplet(state, L, B, rows);
   hipError_t e = launch_triplet_forward(f1, level_stride1, f2, level_stride2, L, B, rows, W, margin, 1e-6f, mining, t.part, t.case_dev,
-                                        mining ? t.mse : nullptr, t.row_stat, loss, static_cast<hipStream_t>(stream));
+                                        mining ? t.mse : nullptr, t.margin, t.row_stat, loss, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_triplet_loss_forward: %s", hipGetErrorString(e));
   return DFN_OK;
 }
@@ -355,7 +344,7 @@ extern "C" int dfn_triplet_loss_backward(const float* f1, size_t level_stride1, 
       !triplet_args_ok(grad_f1, grad_f2, L, B, rows, W, grad_stride1, grad_stride2))
     return set_error(DFN_ERR_ARG, "dfn_triplet_loss_backward: bad argument");
   const TripletState t = carve_triplet(const_cast<void*>(state), L, B, rows);
-  hipError_t e = launch_triplet_backward(f1, level_stride1, f2, level_stride2, L, B, rows, W, 1e-6f, t.case_dev, t.row_stat, grad_loss,
+  hipError_t e = launch_triplet_backward(f1, level_stride1, f2, level_stride2, L, B, rows, W, 1e-6f, t.case_dev, t.row_stat, t.margin, grad_loss,
                                          grad_f1, grad_stride1, grad_f2, grad_stride2, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return set_error(DFN_ERR_HIP, "dfn_triplet_loss_backward: %s", hipGetErrorString(e));
   return DFN_OK;
