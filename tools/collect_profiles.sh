@@ -20,6 +20,22 @@ try:
     d["launches_per_step"] = round(sum(int(r["Calls"]) for r in rows) / it, 1)
     d["launches_under_10us_per_step"] = round(sum(int(r["Calls"]) for r in rows if float(r["AverageNs"]) < 1e4) / it, 1)
     d["kernel_ms_per_step"] = round(sum(float(r["TotalDurationNs"]) for r in rows) / 1e6 / it, 3)
+    try:   # a STEADY step (the average above carries the first step's weight uploads): launches and idle time between two coarse-kernel launches
+        tr = list(csv.DictReader(open(sys.argv[2].replace("kernel_stats", "kernel_trace"))))
+        tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+        idx = [i for i, r in enumerate(tr) if "nerfh_coarse_kernel" in r["Kernel_Name"]]
+        a, b = idx[-3], idx[-2]
+        d["launches_per_steady_step"] = b - a
+        end, idle = int(tr[a]["Start_Timestamp"]), 0
+        for r in tr[a:b + 1]:
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            if st - end > 6000:
+                idle += st - end
+            end = max(end, en)
+        d["gpu_idle_ms_per_steady_step"] = round(idle / 1e6, 3)
+        d["steady_step_span_ms"] = round((int(tr[b]["Start_Timestamp"]) - int(tr[a]["Start_Timestamp"])) / 1e6, 3)
+    except Exception as e:
+        d["steady_step_census_error"] = str(e)
     d["vendor_library_kernels"] = sorted({r["Name"][:60] for r in rows if any(k in r["Name"] for k in ("Cijk_", "rocsolver", "rocblas"))})
     d["source"] = "tools/gpu_dm_step.py 4 24 under rocprofv3 --kernel-trace --stats (profiles/%s_dm_step_kernel_stats.csv)" % sys.argv[3].split("/")[-1].split("_")[0]
 except Exception as e:
