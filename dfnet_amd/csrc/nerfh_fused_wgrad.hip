@@ -126,10 +126,16 @@ DFN_DEV void mma_block(const BlockOps& o, bool bias, float inv, f32x16& master) 
 }
 }  // namespace
 
+#ifndef DFN_FW_TPS1
+#define DFN_FW_TPS1 2
+#endif
+// TPS wave-tiles per ring stage: with one plane a wave-tile is half the bytes behind the same barrier, counted wait and address
+// arithmetic — two tiles per stage give the one-plane stream the per-iteration payload of the two-plane one.
 template <int PL>
 __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr uint32_t kLdsChunk = lds_chunk<PL>();
+  constexpr int TPS = PL == 1 ? DFN_FW_TPS1 : 1;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int j = 0;
@@ -137,25 +143,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a
   const WJob& jb = a.job[j];
   const int kcg = jb.kcg, kcx0 = jb.kcx0, kcx1 = jb.kcx1;
   const int kc_all = kcg + kcx0 + kcx1;
-  const uint32_t stage_bytes = uint32_t(kc_all) * kLdsChunk;
+  const uint32_t tile_bytes = uint32_t(kc_all) * kLdsChunk, stage_bytes = TPS * tile_bytes;
   int D = int(kWgradLdsBytes / stage_bytes);
   D = D > 4 ? 4 : D;
   const int chunk = int(blockIdx.x) - jb.first_wg;
   const int wt0 = chunk * jb.wt_per_chunk;
-  int n_it = a.n_wt - wt0;
-  n_it = n_it > jb.wt_per_chunk ? jb.wt_per_chunk : n_it;
-  if (n_it <= 0) return;
-  const int np = kc_all * PL;                      // 1 KiB pieces per stage
-  const int my_np = (np - wave + WAVES - 1) / WAVES;
+  int n_tiles = a.n_wt - wt0;
+  n_tiles = n_tiles > jb.wt_per_chunk ? jb.wt_per_chunk : n_tiles;
+  if (n_tiles <= 0) return;
+  const int n_it = (n_tiles + TPS - 1) / TPS;
+  const int np = kc_all * PL;                      // 1 KiB pieces per wave-tile
+  const int my_np = TPS * ((np - wave + WAVES - 1) / WAVES);   // ... this wave issues per stage
   auto issue = [&](int it) {
-    const size_t wt = size_t(wt0 + it);
-    char* dst = smem + uint32_t(it % D) * stage_bytes;
-    for (int i = wave; i < np; i += WAVES) {
-      const char* src;
-      if (i < PL * kcg) src = jb.g + ((wt * size_t(jb.g_stride) + jb.g_chunk0) * PL + i) * 1024;
-      else if (i < PL * (kcg + kcx0)) src = jb.x0 + (wt * size_t(PL * kcx0) + (i - PL * kcg)) * 1024;
-      else src = jb.x1 + (wt * size_t(PL * kcx1) + (i - PL * (kcg + kcx0))) * 1024;
-      lds_dma_b128_nt(src + lane * 16, dst + (i / PL) * kLdsChunk + (i % PL) * 1024);
+#pragma unroll
+    for (int sub = 0; sub < TPS; ++sub) {
+      int tl = it * TPS + sub;
+      tl = tl < n_tiles ? tl : n_tiles - 1;        // (an odd tail re-reads the last tile: the counted waits stay uniform; it is not multiplied)
+      const size_t wt = size_t(wt0 + tl);
+      char* dst = smem + uint32_t(it % D) * stage_bytes + sub * tile_bytes;
+      for (int i = wave; i < np; i += WAVES) {
+        const char* src;
+        if (i < PL * kcg) src = jb.g + ((wt * size_t(jb.g_stride) + jb.g_chunk0) * PL + i) * 1024;
+        else if (i < PL * (kcg + kcx0)) src = jb.x0 + (wt * size_t(PL * kcx0) + (i - PL * kcg)) * 1024;
+        else src = jb.x1 + (wt * size_t(PL * kcx1) + (i - PL * (kcg + kcx0))) * 1024;
+        lds_dma_b128_nt(src + lane * 16, dst + (i / PL) * kLdsChunk + (i % PL) * 1024);
+      }
     }
   };
   for (int it = 0; it < D - 1 && it < n_it; ++it) issue(it);
@@ -190,18 +202,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wgrad_stream_kernel(WgradArgs a
     __builtin_amdgcn_s_barrier();   // stage `it` landed for every wave; every wave has left stage it - 1
     asm volatile("" ::: "memory");
     if (it + D - 1 < n_it) issue(it + D - 1);
-    const float inv = 1.f / scalar_f32(jb.gscale + wt0 + it);
-    const uint32_t sb = uint32_t(size_t(DFN_LDS_PTR(smem))) + uint32_t(it % D) * stage_bytes;
-    // block pipeline: while block i's MFMAs run, block i + 1's operands are read (transposed) into the other register set — the
-    // eight waves leave the barrier together, so without this every wave reads, then every wave multiplies
-    BlockOps S[2];
-    if (valid[0]) issue_block<PL>(S[0], sb + goff[0], sb + xoff[0]);
 #pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-      if (!valid[i]) break;
-      wait_block<PL>(S[i & 1]);
-      if (i + 1 < MAXB && valid[i + 1]) issue_block<PL>(S[(i + 1) & 1], sb + goff[i + 1], sb + xoff[i + 1]);
-      mma_block<PL>(S[i & 1], is_bias[i], inv, master[i]);
+    for (int sub = 0; sub < TPS; ++sub) {
+      if (it * TPS + sub >= n_tiles) break;
+      const float inv = 1.f / scalar_f32(jb.gscale + wt0 + it * TPS + sub);
+      const uint32_t sb = uint32_t(size_t(DFN_LDS_PTR(smem))) + uint32_t(it % D) * stage_bytes + sub * tile_bytes;
+      // block pipeline: while block i's MFMAs run, block i + 1's operands are read (transposed) into the other register set — the
+      // eight waves leave the barrier together, so without this every wave reads, then every wave multiplies
+      BlockOps S[2];
+      if (valid[0]) issue_block<PL>(S[0], sb + goff[0], sb + xoff[0]);
+#pragma unroll
+      for (int i = 0; i < MAXB; ++i) {
+        if (!valid[i]) break;
+        wait_block<PL>(S[i & 1]);
+        if (i + 1 < MAXB && valid[i + 1]) issue_block<PL>(S[(i + 1) & 1], sb + goff[i + 1], sb + xoff[i + 1]);
+        mma_block<PL>(S[i & 1], is_bias[i], inv, master[i]);
+      }
     }
   }
 #pragma unroll
