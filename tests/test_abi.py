@@ -101,3 +101,39 @@ def test_product_library_carries_no_bench_scaffolding():
     assert os.path.exists(probe)
     psyms = subprocess.run(["nm", "-D", "--defined-only", probe], capture_output=True, text=True, check=True).stdout
     assert "dfn_probe_mfma_rate" in psyms and "dfn_probe_last_error" in psyms
+
+
+def test_round5_entries_refuse_bad_arguments_without_a_gpu():
+    """The entry points added in round 5 (batched raygen / bicubic, the fused DFNet_dm loss block, the asynchronous range read, the
+    pose orthogonalisation, the stand-alone conv weight gradient, the training modes) check their arguments before any device work:
+    DFN_ERR_ARG with a message, on a box without a GPU too."""
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    one = ctypes.c_void_p(16)      # a non-null token: never dereferenced when another argument is refused first
+    bad = [
+        lib.dfn_raygen_frames(0, 4, 4, 1.0, one, one, one, None, None),
+        lib.dfn_raygen_frames(2, 4, 4, -1.0, one, one, one, None, None),
+        lib.dfn_raygen_frames_backward(2, 0, 4, 1.0, one, one, one, None),
+        lib.dfn_upsample_bicubic_frames(None, 2, 4, 4, 3, 8, 8, 1, one, None),
+        lib.dfn_upsample_bicubic_frames_backward(one, 0, 4, 4, 3, 8, 8, 0, one, None),
+        lib.dfn_dm_loss_forward(one, one, 0, one, one, 12, None, 0.3, 0.2, 1.0, one, one, None),
+        lib.dfn_dm_loss_forward(one, one, 8, one, one, 12, None, 0.3, 0.2, 1.0, None, one, None),
+        lib.dfn_dm_loss_backward(one, one, 8, one, one, 0, 0.3, 0.2, 1.0, one, one, one, None, None),
+        lib.dfn_pose_orthogonalize(None, 2, one, None),
+        lib.dfn_nerfh_range_status_async(None, one, None),
+        lib.dfn_conv_wgrad(None, one, 1, 8, 8, 64, 64, 3, one, None, one, 0, None),
+    ]
+    assert all(rc == -1 for rc in bad), bad
+    assert lib.dfn_dm_loss_scratch_bytes() >= 2048
+    assert b"dfn_" in lib.dfn_last_error()
+    # training modes: 0 fused (fine operands as one f16 plane), 1 exact, 2 fused with hi | lo planes everywhere; anything else is refused
+    h = ctypes.c_void_p()
+    d = _lib.NerfhDesc(8, 128, 10, 4, 10, 5, 2, 1000)
+    assert lib.dfn_nerfh_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    try:
+        for mode in (0, 1, 2):
+            assert lib.dfn_nerfh_set_train_mode(h, mode) == 0
+        assert lib.dfn_nerfh_set_train_mode(h, 3) == -1
+        assert lib.dfn_nerfh_range_status_async(h, None, None) == -1
+    finally:
+        lib.dfn_nerfh_destroy(h)
