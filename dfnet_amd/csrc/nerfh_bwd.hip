@@ -43,6 +43,12 @@ template <class PF, class P> constexpr uint32_t bwd_lds_bytes() { return 3 * bwd
 // mask pass over the finished operand.  4.01 -> 3.65 ms for the DFNet_dm step's 3.7 M points, fewer spilled registers (124 -> 64 B).
 #define DFN_BLAYER(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
   layer<P, UMB, (P::kSplit && NB == 1), NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false, true, true>(st, smem, IN, OUT, head, RB, carry)
+// ... a layer whose output the renormalisation inspects right afterwards (renorm_factor(..., &st.rmax)): no per-piece range tracking
+#ifndef DFN_BWD_NOTRACK
+#define DFN_BWD_NOTRACK 1
+#endif
+#define DFN_BLAYER_NT(KC, MB, EXTRA, RAYBIAS, IN, OUT, RB) \
+  layer<P, UMB, (P::kSplit && NB == 1), NB, KC, MB, false, EXTRA, RAYBIAS, true, -1, true, false, true, true, !(DFN_BWD_NOTRACK && P::kSplit)>(st, smem, IN, OUT, head, RB, carry)
 
 // PF: arithmetic of the forward recompute, P: arithmetic of the backward chain.  Split-f16 for both is the default:
 // activations are O(1), and the gradient vector of a point is carried with a per-point power-of-two scale that is
@@ -286,11 +292,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g1[nb], mt[1][nb]);
         fetch_mt(0);
-        DFN_BLAYER(QC, 2, false, false, g1, g0, norb);    // BW_TE1
+        DFN_BLAYER_NT(QC, 2, false, false, g1, g0, norb);    // BW_TE1
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) apply_mask<P, QC>(g0[nb], mt[0][nb]);
         fetch_md();
-        DFN_BLAYER(SC, 2, false, false, drgb, g1, norb);  // BW_RGB
+        DFN_BLAYER_NT(SC, 2, false, false, drgb, g1, norb);  // BW_RGB
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           apply_mask<P, QC>(g1[nb], md[nb]);
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
       {
         F dfin[NB][HC];
         if constexpr (P::kSplit) {
-          st.lane_mul = renorm_factor<P, HC>(cat[0], sp[0]);   // the two branches share sp up to here
+          st.lane_mul = renorm_factor<P, HC>(cat[0], sp[0], &st.rmax);   // the two branches share sp up to here
           // d sigma_s joins the chain after this layer (slot 64 of BW_FIN's input) at the scale chosen HERE: when the colour /
           // transient gradients of a point are orders of magnitude below its density gradient (near-duplicate samples: alpha ~ 0)
           // a factor chosen from them alone overflowed that slot's f16 halves (inf -> NaN for the whole ray).  Keep
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
             st.lane_mul *= ldexpf(1.f, 11 - e);
           }
         }
-        DFN_BLAYER(HC, 4, true, false, cat, dfin, norb);  // BW_FINCAT: d final + (head) d pe_dir
+        DFN_BLAYER_NT(HC, 4, true, false, cat, dfin, norb);  // BW_FINCAT: d final + (head) d pe_dir
         if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -343,25 +349,25 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
           set_slot<P>(cat2[nb], 64, dsig_true[nb] * sp[nb]);   // slot 64 of half 0: d sigma_s pre-activation (h == 1 lanes hold 0)
         }
       }
-      if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC + SC>(cat2[0], sp[0]);   // incl. the d sigma_s slot
+      if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC + SC>(cat2[0], sp[0], &st.rmax);   // incl. the d sigma_s slot
       fetch_mk(7);
-      DFN_BLAYER(HC + SC, 4, false, false, cat2, gh, norb);  // BW_FIN
+      DFN_BLAYER_NT(HC + SC, 4, false, false, cat2, gh, norb);  // BW_FIN
       if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
     }
     F gh2[NB][HC];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[7][nb]);
-    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0], &st.rmax);
     fetch_mk(6);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L8
     if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[6][nb]);
     fetch_mk(5);
-    DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);          // BW_L7
+    DFN_BLAYER_NT(HC, 4, false, false, gh2, gh, norb);          // BW_L7
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[5][nb]);
-    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0], &st.rmax);
     fetch_mk(4);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L6
     if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
           DFN_BLAYER(HC, 2, false, false, gh2, dpe, norb);   // BW_L5, M-blocks 4, 5
           pe_jacobian(dpe, true);
         }
-        DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);      // BW_L5, M-blocks 0..3
+        DFN_BLAYER_NT(HC, 4, false, false, gh2, gh, norb);      // BW_L5, M-blocks 0..3
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[3][nb]);
       } else {
@@ -438,17 +444,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void nerfh_fine_backward_kernel(BwdA
         pe_jacobian(dpe, true);
       }
     }
-    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0], &st.rmax);
     fetch_mk(2);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L4
     if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh2[nb], mk[2][nb]);
     fetch_mk(1);
-    DFN_BLAYER(HC, 4, false, false, gh2, gh, norb);          // BW_L3
+    DFN_BLAYER_NT(HC, 4, false, false, gh2, gh, norb);          // BW_L3
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) apply_mask<P, HC>(gh[nb], mk[1][nb]);
-    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0]);
+    if constexpr (P::kSplit) st.lane_mul = renorm_factor<P, HC>(gh[0], sp[0], &st.rmax);
     fetch_mk(0);
     DFN_BLAYER(HC, 4, false, false, gh, gh2, norb);          // BW_L2
     if constexpr (P::kSplit) { sp[0] *= st.lane_mul; st.lane_mul = 1.f; }

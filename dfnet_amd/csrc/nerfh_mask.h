@@ -105,8 +105,10 @@ DFN_DEV void clear(typename FragOf<P>::type (&v)[N]) {
 // inf * (d sigma) = NaN poisoned its ray's — and through the pose reduction its frame's — gradient.  Beyond the cap the halves are
 // allowed to underflow: the true value is below 2^-96 of the gradient scale.
 constexpr float kSpCap = 7.9228163e28f;   // 2^96
+// rmax (optional): the range guard's running maximum — the operand's largest |hi| is taken here anyway, so the layer that produced `v`
+// need not track its conversions (layer<..., TRACK = false>): a saturated hi half (65504) raises the guard's pattern.
 template <class P, int C, int N>
-DFN_DEV float renorm_factor(const typename FragOf<P>::type (&v)[N], float sp_now) {
+DFN_DEV float renorm_factor(const typename FragOf<P>::type (&v)[N], float sp_now, uint32_t* rmax = nullptr) {
   if constexpr (!P::kSplit) return 1.f;
   else {
     half8 m = __builtin_elementwise_abs(v[0].hi);
@@ -115,6 +117,7 @@ DFN_DEV float renorm_factor(const typename FragOf<P>::type (&v)[N], float sp_now
     float mx = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)m[j]);
+    if (rmax && !(mx < 65504.f)) *rmax |= 0x7bff7bffu;   // (also catches a NaN)
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (!(mx > 0.f)) return 1.f;
     int e;

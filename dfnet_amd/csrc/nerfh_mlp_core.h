@@ -388,8 +388,10 @@ struct X3Piece {
 // SCALE_FIRST (split-f16, PIPE): the pipelined conversion in its scale-in-fp32-first form (store_hidden_piece, a block of pieces behind
 // each chunk's MFMAs) instead of the three-part X3Piece form, which converts the UNSCALED accumulators and so needs the render
 // kernels' unit weight scale — the gradient kernels keep the 2^10 scale and per-point renormalisation factors (Stager::lane_mul).
+// TRACK = false: the range guard does not watch this layer's conversions (the caller checks the finished operand itself: the gradient
+// kernel's renormalisation already takes the maximum |hi| of it, renorm_factor).
 template <class P, int UMB, bool PIPE, int NB, int KC, int MB, bool RELU, bool EXTRA, bool RAYBIAS, bool NEWUNIT,
-          int CIN, bool CIN_RELU, bool COUT, bool NOBIAS = false, bool SCALE_FIRST = false>
+          int CIN, bool CIN_RELU, bool COUT, bool NOBIAS = false, bool SCALE_FIRST = false, bool TRACK = true>
 DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][KC],
                    typename FragOf<P>::type (&Bout)[NB][(MB ? MB : 1) * chunks_of<P>(16)],
                    f32x16 (&head)[NB], const float* const (&raybias)[NB], f32x16 (&carry)[NB]) {
@@ -403,6 +405,8 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
   static_assert(!COUT || (PIPE && MB >= 1 && !EXTRA), "carry-out needs a regular last M-block");
   static_assert(NEWUNIT || UMB >= TOT, "a layer that continues a unit must fit in it");
   const int h = st.lane >> 5;
+  uint32_t rmax_sink = 0;
+  uint32_t& rmax_ = TRACK ? st.rmax : rmax_sink;
   const float pscale = P::kSplit ? st.out_scale * st.lane_mul * kX3ActScale : 1.f;  // split-f16 pieces: accumulator -> operand scale
   uint32_t pscale2 = 0;   // ... the same factor as a packed f16 pair (X3Piece::B)
   if constexpr (P::kSplit) asm("v_cvt_pkrtz_f16_f32 %0, %1, %1" : "=v"(pscale2) : "v"(pscale));
@@ -496,8 +500,8 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
             for (int q = 0; q < NPMAX; ++q)
               if (q < np && base + q < 8) {
-                if (from_carry) pc[q].template C<CIN_RELU>(Bin[0], CIN / 2, base + q, st.rmax);
-                else pc[q].template C<RELU>(Bout[0], mb - 1, base + q, st.rmax);
+                if (from_carry) pc[q].template C<CIN_RELU>(Bin[0], CIN / 2, base + q, rmax_);
+                else pc[q].template C<RELU>(Bout[0], mb - 1, base + q, rmax_);
               }
             acc[0] = c0;
             if (from_carry && kc == CIN - 1) asm volatile("s_nop 3");
@@ -513,7 +517,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
             for (int q = 0; q < PPKI; ++q) {
               const int piece = kc * PPKI + q;
-              if (piece < 8 * NB) store_hidden_piece<P, CIN_RELU>(carry[piece >> 3], Bin[piece >> 3], CIN / 2, piece & 7, pscale, st.rmax);
+              if (piece < 8 * NB) store_hidden_piece<P, CIN_RELU>(carry[piece >> 3], Bin[piece >> 3], CIN / 2, piece & 7, pscale, rmax_);
             }
             if (kc == CIN - 1) asm volatile("s_nop 3");  // VALU-written B operand is read by the very next MFMA
           }
@@ -521,7 +525,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
 #pragma unroll
             for (int q = 0; q < PPK; ++q) {
               const int piece = kc * PPK + q;
-              if (piece < 8 * NB) store_hidden_piece<P, RELU>(pend[piece >> 3], Bout[piece >> 3], mb - 1, piece & 7, pscale, st.rmax);
+              if (piece < 8 * NB) store_hidden_piece<P, RELU>(pend[piece >> 3], Bout[piece >> 3], mb - 1, piece & 7, pscale, rmax_);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -533,7 +537,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
             for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
           } else {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb, st.out_scale * st.lane_mul, st.rmax);
+            for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(acc[nb], Bout[nb], mb, st.out_scale * st.lane_mul, rmax_);
           }
         } else {
 #pragma unroll
@@ -551,7 +555,7 @@ DFN_DEV void layer(Stager& st, char* smem, typename FragOf<P>::type (&Bin)[NB][K
       for (int nb = 0; nb < NB; ++nb) carry[nb] = pend[nb];
     } else {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1, st.out_scale * st.lane_mul, st.rmax);
+      for (int nb = 0; nb < NB; ++nb) store_hidden<P, RELU>(pend[nb], Bout[nb], MB - 1, st.out_scale * st.lane_mul, rmax_);
     }
   }
 }
