@@ -64,8 +64,18 @@ DFN_DEV void apply_mask(typename FragOf<P>::type (&v)[N], const uint32_t (&m)[(C
       u32x4 keep;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
+#ifdef DFN_MASK_MUL
         const uint32_t t = (m[c >> 2] >> (4 * (c & 3) + w)) & 0x00010001u;
         keep[w] = t * 0xFFFFu;   // 0xFFFF per active half
+#else
+        // 0xFFFF per active half in TWO packed 16-bit shifts: the pair's two bits sit at bit k of either half of the word (relu_mask's
+        // layout), so a left shift by 15 - k puts each into its half's sign bit and an arithmetic right shift by 15 spreads it —
+        // instead of shift, and, multiply.  (op_sel_hi:[0,1]: the scalar shift count serves both halves.)
+        uint32_t t;
+        asm("v_pk_lshlrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "s"(15 - (4 * (c & 3) + w)), "v"(m[c >> 2]));
+        asm("v_pk_ashrrev_i16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "s"(15), "v"(t));
+        keep[w] = t;
+#endif
       }
       if constexpr (P::kSplit) {
         v[c].hi = __builtin_bit_cast(half8, __builtin_bit_cast(u32x4, v[c].hi) & keep);
