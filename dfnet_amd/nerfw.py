@@ -156,8 +156,8 @@ def create_nerf(args):
                          multires_views=args.multires_views, hist_bin=args.hist_bin, dim_a=dim_a, dim_t=dim_t,
                          n_vocab=args.N_vocab, precision=getattr(args, "precision", "f16x3"))
     engine.load_modules(model, model_fine, embedding_a, embedding_t)
-    if engine.fast and getattr(args, "precision", "f16x3") == "f16x3" and getattr(args, "coarse_precision", "f16") == "f16":
-        engine.set_render_options(coarse_f16=True)   # fp32-grade pixels from the split-f16 fine network; f16 places its samples
+    if engine.fast and getattr(args, "precision", "f16x3") == "f16x3" and getattr(args, "coarse_precision", "same") == "f16":
+        engine.set_render_options(coarse_f16=True)   # opt-in: the split-f16 fine network makes the pixel, an f16 coarse network places its samples
 
     from .nerf_train import NerfHTrainer
     query = HipQuery(engine, args.netchunk, modules=(model, model_fine, embedding_a, embedding_t))

@@ -502,10 +502,27 @@ def main():
             ro, rd = ray_utils.get_rays(Ht, Wt, ft, t(c2w))
             sel = r15.choice(Ht * Wt, 64, replace=False)
             ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
-            rgb, disp, acc, extras = rendering.render(Ht, Wt, ft, chunk=32768, rays=torch.stack([ro, rd], 0), near=0., far=2.5,
-                                                       img_idx=t(hist)[None], retraw=True, **kwargs_for("trained", 64, 128))
+            # The reference's own intermediates of this call — the sorted z_vals (rendering.py:300-304), the coarse network's raw output
+            # and compositing weights (:292-296) — are recorded by wrapping the module-level compositor for the duration of the call: the
+            # staged parity test feeds exactly these fine samples to the HIP fine network, which separates arithmetic error (network +
+            # compositing on the SAME samples) from the sampler's bin flips.
+            taps, inner = {}, rendering.raw2outputs_NeRFW
+
+            def tap(raw, z_vals, *a, **kw):
+                out = inner(raw, z_vals, *a, **kw)
+                typ = kw.get("typ", "coarse")
+                taps[typ] = (raw.clone(), z_vals.clone(), out[3].clone())
+                return out
+            rendering.raw2outputs_NeRFW = tap
+            try:
+                rgb, disp, acc, extras = rendering.render(Ht, Wt, ft, chunk=32768, rays=torch.stack([ro, rd], 0), near=0., far=2.5,
+                                                           img_idx=t(hist)[None], retraw=True, **kwargs_for("trained", 64, 128))
+            finally:
+                rendering.raw2outputs_NeRFW = inner
+            assert torch.equal(taps["fine"][0], extras["raw"])
             save("g15_trained_render_rays", Nc=64, Ni=128, near=0., far=2.5, hist=hist, rays_o=ro, rays_d=rd, rgb=rgb, disp=disp, acc=acc,
-                 raw=extras["raw"])
+                 raw=extras["raw"], z_vals=taps["fine"][1], weights=taps["fine"][2],
+                 coarse_raw=taps["coarse"][0], coarse_z=taps["coarse"][1], coarse_weights=taps["coarse"][2])
             H, Wd, focal = 12, 16, 585.0 / 40   # the same field of view at a fifth of the training resolution
             c2w = syn.orbit_pose(11, 40)
             rgb, disp, acc, _ = rendering.render(H, Wd, focal, chunk=100, c2w=t(c2w)[:3, :4], near=0., far=2.5, img_idx=t(hist)[None],

@@ -243,14 +243,25 @@ def _fp64_oracle_of_g15(gold):
     return {"rgb": out["rgb_map"], "disp": out["disp_map"], "acc": out["acc_map"], "rgb_image": img[0], "disp_image": img[1], "acc_image": img[2]}
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("f16", 1e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("f16x3+coarse_f16", 2e-5), ("f16", 1e-3)])
 def test_trained_weights_render_vs_reference(trained, gold, prec, tol):
-    """random-init weights are contractive, trained checkpoints (sharp sigma) amplify error.  All three arithmetic
-    modes on trained weights against (i) the reference's own fp32 outputs (G15) and (ii) the float64 oracle as the yardstick:
+    """random-init weights are contractive, trained checkpoints (sharp sigma) amplify error.  Every arithmetic
+    mode on trained weights — "f16x3+coarse_f16" is the `coarse_precision=f16` OPTION of create_nerf (dfnet_amd/nerfw.py; the shipped
+    default is pure f16x3) — against (i) the reference's own fp32 outputs (G15) and (ii) the float64 oracle as the yardstick:
       * the typical pixel (median error vs the reference) holds the mode's tolerance;
-      * the worst pixel is within 3 x the distance the REFERENCE itself sits from the float64 evaluation (or the tolerance);
+      * the worst pixel is within 1 x the distance the REFERENCE itself sits from the float64 evaluation (+ the tolerance);
       * the narrow modes either do that or raise the range guard — never a silent clamp."""
     E = trained
+    coarse16 = prec.endswith("+coarse_f16")
+    prec = prec.split("+")[0]
+    E.set_render_options(coarse_f16=coarse16)
+    try:
+        _trained_weights_render_vs_reference(E, gold, prec, tol, coarse16)
+    finally:
+        E.set_render_options(coarse_f16=False)
+
+
+def _trained_weights_render_vs_reference(E, gold, prec, tol, coarse16):
     E.range_flags()   # clear
     g, gi = gold("g15_trained_render_rays"), gold("g15_trained_render_image")
     rgb, disp, acc, raw = E.render_rays(dev(g["rays_o"]), dev(g["rays_d"]), dev(g["hist"]), int(g["Nc"]), int(g["Ni"]), float(g["near"]),
@@ -273,9 +284,9 @@ def test_trained_weights_render_vs_reference(trained, gold, prec, tol):
         # plain f16 (not the default, outside north_star's 1e-3 on such weights and stated so): rounding the activations to 11 bits
         # moves fine samples across surfaces at a few grazing pixels — measured 1.3e-2 on one disparity of the 12 x 16 frame, 1e-3 on
         # the ray batch, typical pixel 3e-5 — bounded here at 2e-2 worst / 1e-4 typical
-        worst_ok = err64 <= (2e-2 if prec == "f16" else 3 * yard + tol)
+        worst_ok = err64 <= (2e-2 if prec == "f16" else yard + tol)
         ok = ok and worst_ok and med <= (1e-4 if prec == "f16" else tol)
-    print(f"trained weights, {prec}: " + "; ".join(rows) + f"; PSNR vs the reference {-10 * np.log10(max(mse, 1e-30)):.1f} dB, range flags {flags}")
+    print(f"trained weights, {prec}{' + coarse f16' if coarse16 else ''}: " + "; ".join(rows) + f"; PSNR vs the reference {-10 * np.log10(max(mse, 1e-30)):.1f} dB, range flags {flags}")
     assert relmax(raw[..., [3, 7]], g["raw"][..., [3, 7]]) < 0.2    # per-sample outputs: sanity only (a sample's position decides its density)
     if prec == "f32":
         assert flags == 0
@@ -284,6 +295,100 @@ def test_trained_weights_render_vs_reference(trained, gold, prec, tol):
         assert -10 * np.log10(max(mse, 1e-30)) > (55 if prec == "f16" else 60)
     else:   # a guarded failure: loud, and only in a narrow mode
         assert prec != "f32"
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("f16", 1e-3)])
+def test_trained_weights_stages_on_the_references_own_samples(trained, gold, prec, tol):
+    """G15 records the reference's intermediates (rendering.py:292-304): the coarse network's raw output and weights, and the sorted
+    z_vals the fine network was evaluated at.  Stage by stage on trained weights, each stage fed the REFERENCE's input:
+      * coarse network: sigma on the reference's coarse depths;
+      * sampler: the reference's coarse sigma in -> sorted z_vals (bin occupancy; value where the pdf is well conditioned);
+      * fine network + compositor on the reference's z_vals: raw, rgb, disp, acc at the mode's tolerance.
+    This separates arithmetic from sample placement: whatever the end-to-end worst pixel of
+    test_trained_weights_render_vs_reference shows beyond these numbers is a fine sample that landed on the other side of a surface."""
+    E = trained
+    E.range_flags()
+    g = gold("g15_trained_render_rays")
+    o, d, hist = dev(g["rays_o"]), dev(g["rays_d"]), dev(g["hist"])[None]
+    v = d / d.norm(dim=-1, keepdim=True)
+    Nc, Ni, near, far = int(g["Nc"]), int(g["Ni"]), float(g["near"]), float(g["far"])
+    sig = E.mlp_coarse(o, d, Nc, near, far, precision=prec)
+    e_sig = relmax(sig, g["coarse_raw"][..., 0])
+    # sampler on the reference's own sigma
+    zf, w, zs = eng.sample_fine(dev(g["coarse_raw"][..., 0]), Ni, near, far, want_aux=True)
+    e_w = relmax(w, g["coarse_weights"])
+    dz = (zf.cpu() - T(g["z_vals"])).abs()
+    moved = int((dz > 1e-5).sum())
+    # fine network on the reference's samples, compositor on both raws
+    zref = dev(g["z_vals"])
+    raw = E.mlp_fine(o, d, v, hist, zref, precision=prec)
+    e_raw = {n: relmax(raw[..., ch], g["raw"][..., ch]) for n, ch in
+             (("rgb_s", slice(0, 3)), ("sigma_s", slice(3, 4)), ("rgb_t", slice(4, 7)), ("sigma_t", slice(7, 8)), ("beta", slice(8, 9)))}
+    e_map = {k: relmax(x, g[k]) for k, x in eng.composite_fine(raw, zref).items()}
+    e_comp = {k: relmax(x, g[k]) for k, x in eng.composite_fine(dev(g["raw"]), zref).items()}
+    flags = E.range_flags()
+    print(f"trained stages, {prec}: coarse sigma {e_sig:.1e}; sampler weights {e_w:.1e}, {moved} of {dz.numel()} samples moved > 1e-5 "
+          f"(max {float(dz.max()):.1e}); fine raw {({k: f'{x:.1e}' for k, x in e_raw.items()})}; maps from HIP raw "
+          f"{({k: f'{x:.1e}' for k, x in e_map.items()})}; compositor on the reference's raw {({k: f'{x:.1e}' for k, x in e_comp.items()})}; "
+          f"range flags {flags}")
+    assert max(e_comp.values()) < 2e-5 and e_w < 2e-5           # fp32 stage kernels in every mode
+    assert float(dz.median()) < 1e-6 and float(dz.max()) < (far - near) / (Nc - 2)   # a moved sample stays inside its coarse bin
+    if flags == 0:
+        assert e_sig < tol and max(e_raw.values()) < tol and max(e_map.values()) < tol
+    else:
+        assert prec != "f32"
+
+
+def test_create_nerf_engine_on_trained_checkpoint(trained, gold, tmp_path):
+    """What `run_nerf.py --render_test` runs on a loaded checkpoint: create_nerf (dfnet_amd/nerfw.py) reloading a `{:06d}.tar` in the
+    reference's format (models/nerfw.py:452-472, run_nerf.py:150-158) that holds the TRAINED fixture, then rendering.render with its
+    render_kwargs_test on the G15 inputs.  The engine create_nerf builds must be pure split-f16 (the default arithmetic: coarse AND
+    fine network fp32-grade) and its maps bit-identical to the bare f16x3 engine's, i.e. covered by the yardstick test above;
+    `--coarse_precision f16` turns the f16 coarse network on and is held to the same yardstick."""
+    from dfnet_amd import nerfw, options, rendering
+    tw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_nerfh_weights.npz"))
+    exp = tmp_path / "logs" / "nerfh"
+    exp.mkdir(parents=True)
+    torch.save({'global_step': 20000,
+                'network_fn_state_dict': {k[len("coarse."):]: T(tw[k]) for k in tw.files if k.startswith("coarse.")},
+                'network_fine_state_dict': {k[len("fine."):]: T(tw[k]) for k in tw.files if k.startswith("fine.")},
+                'embedding_a_state_dict': {'weight': T(tw["embedding_a.weight"])},
+                'embedding_t_state_dict': {'weight': T(tw["embedding_t.weight"])}, 'optimizer_state_dict': {}},
+               str(exp / "020000.tar"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = ["--config", os.path.join(root, "script", "config_nerfh.txt"), "--basedir", str(tmp_path / "logs"), "--render_test",
+            "--no_grad_update"]
+    gi, gr = gold("g15_trained_render_image"), gold("g15_trained_render_rays")
+    H, W, focal = int(gi["H"]), int(gi["W"]), float(gi["focal"])
+    f64 = _fp64_oracle_of_g15(gold)
+    bare = trained.render_image(dev(gi["c2w"]), H, W, focal, dev(gi["hist"]), 64, 128, 0., 2.5, precision="f16x3")
+    bare = [t.clone() for t in bare]
+    for extra, want16 in (([], False), (["--coarse_precision", "f16"], True)):
+        args = options.nerf_parser().parse_args(base + extra)
+        _, kw_test, start, _, _ = nerfw.create_nerf(args)
+        E = kw_test["network_query_fn"].engine
+        assert start == 20000 and E.coarse_f16 is want16 and E.precision == "f16x3"
+        with torch.no_grad():
+            rgb, disp, acc, _ = rendering.render(H, W, focal, chunk=args.chunk, c2w=dev(gi["c2w"])[:3, :4], near=0., far=2.5,
+                                                 img_idx=dev(gi["hist"])[None], **kw_test)
+            rr, dr, ar, _ = rendering.render(60, 80, 585.0 / 8, chunk=args.chunk, rays=torch.stack([dev(gr["rays_o"]), dev(gr["rays_d"])], 0),
+                                             near=0., far=2.5, img_idx=dev(gr["hist"])[None], **kw_test)
+        E.check_range()
+        if not want16:
+            assert torch.equal(rgb, bare[0]) and torch.equal(disp, bare[1]) and torch.equal(acc, bare[2])
+        got = {"rgb": rr, "disp": dr, "acc": ar, "rgb_image": rgb, "disp_image": disp, "acc_image": acc}
+        ref = {"rgb": gr["rgb"], "disp": gr["disp"], "acc": gr["acc"], "rgb_image": gi["rgb"], "disp_image": gi["disp"], "acc_image": gi["acc"]}
+        rows = []
+        for k in got:
+            scale = float(np.abs(ref[k]).max())
+            yard = float((T(ref[k]).double() - f64[k]).abs().max()) / scale
+            err64 = float((got[k].double().cpu() - f64[k]).abs().max()) / scale
+            med = float((got[k].double().cpu() - T(ref[k]).double()).abs().median()) / scale
+            rows.append((k, err64, yard, med))
+        print(f"create_nerf engine {'--coarse_precision f16' if want16 else '(default)'} on the trained checkpoint: " +
+              "; ".join(f"{k}: worst vs fp64 {e:.1e} (reference {y:.1e}), median vs reference {m:.1e}" for k, e, y, m in rows))
+        for k, e, y, m in rows:
+            assert e <= y + 2e-5 and m <= 2e-5, (k, e, y, m)
 
 
 def test_render_config1_shape_vs_oracle(scene):
@@ -327,7 +432,8 @@ def test_full_frame_properties(scene):
     rows = orc.pack_ray_rows(ro.reshape(-1, 3)[sub], rd.reshape(-1, 3)[sub], 0., 2.5, syn.HIST_IDX)
     with torch.no_grad():
         ref = orc.render_rays(rows, c, f, ea, et, 64, 128)
-    assert relmax(rgb.reshape(-1, 3)[sub.to(DEV)], ref["rgb_map"]) < 1e-3
+    assert relmax(rgb.reshape(-1, 3)[sub.to(DEV)], ref["rgb_map"]) < 2e-5      # the default arithmetic (split-f16) is fp32-grade
+    assert relmax(disp.reshape(-1)[sub.to(DEV)], ref["disp_map"]) < 2e-5
     assert relmax(r32.reshape(-1, 3)[sub.to(DEV)], ref["rgb_map"]) < 2e-5
     assert relmax(d32.reshape(-1)[sub.to(DEV)], ref["disp_map"]) < 2e-5
 

@@ -42,8 +42,8 @@ def test_config_file_then_cli_override(tmp_path):
     assert d.combine_loss_w == [0., 0., 1.] and d.feature_matching_lvl == [0] and d.DFNet
 
 
-def make_scene(root, n_train=3, n_val=2, H=48, W=64, seed=0):
-    """A synthetic tree with the 7-Scenes layout under root/data/..."""
+def make_scene(root, n_train=3, n_val=2, H=48, W=64, seed=0, poses=None):
+    """A synthetic tree with the 7-Scenes layout under root/data/...  `poses(i)` overrides the 4x4 pose written for frame i."""
     from PIL import Image
     rng = np.random.default_rng(seed)
     datadir = os.path.join(root, "data", "7Scenes", "heads")
@@ -58,7 +58,7 @@ def make_scene(root, n_train=3, n_val=2, H=48, W=64, seed=0):
         for i in range(n):
             img = (rng.random((H, W, 3)) * 255).astype(np.uint8)
             Image.fromarray(img).save(os.path.join(frames, f"seq-{seq:02d}", f"frame-{i:06d}.color.png"))
-            np.savetxt(os.path.join(frames, f"seq-{seq:02d}", f"frame-{i:06d}.pose.txt"), syn.orbit_pose(i, 8))
+            np.savetxt(os.path.join(frames, f"seq-{seq:02d}", f"frame-{i:06d}.pose.txt"), syn.orbit_pose(i, 8) if poses is None else poses(i))
     return datadir
 
 
@@ -465,7 +465,7 @@ def test_render_path_png_job_numbers_by_global_frame_index(tmp_path):
     # the options table carries this implementation's additions with the reference-precision defaults
     from dfnet_amd import options
     ns = options.nerf_parser().parse_known_args([])[0]
-    assert ns.precision == "f16x3" and ns.coarse_precision == "f16"
+    assert ns.precision == "f16x3" and ns.coarse_precision == "same"   # the shipped default: every stage fp32-grade
 
 
 def test_fused_training_tables_selfcheck():

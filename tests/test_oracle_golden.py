@@ -111,12 +111,30 @@ def test_g15_trained_weights(gold):
     c, f, ea, et = trained_nets()
     g = gold("g15_trained_render_rays")
     rows = orc.pack_ray_rows(T(g["rays_o"]), T(g["rays_d"]), float(g["near"]), float(g["far"]), g["hist"])
-    out = orc.render_rays(rows, c, f, ea, et, int(g["Nc"]), int(g["Ni"]), retraw=True)
+    st = {}
+    out = orc.render_rays(rows, c, f, ea, et, int(g["Nc"]), int(g["Ni"]), retraw=True, stages=st)
     assert float(np.max(g["raw"][..., 3])) > 20.0 and float(np.min(g["acc"])) > 0.99      # an occupied scene, not the 0.7-density fog of random init
     close(out["raw"], g["raw"], 5e-5, 5e-5)
     close(out["rgb_map"], g["rgb"], 1e-5, 2e-6)
     close(out["disp_map"], g["disp"], 1e-5, 2e-6)
     close(out["acc_map"], g["acc"], 1e-5, 2e-6)
+    # the reference's own intermediates (recorded by make_golden.py around rendering.py:292-304): the oracle's stages on those
+    assert np.array_equal(st["z_coarse"].numpy(), g["coarse_z"])
+    close(st["sigma_coarse"], g["coarse_raw"][..., 0], 2e-5, 2e-5 * float(np.abs(g["coarse_raw"]).max()))
+    close(st["weights_coarse"], g["coarse_weights"], 1e-4, 2e-6)
+    zref = T(g["z_vals"])
+    assert bool((zref[:, 1:] >= zref[:, :-1]).all()) and zref.shape == (64, 192)
+    # the inverse CDF is ill-conditioned where the coarse pdf is ~1e-5 (empty space in front of a surface): most samples agree to
+    # round-off, a few move within their bin
+    dz = (st["z_fine"] - zref).abs()
+    assert float(dz.median()) < 1e-6 and float(dz.max()) < 2.5 / 62
+    # the fine network and the compositor ON THE REFERENCE'S SAMPLES: arithmetic only, no sampler in between
+    raw = orc.query_fine(f, ea, et, rows[:, 0:3][:, None] + rows[:, 3:6][:, None] * zref[..., None], rows[:, 8:11], rows[:, 11:])
+    close(raw, g["raw"], 2e-5, 2e-5 * float(np.abs(g["raw"]).max()))
+    comp = orc.composite_fine(T(g["raw"]), zref)
+    close(comp["rgb"], g["rgb"], 1e-6, 1e-6)
+    close(comp["disp"], g["disp"], 1e-6, 1e-6)
+    close(comp["weights"], g["weights"], 1e-6, 1e-6)
     g = gold("g15_trained_render_image")
     rgb, disp, acc = orc.render(int(g["H"]), int(g["W"]), float(g["focal"]), 100, c, f, ea, et, int(g["Nc"]), int(g["Ni"]),
                                 float(g["near"]), float(g["far"]), g["hist"], c2w=g["c2w"])
