@@ -56,6 +56,50 @@ def frame_block(n_frames, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def band_mode(n_frames, world):
+    """SURVEY 8(e)'s small-batch fallback: fewer frames than ranks (the single validation frames of run_nerf.py:200,228; configs[0]'s
+    four frames on eight GPUs) -> frames are split into row bands so that no rank idles."""
+    return 0 < n_frames < world
+
+
+def band_unit(n_frames, H, rank, world):
+    """Row-band work unit of `rank` when band_mode(): the RANKS are block-partitioned over the frames (frame f is rendered by the
+    ranks of frame_block(world, f, n_frames): world // n_frames of them, or one more), and the frame's H rows are block-partitioned
+    over those ranks.  Returns (frame, row_lo, row_hi); a band of a [H, W, ...] frame is contiguous memory, so the end gather
+    receives bands in place exactly as it receives frame blocks."""
+    assert band_mode(n_frames, world)
+    for f in range(n_frames):
+        lo, hi = frame_block(world, f, n_frames)
+        if lo <= rank < hi:
+            r0, r1 = frame_block(H, rank - lo, hi - lo)
+            return f, r0, r1
+    raise AssertionError("every rank belongs to a frame")
+
+
+def gather_bands_direct(tensors, n_frames, H, dst=0):
+    """End gather of the row-band fallback: `tensors` = this rank's band of each output, shaped [rows, ...]; rank `dst` allocates
+    the final [n_frames, H, ...] tensors and receives every peer's band straight into its view — the same single grouped
+    send / receive batch as gather_frames_direct (one ncclGroup over xGMI on the nccl backend).  Returns the list of full tensors
+    on rank dst, a list of None elsewhere."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    units = [band_unit(n_frames, H, r, world) for r in range(world)]
+    ops, outs = [], [None] * len(tensors)
+    if rank == dst:
+        outs = [t.new_empty((n_frames, H) + tuple(t.shape[1:])) for t in tensors]
+        for r, (f, r0, r1) in enumerate(units):
+            if r == dst:
+                for t, o in zip(tensors, outs):
+                    o[f, r0:r1].copy_(t)
+            elif r1 > r0:
+                ops += [dist.P2POp(dist.irecv, o[f, r0:r1], r) for o in outs]
+    elif tensors[0].shape[0] > 0:
+        ops += [dist.P2POp(dist.isend, t.contiguous(), dst) for t in tensors]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return outs
+
+
 def gather_frames(local, n_frames, dst=0):
     """Gather per-rank frame stacks (tensor [n_local, ...]) to rank `dst` in global frame order.
 

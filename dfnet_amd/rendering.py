@@ -378,6 +378,8 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
     img_ids = torch.as_tensor(img_ids, dtype=torch.float32, device=dev)
     N = render_poses.shape[0]
     rank, world = ddist.rank_world()
+    if ddist.active() and ddist.band_mode(N, world):
+        return _render_path_bands(render_poses, img_ids, H, W, focal, chunk, render_kwargs, gt_imgs, savedir, single_gt_img)
     lo, hi = ddist.frame_block(N, rank, world)
     n_loc = hi - lo
     # rank 0 renders straight into its block of the final [N, ...] tensors: the end gather receives the other blocks in place
@@ -465,6 +467,76 @@ def render_path(args, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, sav
     render_path.last_timing = {"render_s": t_render, "post_launch_s": t_post, "gather_s": t_gather, "png_tail_s": t_tail, "frames": N, "world": world,
                                "gathered_bytes": n_gathered}
     return rgbs, disps
+
+
+def render_band(H, W, focal, chunk, c2w, img_idx, r0, r1, render_kwargs):
+    """Rows [r0, r1) of the frame at pose c2w: the band's rays out of get_rays (models/ray_utils.py:5-15) through render(rays=...).
+    Rays are independent, so a band is bit-identical to the same rows of the full-frame render (tests/test_gpu_dist.py)."""
+    rays_o, rays_d = get_rays(H, W, focal, c2w)
+    rgb, disp, _, _ = render(H, W, focal, chunk=chunk, rays=(rays_o[r0:r1].contiguous(), rays_d[r0:r1].contiguous()), img_idx=img_idx,
+                             **render_kwargs)
+    return rgb, disp
+
+
+def _render_path_bands(render_poses, img_ids, H, W, focal, chunk, render_kwargs, gt_imgs, savedir, single_gt_img):
+    """SURVEY 8(e)'s small-batch fallback of render_path — fewer frames than ranks (the single validation frames of run_nerf.py:200,228;
+    configs[0]'s four frames on eight GPUs): every rank renders ONE row band of one frame (dist.band_unit), the bands are gathered in
+    place into rank 0's final [N, H, ...] tensors (dist.gather_bands_direct: the same single grouped send / receive batch), and the
+    per-FRAME back-end — disp / max(disp) over the whole frame, the PSNR's mean squared error, to8b, the PNGs: rendering.py:423-452 —
+    runs on rank 0 on the assembled frames (N < world <= 8 of them), so every number is the one a single GPU produces."""
+    from . import engine as eng
+    dev = render_poses.device
+    N = render_poses.shape[0]
+    rank, world = ddist.rank_world()
+    f, r0, r1 = ddist.band_unit(N, H, rank, world)
+    t0 = time.time()
+    if r1 > r0:
+        rgb, disp = render_band(H, W, focal, chunk, render_poses[f][:3, :4], img_ids[f], r0, r1, render_kwargs)
+    else:   # more ranks on this frame than rows
+        rgb, disp = torch.empty(0, W, 3, device=dev), torch.empty(0, W, device=dev)
+    if rank == 0:
+        print(torch.Size([H, W, 3]), torch.Size([H, W]))
+    torch.cuda.synchronize() if dev.type == "cuda" else None
+    t_render = time.time() - t0
+    eng_h = _engine_of(render_kwargs)
+    my_flags = eng_h.range_flags()
+    tg = time.time()
+    all_rgb, all_disp = ddist.gather_bands_direct([rgb, disp], N, H)      # the path's ONE data collective
+    all_flags = ddist.all_gather_flags(my_flags, dev)
+    t_gather = time.time() - tg
+    bad = 0
+    for fl in all_flags:
+        bad |= int(fl)
+    if bad:   # the same message on every rank, after the collective
+        eng_h.raise_range(bad, where="render_path (row bands): ranks " + ", ".join(f"{r} (flags {fl:#x})" for r, fl in enumerate(all_flags) if fl))
+    if rank != 0:
+        return None, None
+    tp = time.time()
+    mse = None
+    if savedir is not None or gt_imgs is not None:
+        gt = None
+        if gt_imgs is not None:
+            g = np.asarray(gt_imgs)
+            gt = torch.as_tensor(g if single_gt_img else g[:N], dtype=torch.float32).to(dev)
+        post = eng.frame_post(all_rgb, all_disp, gt, want_gt8=savedir is not None)
+        mse = post["mse"] if gt is not None else None
+        if savedir is not None:
+            host = [None if t is None else t.cpu() for t in (post["rgb8"], post["disp8"], post["gt8"])]
+
+            class _Done:
+                def synchronize(self):
+                    pass
+            _write_frames(_Done(), host, savedir, 0)
+    t_post = time.time() - tp
+    print(f"rendered {N} frames of {W}x{H} as row bands on {world} GPU(s) in {t_render:.2f} s (gather {t_gather:.2f} s, frame back-end on "
+          f"rank 0 {t_post:.2f} s)")
+    if mse is not None:
+        print("Mean PSNR of this run is:", np.mean(-10. * np.log10(mse.cpu().numpy()), 0))
+    per_frame = (H * W * 4) * 4
+    own = r1 - r0
+    render_path.last_timing = {"render_s": t_render, "post_launch_s": t_post, "gather_s": t_gather, "png_tail_s": 0.0, "frames": N, "world": world,
+                               "gathered_bytes": N * per_frame - own * W * 16, "row_bands": True}
+    return all_rgb.cpu().numpy(), all_disp.cpu().numpy()
 
 
 def _drain(dl):

@@ -66,3 +66,31 @@ def test_bench_under_torchrun_with_rccl_gather(tmp_path):
     assert len(ranks["render_s"]["per_rank"]) == 1 and ranks["render_s"]["max"] > 0 and ranks["gather_s"]["max"] >= 0
     assert ranks["gathered_bytes"] == 0   # one rank: every frame is the root's own
     assert ranks["samples_per_rank"][0] > 0 and 100 < ranks["power_w"]["mean"] < 1600 and 300 < ranks["sclk_mhz"]["mean"] < 2600, ranks
+
+
+def test_row_bands_equal_the_full_frame_bit_for_bit():
+    """SURVEY 8(e)'s small-batch fallback on the device: what each rank of a world-3 / world-8 group would render for 1, 2 and 4 frames
+    (dist.band_unit -> rendering.render_band), assembled the way gather_bands_direct places it, against render(c2w=...) of the whole
+    frame on one rank: rgb and disparity bit-identical (rays are independent), so disp / max(disp) and the PSNR computed on the
+    assembled frame are the single-GPU numbers.  The exchange itself is tests/test_host_logic.py::test_row_band_gather_gloo."""
+    import torch
+    from dfnet_amd import dist as ddist, engine as eng, nerfw, rendering, synthetic as syn
+    dev = torch.device("cuda:0")
+    E = eng.NerfHEngine().load_numpy(*syn.nerfh_weights(0))
+    kw = dict(network_query_fn=nerfw.HipQuery(E, 65536), perturb=False, N_importance=32, N_samples=16, use_viewdirs=True,
+              white_bkgd=False, raw_noise_std=0., test_time=True, ndc=False, lindisp=False, near=0., far=2.5)
+    H, W, focal = 22, 32, 29.0
+    hist = torch.from_numpy(syn.HIST_IDX).float().to(dev)
+    for world, n_frames in ((3, 1), (3, 2), (8, 1), (8, 4), (8, 3)):
+        poses = torch.stack([torch.from_numpy(syn.orbit_pose(k, 8)) for k in range(n_frames)]).to(dev)
+        full = [rendering.render(H, W, focal, c2w=poses[k][:3, :4], img_idx=hist, **kw) for k in range(n_frames)]
+        rgb = torch.full((n_frames, H, W, 3), float("nan"), device=dev)
+        disp = torch.full((n_frames, H, W), float("nan"), device=dev)
+        for rank in range(world):
+            f, r0, r1 = ddist.band_unit(n_frames, H, rank, world)
+            b_rgb, b_disp = rendering.render_band(H, W, focal, 32768, poses[f][:3, :4], hist, r0, r1, kw)
+            assert b_rgb.shape == (r1 - r0, W, 3) and b_disp.shape == (r1 - r0, W)
+            rgb[f, r0:r1], disp[f, r0:r1] = b_rgb, b_disp
+        for k in range(n_frames):
+            assert torch.equal(rgb[k], full[k][0]) and torch.equal(disp[k], full[k][1]), (world, n_frames, k)
+    E.check_range()

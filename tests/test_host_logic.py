@@ -100,6 +100,67 @@ def test_frame_block_partition():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_band_units_cover_every_row_once():
+    """SURVEY 8(e)'s small-batch fallback (fewer frames than ranks): ranks are block-partitioned over the frames, a frame's rows over
+    its ranks — every row of every frame belongs to exactly one rank, no rank idles while H >= its frame's rank count, band heights
+    within a frame differ by at most one row."""
+    for n, w, H in ((1, 8, 480), (4, 8, 120), (3, 8, 480), (1, 2, 7), (2, 3, 5), (1, 3, 2), (7, 8, 480)):
+        assert ddist.band_mode(n, w)
+        seen = np.zeros((n, H), int)
+        per_frame = {}
+        for r in range(w):
+            f, r0, r1 = ddist.band_unit(n, H, r, w)
+            seen[f, r0:r1] += 1
+            per_frame.setdefault(f, []).append(r1 - r0)
+        assert (seen == 1).all(), (n, w, H)
+        assert sorted(per_frame) == list(range(n))
+        for f, hs in per_frame.items():
+            assert len(hs) in (w // n, w // n + 1) and max(hs) - min(hs) <= 1
+    assert not ddist.band_mode(8, 8) and not ddist.band_mode(9, 8) and not ddist.band_mode(0, 8) and not ddist.band_mode(1, 1)
+
+
+_BAND_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from dfnet_amd import dist as ddist
+rank, world, _ = ddist.init_from_env(backend="gloo")
+n_frames, H, W = int(sys.argv[2]), int(sys.argv[3]), 5
+assert ddist.active() and ddist.band_mode(n_frames, world)
+def frame(f):      # what a single rank would render: every element a function of (frame, row, column, channel)
+    y, x, c = torch.meshgrid(torch.arange(H), torch.arange(W), torch.arange(3), indexing="ij")
+    return (1000. * f + 10. * y + x + 0.25 * c).float()
+f, r0, r1 = ddist.band_unit(n_frames, H, rank, world)
+rgb = frame(f)[r0:r1].contiguous()
+disp = frame(f)[r0:r1, :, 0].contiguous() + 0.5
+full_rgb, full_disp = ddist.gather_bands_direct([rgb, disp], n_frames, H)
+flags = ddist.all_gather_flags(rank, torch.device("cpu"))
+assert flags == list(range(world))
+if rank == 0:
+    want = torch.stack([frame(k) for k in range(n_frames)])
+    assert full_rgb.shape == (n_frames, H, W, 3) and torch.equal(full_rgb, want)            # bit-identical to the one-rank result
+    assert full_disp.shape == (n_frames, H, W) and torch.equal(full_disp, want[..., 0] + 0.5)
+    print("BANDS_OK", n_frames, H)
+else:
+    assert full_rgb is None and full_disp is None
+ddist.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,n_frames,H", [(3, 1, 11), (3, 2, 11), (2, 1, 4), (3, 1, 2)])
+def test_row_band_gather_gloo(tmp_path, world, n_frames, H):
+    """render_path's row-band fallback over gloo: world 3 with 1 and 2 frames (3 bands of one frame; 2 + 1 ranks on two frames),
+    world 2 with one frame, and more ranks than rows (an empty band) — rank 0's assembled tensors equal the single-rank frames bit
+    for bit, bands received in place, the flag all-gather behind it."""
+    script = tmp_path / "b.py"
+    script.write_text(_BAND_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29670 + 4 * world + n_frames + H % 3), str(script), ROOT,
+                        str(n_frames), str(H)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"BANDS_OK {n_frames} {H}" in r.stdout
+
+
 _GLOO_WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, sys.argv[1])
