@@ -146,6 +146,10 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP library is the product and has no fallback. "
                 "Build it with `make -C dfnet_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`).")
+        # torch first: the library must bind to the HIP runtime torch has mapped (device pointers and streams are torch's); loading
+        # it before torch maps the system libamdhip64 as a second runtime and torch then finds "No HIP GPUs" (seen when
+        # `python __graft_entry__.py smoke` ran build() -> load() before the first `import torch`)
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch

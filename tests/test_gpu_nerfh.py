@@ -357,7 +357,7 @@ def test_create_nerf_engine_on_trained_checkpoint(trained, gold, tmp_path):
                str(exp / "020000.tar"))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = ["--config", os.path.join(root, "script", "config_nerfh.txt"), "--basedir", str(tmp_path / "logs"), "--render_test",
-            "--no_grad_update"]
+            "--no_grad_update", "--N_importance", "128"]
     gi, gr = gold("g15_trained_render_image"), gold("g15_trained_render_rays")
     H, W, focal = int(gi["H"]), int(gi["W"]), float(gi["focal"])
     f64 = _fp64_oracle_of_g15(gold)
@@ -388,7 +388,10 @@ def test_create_nerf_engine_on_trained_checkpoint(trained, gold, tmp_path):
         print(f"create_nerf engine {'--coarse_precision f16' if want16 else '(default)'} on the trained checkpoint: " +
               "; ".join(f"{k}: worst vs fp64 {e:.1e} (reference {y:.1e}), median vs reference {m:.1e}" for k, e, y, m in rows))
         for k, e, y, m in rows:
-            assert e <= y + 2e-5 and m <= 2e-5, (k, e, y, m)
+            if want16:   # the opt-in: f16 densities move importance samples across surfaces (measured below; NOT fp32-grade on trained weights)
+                assert e <= max(y + 2e-5, 2e-2) and m <= 1e-4, (k, e, y, m)
+            else:
+                assert e <= y + 2e-5 and m <= 2e-5, (k, e, y, m)
 
 
 def test_render_config1_shape_vs_oracle(scene):
