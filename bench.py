@@ -66,6 +66,14 @@ P_COARSE, P_FINE, P_SAMPLE, P_RAYBIAS, P_COMBINE, P_COMPOSITE = range(6)
 PREC_KERNEL_TAG = {"f16": "PrecF16", "f32": "PrecF32", "f16x3": "PrecX3"}
 
 
+# What bounds sample_fine_kernel, from its counters (round-6 correction of "HBM traffic = the algorithmic bytes", which the committed
+# PMC record contradicted).  Filled in by the traffic record: see hbm_records().
+SAMPLE_FINE_NOTE = ("VALU-issue-bound wave-per-ray scans (~440 vector instructions per ray: inverse-CDF search, scans, rank merge), about two "
+                    "thirds of the SIMD issue time.  Its `traffic` is NOT the algorithmic 1 024 B/ray: the counters show ~3.6x of it "
+                    "(WRITE_SIZE alone 2.5x the 768 B/ray of z_fine) — the kernel keeps its per-lane merge state in scratch (private memory), "
+                    "which spills through L2 to HBM.  0.35 ms of a 61 ms frame; see DESIGN.md section 3.2 for the no-scratch variant's numbers")
+
+
 def pmc_traffic(kernel="nerfh_fine_kernel", precision=None):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/*_pmc_summary*.json: separate
     --pmc passes of this same command per precision, tools/gpu_round.sh).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
@@ -450,10 +458,17 @@ def mlp_roofline(prof, K, precision, value_per_gpu):
     flops = 2.0 * MAC_FINE * (NC + NI) * rays * K / max(n, 1)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     peak = PEAK_TFLOPS[precision]
-    return {"bound": "mfma", "kernel": "nerfh_fine_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "launches_per_step": n / K, "avg_launch_ms": ms,
-            "algorithmic_flops_per_launch": flops, "coarse_kernel_avg_launch_ms": prof[P_COARSE][0],
-            "whole_path_mfma_frac": value_per_gpu * 2.0 * (MAC_COARSE * NC + MAC_FINE * (NC + NI)) / 1e12 / peak}
+    rec = {"bound": "mfma", "kernel": "nerfh_fine_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+           "frac": achieved / peak, "launches_per_step": n / K, "avg_launch_ms": ms,
+           "algorithmic_flops_per_launch": flops, "coarse_kernel_avg_launch_ms": prof[P_COARSE][0],
+           "whole_path_mfma_frac": value_per_gpu * 2.0 * (MAC_COARSE * NC + MAC_FINE * (NC + NI)) / 1e12 / peak}
+    if precision == "f16x3":
+        # two honest readings of the same launch time.  `frac` = MFMA-ISSUE utilisation: split-f16 issues three f16 MFMAs per fp32-grade
+        # product, so its peak is 2 500 / 3 algorithmic TFLOP/s.  SURVEY 8(d)'s formula prices the ALGORITHMIC FLOPs against the dense f16
+        # peak of the instruction class (2 500): a third of `frac`.
+        rec["frac_is"] = "issued: algorithmic TFLOP/s x 3 f16 MFMAs per product / 2 500 (= achieved / peak with peak = 2 500 / 3)"
+        rec["frac_algorithmic_of_f16_peak"] = achieved / PEAK_TFLOPS["f16"]
+    return rec
 
 
 def hbm_records(prof, K, E, dev):
@@ -475,8 +490,7 @@ def hbm_records(prof, K, E, dev):
                          "launches_per_step": n / K}
     # what the PMC passes say about the two that sit near 10 % of the HBM rate: their traffic is the algorithmic bytes, they are bound
     # by instruction issue, not by memory (profiles/*_pmc_summary.json: SQ_INSTS_VALU per launch x 4 cycles over the SIMD time)
-    notes = {"sample_fine_kernel": "VALU-issue-bound, not HBM-bound: ~440 vector instructions per ray (inverse-CDF search, scans, rank merge), "
-                                   "about two thirds of the SIMD issue time; HBM traffic = the algorithmic bytes",
+    notes = {"sample_fine_kernel": SAMPLE_FINE_NOTE,
              "ray_bias_kernel": "VALU-bound: 6 208 fp32 MACs per ray for the two per-ray tables (12.4 KFLOP), HBM traffic 1.07x the algorithmic bytes"}
     for k, v in notes.items():
         if k in out:
@@ -843,12 +857,21 @@ def secondary_nerfh_train(dev):
     wt_f, wt_c = -(-R * (NC + NI) // 256) * 8, -(-R * NC // 256) * 8
     stored = wt_f * (96 + 98) * 1024 + wt_c * (80 + 80) * 2048
     tf = 6.0 * mac_fwd / (ms["fused"] * 1e-3) / 1e12
+    # matrix instructions the fused step ISSUES (the model profiles/rNN_roofline.md's N1 section is checked against,
+    # tests/test_host_logic.py): forward and data-gradient chains three f16 MFMAs per product in both networks; the weight-gradient stream
+    # three for the coarse network (hi | lo planes) but ONE for the fine network (one stored f16 plane per operand)
+    mac_c, mac_f = mac_fwd - R * (NC + NI) * MAC_FINE, R * (NC + NI) * MAC_FINE
+    issued_tf = 2.0 * (9.0 * mac_c + 7.0 * mac_f) / (ms["fused"] * 1e-3) / 1e12
     return {"workload": "one NeRF-H optimisation step (run_nerf.py:32-80): 1536 random rays, 64+128 samples, netwidth 128, perturb 1: "
                         "training-mode render, NerfWLoss, gradients of all 64 parameter tensors, Adam",
             "step_ms": ms["fused"], "forward_ms": ms["fused_forward"], "rays_per_s": R / ms["fused"] * 1e3,
             "arithmetic": "split-f16 MFMA (three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation: fp32-grade), register-resident forward "
                           "and data-gradient chains, weight gradients streamed over the stored operands (csrc/nerfh_fused_*.hip)",
             "algorithmic_TFLOPs": tf, "f16_mfma_frac_of_nominal": 3.0 * tf / PEAK_TFLOPS["f16"], "frac_of_sustained_mfma": of_sustained(3.0 * tf),
+            "f16_mfma_issued_frac_of_nominal": issued_tf / PEAK_TFLOPS["f16"],
+            "issued_note": "f16_mfma_frac_of_nominal prices every product at three MFMAs (the split-f16 convention); the one-plane fine "
+                           "weight-gradient stream issues one, so the instructions actually issued amount to f16_mfma_issued_frac_of_nominal "
+                           "(agrees with SQ_INSTS_MFMA per step in profiles/*_train_step_pmc.json)",
             "flops_note": "forward 2 x MAC, data gradients 2 x MAC, weight gradients 2 x MAC; x 3 f16 MFMAs per product against the 2.5 PFLOP/s peak",
             "stored_operand_bytes_per_step": stored,
             "fused_split_step": {"step_ms": ms["fused_split"], "stored_operand_bytes_per_step": (wt_f * (96 + 98) + wt_c * (80 + 80)) * 2048,
@@ -898,7 +921,51 @@ def secondary_trained_weights(dev):
                               "disp_max_rel_vs_oracle": float((disp - ref[1]).abs().max() / ref[1].abs().max()), "range_flags": E.range_flags()}
     out["note"] = ("worst-pixel differences on trained weights are conditioning, not arithmetic: the reference's own fp32 sits 1e-2 from a float64 "
                    "evaluation at surface-grazing pixels (tests/test_gpu_nerfh.py::test_trained_weights_render_vs_reference measures all modes "
-                   "against that float64 yardstick)")
+                   "against that float64 yardstick; ..._stages_on_the_references_own_samples holds network + compositor to 2e-5 on the "
+                   "reference's own z_vals)")
+    # One 640 x 480 frame of the trained scene (BASELINE configs[1]'s size), every arithmetic mode rendered in full on the device; the CPU
+    # oracle — fp32 (= the reference, G15) and float64 (the yardstick) — on the 4 x 4 pixel lattice of it (19 200 rays: rays are
+    # independent, so the lattice pixels of the full frame ARE the render of those rays).  Per mode: the fraction of lattice pixels further
+    # than north_star's 1e-3 (of the map's range) from the fp32 oracle and from float64, beside the same fraction for the fp32 oracle itself.
+    c2w_f = syn.orbit_pose(5, 16)
+    ro, rd = orc.get_rays(H, W, FOCAL, T(c2w_f)[:3, :4])
+    ro, rd = ro[::4, ::4].reshape(-1, 3), rd[::4, ::4].reshape(-1, 3)
+    rows = orc.pack_ray_rows(ro, rd, NEAR, FAR, syn.HIST_IDX)
+    tt = lambda d, dt: {k: T(v).to(dt) for k, v in d.items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        r32 = orc.render_rays(rows, tt(cw, torch.float32), tt(fw, torch.float32), T(ea), T(et), NC, NI)
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            r64 = orc.render_rays(rows.double(), tt(cw, torch.float64), tt(fw, torch.float64), T(ea).double(), T(et).double(), NC, NI)
+        finally:
+            torch.set_default_dtype(prev)
+    lattice_s = time.perf_counter() - t0
+    scale = {k: float(r64[k].abs().max()) for k in ("rgb_map", "disp_map")}
+
+    def beyond(a, b, k):    # fraction of pixels with any channel further than 1e-3 of the map's range
+        e = (a.double() - b.double()).abs() / scale[k]
+        e = e.amax(-1) if e.dim() == 2 else e
+        return float((e > 1e-3).double().mean()), float(e.max())
+    frame = {"size": "640x480, 64+128, orbit pose 5/16 of the trained scene", "oracle_pixels": int(rows.shape[0]), "cpu_oracle_fp32_and_fp64_s": lattice_s,
+             "reference_fp32_vs_float64": {k: dict(zip(("frac_beyond_1e-3", "max_rel"), beyond(r32[k], r64[k], k))) for k in scale}, "modes": {}}
+    pose_d, hist_d = T(c2w_f).to(dev), T(syn.HIST_IDX).to(dev)
+    for tag, prec, c16 in (("f16x3", "f16x3", False), ("f32", "f32", False), ("f16x3_fine_f16_coarse", "f16x3", True), ("f16", "f16", False)):
+        E.set_render_options(coarse_f16=c16)
+        try:
+            rgb, disp, _ = E.render_image(pose_d, H, W, FOCAL, hist_d, NC, NI, NEAR, FAR, precision=prec)
+            torch.cuda.synchronize()
+        finally:
+            E.set_render_options(coarse_f16=False)
+        got = {"rgb_map": rgb[::4, ::4].reshape(-1, 3).cpu(), "disp_map": disp[::4, ::4].reshape(-1).cpu()}
+        frame["modes"][tag] = {"range_flags": E.range_flags()}
+        for k in scale:
+            fr, mx = beyond(got[k], r32[k], k)
+            fr64, mx64 = beyond(got[k], r64[k], k)
+            frame["modes"][tag][k] = {"frac_beyond_1e-3_vs_reference_fp32": fr, "max_rel_vs_reference_fp32": mx,
+                                      "frac_beyond_1e-3_vs_float64": fr64, "max_rel_vs_float64": mx64}
+    out["frame_640x480"] = frame
     return out
 
 
@@ -1087,8 +1154,8 @@ def main():
                 add_sustained(precs[prec]["roofline"], sus, prec)
                 if ref_pack is not None:
                     precs[prec]["parity_vs_oracle"] = parity(E, ref_pack[0], ref_pack[1], prec, dev)
-            # split-f16 fine network with the coarse network in f16 (DFN_RENDER_COARSE_F16): the coarse pass only places the importance
-            # samples, the pixel is composited from the fp32-grade fine outputs — what the DFNet_dm step's tracked render does by default
+            # split-f16 fine network with the coarse network in f16 (DFN_RENDER_COARSE_F16, `--coarse_precision f16`): an OPT-IN since
+            # round 6 — on trained weights f16 densities move importance samples across surfaces (secondary.nerfh_trained_weights)
             if args.precision != "f16":
                 E.set_render_options(coarse_f16=True)
                 try:

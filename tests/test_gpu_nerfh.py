@@ -274,7 +274,7 @@ def _trained_weights_render_vs_reference(E, gold, prec, tol, coarse16):
     f64 = _fp64_oracle_of_g15(gold)
     mse = float(((rgb_i.cpu() - T(gi["rgb"])) ** 2).mean())
     rows = []
-    ok = True
+    ok, narrow = True, prec == "f16" or coarse16
     for k in got:
         scale = float(np.abs(ref[k]).max())
         yard = float((T(ref[k]).double() - f64[k]).abs().max()) / scale           # the reference's own fp32 vs float64
@@ -284,15 +284,19 @@ def _trained_weights_render_vs_reference(E, gold, prec, tol, coarse16):
         # plain f16 (not the default, outside north_star's 1e-3 on such weights and stated so): rounding the activations to 11 bits
         # moves fine samples across surfaces at a few grazing pixels — measured 1.3e-2 on one disparity of the 12 x 16 frame, 1e-3 on
         # the ray batch, typical pixel 3e-5 — bounded here at 2e-2 worst / 1e-4 typical
-        worst_ok = err64 <= (2e-2 if prec == "f16" else yard + tol)
-        ok = ok and worst_ok and med <= (1e-4 if prec == "f16" else tol)
+        # the f16 COARSE network under a split-f16 fine network (`--coarse_precision f16`, an opt-in since round 6: it was create_nerf's
+        # default until this test ran it on trained weights): f16 densities move importance samples — measured 1.0e-3 (ray batch) and
+        # 1.3e-2 (frame) on the disparity where the reference itself sits 1.6e-5 / 1.8e-3 from float64: NOT fp32-grade, same bounds as f16
+        narrow = prec == "f16" or coarse16
+        worst_ok = err64 <= (max(2e-2, yard + tol) if narrow else yard + tol)
+        ok = ok and worst_ok and med <= (1e-4 if narrow else tol)
     print(f"trained weights, {prec}{' + coarse f16' if coarse16 else ''}: " + "; ".join(rows) + f"; PSNR vs the reference {-10 * np.log10(max(mse, 1e-30)):.1f} dB, range flags {flags}")
     assert relmax(raw[..., [3, 7]], g["raw"][..., [3, 7]]) < 0.2    # per-sample outputs: sanity only (a sample's position decides its density)
     if prec == "f32":
         assert flags == 0
     if flags == 0:
         assert ok, rows
-        assert -10 * np.log10(max(mse, 1e-30)) > (55 if prec == "f16" else 60)
+        assert -10 * np.log10(max(mse, 1e-30)) > (55 if narrow else 60)
     else:   # a guarded failure: loud, and only in a narrow mode
         assert prec != "f32"
 
@@ -334,7 +338,11 @@ def test_trained_weights_stages_on_the_references_own_samples(trained, gold, pre
     assert max(e_comp.values()) < 2e-5 and e_w < 2e-5           # fp32 stage kernels in every mode
     assert float(dz.median()) < 1e-6 and float(dz.max()) < (far - near) / (Nc - 2)   # a moved sample stays inside its coarse bin
     if flags == 0:
-        assert e_sig < tol and max(e_raw.values()) < tol and max(e_map.values()) < tol
+        # plain f16 on trained weights is OUTSIDE north_star's 1e-3 already at the arithmetic level (no sampler involved): measured on
+        # these samples coarse sigma 4.5e-4, raw 1.3e-3 (sigma) ... 1.5e-2 (beta), maps <= 1e-2 — bounded at 3e-2, stated in
+        # options.py / INTEGRATION.md; f16 is the fast opt-in, inside 1e-3 on random-init weights only
+        lim = 3e-2 if prec == "f16" else tol
+        assert e_sig < lim and max(e_raw.values()) < lim and max(e_map.values()) < lim
     else:
         assert prec != "f32"
 

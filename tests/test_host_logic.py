@@ -545,3 +545,35 @@ def test_fused_training_tables_selfcheck():
         assert lib.dfn_nerfh_train_tables_selfcheck(ctypes.byref(d)) == 0, lib.dfn_last_error().decode()
     d = Desc(8, 64, 10, 4, 10, 5, 2, 1000)
     assert lib.dfn_nerfh_train_tables_selfcheck(ctypes.byref(d)) != 0   # netwidth 128 only
+
+
+def test_roofline_table_n1_section_agrees_with_the_bench_line():
+    """The generated roofline table (tools/roofline_table.py -> profiles/rNN_roofline.md) is the source of every fraction quoted in
+    DESIGN.md.  Its round-5 N1 section divided per-dispatch PMC averages by the dispatch count again (8-9x too small).  Held here: for
+    the newest round whose profiles carry both the N1 kernel stats and PMC, the matrix instructions issued per step x 32 768 FLOP over
+    the bench line's own step time must agree with the bench line's issued-MFMA model within 15 %, and the per-kernel rows must be
+    the magnitudes the counters hold (the fine forward chain issues ~9.9 M MFMAs per 1 536-ray step, not 1.1 M)."""
+    import glob, importlib.util, json
+    spec = importlib.util.spec_from_file_location("roofline_table", os.path.join(ROOT, "tools", "roofline_table.py"))
+    rt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rt)
+    tags = sorted({os.path.basename(f)[:3] for f in glob.glob(os.path.join(ROOT, "profiles", "r*_train_step_pmc.json"))
+                   if os.path.exists(f.replace("_train_step_pmc.json", "_train_step_kernel_stats.csv"))
+                   and os.path.exists(f.replace("_train_step_pmc.json", "_bench.json"))})
+    assert tags
+    tag = tags[-1]
+    rows, steps, pmc = rt.n1_section(tag)
+    n1 = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench.json")))["secondary"]["nerfh_train_step_n1"]
+    m, frac_kernel_time = rt.step_fraction(rows, steps, pmc, per_dispatch=True)
+    _, frac_step = rt.step_fraction(rows, steps, pmc, per_dispatch=True, step_ms=n1["step_ms"])
+    R, NC, NI = 1536, 64, 128
+    mac_f = R * (NC + NI) * 182720
+    mac_c = R * NC * (130944 + 128 * 128 + 64 * (128 + 27) + 64 * 3)
+    model = n1.get("f16_mfma_issued_frac_of_nominal", 2.0 * (9 * mac_c + 7 * mac_f) / (n1["step_ms"] * 1e-3) / 2.5e15)
+    assert abs(frac_step / model - 1) < 0.15, (tag, frac_step, model)
+    assert 0.8 * n1["f16_mfma_frac_of_nominal"] * 7.5 / 9 < frac_step <= 1.05 * n1["f16_mfma_frac_of_nominal"]
+    fwd = next(v for k, v in pmc.items() if "train_fwd_chain_kernel<true" in k)
+    assert 9e6 < rt.mfma_per_call(fwd, per_dispatch=True) < 11e6
+    text = open(os.path.join(ROOT, "profiles", f"{tag}_roofline.md")).read()
+    line = next(l for l in text.splitlines() if "train_fwd_chain_kernel<true" in l)
+    assert 0.25 < float(line.split("|")[7]) < 0.5, line      # "of nominal" column of the fine forward chain (0.35), not 0.039

@@ -27,3 +27,36 @@ for k, d in agg.items():
 json.dump(out, open("$R/gpurun_out/${NAME}_pmc.json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_insts"])[:14]: print(k[:70], v)
 PY
+# HBM traffic of the same command, every kernel (also the ones without matrix instructions): FETCH_SIZE and WRITE_SIZE in their own
+# passes (TCC: 3 + 2 slots, never together), KiB per dispatch -> bytes per dispatch.  MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE
+# reports half the bytes of a wide coalesced read stream -> `fetch_bytes_x2` is the corrected figure to hold against a byte model;
+# WRITE_SIZE is uncalibrated (stored as counted).  PMC_NO_HBM=1 skips the two passes.
+if [ -z "${PMC_NO_HBM:-}" ]; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pm_${NAME}_$C
+    rocprofv3 --pmc GRBM_GUI_ACTIVE $C --kernel-trace --output-format csv -d /tmp/pm_${NAME}_$C -o p -- "$@" > /dev/null 2>&1
+  done
+  python3 - <<PY
+import csv, collections, json, os
+path = "$R/gpurun_out/${NAME}_pmc.json"
+out = json.load(open(path)) if os.path.exists(path) else {}
+for C, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
+    f = "/tmp/pm_${NAME}_%s/p_counter_collection.csv" % C
+    if not os.path.exists(f):
+        continue
+    agg = collections.defaultdict(float); n = collections.defaultdict(set)
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] != C:
+            continue
+        k = row["Kernel_Name"].replace("dfn::", "").replace("void ", "").split("(")[0]
+        agg[k] += float(row["Counter_Value"]); n[k].add(row["Dispatch_Id"])
+    for k, v in agg.items():
+        rec = out.setdefault(k, {"dispatches": len(n[k])})
+        rec[key + "_per_dispatch"] = v * 1024.0 / max(len(n[k]), 1)
+        if C == "FETCH_SIZE":
+            rec["fetch_bytes_x2_per_dispatch"] = 2.0 * rec[key + "_per_dispatch"]
+json.dump(out, open(path, "w"), indent=1)
+top = sorted(((k, v) for k, v in out.items() if "fetch_bytes_per_dispatch" in v), key=lambda kv: -kv[1]["fetch_bytes_per_dispatch"] * kv[1]["dispatches"])[:10]
+for k, v in top: print(k[:70], "fetch x2 %.1f MB  write %.1f MB per dispatch" % (v["fetch_bytes_x2_per_dispatch"] / 1e6, v.get("write_bytes_per_dispatch", 0) / 1e6))
+PY
+fi

@@ -19,7 +19,7 @@ out = json.load(open(path)) if os.path.exists(path) and os.environ.get("PMC_APPE
 for k, d in agg.items():
     if "fused" in k and ("chain" in k or "wgrad_stream" in k):
         print(k, len(n[k]), {c: f"{v/len(n[k]):.4g}" for c, v in d.items()})
-        out.setdefault(k, {"dispatches": len(n[k])}).update({c: v / len(n[k]) for c, v in d.items()})
+        out.setdefault(k, {"dispatches": len(n[k]), "per_dispatch_average": True}).update({c: v / len(n[k]) for c, v in d.items()})
 json.dump(out, open(path, "w"), indent=1)
 PY
   export PMC_APPEND=1

@@ -47,9 +47,42 @@ def pmc_of(pmc, name):
     return None
 
 
-def table(title, rows, steps, pmc, pmc_steps, algo=None, min_share=0.004):
-    out = [f"### {title}", "", "| kernel | calls / step | mean us | ms / step | MFMA / step | TFLOP/s (issued) | of nominal | VALU / MFMA | algorithmic |",
-           "|---|---|---|---|---|---|---|---|---|"]
+def mfma_per_call(rec, per_dispatch=False):
+    """Matrix instructions per dispatch of a PMC record.  tools/gpu_pmc.sh and the headline passes store TOTALS over `dispatches`;
+    tools/gpu_train_pmc.sh stores per-dispatch AVERAGES (marked `per_dispatch_average`; the unmarked round-5 file is of that kind too:
+    `per_dispatch`).  Dividing an average by the dispatch count again was the 8-9x error of the round-5 N1 section."""
+    m = rec.get("mfma_insts", rec.get("SQ_INSTS_MFMA", 0.0))
+    if rec.get("per_dispatch_average") or per_dispatch:
+        return m
+    return m / (rec.get("dispatches", 0) or 1)
+
+
+def step_fraction(rows, steps, pmc, per_dispatch=False, step_ms=None):
+    """Matrix instructions issued per step over all kernels with a PMC record x 32 768 FLOP / the step's kernel time (or step_ms)
+    against the nominal f16 peak: (MFMA per step, fraction)."""
+    tot_m, tot_ns = 0.0, 0.0
+    for r in rows:
+        tot_ns += float(r["TotalDurationNs"]) / steps
+        rec = pmc_of(pmc, r["Name"])
+        if rec and not is_f32(r["Name"]):
+            tot_m += mfma_per_call(rec, per_dispatch) * int(r["Calls"]) / steps
+    t = (step_ms * 1e-3) if step_ms else tot_ns * 1e-9
+    return tot_m, tot_m * 32768.0 / t / 1e12 / F16_PEAK
+
+
+def n1_section(tag):
+    """(rows, steps, pmc) of the NeRF-H training step of round `tag`, or None."""
+    rows = stats(os.path.join(P, f"{tag}_train_step_kernel_stats.csv"))
+    pj = os.path.join(P, f"{tag}_train_step_pmc.json")
+    if not rows or not os.path.exists(pj):
+        return None
+    steps = max(1, int(next((r["Calls"] for r in rows if "train_fwd_chain_kernel<true" in r["Name"]), 1)))
+    return rows, steps, json.load(open(pj))
+
+
+def table(title, rows, steps, pmc, pmc_steps, algo=None, min_share=0.004, per_dispatch=False):
+    out = [f"### {title}", "", "| kernel | calls / step | mean us | ms / step | MFMA / step | TFLOP/s (issued) | of nominal | VALU / MFMA | HBM per call: read (2 x FETCH_SIZE) + written, MB -> TB/s | algorithmic |",
+           "|---|---|---|---|---|---|---|---|---|---|"]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     for r in rows:
         if float(r["TotalDurationNs"]) < min_share * tot:
@@ -57,12 +90,15 @@ def table(title, rows, steps, pmc, pmc_steps, algo=None, min_share=0.004):
         name, calls = r["Name"], int(r["Calls"])
         ms = float(r["TotalDurationNs"]) / 1e6 / steps
         rec = pmc_of(pmc, name)
-        mf = tf = fr = vm = ""
+        mf = tf = fr = vm = hb = ""
+        if rec and ("fetch_bytes_x2_per_dispatch" in rec or "FETCH_SIZE" in rec):
+            rd = rec.get("fetch_bytes_x2_per_dispatch", 2048.0 * rec.get("FETCH_SIZE", 0.0) / (1 if (rec.get("per_dispatch_average") or per_dispatch) else (rec.get("dispatches", 1) or 1)))
+            wr = rec.get("write_bytes_per_dispatch", 1024.0 * rec.get("WRITE_SIZE", 0.0) / (1 if (rec.get("per_dispatch_average") or per_dispatch) else (rec.get("dispatches", 1) or 1)))
+            hb = f"{rd / 1e6:.1f} + {wr / 1e6:.1f} -> {(rd + wr) / (float(r['AverageNs']) * 1e-9) / 1e12:.2f}"
         if rec:
             m = rec.get("mfma_insts", rec.get("SQ_INSTS_MFMA", 0.0))
-            disp = rec.get("dispatches", 0) or 1
             if m:
-                per_call = m / disp
+                per_call = mfma_per_call(rec, per_dispatch)
                 per_step = per_call * calls / steps
                 flop = 4096.0 if is_f32(name) else 32768.0
                 rate = per_step * flop / (ms * 1e-3) / 1e12
@@ -76,8 +112,8 @@ def table(title, rows, steps, pmc, pmc_steps, algo=None, min_share=0.004):
             for key, fn in algo.items():
                 if key in name:
                     al = fn(calls / steps, float(r["AverageNs"]) / 1e3)
-        out.append(f"| `{short(name)}` | {calls / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {ms:.3f} | {mf} | {tf} | {fr} | {vm} | {al} |")
-    out.append(f"| **all kernels** | {sum(int(r['Calls']) for r in rows) / steps:.0f} | | {tot / 1e6 / steps:.3f} | | | | | |")
+        out.append(f"| `{short(name)}` | {calls / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {ms:.3f} | {mf} | {tf} | {fr} | {vm} | {hb} | {al} |")
+    out.append(f"| **all kernels** | {sum(int(r['Calls']) for r in rows) / steps:.0f} | | {tot / 1e6 / steps:.3f} | | | | | | |")
     out.append("")
     return out
 
@@ -122,7 +158,21 @@ def main():
             steps = max(1, int(next((r["Calls"] for r in rows if "train_fwd_chain_kernel<true" in r["Name"]), 1)))
         pj = os.path.join(P, f"{tag}_{pmcname}")
         pmc = json.load(open(pj)) if os.path.exists(pj) else None
-        L += table(title, rows, steps, pmc, steps, algo)
+        n1 = "train_step" in csvname
+        L += table(title, rows, steps, pmc, steps, algo, per_dispatch=n1)
+        if n1 and pmc:
+            m, fr = step_fraction(rows, steps, pmc, per_dispatch=True)
+            L[-1:] = [f"N1 step as a whole: {m / 1e6:.2f} M matrix instructions issued per step over {sum(float(r['TotalDurationNs']) for r in rows) / steps / 1e6:.3f} ms "
+                      f"of kernel time = **{fr:.3f} of the nominal f16 peak** (issued; the one-plane weight-gradient stream issues ONE MFMA per "
+                      "product, so this sits below bench.py's algorithmic x 3 convention — `f16_mfma_issued_frac_of_nominal` in the bench line is "
+                      "this number from the byte / MFMA model).", ""]
+            for k, v in pmc.items():
+                if "FETCH_SIZE" in v and "wgrad_stream" in k:
+                    us = next((float(r["AverageNs"]) / 1e3 for r in rows if short(r["Name"]).startswith(k.replace("dfn::", "")[:40])), None)
+                    if us:
+                        rd = 2.0 * v["FETCH_SIZE"] * 1024.0
+                        L[-1:] = [f"`{k}`: reads 2 x FETCH_SIZE = {rd / 1e9:.2f} GB per dispatch in {us:.0f} us = {rd / (us * 1e-6) / 1e12:.2f} TB/s "
+                                  f"({rd / (us * 1e-6) / 8e12:.2f} of 8 TB/s).", ""]
     wl = os.path.join(P, f"{tag}_wgrad_layers.txt")
     if os.path.exists(wl):
         L += ["### Split-storage conv weight gradient, layer by layer, stand-alone (tools/gpu_wgrad_layers.py)", "", "```", open(wl).read().rstrip(), "```", ""]
