@@ -19,6 +19,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+
 #include "dfnet_kernels.h"
 #include "mfma_frag.h"
 
@@ -742,10 +745,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
   const int pr = p / TW, pc = p % TW;
   const int tiles_x = (a.W + TW - 1) / TW;
   int tile = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  const int S = a.ksplit > 1 ? a.ksplit : 1;   // K slices of a tile group (ConvArgs::ksplit)
+  int ks = 0, group = 0;
   if (a.xcd_groups > 0) {                 // XCD-aware 1-D grid, see conv_x3_kernel
+    // logical tile groups in contiguous runs per XCD (block id % 8, observed placement: speed only); the S slices of a group are
+    // consecutive blocks of ONE XCD, so the reducing slice reads same-XCD slabs
     const int n8 = (a.xcd_groups + 7) / 8;
-    const int L = (blockIdx.x & 7) * n8 + (blockIdx.x >> 3);
-    if (L >= a.xcd_groups) return;
+    const int q = blockIdx.x >> 3;
+    ks = q % S;
+    const int L = (blockIdx.x & 7) * n8 + q / S;
+    if (L >= a.xcd_groups || q / S >= n8) return;
+    group = L;
     const int tiles = tiles_x * ((a.H + TH - 1) / TH), per_cg = tiles * a.B;
     cg = L / per_cg;
     const int rem = L - cg * per_cg;
@@ -761,13 +771,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
     const f32x4* bq = reinterpret_cast<const f32x4*>(a.bias + ((cg * MB + mb) * 2 + h) * 16);  // pre-scaled bias
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 v = bq[q];
+      const f32x4 v = ks == 0 ? bq[q] : f32x4{0.f, 0.f, 0.f, 0.f};   // the bias enters once: with slice 0
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc[mb][0][4 * q + i] = v[i]; acc[mb][1][4 * q + i] = v[i]; }
     }
   }
   const int NHB = a.nblk_in * KCB;        // half-blocks
   const int n_slices = NHB * KS;
+  const int hb0 = ks * NHB / S, hb1 = (ks + 1) * NHB / S;   // this workgroup's half-blocks (all of them without a split)
   // Where each of this lane's DMA slots comes from (fixed for the tile): slot = piece * 64 + lane = (plane, h, pixel).
   const char* psrc[PPP];
   unsigned inside = 0;                    // bit i: slot i is a pixel of the image (its address advances with the half-block)
@@ -803,15 +814,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
   const float out_scale = a.dyn_scale ? a.out_scale * kConvActScale * a.dyn_scale[1] : a.out_scale;
   CONV_T_DECL;
 #pragma unroll
-  for (int i = 0; i < PPP; ++i) patch_piece(0, i);
+  for (int i = 0; i < PPP; ++i) patch_piece(hb0, i);
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) slice_piece(0, 0, i);
+  for (int i = 0; i < PPW; ++i) slice_piece(hb0 * KS, 0, i);
   if (RING == 3) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) slice_piece(1, 1, i);
+    for (int i = 0; i < PPW; ++i) slice_piece(hb0 * KS + 1, 1, i);
   }
-  int sl = 0, rb = 0;                       // rb: ring slot of sub-slice sl
-  for (int hb = 0; hb < NHB; ++hb) {
+  int sl = hb0 * KS, rb = 0;                // rb: ring slot of sub-slice sl
+  for (int hb = hb0; hb < hb1; ++hb) {
     const char* pb = patch + (hb & 1) * PBUF;
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky, ++sl) {
@@ -873,6 +884,62 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_x3s_kerne
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);      // the tail's repeated DMA pieces land before the buffers are reused by the epilogue
   CONV_T(3);
+  if (S > 1) {
+    // K split: the slab leaves by WRITE-THROUGH (sc1) 16-byte stores — no release fence, whose L2 write-back under 512 workgroups cost
+    // more than the split saved — every wave drains its stores, one lane draws the ticket; the last arriver acquires once (its L1) and
+    // sums the slabs in slice order, two slabs' loads in flight at a time, then goes on to the epilogue (cdna_hip_programming.md,
+    // Guideline 16, R1 in its counter form: correct wherever the slices ran).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int SLAB = MB * 2 * 16 * WAVES * 64;             // floats per slab: [mb][nb][q][thread][4]
+    constexpr int NQ = MB * 8;                                  // 16-byte pieces per thread and slab
+    {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.ks_slab + ((size_t)group * S + ks) * SLAB, 0, SLAB * 4, 0x00020000);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v{acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (((mb * 2 + nb) * 4 + q) * (WAVES * 64) + tid) * 16, 0, 16);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave
+    __syncthreads();
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(smem);   // the one LDS array (the staging buffers are dead)
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.ks_count + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag[0] != unsigned(S - 1)) return;                    // not the last slice of this tile group: done
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(a.ks_count + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the stream's next launch
+    }
+    __syncthreads();
+    const float* all = a.ks_slab + (size_t)group * S * SLAB + tid * 4;
+    auto add_slab = [&](const f32x4 (&u)[NQ], bool first) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float x = u[(mb * 2 + nb) * 4 + q][i];
+              acc[mb][nb][4 * q + i] = first ? x : acc[mb][nb][4 * q + i] + x;
+            }
+    };
+    for (int s2 = 0; s2 < S; s2 += 2) {
+      f32x4 u0[NQ], u1[NQ];
+      const int s3 = s2 + 1 < S ? s2 + 1 : s2;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) u0[j] = *reinterpret_cast<const f32x4*>(all + (size_t)s2 * SLAB + j * (WAVES * 64 * 4));
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) u1[j] = *reinterpret_cast<const f32x4*>(all + (size_t)s3 * SLAB + j * (WAVES * 64 * 4));
+      add_slab(u0, s2 == 0);
+      if (s2 + 1 < S) add_slab(u1, false);
+    }
+  }
   x3_epilogue<MB, TW>(a, acc, out_scale, smem, wave, lane, b, cg, y0, x0);
   CONV_T(4);
   CONV_T_FLUSH;
@@ -919,6 +986,31 @@ static hipError_t launch_conv_x3_t(const ConvArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// Workspace of the K-split launches of ONE stream (launches of a stream are ordered, so they share it; the side stream's concurrent
+// convolutions get their own): slabs + one arrival counter per tile group, zeroed when allocated and reset by each group's reducer.
+// Grown on demand (first launches only), released with the process.
+struct KSplitWs { float* slab = nullptr; unsigned* count = nullptr; size_t slab_bytes = 0; int counters = 0; };
+static KSplitWs* ksplit_workspace(hipStream_t stream, size_t slab_bytes, int counters) {
+  static std::mutex mu;
+  static std::map<hipStream_t, KSplitWs> table;
+  std::lock_guard<std::mutex> lock(mu);
+  KSplitWs& w = table[stream];
+  if (w.slab_bytes < slab_bytes) {
+    if (w.slab) { (void)hipStreamSynchronize(stream); (void)hipFree(w.slab); w.slab = nullptr; w.slab_bytes = 0; }
+    const size_t want = slab_bytes < (size_t(40) << 20) ? (size_t(40) << 20) : slab_bytes;
+    if (hipMalloc(&w.slab, want) != hipSuccess) return nullptr;
+    w.slab_bytes = want;
+  }
+  if (w.counters < counters) {
+    if (w.count) { (void)hipStreamSynchronize(stream); (void)hipFree(w.count); w.count = nullptr; w.counters = 0; }
+    const int want = counters < 4096 ? 4096 : counters;
+    if (hipMalloc(&w.count, size_t(want) * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(w.count, 0, size_t(want) * sizeof(unsigned)) != hipSuccess) return nullptr;
+    w.counters = want;
+  }
+  return &w;
+}
+
 template <int KS, int SB, int MB, int WAVES = 4, int TW = 32, bool SPREAD = true, int RING = 2>
 static hipError_t launch_conv_x3s_t(const ConvArgs& a, hipStream_t stream) {
   if (a.cout_blocks % MB || !a.zeros) return hipErrorInvalidValue;
@@ -935,9 +1027,33 @@ static hipError_t launch_conv_x3s_t(const ConvArgs& a, hipStream_t stream) {
   }
   const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
   const size_t wbytes = size_t(a.cout_blocks) * 32 * a.nblk_in * 32 * KS * KS * 4;
+  const int groups = tiles * (a.cout_blocks / MB) * a.B;
+  // K split (3x3, 4-wave tiles): for grids of at most a third of the chip's 512 workgroup slots (conv5_x on 15 x 20 maps: 64 groups),
+  // up to four slices of at least four half-blocks.  Measured on 4 x 240x320 (LABBOOK R6.2): conv5_x 85 -> 42 us with four slices
+  // (eight: 45; two: 59; the slices' arithmetic alone 34), conv4_x (192 groups = 0.75 per CU) unchanged with two and slower with four,
+  // so grids above 170 groups are left alone.  DFN_CONV_KSPLIT=0 turns it off, =n forces n (A/B runs).
+  int S = 1;
+  if (KS == 3 && SB == 16 && WAVES == 4) {
+    static const int forced = [] { const char* e = getenv("DFN_CONV_KSPLIT"); return e ? atoi(e) : -1; }();
+    const int nhb = a.nblk_in * (SB / 8);
+    if (forced >= 0) S = forced > 1 ? forced : 1;
+    else if (groups * 3 <= 512) S = 512 / groups > 4 ? 4 : 512 / groups;
+    if (S > nhb / 4) S = nhb / 4;
+    if (S > 8) S = 8;
+    if (S < 1) S = 1;
+  }
+  if (S > 1) {
+    ConvArgs ax = a;
+    KSplitWs* ws = ksplit_workspace(stream, size_t(groups) * S * (MB * 2 * 16 * WAVES * 64) * sizeof(float), groups);
+    if (!ws) return hipErrorOutOfMemory;
+    ax.ksplit = S; ax.ks_slab = ws->slab; ax.ks_count = ws->count;
+    ax.xcd_groups = groups;
+    hipLaunchKernelGGL(kern, dim3((groups + 7) / 8 * 8 * S), dim3(WAVES * 64), lds, stream, ax);
+    return hipGetLastError();
+  }
   if (wbytes > (3u << 20) && a.cout_blocks / MB >= 8) {      // XCD-aware grid, as launch_conv_x3_t
     ConvArgs ax = a;
-    ax.xcd_groups = tiles * (a.cout_blocks / MB) * a.B;
+    ax.xcd_groups = groups;
     hipLaunchKernelGGL(kern, dim3((ax.xcd_groups + 7) / 8 * 8), dim3(WAVES * 64), lds, stream, ax);
     return hipGetLastError();
   }

@@ -58,6 +58,13 @@ struct ConvArgs {
   // prec 2, optional: device word that receives max |output| over the image's pixels (unsigned atomicMax on the bit pattern of
   // the non-negative float; the caller zeroes it).  A data-gradient conv leaves the bound its consumer's split needs (gate_split).
   unsigned* absmax_out;
+  // conv_x3s_kernel, 3x3: split of the contraction over input half-blocks into `ksplit` slices, one workgroup each, when the grid
+  // would leave most of the chip idle (the 30 x 40 and 15 x 20 maps of a 240 x 320 batch: 64-192 workgroups for 512 slots).  Every
+  // slice leaves its accumulators as an fp32 slab in ks_slab; the slice that arrives last (ks_count, one word per tile group) sums
+  // the slabs in slice order — bit-identical reruns — and runs the epilogue.  Filled in by launch_conv (per-stream workspace).
+  int ksplit;
+  float* ks_slab;
+  unsigned* ks_count;
 };
 
 // prec: 0 = f16 MFMA inputs / fp32 accumulate, 1 = exact fp32 MFMA, 2 = split-f16 (hi/lo operands, three f16 MFMAs

@@ -10,9 +10,10 @@ if sys.argv[1] == "run":
     from dfnet_amd import engine as eng, synthetic as syn
     E = eng.DfnetEngine(3, 12).load_numpy(syn.dfnet_weights(3))
     B = int(os.environ.get("LAYERS_B", "4"))
-    x = torch.rand(B, 3, 480, 640, device="cuda:0")
+    LH, LW = int(os.environ.get("LAYERS_H", "480")), int(os.environ.get("LAYERS_W", "640"))
+    x = torch.rand(B, 3, LH, LW, device="cuda:0")
     for _ in range(3):
-        E.forward(x, True, True, False, 480, 640, precision=os.environ.get("LAYERS_PREC", "f16x3"))
+        E.forward(x, True, True, False, LH, LW, precision=os.environ.get("LAYERS_PREC", "f16x3"))
     torch.cuda.synchronize()
 else:
     f = sorted(glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True))[-1]
