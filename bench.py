@@ -719,6 +719,7 @@ def secondary_dfnet_train(dev):
     m = DFNet()
     m.load_state_dict({k: T(v) for k, v in w.items()}, strict=False)
     m.to(dev).train()
+    m.pyramid_features = True   # what script/run_feature.py sets under --tripletloss: the triplet loss from the low-resolution pyramid
     opt = torch.optim.Adam(m.parameters(), lr=1e-7)
     g = torch.Generator().manual_seed(1)
     target, rgb, virt = (torch.rand(B, 3, Hh, Ww, generator=g) for _ in range(3))
@@ -757,6 +758,18 @@ def secondary_dfnet_train(dev):
         runs.append((time.perf_counter() - t0) * 1e3 / 9)
     ms = sorted(runs)[1]
     per_iter = runs
+    peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
+    # the materialised form (round 5: two [3, B, 128, H, W] stacks, the stack triplet kernels, upsample and its adjoint), same box
+    m.pyramid_features = False
+    step(); step()
+    torch.cuda.synchronize()
+    runs_s = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        keep = [step() for _ in range(9)]
+        torch.cuda.synchronize()
+        runs_s.append((time.perf_counter() - t0) * 1e3 / 9)
+    m.pyramid_features = True
     with torch.no_grad():
         t0 = time.perf_counter()
         p = {k: T(v) for k, v in w.items()}
@@ -772,9 +785,12 @@ def secondary_dfnet_train(dev):
             "step_ms_is": "the shipped epoch loop (script/run_feature.py): losses stay on the device, the host waits once per epoch — nine steps "
                           "back to back, median of three runs; ..._with_a_host_read...: the reference's loss.item() after every step, median of nine",
             "frames_per_s": 3 * B / ms * 1e3,
+            "triplet_loss": "closed form of the low-resolution pyramid (csrc/dfnet_triplet_pyr.hip): no enlarged stacks, no upsample / adjoint",
+            "step_ms_with_materialised_stacks": sorted(runs_s)[1], "peak_mem_GB": peak_gb,
             "arithmetic": "split-f16 (f16x3) forward, data-gradient and weight-gradient products; fp32 accumulate (fp32-grade)",
             "loss": loss0, "oracle_loss": ref, "loss_rel_diff_vs_oracle": abs(loss0 - ref) / max(abs(ref), 1e-12), "cpu_oracle_forward_s": cpu_s,
-            "gradient_parity": "tests/test_gpu_dfnet.py (G10: the reference module's own training step, 46 gradients; G11: its triplet losses)"}
+            "gradient_parity": "tests/test_gpu_triplet_pyr.py (G16: the reference's DFNet + triplet loss + autograd end to end, 43 gradients), "
+                               "tests/test_gpu_dfnet.py / test_gpu_grad.py (G10: 46 gradients of the module's training step; G11: the triplet losses)"}
 
 
 def secondary_nerfh_train(dev):

@@ -589,7 +589,7 @@ extern "C" int dfn_dfnet_forward_levels(dfn_dfnet_t h, int prec, const float* x,
 
 static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose, int bn_batch,
                               int upH, int upW, float* features, float* pose, float* bn_stats, void* workspace, size_t workspace_bytes,
-                              void* stream);
+                              void* stream, int pyramid_only = 0);
 
 extern "C" int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose,
                                        int bn_batch, int keep, int upH, int upW, float* features, float* pose, float* bn_stats,
@@ -1045,9 +1045,21 @@ int adapt_keep(dfn_dfnet_t h, int prec, int t, int B, int hh, int ww, int cin, b
 // weight-gradient stream (dfnet_wgrad_s.hip: no conversion, bias gradient as an extra column).  Its power-of-two operand scale comes
 // from the |max| word the PRODUCER of the incoming gradient left behind (a conv epilogue's atomicMax, pw.amax), so no extra pass
 // measures anything.  The old chain wrote fp32, measured it, and re-split it per (block pair, kernel row) in every consumer.
+// Where the gradient w.r.t. the features comes from when it is NOT a pair of enlarged stacks: the pyramid triplet loss
+// (dfnet_triplet_pyr.hip) writes d L / d (BatchNorm output) of every level at low resolution from its own row statistics.
+struct TripletSrc { const float* grad_loss; TripletState st; int f1_half; };
+static hipError_t level_feature_gradient(const TripletSrc* ts, const float* grad_features, const DfParamWs& pw, int t, int L, int B, int hh,
+                                         int ww, int upH, int upW, void* g128, hipStream_t s) {
+  if (ts)
+    return launch_triplet_pyr_backward(pw.lvl_z[t], pw.lvl_bn[t], hh, ww, upH, upW, B / 2, ts->f1_half, t, L, 1e-6f, ts->st.case_dev,
+                                       ts->st.row_stat, ts->st.margin, ts->grad_loss, static_cast<float*>(g128), s);
+  return launch_upsample_backward(1, grad_features + size_t(t) * B * (size_t(128) * upH * upW), size_t(128) * upH * upW, B, hh, ww, upH, upW,
+                                  g128, s);
+}
+
 int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, const float* grad_pose, const float* grad_features, int upH,
                           int upW, int level_mask, int bn_batch, int have_forward, float* const* grads, const DfParamWs& pw,
-                          const int* lay_h, const int* lay_w, hipStream_t s, const char* fn) {
+                          const int* lay_h, const int* lay_w, hipStream_t s, const char* fn, const TripletSrc* ts) {
   constexpr int prec = 2;
   const DfBwdWs& w = pw.b;
   const int n_enc = int(h->enc.size());
@@ -1120,8 +1132,7 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
       CHECK_HIP(join_side(), "dfnet params: side stream");   // this block's weight gradients use pw.part on the chain's stream
       if (!have_forward)
         if (int rc = adapt_keep(h, prec, t, B, hh, ww, sp.cout, bn_batch != 0, bn_batch != 0, pw, s, nullptr, nullptr)) return rc;
-      CHECK_HIP(launch_upsample_backward(1, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s),
-                "dfnet params: upsample backward");
+      CHECK_HIP(level_feature_gradient(ts, grad_features, pw, t, h->n_taps, B, hh, ww, upH, upW, w.g128, s), "dfnet params: upsample backward");
       // BatchNorm backward: d L/d y -> d L/d z (z = the plain 5x5 output), in place; leaves max |d z| behind
       CHECK_HIP(launch_bn_backward(bn_batch, reinterpret_cast<float*>(w.g128), pw.lvl_z[t], Q, pw.bn_part, pw.lvl_bn[t], bn_batch ? ag[4] : nullptr,
                                    bn_batch ? ag[5] : nullptr, s, am),
@@ -1201,16 +1212,19 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
 // the BatchNorm-folded ones) and, with bn_batch (BatchNorm on batch statistics), BatchNorm weight and bias.
 int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
                          const float* grad_features, int upH, int upW, int level_mask, int bn_batch, int have_forward,
-                         float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn) {
+                         float* const* grads, int n_grads, void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn,
+                         const TripletSrc* ts = nullptr) {
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
     return set_error(DFN_ERR_UNSUPPORTED, "%s: parameter gradients need fp32 activations (precision F32 or F16X3)", fn);
   if (int rc = check_fresh(h, prec, fn)) return rc;
   const int n_enc = int(h->enc.size());
-  level_mask = grad_features ? (level_mask & ((1 << h->n_taps) - 1)) : 0;
+  const bool feature_grads = grad_features || ts;
+  level_mask = feature_grads ? (level_mask & ((1 << h->n_taps) - 1)) : 0;
   const int per_tap = bn_batch ? 6 : 4;
-  const int want = 2 * n_enc + 2 + (grad_features ? per_tap * h->n_taps : 0);
+  const int want = 2 * n_enc + 2 + (feature_grads ? per_tap * h->n_taps : 0);
+  if (ts && (!have_forward || (B & 1))) return set_error(DFN_ERR_ARG, "%s: the pyramid triplet gradient needs the kept siamese forward", fn);
   if (!x || (!grad_pose && !level_mask) || !grads || !workspace || B < 1 || H < 32 || W < 32 || n_grads != want ||
       (level_mask && (upH < 1 || upW < 1)))
     return set_error(DFN_ERR_ARG, "%s: bad argument (%d gradient pointers expected)", fn, want);
@@ -1237,7 +1251,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
   }
   if (prec == 2)
     return backward_params_split(h, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, bn_batch, have_forward, grads, pw, lay_h, lay_w,
-                                 s, fn);
+                                 s, fn, ts);
   // (exact fp32) Three gradient buffers and the handle's side stream: a layer's bias gradient, the re-pooled conv input and its weight gradient
   // read the gated gradient g_pre(i) and nothing the data-gradient chain waits for, so they run on the side stream beside the
   // data-gradient conv of the same and of the next layer (small grids at training resolutions: both leave CUs idle).  The chain
@@ -1317,8 +1331,7 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
       if (!have_forward)
         if (int rc = adapt_keep(h, prec, t, B, hh, ww, sp.cout, bn_batch != 0, bn_batch != 0, pw, s, nullptr, nullptr)) return rc;
       const float* tmp64 = pw.lvl_tmp64[t];
-      CHECK_HIP(launch_upsample_backward(1, grad_features + size_t(t) * B * plane, plane, B, hh, ww, upH, upW, w.g128, s),
-                "dfnet params: upsample backward");
+      CHECK_HIP(level_feature_gradient(ts, grad_features, pw, t, h->n_taps, B, hh, ww, upH, upW, w.g128, s), "dfnet params: upsample backward");
       // BatchNorm backward: d L/d y -> d L/d z (z = the plain 5x5 output), in place
       CHECK_HIP(launch_bn_backward(bn_batch, reinterpret_cast<float*>(w.g128), pw.lvl_z[t], Q, pw.bn_part, pw.lvl_bn[t], bn_batch ? ag[4] : nullptr,
                                    bn_batch ? ag[5] : nullptr, s),
@@ -1405,14 +1418,17 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
 
 // dfn_dfnet_forward_train(keep = 1): the training forward on the params-workspace layout, leaving every activation, the
 // pre-ReLU taps, each level's 1x1 / plain 5x5 outputs and BatchNorm work block in place for the backward.
+// pyramid_only: the adaptation layers run and their plain 5x5 outputs + BatchNorm work blocks stay in the workspace (what the
+// pyramid triplet loss and the backward read), but no level is enlarged into a feature stack (`features` is not touched).
 static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose, int bn_batch,
                               int upH, int upW, float* features, float* pose, float* bn_stats, void* workspace, size_t workspace_bytes,
-                              void* stream) {
-  const char* fn = "dfn_dfnet_forward_train";
+                              void* stream, int pyramid_only) {
+  const char* fn = pyramid_only ? "dfn_dfnet_forward_train_pyramid" : "dfn_dfnet_forward_train";
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
-  if (!x || !workspace || (!features && !return_pose) || B < 1 || H < 32 || W < 32 || (features && (upH < 1 || upW < 1)) ||
-      (return_pose && !pose) || (features && siamese && (B & 1)))
+  const bool levels = features || pyramid_only;     // the adaptation layers run
+  if (!x || !workspace || (!levels && !return_pose) || B < 1 || H < 32 || W < 32 || (features && (upH < 1 || upW < 1)) ||
+      (return_pose && !pose) || (levels && siamese && (B & 1)) || (pyramid_only && bn_batch && !bn_stats))
     return set_error(DFN_ERR_ARG, "%s: bad argument (need H,W >= 32; even batch for siamese)", fn);
   if (int rc = check_fresh(h, prec, fn)) return rc;
   const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
@@ -1422,16 +1438,17 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
   for (size_t i = 0; i < h->kept.size();)   // this workspace is being overwritten
     if (h->kept[i].ws == workspace) h->kept.erase(h->kept.begin() + i); else ++i;
   int lay_h[13], lay_w[13];
-  if (int rc = encoder_keep(h, prec, x, B, H, W, features ? (1 << h->n_taps) - 1 : 0, pw, s, lay_h, lay_w)) return rc;
+  if (int rc = encoder_keep(h, prec, x, B, H, W, levels ? (1 << h->n_taps) - 1 : 0, pw, s, lay_h, lay_w)) return rc;
   const int n_enc = int(h->enc.size());
   const size_t plane = size_t(128) * upH * upW;
   for (int i = 0; i < n_enc; ++i) {
     const int t = h->enc[i].tap;
-    if (t < 0 || !features) continue;   // features == NULL: the pose path only (its backward needs no adaptation layers)
+    if (t < 0 || !levels) continue;   // no features: the pose path only (its backward needs no adaptation layers)
     const int hh = lay_h[i], ww = lay_w[i];
     if (int rc = adapt_keep(h, prec, t, B, hh, ww, h->enc[i].cout, bn_batch != 0, true, pw, s, bn_batch ? bn_stats + size_t(t) * 256 : nullptr,
                             bn_batch ? bn_stats + size_t(t) * 256 + 128 : nullptr))
       return rc;
+    if (pyramid_only) continue;
     if (!siamese) {
       CHECK_HIP(launch_upsample(prec, pw.lvl_z[t], B, hh, ww, upH, upW, features + size_t(t) * B * plane, plane, s, pw.lvl_bn[t]),
                 "dfnet train: upsample");
@@ -1450,7 +1467,7 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
               "dfnet train: pose head");
   }
   if (h->kept.size() >= 8) h->kept.erase(h->kept.begin());
-  h->kept.push_back({workspace, prec, B, H, W, features ? (bn_batch ? 1 : 0) : -1});   // -1: no feature gradients from this state
+  h->kept.push_back({workspace, prec, B, H, W, levels ? (bn_batch ? 1 : 0) : -1});   // -1: no feature gradients from this state
   return DFN_OK;
 }
 
@@ -1469,6 +1486,77 @@ extern "C" int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const floa
     return set_error(DFN_ERR_ARG, "dfn_dfnet_backward_all_params: null grad_features (use dfn_dfnet_backward_params)");
   return backward_params_core(h, prec, x, B, H, W, grad_pose, grad_features, upH, upW, level_mask, bn_batch != 0, have_forward != 0,
                               grads, n_grads, workspace, workspace_bytes, HS(stream), "dfn_dfnet_backward_all_params");
+}
+
+// ------------------------------------------------------------------------------------------ triplet loss on the kept pyramid
+// The siamese training forward without the enlarged stacks, the triplet loss of misc.py:355-435 from the low-resolution levels it
+// keeps, and the backward that starts from that loss (dfnet_triplet_pyr.hip).  f1_half: which half of the batch misc.py's f1 (the
+// anchor stack) is — run_feature.py:154 passes (features_rgb, features_target) = (second half, first half): f1_half = 1.
+extern "C" int dfn_dfnet_forward_train_pyramid(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_pose, int bn_batch,
+                                               float* pose, float* bn_stats, void* workspace, size_t workspace_bytes, void* stream) {
+  if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
+    return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_forward_train_pyramid: batch statistics need fp32 activations (precision F32 or F16X3)");
+  return forward_train_keep(h, prec, x, B, H, W, 1, return_pose, bn_batch, 0, 0, nullptr, pose, bn_stats, workspace, workspace_bytes, stream, 1);
+}
+
+extern "C" size_t dfn_dfnet_triplet_pyramid_state_bytes(dfn_dfnet_t h, int B, int upH) {
+  if (!h || B < 2 || (B & 1) || upH < 1) return 0;
+  return triplet_state_bytes(h->n_taps, B / 2, 128 * upH);
+}
+
+namespace {
+// the kept state of `workspace` and the level geometry; nullptr (with the error set) when the workspace holds no matching forward
+const dfn_dfnet_s::Kept* kept_levels(dfn_dfnet_t h, int prec, int B, int H, int W, const void* workspace, int* tap_h, int* tap_w,
+                                     const char* fn) {
+  const dfn_dfnet_s::Kept* k = nullptr;
+  for (const auto& e : h->kept) if (e.ws == workspace) k = &e;
+  if (!k || k->prec != prec || k->B != B || k->H != H || k->W != W || k->bn_batch < 0) {
+    set_error(DFN_ERR_STATE, "%s: the workspace does not hold the levels of a matching dfn_dfnet_forward_train(_pyramid) (keep = 1)", fn);
+    return nullptr;
+  }
+  int ch = H, cw = W;
+  for (size_t i = 0; i < h->enc.size(); ++i) {
+    if (h->enc[i].tap >= 0) { tap_h[h->enc[i].tap] = ch; tap_w[h->enc[i].tap] = cw; }
+    if (h->enc[i].pool_after) { ch /= 2; cw /= 2; }
+  }
+  return k;
+}
+}  // namespace
+
+extern "C" int dfn_dfnet_triplet_pyramid_forward(dfn_dfnet_t h, int prec, int B, int H, int W, int upH, int upW, int f1_half, float margin,
+                                                 int mining, float* loss, void* state, size_t state_bytes, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  const char* fn = "dfn_dfnet_triplet_pyramid_forward";
+  if (!h || !loss || !state || !workspace || B < 2 || (B & 1) || upH < 1 || upW < 1 || mining < 0 || mining > 2 || (f1_half & ~1))
+    return set_error(DFN_ERR_ARG, "%s: bad argument", fn);
+  if (state_bytes < dfn_dfnet_triplet_pyramid_state_bytes(h, B, upH)) return set_error(DFN_ERR_ARG, "%s: state too small", fn);
+  int th[3], tw[3];
+  if (!kept_levels(h, prec, B, H, W, workspace, th, tw, fn)) return DFN_ERR_STATE;
+  const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
+  if (pw.total > workspace_bytes) return set_error(DFN_ERR_ARG, "%s: workspace too small", fn);
+  hipStream_t s = HS(stream);
+  const int L = h->n_taps, hb = B / 2, blocks = triplet_pyr_blocks(hb, upH);
+  const TripletState t = carve_triplet(state, L, hb, 128 * upH);
+  for (int l = 0; l < L; ++l)
+    CHECK_HIP(launch_triplet_pyr_forward(pw.lvl_z[l], pw.lvl_bn[l], th[l], tw[l], upH, upW, hb, f1_half, l, L, margin, 1e-6f, t.row_stat,
+                                         t.part, l * blocks, s),
+              "dfnet triplet: level rows");
+  const double n_rows = (double)L * hb * 128 * upH;
+  CHECK_HIP(launch_triplet_finalize(t.part, L * blocks, mining, n_rows * upW, n_rows, margin, t.case_dev, mining ? t.mse : nullptr, t.margin, loss, s),
+            "dfnet triplet: finalize");
+  return DFN_OK;
+}
+
+extern "C" int dfn_dfnet_backward_all_params_triplet(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
+                                                     const float* grad_loss, const void* state, size_t state_bytes, int f1_half, int upH,
+                                                     int upW, int bn_batch, float* const* grads, int n_grads, void* workspace,
+                                                     size_t workspace_bytes, void* stream) {
+  const char* fn = "dfn_dfnet_backward_all_params_triplet";
+  if (!h || !grad_loss || !state || B < 2 || (B & 1) || upH < 1 || upW < 1 || (f1_half & ~1)) return set_error(DFN_ERR_ARG, "%s: bad argument", fn);
+  if (state_bytes < dfn_dfnet_triplet_pyramid_state_bytes(h, B, upH)) return set_error(DFN_ERR_ARG, "%s: state too small", fn);
+  const TripletSrc ts{grad_loss, carve_triplet(const_cast<void*>(state), h->n_taps, B / 2, 128 * upH), f1_half};
+  return backward_params_core(h, prec, x, B, H, W, grad_pose, nullptr, upH, upW, (1 << h->n_taps) - 1, bn_batch != 0, 1, grads, n_grads,
+                              workspace, workspace_bytes, HS(stream), fn, &ts);
 }
 
 // ------------------------------------------------------------------------------------------ device-side parameter refresh

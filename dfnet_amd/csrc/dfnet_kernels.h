@@ -93,6 +93,36 @@ hipError_t launch_triplet_backward(const float* f1, size_t ls1, const float* f2,
                                    const int* case_in, const float* row_stat, const float* margin_in, const float* grad_loss, float* g1,
                                    size_t gs1, float* g2, size_t gs2, hipStream_t s);
 
+// The caller-owned state buffer of a triplet loss (dfn_triplet_loss_state_bytes): [case:int][4 x mse][margin][pad] | row statistics
+// (6 floats per row) | fp64 partials.
+struct TripletState { int* case_dev; float* mse; float* margin; float* row_stat; double* part; };
+inline size_t triplet_state_bytes(int L, int B, int rows) {
+  return 256 + (((size_t)L * B * rows * 6 * sizeof(float) + 255) & ~size_t(255)) + kTripletPartDoubles * sizeof(double);
+}
+inline TripletState carve_triplet(void* state, int L, int B, int rows) {
+  char* base = static_cast<char*>(state);
+  TripletState t;
+  t.case_dev = reinterpret_cast<int*>(base);
+  t.mse = reinterpret_cast<float*>(base + 16);
+  t.margin = reinterpret_cast<float*>(base + 32);
+  t.row_stat = reinterpret_cast<float*>(base + 256);
+  t.part = reinterpret_cast<double*>(base + 256 + (((size_t)L * B * rows * 6 * sizeof(float) + 255) & ~size_t(255)));
+  return t;
+}
+// mode 0 naive / 1 two-case / 2 four-case mining: picks the case from the partial sums, writes case, mse, margin and the loss.
+hipError_t launch_triplet_finalize(const double* part, int n_blocks, int mode, double count, double n_rows, float margin, int* case_out,
+                                   float* mse_out, float* margin_out, float* loss, hipStream_t s);
+// The same loss from the LOW-RESOLUTION pyramid (dfnet_triplet_pyr.hip): z [2 hb][h][w][128] blocked fp32 (the plain 5x5 output of one
+// level), bn = the level's BatchNorm work block; f1_half = which half of the batch is the anchor stack.  Forward: row statistics of
+// the level (rows ((level * hb + b) * UH + Y) * 128 + channel) and its fp64 partials at part[(part0 + block) * 8 ...]; backward:
+// gout [2 hb][h][w][128] = d L / d (BatchNorm output) at low resolution.
+int triplet_pyr_blocks(int hb, int UH);
+hipError_t launch_triplet_pyr_forward(const float* z, const float* bn, int h, int w, int UH, int UW, int hb, int f1_half, int level, int L,
+                                      float margin, float eps, float* row_stat, double* part, int part0, hipStream_t s);
+hipError_t launch_triplet_pyr_backward(const float* z, const float* bn, int h, int w, int UH, int UW, int hb, int f1_half, int level, int L,
+                                       float eps, const int* case_in, const float* row_stat, const float* margin_in, const float* grad_loss,
+                                       float* gout, hipStream_t s);
+
 // BatchNorm work block of one pyramid level: device floats in stored-position order.
 constexpr int kBnSc = 0, kBnSh = 128, kBnMean = 256, kBnRstd = 384, kBnMg = 512, kBnMgx = 640, kBnWorkFloats = 768;
 constexpr int kBnMaxChunks = 1024;   // fp64 partials: [chunk][2][128]

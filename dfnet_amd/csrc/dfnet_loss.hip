@@ -169,6 +169,13 @@ hipError_t launch_triplet_forward(const float* f1, size_t ls1, const float* f2, 
   return hipGetLastError();
 }
 
+hipError_t launch_triplet_finalize(const double* part, int n_blocks, int mode, double count, double n_rows, float margin, int* case_out,
+                                   float* mse_out, float* margin_out, float* loss, hipStream_t s) {
+  hipLaunchKernelGGL(triplet_finalize_kernel, dim3(1), dim3(64), 0, s, part, n_blocks, mode, count, n_rows, margin, case_out, mse_out, margin_out,
+                     loss);
+  return hipGetLastError();
+}
+
 hipError_t launch_triplet_backward(const float* f1, size_t ls1, const float* f2, size_t ls2, int L, int B, int rows, int W, float eps,
                                    const int* case_in, const float* row_stat, const float* margin_in, const float* grad_loss, float* g1,
                                    size_t gs1, float* g2, size_t gs2, hipStream_t s) {
@@ -301,22 +308,10 @@ using namespace dfn;
 
 extern "C" size_t dfn_triplet_loss_state_bytes(int L, int B, int rows) {
   if (L < 1 || B < 1 || rows < 1) return 0;
-  // [case:int][4 x mse][margin][pad] | row statistics (6 floats per row) | fp64 partials
-  return 256 + (((size_t)L * B * rows * 6 * sizeof(float) + 255) & ~size_t(255)) + kTripletPartDoubles * sizeof(double);
+  return triplet_state_bytes(L, B, rows);
 }
 
 namespace {
-struct TripletState { int* case_dev; float* mse; float* margin; float* row_stat; double* part; };
-TripletState carve_triplet(void* state, int L, int B, int rows) {
-  char* base = static_cast<char*>(state);
-  TripletState t;
-  t.case_dev = reinterpret_cast<int*>(base);
-  t.mse = reinterpret_cast<float*>(base + 16);
-  t.margin = reinterpret_cast<float*>(base + 32);
-  t.row_stat = reinterpret_cast<float*>(base + 256);
-  t.part = reinterpret_cast<double*>(base + 256 + (((size_t)L * B * rows * 6 * sizeof(float) + 255) & ~size_t(255)));
-  return t;
-}
 bool triplet_args_ok(const void* f1, const void* f2, int L, int B, int rows, int W, size_t ls1, size_t ls2) {
   const size_t need = (size_t)B * rows * W;
   return f1 && f2 && L >= 1 && B >= 1 && rows >= 1 && W >= 1 && (L == 1 || (ls1 >= need && ls2 >= need));

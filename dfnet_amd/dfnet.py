@@ -108,13 +108,46 @@ class _PoseFn(torch.autograd.Function):
         return (None, None) + out
 
 
+class FeaturePyramid:
+    """One stream's feature stack [L, B, 128, H, W] of a siamese TRAINING forward, not materialised: the levels stay at their own
+    resolution in the engine's tape (DFNet.pyramid_features = True).  The triplet losses of feature_misc accept a pair of these and
+    compute the very loss of the enlarged stacks from the low-resolution maps (csrc/dfnet_triplet_pyr.hip); `shape` is the shape
+    the reference's tensor would have.  Anything else that wants real tensors: leave pyramid_features off."""
+
+    def __init__(self, token, state, half, shape):
+        self.token, self.state, self.half, self.shape = token, state, half, tuple(shape)
+
+    def __repr__(self):
+        return f"FeaturePyramid(shape={self.shape}, stream={self.half})"
+
+
+class _PyramidState:
+    """What the two FeaturePyramid halves of one forward share: engine, tape, geometry — and, once a triplet loss has been taken,
+    its device state for the backward."""
+
+    def __init__(self, engine, tape, B, H, W, upH, upW):
+        self.engine, self.tape, self.B, self.H, self.W, self.upH, self.upW = engine, tape, B, H, W, upH, upW
+        self.triplet = None     # (device state, f1_half)
+
+
 class _TrainFn(torch.autograd.Function):
     """Both heads of DFNet with the gradients of every trained tensor as backward (training DFNet itself)."""
 
     @staticmethod
-    def forward(ctx, x, module, bn_batch, return_pose, single, upH, upW, *params):
+    def forward(ctx, x, module, bn_batch, return_pose, single, upH, upW, pyramid, *params):
         x = x.detach()
         E = module.engine(train=True, running_stats=not bn_batch)
+        if pyramid:
+            # the siamese stacks stay a pyramid in the tape; the two outputs are tokens through which d L / d (triplet loss) returns
+            pose, stats, tape = E.forward_train_pyramid(x, return_pose, bn_batch)
+            if bn_batch:
+                module._update_running_stats(stats, x.shape)
+            ctx.save_for_backward(x)
+            ctx.tape, ctx.tape_version = tape, module._version()
+            ctx.cfg = (module, bn_batch, single)
+            ctx.pyr = module._pyramid_state = _PyramidState(E, tape, x.shape[0], x.shape[2], x.shape[3], upH, upW)
+            return torch.zeros((), device=x.device), torch.zeros((), device=x.device), pose
+        ctx.pyr = None
         # with a graph being recorded the forward keeps its activations (the "tape") and the backward recomputes nothing
         keep = any(ctx.needs_input_grad)
         out = E.forward_train(x, True, return_pose, bn_batch, upH, upW, keep=keep)
@@ -135,6 +168,20 @@ class _TrainFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         m, bn_batch, single = ctx.cfg
         E = m.engine(train=True, running_stats=not bn_batch)
+        if ctx.pyr is not None:
+            st, g_loss = ctx.pyr, (g_a if g_a is not None else g_b)
+            if not (E.holds(ctx.tape) and ctx.tape_version == m._version()):
+                raise RuntimeError("DFNet: the pyramid forward's tape is gone (weights moved or too many forwards since): backward must follow it")
+            if g_loss is None or st.triplet is None:
+                grads = {} if g_pose is None else E.backward_params(x, g_pose.contiguous(), tape=ctx.tape)
+            else:
+                state, f1_half = st.triplet
+                grads = E.backward_all_params_triplet(x, None if g_pose is None else g_pose.contiguous(), g_loss, state, f1_half, st.upH, st.upW,
+                                                      bn_batch, ctx.tape)
+            ctx.tape = ctx.pyr = st.tape = st.triplet = None
+            out = tuple(grads.pop(k, None) for k in E.train_param_names(True))
+            del grads
+            return (None,) * 8 + out
         if single or (g_a is None and g_b is None):
             g_feats = g_a
         else:
@@ -163,7 +210,7 @@ class _TrainFn(torch.autograd.Function):
             ctx.tape = None
         out = tuple(grads.pop(k, None) for k in E.train_param_names(True))   # sole references: .grad adopts them without a copy
         del grads
-        return (None,) * 7 + out
+        return (None,) * 8 + out
 
 
 class _DFNetBase(nn.Module):
@@ -296,8 +343,13 @@ class _DFNetBase(nn.Module):
             # training DFNet itself: unfolded adaptation layers, BatchNorm by its own mode, every parameter gradient
             sd = dict(self.named_parameters())
             names = self._train_param_names()
+            pyramid = bool(getattr(self, "pyramid_features", False)) and not isSingleStream and torch.is_grad_enabled()
             fa, fb, pose = _TrainFn.apply(x, self, bool(bn_batch), bool(return_pose), bool(isSingleStream), int(upsampleH),
-                                          int(upsampleW), *[sd[k] for k in names])
+                                          int(upsampleW), pyramid, *[sd[k] for k in names])
+            if pyramid:   # the reference's two stacks [L, B/2, 128, H, W], as a pyramid (feature_misc's triplet losses take these)
+                shape = (len(self.tap_channels), x.shape[0] // 2, 128, int(upsampleH), int(upsampleW))
+                st = self._pyramid_state
+                return [FeaturePyramid(fa, st, 0, shape), FeaturePyramid(fb, st, 1, shape)], pose
             return ([fa] if isSingleStream else [fa, fb]), pose
         if wants_grad and return_pose and not return_feature:
             # training the regressor (DFNet_dm): parameter gradients of the pose path come from the HIP wgrad kernels

@@ -286,9 +286,33 @@ class _TripletFn(torch.autograd.Function):
         return g1, g2, None, None
 
 
+class _PyramidTripletFn(torch.autograd.Function):
+    """The triplet losses on a pair of dfnet.FeaturePyramid (the two streams of one siamese training forward): the loss of the
+    enlarged stacks from the low-resolution levels (dfn_dfnet_triplet_pyramid_forward).  The tokens carry d L / d loss back to
+    DFNet's backward, which takes the gradient of the loss from the device state left here."""
+
+    @staticmethod
+    def forward(ctx, tok1, tok2, st, f1_half, margin, mining):
+        if st.triplet is not None:
+            raise RuntimeError("one triplet loss per siamese forward: its state is what DFNet's backward differentiates")
+        loss, state = st.engine.triplet_pyramid_forward(st.tape, st.B, st.H, st.W, st.upH, st.upW, f1_half, margin, mining)
+        st.triplet = (state, f1_half)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.detach().reshape(()).to(torch.float32)
+        return g, g, None, None, None, None
+
+
 def _fused_triplet(f1, f2, margin, mining):
     """The HIP path when both stacks live on the GPU in a layout the kernels address in place; None otherwise (CPU
     tensors — the torch composition below is then the reference's own code path, not a fallback of a GPU op)."""
+    from .dfnet import FeaturePyramid
+    if isinstance(f1, FeaturePyramid) or isinstance(f2, FeaturePyramid):
+        if not (isinstance(f1, FeaturePyramid) and isinstance(f2, FeaturePyramid)) or f1.state is not f2.state or f1.half == f2.half:
+            raise ValueError("the pyramid triplet loss takes the two streams of ONE siamese training forward")
+        return _PyramidTripletFn.apply(f1.token, f2.token, f1.state, f1.half, float(margin), mining)
     if f1.shape == f2.shape and _stack_layout(f1) is not None and _stack_layout(f2) is not None:
         return _TripletFn.apply(f1, f2, float(margin), mining)
     if f1.is_cuda:

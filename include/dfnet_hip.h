@@ -383,6 +383,31 @@ int dfn_triplet_loss_backward(const float* f1, size_t level_stride1, const float
                               int B, int rows, int W, const float* grad_loss, const void* state, float* grad_f1,
                               size_t grad_stride1, float* grad_f2, size_t grad_stride2, void* stream);
 
+/* ---- the same triplet loss WITHOUT the enlarged feature stacks ("reductions worth fusing into the upsample";
+ * feature/dfnet.py:142-160 + feature/misc.py:355-435).  Bilinear enlargement (align_corners) is linear and separable, so a row's
+ * distances over the W output columns are closed forms of the LOW-RESOLUTION adapted maps (dfnet_triplet_pyr.hip); the training
+ * step then never writes the [L, B, 128, upH, upW] stacks, their gradients, the upsample or its adjoint.
+ *
+ * dfn_dfnet_forward_train_pyramid: dfn_dfnet_forward_train(siamese = 1, keep = 1) that keeps every level's adapted map (before
+ * BatchNorm's affine, with the level's BatchNorm work block) in the workspace (dfn_dfnet_backward_params_workspace_bytes) and
+ * enlarges nothing; pose [B, feat_dim] and bn_stats as there.
+ * dfn_dfnet_triplet_pyramid_forward: the loss of mining mode `mining` between the two halves of that batch as enlarged to
+ * [upH, upW]; f1_half = which half is misc.py's f1 / anchor (run_feature.py:154 passes (features_rgb, features_target): the SECOND
+ * half of cat([target, rgb]) -> 1).  loss: device float[1]; state: dfn_dfnet_triplet_pyramid_state_bytes of device memory.
+ * dfn_dfnet_backward_all_params_triplet: dfn_dfnet_backward_all_params(have_forward = 1) whose feature gradient is grad_loss
+ * (device float[1] = d L / d triplet loss) times the gradient of that loss, taken from `state`; every level carries gradient
+ * (n_grads as there for all levels).  Same handle, same workspace, no weight refresh in between (DFN_ERR_STATE otherwise). */
+int dfn_dfnet_forward_train_pyramid(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_pose, int bn_batch,
+                                    float* pose, float* bn_stats, void* workspace, size_t workspace_bytes, void* stream);
+size_t dfn_dfnet_triplet_pyramid_state_bytes(dfn_dfnet_t h, int B, int upH);
+int dfn_dfnet_triplet_pyramid_forward(dfn_dfnet_t h, int prec, int B, int H, int W, int upH, int upW, int f1_half, float margin,
+                                      int mining, float* loss, void* state, size_t state_bytes, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+int dfn_dfnet_backward_all_params_triplet(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
+                                          const float* grad_loss, const void* state, size_t state_bytes, int f1_half, int upH,
+                                          int upW, int bn_batch, float* const* grads, int n_grads, void* workspace,
+                                          size_t workspace_bytes, void* stream);
+
 /* ---- the cosine feature loss of the DFNet_dm step (feature/direct_feature_matching.py:114-136 feature_loss with per_channel =
  * False, applied per image at :352-358 and averaged over the batch), fused for the whole mini-batch.
  * fr (features of the rendered images, differentiated) and ft (features of the target images): fp32 device stacks

@@ -193,6 +193,10 @@ def train_feature(args, train_dl, val_dl, test_dl, hwf, i_split, near, far):
     if args.freezeBN:
         feat_model = freeze_bn_layer(feat_model)
     feat_model.to(device)
+    # --tripletloss: the siamese training forward keeps its feature stacks as a low-resolution pyramid and the triplet loss is taken
+    # from there (dfnet.FeaturePyramid, csrc/dfnet_triplet_pyr.hip): the same loss and gradients without the two [3, B, 128, H, W]
+    # stacks, their gradients, the upsample and its adjoint.  Any loss that needs real stacks (MSE FeatureLoss) keeps the tensors.
+    feat_model.pyramid_features = bool(args.tripletloss) and not args.featurelossonly and os.environ.get("DFNET_PYRAMID_TRIPLET", "1") != "0"
     optimizer = torch.optim.Adam(feat_model.parameters(), lr=args.learning_rate)
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.95, patience=args.patience[1])
     early_stopping = EarlyStopping(args, patience=args.patience[0], verbose=False)

@@ -437,6 +437,41 @@ def main():
     assert seen == {0, 1, 2, 3}, seen
     save("g11_triplet_losses", **out)
 
+    # ---------------- G16: the triplet-loss training step of DFNet END TO END through the reference (run_feature.py:141-162, :211-227):
+    # net.train()(cat([target, rgb])) -> triplet loss of feature/misc.py (the functions executed above) on (features_rgb,
+    # features_target) + a linear functional of the pose -> backward: loss, chosen case and every parameter gradient.  Six frames (three
+    # per stream, so that the rolled negatives are not the positives), enlarged to the input size (level 0 = identity, as
+    # run_feature.py does) and to a size that matches no level (24 x 40); train() mode and --freezeBN; all three loss functions.
+    r16 = np.random.default_rng(1616)
+    x16 = r16.uniform(0, 1, (6, 3, 32, 48)).astype(np.float32)
+    x16[3:] = (0.7 * x16[:3] + 0.3 * x16[3:]).astype(np.float32)      # the rendered stream resembles the target stream
+    x16[4] = (0.98 * x16[3] + 0.02 * x16[4]).astype(np.float32)       # two nearly identical neighbours: a roll case can win the mining
+    Gp16 = r16.standard_normal((6, 12)).astype(np.float32)
+    out16 = {"x": x16, "Gp": Gp16, "w_f": 0.7}
+    for mode in ("train", "freezebn"):
+        for (uh, uw) in ((32, 48), (24, 40)):
+            for k, fn in enumerate(wanted):
+                net = ref_dfnet.DFNet()
+                load_into(net, syn.dfnet_weights(seed=3))
+                if mode == "freezebn":
+                    net = freeze_bn_layer(net)
+                net.train()
+                if mode == "freezebn":
+                    net = freeze_bn_layer_train(net)
+                feats, pose = net(t(x16), return_feature=True, isSingleStream=False, return_pose=True, upsampleH=uh, upsampleW=uw)
+                f_t, f_r = feats[0], feats[1]
+                margin = 0.05 + 0.05 * k          # small margins: the hinge is active on part of the rows only
+                lf = ns[fn](f_r, f_t, margin=margin)
+                with torch.no_grad():
+                    mse = torch.nn.MSELoss()
+                    an, ng = torch.roll(f_r, 1, 1), torch.roll(f_t, 1, 1)
+                    cases = torch.stack([mse(f_r, ng), mse(f_t, an), mse(f_r, an), mse(f_t, ng)])
+                (0.7 * lf + (pose * t(Gp16)).sum()).backward()
+                tag = f"{mode}_{uh}x{uw}_m{k}"
+                out16.update({f"{tag}:loss_f": lf.detach(), f"{tag}:margin": margin, f"{tag}:mse": cases, f"{tag}:pose": pose.detach()})
+                out16.update({f"{tag}:{kk}": v for kk, v in grad_digest(net).items()})
+    save("g16_dfnet_triplet_step", **out16)
+
     # ---------------- G14: the remaining render() options of the NeRF-H path (rendering.py:353-400, 269-273):
     # lindisp=True (depths linear in disparity), ndc=True (ndc_rays at near = 1, rendering.py:374-376) and c2w_staticcam
     # (rays from one pose, view directions from another, rendering.py:364-371).  white_bkgd=True is NOT a working option of

@@ -252,6 +252,43 @@ def test_g11_triplet_losses(gold):
             close(f2.grad, g[f"c{case}_m{mining}_g2"], 1e-5, 1e-8)
 
 
+@pytest.mark.parametrize("tag,mining", [("train_32x48", 0), ("train_32x48", 2), ("train_24x40", 1), ("freezebn_24x40", 2), ("freezebn_32x48", 2)])
+def test_g16_dfnet_triplet_training_step(gold, tag, mining):
+    """The triplet-loss training step END TO END (run_feature.py:141-162): the reference's DFNet in train() / --freezeBN, its own
+    triplet functions on (features_rgb, features_target) of a six-frame siamese batch enlarged to the input size or to 24 x 40, its
+    autograd — against the oracle's dfnet_forward + triplet_loss: loss, the four mining sums, pose, every parameter gradient."""
+    g = gold("g16_dfnet_triplet_step")
+    mode, size = tag.split("_")
+    uh, uw = (int(v) for v in size.split("x"))
+    key = f"{tag}_m{mining}"
+    frozen = mode == "freezebn"
+    p = tt(syn.dfnet_weights(seed=3))
+    trained = lambda k: k.endswith(("weight", "bias")) and not (frozen and ".3." in k)
+    pp = {k: v.clone().requires_grad_(trained(k)) for k, v in p.items()}
+    maps, pose = dor.dfnet_forward(pp, T(g["x"]), True, False, True, uh, uw, bn_stats=None if frozen else [])
+    f_t, f_r = maps[0], maps[1]
+    close(dor.triplet_loss_cases(f_r, f_t).detach(), g[key + ":mse"], 2e-5, 1e-7)
+    loss, _ = dor.triplet_loss(f_r, f_t, float(g[key + ":margin"]), mining)
+    close(loss.detach(), g[key + ":loss_f"], 2e-5, 1e-7)
+    close(pose.detach(), g[key + ":pose"], 1e-4, 1e-5)
+    (float(g["w_f"]) * loss + (pose * T(g["Gp"])).sum()).backward()
+    n = 0
+    for k, v in pp.items():
+        if f"{key}:gn:{k}" not in g:
+            assert v.grad is None, k
+            continue
+        if "adapt" in k and k.endswith((".2.bias", ".3.bias")):
+            assert float(v.grad.norm()) < 1e-6 and float(g[f"{key}:gn:{k}"]) < 1e-6
+            continue   # a per-channel SHIFT of a level cancels in every difference the triplet loss takes: exactly zero, rounding noise
+        ref_n = float(g[f"{key}:gn:{k}"])
+        flat = v.grad.reshape(-1)
+        assert abs(float(flat.norm()) - ref_n) <= 3e-4 * ref_n + 1e-6, (k, float(flat.norm()), ref_n)
+        rs = g[f"{key}:gs:{k}"]
+        close(flat[:: max(1, flat.numel() // 256)][:256], rs, 0, 5e-4 * max(float(np.abs(rs).max()), 1e-6))
+        n += 1
+    assert n == (37 if frozen else 40)
+
+
 def _train_rows(g):
     o, d = T(g["rays_o"]), T(g["rays_d"])
     return orc.pack_ray_rows(o, d, float(g["near"]), float(g["far"]), g["hist"])

@@ -24,6 +24,9 @@ if frozen:
 m.to(dev).train()
 if frozen:
     m = freeze_bn_layer_train(m)
+# what script/run_feature.py ships under --tripletloss: the feature stacks stay a low-resolution pyramid (dfnet.FeaturePyramid);
+# FT_STACKS=1 = the materialised stacks + stack triplet kernels (the round-5 form), for A/B
+m.pyramid_features = not os.environ.get("FT_STACKS")
 opt = torch.optim.Adam(m.parameters(), lr=1e-6)
 g = torch.Generator().manual_seed(1)
 target, rgb, virt = (torch.rand(B, 3, H, W, generator=g).to(dev) for _ in range(3))
@@ -71,4 +74,5 @@ breakdown = {k: v / iters for k, v in parts.items()}
 print(json.dumps({"workload": f"DFNet training step (run_feature.py, triplet loss + RVS), featurenet_batch_size {B} -> {2 * B} siamese + {B} "
                               f"synthesised frames at {H}x{W}, BatchNorm {'frozen' if frozen else 'batch statistics'}",
                   "step_ms": full_ms, "epoch_loop_without_per_step_waits": LOOP, "frames_per_s": 3 * B / full_ms * 1e3, "breakdown_ms_with_syncs": breakdown, "loss": loss,
-                  "precision": "split-f16 (f16x3) forward, data-gradient AND weight-gradient products; fp32 accumulate", "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+                  "precision": "split-f16 (f16x3) forward, data-gradient AND weight-gradient products; fp32 accumulate",
+                  "triplet_loss": "from the low-resolution pyramid (no enlarged stacks)" if m.pyramid_features else "on materialised [3,B,128,H,W] stacks", "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
