@@ -205,15 +205,29 @@ __global__ __launch_bounds__(256) void triplet_pyr_backward_kernel(PyrArgs a, fl
     while (Y0 < Y1 && wy_of(Y0, w0, l0, ya, yb) == 0.f) ++Y0;
     while (Y1 > Y0 && wy_of(Y1, w0, l0, ya, yb) == 0.f) --Y1;
   }
-  const int ny = min(Y1 - Y0 + 1, y_cap);
+  const int ny_all = Y1 - Y0 + 1;
+  const size_t img = (size_t)a.h * a.w * 128, rowf = (size_t)a.w * 128;
+  const f32x2 sc = ld2(a.bn + kBnSc + 2 * lane);
+  const float* pX = a.z + (size_t)(oX + b) * img + 2 * lane;
+  const float* pY = a.z + (size_t)(oY + b) * img + 2 * lane;
+  const float* pZm = a.z + (size_t)(oZ + bm) * img + 2 * lane;
+  const float* pXp = a.z + (size_t)(oX + bp) * img + 2 * lane;
+  float* gX = gout + ((size_t)(oX + b) * a.h + i) * rowf + 2 * lane;
+  float* gY = gout + ((size_t)(oY + b) * a.h + i) * rowf + 2 * lane;
+  // the output rows in chunks of at most y_cap (the LDS coefficient table): the first chunk writes the gradient rows, later ones add
+  // to what the same thread wrote (steep enlargements only: 240 x 320 from 15 x 20 is one chunk of 33 rows)
+  for (int yc = 0; yc < ny_all; yc += y_cap) {
+  const int ny = min(ny_all - yc, y_cap);
+  const int Yb = Y0 + yc;
+  __syncthreads();
   for (int t = tid; t < ny; t += 256) {
     float w0, l0; int ya, yb;
-    const float wi = wy_of(Y0 + t, w0, l0, ya, yb);
+    const float wi = wy_of(Yb + t, w0, l0, ya, yb);
     yw[4 * t] = w0; yw[4 * t + 1] = l0; yw[4 * t + 2] = wi;
     yw[4 * t + 3] = __int_as_float((ya - (i - 1)) | ((yb - (i - 1)) << 2));
   }
   for (int t = tid; t < ny * 128; t += 256) {
-    const int yy = t >> 7, p = t & 127, Y = Y0 + yy;
+    const int yy = t >> 7, p = t & 127, Y = Yb + yy;
     const float* st = row_stat + 6 * ((((size_t)a.level * a.hb + b) * a.UH + Y) * 128 + p);
     const float* sp = row_stat + 6 * ((((size_t)a.level * a.hb + bp) * a.UH + Y) * 128 + p);
     const float dxy = st[ixy], dxz = st[ixz];
@@ -225,14 +239,6 @@ __global__ __launch_bounds__(256) void triplet_pyr_backward_kernel(PyrArgs a, fl
     coef[(yy * 3 + 2) * 128 + p] = actp && dxzp > 0.f ? scale / dxzp : 0.f;
   }
   __syncthreads();
-  const size_t img = (size_t)a.h * a.w * 128, rowf = (size_t)a.w * 128;
-  const f32x2 sc = ld2(a.bn + kBnSc + 2 * lane);
-  const float* pX = a.z + (size_t)(oX + b) * img + 2 * lane;
-  const float* pY = a.z + (size_t)(oY + b) * img + 2 * lane;
-  const float* pZm = a.z + (size_t)(oZ + bm) * img + 2 * lane;
-  const float* pXp = a.z + (size_t)(oX + bp) * img + 2 * lane;
-  float* gX = gout + ((size_t)(oX + b) * a.h + i) * rowf + 2 * lane;
-  float* gY = gout + ((size_t)(oY + b) * a.h + i) * rowf + 2 * lane;
   constexpr int NR = IDENT ? 1 : 3;
   size_t roff[NR];
 #pragma unroll
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(256) void triplet_pyr_backward_kernel(PyrArgs a, fl
       if (z_is_x) gx += gz; else gy += gz;
       ax += wi * gx; ay += wi * gy;
     }
+    if (yc > 0) { ax += ld2(gX + (size_t)j * 128); ay += ld2(gY + (size_t)j * 128); }
     *reinterpret_cast<f32x2*>(gX + (size_t)j * 128) = ax;
     *reinterpret_cast<f32x2*>(gY + (size_t)j * 128) = ay;
 #pragma unroll
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(256) void triplet_pyr_backward_kernel(PyrArgs a, fl
       Dzp[r][0] = Dzp[r][1]; Dzp[r][1] = Dzp[r][2];
     }
   }
+  }   // chunks of output rows
 }
 
 // rows of an upsample h -> UH that can blend one source row (bound used for the LDS coefficient table)
@@ -304,8 +312,9 @@ static int pyr_y_cap(int h, int UH) {
   if (h == UH) return 1;
   if (h <= 1) return UH;
   const int per = (UH - 1 + h - 2) / (h - 1);   // ceil((UH - 1) / (h - 1)): output rows per source interval
-  const int cap = 2 * per + 3;
-  return cap < UH ? cap : UH;
+  int cap = 2 * per + 3;
+  if (cap > UH) cap = UH;
+  return cap < 36 ? cap : 36;      // 36 rows x (3 x 128 coefficients + 4) floats = 56 KB of LDS; more rows run in chunks
 }
 
 int triplet_pyr_blocks(int hb, int UH) {   // workgroups of one level's forward launch (<= a third of the fp64 partial slots)

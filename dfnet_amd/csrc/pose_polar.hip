@@ -67,6 +67,69 @@ __device__ inline bool polar(const M3& a, M3* q_out) {
   return true;
 }
 
+// A rank-deficient (or numerically singular) block: the Newton iteration has no inverse to take, while torch.svd — what the reference
+// calls — still returns a finite U V^T (an orthogonal factor with M = Q P, P symmetric positive SEMI-definite; unique only up to the
+// orientation of the null directions).  The same here, by the route the SVD takes: V and the singular values from a cyclic Jacobi
+// eigen-decomposition of M^T M, u_i = M v_i / s_i for the non-zero s_i, the remaining u_i an orthonormal completion (rank 2: the
+// cross product; rank 1: any frame around u_1; rank 0: U = V).  A zero-initialised or collapsed fc_pose output therefore gives a
+// finite pose, as in the reference, instead of poisoning the DFNet_dm loss with NaN.  Non-finite input stays non-finite.
+__device__ inline void cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ inline bool polar_rank_deficient(const M3& a, M3* q_out) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) if (!isfinite(a.m[i][j])) return false;
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += a.m[k][i] * a.m[k][j]; A[i][j] = s; }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (fabs(A[p][q]) < 1e-300) continue;
+        const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0)), c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; ++k) { const double x = A[k][p], y = A[k][q]; A[k][p] = c * x - sn * y; A[k][q] = sn * x + c * y; }
+        for (int k = 0; k < 3; ++k) { const double x = A[p][k], y = A[q][k]; A[p][k] = c * x - sn * y; A[q][k] = sn * x + c * y; }
+        for (int k = 0; k < 3; ++k) { const double x = V[k][p], y = V[k][q]; V[k][p] = c * x - sn * y; V[k][q] = sn * x + c * y; }
+      }
+  }
+  int ord[3] = {0, 1, 2};   // eigenvalues in descending order
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j) if (A[ord[j]][ord[j]] > A[ord[i]][ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+  double v[3][3], u[3][3], sv[3];
+  for (int i = 0; i < 3; ++i) { sv[i] = sqrt(fmax(A[ord[i]][ord[i]], 0.0)); for (int k = 0; k < 3; ++k) v[i][k] = V[k][ord[i]]; }
+  const double tol = 1e-12 * sv[0];
+  int rank = 0;
+  for (int i = 0; i < 3; ++i)
+    if (sv[i] > tol && sv[0] > 0) {
+      for (int k = 0; k < 3; ++k) u[i][k] = (a.m[k][0] * v[i][0] + a.m[k][1] * v[i][1] + a.m[k][2] * v[i][2]) / sv[i];
+      double n = sqrt(u[i][0] * u[i][0] + u[i][1] * u[i][1] + u[i][2] * u[i][2]);
+      for (int k = 0; k < 3; ++k) u[i][k] /= n;
+      rank = i + 1;
+    } else break;
+  if (rank == 0) { for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) u[i][k] = v[i][k]; }
+  else if (rank == 1) {
+    double e[3] = {0, 0, 0};
+    int small = fabs(u[0][0]) <= fabs(u[0][1]) ? (fabs(u[0][0]) <= fabs(u[0][2]) ? 0 : 2) : (fabs(u[0][1]) <= fabs(u[0][2]) ? 1 : 2);
+    e[small] = 1.0;
+    cross3(u[0], e, u[1]);
+    const double n = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+    for (int k = 0; k < 3; ++k) u[1][k] /= n;
+    cross3(u[0], u[1], u[2]);
+  } else if (rank == 2) cross3(u[0], u[1], u[2]);
+  if (rank < 3) {   // keep the completed frame's handedness that of V's, so that det Q = +1 on the completed directions
+    double vx[3];
+    cross3(v[0], v[1], vx);
+    if (vx[0] * v[2][0] + vx[1] * v[2][1] + vx[2] * v[2][2] < 0) for (int k = 0; k < 3; ++k) u[2][k] = -u[2][k];
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) q_out->m[i][j] = u[0][i] * v[0][j] + u[1][i] * v[1][j] + u[2][i] * v[2][j];
+  return true;
+}
+__device__ inline bool polar_any(const M3& a, M3* q_out) { return polar(a, q_out) || polar_rank_deficient(a, q_out); }
+
 // pose_in / pose_out [B][3][4]: rotation block <- its orthogonal polar factor, translation column copied
 __global__ void pose_polar_forward_kernel(const float* __restrict__ pin, int B, float* __restrict__ pout, int* __restrict__ status) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,7 +137,7 @@ __global__ void pose_polar_forward_kernel(const float* __restrict__ pin, int B, 
   M3 a, q;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) a.m[i][j] = pin[b * 12 + i * 4 + j];
-  if (!polar(a, &q)) {
+  if (!polar_any(a, &q)) {      // only non-finite input is left here
     if (status) atomicOr(status, 1);
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) q.m[i][j] = nan("");
@@ -91,7 +154,7 @@ __global__ void pose_polar_backward_kernel(const float* __restrict__ pin, const 
   M3 a, q, g;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) { a.m[i][j] = pin[b * 12 + i * 4 + j]; g.m[i][j] = gout[b * 12 + i * 4 + j]; }
-  const bool ok = polar(a, &q);   // recomputed in fp64 (cheaper than carrying a double-precision tape for 9 numbers)
+  bool ok = polar_any(a, &q);   // recomputed in fp64 (cheaper than carrying a double-precision tape for 9 numbers)
   double P[3][3], QtG[3][3];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
@@ -106,6 +169,9 @@ __global__ void pose_polar_backward_kernel(const float* __restrict__ pin, const 
   const double rhs[3] = {QtG[2][1] - QtG[1][2], QtG[0][2] - QtG[2][0], QtG[1][0] - QtG[0][1]};
   double detK;
   const M3 KiT = cofactor_T_over_det(K, &detK);   // K symmetric: K^-1 = K^-T
+  // K's eigenvalues are the pairwise sums s_i + s_j of M's singular values: singular only at rank <= 1, where the factor is not
+  // differentiable and torch.svd's own backward divides by zero as well
+  ok = ok && fabs(detK) > 1e-300 && isfinite(detK);
   double u[3];
   for (int i = 0; i < 3; ++i) u[i] = KiT.m[i][0] * rhs[0] + KiT.m[i][1] * rhs[1] + KiT.m[i][2] * rhs[2];
   const double ux[3][3] = {{0, -u[2], u[1]}, {u[2], 0, -u[0]}, {-u[1], u[0], 0}};

@@ -58,14 +58,16 @@ class NerfHTrainer:
         # ZEROS in every gradient tensor of that step (csrc/nerfh_fused_train.h: GuardArgs — a skipped step, as a loss scaler skips
         # one) and passes the bits on to the handle's range flag.  What train_step() does about it (`range_check`):
         #   "skip"   (default) reads the flag WITHOUT draining the stream (dfn_nerfh_range_status_async into pinned memory, looked at
-        #            one or two steps later): the flagged step stays skipped, the operand scale is re-committed at the live weights
-        #            (the exact-fp32 step takes over if a step right after a re-commit is flagged again);
+        #            one or two steps later): the flagged step's gradients stay zero — the caller's optimizer still steps on them
+        #            (Adam coasts on its moments: not a loss-scaler style no-op; see train_step) — and the operand scale is re-committed
+        #            at the live weights (the exact-fp32 step takes over if a step right after a re-commit is flagged again);
         #   "repeat" waits for the stream after every `range_check_every`-th step and, if flagged, re-commits and REPEATS the step
         #            (then on the exact-fp32 path if that does not clear it): p.grad always holds the step's gradients;
         #   None     never looks (flagged steps are still skipped by the library).
         self.range_check = "skip"
         self.range_check_every = 1
         self.range_recoveries = 0
+        self.flagged_steps = 0     # steps whose gradients the range guard zeroed (range_check = "skip")
         self._steps = 0
         self._pending = []          # ("skip"): [(event, pinned int32 slot)] of flag reads still in flight
         self._slots = None
@@ -100,6 +102,7 @@ class NerfHTrainer:
         transient_sigmas); keeps what backward() needs.  exact: force the layer-by-layer exact-fp32 step (None: `self.exact`)."""
         exact = self.exact if exact is None else bool(exact)
         self.set_mode(exact)
+        exact = exact or self.engine.width != 128    # what RAN: only netwidth 128 has the fused chains, any other width is the exact step
         rays_o, rays_d = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3)
         n, dev = rays_o.shape[0], rays_o.device
         hist = _f32c(hist).reshape(-1, self.hist_bin)
@@ -212,6 +215,7 @@ class NerfHTrainer:
             return
         flags, step = flagged
         self.range_recoveries += 1
+        self.flagged_steps += 1
         if step - self._last_recommit_step <= 3:
             warnings.warn(f"NerfHTrainer: step {step} left the split-f16 operand range again (flags {flags:#x}) right after a re-commit: "
                           "its gradients were zeroed; the following steps run on the exact-fp32 path", RuntimeWarning)
@@ -225,6 +229,15 @@ class NerfHTrainer:
         self.engine.range_flags()   # the steps enqueued between the flagged one and this re-commit ran at the old scale too
         self._last_recommit_step = self._steps
 
+    def last_step_flagged(self):
+        """True if the step just taken raised the range flag (its gradients are zeros): waits for the flag read of that step —
+        for loops that would rather skip `optimizer.step()` than let Adam coast (range_check = "skip" without this call never waits)."""
+        if not self._pending:
+            return False
+        ev, slot, _ = self._pending[-1]
+        ev.synchronize()
+        return bool(int(slot[0]))
+
     def flush_range_check(self):
         """Wait for the flag reads in flight and act on them (end of a training loop / before a checkpoint)."""
         self._drain_flags(block_beyond=0)
@@ -234,9 +247,14 @@ class NerfHTrainer:
                    lambda_u=0.01):
         """run_nerf.py:50-66 without the optimizer: forward, NerfWLoss, backward into p.grad.  Returns (loss dict of 0-dim
         tensors c_l/f_l/b_l/s_l, psnr, render outputs).  A fused step whose operands left the split-f16 range (range flag) leaves
-        ZERO gradients (the library's guard); `self.range_check` decides whether it is then skipped ("skip": found out without
-        draining the stream, re-commit for the following steps) or repeated ("repeat": at a re-derived operand scale, then, if that
-        does not clear it, on the exact-fp32 step) — p.grad never holds clamped gradients."""
+        ZERO gradients (the library's guard: p.grad never holds clamped gradients); `self.range_check` decides what follows:
+          "repeat"  the flag is read after the step (a stream drain, ~0.35 ms): the step is repeated at a re-derived operand scale and,
+                    if that does not clear it, on the exact-fp32 step — no update is ever taken from a flagged step;
+          "skip"    the flag is read WITHOUT draining the stream and is known one or two steps later.  Until then the caller's
+                    optimizer steps on the zero gradients — NOT a no-op under Adam, which coasts on its moments for those steps (and in
+                    a data-parallel run the flagged rank dilutes the averaged gradient) — then the scale is re-committed;
+                    `flagged_steps` counts them, `last_step_flagged()` tells (with a drain) whether the step just taken was one.
+        The event is rare (64x headroom at commit) and both modes are loud (RuntimeWarning)."""
         n = rays_o.reshape(-1, 3).shape[0]
         t_rand, noise, u = draws if draws is not None else self.draw(n, Nc, Ni, perturb, rays_o.device)
 
@@ -302,7 +320,9 @@ class _RenderTrainFn(torch.autograd.Function):
             g_o, g_d = tr.backward_rays(*gs, 0., g_ts, saved=ctx.saved)
         if any(ctx.needs_input_grad[12:]):
             tr.backward(*gs, 0., g_ts, grads=grads, saved=ctx.saved)
-            if not ctx.saved["exact"] and tr.range_check:
+            if not ctx.saved["exact"] and tr.range_check == "skip":
+                tr._post_flag_read(dev)           # found out without a drain, acted on by the next train_step / flush_range_check
+            elif not ctx.saved["exact"] and tr.range_check:
                 flags = tr.engine.range_flags()   # an autograd node cannot repeat its forward: fail loudly instead of clamped gradients
                 if flags:
                     raise _lib.DfnError(f"render(): the fused training step left the split-f16 operand range (flags {flags:#x}); call "
