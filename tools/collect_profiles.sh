@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of the last tools/gpu_round.sh pass from gpurun_out/ (scratch) into profiles/ (tracked): usage tools/collect_profiles.sh r03
-T=${1:-r05}; cd "$(dirname "$0")/.."; G=gpurun_out; P=profiles
+T=${1:-r06}; cd "$(dirname "$0")/.."; G=gpurun_out; P=profiles
 for prec in f16x3 f32 f16; do
   [ -f $G/prof_$prec/${T}_kernel_stats.csv ] && cp $G/prof_$prec/${T}_kernel_stats.csv $P/${T}_kernel_stats_$prec.csv
   [ -f $G/pmc_$prec/summary.json ] && cp $G/pmc_$prec/summary.json $P/${T}_pmc_summary_$prec.json
@@ -49,4 +49,8 @@ PY
 [ -f $G/ft_step_pmc.json ] && cp $G/ft_step_pmc.json $P/${T}_feature_train_pmc.json
 [ -f $G/dm_step_pmc.json ] && cp $G/dm_step_pmc.json $P/${T}_dm_step_pmc.json
 [ -f $G/wgrad_layers.txt ] && cp $G/wgrad_layers.txt $P/${T}_wgrad_layers.txt
+[ -f $G/trained_parity.log ] && cp $G/trained_parity.log $P/${T}_trained_parity.log
+[ -f $G/dm_step_convs.txt ] && cp $G/dm_step_convs.txt $P/${T}_dm_step_convs.txt
+[ -f $G/dm_step_all_levels.json ] && cp $G/dm_step_all_levels.json $P/${T}_dm_step_all_levels.json
+for f in r06_ks_abl2.log r06_triplet_pyr.log r06_n1_ab.log; do [ "$T" = r06 ] && [ -f $G/$f ] && cp $G/$f $P/$f; done
 ls -la $P | grep $T

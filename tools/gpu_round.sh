@@ -3,13 +3,16 @@
 # usage: tools/gpu_round.sh TAG [notest] [nopmc]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd $R
 mkdir -p gpurun_out
 if [[ " $* " != *" notest "* ]]; then
   timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
   tail -6 gpurun_out/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  # the trained-weight parity figures DESIGN.md section 6 quotes (printed by the tests: mode by mode, stage by stage, create_nerf, CLI)
+  timeout 900 python -m pytest tests/test_gpu_nerfh.py tests/test_gpu_cli.py -q -m gpu -s -k "trained" 2>&1 | grep -oE "(trained (stages|weights|checkpoint)|create_nerf engine).*" > gpurun_out/trained_parity.log
+  wc -l gpurun_out/trained_parity.log
 fi
 timeout 1500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-3000 gpurun_out/bench.json; tail -3 gpurun_out/bench.err
 cd /tmp && export TMPDIR=/tmp
@@ -49,6 +52,8 @@ if [[ " $* " != *" noextra "* ]]; then
   cd /tmp
   rm -rf $R/gpurun_out/prof_dm $R/gpurun_out/prof_train $R/gpurun_out/prof_layers
   DM_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dm -o dm -- python $R/tools/gpu_dm_step.py 4 24 > $R/gpurun_out/dm_step.json 2> $R/gpurun_out/dm_step.err; echo "dm rc=$?"
+  python $R/tools/gpu_step_convs.py $R/gpurun_out/prof_dm > $R/gpurun_out/dm_step_convs.txt 2>&1; tail -4 $R/gpurun_out/dm_step_convs.txt
+  DM_ONLY=1 DM_ALL_LEVELS=1 timeout 300 python $R/tools/gpu_dm_step.py 4 24 > $R/gpurun_out/dm_step_all_levels.json 2>/dev/null; cat $R/gpurun_out/dm_step_all_levels.json
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -o tr -- python $R/tools/gpu_nerf_train_step.py 1536 128 10 > $R/gpurun_out/train_step.json 2> $R/gpurun_out/train_step.err; echo "train rc=$?"
   rm -f $R/gpurun_out/train_step_pmc.json; timeout -k 5 900 $R/tools/gpu_train_pmc.sh > $R/gpurun_out/train_step_pmc.log 2>&1; echo "train pmc rc=$?"
   cd /tmp
