@@ -12,7 +12,7 @@ import csv, collections, json
 rows = list(csv.DictReader(open("/tmp/pm_$NAME/p_counter_collection.csv")))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
 for row in rows:
-    k = row["Kernel_Name"].replace("dfn::", "").replace("void ", "").split("(")[0]
+    k = row["Kernel_Name"].replace("dfn::", "").replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k].add(row["Dispatch_Id"])
 out = {}
 for k, d in agg.items():
@@ -48,7 +48,7 @@ for C, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] != C:
             continue
-        k = row["Kernel_Name"].replace("dfn::", "").replace("void ", "").split("(")[0]
+        k = row["Kernel_Name"].replace("dfn::", "").replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         agg[k] += float(row["Counter_Value"]); n[k].add(row["Dispatch_Id"])
     for k, v in agg.items():
         rec = out.setdefault(k, {"dispatches": len(n[k])})

@@ -41,7 +41,9 @@ def pmc_of(pmc, name):
         return None
     key = short(name)
     for k, v in pmc.items():
-        kk = k.replace("dfn::", "").replace("void ", "")
+        kk = k.replace("dfn::", "").replace("void ", "").replace("(anonymous namespace)::", "")
+        if not kk:      # (a name that began with "(anonymous namespace)::" was cut to nothing by the collector: matches no kernel)
+            continue
         if kk == key or key.startswith(kk) or kk.startswith(key):
             return v
     return None
