@@ -727,9 +727,13 @@ def secondary_dfnet_train(dev):
     dtarget, drgb, dvirt, dpose = (t.to(dev) for t in (target, rgb, virt, pose))
 
     def step(update=True):
-        feats, pred = m(torch.cat([dtarget, drgb]), True, upsampleH=Hh, upsampleW=Ww)
+        if m.pyramid_features:   # script/run_feature.py: the synthesised views' pose forward rides in the siamese encoder pass
+            feats, pall = m(torch.cat([dtarget, drgb, dvirt]), True, upsampleH=Hh, upsampleW=Ww, feature_images=2 * B)
+            pred, vp = pall[:2 * B], pall[2 * B:]
+        else:                    # the reference's two calls (run_feature.py:211, :219)
+            feats, pred = m(torch.cat([dtarget, drgb]), True, upsampleH=Hh, upsampleW=Ww)
+            _, vp = m(dvirt, False)
         loss = PoseLoss(None, pred, torch.cat([dpose, dpose]), dev) + triplet_loss_hard_negative_mining_plus(feats[1], feats[0], margin=1.0)
-        _, vp = m(dvirt, False)
         loss = loss + PoseLoss(None, vp, dpose, dev)
         loss.backward()
         if update:
@@ -785,7 +789,8 @@ def secondary_dfnet_train(dev):
             "step_ms_is": "the shipped epoch loop (script/run_feature.py): losses stay on the device, the host waits once per epoch — nine steps "
                           "back to back, median of three runs; ..._with_a_host_read...: the reference's loss.item() after every step, median of nine",
             "frames_per_s": 3 * B / ms * 1e3,
-            "triplet_loss": "closed form of the low-resolution pyramid (csrc/dfnet_triplet_pyr.hip): no enlarged stacks, no upsample / adjoint",
+            "triplet_loss": "closed form of the low-resolution pyramid (csrc/dfnet_triplet_pyr.hip): no enlarged stacks, no upsample / adjoint; "
+                            "the synthesised views' pose forward rides in the siamese encoder pass (one batch of 3 x 4 frames)",
             "step_ms_with_materialised_stacks": sorted(runs_s)[1], "peak_mem_GB": peak_gb,
             "arithmetic": "split-f16 (f16x3) forward, data-gradient and weight-gradient products; fp32 accumulate (fp32-grade)",
             "loss": loss0, "oracle_loss": ref, "loss_rel_diff_vs_oracle": abs(loss0 - ref) / max(abs(ref), 1e-12), "cpu_oracle_forward_s": cpu_s,

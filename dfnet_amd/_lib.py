@@ -99,11 +99,11 @@ SIGNATURES = {
     "dfn_frame_prep": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dfn_frame_post_scratch_bytes": (c_size_t, [c_int]),
     "dfn_frame_post": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "dfn_dfnet_forward_train_pyramid": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "dfn_dfnet_forward_train_pyramid": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "dfn_dfnet_triplet_pyramid_state_bytes": (c_size_t, [_P, c_int, c_int]),
-    "dfn_dfnet_triplet_pyramid_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P,
+    "dfn_dfnet_triplet_pyramid_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P,
                                                   c_size_t, _P]),
-    "dfn_dfnet_backward_all_params_triplet": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int,
+    "dfn_dfnet_backward_all_params_triplet": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int,
                                                       _P, c_int, _P, c_size_t, _P]),
     "dfn_triplet_loss_state_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dfn_triplet_loss_forward": (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),

@@ -589,7 +589,7 @@ extern "C" int dfn_dfnet_forward_levels(dfn_dfnet_t h, int prec, const float* x,
 
 static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose, int bn_batch,
                               int upH, int upW, float* features, float* pose, float* bn_stats, void* workspace, size_t workspace_bytes,
-                              void* stream, int pyramid_only = 0);
+                              void* stream, int pyramid_only = 0, int feat_images = 0);
 
 extern "C" int dfn_dfnet_forward_train(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose,
                                        int bn_batch, int keep, int upH, int upW, float* features, float* pose, float* bn_stats,
@@ -1047,10 +1047,10 @@ int adapt_keep(dfn_dfnet_t h, int prec, int t, int B, int hh, int ww, int cin, b
 // measures anything.  The old chain wrote fp32, measured it, and re-split it per (block pair, kernel row) in every consumer.
 // Where the gradient w.r.t. the features comes from when it is NOT a pair of enlarged stacks: the pyramid triplet loss
 // (dfnet_triplet_pyr.hip) writes d L / d (BatchNorm output) of every level at low resolution from its own row statistics.
-struct TripletSrc { const float* grad_loss; TripletState st; int f1_half; };
+struct TripletSrc { const float* grad_loss; TripletState st; int f1_half; int feat_images; };
 static hipError_t level_feature_gradient(const TripletSrc* ts, const float* grad_features, const DfParamWs& pw, int t, int L, int B, int hh,
                                          int ww, int upH, int upW, void* g128, hipStream_t s) {
-  if (ts)
+  if (ts)   // (B here = the siamese images, the leading ts->feat_images of the batch)
     return launch_triplet_pyr_backward(pw.lvl_z[t], pw.lvl_bn[t], hh, ww, upH, upW, B / 2, ts->f1_half, t, L, 1e-6f, ts->st.case_dev,
                                        ts->st.row_stat, ts->st.margin, ts->grad_loss, static_cast<float*>(g128), s);
   return launch_upsample_backward(1, grad_features + size_t(t) * B * (size_t(128) * upH * upW), size_t(128) * upH * upW, B, hh, ww, upH, upW,
@@ -1065,6 +1065,10 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
   const int n_enc = int(h->enc.size());
   const int per_tap = bn_batch ? 6 : 4;
   const void* zeros = h->fc + zeros_offset(h->feat_dim);
+  // Bf: the leading images that went through the adaptation layers — all of them, or the siamese pair of a batch that also carries
+  // extra pose-only frames (run_feature.py's synthesised views in ONE encoder pass): the levels' branches run on Bf images, and their
+  // tap gradient joins the trunk's for those images only
+  const int Bf = ts && ts->feat_images > 0 ? ts->feat_images : B;
   if (int rc = ensure_side(h)) return rc;
   hipStream_t side = h->side;
   SideJoin side_join{h, s, true};
@@ -1126,39 +1130,39 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
     if (sp.tap >= 0 && (level_mask >> sp.tap & 1)) {
       const int t = sp.tap;
       float* const* ag = grads + 2 * n_enc + 2 + per_tap * t;
-      const long long Q = (long long)B * hh * ww;
+      const long long Q = (long long)Bf * hh * ww;
       unsigned* am = pw.amax + 16 + 4 * t;
       float* sl128 = pw.scl_lvl + 16 * t, * sl64 = sl128 + 8;
       CHECK_HIP(join_side(), "dfnet params: side stream");   // this block's weight gradients use pw.part on the chain's stream
       if (!have_forward)
-        if (int rc = adapt_keep(h, prec, t, B, hh, ww, sp.cout, bn_batch != 0, bn_batch != 0, pw, s, nullptr, nullptr)) return rc;
-      CHECK_HIP(level_feature_gradient(ts, grad_features, pw, t, h->n_taps, B, hh, ww, upH, upW, w.g128, s), "dfnet params: upsample backward");
+        if (int rc = adapt_keep(h, prec, t, Bf, hh, ww, sp.cout, bn_batch != 0, bn_batch != 0, pw, s, nullptr, nullptr)) return rc;
+      CHECK_HIP(level_feature_gradient(ts, grad_features, pw, t, h->n_taps, Bf, hh, ww, upH, upW, w.g128, s), "dfnet params: upsample backward");
       // BatchNorm backward: d L/d y -> d L/d z (z = the plain 5x5 output), in place; leaves max |d z| behind
       CHECK_HIP(launch_bn_backward(bn_batch, reinterpret_cast<float*>(w.g128), pw.lvl_z[t], Q, pw.bn_part, pw.lvl_bn[t], bn_batch ? ag[4] : nullptr,
                                    bn_batch ? ag[5] : nullptr, s, am),
                 "dfnet params: BatchNorm backward");
-      CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g128), 0, nullptr, 0, nullptr, B, hh, ww, 4, am, nullptr, pw.g128S, 1, sl128, s),
+      CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g128), 0, nullptr, 0, nullptr, Bf, hh, ww, 4, am, nullptr, pw.g128S, 1, sl128, s),
                 "dfnet params: split d z");
-      CHECK_HIP(launch_conv_wgrad_split(5, pw.g128S, pw.lvl_tmp64[t], zeros, B, hh, ww, 128, 64, pw.part, pw.part_floats, pw.part_b,
+      CHECK_HIP(launch_conv_wgrad_split(5, pw.g128S, pw.lvl_tmp64[t], zeros, Bf, hh, ww, 128, 64, pw.part, pw.part_floats, pw.part_b,
                                         pw.part_b_floats, ag[2], ag[3], sl128, s),
                 "dfnet params: adapt 5x5 weight gradient");
       ConvArgs c{};
       const PackedConv& d5 = h->ad5_raw_dgrad[t];
       c.in = pw.g128S; c.w = d5.w[prec]; c.bias = d5.bias; c.out_scale = d5.out_scale; c.out_pre = w.g64;
       c.in_split = 1; c.zeros = zeros; c.dyn_scale = sl128; c.absmax_out = am + 1;
-      c.B = B; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
+      c.B = Bf; c.H = hh; c.W = ww; c.nblk_in = 4; c.cout_blocks = 2; c.relu = 0;
       CHECK_HIP(launch_conv(prec, 5, 16, c, s), "dfnet params: adapt 5x5 dgrad");
       // ReLU gate of the 1x1's output into the split storage (w.tmp64 is free: the kept 1x1 output lives in pw.lvl_tmp64)
-      CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g64), 0, pw.lvl_tmp64[t], 1, nullptr, B, hh, ww, 2, am + 1, nullptr, w.tmp64, 1,
+      CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g64), 0, pw.lvl_tmp64[t], 1, nullptr, Bf, hh, ww, 2, am + 1, nullptr, w.tmp64, 1,
                                   sl64, s),
                 "dfnet params: adapt gate");
-      CHECK_HIP(launch_conv_wgrad_split(1, w.tmp64, w.tap[t], zeros, B, hh, ww, 64, sp.cout, pw.part, pw.part_floats, pw.part_b,
+      CHECK_HIP(launch_conv_wgrad_split(1, w.tmp64, w.tap[t], zeros, Bf, hh, ww, 64, sp.cout, pw.part, pw.part_floats, pw.part_b,
                                         pw.part_b_floats, ag[0], ag[1], sl64, s),
                 "dfnet params: adapt 1x1 weight gradient");
       ConvArgs d{};
       d.in = w.tmp64; d.w = h->ad1_dgrad[t].w[prec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
       d.in_split = 1; d.zeros = zeros; d.dyn_scale = sl64; d.absmax_out = am + 2;
-      d.B = B; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
+      d.B = Bf; d.H = hh; d.W = ww; d.nblk_in = 2; d.cout_blocks = sp.cout / 32; d.relu = 0;
       CHECK_HIP(launch_conv(prec, 1, 16, d, s), "dfnet params: adapt 1x1 dgrad");
       g_tap = reinterpret_cast<const float*>(w.gtap);
       am_tap = am + 2;
@@ -1170,7 +1174,7 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
     float* slot = pw.scl_layer + 8 * i;
     const bool act_is_split = i + 1 < n_enc;
     CHECK_HIP(launch_gate_split(act_idx < 0 ? nullptr : reinterpret_cast<const float*>(gbuf[act_idx]), g_pooled ? 1 : 0, w.act[i], act_is_split,
-                                g_tap, B, hh, ww, sp.cout / 32, act_idx < 0 ? nullptr : pw.amax + i, am_tap, gbuf[pre_idx], i > 0, slot, s),
+                                g_tap, B, hh, ww, sp.cout / 32, act_idx < 0 ? nullptr : pw.amax + i, am_tap, gbuf[pre_idx], i > 0, slot, s, Bf),
               "dfnet params: gate");
     // ---- side stream: weight + bias gradient of conv i
     CHECK_HIP(fork_side(), "dfnet params: side stream");
@@ -1224,7 +1228,9 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
   level_mask = feature_grads ? (level_mask & ((1 << h->n_taps) - 1)) : 0;
   const int per_tap = bn_batch ? 6 : 4;
   const int want = 2 * n_enc + 2 + (feature_grads ? per_tap * h->n_taps : 0);
-  if (ts && (!have_forward || (B & 1))) return set_error(DFN_ERR_ARG, "%s: the pyramid triplet gradient needs the kept siamese forward", fn);
+  if (ts && (!have_forward || ts->feat_images < 2 || (ts->feat_images & 1) || ts->feat_images > B || (ts->feat_images != B && prec != 2)))
+    return set_error(DFN_ERR_ARG, "%s: the pyramid triplet gradient needs the kept siamese forward (feature_images even, <= B; a batch with extra "
+                     "pose-only frames on the split-f16 path only)", fn);
   if (!x || (!grad_pose && !level_mask) || !grads || !workspace || B < 1 || H < 32 || W < 32 || n_grads != want ||
       (level_mask && (upH < 1 || upW < 1)))
     return set_error(DFN_ERR_ARG, "%s: bad argument (%d gradient pointers expected)", fn, want);
@@ -1422,8 +1428,11 @@ int backward_params_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, 
 // pyramid triplet loss and the backward read), but no level is enlarged into a feature stack (`features` is not touched).
 static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int siamese, int return_pose, int bn_batch,
                               int upH, int upW, float* features, float* pose, float* bn_stats, void* workspace, size_t workspace_bytes,
-                              void* stream, int pyramid_only) {
+                              void* stream, int pyramid_only, int feat_images) {
   const char* fn = pyramid_only ? "dfn_dfnet_forward_train_pyramid" : "dfn_dfnet_forward_train";
+  const int Bf = feat_images > 0 ? feat_images : B;    // leading images that go through the adaptation layers (the siamese pair)
+  if (Bf > B || (pyramid_only && (Bf & 1)) || (Bf != B && !pyramid_only))
+    return set_error(DFN_ERR_ARG, "%s: feature_images must be even and <= B", fn);
   if (!h) return set_error(DFN_ERR_ARG, "%s: null handle", fn);
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   const bool levels = features || pyramid_only;     // the adaptation layers run
@@ -1445,7 +1454,7 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
     const int t = h->enc[i].tap;
     if (t < 0 || !levels) continue;   // no features: the pose path only (its backward needs no adaptation layers)
     const int hh = lay_h[i], ww = lay_w[i];
-    if (int rc = adapt_keep(h, prec, t, B, hh, ww, h->enc[i].cout, bn_batch != 0, true, pw, s, bn_batch ? bn_stats + size_t(t) * 256 : nullptr,
+    if (int rc = adapt_keep(h, prec, t, Bf, hh, ww, h->enc[i].cout, bn_batch != 0, true, pw, s, bn_batch ? bn_stats + size_t(t) * 256 : nullptr,
                             bn_batch ? bn_stats + size_t(t) * 256 + 128 : nullptr))
       return rc;
     if (pyramid_only) continue;
@@ -1492,16 +1501,20 @@ extern "C" int dfn_dfnet_backward_all_params(dfn_dfnet_t h, int prec, const floa
 // The siamese training forward without the enlarged stacks, the triplet loss of misc.py:355-435 from the low-resolution levels it
 // keeps, and the backward that starts from that loss (dfnet_triplet_pyr.hip).  f1_half: which half of the batch misc.py's f1 (the
 // anchor stack) is — run_feature.py:154 passes (features_rgb, features_target) = (second half, first half): f1_half = 1.
-extern "C" int dfn_dfnet_forward_train_pyramid(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_pose, int bn_batch,
-                                               float* pose, float* bn_stats, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int dfn_dfnet_forward_train_pyramid(dfn_dfnet_t h, int prec, const float* x, int B, int feature_images, int H, int W,
+                                               int return_pose, int bn_batch, float* pose, float* bn_stats, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
   if (prec != DFN_PREC_F32 && prec != DFN_PREC_F16X3)
     return set_error(DFN_ERR_UNSUPPORTED, "dfn_dfnet_forward_train_pyramid: batch statistics need fp32 activations (precision F32 or F16X3)");
-  return forward_train_keep(h, prec, x, B, H, W, 1, return_pose, bn_batch, 0, 0, nullptr, pose, bn_stats, workspace, workspace_bytes, stream, 1);
+  if (feature_images < 2 || (feature_images & 1) || feature_images > B || (feature_images != B && prec != DFN_PREC_F16X3))
+    return set_error(DFN_ERR_ARG, "dfn_dfnet_forward_train_pyramid: feature_images must be even, >= 2 and <= B (< B: precision F16X3 only)");
+  return forward_train_keep(h, prec, x, B, H, W, 1, return_pose, bn_batch, 0, 0, nullptr, pose, bn_stats, workspace, workspace_bytes, stream, 1,
+                            feature_images);
 }
 
-extern "C" size_t dfn_dfnet_triplet_pyramid_state_bytes(dfn_dfnet_t h, int B, int upH) {
-  if (!h || B < 2 || (B & 1) || upH < 1) return 0;
-  return triplet_state_bytes(h->n_taps, B / 2, 128 * upH);
+extern "C" size_t dfn_dfnet_triplet_pyramid_state_bytes(dfn_dfnet_t h, int feature_images, int upH) {
+  if (!h || feature_images < 2 || (feature_images & 1) || upH < 1) return 0;
+  return triplet_state_bytes(h->n_taps, feature_images / 2, 128 * upH);
 }
 
 namespace {
@@ -1523,19 +1536,20 @@ const dfn_dfnet_s::Kept* kept_levels(dfn_dfnet_t h, int prec, int B, int H, int 
 }
 }  // namespace
 
-extern "C" int dfn_dfnet_triplet_pyramid_forward(dfn_dfnet_t h, int prec, int B, int H, int W, int upH, int upW, int f1_half, float margin,
-                                                 int mining, float* loss, void* state, size_t state_bytes, void* workspace,
-                                                 size_t workspace_bytes, void* stream) {
+extern "C" int dfn_dfnet_triplet_pyramid_forward(dfn_dfnet_t h, int prec, int B, int feature_images, int H, int W, int upH, int upW,
+                                                 int f1_half, float margin, int mining, float* loss, void* state, size_t state_bytes,
+                                                 void* workspace, size_t workspace_bytes, void* stream) {
   const char* fn = "dfn_dfnet_triplet_pyramid_forward";
-  if (!h || !loss || !state || !workspace || B < 2 || (B & 1) || upH < 1 || upW < 1 || mining < 0 || mining > 2 || (f1_half & ~1))
+  if (!h || !loss || !state || !workspace || feature_images < 2 || (feature_images & 1) || feature_images > B || upH < 1 || upW < 1 ||
+      mining < 0 || mining > 2 || (f1_half & ~1))
     return set_error(DFN_ERR_ARG, "%s: bad argument", fn);
-  if (state_bytes < dfn_dfnet_triplet_pyramid_state_bytes(h, B, upH)) return set_error(DFN_ERR_ARG, "%s: state too small", fn);
+  if (state_bytes < dfn_dfnet_triplet_pyramid_state_bytes(h, feature_images, upH)) return set_error(DFN_ERR_ARG, "%s: state too small", fn);
   int th[3], tw[3];
   if (!kept_levels(h, prec, B, H, W, workspace, th, tw, fn)) return DFN_ERR_STATE;
   const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
   if (pw.total > workspace_bytes) return set_error(DFN_ERR_ARG, "%s: workspace too small", fn);
   hipStream_t s = HS(stream);
-  const int L = h->n_taps, hb = B / 2, blocks = triplet_pyr_blocks(hb, upH);
+  const int L = h->n_taps, hb = feature_images / 2, blocks = triplet_pyr_blocks(hb, upH);
   const TripletState t = carve_triplet(state, L, hb, 128 * upH);
   for (int l = 0; l < L; ++l)
     CHECK_HIP(launch_triplet_pyr_forward(pw.lvl_z[l], pw.lvl_bn[l], th[l], tw[l], upH, upW, hb, f1_half, l, L, margin, 1e-6f, t.row_stat,
@@ -1547,14 +1561,15 @@ extern "C" int dfn_dfnet_triplet_pyramid_forward(dfn_dfnet_t h, int prec, int B,
   return DFN_OK;
 }
 
-extern "C" int dfn_dfnet_backward_all_params_triplet(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
-                                                     const float* grad_loss, const void* state, size_t state_bytes, int f1_half, int upH,
-                                                     int upW, int bn_batch, float* const* grads, int n_grads, void* workspace,
-                                                     size_t workspace_bytes, void* stream) {
+extern "C" int dfn_dfnet_backward_all_params_triplet(dfn_dfnet_t h, int prec, const float* x, int B, int feature_images, int H, int W,
+                                                     const float* grad_pose, const float* grad_loss, const void* state, size_t state_bytes,
+                                                     int f1_half, int upH, int upW, int bn_batch, float* const* grads, int n_grads,
+                                                     void* workspace, size_t workspace_bytes, void* stream) {
   const char* fn = "dfn_dfnet_backward_all_params_triplet";
-  if (!h || !grad_loss || !state || B < 2 || (B & 1) || upH < 1 || upW < 1 || (f1_half & ~1)) return set_error(DFN_ERR_ARG, "%s: bad argument", fn);
-  if (state_bytes < dfn_dfnet_triplet_pyramid_state_bytes(h, B, upH)) return set_error(DFN_ERR_ARG, "%s: state too small", fn);
-  const TripletSrc ts{grad_loss, carve_triplet(const_cast<void*>(state), h->n_taps, B / 2, 128 * upH), f1_half};
+  if (!h || !grad_loss || !state || feature_images < 2 || (feature_images & 1) || feature_images > B || upH < 1 || upW < 1 || (f1_half & ~1))
+    return set_error(DFN_ERR_ARG, "%s: bad argument", fn);
+  if (state_bytes < dfn_dfnet_triplet_pyramid_state_bytes(h, feature_images, upH)) return set_error(DFN_ERR_ARG, "%s: state too small", fn);
+  const TripletSrc ts{grad_loss, carve_triplet(const_cast<void*>(state), h->n_taps, feature_images / 2, 128 * upH), f1_half, feature_images};
   return backward_params_core(h, prec, x, B, H, W, grad_pose, nullptr, upH, upW, (1 << h->n_taps) - 1, bn_batch != 0, 1, grads, n_grads,
                               workspace, workspace_bytes, HS(stream), fn, &ts);
 }

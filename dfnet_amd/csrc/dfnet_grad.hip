@@ -180,7 +180,7 @@ template <bool POOL, bool ACT_SPLIT, bool OUT_SPLIT>
 __global__ __launch_bounds__(256) void gate_split_kernel(const float* __restrict__ g, const void* __restrict__ act, const float* __restrict__ add,
                                                          int B, int H, int W, int nblk, const unsigned* __restrict__ absmax_g,
                                                          const unsigned* __restrict__ absmax_add, void* __restrict__ out,
-                                                         float* __restrict__ scale_out) {
+                                                         float* __restrict__ scale_out, int add_images) {
   float inv;
   const float sc = pow2_scale(absmax_g, absmax_add, &inv);
   if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = sc; scale_out[1] = inv; }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void gate_split_kernel(const float* __restrict
         }
       }
     }
-    if (add) {
+    if (add && b < (size_t)add_images) {   // (the tap gradient covers the leading add_images frames: the siamese pair)
       const Piece8 t = load_f32x8(add, row * W + x, nblk, blk, kc, h);
 #pragma unroll
       for (int k = 0; k < 4; ++k) { v.a[k] += t.a[k]; v.b[k] += t.b[k]; }
@@ -259,12 +259,12 @@ __global__ __launch_bounds__(256) void gate_split_kernel(const float* __restrict
 
 hipError_t launch_gate_split(const float* g, int pooled_g, const void* act, int act_split, const float* add, int B, int H, int W, int nblk,
                              const unsigned* absmax_g, const unsigned* absmax_add, void* out, int out_split, float* scale_out,
-                             hipStream_t s) {
+                             hipStream_t s, int add_images) {
   const size_t n = (size_t)B * H * nblk * W * 4;
   if (!n) return hipSuccess;
   if (pooled_g && !act) return hipErrorInvalidValue;
   const dim3 grid(grid_of(n)), block(256);
-#define DFN_GS(P, A, O) hipLaunchKernelGGL((gate_split_kernel<P, A, O>), grid, block, 0, s, g, act, add, B, H, W, nblk, absmax_g, absmax_add, out, scale_out)
+#define DFN_GS(P, A, O) hipLaunchKernelGGL((gate_split_kernel<P, A, O>), grid, block, 0, s, g, act, add, B, H, W, nblk, absmax_g, absmax_add, out, scale_out, add_images < 0 ? B : add_images)
   if (pooled_g) {
     if (act_split) { if (out_split) DFN_GS(true, true, true); else DFN_GS(true, true, false); }
     else { if (out_split) DFN_GS(true, false, true); else DFN_GS(true, false, false); }

@@ -150,7 +150,7 @@ hipError_t launch_maxpool_backward(int prec, const void* act, const void* g, int
 // power-of-two scale derived from the producers' |max| bounds (dfnet_grad.hip: gate_split_kernel); scale_out = [2^k, 2^-k].
 hipError_t launch_gate_split(const float* g, int pooled_g, const void* act, int act_split, const float* add, int B, int H, int W, int nblk,
                              const unsigned* absmax_g, const unsigned* absmax_add, void* out, int out_split, float* scale_out,
-                             hipStream_t s);
+                             hipStream_t s, int add_images = -1);   // add_images >= 0: `add` covers only the leading frames
 // adjoint of launch_upsample: fp32 NCHW planes gup[b*bstride + c*UH*UW + ...] -> blocked [B,h,w,4,32].
 hipError_t launch_upsample_backward(int prec, const float* gup, size_t bstride, int B, int h, int w, int UH, int UW, void* out,
                                     hipStream_t s, unsigned* absmax_out = nullptr);

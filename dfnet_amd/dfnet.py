@@ -125,8 +125,9 @@ class _PyramidState:
     """What the two FeaturePyramid halves of one forward share: engine, tape, geometry — and, once a triplet loss has been taken,
     its device state for the backward."""
 
-    def __init__(self, engine, tape, B, H, W, upH, upW):
+    def __init__(self, engine, tape, B, H, W, upH, upW, feature_images):
         self.engine, self.tape, self.B, self.H, self.W, self.upH, self.upW = engine, tape, B, H, W, upH, upW
+        self.feature_images = feature_images   # the leading frames that are the siamese pair (B: all)
         self.triplet = None     # (device state, f1_half)
 
 
@@ -139,13 +140,14 @@ class _TrainFn(torch.autograd.Function):
         E = module.engine(train=True, running_stats=not bn_batch)
         if pyramid:
             # the siamese stacks stay a pyramid in the tape; the two outputs are tokens through which d L / d (triplet loss) returns
-            pose, stats, tape = E.forward_train_pyramid(x, return_pose, bn_batch)
+            nf = int(pyramid)      # the leading frames that are the siamese pair (frames beyond them: encoder + pose head only)
+            pose, stats, tape = E.forward_train_pyramid(x, return_pose, bn_batch, feature_images=nf)
             if bn_batch:
-                module._update_running_stats(stats, x.shape)
+                module._update_running_stats(stats, (nf,) + tuple(x.shape[1:]))
             ctx.save_for_backward(x)
             ctx.tape, ctx.tape_version = tape, module._version()
             ctx.cfg = (module, bn_batch, single)
-            ctx.pyr = module._pyramid_state = _PyramidState(E, tape, x.shape[0], x.shape[2], x.shape[3], upH, upW)
+            ctx.pyr = module._pyramid_state = _PyramidState(E, tape, x.shape[0], x.shape[2], x.shape[3], upH, upW, nf)
             return torch.zeros((), device=x.device), torch.zeros((), device=x.device), pose
         ctx.pyr = None
         # with a graph being recorded the forward keeps its activations (the "tape") and the backward recomputes nothing
@@ -177,7 +179,7 @@ class _TrainFn(torch.autograd.Function):
             else:
                 state, f1_half = st.triplet
                 grads = E.backward_all_params_triplet(x, None if g_pose is None else g_pose.contiguous(), g_loss, state, f1_half, st.upH, st.upW,
-                                                      bn_batch, ctx.tape)
+                                                      bn_batch, ctx.tape, feature_images=st.feature_images)
             ctx.tape = ctx.pyr = st.tape = st.triplet = None
             out = tuple(grads.pop(k, None) for k in E.train_param_names(True))
             del grads
@@ -327,9 +329,12 @@ class _DFNetBase(nn.Module):
             self._bn_stats_stale = True
             self._folded_stale = True
 
-    def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427):
+    def forward(self, x, return_feature=False, isSingleStream=False, return_pose=True, upsampleH=240, upsampleW=427, feature_images=None):
         """Same contract as dfnet.py:109-172: returns (feature_maps, predict) with feature_maps None,
-        [stack] (single stream: 1 x [L,B,128,H,W]) or [stack_t, stack_r] (siamese: 2 x [L,B/2,128,H,W])."""
+        [stack] (single stream: 1 x [L,B,128,H,W]) or [stack_t, stack_r] (siamese: 2 x [L,B/2,128,H,W]).
+        feature_images (an addition; pyramid_features training forward only): the leading frames of x that are the siamese pair —
+        frames beyond them get a pose prediction and nothing else, i.e. run_feature.py:211-222's second forward
+        `feat_model(rgb_perturb, False)` rides in the same encoder pass (the encoder has no batch-coupled layer)."""
         # One-shot hints a caller left on the engine for THIS call (direct_feature_matching._losses / _target_features): popped before
         # any branch — a call that routes through _TrainFn / _PoseFn, or raises, must not leave them for the next, unrelated forward
         # (which would silently get unwritten planes for the unlisted levels).
@@ -344,10 +349,13 @@ class _DFNetBase(nn.Module):
             sd = dict(self.named_parameters())
             names = self._train_param_names()
             pyramid = bool(getattr(self, "pyramid_features", False)) and not isSingleStream and torch.is_grad_enabled()
+            if feature_images is not None and not pyramid:
+                raise NotImplementedError("feature_images needs the pyramid training forward (model.pyramid_features = True, siamese, grad enabled)")
+            nf = x.shape[0] if feature_images is None else int(feature_images)
             fa, fb, pose = _TrainFn.apply(x, self, bool(bn_batch), bool(return_pose), bool(isSingleStream), int(upsampleH),
-                                          int(upsampleW), pyramid, *[sd[k] for k in names])
+                                          int(upsampleW), nf if pyramid else 0, *[sd[k] for k in names])
             if pyramid:   # the reference's two stacks [L, B/2, 128, H, W], as a pyramid (feature_misc's triplet losses take these)
-                shape = (len(self.tap_channels), x.shape[0] // 2, 128, int(upsampleH), int(upsampleW))
+                shape = (len(self.tap_channels), nf // 2, 128, int(upsampleH), int(upsampleW))
                 st = self._pyramid_state
                 return [FeaturePyramid(fa, st, 0, shape), FeaturePyramid(fb, st, 1, shape)], pose
             return ([fa] if isSingleStream else [fa, fb]), pose

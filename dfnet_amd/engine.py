@@ -485,39 +485,43 @@ class DfnetEngine:
         return (feats, pose, stats, ws) if keep else (feats, pose, stats)
 
     # ------------------------------------------------------------------ training forward that keeps the pyramid, enlarges nothing
-    def forward_train_pyramid(self, x, return_pose=True, bn_batch=True, precision=None):
+    def forward_train_pyramid(self, x, return_pose=True, bn_batch=True, precision=None, feature_images=None):
         """The siamese training forward (x = cat([stream A, stream B])) WITHOUT the enlarged feature stacks: every level's adapted
         map stays at its own resolution in the tape; triplet_pyramid_forward / backward_all_params_triplet work from there
-        (dfn_dfnet_forward_train_pyramid).  Returns (pose | None, bn_stats | None, tape)."""
+        (dfn_dfnet_forward_train_pyramid).  feature_images: the leading frames that are the siamese pair (default: all); frames
+        beyond them run the encoder and the pose head only.  Returns (pose | None, bn_stats | None, tape)."""
         x = _f32c(x)
         B, C, H, W = x.shape
-        assert C == 3 and B % 2 == 0
+        nf = B if feature_images is None else int(feature_images)
+        assert C == 3 and nf % 2 == 0 and 2 <= nf <= B
         prec = _lib.PRECISIONS[precision or self.precision]
         dev = x.device
         pose = torch.empty(B, self.feat_dim, device=dev) if return_pose else None
         stats = torch.empty(self.n_taps, 2, 128, device=dev) if bn_batch else None
         ws = torch.empty(self.lib.dfn_dfnet_backward_params_workspace_bytes(self.handle, prec, B, H, W), dtype=torch.uint8, device=dev)
-        check(self.lib.dfn_dfnet_forward_train_pyramid(self.handle, prec, ptr(x), B, H, W, int(return_pose), int(bool(bn_batch)), ptr(pose),
+        check(self.lib.dfn_dfnet_forward_train_pyramid(self.handle, prec, ptr(x), B, nf, H, W, int(return_pose), int(bool(bn_batch)), ptr(pose),
                                                        ptr(stats), ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream()),
               "dfn_dfnet_forward_train_pyramid")
         self._remember(ws)
         return pose, stats, ws
 
-    def triplet_pyramid_forward(self, tape, B, H, W, upH, upW, f1_half, margin, mining, precision=None):
+    def triplet_pyramid_forward(self, tape, B, H, W, upH, upW, f1_half, margin, mining, precision=None, feature_images=None):
         """Triplet loss (mining 0 / 1 / 2 = misc.py:355 / :371 / :399) between the two halves of the kept siamese batch as enlarged
         to [upH, upW], from the low-resolution levels: (loss 0-dim device tensor, state for backward_all_params_triplet)."""
         prec = _lib.PRECISIONS[precision or self.precision]
         dev = tape.device
-        nbytes = self.lib.dfn_dfnet_triplet_pyramid_state_bytes(self.handle, B, int(upH))
+        nf = B if feature_images is None else int(feature_images)
+        nbytes = self.lib.dfn_dfnet_triplet_pyramid_state_bytes(self.handle, nf, int(upH))
         state = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         loss = torch.empty(1, device=dev)
-        check(self.lib.dfn_dfnet_triplet_pyramid_forward(self.handle, prec, B, H, W, int(upH), int(upW), int(f1_half), float(margin), int(mining),
+        check(self.lib.dfn_dfnet_triplet_pyramid_forward(self.handle, prec, B, nf, H, W, int(upH), int(upW), int(f1_half), float(margin), int(mining),
                                                          ptr(loss), ctypes.c_void_p(state.data_ptr()), nbytes,
                                                          ctypes.c_void_p(tape.data_ptr()), tape.numel(), current_stream()),
               "dfn_dfnet_triplet_pyramid_forward")
         return loss.reshape(()), state
 
-    def backward_all_params_triplet(self, x, grad_pose, grad_loss, state, f1_half, upH, upW, bn_batch, tape, precision=None):
+    def backward_all_params_triplet(self, x, grad_pose, grad_loss, state, f1_half, upH, upW, bn_batch, tape, precision=None,
+                                    feature_images=None):
         """backward_all_params whose feature gradient is grad_loss (0-dim / [1] device tensor) x the gradient of the pyramid triplet
         loss recorded in `state`; dict keyed as train_param_names(bn_affine=bn_batch)."""
         x = _f32c(x)
@@ -536,7 +540,8 @@ class DfnetEngine:
             shapes += [(64, c, 1, 1), (64,), (128, 64, 5, 5), (128,)] + ([(128,), (128,)] if bn_batch else [])
         grads = [torch.empty(sh, device=dev) for sh in shapes]
         ptrs = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
-        check(self.lib.dfn_dfnet_backward_all_params_triplet(self.handle, prec, ptr(x), B, H, W, ptr(gp), ptr(gl),
+        nf = B if feature_images is None else int(feature_images)
+        check(self.lib.dfn_dfnet_backward_all_params_triplet(self.handle, prec, ptr(x), B, nf, H, W, ptr(gp), ptr(gl),
                                                              ctypes.c_void_p(state.data_ptr()), state.numel(), int(f1_half), int(upH), int(upW),
                                                              int(bool(bn_batch)), ptrs, len(grads), ctypes.c_void_p(tape.data_ptr()),
                                                              tape.numel(), current_stream()),

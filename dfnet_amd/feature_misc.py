@@ -295,7 +295,8 @@ class _PyramidTripletFn(torch.autograd.Function):
     def forward(ctx, tok1, tok2, st, f1_half, margin, mining):
         if st.triplet is not None:
             raise RuntimeError("one triplet loss per siamese forward: its state is what DFNet's backward differentiates")
-        loss, state = st.engine.triplet_pyramid_forward(st.tape, st.B, st.H, st.W, st.upH, st.upW, f1_half, margin, mining)
+        loss, state = st.engine.triplet_pyramid_forward(st.tape, st.B, st.H, st.W, st.upH, st.upW, f1_half, margin, mining,
+                                                        feature_images=st.feature_images)
         st.triplet = (state, f1_half)
         return loss
 

@@ -396,17 +396,23 @@ int dfn_triplet_loss_backward(const float* f1, size_t level_stride1, const float
  * half of cat([target, rgb]) -> 1).  loss: device float[1]; state: dfn_dfnet_triplet_pyramid_state_bytes of device memory.
  * dfn_dfnet_backward_all_params_triplet: dfn_dfnet_backward_all_params(have_forward = 1) whose feature gradient is grad_loss
  * (device float[1] = d L / d triplet loss) times the gradient of that loss, taken from `state`; every level carries gradient
- * (n_grads as there for all levels).  Same handle, same workspace, no weight refresh in between (DFN_ERR_STATE otherwise). */
-int dfn_dfnet_forward_train_pyramid(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int return_pose, int bn_batch,
-                                    float* pose, float* bn_stats, void* workspace, size_t workspace_bytes, void* stream);
-size_t dfn_dfnet_triplet_pyramid_state_bytes(dfn_dfnet_t h, int B, int upH);
-int dfn_dfnet_triplet_pyramid_forward(dfn_dfnet_t h, int prec, int B, int H, int W, int upH, int upW, int f1_half, float margin,
-                                      int mining, float* loss, void* state, size_t state_bytes, void* workspace,
-                                      size_t workspace_bytes, void* stream);
-int dfn_dfnet_backward_all_params_triplet(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, const float* grad_pose,
-                                          const float* grad_loss, const void* state, size_t state_bytes, int f1_half, int upH,
-                                          int upW, int bn_batch, float* const* grads, int n_grads, void* workspace,
-                                          size_t workspace_bytes, void* stream);
+ * (n_grads as there for all levels).  Same handle, same workspace, no weight refresh in between (DFN_ERR_STATE otherwise).
+ * feature_images (even, 2 <= feature_images <= B): the LEADING frames of the batch are the siamese pair [stream 0 | stream 1] that
+ * goes through the adaptation layers, BatchNorm statistics and the loss; frames beyond them run the encoder and the pose head only —
+ * run_feature.py:211-222's second forward `feat_model(rgb_perturb, False)` on the synthesised views joins the siamese forward as ONE
+ * encoder pass (B = 3 x featurenet_batch_size, feature_images = 2 x it; the encoder has no batch-coupled layer, so every number is the
+ * two-pass one).  feature_images < B on precision F16X3 only.  pose [B, feat_dim] holds all frames. */
+int dfn_dfnet_forward_train_pyramid(dfn_dfnet_t h, int prec, const float* x, int B, int feature_images, int H, int W,
+                                    int return_pose, int bn_batch, float* pose, float* bn_stats, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+size_t dfn_dfnet_triplet_pyramid_state_bytes(dfn_dfnet_t h, int feature_images, int upH);
+int dfn_dfnet_triplet_pyramid_forward(dfn_dfnet_t h, int prec, int B, int feature_images, int H, int W, int upH, int upW,
+                                      int f1_half, float margin, int mining, float* loss, void* state, size_t state_bytes,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+int dfn_dfnet_backward_all_params_triplet(dfn_dfnet_t h, int prec, const float* x, int B, int feature_images, int H, int W,
+                                          const float* grad_pose, const float* grad_loss, const void* state, size_t state_bytes,
+                                          int f1_half, int upH, int upW, int bn_batch, float* const* grads, int n_grads,
+                                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the cosine feature loss of the DFNet_dm step (feature/direct_feature_matching.py:114-136 feature_loss with per_channel =
  * False, applied per image at :352-358 and averaged over the batch), fused for the whole mini-batch.

@@ -126,10 +126,21 @@ def train_on_batch_with_random_view_synthesis(args, targets, rgbs, poses, virtue
         rgb_perturb = virtue_view[i_inds].permute(0, 3, 1, 2).to(device)
         pose_perturb = poses_perturb[i_inds].reshape(batch_size, 12).to(device)
         pose = torch.cat([pose, pose])
-        features_target, features_rgb, predict_pose = _siamese_forward(args, feat_model, target_in, rgb_in, H, W)
+        if getattr(feat_model, "pyramid_features", False):
+            # the synthesised views' pose forward (the reference's second call, run_feature.py:219: `feat_model(rgb_perturb, False)`) rides in
+            # the siamese forward's encoder pass: one batch of 3 x batch_size frames, the leading 2 x batch_size being the siamese pair —
+            # the encoder has no batch-coupled layer, BatchNorm and the feature loss see the pair only, so every number is the two-pass one
+            features, pose_all = feat_model(torch.cat([target_in, rgb_in, rgb_perturb]), True, upsampleH=H, upsampleW=W,
+                                            feature_images=2 * batch_size)
+            features_target, features_rgb = features[0], features[1]
+            predict_pose, virtue_pose = pose_all[:2 * batch_size], pose_all[2 * batch_size:]
+        else:
+            features_target, features_rgb, predict_pose = _siamese_forward(args, feat_model, target_in, rgb_in, H, W)
+            virtue_pose = None
         loss_pose = PoseLoss(args, predict_pose, pose, device)
         loss_f = _feature_loss(args, features_rgb, features_target, FeatureLoss)
-        _, virtue_pose = feat_model(rgb_perturb, False)
+        if virtue_pose is None:
+            _, virtue_pose = feat_model(rgb_perturb, False)
         loss_pose_perturb = PoseLoss(args, virtue_pose, pose_perturb, device)
         loss = args.combine_loss_w[0] * loss_pose + args.combine_loss_w[1] * loss_f + args.combine_loss_w[2] * loss_pose_perturb
         losses.append(_step(feat_model, optimizer, loss))

@@ -151,3 +151,47 @@ def test_pyramid_misuse_fails_loudly():
     with torch.no_grad():
         fc, _ = m2(x, return_feature=True, upsampleH=32, upsampleW=48)
     assert torch.is_tensor(fc[0]) and fc[0].shape == (3, 2, 128, 32, 48)
+
+
+@pytest.mark.parametrize("mode", ["train", "freezebn"])
+def test_extra_pose_frames_in_the_siamese_pass_equal_the_second_forward(mode):
+    """run_feature.py:211-227 with random view synthesis calls the model twice per step — the siamese pair with features, then
+    `feat_model(rgb_perturb, False)` for the synthesised views' poses.  `feature_images` puts the synthesised frames behind the pair in
+    ONE encoder pass (adaptation layers, BatchNorm statistics and the triplet loss still see the pair only): losses, poses, running
+    statistics and all 46 accumulated gradients must be those of the two calls."""
+    gen = torch.Generator().manual_seed(21)
+    pair = _frames(2, gen).to(DEV)                                  # 3 + 3 frames
+    extra = torch.rand(3, 3, 32, 48, generator=gen).to(DEV)         # synthesised views
+    Gp, Gv = torch.randn(6, 12, generator=gen).to(DEV), torch.randn(3, 12, generator=gen).to(DEV)
+    out = {}
+    for merged in (False, True):
+        m = _module(mode, True)
+        if merged:
+            feats, pose_all = m(torch.cat([pair, extra]), True, upsampleH=32, upsampleW=48, feature_images=6)
+            pose, vp = pose_all[:6], pose_all[6:]
+        else:
+            feats, pose = m(pair, True, upsampleH=32, upsampleW=48)
+        lf = fm.triplet_loss_hard_negative_mining_plus(feats[1], feats[0], margin=0.3)
+        if not merged:
+            _, vp = m(extra, False)
+        loss = 0.7 * lf + (pose * Gp).sum() + (vp * Gv).sum()
+        loss.backward()
+        sd = m.state_dict()
+        out[merged] = (float(lf.detach()), pose.detach().clone(), vp.detach().clone(),
+                       {n: q.grad.detach().clone() for n, q in m.named_parameters() if q.grad is not None},
+                       {k: sd[k].clone() for k in sd if "running" in k})
+    (la, pa, va, ga, ra), (lb, pb, vb, gb, rb) = out[False], out[True]
+    assert abs(la - lb) <= 2e-6 * abs(la)
+    assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max()) and float((va - vb).abs().max()) <= 1e-5 * float(va.abs().max())
+    assert set(ga) == set(gb) and len(ga) == (46 if mode == "train" else 40)
+    for k in ra:
+        assert torch.allclose(ra[k], rb[k], rtol=1e-6, atol=1e-7), k           # BatchNorm saw the pair only, both ways
+    worst = 0.0
+    for k in ga:
+        if "adapt" in k and k.endswith((".2.bias", ".3.bias")):
+            continue
+        worst = max(worst, float((ga[k] - gb[k]).norm() / ga[k].norm().clamp_min(1e-30)))
+    print(f"one encoder pass for pair + synthesised views ({mode}): loss {lb:.6f} vs {la:.6f}, worst relative-L2 gradient difference {worst:.1e}")
+    assert worst <= 2e-5
+    with pytest.raises(NotImplementedError, match="feature_images"):
+        _module(mode, False)(torch.cat([pair, extra]), True, upsampleH=32, upsampleW=48, feature_images=6)

@@ -44,10 +44,16 @@ def step(update=True, rvs=True):
         if not LOOP:
             torch.cuda.synchronize()
         t.append(time.perf_counter())
-    feats, pred = m(torch.cat([target, rgb]), True, upsampleH=H, upsampleW=W); mark()
+    one_pass = rvs and m.pyramid_features and not os.environ.get("FT_TWO_PASS")   # script/run_feature.py: the synthesised views ride in the siamese pass
+    if one_pass:
+        feats, pall = m(torch.cat([target, rgb, virt]), True, upsampleH=H, upsampleW=W, feature_images=2 * B); mark()
+        pred, vp = pall[:2 * B], pall[2 * B:]
+    else:
+        feats, pred = m(torch.cat([target, rgb]), True, upsampleH=H, upsampleW=W); mark()
     loss = PoseLoss(None, pred, pose2, dev) + triplet_loss_hard_negative_mining_plus(feats[1], feats[0], margin=1.0)
     if rvs:
-        _, vp = m(virt, False)
+        if not one_pass:
+            _, vp = m(virt, False)
         loss = loss + PoseLoss(None, vp, pose, dev)
     mark()
     loss.backward(); mark()
