@@ -1437,7 +1437,7 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
   if (!h->committed) return set_error(DFN_ERR_STATE, "%s: dfn_dfnet_commit() has not been called", fn);
   const bool levels = features || pyramid_only;     // the adaptation layers run
   if (!x || !workspace || (!levels && !return_pose) || B < 1 || H < 32 || W < 32 || (features && (upH < 1 || upW < 1)) ||
-      (return_pose && !pose) || (levels && siamese && (B & 1)) || (pyramid_only && bn_batch && !bn_stats))
+      (return_pose && !pose) || (levels && siamese && ((feat_images > 0 ? feat_images : B) & 1)) || (pyramid_only && bn_batch && !bn_stats))
     return set_error(DFN_ERR_ARG, "%s: bad argument (need H,W >= 32; even batch for siamese)", fn);
   if (int rc = check_fresh(h, prec, fn)) return rc;
   const DfParamWs pw = carve_df_params(h, static_cast<char*>(workspace), prec, B, H, W);
