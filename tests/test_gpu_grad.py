@@ -298,18 +298,34 @@ def test_dm_step_pose_gradient_vs_oracle():
     assert e < 2e-3
 
 
+def _pose_grads64(p, x, G, rel_scale, gen):
+    """float64 autograd of loss = sum(pose * G) w.r.t. the encoder / fc_pose parameters, inputs and weights perturbed by round-off."""
+    from oracle import dfnet_oracle as dor
+    from tests.yardstick import float64_default
+    jit = (lambda t: t * (1 + rel_scale * (2 * torch.rand(t.shape, generator=gen, dtype=torch.float64) - 1))) if rel_scale else (lambda t: t)
+    with float64_default():
+        pp = {k: jit(v.double()).requires_grad_(k.startswith("encoder.") or k.startswith("fc_pose.")) for k, v in p.items()}
+        _, pose = dor.dfnet_forward(pp, jit(x.double()), False, True, True)
+        (pose * G.double()).sum().backward()
+    return {k: v.grad for k, v in pp.items() if v.grad is not None}
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 72, 104)])
 def test_dfnet_parameter_gradients_vs_autograd(dfnet, shape):
-    """Weight / bias gradients of the 13 encoder convs and fc_pose for loss = sum(pose * G): HIP wgrad kernels vs torch
-    autograd through the CPU oracle.  Same gate-flip caveat as the input gradient: a ReLU / max-pool tie within round-off resolves
-    differently under another summation order and moves a whole gradient element (measured over ten seeds at the first shape,
-    tools/gpu_debug_params.py: the exact-fp32 path sits 2e-6 from autograd on four of them and 3e-3 ... 1.5e-2 on the other six, the
-    split-f16 path 1.3-2.5e-5 on five and 4e-3 ... 1.6e-2 on the other five — different seeds).  Up to eight seeds, match on one;
-    every seed within 5e-2 relative L2."""
+    """Weight / bias gradients of the 13 encoder convs and fc_pose for loss = sum(pose * G): HIP wgrad kernels vs torch autograd through
+    the CPU oracle, at least FOUR inputs (on until one is at round-off), EVERY ONE of which must either match to 5e-5 or be demonstrably on a gate.  A ReLU / max-pool tie within
+    round-off resolves differently under another summation order and moves a whole gradient element (measured over ten seeds,
+    tools/gpu_debug_params.py: either arithmetic path is at round-off on about half of them, 3e-3 ... 1.6e-2 on the others — different
+    halves).  Since round 6 that explanation is CHECKED per input instead of being granted to seven of eight: the float64 gradient is
+    re-evaluated with inputs and weights perturbed by 3e-7 ... 3e-6 relative — no more than the forward's own parity tolerance
+    (tests/yardstick.gradient_on_a_gate); an error the float64 gradient's own sensitivity does not reach half of is unexplained and fails.  Every input within 5e-2 relative L2."""
     from oracle import dfnet_oracle as dor
+    from tests.yardstick import gradient_on_a_gate
     E, p = dfnet
-    best = 1.0
-    for seed in range(31, 39):
+    tight = 0
+    for n_seen, seed in enumerate(range(31, 41)):
+        if n_seen >= 4 and tight >= 1:     # at least four inputs, and on until one of them is at round-off
+            break
         rng = np.random.default_rng(seed)
         x = T(rng.uniform(0, 1, shape).astype(np.float32))
         G = T(rng.standard_normal((shape[0], 12)).astype(np.float32))
@@ -318,16 +334,20 @@ def test_dfnet_parameter_gradients_vs_autograd(dfnet, shape):
         (pose * G).sum().backward()
         got = E.backward_params(x.to(DEV), G.to(DEV), precision="f16x3")
         assert len(got) == 28
-        worst = 0.0
+        worst, worst_l2 = 0.0, 0.0
         for k, g in got.items():
-            e = relmax(g, pp[k].grad)
-            worst = max(worst, e)
+            worst = max(worst, relmax(g, pp[k].grad))
+            worst_l2 = max(worst_l2, rel_l2(g, pp[k].grad))
             assert rel_l2(g, pp[k].grad) < 5e-2, k
-        print(f"seed {seed} {shape}: worst parameter-gradient error {worst:.2e}")
-        best = min(best, worst)
-        if best < 5e-5:
-            break
-    assert best < 5e-5
+        if worst < 5e-5:
+            tight += 1
+            print(f"seed {seed} {shape}: worst parameter-gradient error {worst:.2e} (round-off)")
+            continue
+        on_gate, moved, at = gradient_on_a_gate(lambda sc, gen: _pose_grads64(p, x, G, sc, gen), worst_l2, seed=seed)
+        print(f"seed {seed} {shape}: worst parameter-gradient error {worst:.2e} (relative L2 {worst_l2:.2e}); the float64 gradient itself moves by "
+              f"{moved:.2e} under perturbations of {at:.0e} -> {'on a gate' if on_gate else 'UNEXPLAINED'}")
+        assert on_gate, (seed, worst, worst_l2, moved)
+    assert tight >= 1, "no input at round-off at all"
 
 
 @pytest.mark.parametrize("bn_batch,with_pose", [(False, True), (False, False), (True, True), (True, False)])
@@ -337,11 +357,26 @@ def test_dfnet_all_parameter_gradients_vs_autograd(dfnet, bn_batch, with_pose):
     (13 encoder convs, fc_pose, 1x1 and 5x5 adaptation convs [+ BatchNorm affine] of the three levels) for
     loss = sum(features * Gf) [+ sum(pose * Gp)], vs torch autograd through the CPU oracle."""
     from oracle import dfnet_oracle as dor
+    from tests.yardstick import float64_default, gradient_on_a_gate
     E, p = dfnet
     shape, uH, uW = (2, 3, 48, 64), 24, 40
-    best = 1.0
+    tight = 0
     trained = lambda k: k.endswith(("weight", "bias")) and (bn_batch or ".3." not in k)
-    for seed in (41, 42, 43):
+
+    def grads64(x, Gf, Gp, rel_scale, gen):   # float64 autograd of the same loss, inputs and weights perturbed by `rel_scale`
+        jit = (lambda t: t * (1 + rel_scale * (2 * torch.rand(t.shape, generator=gen, dtype=torch.float64) - 1))) if rel_scale else (lambda t: t)
+        with float64_default():
+            q = {k: (jit(v.double()) if trained(k) else v.double()).requires_grad_(trained(k)) for k, v in p.items()}
+            maps, pose = dor.dfnet_forward(q, jit(x.double()), True, True, with_pose, uH, uW, bn_stats=[] if bn_batch else None)
+            loss = (maps[0] * Gf.double()).sum()
+            if with_pose:
+                loss = loss + (pose * Gp.double()).sum()
+            loss.backward()
+        return {k: v.grad for k, v in q.items() if v.grad is not None and float(v.grad.abs().max()) > 0 and not (bn_batch and "adapt" in k and k.endswith(".2.bias"))}
+
+    for n_seen, seed in enumerate(range(41, 49)):
+        if n_seen >= 3 and tight >= 1:     # at least three inputs, and on until one of them is at round-off; EVERY one tight or on a gate
+            break
         rng = np.random.default_rng(seed)
         x = T(rng.uniform(0, 1, shape).astype(np.float32))
         Gf = T(rng.standard_normal((3, shape[0], 128, uH, uW)).astype(np.float32))
@@ -364,7 +399,7 @@ def test_dfnet_all_parameter_gradients_vs_autograd(dfnet, bn_batch, with_pose):
             assert st is None
         got = E.backward_all_params(x.to(DEV), None if Gp is None else Gp.to(DEV), Gf.to(DEV), bn_batch=bn_batch, precision="f16x3")
         assert len(got) == (46 if bn_batch else 40)
-        worst = 0.0
+        worst, worst_l2 = 0.0, 0.0
         for k, g in got.items():
             ref = pp[k].grad if pp[k].grad is not None else torch.zeros_like(pp[k])
             if float(ref.abs().max()) == 0.0:
@@ -373,14 +408,18 @@ def test_dfnet_all_parameter_gradients_vs_autograd(dfnet, bn_batch, with_pose):
             if bn_batch and "adapt" in k and k.endswith(".2.bias"):   # d L/d bias of a conv followed by batch-statistics BatchNorm is exactly 0:
                 assert float(g.abs().max()) < 1e-3 * float(got[k.replace(".2.bias", ".3.bias")].abs().max()), k   # rounding noise only
                 continue
-            e = relmax(g, ref)
-            worst = max(worst, e)
+            worst = max(worst, relmax(g, ref))
+            worst_l2 = max(worst_l2, rel_l2(g, ref))
             assert rel_l2(g, ref) < 5e-2, (k, rel_l2(g, ref))
-        print(f"seed {seed} bn_batch={bn_batch} pose={with_pose}: worst parameter-gradient error {worst:.2e}")
-        best = min(best, worst)
-        if best < 5e-5:
-            break
-    assert best < 5e-5
+        if worst < 5e-5:
+            tight += 1
+            print(f"seed {seed} bn_batch={bn_batch} pose={with_pose}: worst parameter-gradient error {worst:.2e} (round-off)")
+            continue
+        on_gate, moved, at = gradient_on_a_gate(lambda sc, gen: grads64(x, Gf, Gp, sc, gen), worst_l2, seed=seed)
+        print(f"seed {seed} bn_batch={bn_batch} pose={with_pose}: worst parameter-gradient error {worst:.2e} (relative L2 {worst_l2:.2e}); the float64 "
+              f"gradient itself moves by {moved:.2e} under perturbations of {at:.0e} -> {'on a gate' if on_gate else 'UNEXPLAINED'}")
+        assert on_gate, (seed, worst, worst_l2, moved)
+    assert tight >= 1, "no input at round-off at all"
 
 
 @pytest.mark.parametrize("bn_batch", [True, False])
@@ -568,9 +607,24 @@ def test_dfnet_s_module_training_step_vs_oracle():
     parameter gradient vs autograd through the oracle, then the device re-pack after an optimizer step."""
     from dfnet_amd.dfnet import DFNet_s
     from oracle import dfnet_oracle as dor
+    from tests.yardstick import float64_default, gradient_on_a_gate
     wts = {k: T(v) for k, v in syn.dfnet_weights(seed=3, taps=(64,)).items()}
-    best = 1.0
-    for seed in range(9, 15):   # the gate-flip caveat of test_dfnet_parameter_gradients_vs_autograd: several inputs, match on one
+    tr = lambda k: k.endswith(("weight", "bias"))
+
+    def grads64(x, Gt, Gr, Gp, rel_scale, gen):
+        jit = (lambda t: t * (1 + rel_scale * (2 * torch.rand(t.shape, generator=gen, dtype=torch.float64) - 1))) if rel_scale else (lambda t: t)
+        with float64_default():
+            q = {k: (jit(v.double()) if tr(k) else v.double()).requires_grad_(tr(k)) for k, v in wts.items()}
+            maps, rp = dor.dfnet_forward(q, jit(x.double()), True, False, True, 24, 32, taps=(2,), bn_stats=[])
+            ((maps[0] * Gt.double()).sum() + (maps[1] * Gr.double()).sum() + (rp * Gp.double()).sum()).backward()
+        return {k: v.grad for k, v in q.items() if v.grad is not None and not ("adapt" in k and k.endswith(".2.bias"))}
+
+    tight = 0
+    # the gate-flip caveat of test_dfnet_parameter_gradients_vs_autograd, CHECKED per input (tests/yardstick.gradient_on_a_gate): at least
+    # three inputs, on until one is at round-off, every one either at round-off or demonstrably on a gate
+    for n_seen, seed in enumerate(range(9, 17)):
+        if n_seen >= 3 and tight >= 1:
+            break
         m = DFNet_s()
         m.load_state_dict(wts, strict=False)
         m.to(DEV).train()
@@ -580,12 +634,12 @@ def test_dfnet_s_module_training_step_vs_oracle():
         Gp = T(rng.standard_normal((4, 12)).astype(np.float32))
         feats, pose = m(x.to(DEV), return_feature=True, isSingleStream=False, return_pose=True, upsampleH=24, upsampleW=32)
         ((feats[0] * Gt.to(DEV)).sum() + (feats[1] * Gr.to(DEV)).sum() + (pose * Gp.to(DEV)).sum()).backward()
-        pp = {k: v.clone().requires_grad_(k.endswith(("weight", "bias"))) for k, v in wts.items()}
+        pp = {k: v.clone().requires_grad_(tr(k)) for k, v in wts.items()}
         stats = []
         maps, rp = dor.dfnet_forward(pp, x, True, False, True, 24, 32, taps=(2,), bn_stats=stats)
         ((maps[0] * Gt).sum() + (maps[1] * Gr).sum() + (rp * Gp).sum()).backward()
         assert rel_l2(feats[0], maps[0].detach()) < 5e-6 and relmax(pose, rp.detach()) < 1e-5
-        worst = 0.0
+        worst, worst_l2 = 0.0, 0.0
         for k, q in m.named_parameters():
             ref = pp[k].grad
             if "adapt" in k and k.endswith(".2.bias"):
@@ -593,11 +647,16 @@ def test_dfnet_s_module_training_step_vs_oracle():
             assert q.grad is not None, k
             assert rel_l2(q.grad, ref) < 5e-2, k
             worst = max(worst, relmax(q.grad, ref))
-        print(f"DFNet_s training step, seed {seed}: worst parameter-gradient error {worst:.2e}")
-        best = min(best, worst)
-        if best < 5e-5:
-            break
-    assert best < 5e-5, best
+            worst_l2 = max(worst_l2, rel_l2(q.grad, ref))
+        if worst < 5e-5:
+            tight += 1
+            print(f"DFNet_s training step, seed {seed}: worst parameter-gradient error {worst:.2e} (round-off)")
+            continue
+        on_gate, moved, at = gradient_on_a_gate(lambda sc, gen: grads64(x, Gt, Gr, Gp, sc, gen), worst_l2, seed=seed)
+        print(f"DFNet_s training step, seed {seed}: worst parameter-gradient error {worst:.2e} (relative L2 {worst_l2:.2e}); the float64 gradient "
+              f"itself moves by {moved:.2e} under perturbations of {at:.0e} -> {'on a gate' if on_gate else 'UNEXPLAINED'}")
+        assert on_gate, (seed, worst, worst_l2, moved)
+    assert tight >= 1, "no input at round-off at all"
     torch.optim.SGD(m.parameters(), lr=1e-7).step()
     p1 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "num_batches" not in k}
     with torch.no_grad():

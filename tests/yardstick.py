@@ -63,3 +63,28 @@ def rays_off_a_gate(got, truth64, single64, max_frac=0.04, trials=6, shift=3e-6,
         if moved >= 0.5 * float(rel[i]):
             keep[i] = False
     return keep
+
+
+def gradient_on_a_gate(grad64, observed_rel, trials=3, scales=(3e-7, 1e-6, 3e-6), seed=0):
+    """Is an observed gradient error of size `observed_rel` (relative L2 of the worst tensor) the signature of a ReLU / max-pool tie within
+    the forward's round-off?  A network of ReLUs and max-pools is piecewise linear in its inputs: where a pre-activation (or the gap
+    between the two largest entries of a pooling window) is below round-off, the parameter gradient is DISCONTINUOUS, and two correct
+    implementations with different summation orders land on different sides (measured, tools/gpu_debug_params.py, seed 32: every wrong
+    element of conv4_3's weight gradient sits in ONE output channel — one flipped gate at one pixel — while its bias gradient and all
+    layers above are at 5e-7).  That is a property of the point, not of the implementation, and it is checkable: `grad64(rel_scale,
+    generator)` evaluates the float64 gradient {name: tensor} with inputs AND weights multiplied by (1 + rel_scale * U(-1, 1)) and
+    `grad64(0, None)` is the unperturbed truth.  The scales stay at or below the forward's own parity tolerance (3e-6 against the 5e-6
+    relative L2 the features are held to): a perturbation no larger than the arithmetic's documented error.  Returns (on_gate, moved,
+    scale): moved = the largest relative-L2 change of any tensor; on_gate = moved >= half the observed error.  An error that the
+    float64 gradient's own round-off sensitivity does not explain is a bug."""
+    base = grad64(0.0, None)
+    gen = torch.Generator().manual_seed(seed)
+    moved = 0.0
+    for scale in scales:
+        for _ in range(trials):
+            g = grad64(scale, gen)
+            for k in base:
+                moved = max(moved, rel_l2(g[k], base[k]))
+            if moved >= 0.5 * observed_rel:
+                return True, moved, scale
+    return False, moved, scales[-1]
