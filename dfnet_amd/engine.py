@@ -5,6 +5,7 @@ All tensors are fp32 CUDA tensors owned by torch (device memory + streams are to
 arithmetic is the HIP library's).  Work is enqueued on torch's current stream.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -31,6 +32,12 @@ def _grow_workspace(old, nbytes, device):
     if cur != default:
         cur.wait_stream(default)
     return ws
+
+
+# DFN_DEBUG_POISON_UNREAD=1: feature planes / gradient planes that a "read only these levels" promise leaves unwritten (zero_unread=False,
+# lazy_grad) are filled with NaN instead of being left as uninitialised memory — the DFNet_dm gradient tests run once under it
+# (tests/test_gpu_grad.py) to prove that no unhinted level is ever read.
+POISON_UNREAD = os.environ.get("DFN_DEBUG_POISON_UNREAD", "0") == "1"
 
 
 def _f32c(t):
@@ -385,6 +392,8 @@ class DfnetEngine:
                 (2, self.n_taps, B // 2, 128, upsampleH, upsampleW)
             pruned = levels is not None and not return_pose and set(int(t) for t in levels) != set(range(self.n_taps))
             feats = torch.zeros(shape, device=dev) if (pruned and zero_unread) else torch.empty(shape, device=dev)
+            if pruned and not zero_unread and POISON_UNREAD:
+                feats.fill_(float("nan"))   # debug: a consumer that reads a level it did not ask for sees NaN, not stale memory
         if return_pose:
             pose = torch.empty(B, self.feat_dim, device=dev)
         nbytes = self.lib.dfn_dfnet_workspace_bytes(self.handle, prec, B, H, W)

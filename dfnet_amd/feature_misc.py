@@ -150,6 +150,9 @@ class _FeatureCosineFn(torch.autograd.Function):
         levels = ctx.levels
         L, B, C, H, W = fr.shape
         G = torch.empty(L, B, C, H, W, device=fr.device)
+        from . import engine as _eng
+        if ctx.lazy_grad and _eng.POISON_UNREAD:
+            G.fill_(float("nan"))   # debug (DFN_DEBUG_POISON_UNREAD): the planes no one promised to read, see engine.POISON_UNREAD
         if not ctx.lazy_grad:       # levels the loss does not read carry no gradient (lazy_grad: the consumer was told which levels
             for l in range(L):      # to read — the feature extractor's grad_levels hint — and the unread planes stay unwritten)
                 if l not in levels:

@@ -816,23 +816,33 @@ def test_dm_train_step_is_identical_with_and_without_level_pruning():
         args = SimpleNamespace(svd_reg=True, chunk=32768, feature_matching_lvl=lvl, per_channel=False, combine_loss=True,
                                combine_loss_w=[0.3, 0.2, 1.0])
         out = {}
-        for prune in (True, False):
+        # "poison": the pruned step once more with every feature / gradient plane that the "only these levels are read" hints leave
+        # unwritten filled with NaN (engine.POISON_UNREAD, DFN_DEBUG_POISON_UNREAD): a consumer that read an unhinted level would turn
+        # the loss or a gradient into NaN — they must stay the pruned step's bits
+        for prune in (True, False, "poison"):
             model, feat_model = DFNet().to(DEV).eval(), DFNet().to(DEV).eval()
             model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
             feat_model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
             for q in feat_model.parameters():
                 q.requires_grad_(False)
             cap = Capture(model)
-            dfm.PRUNE_FEATURE_LEVELS = prune
+            dfm.PRUNE_FEATURE_LEVELS = bool(prune)
+            eng.POISON_UNREAD = prune == "poison"
             try:
                 loss, psnr = dfm.train_on_batch(args, data, model, feat_model, gt, hist, [H, W, focal], cap, True, DEV, setup, **kw)
             finally:
                 dfm.PRUNE_FEATURE_LEVELS = True
+                eng.POISON_UNREAD = False
             out[prune] = (float(loss[0]), float(psnr[0]), cap.grads)
-        assert out[True][0] == out[False][0] and out[True][1] == out[False][1], lvl
-        assert set(out[True][2]) == set(out[False][2])
-        for k in out[True][2]:
-            assert torch.equal(out[True][2][k], out[False][2][k]), (lvl, k)
+        for other in (False, "poison"):
+            assert out[True][0] == out[other][0] and out[True][1] == out[other][1], (lvl, other)
+            assert set(out[True][2]) == set(out[other][2])
+            for k in out[True][2]:
+                assert torch.equal(out[True][2][k], out[other][2][k]), (lvl, other, k)
+        assert np.isfinite(out["poison"][0]) and all(bool(torch.isfinite(g).all()) for g in out["poison"][2].values())
+    with pytest.raises(NameError, match="combine_loss"):   # the reference's step defines `loss` under --combine_loss only (:371-376)
+        dfm.train_on_batch(SimpleNamespace(svd_reg=True, chunk=32768, feature_matching_lvl=[0], per_channel=False, combine_loss=False,
+                                           combine_loss_w=[0.3, 0.2, 1.0]), data, model, feat_model, gt, hist, [H, W, focal], cap, True, DEV, setup, **kw)
 
 
 def test_dm_train_step_at_c5_size_vs_oracle():
