@@ -540,14 +540,7 @@ class DfnetEngine:
         prec = _lib.PRECISIONS[precision or self.precision]
         dev = x.device
         names = self.train_param_names(bn_affine=bn_batch)
-        chans, cin, shapes = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512], 3, []
-        for co in chans:
-            shapes += [(co, cin, 3, 3), (co,)]
-            cin = co
-        shapes += [(self.feat_dim, 512), (self.feat_dim,)]
-        for t, c in zip(range(self.n_taps), (64, 256, 512)):
-            shapes += [(64, c, 1, 1), (64,), (128, 64, 5, 5), (128,)] + ([(128,), (128,)] if bn_batch else [])
-        grads = [torch.empty(sh, device=dev) for sh in shapes]
+        grads = [torch.empty(sh, device=dev) for sh in self._train_grad_shapes(bn_batch)]
         ptrs = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
         nf = B if feature_images is None else int(feature_images)
         check(self.lib.dfn_dfnet_backward_all_params_triplet(self.handle, prec, ptr(x), B, nf, H, W, ptr(gp), ptr(gl),
@@ -556,6 +549,17 @@ class DfnetEngine:
                                                              tape.numel(), current_stream()),
               "dfn_dfnet_backward_all_params_triplet")
         return dict(zip(names, grads))
+
+    def _train_grad_shapes(self, bn_batch):
+        """Shapes of the gradient tensors in train_param_names(bn_affine=bn_batch) order."""
+        chans, cin, shapes = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512], 3, []
+        for co in chans:
+            shapes += [(co, cin, 3, 3), (co,)]
+            cin = co
+        shapes += [(self.feat_dim, 512), (self.feat_dim,)]
+        for t, c in zip(range(self.n_taps), (64, 256, 512)):
+            shapes += [(64, c, 1, 1), (64,), (128, 64, 5, 5), (128,)] + ([(128,), (128,)] if bn_batch else [])
+        return shapes
 
     def train_param_names(self, bn_affine=True):
         """state_dict keys in the order of backward_all_params' gradients."""
@@ -583,14 +587,8 @@ class DfnetEngine:
         prec = _lib.PRECISIONS[precision or self.precision]
         dev = x.device
         names = self.train_param_names(bn_affine=bn_batch)
-        chans, cin, shapes = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512], 3, []
-        for co in chans:
-            shapes += [(co, cin, 3, 3), (co,)]
-            cin = co
-        shapes += [(self.feat_dim, 512), (self.feat_dim,)]
-        for t, c in zip(range(self.n_taps), (64, 256, 512)):
-            shapes += [(64, c, 1, 1), (64,), (128, 64, 5, 5), (128,)] + ([(128,), (128,)] if bn_batch else [])
-        n_pose = 2 * len(chans) + 2
+        shapes = self._train_grad_shapes(bn_batch)
+        n_pose = 2 * 13 + 2
         # zeros for the adaptation layers: levels outside the mask are not written
         grads = [torch.empty(sh, device=dev) if i < n_pose else torch.zeros(sh, device=dev) for i, sh in enumerate(shapes)]
         ptrs = (ctypes.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
