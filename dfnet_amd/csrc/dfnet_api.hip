@@ -933,7 +933,7 @@ DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int
     }
   }
   w.part = take(w.part_floats * 4);
-  w.pooled = take(size_t(B) * 512 * 4);
+  w.pooled = take(size_t(B) * ((H / 16 + 1) / 2) * 512 * 4);   // pose head: row-pair partials of pool5's mean (relu5_3 is H/16 rows)
   w.gC = reinterpret_cast<char*>(take(size_t(B) * H * W * 64 * (prec == 0 ? 2 : 4)));
   w.scl_layer = take(13 * 8 * 4);
   for (int t = 0; t < h->n_taps; ++t) {
@@ -1180,10 +1180,10 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
     CHECK_HIP(fork_side(), "dfnet params: side stream");
     if (i == 0) {
       const float* g_pre = reinterpret_cast<const float*>(gbuf[pre_idx]);
-      CHECK_HIP(launch_bias_grad(g_pre, B, hh, ww, sp.cout, pw.part, pw.part_floats, grads[1], side), "dfnet params: bias gradient");
+      // (conv1_1's bias gradient is the 28th column of the same matrix product: a column of ones beside the 27 taps)
       CHECK_HIP(launch_conv0_wgrad(g_pre, reinterpret_cast<const float*>(w.prep), B, hh, ww, 2 * prep_sb(prec), pw.part, pw.part_floats,
-                                   grads[0], side, slot),
-                "dfnet params: conv1_1 weight gradient");
+                                   grads[0], side, slot, grads[1]),
+                "dfnet params: conv1_1 weight + bias gradient");
       break;
     }
     const void* input = h->enc[i - 1].pool_after ? pw.pooledS[i - 1] : w.act[i - 1];

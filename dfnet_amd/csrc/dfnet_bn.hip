@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "dfnet_kernels.h"
+#include "mfma_frag.h"
 
 namespace dfn {
 
@@ -29,23 +30,53 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict__ a, const float* __restrict__ z,
                                                          const float* __restrict__ bw, long long Q, int n_chunks,
                                                          double* __restrict__ part) {
-  __shared__ double red[2][128];
-  const int p = threadIdx.x & 127, lane = threadIdx.x >> 7;
+  // a thread owns 4 consecutive stored positions (one 16-byte load per pixel) of every 8th pixel of the chunk, four pixels' loads in
+  // flight; the 8 pixel phases are combined through LDS in a fixed order (deterministic)
+  __shared__ double red[7][2][128];
+  const int p4 = (threadIdx.x & 31) * 4, ph = threadIdx.x >> 5;
   const long long per = (Q + n_chunks - 1) / n_chunks;
   const long long q0 = blockIdx.x * per, q1 = q0 + per < Q ? q0 + per : Q;
-  double s0 = 0.0, s1 = 0.0;
-  const float mean = MODE == 1 ? bw[kBnMean + p] : 0.f, rstd = MODE == 1 ? bw[kBnRstd + p] : 0.f;
-  for (long long q = q0 + lane; q < q1; q += 2) {
-    const float v = a[q * 128 + p];
-    s0 += (double)v;
-    if (MODE == 0) s1 += (double)v * (double)v;
-    else s1 += (double)v * (double)((z[q * 128 + p] - mean) * rstd);
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  f32x4 mean{0.f, 0.f, 0.f, 0.f}, rstd{0.f, 0.f, 0.f, 0.f};
+  if (MODE == 1) { mean = *reinterpret_cast<const f32x4*>(bw + kBnMean + p4); rstd = *reinterpret_cast<const f32x4*>(bw + kBnRstd + p4); }
+  auto fold = [&](const f32x4& v, const f32x4& zz) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s0[k] += (double)v[k];
+      if (MODE == 0) s1[k] += (double)v[k] * (double)v[k];
+      else s1[k] += (double)v[k] * (double)((zz[k] - mean[k]) * rstd[k]);
+    }
+  };
+  long long q = q0 + ph;
+  for (; q + 24 < q1; q += 32) {
+    f32x4 v[4], zz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = *reinterpret_cast<const f32x4*>(a + (q + 8 * u) * 128 + p4);
+      if (MODE == 1) zz[u] = *reinterpret_cast<const f32x4*>(z + (q + 8 * u) * 128 + p4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fold(v[u], zz[u]);
   }
-  if (lane == 1) { red[0][p] = s0; red[1][p] = s1; }
+  for (; q < q1; q += 8) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a + q * 128 + p4);
+    f32x4 zz{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) zz = *reinterpret_cast<const f32x4*>(z + q * 128 + p4);
+    fold(v, zz);
+  }
+  if (ph) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[ph - 1][0][p4 + k] = s0[k]; red[ph - 1][1][p4 + k] = s1[k]; }
+  }
   __syncthreads();
-  if (lane == 0) {
-    part[((size_t)blockIdx.x * 2 + 0) * 128 + p] = s0 + red[0][p];
-    part[((size_t)blockIdx.x * 2 + 1) * 128 + p] = s1 + red[1][p];
+  if (!ph) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double t0 = s0[k], t1 = s1[k];
+      for (int r = 0; r < 7; ++r) { t0 += red[r][0][p4 + k]; t1 += red[r][1][p4 + k]; }
+      part[((size_t)blockIdx.x * 2 + 0) * 128 + p4 + k] = t0;
+      part[((size_t)blockIdx.x * 2 + 1) * 128 + p4 + k] = t1;
+    }
   }
 }
 
@@ -58,21 +89,24 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ part, int n_chunks, long long Q,
                                                            const float* __restrict__ bn, float eps, float* __restrict__ bw,
                                                            float* __restrict__ out0, float* __restrict__ out1) {
-  // 128 positions x 8 chunk segments, combined in a fixed order (deterministic)
-  __shared__ double seg[2][8][128];
-  const int p = threadIdx.x & 127, sg = threadIdx.x >> 7, ch = chan_of_pos128(p);
+  // a workgroup owns 32 positions (grid = 4): 32 chunk segments per position, four chunks' loads in flight per thread, the segments
+  // combined in a fixed order (deterministic)
+  __shared__ double seg[2][32][32];
+  const int pl = threadIdx.x & 31, sg = threadIdx.x >> 5, p = blockIdx.x * 32 + pl, ch = chan_of_pos128(p);
   double s0 = 0.0, s1 = 0.0;
   if (MODE != 2) {
-    const int per = (n_chunks + 7) / 8, c1 = min(n_chunks, (sg + 1) * per);
-    for (int c = sg * per; c < c1; ++c) {
-      s0 += part[((size_t)c * 2 + 0) * 128 + p];
-      s1 += part[((size_t)c * 2 + 1) * 128 + p];
-    }
-    seg[0][sg][p] = s0;
-    seg[1][sg][p] = s1;
+    const int per = (n_chunks + 31) / 32, c0 = sg * per, c1 = min(n_chunks, c0 + per);
+    double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+    int c = c0;
+    for (; c + 4 <= c1; c += 4)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a0[k] += part[((size_t)(c + k) * 2 + 0) * 128 + p]; a1[k] += part[((size_t)(c + k) * 2 + 1) * 128 + p]; }
+    for (; c < c1; ++c) { a0[0] += part[((size_t)c * 2 + 0) * 128 + p]; a1[0] += part[((size_t)c * 2 + 1) * 128 + p]; }
+    seg[0][sg][pl] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+    seg[1][sg][pl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
     __syncthreads();
-    s0 = s1 = 0.0;
-    for (int k = 0; k < 8; ++k) { s0 += seg[0][k][p]; s1 += seg[1][k][p]; }
+    if (sg != 0) return;
+    for (int k = 0; k < 32; ++k) { s0 += seg[0][k][pl]; s1 += seg[1][k][pl]; }
   }
   if (sg != 0) return;
   if (MODE == 1) {
@@ -109,11 +143,11 @@ hipError_t launch_bn_batch_stats(const float* z, long long Q, const float* bn, f
                                  float* var_out, hipStream_t s) {
   const int nc = chunks_for(Q);
   hipLaunchKernelGGL(bn_moments_kernel<0>, dim3(nc), dim3(256), 0, s, z, nullptr, nullptr, Q, nc, part);
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(1), dim3(1024), 0, s, part, nc, Q, bn, eps, bw, mean_out, var_out);
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(4), dim3(1024), 0, s, part, nc, Q, bn, eps, bw, mean_out, var_out);
   return hipGetLastError();
 }
 hipError_t launch_bn_running_stats(const float* bn, float eps, float* bw, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel<2>, dim3(1), dim3(1024), 0, s, nullptr, 0, 1, bn, eps, bw, nullptr, nullptr);
+  hipLaunchKernelGGL(bn_finalize_kernel<2>, dim3(4), dim3(1024), 0, s, nullptr, 0, 1, bn, eps, bw, nullptr, nullptr);
   return hipGetLastError();
 }
 
@@ -152,7 +186,7 @@ hipError_t launch_bn_backward(int batch, float* g, const float* z, long long Q, 
   if (batch) {
     const int nc = chunks_for(Q);
     hipLaunchKernelGGL(bn_moments_kernel<1>, dim3(nc), dim3(256), 0, s, g, z, bw, Q, nc, part);
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(1), dim3(1024), 0, s, part, nc, Q, nullptr, 0.f, bw, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(4), dim3(1024), 0, s, part, nc, Q, nullptr, 0.f, bw, dgamma, dbeta);
     hipLaunchKernelGGL(bn_backward_kernel<true>, dim3(grid), dim3(256), 0, s, g, z, bw, n, absmax_out);
   } else {
     hipLaunchKernelGGL(bn_backward_kernel<false>, dim3(grid), dim3(256), 0, s, g, z, bw, n, absmax_out);

@@ -166,9 +166,9 @@ hipError_t launch_conv_wgrad(int ks, const float* g, const float* in, int B, int
                              size_t part_floats, float* dW, hipStream_t s, const float* gscale = nullptr);
 // conv1_1: input = the prep output (pix_stride floats per pixel, RGB first), g has 64 channels; dW [64][3][3][3].
 hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int W, int pix_stride, float* part, size_t part_floats,
-                              float* dW, hipStream_t s, const float* gscale = nullptr);
+                              float* dW, hipStream_t s, const float* gscale = nullptr, float* db = nullptr);   // db (split-f16 only): + the bias gradient
 hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float* part, size_t part_floats, float* db, hipStream_t s);
-// pose head: relu5_3 activations + d pose -> pooled [B,512] (scratch), gradient w.r.t. the activations, fc gradients.
+// pose head: relu5_3 activations + d pose -> gradient w.r.t. the activations, fc gradients; pooled = scratch of B * ((h + 1) / 2) * 512 floats.
 // absmax_out (optional): device word that receives a bound of max |gact| (atomicMax on the float's bit pattern; caller zeroes it)
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
                                      float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s,

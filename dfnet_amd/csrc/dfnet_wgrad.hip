@@ -475,7 +475,8 @@ __global__ __launch_bounds__(256) void conv0_finalize_kernel(const float* __rest
 // The same gradient on the matrix cores (split-f16, as conv_wgrad_x3_kernel): M = the 64 output channels (two blocks),
 // N = the 27 (c, ky, kx) combinations — lane (j, kg) gathers input channel c_j of the pixel shifted by (ky_j, kx_j) for
 // its eight pixels — K = 16 pixels per MFMA.  Six MFMAs per 16 pixels cover the whole layer; the scalar kernel above
-// spends 27 loads and FMAs per pixel and thread.  part[chunk][64 (co position)][32 (combination, 27 used)].
+// spends 27 loads and FMAs per pixel and thread.  part[chunk][64 (co position)][32 (combination: 27 taps, then a column of ones
+// = the bias gradient)].
 __global__ __launch_bounds__(256) void conv0_wgrad_x3_kernel(const float* __restrict__ g, const float* __restrict__ xn, int B, int H, int W,
                                                              int pix_stride, int n_chunks, const float* __restrict__ gscale,
                                                              float* __restrict__ part) {
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_x3_kernel(const float* __rest
       const bool live = ql + t < w1;
       const bool ok = live && combo && (unsigned)(yt + kyj - 1) < (unsigned)H && (unsigned)(xt + kxj - 1) < (unsigned)W;
       xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, ok ? (d + t) * xstep + lane_off : 0xFFFFFFF0u, 0, 0));
+      if (j == 27) xv[t] = live ? 1.f : 0.f;   // column 27 multiplies the gradient by one: the bias gradient, from the same MFMAs
       const uint32_t go = live ? (d + t) * 256u + 4u * j : 0xFFFFFFF0u;
       g0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, go, 0, 0));
       g1[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, live ? go + 128u : go, 0, 0));
@@ -551,26 +553,36 @@ __global__ __launch_bounds__(256) void conv0_wgrad_x3_kernel(const float* __rest
     __syncthreads();
   }
 }
+// A workgroup owns 16 consecutive elements: 16 chunk segments per element (a 64-byte run per segment and chunk, the partials are L2
+// resident), eight loads in flight per thread, segments combined through LDS in a fixed order (deterministic).  (Eight workgroups walking
+// all chunks per element, as this was until round 6, took 49 us at the tail of the training steps' backward chain.)
 __global__ __launch_bounds__(256) void conv0_x3_finalize_kernel(const float* __restrict__ part, int n_chunks, const float* __restrict__ gscale,
-                                                                float* __restrict__ dW) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 64 * 32) return;
-  const int p = i >> 5, t = i & 31;
-  if (t >= 27) return;
-  // eight interleaved chains, then a fixed tree (deterministic): up to 2 048 chunk partials per element, one dependent load each before
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[16][16];
+  const int e = threadIdx.x & 15, seg = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + e;          // < 64 * 32 (grid = 128)
+  const int per = (n_chunks + 15) / 16, c0 = seg * per, c1 = min(n_chunks, c0 + per);
   float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int ch = 0;
-  for (; ch + 8 <= n_chunks; ch += 8)
+  int ch = c0;
+  for (; ch + 8 <= c1; ch += 8)
 #pragma unroll
     for (int k = 0; k < 8; ++k) s8[k] += part[(size_t)(ch + k) * 64 * 32 + i];
-  for (int k = 0; ch < n_chunks; ++ch, ++k) s8[k] += part[(size_t)ch * 64 * 32 + i];
-  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  for (int k = 0; ch < c1; ++ch, ++k) s8[k] += part[(size_t)ch * 64 * 32 + i];
+  red[seg][e] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  __syncthreads();
+  if (seg) return;
+  float s = 0.f;
+  for (int k = 0; k < 16; ++k) s += red[k][e];
+  const int p = i >> 5, t = i & 31;
   const int co = 32 * (p >> 5) + chan_of_pos(p & 31);
-  dW[co * 27 + t] = s * gscale[1] * (1.f / kConvActScale);   // [co][c][ky][kx]
+  const float v = s * gscale[1] * (1.f / kConvActScale);
+  if (t < 27) dW[co * 27 + t] = v;   // [co][c][ky][kx]
+  else if (t == 27 && db) db[co] = v;
 }
 
 hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int W, int pix_stride, float* part, size_t part_floats,
-                              float* dW, hipStream_t s, const float* gscale) {
+                              float* dW, hipStream_t s, const float* gscale, float* db) {
+  if (db && !gscale) return hipErrorInvalidValue;   // (the bias gradient rides the split-f16 kernel only)
   if (gscale) {
     const long long Q = (long long)B * H * W;
     long long n_chunks = (Q + 1023) / 1024;
@@ -578,7 +590,7 @@ hipError_t launch_conv0_wgrad(const float* g, const float* xn, int B, int H, int
     if ((size_t)n_chunks * 64 * 32 > part_floats) return hipErrorInvalidValue;
     if ((unsigned long long)((Q + n_chunks - 1) / n_chunks + W + 64) * 256ull >= (1ull << 31)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(conv0_wgrad_x3_kernel, dim3(int(n_chunks)), dim3(256), 0, s, g, xn, B, H, W, pix_stride, int(n_chunks), gscale, part);
-    hipLaunchKernelGGL(conv0_x3_finalize_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, s, part, int(n_chunks), gscale, dW);
+    hipLaunchKernelGGL(conv0_x3_finalize_kernel, dim3(64 * 32 / 16), dim3(256), 0, s, part, int(n_chunks), gscale, dW, db);
     return hipGetLastError();
   }
 
@@ -618,18 +630,25 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     part[((size_t)chunk * blks + blk) * 32 + pos] = t;
   }
 }
-// One workgroup per 32-channel block: eight chunk lanes per position, combined in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void bias_grad_finalize_kernel(const float* __restrict__ part, int blks, int n_chunks, int cout,
-                                                                 float* __restrict__ db) {
-  __shared__ float red[8][32];
+// One workgroup per 32-channel block: 32 chunk lanes per position with four loads in flight each, combined in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void bias_grad_finalize_kernel(const float* __restrict__ part, int blks, int n_chunks, int cout,
+                                                                  float* __restrict__ db) {
+  __shared__ float red[32][32];
   const int pos = threadIdx.x & 31, cl = threadIdx.x >> 5, blk = blockIdx.x;
-  float s = 0.f;
-  for (int ch = cl; ch < n_chunks; ch += 8) s += part[((size_t)ch * blks + blk) * 32 + pos];
-  red[cl][pos] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int ch = cl;
+  for (; ch + 96 < n_chunks; ch += 128) {
+    s0 += part[((size_t)ch * blks + blk) * 32 + pos];
+    s1 += part[((size_t)(ch + 32) * blks + blk) * 32 + pos];
+    s2 += part[((size_t)(ch + 64) * blks + blk) * 32 + pos];
+    s3 += part[((size_t)(ch + 96) * blks + blk) * 32 + pos];
+  }
+  for (; ch < n_chunks; ch += 32) s0 += part[((size_t)ch * blks + blk) * 32 + pos];
+  red[cl][pos] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (cl == 0) {
     float t = 0.f;
-    for (int i = 0; i < 8; ++i) t += red[i][pos];
+    for (int i = 0; i < 32; ++i) t += red[i][pos];
     const int co = 32 * blk + chan_of_pos(pos);
     if (co < cout) db[co] = t;
   }
@@ -642,61 +661,79 @@ hipError_t launch_bias_grad(const float* g, int B, int H, int W, int cout, float
   if (n_chunks > cap) n_chunks = cap;
   if ((size_t)n_chunks * blks * 32 > part_floats) return hipErrorInvalidValue;
   hipLaunchKernelGGL(bias_grad_kernel, dim3(blks, int(n_chunks)), dim3(256), 0, s, g, Q, blks, int(n_chunks), part);
-  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(blks), dim3(256), 0, s, part, blks, int(n_chunks), cout, db);
+  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(blks), dim3(1024), 0, s, part, blks, int(n_chunks), cout, db);
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ pose head backward
 // forward: relu5_3 act [B,h,w,512] -> pool5 (2x2 max) -> mean over (h/2, w/2) -> fc (feature/dfnet.py:168-170).
-// Given d pose [B,F]: pooled [B,512] (kept for the fc weight gradient), and the gradient w.r.t. act: each pooled
-// pixel's share d_pooled[ch] / (ho wo) goes to the FIRST maximum of its window (torch's max-pool routing).
+// Given d pose [B,F]: the gradient w.r.t. act — each pooled pixel's share d_pooled[ch] / (ho wo) goes to the FIRST maximum of its window
+// (torch's max-pool routing) — and the pooled activation for the fc weight gradient.  One workgroup per (image, pair of rows): the rows'
+// windows and nothing else; the pooled mean is left as per-row-pair partial sums pooled_part[B][(h+1)/2][512] (channel order) that
+// fc_grad_kernel adds in a fixed order.  (One workgroup per image, as this was until round 6, walked the h*w pixels serially: 123 us
+// at the head of the backward chain of both training steps.)
 __global__ __launch_bounds__(512) void pose_head_backward_kernel(const float* __restrict__ act, int h, int w, const float* __restrict__ fc_w,
                                                                  const float* __restrict__ gpose, int feat_dim,
-                                                                 float* __restrict__ pooled_out, float* __restrict__ gact,
+                                                                 float* __restrict__ pooled_part, float* __restrict__ gact,
                                                                  unsigned* __restrict__ absmax_out) {
   const int cpos = threadIdx.x;   // stored position 0..511
   const size_t b = blockIdx.x;
+  const int yo = blockIdx.y, np = gridDim.y;
   const int ho = h / 2, wo = w / 2;
   const int blk = cpos >> 5, e = cpos & 31;
   const int ch = blk * 32 + chan_of_pos(e);
   float dp = 0.f;
   for (int o = 0; o < feat_dim; ++o) dp += gpose[b * feat_dim + o] * fc_w[o * 512 + ch];
   dp /= float(ho * wo);
-  if (absmax_out) {   // bound of |gact| for the split of the gated gradient: one atomicMax per wave
+  if (absmax_out && yo == 0) {   // bound of |gact| for the split of the gated gradient: one atomicMax per wave of the image's first workgroup
     float m = fabsf(dp);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax_out, __float_as_uint(m));
   }
   float sum = 0.f;
-  for (int y = 0; y < h; ++y)
-    for (int x = 0; x < w; ++x) {
-      const int yo = y >> 1, xo = x >> 1;
-      float v = 0.f;
-      if (yo < ho && xo < wo) {
-        const float* s = act + ((b * h + 2 * yo) * (size_t)w + 2 * xo) * 512 + cpos;
-        const float a0 = s[0], a1 = s[512], a2 = s[(size_t)w * 512], a3 = s[(size_t)w * 512 + 512];
-        const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-        const int first = a0 == m ? 0 : (a1 == m ? 1 : (a2 == m ? 2 : 3));
-        if (first == ((y & 1) * 2 + (x & 1))) { v = dp; sum += m; }
-      }
-      gact[((b * h + y) * (size_t)w + x) * 512 + cpos] = v;
+  const float* s0 = act + ((b * h + 2 * yo) * (size_t)w) * 512 + cpos;
+  float* g0 = gact + ((b * h + 2 * yo) * (size_t)w) * 512 + cpos;
+  if (yo < ho) {
+    float* g1 = g0 + (size_t)w * 512;
+    for (int xo = 0; xo < wo; ++xo) {
+      const float* s = s0 + (size_t)xo * 1024;
+      const float a0 = s[0], a1 = s[512], a2 = s[(size_t)w * 512], a3 = s[(size_t)w * 512 + 512];
+      const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+      const int first = a0 == m ? 0 : (a1 == m ? 1 : (a2 == m ? 2 : 3));
+      sum += m;
+      g0[(size_t)xo * 1024] = first == 0 ? dp : 0.f;
+      g0[(size_t)xo * 1024 + 512] = first == 1 ? dp : 0.f;
+      g1[(size_t)xo * 1024] = first == 2 ? dp : 0.f;
+      g1[(size_t)xo * 1024 + 512] = first == 3 ? dp : 0.f;
     }
-  pooled_out[b * 512 + ch] = sum / float(ho * wo);
+    if (w & 1) { g0[(size_t)(w - 1) * 512] = 0.f; g1[(size_t)(w - 1) * 512] = 0.f; }   // a trailing column belongs to no window
+  } else {
+    for (int x = 0; x < w; ++x) g0[(size_t)x * 512] = 0.f;                              // and so does a trailing row
+  }
+  pooled_part[(b * np + yo) * 512 + ch] = sum;
 }
-// dW_fc[o][ch] = sum_b gpose[b][o] pooled[b][ch];  db[o] = sum_b gpose[b][o]
-__global__ __launch_bounds__(512) void fc_grad_kernel(const float* __restrict__ gpose, const float* __restrict__ pooled, int B, int feat_dim,
-                                                      float* __restrict__ dW, float* __restrict__ db) {
+// dW_fc[o][ch] = sum_b gpose[b][o] pooled[b][ch];  db[o] = sum_b gpose[b][o];  pooled[b][ch] = sum of the row-pair partials / (ho wo)
+__global__ __launch_bounds__(512) void fc_grad_kernel(const float* __restrict__ gpose, const float* __restrict__ pooled_part, int B, int np,
+                                                      float inv_windows, int feat_dim, float* __restrict__ dW, float* __restrict__ db) {
   const int ch = threadIdx.x, o = blockIdx.x;
   float s = 0.f, sb = 0.f;
-  for (int b = 0; b < B; ++b) { s += gpose[b * feat_dim + o] * pooled[b * 512 + ch]; sb += gpose[b * feat_dim + o]; }
+  for (int b = 0; b < B; ++b) {
+    float pooled = 0.f;
+    for (int r = 0; r < np; ++r) pooled += pooled_part[((size_t)b * np + r) * 512 + ch];
+    s += gpose[b * feat_dim + o] * (pooled * inv_windows);
+    sb += gpose[b * feat_dim + o];
+  }
   dW[o * 512 + ch] = s;
   if (ch == 0) db[o] = sb;
 }
+// pooled_part: B * ((h + 1) / 2) * 512 floats (pose_head_part_floats)
 hipError_t launch_pose_head_backward(const float* act, int B, int h, int w, const float* fc_w, const float* gpose, int feat_dim,
-                                     float* pooled, float* gact, float* dW_fc, float* db_fc, hipStream_t s, unsigned* absmax_out) {
-  hipLaunchKernelGGL(pose_head_backward_kernel, dim3(B), dim3(512), 0, s, act, h, w, fc_w, gpose, feat_dim, pooled, gact, absmax_out);
-  hipLaunchKernelGGL(fc_grad_kernel, dim3(feat_dim), dim3(512), 0, s, gpose, pooled, B, feat_dim, dW_fc, db_fc);
+                                     float* pooled_part, float* gact, float* dW_fc, float* db_fc, hipStream_t s, unsigned* absmax_out) {
+  const int np = (h + 1) / 2;
+  hipLaunchKernelGGL(pose_head_backward_kernel, dim3(B, np), dim3(512), 0, s, act, h, w, fc_w, gpose, feat_dim, pooled_part, gact, absmax_out);
+  hipLaunchKernelGGL(fc_grad_kernel, dim3(feat_dim), dim3(512), 0, s, gpose, pooled_part, B, np, 1.f / float((h / 2) * (w / 2)), feat_dim, dW_fc,
+                     db_fc);
   return hipGetLastError();
 }
 
