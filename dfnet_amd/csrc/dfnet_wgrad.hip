@@ -748,37 +748,53 @@ __device__ __forceinline__ float pack_source(const float* w, const PackGeom& g, 
   if (co >= g.w_cin || ci >= g.w_cout) return 0.f;                         // padded output channels of the dgrad conv
   return w[(((size_t)ci * g.w_cin + co) * g.ks + (g.ks - 1 - ky)) * g.ks + (g.ks - 1 - kx)];
 }
+// A thread packs the SPC (8, or 1 for fp32 fragments) consecutive slots of one fragment lane: one index decomposition and one 16-byte
+// store per plane instead of eight of each (the per-element form spent the re-pack of a training step, ~30 M elements, on 64-bit
+// divisions and 2-byte stores: 0.17-0.21 ms per step).
 template <int PREC>
 __device__ __forceinline__ void pack_conv_range(const float* __restrict__ w, const PackGeom& g, void* __restrict__ out, size_t first_i, size_t stride) {
   constexpr int SPC = PREC == 1 ? 1 : 8;
-  const int nblk = g.first ? 1 : g.cin / 32, kcb = g.sb / SPC, groups = g.cout / 32 / g.mb;
-  const size_t n = (size_t)groups * nblk * g.ks * g.mb * g.ks * kcb * 64 * SPC;
+  const unsigned nblk = g.first ? 1 : g.cin / 32, kcb = g.sb / SPC, groups = g.cout / 32 / g.mb, ks = g.ks, mb = g.mb;
+  const size_t n = (size_t)groups * nblk * ks * mb * ks * kcb * 64;   // fragment lanes (< 2^32: checked by the launcher)
   for (size_t i = first_i; i < n; i += stride) {
-    size_t r = i;
-    const int j = int(r % SPC); r /= SPC;
-    const int lane = int(r % 64); r /= 64;
+    unsigned r = (unsigned)i;
+    const int lane = int(r & 63); r >>= 6;
     const int kc = int(r % kcb); r /= kcb;
-    const int kx = int(r % g.ks); r /= g.ks;
-    const int m = int(r % g.mb); r /= g.mb;
-    const int ky = int(r % g.ks); r /= g.ks;
+    const int kx = int(r % ks); r /= ks;
+    const int m = int(r % mb); r /= mb;
+    const int ky = int(r % ks); r /= ks;
     const int blk = int(r % nblk);
     const int cg = int(r / nblk);
     const int co = 32 * (cg * g.mb + m) + (lane & 31);
-    const int s = kc * SPC + j, hh = lane >> 5;
-    const int ci = g.first ? ((hh == 0 && s < 3) ? s : -1) : 32 * blk + 4 * hh + (s & 3) + 8 * (s >> 2);
-    const float v = pack_source(w, g, co, ci, ky, kx);
-    if (PREC == 0) static_cast<_Float16*>(out)[i] = (_Float16)v;
-    else if (PREC == 1) static_cast<float*>(out)[i] = v;
-    else {
+    const int hh = lane >> 5;
+    float v[SPC];
+#pragma unroll
+    for (int j = 0; j < SPC; ++j) {
+      const int s = kc * SPC + j;
+      const int ci = g.first ? ((hh == 0 && s < 3) ? s : -1) : 32 * blk + 4 * hh + (s & 3) + 8 * (s >> 2);
+      v[j] = pack_source(w, g, co, ci, ky, kx);
+    }
+    if (PREC == 1) static_cast<float*>(out)[i] = v[0];
+    else if (PREC == 0) {
+      half8 h8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h8[j] = (_Float16)v[j % SPC];
+      *reinterpret_cast<half8*>(static_cast<_Float16*>(out) + i * 8) = h8;
+    } else {
       // layout [cg][blk][ky][kc][hi|lo][mb][kx][lane][8] (dfnet_api.hip: pack_conv_x3)
       const size_t half_slice = (size_t)g.mb * g.ks * 64 * 8;
       const size_t slice = (((size_t)cg * nblk + blk) * g.ks + ky) * kcb + kc;
-      const size_t o = (((size_t)m * g.ks + kx) * 64 + lane) * 8 + j;
+      const size_t o = (((size_t)m * g.ks + kx) * 64 + lane) * 8;
       _Float16* sl = static_cast<_Float16*>(out) + slice * 2 * half_slice;
-      const float vs = v * g.wscale;
-      const _Float16 hi = (_Float16)vs;
-      sl[o] = hi;
-      sl[half_slice + o] = (_Float16)(vs - (float)hi);
+      half8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float vs = v[j % SPC] * g.wscale;
+        hi[j] = (_Float16)vs;
+        lo[j] = (_Float16)(vs - (float)hi[j]);
+      }
+      *reinterpret_cast<half8*>(sl + o) = hi;
+      *reinterpret_cast<half8*>(sl + half_slice + o) = lo;
     }
   }
 }
@@ -806,7 +822,14 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(PackJobs js) {
   else if (j.prec == 1) pack_conv_range<1>(j.w, j.g, j.out, i0, stride);
   else pack_conv_range<2>(j.w, j.g, j.out, i0, stride);
 }
+static bool pack_lanes_fit(const PackGeom& g, int prec) {   // pack_conv_range decomposes the fragment-lane index in 32 bits
+  const int spc = prec == 1 ? 1 : 8;
+  const size_t nblk = g.first ? 1 : g.cin / 32;
+  return (size_t)(g.cout / 32 / g.mb) * nblk * g.ks * g.mb * g.ks * (g.sb / spc) * 64 < (1ull << 32);
+}
 hipError_t launch_pack_multi(const PackJob* jobs, int n_jobs, hipStream_t s) {
+  for (int i = 0; i < n_jobs; ++i)
+    if (jobs[i].kind != 1 && !pack_lanes_fit(jobs[i].g, jobs[i].prec)) return hipErrorInvalidValue;
   for (int at = 0; at < n_jobs; at += kPackJobsPerLaunch) {
     PackJobs js{};
     js.n = n_jobs - at < kPackJobsPerLaunch ? n_jobs - at : kPackJobsPerLaunch;
@@ -818,6 +841,7 @@ hipError_t launch_pack_multi(const PackJob* jobs, int n_jobs, hipStream_t s) {
 hipError_t launch_pack_conv(int prec, const float* w, int cout, int cin, int ks, int first, int sb, int mb, int mode, int w_cout,
                             int w_cin, float wscale, void* out, hipStream_t s) {
   const PackGeom g{cout, cin, ks, first, sb, mb, mode, w_cout, w_cin, wscale};
+  if (!pack_lanes_fit(g, prec)) return hipErrorInvalidValue;
   const dim3 grid(2048), block(256);
   if (prec == 0) hipLaunchKernelGGL(pack_conv_kernel<0>, grid, block, 0, s, w, g, out);
   else if (prec == 1) hipLaunchKernelGGL(pack_conv_kernel<1>, grid, block, 0, s, w, g, out);
