@@ -76,9 +76,12 @@ def timed(fn):
 
 full_ms, loss = timed(step)
 loss = float(loss)
+host_ms = None
+if LOOP:   # host time to ENQUEUE one step on an idle device (nothing to wait for): well under step_ms = the loop is bound by the device
+    torch.cuda.synchronize(); t0 = time.perf_counter(); step(); host_ms = (time.perf_counter() - t0) * 1e3; torch.cuda.synchronize()
 breakdown = {k: v / iters for k, v in parts.items()}
 print(json.dumps({"workload": f"DFNet training step (run_feature.py, triplet loss + RVS), featurenet_batch_size {B} -> {2 * B} siamese + {B} "
                               f"synthesised frames at {H}x{W}, BatchNorm {'frozen' if frozen else 'batch statistics'}",
-                  "step_ms": full_ms, "epoch_loop_without_per_step_waits": LOOP, "frames_per_s": 3 * B / full_ms * 1e3, "breakdown_ms_with_syncs": breakdown, "loss": loss,
+                  "step_ms": full_ms, "epoch_loop_without_per_step_waits": LOOP, "host_enqueue_ms_of_one_step_on_an_idle_device": host_ms, "frames_per_s": 3 * B / full_ms * 1e3, "breakdown_ms_with_syncs": breakdown, "loss": loss,
                   "precision": "split-f16 (f16x3) forward, data-gradient AND weight-gradient products; fp32 accumulate",
                   "triplet_loss": "from the low-resolution pyramid (no enlarged stacks)" if m.pyramid_features else "on materialised [3,B,128,H,W] stacks", "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
