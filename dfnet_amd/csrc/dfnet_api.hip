@@ -67,6 +67,7 @@ struct dfn_dfnet_s {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_buf[3] = {nullptr, nullptr, nullptr};   // backward_params_core: the side stream's last read of a gradient buffer
+  hipEvent_t ev_adapt = nullptr;                         // backward_params_split: the side stream's last read of a level's split operands
 };
 
 static size_t zeros_offset(int feat_dim) { return (size_t(feat_dim) * 513 + 3) & ~size_t(3); }   // floats into h->fc, 16-byte aligned
@@ -137,6 +138,7 @@ extern "C" int dfn_dfnet_destroy(dfn_dfnet_t h) {
   free_dev(h);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_adapt) (void)hipEventDestroy(h->ev_adapt);
   for (hipEvent_t e : h->ev_buf) if (e) (void)hipEventDestroy(e);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
@@ -401,6 +403,7 @@ static int ensure_side(dfn_dfnet_s* h) {
   CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming), "dfnet: side stream");
   CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming), "dfnet: side stream");
   for (hipEvent_t& e : h->ev_buf) CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), "dfnet: side stream");
+  CHECK_HIP(hipEventCreateWithFlags(&h->ev_adapt, hipEventDisableTiming), "dfnet: side stream");
   return DFN_OK;
 }
 
@@ -1075,6 +1078,8 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
   char* gbuf[3] = {w.gA, w.gB, pw.gC};
   bool side_reads[3] = {false, false, false};
   int side_seq[3] = {0, 0, 0}, seq = 0;
+  static const bool adapt_on_side = [] { const char* e = getenv("DFN_ADAPT_WGRAD_SIDE"); return !(e && e[0] == '0'); }();
+  bool side_reads_adapt = false;
   auto fork_side = [&]() -> hipError_t {
     hipError_t e = hipEventRecord(h->ev_fork, s);
     return e != hipSuccess ? e : hipStreamWaitEvent(side, h->ev_fork, 0);
@@ -1133,7 +1138,12 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
       const long long Q = (long long)Bf * hh * ww;
       unsigned* am = pw.amax + 16 + 4 * t;
       float* sl128 = pw.scl_lvl + 16 * t, * sl64 = sl128 + 8;
-      CHECK_HIP(join_side(), "dfnet params: side stream");   // this block's weight gradients use pw.part on the chain's stream
+      // The level's two weight gradients run on the side stream like the encoder's (pw.part stays the side stream's alone), each as soon
+      // as the chain has written its split operand; the chain itself goes on with the data gradients.  Before it overwrites the split
+      // operands of the level before (pw.g128S, w.tmp64) it waits for the side stream's last read of them.
+      if (adapt_on_side && side_reads_adapt) { CHECK_HIP(hipStreamWaitEvent(s, h->ev_adapt, 0), "dfnet params: side stream"); side_reads_adapt = false; }
+      if (!adapt_on_side) CHECK_HIP(join_side(), "dfnet params: side stream");   // (A/B: the block's weight gradients on the chain's stream)
+      hipStream_t ws = adapt_on_side ? side : s;
       if (!have_forward)
         if (int rc = adapt_keep(h, prec, t, Bf, hh, ww, sp.cout, bn_batch != 0, bn_batch != 0, pw, s, nullptr, nullptr)) return rc;
       CHECK_HIP(level_feature_gradient(ts, grad_features, pw, t, h->n_taps, Bf, hh, ww, upH, upW, w.g128, s), "dfnet params: upsample backward");
@@ -1143,8 +1153,9 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
                 "dfnet params: BatchNorm backward");
       CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g128), 0, nullptr, 0, nullptr, Bf, hh, ww, 4, am, nullptr, pw.g128S, 1, sl128, s),
                 "dfnet params: split d z");
+      if (adapt_on_side) CHECK_HIP(fork_side(), "dfnet params: side stream");
       CHECK_HIP(launch_conv_wgrad_split(5, pw.g128S, pw.lvl_tmp64[t], zeros, Bf, hh, ww, 128, 64, pw.part, pw.part_floats, pw.part_b,
-                                        pw.part_b_floats, ag[2], ag[3], sl128, s),
+                                        pw.part_b_floats, ag[2], ag[3], sl128, ws),
                 "dfnet params: adapt 5x5 weight gradient");
       ConvArgs c{};
       const PackedConv& d5 = h->ad5_raw_dgrad[t];
@@ -1156,9 +1167,11 @@ int backward_params_split(dfn_dfnet_t h, const float* x, int B, int H, int W, co
       CHECK_HIP(launch_gate_split(reinterpret_cast<const float*>(w.g64), 0, pw.lvl_tmp64[t], 1, nullptr, Bf, hh, ww, 2, am + 1, nullptr, w.tmp64, 1,
                                   sl64, s),
                 "dfnet params: adapt gate");
+      if (adapt_on_side) CHECK_HIP(fork_side(), "dfnet params: side stream");
       CHECK_HIP(launch_conv_wgrad_split(1, w.tmp64, w.tap[t], zeros, Bf, hh, ww, 64, sp.cout, pw.part, pw.part_floats, pw.part_b,
-                                        pw.part_b_floats, ag[0], ag[1], sl64, s),
+                                        pw.part_b_floats, ag[0], ag[1], sl64, ws),
                 "dfnet params: adapt 1x1 weight gradient");
+      if (adapt_on_side) { CHECK_HIP(hipEventRecord(h->ev_adapt, side), "dfnet params: side stream"); side_reads_adapt = true; }
       ConvArgs d{};
       d.in = w.tmp64; d.w = h->ad1_dgrad[t].w[prec]; d.bias = h->ad1_dgrad[t].bias; d.out_scale = h->ad1_dgrad[t].out_scale; d.out_pre = w.gtap;
       d.in_split = 1; d.zeros = zeros; d.dyn_scale = sl64; d.absmax_out = am + 2;
