@@ -2,6 +2,7 @@
 // parameter intake with the reference's state_dict names, BatchNorm folding, packing of every
 // convolution into MFMA A-fragments (both precisions), and the forward driver.
 #include <hip/hip_runtime.h>
+#include <functional>
 
 #include <cmath>
 #include <cstring>
@@ -975,8 +976,9 @@ namespace {
 // operands the next conv, the data-gradient chain and the weight-gradient stream multiply, split once by the producing epilogue —
 // except conv1_1's fp32 input (its weight gradient gathers RGB taps) and relu5_3 (the pose head reads fp32); a conv followed by
 // the 2x2 max pool also writes the pooled activation (pw.pooledS).
+// on_tap (optional): called right after the conv whose pre-ReLU output is level t's tap has been launched — (layer index) -> rc.
 int encoder_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, int tap_mask, const DfParamWs& pw, hipStream_t s,
-                 int* lay_h, int* lay_w) {
+                 int* lay_h, int* lay_w, const std::function<int(int)>* on_tap = nullptr) {
   const DfBwdWs& w = pw.b;
   const int n_enc = int(h->enc.size());
   const bool split = prec == 2;
@@ -1000,6 +1002,8 @@ int encoder_keep(dfn_dfnet_t h, int prec, const float* x, int B, int H, int W, i
       if (pool_next) a.out_pool = pw.pooledS[i];
     }
     CHECK_HIP(launch_conv(prec, 3, i == 0 ? prep_sb(prec) : 16, a, s), "dfnet train: encoder conv");
+    if (on_tap && a.out_pre)
+      if (int rc = (*on_tap)(i)) return rc;
     cur = w.act[i];
     nblk = sp.cout / 32;
     if (pool_next) {
@@ -1460,33 +1464,55 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
   for (size_t i = 0; i < h->kept.size();)   // this workspace is being overwritten
     if (h->kept[i].ws == workspace) h->kept.erase(h->kept.begin() + i); else ++i;
   int lay_h[13], lay_w[13];
-  if (int rc = encoder_keep(h, prec, x, B, H, W, levels ? (1 << h->n_taps) - 1 : 0, pw, s, lay_h, lay_w)) return rc;
   const int n_enc = int(h->enc.size());
   const size_t plane = size_t(128) * upH * upW;
-  for (int i = 0; i < n_enc; ++i) {
+  // A level's adaptation branch (1x1, 5x5, BatchNorm statistics, enlargement) needs its tap only: it starts on the handle's side stream
+  // as soon as the tapped conv is launched and runs beside the rest of the encoder, whose deep layers' small grids leave CUs idle
+  // (as the inference forward does for levels 1-2, forward_core); the branches share pw.bn_part in the side stream's order.
+  // DFN_ADAPT_FWD_SIDE=0: after the encoder on the caller's stream, for A/B.
+  static const bool branches_beside = [] { const char* e = getenv("DFN_ADAPT_FWD_SIDE"); return !(e && e[0] == '0'); }();
+  hipStream_t bs = s;
+  SideJoin side_join{h, s, false};
+  if (levels && branches_beside) {
+    if (int rc = ensure_side(h)) return rc;
+    bs = h->side;
+  }
+  auto level_branch = [&](int i) -> int {
     const int t = h->enc[i].tap;
-    if (t < 0 || !levels) continue;   // no features: the pose path only (its backward needs no adaptation layers)
     const int hh = lay_h[i], ww = lay_w[i];
-    if (int rc = adapt_keep(h, prec, t, Bf, hh, ww, h->enc[i].cout, bn_batch != 0, true, pw, s, bn_batch ? bn_stats + size_t(t) * 256 : nullptr,
+    if (bs != s) {
+      CHECK_HIP(hipEventRecord(h->ev_fork, s), "dfnet train: side stream");
+      CHECK_HIP(hipStreamWaitEvent(bs, h->ev_fork, 0), "dfnet train: side stream");
+      side_join.armed = true;
+    }
+    if (int rc = adapt_keep(h, prec, t, Bf, hh, ww, h->enc[i].cout, bn_batch != 0, true, pw, bs, bn_batch ? bn_stats + size_t(t) * 256 : nullptr,
                             bn_batch ? bn_stats + size_t(t) * 256 + 128 : nullptr))
       return rc;
-    if (pyramid_only) continue;
+    if (pyramid_only) return DFN_OK;
     if (!siamese) {
-      CHECK_HIP(launch_upsample(prec, pw.lvl_z[t], B, hh, ww, upH, upW, features + size_t(t) * B * plane, plane, s, pw.lvl_bn[t]),
+      CHECK_HIP(launch_upsample(prec, pw.lvl_z[t], B, hh, ww, upH, upW, features + size_t(t) * B * plane, plane, bs, pw.lvl_bn[t]),
                 "dfnet train: upsample");
     } else {
       const int hb = B / 2;
       for (int half = 0; half < 2; ++half)
         CHECK_HIP(launch_upsample(prec, pw.lvl_z[t] + size_t(half) * hb * hh * ww * 128, hb, hh, ww, upH, upW,
-                                  features + (size_t(half) * h->n_taps + t) * hb * plane, plane, s, pw.lvl_bn[t]),
+                                  features + (size_t(half) * h->n_taps + t) * hb * plane, plane, bs, pw.lvl_bn[t]),
                   "dfnet train: upsample");
     }
-  }
+    return DFN_OK;
+  };
+  const std::function<int(int)> on_tap = level_branch;
+  if (int rc = encoder_keep(h, prec, x, B, H, W, levels ? (1 << h->n_taps) - 1 : 0, pw, s, lay_h, lay_w, levels ? &on_tap : nullptr)) return rc;
   if (return_pose) {
     if (lay_h[n_enc - 1] < 2 || lay_w[n_enc - 1] < 2) return set_error(DFN_ERR_ARG, "%s: image too small for pool5", fn);
     CHECK_HIP(launch_pose_head(prec, pw.b.act[n_enc - 1], B, lay_h[n_enc - 1], lay_w[n_enc - 1], h->fc, h->fc + size_t(h->feat_dim) * 512,
                                h->feat_dim, pose, s),
               "dfnet train: pose head");
+  }
+  if (side_join.armed) {
+    side_join.armed = false;
+    CHECK_HIP(hipEventRecord(h->ev_join, h->side), "dfnet train: side stream");
+    CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0), "dfnet train: side stream");
   }
   if (h->kept.size() >= 8) h->kept.erase(h->kept.begin());
   h->kept.push_back({workspace, prec, B, H, W, levels ? (bn_batch ? 1 : 0) : -1});   // -1: no feature gradients from this state
