@@ -1660,17 +1660,17 @@ int refresh_core(dfn_dfnet_t h, const float* const* params, int n_params, bool w
       if (int rc = refresh_conv(h->ad1[t], h->ad1_dgrad[t], ap[0], ap[1], 64, h->tap_channels[t], 1, false, prec_mask, jobs)) return rc;
       if (int rc = refresh_conv(h->ad5_raw[t], h->ad5_raw_dgrad[t], ap[2], ap[3], 128, 64, 5, false, prec_mask, jobs)) return rc;
     }
+  // the plain fp32 copies the kernels read (fc weight | bias, per level gamma, beta, running_mean, running_var) ride in the same launches
+  auto copy_job = [&](const float* src, float* dst, int n) { jobs.push_back(PackJob{src, dst, PackGeom{n, 0, 0, 0, 0, 0, 0, 0, 0, 1.f}, 0, 2}); };
+  copy_job(params[2 * n_enc], h->fc, h->feat_dim * 512);
+  copy_job(params[2 * n_enc + 1], h->fc + size_t(h->feat_dim) * 512, h->feat_dim);
+  if (with_adapt)
+    for (int t = 0; t < h->n_taps; ++t) {
+      const float* const* ap = params + 2 * n_enc + 2 + 8 * t;
+      for (int k = 0; k < 4; ++k) copy_job(ap[4 + k], h->bn_dev[t] + 128 * k, 128);
+    }
   CHECK_HIP(launch_pack_multi(jobs.data(), int(jobs.size()), s), "refresh: multi-tensor pack");
-  CHECK_HIP(hipMemcpyAsync(h->fc, params[2 * n_enc], size_t(h->feat_dim) * 512 * 4, hipMemcpyDeviceToDevice, s), "refresh: fc weight");
-  CHECK_HIP(hipMemcpyAsync(h->fc + size_t(h->feat_dim) * 512, params[2 * n_enc + 1], size_t(h->feat_dim) * 4, hipMemcpyDeviceToDevice, s),
-            "refresh: fc bias");
   h->fresh_mask = prec_mask;   // the weights moved: fragments of the other precisions are stale from here on
-  if (!with_adapt) return DFN_OK;
-  for (int t = 0; t < h->n_taps; ++t) {
-    const float* const* ap = params + 2 * n_enc + 2 + 8 * t;
-    for (int k = 0; k < 4; ++k)   // gamma, beta, running_mean, running_var
-      CHECK_HIP(hipMemcpyAsync(h->bn_dev[t] + 128 * k, ap[4 + k], 128 * 4, hipMemcpyDeviceToDevice, s), "refresh: BatchNorm");
-  }
   return DFN_OK;
 }
 }  // namespace

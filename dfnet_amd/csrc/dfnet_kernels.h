@@ -200,7 +200,7 @@ hipError_t launch_pack_bias(const float* b, int cout, float scale, float* out, h
 // The same, many tensors per launch.  kind 0: conv fragments of precision `prec` (g as for launch_pack_conv); kind 1: bias
 // (g.cout = channels, g.wscale = scale).
 struct PackGeom { int cout, cin, ks, first, sb, mb, mode, w_cout, w_cin; float wscale; };
-struct PackJob { const float* w; void* out; PackGeom g; int prec, kind; };
+struct PackJob { const float* w; void* out; PackGeom g; int prec, kind; };   // kind 0: conv fragments, 1: bias in C-fragment order, 2: plain copy of g.cout floats
 hipError_t launch_pack_multi(const PackJob* jobs, int n_jobs, hipStream_t s);
 
 }  // namespace dfn

@@ -818,6 +818,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(PackJobs js) {
   const PackJob& j = js.job[blockIdx.y];
   const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
   if (j.kind == 1) { pack_bias_range(j.w, j.g.cout, j.g.wscale, static_cast<float*>(j.out), i0, stride); return; }
+  if (j.kind == 2) {   // plain copy of g.cout floats (fc weights, BatchNorm vectors: a dozen 5 us device-to-device copies per step otherwise)
+    for (size_t i = i0; i < (size_t)j.g.cout; i += stride) static_cast<float*>(j.out)[i] = j.w[i];
+    return;
+  }
   if (j.prec == 0) pack_conv_range<0>(j.w, j.g, j.out, i0, stride);
   else if (j.prec == 1) pack_conv_range<1>(j.w, j.g, j.out, i0, stride);
   else pack_conv_range<2>(j.w, j.g, j.out, i0, stride);
@@ -829,7 +833,7 @@ static bool pack_lanes_fit(const PackGeom& g, int prec) {   // pack_conv_range d
 }
 hipError_t launch_pack_multi(const PackJob* jobs, int n_jobs, hipStream_t s) {
   for (int i = 0; i < n_jobs; ++i)
-    if (jobs[i].kind != 1 && !pack_lanes_fit(jobs[i].g, jobs[i].prec)) return hipErrorInvalidValue;
+    if (jobs[i].kind == 0 && !pack_lanes_fit(jobs[i].g, jobs[i].prec)) return hipErrorInvalidValue;
   for (int at = 0; at < n_jobs; at += kPackJobsPerLaunch) {
     PackJobs js{};
     js.n = n_jobs - at < kPackJobsPerLaunch ? n_jobs - at : kPackJobsPerLaunch;
