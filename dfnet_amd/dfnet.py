@@ -312,13 +312,23 @@ class _DFNetBase(nn.Module):
         variance with the module's momentum; stats [n_taps, 2, 128] = mean, biased variance."""
         B, _, H, W = xshape
         with torch.no_grad():
-            for t, scale in enumerate(self.scales):
-                bn = getattr(self.adaptation_layers, "adapt_layer_{}".format(t))[3]
-                n = B * (H // scale) * (W // scale)
-                mom = 0.1 if bn.momentum is None else bn.momentum
-                bn.running_mean.mul_(1 - mom).add_(stats[t, 0].to(bn.running_mean.device), alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(stats[t, 1].to(bn.running_var.device), alpha=mom * n / max(n - 1, 1))
-                bn.num_batches_tracked += 1
+            bns = [getattr(self.adaptation_layers, "adapt_layer_{}".format(t))[3] for t in range(len(self.scales))]
+            ns = [B * (H // scale) * (W // scale) for scale in self.scales]
+            moms = [0.1 if bn.momentum is None else bn.momentum for bn in bns]
+            if stats.is_cuda and len(set(moms)) == 1 and all(b.device == stats.device for bn in bns for b in (bn.running_mean, bn.running_var)):
+                # the same update for all levels in five multi-tensor launches instead of five per level
+                mom = moms[0]
+                means, variances = [bn.running_mean for bn in bns], [bn.running_var for bn in bns]
+                torch._foreach_mul_(means + variances, 1 - mom)
+                torch._foreach_add_(means, list(stats[:, 0].unbind(0)), alpha=mom)
+                torch._foreach_add_(variances, torch._foreach_mul(list(stats[:, 1].unbind(0)), [mom * n / max(n - 1, 1) for n in ns]))
+                torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+            else:
+                for t, bn in enumerate(bns):
+                    bn.running_mean.mul_(1 - moms[t]).add_(stats[t, 0].to(bn.running_mean.device), alpha=moms[t])
+                    bn.running_var.mul_(1 - moms[t]).add_(stats[t, 1].to(bn.running_var.device), alpha=moms[t] * ns[t] / max(ns[t] - 1, 1))
+                    bn.num_batches_tracked += 1
+            for t, bn in enumerate(bns):
                 if self._engine_version is not None:
                     # Only a frozen-BatchNorm forward and the folded inference weights read the engine's copy of these buffers: mark it
                     # stale instead of letting the version bump re-pack all 52 tensors before the step's next kernel call.
