@@ -919,21 +919,25 @@ DfParamWs carve_df_params(const dfn_dfnet_s* h, char* base, int prec, int B, int
   w.part_b_floats = 0;
   const int div[3] = {1, 4, 16};
   if (prec == 2) {
-    auto need = [&](int ks, int hh, int ww, int cout, int cin) {
+    auto need = [&](int ks, int hh, int ww, int cout, int cin, int b_min) {
       if (cout % 64 || cin % 64) return;
-      size_t pf, pb;
-      conv_wgrad_split_scratch(ks, B, hh, ww, cout, cin, &pf, &pb);
-      if (pf > w.part_floats) w.part_floats = pf;
-      if (pb > w.part_b_floats) w.part_b_floats = pb;
+      // (the chunk count of a layer's plan is not monotonic in the batch: frames per workgroup vs chunks per frame)
+      for (int b = b_min; b <= B; ++b) {
+        size_t pf, pb;
+        conv_wgrad_split_scratch(ks, b, hh, ww, cout, cin, &pf, &pb);
+        if (pf > w.part_floats) w.part_floats = pf;
+        if (pb > w.part_b_floats) w.part_b_floats = pb;
+      }
     };
     int ch = H, cw = W;
     for (size_t i = 0; i < h->enc.size(); ++i) {
-      if (i > 0) need(3, ch, cw, h->enc[i].cout, h->enc[i].cin);
+      if (i > 0) need(3, ch, cw, h->enc[i].cout, h->enc[i].cin, B);
       if (h->enc[i].pool_after) { ch /= 2; cw /= 2; }
     }
     for (int t = 0; t < h->n_taps; ++t) {
-      need(5, H / div[t], W / div[t], 128, 64);
-      need(1, H / div[t], W / div[t], 64, h->tap_channels[t]);
+      // the adaptation layers may run on the leading feature_images <= B frames of the batch (forward_train_keep)
+      need(5, H / div[t], W / div[t], 128, 64, 1);
+      need(1, H / div[t], W / div[t], 64, h->tap_channels[t], 1);
     }
   }
   w.part = take(w.part_floats * 4);
