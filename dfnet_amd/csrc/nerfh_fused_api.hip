@@ -522,18 +522,6 @@ Ws carve(char* base, const dfn_nerfh_desc& d, size_t R, int Nc, int Ni, bool spl
 // therefore keeps the largest |w| at ~1): the chains scale in fp32 first, so their weights sit where every lo half is a normal f16.
 float train_scale(const dfn_nerfh_s* h, bool fine) { return h->net[fine][2][0].in_scale * 1024.f; }
 
-int pack_blob(const DevBlob& d, const float* const* params, float in_scale, int* status, hipStream_t s) {
-  PackArgs a{};
-  a.welem = d.welem; a.n_welem = d.n_w;
-  a.belem = d.belem; a.n_belem = d.n_b;
-  a.blob = d.blob;
-  a.wscale = in_scale / kX3ActScale;
-  a.bscale = in_scale;
-  for (int i = 0; i < 64; ++i) a.params[i] = params[i];
-  a.status = status;
-  CHECK_HIP(launch_pack(a, s), "fused training: weight packing");
-  return DFN_OK;
-}
 ChainArgs chain_args(const dfn_nerfh_s* h, const State& st, bool fine, int pass, const NetWs& n, const float* o, const float* d, size_t R,
                      int Ns) {
   ChainArgs a{};
@@ -580,9 +568,18 @@ int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_
             "train forward: fine ray inputs");
   CHECK_HIP(hipMemsetAsync(h->range_flag + 2, 0, sizeof(int), s), "train forward: clearing the step's range word");
   // the step's weights -> staging units of the four chain passes (hi | lo split at the handle's operand scale)
-  for (int f = 0; f < 2; ++f)
-    for (int pass = 0; pass < 2; ++pass)
-      if (int rc = pack_blob(st.blob[f][pass], params, train_scale(h, f), h->range_flag + 2, s)) return rc;
+  {
+    PackArgs4 pa{};
+    for (int f = 0; f < 2; ++f)
+      for (int pass = 0; pass < 2; ++pass) {
+        const DevBlob& d = st.blob[f][pass];
+        const float in_scale = train_scale(h, f);
+        pa.b[2 * f + pass] = PackBlob{d.welem, d.n_w, d.belem, d.n_b, d.blob, in_scale / kX3ActScale, in_scale};
+      }
+    for (int i = 0; i < 64; ++i) pa.params[i] = params[i];
+    pa.status = h->range_flag + 2;
+    CHECK_HIP(launch_pack4(pa, s), "fused training: weight packing");
+  }
   CHECK_HIP(launch_ray_bias_train(pc[2 * DIR], pc[2 * DIR + 1], W + g.kd_c, g.kd_c, w.dir_c, g.ld_dc, nullptr, nullptr, 0, 0, nullptr, 0, R,
                                   w.net[0].ray_bias, s),
             "train forward: coarse per-ray bias");

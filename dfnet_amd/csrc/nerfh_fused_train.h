@@ -119,15 +119,10 @@ constexpr uint32_t kWgradLdsBytes = 81920;    // staging ring of one stream work
 
 // ---- per-step packing of the master weights into the chain kernels' staging units
 struct PackElem { uint32_t off; int32_t src; };    // f16 element: hi at blob + off, lo at + 1024; src = param << 20 | index, < 0: zero
-struct PackArgs {
-  const PackElem* welem; int n_welem;
-  const PackElem* belem; int n_belem;              // fp32 bias element at blob + off
-  char* blob;
-  float wscale, bscale;
-  const float* params[64];
-  int* status;
-};
-hipError_t launch_pack(const PackArgs& a, hipStream_t s);
+// the four unit blobs of a step (coarse / fine x forward / backward) in ONE launch: blockIdx.y = blob
+struct PackBlob { const PackElem* welem; int n_welem; const PackElem* belem; int n_belem; char* blob; float wscale, bscale; };
+struct PackArgs4 { PackBlob b[4]; const float* params[64]; int* status; };
+hipError_t launch_pack4(const PackArgs4& a, hipStream_t s);
 
 // The step's range word (dfn_nerfh_s::range_flag + 2: raised by this step's pack / chain kernels only) decides what the step leaves in
 // the gradient tensors: non-zero -> every gradient is ZEROED (a skipped step, as a loss scaler skips a step whose gradients

@@ -265,8 +265,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs a, int tot
   const int m = a.map[jb.map_off + b * 1024 + e];
   if (m < 0) return;
   const float* src = jb.partial + size_t(b) * 1024 + e;
-  float sum = 0.f;
-  for (int c = 0; c < jb.n_chunks; ++c) sum += src[size_t(c) * nblk * 1024];
+  // four interleaved chains, then a fixed tree (deterministic): the chunk loads of a thread are in flight together
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  const size_t cstride = size_t(nblk) * 1024;
+  int c = 0;
+  for (; c + 4 <= jb.n_chunks; c += 4)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s4[k] += src[size_t(c + k) * cstride];
+  for (int k = 0; c < jb.n_chunks; ++c, ++k) s4[k] += src[size_t(c) * cstride];
+  const float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   const bool bias = (b % nbx1) == jb.nb_x;
   a.grads[m >> 20][m & 0xfffff] = bias ? sum : sum * (1.f / kX3ActScale);
 }
@@ -297,33 +304,34 @@ hipError_t launch_grads_guard(const GuardArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------ per-step weight packing
 // Every f16 fragment element of a chain blob is one master weight (or zero): hi = f16(w x wscale), lo = f16(w x wscale - hi), as
 // the host packer of nerfh_api.hip writes them at commit; the bias fragments are fp32 x bscale.
-__global__ __launch_bounds__(256) void pack_units_kernel(PackArgs a) {
+__global__ __launch_bounds__(256) void pack_units4_kernel(PackArgs4 a) {
+  const PackBlob& b = a.b[blockIdx.y];
   const int stride = gridDim.x * blockDim.x;
   bool over = false;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_welem; i += stride) {
-    const PackElem e = a.welem[i];
-    const float v = e.src >= 0 ? a.params[e.src >> 20][e.src & 0xfffff] * a.wscale : 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n_welem; i += stride) {
+    const PackElem e = b.welem[i];
+    const float v = e.src >= 0 ? a.params[e.src >> 20][e.src & 0xfffff] * b.wscale : 0.f;
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     over |= !(fabsf(v) < 65504.f);
-    *reinterpret_cast<_Float16*>(a.blob + e.off) = hi;
-    *reinterpret_cast<_Float16*>(a.blob + e.off + 1024) = lo;
+    *reinterpret_cast<_Float16*>(b.blob + e.off) = hi;
+    *reinterpret_cast<_Float16*>(b.blob + e.off + 1024) = lo;
   }
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_belem; i += stride) {
-    const PackElem e = a.belem[i];
-    *reinterpret_cast<float*>(a.blob + e.off) = e.src >= 0 ? a.params[e.src >> 20][e.src & 0xfffff] * a.bscale : 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n_belem; i += stride) {
+    const PackElem e = b.belem[i];
+    *reinterpret_cast<float*>(b.blob + e.off) = e.src >= 0 ? a.params[e.src >> 20][e.src & 0xfffff] * b.bscale : 0.f;
   }
   if (over && a.status) atomicOr(a.status, 2);   // a weight left the range of the split-f16 operand scale (DFN_RANGE_X3_SATURATED)
 }
-hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
-  const int n = a.n_welem > a.n_belem ? a.n_welem : a.n_belem;
+hipError_t launch_pack4(const PackArgs4& a, hipStream_t s) {
+  int n = 0;
+  for (const PackBlob& b : a.b) { n = b.n_welem > n ? b.n_welem : n; n = b.n_belem > n ? b.n_belem : n; }
   if (n <= 0) return hipSuccess;
   int grid = (n + 255) / 256;
   grid = grid > 1024 ? 1024 : grid;
-  hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(pack_units4_kernel, dim3(grid, 4), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-
 // ------------------------------------------------------------------------------------------ per-ray bias tables from the master weights
 // What launch_ray_bias (nerfh_stages.hip) computes from the committed copies, here from the step's own parameters and the per-ray
 // inputs the training path already forms (nerfh_train.hip: ray_inputs).  64 outputs per table (netwidth 128).
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(128) void ray_bias_train_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_wd = sm;               // [kd][64]
   float* s_wt = sm + kd * 64;     // [nt][64]
+  float* s_in = s_wt + (w_te ? nt * 64 : 0);   // [kd + nt] the ray's inputs: one coalesced load per ray instead of kd dependent broadcast loads
   // consecutive threads read consecutive columns of a weight row (coalesced); the transposition happens in the LDS store
   for (int i = threadIdx.x; i < kd * 64; i += blockDim.x) { const int f = i / kd, jj = i - f * kd; s_wd[jj * 64 + f] = w_dir[size_t(f) * ldw_dir + kWidth + jj]; }
   if (w_te)
@@ -343,25 +352,25 @@ __global__ __launch_bounds__(128) void ray_bias_train_kernel(const float* __rest
   const int tbl = threadIdx.x >> 6, f = threadIdx.x & 63;
   const int mb = f >> 5, row = f & 31, hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
   const int slot = ((tbl * 2 + mb) * 2 + hh) * 16 + r;
+  const float bias = tbl == 0 ? b_dir[f] : (w_te ? b_te[f] : 0.f);
   for (size_t ray = blockIdx.x; ray < R; ray += gridDim.x) {
-    float acc = 0.f;
+    for (int i = threadIdx.x; i < kd + (w_te ? nt : 0); i += blockDim.x) s_in[i] = i < kd ? dir_in[ray * ld_dir + i] : t_in[ray * ld_t + (i - kd)];
+    __syncthreads();
+    float acc = bias;
     if (tbl == 0) {
-      acc = b_dir[f];
-      const float* in = dir_in + ray * ld_dir;
-      for (int jj = 0; jj < kd; ++jj) acc = fmaf(s_wd[jj * 64 + f], in[jj], acc);
+      for (int jj = 0; jj < kd; ++jj) acc = fmaf(s_wd[jj * 64 + f], s_in[jj], acc);
     } else if (w_te) {
-      acc = b_te[f];
-      const float* in = t_in + ray * ld_t;
-      for (int jj = 0; jj < nt; ++jj) acc = fmaf(s_wt[jj * 64 + f], in[jj], acc);
+      for (int jj = 0; jj < nt; ++jj) acc = fmaf(s_wt[jj * 64 + f], s_in[kd + jj], acc);
     }
     table[ray * kRayBiasFloats + slot] = acc;
+    __syncthreads();   // (the next ray's inputs overwrite s_in)
   }
 }
 hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw_dir, int kd, const float* dir_in, int ld_dir,
                                  const float* w_te, const float* b_te, int ldw_te, int nt, const float* t_in, int ld_t, size_t R,
                                  float* table, hipStream_t s) {
   if (!R) return hipSuccess;
-  const size_t lds = size_t(kd + (w_te ? nt : 0)) * 64 * sizeof(float);
+  const size_t lds = (size_t(kd + (w_te ? nt : 0)) * 64 + size_t(kd + (w_te ? nt : 0))) * sizeof(float);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   const int grid = int(R < 512 ? R : 512);
   hipLaunchKernelGGL(ray_bias_train_kernel, dim3(grid), dim3(128), lds, s, w_dir, b_dir, ldw_dir, kd, dir_in, ld_dir, w_te, b_te, ldw_te,

@@ -1252,12 +1252,21 @@ __global__ __launch_bounds__(256) void embedding_scatter_kernel(const float* __r
   __shared__ float acc[1024];
   const int per = hist_bin * dim;
   if (hist_rows == 1 && per <= 1024) {
-    for (int j = threadIdx.x; j < per; j += blockDim.x) acc[j] = 0.f;
-    __syncthreads();
     const size_t r0 = size_t(blockIdx.x) * 64, r1 = r0 + 64 < R ? r0 + 64 : R;
+    // all 256 threads: thread (entry j, ray phase q) sums every nq-th ray of the block's 64 (was: `per` threads walking all 64 with one
+    // dependent load each), the phases meet in LDS
+    const int nq = per <= 256 ? 256 / per : 1;
+    __shared__ float part[1024];
+    for (int idx = threadIdx.x; idx < per * nq; idx += blockDim.x) {
+      const int j = idx % per, q = idx / per;
+      float s = 0.f;
+      for (size_t r = r0 + q; r < r1; r += nq) s += g_in[r * ld + off + j];
+      part[idx] = s;
+    }
+    __syncthreads();
     for (int j = threadIdx.x; j < per; j += blockDim.x) {
       float s = 0.f;
-      for (size_t r = r0; r < r1; ++r) s += g_in[r * ld + off + j];
+      for (int q = 0; q < nq; ++q) s += part[q * per + j];   // fixed order
       acc[j] = s;
     }
     __syncthreads();
