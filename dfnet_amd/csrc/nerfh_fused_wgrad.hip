@@ -344,10 +344,27 @@ __global__ __launch_bounds__(128) void ray_bias_train_kernel(const float* __rest
   float* s_wd = sm;               // [kd][64]
   float* s_wt = sm + kd * 64;     // [nt][64]
   float* s_in = s_wt + (w_te ? nt * 64 : 0);   // [kd + nt] the ray's inputs: one coalesced load per ray instead of kd dependent broadcast loads
-  // consecutive threads read consecutive columns of a weight row (coalesced); the transposition happens in the LDS store
-  for (int i = threadIdx.x; i < kd * 64; i += blockDim.x) { const int f = i / kd, jj = i - f * kd; s_wd[jj * 64 + f] = w_dir[size_t(f) * ldw_dir + kWidth + jj]; }
-  if (w_te)
-    for (int i = threadIdx.x; i < nt * 64; i += blockDim.x) { const int f = i / nt, jj = i - f * nt; s_wt[jj * 64 + f] = w_te[size_t(f) * ldw_te + kWidth + jj]; }
+  // consecutive threads read consecutive columns of a weight row (coalesced); the transposition happens in the LDS store.  Eight loads
+  // of a thread are in flight together: one load -> one store at a time, this staging (38 + 10 dependent round trips per block) was
+  // most of the kernel's 23 us.
+  auto stage = [&](const float* __restrict__ wsrc, int ldw, int k, float* dst) {
+    const int n = k * 64, bd = blockDim.x;
+    for (int base = threadIdx.x; base < n; base += bd * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * bd, f = i / k, jj = i - f * k;
+        v[u] = i < n ? wsrc[size_t(f) * ldw + kWidth + jj] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * bd, f = i / k, jj = i - f * k;
+        if (i < n) dst[jj * 64 + f] = v[u];
+      }
+    }
+  };
+  stage(w_dir, ldw_dir, kd, s_wd);
+  if (w_te) stage(w_te, ldw_te, nt, s_wt);
   __syncthreads();
   const int tbl = threadIdx.x >> 6, f = threadIdx.x & 63;
   const int mb = f >> 5, row = f & 31, hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
@@ -372,7 +389,7 @@ hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw
   if (!R) return hipSuccess;
   const size_t lds = (size_t(kd + (w_te ? nt : 0)) * 64 + size_t(kd + (w_te ? nt : 0))) * sizeof(float);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  const int grid = int(R < 512 ? R : 512);
+  const int grid = int(R < 256 ? R : 256);   // one workgroup per CU: every workgroup stages the weights once
   hipLaunchKernelGGL(ray_bias_train_kernel, dim3(grid), dim3(128), lds, s, w_dir, b_dir, ldw_dir, kd, dir_in, ld_dir, w_te, b_te, ldw_te,
                      nt, t_in, ld_t, R, table);
   return hipGetLastError();

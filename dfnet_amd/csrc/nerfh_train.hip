@@ -1022,8 +1022,22 @@ __global__ __launch_bounds__(256) void sample_fine_train_kernel(const float* __r
       sq = wave_sum(sq);
       if (lane == 0) z_std[ray] = sqrtf(sq / float(Ni));
     }
-    // sort the samples (random u: arbitrary order) by odd-even transposition, then merge with the sorted coarse depths by rank
-    for (int guard = 0; guard < Ni; ++guard) {
+    // sort the samples (random u: arbitrary order), then merge with the sorted coarse depths by rank.  A power-of-two count (the
+    // reference's 128) takes a bitonic network — log2(Ni) (log2(Ni) + 1) / 2 = 28 wave-wide compare-exchange steps; any other count
+    // the odd-even transposition below (up to Ni double steps).  The sorted sequence does not depend on the network.
+    const bool pow2 = (Ni & (Ni - 1)) == 0;
+    if (pow2) {
+      for (int k = 2; k <= Ni; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = lane; t < (Ni >> 1); t += 64) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+            const float a = zs[i], b = zs[l];
+            if ((a > b) == ((i & k) == 0)) { zs[i] = b; zs[l] = a; }
+          }
+          wave_sync();
+        }
+    }
+    for (int guard = 0; guard < Ni && !pow2; ++guard) {
       bool swapped = false;
       for (int phase = 0; phase < 2; ++phase) {
         for (int k = 2 * lane + phase; k + 1 < Ni; k += 128) {

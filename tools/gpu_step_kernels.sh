@@ -1,7 +1,7 @@
 #!/bin/bash
-# Kernel table of one training step under rocprofv3 (per-step totals, every kernel above a threshold): tools/gpu_step_kernels.sh n2|dm [min_us_per_step]
+# Kernel table of one training step under rocprofv3 (per-step totals, every kernel above a threshold): tools/gpu_step_kernels.sh n2|dm|n1 [min_us_per_step]
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; export TMPDIR=/tmp
-case "$1" in n2) CMD="python $R/tools/gpu_feature_train_step.py 4 20 240 320"; STEPS=21;; dm) CMD="python $R/tools/gpu_dm_step.py 4 24"; STEPS=25; export DM_ONLY=1;; *) echo "n2|dm"; exit 2;; esac
+case "$1" in n2) CMD="python $R/tools/gpu_feature_train_step.py 4 20 240 320"; STEPS=21;; dm) CMD="python $R/tools/gpu_dm_step.py 4 24"; STEPS=25; export DM_ONLY=1;; n1) CMD="python $R/tools/gpu_nerf_train_step.py 1536 128 10"; STEPS=22;; *) echo "n2|dm|n1"; exit 2;; esac
 rm -rf /tmp/prof_sk; ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sk -o k -- $CMD > /tmp/prof_sk.json 2> /tmp/prof_sk.err ); tail -1 /tmp/prof_sk.json | cut -c1-400
 python3 - $STEPS ${2:-20} <<'PY'
 import csv, glob, sys
