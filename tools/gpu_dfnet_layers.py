@@ -30,4 +30,5 @@ else:
     for r in last:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         g = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
-        print(f"{d / 1e3:9.1f} us  {100 * d / tot:5.1f} %  grid {g:>16s}  {r['Kernel_Name'][:90]}")
+        t0 = int(last[0]["Start_Timestamp"])
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} + {d / 1e3:7.1f} us  {100 * d / tot:5.1f} %  q{r.get('Queue_Id', '?')}  grid {g:>16s}  {r['Kernel_Name'][:86]}")
