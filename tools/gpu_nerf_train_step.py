@@ -47,9 +47,11 @@ out = tr.forward(o, d, hist, Nc, Ni, 0., 2.5, *draws[:2], 0., draws[2])
 loss5, gs, gts = tr.loss(out, target)
 bwd_ms = timed(lambda: tr.backward(*gs, gts))
 step_ms = timed(step)
+# host time to ENQUEUE one step on an idle device (nothing to wait for): how far the host is from being the bound
+torch.cuda.synchronize(); t0 = time.perf_counter(); step(); host_ms = (time.perf_counter() - t0) * 1e3; torch.cuda.synchronize()
 macs = R * (Nc * (130944 + 16384 + 64 * (W + 27) + 192) + (Nc + Ni) * 182720) * (W / 128) ** 2   # ~ algorithmic MAC per step forward
 print(json.dumps({"workload": f"NeRF-H optimisation step: {R} rays, {Nc}+{Ni} samples, netwidth {W}, perturb 1", "forward_ms": fwd_ms,
-                  "backward_ms": bwd_ms, "step_ms_with_adam": step_ms, "rays_per_s": R / step_ms * 1e3,
+                  "backward_ms": bwd_ms, "step_ms_with_adam": step_ms, "host_enqueue_ms_of_one_step_on_an_idle_device": host_ms, "rays_per_s": R / step_ms * 1e3,
                   "approx_forward_TFLOPs": 2 * macs / fwd_ms / 1e9, "approx_step_TFLOPs": 6 * macs / step_ms / 1e9,
                   "arithmetic": ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32), layer by layer" if tr.exact or W != 128 else
                                  "split-f16 MFMA, fused register-resident chains + weight-gradient stream")}))
