@@ -570,8 +570,9 @@ static int forward_core(dfn_dfnet_t h, int prec, const float* x, int B, int H, i
   }
   if (return_pose) {
     if (!last_act || last_h < 2 || last_w < 2) return set_error(DFN_ERR_ARG, "dfn_dfnet_forward: image too small for pool5");
+    // (scratch: w.prep — conv1_1 was its only reader; B * (H / 32) * 512 floats fit in the B * H * W * 16 bytes it has at least)
     CHECK_HIP(launch_pose_head(prec, last_act, B, last_h, last_w, h->fc, h->fc + size_t(h->feat_dim) * 512, h->feat_dim,
-                               pose, s),
+                               reinterpret_cast<float*>(w.prep), pose, s),
               "dfnet: pose head");
   }
   return DFN_OK;
@@ -1510,7 +1511,7 @@ static int forward_train_keep(dfn_dfnet_t h, int prec, const float* x, int B, in
   if (return_pose) {
     if (lay_h[n_enc - 1] < 2 || lay_w[n_enc - 1] < 2) return set_error(DFN_ERR_ARG, "%s: image too small for pool5", fn);
     CHECK_HIP(launch_pose_head(prec, pw.b.act[n_enc - 1], B, lay_h[n_enc - 1], lay_w[n_enc - 1], h->fc, h->fc + size_t(h->feat_dim) * 512,
-                               h->feat_dim, pose, s),
+                               h->feat_dim, pw.pooled, pose, s),   // (pw.pooled: the backward's pose-head scratch, free until then)
               "dfnet train: pose head");
   }
   if (side_join.armed) {

@@ -1423,21 +1423,30 @@ hipError_t launch_upsample(int prec, const void* in, int B, int h, int w, int UH
 }
 
 // ------------------------------------------------------------------------------------------ pose head
-// relu5_3 -> pool5 (2x2 max) -> AdaptiveAvgPool2d(1) -> Linear(512, feat_dim).  One workgroup per image,
-// thread c owns stored channel position c (512 of them); fc weights are indexed through the permutation.
+// relu5_3 -> pool5 (2x2 max) -> AdaptiveAvgPool2d(1) -> Linear(512, feat_dim).  Two launches: one workgroup per (image, pooled row) sums
+// the row's window maxima per stored channel position (512 threads) into part[B][h/2][512]; one workgroup per image adds the rows in
+// order, divides, and runs the fc (weights indexed through the storage permutation).  (One workgroup per image walking all windows
+// serially, as this was until round 6, took 0.1 ms for ONE 480x640 frame — a tenth of the pose regressor's forward at batch 1.)
 template <class T>
-__global__ __launch_bounds__(512) void pose_head_kernel(const T* __restrict__ act, int h, int w, const float* __restrict__ fc_w,
-                                                        const float* __restrict__ fc_b, int feat_dim, float* __restrict__ pose) {
-  __shared__ float pooled[512];
+__global__ __launch_bounds__(512) void pose_pool_rows_kernel(const T* __restrict__ act, int h, int w, float* __restrict__ part) {
   const int c = threadIdx.x;  // stored position
   const size_t b = blockIdx.x;
-  const int ho = h / 2, wo = w / 2;
+  const int yo = blockIdx.y, ho = gridDim.y, wo = w / 2;
+  const T* s0 = act + ((b * h + 2 * yo) * (size_t)w) * 512 + c;
   float sum = 0.f;
-  for (int y = 0; y < ho; ++y)
-    for (int x = 0; x < wo; ++x) {
-      const T* s = act + ((b * h + 2 * y) * (size_t)w + 2 * x) * 512 + c;
-      sum += fmaxf(fmaxf((float)s[0], (float)s[512]), fmaxf((float)s[(size_t)w * 512], (float)s[(size_t)w * 512 + 512]));
-    }
+  for (int x = 0; x < wo; ++x) {
+    const T* s = s0 + (size_t)x * 1024;
+    sum += fmaxf(fmaxf((float)s[0], (float)s[512]), fmaxf((float)s[(size_t)w * 512], (float)s[(size_t)w * 512 + 512]));
+  }
+  part[(b * ho + yo) * 512 + c] = sum;
+}
+__global__ __launch_bounds__(512) void pose_fc_kernel(const float* __restrict__ part, int ho, int wo, const float* __restrict__ fc_w,
+                                                      const float* __restrict__ fc_b, int feat_dim, float* __restrict__ pose) {
+  __shared__ float pooled[512];
+  const int c = threadIdx.x;
+  const size_t b = blockIdx.x;
+  float sum = 0.f;
+  for (int yo = 0; yo < ho; ++yo) sum += part[(b * ho + yo) * 512 + c];
   const int blk = c >> 5, e = c & 31, hh = e >> 4, s = e & 15;
   const int ch = blk * 32 + 4 * hh + (s & 3) + 8 * (s >> 2);
   pooled[ch] = sum / float(ho * wo);
@@ -1448,11 +1457,15 @@ __global__ __launch_bounds__(512) void pose_head_kernel(const T* __restrict__ ac
     pose[b * feat_dim + c] = accv;
   }
 }
+// part: scratch of B * (h / 2) * 512 floats
 hipError_t launch_pose_head(int prec, const void* act, int B, int h, int w, const float* fc_w, const float* fc_b,
-                            int feat_dim, float* pose, hipStream_t stream) {
+                            int feat_dim, float* part, float* pose, hipStream_t stream) {
   if (!B) return hipSuccess;
-  if (prec == 0) hipLaunchKernelGGL(pose_head_kernel<_Float16>, dim3(B), dim3(512), 0, stream, static_cast<const _Float16*>(act), h, w, fc_w, fc_b, feat_dim, pose);
-  else hipLaunchKernelGGL(pose_head_kernel<float>, dim3(B), dim3(512), 0, stream, static_cast<const float*>(act), h, w, fc_w, fc_b, feat_dim, pose);
+  if (!part || h < 2 || w < 2) return hipErrorInvalidValue;
+  const dim3 grid(B, h / 2);
+  if (prec == 0) hipLaunchKernelGGL(pose_pool_rows_kernel<_Float16>, grid, dim3(512), 0, stream, static_cast<const _Float16*>(act), h, w, part);
+  else hipLaunchKernelGGL(pose_pool_rows_kernel<float>, grid, dim3(512), 0, stream, static_cast<const float*>(act), h, w, part);
+  hipLaunchKernelGGL(pose_fc_kernel, dim3(B), dim3(512), 0, stream, part, h / 2, w / 2, fc_w, fc_b, feat_dim, pose);
   return hipGetLastError();
 }
 

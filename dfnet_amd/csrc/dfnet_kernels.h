@@ -137,7 +137,7 @@ hipError_t launch_bn_backward(int batch, float* g, const float* z, long long Q, 
                               hipStream_t s, unsigned* absmax_out = nullptr);
 // pose head: relu'd conv5_3 activations [B,h,w,16,32] -> maxpool2 -> global mean -> fc [feat_dim,512].
 hipError_t launch_pose_head(int prec, const void* act, int B, int h, int w, const float* fc_w, const float* fc_b,
-                            int feat_dim, float* pose, hipStream_t stream);
+                            int feat_dim, float* part /* scratch: B * (h / 2) * 512 floats */, float* pose, hipStream_t stream);
 
 
 // --- input-gradient path (dfnet_grad.hip); all tensors in the blocked layout, element type by `prec`
