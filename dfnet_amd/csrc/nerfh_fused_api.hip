@@ -625,13 +625,23 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
   CHECK_HIP(composite_fine_backward_train(raw, w.net[1].z, g_rgb, g_beta, g_tsigma, g_tsigma_dense, R, Nf, w.net[1].gpre, s), "train backward: fine composite");
   CHECK_HIP(composite_coarse_backward(w.raw_c, w.net[0].z, noise, raw_noise_std, g_rgb0, R, Nc, w.net[0].gpre, s), "train backward: coarse composite");
   // data-gradient chains: every pre-activation gradient stored once, in the operand layout the weight-gradient stream reads
-  {
-    ChainArgs a = chain_args(h, st, true, 1, w.net[1], nullptr, nullptr, R, Nf);
-    CHECK_HIP(launch_train_backward_chain(true, planes_of(true, h->train_split_fine), a, n_cu, s), "train backward: fine chain");
-  }
-  {
-    ChainArgs a = chain_args(h, st, false, 1, w.net[0], nullptr, nullptr, R, Nc);
-    CHECK_HIP(launch_train_backward_chain(false, planes_of(false, h->train_split_fine), a, n_cu, s), "train backward: coarse chain");
+  // (the two networks' chains are independent — the coarse loss alone reaches the coarse network, rendering.py:302 detaches the
+  // samples — and run as the two halves of ONE grid, the coarse chain's workgroups starting on the CUs the fine chain leaves first:
+  // train_bwd_chain_pair_kernel.  DFN_TRAIN_BWD_PAIR=0: one launch each, the A/B switch; same kernels' bodies, bit-identical.)
+  static const bool pair = [] { const char* e = getenv("DFN_TRAIN_BWD_PAIR"); return !e || atoi(e) != 0; }();
+  if (pair) {
+    ChainArgs af = chain_args(h, st, true, 1, w.net[1], nullptr, nullptr, R, Nf);
+    ChainArgs ac = chain_args(h, st, false, 1, w.net[0], nullptr, nullptr, R, Nc);
+    CHECK_HIP(launch_train_backward_chain_pair(planes_of(true, h->train_split_fine), af, ac, n_cu, s), "train backward: chains");
+  } else {
+    {
+      ChainArgs a = chain_args(h, st, true, 1, w.net[1], nullptr, nullptr, R, Nf);
+      CHECK_HIP(launch_train_backward_chain(true, planes_of(true, h->train_split_fine), a, n_cu, s), "train backward: fine chain");
+    }
+    {
+      ChainArgs a = chain_args(h, st, false, 1, w.net[0], nullptr, nullptr, R, Nc);
+      CHECK_HIP(launch_train_backward_chain(false, planes_of(false, h->train_split_fine), a, n_cu, s), "train backward: coarse chain");
+    }
   }
   // weight gradients: one stream launch over the jobs of both networks, then the fixed-order reduction into the .grad tensors
   {

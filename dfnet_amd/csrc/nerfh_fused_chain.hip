@@ -220,9 +220,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_fwd_chain_kernel(ChainArg
 }
 
 // ------------------------------------------------------------------------------------------ backward
+// The body takes its place in the persistent grid as arguments (block `blk` of `nblk`): train_bwd_chain_kernel is the grid itself,
+// train_bwd_chain_pair_kernel runs two networks' chains as the two halves of ONE grid.
 template <bool FINE, int PL>
-__global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+DFN_DEV void train_bwd_chain_body(const ChainArgs& a, char* smem, const int blk, const int nblk) {
   constexpr int RAWC = FINE ? 9 : 4;
   Stager st;
   init_stager(st, a);
@@ -230,12 +231,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArg
   const long long n_pts = (long long)a.n_rays * a.n_samples;
   const long long n_tiles = (n_pts + kTilePoints - 1) / kTilePoints;
   const size_t n_wt = size_t(n_tiles) * WAVES;
-  long long tile = blockIdx.x;
+  long long tile = blk;
   if (tile >= n_tiles) return;
   stage_prime(st, smem, kBwdStride);
   const uint32_t lane_slot = uint32_t(2 * p + h) * 16u;
-  for (; tile < n_tiles; tile += gridDim.x) {
-    st.more = tile + gridDim.x < n_tiles;
+  for (; tile < n_tiles; tile += nblk) {
+    st.more = tile + nblk < n_tiles;
     const long long pt = tile * kTilePoints + st.wave * 32 + p;
     const bool on = h == 0 && pt < n_pts;
     float g[RAWC];
@@ -396,6 +397,24 @@ __global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArg
   }
   range_report<P>(st.rmax, a.status);
 }
+template <bool FINE, int PL>
+__global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  train_bwd_chain_body<FINE, PL>(a, smem, int(blockIdx.x), int(gridDim.x));
+}
+// The fine and the coarse network's chains in ONE launch: blocks [0, n_fine) are the fine chain's persistent grid, the rest the
+// coarse chain's.  The two are independent (the coarse loss alone reaches the coarse network: rendering.py:302 detaches the
+// samples), every workgroup takes a CU's whole register file, and workgroups are dispatched in block order — so the coarse chain's
+// workgroups start on the CUs the fine chain leaves first.  At the reference's batch (1 536 rays of 64 + 128 samples: 1 152 fine
+// tiles = 4.5 per CU, 384 coarse tiles = 1.5 per CU) that fills the half-tile tails of both chains: 6.0 tile times instead of
+// 5 + 2.  One stream, one launch: the same overlap from a second HIP stream gave the time back through slower launches of every
+// other kernel of the step, and hipExtAnyOrderLaunch is ignored on this part (LABBOOK R6.17).
+template <int PLF>
+__global__ __launch_bounds__(WAVES * 64, 1) void train_bwd_chain_pair_kernel(ChainArgs fine, ChainArgs coarse, int n_fine) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (int(blockIdx.x) < n_fine) train_bwd_chain_body<true, PLF>(fine, smem, int(blockIdx.x), n_fine);
+  else train_bwd_chain_body<false, 2>(coarse, smem, int(blockIdx.x) - n_fine, int(gridDim.x) - n_fine);
+}
 
 // ------------------------------------------------------------------------------------------ launch
 template <class K>
@@ -427,6 +446,25 @@ hipError_t launch_train_backward_chain(bool fine, int planes, const ChainArgs& a
   if (planes == 1) return launch_chain(train_bwd_chain_kernel<true, 1>, done[1], 3 * kBwdStride, a, n_cu, s);
   if (planes == 2) return launch_chain(train_bwd_chain_kernel<true, 2>, done[2], 3 * kBwdStride, a, n_cu, s);
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_train_backward_chain_pair(int planes_fine, const ChainArgs& fine, const ChainArgs& coarse, int n_cu, hipStream_t s) {
+  static bool done[2] = {false, false};
+  const long long pf = (long long)fine.n_rays * fine.n_samples, pc = (long long)coarse.n_rays * coarse.n_samples;
+  if (pf <= 0 || pc <= 0 || pf >= (1LL << 31) || (planes_fine != 1 && planes_fine != 2)) return hipErrorInvalidValue;
+  const long long tf = (pf + kTilePoints - 1) / kTilePoints, tc = (pc + kTilePoints - 1) / kTilePoints;
+  const int gf = int(tf < n_cu ? tf : n_cu), gc = int(tc < n_cu ? tc : n_cu);   // each chain's own persistent grid, as launch_chain
+  const void* kern = planes_fine == 1 ? reinterpret_cast<const void*>(train_bwd_chain_pair_kernel<1>)
+                                      : reinterpret_cast<const void*>(train_bwd_chain_pair_kernel<2>);
+  bool& attr_done = done[planes_fine - 1];
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(3 * kBwdStride));
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  if (planes_fine == 1) hipLaunchKernelGGL(train_bwd_chain_pair_kernel<1>, dim3(gf + gc), dim3(WAVES * 64), 3 * kBwdStride, s, fine, coarse, gf);
+  else hipLaunchKernelGGL(train_bwd_chain_pair_kernel<2>, dim3(gf + gc), dim3(WAVES * 64), 3 * kBwdStride, s, fine, coarse, gf);
+  return hipGetLastError();
 }
 
 }  // namespace fused

@@ -83,6 +83,8 @@ struct ChainArgs {
 };
 hipError_t launch_train_forward_chain(bool fine, int planes, const ChainArgs& a, int n_cu, hipStream_t s);
 hipError_t launch_train_backward_chain(bool fine, int planes, const ChainArgs& a, int n_cu, hipStream_t s);
+// both networks' data-gradient chains as the two halves of one grid (nerfh_fused_chain.hip: train_bwd_chain_pair_kernel)
+hipError_t launch_train_backward_chain_pair(int planes_fine, const ChainArgs& fine, const ChainArgs& coarse, int n_cu, hipStream_t s);
 size_t chain_wave_tiles(long long n_points);   // wave-tiles the chain kernels write (whole tiles)
 
 // ---- weight-gradient stream

@@ -274,10 +274,14 @@ class NerfHEngine:
         out = composite_fine(raw, z)
         return out["rgb"], out["disp"], out["acc"], z, raw
 
-    def backward_from_saved(self, rays_o, rays_d, viewdirs, hist, z, raw, grad_rgb, derive_viewdirs=True, precision=None, masks=None):
-        """d L/d (rays_o, rays_d[, viewdirs]) from the saved (z_fine, raw[, masks]) of render_rays_saving()."""
+    def backward_from_saved(self, rays_o, rays_d, viewdirs, hist, z, raw, grad_rgb, derive_viewdirs=True, precision=None, masks=None,
+                            grad_raw=None):
+        """d L/d (rays_o, rays_d[, viewdirs]) from the saved (z_fine, raw[, masks]) of render_rays_saving().  grad_raw [n,Nf,9]: a
+        gradient that reaches `raw` directly (render(retraw=True) under autograd), added to the compositor's."""
         rays_o, rays_d, viewdirs = _f32c(rays_o).reshape(-1, 3), _f32c(rays_d).reshape(-1, 3), _f32c(viewdirs).reshape(-1, 3)
         graw = composite_fine_backward(raw, z, _f32c(grad_rgb).reshape(-1, 3))
+        if grad_raw is not None:
+            graw += _f32c(grad_raw).reshape(graw.shape)
         if masks is not None:
             gpts = self.mlp_fine_backward_saved(rays_o, rays_d, viewdirs, z, raw, masks, graw)
         else:

@@ -79,7 +79,9 @@ def _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far):
     return rgb, disp, acc, (o, d, v, hist, z, raw)
 
 
-def _saved_backward(eng, saved, g_rgb):
+def _saved_backward(eng, saved, g_rgb, g_raw=None):
+    if g_rgb is None:
+        g_rgb = torch.zeros(saved[0].shape[0], 3, device=saved[0].device)
     if len(saved) == 5:   # generic width: (rays, viewdirs = d / |d|, histograms, [Nc, Ni, near, far])
         o, d, _, hist, cfg = saved
         Nc, Ni, near, far, lindisp = cfg.tolist()
@@ -87,7 +89,7 @@ def _saved_backward(eng, saved, g_rgb):
         return eng.render_rays_backward(o, d, hist, int(Nc), int(Ni), near, far, g_rgb.contiguous(), precision="generic")
     o, d, v, hist, z, raw = saved[:6]
     masks = saved[6] if len(saved) > 6 else None
-    return eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION, masks=masks)
+    return eng.backward_from_saved(o, d, v, hist, z, raw, g_rgb.contiguous(), True, precision=GRAD_PRECISION, masks=masks, grad_raw=g_raw)
 
 
 class _RenderImageFn(torch.autograd.Function):
@@ -172,22 +174,32 @@ def render_frames(H, W, focal, c2ws, img_idx, **kwargs):
 
 
 class _RenderRaysFn(torch.autograd.Function):
-    """rgb/disp/acc = render(rays); backward: d L/d rays_o, d L/d rays_d (viewdirs = d/|d| differentiated)."""
+    """rgb/disp/acc[/raw] = render(rays); backward: d L/d rays_o, d L/d rays_d (viewdirs = d/|d| differentiated) from d L/d rgb and,
+    with retraw, d L/d raw [n,Nf,9] (rendering.py:353-400 with retraw=True under autograd: `raw` is a function of the sample points and
+    view directions, the depths are detached).  The fine network's backward is a full vector-Jacobian product of all nine raw channels,
+    so an external d L/d raw is ADDED to the compositor's d L/d raw before it."""
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, eng, hist, Nc, Ni, near, far):
+    def forward(ctx, rays_o, rays_d, eng, hist, Nc, Ni, near, far, retraw=False):
         o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
         v = d / torch.norm(d, dim=-1, keepdim=True)
         rgb, disp, acc, saved = _saving_forward(eng, o, d, v, hist, Nc, Ni, near, far)
-        ctx.save_for_backward(*saved)
         ctx.eng = eng
         ctx.mark_non_differentiable(disp, acc)
+        if retraw:
+            if len(saved) == 5:
+                raise NotImplementedError("render(): retraw together with autograd at a network width other than 128 (the generic-width "
+                                          "gradient is stateless and takes d L/d rgb only)")
+            raw = saved[5].clone()    # the caller's tensor: an in-place edit of it must not reach the state the backward reads
+            ctx.save_for_backward(*saved)
+            return rgb, disp, acc, raw
+        ctx.save_for_backward(*saved)
         return rgb, disp, acc
 
     @staticmethod
-    def backward(ctx, g_rgb, _g_disp, _g_acc):
-        go, gd, _ = _saved_backward(ctx.eng, ctx.saved_tensors, g_rgb)
-        return (go, gd) + (None,) * 6
+    def backward(ctx, g_rgb, _g_disp, _g_acc, g_raw=None):
+        go, gd, _ = _saved_backward(ctx.eng, ctx.saved_tensors, g_rgb, g_raw)
+        return (go, gd) + (None,) * 7
 
 
 def _set_options(eng, kw, near):
@@ -297,7 +309,10 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
                                                   float(near), float(far))
             return [rgb, disp, acc, {}]
         if retraw or hist.numel() != eng.hist_bin:
-            o, d = get_rays(H, W, focal, c2w)
+            if track and c2w.requires_grad:    # the pose reaches the ray gradients through get_rays' own node
+                o, d = (t.reshape(int(H), int(W), 3) for t in _RaygenFn.apply(c2w[:3, :4].contiguous(), int(H), int(W), float(focal)))
+            else:
+                o, d = get_rays(H, W, focal, c2w)
             return render(H, W, focal, chunk, rays=(o, d), ndc=ndc, near=near, far=far, use_viewdirs=use_viewdirs,
                           img_idx=img_idx, **kwargs)
         rgb, disp, acc = eng.render_image(c2w, int(H), int(W), float(focal), hist, Nc, Ni, near, far)
@@ -312,11 +327,10 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         raise ValueError(f"img_idx must have 1 or {n} rows of {eng.hist_bin} bins, got {tuple(hist.shape)}")
     lead = list(sh[:-1])
     if track:
-        if retraw:
-            raise NotImplementedError("render(): retraw together with autograd (raw is not differentiated natively)")
-        rgb, disp, acc = _RenderRaysFn.apply(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), eng, hist, Nc, Ni, float(near),
-                                             float(far))
-        return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), {}]
+        out = _RenderRaysFn.apply(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), eng, hist, Nc, Ni, float(near), float(far), retraw)
+        rgb, disp, acc = out[:3]
+        extras = {'raw': out[3].reshape(lead + list(out[3].shape[1:]))} if retraw else {}
+        return [rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), extras]
     rgb, disp, acc, raw = eng.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), hist, Nc, Ni, near, far,
                                           retraw=retraw)
     extras = {'raw': raw.reshape(lead + list(raw.shape[1:]))} if retraw else {}

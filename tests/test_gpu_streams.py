@@ -66,3 +66,64 @@ def test_side_stream_schedules_are_bit_identical_to_one_stream():
     assert len(set(beside["digests"])) == 1, beside          # run after run
     assert len(set(in_line["digests"])) == 1, in_line
     assert beside["digests"][0] == in_line["digests"][0], (beside["loss"], in_line["loss"])
+
+
+# ---------------------------------------------------------------------- N1: both networks' data-gradient chains in one grid
+_N1_STEP = r"""
+import hashlib, json, sys
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+from tests.test_gpu_train import modules
+from dfnet_amd import nerf_train, synthetic as syn
+from oracle import nerfh_oracle as orc
+dev = torch.device("cuda:0")
+E, mods, _ = modules(W=128)
+tr = nerf_train.NerfHTrainer(E, *mods)
+R, Nc, Ni = %(rays)d, 64, 128
+rng = np.random.default_rng(0)
+ro, rd = orc.get_rays(480, 640, 585.0, torch.from_numpy(syn.orbit_pose(0, 8))[:3, :4])
+sel = rng.choice(480 * 640, R, replace=False)
+o, d = ro.reshape(-1, 3)[sel].contiguous().to(dev), rd.reshape(-1, 3)[sel].contiguous().to(dev)
+hist = torch.from_numpy(syn.HIST_IDX)[None].to(dev)
+g = torch.Generator().manual_seed(3)
+target = torch.rand(R, 3, generator=g).to(dev)
+draws = tuple(t.to(dev) for t in (torch.rand(R, Nc, generator=g), torch.randn(R, Nc, generator=g), torch.rand(R, Ni, generator=g)))
+digests, emb = [], []
+for rep in range(3):
+    for p in tr.params:
+        p.grad = None
+    ld, _, _ = tr.train_step(o, d, hist, target, Nc, Ni, 0., 2.5, perturb=1., raw_noise_std=0., draws=draws)
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for k in sorted(ld):
+        h.update(np.float32(float(ld[k])).tobytes())
+    n = 0
+    for name, p in zip(tr.names, tr.params):
+        if "embedding" in name:      # scattered with atomic adds: the last bit depends on the arrival order, in every schedule
+            emb.append(p.grad.double().abs().sum().item())
+        else:
+            h.update(p.grad.cpu().numpy().tobytes()); n += 1
+    digests.append(h.hexdigest())
+print(json.dumps({"digests": digests, "n_grads": n, "emb": emb, "loss": {k: float(v) for k, v in ld.items()}, "fused": not tr.exact}))
+"""
+
+
+@pytest.mark.parametrize("rays", [1536, 200])
+def test_n1_backward_chain_pair_is_bit_identical_to_two_launches(rays):
+    """nerfh_fused_api.hip: train_backward runs the fine and the coarse network's data-gradient chains as the two halves of one grid
+    (train_bwd_chain_pair_kernel: the coarse chain's workgroups fill the fine chain's half-tile tail); DFN_TRAIN_BWD_PAIR=0 launches
+    them one after the other.  The loss and the 62 weight / bias gradients of the step bit for bit, run after run and across the two
+    schedules; the two embedding gradients (atomic scatter) to round-off."""
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", _N1_STEP % {"root": ROOT, "rays": rays}], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    paired, apart = run({}), run({"DFN_TRAIN_BWD_PAIR": "0"})
+    assert paired["fused"] and apart["fused"] and paired["n_grads"] == apart["n_grads"] == 62
+    assert len(set(paired["digests"])) == 1, paired
+    assert len(set(apart["digests"])) == 1, apart
+    assert paired["digests"][0] == apart["digests"][0], (paired["loss"], apart["loss"])
+    for a, b in zip(paired["emb"], apart["emb"]):
+        assert abs(a - b) <= 1e-5 * abs(b)
