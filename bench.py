@@ -612,7 +612,7 @@ def secondary_dm_step(dev):
     """BASELINE configs[4] at its per-GPU shape: DFNet_dm step, batch 4, 240x320, render 60x80 at 64+128 + bicubic x4,
     level-0 feature loss; parity = the step's loss against the composition of the CPU oracles on the same inputs."""
     from types import SimpleNamespace
-    from dfnet_amd import engine as eng, synthetic as syn
+    from dfnet_amd import engine as eng, optim, synthetic as syn
     from dfnet_amd.dfnet import DFNet
     import dfnet_amd.direct_feature_matching as dfm
     from dfnet_amd.direct_feature_matching import matching_step_grad, train_on_batch, train_on_batch_device
@@ -649,7 +649,7 @@ def secondary_dm_step(dev):
         return (time.perf_counter() - t0) / iters * 1e3, o
 
     pose_ms, out = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, hwf, True, dev, setup, **kw))
-    opt = torch.optim.Adam(model.parameters(), lr=1e-7)
+    opt = optim.Adam(model.parameters(), lr=1e-7)
     # the step as train_on_epoch runs it (losses stay on the device, one wait per epoch); train_on_batch itself returns host floats
     # like the reference and so waits for the device every step: timed separately below
     step = lambda: train_on_batch_device(args, data, model, feat_model, gt, hist, hwf, opt, True, dev, setup, **kw)
@@ -709,7 +709,7 @@ def secondary_dfnet_train(dev):
     with in-triplet hard-negative mining, random view synthesis, BatchNorm on batch statistics): siamese forward on [target, render]
     (2B frames), pose forward on B synthesised views, losses, backward of every parameter, Adam, device re-pack.  Parity = the step's
     loss against the CPU oracle's forward in train() mode on the same frames."""
-    from dfnet_amd import synthetic as syn
+    from dfnet_amd import optim, synthetic as syn
     from dfnet_amd.dfnet import DFNet
     from dfnet_amd.feature_misc import PoseLoss, triplet_loss_hard_negative_mining_plus
     from oracle import dfnet_oracle as dor
@@ -720,7 +720,7 @@ def secondary_dfnet_train(dev):
     m.load_state_dict({k: T(v) for k, v in w.items()}, strict=False)
     m.to(dev).train()
     m.pyramid_features = True   # what script/run_feature.py sets under --tripletloss: the triplet loss from the low-resolution pyramid
-    opt = torch.optim.Adam(m.parameters(), lr=1e-7)
+    opt = optim.Adam(m.parameters(), lr=1e-7)
     g = torch.Generator().manual_seed(1)
     target, rgb, virt = (torch.rand(B, 3, Hh, Ww, generator=g) for _ in range(3))
     pose = torch.stack([T(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(B)])
@@ -802,7 +802,7 @@ def secondary_nerfh_train(dev):
     """one NeRF-H optimisation step at the reference's defaults (N_rand 1536 rays, 64+128 samples, netwidth 128,
     perturb 1; run_nerf.py:32-80): forward, fused NerfWLoss, every gradient, Adam.  Parity: a 256-ray step against autograd
     through the CPU oracle (loss terms and the worst relative L2 over the 64 gradient tensors)."""
-    from dfnet_amd import engine as eng, nerf_train, synthetic as syn
+    from dfnet_amd import engine as eng, nerf_train, optim, synthetic as syn
     from dfnet_amd.nerfw import NeRFW
     from oracle import nerfh_oracle as orc
     T = torch.from_numpy
@@ -850,7 +850,7 @@ def secondary_nerfh_train(dev):
     # timing at the reference's batch
     R = 1536
     o, d, hist, target = (t.to(dev) for t in batch(R))
-    opt = torch.optim.Adam(tr.params, lr=5e-4, betas=(0.9, 0.999))
+    opt = optim.Adam(tr.params, lr=5e-4, betas=(0.9, 0.999))
 
     def step():
         tr.train_step(o, d, hist[:1], target, NC, NI, NEAR, FAR, perturb=1., raw_noise_std=0.)

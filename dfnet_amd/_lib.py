@@ -27,6 +27,12 @@ class NerfhDesc(Structure):
                 ("hist_bin", c_int), ("dim_a", c_int), ("dim_t", c_int), ("n_vocab", c_int)]
 
 
+class AdamTensor(Structure):
+    """dfn_adam_tensor (include/dfnet_hip.h)"""
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("numel", c_size_t),
+                ("step_size", c_float), ("bias_correction2_sqrt", c_float)]
+
+
 # name -> (restype, argtypes); mirrors include/dfnet_hip.h one to one
 _P = c_void_p
 SIGNATURES = {
@@ -137,6 +143,7 @@ SIGNATURES = {
     "dfn_linear_backward_input": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, _P]),
     "dfn_linear_backward_weight_scratch_bytes": (c_size_t, [c_int, c_int, c_size_t]),
     "dfn_linear_backward_weight": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "dfn_adam_step": (c_int, [_P, c_int, c_double, c_double, c_double, c_double, _P]),
     "dfn_profile_enable": (c_int, [c_int]),
     "dfn_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
 }

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .engine import NerfHEngine
+from . import optim
 
 img2mse = lambda x, y: torch.mean((x - y) ** 2)
 mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.Tensor([10.]))
@@ -134,7 +135,7 @@ def create_nerf(args):
     if args.no_grad_update:
         grad_vars, optimizer = None, None
     else:
-        optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+        optimizer = optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))   # torch.optim.Adam, one launch per step
 
     start = 0
     if args.ft_path is not None and args.ft_path != 'None':

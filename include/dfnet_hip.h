@@ -588,6 +588,25 @@ size_t dfn_linear_backward_weight_scratch_bytes(int N, int K, size_t n_points);
 int dfn_linear_backward_weight(const float* g, int ldg, int N, const float* x, int ldx, int K, int x_row_div, float* dw, int ldw,
                                int wcol, float* db, void* scratch, size_t n_points, void* stream);
 
+/* optimizer.step() of the training loops (torch.optim.Adam in the reference: run_nerf.py:65, run_feature.py:65,
+ * feature/direct_feature_matching.py:237) as one multi-tensor pass: for every tensor, element by element and in the order of
+ * torch/optim/adam.py's multi-tensor step,
+ *   g = grad (+ weight_decay * param);  exp_avg += (1 - beta1) (g - exp_avg);  exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g g;
+ *   param += step_size * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps)
+ * with the per-tensor step_size = -lr / (1 - beta1^step) and bias_correction2_sqrt = sqrt(1 - beta2^step) computed by the caller
+ * (in double, as torch does); the hyper-parameters are the doubles torch holds, rounded to fp32 once inside.  `tensors` is a HOST array of n_tensors descriptors of fp32 device tensors; nothing is retained. */
+typedef struct dfn_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  size_t numel;
+  float step_size;
+  float bias_correction2_sqrt;
+} dfn_adam_tensor;
+int dfn_adam_step(const dfn_adam_tensor* tensors, int n_tensors, double beta1, double beta2, double eps, double weight_decay,
+                  void* stream);
+
 /* Timing aid for bench.py: average device time in ms of the `which` kernel of the render path
  * (DFN_PROF_*) over the launches since the last reset, measured with HIP events recorded on the
  * launch `stream` around each launch.  Enabled by dfn_profile_enable(1); costs a sync when read. */

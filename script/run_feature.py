@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from dfnet_amd.datasets import load_7Scenes_dataloader, load_Cambridge_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
 from dfnet_amd import dist as ddist  # noqa: E402
+from dfnet_amd import optim  # noqa: E402
 from dfnet_amd.callbacks import EarlyStopping  # noqa: E402
 from dfnet_amd.feature_misc import (PoseLoss, freeze_bn_layer, freeze_bn_layer_train, get_error_in_q,  # noqa: E402
                                     perturb_single_render_pose, render_nerfw_imgs, render_virtual_imgs,
@@ -208,7 +209,7 @@ def train_feature(args, train_dl, val_dl, test_dl, hwf, i_split, near, far):
     # from there (dfnet.FeaturePyramid, csrc/dfnet_triplet_pyr.hip): the same loss and gradients without the two [3, B, 128, H, W]
     # stacks, their gradients, the upsample and its adjoint.  Any loss that needs real stacks (MSE FeatureLoss) keeps the tensors.
     feat_model.pyramid_features = bool(args.tripletloss) and not args.featurelossonly and os.environ.get("DFNET_PYRAMID_TRIPLET", "1") != "0"
-    optimizer = torch.optim.Adam(feat_model.parameters(), lr=args.learning_rate)
+    optimizer = optim.Adam(feat_model.parameters(), lr=args.learning_rate)   # torch.optim.Adam, one launch per step (dfnet_amd/optim.py)
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.95, patience=args.patience[1])
     early_stopping = EarlyStopping(args, patience=args.patience[0], verbose=False)
     loss_func = torch.nn.MSELoss(reduction='mean')

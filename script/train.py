@@ -20,6 +20,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 from dfnet_amd import dist as ddist  # noqa: E402
+from dfnet_amd import optim  # noqa: E402
 from dfnet_amd.datasets import load_7Scenes_dataloader, load_Cambridge_dataloader  # noqa: E402
 from dfnet_amd.dfnet import DFNet, DFNet_s  # noqa: E402
 from dfnet_amd.callbacks import EarlyStopping  # noqa: E402
@@ -57,7 +58,7 @@ def main(argv=None):
         # (direct_feature_matching.py:412-471: train epoch, validation pass, early stopping / checkpoint-<epoch>-<val>.pt, pose
         # error every i_eval epochs); every gradient on the HIP path, the optimizer step by torch
         model.to(device)
-        optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate)
+        optimizer = optim.Adam(model.parameters(), lr=args.learning_rate)   # torch.optim.Adam, one launch per step (dfnet_amd/optim.py)
         early_stopping = EarlyStopping(args, patience=args.patience[0], verbose=False)
         n_epoch = int(os.environ.get("DFNET_DM_EPOCHS", 2001))   # the reference hard-codes 2001 (:437) and relies on early stopping
         train_feature_matching(args, model, feat_model, optimizer, i_split, hwf, near, far, device, early_stopping, train_dl=train_dl,

@@ -8,6 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dfnet_amd import synthetic as syn
+from dfnet_amd import optim
 from dfnet_amd.dfnet import DFNet
 from dfnet_amd.feature_misc import PoseLoss, freeze_bn_layer, freeze_bn_layer_train, triplet_loss_hard_negative_mining_plus
 
@@ -27,7 +28,7 @@ if frozen:
 # what script/run_feature.py ships under --tripletloss: the feature stacks stay a low-resolution pyramid (dfnet.FeaturePyramid);
 # FT_STACKS=1 = the materialised stacks + stack triplet kernels (the round-5 form), for A/B
 m.pyramid_features = not os.environ.get("FT_STACKS")
-opt = torch.optim.Adam(m.parameters(), lr=1e-6)
+opt = optim.Adam(m.parameters(), lr=1e-6)
 g = torch.Generator().manual_seed(1)
 target, rgb, virt = (torch.rand(B, 3, H, W, generator=g).to(dev) for _ in range(3))
 pose = torch.stack([torch.from_numpy(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(B)]).to(dev)

@@ -7,12 +7,13 @@ import torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 from tests.test_gpu_train import modules
 from dfnet_amd import nerf_train, synthetic as syn
+from dfnet_amd import optim
 from oracle import nerfh_oracle as orc
 dev = torch.device("cuda:0")
 R, Nc, Ni = 1536, 64, 128
 E, mods, _ = modules(W=128)
 tr = nerf_train.NerfHTrainer(E, *mods)
-opt = torch.optim.Adam(tr.params, lr=5e-4, betas=(0.9, 0.999))
+opt = (torch.optim.Adam if os.environ.get('DFN_TORCH_ADAM') == '1' else optim.Adam)(tr.params, lr=5e-4, betas=(0.9, 0.999))
 rng = np.random.default_rng(0)
 ro, rd = orc.get_rays(480, 640, 585.0, torch.from_numpy(syn.orbit_pose(0, 8))[:3, :4])
 sel = rng.choice(480 * 640, R, replace=False)

@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.test_gpu_train import modules  # seeded modules on the GPU
 from dfnet_amd import nerf_train, synthetic as syn
+from dfnet_amd import optim
 from oracle import nerfh_oracle as orc
 
 dev = torch.device("cuda:0")
@@ -18,7 +19,7 @@ Nc, Ni = 64, 128
 E, mods, _ = modules(W=W)
 tr = nerf_train.NerfHTrainer(E, *mods)
 tr.exact = os.environ.get("DFN_TRAIN_EXACT", "0") == "1"   # DFN_TRAIN_EXACT=1: time the layer-by-layer exact-fp32 step instead
-opt = torch.optim.Adam(tr.params, lr=5e-4, betas=(0.9, 0.999))
+opt = (torch.optim.Adam if os.environ.get('DFN_TORCH_ADAM') == '1' else optim.Adam)(tr.params, lr=5e-4, betas=(0.9, 0.999))
 rng = np.random.default_rng(0)
 ro, rd = orc.get_rays(480, 640, 585.0, torch.from_numpy(syn.orbit_pose(0, 8))[:3, :4])
 sel = rng.choice(480 * 640, R, replace=False)
