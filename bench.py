@@ -690,7 +690,7 @@ def secondary_dm_step(dev):
                         "+ bicubic x4, level-0 cosine feature loss + photometric + pose terms",
             "forward_backward_to_pose_ms": pose_ms, "full_step_ms": full_ms, "full_step_all_levels_ms": full_all_ms,
             "full_step_returning_host_floats_ms": host_ms,
-            "full_step_is": "all 28 regressor gradients + Adam (torch.optim) + device-side re-pack of the updated weights, as train_on_epoch runs "
+            "full_step_is": "all 28 regressor gradients + Adam (dfnet_amd.optim.Adam: one dfn_adam_step launch) + device-side re-pack of the updated weights, as train_on_epoch runs "
                             "it: the step's loss / PSNR stay on the device and the host waits once per epoch (train_on_batch_device); "
                             "full_step_returning_host_floats_ms = train_on_batch with the reference's signature (numpy floats: one device wait "
                             "per step).  full_step_ms = the "
@@ -899,7 +899,7 @@ def secondary_nerfh_train(dev):
                                  "what": "DFN_TRAIN_FUSED_SPLIT: the fine network's stored operands as hi | lo planes too (the round-4 layout)"},
             "hbm_GBps_floor_over_the_step": 2.0 * stored / (ms["fused"] * 1e-3) / 1e9,
             "hbm_note": "X_l and G_l written once (chains) and read once (weight-gradient stream): 2 x stored bytes over the WHOLE step time — "
-                        "a floor; per kernel: profiles/r05_train_step_kernel_stats.csv.  Fine network: one f16 plane per stored operand "
+                        "a floor; per kernel: profiles/r06_train_step_kernel_stats.csv.  Fine network: one f16 plane per stored operand "
                         "(round 4: hi | lo, 4.67 GB per step), coarse network: hi | lo",
             "range_check": "NerfHTrainer.range_check = 'skip': the range flag is read without draining the stream; a flagged step leaves zero gradients",
             "range_flags_after_the_steps": range_flags,
