@@ -561,12 +561,17 @@ int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_
   const float* emb_a = params[kCoarseParams + kFineParams];
   const float* emb_t = params[kCoarseParams + kFineParams + 1];
   const int n_cu = device_cu_count();
-  CHECK_HIP(launch_viewdirs(rays_d, R, w.view, s), "train forward: viewdirs");
-  CHECK_HIP(ray_inputs(w.view, nullptr, 1, nullptr, nullptr, d.hist_bin, d.dim_a, d.dim_t, d.n_vocab, R, w.dir_c, g.ld_dc, nullptr, 0, s),
-            "train forward: coarse ray inputs");
-  CHECK_HIP(ray_inputs(w.view, hist, hist_rows, emb_a, emb_t, d.hist_bin, d.dim_a, d.dim_t, d.n_vocab, R, w.dir_f, g.ld_df, w.t_in, g.ld_t, s),
-            "train forward: fine ray inputs");
-  CHECK_HIP(hipMemsetAsync(h->range_flag + 2, 0, sizeof(int), s), "train forward: clearing the step's range word");
+  {   // view directions, both networks' per-ray input rows, the stratified coarse depths, the step's range word cleared: one launch
+    TrainRayPrepArgs pa{};
+    pa.rays_d = rays_d; pa.R = R;
+    pa.hist = hist; pa.hist_rows = hist_rows; pa.emb_a = emb_a; pa.emb_t = emb_t;
+    pa.hist_bin = d.hist_bin; pa.dim_a = d.dim_a; pa.dim_t = d.dim_t; pa.n_vocab = d.n_vocab;
+    pa.view = w.view; pa.dir_c = w.dir_c; pa.ld_dc = g.ld_dc; pa.dir_f = w.dir_f; pa.ld_df = g.ld_df; pa.t_in = w.t_in; pa.ld_t = g.ld_t;
+    pa.t_rand = t_rand; pa.Nc = Nc; pa.near = near; pa.far = far; pa.lindisp = (h->render_flags & DFN_RENDER_LINDISP) ? 1 : 0;
+    pa.z = w.net[0].z;
+    pa.range_word = h->range_flag + 2;
+    CHECK_HIP(train_ray_prep(pa, s), "train forward: per-ray inputs");
+  }
   // the step's weights -> staging units of the four chain passes (hi | lo split at the handle's operand scale)
   {
     PackArgs4 pa{};
@@ -580,13 +585,10 @@ int train_forward(dfn_nerfh_s* h, const float* const* params, const float* rays_
     pa.status = h->range_flag + 2;
     CHECK_HIP(launch_pack4(pa, s), "fused training: weight packing");
   }
-  CHECK_HIP(launch_ray_bias_train(pc[2 * DIR], pc[2 * DIR + 1], W + g.kd_c, g.kd_c, w.dir_c, g.ld_dc, nullptr, nullptr, 0, 0, nullptr, 0, R,
-                                  w.net[0].ray_bias, s),
-            "train forward: coarse per-ray bias");
-  CHECK_HIP(launch_ray_bias_train(pf[2 * DIR], pf[2 * DIR + 1], W + g.kd_f, g.kd_f, w.dir_f, g.ld_df, pf[2 * TE0], pf[2 * TE0 + 1], W + g.nt,
-                                  g.nt, w.t_in, g.ld_t, R, w.net[1].ray_bias, s),
-            "train forward: fine per-ray bias");
-  CHECK_HIP(stratified_z(t_rand, R, Nc, near, far, w.net[0].z, s, h->render_flags & DFN_RENDER_LINDISP), "train forward: stratified z");
+  CHECK_HIP(launch_ray_bias_train_pair(pc[2 * DIR], pc[2 * DIR + 1], W + g.kd_c, g.kd_c, w.dir_c, g.ld_dc, w.net[0].ray_bias,
+                                       pf[2 * DIR], pf[2 * DIR + 1], W + g.kd_f, g.kd_f, w.dir_f, g.ld_df, pf[2 * TE0], pf[2 * TE0 + 1], W + g.nt,
+                                       g.nt, w.t_in, g.ld_t, w.net[1].ray_bias, R, s),
+            "train forward: per-ray bias tables");
   {
     ChainArgs a = chain_args(h, st, false, 0, w.net[0], rays_o, rays_d, R, Nc);
     a.raw_out = w.raw_c;
@@ -620,10 +622,11 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
   float* g_emb_a = grads[kCoarseParams + kFineParams];
   float* g_emb_t = grads[kCoarseParams + kFineParams + 1];
   const int n_cu = device_cu_count();
-  CHECK_HIP(hipMemsetAsync(g_emb_a, 0, size_t(d.n_vocab) * d.dim_a * 4, s), "train backward: zero embedding_a grad");
-  CHECK_HIP(hipMemsetAsync(g_emb_t, 0, size_t(d.n_vocab) * d.dim_t * 4, s), "train backward: zero embedding_t grad");
   CHECK_HIP(composite_fine_backward_train(raw, w.net[1].z, g_rgb, g_beta, g_tsigma, g_tsigma_dense, R, Nf, w.net[1].gpre, s), "train backward: fine composite");
-  CHECK_HIP(composite_coarse_backward(w.raw_c, w.net[0].z, noise, raw_noise_std, g_rgb0, R, Nc, w.net[0].gpre, s), "train backward: coarse composite");
+  // (the coarse compositor also zeroes the two embedding gradients that the scatter kernels at the end of the pass accumulate into)
+  CHECK_HIP(composite_coarse_backward(w.raw_c, w.net[0].z, noise, raw_noise_std, g_rgb0, R, Nc, w.net[0].gpre, s, g_emb_a,
+                                      size_t(d.n_vocab) * d.dim_a, g_emb_t, size_t(d.n_vocab) * d.dim_t),
+            "train backward: coarse composite");
   // data-gradient chains: every pre-activation gradient stored once, in the operand layout the weight-gradient stream reads
   // (the two networks' chains are independent — the coarse loss alone reaches the coarse network, rendering.py:302 detaches the
   // samples — and run as the two halves of ONE grid, the coarse chain's workgroups starting on the CUs the fine chain leaves first:

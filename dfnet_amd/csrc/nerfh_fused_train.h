@@ -141,9 +141,10 @@ hipError_t launch_grads_guard(const GuardArgs& a, hipStream_t s);
 
 // table[ray][tbl][mb][h][r] (C-fragment order, nerfh_layout.h) = b[f] + sum_j W[f, 128 + j] in[ray, j]; tbl 0 = dir_encoding.0
 // on dir_in [R, ld_dir] (kd columns), tbl 1 = transient_encoding.0 on t_in (nt columns; w_te == nullptr: table 0 only).
-hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw_dir, int kd, const float* dir_in, int ld_dir,
-                                 const float* w_te, const float* b_te, int ldw_te, int nt, const float* t_in, int ld_t, size_t R,
-                                 float* table, hipStream_t s);
+hipError_t launch_ray_bias_train_pair(const float* w_dir_c, const float* b_dir_c, int ldw_dir_c, int kd_c, const float* dir_in_c, int ld_dir_c,
+                                      float* table_c, const float* w_dir, const float* b_dir, int ldw_dir, int kd, const float* dir_in,
+                                      int ld_dir, const float* w_te, const float* b_te, int ldw_te, int nt, const float* t_in, int ld_t,
+                                      float* table_f, size_t R, hipStream_t s);
 // out[r][feat] (feat < 16 kc) = sum over the ray's samples of the stored gradient array (true scale), feature order = slot order
 // mapped through hidden_feature() per 32-slot group: out[r][64 (s >> 5) + hidden_feature(h, s & 31)].
 hipError_t launch_frag_ray_sum(const char* arr, int kc, int planes, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s);

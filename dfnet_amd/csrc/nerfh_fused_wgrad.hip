@@ -335,12 +335,21 @@ hipError_t launch_pack4(const PackArgs4& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------ per-ray bias tables from the master weights
 // What launch_ray_bias (nerfh_stages.hip) computes from the committed copies, here from the step's own parameters and the per-ray
 // inputs the training path already forms (nerfh_train.hip: ray_inputs).  64 outputs per table (netwidth 128).
-__global__ __launch_bounds__(128) void ray_bias_train_kernel(const float* __restrict__ w_dir, const float* __restrict__ b_dir, int ldw_dir,
-                                                             int kd, const float* __restrict__ dir_in, int ld_dir,
-                                                             const float* __restrict__ w_te, const float* __restrict__ b_te, int ldw_te,
-                                                             int nt, const float* __restrict__ t_in, int ld_t, size_t R,
-                                                             float* __restrict__ table) {
+// One launch for both networks: blockIdx.y = 0 the coarse network's table, 1 the fine one's (two launches of ~8 and ~17 us in a row
+// on a one-stream step: the shorter now runs beside the longer, and a launch less).
+struct RayBiasTrainArgs {
+  const float* w_dir; const float* b_dir; int ldw_dir; int kd; const float* dir_in; int ld_dir;
+  const float* w_te; const float* b_te; int ldw_te; int nt; const float* t_in; int ld_t;
+  float* table;
+};
+__global__ __launch_bounds__(128) void ray_bias_train_kernel(RayBiasTrainArgs a0, RayBiasTrainArgs a1, size_t R) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  const RayBiasTrainArgs& a = blockIdx.y ? a1 : a0;
+  const float* __restrict__ w_dir = a.w_dir; const float* __restrict__ b_dir = a.b_dir; const int ldw_dir = a.ldw_dir, kd = a.kd;
+  const float* __restrict__ dir_in = a.dir_in; const int ld_dir = a.ld_dir;
+  const float* __restrict__ w_te = a.w_te; const float* __restrict__ b_te = a.b_te; const int ldw_te = a.ldw_te, nt = a.nt;
+  const float* __restrict__ t_in = a.t_in; const int ld_t = a.ld_t;
+  float* __restrict__ table = a.table;
   float* s_wd = sm;               // [kd][64]
   float* s_wt = sm + kd * 64;     // [nt][64]
   float* s_in = s_wt + (w_te ? nt * 64 : 0);   // [kd + nt] the ray's inputs: one coalesced load per ray instead of kd dependent broadcast loads
@@ -383,15 +392,19 @@ __global__ __launch_bounds__(128) void ray_bias_train_kernel(const float* __rest
     __syncthreads();   // (the next ray's inputs overwrite s_in)
   }
 }
-hipError_t launch_ray_bias_train(const float* w_dir, const float* b_dir, int ldw_dir, int kd, const float* dir_in, int ld_dir,
-                                 const float* w_te, const float* b_te, int ldw_te, int nt, const float* t_in, int ld_t, size_t R,
-                                 float* table, hipStream_t s) {
+hipError_t launch_ray_bias_train_pair(const float* w_dir_c, const float* b_dir_c, int ldw_dir_c, int kd_c, const float* dir_in_c, int ld_dir_c,
+                                      float* table_c, const float* w_dir, const float* b_dir, int ldw_dir, int kd, const float* dir_in,
+                                      int ld_dir, const float* w_te, const float* b_te, int ldw_te, int nt, const float* t_in, int ld_t,
+                                      float* table_f, size_t R, hipStream_t s) {
   if (!R) return hipSuccess;
-  const size_t lds = (size_t(kd + (w_te ? nt : 0)) * 64 + size_t(kd + (w_te ? nt : 0))) * sizeof(float);
+  const size_t lds_c = (size_t(kd_c) * 64 + size_t(kd_c)) * sizeof(float);
+  const size_t lds_f = (size_t(kd + (w_te ? nt : 0)) * 64 + size_t(kd + (w_te ? nt : 0))) * sizeof(float);
+  const size_t lds = lds_c > lds_f ? lds_c : lds_f;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  const int grid = int(R < 256 ? R : 256);   // one workgroup per CU: every workgroup stages the weights once
-  hipLaunchKernelGGL(ray_bias_train_kernel, dim3(grid), dim3(128), lds, s, w_dir, b_dir, ldw_dir, kd, dir_in, ld_dir, w_te, b_te, ldw_te,
-                     nt, t_in, ld_t, R, table);
+  const int grid = int(R < 256 ? R : 256);   // per table one workgroup per CU: every workgroup stages its weights once
+  const RayBiasTrainArgs a0{w_dir_c, b_dir_c, ldw_dir_c, kd_c, dir_in_c, ld_dir_c, nullptr, nullptr, 0, 0, nullptr, 0, table_c};
+  const RayBiasTrainArgs a1{w_dir, b_dir, ldw_dir, kd, dir_in, ld_dir, w_te, b_te, ldw_te, nt, t_in, ld_t, table_f};
+  hipLaunchKernelGGL(ray_bias_train_kernel, dim3(grid, 2), dim3(128), lds, s, a0, a1, R);
   return hipGetLastError();
 }
 

@@ -50,6 +50,15 @@ hipError_t stratified_z(const float* t_rand, size_t R, int Nc, float near, float
 hipError_t posenc_points(const float* rays_o, const float* rays_d, const float* z, size_t R, int Ns, float* pe, hipStream_t s);
 // per-ray inputs: dir_in[r][0..27) = pe_dir(viewdir) (L = 4), then a = embedding_a[hist] (hist_bin*dim_a) when emb_a != nullptr;
 // t_in[r] = embedding_t[hist] (hist_bin*dim_t) when emb_t != nullptr.  Row strides ld_dir / ld_t; padding zeroed.
+// viewdirs + both networks' per-ray input rows + stratified coarse depths + the step's range word, one launch (nerfh_train.hip)
+struct TrainRayPrepArgs {
+  const float* rays_d; size_t R;
+  const float* hist; size_t hist_rows; const float* emb_a; const float* emb_t; int hist_bin, dim_a, dim_t, n_vocab;
+  float* view; float* dir_c; int ld_dc; float* dir_f; int ld_df; float* t_in; int ld_t;
+  const float* t_rand; int Nc; float near, far; int lindisp; float* z;
+  int* range_word;
+};
+hipError_t train_ray_prep(const TrainRayPrepArgs& a, hipStream_t s);
 hipError_t ray_inputs(const float* viewdirs, const float* hist, size_t hist_rows, const float* emb_a, const float* emb_t,
                       int hist_bin, int dim_a, int dim_t, int n_vocab, size_t R, float* dir_in, int ld_dir, float* t_in, int ld_t,
                       hipStream_t s);
@@ -60,7 +69,8 @@ hipError_t sample_fine_train(const float* raw_c, const float* z_c, const float* 
                              int Nc, int Ni, float* z_fine, float* rgb0, float* disp0, float* acc0, float* z_std, hipStream_t s);
 // d L / d (pre-activation coarse outputs) [R,Nc,4] from d L / d rgb0 [R,3].
 hipError_t composite_coarse_backward(const float* raw_c, const float* z_c, const float* noise, float noise_std, const float* g_rgb0,
-                                     size_t R, int Nc, float* gpre, hipStream_t s);
+                                     size_t R, int Nc, float* gpre, hipStream_t s, float* zero0 = nullptr, size_t n0 = 0,
+                                     float* zero1 = nullptr, size_t n1 = 0);
 // d L / d (pre-activation fine outputs) [R,Nf,9] from d L / d rgb [R,3], d L / d beta [R] and a constant d L / d
 // transient_sigma per sample (training compositing: joint rgb, beta = sum w_t beta_t + beta_min).
 hipError_t composite_fine_backward_train(const float* raw, const float* z, const float* g_rgb, const float* g_beta, float g_tsigma,

@@ -909,6 +909,71 @@ hipError_t ray_inputs(const float* viewdirs, const float* hist, size_t hist_rows
   return hipGetLastError();
 }
 
+// The head of the fused training forward in ONE launch (it was five tiny ones in a row on a one-stream step, ~4.7 us each): per ray the
+// view direction (viewdirs_kernel), the coarse and the fine network's per-ray input rows (ray_inputs_kernel twice), the stratified
+// coarse depths (stratified_z_kernel) — the same functions on the same values, bit for bit — and, by one thread, the step's range
+// word cleared (the hipMemsetAsync in front of the weight packing).
+__global__ __launch_bounds__(128) void train_ray_prep_kernel(TrainRayPrepArgs a) {
+  __shared__ float s_v[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.range_word) *a.range_word = 0;
+  const int na = a.hist_bin * a.dim_a, nt = a.hist_bin * a.dim_t;
+  for (size_t ray = blockIdx.x; ray < a.R; ray += gridDim.x) {
+    if (threadIdx.x == 0) {
+      float vx, vy, vz;
+      normalize3(a.rays_d[ray * 3], a.rays_d[ray * 3 + 1], a.rays_d[ray * 3 + 2], vx, vy, vz);
+      s_v[0] = vx; s_v[1] = vy; s_v[2] = vz;
+      a.view[ray * 3] = vx; a.view[ray * 3 + 1] = vy; a.view[ray * 3 + 2] = vz;
+    }
+    __syncthreads();
+    const float* hrow = a.hist + (a.hist_rows == 1 ? 0 : ray) * a.hist_bin;
+    auto dir_value = [&](int c) {     // column c < kChDir of the direction encoding (ray_inputs_kernel)
+      const int coord = c < 3 ? c : (c - 3) % 3;
+      const float x = s_v[coord];
+      if (c < 3) return x;
+      const int k = (c - 3) / 6;
+      const float arg = x * float(1 << k);
+      return ((c - 3) % 6) >= 3 ? cosf(arg) : sinf(arg);
+    };
+    for (int c = threadIdx.x; c < a.ld_dc; c += blockDim.x) a.dir_c[ray * a.ld_dc + c] = c < kChDir ? dir_value(c) : 0.f;
+    for (int c = threadIdx.x; c < a.ld_df; c += blockDim.x) {
+      float v = 0.f;
+      if (c < kChDir) v = dir_value(c);
+      else if (c < kChDir + na) {
+        const int j = c - kChDir;
+        long long idx = (long long)hrow[j / a.dim_a];   // .long() truncation (nerfw.py:69)
+        idx = idx < 0 ? 0 : (idx >= a.n_vocab ? a.n_vocab - 1 : idx);
+        v = a.emb_a[idx * a.dim_a + j % a.dim_a];
+      }
+      a.dir_f[ray * a.ld_df + c] = v;
+    }
+    for (int c = threadIdx.x; c < a.ld_t; c += blockDim.x) {
+      float v = 0.f;
+      if (c < nt) {
+        long long idx = (long long)hrow[c / a.dim_t];
+        idx = idx < 0 ? 0 : (idx >= a.n_vocab ? a.n_vocab - 1 : idx);
+        v = a.emb_t[idx * a.dim_t + c % a.dim_t];
+      }
+      a.t_in[ray * a.ld_t + c] = v;
+    }
+    const bool ld = a.lindisp != 0;
+    for (int i = threadIdx.x; i < a.Nc; i += blockDim.x) {   // stratified_z_kernel
+      const size_t e = ray * size_t(a.Nc) + i;
+      const float zi = coarse_z_at(i, a.Nc, a.near, a.far, ld);
+      if (!a.t_rand) { a.z[e] = zi; continue; }
+      const float zm = i > 0 ? coarse_z_at(i - 1, a.Nc, a.near, a.far, ld) : zi, zp = i + 1 < a.Nc ? coarse_z_at(i + 1, a.Nc, a.near, a.far, ld) : zi;
+      const float lower = i > 0 ? mul_rn(.5f, add_rn(zi, zm)) : zi;
+      const float upper = i + 1 < a.Nc ? mul_rn(.5f, add_rn(zp, zi)) : zi;
+      a.z[e] = add_rn(lower, mul_rn(sub_rn(upper, lower), a.t_rand[e]));
+    }
+    __syncthreads();   // (the next ray's direction overwrites s_v)
+  }
+}
+hipError_t train_ray_prep(const TrainRayPrepArgs& a, hipStream_t s) {
+  if (!a.R) return hipSuccess;
+  hipLaunchKernelGGL(train_ray_prep_kernel, dim3(grid_for(a.R, 1)), dim3(128), 0, s, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ coarse composite + sampler (training)
 // One wave per ray (as nerfh_stages.hip).  alpha_i = 1 - exp(-delta_i relu(sigma_i + noise_i)), w = alpha T,
 // rgb0 = sum w c, depth = sum w z, disp0 = 1 / max(1e-10, depth / sum w) (rendering.py:168-193,231-243); then
@@ -1083,9 +1148,14 @@ hipError_t sample_fine_train(const float* raw_c, const float* z_c, const float* 
 __global__ __launch_bounds__(256) void composite_coarse_backward_kernel(const float* __restrict__ raw_c, const float* __restrict__ z_c,
                                                                         const float* __restrict__ noise, float noise_std,
                                                                         const float* __restrict__ g_rgb0, size_t R, int Nc,
-                                                                        float* __restrict__ gpre) {
+                                                                        float* __restrict__ gpre, float* __restrict__ zero0, size_t n0,
+                                                                        float* __restrict__ zero1, size_t n1) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // optional: two small buffers zeroed on the way (the embedding gradients that the step's scatter kernels accumulate into, far
+  // behind this kernel in the stream: two memset launches less at the head of the backward pass)
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n0; i += size_t(gridDim.x) * blockDim.x) zero0[i] = 0.f;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n1; i += size_t(gridDim.x) * blockDim.x) zero1[i] = 0.f;
   float* s_e = sm + size_t(wave) * 3 * Nc;   // e_i = w_i g.c_i
   float* s_T = s_e + Nc;
   float* s_al = s_T + Nc;
@@ -1144,10 +1214,10 @@ __global__ __launch_bounds__(256) void composite_coarse_backward_kernel(const fl
   }
 }
 hipError_t composite_coarse_backward(const float* raw_c, const float* z_c, const float* noise, float noise_std, const float* g_rgb0,
-                                     size_t R, int Nc, float* gpre, hipStream_t s) {
+                                     size_t R, int Nc, float* gpre, hipStream_t s, float* zero0, size_t n0, float* zero1, size_t n1) {
   if (!R) return hipSuccess;
   hipLaunchKernelGGL(composite_coarse_backward_kernel, dim3(grid_for((R + 3) / 4, 1)), dim3(256), size_t(4) * 3 * Nc * 4, s, raw_c,
-                     z_c, noise, noise_std, g_rgb0, R, Nc, gpre);
+                     z_c, noise, noise_std, g_rgb0, R, Nc, gpre, zero0, n0, zero1, n1);
   return hipGetLastError();
 }
 
