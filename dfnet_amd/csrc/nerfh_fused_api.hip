@@ -646,31 +646,34 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
       CHECK_HIP(launch_train_backward_chain(false, planes_of(false, h->train_split_fine), a, n_cu, s), "train backward: coarse chain");
     }
   }
-  // weight gradients: one stream launch over the jobs of both networks, then the fixed-order reduction into the .grad tensors
+  // weight gradients: one stream launch per network (n_wt is a launch constant; disjoint partial buffers, the fine one first), then ONE
+  // fixed-order reduction of both networks' partials into the .grad tensors (it was one per network, the fine one between the two
+  // streams: a tiny launch less on the one-stream step, and the two reductions side by side)
   {
     WgradArgs wa{};
-    wa.n_jobs = 0;
+    ReduceArgs ra{};
+    ra.n_jobs = 0;
     float* part = w.partial;
-    // the two networks have different wave-tile counts: one launch each (n_wt is a launch constant), the fine one first
     for (int f = 1; f >= 0; --f) {
       wa.n_jobs = 0;
       const int wgs = make_jobs(f, w.net[f], st, part, wa.job, wa.n_jobs);
       wa.n_wt = int(w.net[f].n_wt);
       CHECK_HIP(launch_wgrad_stream(wa, wgs, planes_of(f, h->train_split_fine), s), "train backward: weight-gradient stream");
-      ReduceArgs ra{};
-      std::memcpy(ra.job, wa.job, sizeof(wa.job));
-      ra.n_jobs = wa.n_jobs;
-      ra.map = st.map;
-      for (int i = 0; i < 64; ++i) ra.grads[i] = grads[i];
-      CHECK_HIP(launch_wgrad_reduce(ra, s), "train backward: weight-gradient reduction");
+      for (int j = 0; j < wa.n_jobs; ++j) {
+        const WJob& q = wa.job[j];
+        ra.job[ra.n_jobs++] = RJob{q.partial, q.nb_g, q.nb_x, q.has_bias, q.n_chunks, q.map_off};
+      }
     }
+    ra.map = st.map;
+    for (int i = 0; i < 64; ++i) ra.grads[i] = grads[i];
+    CHECK_HIP(launch_wgrad_reduce(ra, s), "train backward: weight-gradient reduction");
   }
   // columns beyond `final` of dir_encoding.0 / transient_encoding.0 multiply per-ray inputs: per-ray sums of the stored gradients,
   // then the small products of the layer-by-layer path (nerfh_train.hip) over rays
-  CHECK_HIP(launch_frag_ray_sum(w.net[1].g + w.net[1].g_off[GA_CAT], 8, planes_of(true, h->train_split_fine), w.net[1].gscale + size_t(GA_CAT) * w.net[1].n_wt, R, Nf, w.gsum_f, W, s),
-            "train backward: per-ray sums (fine)");
-  CHECK_HIP(launch_frag_ray_sum(w.net[0].g + w.net[0].g_off[GA_CAT], 4, planes_of(false, h->train_split_fine), w.net[0].gscale + size_t(GA_CAT) * w.net[0].n_wt, R, Nc, w.gsum_c, W2, s),
-            "train backward: per-ray sums (coarse)");
+  CHECK_HIP(launch_frag_ray_sum_pair(w.net[1].g + w.net[1].g_off[GA_CAT], 8, planes_of(true, h->train_split_fine),
+                                     w.net[1].gscale + size_t(GA_CAT) * w.net[1].n_wt, Nf, w.gsum_f, W,
+                                     w.net[0].g + w.net[0].g_off[GA_CAT], 4, w.net[0].gscale + size_t(GA_CAT) * w.net[0].n_wt, Nc, w.gsum_c, W2, R, s),
+            "train backward: per-ray sums");
   const int ldw_dir_f = W + g.kd_f, ldw_dir_c = W + g.kd_c, ldw_te0 = W + g.nt;
   // transient_encoding.0 tail: gsum_f[:, 0:64]
   CHECK_HIP(gemm_wgrad(w.gsum_f, W, W2, Seg{w.t_in, g.ld_t, g.nt, 1, W}, gf[2 * TE0], ldw_te0, nullptr, w.wscratch, (long long)R, s), "train wgrad: transient tail");

@@ -109,8 +109,11 @@ struct WgradArgs {
   int n_jobs;
   int n_wt;
 };
+// (the reduction reads a few fields of a job only: a compact record, so that BOTH networks' jobs — 17 + 13 — fit one launch's arguments)
+struct RJob { const float* partial; int nb_g, nb_x, has_bias, n_chunks, map_off; };
+constexpr int kMaxReduceJobs = 2 * kMaxJobs;
 struct ReduceArgs {
-  WJob job[kMaxJobs];
+  RJob job[kMaxReduceJobs];
   int n_jobs;
   const int* map;          // per job: [n_blocks][1024] destination (param << 20 | offset) or -1, index r * 64 + lane
   float* grads[64];        // the step's gradient tensors in canonical order (dfn_nerfh_train_param_name)
@@ -148,6 +151,9 @@ hipError_t launch_ray_bias_train_pair(const float* w_dir_c, const float* b_dir_c
 // out[r][feat] (feat < 16 kc) = sum over the ray's samples of the stored gradient array (true scale), feature order = slot order
 // mapped through hidden_feature() per 32-slot group: out[r][64 (s >> 5) + hidden_feature(h, s & 31)].
 hipError_t launch_frag_ray_sum(const char* arr, int kc, int planes, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s);
+hipError_t launch_frag_ray_sum_pair(const char* arr_f, int kc_f, int planes_f, const float* gscale_f, int Ns_f, float* out_f, int ldo_f,
+                                    const char* arr_c, int kc_c, const float* gscale_c, int Ns_c, float* out_c, int ldo_c, size_t R,
+                                    hipStream_t s);
 
 
 // ---- host side (nerfh_fused_api.hip), called by dfn_nerfh_train_* when the handle runs the register-resident kernels

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs a, int tot
     q -= nq;
   }
   if (j >= a.n_jobs) return;
-  const WJob& jb = a.job[j];
+  const RJob& jb = a.job[j];
   const int nbx1 = jb.nb_x + jb.has_bias, nblk = jb.nb_g * nbx1;
   const int b = q >> 2, e = (q & 3) * 256 + threadIdx.x;
   const int m = a.map[jb.map_off + b * 1024 + e];
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs a, int tot
   a.grads[m >> 20][m & 0xfffff] = bias ? sum : sum * (1.f / kX3ActScale);
 }
 
+static_assert(sizeof(ReduceArgs) + 16 <= 4096, "kernel arguments of the reduction launch");
 hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t s) {
   int total = 0;
   for (int j = 0; j < a.n_jobs; ++j) total += a.job[j].nb_g * (a.job[j].nb_x + a.job[j].has_bias) * 4;
@@ -412,11 +413,10 @@ hipError_t launch_ray_bias_train_pair(const float* w_dir_c, const float* b_dir_c
 // The columns of dir_encoding.0 / transient_encoding.0 beyond `final` multiply per-RAY inputs (direction encoding, embeddings):
 // their gradients need sum_samples G[p, :] per ray (models/nerfw.py:62-95).  One block per ray; fixed summation order.
 template <int PL>
-__global__ __launch_bounds__(256) void frag_ray_sum_kernel(const char* __restrict__ arr, int kc, const float* __restrict__ gscale, int Ns,
-                                                           float* __restrict__ out, int ldo) {
+DFN_DEV void frag_ray_sum_body(const char* __restrict__ arr, int kc, const float* __restrict__ gscale, int Ns, float* __restrict__ out, int ldo,
+                               float* red) {
   // a lane owns one 16-byte piece (8 slots of one half of one chunk) and walks the ray's samples 256 / (2 kc) at a time: 16-byte loads
   // of the hi and the lo plane instead of one 2-byte load per value
-  __shared__ float red[256 * 8];
   const size_t ray = blockIdx.x;
   const int np = 2 * kc;                       // pieces per point
   const int groups = 256 / np;                 // samples in flight per pass
@@ -446,6 +446,30 @@ __global__ __launch_bounds__(256) void frag_ray_sum_kernel(const char* __restric
       out[ray * ldo + 64 * (slot >> 5) + hidden_feature(hh, slot & 31)] = s;
     }
   }
+}
+template <int PL>
+__global__ __launch_bounds__(256) void frag_ray_sum_kernel(const char* __restrict__ arr, int kc, const float* __restrict__ gscale, int Ns,
+                                                           float* __restrict__ out, int ldo) {
+  __shared__ float red[256 * 8];
+  frag_ray_sum_body<PL>(arr, kc, gscale, Ns, out, ldo, red);
+}
+// both networks' per-ray sums in one launch: blockIdx.y = 0 the fine network's array (PLF planes), 1 the coarse network's (two planes)
+struct FragRaySumArgs { const char* arr; int kc; const float* gscale; int Ns; float* out; int ldo; };
+template <int PLF>
+__global__ __launch_bounds__(256) void frag_ray_sum_pair_kernel(FragRaySumArgs f, FragRaySumArgs c) {
+  __shared__ float red[256 * 8];
+  if (blockIdx.y == 0) frag_ray_sum_body<PLF>(f.arr, f.kc, f.gscale, f.Ns, f.out, f.ldo, red);
+  else frag_ray_sum_body<2>(c.arr, c.kc, c.gscale, c.Ns, c.out, c.ldo, red);
+}
+hipError_t launch_frag_ray_sum_pair(const char* arr_f, int kc_f, int planes_f, const float* gscale_f, int Ns_f, float* out_f, int ldo_f,
+                                    const char* arr_c, int kc_c, const float* gscale_c, int Ns_c, float* out_c, int ldo_c, size_t R,
+                                    hipStream_t s) {
+  if (!R) return hipSuccess;
+  if ((kc_f != 4 && kc_f != 8) || (kc_c != 4 && kc_c != 8) || (planes_f != 1 && planes_f != 2)) return hipErrorInvalidValue;
+  const FragRaySumArgs f{arr_f, kc_f, gscale_f, Ns_f, out_f, ldo_f}, c{arr_c, kc_c, gscale_c, Ns_c, out_c, ldo_c};
+  if (planes_f == 1) hipLaunchKernelGGL(frag_ray_sum_pair_kernel<1>, dim3(unsigned(R), 2), dim3(256), 0, s, f, c);
+  else hipLaunchKernelGGL(frag_ray_sum_pair_kernel<2>, dim3(unsigned(R), 2), dim3(256), 0, s, f, c);
+  return hipGetLastError();
 }
 hipError_t launch_frag_ray_sum(const char* arr, int kc, int planes, const float* gscale, size_t R, int Ns, float* out, int ldo, hipStream_t s) {
   if (!R) return hipSuccess;
