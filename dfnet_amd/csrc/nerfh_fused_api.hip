@@ -412,12 +412,9 @@ struct Ws {
 };
 size_t tail_scratch_floats(const Geo& g, size_t R) {
   const int pairs[][2] = {{kWidth / 2, g.ld_df}, {kWidth / 2, g.ld_dc}, {kWidth / 2, g.ld_t}};
-  size_t best = 0;
-  for (const auto& nk : pairs) {
-    const size_t f = gemm_wgrad_scratch_floats(nk[0], nk[1], (long long)R);
-    best = f > best ? f : best;
-  }
-  return best + 1024;
+  size_t sum = 0;     // the three products' partials side by side (gemm_wgrad_multi: one launch for all three)
+  for (const auto& nk : pairs) sum += gemm_wgrad_scratch_floats(nk[0], nk[1], (long long)R);
+  return sum + 1024;
 }
 // Point chunking of one network's jobs: `target` workgroups per launch (a whole number of rounds of the 2 x CU resident
 // workgroups), shared among the jobs in proportion to the bytes they stream.  Depends on the batch shape only (deterministic).
@@ -675,16 +672,20 @@ int train_backward(dfn_nerfh_s* h, const float* const* params, const float* hist
                                      w.net[0].g + w.net[0].g_off[GA_CAT], 4, w.net[0].gscale + size_t(GA_CAT) * w.net[0].n_wt, Nc, w.gsum_c, W2, R, s),
             "train backward: per-ray sums");
   const int ldw_dir_f = W + g.kd_f, ldw_dir_c = W + g.kd_c, ldw_te0 = W + g.nt;
-  // transient_encoding.0 tail: gsum_f[:, 0:64]
-  CHECK_HIP(gemm_wgrad(w.gsum_f, W, W2, Seg{w.t_in, g.ld_t, g.nt, 1, W}, gf[2 * TE0], ldw_te0, nullptr, w.wscratch, (long long)R, s), "train wgrad: transient tail");
+  // the three small weight products over rays — transient_encoding.0 tail (gsum_f[:, 0:64]), dir_encoding.0 tail of the fine network
+  // (gsum_f[:, 64:128]) and of the coarse one — in one launch + one reduction launch (six tiny launches in a row otherwise)
+  const WgradJob tails[3] = {{w.gsum_f, W, W2, Seg{w.t_in, g.ld_t, g.nt, 1, W}, gf[2 * TE0], ldw_te0, nullptr},
+                             {w.gsum_f + W2, W, W2, Seg{w.dir_f, g.ld_df, g.kd_f, 1, W}, gf[2 * DIR], ldw_dir_f, nullptr},
+                             {w.gsum_c, W2, W2, Seg{w.dir_c, g.ld_dc, g.kd_c, 1, W}, gc[2 * DIR], ldw_dir_c, nullptr}};
+  const bool multi = gemm_wgrad_multi_ok(tails, 3, (long long)R);
+  if (multi) CHECK_HIP(gemm_wgrad_multi(tails, 3, w.wscratch, (long long)R, s), "train wgrad: per-ray tails");
+  else CHECK_HIP(gemm_wgrad(w.gsum_f, W, W2, Seg{w.t_in, g.ld_t, g.nt, 1, W}, gf[2 * TE0], ldw_te0, nullptr, w.wscratch, (long long)R, s), "train wgrad: transient tail");
   CHECK_HIP(gemm_bwd(w.gsum_f, W, W2, pf[2 * TE0], ldw_te0, W, g.nt, w.gray, g.ld_t, 0, nullptr, 0, (long long)R, s), "train backward: d t");
   CHECK_HIP(embedding_scatter(w.gray, g.ld_t, 0, hist, hist_rows, d.hist_bin, d.dim_t, d.n_vocab, R, g_emb_t, s), "train: embedding_t grad");
-  // dir_encoding.0 tail (fine): gsum_f[:, 64:128]
-  CHECK_HIP(gemm_wgrad(w.gsum_f + W2, W, W2, Seg{w.dir_f, g.ld_df, g.kd_f, 1, W}, gf[2 * DIR], ldw_dir_f, nullptr, w.wscratch, (long long)R, s), "train wgrad: dir tail");
+  if (!multi) CHECK_HIP(gemm_wgrad(w.gsum_f + W2, W, W2, Seg{w.dir_f, g.ld_df, g.kd_f, 1, W}, gf[2 * DIR], ldw_dir_f, nullptr, w.wscratch, (long long)R, s), "train wgrad: dir tail");
   CHECK_HIP(gemm_bwd(w.gsum_f + W2, W, W2, pf[2 * DIR], ldw_dir_f, W + kChDir, g.na, w.gray, g.ld_df, 0, nullptr, 0, (long long)R, s), "train backward: d a");
   CHECK_HIP(embedding_scatter(w.gray, g.ld_df, 0, hist, hist_rows, d.hist_bin, d.dim_a, d.n_vocab, R, g_emb_a, s), "train: embedding_a grad");
-  // dir_encoding.0 tail (coarse)
-  CHECK_HIP(gemm_wgrad(w.gsum_c, W2, W2, Seg{w.dir_c, g.ld_dc, g.kd_c, 1, W}, gc[2 * DIR], ldw_dir_c, nullptr, w.wscratch, (long long)R, s), "train wgrad: coarse dir tail");
+  if (!multi) CHECK_HIP(gemm_wgrad(w.gsum_c, W2, W2, Seg{w.dir_c, g.ld_dc, g.kd_c, 1, W}, gc[2 * DIR], ldw_dir_c, nullptr, w.wscratch, (long long)R, s), "train wgrad: coarse dir tail");
   {   // a step whose operands left the split-f16 range leaves zeros, not clamped gradients (GuardArgs)
     GuardArgs ga{};
     for (int f = 0; f < 2; ++f)

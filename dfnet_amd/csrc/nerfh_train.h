@@ -41,6 +41,11 @@ hipError_t gemm_bwd(const float* G, int ldg, int N, const float* W, int ldw, int
 size_t gemm_wgrad_scratch_floats(int N, int K, long long P);
 hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW, int ldw, float* db, float* scratch,
                       long long P, hipStream_t s);
+// Up to three small products (P below the tiled form's threshold) in ONE launch + one reduction launch; `scratch` holds the
+// products' partials back to back: sum of gemm_wgrad_scratch_floats(N, K, P) floats.  Same arithmetic and summation order as gemm_wgrad.
+struct WgradJob { const float* G; int ldg, N; Seg x; float* dW; int ldw; float* db; };
+bool gemm_wgrad_multi_ok(const WgradJob* jobs, int n, long long P);   // every product takes the small (untiled) form at this P
+hipError_t gemm_wgrad_multi(const WgradJob* jobs, int n, float* scratch, long long P, hipStream_t s);
 
 // ---- stages
 // z[r, i] = lower + (upper - lower) * t_rand (rendering.py:277-285); t_rand == nullptr: the plain linspace depths; lindisp: the

@@ -497,14 +497,14 @@ struct WgradArgs {
   int chunk, kgroups, items;
 };
 
-__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs a) {
-  __shared__ float red[3][kWgradK * 16 * 64 + 64];
+typedef float WgradRed[kWgradK * 16 * 64 + 64];
+// (the body takes its place in the grid as arguments: gemm_wgrad_kernel is one product, gemm_wgrad_multi_kernel up to three small ones)
+DFN_DEV void gemm_wgrad_body(const WgradArgs& a, const int bx, const int item, WgradRed* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kh = lane >> 5;
-  const int item = blockIdx.y;
   const int nblk = item / a.kgroups, kg = item - nblk * a.kgroups;
   const int n0 = nblk * 32, k0 = kg * kWgradK * 32;
-  const long long c0 = (long long)blockIdx.x * a.chunk;
+  const long long c0 = (long long)bx * a.chunk;
   const long long c1 = c0 + a.chunk < a.P ? c0 + a.chunk : a.P;
   const int sub = a.chunk / 4;                      // multiple of 8
   const long long w0 = c0 + (long long)wave * sub;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs a) {
       for (int q = 0; q < 16; ++q) acc[kb][q] += r[(kb * 16 + q) * 64 + lane];
     bsum += r[kWgradK * 16 * 64 + lane];
   }
-  float* part = a.part + (size_t)blockIdx.x * a.N * K;
+  float* part = a.part + (size_t)bx * a.N * K;
 #pragma unroll
   for (int kb = 0; kb < kWgradK; ++kb) {
     const int col = k0 + kb * 32 + i;
@@ -587,8 +587,22 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs a) {
   }
   if (kg == 0 && a.bpart) {
     const float tot = bsum + __shfl_xor(bsum, 32, 64);
-    if (kh == 0 && nok) a.bpart[(size_t)blockIdx.x * a.N + n0 + i] = tot;
+    if (kh == 0 && nok) a.bpart[(size_t)bx * a.N + n0 + i] = tot;
   }
+}
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs a) {
+  __shared__ WgradRed red[3];
+  gemm_wgrad_body(a, int(blockIdx.x), int(blockIdx.y), red);
+}
+// Up to three SMALL products in one launch (blockIdx.z = product; grid = the largest chunk / item counts, the others' spare blocks
+// return): the per-ray tails of the fused NeRF-H step are three such products in a row, each with its reduction — six launches of
+// 5-8 us on a one-stream step where a tiny launch costs ~4.7 us whatever it does.
+struct WgradMulti { WgradArgs a[3]; int chunks[3]; int n; };
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_multi_kernel(WgradMulti m) {
+  __shared__ WgradRed red[3];
+  const int j = blockIdx.z;
+  if (int(blockIdx.x) >= m.chunks[j] || int(blockIdx.y) >= m.a[j].items) return;
+  gemm_wgrad_body(m.a[j], int(blockIdx.x), int(blockIdx.y), red);
 }
 
 // Tiled form of the weight-gradient product for N <= 128 outputs and per-point inputs (every Linear of the two networks): a
@@ -700,10 +714,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tile_kernel(WgradArgs a) {
 
 // dW[e] = sum over chunks in a FIXED order: a workgroup owns 64 consecutive elements; wave s of its eight sums the chunks
 // [s C/8, (s+1) C/8) of them (256-byte coalesced rows, 8 loads in flight), then the eight sums are added in wave order.
-__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int chunks,
-                                                           int N, int K, float* __restrict__ dW, int ldw, int wcol,
-                                                           float* __restrict__ db) {
-  __shared__ float sums[8][64];
+DFN_DEV void wgrad_reduce_body(const float* __restrict__ part, const float* __restrict__ bpart, int chunks, int N, int K,
+                               float* __restrict__ dW, int ldw, int wcol, float* __restrict__ db, float (*sums)[64]) {
   const size_t nw = size_t(N) * K, total = nw + (db ? N : 0);
   const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const size_t e = size_t(blockIdx.x) * 64 + lane;
@@ -736,6 +748,61 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restri
       db[e - nw] = t;
     }
   }
+}
+__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int chunks,
+                                                           int N, int K, float* __restrict__ dW, int ldw, int wcol,
+                                                           float* __restrict__ db) {
+  __shared__ float sums[8][64];
+  wgrad_reduce_body(part, bpart, chunks, N, K, dW, ldw, wcol, db, sums);
+}
+struct ReduceMulti { const float* part[3]; const float* bpart[3]; int chunks[3], N[3], K[3], ldw[3], wcol[3]; float* dW[3]; float* db[3]; };
+__global__ __launch_bounds__(512) void wgrad_reduce_multi_kernel(ReduceMulti m) {
+  __shared__ float sums[8][64];
+  const int j = blockIdx.y;
+  wgrad_reduce_body(m.part[j], m.bpart[j], m.chunks[j], m.N[j], m.K[j], m.dW[j], m.ldw[j], m.wcol[j], m.db[j], sums);   // (spare blocks: e >= total)
+}
+
+bool gemm_wgrad_multi_ok(const WgradJob* jobs, int n, long long P) {
+  if (n < 1 || n > 3 || P <= 0) return false;
+  for (int j = 0; j < n; ++j)
+    if (jobs[j].N <= 0 || jobs[j].x.K <= 0 || wgrad_tiled(jobs[j].N, jobs[j].x, P)) return false;
+  return true;
+}
+static_assert(sizeof(WgradMulti) + 16 <= 4096, "kernel arguments");
+hipError_t gemm_wgrad_multi(const WgradJob* jobs, int n, float* scratch, long long P, hipStream_t s) {
+  if (n < 1 || n > 3 || P <= 0) return hipErrorInvalidValue;
+  WgradMulti m{};
+  ReduceMulti r{};
+  m.n = n;
+  int max_chunks = 0, max_items = 0;
+  size_t max_elems = 0;
+  for (int j = 0; j < 3; ++j) {
+    const WgradJob& q = jobs[j < n ? j : 0];
+    if (q.N <= 0 || q.x.K <= 0 || wgrad_tiled(q.N, q.x, P)) return hipErrorInvalidValue;    // small products only
+    const int ch = wgrad_chunk(P, wgrad_items(q.N, q.x.K));
+    const int chunks = int((P + ch - 1) / ch);
+    WgradArgs& a = m.a[j];
+    a.G = q.G; a.ldg = q.ldg; a.N = q.N; a.x = q.x; a.P = P; a.chunk = ch;
+    a.part = scratch;
+    a.bpart = q.db ? scratch + size_t(chunks) * q.N * q.x.K : nullptr;
+    a.kgroups = (q.x.K + kWgradK * 32 - 1) / (kWgradK * 32);
+    a.items = ((q.N + 31) / 32) * a.kgroups;
+    m.chunks[j] = j < n ? chunks : 0;
+    r.part[j] = a.part; r.bpart[j] = a.bpart; r.chunks[j] = chunks; r.N[j] = j < n ? q.N : 0; r.K[j] = q.x.K; r.ldw[j] = q.ldw; r.wcol[j] = q.x.wcol;
+    r.dW[j] = q.dW; r.db[j] = q.db;
+    if (j < n) {
+      scratch += gemm_wgrad_scratch_floats(q.N, q.x.K, P);
+      max_chunks = chunks > max_chunks ? chunks : max_chunks;
+      max_items = a.items > max_items ? a.items : max_items;
+      const size_t elems = size_t(q.N) * q.x.K + (q.db ? q.N : 0);
+      max_elems = elems > max_elems ? elems : max_elems;
+    }
+  }
+  hipLaunchKernelGGL(gemm_wgrad_multi_kernel, dim3(max_chunks, max_items, n), dim3(256), 0, s, m);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)((max_elems + 63) / 64), n), dim3(512), 0, s, r);
+  return hipGetLastError();
 }
 
 hipError_t gemm_wgrad(const float* G, int ldg, int N, const Seg& xseg, float* dW, int ldw, float* db, float* scratch,
