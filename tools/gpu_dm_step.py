@@ -52,7 +52,7 @@ if os.environ.get("DM_NO_OVERLAP"):   # A/B aids: the target features in line / 
 if os.environ.get("DM_ALL_LEVELS"):
     _dfm.PRUNE_FEATURE_LEVELS = False
 if os.environ.get("DM_ONLY"):   # profiling aid: only the full optimisation step (rocprofv3 --stats then shows one step's kernels x iters)
-    opt = optim.Adam(model.parameters(), lr=1e-7)
+    opt = (torch.optim.Adam if os.environ.get('DFN_TORCH_ADAM') == '1' else optim.Adam)(model.parameters(), lr=1e-7)
     if os.environ.get("DM_TRACE"):   # where the memcpys of a STEADY-STATE step come from (three warm steps first)
         import collections
         from torch.profiler import profile, ProfilerActivity
@@ -107,7 +107,7 @@ for gp in ("f32", "f16x3"):
 fwd_ms, _ = timed(lambda: matching_step_forward(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
 step_ms, out = timed(lambda: matching_step_grad(args, data, model, feat_model, gt, hist, [H, W, focal], True, dev, setup, **kw))
 # the full optimisation step: + regressor weight gradients (HIP) + Adam (torch) + device-side re-pack of the updated weights
-opt = optim.Adam(model.parameters(), lr=1e-7)
+opt = (torch.optim.Adam if os.environ.get('DFN_TORCH_ADAM') == '1' else optim.Adam)(model.parameters(), lr=1e-7)
 class NoStep:   # gradients only: isolates the weight-gradient kernels from the optimizer / re-pack cost
     def step(self): pass
     def zero_grad(self):

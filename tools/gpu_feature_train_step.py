@@ -28,7 +28,7 @@ if frozen:
 # what script/run_feature.py ships under --tripletloss: the feature stacks stay a low-resolution pyramid (dfnet.FeaturePyramid);
 # FT_STACKS=1 = the materialised stacks + stack triplet kernels (the round-5 form), for A/B
 m.pyramid_features = not os.environ.get("FT_STACKS")
-opt = optim.Adam(m.parameters(), lr=1e-6)
+opt = (torch.optim.Adam if os.environ.get('DFN_TORCH_ADAM') == '1' else optim.Adam)(m.parameters(), lr=1e-6)
 g = torch.Generator().manual_seed(1)
 target, rgb, virt = (torch.rand(B, 3, H, W, generator=g).to(dev) for _ in range(3))
 pose = torch.stack([torch.from_numpy(syn.orbit_pose(k, 8))[:3, :4].reshape(12) for k in range(B)]).to(dev)
